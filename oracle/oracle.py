@@ -1,0 +1,341 @@
+"""ctypes front-end of the CPU parity oracle (oracle/libvo_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg. The product package (visual_odometry_ros_amd) never
+imports this module. PARITY UNPINNED — see oracle/vo_oracle.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libvo_oracle.so")
+
+SUM_SEQ, SUM_TREE = 0, 1
+GN_CORE, GN_STANDALONE = 0, 1
+IC_REFERENCE, IC_MASKED = 0, 1
+KLT_USE_INITIAL_FLOW = 4
+
+
+def build(force=False):
+    """Compile the C restatement (gcc, oracle/Makefile)."""
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs
+    )
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+class GnInfo(C.Structure):
+    _fields_ = [
+        ("iterations", C.c_int),
+        ("err", C.c_float),
+        ("delta_err", C.c_float),
+        ("delta_norm", C.c_float),
+        ("cnt_invalid", C.c_int),
+        ("is_nan", C.c_int),
+    ]
+
+
+class StereoParams(C.Structure):
+    _fields_ = [
+        ("width", C.c_int),
+        ("height", C.c_int),
+        ("win", C.c_int),
+        ("max_level", C.c_int),
+        ("thres_err", C.c_float),
+        ("thres_bidirection", C.c_float),
+        ("thres_poseba", C.c_float),
+        ("Kl", C.c_float * 4),
+        ("Kr", C.c_float * 4),
+        ("T_lr", C.c_float * 16),
+    ]
+
+
+class FrameCounts(C.Structure):
+    _fields_ = [
+        ("n_l0l1", C.c_int),
+        ("n_refine", C.c_int),
+        ("n_l1r1", C.c_int),
+        ("n_inlier", C.c_int),
+        ("n_new_ok", C.c_int),
+        ("gn_iterations", C.c_int),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def _p(a, t=C.c_float):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _img(a):
+    a = _u8(a)
+    assert a.ndim == 2
+    return a, a.shape[1], a.shape[0], a.strides[0]
+
+
+def se3_exp(xi):
+    xi = _f32(xi)
+    T = np.zeros(16, np.float32)
+    lib().vo_ref_se3_exp(_p(xi), _p(T))
+    return T.reshape(4, 4)
+
+
+def inverse_se3(T):
+    T = _f32(T).reshape(16)
+    o = np.zeros(16, np.float32)
+    lib().vo_ref_inverse_se3(_p(T), _p(o))
+    return o.reshape(4, 4)
+
+
+def ldlt6_solve(A, b):
+    A = _f32(A).reshape(36)
+    b = _f32(b)
+    x = np.zeros(6, np.float32)
+    lib().vo_ref_ldlt6_solve(_p(A), _p(b), _p(x))
+    return x
+
+
+def gn_pose_stereo(X, pl, pr, Kl, Kr, T_lr, thres, T01, sum_mode=SUM_SEQ, tree_width=512):
+    X, pl, pr = _f32(X), _f32(pl), _f32(pr)
+    n = X.shape[0]
+    Kl, Kr, T_lr = _f32(Kl), _f32(Kr), _f32(T_lr).reshape(16)
+    T = _f32(T01).reshape(16).copy()
+    mask = np.zeros(max(n, 1), np.uint8)
+    info = GnInfo()
+    rc = lib().vo_ref_gn_pose_stereo(
+        _p(X), _p(pl), _p(pr), n, _p(Kl), _p(Kr), _p(T_lr), C.c_float(thres), _p(T),
+        _p(mask, C.c_uint8), sum_mode, tree_width, C.byref(info))
+    return rc, T.reshape(4, 4), mask[:n].astype(bool), info
+
+
+def gn_pose_mono(X, p1, K, thres, R01, t01, variant=GN_CORE, sum_mode=SUM_SEQ, tree_width=512):
+    X, p1, K = _f32(X), _f32(p1), _f32(K)
+    n = X.shape[0]
+    R = _f32(R01).reshape(9).copy()
+    t = _f32(t01).reshape(3).copy()
+    mask = np.zeros(max(n, 1), np.uint8)
+    info = GnInfo()
+    rc = lib().vo_ref_gn_pose_mono(
+        _p(X), _p(p1), n, _p(K), int(thres), _p(R), _p(t), _p(mask, C.c_uint8), variant,
+        sum_mode, tree_width, C.byref(info))
+    return rc, R.reshape(3, 3), t, mask[:n].astype(bool), info
+
+
+def pyramid_levels(w, h, win, max_level):
+    return lib().vo_ref_pyramid_levels(w, h, win, max_level)
+
+
+def pyr_down(img):
+    img, w, h, st = _img(img)
+    out = np.zeros(((h + 1) // 2, (w + 1) // 2), np.uint8)
+    lib().vo_ref_pyr_down(_p(img, C.c_uint8), w, h, st, _p(out, C.c_uint8), out.strides[0])
+    return out
+
+
+def build_pyramid(img, win, max_level):
+    """Unpadded levels 0..L as OpenCV's buildOpticalFlowPyramid would hold them."""
+    img = _u8(img)
+    levels = [img]
+    n = pyramid_levels(img.shape[1], img.shape[0], win, max_level)
+    for _ in range(n):
+        levels.append(pyr_down(levels[-1]))
+    return levels
+
+
+def scharr(img):
+    img, w, h, st = _img(img)
+    out = np.zeros((h, w, 2), np.int16)
+    lib().vo_ref_scharr(_p(img, C.c_uint8), w, h, st, _p(out, C.c_int16))
+    return out
+
+
+def sobel3(img):
+    img, w, h, st = _img(img)
+    du = np.zeros((h, w), np.float32)
+    dv = np.zeros((h, w), np.float32)
+    lib().vo_ref_sobel3(_p(img, C.c_uint8), w, h, st, _p(du), _p(dv))
+    return du, dv
+
+
+def calc_optical_flow_pyr_lk(img0, img1, pts0, pts1=None, win=21, max_level=3, flags=0,
+                             max_iter=30, eps=0.01, min_eig=1e-4, n_threads=1):
+    img0, w, h, st = _img(img0)
+    img1, w1, h1, st1 = _img(img1)
+    assert (w, h, st) == (w1, h1, st1)
+    pts0 = _f32(pts0)
+    n = pts0.shape[0]
+    p1 = np.zeros((max(n, 1), 2), np.float32) if pts1 is None else _f32(pts1).copy()
+    status = np.zeros(max(n, 1), np.uint8)
+    err = np.zeros(max(n, 1), np.float32)
+    rc = lib().vo_ref_calc_optical_flow_pyr_lk(
+        _p(img0, C.c_uint8), _p(img1, C.c_uint8), w, h, st, _p(pts0), _p(p1), n, win, max_level,
+        flags, max_iter, C.c_double(eps), C.c_float(min_eig), _p(status, C.c_uint8), _p(err),
+        n_threads)
+    return rc, p1[:n], status[:n], err[:n]
+
+
+def _track_common(fn, img0, img1, pts0, pts_track, mask, win, max_level, extra, n_threads):
+    img0, w, h, st = _img(img0)
+    img1, _, _, _ = _img(img1)
+    pts0 = _f32(pts0)
+    n = pts0.shape[0]
+    pt = np.zeros((max(n, 1), 2), np.float32)
+    if pts_track is not None:
+        pt[:n] = _f32(pts_track)
+    m = np.ones(max(n, 1), np.uint8)
+    if mask is not None:
+        m[:n] = np.asarray(mask, np.uint8)
+    rc = fn(_p(img0, C.c_uint8), _p(img1, C.c_uint8), w, h, st, _p(pts0), n, win, max_level,
+            *extra, _p(pt), _p(m, C.c_uint8), n_threads)
+    return rc, pt[:n], m[:n].astype(bool)
+
+
+def track(img0, img1, pts0, win, max_level, thres_err, mask=None, n_threads=1):
+    return _track_common(lib().vo_ref_track, img0, img1, pts0, None, mask, win, max_level,
+                         (C.c_float(thres_err),), n_threads)
+
+
+def track_bidirection(img0, img1, pts0, win, max_level, thres_err, thres_bidir, mask=None,
+                      n_threads=1):
+    return _track_common(lib().vo_ref_track_bidirection, img0, img1, pts0, None, mask, win,
+                         max_level, (C.c_float(thres_err), C.c_float(thres_bidir)), n_threads)
+
+
+def track_bidirection_with_prior(img0, img1, pts0, pts_prior, win, max_level, thres_err,
+                                 thres_bidir, mask=None, n_threads=1):
+    return _track_common(lib().vo_ref_track_bidirection_with_prior, img0, img1, pts0, pts_prior,
+                         mask, win, max_level, (C.c_float(thres_err), C.c_float(thres_bidir)),
+                         n_threads)
+
+
+def track_with_prior(img0, img1, pts0, pts_prior, win, max_level, thres_err, mask=None,
+                     n_threads=1):
+    return _track_common(lib().vo_ref_track_with_prior, img0, img1, pts0, pts_prior, mask, win,
+                         max_level, (C.c_float(thres_err),), n_threads)
+
+
+def calc_prior(pts0, Xw, Tw1, K):
+    pts0, Xw = _f32(pts0), _f32(Xw)
+    Tw1, K = _f32(Tw1).reshape(16), _f32(K).reshape(9)
+    out = np.zeros_like(pts0)
+    lib().vo_ref_calc_prior(_p(pts0), pts0.shape[0], _p(Xw), Xw.shape[0], _p(Tw1), _p(K), _p(out))
+    return out
+
+
+def track_with_scale(img0, img1, pts0, scale, pts_track, mask=None, border_mode=IC_REFERENCE,
+                     sum_mode=SUM_SEQ):
+    img0, w, h, st = _img(img0)
+    img1, _, _, _ = _img(img1)
+    pts0, scale = _f32(pts0), _f32(scale)
+    n = pts0.shape[0]
+    pt = _f32(pts_track).copy()
+    m = np.ones(max(n, 1), np.uint8)
+    if mask is not None:
+        m[:n] = np.asarray(mask, np.uint8)
+    tb = np.zeros(max(n, 1), np.uint8)
+    rc = lib().vo_ref_track_with_scale(
+        _p(img0, C.c_uint8), _p(img1, C.c_uint8), w, h, st, _p(pts0), _p(scale), n, _p(pt),
+        _p(m, C.c_uint8), border_mode, sum_mode, _p(tb, C.c_uint8))
+    return rc, pt, m[:n].astype(bool), tb[:n].astype(bool)
+
+
+def descriptor_distance(a, b):
+    a, b = _u8(a), _u8(b)
+    return lib().vo_ref_descriptor_distance(_p(a, C.c_uint8), _p(b, C.c_uint8))
+
+
+def hamming_matrix(a, b):
+    a, b = _u8(a), _u8(b)
+    out = np.zeros((a.shape[0], b.shape[0]), np.uint16)
+    lib().vo_ref_hamming_matrix(_p(a, C.c_uint8), a.shape[0], _p(b, C.c_uint8), b.shape[0],
+                                _p(out, C.c_uint16))
+    return out
+
+
+def hamming_match(a, b, th_low=50, ratio=0.6):
+    a, b = _u8(a), _u8(b)
+    na = a.shape[0]
+    bi = np.zeros(max(na, 1), np.int32)
+    bd = np.zeros(max(na, 1), np.uint16)
+    sd = np.zeros(max(na, 1), np.uint16)
+    lib().vo_ref_hamming_match(_p(a, C.c_uint8), na, _p(b, C.c_uint8), b.shape[0], th_low,
+                               C.c_float(ratio), _p(bi, C.c_int32), _p(bd, C.c_uint16),
+                               _p(sd, C.c_uint16))
+    return bi[:na], bd[:na], sd[:na]
+
+
+def compact_indices(mask, alive=None, tracked=None):
+    mask = _u8(mask)
+    n = mask.shape[0]
+    idx = np.zeros(max(n, 1), np.int32)
+    tr = np.zeros(max(n, 1), np.uint8)
+    al = _u8(alive) if alive is not None else None
+    tk = _u8(tracked) if tracked is not None else None
+    cnt = lib().vo_ref_compact_indices(
+        _p(mask, C.c_uint8), _p(al, C.c_uint8) if al is not None else None,
+        _p(tk, C.c_uint8) if tk is not None else None, n, _p(idx, C.c_int32), _p(tr, C.c_uint8))
+    return idx[:cnt].copy(), tr[:n].astype(bool)
+
+
+def make_stereo_params(width, height, win, max_level, thres_err, thres_bidir, thres_poseba, Kl,
+                       Kr, T_lr):
+    p = StereoParams()
+    p.width, p.height, p.win, p.max_level = width, height, win, max_level
+    p.thres_err, p.thres_bidirection, p.thres_poseba = thres_err, thres_bidir, thres_poseba
+    for i in range(4):
+        p.Kl[i] = float(Kl[i])
+        p.Kr[i] = float(Kr[i])
+    T = _f32(T_lr).reshape(16)
+    for i in range(16):
+        p.T_lr[i] = float(T[i])
+    return p
+
+
+def stereo_frame(prm, I0l, I1l, I1r, pts_l0, pts_r0, Xp, dT_prior, pts_new, sum_mode=SUM_TREE,
+                 tree_width=512, ic_border_mode=IC_MASKED, n_threads=1):
+    I0l, w, h, st = _img(I0l)
+    I1l, _, _, _ = _img(I1l)
+    I1r, _, _, _ = _img(I1r)
+    pts_l0, Xp = _f32(pts_l0), _f32(Xp)
+    n = pts_l0.shape[0]
+    pts_new = _f32(pts_new).reshape(-1, 2)
+    nn = pts_new.shape[0]
+    pts_l1 = np.zeros((max(n, 1), 2), np.float32)
+    pts_r1 = np.zeros((max(n, 1), 2), np.float32)
+    pts_r1[:n] = _f32(pts_r0)
+    stage = np.zeros(max(n, 1), np.uint8)
+    dT = np.zeros(16, np.float32)
+    pnr = np.zeros((max(nn, 1), 2), np.float32)
+    mnew = np.zeros(max(nn, 1), np.uint8)
+    counts = FrameCounts()
+    dTp = _f32(dT_prior).reshape(16)
+    rc = lib().vo_ref_stereo_frame(
+        C.byref(prm), _p(I0l, C.c_uint8), _p(I1l, C.c_uint8), _p(I1r, C.c_uint8), st, _p(pts_l0),
+        _p(Xp), n, _p(dTp), _p(pts_new), nn, sum_mode, tree_width, ic_border_mode, n_threads,
+        _p(pts_l1), _p(pts_r1), _p(stage, C.c_uint8), _p(dT), _p(pnr), _p(mnew, C.c_uint8),
+        C.byref(counts))
+    return dict(rc=rc, pts_l1=pts_l1[:n], pts_r1=pts_r1[:n], stage=stage[:n], dT=dT.reshape(4, 4),
+                pts_new_r=pnr[:nn], mask_new=mnew[:nn].astype(bool), counts=counts)

@@ -1,0 +1,272 @@
+/*
+ * oracle_misc.c — ORB descriptor distance, landmark mask compaction, and the
+ * steady-state stereo frame operator sequence.
+ * TEST INFRASTRUCTURE ONLY (see vo_oracle.h). PARITY UNPINNED.
+ * Follows:
+ *   core/visual_odometry/feature_extractor.cpp:338-357   (descriptorDistance)
+ *   test/test_orbmatching.cpp:87-137                     (NN + ratio matcher skeleton)
+ *   core/visual_odometry/landmark.cpp:291-332, :194-231  (mask compaction ctors)
+ *   core/visual_odometry/stereo_vo/stereo_vo.cpp:465-740 (steady-state frame)
+ *   core/visual_odometry/camera.cpp:208-229              (projectToPixel, inImage)
+ */
+#include "vo_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* feature_extractor.cpp:338-357: 8 x (xor, SWAR popcount) over 32 bytes */
+int vo_ref_descriptor_distance(const uint8_t *a, const uint8_t *b) {
+  int dist = 0;
+  for (int i = 0; i < 8; ++i) {
+    uint32_t pa, pb;
+    memcpy(&pa, a + 4 * i, 4);
+    memcpy(&pb, b + 4 * i, 4);
+    uint32_t v = pa ^ pb;
+    v = v - ((v >> 1) & 0x55555555);
+    v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+    dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+  }
+  return dist;
+}
+
+void vo_ref_hamming_matrix(const uint8_t *a, int na, const uint8_t *b, int nb,
+                           uint16_t *dist) {
+  for (int i = 0; i < na; ++i)
+    for (int j = 0; j < nb; ++j)
+      dist[(size_t)i * nb + j] = (uint16_t)vo_ref_descriptor_distance(a + 32 * i, b + 32 * j);
+}
+
+/* test/test_orbmatching.cpp:87-137 policy: for every query the nearest and
+ * second-nearest train descriptor (first index wins ties), accepted iff
+ * best <= th_low and best < ratio * second. best_idx = -1 when rejected. */
+void vo_ref_hamming_match(const uint8_t *a, int na, const uint8_t *b, int nb,
+                          int th_low, float ratio, int32_t *best_idx,
+                          uint16_t *best_dist, uint16_t *second_dist) {
+  for (int i = 0; i < na; ++i) {
+    int bd = 256, bd2 = 256, bi = -1;
+    for (int j = 0; j < nb; ++j) {
+      int d = vo_ref_descriptor_distance(a + 32 * i, b + 32 * j);
+      if (d < bd) {
+        bd2 = bd;
+        bd = d;
+        bi = j;
+      } else if (d < bd2) {
+        bd2 = d;
+      }
+    }
+    best_dist[i] = (uint16_t)bd;
+    second_dist[i] = (uint16_t)bd2;
+    if (bi >= 0 && bd <= th_low && (float)bd < ratio * (float)bd2)
+      best_idx[i] = bi;
+    else
+      best_idx[i] = -1;
+  }
+}
+
+/* landmark.cpp:291-332: stable compaction by mask && alive && tracked; every
+ * rejected landmark is setUntracked(). Returns the survivor count. */
+int vo_ref_compact_indices(const uint8_t *mask, const uint8_t *alive,
+                           const uint8_t *tracked, int n, int32_t *index_valid,
+                           uint8_t *tracked_out) {
+  int cnt = 0;
+  for (int i = 0; i < n; ++i) {
+    int al = alive ? alive[i] : 1, tr = tracked ? tracked[i] : 1;
+    if (mask[i] && al && tr) {
+      index_valid[cnt++] = i;
+      if (tracked_out) tracked_out[i] = 1;
+    } else if (tracked_out)
+      tracked_out[i] = 0;
+  }
+  return cnt;
+}
+
+/* camera.cpp:208-213 */
+static void project(const float K[4], const float X[3], float *px, float *py) {
+  const float invz = 1.0f / X[2];
+  *px = K[0] * X[0] * invz + K[2];
+  *py = K[1] * X[1] * invz + K[3];
+}
+/* camera.cpp:220-229 */
+static int in_image(float x, float y, int n_cols, int n_rows) {
+  const float offset = 3.0f;
+  return !(x < offset || y < offset || x >= n_cols - offset || y >= n_rows - offset);
+}
+static void xform(const float T[16], const float X[3], float Y[3]) {
+  for (int r = 0; r < 3; ++r)
+    Y[r] = ((T[r * 4 + 0] * X[0] + T[r * 4 + 1] * X[1]) + T[r * 4 + 2] * X[2]) + T[r * 4 + 3];
+}
+
+/*
+ * Steady-state stereo frame, expressed in the previous left-camera frame
+ * (the reference carries world-frame landmarks and T_wp; with Xp = T_pw X and
+ * dT = T_pw T_wc the operator sequence is the same):
+ *   [3] prior pixels + patch scale            stereo_vo.cpp:483-522
+ *   [4] trackWithPrior  I0_L -> I1_L          :531-538
+ *   [4-1] Sobel + trackWithScale              :549-558
+ *   [5] trackWithPrior  I1_L -> I1_R          :564-571
+ *   [6] poseOnlyBundleAdjustment_Stereo       :595-646
+ *   [7] the y>660 gate                        :653-670 (thres_sampson = 60)
+ *   [10] trackBidirection for new points      :706-711
+ * stage_mask[i] = number of gates point i passed (0..4; 4 = survived all).
+ * pts_r0 is taken as pts_l0 when a prior falls outside the image only through
+ * the caller: here the prior for such points is (pts_l0, pts_l0 - disparity)
+ * — the caller passes pts_r0 through pts_r1 (in/out).
+ */
+int vo_ref_stereo_frame(const vo_ref_stereo_params *prm, const uint8_t *I0l,
+                        const uint8_t *I1l, const uint8_t *I1r, int stride,
+                        const float *pts_l0, const float *Xp, int n,
+                        const float dT_prior[16], const float *pts_new,
+                        int n_new, int sum_mode, int tree_width,
+                        int ic_border_mode, int n_threads, float *pts_l1,
+                        float *pts_r1, uint8_t *stage_mask, float dT_out[16],
+                        float *pts_new_r, uint8_t *mask_new,
+                        vo_ref_frame_counts *counts) {
+  const int W = prm->width, H = prm->height;
+  float T_rl[16], T_cp[16];
+  vo_ref_inverse_se3(prm->T_lr, T_rl);
+  vo_ref_inverse_se3(dT_prior, T_cp);
+  float *scale = (float *)malloc(sizeof(float) * ((size_t)n + 1));
+  int32_t *idx = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n + 1));
+  uint8_t *m = (uint8_t *)malloc((size_t)n + 1);
+  float *a0 = (float *)malloc(sizeof(float) * 2 * ((size_t)n + 1));
+  float *a1 = (float *)malloc(sizeof(float) * 2 * ((size_t)n + 1));
+  float *a2 = (float *)malloc(sizeof(float) * 2 * ((size_t)n + 1));
+  float *aX = (float *)malloc(sizeof(float) * 3 * ((size_t)n + 1));
+  float *as = (float *)malloc(sizeof(float) * ((size_t)n + 1));
+  memset(counts, 0, sizeof(*counts));
+  /* [3] priors; pts_r1 holds pts_r0 on entry */
+  for (int i = 0; i < n; ++i) {
+    float Xl1[3], Xr1[3];
+    xform(T_cp, Xp + 3 * i, Xl1);
+    xform(T_rl, Xl1, Xr1);
+    scale[i] = Xp[3 * i + 2] / Xl1[2];
+    float plx, ply, prx, pry;
+    project(prm->Kl, Xl1, &plx, &ply);
+    project(prm->Kr, Xr1, &prx, &pry);
+    if (!in_image(plx, ply, W, H) || !in_image(prx, pry, W, H) || Xl1[2] < 0.1 || Xr1[2] < 0.1) {
+      pts_l1[2 * i] = pts_l0[2 * i];
+      pts_l1[2 * i + 1] = pts_l0[2 * i + 1];
+      /* pts_r1 keeps pts_r0 */
+    } else {
+      pts_l1[2 * i] = plx;
+      pts_l1[2 * i + 1] = ply;
+      pts_r1[2 * i] = prx;
+      pts_r1[2 * i + 1] = pry;
+    }
+    stage_mask[i] = 0;
+    idx[i] = i;
+  }
+  int cur = n;
+  /* [4] l0 -> l1 */
+  for (int i = 0; i < n; ++i) m[i] = 1;
+  vo_ref_track_with_prior(I0l, I1l, W, H, stride, pts_l0, n, prm->win, prm->max_level,
+                          prm->thres_err, pts_l1, m, n_threads);
+  int c = 0;
+  for (int i = 0; i < cur; ++i)
+    if (m[i]) {
+      stage_mask[idx[i]] = 1;
+      idx[c] = idx[i];
+      ++c;
+    }
+  cur = c;
+  counts->n_l0l1 = cur;
+  /* [4-1] refine on the compacted set */
+  for (int i = 0; i < cur; ++i) {
+    int o = idx[i];
+    a0[2 * i] = pts_l0[2 * o];
+    a0[2 * i + 1] = pts_l0[2 * o + 1];
+    a1[2 * i] = pts_l1[2 * o];
+    a1[2 * i + 1] = pts_l1[2 * o + 1];
+    as[i] = scale[o];
+    m[i] = 1;
+  }
+  int rc = vo_ref_track_with_scale(I0l, I1l, W, H, stride, a0, as, cur, a1, m, ic_border_mode,
+                                   sum_mode, NULL);
+  if (rc < 0) goto fail;
+  c = 0;
+  for (int i = 0; i < cur; ++i) {
+    int o = idx[i];
+    pts_l1[2 * o] = a1[2 * i];
+    pts_l1[2 * o + 1] = a1[2 * i + 1];
+    if (m[i]) {
+      stage_mask[o] = 2;
+      idx[c++] = o;
+    }
+  }
+  cur = c;
+  counts->n_refine = cur;
+  /* [5] l1 -> r1 */
+  for (int i = 0; i < cur; ++i) {
+    int o = idx[i];
+    a0[2 * i] = pts_l1[2 * o];
+    a0[2 * i + 1] = pts_l1[2 * o + 1];
+    a1[2 * i] = pts_r1[2 * o];
+    a1[2 * i + 1] = pts_r1[2 * o + 1];
+    m[i] = 1;
+  }
+  vo_ref_track_with_prior(I1l, I1r, W, H, stride, a0, cur, prm->win, prm->max_level,
+                          prm->thres_err, a1, m, n_threads);
+  c = 0;
+  for (int i = 0; i < cur; ++i) {
+    int o = idx[i];
+    pts_r1[2 * o] = a1[2 * i];
+    pts_r1[2 * o + 1] = a1[2 * i + 1];
+    if (m[i]) {
+      stage_mask[o] = 3;
+      idx[c++] = o;
+    }
+  }
+  cur = c;
+  counts->n_l1r1 = cur;
+  /* [6] stereo pose-only BA */
+  for (int i = 0; i < cur; ++i) {
+    int o = idx[i];
+    a0[2 * i] = pts_l1[2 * o];
+    a0[2 * i + 1] = pts_l1[2 * o + 1];
+    a2[2 * i] = pts_r1[2 * o];
+    a2[2 * i + 1] = pts_r1[2 * o + 1];
+    aX[3 * i] = Xp[3 * o];
+    aX[3 * i + 1] = Xp[3 * o + 1];
+    aX[3 * i + 2] = Xp[3 * o + 2];
+  }
+  memcpy(dT_out, dT_prior, sizeof(float) * 16);
+  vo_ref_gn_info gi;
+  rc = vo_ref_gn_pose_stereo(aX, a0, a2, cur, prm->Kl, prm->Kr, prm->T_lr, prm->thres_poseba,
+                             dT_out, m, sum_mode, tree_width, &gi);
+  if (rc <= 0) {
+    rc = -6; /* reference throws "PoseOnlyStereoBA is failed!" (:626) */
+    goto fail;
+  }
+  counts->gn_iterations = gi.iterations;
+  /* [7] y > 660 gate (thres_sampson 60 < 100) */
+  c = 0;
+  for (int i = 0; i < cur; ++i) {
+    int o = idx[i];
+    float d = pts_l1[2 * o + 1] > 660 ? 100.f : 0.f;
+    if (m[i] && d < 60.0f) {
+      stage_mask[o] = 4;
+      ++c;
+    }
+  }
+  counts->n_inlier = c;
+  /* [10] new points */
+  if (n_new > 0) {
+    for (int i = 0; i < n_new; ++i) mask_new[i] = 1;
+    vo_ref_track_bidirection(I1l, I1r, W, H, stride, pts_new, n_new, prm->win, prm->max_level,
+                             prm->thres_err, prm->thres_bidirection, pts_new_r, mask_new,
+                             n_threads);
+    for (int i = 0; i < n_new; ++i) counts->n_new_ok += mask_new[i];
+  }
+  rc = 0;
+fail:
+  free(scale);
+  free(idx);
+  free(m);
+  free(a0);
+  free(a1);
+  free(a2);
+  free(aX);
+  free(as);
+  return rc;
+}

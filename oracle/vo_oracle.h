@@ -1,0 +1,176 @@
+/*
+ * vo_oracle.h — CPU parity oracle for the per-frame VO hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load it, and only as the checker (never as the thing measured or shipped).
+ *
+ * PARITY UNPINNED: the reference (ChanghyeonKim93/visual_odometry_ros) holds
+ * no golden vector, known-answer test or fixture for this path (its test/
+ * directory is four print-only programs), and it cannot be compiled in the
+ * build container (Eigen3 and OpenCV 4 are absent).  This file is a plain-C
+ * restatement that follows the reference text function by function; every
+ * function cites the reference file:line it restates.  The KLT core
+ * (cv::calcOpticalFlowPyrLK) is a third-party dependency that is NOT in the
+ * reference tree (OpenCV 4.x, modules/video/src/lkpyramid.cpp, pinned only as
+ * "find_package(OpenCV 4 REQUIRED)" in core/CMakeLists.txt:12); its published
+ * algorithm is restated here and anchored on the reference's call sites
+ * (core/visual_odometry/feature_tracker.cpp:29,60,69,108,117,186).
+ *
+ * All matrices crossing this interface are ROW-MAJOR float[16]/float[9].
+ */
+#ifndef VO_ORACLE_H_
+#define VO_ORACLE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Summation order for the genuinely-floating-point reductions (GN, IC).
+ *  SEQ : the reference's order (one accumulator, index ascending).
+ *  TREE: the order the wavefront kernels use — T strided serial partials
+ *        (partial t takes elements t, t+T, ...) combined by a balanced binary
+ *        tree over the partials in natural order (adjacent pairs first). */
+#define VO_SUM_SEQ 0
+#define VO_SUM_TREE 1
+
+/* Mono GN variant: core adds the weighted w*ry^2 for the y row
+ * when the Huber weight is active; standalone adds the unweighted ry^2. */
+#define VO_GN_VARIANT_CORE 0
+#define VO_GN_VARIANT_STANDALONE 1
+
+/* IC border semantics.
+ *  REFERENCE: reproduce the reference exactly, including the tap mask / value
+ *             vectors that are never reset between points and iterations.
+ *  MASKED   : the evident intent — a tap outside the image is excluded from
+ *             that evaluation's sums. Identical to REFERENCE for every point
+ *             whose taps all stay inside the image in every evaluation. */
+#define VO_IC_BORDER_REFERENCE 0
+#define VO_IC_BORDER_MASKED 1
+
+/* OpenCV flag (cv::OPTFLOW_USE_INITIAL_FLOW == 4). */
+#define VO_KLT_USE_INITIAL_FLOW 4
+
+typedef struct {
+  int iterations;   /* GN iterations executed (reference `iter`+1 at break) */
+  float err;        /* last err_curr */
+  float delta_err;  /* last |err_curr - err_prev| */
+  float delta_norm; /* last ||delta_xi|| */
+  int cnt_invalid;  /* outliers counted in the last iteration */
+  int is_nan;       /* 1 if the pose went NaN (reference returns false) */
+} vo_ref_gn_info;
+
+/* ---- geometry helpers -------------------------------------------------- */
+void vo_ref_se3_exp(const float xi[6], float T[16]);
+void vo_ref_inverse_se3(const float T[16], float Tinv[16]);
+void vo_ref_inverse4x4(const float T[16], float Tinv[16]);
+int vo_ref_ldlt6_solve(const float A[36], const float b[6], float x[6]);
+
+/* ---- Gauss-Newton pose-only BA ----------------------------------------- */
+int vo_ref_gn_pose_mono(const float *X, const float *pts1, int n,
+                        const float K[4], int thres_reproj_outlier,
+                        float R01[9], float t01[3], uint8_t *mask_inlier,
+                        int variant, int sum_mode, int tree_width,
+                        vo_ref_gn_info *info);
+int vo_ref_gn_pose_stereo(const float *X, const float *pts_l1,
+                          const float *pts_r1, int n, const float Kl[4],
+                          const float Kr[4], const float T_lr[16],
+                          float thres_reproj_outlier, float T01[16],
+                          uint8_t *mask_inlier, int sum_mode, int tree_width,
+                          vo_ref_gn_info *info);
+
+/* ---- image pyramid (OpenCV buildOpticalFlowPyramid semantics) ---------- */
+int vo_ref_pyramid_levels(int w, int h, int win, int max_level);
+void vo_ref_level_size(int w, int h, int level, int *lw, int *lh);
+void vo_ref_pyr_down(const uint8_t *src, int sw, int sh, int sstride,
+                     uint8_t *dst, int dstride);
+void vo_ref_scharr(const uint8_t *src, int w, int h, int sstride,
+                   int16_t *dxy /* w*h*2 interleaved */);
+void vo_ref_sobel3(const uint8_t *src, int w, int h, int sstride, float *du,
+                   float *dv);
+
+/* ---- pyramidal LK (cv::calcOpticalFlowPyrLK semantics) ------------------ */
+int vo_ref_calc_optical_flow_pyr_lk(const uint8_t *img0, const uint8_t *img1,
+                                    int w, int h, int stride, const float *pts0,
+                                    float *pts1, int n, int win, int max_level,
+                                    int flags, int max_iter, double eps,
+                                    float min_eig_thr, uint8_t *status,
+                                    float *err, int n_threads);
+
+/* ---- FeatureTracker front-ends (masks) ---------------------------------- */
+int vo_ref_track(const uint8_t *img0, const uint8_t *img1, int w, int h,
+                 int stride, const float *pts0, int n, int win, int max_level,
+                 float thres_err, float *pts_track, uint8_t *mask,
+                 int n_threads);
+int vo_ref_track_bidirection(const uint8_t *img0, const uint8_t *img1, int w,
+                             int h, int stride, const float *pts0, int n,
+                             int win, int max_level, float thres_err,
+                             float thres_bidirection, float *pts_track,
+                             uint8_t *mask, int n_threads);
+int vo_ref_track_bidirection_with_prior(const uint8_t *img0,
+                                        const uint8_t *img1, int w, int h,
+                                        int stride, const float *pts0, int n,
+                                        int win, int max_level, float thres_err,
+                                        float thres_bidirection,
+                                        float *pts_track, uint8_t *mask,
+                                        int n_threads);
+int vo_ref_track_with_prior(const uint8_t *img0, const uint8_t *img1, int w,
+                            int h, int stride, const float *pts0, int n,
+                            int win, int max_level, float thres_err,
+                            float *pts_track, uint8_t *mask, int n_threads);
+void vo_ref_calc_prior(const float *pts0, int n_pts0, const float *Xw, int n,
+                       const float Tw1[16], const float K[9],
+                       float *pts1_prior);
+
+/* ---- scale-compensated inverse-compositional refinement ---------------- */
+int vo_ref_track_with_scale(const uint8_t *img0, const uint8_t *img1, int w,
+                            int h, int stride, const float *pts0,
+                            const float *scale_est, int n, float *pts_track,
+                            uint8_t *mask, int border_mode, int sum_mode,
+                            uint8_t *touched_border /* optional, n */);
+
+/* ---- ORB descriptor distance ------------------------------------------- */
+int vo_ref_descriptor_distance(const uint8_t *a, const uint8_t *b);
+void vo_ref_hamming_matrix(const uint8_t *a, int na, const uint8_t *b, int nb,
+                           uint16_t *dist);
+void vo_ref_hamming_match(const uint8_t *a, int na, const uint8_t *b, int nb,
+                          int th_low, float ratio, int32_t *best_idx,
+                          uint16_t *best_dist, uint16_t *second_dist);
+
+/* ---- landmark mask compaction / track ids ------------------------------ */
+int vo_ref_compact_indices(const uint8_t *mask, const uint8_t *alive,
+                           const uint8_t *tracked, int n, int32_t *index_valid,
+                           uint8_t *tracked_out);
+
+/* ---- steady-state stereo frame (operator sequence of
+ *      core/visual_odometry/stereo_vo/stereo_vo.cpp:465-740) ------------- */
+typedef struct {
+  int width, height;
+  int win, max_level;
+  float thres_err, thres_bidirection, thres_poseba;
+  float Kl[4], Kr[4];
+  float T_lr[16];
+} vo_ref_stereo_params;
+
+typedef struct {
+  int n_l0l1, n_refine, n_l1r1, n_inlier, n_new_ok;
+  int gn_iterations;
+} vo_ref_frame_counts;
+
+int vo_ref_stereo_frame(const vo_ref_stereo_params *prm, const uint8_t *I0l,
+                        const uint8_t *I1l, const uint8_t *I1r, int stride,
+                        const float *pts_l0, const float *Xp /* prev-cam */,
+                        int n, const float dT_prior[16] /* T_pc prior */,
+                        const float *pts_new, int n_new, int sum_mode,
+                        int tree_width, int ic_border_mode, int n_threads,
+                        /* outputs, all sized n (or n_new) */
+                        float *pts_l1, float *pts_r1, uint8_t *stage_mask,
+                        float dT_out[16], float *pts_new_r, uint8_t *mask_new,
+                        vo_ref_frame_counts *counts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VO_ORACLE_H_ */
