@@ -1,0 +1,208 @@
+/*
+ * vo_hip.h — C ABI of libvo_hip.so, the MI355X (gfx950) implementation of the
+ * per-frame visual-odometry hot path of ChanghyeonKim93/visual_odometry_ros.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types,
+ * no exceptions across the ABI. Every entry point names the reference
+ * interface it replaces (paths relative to the reference repository root).
+ * The C++ classes in visual_odometry_ros_amd/core/visual_odometry/ (same class
+ * and method names as the reference) sit directly on top of these calls; see
+ * INTEGRATION.md for the reference-side binding.
+ *
+ * Conventions
+ *  - Pixels are float pairs (x,y), row i at pts[2*i], pts[2*i+1]
+ *    (cv::Point2f layout, core/defines/define_type.h:16).
+ *  - 3-D points are float triples (Eigen::Vector3f layout, define_type.h:17).
+ *  - Masks are one uint8_t per element (the adapter converts the reference's
+ *    bit-packed std::vector<bool>, define_type.h:33).
+ *  - 4x4 / 3x3 matrices are ROW-MAJOR here; Eigen::Matrix4f (PoseSE3,
+ *    define_type.h:41) is column-major, the adapter transposes explicitly.
+ *  - Unless a parameter is documented as a device pointer, pointers are HOST
+ *    pointers; the call is synchronous at return (like the reference methods).
+ *  - Return value: VO_OK (0) or a negative vo_status. vo_last_error() gives
+ *    the message. Codes VO_ERR_NAN_* mirror the reference's
+ *    `throw std::runtime_error` sites; VO_ERR_SIZE its size-mismatch throws.
+ *  - There is NO CPU fallback: every compute entry point fails with
+ *    VO_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef VO_HIP_H_
+#define VO_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VO_HIP_ABI_VERSION 1
+
+typedef enum {
+  VO_OK = 0,
+  VO_ERR_INVALID = -1,    /* bad argument */
+  VO_ERR_HIP = -2,        /* HIP runtime error */
+  VO_ERR_NO_DEVICE = -3,  /* no usable gfx950 device */
+  VO_ERR_SIZE = -4,       /* reference: throw on size mismatch (feature_tracker.cpp:283, motion_estimator.cpp:670,873) */
+  VO_ERR_NAN_AXAY = -5,   /* feature_tracker.cpp:414 "ax ay nan" */
+  VO_ERR_NAN_PATCH = -6,  /* feature_tracker.cpp:443,447 */
+  VO_ERR_NAN_UPDATE = -7, /* feature_tracker.cpp:465 "dtu dtv nan" */
+  VO_ERR_CAPACITY = -8,   /* more points / larger image than vo_config allows */
+  VO_ERR_GN_FAILED = -9   /* stereo_vo.cpp:626 "PoseOnlyStereoBA is failed!" */
+} vo_status;
+
+/* cv::OPTFLOW_USE_INITIAL_FLOW */
+#define VO_KLT_USE_INITIAL_FLOW 4
+
+/* mono GN variant: core/visual_odometry/motion_estimator.cpp:793-799 (core)
+ * vs standalone/motion_estimator/motion_estimator.cpp:135 (standalone) */
+#define VO_GN_VARIANT_CORE 0
+#define VO_GN_VARIANT_STANDALONE 1
+
+typedef struct vo_ctx vo_ctx;
+
+typedef struct {
+  int device;      /* HIP device ordinal */
+  int max_width;   /* largest image accepted by vo_set_image */
+  int max_height;
+  int max_points;  /* capacity of every per-point buffer */
+  int n_slots;     /* image slots (each holds an image pyramid), >= 3 for stereo */
+  int max_level;   /* deepest pyramid level ever requested (OpenCV maxLevel) */
+} vo_config;
+
+typedef struct {
+  int iterations;   /* GN iterations executed */
+  float err;        /* last err_curr (motion_estimator.cpp:812 / :1042-1043) */
+  float delta_err;
+  float delta_norm; /* ||delta_xi|| of the last step */
+  int cnt_invalid;  /* outliers in the last iteration */
+  int is_nan;       /* pose went NaN: reference returns false, pose untouched */
+} vo_gn_info;
+
+/* ---- context ------------------------------------------------------------ */
+int vo_abi_version(void);
+int vo_device_count(void);
+int vo_create(const vo_config *cfg, vo_ctx **out);
+void vo_destroy(vo_ctx *ctx);
+const char *vo_last_error(const vo_ctx *ctx);
+/* hipStream_t of the context, as void* (for event timing by the caller). */
+void *vo_stream(vo_ctx *ctx);
+int vo_synchronize(vo_ctx *ctx);
+
+/* ---- images & pyramids ---------------------------------------------------
+ * Replaces what cv::calcOpticalFlowPyrLK does internally on every call
+ * (buildOpticalFlowPyramid: pyrDown 5-tap, REFLECT_101 borders; reference call
+ * sites core/visual_odometry/feature_tracker.cpp:29,60,69,108,117,186). A slot
+ * keeps its pyramid device-resident so the 4 PyrLK calls of a frame and the
+ * next frame reuse it. */
+int vo_set_image(vo_ctx *ctx, int slot, const uint8_t *host, int width, int height, int stride);
+/* same, `dev` is a DEVICE pointer (image already resident in HBM) */
+int vo_set_image_device(vo_ctx *ctx, int slot, const void *dev, int width, int height, int stride);
+int vo_swap_slots(vo_ctx *ctx, int slot_a, int slot_b);
+/* effective OpenCV maxLevel for (width,height,win,max_level) */
+int vo_pyramid_levels(int width, int height, int win, int max_level);
+/* test hook: copy unpadded level `level` of a slot back to host (tightly packed) */
+int vo_get_level(vo_ctx *ctx, int slot, int level, uint8_t *host, int *width, int *height);
+
+/* ---- pyramidal LK -------------------------------------------------------
+ * cv::calcOpticalFlowPyrLK(prev, next, prevPts, nextPts, status, err, winSize,
+ * maxLevel, criteria, flags, minEigThreshold) on two slots. max_iter <= 0 and
+ * eps <= 0 select what the reference's `{}` TermCriteria yields (30, 0.01).
+ * pts1 is in/out when flags has VO_KLT_USE_INITIAL_FLOW. */
+int vo_klt_track(vo_ctx *ctx, int slot0, int slot1, const float *pts0, float *pts1, int n,
+                 int win, int max_level, int flags, int max_iter, double eps, float min_eig_thr,
+                 uint8_t *status, float *err);
+
+/* ---- FeatureTracker (core/visual_odometry/feature_tracker.h:44-104) ------ */
+/* FeatureTracker::track, feature_tracker.cpp:13-37 */
+int vo_track(vo_ctx *ctx, int slot0, int slot1, const float *pts0, int n, int win, int max_level,
+             float thres_err, float *pts_track, uint8_t *mask_valid);
+/* FeatureTracker::trackBidirection, feature_tracker.cpp:39-86 */
+int vo_track_bidirection(vo_ctx *ctx, int slot0, int slot1, const float *pts0, int n, int win,
+                         int max_level, float thres_err, float thres_bidirection,
+                         float *pts_track, uint8_t *mask_valid);
+/* FeatureTracker::trackBidirectionWithPrior, feature_tracker.cpp:88-169 (pts_track in/out) */
+int vo_track_bidirection_with_prior(vo_ctx *ctx, int slot0, int slot1, const float *pts0, int n,
+                                    int win, int max_level, float thres_err,
+                                    float thres_bidirection, float *pts_track,
+                                    uint8_t *mask_valid);
+/* FeatureTracker::trackWithPrior, feature_tracker.cpp:171-206 (pts_track in/out) */
+int vo_track_with_prior(vo_ctx *ctx, int slot0, int slot1, const float *pts0, int n, int win,
+                        int max_level, float thres_err, float *pts_track, uint8_t *mask_valid);
+/* FeatureTracker::calcPrior, feature_tracker.cpp:208-234 (K row-major 3x3, Tw1 row-major 4x4) */
+int vo_calc_prior(vo_ctx *ctx, const float *pts0, int n_pts0, const float *Xw, int n,
+                  const float Tw1[16], const float K[9], float *pts1_prior);
+/* FeatureTracker::trackWithScale, feature_tracker.cpp:236-504, fused with the
+ * cv::Sobel(ksize 3, CV_32F) pair the drivers compute first
+ * (stereo_vo.cpp:549-552, mono_vo.cpp:779-782). pts_track and mask_valid are
+ * in/out. strict_border != 0 reproduces the reference's never-reset tap masks
+ * for points whose taps leave the image; 0 excludes such taps. */
+int vo_track_with_scale(vo_ctx *ctx, int slot0, int slot1, const float *pts0,
+                        const float *scale_est, int n, float *pts_track, uint8_t *mask_valid,
+                        int strict_border);
+
+/* ---- MotionEstimator (core/visual_odometry/motion_estimator.h:117-120) --- */
+/* poseOnlyBundleAdjustment, motion_estimator.cpp:665-861. K = (fx,fy,cx,cy).
+ * Returns 1 = true, 0 = false (NaN pose, R01/t01 untouched), <0 = error. */
+int vo_gn_pose_mono(vo_ctx *ctx, const float *X, const float *pts1, int n, const float K[4],
+                    int thres_reproj_outlier, float R01[9], float t01[3], uint8_t *mask_inlier,
+                    int variant, vo_gn_info *info);
+/* poseOnlyBundleAdjustment_Stereo, motion_estimator.cpp:863-1088. */
+int vo_gn_pose_stereo(vo_ctx *ctx, const float *X, const float *pts_l1, const float *pts_r1,
+                      int n, const float Kl[4], const float Kr[4], const float T_lr[16],
+                      float thres_reproj_outlier, float T01[16], uint8_t *mask_inlier,
+                      vo_gn_info *info);
+
+/* ---- FeatureExtractor::descriptorDistance (feature_extractor.cpp:338-357) - */
+/* all-pairs 256-bit Hamming distance, dist is na x nb row-major */
+int vo_orb_hamming(vo_ctx *ctx, const uint8_t *a, int na, const uint8_t *b, int nb,
+                   uint16_t *dist);
+/* nearest / second-nearest + the test/test_orbmatching.cpp:87-137 accept rule */
+int vo_orb_match(vo_ctx *ctx, const uint8_t *a, int na, const uint8_t *b, int nb, int th_low,
+                 float ratio, int32_t *best_idx, uint16_t *best_dist, uint16_t *second_dist);
+
+/* ---- landmark mask compaction (landmark.cpp:291-332, :194-231) ----------- */
+/* stable compaction indices of mask && alive && tracked; returns count in *n_out */
+int vo_compact_indices(vo_ctx *ctx, const uint8_t *mask, const uint8_t *alive,
+                       const uint8_t *tracked, int n, int32_t *index_valid, int *n_out);
+
+/* ---- steady-state stereo frame -------------------------------------------
+ * The operator sequence of StereoVO::trackStereoImages, steps [3]-[7] and the
+ * tracking part of [10] (core/visual_odometry/stereo_vo/stereo_vo.cpp:483-711),
+ * chained on the device with no host round trip. */
+typedef struct {
+  int width, height;
+  int win, max_level;
+  float thres_err, thres_bidirection, thres_poseba;
+  float Kl[4], Kr[4];
+  float T_lr[16];
+} vo_stereo_params;
+
+typedef struct {
+  int n_l0l1, n_refine, n_l1r1, n_inlier, n_new_ok;
+  int gn_iterations;
+} vo_frame_counts;
+
+/* Asynchronous: enqueues one frame on the context stream. slot_l0 must hold the
+ * previous left pyramid, slot_l1 / slot_r1 the current pair. Track-set inputs
+ * are DEVICE pointers when `inputs_on_device` != 0, else host pointers. */
+int vo_stereo_frame_enqueue(vo_ctx *ctx, const vo_stereo_params *prm, int slot_l0, int slot_l1,
+                            int slot_r1, const float *pts_l0, const float *pts_r0,
+                            const float *Xp, int n, const float dT_prior[16],
+                            const float *pts_new, int n_new, int inputs_on_device);
+/* Waits for the last enqueued frame and copies its results to host buffers
+ * (any of which may be NULL). stage[i] = number of gates point i passed (0..4). */
+int vo_stereo_frame_result(vo_ctx *ctx, float *pts_l1, float *pts_r1, uint8_t *stage,
+                           float dT[16], float *pts_new_r, uint8_t *mask_new,
+                           vo_frame_counts *counts, vo_gn_info *gn);
+
+/* ---- kernel timing (HIP events on the context stream) --------------------- */
+enum { VO_K_PYRAMID = 0, VO_K_KLT = 1, VO_K_IC = 2, VO_K_GN = 3, VO_K_HAMMING = 4, VO_K_AUX = 5, VO_K_COUNT = 6 };
+int vo_profile_enable(vo_ctx *ctx, int max_records);
+int vo_profile_reset(vo_ctx *ctx);
+/* after vo_synchronize(): launches and summed device time (ms) of one kernel class */
+int vo_profile_get(vo_ctx *ctx, int kernel_class, int *launches, double *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VO_HIP_H_ */

@@ -1,0 +1,89 @@
+"""GPU parity: HIP Gauss-Newton pose-only BA vs the CPU oracle (through the C ABI)."""
+import numpy as np
+import pytest
+
+from visual_odometry_ros_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+GN_T = 512  # workgroup width of gn_pose_kernel == oracle tree_width
+
+
+def rel_frob(A, B):
+    return np.linalg.norm(np.asarray(A, np.float64) - np.asarray(B, np.float64)) / np.linalg.norm(B)
+
+
+@pytest.mark.parametrize("n,seed", [(500, 1), (1500, 2), (37, 3), (3000, 4), (1, 5)])
+def test_stereo_gn_parity(ctx, vo, oracle, n, seed):
+    d = S.two_view_points(n=n, seed=seed)
+    me = vo.MotionEstimator(ctx, True, d["T_lr"])
+    T0 = np.eye(4, dtype=np.float32)
+    ok, T, mask, info = me.poseOnlyBundleAdjustment_Stereo(d["X"], d["pts_l"], d["pts_r"], d["K"], d["K"],
+                                                          d["T_lr"], 3.0, T0)
+    rc_t, T_t, mask_t, info_t = oracle.gn_pose_stereo(d["X"], d["pts_l"], d["pts_r"], d["K"], d["K"],
+                                                      d["T_lr"], 3.0, T0, oracle.SUM_TREE, GN_T)
+    rc_s, T_s, mask_s, info_s = oracle.gn_pose_stereo(d["X"], d["pts_l"], d["pts_r"], d["K"], d["K"],
+                                                      d["T_lr"], 3.0, T0, oracle.SUM_SEQ, 0)
+    assert ok == bool(rc_t) == bool(rc_s)
+    # same summation tree: iteration count and inlier mask identical, pose to float rounding
+    assert info.iterations == info_t.iterations
+    assert np.array_equal(mask, mask_t)
+    assert rel_frob(T, T_t) < 1e-6
+    # reference (sequential) order: north-star tolerance 1e-4 relative Frobenius, masks bit-exact
+    assert rel_frob(T, T_s) < 1e-4
+    assert np.array_equal(mask, mask_s)
+    assert info.cnt_invalid == info_s.cnt_invalid
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("n,seed", [(500, 1), (1000, 7)])
+def test_mono_gn_parity(ctx, vo, oracle, n, seed, variant):
+    d = S.two_view_points(n=n, seed=seed)
+    me = vo.MotionEstimator(ctx)
+    R0, t0 = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+    ok, R, t, mask, info = me.poseOnlyBundleAdjustment(d["X"], d["pts_l"], d["K"], 3, R0, t0, variant)
+    rc_t, R_t, t_t, mask_t, info_t = oracle.gn_pose_mono(d["X"], d["pts_l"], d["K"], 3, R0, t0, variant,
+                                                         oracle.SUM_TREE, GN_T)
+    rc_s, R_s, t_s, mask_s, info_s = oracle.gn_pose_mono(d["X"], d["pts_l"], d["K"], 3, R0, t0, variant,
+                                                         oracle.SUM_SEQ, 0)
+    T = np.eye(4); T[:3, :3] = R; T[:3, 3] = t
+    Tt = np.eye(4); Tt[:3, :3] = R_t; Tt[:3, 3] = t_t
+    Ts = np.eye(4); Ts[:3, :3] = R_s; Ts[:3, 3] = t_s
+    assert ok == bool(rc_s)
+    assert info.iterations == info_t.iterations
+    assert np.array_equal(mask, mask_t)
+    assert rel_frob(T, Tt) < 1e-6
+    assert rel_frob(T, Ts) < 1e-4
+    assert np.array_equal(mask, mask_s)
+
+
+def test_gn_noise_free_recovers_truth(ctx, vo):
+    d = S.two_view_points(n=800, seed=11, noise_px=0.0, outlier_frac=0.0)
+    me = vo.MotionEstimator(ctx, True, d["T_lr"])
+    ok, T, mask, info = me.poseOnlyBundleAdjustment_Stereo(d["X"], d["pts_l"], d["pts_r"], d["K"], d["K"],
+                                                          d["T_lr"], 3.0, np.eye(4, dtype=np.float32))
+    assert ok and mask.all()
+    assert np.abs(T - d["T01_true"]).max() < 1e-5
+
+
+def test_gn_nan_returns_false_and_keeps_pose(ctx, vo):
+    d = S.two_view_points(n=100, seed=12)
+    X = d["X"].copy()
+    X[5] = np.nan
+    me = vo.MotionEstimator(ctx, True, d["T_lr"])
+    T0 = np.eye(4, dtype=np.float32)
+    ok, T, mask, info = me.poseOnlyBundleAdjustment_Stereo(X, d["pts_l"], d["pts_r"], d["K"], d["K"],
+                                                          d["T_lr"], 3.0, T0)
+    assert not ok and info.is_nan == 1
+    assert np.array_equal(T, T0)  # motion_estimator.cpp:1079-1085: pose not updated
+
+
+def test_gn_size_mismatch_raises(ctx, vo):
+    me = vo.MotionEstimator(ctx, True)
+    with pytest.raises(vo.VoError):
+        me.poseOnlyBundleAdjustment_Stereo(np.zeros((4, 3)), np.zeros((3, 2)), np.zeros((4, 2)),
+                                           S.KITTI_K, S.KITTI_K, np.eye(4), 3.0, np.eye(4))
+    me2 = vo.MotionEstimator(ctx, False)
+    with pytest.raises(vo.VoError):  # stereo call on a mono-mode estimator (motion_estimator.cpp:866)
+        me2.poseOnlyBundleAdjustment_Stereo(np.zeros((4, 3)), np.zeros((4, 2)), np.zeros((4, 2)),
+                                            S.KITTI_K, S.KITTI_K, np.eye(4), 3.0, np.eye(4))

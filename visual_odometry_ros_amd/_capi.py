@@ -1,0 +1,74 @@
+"""ctypes binding of libvo_hip.so (C ABI in include/vo_hip.h).
+
+The library is the product; there is no Python or CPU fallback. Importing this
+module raises if the shared object has not been built, and every compute call
+raises VoError when no gfx950 device is usable.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvo_hip.so")
+
+
+class VoError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libvo_hip error {code}: {msg}")
+        self.code = code
+
+
+class VoConfig(C.Structure):
+    _fields_ = [("device", C.c_int), ("max_width", C.c_int), ("max_height", C.c_int),
+                ("max_points", C.c_int), ("n_slots", C.c_int), ("max_level", C.c_int)]
+
+
+class GnInfo(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("err", C.c_float), ("delta_err", C.c_float),
+                ("delta_norm", C.c_float), ("cnt_invalid", C.c_int), ("is_nan", C.c_int)]
+
+
+class StereoParams(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("win", C.c_int), ("max_level", C.c_int),
+                ("thres_err", C.c_float), ("thres_bidirection", C.c_float),
+                ("thres_poseba", C.c_float), ("Kl", C.c_float * 4), ("Kr", C.c_float * 4),
+                ("T_lr", C.c_float * 16)]
+
+
+class FrameCounts(C.Structure):
+    _fields_ = [("n_l0l1", C.c_int), ("n_refine", C.c_int), ("n_l1r1", C.c_int),
+                ("n_inlier", C.c_int), ("n_new_ok", C.c_int), ("gn_iterations", C.c_int)]
+
+
+# every symbol include/vo_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "vo_abi_version", "vo_device_count", "vo_create", "vo_destroy", "vo_last_error", "vo_stream",
+    "vo_synchronize", "vo_set_image", "vo_set_image_device", "vo_swap_slots", "vo_pyramid_levels",
+    "vo_get_level", "vo_klt_track", "vo_track", "vo_track_bidirection",
+    "vo_track_bidirection_with_prior", "vo_track_with_prior", "vo_calc_prior",
+    "vo_track_with_scale", "vo_gn_pose_mono", "vo_gn_pose_stereo", "vo_orb_hamming",
+    "vo_orb_match", "vo_compact_indices", "vo_stereo_frame_enqueue", "vo_stereo_frame_result",
+    "vo_profile_enable", "vo_profile_reset", "vo_profile_get",
+]
+
+_lib = None
+
+
+def load():
+    """Load libvo_hip.so; raises if it is missing (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). visual_odometry_ros_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.vo_last_error.restype = C.c_char_p
+    lib.vo_last_error.argtypes = [C.c_void_p]
+    lib.vo_stream.restype = C.c_void_p
+    lib.vo_stream.argtypes = [C.c_void_p]
+    lib.vo_create.argtypes = [C.POINTER(VoConfig), C.POINTER(C.c_void_p)]
+    lib.vo_destroy.argtypes = [C.c_void_p]
+    lib.vo_destroy.restype = None
+    _lib = lib
+    return lib

@@ -1,0 +1,344 @@
+"""Python host-side mirror of the reference operator interface, on the C ABI.
+
+Class and method names follow the reference
+(core/visual_odometry/feature_tracker.h:44-104, motion_estimator.h:117-120,
+feature_extractor.h descriptorDistance); argument meaning and error behaviour
+match: a reference `throw std::runtime_error` surfaces as VoError, a reference
+`return false` as False. numpy arrays stand in for PixelVec / PointVec /
+MaskVec; matrices are row-major numpy arrays.
+
+Everything here calls libvo_hip.so. Nothing falls back to numpy or the oracle.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import FrameCounts, GnInfo, StereoParams, VoConfig, VoError
+
+KLT_USE_INITIAL_FLOW = 4
+GN_CORE, GN_STANDALONE = 0, 1
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def _p(a, t=C.c_float):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class Context:
+    """Owns one vo_ctx: a HIP stream, image-pyramid slots and point buffers."""
+
+    def __init__(self, device=0, max_width=1241, max_height=376, max_points=4096, n_slots=4,
+                 max_level=6):
+        self.lib = _capi.load()
+        self._h = C.c_void_p()
+        cfg = VoConfig(device, max_width, max_height, max_points, n_slots, max_level)
+        rc = self.lib.vo_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            msg = self.lib.vo_last_error(self._h if self._h else None).decode()
+            if self._h:
+                self.lib.vo_destroy(self._h)
+                self._h = C.c_void_p()
+            raise VoError(rc, msg)
+        self.cfg = cfg
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.vo_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def check(self, rc):
+        if rc < 0:
+            raise VoError(rc, self.lib.vo_last_error(self._h).decode())
+        return rc
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def stream(self):
+        return self.lib.vo_stream(self._h)
+
+    def synchronize(self):
+        self.check(self.lib.vo_synchronize(self._h))
+
+    # ---- images ---------------------------------------------------------
+    def set_image(self, slot, img):
+        img = _u8(img)
+        assert img.ndim == 2
+        self.check(self.lib.vo_set_image(self._h, slot, _p(img, C.c_uint8), img.shape[1], img.shape[0],
+                                         img.strides[0]))
+
+    def set_image_device(self, slot, dev_ptr, width, height, stride):
+        self.check(self.lib.vo_set_image_device(self._h, slot, C.c_void_p(dev_ptr), width, height, stride))
+
+    def swap_slots(self, a, b):
+        self.check(self.lib.vo_swap_slots(self._h, a, b))
+
+    def pyramid_levels(self, w, h, win, max_level):
+        return self.lib.vo_pyramid_levels(w, h, win, max_level)
+
+    def get_level(self, slot, level):
+        w, h = C.c_int(), C.c_int()
+        buf = np.zeros((self.cfg.max_height, self.cfg.max_width), np.uint8).reshape(-1)
+        self.check(self.lib.vo_get_level(self._h, slot, level, _p(buf, C.c_uint8), C.byref(w), C.byref(h)))
+        return buf[: w.value * h.value].reshape(h.value, w.value).copy()
+
+    # ---- profiling --------------------------------------------------------
+    def profile_enable(self, max_records):
+        self.check(self.lib.vo_profile_enable(self._h, max_records))
+
+    def profile_reset(self):
+        self.check(self.lib.vo_profile_reset(self._h))
+
+    def profile_get(self, cls):
+        n, ms = C.c_int(), C.c_double()
+        self.check(self.lib.vo_profile_get(self._h, cls, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+
+class FeatureTracker:
+    """Mirror of the reference FeatureTracker. Images live in context slots
+    (set with Context.set_image) instead of cv::Mat arguments; everything else
+    keeps the reference argument order."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.lib = ctx.lib
+
+    def calcOpticalFlowPyrLK(self, slot0, slot1, pts0, pts1=None, win=21, max_level=3, flags=0,
+                             max_iter=30, eps=0.01, min_eig=1e-4):
+        pts0 = _f32(pts0).reshape(-1, 2)
+        n = pts0.shape[0]
+        p1 = np.zeros((max(n, 1), 2), np.float32)
+        if pts1 is not None:
+            p1[:n] = _f32(pts1).reshape(-1, 2)
+        status = np.zeros(max(n, 1), np.uint8)
+        err = np.zeros(max(n, 1), np.float32)
+        rc = self.ctx.check(self.lib.vo_klt_track(
+            self.ctx.handle, slot0, slot1, _p(pts0), _p(p1), n, win, max_level, flags, max_iter,
+            C.c_double(eps), C.c_float(min_eig), _p(status, C.c_uint8), _p(err)))
+        return rc, p1[:n], status[:n], err[:n]
+
+    def _run(self, fn, slot0, slot1, pts0, pts_track, mask_valid, win, max_level, extra):
+        pts0 = _f32(pts0).reshape(-1, 2)
+        n = pts0.shape[0]
+        pt = np.zeros((max(n, 1), 2), np.float32)
+        if pts_track is not None:
+            pts_track = _f32(pts_track).reshape(-1, 2)
+            if pts_track.shape[0] != n:
+                raise VoError(-4, "pts_track.size() != pts0.size()")
+            pt[:n] = pts_track
+        m = np.ones(max(n, 1), np.uint8)
+        if mask_valid is not None:
+            m[:n] = np.asarray(mask_valid, np.uint8)
+        self.ctx.check(fn(self.ctx.handle, slot0, slot1, _p(pts0), n, win, max_level, *extra, _p(pt),
+                          _p(m, C.c_uint8)))
+        return pt[:n], m[:n].astype(bool)
+
+    def track(self, slot0, slot1, pts0, window_size, max_pyr_lvl, thres_err, mask_valid=None):
+        return self._run(self.lib.vo_track, slot0, slot1, pts0, None, mask_valid, window_size,
+                         max_pyr_lvl, (C.c_float(thres_err),))
+
+    def trackBidirection(self, slot0, slot1, pts0, window_size, max_pyr_lvl, thres_err,
+                         thres_bidirection, mask_valid=None):
+        return self._run(self.lib.vo_track_bidirection, slot0, slot1, pts0, None, mask_valid,
+                         window_size, max_pyr_lvl, (C.c_float(thres_err), C.c_float(thres_bidirection)))
+
+    def trackBidirectionWithPrior(self, slot0, slot1, pts0, window_size, max_pyr_lvl, thres_err,
+                                  thres_bidirection, pts_track, mask_valid=None):
+        return self._run(self.lib.vo_track_bidirection_with_prior, slot0, slot1, pts0, pts_track,
+                         mask_valid, window_size, max_pyr_lvl,
+                         (C.c_float(thres_err), C.c_float(thres_bidirection)))
+
+    def trackWithPrior(self, slot0, slot1, pts0, window_size, max_pyr_lvl, thres_err, pts_track,
+                       mask_valid=None):
+        return self._run(self.lib.vo_track_with_prior, slot0, slot1, pts0, pts_track, mask_valid,
+                         window_size, max_pyr_lvl, (C.c_float(thres_err),))
+
+    def calcPrior(self, pts0, Xw, Tw1, K):
+        pts0, Xw = _f32(pts0).reshape(-1, 2), _f32(Xw).reshape(-1, 3)
+        Tw1, K = _f32(Tw1).reshape(16), _f32(K).reshape(9)
+        out = np.zeros_like(pts0)
+        self.ctx.check(self.lib.vo_calc_prior(self.ctx.handle, _p(pts0), pts0.shape[0], _p(Xw),
+                                              Xw.shape[0], _p(Tw1), _p(K), _p(out)))
+        return out
+
+    def trackWithScale(self, slot0, slot1, pts0, scale_est, pts_track, mask_valid=None,
+                       strict_border=True):
+        pts0 = _f32(pts0).reshape(-1, 2)
+        n = pts0.shape[0]
+        pt = _f32(pts_track).reshape(-1, 2).copy()
+        if pt.shape[0] != n:
+            raise VoError(-4, "pts_track.size() != pts0.size()")  # feature_tracker.cpp:282-283
+        scale = _f32(scale_est)
+        m = np.ones(max(n, 1), np.uint8)
+        if mask_valid is not None:
+            m[:n] = np.asarray(mask_valid, np.uint8)
+        if n == 0:
+            return pt, m[:0].astype(bool)
+        self.ctx.check(self.lib.vo_track_with_scale(self.ctx.handle, slot0, slot1, _p(pts0), _p(scale),
+                                                    n, _p(pt), _p(m, C.c_uint8), int(strict_border)))
+        return pt, m[:n].astype(bool)
+
+
+class MotionEstimator:
+    """Mirror of the reference MotionEstimator's pose-only BA entry points."""
+
+    def __init__(self, ctx, is_stereo_mode=False, T_left2right=None):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.is_stereo_mode_ = bool(is_stereo_mode)
+        self.T_left2right_ = np.eye(4, dtype=np.float32) if T_left2right is None else _f32(T_left2right)
+
+    def poseOnlyBundleAdjustment(self, X, pts1, K, thres_reproj_outlier, R01, t01, variant=GN_CORE):
+        X, pts1 = _f32(X).reshape(-1, 3), _f32(pts1).reshape(-1, 2)
+        if X.shape[0] != pts1.shape[0]:  # motion_estimator.cpp:669-670
+            raise VoError(-4, "In 'poseOnlyBundleAdjustment()': X.size() != pts1.size().")
+        n = X.shape[0]
+        K = _f32(K)
+        R = _f32(R01).reshape(9).copy()
+        t = _f32(t01).reshape(3).copy()
+        mask = np.zeros(max(n, 1), np.uint8)
+        info = GnInfo()
+        rc = self.ctx.check(self.lib.vo_gn_pose_mono(
+            self.ctx.handle, _p(X), _p(pts1), n, _p(K), int(thres_reproj_outlier), _p(R), _p(t),
+            _p(mask, C.c_uint8), variant, C.byref(info)))
+        return bool(rc), R.reshape(3, 3), t, mask[:n].astype(bool), info
+
+    def poseOnlyBundleAdjustment_Stereo(self, X, pts_l1, pts_r1, Kl, Kr, T_lr, thres_reproj_outlier, T01):
+        if not self.is_stereo_mode_:  # motion_estimator.cpp:866-867
+            raise VoError(-1, "In 'poseOnlyBundleAdjustment_Stereo()', is_stereo_mode_ == false")
+        X = _f32(X).reshape(-1, 3)
+        pts_l1, pts_r1 = _f32(pts_l1).reshape(-1, 2), _f32(pts_r1).reshape(-1, 2)
+        if X.shape[0] != pts_l1.shape[0] or X.shape[0] != pts_r1.shape[0]:  # :872-873
+            raise VoError(-4, "In 'poseOnlyStereoBundleAdjustment()': size mismatch")
+        n = X.shape[0]
+        Kl, Kr, T_lr = _f32(Kl), _f32(Kr), _f32(T_lr).reshape(16)
+        T = _f32(T01).reshape(16).copy()
+        mask = np.zeros(max(n, 1), np.uint8)
+        info = GnInfo()
+        rc = self.ctx.check(self.lib.vo_gn_pose_stereo(
+            self.ctx.handle, _p(X), _p(pts_l1), _p(pts_r1), n, _p(Kl), _p(Kr), _p(T_lr),
+            C.c_float(thres_reproj_outlier), _p(T), _p(mask, C.c_uint8), C.byref(info)))
+        return bool(rc), T.reshape(4, 4), mask[:n].astype(bool), info
+
+
+class FeatureExtractor:
+    """descriptorDistance (feature_extractor.cpp:338-357) for whole descriptor sets."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.lib = ctx.lib
+
+    def descriptorDistance(self, a, b):
+        a, b = _u8(a).reshape(-1, 32), _u8(b).reshape(-1, 32)
+        out = np.zeros((a.shape[0], b.shape[0]), np.uint16)
+        if a.shape[0] and b.shape[0]:
+            self.ctx.check(self.lib.vo_orb_hamming(self.ctx.handle, _p(a, C.c_uint8), a.shape[0],
+                                                   _p(b, C.c_uint8), b.shape[0], _p(out, C.c_uint16)))
+        return out
+
+    def match(self, a, b, th_low=50, ratio=0.6):
+        a, b = _u8(a).reshape(-1, 32), _u8(b).reshape(-1, 32)
+        na = a.shape[0]
+        bi = np.zeros(max(na, 1), np.int32)
+        bd = np.zeros(max(na, 1), np.uint16)
+        sd = np.zeros(max(na, 1), np.uint16)
+        self.ctx.check(self.lib.vo_orb_match(self.ctx.handle, _p(a, C.c_uint8), na, _p(b, C.c_uint8),
+                                             b.shape[0], th_low, C.c_float(ratio), _p(bi, C.c_int32),
+                                             _p(bd, C.c_uint16), _p(sd, C.c_uint16)))
+        return bi[:na], bd[:na], sd[:na]
+
+
+def compact_indices(ctx, mask, alive=None, tracked=None):
+    """Stable compaction of mask && alive && tracked (landmark.cpp:291-332)."""
+    mask = _u8(mask)
+    n = mask.shape[0]
+    idx = np.zeros(max(n, 1), np.int32)
+    cnt = C.c_int()
+    al = _u8(alive) if alive is not None else None
+    tk = _u8(tracked) if tracked is not None else None
+    ctx.check(ctx.lib.vo_compact_indices(
+        ctx.handle, _p(mask, C.c_uint8), _p(al, C.c_uint8) if al is not None else None,
+        _p(tk, C.c_uint8) if tk is not None else None, n, _p(idx, C.c_int32), C.byref(cnt)))
+    return idx[: cnt.value].copy()
+
+
+def make_stereo_params(width, height, win, max_level, thres_err, thres_bidir, thres_poseba, Kl, Kr,
+                       T_lr):
+    p = StereoParams()
+    p.width, p.height, p.win, p.max_level = width, height, win, max_level
+    p.thres_err, p.thres_bidirection, p.thres_poseba = thres_err, thres_bidir, thres_poseba
+    T = _f32(T_lr).reshape(16)
+    for i in range(4):
+        p.Kl[i] = float(Kl[i])
+        p.Kr[i] = float(Kr[i])
+    for i in range(16):
+        p.T_lr[i] = float(T[i])
+    return p
+
+
+class StereoFramePipeline:
+    """The steady-state stereo frame (stereo_vo.cpp:483-711 operator sequence)
+    chained on the device. Slots: 0 = previous left, 1 = current left,
+    2 = current right; advance() rotates current-left into previous-left."""
+
+    def __init__(self, ctx, params):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.prm = params
+
+    def enqueue(self, pts_l0, pts_r0, Xp, dT_prior, pts_new, slots=(0, 1, 2)):
+        pts_l0, pts_r0 = _f32(pts_l0).reshape(-1, 2), _f32(pts_r0).reshape(-1, 2)
+        Xp = _f32(Xp).reshape(-1, 3)
+        dT = _f32(dT_prior).reshape(16)
+        pts_new = _f32(pts_new).reshape(-1, 2)
+        self._n, self._nn = pts_l0.shape[0], pts_new.shape[0]
+        self.ctx.check(self.lib.vo_stereo_frame_enqueue(
+            self.ctx.handle, C.byref(self.prm), slots[0], slots[1], slots[2], _p(pts_l0), _p(pts_r0),
+            _p(Xp), self._n, _p(dT), _p(pts_new), self._nn, 0))
+
+    def enqueue_device(self, d_pts_l0, d_pts_r0, d_Xp, n, dT_prior, d_pts_new, n_new, slots=(0, 1, 2)):
+        dT = _f32(dT_prior).reshape(16)
+        self._n, self._nn = n, n_new
+        f = C.POINTER(C.c_float)
+        self.ctx.check(self.lib.vo_stereo_frame_enqueue(
+            self.ctx.handle, C.byref(self.prm), slots[0], slots[1], slots[2],
+            C.cast(C.c_void_p(d_pts_l0), f), C.cast(C.c_void_p(d_pts_r0), f),
+            C.cast(C.c_void_p(d_Xp), f), n, _p(dT), C.cast(C.c_void_p(d_pts_new), f), n_new, 1))
+
+    def result(self):
+        n, nn = self._n, self._nn
+        pts_l1 = np.zeros((max(n, 1), 2), np.float32)
+        pts_r1 = np.zeros((max(n, 1), 2), np.float32)
+        stage = np.zeros(max(n, 1), np.uint8)
+        dT = np.zeros(16, np.float32)
+        pnr = np.zeros((max(nn, 1), 2), np.float32)
+        mnew = np.zeros(max(nn, 1), np.uint8)
+        counts, gn = FrameCounts(), GnInfo()
+        self.ctx.check(self.lib.vo_stereo_frame_result(
+            self.ctx.handle, _p(pts_l1), _p(pts_r1), _p(stage, C.c_uint8), _p(dT), _p(pnr),
+            _p(mnew, C.c_uint8), C.byref(counts), C.byref(gn)))
+        return dict(pts_l1=pts_l1[:n], pts_r1=pts_r1[:n], stage=stage[:n], dT=dT.reshape(4, 4),
+                    pts_new_r=pnr[:nn], mask_new=mnew[:nn].astype(bool), counts=counts, gn=gn)

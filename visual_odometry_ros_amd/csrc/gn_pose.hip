@@ -1,0 +1,547 @@
+// gn_pose.hip — pose-only Gauss-Newton motion estimator on one gfx950 workgroup.
+//
+// Replaces MotionEstimator::poseOnlyBundleAdjustment      (core/visual_odometry/motion_estimator.cpp:665-861)
+//      and MotionEstimator::poseOnlyBundleAdjustment_Stereo (core/visual_odometry/motion_estimator.cpp:863-1088)
+// including calcJtJ_x/_y, calcJtWJ_x/_y (:1342-1576), geometry::se3Exp_f and
+// inverseSE3_f (core/util/geometry_library.cpp:386-440, :554-560) and the 6x6
+// Eigen LDLT solve (:823, :1054).
+//
+// Shape of the work: N (~1500) points x 4 residuals, Jacobian rows generated on
+// the fly and contracted into 21 + 6 + 2 scalars. That is a reduction, not a
+// GEMM (a 6x6 output would waste >85 % of any MFMA tile), so the kernel is a
+// wavefront reduction: one persistent workgroup of GN_T threads runs ALL
+// iterations without returning to the host:
+//   thread t   : serial partial over points t, t+GN_T, ...      (29 registers)
+//   wavefront  : DPP butterfly (quad_perm, row_half_mirror, row_mirror, readlane)
+//   workgroup  : GN_T/64 wave totals through LDS, balanced tree
+//   lane 0     : damped 6x6 LDLT (symmetric pivoting), se3 exp, update, stop test
+// The summation tree is the balanced binary tree over the GN_T thread partials
+// in natural order — the oracle's VO_SUM_TREE with tree_width = GN_T.
+#include "vo_internal.hpp"
+
+#define GN_T 512
+#define GN_NW (GN_T / 64)
+#define GN_NACC 29  // 21 H + 6 g + err + cnt
+
+struct GnArgs {
+  const float *X;      // n x 3
+  const float *p1;     // n x 2 (left / mono pixels)
+  const float *p2;     // n x 2 (right pixels, stereo only)
+  int n;
+  const int *d_n;      // optional device-side count (frame pipeline)
+  float Kl[4], Kr[4];
+  float Rrl[9], trl[3];
+  float thres;
+  int variant;
+  float T10[16];       // initial T10 (row-major)
+  const float *d_T10;  // optional device-side initial T10 (overrides T10)
+  float *T_out;        // 16 floats: T01 on success; untouched if NaN
+  uint8_t *mask;
+  vo_gn_dev_info *info;
+};
+
+// upper-triangular index of (i,j), i<=j, row-major: matches oracle UT[][]
+__device__ __forceinline__ constexpr int ut(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
+
+struct GnAcc {
+  float H[21];
+  float g[6];
+  float err;
+  float cnt;
+};
+
+// x rows: Jt(1) == 0 (calcJtWJ_x / calcJtJ_x)
+template <bool W>
+__device__ __forceinline__ void acc_row_x(GnAcc &A, float w, const float (&Jt)[6]) {
+  const int idx[5] = {0, 2, 3, 4, 5};
+#pragma unroll
+  for (int a = 0; a < 5; ++a) {
+    const float l = W ? w * Jt[idx[a]] : Jt[idx[a]];
+#pragma unroll
+    for (int b = a; b < 5; ++b) A.H[ut(idx[a], idx[b])] += l * Jt[idx[b]];
+  }
+}
+// y rows: Jt(0) == 0 (calcJtWJ_y / calcJtJ_y)
+template <bool W>
+__device__ __forceinline__ void acc_row_y(GnAcc &A, float w, const float (&Jt)[6]) {
+#pragma unroll
+  for (int a = 1; a < 6; ++a) {
+    const float l = W ? w * Jt[a] : Jt[a];
+#pragma unroll
+    for (int b = a; b < 6; ++b) A.H[ut(a, b)] += l * Jt[b];
+  }
+}
+__device__ __forceinline__ void acc_g_x(GnAcc &A, float s, const float (&Jt)[6]) {
+  A.g[0] -= s * Jt[0];
+  A.g[2] -= s * Jt[2];
+  A.g[3] -= s * Jt[3];
+  A.g[4] -= s * Jt[4];
+  A.g[5] -= s * Jt[5];
+}
+__device__ __forceinline__ void acc_g_y(GnAcc &A, float s, const float (&Jt)[6]) {
+  A.g[1] -= s * Jt[1];
+  A.g[2] -= s * Jt[2];
+  A.g[3] -= s * Jt[3];
+  A.g[4] -= s * Jt[4];
+  A.g[5] -= s * Jt[5];
+}
+
+__device__ __forceinline__ void jac_x(float (&Jt)[6], float f, float iz, float fxxiz, float xiz, float yiz) {
+  Jt[0] = f * iz;
+  Jt[1] = 0.0f;
+  Jt[2] = -fxxiz * iz;
+  Jt[3] = -fxxiz * yiz;
+  Jt[4] = f * (1.0f + xiz * xiz);
+  Jt[5] = -f * yiz;
+}
+__device__ __forceinline__ void jac_y(float (&Jt)[6], float f, float iz, float fyyiz, float xiz, float yiz) {
+  Jt[0] = 0.0f;
+  Jt[1] = f * iz;
+  Jt[2] = -fyyiz * iz;
+  Jt[3] = -f * (1.0f + yiz * yiz);
+  Jt[4] = fyyiz * xiz;
+  Jt[5] = f * xiz;
+}
+
+// ---- lane-0 small dense algebra (same operation order as the oracle) ---------
+__device__ void ldlt6_solve(const float (&Ain)[36], const float (&b)[6], float (&x)[6]) {
+  float m[6][6];
+  int tr[6];
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) m[i][j] = Ain[i * 6 + j];
+  float temp[6];
+  for (int k = 0; k < 6; ++k) {
+    int piv = k;
+    float best = fabsf(m[k][k]);
+    for (int i = k + 1; i < 6; ++i) {
+      float a = fabsf(m[i][i]);
+      if (a > best) {
+        best = a;
+        piv = i;
+      }
+    }
+    tr[k] = piv;
+    if (piv != k) {
+      for (int j = 0; j < k; ++j) {
+        float t = m[k][j];
+        m[k][j] = m[piv][j];
+        m[piv][j] = t;
+      }
+      for (int i = piv + 1; i < 6; ++i) {
+        float t = m[i][k];
+        m[i][k] = m[i][piv];
+        m[i][piv] = t;
+      }
+      {
+        float t = m[k][k];
+        m[k][k] = m[piv][piv];
+        m[piv][piv] = t;
+      }
+      for (int i = k + 1; i < piv; ++i) {
+        float t = m[i][k];
+        m[i][k] = m[piv][i];
+        m[piv][i] = t;
+      }
+    }
+    int rs = 6 - k - 1;
+    if (k > 0) {
+      for (int j = 0; j < k; ++j) temp[j] = m[j][j] * m[k][j];
+      float s = 0.0f;
+      for (int j = 0; j < k; ++j) s += m[k][j] * temp[j];
+      m[k][k] -= s;
+      for (int i = 0; i < rs; ++i) {
+        float d = 0.0f;
+        for (int j = 0; j < k; ++j) d += m[k + 1 + i][j] * temp[j];
+        m[k + 1 + i][k] -= d;
+      }
+    }
+    float akk = m[k][k];
+    if (fabsf(akk) > 0.0f)
+      for (int i = 0; i < rs; ++i) m[k + 1 + i][k] /= akk;
+  }
+  float y[6];
+  for (int i = 0; i < 6; ++i) y[i] = b[i];
+  for (int k = 0; k < 6; ++k)
+    if (tr[k] != k) {
+      float t = y[k];
+      y[k] = y[tr[k]];
+      y[tr[k]] = t;
+    }
+  for (int i = 0; i < 6; ++i) {
+    float s = y[i];
+    for (int j = 0; j < i; ++j) s -= m[i][j] * y[j];
+    y[i] = s;
+  }
+  const float tol = 1.17549435e-38f;
+  for (int i = 0; i < 6; ++i) {
+    if (fabsf(m[i][i]) > tol)
+      y[i] /= m[i][i];
+    else
+      y[i] = 0.0f;
+  }
+  for (int i = 5; i >= 0; --i) {
+    float s = y[i];
+    for (int j = i + 1; j < 6; ++j) s -= m[j][i] * y[j];
+    y[i] = s;
+  }
+  for (int k = 5; k >= 0; --k)
+    if (tr[k] != k) {
+      float t = y[k];
+      y[k] = y[tr[k]];
+      y[tr[k]] = t;
+    }
+  for (int i = 0; i < 6; ++i) x[i] = y[i];
+}
+
+__device__ void se3_exp_dev(const float (&xi)[6], float (&T)[16]) {
+  float v[3] = {xi[0], xi[1], xi[2]};
+  float w[3] = {xi[3], xi[4], xi[5]};
+  float theta = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  float wx[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+  float wx2[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      float s = 0.0f;
+      for (int k = 0; k < 3; ++k) s += wx[i * 3 + k] * wx[k * 3 + j];
+      wx2[i * 3 + j] = s;
+    }
+  float a, b, bV, c;
+  if ((double)theta < 1e-7) {
+    a = 1.0f;
+    b = 0.5f;
+    bV = 0.5f;
+    c = 0.33333333333333333333333333f;
+  } else {
+    double th = (double)theta;
+    a = (float)(sin(th) / th);
+    b = (float)((1 - cos(th)) / (double)(theta * theta));
+    bV = b;
+    c = (float)((th - sin(th)) / (double)(theta * theta * theta));
+  }
+  float R[9], V[9];
+  for (int i = 0; i < 9; ++i) {
+    float I = (i == 0 || i == 4 || i == 8) ? 1.0f : 0.0f;
+    R[i] = (I + a * wx[i]) + b * wx2[i];
+    V[i] = (I + bV * wx[i]) + c * wx2[i];
+  }
+  float t[3];
+  for (int i = 0; i < 3; ++i) t[i] = (V[i * 3 + 0] * v[0] + V[i * 3 + 1] * v[1]) + V[i * 3 + 2] * v[2];
+  for (int i = 0; i < 16; ++i) T[i] = 0.0f;
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) T[i * 4 + j] = R[i * 3 + j];
+    T[i * 4 + 3] = t[i];
+  }
+  T[15] = 1.0f;
+}
+
+template <bool STEREO>
+__global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
+  __shared__ float s_T10[16];
+  __shared__ float s_part[GN_NW][32];
+  __shared__ float s_tot[32];
+  __shared__ int s_stop;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int n = a.d_n ? *a.d_n : a.n;
+  if (tid < 16) s_T10[tid] = a.d_T10 ? a.d_T10[tid] : a.T10[tid];
+  if (tid == 0) s_stop = 0;
+
+  const float THRES_HUBER = 0.5f;
+  const float fx_l = a.Kl[0], fy_l = a.Kl[1], cx_l = a.Kl[2], cy_l = a.Kl[3];
+  const float fx_r = a.Kr[0], fy_r = a.Kr[1], cx_r = a.Kr[2], cy_r = a.Kr[3];
+  const float thres = a.thres;
+
+  float err_prev = 1e10f;  // only lane 0 of wave 0 uses it
+  int iter = 0;
+  float last_err = 0, last_derr = 0, last_dnorm = 0;
+  int last_cnt = 0;
+
+  for (iter = 0; iter < 100; ++iter) {
+    __syncthreads();
+    float R10[9], t10[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) R10[i * 3 + j] = s_T10[i * 4 + j];
+      t10[i] = s_T10[i * 4 + 3];
+    }
+    GnAcc A;
+#pragma unroll
+    for (int k = 0; k < 21; ++k) A.H[k] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) A.g[k] = 0.0f;
+    A.err = 0.0f;
+    A.cnt = 0.0f;
+
+    for (int i = tid; i < n; i += GN_T) {
+      const float X0 = a.X[3 * i], X1 = a.X[3 * i + 1], X2 = a.X[3 * i + 2];
+      float Xl[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) Xl[r] = ((R10[r * 3 + 0] * X0 + R10[r * 3 + 1] * X1) + R10[r * 3 + 2] * X2) + t10[r];
+      const float plx = a.p1[2 * i], ply = a.p1[2 * i + 1];
+      float Jt[6];
+      if (STEREO) {
+        float Xr[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+          Xr[r] = ((a.Rrl[r * 3 + 0] * Xl[0] + a.Rrl[r * 3 + 1] * Xl[1]) + a.Rrl[r * 3 + 2] * Xl[2]) + a.trl[r];
+        const float prx = a.p2[2 * i], pry = a.p2[2 * i + 1];
+        const float iz_l = 1.0f / Xl[2];
+        const float xiz_l = Xl[0] * iz_l, yiz_l = Xl[1] * iz_l;
+        const float fxxiz_l = fx_l * xiz_l, fyyiz_l = fy_l * yiz_l;
+        const float rx_l = (fxxiz_l + cx_l) - plx, ry_l = (fyyiz_l + cy_l) - ply;
+        const float iz_r = 1.0f / Xr[2];
+        const float xiz_r = Xr[0] * iz_r, yiz_r = Xr[1] * iz_r;
+        const float fxxiz_r = fx_r * xiz_r, fyyiz_r = fy_r * yiz_r;
+        const float rx_r = (fxxiz_r + cx_r) - prx, ry_r = (fyyiz_r + cy_r) - pry;
+        float weight = 1.0f;
+        float absrxry = ((fabsf(rx_l) + fabsf(ry_l)) + fabsf(rx_r)) + fabsf(ry_r);
+        absrxry *= 0.5f;
+        if (absrxry >= THRES_HUBER) weight = THRES_HUBER / absrxry;
+        const bool outl = absrxry >= thres;
+        a.mask[i] = outl ? 0 : 1;
+        if (outl) A.cnt += 1.0f;
+        jac_x(Jt, fx_l, iz_l, fxxiz_l, xiz_l, yiz_l);
+        acc_row_x<true>(A, weight, Jt);
+        acc_g_x(A, weight * rx_l, Jt);
+        A.err += rx_l * rx_l;
+        jac_y(Jt, fy_l, iz_l, fyyiz_l, xiz_l, yiz_l);
+        acc_row_y<true>(A, weight, Jt);
+        acc_g_y(A, weight * ry_l, Jt);
+        A.err += ry_l * ry_l;
+        jac_x(Jt, fx_r, iz_r, fxxiz_r, xiz_r, yiz_r);
+        acc_row_x<true>(A, weight, Jt);
+        acc_g_x(A, weight * rx_r, Jt);
+        A.err += rx_r * rx_r;
+        jac_y(Jt, fy_r, iz_r, fyyiz_r, xiz_r, yiz_r);
+        acc_row_y<true>(A, weight, Jt);
+        acc_g_y(A, weight * ry_r, Jt);
+        A.err += ry_r * ry_r;
+      } else {
+        const float iz = 1.0f / Xl[2];
+        const float xiz = Xl[0] * iz, yiz = Xl[1] * iz;
+        const float fxxiz = fx_l * xiz, fyyiz = fy_l * yiz;
+        const float rx = (fxxiz + cx_l) - plx, ry = (fyyiz + cy_l) - ply;
+        float weight = 1.0f;
+        bool flag_weight = false;
+        const float absrxry = fabsf(rx) + fabsf(ry);
+        if (absrxry >= THRES_HUBER) {
+          weight = THRES_HUBER / absrxry;
+          flag_weight = true;
+        }
+        const bool outl = absrxry >= thres;
+        a.mask[i] = outl ? 0 : 1;
+        if (outl) A.cnt += 1.0f;
+        jac_x(Jt, fx_l, iz, fxxiz, xiz, yiz);
+        if (flag_weight) {
+          acc_row_x<true>(A, weight, Jt);
+          acc_g_x(A, weight * rx, Jt);
+        } else {
+          acc_row_x<false>(A, 1.0f, Jt);
+          acc_g_x(A, rx, Jt);
+        }
+        A.err += rx * rx;
+        jac_y(Jt, fy_l, iz, fyyiz, xiz, yiz);
+        if (flag_weight) {
+          const float w_ry = weight * ry;
+          acc_row_y<true>(A, weight, Jt);
+          acc_g_y(A, w_ry, Jt);
+          if (a.variant == VO_GN_VARIANT_CORE)
+            A.err += w_ry * ry;
+          else
+            A.err += ry * ry;
+        } else {
+          acc_row_y<false>(A, 1.0f, Jt);
+          acc_g_y(A, ry, Jt);
+          A.err += ry * ry;
+        }
+      }
+    }
+
+    // wavefront butterfly, then one LDS row per wave
+#pragma unroll
+    for (int k = 0; k < 21; ++k) {
+      float s = wave_sum_f32(A.H[k]);
+      if (lane == 0) s_part[wave][k] = s;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      float s = wave_sum_f32(A.g[k]);
+      if (lane == 0) s_part[wave][21 + k] = s;
+    }
+    {
+      float s = wave_sum_f32(A.err);
+      if (lane == 0) s_part[wave][27] = s;
+      s = wave_sum_f32(A.cnt);
+      if (lane == 0) s_part[wave][28] = s;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      if (lane < GN_NACC) {
+        float p[GN_NW];
+#pragma unroll
+        for (int w = 0; w < GN_NW; ++w) p[w] = s_part[w][lane];
+#pragma unroll
+        for (int st = 1; st < GN_NW; st <<= 1)
+#pragma unroll
+          for (int w = 0; w < GN_NW; w += 2 * st) p[w] = p[w] + p[w + st];
+        s_tot[lane] = p[0];
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float JtWJ[36], g[6], dxi[6];
+      for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) JtWJ[i * 6 + j] = s_tot[i <= j ? ut(i, j) : ut(j, i)];
+      for (int k = 0; k < 6; ++k) g[k] = s_tot[21 + k];
+      float err_curr = s_tot[27];
+      const float inv_npts = 1.0f / (float)n;
+      err_curr *= (inv_npts * 0.5f);
+      if (STEREO) err_curr = sqrtf(err_curr);
+      const float delta_err = fabsf(err_curr - err_prev);
+      const float lambda = 0.00001f;
+      for (int k = 0; k < 6; ++k) JtWJ[k * 6 + k] *= (1.0f + lambda);
+      ldlt6_solve(JtWJ, g, dxi);
+      float dT[16], Tn[16];
+      se3_exp_dev(dxi, dT);
+      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+          float s = dT[i * 4 + 0] * s_T10[0 * 4 + j];
+          s += dT[i * 4 + 1] * s_T10[1 * 4 + j];
+          s += dT[i * 4 + 2] * s_T10[2 * 4 + j];
+          s += dT[i * 4 + 3] * s_T10[3 * 4 + j];
+          Tn[i * 4 + j] = s;
+        }
+      for (int i = 0; i < 16; ++i) s_T10[i] = Tn[i];
+      err_prev = err_curr;
+      float s2 = 0.0f;
+      for (int k = 0; k < 6; ++k) s2 += dxi[k] * dxi[k];
+      const float dnorm = sqrtf(s2);
+      last_err = err_curr;
+      last_derr = delta_err;
+      last_dnorm = dnorm;
+      last_cnt = (int)s_tot[28];
+      if (dnorm < (float)1e-6 || delta_err < (float)1e-7) s_stop = 1;
+    }
+    __syncthreads();
+    if (s_stop) {
+      ++iter;
+      break;
+    }
+  }
+  if (tid == 0) {
+    float s = 0.0f;
+    for (int i = 0; i < 16; ++i) s += s_T10[i] * s_T10[i];
+    const float nrm = sqrtf(s);
+    const int is_nan = isnan(nrm) ? 1 : 0;
+    if (!is_nan) {
+      // inverseSE3_f
+      float Rt[9];
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Rt[i * 3 + j] = s_T10[j * 4 + i];
+      const float t0 = s_T10[3], t1 = s_T10[7], t2 = s_T10[11];
+      for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) a.T_out[i * 4 + j] = Rt[i * 3 + j];
+        a.T_out[i * 4 + 3] = ((-Rt[i * 3 + 0]) * t0 + (-Rt[i * 3 + 1]) * t1) + (-Rt[i * 3 + 2]) * t2;
+      }
+      a.T_out[12] = 0;
+      a.T_out[13] = 0;
+      a.T_out[14] = 0;
+      a.T_out[15] = 1;
+    }
+    if (a.info) {
+      a.info->iterations = iter;
+      a.info->err = last_err;
+      a.info->delta_err = last_derr;
+      a.info->delta_norm = last_dnorm;
+      a.info->cnt_invalid = last_cnt;
+      a.info->is_nan = is_nan;
+    }
+  }
+}
+
+// ---- host side ---------------------------------------------------------------
+static void inverse_se3_host(const float T[16], float Ti[16]) {
+  float Rt[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Rt[i * 3 + j] = T[j * 4 + i];
+  const float t[3] = {T[3], T[7], T[11]};
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) Ti[i * 4 + j] = Rt[i * 3 + j];
+    Ti[i * 4 + 3] = ((-Rt[i * 3 + 0]) * t[0] + (-Rt[i * 3 + 1]) * t[1]) + (-Rt[i * 3 + 2]) * t[2];
+  }
+  Ti[12] = Ti[13] = Ti[14] = 0;
+  Ti[15] = 1;
+}
+
+// general 4x4 inverse by cofactors (Matrix4f::inverse() at motion_estimator.cpp:700)
+static void inverse4x4_host(const float m[16], float inv[16]) {
+  float s0 = m[0] * m[5] - m[4] * m[1], s1 = m[0] * m[6] - m[4] * m[2], s2 = m[0] * m[7] - m[4] * m[3];
+  float s3 = m[1] * m[6] - m[5] * m[2], s4 = m[1] * m[7] - m[5] * m[3], s5 = m[2] * m[7] - m[6] * m[3];
+  float c5 = m[10] * m[15] - m[14] * m[11], c4 = m[9] * m[15] - m[13] * m[11], c3 = m[9] * m[14] - m[13] * m[10];
+  float c2 = m[8] * m[15] - m[12] * m[11], c1 = m[8] * m[14] - m[12] * m[10], c0 = m[8] * m[13] - m[12] * m[9];
+  float det = ((s0 * c5 - s1 * c4) + s2 * c3 + s3 * c2 - s4 * c1) + s5 * c0;
+  float id = 1.0f / det;
+  inv[0] = ((m[5] * c5 - m[6] * c4) + m[7] * c3) * id;
+  inv[1] = ((-m[1] * c5 + m[2] * c4) - m[3] * c3) * id;
+  inv[2] = ((m[13] * s5 - m[14] * s4) + m[15] * s3) * id;
+  inv[3] = ((-m[9] * s5 + m[10] * s4) - m[11] * s3) * id;
+  inv[4] = ((-m[4] * c5 + m[6] * c2) - m[7] * c1) * id;
+  inv[5] = ((m[0] * c5 - m[2] * c2) + m[3] * c1) * id;
+  inv[6] = ((-m[12] * s5 + m[14] * s2) - m[15] * s1) * id;
+  inv[7] = ((m[8] * s5 - m[10] * s2) + m[11] * s1) * id;
+  inv[8] = ((m[4] * c4 - m[5] * c2) + m[7] * c0) * id;
+  inv[9] = ((-m[0] * c4 + m[1] * c2) - m[3] * c0) * id;
+  inv[10] = ((m[12] * s4 - m[13] * s2) + m[15] * s0) * id;
+  inv[11] = ((-m[8] * s4 + m[9] * s2) - m[11] * s0) * id;
+  inv[12] = ((-m[4] * c3 + m[5] * c1) - m[6] * c0) * id;
+  inv[13] = ((m[0] * c3 - m[1] * c1) + m[2] * c0) * id;
+  inv[14] = ((-m[12] * s3 + m[13] * s1) - m[14] * s0) * id;
+  inv[15] = ((m[8] * s3 - m[9] * s1) + m[10] * s0) * id;
+}
+
+// Enqueue a GN solve on device-resident inputs. T01_init is the reference's
+// in/out pose; the kernel writes T01 to d_Tout unless the pose went NaN.
+int vo_gn_enqueue(vo_ctx *c, bool stereo, bool mono_general_inverse, const float *dX, const float *dP1,
+                  const float *dP2, int n, const int *d_n, const float Kl[4], const float Kr[4],
+                  const float T_lr[16], float thres, int variant, const float T01_init[16],
+                  float *d_Tout, uint8_t *d_mask, vo_gn_dev_info *d_info) {
+  GnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.X = dX;
+  a.p1 = dP1;
+  a.p2 = dP2;
+  a.n = n;
+  a.d_n = d_n;
+  for (int i = 0; i < 4; ++i) {
+    a.Kl[i] = Kl[i];
+    a.Kr[i] = Kr ? Kr[i] : Kl[i];
+  }
+  if (stereo) {
+    float Trl[16];
+    inverse_se3_host(T_lr, Trl);  // motion_estimator.cpp:869
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) a.Rrl[i * 3 + j] = Trl[i * 4 + j];
+      a.trl[i] = Trl[i * 4 + 3];
+    }
+  }
+  a.thres = thres;
+  a.variant = variant;
+  if (mono_general_inverse)
+    inverse4x4_host(T01_init, a.T10);  // :700
+  else
+    inverse_se3_host(T01_init, a.T10);  // :904
+  a.d_T10 = nullptr;
+  a.T_out = d_Tout;
+  a.mask = d_mask;
+  a.info = d_info;
+  vo_prof_begin(c, VO_K_GN);
+  if (stereo)
+    hipLaunchKernelGGL(gn_pose_kernel<true>, dim3(1), dim3(GN_T), 0, c->stream, a);
+  else
+    hipLaunchKernelGGL(gn_pose_kernel<false>, dim3(1), dim3(GN_T), 0, c->stream, a);
+  vo_prof_end(c);
+  VO_CHECK_HIP(c, hipGetLastError());
+  return VO_OK;
+}

@@ -1,0 +1,252 @@
+// vo_capi.hip — extern "C" surface of libvo_hip.so (declared in include/vo_hip.h):
+// context / buffers, host<->device staging, and the per-operator entry points.
+// No CPU fallback anywhere: without a usable gfx950 device every compute entry
+// point returns VO_ERR_NO_DEVICE.
+#include "vo_internal.hpp"
+#include "vo_kernels.hpp"
+
+#include <stdlib.h>
+
+static thread_local char g_err[256] = "";
+
+extern "C" int vo_abi_version(void) { return VO_HIP_ABI_VERSION; }
+
+extern "C" int vo_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" const char *vo_last_error(const vo_ctx *ctx) { return ctx ? ctx->err : g_err; }
+
+extern "C" void *vo_stream(vo_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+extern "C" int vo_synchronize(vo_ctx *ctx) {
+  if (!ctx) return VO_ERR_INVALID;
+  VO_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VO_OK;
+}
+
+template <typename T>
+static hipError_t dalloc(T **p, size_t n) {
+  return hipMalloc((void **)p, n * sizeof(T));
+}
+
+static size_t pyramid_bytes(int w, int h, int max_level, vo_pyramid *P) {
+  size_t off = 0;
+  for (int l = 0; l <= max_level && l < VO_MAX_LEVELS; ++l) {
+    int stride = ((w + 2 * VO_PAD) + 63) & ~63;
+    if (P) {
+      P->lv[l].w = w;
+      P->lv[l].h = h;
+      P->lv[l].stride = stride;
+      P->lv[l].base = (uint8_t *)off;  // offset for now
+    }
+    off += (size_t)stride * (size_t)(h + 2 * VO_PAD);
+    off = (off + 255) & ~(size_t)255;
+    w = (w + 1) / 2;
+    h = (h + 1) / 2;
+  }
+  return off;
+}
+
+extern "C" int vo_create(const vo_config *cfg, vo_ctx **out) {
+  if (!cfg || !out) return VO_ERR_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    snprintf(g_err, sizeof(g_err), "no HIP device visible (libvo_hip has no CPU fallback)");
+    return VO_ERR_NO_DEVICE;
+  }
+  if (cfg->device < 0 || cfg->device >= ndev || cfg->max_points <= 0 || cfg->n_slots <= 0 ||
+      cfg->max_width <= 0 || cfg->max_height <= 0 || cfg->max_level < 0 ||
+      cfg->max_level >= VO_MAX_LEVELS) {
+    snprintf(g_err, sizeof(g_err), "vo_create: invalid config");
+    return VO_ERR_INVALID;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return VO_ERR_HIP;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    snprintf(g_err, sizeof(g_err), "device %d is %s; libvo_hip is built for gfx950 only", cfg->device,
+             prop.gcnArchName);
+    return VO_ERR_NO_DEVICE;
+  }
+  vo_ctx *c = (vo_ctx *)calloc(1, sizeof(vo_ctx));
+  c->cfg = *cfg;
+  c->device = cfg->device;
+  *out = c;  // so that the caller can read the error and destroy
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  VO_CHECK_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  const size_t N = (size_t)cfg->max_points;
+  c->slots = (vo_pyramid *)calloc((size_t)cfg->n_slots, sizeof(vo_pyramid));
+  for (int s = 0; s < cfg->n_slots; ++s) {
+    vo_pyramid *P = &c->slots[s];
+    P->bytes = pyramid_bytes(cfg->max_width, cfg->max_height, cfg->max_level, nullptr);
+    VO_CHECK_HIP(c, hipMalloc((void **)&P->mem, P->bytes));
+    P->n_levels = 0;
+  }
+  VO_CHECK_HIP(c, dalloc(&c->d_pts0, 2 * N));
+  VO_CHECK_HIP(c, dalloc(&c->d_pts1, 2 * N));
+  VO_CHECK_HIP(c, dalloc(&c->d_pts2, 2 * N));
+  VO_CHECK_HIP(c, dalloc(&c->d_pts3, 2 * N));
+  VO_CHECK_HIP(c, dalloc(&c->d_err, N));
+  VO_CHECK_HIP(c, dalloc(&c->d_err2, N));
+  VO_CHECK_HIP(c, dalloc(&c->d_scale, N));
+  VO_CHECK_HIP(c, dalloc(&c->d_X, 3 * N));
+  VO_CHECK_HIP(c, dalloc(&c->d_status, N));
+  VO_CHECK_HIP(c, dalloc(&c->d_status2, N));
+  VO_CHECK_HIP(c, dalloc(&c->d_mask, N));
+  VO_CHECK_HIP(c, dalloc(&c->d_mask2, N));
+  VO_CHECK_HIP(c, dalloc(&c->d_idx, N));
+  VO_CHECK_HIP(c, dalloc(&c->d_count, 16));
+  VO_CHECK_HIP(c, dalloc(&c->d_mat, 256));
+  VO_CHECK_HIP(c, dalloc(&c->d_gninfo, 4));
+  VO_CHECK_HIP(c, dalloc(&c->d_flags, 16));
+  VO_CHECK_HIP(c, hipMemsetAsync(c->d_flags, 0, 16 * sizeof(int), c->stream));
+  c->h_stage_bytes = (size_t)cfg->max_width * cfg->max_height + 64 * N + 4096;
+  VO_CHECK_HIP(c, hipHostMalloc((void **)&c->h_stage, c->h_stage_bytes, hipHostMallocDefault));
+  VO_CHECK_HIP(c, hipMalloc((void **)&c->d_img_stage, (size_t)cfg->max_width * cfg->max_height));
+  VO_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+  return VO_OK;
+}
+
+extern "C" void vo_destroy(vo_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  vo_frame_free(c);
+  if (c->prof) {
+    for (int i = 0; i < c->prof_cap; ++i) {
+      (void)hipEventDestroy(c->prof[i].a);
+      (void)hipEventDestroy(c->prof[i].b);
+    }
+    free(c->prof);
+  }
+  if (c->slots) {
+    for (int s = 0; s < c->cfg.n_slots; ++s) (void)hipFree(c->slots[s].mem);
+    free(c->slots);
+  }
+  void *bufs[] = {c->d_pts0, c->d_pts1, c->d_pts2, c->d_pts3, c->d_err, c->d_err2, c->d_scale, c->d_X,
+                  c->d_status, c->d_status2, c->d_mask, c->d_mask2, c->d_idx, c->d_count, c->d_mat,
+                  c->d_gninfo, c->d_flags, c->d_img_stage, c->d_desc_a, c->d_desc_b, c->d_dist};
+  for (void *b : bufs)
+    if (b) (void)hipFree(b);
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  free(c);
+}
+
+// ---- profiling ---------------------------------------------------------------
+extern "C" int vo_profile_enable(vo_ctx *c, int max_records) {
+  if (!c || max_records <= 0) return VO_ERR_INVALID;
+  if (c->prof) return vo_profile_reset(c);
+  c->prof = (vo_prof_rec *)calloc((size_t)max_records, sizeof(vo_prof_rec));
+  for (int i = 0; i < max_records; ++i) {
+    VO_CHECK_HIP(c, hipEventCreate(&c->prof[i].a));
+    VO_CHECK_HIP(c, hipEventCreate(&c->prof[i].b));
+  }
+  c->prof_cap = max_records;
+  c->prof_n = 0;
+  return VO_OK;
+}
+extern "C" int vo_profile_reset(vo_ctx *c) {
+  if (!c) return VO_ERR_INVALID;
+  c->prof_n = 0;
+  return VO_OK;
+}
+extern "C" int vo_profile_get(vo_ctx *c, int cls, int *launches, double *total_ms) {
+  if (!c || !launches || !total_ms) return VO_ERR_INVALID;
+  *launches = 0;
+  *total_ms = 0.0;
+  for (int i = 0; i < c->prof_n; ++i) {
+    if (c->prof[i].cls != cls) continue;
+    float ms = 0.f;
+    VO_CHECK_HIP(c, hipEventElapsedTime(&ms, c->prof[i].a, c->prof[i].b));
+    *total_ms += ms;
+    ++*launches;
+  }
+  return VO_OK;
+}
+
+// ---- helpers -------------------------------------------------------------------
+static int check_n(vo_ctx *c, int n) {
+  if (n < 0) VO_FAIL(c, VO_ERR_INVALID, "negative point count");
+  if (n > c->cfg.max_points) VO_FAIL(c, VO_ERR_CAPACITY, "n=%d exceeds vo_config.max_points=%d", n, c->cfg.max_points);
+  return VO_OK;
+}
+#define H2D(dst, src, bytes) VO_CHECK_HIP(c, hipMemcpyAsync((dst), (src), (bytes), hipMemcpyHostToDevice, c->stream))
+#define D2H(dst, src, bytes) VO_CHECK_HIP(c, hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, c->stream))
+#define SYNC() VO_CHECK_HIP(c, hipStreamSynchronize(c->stream))
+
+// ---- MotionEstimator -----------------------------------------------------------
+extern "C" int vo_gn_pose_stereo(vo_ctx *c, const float *X, const float *pts_l1, const float *pts_r1, int n,
+                                 const float Kl[4], const float Kr[4], const float T_lr[16],
+                                 float thres, float T01[16], uint8_t *mask_inlier, vo_gn_info *info) {
+  if (!c || !X || !pts_l1 || !pts_r1 || !Kl || !Kr || !T_lr || !T01 || !mask_inlier) return VO_ERR_INVALID;
+  int rc = check_n(c, n);
+  if (rc) return rc;
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  if (n > 0) {
+    H2D(c->d_X, X, sizeof(float) * 3 * (size_t)n);
+    H2D(c->d_pts0, pts_l1, sizeof(float) * 2 * (size_t)n);
+    H2D(c->d_pts1, pts_r1, sizeof(float) * 2 * (size_t)n);
+  }
+  rc = vo_gn_enqueue(c, true, false, c->d_X, c->d_pts0, c->d_pts1, n, nullptr, Kl, Kr, T_lr, thres, 0, T01,
+                     c->d_mat, c->d_mask, c->d_gninfo);
+  if (rc) return rc;
+  vo_gn_dev_info gi;
+  float Tout[16];
+  D2H(&gi, c->d_gninfo, sizeof(gi));
+  D2H(Tout, c->d_mat, sizeof(Tout));
+  if (n > 0) D2H(mask_inlier, c->d_mask, (size_t)n);
+  SYNC();
+  if (info) {
+    info->iterations = gi.iterations;
+    info->err = gi.err;
+    info->delta_err = gi.delta_err;
+    info->delta_norm = gi.delta_norm;
+    info->cnt_invalid = gi.cnt_invalid;
+    info->is_nan = gi.is_nan;
+  }
+  if (gi.is_nan) return 0;
+  memcpy(T01, Tout, sizeof(Tout));
+  return 1;
+}
+
+extern "C" int vo_gn_pose_mono(vo_ctx *c, const float *X, const float *pts1, int n, const float K[4],
+                               int thres_reproj_outlier, float R01[9], float t01[3], uint8_t *mask_inlier,
+                               int variant, vo_gn_info *info) {
+  if (!c || !X || !pts1 || !K || !R01 || !t01 || !mask_inlier) return VO_ERR_INVALID;
+  int rc = check_n(c, n);
+  if (rc) return rc;
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  if (n > 0) {
+    H2D(c->d_X, X, sizeof(float) * 3 * (size_t)n);
+    H2D(c->d_pts0, pts1, sizeof(float) * 2 * (size_t)n);
+  }
+  float T01[16] = {R01[0], R01[1], R01[2], t01[0], R01[3], R01[4], R01[5], t01[1],
+                   R01[6], R01[7], R01[8], t01[2], 0, 0, 0, 1};
+  rc = vo_gn_enqueue(c, false, true, c->d_X, c->d_pts0, nullptr, n, nullptr, K, K, nullptr,
+                     (float)thres_reproj_outlier, variant, T01, c->d_mat, c->d_mask, c->d_gninfo);
+  if (rc) return rc;
+  vo_gn_dev_info gi;
+  float Tout[16];
+  D2H(&gi, c->d_gninfo, sizeof(gi));
+  D2H(Tout, c->d_mat, sizeof(Tout));
+  if (n > 0) D2H(mask_inlier, c->d_mask, (size_t)n);
+  SYNC();
+  if (info) {
+    info->iterations = gi.iterations;
+    info->err = gi.err;
+    info->delta_err = gi.delta_err;
+    info->delta_norm = gi.delta_norm;
+    info->cnt_invalid = gi.cnt_invalid;
+    info->is_nan = gi.is_nan;
+  }
+  if (gi.is_nan) return 0;
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) R01[i * 3 + j] = Tout[i * 4 + j];
+    t01[i] = Tout[i * 4 + 3];
+  }
+  return 1;
+}

@@ -1,0 +1,157 @@
+// vo_internal.hpp — context layout and device helpers shared by the gfx950 kernels.
+// Wave width is 64 everywhere (CDNA4); reductions use DPP butterflies whose
+// summation tree is the balanced binary tree over lanes in natural order
+// (adjacent pairs first) — the order oracle/ calls VO_SUM_TREE.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/vo_hip.h"
+
+#define VO_PAD 32          // border (pixels) around every pyramid level, >= win+2 for win <= 30
+#define VO_MAX_LEVELS 10
+#define VO_WAVE 64
+
+struct vo_level {
+  uint8_t *base;   // start of the padded allocation
+  int w, h;        // image size at this level
+  int stride;      // bytes per padded row (multiple of 64)
+  __host__ __device__ const uint8_t *origin() const { return base + (size_t)VO_PAD * stride + VO_PAD; }
+};
+
+struct vo_pyramid {
+  vo_level lv[VO_MAX_LEVELS];
+  int n_levels;    // levels built (0..n_levels-1 valid)
+  int w, h;
+  uint8_t *mem;    // one allocation for all levels
+  size_t bytes;
+};
+
+struct vo_gn_dev_info {
+  int iterations;
+  float err, delta_err, delta_norm;
+  int cnt_invalid;
+  int is_nan;
+};
+
+struct vo_prof_rec {
+  hipEvent_t a, b;
+  int cls;
+};
+
+struct vo_ctx {
+  vo_config cfg;
+  int device;
+  hipStream_t stream;
+  char err[512];
+  vo_pyramid *slots;
+  // per-point device buffers (capacity cfg.max_points)
+  float *d_pts0, *d_pts1, *d_pts2, *d_pts3, *d_err, *d_err2, *d_scale, *d_X;
+  uint8_t *d_status, *d_status2, *d_mask, *d_mask2;
+  int32_t *d_idx;
+  int *d_count;
+  float *d_mat;            // small matrices / scalars
+  vo_gn_dev_info *d_gninfo;
+  int *d_flags;            // error flags raised by kernels
+  // pinned host staging
+  uint8_t *h_stage;
+  size_t h_stage_bytes;
+  uint8_t *d_img_stage;    // device staging for host images
+  // hamming
+  uint8_t *d_desc_a, *d_desc_b;
+  uint16_t *d_dist;
+  size_t desc_cap, dist_cap;
+  // frame pipeline state
+  struct vo_frame_state *frame;
+  // profiling
+  vo_prof_rec *prof;
+  int prof_cap, prof_n;
+};
+
+#define VO_CHECK_HIP(ctx, expr)                                                            \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, \
+               hipGetErrorString(_e));                                                     \
+      return VO_ERR_HIP;                                                                   \
+    }                                                                                      \
+  } while (0)
+
+#define VO_FAIL(ctx, code, ...)                                \
+  do {                                                         \
+    snprintf((ctx)->err, sizeof((ctx)->err), __VA_ARGS__);     \
+    return (code);                                             \
+  } while (0)
+
+// ---- profiling brackets (no-ops unless vo_profile_enable was called) --------
+static inline void vo_prof_begin(vo_ctx *c, int cls) {
+  if (c->prof && c->prof_n < c->prof_cap) {
+    c->prof[c->prof_n].cls = cls;
+    (void)hipEventRecord(c->prof[c->prof_n].a, c->stream);
+  }
+}
+static inline void vo_prof_end(vo_ctx *c) {
+  if (c->prof && c->prof_n < c->prof_cap) {
+    (void)hipEventRecord(c->prof[c->prof_n].b, c->stream);
+    ++c->prof_n;
+  }
+}
+
+#ifdef __HIPCC__
+// ---- DPP cross-lane helpers ---------------------------------------------------
+// dpp_ctrl: quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E,
+//           row_half_mirror = 0x141, row_mirror = 0x140.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+
+// Sum over the 64 lanes; every lane returns the same bits.
+// Tree: ((l0+l1)+(l2+l3)) ... rows of 16 -> (r0+r1)+(r2+r3).
+__device__ __forceinline__ float wave_sum_f32(float v) {
+  v = v + dpp_f32<0xB1>(v);
+  v = v + dpp_f32<0x4E>(v);
+  v = v + dpp_f32<0x141>(v);
+  v = v + dpp_f32<0x140>(v);
+  float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return (r0 + r1) + (r2 + r3);
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+  v = v + dpp_i32<0xB1>(v);
+  v = v + dpp_i32<0x4E>(v);
+  v = v + dpp_i32<0x141>(v);
+  v = v + dpp_i32<0x140>(v);
+  int r0 = __builtin_amdgcn_readlane(v, 0);
+  int r1 = __builtin_amdgcn_readlane(v, 16);
+  int r2 = __builtin_amdgcn_readlane(v, 32);
+  int r3 = __builtin_amdgcn_readlane(v, 48);
+  return (r0 + r1) + (r2 + r3);
+}
+// Exact 64-bit sum of 64 int32 lane values (each |v| < 2^30): split 16/16 so the
+// two int32 wave sums cannot overflow, recombine in int64.
+__device__ __forceinline__ long long wave_sum_i32_to_i64(int v) {
+  int lo = v & 0xFFFF;
+  int hi = v >> 16;
+  int slo = wave_sum_i32(lo);
+  int shi = wave_sum_i32(hi);
+  return (long long)shi * 65536LL + (long long)slo;
+}
+
+__device__ __forceinline__ int reflect101_dev(int p, int n) {
+  if (n == 1) return 0;
+  while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
+  return p;
+}
+#endif  // __HIPCC__
+
