@@ -29,6 +29,6 @@ def vo():
 
 @pytest.fixture(scope="session")
 def ctx(vo):
-    c = vo.Context(device=0, max_width=1241, max_height=376, max_points=8192, n_slots=4, max_level=6)
+    c = vo.Context(device=0, max_width=1241, max_height=480, max_points=8192, n_slots=4, max_level=6)
     yield c
     c.close()

@@ -250,3 +250,139 @@ extern "C" int vo_gn_pose_mono(vo_ctx *c, const float *X, const float *pts1, int
   }
   return 1;
 }
+
+// ---- images & pyramids ---------------------------------------------------------
+extern "C" int vo_pyramid_levels(int width, int height, int win, int max_level) {
+  return vo_pyr_levels_host(width, height, win, max_level);
+}
+
+extern "C" int vo_set_image_device(vo_ctx *c, int slot, const void *dev, int width, int height, int stride) {
+  if (!c || !dev) return VO_ERR_INVALID;
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  return vo_pyramid_build(c, slot, (const uint8_t *)dev, width, height, stride);
+}
+
+extern "C" int vo_set_image(vo_ctx *c, int slot, const uint8_t *host, int width, int height, int stride) {
+  if (!c || !host) return VO_ERR_INVALID;
+  if (width <= 0 || height <= 0 || width > c->cfg.max_width || height > c->cfg.max_height)
+    VO_FAIL(c, VO_ERR_CAPACITY, "image %dx%d exceeds vo_config %dx%d", width, height, c->cfg.max_width,
+            c->cfg.max_height);
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  // the previous use of the staging buffers must have drained
+  SYNC();
+  for (int y = 0; y < height; ++y) memcpy(c->h_stage + (size_t)y * width, host + (size_t)y * stride, (size_t)width);
+  H2D(c->d_img_stage, c->h_stage, (size_t)width * height);
+  int rc = vo_pyramid_build(c, slot, c->d_img_stage, width, height, width);
+  if (rc) return rc;
+  SYNC();
+  return VO_OK;
+}
+
+extern "C" int vo_swap_slots(vo_ctx *c, int a, int b) {
+  if (!c || a < 0 || b < 0 || a >= c->cfg.n_slots || b >= c->cfg.n_slots) return VO_ERR_INVALID;
+  vo_pyramid t = c->slots[a];
+  c->slots[a] = c->slots[b];
+  c->slots[b] = t;
+  return VO_OK;
+}
+
+extern "C" int vo_get_level(vo_ctx *c, int slot, int level, uint8_t *host, int *width, int *height) {
+  if (!c || !host || slot < 0 || slot >= c->cfg.n_slots) return VO_ERR_INVALID;
+  const vo_pyramid &P = c->slots[slot];
+  if (level < 0 || level >= P.n_levels) VO_FAIL(c, VO_ERR_INVALID, "level %d not built (%d levels)", level, P.n_levels);
+  const vo_level &L = P.lv[level];
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  VO_CHECK_HIP(c, hipMemcpy2DAsync(host, (size_t)L.w, L.origin(), (size_t)L.stride, (size_t)L.w, (size_t)L.h,
+                                   hipMemcpyDeviceToHost, c->stream));
+  SYNC();
+  if (width) *width = L.w;
+  if (height) *height = L.h;
+  return VO_OK;
+}
+
+// ---- pyramidal LK ----------------------------------------------------------------
+extern "C" int vo_klt_track(vo_ctx *c, int slot0, int slot1, const float *pts0, float *pts1, int n, int win,
+                            int max_level, int flags, int max_iter, double eps, float min_eig_thr,
+                            uint8_t *status, float *err) {
+  if (!c || !pts0 || !pts1 || !status || !err) return VO_ERR_INVALID;
+  int rc = check_n(c, n);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  H2D(c->d_pts0, pts0, sizeof(float) * 2 * (size_t)n);
+  if (flags & VO_KLT_USE_INITIAL_FLOW)
+    H2D(c->d_pts1, pts1, sizeof(float) * 2 * (size_t)n);
+  else
+    VO_CHECK_HIP(c, hipMemsetAsync(c->d_pts1, 0, sizeof(float) * 2 * (size_t)n, c->stream));
+  rc = vo_klt_enqueue(c, slot0, slot1, c->d_pts0, c->d_pts1, n, nullptr, win, max_level, flags, max_iter, eps,
+                      min_eig_thr, c->d_status, c->d_err);
+  if (rc < 0) return rc;
+  D2H(pts1, c->d_pts1, sizeof(float) * 2 * (size_t)n);
+  D2H(status, c->d_status, (size_t)n);
+  D2H(err, c->d_err, sizeof(float) * (size_t)n);
+  SYNC();
+  return rc;
+}
+
+// shared body of the four FeatureTracker wrappers.
+//  mode 0 track, 1 trackWithPrior, 2 trackBidirection, 3 trackBidirectionWithPrior
+static int track_common(vo_ctx *c, int mode, int slot0, int slot1, const float *pts0, int n, int win,
+                        int max_level, float thres_err, float thres_bidir, float *pts_track,
+                        uint8_t *mask_valid) {
+  if (!c || !pts0 || !pts_track || !mask_valid) return VO_ERR_INVALID;
+  int rc = check_n(c, n);
+  if (rc) return rc;
+  if (n == 0) return VO_OK;
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  const vo_pyramid &P0 = c->slots[slot0 >= 0 && slot0 < c->cfg.n_slots ? slot0 : 0];
+  const size_t pb = sizeof(float) * 2 * (size_t)n;
+  H2D(c->d_pts0, pts0, pb);
+  H2D(c->d_mask, mask_valid, (size_t)n);
+  const bool prior = (mode == 1 || mode == 3);
+  if (prior)
+    H2D(c->d_pts1, pts_track, pb);
+  else
+    VO_CHECK_HIP(c, hipMemsetAsync(c->d_pts1, 0, pb, c->stream));
+  // forward: track()/trackBidirection() use the OpenCV defaults (30, 0.01, minEig 1e-4);
+  // the *WithPrior variants pass `{}` criteria and `{}` minEigThreshold (= 0)
+  rc = vo_klt_enqueue(c, slot0, slot1, c->d_pts0, c->d_pts1, n, nullptr, win, max_level,
+                      prior ? VO_KLT_USE_INITIAL_FLOW : 0, 30, 0.01, prior ? 0.f : 1e-4f, c->d_status, c->d_err);
+  if (rc < 0) return rc;
+  if (mode >= 2) {
+    // backward: pts0_backward starts as a copy of pts0; trackBidirection uses maxLevel-1
+    VO_CHECK_HIP(c, hipMemcpyAsync(c->d_pts2, c->d_pts0, pb, hipMemcpyDeviceToDevice, c->stream));
+    const int ml = (mode == 2) ? max_level - 1 : max_level;
+    rc = vo_klt_enqueue(c, slot1, slot0, c->d_pts1, c->d_pts2, n, nullptr, win, ml, VO_KLT_USE_INITIAL_FLOW, 0,
+                        0., 0.f, c->d_status2, c->d_err2);
+    if (rc < 0) return rc;
+  }
+  rc = vo_klt_mask_enqueue(c, mode == 0 ? 0 : (mode == 1 ? 1 : mode), n, nullptr, P0.w, P0.h, thres_err,
+                           thres_bidir, c->d_pts0, c->d_pts1, c->d_pts2, c->d_status, c->d_status2, c->d_err,
+                           c->d_err2, c->d_mask);
+  if (rc < 0) return rc;
+  D2H(pts_track, c->d_pts1, pb);
+  D2H(mask_valid, c->d_mask, (size_t)n);
+  SYNC();
+  return VO_OK;
+}
+
+extern "C" int vo_track(vo_ctx *c, int slot0, int slot1, const float *pts0, int n, int win, int max_level,
+                        float thres_err, float *pts_track, uint8_t *mask_valid) {
+  return track_common(c, 0, slot0, slot1, pts0, n, win, max_level, thres_err, 0.f, pts_track, mask_valid);
+}
+extern "C" int vo_track_with_prior(vo_ctx *c, int slot0, int slot1, const float *pts0, int n, int win,
+                                   int max_level, float thres_err, float *pts_track, uint8_t *mask_valid) {
+  return track_common(c, 1, slot0, slot1, pts0, n, win, max_level, thres_err, 0.f, pts_track, mask_valid);
+}
+extern "C" int vo_track_bidirection(vo_ctx *c, int slot0, int slot1, const float *pts0, int n, int win,
+                                    int max_level, float thres_err, float thres_bidirection, float *pts_track,
+                                    uint8_t *mask_valid) {
+  return track_common(c, 2, slot0, slot1, pts0, n, win, max_level, thres_err, thres_bidirection, pts_track,
+                      mask_valid);
+}
+extern "C" int vo_track_bidirection_with_prior(vo_ctx *c, int slot0, int slot1, const float *pts0, int n, int win,
+                                               int max_level, float thres_err, float thres_bidirection,
+                                               float *pts_track, uint8_t *mask_valid) {
+  return track_common(c, 3, slot0, slot1, pts0, n, win, max_level, thres_err, thres_bidirection, pts_track,
+                      mask_valid);
+}

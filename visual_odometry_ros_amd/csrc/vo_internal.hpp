@@ -11,7 +11,7 @@
 
 #include "../../include/vo_hip.h"
 
-#define VO_PAD 32          // border (pixels) around every pyramid level, >= win+2 for win <= 30
+#define VO_PAD 40          // border (pixels) around every pyramid level: >= winSize + tile halo + 4-byte alignment slack (winSize <= 31)
 #define VO_MAX_LEVELS 10
 #define VO_WAVE 64
 
