@@ -182,6 +182,11 @@ typedef struct {
   int gn_iterations;
 } vo_frame_counts;
 
+/* strict != 0: the frame's trackWithScale step replays border-touching points
+ * with the reference's never-reset tap state (same as vo_track_with_scale's
+ * strict_border). Default 0. */
+int vo_stereo_frame_set_strict_border(vo_ctx *ctx, int strict);
+
 /* Asynchronous: enqueues one frame on the context stream. slot_l0 must hold the
  * previous left pyramid, slot_l1 / slot_r1 the current pair. Track-set inputs
  * are DEVICE pointers when `inputs_on_device` != 0, else host pointers. */

@@ -1,0 +1,90 @@
+"""GPU parity of the device-chained steady-state stereo frame (stereo_vo.cpp:483-711
+operator sequence) against the oracle running the same sequence on the CPU."""
+import numpy as np
+import pytest
+
+from visual_odometry_ros_amd import synthetic as S
+from visual_odometry_ros_amd.api import StereoFramePipeline, make_stereo_params
+
+pytestmark = pytest.mark.gpu
+GN_T = 512
+
+
+def rel_frob(A, B):
+    return np.linalg.norm(np.asarray(A, np.float64) - np.asarray(B, np.float64)) / np.linalg.norm(B)
+
+
+def _run_stream(ctx, oracle, stream, n_frames, strict, win=21, max_level=6):
+    prm_g = make_stereo_params(stream.width, stream.height, win, max_level, 80.0, 0.5, 3.0, stream.K, stream.K,
+                               stream.T_lr)
+    prm_o = oracle.make_stereo_params(stream.width, stream.height, win, max_level, 80.0, 0.5, 3.0, stream.K,
+                                      stream.K, stream.T_lr)
+    pipe = StereoFramePipeline(ctx, prm_g, strict_border=strict)
+    poses = stream.poses(n_frames)
+    Lp, Rp, _ = stream.render_pair(poses[0])
+    ctx.set_image(0, Lp)
+    worst = 0.0
+    for k in range(1, n_frames):
+        L, R, _ = stream.render_pair(poses[k])
+        ts = stream.track_set(k - 1, poses[k - 1], poses[k])
+        ctx.set_image(1, L)
+        ctx.set_image(2, R)
+        pipe.enqueue(ts["pts_l0"], ts["pts_r0"], ts["Xp"], ts["dT_prior"], ts["pts_new"])
+        g = pipe.result()
+        o = oracle.stereo_frame(prm_o, Lp, L, R, ts["pts_l0"], ts["pts_r0"], ts["Xp"], ts["dT_prior"],
+                                ts["pts_new"], oracle.SUM_TREE, GN_T,
+                                oracle.IC_REFERENCE if strict else oracle.IC_MASKED, 8)
+        assert o["rc"] == 0
+        # feature indices / survivors: bit-exact at every gate
+        assert np.array_equal(g["stage"], o["stage"]), np.nonzero(g["stage"] != o["stage"])[0][:10]
+        for f in ("n_l0l1", "n_refine", "n_l1r1", "n_inlier", "n_new_ok", "gn_iterations"):
+            assert getattr(g["counts"], f) == getattr(o["counts"], f), f
+        assert np.array_equal(g["pts_l1"].view(np.uint32), o["pts_l1"].view(np.uint32))
+        assert np.array_equal(g["pts_r1"].view(np.uint32), o["pts_r1"].view(np.uint32))
+        assert np.array_equal(g["mask_new"], o["mask_new"])
+        assert np.array_equal(g["pts_new_r"].view(np.uint32), o["pts_new_r"].view(np.uint32))
+        e = rel_frob(g["dT"], o["dT"])
+        worst = max(worst, e)
+        assert e < 1e-6
+        # reference summation order: north-star tolerance
+        os_ = oracle.stereo_frame(prm_o, Lp, L, R, ts["pts_l0"], ts["pts_r0"], ts["Xp"], ts["dT_prior"],
+                                  ts["pts_new"], oracle.SUM_SEQ, 0,
+                                  oracle.IC_REFERENCE if strict else oracle.IC_MASKED, 8)
+        assert rel_frob(g["dT"], os_["dT"]) < 1e-4
+        assert np.array_equal(g["stage"], os_["stage"])
+        # and the estimate is a sane odometry result
+        assert rel_frob(g["dT"], ts["dT_true"]) < 5e-3
+        assert g["counts"].n_inlier > 0.5 * ts["pts_l0"].shape[0]
+        ctx.swap_slots(0, 1)  # current left becomes previous left
+        Lp = L
+    return worst
+
+
+@pytest.mark.parametrize("strict", [False, True])
+def test_stereo_frame_kitti_shape(ctx, oracle, strict):
+    stream = S.StereoStream(seed=2, margin=4.0 if strict else 16.0)
+    _run_stream(ctx, oracle, stream, 3, strict)
+
+
+def test_stereo_frame_small_many_frames(ctx, oracle):
+    K = tuple(v * 0.5 for v in S.KITTI_K)
+    stream = S.StereoStream(width=620, height=188, K=K, n_u=30, n_v=12, n_new=40, seed=5, margin=14.0)
+    _run_stream(ctx, oracle, stream, 6, False, win=15, max_level=4)
+
+
+def test_stereo_frame_empty_sets(ctx, oracle):
+    stream = S.StereoStream(width=320, height=200, K=(300.0, 300.0, 160.0, 100.0), n_u=8, n_v=5, n_new=10, seed=7)
+    prm = make_stereo_params(320, 200, 21, 3, 80.0, 0.5, 3.0, stream.K, stream.K, stream.T_lr)
+    pipe = StereoFramePipeline(ctx, prm)
+    poses = stream.poses(2)
+    L0, R0, _ = stream.render_pair(poses[0])
+    L1, R1, _ = stream.render_pair(poses[1])
+    ctx.set_image(0, L0)
+    ctx.set_image(1, L1)
+    ctx.set_image(2, R1)
+    ts = stream.track_set(0, poses[0], poses[1])
+    z2, z3 = np.zeros((0, 2), np.float32), np.zeros((0, 3), np.float32)
+    pipe.enqueue(z2, z2, z3, ts["dT_prior"], z2)
+    g = pipe.result()
+    assert g["counts"].n_inlier == 0 and g["stage"].size == 0
+    assert np.allclose(g["dT"], ts["dT_prior"], atol=1e-6)  # T01 = inverse(inverse(prior))

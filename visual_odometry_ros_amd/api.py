@@ -304,10 +304,11 @@ class StereoFramePipeline:
     chained on the device. Slots: 0 = previous left, 1 = current left,
     2 = current right; advance() rotates current-left into previous-left."""
 
-    def __init__(self, ctx, params):
+    def __init__(self, ctx, params, strict_border=False):
         self.ctx = ctx
         self.lib = ctx.lib
         self.prm = params
+        self.ctx.check(self.lib.vo_stereo_frame_set_strict_border(ctx.handle, int(strict_border)))
 
     def enqueue(self, pts_l0, pts_r0, Xp, dT_prior, pts_new, slots=(0, 1, 2)):
         pts_l0, pts_r0 = _f32(pts_l0).reshape(-1, 2), _f32(pts_r0).reshape(-1, 2)

@@ -1,3 +1,311 @@
+// frame_pipeline.hip — the steady-state stereo frame, chained on the device.
+//
+// Operator sequence of StereoVO::trackStereoImages
+// (core/visual_odometry/stereo_vo/stereo_vo.cpp), steps
+//   [3]  prior pixels + patch scale                    :483-522
+//   [4]  trackWithPrior  I0_L -> I1_L  + compaction    :531-538
+//   [4-1] Sobel + trackWithScale       + compaction    :549-558
+//   [5]  trackWithPrior  I1_L -> I1_R  + compaction    :564-571
+//   [6]  poseOnlyBundleAdjustment_Stereo               :595-646
+//   [7]  the y > 660 gate                              :653-670
+//   [10] trackBidirection for the new points           :706-711
+// expressed in the previous left-camera frame. The reference returns to the
+// host between every step (std::vector compaction in the StereoLandmarkTracking
+// constructors, landmark.cpp:291-332); here every step is a kernel on one HIP
+// stream, live counts stay in device memory (kernels take `const int* d_n` and
+// surplus workgroups exit), and the host reads results once per frame.
 #include "vo_internal.hpp"
 #include "vo_kernels.hpp"
-void vo_frame_free(vo_ctx *c) { (void)c; }
+
+#include <stdlib.h>
+
+struct vo_frame_state {
+  int cap, cap_new;
+  // inputs (device copies when the caller passes host pointers)
+  float *in_l0, *in_r0, *in_X, *in_new;
+  // full-index-space arrays
+  float *F_pl1, *F_pr1, *F_scale;
+  int32_t *F_orig;
+  uint8_t *stage;
+  // compacted sets
+  float *A_pl0, *A_pl1, *A_pr1, *A_X, *A_scale, *A_ref, *A_lastpu;
+  uint8_t *A_touched, *A_cls;
+  int32_t *A_orig;
+  float *B_pl1, *B_pr1, *B_X;
+  int32_t *B_orig;
+  float *C_pl1, *C_pr1, *C_X;
+  int32_t *C_orig;
+  uint8_t *m1, *m2, *m3, *mG, *mNew;
+  uint8_t *st1, *st2;
+  float *e1, *e2;
+  float *new_r, *new_back;
+  int *cnt;  // [0]=nA [1]=nB [2]=nC [3]=n_inlier [4]=n_new_ok
+  float *dT;
+  vo_gn_dev_info *gn;
+  int n, n_new;
+  bool pending;
+};
+
+template <typename T>
+static hipError_t fs_alloc(T **p, size_t n) {
+  return hipMalloc((void **)p, (n ? n : 1) * sizeof(T));
+}
+
+static int frame_init(vo_ctx *c) {
+  if (c->frame) return VO_OK;
+  vo_frame_state *f = (vo_frame_state *)calloc(1, sizeof(vo_frame_state));
+  c->frame = f;
+  const size_t N = (size_t)c->cfg.max_points;
+  f->cap = (int)N;
+  f->cap_new = (int)N;
+  float **f2[] = {&f->in_l0, &f->in_r0, &f->in_new, &f->F_pl1, &f->F_pr1, &f->A_pl0, &f->A_pl1, &f->A_pr1,
+                  &f->B_pl1, &f->B_pr1, &f->C_pl1, &f->C_pr1, &f->new_r, &f->new_back, &f->A_ref, &f->A_lastpu};
+  for (float **p : f2) VO_CHECK_HIP(c, fs_alloc(p, 2 * N));
+  float **f3[] = {&f->in_X, &f->A_X, &f->B_X, &f->C_X};
+  for (float **p : f3) VO_CHECK_HIP(c, fs_alloc(p, 3 * N));
+  float **f1[] = {&f->F_scale, &f->A_scale, &f->e1, &f->e2};
+  for (float **p : f1) VO_CHECK_HIP(c, fs_alloc(p, N));
+  int32_t **i1[] = {&f->F_orig, &f->A_orig, &f->B_orig, &f->C_orig};
+  for (int32_t **p : i1) VO_CHECK_HIP(c, fs_alloc(p, N));
+  uint8_t **u1[] = {&f->stage, &f->m1, &f->m2, &f->m3, &f->mG, &f->mNew, &f->st1, &f->st2, &f->A_touched, &f->A_cls};
+  for (uint8_t **p : u1) VO_CHECK_HIP(c, fs_alloc(p, N));
+  VO_CHECK_HIP(c, fs_alloc(&f->cnt, 8));
+  VO_CHECK_HIP(c, fs_alloc(&f->dT, 16));
+  VO_CHECK_HIP(c, fs_alloc(&f->gn, 1));
+  return VO_OK;
+}
+
+void vo_frame_free(vo_ctx *c) {
+  vo_frame_state *f = c->frame;
+  if (!f) return;
+  void *bufs[] = {f->in_l0, f->in_r0, f->in_X, f->in_new, f->F_pl1, f->F_pr1, f->F_scale, f->F_orig, f->stage,
+                  f->A_pl0, f->A_pl1, f->A_pr1, f->A_X, f->A_scale, f->A_orig, f->B_pl1, f->B_pr1, f->B_X,
+                  f->B_orig, f->C_pl1, f->C_pr1, f->C_X, f->C_orig, f->m1, f->m2, f->m3, f->mG, f->mNew,
+                  f->st1, f->st2, f->e1, f->e2, f->new_r, f->new_back, f->cnt, f->dT, f->gn, f->A_ref, f->A_lastpu,
+                  f->A_touched, f->A_cls};
+  for (void *b : bufs)
+    if (b) (void)hipFree(b);
+  free(f);
+  c->frame = nullptr;
+}
+
+static void inv_se3(const float T[16], float Ti[16]) {
+  float Rt[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Rt[i * 3 + j] = T[j * 4 + i];
+  const float t[3] = {T[3], T[7], T[11]};
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) Ti[i * 4 + j] = Rt[i * 3 + j];
+    Ti[i * 4 + 3] = ((-Rt[i * 3 + 0]) * t[0] + (-Rt[i * 3 + 1]) * t[1]) + (-Rt[i * 3 + 2]) * t[2];
+  }
+  Ti[12] = Ti[13] = Ti[14] = 0;
+  Ti[15] = 1;
+}
+
+#define RC(x)            \
+  do {                   \
+    int _rc = (x);       \
+    if (_rc < 0) return _rc; \
+  } while (0)
+
+extern "C" int vo_stereo_frame_set_strict_border(vo_ctx *c, int strict) {
+  if (!c) return VO_ERR_INVALID;
+  c->frame_strict_ic = strict ? 1 : 0;
+  return VO_OK;
+}
+
+extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, int slot_l1,
+                                       int slot_r1, const float *pts_l0, const float *pts_r0, const float *Xp,
+                                       int n, const float dT_prior[16], const float *pts_new, int n_new,
+                                       int inputs_on_device) {
+  if (!c || !prm || !dT_prior || n < 0 || n_new < 0) return VO_ERR_INVALID;
+  if (n > c->cfg.max_points || n_new > c->cfg.max_points)
+    VO_FAIL(c, VO_ERR_CAPACITY, "n=%d / n_new=%d exceed vo_config.max_points=%d", n, n_new, c->cfg.max_points);
+  if ((n > 0 && (!pts_l0 || !pts_r0 || !Xp)) || (n_new > 0 && !pts_new)) return VO_ERR_INVALID;
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  RC(frame_init(c));
+  vo_frame_state *f = c->frame;
+  hipStream_t s = c->stream;
+  const float *d_l0 = pts_l0, *d_r0 = pts_r0, *d_X = Xp, *d_new = pts_new;
+  if (!inputs_on_device) {
+    if (n > 0) {
+      VO_CHECK_HIP(c, hipMemcpyAsync(f->in_l0, pts_l0, sizeof(float) * 2 * n, hipMemcpyHostToDevice, s));
+      VO_CHECK_HIP(c, hipMemcpyAsync(f->in_r0, pts_r0, sizeof(float) * 2 * n, hipMemcpyHostToDevice, s));
+      VO_CHECK_HIP(c, hipMemcpyAsync(f->in_X, Xp, sizeof(float) * 3 * n, hipMemcpyHostToDevice, s));
+    }
+    if (n_new > 0)
+      VO_CHECK_HIP(c, hipMemcpyAsync(f->in_new, pts_new, sizeof(float) * 2 * n_new, hipMemcpyHostToDevice, s));
+    d_l0 = f->in_l0;
+    d_r0 = f->in_r0;
+    d_X = f->in_X;
+    d_new = f->in_new;
+  }
+  f->n = n;
+  f->n_new = n_new;
+  const int W = prm->width, H = prm->height;
+  float T_rl[16], T_cp[16];
+  inv_se3(prm->T_lr, T_rl);
+  inv_se3(dT_prior, T_cp);
+  VO_CHECK_HIP(c, hipMemsetAsync(f->cnt, 0, 8 * sizeof(int), s));
+  VO_CHECK_HIP(c, hipMemcpyAsync(f->dT, dT_prior, 16 * sizeof(float), hipMemcpyHostToDevice, s));
+
+  if (n > 0) {
+    VO_CHECK_HIP(c, hipMemsetAsync(f->m1, 1, (size_t)n, s));
+    VO_CHECK_HIP(c, hipMemsetAsync(f->m2, 1, (size_t)n, s));
+    VO_CHECK_HIP(c, hipMemsetAsync(f->m3, 1, (size_t)n, s));
+    // [3] priors
+    RC(vo_stereo_prior_enqueue(c, d_X, d_l0, d_r0, n, T_cp, T_rl, prm->Kl, prm->Kr, W, H, f->F_pl1, f->F_pr1,
+                               f->F_scale, f->F_orig, f->stage));
+    // [4] l0 -> l1 ({} criteria, {} minEig)
+    RC(vo_klt_enqueue(c, slot_l0, slot_l1, d_l0, f->F_pl1, n, nullptr, prm->win, prm->max_level,
+                      VO_KLT_USE_INITIAL_FLOW, 0, 0., 0.f, f->st1, f->e1));
+    RC(vo_klt_mask_enqueue(c, 1, n, nullptr, W, H, prm->thres_err, 0.f, d_l0, f->F_pl1, nullptr, f->st1, nullptr,
+                           f->e1, nullptr, f->m1));
+    {
+      CompactArgsHost h;
+      h.mask = f->m1;
+      h.n = n;
+      h.d_n_out = &f->cnt[0];
+      h.in2[0] = d_l0;      h.out2[0] = f->A_pl0;
+      h.in2[1] = f->F_pl1;  h.out2[1] = f->A_pl1;
+      h.in2[2] = f->F_pr1;  h.out2[2] = f->A_pr1;
+      h.in3 = d_X;          h.out3 = f->A_X;
+      h.in1 = f->F_scale;   h.out1 = f->A_scale;
+      h.in_i = f->F_orig;   h.out_i = f->A_orig;
+      h.stage = f->stage;
+      h.stage_val = 1;
+      RC(vo_compact_enqueue(c, h));
+    }
+    // [4-1] scale-compensated refinement on the compacted set
+    RC(vo_ic_enqueue(c, slot_l0, slot_l1, f->A_pl0, f->A_scale, f->A_pl1, f->A_ref, f->m2, f->A_touched, f->A_cls,
+                     f->A_lastpu, n, &f->cnt[0]));
+    if (c->frame_strict_ic)
+      RC(vo_ic_strict_enqueue(c, slot_l0, slot_l1, f->A_pl0, f->A_scale, f->A_pl1, f->A_ref, f->m2, f->A_touched,
+                              f->A_cls, f->A_lastpu, n, &f->cnt[0]));
+    {
+      CompactArgsHost h;
+      h.mask = f->m2;
+      h.n = n;
+      h.d_n = &f->cnt[0];
+      h.d_n_out = &f->cnt[1];
+      h.in2[0] = f->A_ref;  h.out2[0] = f->B_pl1;
+      h.in2[1] = f->A_pr1;  h.out2[1] = f->B_pr1;
+      h.in3 = f->A_X;       h.out3 = f->B_X;
+      h.in_i = f->A_orig;   h.out_i = f->B_orig;
+      h.stage = f->stage;
+      h.stage_val = 2;
+      h.sc_src = f->A_ref;  // refined left pixels back to input index space
+      h.sc_dst = f->F_pl1;
+      RC(vo_compact_enqueue(c, h));
+    }
+    // [5] l1 -> r1
+    RC(vo_klt_enqueue(c, slot_l1, slot_r1, f->B_pl1, f->B_pr1, n, &f->cnt[1], prm->win, prm->max_level,
+                      VO_KLT_USE_INITIAL_FLOW, 0, 0., 0.f, f->st1, f->e1));
+    RC(vo_klt_mask_enqueue(c, 1, n, &f->cnt[1], W, H, prm->thres_err, 0.f, f->B_pl1, f->B_pr1, nullptr, f->st1,
+                           nullptr, f->e1, nullptr, f->m3));
+    {
+      CompactArgsHost h;
+      h.mask = f->m3;
+      h.n = n;
+      h.d_n = &f->cnt[1];
+      h.d_n_out = &f->cnt[2];
+      h.in2[0] = f->B_pl1;  h.out2[0] = f->C_pl1;
+      h.in2[1] = f->B_pr1;  h.out2[1] = f->C_pr1;
+      h.in3 = f->B_X;       h.out3 = f->C_X;
+      h.in_i = f->B_orig;   h.out_i = f->C_orig;
+      h.stage = f->stage;
+      h.stage_val = 3;
+      h.sc_src = f->B_pr1;
+      h.sc_dst = f->F_pr1;
+      RC(vo_compact_enqueue(c, h));
+    }
+  }
+  // [6] stereo pose-only BA on the survivors (T01 init = constant-velocity prior)
+  RC(vo_gn_enqueue(c, true, false, f->C_X, f->C_pl1, f->C_pr1, n, &f->cnt[2], prm->Kl, prm->Kr, prm->T_lr,
+                   prm->thres_poseba, 0, dT_prior, f->dT, f->mG, f->gn));
+  if (n > 0) {
+    // [7] inlier mask & the y > 660 gate (thres_sampson = 60 in every shipped config)
+    CompactArgsHost h;
+    h.mask = f->mG;
+    h.n = n;
+    h.d_n = &f->cnt[2];
+    h.d_n_out = &f->cnt[3];
+    h.in_i = f->C_orig;
+    h.out_i = f->A_orig;  // scratch
+    h.stage = f->stage;
+    h.stage_val = 4;
+    h.gate_pts = f->C_pl1;
+    h.gate_thres = 60.0f;
+    RC(vo_compact_enqueue(c, h));
+  }
+  // [10] new points: forward (defaults), backward (maxLevel-1, initial flow, {} criteria / minEig)
+  if (n_new > 0) {
+    VO_CHECK_HIP(c, hipMemsetAsync(f->mNew, 1, (size_t)n_new, s));
+    VO_CHECK_HIP(c, hipMemsetAsync(f->new_r, 0, sizeof(float) * 2 * n_new, s));
+    RC(vo_klt_enqueue(c, slot_l1, slot_r1, d_new, f->new_r, n_new, nullptr, prm->win, prm->max_level, 0, 30, 0.01,
+                      1e-4f, f->st1, f->e1));
+    VO_CHECK_HIP(c, hipMemcpyAsync(f->new_back, d_new, sizeof(float) * 2 * n_new, hipMemcpyDeviceToDevice, s));
+    if (prm->max_level - 1 < 0) VO_FAIL(c, VO_ERR_INVALID, "trackBidirection needs max_level >= 1");
+    RC(vo_klt_enqueue(c, slot_r1, slot_l1, f->new_r, f->new_back, n_new, nullptr, prm->win, prm->max_level - 1,
+                      VO_KLT_USE_INITIAL_FLOW, 0, 0., 0.f, f->st2, f->e2));
+    RC(vo_klt_mask_enqueue(c, 2, n_new, nullptr, W, H, prm->thres_err, prm->thres_bidirection, d_new, f->new_r,
+                           f->new_back, f->st1, f->st2, f->e1, f->e2, f->mNew));
+    CompactArgsHost h;
+    h.mask = f->mNew;
+    h.n = n_new;
+    h.d_n_out = &f->cnt[4];
+    RC(vo_compact_enqueue(c, h));
+  }
+  f->pending = true;
+  return VO_OK;
+}
+
+extern "C" int vo_stereo_frame_result(vo_ctx *c, float *pts_l1, float *pts_r1, uint8_t *stage, float dT[16],
+                                      float *pts_new_r, uint8_t *mask_new, vo_frame_counts *counts,
+                                      vo_gn_info *gn) {
+  if (!c || !c->frame || !c->frame->pending) return VO_ERR_INVALID;
+  vo_frame_state *f = c->frame;
+  hipStream_t s = c->stream;
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  const int n = f->n, nn = f->n_new;
+  int cnt[8];
+  int flags = 0;
+  vo_gn_dev_info gi;
+  if (pts_l1 && n) VO_CHECK_HIP(c, hipMemcpyAsync(pts_l1, f->F_pl1, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, s));
+  if (pts_r1 && n) VO_CHECK_HIP(c, hipMemcpyAsync(pts_r1, f->F_pr1, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, s));
+  if (stage && n) VO_CHECK_HIP(c, hipMemcpyAsync(stage, f->stage, (size_t)n, hipMemcpyDeviceToHost, s));
+  if (dT) VO_CHECK_HIP(c, hipMemcpyAsync(dT, f->dT, sizeof(float) * 16, hipMemcpyDeviceToHost, s));
+  if (pts_new_r && nn)
+    VO_CHECK_HIP(c, hipMemcpyAsync(pts_new_r, f->new_r, sizeof(float) * 2 * nn, hipMemcpyDeviceToHost, s));
+  if (mask_new && nn) VO_CHECK_HIP(c, hipMemcpyAsync(mask_new, f->mNew, (size_t)nn, hipMemcpyDeviceToHost, s));
+  VO_CHECK_HIP(c, hipMemcpyAsync(cnt, f->cnt, sizeof(cnt), hipMemcpyDeviceToHost, s));
+  VO_CHECK_HIP(c, hipMemcpyAsync(&gi, f->gn, sizeof(gi), hipMemcpyDeviceToHost, s));
+  VO_CHECK_HIP(c, hipMemcpyAsync(&flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, s));
+  VO_CHECK_HIP(c, hipStreamSynchronize(s));
+  f->pending = false;
+  if (counts) {
+    counts->n_l0l1 = cnt[0];
+    counts->n_refine = cnt[1];
+    counts->n_l1r1 = cnt[2];
+    counts->n_inlier = cnt[3];
+    counts->n_new_ok = cnt[4];
+    counts->gn_iterations = gi.iterations;
+  }
+  if (gn) {
+    gn->iterations = gi.iterations;
+    gn->err = gi.err;
+    gn->delta_err = gi.delta_err;
+    gn->delta_norm = gi.delta_norm;
+    gn->cnt_invalid = gi.cnt_invalid;
+    gn->is_nan = gi.is_nan;
+  }
+  if (flags) {
+    VO_CHECK_HIP(c, hipMemsetAsync(c->d_flags, 0, sizeof(int), s));
+    VO_CHECK_HIP(c, hipStreamSynchronize(s));
+    if (flags & 1) VO_FAIL(c, VO_ERR_NAN_AXAY, "ax ay nan");
+    if (flags & 2) VO_FAIL(c, VO_ERR_NAN_PATCH, "I0 I1 / du0 dv0 nan");
+    VO_FAIL(c, VO_ERR_NAN_UPDATE, "dtu dtv nan");
+  }
+  if (gi.is_nan) VO_FAIL(c, VO_ERR_GN_FAILED, "PoseOnlyStereoBA is failed!");
+  return VO_OK;
+}

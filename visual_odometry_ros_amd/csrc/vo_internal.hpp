@@ -66,6 +66,7 @@ struct vo_ctx {
   size_t desc_cap, dist_cap;
   // frame pipeline state
   struct vo_frame_state *frame;
+  int frame_strict_ic;     // replay border-touching points with the reference's sticky tap state
   // profiling
   vo_prof_rec *prof;
   int prof_cap, prof_n;

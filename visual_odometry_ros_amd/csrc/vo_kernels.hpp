@@ -1,6 +1,6 @@
 // vo_kernels.hpp — host-side launchers of the gfx950 kernels (one .hip file each).
 // Every launcher only ENQUEUES on ctx->stream (no synchronisation, no allocation),
-// so callers can chain them and capture them.
+// so callers can chain them without returning to the host.
 #pragma once
 #include "vo_internal.hpp"
 
@@ -22,6 +22,47 @@ int vo_klt_mask_enqueue(vo_ctx *c, int mode, int n_max, const int *d_n, int n_co
                         float thres_err, float thres_bidir, const float *pts0, const float *pts_track,
                         const float *pts_back, const uint8_t *st_f, const uint8_t *st_b,
                         const float *err_f, const float *err_b, uint8_t *mask);
+
+// ic_refine.hip
+int vo_ic_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, const float *d_scale,
+                  const float *d_prior, float *d_pts_track, uint8_t *d_mask, uint8_t *d_touched, uint8_t *d_cls,
+                  float *d_last_pu, int n_max, const int *d_n);
+int vo_ic_strict_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, const float *d_scale,
+                         const float *d_prior, float *d_pts_track, uint8_t *d_mask, uint8_t *d_touched,
+                         uint8_t *d_cls, float *d_last_pu, int n_max, const int *d_n);
+
+// misc_kernels.hip
+int vo_hamming_enqueue(vo_ctx *c, const uint8_t *d_a, int na, const uint8_t *d_b, int nb, uint16_t *d_dist);
+int vo_match_enqueue(vo_ctx *c, const uint8_t *d_a, int na, const uint8_t *d_b, int nb, int th_low, float ratio,
+                     int32_t *d_best, uint16_t *d_bd, uint16_t *d_sd);
+struct CompactArgsHost {
+  const uint8_t *mask = nullptr, *alive = nullptr, *tracked = nullptr;
+  int n = 0;
+  const int *d_n = nullptr;
+  int32_t *index_valid = nullptr;
+  int *d_n_out = nullptr;
+  const float *in2[4] = {nullptr, nullptr, nullptr, nullptr};
+  float *out2[4] = {nullptr, nullptr, nullptr, nullptr};
+  const float *in3 = nullptr;
+  float *out3 = nullptr;
+  const float *in1 = nullptr;
+  float *out1 = nullptr;
+  const int32_t *in_i = nullptr;
+  int32_t *out_i = nullptr;
+  uint8_t *stage = nullptr;
+  int stage_val = 0;
+  const float *sc_src = nullptr;
+  float *sc_dst = nullptr;
+  const float *gate_pts = nullptr;
+  float gate_thres = 0.f;
+};
+int vo_compact_enqueue(vo_ctx *c, const CompactArgsHost &h);
+int vo_calc_prior_enqueue(vo_ctx *c, const float *d_pts0, int n_pts0, const float *d_Xw, int n,
+                          const float T1w[16], const float K[9], float *d_out);
+int vo_stereo_prior_enqueue(vo_ctx *c, const float *d_Xp, const float *d_pl0, const float *d_pr0, int n,
+                            const float T_cp[16], const float T_rl[16], const float Kl[4], const float Kr[4],
+                            int W, int H, float *d_pl1, float *d_pr1, float *d_scale, int32_t *d_orig,
+                            uint8_t *d_stage);
 
 // frame_pipeline.hip
 void vo_frame_free(vo_ctx *c);
