@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py — stereo VO frames/s on the synthetic KITTI-shaped stream (BASELINE.json
+configs[1]: 1241x376, 1500 tracked features per frame), one image stream per GPU.
+
+A "step" is one steady-state stereo frame through the hot path: pyramids of the new
+left/right images, trackWithPrior l0->l1, trackWithScale, trackWithPrior l1->r1,
+stereo pose-only GN, and trackBidirection of the new-point candidates — the operator
+sequence of StereoVO::trackStereoImages (stereo_vo.cpp:483-711) — with the result
+(pose, survivors) read back to the host every frame, as a sequential VO needs it.
+Inputs (images and track sets) are resident in HBM before the timed region.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL gather of the totals)
+
+Prints ONE JSON line on rank 0 (see DESIGN.md §Measurement for every field).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WIN, MAX_LEVEL = 21, 6
+THRES_ERR, THRES_BIDIR, THRES_POSEBA = 80.0, 0.5, 3.0
+N_U, N_V, N_NEW = 60, 25, 150
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def klt_bytes_per_point_level(win):
+    # u8 template tile incl. Scharr halo + one u8 search tile
+    return (win + 2) ** 2 + (win + 1) ** 2
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--frames", type=int, default=12, help="distinct rendered frames (played back and forth)")
+    ap.add_argument("--cpu-frames", type=int, default=8, help="frames timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--strict-border", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    # torch first: its bundled libamdhip64.so.7 must be THE HIP runtime of the process;
+    # libvo_hip.so (NEEDED libamdhip64.so.7) then binds to the already-loaded one.
+    import torch
+    import torch.distributed as dist
+    import visual_odometry_ros_amd as V  # loads libvo_hip.so (fails loudly if missing)
+    from visual_odometry_ros_amd import synthetic as S
+    from visual_odometry_ros_amd.api import StereoFramePipeline, make_stereo_params
+    V.load()
+
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    # ---- synthetic stream (one independent sequence per rank), rendered on the host ----
+    stream = S.StereoStream(n_u=N_U, n_v=N_V, n_new=N_NEW, seed=2 + rank)
+    F = max(args.frames, 3)
+    poses = stream.poses(F)
+    imgs = [stream.render_pair(p)[:2] for p in poses]
+    # back-and-forth playback: 0,1,..,F-1,F-2,..,1,0,1,...
+    order = list(range(F)) + list(range(F - 2, 0, -1))
+    W_, H_ = stream.width, stream.height
+
+    def frame_id(step):
+        return order[step % len(order)]
+
+    track_sets = {}
+    for s in range(len(order)):
+        a, b = frame_id(s), frame_id(s + 1)
+        if (a, b) not in track_sets:
+            track_sets[(a, b)] = stream.track_set(a * 131 + b, poses[a], poses[b])
+
+    # ---- everything resident in HBM before timing ----
+    d_L = [torch.from_numpy(np.ascontiguousarray(L)).to(dev) for L, _ in imgs]
+    d_R = [torch.from_numpy(np.ascontiguousarray(R)).to(dev) for _, R in imgs]
+    d_ts = {}
+    for key, ts in track_sets.items():
+        d_ts[key] = {k: torch.from_numpy(np.ascontiguousarray(ts[k])).to(dev)
+                     for k in ("pts_l0", "pts_r0", "Xp", "pts_new")}
+    torch.cuda.synchronize()
+
+    n_pts = N_U * N_V
+    ctx = V.Context(device=local_rank, max_width=W_, max_height=H_, max_points=max(n_pts, N_NEW) + 64,
+                    n_slots=3, max_level=MAX_LEVEL)
+    prm = make_stereo_params(W_, H_, WIN, MAX_LEVEL, THRES_ERR, THRES_BIDIR, THRES_POSEBA, stream.K, stream.K,
+                             stream.T_lr)
+    pipe = StereoFramePipeline(ctx, prm, strict_border=bool(args.strict_border))
+    ctx.set_pyramid_window_hint(WIN)  # build only the levels PyrLK with this window uses
+    eff_levels = ctx.pyramid_levels(W_, H_, WIN, MAX_LEVEL) + 1
+    eff_levels_bwd = ctx.pyramid_levels(W_, H_, WIN, MAX_LEVEL - 1) + 1
+
+    def step(s, keep=None):
+        a, b = frame_id(s), frame_id(s + 1)
+        ctx.set_stereo_pair_device(1, d_L[b].data_ptr(), 2, d_R[b].data_ptr(), W_, H_, W_)
+        t = d_ts[(a, b)]
+        pipe.enqueue_device(t["pts_l0"].data_ptr(), t["pts_r0"].data_ptr(), t["Xp"].data_ptr(), n_pts,
+                            track_sets[(a, b)]["dT_prior"], t["pts_new"].data_ptr(), N_NEW)
+        r = pipe.result()  # sync + D2H of pose / survivors: a sequential VO needs them per frame
+        ctx.swap_slots(0, 1)
+        if keep is not None:
+            keep.append(r)
+        return r
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.synchronize()
+
+    ctx.set_image_device(0, d_L[frame_id(0)].data_ptr(), W_, H_, W_)
+    ctx.synchronize()
+    for s in range(args.warmup):
+        step(s)
+    K = args.steps
+    ctx.profile_enable(K * 4 + 64)
+    ctx.profile_set_classes(1 << 1)  # event-bracket only the dominant kernel class (klt_track)
+    ctx.profile_reset()
+    klt_alg_bytes = 0
+    results = []
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.warmup, args.warmup + K):
+        r = step(s, results if len(results) < args.cpu_frames else None)
+        c = r["counts"]
+        klt_alg_bytes += klt_bytes_per_point_level(WIN) * (
+            (n_pts + c.n_refine) * eff_levels + N_NEW * (eff_levels + eff_levels_bwd))
+    barrier()
+    dt = time.perf_counter() - t0
+
+    # ---- aggregate over ranks (RCCL all_gather of {frames, seconds}) ----
+    if world > 1:
+        mine = torch.tensor([float(K), dt], dtype=torch.float64, device=dev)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        tot_frames = sum(float(v[0]) for v in allv)
+        max_dt = max(float(v[1]) for v in allv)
+    else:
+        tot_frames, max_dt = float(K), dt
+
+    out = None
+    if rank == 0:
+        names = {0: "pyramid", 1: "klt_track", 2: "ic_refine", 3: "gn_pose", 4: "hamming", 5: "aux"}
+        per_kernel = {}
+        for cls, nm in names.items():
+            n_l, ms = ctx.profile_get(cls)
+            if n_l:
+                per_kernel[nm] = {"launches": n_l, "total_ms": round(ms, 3), "avg_us": round(1e3 * ms / n_l, 2)}
+        klt_n, klt_ms = ctx.profile_get(1)
+        achieved = (klt_alg_bytes / max(klt_n, 1)) / (klt_ms / max(klt_n, 1) * 1e-3) / 1e9 if klt_n else 0.0
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_klt_pmc.json")
+        if os.path.exists(pmc_path):
+            try:
+                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "stereo VO frames/sec @1241x376, 1500 feats",
+            "value": round(tot_frames / max_dt, 2),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * max_dt / K, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8/i32 (KLT) + f32 (IC, GN)",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[1]: synthetic KITTI-shaped stereo stream 1241x376, 1500 tracked "
+                            "features/frame (60x25 buckets) + 150 new-point candidates, win 21, max_level 6 "
+                            "(5 effective levels), thresholds of config/stereo/kitti_00_stereo.yaml; one "
+                            "independent stream per GPU; result read back every frame",
+                "strict_border": int(args.strict_border),
+                "distinct_frames": F,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "klt_track_kernel<21>",
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": traffic,
+                "alg_bytes_per_launch": round(klt_alg_bytes / max(klt_n, 1)),
+                "avg_launch_us": round(1e3 * klt_ms / max(klt_n, 1), 2),
+            },
+            "kernels": per_kernel,
+        }
+
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle as O
+            prm_o = O.make_stereo_params(W_, H_, WIN, MAX_LEVEL, THRES_ERR, THRES_BIDIR, THRES_POSEBA, stream.K,
+                                         stream.K, stream.T_lr)
+            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            border = O.IC_REFERENCE if args.strict_border else O.IC_MASKED
+            worst, stage_equal = 0.0, True
+            tcpu = 0.0
+            nf = min(args.cpu_frames, len(results))
+            for i in range(nf):
+                s = args.warmup + i
+                a, b = frame_id(s), frame_id(s + 1)
+                ts = track_sets[(a, b)]
+                t1 = time.perf_counter()
+                o = O.stereo_frame(prm_o, imgs[a][0], imgs[b][0], imgs[b][1], ts["pts_l0"], ts["pts_r0"],
+                                   ts["Xp"], ts["dT_prior"], ts["pts_new"], O.SUM_SEQ, 0, border, cores)
+                tcpu += time.perf_counter() - t1
+                g = results[i]
+                e = float(np.linalg.norm(g["dT"].astype(np.float64) - o["dT"]) / np.linalg.norm(o["dT"]))
+                worst = max(worst, e)
+                stage_equal = stage_equal and bool(np.array_equal(g["stage"], o["stage"]))
+            out["cpu_baseline"] = {
+                "value": round(nf / tcpu, 3) if tcpu > 0 else None,
+                "unit": "frames/s",
+                "cores": cores,
+                "kind": "port",
+                "sample": f"{nf} frames of the same stream on the CPU restatement (oracle/, reference summation "
+                          f"order); PyrLK over {cores} OpenMP threads, IC and GN single-threaded as in the reference",
+            }
+            out["parity"] = {"pose_rel_frobenius_max": worst, "survivor_sets_bit_exact": stage_equal,
+                             "frames_checked": nf}
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

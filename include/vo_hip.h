@@ -98,6 +98,12 @@ int vo_set_image(vo_ctx *ctx, int slot, const uint8_t *host, int width, int heig
 /* same, `dev` is a DEVICE pointer (image already resident in HBM) */
 int vo_set_image_device(vo_ctx *ctx, int slot, const void *dev, int width, int height, int stride);
 int vo_swap_slots(vo_ctx *ctx, int slot_a, int slot_b);
+/* Both images of a stereo pair in one call (one launch per pyramid level for the pair). */
+int vo_set_stereo_pair_device(vo_ctx *ctx, int slot_l, const void *dev_l, int slot_r, const void *dev_r,
+                              int width, int height, int stride);
+/* win > 0: build only levels 0..vo_pyramid_levels(w,h,win,max_level) (what PyrLK with that window
+ * can use); 0 (default): every level down to vo_config.max_level. */
+int vo_set_pyramid_window_hint(vo_ctx *ctx, int win);
 /* effective OpenCV maxLevel for (width,height,win,max_level) */
 int vo_pyramid_levels(int width, int height, int win, int max_level);
 /* test hook: copy unpadded level `level` of a slot back to host (tightly packed) */
@@ -204,6 +210,8 @@ int vo_stereo_frame_result(vo_ctx *ctx, float *pts_l1, float *pts_r1, uint8_t *s
 enum { VO_K_PYRAMID = 0, VO_K_KLT = 1, VO_K_IC = 2, VO_K_GN = 3, VO_K_HAMMING = 4, VO_K_AUX = 5, VO_K_COUNT = 6 };
 int vo_profile_enable(vo_ctx *ctx, int max_records);
 int vo_profile_reset(vo_ctx *ctx);
+/* restrict the event brackets to a set of kernel classes: mask = OR of (1 << VO_K_*); 0 = all */
+int vo_profile_set_classes(vo_ctx *ctx, unsigned mask);
 /* after vo_synchronize(): launches and summed device time (ms) of one kernel class */
 int vo_profile_get(vo_ctx *ctx, int kernel_class, int *launches, double *total_ms);
 

@@ -48,7 +48,8 @@ SYMBOLS = [
     "vo_track_with_scale", "vo_gn_pose_mono", "vo_gn_pose_stereo", "vo_orb_hamming",
     "vo_orb_match", "vo_compact_indices", "vo_stereo_frame_set_strict_border",
     "vo_stereo_frame_enqueue", "vo_stereo_frame_result",
-    "vo_profile_enable", "vo_profile_reset", "vo_profile_get",
+    "vo_profile_enable", "vo_profile_reset", "vo_profile_get", "vo_profile_set_classes",
+    "vo_set_stereo_pair_device", "vo_set_pyramid_window_hint",
 ]
 
 _lib = None

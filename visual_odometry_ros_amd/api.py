@@ -92,6 +92,13 @@ class Context:
     def set_image_device(self, slot, dev_ptr, width, height, stride):
         self.check(self.lib.vo_set_image_device(self._h, slot, C.c_void_p(dev_ptr), width, height, stride))
 
+    def set_stereo_pair_device(self, slot_l, ptr_l, slot_r, ptr_r, width, height, stride):
+        self.check(self.lib.vo_set_stereo_pair_device(self._h, slot_l, C.c_void_p(ptr_l), slot_r,
+                                                      C.c_void_p(ptr_r), width, height, stride))
+
+    def set_pyramid_window_hint(self, win):
+        self.check(self.lib.vo_set_pyramid_window_hint(self._h, win))
+
     def swap_slots(self, a, b):
         self.check(self.lib.vo_swap_slots(self._h, a, b))
 
@@ -107,6 +114,9 @@ class Context:
     # ---- profiling --------------------------------------------------------
     def profile_enable(self, max_records):
         self.check(self.lib.vo_profile_enable(self._h, max_records))
+
+    def profile_set_classes(self, mask):
+        self.check(self.lib.vo_profile_set_classes(self._h, C.c_uint(mask)))
 
     def profile_reset(self):
         self.check(self.lib.vo_profile_reset(self._h))

@@ -13,20 +13,29 @@
 // host between every step (std::vector compaction in the StereoLandmarkTracking
 // constructors, landmark.cpp:291-332); here every step is a kernel on one HIP
 // stream, live counts stay in device memory (kernels take `const int* d_n` and
-// surplus workgroups exit), and the host reads results once per frame.
+// surplus workgroups exit), and the host reads ONE packed result block per
+// frame (a single D2H copy into pinned memory).
 #include "vo_internal.hpp"
 #include "vo_kernels.hpp"
 
 #include <stdlib.h>
 
+// header of the packed result block (device and pinned-host copies share the layout)
+struct vo_frame_hdr {
+  int cnt[8];  // [0]=nA [1]=nB [2]=nC [3]=n_inlier [4]=n_new_ok
+  vo_gn_dev_info gn;
+  int flags;
+  int pad_[1];
+  float dT[16];
+};
+
 struct vo_frame_state {
-  int cap, cap_new;
+  int cap;
   // inputs (device copies when the caller passes host pointers)
   float *in_l0, *in_r0, *in_X, *in_new;
-  // full-index-space arrays
-  float *F_pl1, *F_pr1, *F_scale;
+  // scratch in full index space
+  float *F_scale;
   int32_t *F_orig;
-  uint8_t *stage;
   // compacted sets
   float *A_pl0, *A_pl1, *A_pr1, *A_X, *A_scale, *A_ref, *A_lastpu;
   uint8_t *A_touched, *A_cls;
@@ -35,13 +44,18 @@ struct vo_frame_state {
   int32_t *B_orig;
   float *C_pl1, *C_pr1, *C_X;
   int32_t *C_orig;
-  uint8_t *m1, *m2, *m3, *mG, *mNew;
+  uint8_t *m1, *m2, *m3, *mG;
   uint8_t *st1, *st2;
   float *e1, *e2;
-  float *new_r, *new_back;
-  int *cnt;  // [0]=nA [1]=nB [2]=nC [3]=n_inlier [4]=n_new_ok
-  float *dT;
-  vo_gn_dev_info *gn;
+  float *new_back;
+  // packed result block
+  uint8_t *res_dev, *res_host;
+  size_t res_cap;
+  // views into res_dev for the frame in flight
+  vo_frame_hdr *hdr;
+  uint8_t *stage, *mNew;
+  float *F_pl1, *F_pr1, *new_r;
+  size_t off_stage, off_mnew, off_pl1, off_pr1, off_newr, res_bytes;
   int n, n_new;
   bool pending;
 };
@@ -51,15 +65,16 @@ static hipError_t fs_alloc(T **p, size_t n) {
   return hipMalloc((void **)p, (n ? n : 1) * sizeof(T));
 }
 
+static size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
 static int frame_init(vo_ctx *c) {
   if (c->frame) return VO_OK;
   vo_frame_state *f = (vo_frame_state *)calloc(1, sizeof(vo_frame_state));
   c->frame = f;
   const size_t N = (size_t)c->cfg.max_points;
   f->cap = (int)N;
-  f->cap_new = (int)N;
-  float **f2[] = {&f->in_l0, &f->in_r0, &f->in_new, &f->F_pl1, &f->F_pr1, &f->A_pl0, &f->A_pl1, &f->A_pr1,
-                  &f->B_pl1, &f->B_pr1, &f->C_pl1, &f->C_pr1, &f->new_r, &f->new_back, &f->A_ref, &f->A_lastpu};
+  float **f2[] = {&f->in_l0, &f->in_r0, &f->in_new, &f->A_pl0, &f->A_pl1, &f->A_pr1, &f->B_pl1, &f->B_pr1,
+                  &f->C_pl1, &f->C_pr1, &f->new_back, &f->A_ref, &f->A_lastpu};
   for (float **p : f2) VO_CHECK_HIP(c, fs_alloc(p, 2 * N));
   float **f3[] = {&f->in_X, &f->A_X, &f->B_X, &f->C_X};
   for (float **p : f3) VO_CHECK_HIP(c, fs_alloc(p, 3 * N));
@@ -67,24 +82,24 @@ static int frame_init(vo_ctx *c) {
   for (float **p : f1) VO_CHECK_HIP(c, fs_alloc(p, N));
   int32_t **i1[] = {&f->F_orig, &f->A_orig, &f->B_orig, &f->C_orig};
   for (int32_t **p : i1) VO_CHECK_HIP(c, fs_alloc(p, N));
-  uint8_t **u1[] = {&f->stage, &f->m1, &f->m2, &f->m3, &f->mG, &f->mNew, &f->st1, &f->st2, &f->A_touched, &f->A_cls};
+  uint8_t **u1[] = {&f->m1, &f->m2, &f->m3, &f->mG, &f->st1, &f->st2, &f->A_touched, &f->A_cls};
   for (uint8_t **p : u1) VO_CHECK_HIP(c, fs_alloc(p, N));
-  VO_CHECK_HIP(c, fs_alloc(&f->cnt, 8));
-  VO_CHECK_HIP(c, fs_alloc(&f->dT, 16));
-  VO_CHECK_HIP(c, fs_alloc(&f->gn, 1));
+  f->res_cap = align16(sizeof(vo_frame_hdr)) + 2 * align16(N) + 3 * align16(sizeof(float) * 2 * N);
+  VO_CHECK_HIP(c, hipMalloc((void **)&f->res_dev, f->res_cap));
+  VO_CHECK_HIP(c, hipHostMalloc((void **)&f->res_host, f->res_cap, hipHostMallocDefault));
   return VO_OK;
 }
 
 void vo_frame_free(vo_ctx *c) {
   vo_frame_state *f = c->frame;
   if (!f) return;
-  void *bufs[] = {f->in_l0, f->in_r0, f->in_X, f->in_new, f->F_pl1, f->F_pr1, f->F_scale, f->F_orig, f->stage,
-                  f->A_pl0, f->A_pl1, f->A_pr1, f->A_X, f->A_scale, f->A_orig, f->B_pl1, f->B_pr1, f->B_X,
-                  f->B_orig, f->C_pl1, f->C_pr1, f->C_X, f->C_orig, f->m1, f->m2, f->m3, f->mG, f->mNew,
-                  f->st1, f->st2, f->e1, f->e2, f->new_r, f->new_back, f->cnt, f->dT, f->gn, f->A_ref, f->A_lastpu,
-                  f->A_touched, f->A_cls};
+  void *bufs[] = {f->in_l0, f->in_r0, f->in_X, f->in_new, f->F_scale, f->F_orig, f->A_pl0, f->A_pl1, f->A_pr1,
+                  f->A_X, f->A_scale, f->A_orig, f->B_pl1, f->B_pr1, f->B_X, f->B_orig, f->C_pl1, f->C_pr1,
+                  f->C_X, f->C_orig, f->m1, f->m2, f->m3, f->mG, f->st1, f->st2, f->e1, f->e2, f->new_back,
+                  f->A_ref, f->A_lastpu, f->A_touched, f->A_cls, f->res_dev};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
+  if (f->res_host) (void)hipHostFree(f->res_host);
   free(f);
   c->frame = nullptr;
 }
@@ -102,9 +117,9 @@ static void inv_se3(const float T[16], float Ti[16]) {
   Ti[15] = 1;
 }
 
-#define RC(x)            \
-  do {                   \
-    int _rc = (x);       \
+#define RC(x)                \
+  do {                       \
+    int _rc = (x);           \
     if (_rc < 0) return _rc; \
   } while (0)
 
@@ -122,6 +137,7 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
   if (n > c->cfg.max_points || n_new > c->cfg.max_points)
     VO_FAIL(c, VO_ERR_CAPACITY, "n=%d / n_new=%d exceed vo_config.max_points=%d", n, n_new, c->cfg.max_points);
   if ((n > 0 && (!pts_l0 || !pts_r0 || !Xp)) || (n_new > 0 && !pts_new)) return VO_ERR_INVALID;
+  if (n_new > 0 && prm->max_level - 1 < 0) VO_FAIL(c, VO_ERR_INVALID, "trackBidirection needs max_level >= 1");
   VO_CHECK_HIP(c, hipSetDevice(c->device));
   RC(frame_init(c));
   vo_frame_state *f = c->frame;
@@ -140,32 +156,44 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
     d_X = f->in_X;
     d_new = f->in_new;
   }
+  // ---- carve the packed result block for this frame ----
   f->n = n;
   f->n_new = n_new;
+  size_t off = align16(sizeof(vo_frame_hdr));
+  f->off_stage = off;  off += align16((size_t)n);
+  f->off_mnew = off;   off += align16((size_t)n_new);
+  f->off_pl1 = off;    off += align16(sizeof(float) * 2 * (size_t)n);
+  f->off_pr1 = off;    off += align16(sizeof(float) * 2 * (size_t)n);
+  f->off_newr = off;   off += align16(sizeof(float) * 2 * (size_t)n_new);
+  f->res_bytes = off;
+  f->hdr = (vo_frame_hdr *)f->res_dev;
+  f->stage = f->res_dev + f->off_stage;
+  f->mNew = f->res_dev + f->off_mnew;
+  f->F_pl1 = (float *)(f->res_dev + f->off_pl1);
+  f->F_pr1 = (float *)(f->res_dev + f->off_pr1);
+  f->new_r = (float *)(f->res_dev + f->off_newr);
+  int *cnt = f->hdr->cnt;
+  VO_CHECK_HIP(c, hipMemsetAsync(f->hdr, 0, sizeof(vo_frame_hdr), s));  // counts, flags
+
   const int W = prm->width, H = prm->height;
   float T_rl[16], T_cp[16];
   inv_se3(prm->T_lr, T_rl);
   inv_se3(dT_prior, T_cp);
-  VO_CHECK_HIP(c, hipMemsetAsync(f->cnt, 0, 8 * sizeof(int), s));
-  VO_CHECK_HIP(c, hipMemcpyAsync(f->dT, dT_prior, 16 * sizeof(float), hipMemcpyHostToDevice, s));
 
   if (n > 0) {
-    VO_CHECK_HIP(c, hipMemsetAsync(f->m1, 1, (size_t)n, s));
-    VO_CHECK_HIP(c, hipMemsetAsync(f->m2, 1, (size_t)n, s));
-    VO_CHECK_HIP(c, hipMemsetAsync(f->m3, 1, (size_t)n, s));
     // [3] priors
     RC(vo_stereo_prior_enqueue(c, d_X, d_l0, d_r0, n, T_cp, T_rl, prm->Kl, prm->Kr, W, H, f->F_pl1, f->F_pr1,
                                f->F_scale, f->F_orig, f->stage));
     // [4] l0 -> l1 ({} criteria, {} minEig)
-    RC(vo_klt_enqueue(c, slot_l0, slot_l1, d_l0, f->F_pl1, n, nullptr, prm->win, prm->max_level,
+    RC(vo_klt_enqueue(c, slot_l0, slot_l1, d_l0, nullptr, f->F_pl1, n, nullptr, prm->win, prm->max_level,
                       VO_KLT_USE_INITIAL_FLOW, 0, 0., 0.f, f->st1, f->e1));
     RC(vo_klt_mask_enqueue(c, 1, n, nullptr, W, H, prm->thres_err, 0.f, d_l0, f->F_pl1, nullptr, f->st1, nullptr,
-                           f->e1, nullptr, f->m1));
+                           f->e1, nullptr, nullptr, f->m1));
     {
       CompactArgsHost h;
       h.mask = f->m1;
       h.n = n;
-      h.d_n_out = &f->cnt[0];
+      h.d_n_out = &cnt[0];
       h.in2[0] = d_l0;      h.out2[0] = f->A_pl0;
       h.in2[1] = f->F_pl1;  h.out2[1] = f->A_pl1;
       h.in2[2] = f->F_pr1;  h.out2[2] = f->A_pr1;
@@ -176,18 +204,18 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
       h.stage_val = 1;
       RC(vo_compact_enqueue(c, h));
     }
-    // [4-1] scale-compensated refinement on the compacted set
-    RC(vo_ic_enqueue(c, slot_l0, slot_l1, f->A_pl0, f->A_scale, f->A_pl1, f->A_ref, f->m2, f->A_touched, f->A_cls,
-                     f->A_lastpu, n, &f->cnt[0]));
+    // [4-1] scale-compensated refinement on the compacted set (entry mask all true)
+    RC(vo_ic_enqueue(c, slot_l0, slot_l1, f->A_pl0, f->A_scale, f->A_pl1, f->A_ref, nullptr, f->m2, f->A_touched,
+                     f->A_cls, f->A_lastpu, n, &cnt[0], &f->hdr->flags));
     if (c->frame_strict_ic)
       RC(vo_ic_strict_enqueue(c, slot_l0, slot_l1, f->A_pl0, f->A_scale, f->A_pl1, f->A_ref, f->m2, f->A_touched,
-                              f->A_cls, f->A_lastpu, n, &f->cnt[0]));
+                              f->A_cls, f->A_lastpu, n, &cnt[0], &f->hdr->flags));
     {
       CompactArgsHost h;
       h.mask = f->m2;
       h.n = n;
-      h.d_n = &f->cnt[0];
-      h.d_n_out = &f->cnt[1];
+      h.d_n = &cnt[0];
+      h.d_n_out = &cnt[1];
       h.in2[0] = f->A_ref;  h.out2[0] = f->B_pl1;
       h.in2[1] = f->A_pr1;  h.out2[1] = f->B_pr1;
       h.in3 = f->A_X;       h.out3 = f->B_X;
@@ -199,16 +227,16 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
       RC(vo_compact_enqueue(c, h));
     }
     // [5] l1 -> r1
-    RC(vo_klt_enqueue(c, slot_l1, slot_r1, f->B_pl1, f->B_pr1, n, &f->cnt[1], prm->win, prm->max_level,
+    RC(vo_klt_enqueue(c, slot_l1, slot_r1, f->B_pl1, nullptr, f->B_pr1, n, &cnt[1], prm->win, prm->max_level,
                       VO_KLT_USE_INITIAL_FLOW, 0, 0., 0.f, f->st1, f->e1));
-    RC(vo_klt_mask_enqueue(c, 1, n, &f->cnt[1], W, H, prm->thres_err, 0.f, f->B_pl1, f->B_pr1, nullptr, f->st1,
-                           nullptr, f->e1, nullptr, f->m3));
+    RC(vo_klt_mask_enqueue(c, 1, n, &cnt[1], W, H, prm->thres_err, 0.f, f->B_pl1, f->B_pr1, nullptr, f->st1,
+                           nullptr, f->e1, nullptr, nullptr, f->m3));
     {
       CompactArgsHost h;
       h.mask = f->m3;
       h.n = n;
-      h.d_n = &f->cnt[1];
-      h.d_n_out = &f->cnt[2];
+      h.d_n = &cnt[1];
+      h.d_n_out = &cnt[2];
       h.in2[0] = f->B_pl1;  h.out2[0] = f->C_pl1;
       h.in2[1] = f->B_pr1;  h.out2[1] = f->C_pr1;
       h.in3 = f->B_X;       h.out3 = f->C_X;
@@ -220,16 +248,16 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
       RC(vo_compact_enqueue(c, h));
     }
   }
-  // [6] stereo pose-only BA on the survivors (T01 init = constant-velocity prior)
-  RC(vo_gn_enqueue(c, true, false, f->C_X, f->C_pl1, f->C_pr1, n, &f->cnt[2], prm->Kl, prm->Kr, prm->T_lr,
-                   prm->thres_poseba, 0, dT_prior, f->dT, f->mG, f->gn));
+  // [6] stereo pose-only BA on the survivors (T01 init = constant-velocity prior; kept on NaN)
+  RC(vo_gn_enqueue(c, true, false, f->C_X, f->C_pl1, f->C_pr1, n, &cnt[2], prm->Kl, prm->Kr, prm->T_lr,
+                   prm->thres_poseba, 0, dT_prior, f->hdr->dT, f->mG, &f->hdr->gn, true));
   if (n > 0) {
     // [7] inlier mask & the y > 660 gate (thres_sampson = 60 in every shipped config)
     CompactArgsHost h;
     h.mask = f->mG;
     h.n = n;
-    h.d_n = &f->cnt[2];
-    h.d_n_out = &f->cnt[3];
+    h.d_n = &cnt[2];
+    h.d_n_out = &cnt[3];
     h.in_i = f->C_orig;
     h.out_i = f->A_orig;  // scratch
     h.stage = f->stage;
@@ -238,24 +266,22 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
     h.gate_thres = 60.0f;
     RC(vo_compact_enqueue(c, h));
   }
-  // [10] new points: forward (defaults), backward (maxLevel-1, initial flow, {} criteria / minEig)
+  // [10] new points: forward (defaults), backward (maxLevel-1, initial flow = pts_new, {} criteria / minEig)
   if (n_new > 0) {
-    VO_CHECK_HIP(c, hipMemsetAsync(f->mNew, 1, (size_t)n_new, s));
-    VO_CHECK_HIP(c, hipMemsetAsync(f->new_r, 0, sizeof(float) * 2 * n_new, s));
-    RC(vo_klt_enqueue(c, slot_l1, slot_r1, d_new, f->new_r, n_new, nullptr, prm->win, prm->max_level, 0, 30, 0.01,
-                      1e-4f, f->st1, f->e1));
-    VO_CHECK_HIP(c, hipMemcpyAsync(f->new_back, d_new, sizeof(float) * 2 * n_new, hipMemcpyDeviceToDevice, s));
-    if (prm->max_level - 1 < 0) VO_FAIL(c, VO_ERR_INVALID, "trackBidirection needs max_level >= 1");
-    RC(vo_klt_enqueue(c, slot_r1, slot_l1, f->new_r, f->new_back, n_new, nullptr, prm->win, prm->max_level - 1,
-                      VO_KLT_USE_INITIAL_FLOW, 0, 0., 0.f, f->st2, f->e2));
+    RC(vo_klt_enqueue(c, slot_l1, slot_r1, d_new, nullptr, f->new_r, n_new, nullptr, prm->win, prm->max_level, 0,
+                      30, 0.01, 1e-4f, f->st1, f->e1));
+    RC(vo_klt_enqueue(c, slot_r1, slot_l1, f->new_r, d_new, f->new_back, n_new, nullptr, prm->win,
+                      prm->max_level - 1, VO_KLT_USE_INITIAL_FLOW, 0, 0., 0.f, f->st2, f->e2));
     RC(vo_klt_mask_enqueue(c, 2, n_new, nullptr, W, H, prm->thres_err, prm->thres_bidirection, d_new, f->new_r,
-                           f->new_back, f->st1, f->st2, f->e1, f->e2, f->mNew));
+                           f->new_back, f->st1, f->st2, f->e1, f->e2, nullptr, f->mNew));
     CompactArgsHost h;
     h.mask = f->mNew;
     h.n = n_new;
-    h.d_n_out = &f->cnt[4];
+    h.d_n_out = &cnt[4];
     RC(vo_compact_enqueue(c, h));
   }
+  // one D2H of the packed block into pinned memory
+  VO_CHECK_HIP(c, hipMemcpyAsync(f->res_host, f->res_dev, f->res_bytes, hipMemcpyDeviceToHost, s));
   f->pending = true;
   return VO_OK;
 }
@@ -265,47 +291,38 @@ extern "C" int vo_stereo_frame_result(vo_ctx *c, float *pts_l1, float *pts_r1, u
                                       vo_gn_info *gn) {
   if (!c || !c->frame || !c->frame->pending) return VO_ERR_INVALID;
   vo_frame_state *f = c->frame;
-  hipStream_t s = c->stream;
   VO_CHECK_HIP(c, hipSetDevice(c->device));
-  const int n = f->n, nn = f->n_new;
-  int cnt[8];
-  int flags = 0;
-  vo_gn_dev_info gi;
-  if (pts_l1 && n) VO_CHECK_HIP(c, hipMemcpyAsync(pts_l1, f->F_pl1, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, s));
-  if (pts_r1 && n) VO_CHECK_HIP(c, hipMemcpyAsync(pts_r1, f->F_pr1, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, s));
-  if (stage && n) VO_CHECK_HIP(c, hipMemcpyAsync(stage, f->stage, (size_t)n, hipMemcpyDeviceToHost, s));
-  if (dT) VO_CHECK_HIP(c, hipMemcpyAsync(dT, f->dT, sizeof(float) * 16, hipMemcpyDeviceToHost, s));
-  if (pts_new_r && nn)
-    VO_CHECK_HIP(c, hipMemcpyAsync(pts_new_r, f->new_r, sizeof(float) * 2 * nn, hipMemcpyDeviceToHost, s));
-  if (mask_new && nn) VO_CHECK_HIP(c, hipMemcpyAsync(mask_new, f->mNew, (size_t)nn, hipMemcpyDeviceToHost, s));
-  VO_CHECK_HIP(c, hipMemcpyAsync(cnt, f->cnt, sizeof(cnt), hipMemcpyDeviceToHost, s));
-  VO_CHECK_HIP(c, hipMemcpyAsync(&gi, f->gn, sizeof(gi), hipMemcpyDeviceToHost, s));
-  VO_CHECK_HIP(c, hipMemcpyAsync(&flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, s));
-  VO_CHECK_HIP(c, hipStreamSynchronize(s));
+  VO_CHECK_HIP(c, hipStreamSynchronize(c->stream));
   f->pending = false;
+  const int n = f->n, nn = f->n_new;
+  const vo_frame_hdr *h = (const vo_frame_hdr *)f->res_host;
+  if (pts_l1 && n) memcpy(pts_l1, f->res_host + f->off_pl1, sizeof(float) * 2 * (size_t)n);
+  if (pts_r1 && n) memcpy(pts_r1, f->res_host + f->off_pr1, sizeof(float) * 2 * (size_t)n);
+  if (stage && n) memcpy(stage, f->res_host + f->off_stage, (size_t)n);
+  if (dT) memcpy(dT, h->dT, sizeof(float) * 16);
+  if (pts_new_r && nn) memcpy(pts_new_r, f->res_host + f->off_newr, sizeof(float) * 2 * (size_t)nn);
+  if (mask_new && nn) memcpy(mask_new, f->res_host + f->off_mnew, (size_t)nn);
   if (counts) {
-    counts->n_l0l1 = cnt[0];
-    counts->n_refine = cnt[1];
-    counts->n_l1r1 = cnt[2];
-    counts->n_inlier = cnt[3];
-    counts->n_new_ok = cnt[4];
-    counts->gn_iterations = gi.iterations;
+    counts->n_l0l1 = h->cnt[0];
+    counts->n_refine = h->cnt[1];
+    counts->n_l1r1 = h->cnt[2];
+    counts->n_inlier = h->cnt[3];
+    counts->n_new_ok = h->cnt[4];
+    counts->gn_iterations = h->gn.iterations;
   }
   if (gn) {
-    gn->iterations = gi.iterations;
-    gn->err = gi.err;
-    gn->delta_err = gi.delta_err;
-    gn->delta_norm = gi.delta_norm;
-    gn->cnt_invalid = gi.cnt_invalid;
-    gn->is_nan = gi.is_nan;
+    gn->iterations = h->gn.iterations;
+    gn->err = h->gn.err;
+    gn->delta_err = h->gn.delta_err;
+    gn->delta_norm = h->gn.delta_norm;
+    gn->cnt_invalid = h->gn.cnt_invalid;
+    gn->is_nan = h->gn.is_nan;
   }
-  if (flags) {
-    VO_CHECK_HIP(c, hipMemsetAsync(c->d_flags, 0, sizeof(int), s));
-    VO_CHECK_HIP(c, hipStreamSynchronize(s));
-    if (flags & 1) VO_FAIL(c, VO_ERR_NAN_AXAY, "ax ay nan");
-    if (flags & 2) VO_FAIL(c, VO_ERR_NAN_PATCH, "I0 I1 / du0 dv0 nan");
+  if (h->flags) {
+    if (h->flags & 1) VO_FAIL(c, VO_ERR_NAN_AXAY, "ax ay nan");
+    if (h->flags & 2) VO_FAIL(c, VO_ERR_NAN_PATCH, "I0 I1 / du0 dv0 nan");
     VO_FAIL(c, VO_ERR_NAN_UPDATE, "dtu dtv nan");
   }
-  if (gi.is_nan) VO_FAIL(c, VO_ERR_GN_FAILED, "PoseOnlyStereoBA is failed!");
+  if (h->gn.is_nan) VO_FAIL(c, VO_ERR_GN_FAILED, "PoseOnlyStereoBA is failed!");
   return VO_OK;
 }

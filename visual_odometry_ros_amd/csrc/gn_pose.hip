@@ -35,7 +35,9 @@ struct GnArgs {
   int variant;
   float T10[16];       // initial T10 (row-major)
   const float *d_T10;  // optional device-side initial T10 (overrides T10)
-  float *T_out;        // 16 floats: T01 on success; untouched if NaN
+  float *T_out;        // 16 floats: T01 on success; untouched if NaN (or T01_init when nan_writes_init)
+  float T01_init[16];
+  int nan_writes_init;
   uint8_t *mask;
   vo_gn_dev_info *info;
 };
@@ -104,92 +106,107 @@ __device__ __forceinline__ void jac_y(float (&Jt)[6], float f, float iz, float f
 }
 
 // ---- lane-0 small dense algebra (same operation order as the oracle) ---------
-__device__ void ldlt6_solve(const float (&Ain)[36], const float (&b)[6], float (&x)[6]) {
+// Eigen LDLT<Matrix<float,6,6>,Lower>: unblocked, symmetric pivoting on the largest
+// remaining |diagonal|. Everything is fully unrolled with compile-time indices; the
+// data-dependent pivot becomes predicated swaps, so the 6x6 lives in registers
+// (no scratch memory on the critical path of every GN iteration).
+__device__ __forceinline__ void swapf(float &a, float &b) {
+  const float t = a;
+  a = b;
+  b = t;
+}
+__device__ __forceinline__ void ldlt6_solve(const float (&Ain)[36], const float (&b)[6], float (&x)[6]) {
   float m[6][6];
   int tr[6];
+#pragma unroll
   for (int i = 0; i < 6; ++i)
+#pragma unroll
     for (int j = 0; j < 6; ++j) m[i][j] = Ain[i * 6 + j];
-  float temp[6];
+#pragma unroll
   for (int k = 0; k < 6; ++k) {
     int piv = k;
     float best = fabsf(m[k][k]);
+#pragma unroll
     for (int i = k + 1; i < 6; ++i) {
-      float a = fabsf(m[i][i]);
+      const float a = fabsf(m[i][i]);
       if (a > best) {
         best = a;
         piv = i;
       }
     }
     tr[k] = piv;
-    if (piv != k) {
-      for (int j = 0; j < k; ++j) {
-        float t = m[k][j];
-        m[k][j] = m[piv][j];
-        m[piv][j] = t;
-      }
-      for (int i = piv + 1; i < 6; ++i) {
-        float t = m[i][k];
-        m[i][k] = m[i][piv];
-        m[i][piv] = t;
-      }
-      {
-        float t = m[k][k];
-        m[k][k] = m[piv][piv];
-        m[piv][piv] = t;
-      }
-      for (int i = k + 1; i < piv; ++i) {
-        float t = m[i][k];
-        m[i][k] = m[piv][i];
-        m[piv][i] = t;
+#pragma unroll
+    for (int p = k + 1; p < 6; ++p) {
+      if (piv == p) {
+#pragma unroll
+        for (int j = 0; j < k; ++j) swapf(m[k][j], m[p][j]);
+#pragma unroll
+        for (int i = p + 1; i < 6; ++i) swapf(m[i][k], m[i][p]);
+        swapf(m[k][k], m[p][p]);
+#pragma unroll
+        for (int i = k + 1; i < p; ++i) swapf(m[i][k], m[p][i]);
       }
     }
-    int rs = 6 - k - 1;
     if (k > 0) {
+      float temp[6];
+#pragma unroll
       for (int j = 0; j < k; ++j) temp[j] = m[j][j] * m[k][j];
       float s = 0.0f;
+#pragma unroll
       for (int j = 0; j < k; ++j) s += m[k][j] * temp[j];
       m[k][k] -= s;
-      for (int i = 0; i < rs; ++i) {
+#pragma unroll
+      for (int i = k + 1; i < 6; ++i) {
         float d = 0.0f;
-        for (int j = 0; j < k; ++j) d += m[k + 1 + i][j] * temp[j];
-        m[k + 1 + i][k] -= d;
+#pragma unroll
+        for (int j = 0; j < k; ++j) d += m[i][j] * temp[j];
+        m[i][k] -= d;
       }
     }
-    float akk = m[k][k];
-    if (fabsf(akk) > 0.0f)
-      for (int i = 0; i < rs; ++i) m[k + 1 + i][k] /= akk;
+    const float akk = m[k][k];
+    if (fabsf(akk) > 0.0f) {
+#pragma unroll
+      for (int i = k + 1; i < 6; ++i) m[i][k] /= akk;
+    }
   }
   float y[6];
+#pragma unroll
   for (int i = 0; i < 6; ++i) y[i] = b[i];
-  for (int k = 0; k < 6; ++k)
-    if (tr[k] != k) {
-      float t = y[k];
-      y[k] = y[tr[k]];
-      y[tr[k]] = t;
-    }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+#pragma unroll
+    for (int p = k + 1; p < 6; ++p)
+      if (tr[k] == p) swapf(y[k], y[p]);
+  }
+#pragma unroll
   for (int i = 0; i < 6; ++i) {
     float s = y[i];
+#pragma unroll
     for (int j = 0; j < i; ++j) s -= m[i][j] * y[j];
     y[i] = s;
   }
   const float tol = 1.17549435e-38f;
+#pragma unroll
   for (int i = 0; i < 6; ++i) {
     if (fabsf(m[i][i]) > tol)
       y[i] /= m[i][i];
     else
       y[i] = 0.0f;
   }
+#pragma unroll
   for (int i = 5; i >= 0; --i) {
     float s = y[i];
+#pragma unroll
     for (int j = i + 1; j < 6; ++j) s -= m[j][i] * y[j];
     y[i] = s;
   }
-  for (int k = 5; k >= 0; --k)
-    if (tr[k] != k) {
-      float t = y[k];
-      y[k] = y[tr[k]];
-      y[tr[k]] = t;
-    }
+#pragma unroll
+  for (int k = 5; k >= 0; --k) {
+#pragma unroll
+    for (int p = k + 1; p < 6; ++p)
+      if (tr[k] == p) swapf(y[k], y[p]);
+  }
+#pragma unroll
   for (int i = 0; i < 6; ++i) x[i] = y[i];
 }
 
@@ -449,6 +466,8 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
       a.T_out[13] = 0;
       a.T_out[14] = 0;
       a.T_out[15] = 1;
+    } else if (a.nan_writes_init) {
+      for (int i = 0; i < 16; ++i) a.T_out[i] = a.T01_init[i];
     }
     if (a.info) {
       a.info->iterations = iter;
@@ -506,7 +525,7 @@ static void inverse4x4_host(const float m[16], float inv[16]) {
 int vo_gn_enqueue(vo_ctx *c, bool stereo, bool mono_general_inverse, const float *dX, const float *dP1,
                   const float *dP2, int n, const int *d_n, const float Kl[4], const float Kr[4],
                   const float T_lr[16], float thres, int variant, const float T01_init[16],
-                  float *d_Tout, uint8_t *d_mask, vo_gn_dev_info *d_info) {
+                  float *d_Tout, uint8_t *d_mask, vo_gn_dev_info *d_info, bool write_init_on_nan) {
   GnArgs a;
   memset(&a, 0, sizeof(a));
   a.X = dX;
@@ -533,6 +552,8 @@ int vo_gn_enqueue(vo_ctx *c, bool stereo, bool mono_general_inverse, const float
   else
     inverse_se3_host(T01_init, a.T10);  // :904
   a.d_T10 = nullptr;
+  memcpy(a.T01_init, T01_init, sizeof(a.T01_init));
+  a.nan_writes_init = write_init_on_nan ? 1 : 0;
   a.T_out = d_Tout;
   a.mask = d_mask;
   a.info = d_info;

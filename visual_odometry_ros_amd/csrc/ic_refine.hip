@@ -46,7 +46,8 @@ struct IcArgs {
   const float *scale;
   const float *pts_prior;  // initial pts_track
   float *pts_track;        // out (pre-set to the prior)
-  uint8_t *mask;           // phase 1: in/out ; strict pass: out
+  const uint8_t *mask_in;  // phase 1: entry mask (null = all true); may alias mask
+  uint8_t *mask;           // out
   uint8_t *touched;        // out (phase 1) / in (strict)
   uint8_t *cls;            // out (phase 1) / in (strict): 0 skipped, 1 template only, 2 iterated
   float *last_pu;          // out (phase 1) / in (strict): last evaluated pt_update
@@ -266,6 +267,7 @@ __device__ int ic_point(const IcArgs &a, int pt, int lane, uint32_t *s_t, IcStat
   if (lane == 0) {
     if (err_flag) {
       atomicOr(a.flags, err_flag);
+      a.mask[pt] = 0;
     } else if (isnan(err_curr)) {
       a.mask[pt] = 0;
     } else if (err_curr <= 30) {
@@ -300,10 +302,13 @@ __global__ __launch_bounds__(64) void ic_refine_kernel(IcArgs a) {
   }
   int cls = 0, touched = 0;
   float lpx = 0.f, lpy = 0.f;
-  if (a.mask[pt]) {
+  const bool entry = a.mask_in ? a.mask_in[pt] != 0 : true;
+  if (entry) {
     IcState S;
     ic_state_clear(S);
     cls = ic_point<false>(a, pt, lane, s_t, S, touched, lpx, lpy);
+  } else if (lane == 0) {
+    a.mask[pt] = 0;
   }
   const int any_t = __any(touched);
   if (lane == 0) {
@@ -369,7 +374,7 @@ __global__ __launch_bounds__(64) void ic_strict_kernel(IcArgs a) {
   }
 }
 
-static int ic_args(vo_ctx *c, int slot0, int slot1, IcArgs &a) {
+static int ic_args(vo_ctx *c, int slot0, int slot1, IcArgs &a, int *d_flags) {
   if (slot0 < 0 || slot0 >= c->cfg.n_slots || slot1 < 0 || slot1 >= c->cfg.n_slots)
     VO_FAIL(c, VO_ERR_INVALID, "slot out of range");
   const vo_pyramid &P0 = c->slots[slot0], &P1 = c->slots[slot1];
@@ -377,18 +382,19 @@ static int ic_args(vo_ctx *c, int slot0, int slot1, IcArgs &a) {
   if (P0.w != P1.w || P0.h != P1.h) VO_FAIL(c, VO_ERR_SIZE, "image size mismatch");
   a.I0 = P0.lv[0];
   a.I1 = P1.lv[0];
-  a.flags = c->d_flags;
+  a.flags = d_flags ? d_flags : c->d_flags;
   return VO_OK;
 }
 
 // pass 1. d_prior and d_pts_track must be different buffers.
 int vo_ic_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, const float *d_scale,
-                  const float *d_prior, float *d_pts_track, uint8_t *d_mask, uint8_t *d_touched, uint8_t *d_cls,
-                  float *d_last_pu, int n_max, const int *d_n) {
+                  const float *d_prior, float *d_pts_track, const uint8_t *d_mask_in, uint8_t *d_mask,
+                  uint8_t *d_touched, uint8_t *d_cls, float *d_last_pu, int n_max, const int *d_n, int *d_flags) {
   if (n_max <= 0) return VO_OK;
   IcArgs a;
   memset(&a, 0, sizeof(a));
-  int rc = ic_args(c, slot0, slot1, a);
+  int rc = ic_args(c, slot0, slot1, a, d_flags);
+  a.mask_in = d_mask_in;
   if (rc) return rc;
   a.pts0 = d_pts0;
   a.scale = d_scale;
@@ -410,11 +416,11 @@ int vo_ic_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, const fl
 // pass 2 (reference-exact border state); consumes pass 1's touched / cls / last_pu.
 int vo_ic_strict_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, const float *d_scale,
                          const float *d_prior, float *d_pts_track, uint8_t *d_mask, uint8_t *d_touched,
-                         uint8_t *d_cls, float *d_last_pu, int n_max, const int *d_n) {
+                         uint8_t *d_cls, float *d_last_pu, int n_max, const int *d_n, int *d_flags) {
   if (n_max <= 0) return VO_OK;
   IcArgs a;
   memset(&a, 0, sizeof(a));
-  int rc = ic_args(c, slot0, slot1, a);
+  int rc = ic_args(c, slot0, slot1, a, d_flags);
   if (rc) return rc;
   a.pts0 = d_pts0;
   a.scale = d_scale;

@@ -37,7 +37,8 @@ struct KltArgs {
   vo_level J[VO_MAX_LEVELS];
   int max_level;  // effective OpenCV maxLevel: levels 0..max_level are used
   const float *pts0;
-  float *pts1;  // in (USE_INITIAL_FLOW) / out
+  float *pts1;             // out (and initial guess when pts1_init is null)
+  const float *pts1_init;  // optional: initial nextPts read from here (USE_INITIAL_FLOW)
   int n;
   const int *d_n;
   int flags;
@@ -109,7 +110,8 @@ __global__ __launch_bounds__(64) void klt_track_kernel(KltArgs a) {
   const float halfWin = (WIN - 1) * 0.5f;
   const float FLT_SCALE = 1.f / (1 << 20);
   const float p0x = a.pts0[2 * pt], p0y = a.pts0[2 * pt + 1];
-  float npx = a.pts1[2 * pt], npy = a.pts1[2 * pt + 1];  // "nextPts[ptidx]"
+  const float *pin = a.pts1_init ? a.pts1_init : a.pts1;
+  float npx = pin[2 * pt], npy = pin[2 * pt + 1];  // "nextPts[ptidx]"
   int status = 1;
   float errv = 0.f;
 
@@ -359,14 +361,15 @@ struct MaskArgs {
   const float *pts0, *pts_track, *pts_back;
   const uint8_t *st_f, *st_b;
   const float *err_f, *err_b;
-  uint8_t *mask;  // in/out
+  const uint8_t *mask_in;  // optional (null = all true)
+  uint8_t *mask;           // out (may alias mask_in)
 };
 __global__ __launch_bounds__(256) void klt_mask_kernel(MaskArgs a) {
   const int n = a.d_n ? *a.d_n : a.n;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float x = a.pts_track[2 * i], y = a.pts_track[2 * i + 1];
-  bool m = a.mask[i] != 0;
+  bool m = a.mask_in ? a.mask_in[i] != 0 : true;
   if (a.mode == 0) {
     m = m && a.st_f[i] > 0 && a.err_f[i] <= a.thres_err;
   } else if (a.mode == 1) {
@@ -396,7 +399,8 @@ static void launch_klt(vo_ctx *c, const KltArgs &a, int grid) {
 
 // Enqueue one calcOpticalFlowPyrLK on device-resident points. n_max bounds the grid
 // when the live count is only known on the device (d_n).
-int vo_klt_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, float *d_pts1, int n_max,
+int vo_klt_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, const float *d_pts1_init,
+                   float *d_pts1, int n_max,
                    const int *d_n, int win, int max_level, int flags, int max_iter, double eps,
                    float min_eig, uint8_t *d_status, float *d_err) {
   if (slot0 < 0 || slot0 >= c->cfg.n_slots || slot1 < 0 || slot1 >= c->cfg.n_slots)
@@ -418,6 +422,7 @@ int vo_klt_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, float *
   a.max_level = eff;
   a.pts0 = d_pts0;
   a.pts1 = d_pts1;
+  a.pts1_init = d_pts1_init;
   a.n = n_max;
   a.d_n = d_n;
   a.flags = flags;
@@ -452,10 +457,10 @@ int vo_klt_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, float *
 int vo_klt_mask_enqueue(vo_ctx *c, int mode, int n_max, const int *d_n, int n_cols, int n_rows,
                         float thres_err, float thres_bidir, const float *pts0, const float *pts_track,
                         const float *pts_back, const uint8_t *st_f, const uint8_t *st_b,
-                        const float *err_f, const float *err_b, uint8_t *mask) {
+                        const float *err_f, const float *err_b, const uint8_t *mask_in, uint8_t *mask) {
   if (n_max <= 0) return VO_OK;
   MaskArgs a = {mode, n_max, d_n, n_cols, n_rows, thres_err, thres_bidir, pts0, pts_track, pts_back,
-                st_f, st_b, err_f, err_b, mask};
+                st_f, st_b, err_f, err_b, mask_in, mask};
   vo_prof_begin(c, VO_K_AUX);
   hipLaunchKernelGGL(klt_mask_kernel, dim3((n_max + 255) / 256), dim3(256), 0, c->stream, a);
   vo_prof_end(c);

@@ -5,7 +5,9 @@
 // modules/imgproc/src/pyramids.cpp; reference call sites
 // core/visual_odometry/feature_tracker.cpp:29,60,69,108,117,186 — eight pyramid
 // builds per stereo frame for three distinct images). Here a slot's pyramid is
-// built once per image and stays in HBM/L2 for every tracker call that uses it.
+// built once per image and stays in HBM/L2 for every tracker call that uses it;
+// the left and right image of a stereo pair are built by the same launches
+// (blockIdx.z selects the image).
 //
 // Layout: level l is a padded u8 plane, VO_PAD pixels of REFLECT_101 border on
 // every side (OpenCV pads by winSize; a fixed VO_PAD >= winSize+9 lets the
@@ -19,23 +21,29 @@
 #include "vo_internal.hpp"
 #include "vo_kernels.hpp"
 
+struct PadArgs {
+  const uint8_t *src[2];
+  uint8_t *dst[2];
+  int w, h, sstride, dstride;
+};
+
 // level 0: copy the source image into the padded plane, REFLECT_101 border.
-__global__ __launch_bounds__(256) void pad_level0_kernel(const uint8_t *__restrict__ src, int w, int h,
-                                                         int sstride, uint8_t *__restrict__ dst_base,
-                                                         int dstride) {
+__global__ __launch_bounds__(256) void pad_level0_kernel(PadArgs a) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;  // dword index within a padded row
   const int py = blockIdx.y;                            // padded row
-  const int pw = w + 2 * VO_PAD;
+  const int pw = a.w + 2 * VO_PAD;
   if (q * 4 >= pw) return;
-  const int y = reflect101_dev(py - VO_PAD, h);
-  const uint8_t *srow = src + (size_t)y * sstride;
+  const uint8_t *__restrict__ src = a.src[blockIdx.z];
+  uint8_t *__restrict__ dst = a.dst[blockIdx.z];
+  const int y = reflect101_dev(py - VO_PAD, a.h);
+  const uint8_t *srow = src + (size_t)y * a.sstride;
   uint32_t v = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int x = reflect101_dev(q * 4 + k - VO_PAD, w);
+    const int x = reflect101_dev(q * 4 + k - VO_PAD, a.w);
     v |= (uint32_t)srow[x] << (8 * k);
   }
-  *(uint32_t *)(dst_base + (size_t)py * dstride + q * 4) = v;
+  *(uint32_t *)(dst + (size_t)py * a.dstride + q * 4) = v;
 }
 
 // cv::pyrDown (5-tap [1 4 6 4 1]/16 both ways, +128 >> 8) of the padded level
@@ -43,10 +51,14 @@ __global__ __launch_bounds__(256) void pad_level0_kernel(const uint8_t *__restri
 // REFLECT_101 extension, so interior outputs read straight through it; border
 // outputs are the pyrDown value at the reflected coordinate (the same bytes
 // copyMakeBorder would copy), recomputed instead of waiting for the interior.
+struct DownArgs {
+  vo_level S[2], D[2];
+};
 __device__ __forceinline__ int pyr_tap5(const uint8_t *p) {
   return (int)p[0] + 4 * (int)p[1] + 6 * (int)p[2] + 4 * (int)p[3] + (int)p[4];
 }
-__global__ __launch_bounds__(256) void pyr_down_kernel(vo_level S, vo_level D) {
+__global__ __launch_bounds__(256) void pyr_down_kernel(DownArgs a) {
+  const vo_level S = a.S[blockIdx.z], D = a.D[blockIdx.z];
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   const int py = blockIdx.y;
   const int pw = D.w + 2 * VO_PAD;
@@ -116,32 +128,54 @@ static void layout_slot(vo_ctx *c, vo_pyramid *P, int w, int h) {
   }
 }
 
-// Build the full pyramid of slot `slot` from a device-resident image. Levels are
-// always built down to the smallest size that is still >= 2x2 and within
-// cfg.max_level; the tracker clips to OpenCV's effective maxLevel per call.
-int vo_pyramid_build(vo_ctx *c, int slot, const uint8_t *d_img, int w, int h, int stride) {
-  if (slot < 0 || slot >= c->cfg.n_slots) VO_FAIL(c, VO_ERR_INVALID, "slot %d out of range", slot);
+// Build the pyramids of one image (d_r == nullptr) or of a stereo pair.
+static int build(vo_ctx *c, int slot_l, const uint8_t *d_l, int slot_r, const uint8_t *d_r, int w, int h,
+                 int stride) {
+  const int nimg = d_r ? 2 : 1;
+  if (slot_l < 0 || slot_l >= c->cfg.n_slots || (d_r && (slot_r < 0 || slot_r >= c->cfg.n_slots || slot_r == slot_l)))
+    VO_FAIL(c, VO_ERR_INVALID, "slot out of range");
   if (w <= 0 || h <= 0 || w > c->cfg.max_width || h > c->cfg.max_height)
     VO_FAIL(c, VO_ERR_CAPACITY, "image %dx%d exceeds vo_config %dx%d", w, h, c->cfg.max_width, c->cfg.max_height);
-  vo_pyramid *P = &c->slots[slot];
-  layout_slot(c, P, w, h);
+  vo_pyramid *P[2] = {&c->slots[slot_l], d_r ? &c->slots[slot_r] : nullptr};
+  for (int i = 0; i < nimg; ++i) layout_slot(c, P[i], w, h);
+  int top = c->cfg.max_level;
+  if (c->pyr_win_hint > 0) top = vo_pyr_levels_host(w, h, c->pyr_win_hint, c->cfg.max_level);
   vo_prof_begin(c, VO_K_PYRAMID);
   {
-    const vo_level &L = P->lv[0];
-    dim3 grid(((L.w + 2 * VO_PAD + 3) / 4 + 255) / 256, L.h + 2 * VO_PAD);
-    hipLaunchKernelGGL(pad_level0_kernel, grid, dim3(256), 0, c->stream, d_img, w, h, stride, L.base, L.stride);
+    PadArgs a;
+    a.src[0] = d_l;
+    a.src[1] = d_r ? d_r : d_l;
+    a.dst[0] = P[0]->lv[0].base;
+    a.dst[1] = d_r ? P[1]->lv[0].base : P[0]->lv[0].base;
+    a.w = w;
+    a.h = h;
+    a.sstride = stride;
+    a.dstride = P[0]->lv[0].stride;
+    dim3 grid(((w + 2 * VO_PAD + 3) / 4 + 255) / 256, h + 2 * VO_PAD, nimg);
+    hipLaunchKernelGGL(pad_level0_kernel, grid, dim3(256), 0, c->stream, a);
   }
   int nl = 1;
-  for (int l = 1; l <= c->cfg.max_level && l < VO_MAX_LEVELS; ++l) {
-    const vo_level &S = P->lv[l - 1];
-    const vo_level &D = P->lv[l];
-    if (S.w < 2 || S.h < 2) break;
-    dim3 grid(((D.w + 2 * VO_PAD + 3) / 4 + 255) / 256, D.h + 2 * VO_PAD);
-    hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(256), 0, c->stream, S, D);
+  for (int l = 1; l <= top && l < VO_MAX_LEVELS; ++l) {
+    DownArgs a;
+    a.S[0] = P[0]->lv[l - 1];
+    a.D[0] = P[0]->lv[l];
+    a.S[1] = d_r ? P[1]->lv[l - 1] : a.S[0];
+    a.D[1] = d_r ? P[1]->lv[l] : a.D[0];
+    if (a.S[0].w < 2 || a.S[0].h < 2) break;
+    dim3 grid(((a.D[0].w + 2 * VO_PAD + 3) / 4 + 255) / 256, a.D[0].h + 2 * VO_PAD, nimg);
+    hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(256), 0, c->stream, a);
     ++nl;
   }
   vo_prof_end(c);
-  P->n_levels = nl;
+  for (int i = 0; i < nimg; ++i) P[i]->n_levels = nl;
   VO_CHECK_HIP(c, hipGetLastError());
   return VO_OK;
+}
+
+int vo_pyramid_build(vo_ctx *c, int slot, const uint8_t *d_img, int w, int h, int stride) {
+  return build(c, slot, d_img, -1, nullptr, w, h, stride);
+}
+int vo_pyramid_build_pair(vo_ctx *c, int slot_l, const uint8_t *d_l, int slot_r, const uint8_t *d_r, int w, int h,
+                          int stride) {
+  return build(c, slot_l, d_l, slot_r, d_r, w, h, stride);
 }

@@ -154,6 +154,11 @@ extern "C" int vo_profile_reset(vo_ctx *c) {
   c->prof_n = 0;
   return VO_OK;
 }
+extern "C" int vo_profile_set_classes(vo_ctx *c, unsigned mask) {
+  if (!c) return VO_ERR_INVALID;
+  c->prof_mask = mask;
+  return VO_OK;
+}
 extern "C" int vo_profile_get(vo_ctx *c, int cls, int *launches, double *total_ms) {
   if (!c || !launches || !total_ms) return VO_ERR_INVALID;
   *launches = 0;
@@ -278,6 +283,20 @@ extern "C" int vo_set_image(vo_ctx *c, int slot, const uint8_t *host, int width,
   return VO_OK;
 }
 
+extern "C" int vo_set_stereo_pair_device(vo_ctx *c, int slot_l, const void *dev_l, int slot_r, const void *dev_r,
+                                         int width, int height, int stride) {
+  if (!c || !dev_l || !dev_r) return VO_ERR_INVALID;
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  return vo_pyramid_build_pair(c, slot_l, (const uint8_t *)dev_l, slot_r, (const uint8_t *)dev_r, width, height,
+                               stride);
+}
+
+extern "C" int vo_set_pyramid_window_hint(vo_ctx *c, int win) {
+  if (!c || win < 0) return VO_ERR_INVALID;
+  c->pyr_win_hint = win;
+  return VO_OK;
+}
+
 extern "C" int vo_swap_slots(vo_ctx *c, int a, int b) {
   if (!c || a < 0 || b < 0 || a >= c->cfg.n_slots || b >= c->cfg.n_slots) return VO_ERR_INVALID;
   vo_pyramid t = c->slots[a];
@@ -314,7 +333,7 @@ extern "C" int vo_klt_track(vo_ctx *c, int slot0, int slot1, const float *pts0, 
     H2D(c->d_pts1, pts1, sizeof(float) * 2 * (size_t)n);
   else
     VO_CHECK_HIP(c, hipMemsetAsync(c->d_pts1, 0, sizeof(float) * 2 * (size_t)n, c->stream));
-  rc = vo_klt_enqueue(c, slot0, slot1, c->d_pts0, c->d_pts1, n, nullptr, win, max_level, flags, max_iter, eps,
+  rc = vo_klt_enqueue(c, slot0, slot1, c->d_pts0, nullptr, c->d_pts1, n, nullptr, win, max_level, flags, max_iter, eps,
                       min_eig_thr, c->d_status, c->d_err);
   if (rc < 0) return rc;
   D2H(pts1, c->d_pts1, sizeof(float) * 2 * (size_t)n);
@@ -345,20 +364,20 @@ static int track_common(vo_ctx *c, int mode, int slot0, int slot1, const float *
     VO_CHECK_HIP(c, hipMemsetAsync(c->d_pts1, 0, pb, c->stream));
   // forward: track()/trackBidirection() use the OpenCV defaults (30, 0.01, minEig 1e-4);
   // the *WithPrior variants pass `{}` criteria and `{}` minEigThreshold (= 0)
-  rc = vo_klt_enqueue(c, slot0, slot1, c->d_pts0, c->d_pts1, n, nullptr, win, max_level,
+  rc = vo_klt_enqueue(c, slot0, slot1, c->d_pts0, nullptr, c->d_pts1, n, nullptr, win, max_level,
                       prior ? VO_KLT_USE_INITIAL_FLOW : 0, 30, 0.01, prior ? 0.f : 1e-4f, c->d_status, c->d_err);
   if (rc < 0) return rc;
   if (mode >= 2) {
     // backward: pts0_backward starts as a copy of pts0; trackBidirection uses maxLevel-1
     VO_CHECK_HIP(c, hipMemcpyAsync(c->d_pts2, c->d_pts0, pb, hipMemcpyDeviceToDevice, c->stream));
     const int ml = (mode == 2) ? max_level - 1 : max_level;
-    rc = vo_klt_enqueue(c, slot1, slot0, c->d_pts1, c->d_pts2, n, nullptr, win, ml, VO_KLT_USE_INITIAL_FLOW, 0,
+    rc = vo_klt_enqueue(c, slot1, slot0, c->d_pts1, nullptr, c->d_pts2, n, nullptr, win, ml, VO_KLT_USE_INITIAL_FLOW, 0,
                         0., 0.f, c->d_status2, c->d_err2);
     if (rc < 0) return rc;
   }
   rc = vo_klt_mask_enqueue(c, mode == 0 ? 0 : (mode == 1 ? 1 : mode), n, nullptr, P0.w, P0.h, thres_err,
                            thres_bidir, c->d_pts0, c->d_pts1, c->d_pts2, c->d_status, c->d_status2, c->d_err,
-                           c->d_err2, c->d_mask);
+                           c->d_err2, c->d_mask, c->d_mask);
   if (rc < 0) return rc;
   D2H(pts_track, c->d_pts1, pb);
   D2H(mask_valid, c->d_mask, (size_t)n);

@@ -70,6 +70,9 @@ struct vo_ctx {
   // profiling
   vo_prof_rec *prof;
   int prof_cap, prof_n;
+  unsigned prof_mask;      // bit per kernel class; 0 = all
+  int prof_open;           // begin() recorded an event that end() must close
+  int pyr_win_hint;        // > 0: build only the levels calcOpticalFlowPyrLK would use for this window
 };
 
 #define VO_CHECK_HIP(ctx, expr)                                                            \
@@ -90,15 +93,18 @@ struct vo_ctx {
 
 // ---- profiling brackets (no-ops unless vo_profile_enable was called) --------
 static inline void vo_prof_begin(vo_ctx *c, int cls) {
-  if (c->prof && c->prof_n < c->prof_cap) {
+  c->prof_open = 0;
+  if (c->prof && c->prof_n < c->prof_cap && (!c->prof_mask || (c->prof_mask & (1u << cls)))) {
     c->prof[c->prof_n].cls = cls;
     (void)hipEventRecord(c->prof[c->prof_n].a, c->stream);
+    c->prof_open = 1;
   }
 }
 static inline void vo_prof_end(vo_ctx *c) {
-  if (c->prof && c->prof_n < c->prof_cap) {
+  if (c->prof_open) {
     (void)hipEventRecord(c->prof[c->prof_n].b, c->stream);
     ++c->prof_n;
+    c->prof_open = 0;
   }
 }
 

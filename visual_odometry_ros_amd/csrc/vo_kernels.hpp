@@ -8,28 +8,32 @@
 int vo_gn_enqueue(vo_ctx *c, bool stereo, bool mono_general_inverse, const float *dX, const float *dP1,
                   const float *dP2, int n, const int *d_n, const float Kl[4], const float Kr[4],
                   const float T_lr[16], float thres, int variant, const float T01_init[16],
-                  float *d_Tout, uint8_t *d_mask, vo_gn_dev_info *d_info);
+                  float *d_Tout, uint8_t *d_mask, vo_gn_dev_info *d_info, bool write_init_on_nan = false);
 
 // pyramid.hip
 int vo_pyr_levels_host(int w, int h, int win, int max_level);
 int vo_pyramid_build(vo_ctx *c, int slot, const uint8_t *d_img, int w, int h, int stride);
+int vo_pyramid_build_pair(vo_ctx *c, int slot_l, const uint8_t *d_l, int slot_r, const uint8_t *d_r, int w, int h,
+                          int stride);
 
 // klt_track.hip
-int vo_klt_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, float *d_pts1, int n_max,
+int vo_klt_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, const float *d_pts1_init,
+                   float *d_pts1, int n_max,
                    const int *d_n, int win, int max_level, int flags, int max_iter, double eps,
                    float min_eig, uint8_t *d_status, float *d_err);
 int vo_klt_mask_enqueue(vo_ctx *c, int mode, int n_max, const int *d_n, int n_cols, int n_rows,
                         float thres_err, float thres_bidir, const float *pts0, const float *pts_track,
                         const float *pts_back, const uint8_t *st_f, const uint8_t *st_b,
-                        const float *err_f, const float *err_b, uint8_t *mask);
+                        const float *err_f, const float *err_b, const uint8_t *mask_in, uint8_t *mask);
 
 // ic_refine.hip
 int vo_ic_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, const float *d_scale,
-                  const float *d_prior, float *d_pts_track, uint8_t *d_mask, uint8_t *d_touched, uint8_t *d_cls,
-                  float *d_last_pu, int n_max, const int *d_n);
+                  const float *d_prior, float *d_pts_track, const uint8_t *d_mask_in, uint8_t *d_mask,
+                  uint8_t *d_touched, uint8_t *d_cls, float *d_last_pu, int n_max, const int *d_n,
+                  int *d_flags = nullptr);
 int vo_ic_strict_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, const float *d_scale,
                          const float *d_prior, float *d_pts_track, uint8_t *d_mask, uint8_t *d_touched,
-                         uint8_t *d_cls, float *d_last_pu, int n_max, const int *d_n);
+                         uint8_t *d_cls, float *d_last_pu, int n_max, const int *d_n, int *d_flags = nullptr);
 
 // misc_kernels.hip
 int vo_hamming_enqueue(vo_ctx *c, const uint8_t *d_a, int na, const uint8_t *d_b, int nb, uint16_t *d_dist);
