@@ -37,6 +37,25 @@ def klt_bytes_per_point_level(win):
     return (win + 2) ** 2 + (win + 1) ** 2
 
 
+def aggregate(frames, seconds, world, device=None):
+    """Whole-job totals: every rank ran `frames` frames of its own stream in `seconds`.
+    One all_gather of {frames, seconds} (RCCL on GPUs, gloo in the CPU test): 16 B per rank.
+    Returns (total frames, max seconds over ranks)."""
+    if world <= 1:
+        return float(frames), float(seconds)
+    import torch
+    import torch.distributed as dist
+    mine = torch.tensor([float(frames), float(seconds)], dtype=torch.float64, device=device)
+    allv = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allv, mine)
+    return sum(float(v[0]) for v in allv), max(float(v[1]) for v in allv)
+
+
+def stream_seed(rank):
+    """Independent image stream per rank (stream s -> GPU s)."""
+    return 2 + rank
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,7 +86,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     # ---- synthetic stream (one independent sequence per rank), rendered on the host ----
-    stream = S.StereoStream(n_u=N_U, n_v=N_V, n_new=N_NEW, seed=2 + rank)
+    stream = S.StereoStream(n_u=N_U, n_v=N_V, n_new=N_NEW, seed=stream_seed(rank))
     F = max(args.frames, 3)
     poses = stream.poses(F)
     imgs = [stream.render_pair(p)[:2] for p in poses]
@@ -141,15 +160,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
 
-    # ---- aggregate over ranks (RCCL all_gather of {frames, seconds}) ----
-    if world > 1:
-        mine = torch.tensor([float(K), dt], dtype=torch.float64, device=dev)
-        allv = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allv, mine)
-        tot_frames = sum(float(v[0]) for v in allv)
-        max_dt = max(float(v[1]) for v in allv)
-    else:
-        tot_frames, max_dt = float(K), dt
+    tot_frames, max_dt = aggregate(K, dt, world, dev)
 
     out = None
     if rank == 0:

@@ -1,0 +1,193 @@
+"""CPU tests of the oracle itself. The reference ships no golden vector for this path
+(parity unpinned), so the restatement is pinned against independent numpy / scipy
+implementations and analytic properties, and against the fixtures in tests/golden/."""
+import os
+
+import numpy as np
+import pytest
+from scipy import linalg, ndimage
+
+from visual_odometry_ros_amd import synthetic as S
+from util import grid_points, image_pair, move_points
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_se3_exp_matches_expm(oracle):
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        xi = rng.normal(0, 0.3, 6)
+        M = np.zeros((4, 4))
+        w = xi[3:]
+        M[:3, :3] = [[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]
+        M[:3, 3] = xi[:3]
+        assert np.abs(oracle.se3_exp(xi) - linalg.expm(M)).max() < 2e-6
+    T = oracle.se3_exp([1, 2, 3, 0, 0, 0])
+    assert np.array_equal(T, np.array([[1, 0, 0, 1], [0, 1, 0, 2], [0, 0, 1, 3], [0, 0, 0, 1]], np.float32))
+
+
+def test_inverse_se3(oracle):
+    T = S.se3_exp([0.3, -0.2, 1.0, 0.1, -0.2, 0.05]).astype(np.float32)
+    assert np.abs(oracle.inverse_se3(T) @ T - np.eye(4)).max() < 1e-6
+
+
+def test_ldlt_matches_numpy_and_pivots(oracle):
+    rng = np.random.default_rng(1)
+    for _ in range(20):
+        A = rng.normal(size=(6, 6))
+        A = A @ A.T + 0.1 * np.eye(6)
+        A = A * rng.uniform(0.1, 100, (6, 1)) * rng.uniform(0.1, 100, (1, 6))
+        A = (A + A.T) / 2
+        b = rng.normal(size=6)
+        x = oracle.ldlt6_solve(A, b)
+        ref = np.linalg.solve(A.astype(np.float32).astype(np.float64), b.astype(np.float32).astype(np.float64))
+        assert np.abs(x - ref).max() / np.abs(ref).max() < 5e-3
+    assert np.array_equal(oracle.ldlt6_solve(np.zeros((6, 6)), np.ones(6)), np.zeros(6, np.float32))
+
+
+def test_gn_noise_free_converges_to_truth(oracle):
+    d = S.two_view_points(n=500, seed=1, noise_px=0.0, outlier_frac=0.0)
+    T0 = np.eye(4, dtype=np.float32)
+    for mode, tw in ((oracle.SUM_SEQ, 0), (oracle.SUM_TREE, 512)):
+        rc, T, mask, info = oracle.gn_pose_stereo(d["X"], d["pts_l"], d["pts_r"], d["K"], d["K"], d["T_lr"],
+                                                  3.0, T0, mode, tw)
+        assert rc == 1 and mask.all() and info.iterations < 10
+        assert np.abs(T - d["T01_true"]).max() < 1e-5
+    rc, R, t, mask, info = oracle.gn_pose_mono(d["X"], d["pts_l"], d["K"], 3, np.eye(3), np.zeros(3))
+    assert rc == 1 and mask.all()
+    assert np.abs(R - d["T01_true"][:3, :3]).max() < 1e-5 and np.abs(t - d["T01_true"][:3, 3]).max() < 1e-4
+
+
+def test_gn_outliers_flagged_and_tree_equals_seq_masks(oracle):
+    d = S.two_view_points(n=500, seed=1)  # BASELINE config 1
+    T0 = np.eye(4, dtype=np.float32)
+    rc, T, mask, info = oracle.gn_pose_stereo(d["X"], d["pts_l"], d["pts_r"], d["K"], d["K"], d["T_lr"], 3.0, T0)
+    assert rc == 1 and np.array_equal(mask, ~d["is_outlier"])
+    rc2, T2, mask2, info2 = oracle.gn_pose_stereo(d["X"], d["pts_l"], d["pts_r"], d["K"], d["K"], d["T_lr"], 3.0,
+                                                  T0, oracle.SUM_TREE, 512)
+    assert np.array_equal(mask, mask2) and np.abs(T - T2).max() < 1e-6
+    assert np.linalg.norm(T - d["T01_true"]) / np.linalg.norm(d["T01_true"]) < 1e-3
+
+
+def test_gn_mono_variants_differ_only_in_err(oracle):
+    d = S.two_view_points(n=300, seed=3)
+    a = oracle.gn_pose_mono(d["X"], d["pts_l"], d["K"], 3, np.eye(3), np.zeros(3), oracle.GN_CORE)
+    b = oracle.gn_pose_mono(d["X"], d["pts_l"], d["K"], 3, np.eye(3), np.zeros(3), oracle.GN_STANDALONE)
+    assert a[4].err != b[4].err  # core adds w*ry^2, standalone ry^2
+    assert np.abs(a[1] - b[1]).max() < 1e-4
+
+
+def _np_pyr_down(img):
+    k = np.array([1, 4, 6, 4, 1], np.int64)
+    p = np.pad(img.astype(np.int64), 2, mode="reflect")
+    h, w = img.shape
+    dh, dw = (h + 1) // 2, (w + 1) // 2
+    out = np.zeros((dh, dw), np.int64)
+    for j in range(5):
+        for i in range(5):
+            out += k[j] * k[i] * p[j:j + 2 * dh:2, i:i + 2 * dw:2][:dh, :dw]
+    return ((out + 128) >> 8).astype(np.uint8)
+
+
+@pytest.mark.parametrize("shape", [(64, 80), (33, 47), (376, 1241)])
+def test_pyr_down_matches_numpy(oracle, shape):
+    img = np.random.default_rng(shape[0]).integers(0, 256, shape, dtype=np.uint8)
+    assert np.array_equal(oracle.pyr_down(img), _np_pyr_down(img))
+
+
+def test_pyramid_level_rule(oracle):
+    assert oracle.pyramid_levels(1241, 376, 21, 6) == 4
+    assert oracle.pyramid_levels(752, 480, 15, 5) == 4
+    assert oracle.pyramid_levels(1241, 376, 21, 2) == 2
+    assert oracle.pyramid_levels(40, 40, 21, 3) == 0
+
+
+def test_scharr_and_sobel_match_scipy(oracle):
+    img = np.random.default_rng(5).integers(0, 256, (50, 70), dtype=np.uint8)
+    f = img.astype(np.int64)
+    sm = ndimage.correlate1d(f, [3, 10, 3], axis=0, mode="mirror")
+    dx = ndimage.correlate1d(sm, [-1, 0, 1], axis=1, mode="mirror")
+    sm = ndimage.correlate1d(f, [3, 10, 3], axis=1, mode="mirror")
+    dy = ndimage.correlate1d(sm, [-1, 0, 1], axis=0, mode="mirror")
+    d = oracle.scharr(img)
+    assert np.array_equal(d[..., 0], dx) and np.array_equal(d[..., 1], dy)
+    du, dv = oracle.sobel3(img)
+    assert np.array_equal(du, ndimage.sobel(f, axis=1, mode="mirror"))
+    assert np.array_equal(dv, ndimage.sobel(f, axis=0, mode="mirror"))
+
+
+def test_klt_recovers_translation_and_bidirection_gate(oracle):
+    motion = dict(dx=5.2, dy=-3.4)
+    img0, img1 = image_pair(300, 400, seed=5, **motion)
+    pts0 = grid_points(300, 400, step=19, margin=30)
+    lv, p1, st, err = oracle.calc_optical_flow_pyr_lk(img0, img1, pts0, None, 21, 3)
+    gt = move_points(pts0.astype(np.float64), img0.shape, **motion)
+    assert lv == 3 and st.all() and np.abs(p1 - gt).max() < 0.05
+    rc, pt, m = oracle.track_bidirection(img0, img1, pts0, 21, 3, 20.0, 0.5)
+    assert m.mean() > 0.95
+    lv, p1, st, err = oracle.calc_optical_flow_pyr_lk(img0, img0, pts0, None, 21, 3)
+    assert st.all() and np.abs(p1 - pts0).max() < 1e-3 and err.max() == 0
+
+
+def test_klt_threads_do_not_change_results(oracle):
+    img0, img1 = image_pair(200, 260, seed=2, dx=1.5, dy=0.7)
+    pts0 = grid_points(200, 260, step=13, margin=3)
+    a = oracle.calc_optical_flow_pyr_lk(img0, img1, pts0, None, 15, 3, n_threads=1)
+    b = oracle.calc_optical_flow_pyr_lk(img0, img1, pts0, None, 15, 3, n_threads=4)
+    for x, y in zip(a[1:], b[1:]):
+        assert np.array_equal(x, y)
+
+
+def test_ic_border_modes_agree_on_interior_points(oracle):
+    motion = dict(dx=2.0, dy=-1.0, scale=1.03)
+    img0, img1 = image_pair(260, 340, seed=4, **motion)
+    pts0 = grid_points(260, 340, step=15, margin=3)
+    gt = move_points(pts0.astype(np.float64), img0.shape, **motion).astype(np.float32)
+    scale = np.full(pts0.shape[0], 1.03, np.float32)
+    rc, pr, mr, tb = oracle.track_with_scale(img0, img1, pts0, scale, gt + 0.6, None, oracle.IC_REFERENCE)
+    rc, pm, mm, tb2 = oracle.track_with_scale(img0, img1, pts0, scale, gt + 0.6, None, oracle.IC_MASKED)
+    assert np.array_equal(tb, tb2) and tb.any() and (~tb).any()
+    first = np.argmax(tb)  # every point before the first border-touching one is unaffected
+    assert np.array_equal(pr[:first], pm[:first])
+    clean = ~tb
+    # an interior point is independent of the carried state in BOTH modes
+    assert np.array_equal(pr[clean], pm[clean]) and np.array_equal(mr[clean], mm[clean])
+    ok = clean & mr
+    assert np.abs(pr[ok] - gt[ok]).max() < 1.0
+
+
+def test_hamming_vs_numpy_popcount(oracle):
+    a = S.random_descriptors(40, seed=1)
+    b = S.random_descriptors(33, seed=2)
+    ref = np.unpackbits(a[:, None, :] ^ b[None, :, :], axis=2).sum(2)
+    assert np.array_equal(oracle.hamming_matrix(a, b), ref)
+    assert oracle.descriptor_distance(a[0], a[0]) == 0
+    assert oracle.descriptor_distance(np.zeros(32, np.uint8), np.full(32, 255, np.uint8)) == 256
+    bi, bd, sd = oracle.hamming_match(a, b, 256, 2.0)
+    assert np.array_equal(bd, ref.min(1)) and np.array_equal(bi, ref.argmin(1))
+    assert np.array_equal(sd, np.sort(ref, 1)[:, 1])
+
+
+def test_compaction_order_is_stable(oracle):
+    mask = np.array([1, 0, 1, 1, 0, 1], bool)
+    alive = np.array([1, 1, 1, 0, 1, 1], bool)
+    idx, tr = oracle.compact_indices(mask, alive, None)
+    assert idx.tolist() == [0, 2, 5] and tr.tolist() == [True, False, True, False, False, True]
+
+
+def test_golden_fixtures_reproduce(oracle):
+    """tests/golden/*.npz were produced by tests/golden/make_golden.py with this oracle; a change in
+    the restatement (or the compiler flags) that moves any bit shows up here."""
+    g = np.load(os.path.join(GOLD, "gn_config1.npz"))
+    rc, T, mask, info = oracle.gn_pose_stereo(g["X"], g["pts_l"], g["pts_r"], g["K"], g["K"], g["T_lr"], 3.0,
+                                              np.eye(4, dtype=np.float32))
+    assert np.array_equal(T, g["T01_seq"]) and np.array_equal(mask, g["mask_seq"])
+    assert info.iterations == int(g["iters_seq"])
+    k = np.load(os.path.join(GOLD, "klt_small.npz"))
+    lv, p1, st, err = oracle.calc_optical_flow_pyr_lk(k["img0"], k["img1"], k["pts0"], None, 21, 3)
+    assert np.array_equal(p1, k["pts1"]) and np.array_equal(st, k["status"]) and np.array_equal(err, k["err"])
+    rc, pt, m, tb = oracle.track_with_scale(k["img0"], k["img1"], k["pts0"], k["scale"], k["prior"], None,
+                                            oracle.IC_REFERENCE, oracle.SUM_SEQ)
+    assert np.array_equal(pt, k["ic_pts"]) and np.array_equal(m, k["ic_mask"])
+    h = np.load(os.path.join(GOLD, "hamming.npz"))
+    assert np.array_equal(oracle.hamming_matrix(h["a"], h["b"]), h["dist"])
