@@ -114,7 +114,7 @@ def main():
 
     n_pts = N_U * N_V
     ctx = V.Context(device=local_rank, max_width=W_, max_height=H_, max_points=max(n_pts, N_NEW) + 64,
-                    n_slots=3, max_level=MAX_LEVEL)
+                    n_slots=5, max_level=MAX_LEVEL)
     prm = make_stereo_params(W_, H_, WIN, MAX_LEVEL, THRES_ERR, THRES_BIDIR, THRES_POSEBA, stream.K, stream.K,
                              stream.T_lr)
     pipe = StereoFramePipeline(ctx, prm, strict_border=bool(args.strict_border))
@@ -124,12 +124,17 @@ def main():
 
     def step(s, keep=None):
         a, b = frame_id(s), frame_id(s + 1)
-        ctx.set_stereo_pair_device(1, d_L[b].data_ptr(), 2, d_R[b].data_ptr(), W_, H_, W_)
         t = d_ts[(a, b)]
         pipe.enqueue_device(t["pts_l0"].data_ptr(), t["pts_r0"].data_ptr(), t["Xp"].data_ptr(), n_pts,
                             track_sets[(a, b)]["dT_prior"], t["pts_new"].data_ptr(), N_NEW)
-        r = pipe.result()  # sync + D2H of pose / survivors: a sequential VO needs them per frame
-        ctx.swap_slots(0, 1)
+        # the NEXT stereo pair does not depend on this frame's result: its pyramids are enqueued
+        # now (slots 3,4) and build while the host waits for / consumes this frame's result
+        nb = frame_id(s + 2)
+        ctx.set_stereo_pair_device(3, d_L[nb].data_ptr(), 4, d_R[nb].data_ptr(), W_, H_, W_)
+        r = pipe.result(copy=keep is not None)  # pose / survivors of THIS frame: a sequential VO needs them
+        ctx.swap_slots(0, 1)  # current left -> previous left
+        ctx.swap_slots(1, 3)  # prefetched pair -> current pair
+        ctx.swap_slots(2, 4)
         if keep is not None:
             keep.append(r)
         return r
@@ -141,6 +146,7 @@ def main():
         ctx.synchronize()
 
     ctx.set_image_device(0, d_L[frame_id(0)].data_ptr(), W_, H_, W_)
+    ctx.set_stereo_pair_device(1, d_L[frame_id(1)].data_ptr(), 2, d_R[frame_id(1)].data_ptr(), W_, H_, W_)
     ctx.synchronize()
     for s in range(args.warmup):
         step(s)
@@ -154,9 +160,8 @@ def main():
     t0 = time.perf_counter()
     for s in range(args.warmup, args.warmup + K):
         r = step(s, results if len(results) < args.cpu_frames else None)
-        c = r["counts"]
         klt_alg_bytes += klt_bytes_per_point_level(WIN) * (
-            (n_pts + c.n_refine) * eff_levels + N_NEW * (eff_levels + eff_levels_bwd))
+            (n_pts + r["counts"].n_refine) * eff_levels + N_NEW * (eff_levels + eff_levels_bwd))
     barrier()
     dt = time.perf_counter() - t0
 

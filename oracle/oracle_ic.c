@@ -26,17 +26,36 @@
 #define IC_LEN (2 * IC_HALF + 1)
 #define IC_MAXELEM (IC_LEN * IC_LEN)
 
-static float tree64(const float *part) {
-  float v[64];
+#define IC_TREE_W 256 /* lanes per point of ic_refine_kernel */
+
+/* diagnostic: dependency depth of the never-reset tap state (REFERENCE mode): depth(P) = 1 + max depth of
+ * the points whose stale tap values P actually read; untouched points have depth 0 */
+static int g_depth_max, g_depth_hist[64];
+void vo_ref_ic_depth_hist(int *out64, int *maxd) {
+  for (int i = 0; i < 64; ++i) out64[i] = g_depth_hist[i];
+  *maxd = g_depth_max;
+  memset(g_depth_hist, 0, sizeof(g_depth_hist));
+  g_depth_max = 0;
+}
+
+/* diagnostic: histogram of IC iterations executed per processed point since the last reset */
+static int g_iter_hist[32];
+void vo_ref_ic_iter_hist(int *out31, int reset) {
+  for (int i = 0; i < 31; ++i) out31[i] = g_iter_hist[i];
+  if (reset) memset(g_iter_hist, 0, sizeof(g_iter_hist));
+}
+
+static float tree_w(const float *part) {
+  float v[IC_TREE_W];
   memcpy(v, part, sizeof(v));
-  for (int n = 1; n < 64; n <<= 1)
-    for (int i = 0; i < 64; i += 2 * n) v[i] = v[i] + v[i + n];
+  for (int n = 1; n < IC_TREE_W; n <<= 1)
+    for (int i = 0; i < IC_TREE_W; i += 2 * n) v[i] = v[i] + v[i + n];
   return v[0];
 }
 
 /* Sum of term[j] over j in [0,n) where use[j]!=0.
- * SEQ: j ascending. TREE: lane l accumulates j=l,l+64,... then a balanced tree
- * over the 64 lane partials. */
+ * SEQ: j ascending. TREE: partial l accumulates j=l,l+256,... then a balanced tree
+ * over the 256 partials (adjacent pairs first). */
 static float masked_sum(const float *term, const uint8_t *use, int n, int mode) {
   if (mode == VO_SUM_SEQ) {
     float s = 0.0f;
@@ -44,14 +63,14 @@ static float masked_sum(const float *term, const uint8_t *use, int n, int mode) 
       if (use[j]) s += term[j];
     return s;
   }
-  float part[64];
-  for (int l = 0; l < 64; ++l) {
+  float part[IC_TREE_W];
+  for (int l = 0; l < IC_TREE_W; ++l) {
     float s = 0.0f;
-    for (int j = l; j < n; j += 64)
+    for (int j = l; j < n; j += IC_TREE_W)
       if (use[j]) s += term[j];
     part[l] = s;
   }
-  return tree64(part);
+  return tree_w(part);
 }
 
 static inline float bilin(const float I1, const float I2, const float I3,
@@ -101,6 +120,9 @@ int vo_ref_track_with_scale(const uint8_t *img0, const uint8_t *img1, int w,
   uint8_t use[IC_MAXELEM];
   float patt_sx[IC_MAXELEM], patt_sy[IC_MAXELEM];
   int rc = 0;
+  int w0[IC_MAXELEM], w1[IC_MAXELEM]; /* diagnostics: last writer point of each tap */
+  int *depth = (int *)calloc((size_t)n + 1, sizeof(int));
+  for (int j = 0; j < IC_MAXELEM; ++j) w0[j] = w1[j] = -1;
 
   for (int i = 0; i < n; ++i) {
     if (touched_border) touched_border[i] = 0;
@@ -126,8 +148,10 @@ int vo_ref_track_with_scale(const uint8_t *img0, const uint8_t *img1, int w,
       int u0 = (int)uc, v0 = (int)vc;
       if (u0 < 1 || u0 >= n_cols - 2 || v0 < 1 || v0 >= n_rows - 2) {
         if (touched_border) touched_border[i] = 1;
+        if (mask_I0[j] && w0[j] >= 0 && w0[j] != i && depth[w0[j]] + 1 > depth[i]) depth[i] = depth[w0[j]] + 1;
         continue;
       }
+      w0[j] = i;
       int idx = v0 * n_cols + u0;
       I0_patt[j] = bilin(I0[idx], I0[idx + 1], I0[idx + n_cols], I0[idx + n_cols + 1], ax, ay, axay);
       du0_patt[j] = bilin(dU[idx], dU[idx + 1], dU[idx + n_cols], dU[idx + n_cols + 1], ax, ay, axay);
@@ -150,7 +174,9 @@ int vo_ref_track_with_scale(const uint8_t *img0, const uint8_t *img1, int w,
 
     float err_curr = 0, err_prev = 1e12;
     float tx = pt1x - pt0x, ty = pt1y - pt0y;
+    int iters_done = 0;
     for (int iter = 0; iter < MAX_ITER; ++iter) {
+      iters_done = iter + 1;
       float pux = pt0x + tx, puy = pt0y + ty;
       ax = (float)((double)pux - floor((double)pux));
       ay = (float)((double)puy - floor((double)puy));
@@ -169,8 +195,10 @@ int vo_ref_track_with_scale(const uint8_t *img0, const uint8_t *img1, int w,
         float uc = pux + patt_sx[j], vc = puy + patt_sy[j];
         if (uc < 1 || uc >= (float)(n_cols - 2) || vc < 1 || vc >= (float)(n_rows - 2)) {
           if (touched_border) touched_border[i] = 1;
+          if (mask_I1[j] && mask_I0[j] && w1[j] >= 0 && w1[j] != i && depth[w1[j]] + 1 > depth[i]) depth[i] = depth[w1[j]] + 1;
           continue;
         }
+        w1[j] = i;
         int u0 = (int)uc, v0 = (int)vc;
         int idx = v0 * n_cols + u0;
         I1_patt[j] = bilin(I1[idx], I1[idx + 1], I1[idx + n_cols], I1[idx + n_cols + 1], ax, ay, axay);
@@ -213,6 +241,9 @@ int vo_ref_track_with_scale(const uint8_t *img0, const uint8_t *img1, int w,
       }
       err_prev = err_curr;
     }
+    g_iter_hist[iters_done > 30 ? 30 : iters_done]++;
+    g_depth_hist[depth[i] > 63 ? 63 : depth[i]]++;
+    if (depth[i] > g_depth_max) g_depth_max = depth[i];
     if (isnan(err_curr)) {
       mask[i] = 0;
     } else if (err_curr <= 30) {
@@ -223,6 +254,7 @@ int vo_ref_track_with_scale(const uint8_t *img0, const uint8_t *img1, int w,
       mask[i] = 0;
   }
 done:
+  free(depth);
   free(I0);
   free(I1);
   free(dU);

@@ -31,6 +31,15 @@
 
 #define W_BITS 14
 
+/* diagnostic: LK iterations executed per point, summed over levels (reset by the reader) */
+static int g_klt_iters[1 << 16];
+void vo_ref_klt_iters(int *out, int n) {
+  for (int i = 0; i < n && i < (1 << 16); ++i) {
+    out[i] = g_klt_iters[i];
+    g_klt_iters[i] = 0;
+  }
+}
+
 static inline int reflect101(int p, int n) {
   if (n == 1) return 0;
   while (p < 0 || p >= n) {
@@ -278,6 +287,7 @@ static void lk_point_level(const lk_level *I, const lk_level *J, const float *pr
   nextPt_y -= halfWin;
   float prevDelta_x = 0, prevDelta_y = 0;
   for (int j = 0; j < max_count; ++j) {
+    if (ptidx < (1 << 16)) g_klt_iters[ptidx]++;
     int inext_x = cv_floor(nextPt_x), inext_y = cv_floor(nextPt_y);
     if (inext_x < -win || inext_x >= J->w || inext_y < -win || inext_y >= J->h) {
       if (level == 0) status[ptidx] = 0;

@@ -339,17 +339,31 @@ class StereoFramePipeline:
             C.cast(C.c_void_p(d_pts_l0), f), C.cast(C.c_void_p(d_pts_r0), f),
             C.cast(C.c_void_p(d_Xp), f), n, _p(dT), C.cast(C.c_void_p(d_pts_new), f), n_new, 1))
 
-    def result(self):
+    def _buffers(self, n, nn):
+        key = (n, nn)
+        if getattr(self, "_buf_key", None) != key:
+            self._buf_key = key
+            self._b = dict(pts_l1=np.zeros((max(n, 1), 2), np.float32), pts_r1=np.zeros((max(n, 1), 2), np.float32),
+                           stage=np.zeros(max(n, 1), np.uint8), dT=np.zeros(16, np.float32),
+                           pnr=np.zeros((max(nn, 1), 2), np.float32), mnew=np.zeros(max(nn, 1), np.uint8),
+                           counts=FrameCounts(), gn=GnInfo())
+            b = self._b
+            self._args = (_p(b["pts_l1"]), _p(b["pts_r1"]), _p(b["stage"], C.c_uint8), _p(b["dT"]), _p(b["pnr"]),
+                          _p(b["mnew"], C.c_uint8), C.byref(b["counts"]), C.byref(b["gn"]))
+        return self._b
+
+    def result(self, copy=True):
+        """Waits for the enqueued frame. copy=False returns views of internal buffers that the
+        next result() overwrites (what a frame-by-frame consumer needs; no allocations)."""
         n, nn = self._n, self._nn
-        pts_l1 = np.zeros((max(n, 1), 2), np.float32)
-        pts_r1 = np.zeros((max(n, 1), 2), np.float32)
-        stage = np.zeros(max(n, 1), np.uint8)
-        dT = np.zeros(16, np.float32)
-        pnr = np.zeros((max(nn, 1), 2), np.float32)
-        mnew = np.zeros(max(nn, 1), np.uint8)
-        counts, gn = FrameCounts(), GnInfo()
-        self.ctx.check(self.lib.vo_stereo_frame_result(
-            self.ctx.handle, _p(pts_l1), _p(pts_r1), _p(stage, C.c_uint8), _p(dT), _p(pnr),
-            _p(mnew, C.c_uint8), C.byref(counts), C.byref(gn)))
-        return dict(pts_l1=pts_l1[:n], pts_r1=pts_r1[:n], stage=stage[:n], dT=dT.reshape(4, 4),
-                    pts_new_r=pnr[:nn], mask_new=mnew[:nn].astype(bool), counts=counts, gn=gn)
+        b = self._buffers(n, nn)
+        self.ctx.check(self.lib.vo_stereo_frame_result(self.ctx.handle, *self._args))
+        out = dict(pts_l1=b["pts_l1"][:n], pts_r1=b["pts_r1"][:n], stage=b["stage"][:n], dT=b["dT"].reshape(4, 4),
+                   pts_new_r=b["pnr"][:nn], mask_new=b["mnew"][:nn].view(bool), counts=b["counts"], gn=b["gn"])
+        if copy:
+            cnt, gn = FrameCounts(), GnInfo()
+            C.memmove(C.byref(cnt), C.byref(b["counts"]), C.sizeof(cnt))
+            C.memmove(C.byref(gn), C.byref(b["gn"]), C.sizeof(gn))
+            out = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in out.items()}
+            out["counts"], out["gn"] = cnt, gn
+        return out

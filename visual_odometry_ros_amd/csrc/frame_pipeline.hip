@@ -45,8 +45,8 @@ struct vo_frame_state {
   float *C_pl1, *C_pr1, *C_X;
   int32_t *C_orig;
   uint8_t *m1, *m2, *m3, *mG;
-  uint8_t *st1, *st2;
-  float *e1, *e2;
+  uint8_t *st1, *st2, *st3;
+  float *e1, *e2, *e3;
   float *new_back;
   // packed result block
   uint8_t *res_dev, *res_host;
@@ -58,6 +58,7 @@ struct vo_frame_state {
   size_t off_stage, off_mnew, off_pl1, off_pr1, off_newr, res_bytes;
   int n, n_new;
   bool pending;
+  hipEvent_t ev_done;  // recorded after the packed D2H: result() waits for this, not for the stream
 };
 
 template <typename T>
@@ -78,15 +79,16 @@ static int frame_init(vo_ctx *c) {
   for (float **p : f2) VO_CHECK_HIP(c, fs_alloc(p, 2 * N));
   float **f3[] = {&f->in_X, &f->A_X, &f->B_X, &f->C_X};
   for (float **p : f3) VO_CHECK_HIP(c, fs_alloc(p, 3 * N));
-  float **f1[] = {&f->F_scale, &f->A_scale, &f->e1, &f->e2};
+  float **f1[] = {&f->F_scale, &f->A_scale, &f->e1, &f->e2, &f->e3};
   for (float **p : f1) VO_CHECK_HIP(c, fs_alloc(p, N));
   int32_t **i1[] = {&f->F_orig, &f->A_orig, &f->B_orig, &f->C_orig};
   for (int32_t **p : i1) VO_CHECK_HIP(c, fs_alloc(p, N));
-  uint8_t **u1[] = {&f->m1, &f->m2, &f->m3, &f->mG, &f->st1, &f->st2, &f->A_touched, &f->A_cls};
+  uint8_t **u1[] = {&f->m1, &f->m2, &f->m3, &f->mG, &f->st1, &f->st2, &f->st3, &f->A_touched, &f->A_cls};
   for (uint8_t **p : u1) VO_CHECK_HIP(c, fs_alloc(p, N));
   f->res_cap = align16(sizeof(vo_frame_hdr)) + 2 * align16(N) + 3 * align16(sizeof(float) * 2 * N);
   VO_CHECK_HIP(c, hipMalloc((void **)&f->res_dev, f->res_cap));
   VO_CHECK_HIP(c, hipHostMalloc((void **)&f->res_host, f->res_cap, hipHostMallocDefault));
+  VO_CHECK_HIP(c, hipEventCreateWithFlags(&f->ev_done, hipEventDisableTiming));
   return VO_OK;
 }
 
@@ -96,10 +98,11 @@ void vo_frame_free(vo_ctx *c) {
   void *bufs[] = {f->in_l0, f->in_r0, f->in_X, f->in_new, f->F_scale, f->F_orig, f->A_pl0, f->A_pl1, f->A_pr1,
                   f->A_X, f->A_scale, f->A_orig, f->B_pl1, f->B_pr1, f->B_X, f->B_orig, f->C_pl1, f->C_pr1,
                   f->C_X, f->C_orig, f->m1, f->m2, f->m3, f->mG, f->st1, f->st2, f->e1, f->e2, f->new_back,
-                  f->A_ref, f->A_lastpu, f->A_touched, f->A_cls, f->res_dev};
+                  f->A_ref, f->A_lastpu, f->A_touched, f->A_cls, f->res_dev, f->st3, f->e3};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   if (f->res_host) (void)hipHostFree(f->res_host);
+  if (f->ev_done) (void)hipEventDestroy(f->ev_done);
   free(f);
   c->frame = nullptr;
 }
@@ -180,18 +183,41 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
   inv_se3(prm->T_lr, T_rl);
   inv_se3(dT_prior, T_cp);
 
+  // [10] new points on the side stream: they depend only on the two new pyramids, not on the
+  // main chain, and the chain's kernels leave most of the chip idle (one wave per point).
+  if (n_new > 0) {
+    VO_CHECK_HIP(c, hipEventRecord(c->ev_fork, s));
+    VO_CHECK_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    c->stream = c->stream2;
+    int rc2 = vo_klt_enqueue(c, slot_l1, slot_r1, d_new, nullptr, f->new_r, n_new, nullptr, prm->win,
+                             prm->max_level, 0, 30, 0.01, 1e-4f, f->st3, f->e3);
+    // backward: maxLevel-1, initial flow = pts_new, {} criteria / minEig (feature_tracker.cpp:69-71)
+    if (rc2 >= 0)
+      rc2 = vo_klt_enqueue(c, slot_r1, slot_l1, f->new_r, d_new, f->new_back, n_new, nullptr, prm->win,
+                           prm->max_level - 1, VO_KLT_USE_INITIAL_FLOW, 0, 0., 0.f, f->st2, f->e2);
+    if (rc2 >= 0)
+      rc2 = vo_klt_mask_enqueue(c, 2, n_new, nullptr, W, H, prm->thres_err, prm->thres_bidirection, d_new,
+                                f->new_r, f->new_back, f->st3, f->st2, f->e3, f->e2, nullptr, f->mNew);
+    c->stream = s;
+    if (rc2 < 0) return rc2;
+    VO_CHECK_HIP(c, hipEventRecord(c->ev_join, c->stream2));
+  }
+
   if (n > 0) {
     // [3] priors
     RC(vo_stereo_prior_enqueue(c, d_X, d_l0, d_r0, n, T_cp, T_rl, prm->Kl, prm->Kr, W, H, f->F_pl1, f->F_pr1,
                                f->F_scale, f->F_orig, f->stage));
-    // [4] l0 -> l1 ({} criteria, {} minEig)
+    // [4] l0 -> l1 ({} criteria, {} minEig); validity mask fused into the compaction
     RC(vo_klt_enqueue(c, slot_l0, slot_l1, d_l0, nullptr, f->F_pl1, n, nullptr, prm->win, prm->max_level,
                       VO_KLT_USE_INITIAL_FLOW, 0, 0., 0.f, f->st1, f->e1));
-    RC(vo_klt_mask_enqueue(c, 1, n, nullptr, W, H, prm->thres_err, 0.f, d_l0, f->F_pl1, nullptr, f->st1, nullptr,
-                           f->e1, nullptr, nullptr, f->m1));
     {
       CompactArgsHost h;
-      h.mask = f->m1;
+      h.klt_status = f->st1;
+      h.klt_err = f->e1;
+      h.klt_pts = f->F_pl1;
+      h.klt_thres_err = prm->thres_err;
+      h.klt_W = W;
+      h.klt_H = H;
       h.n = n;
       h.d_n_out = &cnt[0];
       h.in2[0] = d_l0;      h.out2[0] = f->A_pl0;
@@ -206,7 +232,7 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
     }
     // [4-1] scale-compensated refinement on the compacted set (entry mask all true)
     RC(vo_ic_enqueue(c, slot_l0, slot_l1, f->A_pl0, f->A_scale, f->A_pl1, f->A_ref, nullptr, f->m2, f->A_touched,
-                     f->A_cls, f->A_lastpu, n, &cnt[0], &f->hdr->flags));
+                     f->A_cls, f->A_lastpu, n, &cnt[0], &f->hdr->flags, c->frame_strict_ic != 0));
     if (c->frame_strict_ic)
       RC(vo_ic_strict_enqueue(c, slot_l0, slot_l1, f->A_pl0, f->A_scale, f->A_pl1, f->A_ref, f->m2, f->A_touched,
                               f->A_cls, f->A_lastpu, n, &cnt[0], &f->hdr->flags));
@@ -229,11 +255,14 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
     // [5] l1 -> r1
     RC(vo_klt_enqueue(c, slot_l1, slot_r1, f->B_pl1, nullptr, f->B_pr1, n, &cnt[1], prm->win, prm->max_level,
                       VO_KLT_USE_INITIAL_FLOW, 0, 0., 0.f, f->st1, f->e1));
-    RC(vo_klt_mask_enqueue(c, 1, n, &cnt[1], W, H, prm->thres_err, 0.f, f->B_pl1, f->B_pr1, nullptr, f->st1,
-                           nullptr, f->e1, nullptr, nullptr, f->m3));
     {
       CompactArgsHost h;
-      h.mask = f->m3;
+      h.klt_status = f->st1;
+      h.klt_err = f->e1;
+      h.klt_pts = f->B_pr1;
+      h.klt_thres_err = prm->thres_err;
+      h.klt_W = W;
+      h.klt_H = H;
       h.n = n;
       h.d_n = &cnt[1];
       h.d_n_out = &cnt[2];
@@ -248,40 +277,15 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
       RC(vo_compact_enqueue(c, h));
     }
   }
-  // [6] stereo pose-only BA on the survivors (T01 init = constant-velocity prior; kept on NaN)
+  // [6] stereo pose-only BA on the survivors (T01 init = constant-velocity prior; kept on NaN);
+  // [7] its epilogue marks stage 4 for inliers that pass the y > 660 gate (thres_sampson = 60)
   RC(vo_gn_enqueue(c, true, false, f->C_X, f->C_pl1, f->C_pr1, n, &cnt[2], prm->Kl, prm->Kr, prm->T_lr,
-                   prm->thres_poseba, 0, dT_prior, f->hdr->dT, f->mG, &f->hdr->gn, true));
-  if (n > 0) {
-    // [7] inlier mask & the y > 660 gate (thres_sampson = 60 in every shipped config)
-    CompactArgsHost h;
-    h.mask = f->mG;
-    h.n = n;
-    h.d_n = &cnt[2];
-    h.d_n_out = &cnt[3];
-    h.in_i = f->C_orig;
-    h.out_i = f->A_orig;  // scratch
-    h.stage = f->stage;
-    h.stage_val = 4;
-    h.gate_pts = f->C_pl1;
-    h.gate_thres = 60.0f;
-    RC(vo_compact_enqueue(c, h));
-  }
-  // [10] new points: forward (defaults), backward (maxLevel-1, initial flow = pts_new, {} criteria / minEig)
-  if (n_new > 0) {
-    RC(vo_klt_enqueue(c, slot_l1, slot_r1, d_new, nullptr, f->new_r, n_new, nullptr, prm->win, prm->max_level, 0,
-                      30, 0.01, 1e-4f, f->st1, f->e1));
-    RC(vo_klt_enqueue(c, slot_r1, slot_l1, f->new_r, d_new, f->new_back, n_new, nullptr, prm->win,
-                      prm->max_level - 1, VO_KLT_USE_INITIAL_FLOW, 0, 0., 0.f, f->st2, f->e2));
-    RC(vo_klt_mask_enqueue(c, 2, n_new, nullptr, W, H, prm->thres_err, prm->thres_bidirection, d_new, f->new_r,
-                           f->new_back, f->st1, f->st2, f->e1, f->e2, nullptr, f->mNew));
-    CompactArgsHost h;
-    h.mask = f->mNew;
-    h.n = n_new;
-    h.d_n_out = &cnt[4];
-    RC(vo_compact_enqueue(c, h));
-  }
+                   prm->thres_poseba, 0, dT_prior, f->hdr->dT, f->mG, &f->hdr->gn, true, n > 0 ? f->stage : nullptr,
+                   f->C_orig, 4, 60.0f));
+  if (n_new > 0) VO_CHECK_HIP(c, hipStreamWaitEvent(s, c->ev_join, 0));
   // one D2H of the packed block into pinned memory
   VO_CHECK_HIP(c, hipMemcpyAsync(f->res_host, f->res_dev, f->res_bytes, hipMemcpyDeviceToHost, s));
+  VO_CHECK_HIP(c, hipEventRecord(f->ev_done, s));
   f->pending = true;
   return VO_OK;
 }
@@ -292,7 +296,9 @@ extern "C" int vo_stereo_frame_result(vo_ctx *c, float *pts_l1, float *pts_r1, u
   if (!c || !c->frame || !c->frame->pending) return VO_ERR_INVALID;
   vo_frame_state *f = c->frame;
   VO_CHECK_HIP(c, hipSetDevice(c->device));
-  VO_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+  // wait for THIS frame's results only: work enqueued after it (e.g. the next frame's pyramids)
+  // keeps running
+  VO_CHECK_HIP(c, hipEventSynchronize(f->ev_done));
   f->pending = false;
   const int n = f->n, nn = f->n_new;
   const vo_frame_hdr *h = (const vo_frame_hdr *)f->res_host;
@@ -306,8 +312,12 @@ extern "C" int vo_stereo_frame_result(vo_ctx *c, float *pts_l1, float *pts_r1, u
     counts->n_l0l1 = h->cnt[0];
     counts->n_refine = h->cnt[1];
     counts->n_l1r1 = h->cnt[2];
-    counts->n_inlier = h->cnt[3];
-    counts->n_new_ok = h->cnt[4];
+    int ninl = 0, nnew = 0;
+    const uint8_t *sg = f->res_host + f->off_stage, *mn = f->res_host + f->off_mnew;
+    for (int i = 0; i < n; ++i) ninl += sg[i] == 4;
+    for (int i = 0; i < nn; ++i) nnew += mn[i] != 0;
+    counts->n_inlier = ninl;
+    counts->n_new_ok = nnew;
     counts->gn_iterations = h->gn.iterations;
   }
   if (gn) {

@@ -40,6 +40,12 @@ struct GnArgs {
   int nan_writes_init;
   uint8_t *mask;
   vo_gn_dev_info *info;
+  // optional epilogue of the frame pipeline: stage[orig[i]] = stage_val for every inlier that also
+  // passes the y > 660 gate of stereo_vo.cpp:653-668
+  uint8_t *stage;
+  const int32_t *orig;
+  int stage_val;
+  float gate_thres;
 };
 
 // upper-triangular index of (i,j), i<=j, row-major: matches oracle UT[][]
@@ -229,11 +235,23 @@ __device__ void se3_exp_dev(const float (&xi)[6], float (&T)[16]) {
     bV = 0.5f;
     c = 0.33333333333333333333333333f;
   } else {
-    double th = (double)theta;
-    a = (float)(sin(th) / th);
-    b = (float)((1 - cos(th)) / (double)(theta * theta));
+    // The reference evaluates sin/cos in double and rounds each coefficient to float once.
+    // GN steps are small: below 0.25 rad the double Taylor series (terms to th^13, truncation
+    // < 1e-19) gives the same doubles as libm to within an ulp, at a fraction of the cost.
+    const double th = (double)theta;
+    double sn, cs1;  // sin(th), 1 - cos(th)
+    if (th < 0.25) {
+      const double t2 = th * th;
+      sn = th * (1.0 + t2 * (-1.0 / 6 + t2 * (1.0 / 120 + t2 * (-1.0 / 5040 + t2 * (1.0 / 362880 + t2 * (-1.0 / 39916800 + t2 * (1.0 / 6227020800.0)))))));
+      cs1 = t2 * (0.5 + t2 * (-1.0 / 24 + t2 * (1.0 / 720 + t2 * (-1.0 / 40320 + t2 * (1.0 / 3628800 + t2 * (-1.0 / 479001600.0))))));
+    } else {
+      sn = sin(th);
+      cs1 = 1 - cos(th);
+    }
+    a = (float)(sn / th);
+    b = (float)(cs1 / (double)(theta * theta));
     bV = b;
-    c = (float)((th - sin(th)) / (double)(theta * theta * theta));
+    c = (float)((th - sn) / (double)(theta * theta * theta));
   }
   float R[9], V[9];
   for (int i = 0; i < 9; ++i) {
@@ -447,6 +465,12 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
       break;
     }
   }
+  if (a.stage) {
+    for (int i = tid; i < n; i += GN_T) {
+      const float gate = a.p1[2 * i + 1] > 660 ? 100.f : 0.f;
+      if (a.mask[i] && gate < a.gate_thres) a.stage[a.orig[i]] = (uint8_t)a.stage_val;
+    }
+  }
   if (tid == 0) {
     float s = 0.0f;
     for (int i = 0; i < 16; ++i) s += s_T10[i] * s_T10[i];
@@ -525,7 +549,8 @@ static void inverse4x4_host(const float m[16], float inv[16]) {
 int vo_gn_enqueue(vo_ctx *c, bool stereo, bool mono_general_inverse, const float *dX, const float *dP1,
                   const float *dP2, int n, const int *d_n, const float Kl[4], const float Kr[4],
                   const float T_lr[16], float thres, int variant, const float T01_init[16],
-                  float *d_Tout, uint8_t *d_mask, vo_gn_dev_info *d_info, bool write_init_on_nan) {
+                  float *d_Tout, uint8_t *d_mask, vo_gn_dev_info *d_info, bool write_init_on_nan, uint8_t *d_stage,
+                  const int32_t *d_orig, int stage_val, float gate_thres) {
   GnArgs a;
   memset(&a, 0, sizeof(a));
   a.X = dX;
@@ -557,6 +582,10 @@ int vo_gn_enqueue(vo_ctx *c, bool stereo, bool mono_general_inverse, const float
   a.T_out = d_Tout;
   a.mask = d_mask;
   a.info = d_info;
+  a.stage = d_stage;
+  a.orig = d_orig;
+  a.stage_val = stage_val;
+  a.gate_thres = gate_thres;
   vo_prof_begin(c, VO_K_GN);
   if (stereo)
     hipLaunchKernelGGL(gn_pose_kernel<true>, dim3(1), dim3(GN_T), 0, c->stream, a);

@@ -1,5 +1,5 @@
 // ic_refine.hip — scale-compensated inverse-compositional patch refinement,
-// one gfx950 wavefront per feature point.
+// one 256-lane workgroup (4 wavefronts, one per SIMD of a CU) per feature point.
 //
 // Replaces FeatureTracker::trackWithScale (core/visual_odometry/feature_tracker.cpp:236-504)
 // with its samplers image_processing::interpImage3SameRatio / interpImageSameRatio
@@ -10,11 +10,14 @@
 // level-0 planes already resident for the KLT tracker are read, Sobel is
 // evaluated at the four bilinear corners from a 27-row u8 LDS tile.
 //
-// Mapping: 264 checkerboard taps of the 23x23 window; lane l owns taps
-// j = l, l+64, l+128, l+192 (+256 for l < 8). The template (I0, du0, dv0 per tap)
-// stays in registers for all iterations. Float sums use the canonical order
-// "lane partial over its taps ascending, then balanced tree over the 64 lanes"
-// (oracle VO_SUM_TREE).
+// The kernel is latency-bound (a dependent sample -> reduce -> 2x2 solve chain per
+// iteration, up to 30 iterations per point), so the 264 checkerboard taps of the
+// 23x23 window are spread over 256 lanes: lane t owns tap t, lanes 0..7 also tap
+// 256+t. One iteration is ~50 VALU instructions per lane, a DPP butterfly per
+// wavefront, one LDS exchange of the four wave totals and one s_barrier; every
+// wavefront then solves the 2x2 system redundantly (identical arithmetic).
+// Float sums use the canonical order "256 strided partials (element j -> partial
+// j mod 256), balanced binary tree" — the oracle's VO_SUM_TREE with width 256.
 //
 // Border semantics, two kernels:
 //  * ic_refine_kernel (all points in parallel): a tap whose footprint leaves the
@@ -29,16 +32,27 @@
 //    see that state, and the state after an untouched, iterated ("clean") point
 //    is fully determined by that point alone. So each run of points between two
 //    clean points that contains a touched point is replayed sequentially by one
-//    wavefront, the carried state living in registers (5 taps x 4 values per
-//    lane); runs replay in parallel.
+//    workgroup, the carried state living in registers (one tap per lane); runs
+//    replay in parallel.
 #include "vo_internal.hpp"
 #include "vo_kernels.hpp"
 
 #define IC_HALF 11
 #define IC_NELEM 264
-#define IC_K 5
-#define IC_TW 8    // tile dwords per row (32 bytes)
-#define IC_TH 27   // tile rows
+#define IC_T 256   // lanes per point
+#define IC_NW 4    // wavefronts per point
+#define IC_K 2     // taps per lane: t and (t < 8) 256 + t
+#define IC_TW 8    // template tile dwords per row (32 bytes)
+#define IC_TH 27   // template tile rows
+#define IC_JW 11   // I1 search tile: dwords per row (44 bytes)
+#define IC_JH 40   // I1 search tile rows
+#define IC_MW 9        // mask words per point (264 bits)
+#define IC_MAXRUN 192  // longest run the parallel strict replay handles (else sequential fallback)
+#define IC_ROUNDS 10
+#define IC_JAC_OVF 15
+#ifndef IC_MAX_ITER
+#define IC_MAX_ITER 30  // feature_tracker.cpp:290
+#endif
 
 struct IcArgs {
   vo_level I0, I1;
@@ -54,20 +68,33 @@ struct IcArgs {
   int n;
   const int *d_n;
   int *flags;              // [0] |= 1 ax/ay NaN, |= 2 patch NaN, |= 4 update NaN
+  // per-point tap records for the parallel strict replay (optional; see ic_jacobi_kernel)
+  uint32_t *recW0, *recW1;  // [n][IC_MW] bit j: tap j written by the point's template / I1 samples
+  float *recV0;             // [n][3][IC_NELEM] template values (I0, du, dv) of the written taps
+  float *recV1;             // [n][IC_NELEM] last I1 value the point wrote per tap
+  float *pre1;              // [n][IC_NELEM] I1 pre-state the point last ran with
+  uint32_t *preM;           // [n][IC_MW] its mask
+  int *jac;                 // [r] = records changed in round r ; [IC_JAC_OVF] = run too long
+};
+
+struct IcShared {
+  uint32_t tt[IC_TH * IC_TW];
+  uint32_t tj[IC_JH * IC_JW];
+  float red[2][IC_NW][4];
 };
 
 struct IcState {
   float I0[IC_K], du[IC_K], dv[IC_K], I1[IC_K];
-  bool m0[IC_K], m1[IC_K];
+  unsigned m;  // bit k: template tap k valid (mask_I0) ; bit 8+k: I1 tap k valid (mask_I1)
 };
 
-__device__ __forceinline__ float ic_bilin(float I1, float I2, float I3, float I4, float ax, float ay, float axay) {
-  return ((axay * (((I1 - I2) - I3) + I4) + ax * (-I1 + I2)) + ay * (-I1 + I3)) + I1;
-}
-
-__device__ __forceinline__ void ic_tap_offset(int j, float &px, float &py) {
-  // feature_tracker.cpp:308-320: rows v = 0..22; even rows hold u = 1,3,..,21 (11 taps),
-  // odd rows u = 0,2,..,22 (12 taps)
+// lane-constant tap offsets (feature_tracker.cpp:308-320): rows v = 0..22; even rows hold
+// u = 1,3,..,21 (11 taps), odd rows u = 0,2,..,22 (12 taps)
+struct IcTaps {
+  float px[IC_K], py[IC_K];
+  bool second;  // lanes 0..7 of wavefront 0 own a second tap (256 + t)
+};
+__device__ __forceinline__ void ic_tap_xy(int j, float &px, float &py) {
   const int p = j / 23, r = j - p * 23;
   int u, v;
   if (r < 11) {
@@ -80,16 +107,74 @@ __device__ __forceinline__ void ic_tap_offset(int j, float &px, float &py) {
   px = (float)(u - IC_HALF);
   py = (float)(v - IC_HALF);
 }
+__device__ __forceinline__ IcTaps ic_make_taps(int t) {
+  IcTaps tp;
+  ic_tap_xy(t, tp.px[0], tp.py[0]);
+  tp.second = t < IC_NELEM - IC_T;
+  ic_tap_xy(tp.second ? IC_T + t : 0, tp.px[1], tp.py[1]);
+  return tp;
+}
+
+__device__ __forceinline__ float ic_bilin(float I1, float I2, float I3, float I4, float ax, float ay, float axay) {
+  return ((axay * (((I1 - I2) - I3) + I4) + ax * (-I1 + I2)) + ay * (-I1 + I3)) + I1;
+}
 
 __device__ __forceinline__ int ic_safe_int(float v) {
   return (int)fminf(fmaxf(v, -1.0e6f), 1.0e6f);
 }
 
+// Block-wide sums of four per-lane values in the canonical tree order; every lane of every
+// wavefront returns the same bits. `buf` alternates so that one barrier per call suffices.
+__device__ __forceinline__ void ic_block_sum4(float (&v)[4], IcShared &sh, int &buf, int lane, int wave) {
+  float w[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) w[q] = wave_sum_f32(v[q]);
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sh.red[buf][wave][q] = w[q];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    v[q] = (sh.red[buf][0][q] + sh.red[buf][1][q]) + (sh.red[buf][2][q] + sh.red[buf][3][q]);
+  buf ^= 1;
+}
+
+// one template tap: 4x4 neighbourhood (u0-1..u0+2, v0-1..v0+2) from the LDS tile
+__device__ __forceinline__ void ic_template_tap(const uint32_t *s_t, int bx, int by, float ax, float ay, float axay,
+                                                float &nI, float &nu, float &nv) {
+  const int dwo = bx >> 2, sh = bx & 3;
+  int b[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint32_t w0 = s_t[(by + r) * IC_TW + dwo];
+    const uint32_t w1 = s_t[(by + r) * IC_TW + min(dwo + 1, IC_TW - 1)];
+    const uint32_t v = __builtin_amdgcn_alignbyte(w1, w0, sh);
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) b[r][cc] = (int)((v >> (8 * cc)) & 0xFFu);
+  }
+  float Iv[2][2], du[2][2], dv[2][2];
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+      Iv[jj][ii] = (float)b[1 + jj][1 + ii];
+      du[jj][ii] = (float)((b[jj][ii + 2] - b[jj][ii]) + 2 * (b[jj + 1][ii + 2] - b[jj + 1][ii]) +
+                           (b[jj + 2][ii + 2] - b[jj + 2][ii]));
+      dv[jj][ii] = (float)((b[jj + 2][ii] - b[jj][ii]) + 2 * (b[jj + 2][ii + 1] - b[jj][ii + 1]) +
+                           (b[jj + 2][ii + 2] - b[jj][ii + 2]));
+    }
+  nI = ic_bilin(Iv[0][0], Iv[0][1], Iv[1][0], Iv[1][1], ax, ay, axay);
+  nu = ic_bilin(du[0][0], du[0][1], du[1][0], du[1][1], ax, ay, axay);
+  nv = ic_bilin(dv[0][0], dv[0][1], dv[1][0], dv[1][1], ax, ay, axay);
+}
+
 // interpImage3SameRatio on the taps of this lane: writes state where the tap is valid.
 // STRICT: mask bits are sticky (never reset); otherwise they are this evaluation's validity.
 template <bool STRICT>
-__device__ __forceinline__ void ic_template(const vo_level &L0, float pt0x, float pt0y, float ax, float ay,
-                                            float axay, int lane, uint32_t *s_t, IcState &S, int &touched) {
+__device__ __forceinline__ void ic_template(const vo_level &L0, const IcTaps &tp, float pt0x, float pt0y, float ax,
+                                            float ay, float axay, int t, int wave, IcShared &sh, IcState &S,
+                                            int &touched) {
   const int W = L0.w, H = L0.h;
   const int cx = ic_safe_int(pt0x), cy = ic_safe_int(pt0y);
   int tox = (cx - 13) & ~3;
@@ -99,115 +184,134 @@ __device__ __forceinline__ void ic_template(const vo_level &L0, float pt0x, floa
   {
     const uint8_t *g = L0.origin() + (ptrdiff_t)toy * L0.stride + tox;
     __syncthreads();
-    for (int i = lane; i < IC_TH * IC_TW; i += 64) {
-      const int r = i / IC_TW, cdw = i - r * IC_TW;
-      s_t[i] = *(const uint32_t *)(g + (ptrdiff_t)r * L0.stride + cdw * 4);
+    if (t < IC_TH * IC_TW) {
+      const int r = t / IC_TW, cdw = t - r * IC_TW;
+      sh.tt[t] = *(const uint32_t *)(g + (ptrdiff_t)r * L0.stride + cdw * 4);
     }
     __syncthreads();
   }
-#pragma unroll
-  for (int k = 0; k < IC_K; ++k) {
-    const int j = lane + 64 * k;
-    const bool on = j < IC_NELEM;
-    float px = 0.f, py = 0.f;
-    if (on) ic_tap_offset(j, px, py);
-    const float uc = pt0x + px, vc = pt0y + py;
+  if (!STRICT) S.m &= ~0x3u;
+  {
+    const float uc = pt0x + tp.px[0], vc = pt0y + tp.py[0];
     const int u0 = (int)uc, v0 = (int)vc;
-    const bool valid = on && !(u0 < 1 || u0 >= W - 2 || v0 < 1 || v0 >= H - 2);
-    if (on && !valid) touched = 1;
-    if (!STRICT) S.m0[k] = valid;
-    if (valid) {
-      // 4x4 neighbourhood (u0-1..u0+2, v0-1..v0+2)
-      const int bx = (u0 - 1) - tox, by = (v0 - 1) - toy;
-      const int dwo = bx >> 2, sh = bx & 3;
-      int b[4][4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const uint32_t w0 = s_t[(by + r) * IC_TW + dwo];
-        const uint32_t w1 = s_t[(by + r) * IC_TW + min(dwo + 1, IC_TW - 1)];
-        const uint32_t v = __builtin_amdgcn_alignbyte(w1, w0, sh);
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) b[r][cc] = (int)((v >> (8 * cc)) & 0xFFu);
-      }
-      float Iv[2][2], du[2][2], dv[2][2];
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-          Iv[jj][ii] = (float)b[1 + jj][1 + ii];
-          du[jj][ii] = (float)((b[jj][ii + 2] - b[jj][ii]) + 2 * (b[jj + 1][ii + 2] - b[jj + 1][ii]) +
-                               (b[jj + 2][ii + 2] - b[jj + 2][ii]));
-          dv[jj][ii] = (float)((b[jj + 2][ii] - b[jj][ii]) + 2 * (b[jj + 2][ii + 1] - b[jj][ii + 1]) +
-                               (b[jj + 2][ii + 2] - b[jj][ii + 2]));
-        }
-      S.I0[k] = ic_bilin(Iv[0][0], Iv[0][1], Iv[1][0], Iv[1][1], ax, ay, axay);
-      S.du[k] = ic_bilin(du[0][0], du[0][1], du[1][0], du[1][1], ax, ay, axay);
-      S.dv[k] = ic_bilin(dv[0][0], dv[0][1], dv[1][0], dv[1][1], ax, ay, axay);
-      S.m0[k] = true;
-    }
+    const bool valid = !(u0 < 1 || u0 >= W - 2 || v0 < 1 || v0 >= H - 2);
+    if (!valid) touched = 1;
+    float nI, nu, nv;
+    ic_template_tap(sh.tt, valid ? (u0 - 1) - tox : 0, valid ? (v0 - 1) - toy : 0, ax, ay, axay, nI, nu, nv);
+    S.I0[0] = valid ? nI : S.I0[0];
+    S.du[0] = valid ? nu : S.du[0];
+    S.dv[0] = valid ? nv : S.dv[0];
+    if (valid) S.m |= 0x10001u;  // bit 16+k: written by THIS point
+  }
+  if (wave == 0) {  // taps 256..263 live on lanes 0..7 of wavefront 0
+    const float uc = pt0x + tp.px[1], vc = pt0y + tp.py[1];
+    const int u0 = (int)uc, v0 = (int)vc;
+    const bool valid = tp.second && !(u0 < 1 || u0 >= W - 2 || v0 < 1 || v0 >= H - 2);
+    if (tp.second && !valid) touched = 1;
+    float nI, nu, nv;
+    ic_template_tap(sh.tt, valid ? (u0 - 1) - tox : 0, valid ? (v0 - 1) - toy : 0, ax, ay, axay, nI, nu, nv);
+    S.I0[1] = valid ? nI : S.I0[1];
+    S.du[1] = valid ? nu : S.du[1];
+    S.dv[1] = valid ? nv : S.dv[1];
+    if (valid) S.m |= 0x20002u;
   }
 }
 
-// interpImageSameRatio (float compares) on the taps of this lane
+// I1 search tile: 40 rows x 44 B of the current image around the prior position, staged once per
+// point; taps that fall outside it (large drift or scale) fall back to global loads per lane.
+struct IcTile {
+  int x0, y0;  // image coordinates of tile byte (0,0); x0 is 4-byte aligned in memory
+};
+__device__ __forceinline__ IcTile ic_load_I1_tile(const vo_level &L1, float cxf, float cyf, int t, IcShared &sh) {
+  IcTile tl;
+  const int cx = ic_safe_int(cxf), cy = ic_safe_int(cyf);
+  tl.x0 = (cx - 19) & ~3;
+  tl.y0 = cy - 19;
+  tl.x0 = max(-VO_PAD, min(tl.x0, ((L1.w + VO_PAD - IC_JW * 4) & ~3)));
+  tl.y0 = max(-VO_PAD, min(tl.y0, L1.h + VO_PAD - IC_JH));
+  const uint8_t *g = L1.origin() + (ptrdiff_t)tl.y0 * L1.stride + tl.x0;
+  __syncthreads();
+  for (int i = t; i < IC_JH * IC_JW; i += IC_T) {
+    const int r = i / IC_JW, cdw = i - r * IC_JW;
+    sh.tj[i] = *(const uint32_t *)(g + (ptrdiff_t)r * L1.stride + cdw * 4);
+  }
+  __syncthreads();
+  return tl;
+}
+
+// one I1 tap (interpImageSameRatio: float compares). Returns validity; `val` only if valid.
+__device__ __forceinline__ bool ic_I1_tap(const vo_level &L1, bool on, float uc, float vc, float ax, float ay,
+                                          float axay, const IcTile &tile, const uint8_t *sb, float &val) {
+  const bool valid = on && !(uc < 1 || uc >= (float)(L1.w - 2) || vc < 1 || vc >= (float)(L1.h - 2));
+  const int u0 = (int)uc, v0 = (int)vc;
+  const int lx = u0 - tile.x0, ly = v0 - tile.y0;
+  const bool inside = valid && (unsigned)lx < (unsigned)(IC_JW * 4 - 1) && (unsigned)ly < (unsigned)(IC_JH - 1);
+  const uint8_t *q = sb + (inside ? ly * (IC_JW * 4) + lx : 0);
+  val = ic_bilin((float)q[0], (float)q[1], (float)q[IC_JW * 4], (float)q[IC_JW * 4 + 1], ax, ay, axay);
+  if (valid && !inside) {  // rare: the window left the staged tile
+    const uint8_t *p = L1.origin() + (ptrdiff_t)v0 * L1.stride + u0;
+    val = ic_bilin((float)p[0], (float)p[1], (float)p[L1.stride], (float)p[L1.stride + 1], ax, ay, axay);
+  }
+  return valid;
+}
+
 template <bool STRICT>
-__device__ __forceinline__ void ic_sample_I1(const vo_level &L1, float pux, float puy, float scale, float ax,
-                                             float ay, float axay, int lane, IcState &S, int &touched) {
-  const int W = L1.w, H = L1.h;
-  const uint8_t *o1 = L1.origin();
-  const int st1 = L1.stride;
-#pragma unroll
-  for (int k = 0; k < IC_K; ++k) {
-    const int j = lane + 64 * k;
-    const bool on = j < IC_NELEM;
-    float px = 0.f, py = 0.f;
-    if (on) ic_tap_offset(j, px, py);
-    const float uc = pux + px * scale, vc = puy + py * scale;
-    const bool valid = on && !(uc < 1 || uc >= (float)(W - 2) || vc < 1 || vc >= (float)(H - 2));
-    if (on && !valid) touched = 1;
-    if (!STRICT) S.m1[k] = valid;
-    if (valid) {
-      const int u0 = (int)uc, v0 = (int)vc;
-      const uint8_t *p = o1 + (ptrdiff_t)v0 * st1 + u0;
-      S.I1[k] = ic_bilin((float)p[0], (float)p[1], (float)p[st1], (float)p[st1 + 1], ax, ay, axay);
-      S.m1[k] = true;
-    }
+__device__ __forceinline__ void ic_sample_I1(const vo_level &L1, const IcTaps &tp, float scale, float pux, float puy,
+                                             float ax, float ay, float axay, int wave, IcState &S, int &touched,
+                                             const IcTile &tile, const IcShared &sh) {
+  const uint8_t *sb = (const uint8_t *)sh.tj;
+  if (!STRICT) S.m &= ~0x300u;
+  {
+    float val;
+    const bool valid = ic_I1_tap(L1, true, pux + tp.px[0] * scale, puy + tp.py[0] * scale, ax, ay, axay, tile, sb, val);
+    if (!valid) touched = 1;
+    S.I1[0] = valid ? val : S.I1[0];
+    if (valid) S.m |= 0x1000100u;  // bit 24+k: written by THIS point
+  }
+  if (wave == 0) {
+    float val;
+    const bool valid =
+        ic_I1_tap(L1, tp.second, pux + tp.px[1] * scale, puy + tp.py[1] * scale, ax, ay, axay, tile, sb, val);
+    if (tp.second && !valid) touched = 1;
+    S.I1[1] = valid ? val : S.I1[1];
+    if (valid) S.m |= 0x2000200u;
   }
 }
 
 __device__ __forceinline__ void ic_frac(float x, float y, float &ax, float &ay, float &axay) {
-  ax = (float)((double)x - floor((double)x));
-  ay = (float)((double)y - floor((double)y));
+  // pt - floor(pt) (feature_tracker.cpp:355-356, :404-405); exact in float
+  ax = x - floorf(x);
+  ay = y - floorf(y);
   axay = ax * ay;
 }
 
 // One point, feature_tracker.cpp:336-503. Returns cls (1 template only, 2 iterated).
 template <bool STRICT>
-__device__ int ic_point(const IcArgs &a, int pt, int lane, uint32_t *s_t, IcState &S, int &touched,
-                        float &last_pux, float &last_puy) {
+__device__ int ic_point(const IcArgs &a, const IcTaps &tp, int pt, int t, int lane, int wave, IcShared &sh, int &buf,
+                        IcState &S, int &touched, float &last_pux, float &last_puy) {
   const float pt0x = a.pts0[2 * pt], pt0y = a.pts0[2 * pt + 1];
   const float pt1x = a.pts_prior[2 * pt], pt1y = a.pts_prior[2 * pt + 1];
   const float scale = a.scale[pt];
   float ax, ay, axay;
   ic_frac(pt0x, pt0y, ax, ay, axay);
   if (ax < 0 || ax > 1 || ay < 0 || ay > 1) {
-    if (lane == 0) a.mask[pt] = 0;
+    if (t == 0) a.mask[pt] = 0;
     return 1;
   }
-  ic_template<STRICT>(a.I0, pt0x, pt0y, ax, ay, axay, lane, s_t, S, touched);
-  float pA11 = 0.f, pA12 = 0.f, pA22 = 0.f;
+  ic_template<STRICT>(a.I0, tp, pt0x, pt0y, ax, ay, axay, t, wave, sh, S, touched);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int k = 0; k < IC_K; ++k)
-    if (S.m0[k]) {
-      pA11 += S.du[k] * S.du[k];
-      pA12 += S.du[k] * S.dv[k];
-      pA22 += S.dv[k] * S.dv[k];
+    if ((S.m >> k) & 1u) {
+      acc[0] += S.du[k] * S.du[k];
+      acc[1] += S.du[k] * S.dv[k];
+      acc[2] += S.dv[k] * S.dv[k];
     }
-  const float A11 = wave_sum_f32(pA11);
-  const float A12 = wave_sum_f32(pA12);
-  const float A22 = wave_sum_f32(pA22);
+  ic_block_sum4(acc, sh, buf, lane, wave);
+  const float A11 = acc[0], A12 = acc[1], A22 = acc[2];
   const float D = A11 * A22 - A12 * A12;
   if (D < 1e-4f) {
-    if (lane == 0) a.mask[pt] = 0;
+    if (t == 0) a.mask[pt] = 0;
     return 1;
   }
   const float invD = (float)(1.0 / (double)D);
@@ -216,7 +320,8 @@ __device__ int ic_point(const IcArgs &a, int pt, int lane, uint32_t *s_t, IcStat
   float err_curr = 0.f, err_prev = 1e12f;
   float tx = pt1x - pt0x, ty = pt1y - pt0y;
   int err_flag = 0;
-  for (int iter = 0; iter < 30; ++iter) {
+  const IcTile tile = ic_load_I1_tile(a.I1, pt1x, pt1y, t, sh);
+  for (int iter = 0; iter < IC_MAX_ITER; ++iter) {
     const float pux = pt0x + tx, puy = pt0y + ty;
     ic_frac(pux, puy, ax, ay, axay);
     if (ax < 0 || ax > 1 || ay < 0 || ay > 1) break;  // :407-411 (mask is overwritten below, as in the reference)
@@ -226,27 +331,26 @@ __device__ int ic_point(const IcArgs &a, int pt, int lane, uint32_t *s_t, IcStat
     }
     last_pux = pux;
     last_puy = puy;
-    ic_sample_I1<STRICT>(a.I1, pux, puy, scale, ax, ay, axay, lane, S, touched);
-    float pb1 = 0.f, pb2 = 0.f, pe = 0.f;
-    int cnt = 0, nanp = 0;
+    ic_sample_I1<STRICT>(a.I1, tp, scale, pux, puy, ax, ay, axay, wave, S, touched, tile, sh);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};  // b1, b2, sum r^2, count
 #pragma unroll
     for (int k = 0; k < IC_K; ++k)
-      if (S.m0[k] && S.m1[k]) {
-        if (isnan(S.I0[k]) || isnan(S.I1[k]) || isnan(S.du[k]) || isnan(S.dv[k])) nanp = 1;
+      if (((S.m >> k) & (S.m >> (8 + k))) & 1u) {
         const float r = S.I1[k] - S.I0[k];
-        pb1 += S.du[k] * r;
-        pb2 += S.dv[k] * r;
-        pe += r * r;
-        ++cnt;
+        v[0] += S.du[k] * r;
+        v[1] += S.dv[k] * r;
+        v[2] += r * r;
+        v[3] += 1.0f;
       }
-    if (__any(nanp)) {
+    ic_block_sum4(v, sh, buf, lane, wave);
+    // the reference throws "I0 I1 nan" / "du0 dv0 nan" when a used tap is NaN (:438-448); such a
+    // NaN reaches every sum, so test the sums (all inputs are finite u8-derived values otherwise)
+    if (isnan(v[0]) || isnan(v[1]) || isnan(v[2])) {
       err_flag |= 2;
       break;
     }
-    const float b1 = wave_sum_f32(pb1);
-    const float b2 = wave_sum_f32(pb2);
-    err_curr = wave_sum_f32(pe);
-    const int cnt_valid = wave_sum_i32(cnt);
+    const float b1 = v[0], b2 = v[1];
+    err_curr = v[2];
     const float dtu = (-iD_A22 * b1 + iD_A12 * b2);
     const float dtv = (iD_A12 * b1 - iD_A11 * b2);
     if (isnan(dtu + dtv)) {
@@ -255,7 +359,7 @@ __device__ int ic_point(const IcArgs &a, int pt, int lane, uint32_t *s_t, IcStat
     }
     tx += dtu;
     ty += dtv;
-    err_curr /= (float)cnt_valid;
+    err_curr /= v[3];
     err_curr = sqrtf(err_curr);
     const float err_rate = fabsf(err_prev - err_curr) / err_prev;
     const float dt_norm = dtu * dtu + dtv * dtv;
@@ -264,7 +368,7 @@ __device__ int ic_point(const IcArgs &a, int pt, int lane, uint32_t *s_t, IcStat
     }
     err_prev = err_curr;
   }
-  if (lane == 0) {
+  if (t == 0) {
     if (err_flag) {
       atomicOr(a.flags, err_flag);
       a.mask[pt] = 0;
@@ -283,35 +387,40 @@ __device__ int ic_point(const IcArgs &a, int pt, int lane, uint32_t *s_t, IcStat
 
 __device__ __forceinline__ void ic_state_clear(IcState &S) {
 #pragma unroll
-  for (int k = 0; k < IC_K; ++k) {
-    S.I0[k] = S.du[k] = S.dv[k] = S.I1[k] = 0.f;
-    S.m0[k] = S.m1[k] = false;
-  }
+  for (int k = 0; k < IC_K; ++k) S.I0[k] = S.du[k] = S.dv[k] = S.I1[k] = 0.f;
+  S.m = 0;
 }
 
+__device__ __forceinline__ void ic_store_records(const IcArgs &a, int pt, int t, int lane, int wave, const IcTaps &tp,
+                                                 const IcState &S, int cls);
+
 // ---- pass 1: every point in parallel -------------------------------------------
-__global__ __launch_bounds__(64) void ic_refine_kernel(IcArgs a) {
-  __shared__ uint32_t s_t[IC_TH * IC_TW];
+__global__ __launch_bounds__(IC_T) void ic_refine_kernel(IcArgs a) {
+  __shared__ IcShared sh;
   const int n = a.d_n ? *a.d_n : a.n;
   const int pt = blockIdx.x;
   if (pt >= n) return;
-  const int lane = threadIdx.x;
-  if (lane == 0) {
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  if (t == 0) {
     a.pts_track[2 * pt] = a.pts_prior[2 * pt];
     a.pts_track[2 * pt + 1] = a.pts_prior[2 * pt + 1];
   }
-  int cls = 0, touched = 0;
+  int cls = 0, touched = 0, buf = 0;
   float lpx = 0.f, lpy = 0.f;
+  const IcTaps tp = ic_make_taps(t);
   const bool entry = a.mask_in ? a.mask_in[pt] != 0 : true;
+  if (a.jac && pt == 0 && t < 16) a.jac[t] = 0;
+  IcState S;
+  ic_state_clear(S);
   if (entry) {
-    IcState S;
-    ic_state_clear(S);
-    cls = ic_point<false>(a, pt, lane, s_t, S, touched, lpx, lpy);
-  } else if (lane == 0) {
+    cls = ic_point<false>(a, tp, pt, t, lane, wave, sh, buf, S, touched, lpx, lpy);
+  } else if (t == 0) {
     a.mask[pt] = 0;
   }
-  const int any_t = __any(touched);
-  if (lane == 0) {
+  ic_store_records(a, pt, t, lane, wave, tp, S, cls);
+  const int any_t = __syncthreads_or(touched);
+  if (t == 0) {
     if (a.touched) a.touched[pt] = (uint8_t)(any_t ? 1 : 0);
     if (a.cls) a.cls[pt] = (uint8_t)cls;
     if (a.last_pu) {
@@ -321,13 +430,182 @@ __global__ __launch_bounds__(64) void ic_refine_kernel(IcArgs a) {
   }
 }
 
-// ---- pass 2: sequential replay of the runs that contain touched points --------------
-__global__ __launch_bounds__(64) void ic_strict_kernel(IcArgs a) {
-  __shared__ uint32_t s_t[IC_TH * IC_TW];
+// ---- tap records (who wrote which tap, and what) -----------------------------------
+// 264 mask bits: wavefront w packs taps 64w..64w+63 into words 2w, 2w+1; taps 256..263 -> word 8.
+__device__ __forceinline__ void ic_store_mask(uint32_t *dst, bool b0, bool b1, int lane, int wave) {
+  const unsigned long long m = __ballot(b0);
+  if (lane == 0) {
+    dst[2 * wave] = (uint32_t)m;
+    dst[2 * wave + 1] = (uint32_t)(m >> 32);
+  }
+  if (wave == 0) {
+    const unsigned long long m2 = __ballot(b1);
+    if (lane == 0) dst[8] = (uint32_t)m2;
+  }
+}
+__device__ __forceinline__ bool ic_bit(const uint32_t *w, int j) { return (w[j >> 5] >> (j & 31)) & 1u; }
+
+__device__ __forceinline__ void ic_store_records(const IcArgs &a, int pt, int t, int lane, int wave, const IcTaps &tp,
+                                                 const IcState &S, int cls) {
+  if (!a.recW0) return;
+  const bool processed = cls >= 1, iterated = cls == 2;
+  ic_store_mask(a.recW0 + (size_t)pt * IC_MW, processed && ((S.m >> 16) & 1u), processed && ((S.m >> 17) & 1u), lane,
+                wave);
+  ic_store_mask(a.recW1 + (size_t)pt * IC_MW, iterated && ((S.m >> 24) & 1u), iterated && ((S.m >> 25) & 1u), lane,
+                wave);
+  float *v0 = a.recV0 + (size_t)pt * 3 * IC_NELEM;
+  float *v1 = a.recV1 + (size_t)pt * IC_NELEM;
+  v0[t] = S.I0[0];
+  v0[IC_NELEM + t] = S.du[0];
+  v0[2 * IC_NELEM + t] = S.dv[0];
+  v1[t] = S.I1[0];
+  if (tp.second) {
+    v0[IC_T + t] = S.I0[1];
+    v0[IC_NELEM + IC_T + t] = S.du[1];
+    v0[2 * IC_NELEM + IC_T + t] = S.dv[1];
+    v1[IC_T + t] = S.I1[1];
+  }
+}
+
+// ---- pass 2a: parallel fixed-point replay of the touched points ------------------------
+// The state a touched point P sees is, per tap, the value written by the NEAREST earlier point
+// that wrote that tap (template taps: a static function of pts0; I1 taps: depends on that
+// point's own trajectory). Measured on forward-driving streams the runs of consecutive touched
+// points are ~100 long but the true value-dependency depth is <= 6, so instead of replaying a
+// run sequentially every touched point is recomputed in parallel from the current records of its
+// predecessors, round after round, until a whole round changes nothing. That fixed point is
+// unique and equals the sequential (reference) result: by induction over the index order, a
+// point whose predecessors' records are final computes its final record. Reads may race with
+// writes of the same round; a racy read can only delay convergence, because the terminating
+// round (no record changed) reads stable data. If IC_ROUNDS rounds do not converge, or a run
+// exceeds IC_MAXRUN, ic_strict_kernel replays sequentially.
+__global__ __launch_bounds__(IC_T) void ic_jacobi_kernel(IcArgs a, int round) {
+  __shared__ IcShared sh;
+  __shared__ uint32_t s_w0[IC_MAXRUN * IC_MW], s_w1[IC_MAXRUN * IC_MW];
+  __shared__ uint8_t s_cls[IC_MAXRUN];
+  __shared__ int s_first[IC_NW];
   const int n = a.d_n ? *a.d_n : a.n;
   const int pt = blockIdx.x;
   if (pt >= n) return;
-  const int lane = threadIdx.x;
+  if (round > 0 && a.jac[round - 1] == 0) return;  // converged in the previous round
+  if (a.jac[IC_JAC_OVF]) return;                   // sequential fallback will run
+  if (!a.touched[pt]) return;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+
+  // nearest clean (untouched, iterated) predecessor: one candidate per lane
+  {
+    const int q = pt - 1 - t;
+    const bool is_clean = q >= 0 && a.cls[q] == 2 && !a.touched[q];
+    const unsigned long long bal = __ballot(is_clean);
+    if (lane == 0) s_first[wave] = bal ? (64 * wave + __ffsll((long long)bal) - 1) : 0x7fffffff;
+  }
+  __syncthreads();
+  int dist = min(min(s_first[0], s_first[1]), min(s_first[2], s_first[3]));  // pt-1-dist is the clean point
+  int lo;
+  if (dist == 0x7fffffff) {
+    if (pt > IC_T) {  // no clean point within reach
+      if (t == 0) atomicExch(&a.jac[IC_JAC_OVF], 1);
+      return;
+    }
+    lo = 0;
+  } else {
+    lo = pt - 1 - dist;
+  }
+  const bool have_clean = dist != 0x7fffffff;
+  const int L = pt - lo;  // predecessors lo .. pt-1
+  if (L > IC_MAXRUN) {
+    if (t == 0) atomicExch(&a.jac[IC_JAC_OVF], 1);
+    return;
+  }
+  for (int i = t; i < L * IC_MW; i += IC_T) {
+    s_w0[i] = a.recW0[(size_t)lo * IC_MW + i];
+    s_w1[i] = a.recW1[(size_t)lo * IC_MW + i];
+  }
+  for (int i = t; i < L; i += IC_T) s_cls[i] = a.cls[lo + i];
+  __syncthreads();
+  (void)have_clean;
+
+  const IcTaps tp = ic_make_taps(t);
+  IcState S;
+  ic_state_clear(S);
+  // nearest earlier writer per tap
+#pragma unroll
+  for (int k = 0; k < IC_K; ++k) {
+    if (k == 1 && !tp.second) break;
+    const int j = k ? IC_T + t : t;
+    int src0 = -1, src1 = -1;
+    for (int r = L - 1; r >= 0 && (src0 < 0 || src1 < 0); --r) {
+      const int c = s_cls[r];
+      if (c == 0) continue;
+      if (src0 < 0 && ic_bit(&s_w0[r * IC_MW], j)) src0 = lo + r;
+      if (src1 < 0 && c == 2 && ic_bit(&s_w1[r * IC_MW], j)) src1 = lo + r;
+    }
+    if (src0 >= 0) {
+      const float *v0 = a.recV0 + (size_t)src0 * 3 * IC_NELEM;
+      S.I0[k] = v0[j];
+      S.du[k] = v0[IC_NELEM + j];
+      S.dv[k] = v0[2 * IC_NELEM + j];
+      S.m |= 1u << k;
+    }
+    if (src1 >= 0) {
+      S.I1[k] = a.recV1[(size_t)src1 * IC_NELEM + j];
+      S.m |= 0x100u << k;
+    }
+  }
+  // skip when the I1 pre-state is exactly the one this point last ran with (template part is static)
+  {
+    float *p1 = a.pre1 + (size_t)pt * IC_NELEM;
+    uint32_t *pm = a.preM + (size_t)pt * IC_MW;
+    int diff = round == 0;
+    const bool b0 = (S.m >> 8) & 1u, b1 = (S.m >> 9) & 1u;
+    if (!diff) {
+      if (b0 != ic_bit(pm, t) || (b0 && __float_as_uint(p1[t]) != __float_as_uint(S.I1[0]))) diff = 1;
+      if (tp.second && (b1 != ic_bit(pm, IC_T + t) || (b1 && __float_as_uint(p1[IC_T + t]) != __float_as_uint(S.I1[1]))))
+        diff = 1;
+    }
+    if (!__syncthreads_or(diff)) return;
+    p1[t] = S.I1[0];
+    if (tp.second) p1[IC_T + t] = S.I1[1];
+    ic_store_mask(pm, b0, b1, lane, wave);
+  }
+  if (t == 0) {
+    a.pts_track[2 * pt] = a.pts_prior[2 * pt];
+    a.pts_track[2 * pt + 1] = a.pts_prior[2 * pt + 1];
+  }
+  int dummy = 0, buf = 0;
+  float lx = 0.f, ly = 0.f;
+  const int cls = ic_point<true>(a, tp, pt, t, lane, wave, sh, buf, S, dummy, lx, ly);
+  // own I1 writes of this run of the point vs the stored record
+  const bool iterated = cls == 2;
+  const bool o0 = iterated && ((S.m >> 24) & 1u), o1 = iterated && ((S.m >> 25) & 1u);
+  uint32_t *w1 = a.recW1 + (size_t)pt * IC_MW;
+  float *v1 = a.recV1 + (size_t)pt * IC_NELEM;
+  int changed = a.cls[pt] != cls;
+  if (o0 != ic_bit(w1, t) || (o0 && __float_as_uint(v1[t]) != __float_as_uint(S.I1[0]))) changed = 1;
+  if (tp.second && (o1 != ic_bit(w1, IC_T + t) || (o1 && __float_as_uint(v1[IC_T + t]) != __float_as_uint(S.I1[1]))))
+    changed = 1;
+  if (__syncthreads_or(changed)) {
+    v1[t] = S.I1[0];
+    if (tp.second) v1[IC_T + t] = S.I1[1];
+    ic_store_mask(w1, o0, o1, lane, wave);
+    if (t == 0) {
+      a.cls[pt] = (uint8_t)cls;
+      atomicAdd(&a.jac[round], 1);
+    }
+  }
+}
+
+// ---- pass 2: sequential replay of the runs that contain touched points --------------
+__global__ __launch_bounds__(IC_T) void ic_strict_kernel(IcArgs a) {
+  __shared__ IcShared sh;
+  const int n = a.d_n ? *a.d_n : a.n;
+  const int pt = blockIdx.x;
+  if (pt >= n) return;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  // with the parallel replay in front, this kernel only runs when that did not finish
+  if (a.jac && a.jac[IC_ROUNDS - 1] == 0 && a.jac[IC_JAC_OVF] == 0) return;
   if (!a.touched[pt]) return;
   // head test: walk back over skipped / template-only untouched points
   int start = 0, clean = -1;
@@ -343,34 +621,36 @@ __global__ __launch_bounds__(64) void ic_strict_kernel(IcArgs a) {
   start = clean + 1;
   IcState S;
   ic_state_clear(S);
-  int dummy = 0;
+  const IcTaps tp = ic_make_taps(t);
+  int dummy = 0, buf = 0;
   if (clean >= 0) {
     // state left behind by an untouched, iterated point: its template and its last I1 patch
     float ax, ay, axay;
     ic_frac(a.pts0[2 * clean], a.pts0[2 * clean + 1], ax, ay, axay);
-    ic_template<true>(a.I0, a.pts0[2 * clean], a.pts0[2 * clean + 1], ax, ay, axay, lane, s_t, S, dummy);
+    ic_template<true>(a.I0, tp, a.pts0[2 * clean], a.pts0[2 * clean + 1], ax, ay, axay, t, wave, sh, S, dummy);
     const float pux = a.last_pu[2 * clean], puy = a.last_pu[2 * clean + 1];
     ic_frac(pux, puy, ax, ay, axay);
-    ic_sample_I1<true>(a.I1, pux, puy, a.scale[clean], ax, ay, axay, lane, S, dummy);
+    const IcTile tile = ic_load_I1_tile(a.I1, pux, puy, t, sh);
+    ic_sample_I1<true>(a.I1, tp, a.scale[clean], pux, puy, ax, ay, axay, wave, S, dummy, tile, sh);
   }
   for (int p = start; p < n; ++p) {
     const int cp = a.cls[p];
     if (cp == 0) continue;
-    const int tp = a.touched[p];
-    if (!tp) {
+    const int is_touched = a.touched[p];
+    if (!is_touched) {
       if (cp == 2) break;  // next clean point: end of the run
       // untouched, failed the determinant test: it only rewrote the template state
       float ax, ay, axay;
       ic_frac(a.pts0[2 * p], a.pts0[2 * p + 1], ax, ay, axay);
-      ic_template<true>(a.I0, a.pts0[2 * p], a.pts0[2 * p + 1], ax, ay, axay, lane, s_t, S, dummy);
+      ic_template<true>(a.I0, tp, a.pts0[2 * p], a.pts0[2 * p + 1], ax, ay, axay, t, wave, sh, S, dummy);
       continue;
     }
-    if (lane == 0) {
+    if (t == 0) {
       a.pts_track[2 * p] = a.pts_prior[2 * p];
       a.pts_track[2 * p + 1] = a.pts_prior[2 * p + 1];
     }
     float lx, ly;
-    (void)ic_point<true>(a, p, lane, s_t, S, dummy, lx, ly);
+    (void)ic_point<true>(a, tp, p, t, lane, wave, sh, buf, S, dummy, lx, ly);
   }
 }
 
@@ -386,16 +666,42 @@ static int ic_args(vo_ctx *c, int slot0, int slot1, IcArgs &a, int *d_flags) {
   return VO_OK;
 }
 
-// pass 1. d_prior and d_pts_track must be different buffers.
+// tap records of the parallel strict replay, allocated on first use (capacity cfg.max_points)
+static int ic_records(vo_ctx *c, IcArgs &a) {
+  if (!c->ic_rec) {
+    const size_t N = (size_t)c->cfg.max_points;
+    const size_t bytes = N * (2 * IC_MW * 4 + 3 * IC_NELEM * 4 + IC_NELEM * 4 + IC_NELEM * 4 + IC_MW * 4) + 64;
+    VO_CHECK_HIP(c, hipMalloc(&c->ic_rec, bytes));
+    VO_CHECK_HIP(c, hipMemsetAsync(c->ic_rec, 0, bytes, c->stream));
+  }
+  const size_t N = (size_t)c->cfg.max_points;
+  uint8_t *p = (uint8_t *)c->ic_rec;
+  a.jac = (int *)p;                 p += 64;
+  a.recW0 = (uint32_t *)p;          p += N * IC_MW * 4;
+  a.recW1 = (uint32_t *)p;          p += N * IC_MW * 4;
+  a.preM = (uint32_t *)p;           p += N * IC_MW * 4;
+  a.recV0 = (float *)p;             p += N * 3 * IC_NELEM * 4;
+  a.recV1 = (float *)p;             p += N * IC_NELEM * 4;
+  a.pre1 = (float *)p;
+  return VO_OK;
+}
+
+// pass 1. d_prior and d_pts_track must be different buffers. with_records: also write the tap
+// records the strict replay consumes.
 int vo_ic_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, const float *d_scale,
                   const float *d_prior, float *d_pts_track, const uint8_t *d_mask_in, uint8_t *d_mask,
-                  uint8_t *d_touched, uint8_t *d_cls, float *d_last_pu, int n_max, const int *d_n, int *d_flags) {
+                  uint8_t *d_touched, uint8_t *d_cls, float *d_last_pu, int n_max, const int *d_n, int *d_flags,
+                  bool with_records) {
   if (n_max <= 0) return VO_OK;
   IcArgs a;
   memset(&a, 0, sizeof(a));
   int rc = ic_args(c, slot0, slot1, a, d_flags);
-  a.mask_in = d_mask_in;
   if (rc) return rc;
+  if (with_records) {
+    rc = ic_records(c, a);
+    if (rc) return rc;
+  }
+  a.mask_in = d_mask_in;
   a.pts0 = d_pts0;
   a.scale = d_scale;
   a.pts_prior = d_prior;
@@ -407,13 +713,15 @@ int vo_ic_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, const fl
   a.n = n_max;
   a.d_n = d_n;
   vo_prof_begin(c, VO_K_IC);
-  hipLaunchKernelGGL(ic_refine_kernel, dim3(n_max), dim3(64), 0, c->stream, a);
+  hipLaunchKernelGGL(ic_refine_kernel, dim3(n_max), dim3(IC_T), 0, c->stream, a);
   vo_prof_end(c);
   VO_CHECK_HIP(c, hipGetLastError());
   return VO_OK;
 }
 
-// pass 2 (reference-exact border state); consumes pass 1's touched / cls / last_pu.
+// pass 2 (reference-exact border state); consumes pass 1's touched / cls / last_pu and tap records:
+// IC_ROUNDS parallel fixed-point rounds (each exits at once when the previous one changed nothing),
+// then the sequential replay, which only runs if the rounds did not converge.
 int vo_ic_strict_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, const float *d_scale,
                          const float *d_prior, float *d_pts_track, uint8_t *d_mask, uint8_t *d_touched,
                          uint8_t *d_cls, float *d_last_pu, int n_max, const int *d_n, int *d_flags) {
@@ -422,6 +730,8 @@ int vo_ic_strict_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, c
   memset(&a, 0, sizeof(a));
   int rc = ic_args(c, slot0, slot1, a, d_flags);
   if (rc) return rc;
+  rc = ic_records(c, a);
+  if (rc) return rc;
   a.pts0 = d_pts0;
   a.scale = d_scale;
   a.pts_prior = d_prior;
@@ -433,7 +743,9 @@ int vo_ic_strict_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, c
   a.n = n_max;
   a.d_n = d_n;
   vo_prof_begin(c, VO_K_IC);
-  hipLaunchKernelGGL(ic_strict_kernel, dim3(n_max), dim3(64), 0, c->stream, a);
+  for (int r = 0; r < IC_ROUNDS; ++r)
+    hipLaunchKernelGGL(ic_jacobi_kernel, dim3(n_max), dim3(IC_T), 0, c->stream, a, r);
+  hipLaunchKernelGGL(ic_strict_kernel, dim3(n_max), dim3(IC_T), 0, c->stream, a);
   vo_prof_end(c);
   VO_CHECK_HIP(c, hipGetLastError());
   return VO_OK;

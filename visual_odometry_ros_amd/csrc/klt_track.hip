@@ -220,12 +220,9 @@ __global__ __launch_bounds__(64) void klt_track_kernel(KltArgs a) {
         pA22 += tY[j] * tY[j];
       }
     }
-    const long long iA11 = wave_sum_i32_to_i64(pA11);
-    const long long iA12 = wave_sum_i32_to_i64(pA12);
-    const long long iA22 = wave_sum_i32_to_i64(pA22);
-    const float A11 = (float)iA11 * FLT_SCALE;
-    const float A12 = (float)iA12 * FLT_SCALE;
-    const float A22 = (float)iA22 * FLT_SCALE;
+    const float A11 = wave_sum_i32_to_f32(pA11) * FLT_SCALE;
+    const float A12 = wave_sum_i32_to_f32(pA12) * FLT_SCALE;
+    const float A22 = wave_sum_i32_to_f32(pA22) * FLT_SCALE;
     float D = A11 * A22 - A12 * A12;
     const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
     if (minEig < a.min_eig || D < 1.19209290e-07f) {
@@ -299,8 +296,8 @@ __global__ __launch_bounds__(64) void klt_track_kernel(KltArgs a) {
         pb1 += diff[k] * tX[k];
         pb2 += diff[k] * tY[k];
       }
-      const float b1 = (float)wave_sum_i32_to_i64(pb1) * FLT_SCALE;
-      const float b2 = (float)wave_sum_i32_to_i64(pb2) * FLT_SCALE;
+      const float b1 = wave_sum_i32_to_f32(pb1) * FLT_SCALE;
+      const float b2 = wave_sum_i32_to_f32(pb2) * FLT_SCALE;
       const float dx = (float)((A12 * b2 - A22 * b1) * D);
       const float dy = (float)((A12 * b1 - A11 * b2) * D);
       nextx += dx;

@@ -145,6 +145,13 @@ struct CompactArgs {
   // optional gate of stereo_vo.cpp:653-668: keep only if ((y > 660) ? 100 : 0) < thres_sampson
   const float *gate_pts;
   float gate_thres;
+  // optional fused trackWithPrior validity (feature_tracker.cpp:191-197): when klt_status is set the
+  // keep flag is status>0 && 0<x<W && 0<y<H && err<=thr (AND mask when mask is non-null)
+  const uint8_t *klt_status;
+  const float *klt_err;
+  const float *klt_pts;
+  float klt_thres_err;
+  int klt_W, klt_H;
 };
 
 __global__ __launch_bounds__(1024) void compact_kernel(CompactArgs a) {
@@ -158,7 +165,12 @@ __global__ __launch_bounds__(1024) void compact_kernel(CompactArgs a) {
     const int i = c0 + tid;
     bool keep = false;
     if (i < n) {
-      keep = a.mask[i] && (!a.alive || a.alive[i]) && (!a.tracked || a.tracked[i]);
+      keep = (!a.mask || a.mask[i]) && (!a.alive || a.alive[i]) && (!a.tracked || a.tracked[i]);
+      if (a.klt_status) {
+        const float x = a.klt_pts[2 * i], y = a.klt_pts[2 * i + 1];
+        keep = keep && a.klt_status[i] > 0 && x > 0 && x < a.klt_W && y > 0 && y < a.klt_H;
+        keep = keep && a.klt_err[i] <= a.klt_thres_err;
+      }
       if (a.gate_pts) keep = keep && ((a.gate_pts[2 * i + 1] > 660 ? 100.f : 0.f) < a.gate_thres);
       if (a.sc_src) {
         const int o = a.in_i ? a.in_i[i] : i;
@@ -232,6 +244,12 @@ int vo_compact_enqueue(vo_ctx *c, const CompactArgsHost &h) {
   a.sc_dst = h.sc_dst;
   a.gate_pts = h.gate_pts;
   a.gate_thres = h.gate_thres;
+  a.klt_status = h.klt_status;
+  a.klt_err = h.klt_err;
+  a.klt_pts = h.klt_pts;
+  a.klt_thres_err = h.klt_thres_err;
+  a.klt_W = h.klt_W;
+  a.klt_H = h.klt_H;
   vo_prof_begin(c, VO_K_AUX);
   hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(1024), 0, c->stream, a);
   vo_prof_end(c);

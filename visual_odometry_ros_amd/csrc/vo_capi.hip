@@ -77,6 +77,9 @@ extern "C" int vo_create(const vo_config *cfg, vo_ctx **out) {
   *out = c;  // so that the caller can read the error and destroy
   VO_CHECK_HIP(c, hipSetDevice(c->device));
   VO_CHECK_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  VO_CHECK_HIP(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  VO_CHECK_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  VO_CHECK_HIP(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   const size_t N = (size_t)cfg->max_points;
   c->slots = (vo_pyramid *)calloc((size_t)cfg->n_slots, sizeof(vo_pyramid));
   for (int s = 0; s < cfg->n_slots; ++s) {
@@ -113,6 +116,7 @@ extern "C" int vo_create(const vo_config *cfg, vo_ctx **out) {
 extern "C" void vo_destroy(vo_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   vo_frame_free(c);
   if (c->prof) {
@@ -128,10 +132,13 @@ extern "C" void vo_destroy(vo_ctx *c) {
   }
   void *bufs[] = {c->d_pts0, c->d_pts1, c->d_pts2, c->d_pts3, c->d_err, c->d_err2, c->d_scale, c->d_X,
                   c->d_status, c->d_status2, c->d_mask, c->d_mask2, c->d_idx, c->d_count, c->d_mat,
-                  c->d_gninfo, c->d_flags, c->d_img_stage, c->d_desc_a, c->d_desc_b, c->d_dist};
+                  c->d_gninfo, c->d_flags, c->d_img_stage, c->d_desc_a, c->d_desc_b, c->d_dist, c->ic_rec};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   free(c);
 }

@@ -41,7 +41,7 @@ extern "C" int vo_track_with_scale(vo_ctx *c, int slot0, int slot1, const float 
   H2D(c->d_mask, mask_valid, (size_t)n);
   // d_pts1 = prior (in), d_pts2 = refined (out), d_mask2 = touched, d_status = class, d_pts3 = last pt_update
   rc = vo_ic_enqueue(c, slot0, slot1, c->d_pts0, c->d_scale, c->d_pts1, c->d_pts2, c->d_mask, c->d_mask,
-                     c->d_mask2, c->d_status, c->d_pts3, n, nullptr);
+                     c->d_mask2, c->d_status, c->d_pts3, n, nullptr, nullptr, strict_border != 0);
   if (rc < 0) return rc;
   if (strict_border) {
     rc = vo_ic_strict_enqueue(c, slot0, slot1, c->d_pts0, c->d_scale, c->d_pts1, c->d_pts2, c->d_mask,

@@ -46,6 +46,8 @@ struct vo_ctx {
   vo_config cfg;
   int device;
   hipStream_t stream;
+  hipStream_t stream2;     // side stream: work that does not depend on the main chain of a frame
+  hipEvent_t ev_fork, ev_join;
   char err[512];
   vo_pyramid *slots;
   // per-point device buffers (capacity cfg.max_points)
@@ -65,6 +67,7 @@ struct vo_ctx {
   uint16_t *d_dist;
   size_t desc_cap, dist_cap;
   // frame pipeline state
+  void *ic_rec;            // tap records of the IC strict replay (ic_refine.hip)
   struct vo_frame_state *frame;
   int frame_strict_ic;     // replay border-touching points with the reference's sticky tap state
   // profiling
@@ -122,28 +125,26 @@ __device__ __forceinline__ int dpp_i32(int v) {
 }
 
 // Sum over the 64 lanes; every lane returns the same bits.
-// Tree: ((l0+l1)+(l2+l3)) ... rows of 16 -> (r0+r1)+(r2+r3).
+// Tree: ((l0+l1)+(l2+l3)) ... within rows of 16 (quad_perm, half_mirror, mirror), then
+// row_bcast15 (rows 1,3 += previous row), row_bcast31 (rows 2,3 += row 1) and one readlane(63):
+// (r3+r2)+(r1+r0), the same additions as the balanced tree (r0+r1)+(r2+r3) since + commutes.
 __device__ __forceinline__ float wave_sum_f32(float v) {
   v = v + dpp_f32<0xB1>(v);
   v = v + dpp_f32<0x4E>(v);
   v = v + dpp_f32<0x141>(v);
   v = v + dpp_f32<0x140>(v);
-  float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
-  float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
-  float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
-  float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
-  return (r0 + r1) + (r2 + r3);
+  v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
+  v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ int wave_sum_i32(int v) {
   v = v + dpp_i32<0xB1>(v);
   v = v + dpp_i32<0x4E>(v);
   v = v + dpp_i32<0x141>(v);
   v = v + dpp_i32<0x140>(v);
-  int r0 = __builtin_amdgcn_readlane(v, 0);
-  int r1 = __builtin_amdgcn_readlane(v, 16);
-  int r2 = __builtin_amdgcn_readlane(v, 32);
-  int r3 = __builtin_amdgcn_readlane(v, 48);
-  return (r0 + r1) + (r2 + r3);
+  v = v + __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+  v = v + __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+  return __builtin_amdgcn_readlane(v, 63);
 }
 // Exact 64-bit sum of 64 int32 lane values (each |v| < 2^30): split 16/16 so the
 // two int32 wave sums cannot overflow, recombine in int64.
@@ -153,6 +154,15 @@ __device__ __forceinline__ long long wave_sum_i32_to_i64(int v) {
   int slo = wave_sum_i32(lo);
   int shi = wave_sum_i32(hi);
   return (long long)shi * 65536LL + (long long)slo;
+}
+// (float)(exact int64 sum): the sum is < 2^53, so hi*65536 + lo is exact in double and the
+// double -> float conversion rounds once, exactly like (float)(int64_t).
+__device__ __forceinline__ float wave_sum_i32_to_f32(int v) {
+  int lo = v & 0xFFFF;
+  int hi = v >> 16;
+  int slo = wave_sum_i32(lo);
+  int shi = wave_sum_i32(hi);
+  return (float)((double)shi * 65536.0 + (double)slo);
 }
 
 __device__ __forceinline__ int reflect101_dev(int p, int n) {

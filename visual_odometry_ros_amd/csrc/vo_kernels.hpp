@@ -8,7 +8,9 @@
 int vo_gn_enqueue(vo_ctx *c, bool stereo, bool mono_general_inverse, const float *dX, const float *dP1,
                   const float *dP2, int n, const int *d_n, const float Kl[4], const float Kr[4],
                   const float T_lr[16], float thres, int variant, const float T01_init[16],
-                  float *d_Tout, uint8_t *d_mask, vo_gn_dev_info *d_info, bool write_init_on_nan = false);
+                  float *d_Tout, uint8_t *d_mask, vo_gn_dev_info *d_info, bool write_init_on_nan = false,
+                  uint8_t *d_stage = nullptr, const int32_t *d_orig = nullptr, int stage_val = 0,
+                  float gate_thres = 0.f);
 
 // pyramid.hip
 int vo_pyr_levels_host(int w, int h, int win, int max_level);
@@ -30,7 +32,7 @@ int vo_klt_mask_enqueue(vo_ctx *c, int mode, int n_max, const int *d_n, int n_co
 int vo_ic_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, const float *d_scale,
                   const float *d_prior, float *d_pts_track, const uint8_t *d_mask_in, uint8_t *d_mask,
                   uint8_t *d_touched, uint8_t *d_cls, float *d_last_pu, int n_max, const int *d_n,
-                  int *d_flags = nullptr);
+                  int *d_flags = nullptr, bool with_records = false);
 int vo_ic_strict_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, const float *d_scale,
                          const float *d_prior, float *d_pts_track, uint8_t *d_mask, uint8_t *d_touched,
                          uint8_t *d_cls, float *d_last_pu, int n_max, const int *d_n, int *d_flags = nullptr);
@@ -59,6 +61,11 @@ struct CompactArgsHost {
   float *sc_dst = nullptr;
   const float *gate_pts = nullptr;
   float gate_thres = 0.f;
+  const uint8_t *klt_status = nullptr;
+  const float *klt_err = nullptr;
+  const float *klt_pts = nullptr;
+  float klt_thres_err = 0.f;
+  int klt_W = 0, klt_H = 0;
 };
 int vo_compact_enqueue(vo_ctx *c, const CompactArgsHost &h);
 int vo_calc_prior_enqueue(vo_ctx *c, const float *d_pts0, int n_pts0, const float *d_Xw, int n,

@@ -205,11 +205,13 @@ def bucket_points(width, height, n_u, n_v, rng, margin=16.0):
 class StereoStream:
     """Synthetic stereo stream + per-frame track sets for the steady-state frame
     operator (open loop: the track set entering frame k+1 comes from the scene's
-    ground truth at frame k, perturbed; see DESIGN.md §bench workload)."""
+    ground truth at frame k, perturbed; see DESIGN.md §bench workload).
+    `margin` = 31 px keeps features as far from the border as the reference's ORB
+    detector does (extractor_orb_->setEdgeThreshold(31), feature_extractor.cpp:53)."""
 
     def __init__(self, width=KITTI_SIZE[0], height=KITTI_SIZE[1], K=KITTI_K,
                  baseline=KITTI_BASELINE, n_u=60, n_v=25, n_new=150, seed=2, speed=0.8,
-                 depth_noise=0.01, prior_noise=(0.02, 0.002), margin=16.0):
+                 depth_noise=0.01, prior_noise=(0.02, 0.002), margin=31.0):
         self.width, self.height, self.K, self.baseline = width, height, K, baseline
         self.n_u, self.n_v, self.n_new = n_u, n_v, n_new
         self.seed, self.speed = seed, speed
