@@ -183,25 +183,7 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
   inv_se3(prm->T_lr, T_rl);
   inv_se3(dT_prior, T_cp);
 
-  // [10] new points on the side stream: they depend only on the two new pyramids, not on the
-  // main chain, and the chain's kernels leave most of the chip idle (one wave per point).
-  if (n_new > 0) {
-    VO_CHECK_HIP(c, hipEventRecord(c->ev_fork, s));
-    VO_CHECK_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-    c->stream = c->stream2;
-    int rc2 = vo_klt_enqueue(c, slot_l1, slot_r1, d_new, nullptr, f->new_r, n_new, nullptr, prm->win,
-                             prm->max_level, 0, 30, 0.01, 1e-4f, f->st3, f->e3);
-    // backward: maxLevel-1, initial flow = pts_new, {} criteria / minEig (feature_tracker.cpp:69-71)
-    if (rc2 >= 0)
-      rc2 = vo_klt_enqueue(c, slot_r1, slot_l1, f->new_r, d_new, f->new_back, n_new, nullptr, prm->win,
-                           prm->max_level - 1, VO_KLT_USE_INITIAL_FLOW, 0, 0., 0.f, f->st2, f->e2);
-    if (rc2 >= 0)
-      rc2 = vo_klt_mask_enqueue(c, 2, n_new, nullptr, W, H, prm->thres_err, prm->thres_bidirection, d_new,
-                                f->new_r, f->new_back, f->st3, f->st2, f->e3, f->e2, nullptr, f->mNew);
-    c->stream = s;
-    if (rc2 < 0) return rc2;
-    VO_CHECK_HIP(c, hipEventRecord(c->ev_join, c->stream2));
-  }
+  if (n_new > 0) VO_CHECK_HIP(c, hipEventRecord(c->ev_fork, s));  // the new pyramids are enqueued before this point
 
   if (n > 0) {
     // [3] priors
@@ -210,6 +192,26 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
     // [4] l0 -> l1 ({} criteria, {} minEig); validity mask fused into the compaction
     RC(vo_klt_enqueue(c, slot_l0, slot_l1, d_l0, nullptr, f->F_pl1, n, nullptr, prm->win, prm->max_level,
                       VO_KLT_USE_INITIAL_FLOW, 0, 0., 0.f, f->st1, f->e1));
+    // (the main chain's first long kernel is queued; now feed the side stream)
+    // [10] new points on the side stream: they depend only on the two new pyramids, not on the
+    // main chain, and the chain's kernels leave most of the chip idle (one wave per point).
+    if (n_new > 0) {
+      VO_CHECK_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+      c->stream = c->stream2;
+      int rc2 = vo_klt_enqueue(c, slot_l1, slot_r1, d_new, nullptr, f->new_r, n_new, nullptr, prm->win,
+                               prm->max_level, 0, 30, 0.01, 1e-4f, f->st3, f->e3);
+      // backward: maxLevel-1, initial flow = pts_new, {} criteria / minEig (feature_tracker.cpp:69-71)
+      if (rc2 >= 0)
+        rc2 = vo_klt_enqueue(c, slot_r1, slot_l1, f->new_r, d_new, f->new_back, n_new, nullptr, prm->win,
+                             prm->max_level - 1, VO_KLT_USE_INITIAL_FLOW, 0, 0., 0.f, f->st2, f->e2);
+      if (rc2 >= 0)
+        rc2 = vo_klt_mask_enqueue(c, 2, n_new, nullptr, W, H, prm->thres_err, prm->thres_bidirection, d_new,
+                                  f->new_r, f->new_back, f->st3, f->st2, f->e3, f->e2, nullptr, f->mNew);
+      c->stream = s;
+      if (rc2 < 0) return rc2;
+      VO_CHECK_HIP(c, hipEventRecord(c->ev_join, c->stream2));
+    }
+
     {
       CompactArgsHost h;
       h.klt_status = f->st1;
@@ -277,6 +279,7 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
       RC(vo_compact_enqueue(c, h));
     }
   }
+  if (n == 0 && n_new > 0) VO_FAIL(c, VO_ERR_INVALID, "new-point candidates without a track set are not supported");
   // [6] stereo pose-only BA on the survivors (T01 init = constant-velocity prior; kept on NaN);
   // [7] its epilogue marks stage 4 for inliers that pass the y > 660 gate (thres_sampson = 60)
   RC(vo_gn_enqueue(c, true, false, f->C_X, f->C_pl1, f->C_pr1, n, &cnt[2], prm->Kl, prm->Kr, prm->T_lr,

@@ -394,22 +394,25 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
       }
     }
 
-    // wavefront butterfly, then one LDS row per wave
-#pragma unroll
-    for (int k = 0; k < 21; ++k) {
-      float s = wave_sum_f32(A.H[k]);
-      if (lane == 0) s_part[wave][k] = s;
-    }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      float s = wave_sum_f32(A.g[k]);
-      if (lane == 0) s_part[wave][21 + k] = s;
-    }
+    // wavefront butterflies (four interleaved chains at a time), then one LDS row per wave
     {
-      float s = wave_sum_f32(A.err);
-      if (lane == 0) s_part[wave][27] = s;
-      s = wave_sum_f32(A.cnt);
-      if (lane == 0) s_part[wave][28] = s;
+      float r[32];
+#pragma unroll
+      for (int k = 0; k < 21; ++k) r[k] = A.H[k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) r[21 + k] = A.g[k];
+      r[27] = A.err;
+      r[28] = A.cnt;
+      r[29] = r[30] = r[31] = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 32; k += 4) {
+        if (k >= GN_NACC) break;
+        wave_sum4_f32(r[k], r[k + 1], r[k + 2], r[k + 3]);
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < GN_NACC; ++k) s_part[wave][k] = r[k];
+      }
     }
     __syncthreads();
     if (wave == 0) {

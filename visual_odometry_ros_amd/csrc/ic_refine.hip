@@ -1,5 +1,5 @@
 // ic_refine.hip — scale-compensated inverse-compositional patch refinement,
-// one 256-lane workgroup (4 wavefronts, one per SIMD of a CU) per feature point.
+// one 320-lane workgroup (5 wavefronts) per feature point, one checkerboard tap per lane.
 //
 // Replaces FeatureTracker::trackWithScale (core/visual_odometry/feature_tracker.cpp:236-504)
 // with its samplers image_processing::interpImage3SameRatio / interpImageSameRatio
@@ -39,9 +39,9 @@
 
 #define IC_HALF 11
 #define IC_NELEM 264
-#define IC_T 256   // lanes per point
-#define IC_NW 4    // wavefronts per point
-#define IC_K 2     // taps per lane: t and (t < 8) 256 + t
+#define IC_T 320   // lanes per point: lane t owns tap t (t < 264)
+#define IC_NW 5    // wavefronts per point
+#define IC_K 1     // taps per lane
 #define IC_TW 8    // template tile dwords per row (32 bytes)
 #define IC_TH 27   // template tile rows
 #define IC_JW 11   // I1 search tile: dwords per row (44 bytes)
@@ -50,6 +50,8 @@
 #define IC_MAXRUN 192  // longest run the parallel strict replay handles (else sequential fallback)
 #define IC_ROUNDS 10
 #define IC_JAC_OVF 15
+#define IC_JAC_NT 14
+#define IC_JGRID 160   // workgroups of a replay round; each strides over the touched list
 #ifndef IC_MAX_ITER
 #define IC_MAX_ITER 30  // feature_tracker.cpp:290
 #endif
@@ -74,13 +76,14 @@ struct IcArgs {
   float *recV1;             // [n][IC_NELEM] last I1 value the point wrote per tap
   float *pre1;              // [n][IC_NELEM] I1 pre-state the point last ran with
   uint32_t *preM;           // [n][IC_MW] its mask
-  int *jac;                 // [r] = records changed in round r ; [IC_JAC_OVF] = run too long
+  int *jac;                 // [r] = records changed in round r ; [IC_JAC_OVF] = run too long ; [IC_JAC_NT] = #touched
+  int *tlist;               // indices of the touched points (any order)
 };
 
 struct IcShared {
   uint32_t tt[IC_TH * IC_TW];
   uint32_t tj[IC_JH * IC_JW];
-  float red[2][IC_NW][4];
+  float4 red[2][IC_NW];
 };
 
 struct IcState {
@@ -92,7 +95,7 @@ struct IcState {
 // u = 1,3,..,21 (11 taps), odd rows u = 0,2,..,22 (12 taps)
 struct IcTaps {
   float px[IC_K], py[IC_K];
-  bool second;  // lanes 0..7 of wavefront 0 own a second tap (256 + t)
+  bool on;  // lane owns a tap (t < 264)
 };
 __device__ __forceinline__ void ic_tap_xy(int j, float &px, float &py) {
   const int p = j / 23, r = j - p * 23;
@@ -109,9 +112,8 @@ __device__ __forceinline__ void ic_tap_xy(int j, float &px, float &py) {
 }
 __device__ __forceinline__ IcTaps ic_make_taps(int t) {
   IcTaps tp;
-  ic_tap_xy(t, tp.px[0], tp.py[0]);
-  tp.second = t < IC_NELEM - IC_T;
-  ic_tap_xy(tp.second ? IC_T + t : 0, tp.px[1], tp.py[1]);
+  tp.on = t < IC_NELEM;
+  ic_tap_xy(tp.on ? t : 0, tp.px[0], tp.py[0]);
   return tp;
 }
 
@@ -126,17 +128,18 @@ __device__ __forceinline__ int ic_safe_int(float v) {
 // Block-wide sums of four per-lane values in the canonical tree order; every lane of every
 // wavefront returns the same bits. `buf` alternates so that one barrier per call suffices.
 __device__ __forceinline__ void ic_block_sum4(float (&v)[4], IcShared &sh, int &buf, int lane, int wave) {
-  float w[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) w[q] = wave_sum_f32(v[q]);
-  if (lane == 0) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) sh.red[buf][wave][q] = w[q];
-  }
+  float4 w = make_float4(v[0], v[1], v[2], v[3]);
+  wave_sum4_f32(w.x, w.y, w.z, w.w);
+  if (lane == 0) sh.red[buf][wave] = w;
   __syncthreads();
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-    v[q] = (sh.red[buf][0][q] + sh.red[buf][1][q]) + (sh.red[buf][2][q] + sh.red[buf][3][q]);
+  const float4 r0 = sh.red[buf][0], r1 = sh.red[buf][1], r2 = sh.red[buf][2], r3 = sh.red[buf][3],
+               r4 = sh.red[buf][4];
+  // balanced tree over 512 zero-padded partials: (w0+w1)+(w2+w3) for taps 0..255, then the half
+  // that holds taps 256..263 and zeros: ((w4+0)+(0+0))
+  v[0] = ((r0.x + r1.x) + (r2.x + r3.x)) + ((r4.x + 0.0f) + 0.0f);
+  v[1] = ((r0.y + r1.y) + (r2.y + r3.y)) + ((r4.y + 0.0f) + 0.0f);
+  v[2] = ((r0.z + r1.z) + (r2.z + r3.z)) + ((r4.z + 0.0f) + 0.0f);
+  v[3] = ((r0.w + r1.w) + (r2.w + r3.w)) + ((r4.w + 0.0f) + 0.0f);
   buf ^= 1;
 }
 
@@ -194,26 +197,14 @@ __device__ __forceinline__ void ic_template(const vo_level &L0, const IcTaps &tp
   {
     const float uc = pt0x + tp.px[0], vc = pt0y + tp.py[0];
     const int u0 = (int)uc, v0 = (int)vc;
-    const bool valid = !(u0 < 1 || u0 >= W - 2 || v0 < 1 || v0 >= H - 2);
-    if (!valid) touched = 1;
+    const bool valid = tp.on && !(u0 < 1 || u0 >= W - 2 || v0 < 1 || v0 >= H - 2);
+    if (tp.on && !valid) touched = 1;
     float nI, nu, nv;
     ic_template_tap(sh.tt, valid ? (u0 - 1) - tox : 0, valid ? (v0 - 1) - toy : 0, ax, ay, axay, nI, nu, nv);
     S.I0[0] = valid ? nI : S.I0[0];
     S.du[0] = valid ? nu : S.du[0];
     S.dv[0] = valid ? nv : S.dv[0];
     if (valid) S.m |= 0x10001u;  // bit 16+k: written by THIS point
-  }
-  if (wave == 0) {  // taps 256..263 live on lanes 0..7 of wavefront 0
-    const float uc = pt0x + tp.px[1], vc = pt0y + tp.py[1];
-    const int u0 = (int)uc, v0 = (int)vc;
-    const bool valid = tp.second && !(u0 < 1 || u0 >= W - 2 || v0 < 1 || v0 >= H - 2);
-    if (tp.second && !valid) touched = 1;
-    float nI, nu, nv;
-    ic_template_tap(sh.tt, valid ? (u0 - 1) - tox : 0, valid ? (v0 - 1) - toy : 0, ax, ay, axay, nI, nu, nv);
-    S.I0[1] = valid ? nI : S.I0[1];
-    S.du[1] = valid ? nu : S.du[1];
-    S.dv[1] = valid ? nv : S.dv[1];
-    if (valid) S.m |= 0x20002u;
   }
 }
 
@@ -263,18 +254,10 @@ __device__ __forceinline__ void ic_sample_I1(const vo_level &L1, const IcTaps &t
   if (!STRICT) S.m &= ~0x300u;
   {
     float val;
-    const bool valid = ic_I1_tap(L1, true, pux + tp.px[0] * scale, puy + tp.py[0] * scale, ax, ay, axay, tile, sb, val);
-    if (!valid) touched = 1;
+    const bool valid = ic_I1_tap(L1, tp.on, pux + tp.px[0] * scale, puy + tp.py[0] * scale, ax, ay, axay, tile, sb, val);
+    if (tp.on && !valid) touched = 1;
     S.I1[0] = valid ? val : S.I1[0];
     if (valid) S.m |= 0x1000100u;  // bit 24+k: written by THIS point
-  }
-  if (wave == 0) {
-    float val;
-    const bool valid =
-        ic_I1_tap(L1, tp.second, pux + tp.px[1] * scale, puy + tp.py[1] * scale, ax, ay, axay, tile, sb, val);
-    if (tp.second && !valid) touched = 1;
-    S.I1[1] = valid ? val : S.I1[1];
-    if (valid) S.m |= 0x2000200u;
   }
 }
 
@@ -410,7 +393,6 @@ __global__ __launch_bounds__(IC_T) void ic_refine_kernel(IcArgs a) {
   float lpx = 0.f, lpy = 0.f;
   const IcTaps tp = ic_make_taps(t);
   const bool entry = a.mask_in ? a.mask_in[pt] != 0 : true;
-  if (a.jac && pt == 0 && t < 16) a.jac[t] = 0;
   IcState S;
   ic_state_clear(S);
   if (entry) {
@@ -422,6 +404,7 @@ __global__ __launch_bounds__(IC_T) void ic_refine_kernel(IcArgs a) {
   const int any_t = __syncthreads_or(touched);
   if (t == 0) {
     if (a.touched) a.touched[pt] = (uint8_t)(any_t ? 1 : 0);
+    if (a.tlist && any_t) a.tlist[atomicAdd(&a.jac[IC_JAC_NT], 1)] = pt;
     if (a.cls) a.cls[pt] = (uint8_t)cls;
     if (a.last_pu) {
       a.last_pu[2 * pt] = lpx;
@@ -432,15 +415,15 @@ __global__ __launch_bounds__(IC_T) void ic_refine_kernel(IcArgs a) {
 
 // ---- tap records (who wrote which tap, and what) -----------------------------------
 // 264 mask bits: wavefront w packs taps 64w..64w+63 into words 2w, 2w+1; taps 256..263 -> word 8.
-__device__ __forceinline__ void ic_store_mask(uint32_t *dst, bool b0, bool b1, int lane, int wave) {
+__device__ __forceinline__ void ic_store_mask(uint32_t *dst, bool b0, int lane, int wave) {
   const unsigned long long m = __ballot(b0);
   if (lane == 0) {
-    dst[2 * wave] = (uint32_t)m;
-    dst[2 * wave + 1] = (uint32_t)(m >> 32);
-  }
-  if (wave == 0) {
-    const unsigned long long m2 = __ballot(b1);
-    if (lane == 0) dst[8] = (uint32_t)m2;
+    if (wave < 4) {
+      dst[2 * wave] = (uint32_t)m;
+      dst[2 * wave + 1] = (uint32_t)(m >> 32);
+    } else {
+      dst[8] = (uint32_t)m;  // taps 256..263 (lanes 8.. of wavefront 4 own no tap)
+    }
   }
 }
 __device__ __forceinline__ bool ic_bit(const uint32_t *w, int j) { return (w[j >> 5] >> (j & 31)) & 1u; }
@@ -449,21 +432,15 @@ __device__ __forceinline__ void ic_store_records(const IcArgs &a, int pt, int t,
                                                  const IcState &S, int cls) {
   if (!a.recW0) return;
   const bool processed = cls >= 1, iterated = cls == 2;
-  ic_store_mask(a.recW0 + (size_t)pt * IC_MW, processed && ((S.m >> 16) & 1u), processed && ((S.m >> 17) & 1u), lane,
-                wave);
-  ic_store_mask(a.recW1 + (size_t)pt * IC_MW, iterated && ((S.m >> 24) & 1u), iterated && ((S.m >> 25) & 1u), lane,
-                wave);
-  float *v0 = a.recV0 + (size_t)pt * 3 * IC_NELEM;
-  float *v1 = a.recV1 + (size_t)pt * IC_NELEM;
-  v0[t] = S.I0[0];
-  v0[IC_NELEM + t] = S.du[0];
-  v0[2 * IC_NELEM + t] = S.dv[0];
-  v1[t] = S.I1[0];
-  if (tp.second) {
-    v0[IC_T + t] = S.I0[1];
-    v0[IC_NELEM + IC_T + t] = S.du[1];
-    v0[2 * IC_NELEM + IC_T + t] = S.dv[1];
-    v1[IC_T + t] = S.I1[1];
+  ic_store_mask(a.recW0 + (size_t)pt * IC_MW, processed && tp.on && ((S.m >> 16) & 1u), lane, wave);
+  ic_store_mask(a.recW1 + (size_t)pt * IC_MW, iterated && tp.on && ((S.m >> 24) & 1u), lane, wave);
+  if (tp.on) {
+    float *v0 = a.recV0 + (size_t)pt * 3 * IC_NELEM;
+    float *v1 = a.recV1 + (size_t)pt * IC_NELEM;
+    v0[t] = S.I0[0];
+    v0[IC_NELEM + t] = S.du[0];
+    v0[2 * IC_NELEM + t] = S.dv[0];
+    v1[t] = S.I1[0];
   }
 }
 
@@ -484,14 +461,14 @@ __global__ __launch_bounds__(IC_T) void ic_jacobi_kernel(IcArgs a, int round) {
   __shared__ uint32_t s_w0[IC_MAXRUN * IC_MW], s_w1[IC_MAXRUN * IC_MW];
   __shared__ uint8_t s_cls[IC_MAXRUN];
   __shared__ int s_first[IC_NW];
-  const int n = a.d_n ? *a.d_n : a.n;
-  const int pt = blockIdx.x;
-  if (pt >= n) return;
   if (round > 0 && a.jac[round - 1] == 0) return;  // converged in the previous round
   if (a.jac[IC_JAC_OVF]) return;                   // sequential fallback will run
-  if (!a.touched[pt]) return;
+  const int n_touched = a.jac[IC_JAC_NT];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  for (int li = blockIdx.x; li < n_touched; li += gridDim.x) {
+  const int pt = a.tlist[li];
+  __syncthreads();  // LDS of the previous list entry is free
 
   // nearest clean (untouched, iterated) predecessor: one candidate per lane
   {
@@ -501,12 +478,12 @@ __global__ __launch_bounds__(IC_T) void ic_jacobi_kernel(IcArgs a, int round) {
     if (lane == 0) s_first[wave] = bal ? (64 * wave + __ffsll((long long)bal) - 1) : 0x7fffffff;
   }
   __syncthreads();
-  int dist = min(min(s_first[0], s_first[1]), min(s_first[2], s_first[3]));  // pt-1-dist is the clean point
+  int dist = min(min(min(s_first[0], s_first[1]), min(s_first[2], s_first[3])), s_first[4]);  // pt-1-dist = clean point
   int lo;
   if (dist == 0x7fffffff) {
-    if (pt > IC_T) {  // no clean point within reach
+    if (pt > IC_T) {  // no clean point among the IC_T candidates
       if (t == 0) atomicExch(&a.jac[IC_JAC_OVF], 1);
-      return;
+      continue;
     }
     lo = 0;
   } else {
@@ -516,7 +493,7 @@ __global__ __launch_bounds__(IC_T) void ic_jacobi_kernel(IcArgs a, int round) {
   const int L = pt - lo;  // predecessors lo .. pt-1
   if (L > IC_MAXRUN) {
     if (t == 0) atomicExch(&a.jac[IC_JAC_OVF], 1);
-    return;
+    continue;
   }
   for (int i = t; i < L * IC_MW; i += IC_T) {
     s_w0[i] = a.recW0[(size_t)lo * IC_MW + i];
@@ -529,11 +506,9 @@ __global__ __launch_bounds__(IC_T) void ic_jacobi_kernel(IcArgs a, int round) {
   const IcTaps tp = ic_make_taps(t);
   IcState S;
   ic_state_clear(S);
-  // nearest earlier writer per tap
-#pragma unroll
-  for (int k = 0; k < IC_K; ++k) {
-    if (k == 1 && !tp.second) break;
-    const int j = k ? IC_T + t : t;
+  // nearest earlier writer of this lane's tap
+  if (tp.on) {
+    const int j = t;
     int src0 = -1, src1 = -1;
     for (int r = L - 1; r >= 0 && (src0 < 0 || src1 < 0); --r) {
       const int c = s_cls[r];
@@ -543,14 +518,14 @@ __global__ __launch_bounds__(IC_T) void ic_jacobi_kernel(IcArgs a, int round) {
     }
     if (src0 >= 0) {
       const float *v0 = a.recV0 + (size_t)src0 * 3 * IC_NELEM;
-      S.I0[k] = v0[j];
-      S.du[k] = v0[IC_NELEM + j];
-      S.dv[k] = v0[2 * IC_NELEM + j];
-      S.m |= 1u << k;
+      S.I0[0] = v0[j];
+      S.du[0] = v0[IC_NELEM + j];
+      S.dv[0] = v0[2 * IC_NELEM + j];
+      S.m |= 1u;
     }
     if (src1 >= 0) {
-      S.I1[k] = a.recV1[(size_t)src1 * IC_NELEM + j];
-      S.m |= 0x100u << k;
+      S.I1[0] = a.recV1[(size_t)src1 * IC_NELEM + j];
+      S.m |= 0x100u;
     }
   }
   // skip when the I1 pre-state is exactly the one this point last ran with (template part is static)
@@ -558,16 +533,13 @@ __global__ __launch_bounds__(IC_T) void ic_jacobi_kernel(IcArgs a, int round) {
     float *p1 = a.pre1 + (size_t)pt * IC_NELEM;
     uint32_t *pm = a.preM + (size_t)pt * IC_MW;
     int diff = round == 0;
-    const bool b0 = (S.m >> 8) & 1u, b1 = (S.m >> 9) & 1u;
-    if (!diff) {
+    const bool b0 = tp.on && ((S.m >> 8) & 1u);
+    if (!diff && tp.on) {
       if (b0 != ic_bit(pm, t) || (b0 && __float_as_uint(p1[t]) != __float_as_uint(S.I1[0]))) diff = 1;
-      if (tp.second && (b1 != ic_bit(pm, IC_T + t) || (b1 && __float_as_uint(p1[IC_T + t]) != __float_as_uint(S.I1[1]))))
-        diff = 1;
     }
-    if (!__syncthreads_or(diff)) return;
-    p1[t] = S.I1[0];
-    if (tp.second) p1[IC_T + t] = S.I1[1];
-    ic_store_mask(pm, b0, b1, lane, wave);
+    if (!__syncthreads_or(diff)) continue;
+    if (tp.on) p1[t] = S.I1[0];
+    ic_store_mask(pm, b0, lane, wave);
   }
   if (t == 0) {
     a.pts_track[2 * pt] = a.pts_prior[2 * pt];
@@ -578,22 +550,20 @@ __global__ __launch_bounds__(IC_T) void ic_jacobi_kernel(IcArgs a, int round) {
   const int cls = ic_point<true>(a, tp, pt, t, lane, wave, sh, buf, S, dummy, lx, ly);
   // own I1 writes of this run of the point vs the stored record
   const bool iterated = cls == 2;
-  const bool o0 = iterated && ((S.m >> 24) & 1u), o1 = iterated && ((S.m >> 25) & 1u);
+  const bool o0 = iterated && tp.on && ((S.m >> 24) & 1u);
   uint32_t *w1 = a.recW1 + (size_t)pt * IC_MW;
   float *v1 = a.recV1 + (size_t)pt * IC_NELEM;
   int changed = a.cls[pt] != cls;
-  if (o0 != ic_bit(w1, t) || (o0 && __float_as_uint(v1[t]) != __float_as_uint(S.I1[0]))) changed = 1;
-  if (tp.second && (o1 != ic_bit(w1, IC_T + t) || (o1 && __float_as_uint(v1[IC_T + t]) != __float_as_uint(S.I1[1]))))
-    changed = 1;
+  if (tp.on && (o0 != ic_bit(w1, t) || (o0 && __float_as_uint(v1[t]) != __float_as_uint(S.I1[0])))) changed = 1;
   if (__syncthreads_or(changed)) {
-    v1[t] = S.I1[0];
-    if (tp.second) v1[IC_T + t] = S.I1[1];
-    ic_store_mask(w1, o0, o1, lane, wave);
+    if (tp.on) v1[t] = S.I1[0];
+    ic_store_mask(w1, o0, lane, wave);
     if (t == 0) {
       a.cls[pt] = (uint8_t)cls;
       atomicAdd(&a.jac[round], 1);
     }
   }
+  }  // touched list
 }
 
 // ---- pass 2: sequential replay of the runs that contain touched points --------------
@@ -670,13 +640,14 @@ static int ic_args(vo_ctx *c, int slot0, int slot1, IcArgs &a, int *d_flags) {
 static int ic_records(vo_ctx *c, IcArgs &a) {
   if (!c->ic_rec) {
     const size_t N = (size_t)c->cfg.max_points;
-    const size_t bytes = N * (2 * IC_MW * 4 + 3 * IC_NELEM * 4 + IC_NELEM * 4 + IC_NELEM * 4 + IC_MW * 4) + 64;
+    const size_t bytes = N * (4 + 2 * IC_MW * 4 + 3 * IC_NELEM * 4 + IC_NELEM * 4 + IC_NELEM * 4 + IC_MW * 4) + 64;
     VO_CHECK_HIP(c, hipMalloc(&c->ic_rec, bytes));
     VO_CHECK_HIP(c, hipMemsetAsync(c->ic_rec, 0, bytes, c->stream));
   }
   const size_t N = (size_t)c->cfg.max_points;
   uint8_t *p = (uint8_t *)c->ic_rec;
   a.jac = (int *)p;                 p += 64;
+  a.tlist = (int *)p;               p += N * 4;
   a.recW0 = (uint32_t *)p;          p += N * IC_MW * 4;
   a.recW1 = (uint32_t *)p;          p += N * IC_MW * 4;
   a.preM = (uint32_t *)p;           p += N * IC_MW * 4;
@@ -700,6 +671,7 @@ int vo_ic_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, const fl
   if (with_records) {
     rc = ic_records(c, a);
     if (rc) return rc;
+    VO_CHECK_HIP(c, hipMemsetAsync(a.jac, 0, 64, c->stream));
   }
   a.mask_in = d_mask_in;
   a.pts0 = d_pts0;
@@ -744,7 +716,7 @@ int vo_ic_strict_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, c
   a.d_n = d_n;
   vo_prof_begin(c, VO_K_IC);
   for (int r = 0; r < IC_ROUNDS; ++r)
-    hipLaunchKernelGGL(ic_jacobi_kernel, dim3(n_max), dim3(IC_T), 0, c->stream, a, r);
+    hipLaunchKernelGGL(ic_jacobi_kernel, dim3(n_max < IC_JGRID ? n_max : IC_JGRID), dim3(IC_T), 0, c->stream, a, r);
   hipLaunchKernelGGL(ic_strict_kernel, dim3(n_max), dim3(IC_T), 0, c->stream, a);
   vo_prof_end(c);
   VO_CHECK_HIP(c, hipGetLastError());

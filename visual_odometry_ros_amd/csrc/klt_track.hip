@@ -220,9 +220,12 @@ __global__ __launch_bounds__(64) void klt_track_kernel(KltArgs a) {
         pA22 += tY[j] * tY[j];
       }
     }
-    const float A11 = wave_sum_i32_to_f32(pA11) * FLT_SCALE;
-    const float A12 = wave_sum_i32_to_f32(pA12) * FLT_SCALE;
-    const float A22 = wave_sum_i32_to_f32(pA22) * FLT_SCALE;
+    float sA11, sA12, sA22, sdummy;
+    wave_sum2_i32_to_f32(pA11, pA12, sA11, sA12);
+    wave_sum2_i32_to_f32(pA22, 0, sA22, sdummy);
+    const float A11 = sA11 * FLT_SCALE;
+    const float A12 = sA12 * FLT_SCALE;
+    const float A22 = sA22 * FLT_SCALE;
     float D = A11 * A22 - A12 * A12;
     const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
     if (minEig < a.min_eig || D < 1.19209290e-07f) {
@@ -296,8 +299,10 @@ __global__ __launch_bounds__(64) void klt_track_kernel(KltArgs a) {
         pb1 += diff[k] * tX[k];
         pb2 += diff[k] * tY[k];
       }
-      const float b1 = wave_sum_i32_to_f32(pb1) * FLT_SCALE;
-      const float b2 = wave_sum_i32_to_f32(pb2) * FLT_SCALE;
+      float sb1, sb2;
+      wave_sum2_i32_to_f32(pb1, pb2, sb1, sb2);
+      const float b1 = sb1 * FLT_SCALE;
+      const float b2 = sb2 * FLT_SCALE;
       const float dx = (float)((A12 * b2 - A22 * b1) * D);
       const float dy = (float)((A12 * b1 - A11 * b2) * D);
       nextx += dx;

@@ -137,6 +137,41 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
   v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// Four independent sums, stepped together so that each DPP's wait states are filled by the other
+// three chains (a lone wavefront otherwise stalls on every dependent DPP). Same tree as wave_sum_f32.
+__device__ __forceinline__ void wave_sum4_f32(float &a, float &b, float &c, float &d) {
+#define VO_STEP4(CTRL)                                    \
+  {                                                       \
+    const float ta = dpp_f32<CTRL>(a), tb = dpp_f32<CTRL>(b), tc = dpp_f32<CTRL>(c), td = dpp_f32<CTRL>(d); \
+    a = a + ta;                                           \
+    b = b + tb;                                           \
+    c = c + tc;                                           \
+    d = d + td;                                           \
+  }
+  VO_STEP4(0xB1)
+  VO_STEP4(0x4E)
+  VO_STEP4(0x141)
+  VO_STEP4(0x140)
+#undef VO_STEP4
+#define VO_BC4(CTRL, RM)                                                                                   \
+  {                                                                                                        \
+    const float ta = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), CTRL, RM, 0xF, false)); \
+    const float tb = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), CTRL, RM, 0xF, false)); \
+    const float tc = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c), CTRL, RM, 0xF, false)); \
+    const float td = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), CTRL, RM, 0xF, false)); \
+    a = a + ta;                                                                                            \
+    b = b + tb;                                                                                            \
+    c = c + tc;                                                                                            \
+    d = d + td;                                                                                            \
+  }
+  VO_BC4(0x142, 0xA)
+  VO_BC4(0x143, 0xC)
+#undef VO_BC4
+  a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 63));
+  b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b), 63));
+  c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c), 63));
+  d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), 63));
+}
 __device__ __forceinline__ int wave_sum_i32(int v) {
   v = v + dpp_i32<0xB1>(v);
   v = v + dpp_i32<0x4E>(v);
@@ -145,6 +180,46 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
   v = v + __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
   v = v + __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
   return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ void wave_sum4_i32(int &a, int &b, int &c, int &d) {
+#define VO_STEP4I(CTRL)                                                                       \
+  {                                                                                           \
+    const int ta = dpp_i32<CTRL>(a), tb = dpp_i32<CTRL>(b), tc = dpp_i32<CTRL>(c), td = dpp_i32<CTRL>(d); \
+    a += ta;                                                                                  \
+    b += tb;                                                                                  \
+    c += tc;                                                                                  \
+    d += td;                                                                                  \
+  }
+  VO_STEP4I(0xB1)
+  VO_STEP4I(0x4E)
+  VO_STEP4I(0x141)
+  VO_STEP4I(0x140)
+#undef VO_STEP4I
+#define VO_BC4I(CTRL, RM)                                                  \
+  {                                                                        \
+    const int ta = __builtin_amdgcn_update_dpp(0, a, CTRL, RM, 0xF, false); \
+    const int tb = __builtin_amdgcn_update_dpp(0, b, CTRL, RM, 0xF, false); \
+    const int tc = __builtin_amdgcn_update_dpp(0, c, CTRL, RM, 0xF, false); \
+    const int td = __builtin_amdgcn_update_dpp(0, d, CTRL, RM, 0xF, false); \
+    a += ta;                                                               \
+    b += tb;                                                               \
+    c += tc;                                                               \
+    d += td;                                                               \
+  }
+  VO_BC4I(0x142, 0xA)
+  VO_BC4I(0x143, 0xC)
+#undef VO_BC4I
+  a = __builtin_amdgcn_readlane(a, 63);
+  b = __builtin_amdgcn_readlane(b, 63);
+  c = __builtin_amdgcn_readlane(c, 63);
+  d = __builtin_amdgcn_readlane(d, 63);
+}
+// two exact (float)(int64 sum) at once: 16/16 split of both partials, one interleaved 4-way butterfly
+__device__ __forceinline__ void wave_sum2_i32_to_f32(int p, int q, float &fp, float &fq) {
+  int plo = p & 0xFFFF, phi = p >> 16, qlo = q & 0xFFFF, qhi = q >> 16;
+  wave_sum4_i32(plo, phi, qlo, qhi);
+  fp = (float)((double)phi * 65536.0 + (double)plo);
+  fq = (float)((double)qhi * 65536.0 + (double)qlo);
 }
 // Exact 64-bit sum of 64 int32 lane values (each |v| < 2^30): split 16/16 so the
 // two int32 wave sums cannot overflow, recombine in int64.
