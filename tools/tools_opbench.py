@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Times single operators (IC refine, KLT) on one bench-shaped frame with HIP events."""
 import sys, time, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, '..')
 import visual_odometry_ros_amd as V
 from visual_odometry_ros_amd import synthetic as S
 from visual_odometry_ros_amd.api import make_stereo_params, StereoFramePipeline

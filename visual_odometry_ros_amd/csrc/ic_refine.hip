@@ -304,17 +304,28 @@ __device__ int ic_point(const IcArgs &a, const IcTaps &tp, int pt, int t, int la
   float tx = pt1x - pt0x, ty = pt1y - pt0y;
   int err_flag = 0;
   const IcTile tile = ic_load_I1_tile(a.I1, pt1x, pt1y, t, sh);
+#ifdef IC_STAMP
+  unsigned long long stA = 0, stB = 0, stC = 0, st0 = 0, st1 = 0, st2 = 0;
+  int stN = 0;
+#define IC_STAMP_AT(x) x = __builtin_amdgcn_s_memtime();
+#else
+#define IC_STAMP_AT(x)
+#endif
+  // ax = x - floorf(x) lies in [0, 1] for every finite x, so the reference's range test (:407-411)
+  // can only be "failed" by a NaN, which its next test reports; and a NaN in ax/ay, in a used tap
+  // or in the update reaches dtu + dtv (all other inputs are finite u8-derived values). One
+  // wave-uniform test per iteration therefore covers the three throw sites (:412, :438-448, :466);
+  // which one it was is sorted out after the loop, off the hot path.
+  float b1 = 0.f, b2 = 0.f, e2 = 0.f;
+  bool nan_exit = false;
   for (int iter = 0; iter < IC_MAX_ITER; ++iter) {
+    IC_STAMP_AT(st0)
     const float pux = pt0x + tx, puy = pt0y + ty;
     ic_frac(pux, puy, ax, ay, axay);
-    if (ax < 0 || ax > 1 || ay < 0 || ay > 1) break;  // :407-411 (mask is overwritten below, as in the reference)
-    if (isnan(ax + ay)) {
-      err_flag |= 1;
-      break;
-    }
     last_pux = pux;
     last_puy = puy;
     ic_sample_I1<STRICT>(a.I1, tp, scale, pux, puy, ax, ay, axay, wave, S, touched, tile, sh);
+    IC_STAMP_AT(st1)
     float v[4] = {0.f, 0.f, 0.f, 0.f};  // b1, b2, sum r^2, count
 #pragma unroll
     for (int k = 0; k < IC_K; ++k)
@@ -326,31 +337,52 @@ __device__ int ic_point(const IcArgs &a, const IcTaps &tp, int pt, int t, int la
         v[3] += 1.0f;
       }
     ic_block_sum4(v, sh, buf, lane, wave);
-    // the reference throws "I0 I1 nan" / "du0 dv0 nan" when a used tap is NaN (:438-448); such a
-    // NaN reaches every sum, so test the sums (all inputs are finite u8-derived values otherwise)
-    if (isnan(v[0]) || isnan(v[1]) || isnan(v[2])) {
-      err_flag |= 2;
-      break;
-    }
-    const float b1 = v[0], b2 = v[1];
-    err_curr = v[2];
+    IC_STAMP_AT(st2)
+    b1 = v[0];
+    b2 = v[1];
+    e2 = v[2];
     const float dtu = (-iD_A22 * b1 + iD_A12 * b2);
     const float dtv = (iD_A12 * b1 - iD_A11 * b2);
-    if (isnan(dtu + dtv)) {
-      err_flag |= 4;
+    const float e = sqrtf(e2 / v[3]);
+    const float err_rate = fabsf(err_prev - e) / err_prev;
+    const float dt_norm = dtu * dtu + dtv * dtv;
+    const bool is_nan = isnan(dtu + dtv) | isnan(ax + ay);
+    const bool conv = (iter > 1) & ((err_rate <= 1e-3f) | (dt_norm <= 1e-4f));
+#ifdef IC_STAMP
+    {
+      unsigned long long st3 = __builtin_amdgcn_s_memtime();
+      stA += st1 - st0;
+      stB += st2 - st1;
+      stC += st3 - st2;
+      ++stN;
+    }
+#endif
+    // every lane holds the same values: make the exit a scalar branch
+    const int ex = __builtin_amdgcn_readfirstlane((is_nan ? 2 : 0) | (conv ? 1 : 0));
+    if (ex & 2) {
+      nan_exit = true;
       break;
     }
     tx += dtu;
     ty += dtv;
-    err_curr /= v[3];
-    err_curr = sqrtf(err_curr);
-    const float err_rate = fabsf(err_prev - err_curr) / err_prev;
-    const float dt_norm = dtu * dtu + dtv * dtv;
-    if (iter > 1) {
-      if (err_rate <= 1e-3f || dt_norm <= 1e-4f) break;
-    }
-    err_prev = err_curr;
+    err_curr = e;
+    if (ex) break;
+    err_prev = e;
   }
+  if (nan_exit) {
+    // the reference would have stopped before this iteration's sampling (ax/ay NaN), at the
+    // tap test (patch NaN) or at the update test; err_curr keeps the previous iteration's value
+    err_flag = isnan(ax + ay) ? 1 : ((isnan(b1) || isnan(b2) || isnan(e2)) ? 2 : 4);
+  }
+#ifdef IC_STAMP
+  if (t == 0 && a.pre1 && !STRICT) {
+    float *dbg = a.pre1 + (size_t)pt * IC_NELEM;
+    dbg[0] = (float)stN;
+    dbg[1] = (float)stA;
+    dbg[2] = (float)stB;
+    dbg[3] = (float)stC;
+  }
+#endif
   if (t == 0) {
     if (err_flag) {
       atomicOr(a.flags, err_flag);
@@ -393,6 +425,9 @@ __global__ __launch_bounds__(IC_T) void ic_refine_kernel(IcArgs a) {
   float lpx = 0.f, lpy = 0.f;
   const IcTaps tp = ic_make_taps(t);
   const bool entry = a.mask_in ? a.mask_in[pt] != 0 : true;
+#ifdef IC_STAMP
+  const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
   IcState S;
   ic_state_clear(S);
   if (entry) {
@@ -401,6 +436,14 @@ __global__ __launch_bounds__(IC_T) void ic_refine_kernel(IcArgs a) {
     a.mask[pt] = 0;
   }
   ic_store_records(a, pt, t, lane, wave, tp, S, cls);
+#ifdef IC_STAMP
+  if (t == 0 && a.pre1) {
+    float *dbg = a.pre1 + (size_t)pt * IC_NELEM;
+    const unsigned long long wg_t1 = __builtin_amdgcn_s_memrealtime();
+    dbg[4] = (float)(wg_t0 & 0xFFFFFF);
+    dbg[5] = (float)(wg_t1 & 0xFFFFFF);
+  }
+#endif
   const int any_t = __syncthreads_or(touched);
   if (t == 0) {
     if (a.touched) a.touched[pt] = (uint8_t)(any_t ? 1 : 0);
@@ -722,3 +765,16 @@ int vo_ic_strict_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, c
   VO_CHECK_HIP(c, hipGetLastError());
   return VO_OK;
 }
+
+#ifdef IC_STAMP
+// diagnostic (IC_STAMP builds): first `k` floats of each point's pre1 row
+extern "C" int vo_debug_ic_rows(vo_ctx *c, float *dst, int k, int n) {
+  if (!c || !c->ic_rec || !dst) return VO_ERR_INVALID;
+  IcArgs a;
+  memset(&a, 0, sizeof(a));
+  ic_records(c, a);
+  VO_CHECK_HIP(c, hipMemcpy2D(dst, sizeof(float) * k, a.pre1, sizeof(float) * IC_NELEM, sizeof(float) * k, n,
+                              hipMemcpyDeviceToHost));
+  return VO_OK;
+}
+#endif
