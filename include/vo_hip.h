@@ -141,7 +141,9 @@ int vo_calc_prior(vo_ctx *ctx, const float *pts0, int n_pts0, const float *Xw, i
  * cv::Sobel(ksize 3, CV_32F) pair the drivers compute first
  * (stereo_vo.cpp:549-552, mono_vo.cpp:779-782). pts_track and mask_valid are
  * in/out. strict_border != 0 reproduces the reference's never-reset tap masks
- * for points whose taps leave the image; 0 excludes such taps. */
+ * for points whose taps leave the image; 0 excludes such taps.
+ * 1 = parallel fixed-point replay with a sequential fallback, 2 = sequential
+ * replay only (validation of the fallback; same results, slower). */
 int vo_track_with_scale(vo_ctx *ctx, int slot0, int slot1, const float *pts0,
                         const float *scale_est, int n, float *pts_track, uint8_t *mask_valid,
                         int strict_border);

@@ -86,6 +86,10 @@ def test_ic_border_points_strict_reference_semantics(ctx, vo, oracle, seed, orde
     assert rc == 0 and tb.sum() > 30
     assert np.array_equal(m, mr)
     assert np.array_equal(p.view(np.uint32), pr.view(np.uint32))
+    # the sequential fallback of the parallel replay gives the same bits
+    p2, m2 = ft.trackWithScale(0, 1, pts0, scale, prior, m_in, strict_border=2)
+    assert np.array_equal(m2, mr)
+    assert np.array_equal(p2.view(np.uint32), pr.view(np.uint32))
     # the two semantics genuinely differ on this input (otherwise the test proves nothing)
     rc, pm, mm, _ = oracle.track_with_scale(img0, img1, pts0, scale, prior, m_in, oracle.IC_MASKED,
                                             oracle.SUM_TREE)

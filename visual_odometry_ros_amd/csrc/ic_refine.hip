@@ -12,28 +12,32 @@
 //
 // The kernel is latency-bound (a dependent sample -> reduce -> 2x2 solve chain per
 // iteration, up to 30 iterations per point), so the 264 checkerboard taps of the
-// 23x23 window are spread over 256 lanes: lane t owns tap t, lanes 0..7 also tap
-// 256+t. One iteration is ~50 VALU instructions per lane, a DPP butterfly per
-// wavefront, one LDS exchange of the four wave totals and one s_barrier; every
-// wavefront then solves the 2x2 system redundantly (identical arithmetic).
-// Float sums use the canonical order "256 strided partials (element j -> partial
-// j mod 256), balanced binary tree" — the oracle's VO_SUM_TREE with width 256.
+// 23x23 window are spread one per lane over five wavefronts (lane t owns tap t,
+// lanes 264..319 idle). One iteration is ~250 instructions per wavefront: the
+// bilinear tap from an LDS-staged search tile, a 4-way interleaved DPP butterfly,
+// one LDS exchange of the five wave totals behind a single s_barrier, and the 2x2
+// solve + error test that every wavefront repeats redundantly (identical
+// arithmetic, so the loop exit is a scalar branch).
+// Float sums use the canonical order "balanced binary tree over the taps in index
+// order, zero-padded to 512" — the oracle's VO_SUM_TREE for this operator.
 //
-// Border semantics, two kernels:
+// Border semantics, three kernels:
 //  * ic_refine_kernel (all points in parallel): a tap whose footprint leaves the
 //    valid region is excluded from that evaluation (oracle VO_IC_BORDER_MASKED);
 //    such points are reported in `touched`. Every point that never touches the
 //    border gets exactly the reference result.
-//  * ic_strict_kernel (optional second pass): the reference allocates its tap
-//    value / mask vectors once per call and never resets them
-//    (feature_tracker.cpp:324-333, image_processing.cpp:88-89,276-279), so an
-//    out-of-image tap keeps the value and mask bit of the most recent earlier
-//    evaluation in which it was inside. Only touched points
-//    see that state, and the state after an untouched, iterated ("clean") point
-//    is fully determined by that point alone. So each run of points between two
-//    clean points that contains a touched point is replayed sequentially by one
-//    workgroup, the carried state living in registers (one tap per lane); runs
-//    replay in parallel.
+//  * The reference allocates its tap value / mask vectors once per call and never
+//    resets them (feature_tracker.cpp:324-333, image_processing.cpp:88-89,276-279),
+//    so an out-of-image tap keeps the value and mask bit of the most recent earlier
+//    evaluation in which it was inside. Only touched points see
+//    that state, and the state after an untouched, iterated ("clean") point is
+//    fully determined by that point alone.
+//    ic_jacobi_kernel recomputes all touched points in parallel from per-point tap
+//    records, round after round inside one launch, until a round changes nothing
+//    (see the comment at the kernel);
+//  * ic_strict_kernel is the sequential replay (one workgroup walks a run of points
+//    between two clean points, the carried state living in registers); it only
+//    runs when the parallel replay asks for it.
 #include "vo_internal.hpp"
 #include "vo_kernels.hpp"
 
@@ -48,10 +52,16 @@
 #define IC_JH 40   // I1 search tile rows
 #define IC_MW 9        // mask words per point (264 bits)
 #define IC_MAXRUN 192  // longest run the parallel strict replay handles (else sequential fallback)
-#define IC_ROUNDS 10
 #define IC_JAC_OVF 15
 #define IC_JAC_NT 14
-#define IC_JGRID 160   // workgroups of a replay round; each strides over the touched list
+#define IC_JAC_VER 13    // replay kernel: number of record publications so far
+#define IC_JAC_SLOTS 16  // replay kernel: one "idle at version" word per workgroup
+#define IC_JAC_WORDS (IC_JAC_SLOTS + IC_JGRID)
+#define IC_MAX_PASSES 64
+#define IC_JAC_BYTES (((IC_JAC_WORDS * 4 + 63) / 64) * 64)
+#define IC_JGRID 160   // workgroups of the replay kernel (<= 256 CUs: all co-resident); each strides over the touched list
+#define IC_SPIN_LIMIT (1 << 17)  // idle polls before a workgroup gives up (~0.2 s) and requests the sequential replay
+#define IC_DBG_OFF 4096  // IC_STAMP builds: debug words in the unused tail of tlist (needs max_points >= 4200)
 #ifndef IC_MAX_ITER
 #define IC_MAX_ITER 30  // feature_tracker.cpp:290
 #endif
@@ -76,7 +86,7 @@ struct IcArgs {
   float *recV1;             // [n][IC_NELEM] last I1 value the point wrote per tap
   float *pre1;              // [n][IC_NELEM] I1 pre-state the point last ran with
   uint32_t *preM;           // [n][IC_MW] its mask
-  int *jac;                 // [r] = records changed in round r ; [IC_JAC_OVF] = run too long ; [IC_JAC_NT] = #touched
+  int *jac;                 // control words of the replay: [IC_JAC_NT] #touched, [IC_JAC_OVF], [IC_JAC_VER], slots
   int *tlist;               // indices of the touched points (any order)
 };
 
@@ -304,9 +314,12 @@ __device__ int ic_point(const IcArgs &a, const IcTaps &tp, int pt, int t, int la
   float tx = pt1x - pt0x, ty = pt1y - pt0y;
   int err_flag = 0;
   const IcTile tile = ic_load_I1_tile(a.I1, pt1x, pt1y, t, sh);
-#ifdef IC_STAMP
-  unsigned long long stA = 0, stB = 0, stC = 0, st0 = 0, st1 = 0, st2 = 0;
+#if defined(IC_STAMP) && IC_STAMP >= 2
+#define IC_STAMP_ITER
+#endif
   int stN = 0;
+#ifdef IC_STAMP_ITER
+  unsigned long long stA = 0, stB = 0, stC = 0, st0 = 0, st1 = 0, st2 = 0;
 #define IC_STAMP_AT(x) x = __builtin_amdgcn_s_memtime();
 #else
 #define IC_STAMP_AT(x)
@@ -348,13 +361,13 @@ __device__ int ic_point(const IcArgs &a, const IcTaps &tp, int pt, int t, int la
     const float dt_norm = dtu * dtu + dtv * dtv;
     const bool is_nan = isnan(dtu + dtv) | isnan(ax + ay);
     const bool conv = (iter > 1) & ((err_rate <= 1e-3f) | (dt_norm <= 1e-4f));
-#ifdef IC_STAMP
+    ++stN;
+#ifdef IC_STAMP_ITER
     {
       unsigned long long st3 = __builtin_amdgcn_s_memtime();
       stA += st1 - st0;
       stB += st2 - st1;
       stC += st3 - st2;
-      ++stN;
     }
 #endif
     // every lane holds the same values: make the exit a scalar branch
@@ -378,9 +391,11 @@ __device__ int ic_point(const IcArgs &a, const IcTaps &tp, int pt, int t, int la
   if (t == 0 && a.pre1 && !STRICT) {
     float *dbg = a.pre1 + (size_t)pt * IC_NELEM;
     dbg[0] = (float)stN;
+#ifdef IC_STAMP_ITER
     dbg[1] = (float)stA;
     dbg[2] = (float)stB;
     dbg[3] = (float)stC;
+#endif
   }
 #endif
   if (t == 0) {
@@ -493,23 +508,64 @@ __device__ __forceinline__ void ic_store_records(const IcArgs &a, int pt, int t,
 // point's own trajectory). Measured on forward-driving streams the runs of consecutive touched
 // points are ~100 long but the true value-dependency depth is <= 6, so instead of replaying a
 // run sequentially every touched point is recomputed in parallel from the current records of its
-// predecessors, round after round, until a whole round changes nothing. That fixed point is
-// unique and equals the sequential (reference) result: by induction over the index order, a
-// point whose predecessors' records are final computes its final record. Reads may race with
-// writes of the same round; a racy read can only delay convergence, because the terminating
-// round (no record changed) reads stable data. If IC_ROUNDS rounds do not converge, or a run
-// exceeds IC_MAXRUN, ic_strict_kernel replays sequentially.
-__global__ __launch_bounds__(IC_T) void ic_jacobi_kernel(IcArgs a, int round) {
+// predecessors, again and again, until nothing changes any more. That fixed point is unique and
+// equals the sequential (reference) result: by induction over the index order, a point whose
+// predecessors' records are final computes its final record the next time it looks.
+//
+// The iteration is asynchronous ("chaotic relaxation"): one launch, each workgroup owns one or
+// more touched points and loops  look -> (recompute, publish)  without waiting for the others,
+// so a slow point (30 iterations) only delays the points that really depend on it.
+//   publish : write the record, release fence, bump the global `version` counter;
+//   look    : read `version` (acquire), rebuild the pre-state from the predecessors' records and
+//             compare the taps the point can observe with the pre-state of its last run;
+//   idle    : a workgroup whose pass changed nothing stores version+1 in its slot and polls;
+//             it looks again as soon as `version` moves.
+// Reads may race with a concurrent publish; a torn read can only cause an extra recomputation,
+// because every publish ends in a version bump that makes every reader look again.
+// Termination: version == v before and after seeing every slot at v+1 means every workgroup
+// finished a full pass at version v and nobody can publish any more. All waits are bounded
+// (IC_SPIN_LIMIT polls, IC_MAX_PASSES passes); on overflow, or when a run exceeds IC_MAXRUN,
+// IC_JAC_OVF is raised and ic_strict_kernel replays sequentially.
+__device__ __forceinline__ int ic_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ic_st(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(IC_T) void ic_jacobi_kernel(IcArgs a) {
   __shared__ IcShared sh;
   __shared__ uint32_t s_w0[IC_MAXRUN * IC_MW], s_w1[IC_MAXRUN * IC_MW];
   __shared__ uint8_t s_cls[IC_MAXRUN];
   __shared__ int s_first[IC_NW];
-  if (round > 0 && a.jac[round - 1] == 0) return;  // converged in the previous round
-  if (a.jac[IC_JAC_OVF]) return;                   // sequential fallback will run
+  __shared__ int s_ctl;
   const int n_touched = a.jac[IC_JAC_NT];
+  if (n_touched == 0) return;  // nothing left the image: pass 1 already is the reference result
+  // the workgroups that own list entries are co-resident by construction (IC_JGRID <= number of
+  // CUs, and one workgroup fits any CU next to whatever else runs)
+  const int P = min((int)gridDim.x, n_touched);
+  if ((int)blockIdx.x >= P) return;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  for (int li = blockIdx.x; li < n_touched; li += gridDim.x) {
+  int *const ver = &a.jac[IC_JAC_VER];
+  int *const ovf = &a.jac[IC_JAC_OVF];
+  int *const slots = a.jac + IC_JAC_SLOTS;
+  int polls = 0;
+#ifdef IC_STAMP
+  if (t == 0 && blockIdx.x == 0) a.tlist[IC_DBG_OFF + 31] = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff);
+#endif
+  for (int pass = 0;; ++pass) {
+  // ---- look ----
+  if (t == 0) {
+    int v = ic_ld(ver);
+    if (ic_ld(ovf) || pass >= IC_MAX_PASSES) {
+      if (pass >= IC_MAX_PASSES) atomicExch(ovf, 1);
+      v = -1;
+    }
+    __threadfence();
+    s_ctl = v;
+  }
+  __syncthreads();
+  const int v = s_ctl;
+  if (v < 0) break;
+  int any_change = 0;
+  for (int li = blockIdx.x; li < n_touched; li += P) {
   const int pt = a.tlist[li];
   __syncthreads();  // LDS of the previous list entry is free
 
@@ -525,17 +581,16 @@ __global__ __launch_bounds__(IC_T) void ic_jacobi_kernel(IcArgs a, int round) {
   int lo;
   if (dist == 0x7fffffff) {
     if (pt > IC_T) {  // no clean point among the IC_T candidates
-      if (t == 0) atomicExch(&a.jac[IC_JAC_OVF], 1);
+      if (t == 0) atomicExch(ovf, 1);
       continue;
     }
     lo = 0;
   } else {
     lo = pt - 1 - dist;
   }
-  const bool have_clean = dist != 0x7fffffff;
   const int L = pt - lo;  // predecessors lo .. pt-1
   if (L > IC_MAXRUN) {
-    if (t == 0) atomicExch(&a.jac[IC_JAC_OVF], 1);
+    if (t == 0) atomicExch(ovf, 1);
     continue;
   }
   for (int i = t; i < L * IC_MW; i += IC_T) {
@@ -544,7 +599,6 @@ __global__ __launch_bounds__(IC_T) void ic_jacobi_kernel(IcArgs a, int round) {
   }
   for (int i = t; i < L; i += IC_T) s_cls[i] = a.cls[lo + i];
   __syncthreads();
-  (void)have_clean;
 
   const IcTaps tp = ic_make_taps(t);
   IcState S;
@@ -575,12 +629,26 @@ __global__ __launch_bounds__(IC_T) void ic_jacobi_kernel(IcArgs a, int round) {
   {
     float *p1 = a.pre1 + (size_t)pt * IC_NELEM;
     uint32_t *pm = a.preM + (size_t)pt * IC_MW;
-    int diff = round == 0;
+    int diff = pass == 0;
     const bool b0 = tp.on && ((S.m >> 8) & 1u);
-    if (!diff && tp.on) {
+    // Only taps that are outside the image at the point's FIRST I1 evaluation (the prior position:
+    // static) can show their pre-state to the point; every other tap is overwritten by that
+    // evaluation before anything reads it. Comparing just those taps prunes the false dependencies.
+    bool seen;
+    {
+      const float p0x = a.pts0[2 * pt], p0y = a.pts0[2 * pt + 1];
+      const float pux = p0x + (a.pts_prior[2 * pt] - p0x), puy = p0y + (a.pts_prior[2 * pt + 1] - p0y);
+      const float sc = a.scale[pt];
+      const float uc = pux + tp.px[0] * sc, vc = puy + tp.py[0] * sc;
+      seen = uc < 1 || uc >= (float)(a.I1.w - 2) || vc < 1 || vc >= (float)(a.I1.h - 2);
+    }
+    if (!diff && tp.on && seen) {
       if (b0 != ic_bit(pm, t) || (b0 && __float_as_uint(p1[t]) != __float_as_uint(S.I1[0]))) diff = 1;
     }
     if (!__syncthreads_or(diff)) continue;
+#ifdef IC_STAMP
+    if (t == 0) atomicAdd(&a.tlist[IC_DBG_OFF + 32], 1);
+#endif
     if (tp.on) p1[t] = S.I1[0];
     ic_store_mask(pm, b0, lane, wave);
   }
@@ -599,14 +667,60 @@ __global__ __launch_bounds__(IC_T) void ic_jacobi_kernel(IcArgs a, int round) {
   int changed = a.cls[pt] != cls;
   if (tp.on && (o0 != ic_bit(w1, t) || (o0 && __float_as_uint(v1[t]) != __float_as_uint(S.I1[0])))) changed = 1;
   if (__syncthreads_or(changed)) {
+    // publish
     if (tp.on) v1[t] = S.I1[0];
     ic_store_mask(w1, o0, lane, wave);
+    if (t == 0) a.cls[pt] = (uint8_t)cls;
+    __syncthreads();
     if (t == 0) {
-      a.cls[pt] = (uint8_t)cls;
-      atomicAdd(&a.jac[round], 1);
+      __threadfence();
+      atomicAdd(ver, 1);
+#ifdef IC_STAMP
+      atomicAdd(&a.tlist[IC_DBG_OFF + 33], 1);
+#endif
     }
+    any_change = 1;
   }
   }  // touched list
+  if (any_change) continue;  // (uniform) look again at once: the version moved at least by our own publish
+
+  // ---- idle at version v: vote, then poll until the version moves or everybody is idle ----
+  __syncthreads();
+  if (wave == 0) {
+    if (lane == 0) ic_st(&slots[blockIdx.x], v + 1);
+    int res;
+    for (;;) {
+      const int cur = ic_ld(ver);
+      if (ic_ld(ovf)) {
+        res = 2;
+        break;
+      }
+      if (cur != v) {
+        res = 1;
+        break;
+      }
+      bool ok = true;
+      for (int k = lane; k < P; k += 64) ok = ok && (ic_ld(&slots[k]) == v + 1);
+      const bool all_idle = __all(ok);
+      if (all_idle && ic_ld(ver) == v) {
+        res = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(4);
+      if (++polls > IC_SPIN_LIMIT) {
+        if (lane == 0) atomicExch(ovf, 1);
+        res = 2;
+        break;
+      }
+    }
+    if (lane == 0) s_ctl = res;
+  }
+  __syncthreads();
+  if (s_ctl != 1) break;  // 0: quiescent -> done ; 2: sequential fallback requested
+  }  // passes
+#ifdef IC_STAMP
+  if (t == 0 && blockIdx.x == 0) a.tlist[IC_DBG_OFF + 0] = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff);
+#endif
 }
 
 // ---- pass 2: sequential replay of the runs that contain touched points --------------
@@ -618,7 +732,7 @@ __global__ __launch_bounds__(IC_T) void ic_strict_kernel(IcArgs a) {
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   // with the parallel replay in front, this kernel only runs when that did not finish
-  if (a.jac && a.jac[IC_ROUNDS - 1] == 0 && a.jac[IC_JAC_OVF] == 0) return;
+  if (a.jac && a.jac[IC_JAC_OVF] == 0) return;
   if (!a.touched[pt]) return;
   // head test: walk back over skipped / template-only untouched points
   int start = 0, clean = -1;
@@ -683,13 +797,13 @@ static int ic_args(vo_ctx *c, int slot0, int slot1, IcArgs &a, int *d_flags) {
 static int ic_records(vo_ctx *c, IcArgs &a) {
   if (!c->ic_rec) {
     const size_t N = (size_t)c->cfg.max_points;
-    const size_t bytes = N * (4 + 2 * IC_MW * 4 + 3 * IC_NELEM * 4 + IC_NELEM * 4 + IC_NELEM * 4 + IC_MW * 4) + 64;
+    const size_t bytes = N * (4 + 2 * IC_MW * 4 + 3 * IC_NELEM * 4 + IC_NELEM * 4 + IC_NELEM * 4 + IC_MW * 4) + IC_JAC_BYTES;
     VO_CHECK_HIP(c, hipMalloc(&c->ic_rec, bytes));
     VO_CHECK_HIP(c, hipMemsetAsync(c->ic_rec, 0, bytes, c->stream));
   }
   const size_t N = (size_t)c->cfg.max_points;
   uint8_t *p = (uint8_t *)c->ic_rec;
-  a.jac = (int *)p;                 p += 64;
+  a.jac = (int *)p;                 p += IC_JAC_BYTES;
   a.tlist = (int *)p;               p += N * 4;
   a.recW0 = (uint32_t *)p;          p += N * IC_MW * 4;
   a.recW1 = (uint32_t *)p;          p += N * IC_MW * 4;
@@ -714,7 +828,7 @@ int vo_ic_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, const fl
   if (with_records) {
     rc = ic_records(c, a);
     if (rc) return rc;
-    VO_CHECK_HIP(c, hipMemsetAsync(a.jac, 0, 64, c->stream));
+    VO_CHECK_HIP(c, hipMemsetAsync(a.jac, 0, IC_JAC_BYTES, c->stream));
   }
   a.mask_in = d_mask_in;
   a.pts0 = d_pts0;
@@ -735,11 +849,11 @@ int vo_ic_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, const fl
 }
 
 // pass 2 (reference-exact border state); consumes pass 1's touched / cls / last_pu and tap records:
-// IC_ROUNDS parallel fixed-point rounds (each exits at once when the previous one changed nothing),
-// then the sequential replay, which only runs if the rounds did not converge.
+// the parallel fixed-point replay, then the sequential replay, which only runs if the former asked for it.
 int vo_ic_strict_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, const float *d_scale,
                          const float *d_prior, float *d_pts_track, uint8_t *d_mask, uint8_t *d_touched,
-                         uint8_t *d_cls, float *d_last_pu, int n_max, const int *d_n, int *d_flags) {
+                         uint8_t *d_cls, float *d_last_pu, int n_max, const int *d_n, int *d_flags,
+                         bool sequential_only) {
   if (n_max <= 0) return VO_OK;
   IcArgs a;
   memset(&a, 0, sizeof(a));
@@ -758,8 +872,10 @@ int vo_ic_strict_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, c
   a.n = n_max;
   a.d_n = d_n;
   vo_prof_begin(c, VO_K_IC);
-  for (int r = 0; r < IC_ROUNDS; ++r)
-    hipLaunchKernelGGL(ic_jacobi_kernel, dim3(n_max < IC_JGRID ? n_max : IC_JGRID), dim3(IC_T), 0, c->stream, a, r);
+  if (sequential_only)  // validation mode: request the fallback up front
+    VO_CHECK_HIP(c, hipMemsetAsync(&a.jac[IC_JAC_OVF], 1, sizeof(int), c->stream));
+  else
+    hipLaunchKernelGGL(ic_jacobi_kernel, dim3(n_max < IC_JGRID ? n_max : IC_JGRID), dim3(IC_T), 0, c->stream, a);
   hipLaunchKernelGGL(ic_strict_kernel, dim3(n_max), dim3(IC_T), 0, c->stream, a);
   vo_prof_end(c);
   VO_CHECK_HIP(c, hipGetLastError());
@@ -767,6 +883,18 @@ int vo_ic_strict_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, c
 }
 
 #ifdef IC_STAMP
+// diagnostic (IC_STAMP builds): jac[16] + 64 debug words; clears the debug words
+extern "C" int vo_debug_ic_jac(vo_ctx *c, int *dst) {
+  if (!c || !c->ic_rec || !dst) return VO_ERR_INVALID;
+  IcArgs a;
+  memset(&a, 0, sizeof(a));
+  ic_records(c, a);
+  VO_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+  VO_CHECK_HIP(c, hipMemcpy(dst, a.jac, 64, hipMemcpyDeviceToHost));
+  VO_CHECK_HIP(c, hipMemcpy(dst + 16, a.tlist + IC_DBG_OFF, 256, hipMemcpyDeviceToHost));
+  VO_CHECK_HIP(c, hipMemset(a.tlist + IC_DBG_OFF, 0, 256));
+  return VO_OK;
+}
 // diagnostic (IC_STAMP builds): first `k` floats of each point's pre1 row
 extern "C" int vo_debug_ic_rows(vo_ctx *c, float *dst, int k, int n) {
   if (!c || !c->ic_rec || !dst) return VO_ERR_INVALID;

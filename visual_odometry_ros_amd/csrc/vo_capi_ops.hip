@@ -45,7 +45,7 @@ extern "C" int vo_track_with_scale(vo_ctx *c, int slot0, int slot1, const float 
   if (rc < 0) return rc;
   if (strict_border) {
     rc = vo_ic_strict_enqueue(c, slot0, slot1, c->d_pts0, c->d_scale, c->d_pts1, c->d_pts2, c->d_mask,
-                              c->d_mask2, c->d_status, c->d_pts3, n, nullptr);
+                              c->d_mask2, c->d_status, c->d_pts3, n, nullptr, nullptr, strict_border == 2);
     if (rc < 0) return rc;
   }
   D2H(pts_track, c->d_pts2, pb);

@@ -35,7 +35,8 @@ int vo_ic_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, const fl
                   int *d_flags = nullptr, bool with_records = false);
 int vo_ic_strict_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, const float *d_scale,
                          const float *d_prior, float *d_pts_track, uint8_t *d_mask, uint8_t *d_touched,
-                         uint8_t *d_cls, float *d_last_pu, int n_max, const int *d_n, int *d_flags = nullptr);
+                         uint8_t *d_cls, float *d_last_pu, int n_max, const int *d_n, int *d_flags = nullptr,
+                         bool sequential_only = false);
 
 // misc_kernels.hip
 int vo_hamming_enqueue(vo_ctx *c, const uint8_t *d_a, int na, const uint8_t *d_b, int nb, uint16_t *d_dist);
