@@ -26,7 +26,7 @@
 #define IC_LEN (2 * IC_HALF + 1)
 #define IC_MAXELEM (IC_LEN * IC_LEN)
 
-#define IC_TREE_W 512 /* ic_refine_kernel: one tap per lane, tree over the taps zero-padded to 512 */
+#define IC_TREE_W 64 /* ic_refine_kernel: one wavefront per point, tap j -> lane j mod 64 (ascending j), tree over the 64 lanes */
 
 /* diagnostic: dependency depth of the never-reset tap state (REFERENCE mode): depth(P) = 1 + max depth of
  * the points whose stale tap values P actually read; untouched points have depth 0 */
@@ -54,8 +54,8 @@ static float tree_w(const float *part) {
 }
 
 /* Sum of term[j] over j in [0,n) where use[j]!=0.
- * SEQ: j ascending. TREE: balanced binary tree over the terms in index order, zero-padded
- * to 512 (adjacent pairs first). */
+ * SEQ: j ascending. TREE: IC_TREE_W strided partials (term j -> partial j mod IC_TREE_W, ascending j),
+ * then a balanced binary tree over the partials (adjacent pairs first). */
 static float masked_sum(const float *term, const uint8_t *use, int n, int mode) {
   if (mode == VO_SUM_SEQ) {
     float s = 0.0f;
