@@ -1,0 +1,346 @@
+// frame_fused.hip — the per-point part of the steady-state stereo frame in ONE launch.
+//
+// Steps [3] .. [5] of StereoVO::trackStereoImages (core/visual_odometry/stereo_vo/stereo_vo.cpp)
+//   [3]   prior pixels + patch scale                       :483-522
+//   [4]   trackWithPrior  I0_L -> I1_L  (+ validity)       :531-538, feature_tracker.cpp:186-197
+//   [4-1] trackWithScale refinement     (+ validity)       :549-558, feature_tracker.cpp:236-504
+//   [5]   trackWithPrior  I1_L -> I1_R  (+ validity)       :564-571
+// only ever combine data of ONE feature (the reference's std::vector compactions between the
+// steps, landmark.cpp:291-332, just drop rejected features), so a feature is one gfx950
+// wavefront that walks through all four steps; the compaction happens once, at the end, in index
+// order (frame_finish_kernel). Every step of the frame is latency-bound on a handful of
+// stragglers (a KLT level that runs all 30 iterations, an IC point that does not converge);
+// as separate launches the frame pays the slowest feature of EVERY step plus the launch gaps,
+// fused it pays the slowest feature once.
+//
+// The one cross-feature dependency is the never-reset tap state of trackWithScale
+// (ic_refine.hip): a feature whose IC window leaves the image ("touched") is deferred after its
+// pass-1 refinement; frame_replay_kernel brings the touched features to the reference-exact
+// state (ic_replay) and then finishes step [5] for them. If that replay asks for the sequential
+// fallback, ic_strict_kernel and frame_tail_kernel do the same work in two more launches.
+#include "ic_device.hpp"
+#include "klt_device.hpp"
+#include "vo_kernels.hpp"
+
+struct FrameArgs {
+  vo_level L0[VO_MAX_LEVELS];  // previous left
+  vo_level L1[VO_MAX_LEVELS];  // current left
+  vo_level R1[VO_MAX_LEVELS];  // current right
+  int max_level;               // effective OpenCV maxLevel
+  int n;
+  const float *Xp, *pts_l0, *pts_r0;
+  float T_cp[16], T_rl[16], Kl[4], Kr[4];
+  int W, H;
+  float thres_err;
+  int strict;
+  float *scale;     // out [n]    patch scale (= ic.scale)
+  float *k1;        // out [n][2] step [4] result (= ic.pts_prior)
+  float *pr_prior;  // out [n][2] prior right pixels
+  float *pl1;       // out [n][2] left pixels:  [4] result, replaced by the refined position when [4-1] accepts
+  float *pr1;       // out [n][2] right pixels: the prior, replaced by the [5] result for features that reach [5]
+  uint8_t *stage;   // out [n]    0 lost in [4], 1 in [4-1], 2 in [5], 3 survivor
+  IcArgs ic;        // tap records / touched list / replay control (index space = input index)
+};
+
+template <int WIN>
+struct FrameShared {
+  uint32_t tt[KltCfg<WIN>::TT_H * KltCfg<WIN>::TT_WD];
+  uint32_t tj[KltCfg<WIN>::TJ_H * KltCfg<WIN>::TJ_WD];
+  IcShared ic;
+};
+
+__device__ __forceinline__ bool frame_in_image(float x, float y, int W, int H) {
+  const float offset = 3.0f;
+  return !(x < offset || y < offset || x >= W - offset || y >= H - offset);
+}
+
+// trackWithPrior validity, feature_tracker.cpp:191-197
+__device__ __forceinline__ bool frame_klt_valid(const KltResult &r, int W, int H, float thres_err) {
+  return r.status > 0 && r.x > 0 && r.x < W && r.y > 0 && r.y < H && r.err <= thres_err;
+}
+
+// steps after [4-1] for one feature: `ok` / (rx, ry) are the refinement's mask and position
+template <int WIN>
+__device__ __forceinline__ void frame_tail(const FrameArgs &a, int i, int ok, float rx, float ry, float kx, float ky,
+                                           float prx, float pry, uint32_t *s_tt, uint32_t *s_tj, int lane) {
+  int stage = 1;
+  float ox = prx, oy = pry;
+  if (ok) {
+    stage = 2;
+    // [5] l1 -> r1 from the refined left pixel, initial flow = prior right pixel ({} criteria, {} minEig)
+    const KltResult k2 = klt_point<WIN>(a.L1, a.R1, a.max_level, VO_KLT_USE_INITIAL_FLOW, 30, 0.01 * 0.01, 0.f, rx, ry,
+                                        prx, pry, s_tt, s_tj, lane);
+    ox = k2.x;  // reported for every feature that entered step [5], valid or not
+    oy = k2.y;
+    if (frame_klt_valid(k2, a.W, a.H, a.thres_err)) stage = 3;
+  }
+  if (lane == 0) {
+    a.pl1[2 * i] = ok ? rx : kx;  // the step [4] result stays when the refinement is rejected
+    a.pl1[2 * i + 1] = ok ? ry : ky;
+    a.pr1[2 * i] = ox;
+    a.pr1[2 * i + 1] = oy;
+    a.stage[i] = (uint8_t)stage;
+  }
+}
+
+template <int WIN>
+__global__ __launch_bounds__(64) void frame_track_kernel(FrameArgs a) {
+  __shared__ FrameShared<WIN> sh;
+  const int i = blockIdx.x;
+  if (i >= a.n) return;
+  const int lane = threadIdx.x;
+  // ---- [3] priors (stereo_vo.cpp:483-522); every lane computes the same values ----
+  const float *Xi = a.Xp + 3 * i;
+  float Xl[3], Xr[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    Xl[r] = ((a.T_cp[r * 4 + 0] * Xi[0] + a.T_cp[r * 4 + 1] * Xi[1]) + a.T_cp[r * 4 + 2] * Xi[2]) + a.T_cp[r * 4 + 3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    Xr[r] = ((a.T_rl[r * 4 + 0] * Xl[0] + a.T_rl[r * 4 + 1] * Xl[1]) + a.T_rl[r * 4 + 2] * Xl[2]) + a.T_rl[r * 4 + 3];
+  const float scale = Xi[2] / Xl[2];
+  const float izl = 1.0f / Xl[2], izr = 1.0f / Xr[2];
+  float plx = a.Kl[0] * Xl[0] * izl + a.Kl[2], ply = a.Kl[1] * Xl[1] * izl + a.Kl[3];
+  float prx = a.Kr[0] * Xr[0] * izr + a.Kr[2], pry = a.Kr[1] * Xr[1] * izr + a.Kr[3];
+  const float l0x = a.pts_l0[2 * i], l0y = a.pts_l0[2 * i + 1];
+  if (!frame_in_image(plx, ply, a.W, a.H) || !frame_in_image(prx, pry, a.W, a.H) || (double)Xl[2] < 0.1 ||
+      (double)Xr[2] < 0.1) {
+    plx = l0x;
+    ply = l0y;
+    prx = a.pts_r0[2 * i];
+    pry = a.pts_r0[2 * i + 1];
+  }
+  // ---- [4] l0 -> l1 ({} criteria: 30 iterations / eps 0.01, {} minEig: 0) ----
+  const KltResult k1 = klt_point<WIN>(a.L0, a.L1, a.max_level, VO_KLT_USE_INITIAL_FLOW, 30, 0.01 * 0.01, 0.f, l0x, l0y,
+                                      plx, ply, sh.tt, sh.tj, lane);
+  const bool valid1 = frame_klt_valid(k1, a.W, a.H, a.thres_err);
+  if (lane == 0) {
+    a.scale[i] = scale;
+    a.k1[2 * i] = k1.x;
+    a.k1[2 * i + 1] = k1.y;
+    a.pr_prior[2 * i] = prx;
+    a.pr_prior[2 * i + 1] = pry;
+  }
+  const IcTaps tp = ic_make_taps(lane);
+  IcState S;
+  ic_state_clear(S);
+  int cls = 0, touched = 0, n_iter = 0;
+  float lpx = 0.f, lpy = 0.f;
+  IcResult rf;
+  rf.cls = 0;
+  rf.ok = 0;
+  rf.x = k1.x;
+  rf.y = k1.y;
+  rf.err_flag = 0;
+  if (valid1) {
+    // ---- [4-1] refinement of the left pixel (pass 1: taps outside the image are masked) ----
+    rf = ic_point<false>(a.L0[0], a.L1[0], tp, l0x, l0y, k1.x, k1.y, scale, lane, sh.ic, S, touched, lpx, lpy, n_iter);
+    cls = rf.cls;
+  }
+  const int any_t = __any(touched);
+  if (a.strict) {
+    // records for the replay; pass-1 results of every point (the replay overwrites touched ones)
+    ic_store_records(a.ic, i, lane, tp, S, cls);
+    if (lane == 0) {
+      a.ic.touched[i] = (uint8_t)(any_t ? 1 : 0);
+      a.ic.cls[i] = (uint8_t)cls;
+      a.ic.last_pu[2 * i] = lpx;
+      a.ic.last_pu[2 * i + 1] = lpy;
+      a.ic.pts_track[2 * i] = rf.x;
+      a.ic.pts_track[2 * i + 1] = rf.y;
+      a.ic.mask[i] = (uint8_t)rf.ok;
+      if (any_t) a.ic.tlist[atomicAdd(&a.ic.jac[IC_JAC_NT], 1)] = i;
+    }
+  }
+  if (lane == 0 && rf.err_flag) atomicOr(a.ic.flags, rf.err_flag);
+  if (!valid1) {
+    if (lane == 0) {
+      a.pl1[2 * i] = k1.x;
+      a.pl1[2 * i + 1] = k1.y;
+      a.pr1[2 * i] = prx;
+      a.pr1[2 * i + 1] = pry;
+      a.stage[i] = 0;
+    }
+    return;
+  }
+  if (a.strict && any_t) {
+    // deferred: frame_replay_kernel (or frame_tail_kernel) finishes this feature
+    if (lane == 0) {
+      a.pl1[2 * i] = k1.x;
+      a.pl1[2 * i + 1] = k1.y;
+      a.pr1[2 * i] = prx;
+      a.pr1[2 * i + 1] = pry;
+      a.stage[i] = 1;
+    }
+    return;
+  }
+  frame_tail<WIN>(a, i, rf.ok, rf.x, rf.y, k1.x, k1.y, prx, pry, sh.tt, sh.tj, lane);
+}
+
+// strict border: replay of the touched features, then their step [5]
+template <int WIN>
+__global__ __launch_bounds__(64) void frame_replay_kernel(FrameArgs a) {
+  __shared__ IcReplayShared rs;
+  __shared__ uint32_t s_tt[KltCfg<WIN>::TT_H * KltCfg<WIN>::TT_WD];
+  __shared__ uint32_t s_tj[KltCfg<WIN>::TJ_H * KltCfg<WIN>::TJ_WD];
+  const int lane = threadIdx.x;
+  const int P = ic_replay(a.ic, rs, lane);
+  if (P <= 0) return;  // no list entry here, or the sequential fallback takes over
+  __threadfence();     // this workgroup's own last results (written by lane 0) are re-read below
+  const int n_touched = a.ic.jac[IC_JAC_NT];
+  for (int li = blockIdx.x; li < n_touched; li += P) {
+    const int i = a.ic.tlist[li];
+    frame_tail<WIN>(a, i, a.ic.mask[i], a.ic.pts_track[2 * i], a.ic.pts_track[2 * i + 1], a.k1[2 * i], a.k1[2 * i + 1],
+                    a.pr_prior[2 * i], a.pr_prior[2 * i + 1], s_tt, s_tj, lane);
+  }
+}
+
+// after ic_strict_kernel (sequential fallback only): step [5] of the touched features
+template <int WIN>
+__global__ __launch_bounds__(64) void frame_tail_kernel(FrameArgs a) {
+  __shared__ uint32_t s_tt[KltCfg<WIN>::TT_H * KltCfg<WIN>::TT_WD];
+  __shared__ uint32_t s_tj[KltCfg<WIN>::TJ_H * KltCfg<WIN>::TJ_WD];
+  if (a.ic.jac[IC_JAC_OVF] == 0) return;
+  const int i = blockIdx.x;
+  if (i >= a.n || !a.ic.touched[i] || a.ic.cls[i] == 0) return;
+  frame_tail<WIN>(a, i, a.ic.mask[i], a.ic.pts_track[2 * i], a.ic.pts_track[2 * i + 1], a.k1[2 * i], a.k1[2 * i + 1],
+                  a.pr_prior[2 * i], a.pr_prior[2 * i + 1], s_tt, s_tj, threadIdx.x);
+}
+
+// ---- the one compaction of the frame: survivors (stage 3) in index order + the three step counts ----
+struct FinishArgs {
+  int n;
+  const uint8_t *stage;
+  const float *Xp, *pl1, *pr1;
+  float *C_X, *C_pl1, *C_pr1;
+  int32_t *C_orig;
+  int *cnt;  // [0] survivors of [4], [1] of [4-1], [2] of [5]
+};
+__global__ __launch_bounds__(1024) void frame_finish_kernel(FinishArgs a) {
+  __shared__ int s_wave[16][3];
+  __shared__ int s_base[3];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 3) s_base[tid] = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < a.n; c0 += 1024) {
+    const int i = c0 + tid;
+    const int st = i < a.n ? a.stage[i] : 0;
+    const unsigned long long b1 = __ballot(st >= 1), b2 = __ballot(st >= 2), b3 = __ballot(st >= 3);
+    const int below = __popcll(b3 & ((1ull << lane) - 1ull));
+    if (lane == 0) {
+      s_wave[wave][0] = __popcll(b1);
+      s_wave[wave][1] = __popcll(b2);
+      s_wave[wave][2] = __popcll(b3);
+    }
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += s_wave[w][2];
+    const int base = s_base[2];
+    if (st >= 3) {
+      const int o = base + woff + below;
+      a.C_X[3 * o] = a.Xp[3 * i];
+      a.C_X[3 * o + 1] = a.Xp[3 * i + 1];
+      a.C_X[3 * o + 2] = a.Xp[3 * i + 2];
+      a.C_pl1[2 * o] = a.pl1[2 * i];
+      a.C_pl1[2 * o + 1] = a.pl1[2 * i + 1];
+      a.C_pr1[2 * o] = a.pr1[2 * i];
+      a.C_pr1[2 * o + 1] = a.pr1[2 * i + 1];
+      a.C_orig[o] = i;
+    }
+    __syncthreads();
+    if (tid < 3) {
+      int tot = 0;
+      for (int w = 0; w < 16; ++w) tot += s_wave[w][tid];
+      s_base[tid] += tot;
+    }
+    __syncthreads();
+  }
+  if (tid < 3) a.cnt[tid] = s_base[tid];
+}
+
+// ---- host side ---------------------------------------------------------------------
+// phase 0: the per-feature kernel; phase 1: replay (strict) + final compaction. Two phases so that
+// the caller can feed other streams while the long first kernel is already running.
+template <int WIN>
+static void frame_launch(vo_ctx *c, const FrameArgs &a, const FinishArgs &f, int phase) {
+  if (phase == 0) {
+    vo_prof_begin(c, VO_K_KLT);
+    hipLaunchKernelGGL(frame_track_kernel<WIN>, dim3(a.n), dim3(64), 0, c->stream, a);
+    vo_prof_end(c);
+    return;
+  }
+  if (a.strict) {
+    vo_prof_begin(c, VO_K_IC);
+    hipLaunchKernelGGL(frame_replay_kernel<WIN>, dim3(a.n < IC_JGRID ? a.n : IC_JGRID), dim3(64), 0, c->stream, a);
+    vo_ic_strict_launch(c, a.ic);  // returns at once unless the replay asked for it
+    hipLaunchKernelGGL(frame_tail_kernel<WIN>, dim3(a.n), dim3(64), 0, c->stream, a);
+    vo_prof_end(c);
+  }
+  vo_prof_begin(c, VO_K_AUX);
+  hipLaunchKernelGGL(frame_finish_kernel, dim3(1), dim3(1024), 0, c->stream, f);
+  vo_prof_end(c);
+}
+
+int vo_frame_fused_supported(int win) { return win == 15 || win == 21 || win == 31; }
+
+int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, int slot_l1, int slot_r1,
+                           const float *d_l0, const float *d_r0, const float *d_X, int n, const float T_cp[16],
+                           const float T_rl[16], const vo_frame_fused_bufs &b, int phase) {
+  if (n <= 0) return VO_OK;
+  const int slots[3] = {slot_l0, slot_l1, slot_r1};
+  for (int s : slots)
+    if (s < 0 || s >= c->cfg.n_slots || c->slots[s].n_levels <= 0) VO_FAIL(c, VO_ERR_INVALID, "slot holds no image");
+  const vo_pyramid &P0 = c->slots[slot_l0], &P1 = c->slots[slot_l1], &P2 = c->slots[slot_r1];
+  if (P0.w != P1.w || P0.h != P1.h || P0.w != P2.w || P0.h != P2.h) VO_FAIL(c, VO_ERR_SIZE, "image size mismatch");
+  if (prm->max_level < 0 || prm->win <= 2) VO_FAIL(c, VO_ERR_INVALID, "maxLevel >= 0 && winSize > 2 violated");
+  FrameArgs a;
+  memset(&a, 0, sizeof(a));
+  int eff = vo_pyr_levels_host(P0.w, P0.h, prm->win, prm->max_level);
+  for (const vo_pyramid *P : {&P0, &P1, &P2})
+    if (eff > P->n_levels - 1) eff = P->n_levels - 1;
+  for (int l = 0; l <= eff; ++l) {
+    a.L0[l] = P0.lv[l];
+    a.L1[l] = P1.lv[l];
+    a.R1[l] = P2.lv[l];
+  }
+  a.max_level = eff;
+  a.n = n;
+  a.Xp = d_X;
+  a.pts_l0 = d_l0;
+  a.pts_r0 = d_r0;
+  memcpy(a.T_cp, T_cp, sizeof(a.T_cp));
+  memcpy(a.T_rl, T_rl, sizeof(a.T_rl));
+  memcpy(a.Kl, prm->Kl, sizeof(a.Kl));
+  memcpy(a.Kr, prm->Kr, sizeof(a.Kr));
+  a.W = prm->width;
+  a.H = prm->height;
+  a.thres_err = prm->thres_err;
+  a.strict = c->frame_strict_ic ? 1 : 0;
+  a.scale = b.scale;
+  a.k1 = b.k1;
+  a.pr_prior = b.pr_prior;
+  a.pl1 = b.pl1;
+  a.pr1 = b.pr1;
+  a.stage = b.stage;
+  // phase 0 also clears the replay control words
+  int rc = vo_ic_frame_args(c, slot_l0, slot_l1, &a.ic, b.flags, a.strict != 0, phase == 0);
+  if (rc) return rc;
+  a.ic.pts0 = d_l0;
+  a.ic.scale = b.scale;
+  a.ic.pts_prior = b.k1;
+  a.ic.pts_track = b.ref;
+  a.ic.mask = b.m2;
+  a.ic.touched = b.touched;
+  a.ic.cls = b.cls;
+  a.ic.last_pu = b.lastpu;
+  a.ic.n = n;
+  const FinishArgs f = {n, b.stage, d_X, b.pl1, b.pr1, b.C_X, b.C_pl1, b.C_pr1, b.C_orig, b.cnt};
+  switch (prm->win) {
+    case 15: frame_launch<15>(c, a, f, phase); break;
+    case 21: frame_launch<21>(c, a, f, phase); break;
+    case 31: frame_launch<31>(c, a, f, phase); break;
+    default: VO_FAIL(c, VO_ERR_INVALID, "fused frame kernel not instantiated for window %d", prm->win);
+  }
+  VO_CHECK_HIP(c, hipGetLastError());
+  return VO_OK;
+}

@@ -185,7 +185,50 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
 
   if (n_new > 0) VO_CHECK_HIP(c, hipEventRecord(c->ev_fork, s));  // the new pyramids are enqueued before this point
 
-  if (n > 0) {
+  const bool fused = n > 0 && vo_frame_fused_supported(prm->win);
+  if (fused) {
+    // steps [3] .. [5] of a feature are one wavefront of ONE launch (frame_fused.hip)
+    vo_frame_fused_bufs b;
+    b.scale = f->F_scale;
+    b.k1 = f->A_pl1;
+    b.pr_prior = f->A_pr1;
+    b.pl1 = f->F_pl1;
+    b.pr1 = f->F_pr1;
+    b.ref = f->A_ref;
+    b.lastpu = f->A_lastpu;
+    b.stage = f->stage;
+    b.m2 = f->m2;
+    b.touched = f->A_touched;
+    b.cls = f->A_cls;
+    b.flags = &f->hdr->flags;
+    b.C_X = f->C_X;
+    b.C_pl1 = f->C_pl1;
+    b.C_pr1 = f->C_pr1;
+    b.C_orig = f->C_orig;
+    b.cnt = cnt;
+    RC(vo_frame_fused_enqueue(c, prm, slot_l0, slot_l1, slot_r1, d_l0, d_r0, d_X, n, T_cp, T_rl, b, 0));
+    // (the main chain's long kernel is queued; now feed the side stream)
+    // [10] new points on the side stream: they depend only on the two new pyramids, not on the
+    // main chain, and the chain's kernels leave most of the chip idle (one wave per point).
+    if (n_new > 0) {
+      VO_CHECK_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+      c->stream = c->stream2;
+      int rc2 = vo_klt_enqueue(c, slot_l1, slot_r1, d_new, nullptr, f->new_r, n_new, nullptr, prm->win,
+                               prm->max_level, 0, 30, 0.01, 1e-4f, f->st3, f->e3);
+      // backward: maxLevel-1, initial flow = pts_new, {} criteria / minEig (feature_tracker.cpp:69-71)
+      if (rc2 >= 0)
+        rc2 = vo_klt_enqueue(c, slot_r1, slot_l1, f->new_r, d_new, f->new_back, n_new, nullptr, prm->win,
+                             prm->max_level - 1, VO_KLT_USE_INITIAL_FLOW, 0, 0., 0.f, f->st2, f->e2);
+      if (rc2 >= 0)
+        rc2 = vo_klt_mask_enqueue(c, 2, n_new, nullptr, W, H, prm->thres_err, prm->thres_bidirection, d_new,
+                                  f->new_r, f->new_back, f->st3, f->st2, f->e3, f->e2, nullptr, f->mNew);
+      c->stream = s;
+      if (rc2 < 0) return rc2;
+      VO_CHECK_HIP(c, hipEventRecord(c->ev_join, c->stream2));
+    }
+    RC(vo_frame_fused_enqueue(c, prm, slot_l0, slot_l1, slot_r1, d_l0, d_r0, d_X, n, T_cp, T_rl, b, 1));
+  } else if (n > 0) {
+    // general window sizes: one launch per step, compaction in between
     // [3] priors
     RC(vo_stereo_prior_enqueue(c, d_X, d_l0, d_r0, n, T_cp, T_rl, prm->Kl, prm->Kr, W, H, f->F_pl1, f->F_pr1,
                                f->F_scale, f->F_orig, f->stage));
@@ -211,7 +254,6 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
       if (rc2 < 0) return rc2;
       VO_CHECK_HIP(c, hipEventRecord(c->ev_join, c->stream2));
     }
-
     {
       CompactArgsHost h;
       h.klt_status = f->st1;

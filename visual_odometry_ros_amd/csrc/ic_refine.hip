@@ -38,436 +38,8 @@
 //  * ic_strict_kernel is the sequential replay (one wavefront walks a run of points
 //    between two clean points, the carried state living in registers); it only
 //    runs when the parallel replay asks for it.
-#include "vo_internal.hpp"
+#include "ic_device.hpp"
 #include "vo_kernels.hpp"
-
-#define IC_HALF 11
-#define IC_NELEM 264
-#define IC_T 64    // lanes per point (one wavefront)
-#define IC_K 5     // taps per lane: lane l owns taps l + 64 k
-#define IC_TW 8    // template tile dwords per row (32 bytes)
-#define IC_TH 27   // template tile rows
-#define IC_TN ((IC_TH * IC_TW + IC_T - 1) / IC_T)  // template tile dwords per lane
-#define IC_JW 11   // I1 search tile: dwords per row (44 bytes)
-#define IC_JH 40   // I1 search tile rows
-#define IC_JN ((IC_JH * IC_JW + IC_T - 1) / IC_T)  // search tile dwords per lane
-#define IC_MW 9        // mask words per point (264 bits)
-#define IC_MAXRUN 192  // longest run the parallel strict replay handles (else sequential fallback)
-#define IC_CAND 320    // predecessors examined for the nearest clean point
-#define IC_JAC_OVF 15
-#define IC_JAC_NT 14
-#define IC_JAC_VER 13    // replay kernel: number of record publications so far
-#define IC_JAC_SLOTS 16  // replay kernel: one "idle at version" word per workgroup
-#define IC_JGRID 512     // workgroups of the replay kernel (2 per CU: all co-resident); each strides over the touched list
-#define IC_JAC_WORDS (IC_JAC_SLOTS + IC_JGRID)
-#define IC_JAC_BYTES (((IC_JAC_WORDS * 4 + 63) / 64) * 64)
-#define IC_MAX_PASSES (1 << 14)  // a look per version bump is normal; this only guards against a hang
-#define IC_SPIN_LIMIT (1 << 17)  // idle polls before a workgroup gives up (~0.2 s) and requests the sequential replay
-#define IC_DBG_OFF 4096  // IC_STAMP builds: debug words in the unused tail of tlist (needs max_points >= 4200)
-#ifndef IC_MAX_ITER
-#define IC_MAX_ITER 30  // feature_tracker.cpp:290
-#endif
-
-struct IcArgs {
-  vo_level I0, I1;
-  const float *pts0;
-  const float *scale;
-  const float *pts_prior;  // initial pts_track
-  float *pts_track;        // out (pre-set to the prior)
-  const uint8_t *mask_in;  // phase 1: entry mask (null = all true); may alias mask
-  uint8_t *mask;           // out
-  uint8_t *touched;        // out (phase 1) / in (strict)
-  uint8_t *cls;            // out (phase 1) / in (strict): 0 skipped, 1 template only, 2 iterated
-  float *last_pu;          // out (phase 1) / in (strict): last evaluated pt_update
-  int n;
-  const int *d_n;
-  int *flags;              // [0] |= 1 ax/ay NaN, |= 2 patch NaN, |= 4 update NaN
-  // per-point tap records for the parallel strict replay (optional; see ic_jacobi_kernel)
-  uint32_t *recW0, *recW1;  // [n][IC_MW] bit j: tap j written by the point's template / I1 samples
-  float *recV0;             // [n][3][IC_NELEM] template values (I0, du, dv) of the written taps
-  float *recV1;             // [n][IC_NELEM] last I1 value the point wrote per tap
-  float *pre1;              // [n][IC_NELEM] I1 pre-state the point last ran with
-  uint32_t *preM;           // [n][IC_MW] its mask
-  int *jac;                 // control words of the replay: [IC_JAC_NT] #touched, [IC_JAC_OVF], [IC_JAC_VER], slots
-  int *tlist;               // indices of the touched points (any order)
-};
-
-struct IcShared {
-  uint32_t tt[IC_TH * IC_TW];
-  uint32_t tj[IC_JH * IC_JW];
-};
-
-struct IcState {
-  float I0[IC_K], du[IC_K], dv[IC_K], I1[IC_K];
-  unsigned m;  // bit k: template tap k valid (mask_I0) ; bit 8+k: I1 tap k valid (mask_I1)
-               // bit 16+k / 24+k: written by THIS point's template / I1 evaluations
-};
-
-// lane-constant tap offsets (feature_tracker.cpp:308-320): rows v = 0..22; even rows hold
-// u = 1,3,..,21 (11 taps), odd rows u = 0,2,..,22 (12 taps)
-struct IcTaps {
-  float px[IC_K], py[IC_K];
-  unsigned on;  // bit k: the lane owns tap lane + 64 k (< 264)
-};
-__device__ __forceinline__ void ic_tap_xy(int j, float &px, float &py) {
-  const int p = j / 23, r = j - p * 23;
-  int u, v;
-  if (r < 11) {
-    v = 2 * p;
-    u = 1 + 2 * r;
-  } else {
-    v = 2 * p + 1;
-    u = 2 * (r - 11);
-  }
-  px = (float)(u - IC_HALF);
-  py = (float)(v - IC_HALF);
-}
-__device__ __forceinline__ IcTaps ic_make_taps(int lane) {
-  IcTaps tp;
-  tp.on = 0;
-#pragma unroll
-  for (int k = 0; k < IC_K; ++k) {
-    const int j = lane + 64 * k;
-    const bool on = j < IC_NELEM;
-    if (on) tp.on |= 1u << k;
-    ic_tap_xy(on ? j : 0, tp.px[k], tp.py[k]);
-  }
-  return tp;
-}
-
-__device__ __forceinline__ float ic_bilin(float I1, float I2, float I3, float I4, float ax, float ay, float axay) {
-  return ((axay * (((I1 - I2) - I3) + I4) + ax * (-I1 + I2)) + ay * (-I1 + I3)) + I1;
-}
-
-__device__ __forceinline__ int ic_safe_int(float v) {
-  return (int)fminf(fmaxf(v, -1.0e6f), 1.0e6f);
-}
-
-// Wavefront sums of four per-lane partials in the canonical tree order; every lane gets the same bits.
-__device__ __forceinline__ void ic_wave_sum4(float (&v)[4]) { wave_sum4_f32(v[0], v[1], v[2], v[3]); }
-
-// ---- LDS tiles: the global loads are issued first (registers), committed to LDS later, so
-// that both tiles of a point share one exposure of the memory latency ----
-template <int N>
-struct IcTileRegs {
-  uint32_t r[N];
-  int x0, y0;  // image coordinates of tile byte (0,0); x0 is 4-byte aligned in memory
-};
-template <int N, int TW, int TH>
-__device__ __forceinline__ void ic_tile_fetch(const vo_level &L, int x0, int y0, int lane, IcTileRegs<N> &R) {
-  R.x0 = x0;
-  R.y0 = y0;
-  const uint8_t *g = L.origin() + (ptrdiff_t)y0 * L.stride + x0;
-#pragma unroll
-  for (int q = 0; q < N; ++q) {
-    const int i = lane + IC_T * q;
-    const int ii = i < TW * TH ? i : 0;
-    const int r = ii / TW, cdw = ii - r * TW;
-    R.r[q] = *(const uint32_t *)(g + (ptrdiff_t)r * L.stride + cdw * 4);
-  }
-}
-template <int N, int TW, int TH>
-__device__ __forceinline__ void ic_tile_commit(const IcTileRegs<N> &R, int lane, uint32_t *dst) {
-  __syncthreads();  // earlier readers of the tile are done (one wavefront: ordering only)
-#pragma unroll
-  for (int q = 0; q < N; ++q) {
-    const int i = lane + IC_T * q;
-    if (i < TW * TH) dst[i] = R.r[q];
-  }
-  __syncthreads();
-}
-typedef IcTileRegs<IC_TN> IcTRegs;
-typedef IcTileRegs<IC_JN> IcJRegs;
-
-__device__ __forceinline__ void ic_template_fetch(const vo_level &L0, float pt0x, float pt0y, int lane, IcTRegs &R) {
-  const int W = L0.w, H = L0.h;
-  const int cx = ic_safe_int(pt0x), cy = ic_safe_int(pt0y);
-  int tox = (cx - 13) & ~3;
-  int toy = cy - 12;  // rows cy-12 .. cy+14 cover every valid tap's 4x4 neighbourhood
-  tox = max(-VO_PAD, min(tox, ((W + VO_PAD - IC_TW * 4) & ~3)));
-  toy = max(-VO_PAD, min(toy, H + VO_PAD - IC_TH));
-  ic_tile_fetch<IC_TN, IC_TW, IC_TH>(L0, tox, toy, lane, R);
-}
-// I1 search tile: 40 rows x 44 B of the current image around the prior position, staged once per
-// point; taps that fall outside it (large drift or scale) fall back to global loads per lane.
-__device__ __forceinline__ void ic_I1_fetch(const vo_level &L1, float cxf, float cyf, int lane, IcJRegs &R) {
-  const int cx = ic_safe_int(cxf), cy = ic_safe_int(cyf);
-  int x0 = (cx - 19) & ~3;
-  int y0 = cy - 19;
-  x0 = max(-VO_PAD, min(x0, ((L1.w + VO_PAD - IC_JW * 4) & ~3)));
-  y0 = max(-VO_PAD, min(y0, L1.h + VO_PAD - IC_JH));
-  ic_tile_fetch<IC_JN, IC_JW, IC_JH>(L1, x0, y0, lane, R);
-}
-struct IcTile {
-  int x0, y0;
-};
-
-// one template tap: 4x4 neighbourhood (u0-1..u0+2, v0-1..v0+2) from the LDS tile
-__device__ __forceinline__ void ic_template_tap(const uint32_t *s_t, int bx, int by, float ax, float ay, float axay,
-                                                float &nI, float &nu, float &nv) {
-  const int dwo = bx >> 2, sh = bx & 3;
-  int b[4][4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const uint32_t w0 = s_t[(by + r) * IC_TW + dwo];
-    const uint32_t w1 = s_t[(by + r) * IC_TW + min(dwo + 1, IC_TW - 1)];
-    const uint32_t v = __builtin_amdgcn_alignbyte(w1, w0, sh);
-#pragma unroll
-    for (int cc = 0; cc < 4; ++cc) b[r][cc] = (int)((v >> (8 * cc)) & 0xFFu);
-  }
-  float Iv[2][2], du[2][2], dv[2][2];
-#pragma unroll
-  for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii) {
-      Iv[jj][ii] = (float)b[1 + jj][1 + ii];
-      du[jj][ii] = (float)((b[jj][ii + 2] - b[jj][ii]) + 2 * (b[jj + 1][ii + 2] - b[jj + 1][ii]) +
-                           (b[jj + 2][ii + 2] - b[jj + 2][ii]));
-      dv[jj][ii] = (float)((b[jj + 2][ii] - b[jj][ii]) + 2 * (b[jj + 2][ii + 1] - b[jj][ii + 1]) +
-                           (b[jj + 2][ii + 2] - b[jj][ii + 2]));
-    }
-  nI = ic_bilin(Iv[0][0], Iv[0][1], Iv[1][0], Iv[1][1], ax, ay, axay);
-  nu = ic_bilin(du[0][0], du[0][1], du[1][0], du[1][1], ax, ay, axay);
-  nv = ic_bilin(dv[0][0], dv[0][1], dv[1][0], dv[1][1], ax, ay, axay);
-}
-
-// interpImage3SameRatio on the taps of this lane (tile already in LDS): writes state where the
-// tap is valid. STRICT: mask bits are sticky (never reset); otherwise they are this evaluation's validity.
-template <bool STRICT>
-__device__ __forceinline__ void ic_template(const vo_level &L0, const IcTaps &tp, float pt0x, float pt0y, float ax,
-                                            float ay, float axay, const IcTile &tile, const IcShared &sh, IcState &S,
-                                            int &touched) {
-  const int W = L0.w, H = L0.h;
-  if (!STRICT) S.m &= ~0x1Fu;
-#pragma unroll
-  for (int k = 0; k < IC_K; ++k) {
-    const bool on = (tp.on >> k) & 1u;
-    const float uc = pt0x + tp.px[k], vc = pt0y + tp.py[k];
-    const int u0 = (int)uc, v0 = (int)vc;
-    const bool valid = on && !(u0 < 1 || u0 >= W - 2 || v0 < 1 || v0 >= H - 2);
-    if (on && !valid) touched = 1;
-    float nI, nu, nv;
-    ic_template_tap(sh.tt, valid ? (u0 - 1) - tile.x0 : 0, valid ? (v0 - 1) - tile.y0 : 0, ax, ay, axay, nI, nu, nv);
-    S.I0[k] = valid ? nI : S.I0[k];
-    S.du[k] = valid ? nu : S.du[k];
-    S.dv[k] = valid ? nv : S.dv[k];
-    if (valid) S.m |= 0x10001u << k;  // bit 16+k: written by THIS point
-  }
-}
-
-// interpImageSameRatio on the taps of this lane (float compares, image_processing.cpp:79-118)
-template <bool STRICT>
-__device__ __forceinline__ void ic_sample_I1(const vo_level &L1, const IcTaps &tp, const float (&sx)[IC_K],
-                                             const float (&sy)[IC_K], float pux, float puy, float ax, float ay,
-                                             float axay, IcState &S, int &touched, const IcTile &tile,
-                                             const IcShared &sh) {
-  const uint8_t *sb = (const uint8_t *)sh.tj;
-  if (!STRICT) S.m &= ~0x1F00u;
-  const float fw = (float)(L1.w - 2), fh = (float)(L1.h - 2);
-  float val[IC_K];
-  unsigned vmask = 0, gmask = 0;
-#pragma unroll
-  for (int k = 0; k < IC_K; ++k) {
-    const bool on = (tp.on >> k) & 1u;
-    const float uc = pux + sx[k], vc = puy + sy[k];
-    const bool valid = on && !(uc < 1 || uc >= fw || vc < 1 || vc >= fh);
-    const int u0 = (int)uc, v0 = (int)vc;
-    const int lx = u0 - tile.x0, ly = v0 - tile.y0;
-    const bool inside = valid && (unsigned)lx < (unsigned)(IC_JW * 4 - 1) && (unsigned)ly < (unsigned)(IC_JH - 1);
-    const uint8_t *q = sb + (inside ? ly * (IC_JW * 4) + lx : 0);
-    val[k] = ic_bilin((float)q[0], (float)q[1], (float)q[IC_JW * 4], (float)q[IC_JW * 4 + 1], ax, ay, axay);
-    if (valid) vmask |= 1u << k;
-    if (valid && !inside) gmask |= 1u << k;
-    if (on && !valid) touched = 1;
-  }
-  if (__any(gmask != 0)) {  // rare: the window left the staged tile
-#pragma unroll
-    for (int k = 0; k < IC_K; ++k)
-      if ((gmask >> k) & 1u) {
-        const int u0 = (int)(pux + sx[k]), v0 = (int)(puy + sy[k]);
-        const uint8_t *p = L1.origin() + (ptrdiff_t)v0 * L1.stride + u0;
-        val[k] = ic_bilin((float)p[0], (float)p[1], (float)p[L1.stride], (float)p[L1.stride + 1], ax, ay, axay);
-      }
-  }
-#pragma unroll
-  for (int k = 0; k < IC_K; ++k) {
-    const bool valid = (vmask >> k) & 1u;
-    S.I1[k] = valid ? val[k] : S.I1[k];
-  }
-  S.m |= vmask * 0x1000100u;  // bits 8+k and 24+k (written by THIS point)
-}
-
-__device__ __forceinline__ void ic_frac(float x, float y, float &ax, float &ay, float &axay) {
-  // pt - floor(pt) (feature_tracker.cpp:355-356, :404-405); exact in float
-  ax = x - floorf(x);
-  ay = y - floorf(y);
-  axay = ax * ay;
-}
-
-// One point, feature_tracker.cpp:336-503. Returns cls (1 template only, 2 iterated).
-template <bool STRICT>
-__device__ int ic_point(const IcArgs &a, const IcTaps &tp, int pt, int lane, IcShared &sh, IcState &S, int &touched,
-                        float &last_pux, float &last_puy, int &n_iter) {
-  const float pt0x = a.pts0[2 * pt], pt0y = a.pts0[2 * pt + 1];
-  const float pt1x = a.pts_prior[2 * pt], pt1y = a.pts_prior[2 * pt + 1];
-  const float scale = a.scale[pt];
-  float ax, ay, axay;
-  ic_frac(pt0x, pt0y, ax, ay, axay);
-  if (ax < 0 || ax > 1 || ay < 0 || ay > 1) {
-    if (lane == 0) a.mask[pt] = 0;
-    return 1;
-  }
-  IcTRegs rt;
-  IcJRegs rj;
-  ic_template_fetch(a.I0, pt0x, pt0y, lane, rt);
-  ic_I1_fetch(a.I1, pt1x, pt1y, lane, rj);
-  ic_tile_commit<IC_TN, IC_TW, IC_TH>(rt, lane, sh.tt);
-  const IcTile tt = {rt.x0, rt.y0};
-  ic_template<STRICT>(a.I0, tp, pt0x, pt0y, ax, ay, axay, tt, sh, S, touched);
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int k = 0; k < IC_K; ++k) {
-    const bool use = (S.m >> k) & 1u;
-    acc[0] = use ? acc[0] + S.du[k] * S.du[k] : acc[0];
-    acc[1] = use ? acc[1] + S.du[k] * S.dv[k] : acc[1];
-    acc[2] = use ? acc[2] + S.dv[k] * S.dv[k] : acc[2];
-  }
-  ic_wave_sum4(acc);
-  const float A11 = acc[0], A12 = acc[1], A22 = acc[2];
-  const float D = A11 * A22 - A12 * A12;
-  if (D < 1e-4f) {
-    if (lane == 0) a.mask[pt] = 0;
-    return 1;
-  }
-  const float invD = (float)(1.0 / (double)D);
-  const float iD_A11 = A11 * invD, iD_A12 = A12 * invD, iD_A22 = A22 * invD;
-
-  float err_curr = 0.f, err_prev = 1e12f;
-  float tx = pt1x - pt0x, ty = pt1y - pt0y;
-  int err_flag = 0;
-  ic_tile_commit<IC_JN, IC_JW, IC_JH>(rj, lane, sh.tj);
-  const IcTile tile = {rj.x0, rj.y0};
-  float sx[IC_K], sy[IC_K];
-#pragma unroll
-  for (int k = 0; k < IC_K; ++k) {
-    sx[k] = tp.px[k] * scale;
-    sy[k] = tp.py[k] * scale;
-  }
-  // ax = x - floorf(x) lies in [0, 1] for every finite x, so the reference's range test (:407-411)
-  // can only be "failed" by a NaN, which its next test reports; and a NaN in ax/ay, in a used tap
-  // or in the update reaches dtu + dtv (all other inputs are finite u8-derived values). One
-  // wave-uniform test per iteration therefore covers the three throw sites (:412, :438-448, :466);
-  // which one it was is sorted out after the loop, off the hot path.
-  float b1 = 0.f, b2 = 0.f, e2 = 0.f;
-  bool nan_exit = false;
-  for (int iter = 0; iter < IC_MAX_ITER; ++iter) {
-    const float pux = pt0x + tx, puy = pt0y + ty;
-    ic_frac(pux, puy, ax, ay, axay);
-    last_pux = pux;
-    last_puy = puy;
-    ic_sample_I1<STRICT>(a.I1, tp, sx, sy, pux, puy, ax, ay, axay, S, touched, tile, sh);
-    float v[4] = {0.f, 0.f, 0.f, 0.f};  // b1, b2, sum r^2, count
-#pragma unroll
-    for (int k = 0; k < IC_K; ++k) {
-      const bool use = ((S.m >> k) & (S.m >> (8 + k))) & 1u;
-      const float r = S.I1[k] - S.I0[k];
-      v[0] = use ? v[0] + S.du[k] * r : v[0];
-      v[1] = use ? v[1] + S.dv[k] * r : v[1];
-      v[2] = use ? v[2] + r * r : v[2];
-      v[3] = use ? v[3] + 1.0f : v[3];
-    }
-    ic_wave_sum4(v);
-    ++n_iter;
-    b1 = v[0];
-    b2 = v[1];
-    e2 = v[2];
-    const float dtu = (-iD_A22 * b1 + iD_A12 * b2);
-    const float dtv = (iD_A12 * b1 - iD_A11 * b2);
-    const float e = sqrtf(e2 / v[3]);
-    const float err_rate = fabsf(err_prev - e) / err_prev;
-    const float dt_norm = dtu * dtu + dtv * dtv;
-    const bool is_nan = isnan(dtu + dtv) | isnan(ax + ay);
-    const bool conv = (iter > 1) & ((err_rate <= 1e-3f) | (dt_norm <= 1e-4f));
-    // every lane holds the same values: make the exit a scalar branch
-    const int ex = __builtin_amdgcn_readfirstlane((is_nan ? 2 : 0) | (conv ? 1 : 0));
-    if (ex & 2) {
-      nan_exit = true;
-      break;
-    }
-    tx += dtu;
-    ty += dtv;
-    err_curr = e;
-    if (ex) break;
-    err_prev = e;
-  }
-  if (nan_exit) {
-    // the reference would have stopped before this iteration's sampling (ax/ay NaN), at the
-    // tap test (patch NaN) or at the update test; err_curr keeps the previous iteration's value
-    err_flag = isnan(ax + ay) ? 1 : ((isnan(b1) || isnan(b2) || isnan(e2)) ? 2 : 4);
-  }
-  if (lane == 0) {
-    if (err_flag) {
-      atomicOr(a.flags, err_flag);
-      a.mask[pt] = 0;
-    } else if (isnan(err_curr)) {
-      a.mask[pt] = 0;
-    } else if (err_curr <= 30) {
-      a.pts_track[2 * pt] = pt0x + tx;
-      a.pts_track[2 * pt + 1] = pt0y + ty;
-      a.mask[pt] = 1;
-    } else {
-      a.mask[pt] = 0;
-    }
-  }
-  return 2;
-}
-
-__device__ __forceinline__ void ic_state_clear(IcState &S) {
-#pragma unroll
-  for (int k = 0; k < IC_K; ++k) S.I0[k] = S.du[k] = S.dv[k] = S.I1[k] = 0.f;
-  S.m = 0;
-}
-
-// ---- tap records (who wrote which tap, and what) -----------------------------------
-// 264 mask bits: taps 64k..64k+63 (k < 4) go to words 2k, 2k+1; taps 256..263 to word 8.
-// `bits`: bit k of the lane = predicate of tap lane + 64 k.
-__device__ __forceinline__ void ic_store_mask(uint32_t *dst, unsigned bits, int lane) {
-#pragma unroll
-  for (int k = 0; k < IC_K; ++k) {
-    const unsigned long long m = __ballot((bits >> k) & 1u);
-    if (lane == 0) {
-      if (k < 4) {
-        dst[2 * k] = (uint32_t)m;
-        dst[2 * k + 1] = (uint32_t)(m >> 32);
-      } else {
-        dst[8] = (uint32_t)m;  // taps 256..263 (lanes 8.. own no tap there)
-      }
-    }
-  }
-}
-// bit of tap lane + 64 k in a 9-word mask
-__device__ __forceinline__ bool ic_bit_k(const uint32_t *w, int lane, int k) {
-  return (w[k < 4 ? 2 * k + (lane >> 5) : 8] >> (lane & 31)) & 1u;
-}
-
-__device__ __forceinline__ void ic_store_records(const IcArgs &a, int pt, int lane, const IcTaps &tp, const IcState &S,
-                                                 int cls) {
-  if (!a.recW0) return;
-  const bool processed = cls >= 1, iterated = cls == 2;
-  ic_store_mask(a.recW0 + (size_t)pt * IC_MW, processed ? ((S.m >> 16) & tp.on) : 0u, lane);
-  ic_store_mask(a.recW1 + (size_t)pt * IC_MW, iterated ? ((S.m >> 24) & tp.on) : 0u, lane);
-  float *v0 = a.recV0 + (size_t)pt * 3 * IC_NELEM;
-  float *v1 = a.recV1 + (size_t)pt * IC_NELEM;
-#pragma unroll
-  for (int k = 0; k < IC_K; ++k)
-    if ((tp.on >> k) & 1u) {
-      const int j = lane + 64 * k;
-      v0[j] = S.I0[k];
-      v0[IC_NELEM + j] = S.du[k];
-      v0[2 * IC_NELEM + j] = S.dv[k];
-      v1[j] = S.I1[k];
-    }
-}
 
 // ---- pass 1: every point in parallel -------------------------------------------
 __global__ __launch_bounds__(IC_T) void ic_refine_kernel(IcArgs a) {
@@ -476,10 +48,6 @@ __global__ __launch_bounds__(IC_T) void ic_refine_kernel(IcArgs a) {
   const int pt = blockIdx.x;
   if (pt >= n) return;
   const int lane = threadIdx.x;
-  if (lane == 0) {
-    a.pts_track[2 * pt] = a.pts_prior[2 * pt];
-    a.pts_track[2 * pt + 1] = a.pts_prior[2 * pt + 1];
-  }
   int cls = 0, touched = 0, n_iter = 0;
   float lpx = 0.f, lpy = 0.f;
   const IcTaps tp = ic_make_taps(lane);
@@ -490,8 +58,10 @@ __global__ __launch_bounds__(IC_T) void ic_refine_kernel(IcArgs a) {
   IcState S;
   ic_state_clear(S);
   if (entry) {
-    cls = ic_point<false>(a, tp, pt, lane, sh, S, touched, lpx, lpy, n_iter);
+    cls = ic_point_io<false>(a, tp, pt, lane, sh, S, touched, lpx, lpy, n_iter);
   } else if (lane == 0) {
+    a.pts_track[2 * pt] = a.pts_prior[2 * pt];
+    a.pts_track[2 * pt + 1] = a.pts_prior[2 * pt + 1];
     a.mask[pt] = 0;
   }
   ic_store_records(a, pt, lane, tp, S, cls);
@@ -516,243 +86,10 @@ __global__ __launch_bounds__(IC_T) void ic_refine_kernel(IcArgs a) {
   }
 }
 
-// ---- pass 2a: parallel fixed-point replay of the touched points ------------------------
-// The state a touched point P sees is, per tap, the value written by the NEAREST earlier point
-// that wrote that tap (template taps: a static function of pts0; I1 taps: depends on that
-// point's own trajectory). Measured on forward-driving streams the runs of consecutive touched
-// points are ~100 long but the true value-dependency depth is <= 6, so instead of replaying a
-// run sequentially every touched point is recomputed in parallel from the current records of its
-// predecessors, again and again, until nothing changes any more. That fixed point is unique and
-// equals the sequential (reference) result: by induction over the index order, a point whose
-// predecessors' records are final computes its final record the next time it looks.
-//
-// The iteration is asynchronous ("chaotic relaxation"): one launch, each workgroup (one
-// wavefront) owns one or more touched points and loops  look -> (recompute, publish)  without
-// waiting for the others, so a slow point (30 iterations) only delays the points that really
-// depend on it.
-//   publish : write the record, release fence, bump the global `version` counter;
-//   look    : read `version` (acquire), rebuild the pre-state from the predecessors' records and
-//             compare the taps the point can observe with the pre-state of its last run;
-//   idle    : a workgroup whose pass changed nothing stores version+1 in its slot and polls;
-//             it looks again as soon as `version` moves.
-// Reads may race with a concurrent publish; a torn read can only cause an extra recomputation,
-// because every publish ends in a version bump that makes every reader look again.
-// Termination: version == v before and after seeing every slot at v+1 means every workgroup
-// finished a full pass at version v and nobody can publish any more. The workgroups that own
-// list entries are co-resident by construction (IC_JGRID = 2 per CU, ~17 KB of LDS each). All
-// waits are bounded (IC_SPIN_LIMIT polls, IC_MAX_PASSES passes); on overflow, or when a run
-// exceeds IC_MAXRUN, IC_JAC_OVF is raised and ic_strict_kernel replays sequentially.
-__device__ __forceinline__ int ic_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void ic_st(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
+// ---- pass 2a: parallel fixed-point replay of the touched points (ic_device.hpp: ic_replay) ----
 __global__ __launch_bounds__(IC_T) void ic_jacobi_kernel(IcArgs a) {
-  __shared__ IcShared sh;
-  __shared__ uint32_t s_w0[IC_MAXRUN * IC_MW], s_w1[IC_MAXRUN * IC_MW];
-  __shared__ uint8_t s_cls[IC_MAXRUN];
-  const int n_touched = a.jac[IC_JAC_NT];
-  if (n_touched == 0) return;  // nothing left the image: pass 1 already is the reference result
-  const int P = min((int)gridDim.x, n_touched);
-  if ((int)blockIdx.x >= P) return;
-  const int lane = threadIdx.x;
-  int *const ver = &a.jac[IC_JAC_VER];
-  int *const ovf = &a.jac[IC_JAC_OVF];
-  int *const slots = a.jac + IC_JAC_SLOTS;
-  const IcTaps tp = ic_make_taps(lane);
-  int polls = 0;
-#ifdef IC_STAMP
-  if (lane == 0 && blockIdx.x == 0) a.tlist[IC_DBG_OFF + 31] = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff);
-#endif
-  for (int pass = 0;; ++pass) {
-    // ---- look ----
-    int v = ic_ld(ver);
-    if (ic_ld(ovf)) break;
-    if (pass >= IC_MAX_PASSES) {
-      if (lane == 0) atomicExch(ovf, 1);
-      break;
-    }
-    v = __builtin_amdgcn_readfirstlane(v);
-    __threadfence();
-    int any_change = 0;
-    for (int li = blockIdx.x; li < n_touched; li += P) {
-      const int pt = a.tlist[li];
-      __syncthreads();  // LDS of the previous list entry is free
-      // nearest clean (untouched, iterated) predecessor: 64 candidates at a time
-      int dist = -1;
-      for (int c0 = 0; c0 < IC_CAND; c0 += 64) {
-        const int q = pt - 1 - c0 - lane;
-        const bool is_clean = q >= 0 && a.cls[q] == 2 && !a.touched[q];
-        const unsigned long long bal = __ballot(is_clean);
-        if (bal) {
-          dist = c0 + __ffsll((long long)bal) - 1;
-          break;
-        }
-        if (pt - 1 - c0 - 63 <= 0) break;  // ran past index 0
-      }
-      int lo;
-      if (dist < 0) {
-        if (pt > IC_CAND) {  // no clean point among the candidates
-          if (lane == 0) atomicExch(ovf, 1);
-          continue;
-        }
-        lo = 0;
-      } else {
-        lo = pt - 1 - dist;
-      }
-      const int L = pt - lo;  // predecessors lo .. pt-1
-      if (L > IC_MAXRUN) {
-        if (lane == 0) atomicExch(ovf, 1);
-        continue;
-      }
-      for (int i = lane; i < L * IC_MW; i += IC_T) {
-        s_w0[i] = a.recW0[(size_t)lo * IC_MW + i];
-        s_w1[i] = a.recW1[(size_t)lo * IC_MW + i];
-      }
-      for (int i = lane; i < L; i += IC_T) s_cls[i] = a.cls[lo + i];
-      __syncthreads();
-
-      IcState S;
-      ic_state_clear(S);
-      // nearest earlier writer of each of this lane's taps
-      {
-        int src0[IC_K], src1[IC_K];
-        unsigned open0 = tp.on, open1 = tp.on;  // taps still looking for a writer
-#pragma unroll
-        for (int k = 0; k < IC_K; ++k) src0[k] = src1[k] = -1;
-        for (int r = L - 1; r >= 0 && (open0 | open1); --r) {
-          const int c = s_cls[r];
-          if (c == 0) continue;
-#pragma unroll
-          for (int k = 0; k < IC_K; ++k) {
-            if (((open0 >> k) & 1u) && ic_bit_k(&s_w0[r * IC_MW], lane, k)) {
-              src0[k] = lo + r;
-              open0 &= ~(1u << k);
-            }
-            if (((open1 >> k) & 1u) && c == 2 && ic_bit_k(&s_w1[r * IC_MW], lane, k)) {
-              src1[k] = lo + r;
-              open1 &= ~(1u << k);
-            }
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < IC_K; ++k) {
-          const int j = lane + 64 * k;
-          if (src0[k] >= 0) {
-            const float *v0 = a.recV0 + (size_t)src0[k] * 3 * IC_NELEM;
-            S.I0[k] = v0[j];
-            S.du[k] = v0[IC_NELEM + j];
-            S.dv[k] = v0[2 * IC_NELEM + j];
-            S.m |= 1u << k;
-          }
-          if (src1[k] >= 0) {
-            S.I1[k] = a.recV1[(size_t)src1[k] * IC_NELEM + j];
-            S.m |= 0x100u << k;
-          }
-        }
-      }
-      // skip when the I1 pre-state is exactly the one this point last ran with (template part is static)
-      {
-        float *p1 = a.pre1 + (size_t)pt * IC_NELEM;
-        uint32_t *pm = a.preM + (size_t)pt * IC_MW;
-        int diff = pass == 0;
-        // Only taps that are outside the image at the point's FIRST I1 evaluation (the prior position:
-        // static) can show their pre-state to the point; every other tap is overwritten by that
-        // evaluation before anything reads it. Comparing just those taps prunes the false dependencies.
-        const float p0x = a.pts0[2 * pt], p0y = a.pts0[2 * pt + 1];
-        const float pux = p0x + (a.pts_prior[2 * pt] - p0x), puy = p0y + (a.pts_prior[2 * pt + 1] - p0y);
-        const float sc = a.scale[pt];
-        const float fw = (float)(a.I1.w - 2), fh = (float)(a.I1.h - 2);
-        if (!diff) {
-#pragma unroll
-          for (int k = 0; k < IC_K; ++k) {
-            const float uc = pux + tp.px[k] * sc, vc = puy + tp.py[k] * sc;
-            const bool seen = uc < 1 || uc >= fw || vc < 1 || vc >= fh;
-            if (((tp.on >> k) & 1u) && seen) {
-              const bool b0 = (S.m >> (8 + k)) & 1u;
-              const int j = lane + 64 * k;
-              if (b0 != ic_bit_k(pm, lane, k) || (b0 && __float_as_uint(p1[j]) != __float_as_uint(S.I1[k]))) diff = 1;
-            }
-          }
-        }
-        if (!__any(diff)) continue;
-#ifdef IC_STAMP
-        if (lane == 0) atomicAdd(&a.tlist[IC_DBG_OFF + 32], 1);
-#endif
-#pragma unroll
-        for (int k = 0; k < IC_K; ++k)
-          if ((tp.on >> k) & 1u) p1[lane + 64 * k] = S.I1[k];
-        ic_store_mask(pm, (S.m >> 8) & tp.on, lane);
-      }
-      if (lane == 0) {
-        a.pts_track[2 * pt] = a.pts_prior[2 * pt];
-        a.pts_track[2 * pt + 1] = a.pts_prior[2 * pt + 1];
-      }
-      int dummy = 0, n_iter = 0;
-      float lx = 0.f, ly = 0.f;
-      const int cls = ic_point<true>(a, tp, pt, lane, sh, S, dummy, lx, ly, n_iter);
-      // own I1 writes of this run of the point vs the stored record
-      const bool iterated = cls == 2;
-      const unsigned o = iterated ? ((S.m >> 24) & tp.on) : 0u;
-      uint32_t *w1 = a.recW1 + (size_t)pt * IC_MW;
-      float *v1 = a.recV1 + (size_t)pt * IC_NELEM;
-      int changed = a.cls[pt] != cls;
-#pragma unroll
-      for (int k = 0; k < IC_K; ++k)
-        if ((tp.on >> k) & 1u) {
-          const bool ok = (o >> k) & 1u;
-          if (ok != ic_bit_k(w1, lane, k) || (ok && __float_as_uint(v1[lane + 64 * k]) != __float_as_uint(S.I1[k])))
-            changed = 1;
-        }
-      if (__any(changed)) {
-        // publish
-#pragma unroll
-        for (int k = 0; k < IC_K; ++k)
-          if ((tp.on >> k) & 1u) v1[lane + 64 * k] = S.I1[k];
-        ic_store_mask(w1, o, lane);
-        if (lane == 0) a.cls[pt] = (uint8_t)cls;
-        __threadfence();  // release: every lane's record stores, then the bump
-        if (lane == 0) {
-          atomicAdd(ver, 1);
-#ifdef IC_STAMP
-          atomicAdd(&a.tlist[IC_DBG_OFF + 33], 1);
-#endif
-        }
-        any_change = 1;
-      }
-    }  // touched list
-    if (any_change) continue;  // look again at once: the version moved at least by our own publish
-
-    // ---- idle at version v: vote, then poll until the version moves or everybody is idle ----
-    if (lane == 0) ic_st(&slots[blockIdx.x], v + 1);
-    int res;
-    for (;;) {
-      const int cur = __builtin_amdgcn_readfirstlane(ic_ld(ver));
-      if (__builtin_amdgcn_readfirstlane(ic_ld(ovf))) {
-        res = 2;
-        break;
-      }
-      if (cur != v) {
-        res = 1;
-        break;
-      }
-      bool ok = true;
-      for (int k = lane; k < P; k += 64) ok = ok && (ic_ld(&slots[k]) == v + 1);
-      const bool all_idle = __all(ok);
-      if (all_idle && __builtin_amdgcn_readfirstlane(ic_ld(ver)) == v) {
-        res = 0;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(4);
-      if (++polls > IC_SPIN_LIMIT) {
-        if (lane == 0) atomicExch(ovf, 1);
-        res = 2;
-        break;
-      }
-    }
-    if (res != 1) break;  // 0: quiescent -> done ; 2: sequential fallback requested
-  }  // passes
-#ifdef IC_STAMP
-  if (lane == 0 && blockIdx.x == 0) a.tlist[IC_DBG_OFF + 0] = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff);
-#endif
+  __shared__ IcReplayShared rs;
+  (void)ic_replay(a, rs, threadIdx.x);
 }
 
 // ---- pass 2: sequential replay of the runs that contain touched points --------------
@@ -823,12 +160,8 @@ __global__ __launch_bounds__(IC_T) void ic_strict_kernel(IcArgs a) {
       ic_template<true>(a.I0, tp, cx, cy, ax, ay, axay, tt, sh, S, dummy);
       continue;
     }
-    if (lane == 0) {
-      a.pts_track[2 * p] = a.pts_prior[2 * p];
-      a.pts_track[2 * p + 1] = a.pts_prior[2 * p + 1];
-    }
     float lx, ly;
-    (void)ic_point<true>(a, tp, p, lane, sh, S, dummy, lx, ly, n_iter);
+    (void)ic_point_io<true>(a, tp, p, lane, sh, S, dummy, lx, ly, n_iter);
   }
 }
 
@@ -863,6 +196,22 @@ static int ic_records(vo_ctx *c, IcArgs &a) {
   a.recV1 = (float *)p;             p += N * IC_NELEM * 4;
   a.pre1 = (float *)p;
   return VO_OK;
+}
+
+// IcArgs for the fused frame kernel: image levels, error flags and (strict border) the tap records
+int vo_ic_frame_args(vo_ctx *c, int slot0, int slot1, IcArgs *a, int *d_flags, bool with_records, bool clear_control) {
+  memset(a, 0, sizeof(*a));
+  int rc = ic_args(c, slot0, slot1, *a, d_flags);
+  if (rc) return rc;
+  if (with_records) {
+    rc = ic_records(c, *a);
+    if (rc) return rc;
+    if (clear_control) VO_CHECK_HIP(c, hipMemsetAsync(a->jac, 0, IC_JAC_BYTES, c->stream));
+  }
+  return VO_OK;
+}
+void vo_ic_strict_launch(vo_ctx *c, const IcArgs &a) {
+  hipLaunchKernelGGL(ic_strict_kernel, dim3(a.n), dim3(IC_T), 0, c->stream, a);
 }
 
 // pass 1. d_prior and d_pts_track must be different buffers. with_records: also write the tap

@@ -27,10 +27,8 @@
 // bytes of L2/HBM-resident pyramid; arithmetic is ~10 int ops per sample per
 // iteration. At 1500 points it is latency-bound (dependent LDS->ALU->DPP chain
 // per iteration), not HBM-bound; see DESIGN.md.
-#include "vo_internal.hpp"
+#include "klt_device.hpp"
 #include "vo_kernels.hpp"
-
-#define KLT_W_BITS 14
 
 struct KltArgs {
   vo_level I[VO_MAX_LEVELS];
@@ -50,302 +48,22 @@ struct KltArgs {
 };
 
 template <int WIN>
-struct KltCfg {
-  static constexpr int rl_for() {
-    for (int r = 1; r <= WIN; ++r)
-      if (((WIN + r - 1) / r) * WIN <= 64) return r;
-    return WIN;
-  }
-  static constexpr int RL = rl_for();             // samples per lane
-  static constexpr int RPR = (WIN + RL - 1) / RL;  // runs per window row
-  static constexpr int SPAN = RPR * RL;            // columns covered (>= WIN)
-  // template tile: rows -1..WIN+1, cols (aligned) covering -1..SPAN+1
-  static constexpr int TT_H = WIN + 3;
-  static constexpr int TT_WD = (SPAN + 3 + 3 + 3) / 4;  // dwords per row (3 align slack)
-  // search tile
-  static constexpr int M = (WIN <= 21) ? 4 : 3;
-  static constexpr int TJ_H = WIN + 1 + 2 * M;
-  static constexpr int TJ_WD = (SPAN + 1 + 2 * M + 3 + 3 + 3) / 4;  // ceil, incl. 3 align slack each side
-  // per-lane register rows
-  static constexpr int NB_T = RL + 3;                 // bytes per template row incl. halo
-  static constexpr int ND_T = (NB_T + 3) / 4 + 1;     // dwords to read for any byte alignment
-  static constexpr int NB_J = RL + 1;
-  static constexpr int ND_J = (NB_J + 3) / 4 + 1;
-};
-
-__device__ __forceinline__ int descale_dev(int x, int n) { return (x + (1 << (n - 1))) >> n; }
-
-// byte k of a little-endian dword array starting at byte offset `sh` (0..3) of w[0]
-template <int ND>
-__device__ __forceinline__ void align_row(const uint32_t (&w)[ND], int sh, uint32_t (&out)[ND - 1]) {
-#pragma unroll
-  for (int i = 0; i < ND - 1; ++i) out[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], sh);
-}
-template <int NW>
-__device__ __forceinline__ int byte_at(const uint32_t (&w)[NW], int k) {
-  return (int)((w[k >> 2] >> (8 * (k & 3))) & 0xFFu);
-}
-
-__device__ __forceinline__ float uniform_f(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
-}
-
-template <int WIN>
 __global__ __launch_bounds__(64) void klt_track_kernel(KltArgs a) {
   using C = KltCfg<WIN>;
-  constexpr int RL = C::RL;
   __shared__ uint32_t s_tt[C::TT_H * C::TT_WD];
   __shared__ uint32_t s_tj[C::TJ_H * C::TJ_WD];
-
   const int n = a.d_n ? *a.d_n : a.n;
   const int pt = blockIdx.x;
   if (pt >= n) return;
   const int lane = threadIdx.x;
-  const int row = lane / C::RPR;
-  const int x0 = (lane % C::RPR) * RL;
-  const bool lane_on = row < WIN;
-  // samples of this lane: columns x0 .. x0+nx-1 of window row `row`
-  const int nx = lane_on ? ((x0 + RL <= WIN) ? RL : (WIN - x0 > 0 ? WIN - x0 : 0)) : 0;
-
-  const float halfWin = (WIN - 1) * 0.5f;
-  const float FLT_SCALE = 1.f / (1 << 20);
-  const float p0x = a.pts0[2 * pt], p0y = a.pts0[2 * pt + 1];
   const float *pin = a.pts1_init ? a.pts1_init : a.pts1;
-  float npx = pin[2 * pt], npy = pin[2 * pt + 1];  // "nextPts[ptidx]"
-  int status = 1;
-  float errv = 0.f;
-
-  for (int level = a.max_level; level >= 0; --level) {
-    const vo_level LI = a.I[level];
-    const vo_level LJ = a.J[level];
-    const float lscale = (float)(1. / (1 << level));
-    float prevx = p0x * lscale, prevy = p0y * lscale;
-    float nextx, nexty;
-    if (level == a.max_level) {
-      if (a.flags & VO_KLT_USE_INITIAL_FLOW) {
-        nextx = npx * lscale;
-        nexty = npy * lscale;
-      } else {
-        nextx = prevx;
-        nexty = prevy;
-      }
-    } else {
-      nextx = npx * 2.f;
-      nexty = npy * 2.f;
-    }
-    npx = nextx;
-    npy = nexty;
-    prevx -= halfWin;
-    prevy -= halfWin;
-    const int ipx = __builtin_amdgcn_readfirstlane((int)floorf(prevx));
-    const int ipy = __builtin_amdgcn_readfirstlane((int)floorf(prevy));
-    if (ipx < -WIN || ipx >= LI.w || ipy < -WIN || ipy >= LI.h) {
-      if (level == 0) {
-        status = 0;
-        errv = 0.f;
-      }
-      continue;
-    }
-    float fa = prevx - ipx, fb = prevy - ipy;
-    int iw00 = (int)rintf((1.f - fa) * (1.f - fb) * (1 << KLT_W_BITS));
-    int iw01 = (int)rintf(fa * (1.f - fb) * (1 << KLT_W_BITS));
-    int iw10 = (int)rintf((1.f - fa) * fb * (1 << KLT_W_BITS));
-    int iw11 = (1 << KLT_W_BITS) - iw00 - iw01 - iw10;
-
-    // ---- stage the template tile (rows ipy-1.., cols aligned down from ipx-1) ----
-    const int tx0 = (ipx - 1) & ~3;  // VO_PAD is a multiple of 4, so this is 4-byte aligned in memory
-    const int tsh = (ipx - 1) - tx0;
-    {
-      const uint8_t *g = LI.origin() + (ptrdiff_t)(ipy - 1) * LI.stride + tx0;
-      __syncthreads();
-      for (int i = lane; i < C::TT_H * C::TT_WD; i += 64) {
-        const int r = i / C::TT_WD, cdw = i - r * C::TT_WD;
-        s_tt[i] = *(const uint32_t *)(g + (ptrdiff_t)r * LI.stride + cdw * 4);
-      }
-      __syncthreads();
-    }
-    // ---- per-lane template: I, Ix, Iy at RL samples (Scharr on the fly) ----
-    int tI[RL], tX[RL], tY[RL];
-    int pA11 = 0, pA12 = 0, pA22 = 0;
-    {
-      // tile rows row..row+3 <-> image rows ipy+row-1 .. ipy+row+2 ; bytes from column (x0) incl. halo
-      uint32_t rb[4][C::ND_T - 1];
-      const int boff = tsh + x0;  // byte offset of image column ipx+x0-1 within the tile row
-      const int dwo = boff >> 2, sh = boff & 3;
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        uint32_t w[C::ND_T];
-        const int trow = lane_on ? row + rr : rr;
-#pragma unroll
-        for (int d = 0; d < C::ND_T; ++d) {
-          const int cd = dwo + d;
-          w[d] = s_tt[trow * C::TT_WD + (cd < C::TT_WD ? cd : C::TT_WD - 1)];
-        }
-        align_row<C::ND_T>(w, sh, rb[rr]);
-      }
-      // column sums for the two derivative rows r=0,1 (image rows ipy+row+r)
-      int dxv[2][RL + 1], dyv[2][RL + 1];
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        int t0[RL + 3], t1[RL + 3];
-#pragma unroll
-        for (int k = 0; k < RL + 3; ++k) {
-          const int up = byte_at(rb[r], k), ce = byte_at(rb[r + 1], k), dn = byte_at(rb[r + 2], k);
-          t0[k] = (up + dn) * 3 + ce * 10;
-          t1[k] = dn - up;
-        }
-        const int yy = ipy + row + r;
-        const bool yin = (yy >= 0) && (yy < LI.h);
-#pragma unroll
-        for (int k = 0; k < RL + 1; ++k) {
-          const int xx = ipx + x0 + k;
-          const bool in = yin && (xx >= 0) && (xx < LI.w);  // derivative plane is zero-padded
-          dxv[r][k] = in ? (t0[k + 2] - t0[k]) : 0;
-          dyv[r][k] = in ? ((t1[k + 2] + t1[k]) * 3 + t1[k + 1] * 10) : 0;
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < RL; ++j) {
-        const int i00 = byte_at(rb[1], j + 1), i01 = byte_at(rb[1], j + 2);
-        const int i10 = byte_at(rb[2], j + 1), i11 = byte_at(rb[2], j + 2);
-        const int ival = descale_dev(i00 * iw00 + i01 * iw01 + i10 * iw10 + i11 * iw11, KLT_W_BITS - 5);
-        const int ixval = descale_dev(dxv[0][j] * iw00 + dxv[0][j + 1] * iw01 + dxv[1][j] * iw10 + dxv[1][j + 1] * iw11, KLT_W_BITS);
-        const int iyval = descale_dev(dyv[0][j] * iw00 + dyv[0][j + 1] * iw01 + dyv[1][j] * iw10 + dyv[1][j + 1] * iw11, KLT_W_BITS);
-        const bool on = j < nx;
-        tI[j] = (int)(short)ival;
-        tX[j] = on ? (int)(short)ixval : 0;
-        tY[j] = on ? (int)(short)iyval : 0;
-        pA11 += tX[j] * tX[j];
-        pA12 += tX[j] * tY[j];
-        pA22 += tY[j] * tY[j];
-      }
-    }
-    float sA11, sA12, sA22, sdummy;
-    wave_sum2_i32_to_f32(pA11, pA12, sA11, sA12);
-    wave_sum2_i32_to_f32(pA22, 0, sA22, sdummy);
-    const float A11 = sA11 * FLT_SCALE;
-    const float A12 = sA12 * FLT_SCALE;
-    const float A22 = sA22 * FLT_SCALE;
-    float D = A11 * A22 - A12 * A12;
-    const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
-    if (minEig < a.min_eig || D < 1.19209290e-07f) {
-      if (level == 0) status = 0;
-      continue;
-    }
-    D = 1.f / D;
-    nextx -= halfWin;
-    nexty -= halfWin;
-    float pdx = 0.f, pdy = 0.f;
-    int tjx = 0, tjy = 0;   // image coords of search-tile byte (0,0)
-    bool tile_ok = false;
-
-    // bilinear difference of the current window against the template, per lane
-    auto eval_diffs = [&](int inx, int iny, int w00, int w01, int w10, int w11, int (&diff)[RL]) {
-      if (!tile_ok || inx < tjx || inx + C::SPAN + 1 > tjx + C::TJ_WD * 4 - 3 || iny < tjy ||
-          iny + WIN + 1 > tjy + C::TJ_H) {
-        tjx = (inx - C::M) & ~3;
-        tjy = iny - C::M;
-        const uint8_t *g = LJ.origin() + (ptrdiff_t)tjy * LJ.stride + tjx;
-        __syncthreads();
-        for (int i = lane; i < C::TJ_H * C::TJ_WD; i += 64) {
-          const int r = i / C::TJ_WD, cdw = i - r * C::TJ_WD;
-          s_tj[i] = *(const uint32_t *)(g + (ptrdiff_t)r * LJ.stride + cdw * 4);
-        }
-        __syncthreads();
-        tile_ok = true;
-      }
-      const int boff = (inx - tjx) + x0;
-      const int dwo = boff >> 2, sh = boff & 3;
-      const int trow = (iny - tjy) + (lane_on ? row : 0);
-      uint32_t r0[C::ND_J - 1], r1[C::ND_J - 1];
-      {
-        uint32_t w0[C::ND_J], w1[C::ND_J];
-#pragma unroll
-        for (int d = 0; d < C::ND_J; ++d) {
-          const int cd = dwo + d < C::TJ_WD ? dwo + d : C::TJ_WD - 1;
-          w0[d] = s_tj[trow * C::TJ_WD + cd];
-          w1[d] = s_tj[(trow + 1) * C::TJ_WD + cd];
-        }
-        align_row<C::ND_J>(w0, sh, r0);
-        align_row<C::ND_J>(w1, sh, r1);
-      }
-#pragma unroll
-      for (int j = 0; j < RL; ++j) {
-        const int v = descale_dev(byte_at(r0, j) * w00 + byte_at(r0, j + 1) * w01 + byte_at(r1, j) * w10 +
-                                      byte_at(r1, j + 1) * w11,
-                                  KLT_W_BITS - 5);
-        diff[j] = v - tI[j];
-      }
-    };
-
-    for (int j = 0; j < a.max_count; ++j) {
-      const int inx = __builtin_amdgcn_readfirstlane((int)floorf(nextx));
-      const int iny = __builtin_amdgcn_readfirstlane((int)floorf(nexty));
-      if (inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h) {
-        if (level == 0) status = 0;
-        break;
-      }
-      fa = nextx - inx;
-      fb = nexty - iny;
-      iw00 = (int)rintf((1.f - fa) * (1.f - fb) * (1 << KLT_W_BITS));
-      iw01 = (int)rintf(fa * (1.f - fb) * (1 << KLT_W_BITS));
-      iw10 = (int)rintf((1.f - fa) * fb * (1 << KLT_W_BITS));
-      iw11 = (1 << KLT_W_BITS) - iw00 - iw01 - iw10;
-      int diff[RL];
-      eval_diffs(inx, iny, iw00, iw01, iw10, iw11, diff);
-      int pb1 = 0, pb2 = 0;
-#pragma unroll
-      for (int k = 0; k < RL; ++k) {
-        pb1 += diff[k] * tX[k];
-        pb2 += diff[k] * tY[k];
-      }
-      float sb1, sb2;
-      wave_sum2_i32_to_f32(pb1, pb2, sb1, sb2);
-      const float b1 = sb1 * FLT_SCALE;
-      const float b2 = sb2 * FLT_SCALE;
-      const float dx = (float)((A12 * b2 - A22 * b1) * D);
-      const float dy = (float)((A12 * b1 - A11 * b2) * D);
-      nextx += dx;
-      nexty += dy;
-      npx = nextx + halfWin;
-      npy = nexty + halfWin;
-      if ((double)dx * dx + (double)dy * dy <= a.epsilon) break;
-      if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
-        npx -= dx * 0.5f;
-        npy -= dy * 0.5f;
-        break;
-      }
-      pdx = dx;
-      pdy = dy;
-    }
-
-    if (status && level == 0) {
-      const float ex = npx - halfWin, ey = npy - halfWin;
-      const int inx = __builtin_amdgcn_readfirstlane((int)floorf(ex));
-      const int iny = __builtin_amdgcn_readfirstlane((int)floorf(ey));
-      if (inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h) {
-        status = 0;
-      } else {
-        const float aa = ex - inx, bb = ey - iny;
-        iw00 = (int)rintf((1.f - aa) * (1.f - bb) * (1 << KLT_W_BITS));
-        iw01 = (int)rintf(aa * (1.f - bb) * (1 << KLT_W_BITS));
-        iw10 = (int)rintf((1.f - aa) * bb * (1 << KLT_W_BITS));
-        iw11 = (1 << KLT_W_BITS) - iw00 - iw01 - iw10;
-        int diff[RL];
-        eval_diffs(inx, iny, iw00, iw01, iw10, iw11, diff);
-        int pe = 0;
-#pragma unroll
-        for (int k = 0; k < RL; ++k) pe += (k < nx) ? abs(diff[k]) : 0;
-        const float errval = (float)wave_sum_i32(pe);  // < 2^24: exact
-        errv = errval * 1.f / (float)(32 * WIN * WIN);
-      }
-    }
-  }
+  const KltResult r = klt_point<WIN>(a.I, a.J, a.max_level, a.flags, a.max_count, a.epsilon, a.min_eig, a.pts0[2 * pt],
+                                     a.pts0[2 * pt + 1], pin[2 * pt], pin[2 * pt + 1], s_tt, s_tj, lane);
   if (lane == 0) {
-    a.pts1[2 * pt] = npx;
-    a.pts1[2 * pt + 1] = npy;
-    a.status[pt] = (uint8_t)status;
-    a.err[pt] = errv;
+    a.pts1[2 * pt] = r.x;
+    a.pts1[2 * pt + 1] = r.y;
+    a.status[pt] = (uint8_t)r.status;
+    a.err[pt] = r.err;
   }
 }
 

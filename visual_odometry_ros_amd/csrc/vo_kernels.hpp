@@ -38,6 +38,25 @@ int vo_ic_strict_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, c
                          uint8_t *d_cls, float *d_last_pu, int n_max, const int *d_n, int *d_flags = nullptr,
                          bool sequential_only = false);
 
+// the frame kernel's view of the IC state (ic_refine.hip); IcArgs lives in ic_device.hpp
+struct IcArgs;
+int vo_ic_frame_args(vo_ctx *c, int slot0, int slot1, IcArgs *a, int *d_flags, bool with_records, bool clear_control);
+void vo_ic_strict_launch(vo_ctx *c, const IcArgs &a);
+
+// frame_fused.hip
+struct vo_frame_fused_bufs {
+  float *scale, *k1, *pr_prior, *pl1, *pr1, *ref, *lastpu;
+  uint8_t *stage, *m2, *touched, *cls;
+  int *flags;
+  float *C_X, *C_pl1, *C_pr1;
+  int32_t *C_orig;
+  int *cnt;
+};
+int vo_frame_fused_supported(int win);
+int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, int slot_l1, int slot_r1,
+                           const float *d_l0, const float *d_r0, const float *d_X, int n, const float T_cp[16],
+                           const float T_rl[16], const vo_frame_fused_bufs &b, int phase);
+
 // misc_kernels.hip
 int vo_hamming_enqueue(vo_ctx *c, const uint8_t *d_a, int na, const uint8_t *d_b, int nb, uint16_t *d_dist);
 int vo_match_enqueue(vo_ctx *c, const uint8_t *d_a, int na, const uint8_t *d_b, int nb, int th_low, float ratio,
