@@ -15,6 +15,7 @@ Inputs (images and track sets) are resident in HBM before the timed region.
 Prints ONE JSON line on rank 0 (see DESIGN.md §Measurement for every field).
 """
 import argparse
+import gc
 import ctypes as C
 import json
 import os
@@ -156,6 +157,11 @@ def main():
     ctx.profile_reset()
     klt_alg_bytes = 0
     results = []
+    # A generational GC pass of the interpreter (tens of ms with torch loaded) inside the timed loop
+    # would be charged to a few frames; the loop allocates nothing that needs it.
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     for s in range(args.warmup, args.warmup + K):
@@ -164,6 +170,7 @@ def main():
             (n_pts + r["counts"].n_refine) * eff_levels + N_NEW * (eff_levels + eff_levels_bwd))
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
 
     tot_frames, max_dt = aggregate(K, dt, world, dev)
 

@@ -1,0 +1,23 @@
+"""Host-side time split of the bench loop (masked border): where does a frame period go?"""
+import sys, time, runpy, os
+sys.path.insert(0, '.')
+import torch
+import visual_odometry_ros_amd as V
+from visual_odometry_ros_amd import api
+acc = {}
+def wrap(cls, name):
+    f = getattr(cls, name)
+    def g(*a, **k):
+        t = time.perf_counter(); r = f(*a, **k); acc[name] = acc.get(name, 0.0) + time.perf_counter() - t; acc[name + '#'] = acc.get(name + '#', 0) + 1
+        return r
+    setattr(cls, name, g)
+for n in ("enqueue_device", "result"): wrap(api.StereoFramePipeline, n)
+for n in ("set_stereo_pair_device", "swap_slots"): wrap(api.Context, n)
+sys.argv = ["bench.py", "--no-cpu-baseline", "--strict-border", os.environ.get("STRICT", "0"), "--steps", "400"]
+t0 = time.perf_counter()
+try:
+    runpy.run_path("bench.py", run_name="__main__")
+except SystemExit:
+    pass
+for k in ("enqueue_device", "set_stereo_pair_device", "result", "swap_slots"):
+    print(f"{k:26s} {1e6 * acc[k] / acc[k + '#']:8.1f} us/call  x{acc[k + '#']}", file=sys.stderr)

@@ -27,7 +27,13 @@ struct FrameArgs {
   vo_level L1[VO_MAX_LEVELS];  // current left
   vo_level R1[VO_MAX_LEVELS];  // current right
   int max_level;               // effective OpenCV maxLevel
+  int max_level_bwd;           // effective maxLevel of the candidates' backward track (maxLevel - 1 requested)
   int n;
+  int n_new;                   // new-point candidates (step [10])
+  const float *pts_new;        // [n_new][2]
+  float *new_r;                // out [n_new][2] forward result
+  uint8_t *m_new;              // out [n_new]    trackBidirection mask
+  float thres_bidir;
   const float *Xp, *pts_l0, *pts_r0;
   float T_cp[16], T_rl[16], Kl[4], Kr[4];
   int W, H;
@@ -83,98 +89,165 @@ __device__ __forceinline__ void frame_tail(const FrameArgs &a, int i, int ok, fl
   }
 }
 
+// Workgroups 0..n-1 are the tracked features (steps [3],[4],[4-1],[5]); workgroups n..n+n_new-1 are
+// the new-point candidates of step [10] (trackBidirection, feature_tracker.cpp:60-83: forward
+// l1 -> r1, backward r1 -> l1 at maxLevel-1 with the candidates as initial flow, validity mask).
+// Both roles are "KLT, something in between, KLT", so the kernel is a two-pass loop around ONE
+// inlined copy of klt_point (its code is ~3000 instructions; one copy per call site would not fit
+// the instruction cache).
 template <int WIN>
 __global__ __launch_bounds__(64) void frame_track_kernel(FrameArgs a) {
   __shared__ FrameShared<WIN> sh;
   const int i = blockIdx.x;
-  if (i >= a.n) return;
+  if (i >= a.n + a.n_new) return;
   const int lane = threadIdx.x;
-  // ---- [3] priors (stereo_vo.cpp:483-522); every lane computes the same values ----
-  const float *Xi = a.Xp + 3 * i;
-  float Xl[3], Xr[3];
+  const bool feat = i < a.n;
+  const int j = i - a.n;  // candidate index (new-point role)
+  float p0x, p0y, ix, iy;  // KLT operands of the current pass
+  float prx = 0.f, pry = 0.f, scale = 1.f, l0x = 0.f, l0y = 0.f;
+  if (feat) {
+    // ---- [3] priors (stereo_vo.cpp:483-522); every lane computes the same values ----
+    const float *Xi = a.Xp + 3 * i;
+    float Xl[3], Xr[3];
 #pragma unroll
-  for (int r = 0; r < 3; ++r)
-    Xl[r] = ((a.T_cp[r * 4 + 0] * Xi[0] + a.T_cp[r * 4 + 1] * Xi[1]) + a.T_cp[r * 4 + 2] * Xi[2]) + a.T_cp[r * 4 + 3];
+    for (int r = 0; r < 3; ++r)
+      Xl[r] = ((a.T_cp[r * 4 + 0] * Xi[0] + a.T_cp[r * 4 + 1] * Xi[1]) + a.T_cp[r * 4 + 2] * Xi[2]) + a.T_cp[r * 4 + 3];
 #pragma unroll
-  for (int r = 0; r < 3; ++r)
-    Xr[r] = ((a.T_rl[r * 4 + 0] * Xl[0] + a.T_rl[r * 4 + 1] * Xl[1]) + a.T_rl[r * 4 + 2] * Xl[2]) + a.T_rl[r * 4 + 3];
-  const float scale = Xi[2] / Xl[2];
-  const float izl = 1.0f / Xl[2], izr = 1.0f / Xr[2];
-  float plx = a.Kl[0] * Xl[0] * izl + a.Kl[2], ply = a.Kl[1] * Xl[1] * izl + a.Kl[3];
-  float prx = a.Kr[0] * Xr[0] * izr + a.Kr[2], pry = a.Kr[1] * Xr[1] * izr + a.Kr[3];
-  const float l0x = a.pts_l0[2 * i], l0y = a.pts_l0[2 * i + 1];
-  if (!frame_in_image(plx, ply, a.W, a.H) || !frame_in_image(prx, pry, a.W, a.H) || (double)Xl[2] < 0.1 ||
-      (double)Xr[2] < 0.1) {
-    plx = l0x;
-    ply = l0y;
-    prx = a.pts_r0[2 * i];
-    pry = a.pts_r0[2 * i + 1];
-  }
-  // ---- [4] l0 -> l1 ({} criteria: 30 iterations / eps 0.01, {} minEig: 0) ----
-  const KltResult k1 = klt_point<WIN>(a.L0, a.L1, a.max_level, VO_KLT_USE_INITIAL_FLOW, 30, 0.01 * 0.01, 0.f, l0x, l0y,
-                                      plx, ply, sh.tt, sh.tj, lane);
-  const bool valid1 = frame_klt_valid(k1, a.W, a.H, a.thres_err);
-  if (lane == 0) {
-    a.scale[i] = scale;
-    a.k1[2 * i] = k1.x;
-    a.k1[2 * i + 1] = k1.y;
-    a.pr_prior[2 * i] = prx;
-    a.pr_prior[2 * i + 1] = pry;
-  }
-  const IcTaps tp = ic_make_taps(lane);
-  IcState S;
-  ic_state_clear(S);
-  int cls = 0, touched = 0, n_iter = 0;
-  float lpx = 0.f, lpy = 0.f;
-  IcResult rf;
-  rf.cls = 0;
-  rf.ok = 0;
-  rf.x = k1.x;
-  rf.y = k1.y;
-  rf.err_flag = 0;
-  if (valid1) {
-    // ---- [4-1] refinement of the left pixel (pass 1: taps outside the image are masked) ----
-    rf = ic_point<false>(a.L0[0], a.L1[0], tp, l0x, l0y, k1.x, k1.y, scale, lane, sh.ic, S, touched, lpx, lpy, n_iter);
-    cls = rf.cls;
-  }
-  const int any_t = __any(touched);
-  if (a.strict) {
-    // records for the replay; pass-1 results of every point (the replay overwrites touched ones)
-    ic_store_records(a.ic, i, lane, tp, S, cls);
-    if (lane == 0) {
-      a.ic.touched[i] = (uint8_t)(any_t ? 1 : 0);
-      a.ic.cls[i] = (uint8_t)cls;
-      a.ic.last_pu[2 * i] = lpx;
-      a.ic.last_pu[2 * i + 1] = lpy;
-      a.ic.pts_track[2 * i] = rf.x;
-      a.ic.pts_track[2 * i + 1] = rf.y;
-      a.ic.mask[i] = (uint8_t)rf.ok;
-      if (any_t) a.ic.tlist[atomicAdd(&a.ic.jac[IC_JAC_NT], 1)] = i;
+    for (int r = 0; r < 3; ++r)
+      Xr[r] = ((a.T_rl[r * 4 + 0] * Xl[0] + a.T_rl[r * 4 + 1] * Xl[1]) + a.T_rl[r * 4 + 2] * Xl[2]) + a.T_rl[r * 4 + 3];
+    scale = Xi[2] / Xl[2];
+    const float izl = 1.0f / Xl[2], izr = 1.0f / Xr[2];
+    float plx = a.Kl[0] * Xl[0] * izl + a.Kl[2], ply = a.Kl[1] * Xl[1] * izl + a.Kl[3];
+    prx = a.Kr[0] * Xr[0] * izr + a.Kr[2];
+    pry = a.Kr[1] * Xr[1] * izr + a.Kr[3];
+    l0x = a.pts_l0[2 * i];
+    l0y = a.pts_l0[2 * i + 1];
+    if (!frame_in_image(plx, ply, a.W, a.H) || !frame_in_image(prx, pry, a.W, a.H) || (double)Xl[2] < 0.1 ||
+        (double)Xr[2] < 0.1) {
+      plx = l0x;
+      ply = l0y;
+      prx = a.pts_r0[2 * i];
+      pry = a.pts_r0[2 * i + 1];
     }
+    p0x = l0x;
+    p0y = l0y;
+    ix = plx;
+    iy = ply;
+  } else {
+    p0x = ix = a.pts_new[2 * j];
+    p0y = iy = a.pts_new[2 * j + 1];
   }
-  if (lane == 0 && rf.err_flag) atomicOr(a.ic.flags, rf.err_flag);
-  if (!valid1) {
-    if (lane == 0) {
-      a.pl1[2 * i] = k1.x;
-      a.pl1[2 * i + 1] = k1.y;
-      a.pr1[2 * i] = prx;
-      a.pr1[2 * i + 1] = pry;
-      a.stage[i] = 0;
+  KltResult first;  // pass 0 result: [4] of a feature / forward track of a candidate
+  first.x = first.y = first.err = 0.f;
+  first.status = 0;
+  int rf_ok = 0;
+  float rfx = 0.f, rfy = 0.f;
+#pragma nounroll
+  for (int pass = 0; pass < 2; ++pass) {
+    // pass 0: feature [4] l0 -> l1 (initial flow = prior; {} criteria -> 30 / 0.01, {} minEig -> 0)
+    //         candidate forward l1 -> r1 (no initial flow, 30 / 0.01, minEig 1e-4)
+    // pass 1: feature [5] l1 -> r1 from the refined pixel (initial flow = prior right pixel)
+    //         candidate backward r1 -> l1 at maxLevel - 1 (initial flow = the candidate)
+    const vo_level *I = feat ? (pass == 0 ? a.L0 : a.L1) : (pass == 0 ? a.L1 : a.R1);
+    const vo_level *J = feat ? (pass == 0 ? a.L1 : a.R1) : (pass == 0 ? a.R1 : a.L1);
+    const int lvl = (!feat && pass == 1) ? a.max_level_bwd : a.max_level;
+    const int flags = (!feat && pass == 0) ? 0 : VO_KLT_USE_INITIAL_FLOW;
+    const float min_eig = (!feat && pass == 0) ? 1e-4f : 0.f;
+    const KltResult k = klt_point<WIN>(I, J, lvl, flags, 30, 0.01 * 0.01, min_eig, p0x, p0y, ix, iy, sh.tt, sh.tj, lane);
+    if (!feat) {
+      if (pass == 0) {
+        first = k;
+        p0x = k.x;  // backward: from the forward result, initial flow = the candidate (ix, iy unchanged)
+        p0y = k.y;
+        continue;
+      }
+      // trackBidirection validity, feature_tracker.cpp:74-83
+      const float dx = k.x - ix, dy = k.y - iy;
+      const float dist2 = dx * dx + dy * dy;
+      const float thres2 = a.thres_bidir * a.thres_bidir;
+      bool m = first.x > 3 && first.x < a.W - 3 && first.y > 3 && first.y < a.H - 3;
+      m = m && first.status && k.status && first.err <= a.thres_err && k.err <= a.thres_err && dist2 <= thres2;
+      if (lane == 0) {
+        a.new_r[2 * j] = first.x;
+        a.new_r[2 * j + 1] = first.y;
+        a.m_new[j] = m ? 1 : 0;
+      }
+      return;
     }
-    return;
-  }
-  if (a.strict && any_t) {
-    // deferred: frame_replay_kernel (or frame_tail_kernel) finishes this feature
-    if (lane == 0) {
-      a.pl1[2 * i] = k1.x;
-      a.pl1[2 * i + 1] = k1.y;
-      a.pr1[2 * i] = prx;
-      a.pr1[2 * i + 1] = pry;
-      a.stage[i] = 1;
+    if (pass == 1) {
+      // ---- end of [5] ----
+      const int stage = frame_klt_valid(k, a.W, a.H, a.thres_err) ? 3 : 2;
+      if (lane == 0) {
+        a.pl1[2 * i] = rfx;
+        a.pl1[2 * i + 1] = rfy;
+        a.pr1[2 * i] = k.x;  // reported for every feature that entered step [5], valid or not
+        a.pr1[2 * i + 1] = k.y;
+        a.stage[i] = (uint8_t)stage;
+      }
+      return;
     }
-    return;
+    // ---- feature, after [4] ----
+    first = k;
+    const bool valid1 = frame_klt_valid(k, a.W, a.H, a.thres_err);
+    if (lane == 0) {
+      a.scale[i] = scale;
+      a.k1[2 * i] = k.x;
+      a.k1[2 * i + 1] = k.y;
+      a.pr_prior[2 * i] = prx;
+      a.pr_prior[2 * i + 1] = pry;
+    }
+    const IcTaps tp = ic_make_taps(lane);
+    IcState S;
+    ic_state_clear(S);
+    int cls = 0, touched = 0, n_iter = 0;
+    float lpx = 0.f, lpy = 0.f;
+    IcResult rf;
+    rf.cls = 0;
+    rf.ok = 0;
+    rf.x = k.x;
+    rf.y = k.y;
+    rf.err_flag = 0;
+    if (valid1) {
+      // ---- [4-1] refinement of the left pixel (pass 1: taps outside the image are masked) ----
+      rf = ic_point<false>(a.L0[0], a.L1[0], tp, l0x, l0y, k.x, k.y, scale, lane, sh.ic, S, touched, lpx, lpy, n_iter);
+      cls = rf.cls;
+    }
+    const int any_t = __any(touched);
+    if (a.strict) {
+      // records for the replay; pass-1 results of every point (the replay overwrites touched ones)
+      ic_store_records(a.ic, i, lane, tp, S, cls);
+      if (lane == 0) {
+        a.ic.touched[i] = (uint8_t)(any_t ? 1 : 0);
+        a.ic.cls[i] = (uint8_t)cls;
+        a.ic.last_pu[2 * i] = lpx;
+        a.ic.last_pu[2 * i + 1] = lpy;
+        a.ic.pts_track[2 * i] = rf.x;
+        a.ic.pts_track[2 * i + 1] = rf.y;
+        a.ic.mask[i] = (uint8_t)rf.ok;
+        if (any_t) a.ic.tlist[atomicAdd(&a.ic.jac[IC_JAC_NT], 1)] = i;
+      }
+    }
+    if (lane == 0 && rf.err_flag) atomicOr(a.ic.flags, rf.err_flag);
+    const bool deferred = a.strict && any_t;  // frame_replay_kernel (or frame_tail_kernel) finishes this feature
+    if (!valid1 || !rf.ok || deferred) {
+      if (lane == 0) {
+        a.pl1[2 * i] = rf.x;  // the step [4] result unless the refinement accepted
+        a.pl1[2 * i + 1] = rf.y;
+        a.pr1[2 * i] = prx;
+        a.pr1[2 * i + 1] = pry;
+        a.stage[i] = valid1 ? 1 : 0;
+      }
+      return;
+    }
+    rf_ok = rf.ok;
+    rfx = rf.x;
+    rfy = rf.y;
+    p0x = rf.x;
+    p0y = rf.y;
+    ix = prx;
+    iy = pry;
   }
-  frame_tail<WIN>(a, i, rf.ok, rf.x, rf.y, k1.x, k1.y, prx, pry, sh.tt, sh.tj, lane);
+  (void)rf_ok;
 }
 
 // strict border: replay of the touched features, then their step [5]
@@ -215,6 +288,9 @@ struct FinishArgs {
   float *C_X, *C_pl1, *C_pr1;
   int32_t *C_orig;
   int *cnt;  // [0] survivors of [4], [1] of [4-1], [2] of [5]
+  int *ctl;        // control block: [0] error flags of this frame; cleared here for the next frame
+  int ctl_words;
+  int *hdr_flags;  // out
 };
 __global__ __launch_bounds__(1024) void frame_finish_kernel(FinishArgs a) {
   __shared__ int s_wave[16][3];
@@ -256,6 +332,10 @@ __global__ __launch_bounds__(1024) void frame_finish_kernel(FinishArgs a) {
     __syncthreads();
   }
   if (tid < 3) a.cnt[tid] = s_base[tid];
+  // every producer / consumer of the control block ran before this kernel: report, then reset
+  if (tid == 0) *a.hdr_flags = a.ctl[0];
+  __syncthreads();
+  for (int k = tid; k < a.ctl_words; k += 1024) a.ctl[k] = 0;
 }
 
 // ---- host side ---------------------------------------------------------------------
@@ -265,7 +345,7 @@ template <int WIN>
 static void frame_launch(vo_ctx *c, const FrameArgs &a, const FinishArgs &f, int phase) {
   if (phase == 0) {
     vo_prof_begin(c, VO_K_KLT);
-    hipLaunchKernelGGL(frame_track_kernel<WIN>, dim3(a.n), dim3(64), 0, c->stream, a);
+    hipLaunchKernelGGL(frame_track_kernel<WIN>, dim3(a.n + a.n_new), dim3(64), 0, c->stream, a);
     vo_prof_end(c);
     return;
   }
@@ -285,7 +365,8 @@ int vo_frame_fused_supported(int win) { return win == 15 || win == 21 || win == 
 
 int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, int slot_l1, int slot_r1,
                            const float *d_l0, const float *d_r0, const float *d_X, int n, const float T_cp[16],
-                           const float T_rl[16], const vo_frame_fused_bufs &b, int phase) {
+                           const float T_rl[16], const float *d_new, int n_new, const vo_frame_fused_bufs &b,
+                           int phase) {
   if (n <= 0) return VO_OK;
   const int slots[3] = {slot_l0, slot_l1, slot_r1};
   for (int s : slots)
@@ -304,7 +385,17 @@ int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, 
     a.R1[l] = P2.lv[l];
   }
   a.max_level = eff;
+  if (n_new > 0) {
+    if (prm->max_level - 1 < 0) VO_FAIL(c, VO_ERR_INVALID, "trackBidirection needs max_level >= 1");
+    int effb = vo_pyr_levels_host(P0.w, P0.h, prm->win, prm->max_level - 1);
+    a.max_level_bwd = effb < eff ? effb : eff;
+  }
   a.n = n;
+  a.n_new = n_new;
+  a.pts_new = d_new;
+  a.new_r = b.new_r;
+  a.m_new = b.m_new;
+  a.thres_bidir = prm->thres_bidirection;
   a.Xp = d_X;
   a.pts_l0 = d_l0;
   a.pts_r0 = d_r0;
@@ -322,8 +413,7 @@ int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, 
   a.pl1 = b.pl1;
   a.pr1 = b.pr1;
   a.stage = b.stage;
-  // phase 0 also clears the replay control words
-  int rc = vo_ic_frame_args(c, slot_l0, slot_l1, &a.ic, b.flags, a.strict != 0, phase == 0);
+  int rc = vo_ic_frame_args(c, slot_l0, slot_l1, &a.ic, b.ctl, a.strict != 0);
   if (rc) return rc;
   a.ic.pts0 = d_l0;
   a.ic.scale = b.scale;
@@ -334,7 +424,8 @@ int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, 
   a.ic.cls = b.cls;
   a.ic.last_pu = b.lastpu;
   a.ic.n = n;
-  const FinishArgs f = {n, b.stage, d_X, b.pl1, b.pr1, b.C_X, b.C_pl1, b.C_pr1, b.C_orig, b.cnt};
+  const FinishArgs f = {n, b.stage, d_X, b.pl1, b.pr1, b.C_X, b.C_pl1, b.C_pr1, b.C_orig, b.cnt, b.ctl,
+                        (int)(vo_ic_ctl_bytes() / 4), b.hdr_flags};
   switch (prm->win) {
     case 15: frame_launch<15>(c, a, f, phase); break;
     case 21: frame_launch<21>(c, a, f, phase); break;

@@ -19,6 +19,14 @@
 #include "vo_kernels.hpp"
 
 #include <stdlib.h>
+#ifdef VO_TRACE_HOST
+#include <chrono>
+static double vo_now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define VO_TT(label) do { double _t = vo_now_us(); if (vo_tt_n < 40) fprintf(stderr, "  [host] %-14s +%.1f us\n", label, _t - vo_tt_last); vo_tt_last = _t; } while (0)
+static double vo_tt_last; static int vo_tt_n;
+#else
+#define VO_TT(label)
+#endif
 
 // header of the packed result block (device and pinned-host copies share the layout)
 struct vo_frame_hdr {
@@ -48,6 +56,7 @@ struct vo_frame_state {
   uint8_t *st1, *st2, *st3;
   float *e1, *e2, *e3;
   float *new_back;
+  int *ctl;  // fused path: error flags + replay control words (zero between frames)
   // packed result block
   uint8_t *res_dev, *res_host;
   size_t res_cap;
@@ -89,6 +98,8 @@ static int frame_init(vo_ctx *c) {
   VO_CHECK_HIP(c, hipMalloc((void **)&f->res_dev, f->res_cap));
   VO_CHECK_HIP(c, hipHostMalloc((void **)&f->res_host, f->res_cap, hipHostMallocDefault));
   VO_CHECK_HIP(c, hipEventCreateWithFlags(&f->ev_done, hipEventDisableTiming));
+  VO_CHECK_HIP(c, hipMalloc((void **)&f->ctl, vo_ic_ctl_bytes()));
+  VO_CHECK_HIP(c, hipMemsetAsync(f->ctl, 0, vo_ic_ctl_bytes(), c->stream));
   return VO_OK;
 }
 
@@ -98,7 +109,7 @@ void vo_frame_free(vo_ctx *c) {
   void *bufs[] = {f->in_l0, f->in_r0, f->in_X, f->in_new, f->F_scale, f->F_orig, f->A_pl0, f->A_pl1, f->A_pr1,
                   f->A_X, f->A_scale, f->A_orig, f->B_pl1, f->B_pr1, f->B_X, f->B_orig, f->C_pl1, f->C_pr1,
                   f->C_X, f->C_orig, f->m1, f->m2, f->m3, f->mG, f->st1, f->st2, f->e1, f->e2, f->new_back,
-                  f->A_ref, f->A_lastpu, f->A_touched, f->A_cls, f->res_dev, f->st3, f->e3};
+                  f->A_ref, f->A_lastpu, f->A_touched, f->A_cls, f->res_dev, f->st3, f->e3, f->ctl};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   if (f->res_host) (void)hipHostFree(f->res_host);
@@ -137,12 +148,19 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
                                        int n, const float dT_prior[16], const float *pts_new, int n_new,
                                        int inputs_on_device) {
   if (!c || !prm || !dT_prior || n < 0 || n_new < 0) return VO_ERR_INVALID;
+#ifdef VO_TRACE_HOST
+  vo_tt_last = vo_now_us();
+#endif
   if (n > c->cfg.max_points || n_new > c->cfg.max_points)
     VO_FAIL(c, VO_ERR_CAPACITY, "n=%d / n_new=%d exceed vo_config.max_points=%d", n, n_new, c->cfg.max_points);
   if ((n > 0 && (!pts_l0 || !pts_r0 || !Xp)) || (n_new > 0 && !pts_new)) return VO_ERR_INVALID;
   if (n_new > 0 && prm->max_level - 1 < 0) VO_FAIL(c, VO_ERR_INVALID, "trackBidirection needs max_level >= 1");
   VO_CHECK_HIP(c, hipSetDevice(c->device));
+  VO_TT("setdevice");
   RC(frame_init(c));
+#ifdef VO_TRACE_HOST
+  ++vo_tt_n;
+#endif
   vo_frame_state *f = c->frame;
   hipStream_t s = c->stream;
   const float *d_l0 = pts_l0, *d_r0 = pts_r0, *d_X = Xp, *d_new = pts_new;
@@ -176,16 +194,17 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
   f->F_pr1 = (float *)(f->res_dev + f->off_pr1);
   f->new_r = (float *)(f->res_dev + f->off_newr);
   int *cnt = f->hdr->cnt;
-  VO_CHECK_HIP(c, hipMemsetAsync(f->hdr, 0, sizeof(vo_frame_hdr), s));  // counts, flags
+  const bool fused = n > 0 && vo_frame_fused_supported(prm->win);
+  // the fused path writes every header field itself and keeps its control block zero between frames
+  if (!fused) VO_CHECK_HIP(c, hipMemsetAsync(f->hdr, 0, sizeof(vo_frame_hdr), s));  // counts, flags
 
   const int W = prm->width, H = prm->height;
   float T_rl[16], T_cp[16];
   inv_se3(prm->T_lr, T_rl);
   inv_se3(dT_prior, T_cp);
 
-  if (n_new > 0) VO_CHECK_HIP(c, hipEventRecord(c->ev_fork, s));  // the new pyramids are enqueued before this point
+  if (n_new > 0 && !fused) VO_CHECK_HIP(c, hipEventRecord(c->ev_fork, s));  // the new pyramids are enqueued before this point
 
-  const bool fused = n > 0 && vo_frame_fused_supported(prm->win);
   if (fused) {
     // steps [3] .. [5] of a feature are one wavefront of ONE launch (frame_fused.hip)
     vo_frame_fused_bufs b;
@@ -200,33 +219,21 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
     b.m2 = f->m2;
     b.touched = f->A_touched;
     b.cls = f->A_cls;
-    b.flags = &f->hdr->flags;
+    b.ctl = f->ctl;
+    b.hdr_flags = &f->hdr->flags;
     b.C_X = f->C_X;
     b.C_pl1 = f->C_pl1;
     b.C_pr1 = f->C_pr1;
     b.C_orig = f->C_orig;
     b.cnt = cnt;
-    RC(vo_frame_fused_enqueue(c, prm, slot_l0, slot_l1, slot_r1, d_l0, d_r0, d_X, n, T_cp, T_rl, b, 0));
-    // (the main chain's long kernel is queued; now feed the side stream)
-    // [10] new points on the side stream: they depend only on the two new pyramids, not on the
-    // main chain, and the chain's kernels leave most of the chip idle (one wave per point).
-    if (n_new > 0) {
-      VO_CHECK_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-      c->stream = c->stream2;
-      int rc2 = vo_klt_enqueue(c, slot_l1, slot_r1, d_new, nullptr, f->new_r, n_new, nullptr, prm->win,
-                               prm->max_level, 0, 30, 0.01, 1e-4f, f->st3, f->e3);
-      // backward: maxLevel-1, initial flow = pts_new, {} criteria / minEig (feature_tracker.cpp:69-71)
-      if (rc2 >= 0)
-        rc2 = vo_klt_enqueue(c, slot_r1, slot_l1, f->new_r, d_new, f->new_back, n_new, nullptr, prm->win,
-                             prm->max_level - 1, VO_KLT_USE_INITIAL_FLOW, 0, 0., 0.f, f->st2, f->e2);
-      if (rc2 >= 0)
-        rc2 = vo_klt_mask_enqueue(c, 2, n_new, nullptr, W, H, prm->thres_err, prm->thres_bidirection, d_new,
-                                  f->new_r, f->new_back, f->st3, f->st2, f->e3, f->e2, nullptr, f->mNew);
-      c->stream = s;
-      if (rc2 < 0) return rc2;
-      VO_CHECK_HIP(c, hipEventRecord(c->ev_join, c->stream2));
-    }
-    RC(vo_frame_fused_enqueue(c, prm, slot_l0, slot_l1, slot_r1, d_l0, d_r0, d_X, n, T_cp, T_rl, b, 1));
+    b.new_r = f->new_r;
+    b.m_new = f->mNew;
+    // [10] the new-point candidates are extra workgroups of the same launch
+    VO_TT("setup");
+    RC(vo_frame_fused_enqueue(c, prm, slot_l0, slot_l1, slot_r1, d_l0, d_r0, d_X, n, T_cp, T_rl, d_new, n_new, b, 0));
+    VO_TT("track launch");
+    RC(vo_frame_fused_enqueue(c, prm, slot_l0, slot_l1, slot_r1, d_l0, d_r0, d_X, n, T_cp, T_rl, d_new, n_new, b, 1));
+    VO_TT("phase1");
   } else if (n > 0) {
     // general window sizes: one launch per step, compaction in between
     // [3] priors
@@ -327,10 +334,13 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
   RC(vo_gn_enqueue(c, true, false, f->C_X, f->C_pl1, f->C_pr1, n, &cnt[2], prm->Kl, prm->Kr, prm->T_lr,
                    prm->thres_poseba, 0, dT_prior, f->hdr->dT, f->mG, &f->hdr->gn, true, n > 0 ? f->stage : nullptr,
                    f->C_orig, 4, 60.0f));
-  if (n_new > 0) VO_CHECK_HIP(c, hipStreamWaitEvent(s, c->ev_join, 0));
+  if (n_new > 0 && !fused) VO_CHECK_HIP(c, hipStreamWaitEvent(s, c->ev_join, 0));
+  VO_TT("gn launch");
   // one D2H of the packed block into pinned memory
   VO_CHECK_HIP(c, hipMemcpyAsync(f->res_host, f->res_dev, f->res_bytes, hipMemcpyDeviceToHost, s));
+  VO_TT("memcpy");
   VO_CHECK_HIP(c, hipEventRecord(f->ev_done, s));
+  VO_TT("event");
   f->pending = true;
   return VO_OK;
 }

@@ -198,16 +198,19 @@ static int ic_records(vo_ctx *c, IcArgs &a) {
   return VO_OK;
 }
 
-// IcArgs for the fused frame kernel: image levels, error flags and (strict border) the tap records
-int vo_ic_frame_args(vo_ctx *c, int slot0, int slot1, IcArgs *a, int *d_flags, bool with_records, bool clear_control) {
+// IcArgs for the fused frame kernel: image levels and (strict border) the tap records. `ctl` is the
+// frame's own control block: ctl[0] = error flags, ctl[16..] = replay control words. It is zeroed
+// once at allocation and re-zeroed by frame_finish_kernel at the end of every frame.
+size_t vo_ic_ctl_bytes() { return 64 + IC_JAC_BYTES; }
+int vo_ic_frame_args(vo_ctx *c, int slot0, int slot1, IcArgs *a, int *ctl, bool with_records) {
   memset(a, 0, sizeof(*a));
-  int rc = ic_args(c, slot0, slot1, *a, d_flags);
+  int rc = ic_args(c, slot0, slot1, *a, ctl);
   if (rc) return rc;
   if (with_records) {
     rc = ic_records(c, *a);
     if (rc) return rc;
-    if (clear_control) VO_CHECK_HIP(c, hipMemsetAsync(a->jac, 0, IC_JAC_BYTES, c->stream));
   }
+  a->jac = ctl + 16;
   return VO_OK;
 }
 void vo_ic_strict_launch(vo_ctx *c, const IcArgs &a) {

@@ -40,14 +40,18 @@ int vo_ic_strict_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, c
 
 // the frame kernel's view of the IC state (ic_refine.hip); IcArgs lives in ic_device.hpp
 struct IcArgs;
-int vo_ic_frame_args(vo_ctx *c, int slot0, int slot1, IcArgs *a, int *d_flags, bool with_records, bool clear_control);
+size_t vo_ic_ctl_bytes();
+int vo_ic_frame_args(vo_ctx *c, int slot0, int slot1, IcArgs *a, int *ctl, bool with_records);
 void vo_ic_strict_launch(vo_ctx *c, const IcArgs &a);
 
 // frame_fused.hip
 struct vo_frame_fused_bufs {
   float *scale, *k1, *pr_prior, *pl1, *pr1, *ref, *lastpu;
   uint8_t *stage, *m2, *touched, *cls;
-  int *flags;
+  float *new_r;    // new-point candidates: forward result / mask
+  uint8_t *m_new;
+  int *ctl;        // control block (vo_ic_ctl_bytes): error flags + replay control words
+  int *hdr_flags;  // where the frame's error flags are reported
   float *C_X, *C_pl1, *C_pr1;
   int32_t *C_orig;
   int *cnt;
@@ -55,7 +59,8 @@ struct vo_frame_fused_bufs {
 int vo_frame_fused_supported(int win);
 int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, int slot_l1, int slot_r1,
                            const float *d_l0, const float *d_r0, const float *d_X, int n, const float T_cp[16],
-                           const float T_rl[16], const vo_frame_fused_bufs &b, int phase);
+                           const float T_rl[16], const float *d_new, int n_new, const vo_frame_fused_bufs &b,
+                           int phase);
 
 // misc_kernels.hip
 int vo_hamming_enqueue(vo_ctx *c, const uint8_t *d_a, int na, const uint8_t *d_b, int nb, uint16_t *d_dist);
