@@ -46,6 +46,9 @@ struct FrameArgs {
   float *pr1;       // out [n][2] right pixels: the prior, replaced by the [5] result for features that reach [5]
   uint8_t *stage;   // out [n]    0 lost in [4], 1 in [4-1], 2 in [5], 3 survivor
   IcArgs ic;        // tap records / touched list / replay control (index space = input index)
+#ifdef FRAME_STAMP
+  int *dbg;         // [n + n_new][8] diagnostic stamps (s_memrealtime, 100 MHz) and iteration counts
+#endif
 };
 
 template <int WIN>
@@ -103,6 +106,14 @@ __global__ __launch_bounds__(64) void frame_track_kernel(FrameArgs a) {
   const int lane = threadIdx.x;
   const bool feat = i < a.n;
   const int j = i - a.n;  // candidate index (new-point role)
+#ifdef FRAME_STAMP
+#define FSTAMP(k) if (lane == 0) a.dbg[8 * i + (k)] = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff);
+#define FNOTE(k, v) if (lane == 0) a.dbg[8 * i + (k)] = (v);
+#else
+#define FSTAMP(k)
+#define FNOTE(k, v)
+#endif
+  FSTAMP(0)
   float p0x, p0y, ix, iy;  // KLT operands of the current pass
   float prx = 0.f, pry = 0.f, scale = 1.f, l0x = 0.f, l0y = 0.f;
   if (feat) {
@@ -154,6 +165,10 @@ __global__ __launch_bounds__(64) void frame_track_kernel(FrameArgs a) {
     const int flags = (!feat && pass == 0) ? 0 : VO_KLT_USE_INITIAL_FLOW;
     const float min_eig = (!feat && pass == 0) ? 1e-4f : 0.f;
     const KltResult k = klt_point<WIN>(I, J, lvl, flags, 30, 0.01 * 0.01, min_eig, p0x, p0y, ix, iy, sh.tt, sh.tj, lane);
+#ifdef FRAME_STAMP
+    FSTAMP(pass == 0 ? 1 : 3)
+    FNOTE(pass == 0 ? 4 : 5, k.iters)
+#endif
     if (!feat) {
       if (pass == 0) {
         first = k;
@@ -212,6 +227,8 @@ __global__ __launch_bounds__(64) void frame_track_kernel(FrameArgs a) {
       rf = ic_point<false>(a.L0[0], a.L1[0], tp, l0x, l0y, k.x, k.y, scale, lane, sh.ic, S, touched, lpx, lpy, n_iter);
       cls = rf.cls;
     }
+    FSTAMP(2)
+    FNOTE(6, n_iter)
     const int any_t = __any(touched);
     if (a.strict) {
       // records for the replay; pass-1 results of every point (the replay overwrites touched ones)
@@ -338,6 +355,16 @@ __global__ __launch_bounds__(1024) void frame_finish_kernel(FinishArgs a) {
   for (int k = tid; k < a.ctl_words; k += 1024) a.ctl[k] = 0;
 }
 
+#ifdef FRAME_STAMP
+static int *vo_frame_dbg_ptr;
+extern "C" int vo_debug_frame_stamps(vo_ctx *c, int *dst, int rows) {
+  if (!vo_frame_dbg_ptr) return VO_ERR_INVALID;
+  VO_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+  VO_CHECK_HIP(c, hipMemcpy(dst, vo_frame_dbg_ptr, sizeof(int) * 8 * (size_t)rows, hipMemcpyDeviceToHost));
+  return VO_OK;
+}
+#endif
+
 // ---- host side ---------------------------------------------------------------------
 // phase 0: the per-feature kernel; phase 1: replay (strict) + final compaction. Two phases so that
 // the caller can feed other streams while the long first kernel is already running.
@@ -396,6 +423,15 @@ int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, 
   a.new_r = b.new_r;
   a.m_new = b.m_new;
   a.thres_bidir = prm->thres_bidirection;
+#ifdef FRAME_STAMP
+  {
+    static int *dbg = nullptr;
+    if (!dbg) (void)hipMalloc((void **)&dbg, sizeof(int) * 8 * (size_t)(2 * c->cfg.max_points));
+    if (phase == 0) (void)hipMemsetAsync(dbg, 0, sizeof(int) * 8 * (size_t)(n + n_new), c->stream);
+    a.dbg = dbg;
+    vo_frame_dbg_ptr = dbg;
+  }
+#endif
   a.Xp = d_X;
   a.pts_l0 = d_l0;
   a.pts_r0 = d_r0;

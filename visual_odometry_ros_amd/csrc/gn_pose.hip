@@ -269,37 +269,140 @@ __device__ void se3_exp_dev(const float (&xi)[6], float (&T)[16]) {
   T[15] = 1.0f;
 }
 
+// residual rows of one point (motion_estimator.cpp:733-800 mono, :935-1020 stereo)
+template <bool STEREO>
+__device__ __forceinline__ void gn_point(GnAcc &A, const GnArgs &a, const float (&R10)[9], const float (&t10)[3], float X0,
+                                         float X1, float X2, float plx, float ply, float prx, float pry, int i) {
+  const float THRES_HUBER = 0.5f;
+  const float fx_l = a.Kl[0], fy_l = a.Kl[1], cx_l = a.Kl[2], cy_l = a.Kl[3];
+  const float fx_r = a.Kr[0], fy_r = a.Kr[1], cx_r = a.Kr[2], cy_r = a.Kr[3];
+  const float thres = a.thres;
+  float Xl[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) Xl[r] = ((R10[r * 3 + 0] * X0 + R10[r * 3 + 1] * X1) + R10[r * 3 + 2] * X2) + t10[r];
+  float Jt[6];
+  if (STEREO) {
+    float Xr[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      Xr[r] = ((a.Rrl[r * 3 + 0] * Xl[0] + a.Rrl[r * 3 + 1] * Xl[1]) + a.Rrl[r * 3 + 2] * Xl[2]) + a.trl[r];
+    const float iz_l = 1.0f / Xl[2];
+    const float xiz_l = Xl[0] * iz_l, yiz_l = Xl[1] * iz_l;
+    const float fxxiz_l = fx_l * xiz_l, fyyiz_l = fy_l * yiz_l;
+    const float rx_l = (fxxiz_l + cx_l) - plx, ry_l = (fyyiz_l + cy_l) - ply;
+    const float iz_r = 1.0f / Xr[2];
+    const float xiz_r = Xr[0] * iz_r, yiz_r = Xr[1] * iz_r;
+    const float fxxiz_r = fx_r * xiz_r, fyyiz_r = fy_r * yiz_r;
+    const float rx_r = (fxxiz_r + cx_r) - prx, ry_r = (fyyiz_r + cy_r) - pry;
+    float weight = 1.0f;
+    float absrxry = ((fabsf(rx_l) + fabsf(ry_l)) + fabsf(rx_r)) + fabsf(ry_r);
+    absrxry *= 0.5f;
+    if (absrxry >= THRES_HUBER) weight = THRES_HUBER / absrxry;
+    const bool outl = absrxry >= thres;
+    a.mask[i] = outl ? 0 : 1;
+    if (outl) A.cnt += 1.0f;
+    jac_x(Jt, fx_l, iz_l, fxxiz_l, xiz_l, yiz_l);
+    acc_row_x<true>(A, weight, Jt);
+    acc_g_x(A, weight * rx_l, Jt);
+    A.err += rx_l * rx_l;
+    jac_y(Jt, fy_l, iz_l, fyyiz_l, xiz_l, yiz_l);
+    acc_row_y<true>(A, weight, Jt);
+    acc_g_y(A, weight * ry_l, Jt);
+    A.err += ry_l * ry_l;
+    jac_x(Jt, fx_r, iz_r, fxxiz_r, xiz_r, yiz_r);
+    acc_row_x<true>(A, weight, Jt);
+    acc_g_x(A, weight * rx_r, Jt);
+    A.err += rx_r * rx_r;
+    jac_y(Jt, fy_r, iz_r, fyyiz_r, xiz_r, yiz_r);
+    acc_row_y<true>(A, weight, Jt);
+    acc_g_y(A, weight * ry_r, Jt);
+    A.err += ry_r * ry_r;
+  } else {
+    const float iz = 1.0f / Xl[2];
+    const float xiz = Xl[0] * iz, yiz = Xl[1] * iz;
+    const float fxxiz = fx_l * xiz, fyyiz = fy_l * yiz;
+    const float rx = (fxxiz + cx_l) - plx, ry = (fyyiz + cy_l) - ply;
+    float weight = 1.0f;
+    bool flag_weight = false;
+    const float absrxry = fabsf(rx) + fabsf(ry);
+    if (absrxry >= THRES_HUBER) {
+      weight = THRES_HUBER / absrxry;
+      flag_weight = true;
+    }
+    const bool outl = absrxry >= thres;
+    a.mask[i] = outl ? 0 : 1;
+    if (outl) A.cnt += 1.0f;
+    jac_x(Jt, fx_l, iz, fxxiz, xiz, yiz);
+    if (flag_weight) {
+      acc_row_x<true>(A, weight, Jt);
+      acc_g_x(A, weight * rx, Jt);
+    } else {
+      acc_row_x<false>(A, 1.0f, Jt);
+      acc_g_x(A, rx, Jt);
+    }
+    A.err += rx * rx;
+    jac_y(Jt, fy_l, iz, fyyiz, xiz, yiz);
+    if (flag_weight) {
+      const float w_ry = weight * ry;
+      acc_row_y<true>(A, weight, Jt);
+      acc_g_y(A, w_ry, Jt);
+      if (a.variant == VO_GN_VARIANT_CORE)
+        A.err += w_ry * ry;
+      else
+        A.err += ry * ry;
+    } else {
+      acc_row_y<false>(A, 1.0f, Jt);
+      acc_g_y(A, ry, Jt);
+      A.err += ry * ry;
+    }
+  }
+}
+
+#define GN_PC 4  // points per thread kept in registers across the iterations (n <= GN_PC * GN_T: no reloads)
+
 template <bool STEREO>
 __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
-  __shared__ float s_T10[16];
-  __shared__ float s_part[GN_NW][32];
+  // thread partials, transposed: s_red[k][t]; wavefront w then reduces sums 4w .. 4w+3
+  __shared__ float s_red[GN_NACC * GN_T];
   __shared__ float s_tot[32];
+  __shared__ float s_T10[16];
   __shared__ int s_stop;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int n = a.d_n ? *a.d_n : a.n;
-  if (tid < 16) s_T10[tid] = a.d_T10 ? a.d_T10[tid] : a.T10[tid];
-  if (tid == 0) s_stop = 0;
+  float T10[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) T10[k] = a.d_T10 ? a.d_T10[k] : a.T10[k];
 
-  const float THRES_HUBER = 0.5f;
-  const float fx_l = a.Kl[0], fy_l = a.Kl[1], cx_l = a.Kl[2], cy_l = a.Kl[3];
-  const float fx_r = a.Kr[0], fy_r = a.Kr[1], cx_r = a.Kr[2], cy_r = a.Kr[3];
-  const float thres = a.thres;
+  // the first GN_PC points of this thread stay in registers
+  float cX[GN_PC][3], cP1[GN_PC][2], cP2[GN_PC][2];
+#pragma unroll
+  for (int q = 0; q < GN_PC; ++q) {
+    const int i = tid + q * GN_T;
+    const int ii = i < n ? i : 0;
+    const bool ok = n > 0;
+    cX[q][0] = ok ? a.X[3 * ii] : 0.f;
+    cX[q][1] = ok ? a.X[3 * ii + 1] : 0.f;
+    cX[q][2] = ok ? a.X[3 * ii + 2] : 0.f;
+    cP1[q][0] = ok ? a.p1[2 * ii] : 0.f;
+    cP1[q][1] = ok ? a.p1[2 * ii + 1] : 0.f;
+    cP2[q][0] = (STEREO && ok) ? a.p2[2 * ii] : 0.f;
+    cP2[q][1] = (STEREO && ok) ? a.p2[2 * ii + 1] : 0.f;
+  }
 
-  float err_prev = 1e10f;  // only lane 0 of wave 0 uses it
+  float err_prev = 1e10f;
   int iter = 0;
   float last_err = 0, last_derr = 0, last_dnorm = 0;
   int last_cnt = 0;
 
   for (iter = 0; iter < 100; ++iter) {
-    __syncthreads();
     float R10[9], t10[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) R10[i * 3 + j] = s_T10[i * 4 + j];
-      t10[i] = s_T10[i * 4 + 3];
+      for (int j = 0; j < 3; ++j) R10[i * 3 + j] = T10[i * 4 + j];
+      t10[i] = T10[i * 4 + 3];
     }
     GnAcc A;
 #pragma unroll
@@ -309,160 +412,105 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
     A.err = 0.0f;
     A.cnt = 0.0f;
 
-    for (int i = tid; i < n; i += GN_T) {
-      const float X0 = a.X[3 * i], X1 = a.X[3 * i + 1], X2 = a.X[3 * i + 2];
-      float Xl[3];
+    // thread t: points t, t + GN_T, ... in ascending order
 #pragma unroll
-      for (int r = 0; r < 3; ++r) Xl[r] = ((R10[r * 3 + 0] * X0 + R10[r * 3 + 1] * X1) + R10[r * 3 + 2] * X2) + t10[r];
-      const float plx = a.p1[2 * i], ply = a.p1[2 * i + 1];
-      float Jt[6];
-      if (STEREO) {
-        float Xr[3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-          Xr[r] = ((a.Rrl[r * 3 + 0] * Xl[0] + a.Rrl[r * 3 + 1] * Xl[1]) + a.Rrl[r * 3 + 2] * Xl[2]) + a.trl[r];
-        const float prx = a.p2[2 * i], pry = a.p2[2 * i + 1];
-        const float iz_l = 1.0f / Xl[2];
-        const float xiz_l = Xl[0] * iz_l, yiz_l = Xl[1] * iz_l;
-        const float fxxiz_l = fx_l * xiz_l, fyyiz_l = fy_l * yiz_l;
-        const float rx_l = (fxxiz_l + cx_l) - plx, ry_l = (fyyiz_l + cy_l) - ply;
-        const float iz_r = 1.0f / Xr[2];
-        const float xiz_r = Xr[0] * iz_r, yiz_r = Xr[1] * iz_r;
-        const float fxxiz_r = fx_r * xiz_r, fyyiz_r = fy_r * yiz_r;
-        const float rx_r = (fxxiz_r + cx_r) - prx, ry_r = (fyyiz_r + cy_r) - pry;
-        float weight = 1.0f;
-        float absrxry = ((fabsf(rx_l) + fabsf(ry_l)) + fabsf(rx_r)) + fabsf(ry_r);
-        absrxry *= 0.5f;
-        if (absrxry >= THRES_HUBER) weight = THRES_HUBER / absrxry;
-        const bool outl = absrxry >= thres;
-        a.mask[i] = outl ? 0 : 1;
-        if (outl) A.cnt += 1.0f;
-        jac_x(Jt, fx_l, iz_l, fxxiz_l, xiz_l, yiz_l);
-        acc_row_x<true>(A, weight, Jt);
-        acc_g_x(A, weight * rx_l, Jt);
-        A.err += rx_l * rx_l;
-        jac_y(Jt, fy_l, iz_l, fyyiz_l, xiz_l, yiz_l);
-        acc_row_y<true>(A, weight, Jt);
-        acc_g_y(A, weight * ry_l, Jt);
-        A.err += ry_l * ry_l;
-        jac_x(Jt, fx_r, iz_r, fxxiz_r, xiz_r, yiz_r);
-        acc_row_x<true>(A, weight, Jt);
-        acc_g_x(A, weight * rx_r, Jt);
-        A.err += rx_r * rx_r;
-        jac_y(Jt, fy_r, iz_r, fyyiz_r, xiz_r, yiz_r);
-        acc_row_y<true>(A, weight, Jt);
-        acc_g_y(A, weight * ry_r, Jt);
-        A.err += ry_r * ry_r;
-      } else {
-        const float iz = 1.0f / Xl[2];
-        const float xiz = Xl[0] * iz, yiz = Xl[1] * iz;
-        const float fxxiz = fx_l * xiz, fyyiz = fy_l * yiz;
-        const float rx = (fxxiz + cx_l) - plx, ry = (fyyiz + cy_l) - ply;
-        float weight = 1.0f;
-        bool flag_weight = false;
-        const float absrxry = fabsf(rx) + fabsf(ry);
-        if (absrxry >= THRES_HUBER) {
-          weight = THRES_HUBER / absrxry;
-          flag_weight = true;
-        }
-        const bool outl = absrxry >= thres;
-        a.mask[i] = outl ? 0 : 1;
-        if (outl) A.cnt += 1.0f;
-        jac_x(Jt, fx_l, iz, fxxiz, xiz, yiz);
-        if (flag_weight) {
-          acc_row_x<true>(A, weight, Jt);
-          acc_g_x(A, weight * rx, Jt);
-        } else {
-          acc_row_x<false>(A, 1.0f, Jt);
-          acc_g_x(A, rx, Jt);
-        }
-        A.err += rx * rx;
-        jac_y(Jt, fy_l, iz, fyyiz, xiz, yiz);
-        if (flag_weight) {
-          const float w_ry = weight * ry;
-          acc_row_y<true>(A, weight, Jt);
-          acc_g_y(A, w_ry, Jt);
-          if (a.variant == VO_GN_VARIANT_CORE)
-            A.err += w_ry * ry;
-          else
-            A.err += ry * ry;
-        } else {
-          acc_row_y<false>(A, 1.0f, Jt);
-          acc_g_y(A, ry, Jt);
-          A.err += ry * ry;
-        }
-      }
+    for (int q = 0; q < GN_PC; ++q) {
+      const int i = tid + q * GN_T;
+      if (i < n)
+        gn_point<STEREO>(A, a, R10, t10, cX[q][0], cX[q][1], cX[q][2], cP1[q][0], cP1[q][1], cP2[q][0], cP2[q][1], i);
     }
+    for (int i = tid + GN_PC * GN_T; i < n; i += GN_T)
+      gn_point<STEREO>(A, a, R10, t10, a.X[3 * i], a.X[3 * i + 1], a.X[3 * i + 2], a.p1[2 * i], a.p1[2 * i + 1],
+                       STEREO ? a.p2[2 * i] : 0.f, STEREO ? a.p2[2 * i + 1] : 0.f, i);
 
-    // wavefront butterflies (four interleaved chains at a time), then one LDS row per wave
+    // ---- reduction: balanced binary tree over the GN_T thread partials in natural order ----
+    // transposed through LDS so that a lane adds 8 neighbouring partials (three tree levels) and
+    // ONE 4-way DPP butterfly per wavefront finishes the other six, instead of eight butterflies
     {
-      float r[32];
 #pragma unroll
-      for (int k = 0; k < 21; ++k) r[k] = A.H[k];
+      for (int k = 0; k < 21; ++k) s_red[k * GN_T + tid] = A.H[k];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) r[21 + k] = A.g[k];
-      r[27] = A.err;
-      r[28] = A.cnt;
-      r[29] = r[30] = r[31] = 0.0f;
+      for (int k = 0; k < 6; ++k) s_red[(21 + k) * GN_T + tid] = A.g[k];
+      s_red[27 * GN_T + tid] = A.err;
+      s_red[28 * GN_T + tid] = A.cnt;
+    }
+    __syncthreads();
+    {
+      float v[4];
 #pragma unroll
-      for (int k = 0; k < 32; k += 4) {
-        if (k >= GN_NACC) break;
-        wave_sum4_f32(r[k], r[k + 1], r[k + 2], r[k + 3]);
+      for (int c = 0; c < 4; ++c) {
+        const int k = 4 * wave + c;
+        if (k < GN_NACC) {
+          const float4 lo = *(const float4 *)&s_red[k * GN_T + 8 * lane];
+          const float4 hi = *(const float4 *)&s_red[k * GN_T + 8 * lane + 4];
+          v[c] = ((lo.x + lo.y) + (lo.z + lo.w)) + ((hi.x + hi.y) + (hi.z + hi.w));
+        } else {
+          v[c] = 0.0f;
+        }
       }
+      wave_sum4_f32(v[0], v[1], v[2], v[3]);
       if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < GN_NACC; ++k) s_part[wave][k] = r[k];
+        for (int c = 0; c < 4; ++c) s_tot[4 * wave + c] = v[c];
       }
     }
     __syncthreads();
+    // ---- wavefront 0 (all lanes alike): damped normal equations, LDLT, pose update, stop test.
+    // The ~1600-instruction solve is issue-bound; run by every wavefront it would compete with
+    // itself for the four SIMDs of the CU.
     if (wave == 0) {
-      if (lane < GN_NACC) {
-        float p[GN_NW];
+      float tot[GN_NACC];
 #pragma unroll
-        for (int w = 0; w < GN_NW; ++w) p[w] = s_part[w][lane];
-#pragma unroll
-        for (int st = 1; st < GN_NW; st <<= 1)
-#pragma unroll
-          for (int w = 0; w < GN_NW; w += 2 * st) p[w] = p[w] + p[w + st];
-        s_tot[lane] = p[0];
-      }
-    }
-    __syncthreads();
-    if (tid == 0) {
+      for (int k = 0; k < GN_NACC; ++k) tot[k] = s_tot[k];
       float JtWJ[36], g[6], dxi[6];
+#pragma unroll
       for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < 6; ++j) JtWJ[i * 6 + j] = s_tot[i <= j ? ut(i, j) : ut(j, i)];
-      for (int k = 0; k < 6; ++k) g[k] = s_tot[21 + k];
-      float err_curr = s_tot[27];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) JtWJ[i * 6 + j] = tot[i <= j ? ut(i, j) : ut(j, i)];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) g[k] = tot[21 + k];
+      float err_curr = tot[27];
       const float inv_npts = 1.0f / (float)n;
       err_curr *= (inv_npts * 0.5f);
       if (STEREO) err_curr = sqrtf(err_curr);
       const float delta_err = fabsf(err_curr - err_prev);
       const float lambda = 0.00001f;
+#pragma unroll
       for (int k = 0; k < 6; ++k) JtWJ[k * 6 + k] *= (1.0f + lambda);
       ldlt6_solve(JtWJ, g, dxi);
       float dT[16], Tn[16];
       se3_exp_dev(dxi, dT);
+#pragma unroll
       for (int i = 0; i < 4; ++i)
+#pragma unroll
         for (int j = 0; j < 4; ++j) {
-          float s = dT[i * 4 + 0] * s_T10[0 * 4 + j];
-          s += dT[i * 4 + 1] * s_T10[1 * 4 + j];
-          s += dT[i * 4 + 2] * s_T10[2 * 4 + j];
-          s += dT[i * 4 + 3] * s_T10[3 * 4 + j];
+          float s = dT[i * 4 + 0] * T10[0 * 4 + j];
+          s += dT[i * 4 + 1] * T10[1 * 4 + j];
+          s += dT[i * 4 + 2] * T10[2 * 4 + j];
+          s += dT[i * 4 + 3] * T10[3 * 4 + j];
           Tn[i * 4 + j] = s;
         }
-      for (int i = 0; i < 16; ++i) s_T10[i] = Tn[i];
       err_prev = err_curr;
       float s2 = 0.0f;
+#pragma unroll
       for (int k = 0; k < 6; ++k) s2 += dxi[k] * dxi[k];
       const float dnorm = sqrtf(s2);
       last_err = err_curr;
       last_derr = delta_err;
       last_dnorm = dnorm;
-      last_cnt = (int)s_tot[28];
-      if (dnorm < (float)1e-6 || delta_err < (float)1e-7) s_stop = 1;
+      last_cnt = (int)tot[28];
+      const bool stop = dnorm < (float)1e-6 || delta_err < (float)1e-7;
+      if (lane < 16) {
+        float tv = Tn[0];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) tv = lane == k ? Tn[k] : tv;
+        s_T10[lane] = tv;
+      }
+      if (lane == 0) s_stop = stop ? 1 : 0;
     }
     __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) T10[k] = s_T10[k];
     if (s_stop) {
       ++iter;
       break;

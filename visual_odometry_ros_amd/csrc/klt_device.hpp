@@ -32,6 +32,21 @@ struct KltCfg {
 
 __device__ __forceinline__ int descale_dev(int x, int n) { return (x + (1 << (n - 1))) >> n; }
 
+// a*w00 + b*w01 + c*w10 + d*w11 (+ acc) for |a..d| <= 4080 and weights in [-1, 2^14]: every operand
+// fits the signed 24-bit multiplier. Written as v_mad_i32_i24 (full rate, multiply and add in one
+// instruction); left to the compiler these become quarter-rate v_mul_lo_u32 plus separate adds.
+__device__ __forceinline__ int klt_mad24(int a, int b, int c) {
+  int d;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ int klt_dot4(int a, int b, int c, int d, int w00, int w01, int w10, int w11, int acc) {
+  return klt_mad24(d, w11, klt_mad24(c, w10, klt_mad24(b, w01, klt_mad24(a, w00, acc))));
+}
+__device__ __forceinline__ int klt_descale_dot4(int a, int b, int c, int d, int w00, int w01, int w10, int w11, int n) {
+  return klt_dot4(a, b, c, d, w00, w01, w10, w11, 1 << (n - 1)) >> n;
+}
+
 // byte k of a little-endian dword array starting at byte offset `sh` (0..3) of w[0]
 template <int ND>
 __device__ __forceinline__ void align_row(const uint32_t (&w)[ND], int sh, uint32_t (&out)[ND - 1]) {
@@ -51,6 +66,9 @@ struct KltResult {
   float x, y;  // nextPts
   int status;
   float err;
+#ifdef FRAME_STAMP
+  int iters;   // diagnostic: iterations over all levels
+#endif
 };
 
 // One point of cv::calcOpticalFlowPyrLK on one wavefront (all 64 lanes must call it together).
@@ -71,6 +89,9 @@ __device__ __forceinline__ KltResult klt_point(const vo_level *I, const vo_level
   const float halfWin = (WIN - 1) * 0.5f;
   const float FLT_SCALE = 1.f / (1 << 20);
   float npx = ix, npy = iy;  // "nextPts[ptidx]"
+#ifdef FRAME_STAMP
+  int dbg_iters = 0;
+#endif
   int status = 1;
   float errv = 0.f;
 
@@ -167,9 +188,9 @@ __device__ __forceinline__ KltResult klt_point(const vo_level *I, const vo_level
       for (int j = 0; j < RL; ++j) {
         const int i00 = byte_at(rb[1], j + 1), i01 = byte_at(rb[1], j + 2);
         const int i10 = byte_at(rb[2], j + 1), i11 = byte_at(rb[2], j + 2);
-        const int ival = descale_dev(i00 * iw00 + i01 * iw01 + i10 * iw10 + i11 * iw11, KLT_W_BITS - 5);
-        const int ixval = descale_dev(dxv[0][j] * iw00 + dxv[0][j + 1] * iw01 + dxv[1][j] * iw10 + dxv[1][j + 1] * iw11, KLT_W_BITS);
-        const int iyval = descale_dev(dyv[0][j] * iw00 + dyv[0][j + 1] * iw01 + dyv[1][j] * iw10 + dyv[1][j + 1] * iw11, KLT_W_BITS);
+        const int ival = klt_descale_dot4(i00, i01, i10, i11, iw00, iw01, iw10, iw11, KLT_W_BITS - 5);
+        const int ixval = klt_descale_dot4(dxv[0][j], dxv[0][j + 1], dxv[1][j], dxv[1][j + 1], iw00, iw01, iw10, iw11, KLT_W_BITS);
+        const int iyval = klt_descale_dot4(dyv[0][j], dyv[0][j + 1], dyv[1][j], dyv[1][j + 1], iw00, iw01, iw10, iw11, KLT_W_BITS);
         const bool on = j < nx;
         tI[j] = (int)(short)ival;
         tX[j] = on ? (int)(short)ixval : 0;
@@ -230,14 +251,16 @@ __device__ __forceinline__ KltResult klt_point(const vo_level *I, const vo_level
       }
 #pragma unroll
       for (int j = 0; j < RL; ++j) {
-        const int v = descale_dev(byte_at(r0, j) * w00 + byte_at(r0, j + 1) * w01 + byte_at(r1, j) * w10 +
-                                      byte_at(r1, j + 1) * w11,
-                                  KLT_W_BITS - 5);
+        const int v = klt_descale_dot4(byte_at(r0, j), byte_at(r0, j + 1), byte_at(r1, j), byte_at(r1, j + 1), w00, w01, w10,
+                                       w11, KLT_W_BITS - 5);
         diff[j] = v - tI[j];
       }
     };
 
     for (int j = 0; j < max_count; ++j) {
+#ifdef FRAME_STAMP
+      ++dbg_iters;
+#endif
       const int inx = __builtin_amdgcn_readfirstlane((int)floorf(nextx));
       const int iny = __builtin_amdgcn_readfirstlane((int)floorf(nexty));
       if (inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h) {
@@ -305,6 +328,9 @@ __device__ __forceinline__ KltResult klt_point(const vo_level *I, const vo_level
   res.y = npy;
   res.status = status;
   res.err = errv;
+#ifdef FRAME_STAMP
+  res.iters = dbg_iters;
+#endif
   return res;
 }
 
