@@ -38,6 +38,18 @@ def klt_bytes_per_point_level(win):
     return (win + 2) ** 2 + (win + 1) ** 2
 
 
+IC_BYTES_PER_POINT = 27 * 32 + 40 * 44          # u8 template tile (Sobel halo) + u8 search tile
+IC_RECORD_BYTES = (3 + 1) * 264 * 4 + 2 * 9 * 4  # strict border: tap values + tap masks written per feature
+POINT_IO_BYTES = 64                              # landmark, pixels, priors in; pixels, stage out
+
+
+def frame_kernel_bytes(win, n, n_l0l1, n_step5, n_new, levels, levels_bwd, strict):
+    """Algorithmic bytes of ONE frame_track_kernel launch (kernel table): the tiles every
+    feature has to see once per pyramid level and pass, the IC tiles, the tap records."""
+    klt = klt_bytes_per_point_level(win) * ((n + n_step5) * levels + n_new * (levels + levels_bwd))
+    return klt + IC_BYTES_PER_POINT * n_l0l1 + (IC_RECORD_BYTES * n if strict else 0) + POINT_IO_BYTES * (n + n_new)
+
+
 def aggregate(frames, seconds, world, device=None):
     """Whole-job totals: every rank ran `frames` frames of its own stream in `seconds`.
     One all_gather of {frames, seconds} (RCCL on GPUs, gloo in the CPU test): 16 B per rank.
@@ -153,7 +165,7 @@ def main():
         step(s)
     K = args.steps
     ctx.profile_enable(K * 4 + 64)
-    ctx.profile_set_classes(1 << 1)  # event-bracket only the dominant kernel class (klt_track)
+    ctx.profile_set_classes(1 << 1)  # event-bracket only the dominant kernel (frame_track_kernel)
     ctx.profile_reset()
     klt_alg_bytes = 0
     results = []
@@ -166,8 +178,9 @@ def main():
     t0 = time.perf_counter()
     for s in range(args.warmup, args.warmup + K):
         r = step(s, results if len(results) < args.cpu_frames else None)
-        klt_alg_bytes += klt_bytes_per_point_level(WIN) * (
-            (n_pts + r["counts"].n_refine) * eff_levels + N_NEW * (eff_levels + eff_levels_bwd))
+        cts = r["counts"]  # features finished by the replay kernel do their step [5] there
+        klt_alg_bytes += frame_kernel_bytes(WIN, n_pts, cts.n_l0l1, cts.n_refine - cts.n_replayed, N_NEW, eff_levels,
+                                            eff_levels_bwd, bool(args.strict_border))
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
@@ -176,7 +189,7 @@ def main():
 
     out = None
     if rank == 0:
-        names = {0: "pyramid", 1: "klt_track", 2: "ic_refine", 3: "gn_pose", 4: "hamming", 5: "aux"}
+        names = {0: "pyramid", 1: "frame_track", 2: "ic_replay", 3: "gn_pose", 4: "hamming", 5: "aux"}
         per_kernel = {}
         for cls, nm in names.items():
             n_l, ms = ctx.profile_get(cls)
@@ -185,7 +198,7 @@ def main():
         klt_n, klt_ms = ctx.profile_get(1)
         achieved = (klt_alg_bytes / max(klt_n, 1)) / (klt_ms / max(klt_n, 1) * 1e-3) / 1e9 if klt_n else 0.0
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_klt_pmc.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r01_frame_pmc.json")
         if os.path.exists(pmc_path):
             try:
                 traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
@@ -214,7 +227,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "klt_track_kernel<21>",
+                "kernel": "frame_track_kernel<21>",
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -231,6 +244,7 @@ def main():
             prm_o = O.make_stereo_params(W_, H_, WIN, MAX_LEVEL, THRES_ERR, THRES_BIDIR, THRES_POSEBA, stream.K,
                                          stream.K, stream.T_lr)
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            cores = min(cores, 16)  # the box's CPU share for one GPU; 1500 points do not feed more threads
             border = O.IC_REFERENCE if args.strict_border else O.IC_MASKED
             worst, stage_equal = 0.0, True
             tcpu = 0.0

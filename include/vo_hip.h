@@ -188,6 +188,7 @@ typedef struct {
 typedef struct {
   int n_l0l1, n_refine, n_l1r1, n_inlier, n_new_ok;
   int gn_iterations;
+  int n_replayed; /* strict border: features whose refinement was replayed (their IC window left the image) */
 } vo_frame_counts;
 
 /* strict != 0: the frame's trackWithScale step replays border-touching points

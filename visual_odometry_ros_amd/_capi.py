@@ -36,7 +36,8 @@ class StereoParams(C.Structure):
 
 class FrameCounts(C.Structure):
     _fields_ = [("n_l0l1", C.c_int), ("n_refine", C.c_int), ("n_l1r1", C.c_int),
-                ("n_inlier", C.c_int), ("n_new_ok", C.c_int), ("gn_iterations", C.c_int)]
+                ("n_inlier", C.c_int), ("n_new_ok", C.c_int), ("gn_iterations", C.c_int),
+                ("n_replayed", C.c_int)]
 
 
 # every symbol include/vo_hip.h declares (checked by tests/test_abi.py)

@@ -350,7 +350,10 @@ __global__ __launch_bounds__(1024) void frame_finish_kernel(FinishArgs a) {
   }
   if (tid < 3) a.cnt[tid] = s_base[tid];
   // every producer / consumer of the control block ran before this kernel: report, then reset
-  if (tid == 0) *a.hdr_flags = a.ctl[0];
+  if (tid == 0) {
+    *a.hdr_flags = a.ctl[0];
+    a.cnt[3] = a.ctl[16 + IC_JAC_NT];  // features the strict-border pass replayed (0 when it is off)
+  }
   __syncthreads();
   for (int k = tid; k < a.ctl_words; k += 1024) a.ctl[k] = 0;
 }

@@ -30,7 +30,7 @@ static double vo_tt_last; static int vo_tt_n;
 
 // header of the packed result block (device and pinned-host copies share the layout)
 struct vo_frame_hdr {
-  int cnt[8];  // [0]=nA [1]=nB [2]=nC [3]=n_inlier [4]=n_new_ok
+  int cnt[8];  // [0]=nA [1]=nB [2]=nC [3]=features replayed by the strict-border pass
   vo_gn_dev_info gn;
   int flags;
   int pad_[1];
@@ -374,6 +374,7 @@ extern "C" int vo_stereo_frame_result(vo_ctx *c, float *pts_l1, float *pts_r1, u
     counts->n_inlier = ninl;
     counts->n_new_ok = nnew;
     counts->gn_iterations = h->gn.iterations;
+    counts->n_replayed = h->cnt[3];
   }
   if (gn) {
     gn->iterations = h->gn.iterations;
