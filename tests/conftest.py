@@ -32,3 +32,11 @@ def ctx(vo):
     c = vo.Context(device=0, max_width=1241, max_height=480, max_points=8192, n_slots=4, max_level=6)
     yield c
     c.close()
+
+
+@pytest.fixture(scope="module")
+def ctx5(vo):
+    """BASELINE configs[4]-sized context: 3840x2160 images, 8000+ features."""
+    c = vo.Context(device=0, max_width=3840, max_height=2160, max_points=8448, n_slots=3, max_level=4)
+    yield c
+    c.close()

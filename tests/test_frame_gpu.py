@@ -14,7 +14,7 @@ def rel_frob(A, B):
     return np.linalg.norm(np.asarray(A, np.float64) - np.asarray(B, np.float64)) / np.linalg.norm(B)
 
 
-def _run_stream(ctx, oracle, stream, n_frames, strict, win=21, max_level=6):
+def _run_stream(ctx, oracle, stream, n_frames, strict, win=21, max_level=6, sanity=True):
     prm_g = make_stereo_params(stream.width, stream.height, win, max_level, 80.0, 0.5, 3.0, stream.K, stream.K,
                                stream.T_lr)
     prm_o = oracle.make_stereo_params(stream.width, stream.height, win, max_level, 80.0, 0.5, 3.0, stream.K,
@@ -53,8 +53,9 @@ def _run_stream(ctx, oracle, stream, n_frames, strict, win=21, max_level=6):
         assert rel_frob(g["dT"], os_["dT"]) < 1e-4
         assert np.array_equal(g["stage"], os_["stage"])
         # and the estimate is a sane odometry result
-        assert rel_frob(g["dT"], ts["dT_true"]) < 5e-3
-        assert g["counts"].n_inlier > 0.5 * ts["pts_l0"].shape[0]
+        if sanity:
+            assert rel_frob(g["dT"], ts["dT_true"]) < 5e-3
+            assert g["counts"].n_inlier > 0.5 * ts["pts_l0"].shape[0]
         ctx.swap_slots(0, 1)  # current left becomes previous left
         Lp = L
     return worst
@@ -70,6 +71,25 @@ def test_stereo_frame_small_many_frames(ctx, oracle):
     K = tuple(v * 0.5 for v in S.KITTI_K)
     stream = S.StereoStream(width=620, height=188, K=K, n_u=30, n_v=12, n_new=40, seed=5, margin=14.0)
     _run_stream(ctx, oracle, stream, 6, False, win=15, max_level=4)
+
+
+@pytest.mark.parametrize("win,strict", [(31, True), (17, True), (17, False), (15, True)])
+def test_stereo_frame_other_windows(ctx, oracle, win, strict):
+    """win 15 / 31: the other instantiations of the fused frame kernel; win 17: the general
+    one-launch-per-step path (windows the fused kernel is not instantiated for)."""
+    K = tuple(v * 0.5 for v in S.KITTI_K)
+    stream = S.StereoStream(width=620, height=188, K=K, n_u=30, n_v=12, n_new=40, seed=11 + win,
+                            margin=5.0 if strict else 14.0)
+    _run_stream(ctx, oracle, stream, 3, strict, win=win, max_level=4)
+
+
+def test_stereo_frame_config5_shape(ctx5, oracle):
+    """BASELINE configs[4]: 3840x2160, 8000 features, 5-level pyramid (max_level 4), strict border
+    (more touched features than replay workgroups: every workgroup owns several)."""
+    K = tuple(v * 3.0 for v in S.KITTI_K[:2]) + (1920.0, 1080.0)
+    stream = S.StereoStream(width=3840, height=2160, K=K, n_u=100, n_v=80, n_new=200, seed=3, margin=5.0)
+    # (3x the KITTI focal length at the same speed: flows of ~60 px, many features are lost; parity only)
+    _run_stream(ctx5, oracle, stream, 2, True, win=21, max_level=4, sanity=False)
 
 
 def test_stereo_frame_empty_sets(ctx, oracle):
