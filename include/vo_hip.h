@@ -160,6 +160,15 @@ int vo_gn_pose_stereo(vo_ctx *ctx, const float *X, const float *pts_l1, const fl
                       float thres_reproj_outlier, float T01[16], uint8_t *mask_inlier,
                       vo_gn_info *info);
 
+/* Epipolar gates. MotionEstimator::calcSampsonDistance(pts0, pts1, F10, out)
+ * (motion_estimator.cpp:572-599) and calcSymmetricEpipolarDistance (:621-653, its per-point part):
+ * F10 row-major 3x3. The camera/pose overloads (:538-570) build F10 = Kinv^T [t10]x R10 Kinv on the
+ * host and call these. */
+int vo_sampson_distance(vo_ctx *ctx, const float *pts0, const float *pts1, int n, const float F10[9],
+                        float *dist);
+int vo_symmetric_epipolar_distance(vo_ctx *ctx, const float *pts0, const float *pts1, int n,
+                                   const float F10[9], float *dist);
+
 /* ---- FeatureExtractor::descriptorDistance (feature_extractor.cpp:338-357) - */
 /* all-pairs 256-bit Hamming distance, dist is na x nb row-major */
 int vo_orb_hamming(vo_ctx *ctx, const uint8_t *a, int na, const uint8_t *b, int nb,

@@ -245,6 +245,27 @@ def calc_prior(pts0, Xw, Tw1, K):
     return out
 
 
+def sampson_distance(pts0, pts1, F10):
+    pts0, pts1, F = _f32(pts0).reshape(-1, 2), _f32(pts1).reshape(-1, 2), _f32(F10).reshape(9)
+    out = np.zeros(max(pts0.shape[0], 1), np.float32)
+    lib().vo_ref_sampson_distance(_p(pts0), _p(pts1), pts0.shape[0], _p(F), _p(out))
+    return out[:pts0.shape[0]]
+
+
+def symmetric_epipolar_distance(pts0, pts1, F10):
+    pts0, pts1, F = _f32(pts0).reshape(-1, 2), _f32(pts1).reshape(-1, 2), _f32(F10).reshape(9)
+    out = np.zeros(max(pts0.shape[0], 1), np.float32)
+    lib().vo_ref_symmetric_epipolar_distance(_p(pts0), _p(pts1), pts0.shape[0], _p(F), _p(out))
+    return out[:pts0.shape[0]]
+
+
+def fundamental_from_pose(K, R10, t10):
+    K, R, t = _f32(K).reshape(4), _f32(R10).reshape(9), _f32(t10).reshape(3)
+    F = np.zeros(9, np.float32)
+    lib().vo_ref_fundamental_from_pose(_p(K), _p(R), _p(t), _p(F))
+    return F.reshape(3, 3)
+
+
 def track_with_scale(img0, img1, pts0, scale, pts_track, mask=None, border_mode=IC_REFERENCE,
                      sum_mode=SUM_SEQ):
     img0, w, h, st = _img(img0)

@@ -270,3 +270,53 @@ fail:
   free(as);
   return rc;
 }
+
+/* ---- epipolar gates ---------------------------------------------------
+ * MotionEstimator::calcSampsonDistance (core/visual_odometry/motion_estimator.cpp:572-599) and
+ * calcSymmetricEpipolarDistance (:621-653), the per-point part on a given F10 (row-major).
+ * Eigen evaluates the 3x3 * 3x1 products and the 1x3 * 3x1 dot coefficient-wise as an unrolled
+ * 3-term redux, which associates as e0 + (e1 + e2); the hand-written sums are left to right. */
+static inline float eig_dot3(float a0, float b0, float a1, float b1, float a2, float b2) {
+  return a0 * b0 + (a1 * b1 + a2 * b2);
+}
+static void epi_terms(const float *F, float x0, float y0, float x1, float y1, float *Fp0, float *Ftp1, float *num) {
+  for (int i = 0; i < 3; ++i) Fp0[i] = eig_dot3(F[i * 3 + 0], x0, F[i * 3 + 1], y0, F[i * 3 + 2], 1.0f);
+  for (int i = 0; i < 3; ++i) Ftp1[i] = eig_dot3(F[0 * 3 + i], x1, F[1 * 3 + i], y1, F[2 * 3 + i], 1.0f);
+  *num = eig_dot3(x1, Fp0[0], y1, Fp0[1], 1.0f, Fp0[2]);
+}
+void vo_ref_sampson_distance(const float *pts0, const float *pts1, int n, const float F10[9], float *dist) {
+  for (int i = 0; i < n; ++i) {
+    float a[3], b[3], num;
+    epi_terms(F10, pts0[2 * i], pts0[2 * i + 1], pts1[2 * i], pts1[2 * i + 1], a, b, &num);
+    num *= num;
+    const float den = ((a[0] * a[0] + a[1] * a[1]) + b[0] * b[0]) + b[1] * b[1];
+    dist[i] = num / den;
+  }
+}
+void vo_ref_symmetric_epipolar_distance(const float *pts0, const float *pts1, int n, const float F10[9],
+                                        float *dist) {
+  for (int i = 0; i < n; ++i) {
+    float a[3], b[3], num;
+    epi_terms(F10, pts0[2 * i], pts0[2 * i + 1], pts1[2 * i], pts1[2 * i + 1], a, b, &num);
+    num = fabsf(num);
+    const float den = 1.0f / sqrtf(a[0] * a[0] + a[1] * a[1]) + 1.0f / sqrtf(b[0] * b[0] + b[1] * b[1]);
+    dist[i] = num * den;
+  }
+}
+/* F10 = Kinv^T * (skew(t10) * R10) * Kinv (motion_estimator.cpp:551-552), 3x3 products as Eigen
+ * evaluates them (same 3-term redux); K = (fx, fy, cx, cy), Kinv as Camera::Kinv (camera.cpp) */
+static void mat3_mul(const float *A, const float *B, float *C) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      C[i * 3 + j] = eig_dot3(A[i * 3 + 0], B[0 * 3 + j], A[i * 3 + 1], B[1 * 3 + j], A[i * 3 + 2], B[2 * 3 + j]);
+}
+void vo_ref_fundamental_from_pose(const float K[4], const float R10[9], const float t10[3], float F10[9]) {
+  const float fxi = 1.0f / K[0], fyi = 1.0f / K[1];
+  const float Kinv[9] = {fxi, 0.0f, -K[2] * fxi, 0.0f, fyi, -K[3] * fyi, 0.0f, 0.0f, 1.0f};
+  const float KinvT[9] = {Kinv[0], Kinv[3], Kinv[6], Kinv[1], Kinv[4], Kinv[7], Kinv[2], Kinv[5], Kinv[8]};
+  const float S[9] = {0.0f, -t10[2], t10[1], t10[2], 0.0f, -t10[0], -t10[1], t10[0], 0.0f};
+  float E[9], T[9];
+  mat3_mul(S, R10, E);
+  mat3_mul(KinvT, E, T);
+  mat3_mul(T, Kinv, F10);
+}

@@ -69,3 +69,30 @@ def test_calc_prior(ctx, vo, oracle):
     out = ft.calcPrior(pts0, Xw, Tw1, K)
     ref = oracle.calc_prior(pts0, Xw, Tw1, K)
     assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("n", [1, 255, 256, 1500, 8000])
+def test_epipolar_distances_bit_exact(ctx, vo, oracle, n):
+    """calcSampsonDistance / calcSymmetricEpipolarDistance (motion_estimator.cpp:538-653) vs the oracle."""
+    rng = np.random.default_rng(n)
+    K = np.array([718.856, 718.856, 607.19, 185.2], np.float32)
+    ang = 0.015
+    R10 = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], np.float32)
+    t10 = np.array([0.05, -0.02, -0.8], np.float32)
+    pts0 = np.stack([rng.uniform(0, 1241, n), rng.uniform(0, 376, n)], 1).astype(np.float32)
+    pts1 = (pts0 + rng.normal(0, 4, (n, 2))).astype(np.float32)
+    me = vo.MotionEstimator(ctx)
+    F = me.fundamentalFromPose(K, R10, t10)
+    assert np.array_equal(F.view(np.uint32), oracle.fundamental_from_pose(K, R10, t10).view(np.uint32))
+    s_g = me.calcSampsonDistance(pts0, pts1, K=K, R10=R10, t10=t10)
+    e_g = me.calcSymmetricEpipolarDistance(pts0, pts1, K, R10, t10)
+    assert np.array_equal(s_g.view(np.uint32), oracle.sampson_distance(pts0, pts1, F).view(np.uint32))
+    assert np.array_equal(e_g.view(np.uint32), oracle.symmetric_epipolar_distance(pts0, pts1, F).view(np.uint32))
+    assert np.array_equal(me.calcSampsonDistance(pts0, pts1, F10=F).view(np.uint32), s_g.view(np.uint32))
+
+
+def test_epipolar_distance_errors(ctx, vo):
+    me = vo.MotionEstimator(ctx)
+    with pytest.raises(vo.VoError):
+        me.calcSampsonDistance(np.zeros((3, 2)), np.zeros((4, 2)), F10=np.eye(3))
+    assert me.calcSampsonDistance(np.zeros((0, 2)), np.zeros((0, 2)), F10=np.eye(3)).size == 0

@@ -191,3 +191,40 @@ def test_golden_fixtures_reproduce(oracle):
     assert np.array_equal(pt, k["ic_pts"]) and np.array_equal(m, k["ic_mask"])
     h = np.load(os.path.join(GOLD, "hamming.npz"))
     assert np.array_equal(oracle.hamming_matrix(h["a"], h["b"]), h["dist"])
+
+
+def test_epipolar_distances_vs_float64(oracle):
+    """Sampson / symmetric epipolar distance (motion_estimator.cpp:538-653) against a float64 numpy
+    restatement of the textbook formulas; exact correspondences have zero distance."""
+    rng = np.random.default_rng(11)
+    K = np.array([718.856, 718.856, 607.19, 185.2], np.float64)
+    Km = np.array([[K[0], 0, K[2]], [0, K[1], K[3]], [0, 0, 1]])
+    ang = 0.02
+    R10 = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    t10 = np.array([0.1, -0.02, -0.9])
+    X0 = np.stack([rng.uniform(-8, 8, 300), rng.uniform(-2, 2, 300), rng.uniform(5, 40, 300)], 1)
+    X1 = X0 @ R10.T + t10
+    p0 = (X0 / X0[:, 2:]) @ Km.T
+    p1 = (X1 / X1[:, 2:]) @ Km.T
+    noise = rng.normal(0, 1.5, (300, 2))
+    p1n = p1[:, :2] + noise
+    F = oracle.fundamental_from_pose(K, R10, t10)
+    S = np.array([[0, -t10[2], t10[1]], [t10[2], 0, -t10[0]], [-t10[1], t10[0], 0]])
+    F64 = np.linalg.inv(Km).T @ S @ R10 @ np.linalg.inv(Km)
+    assert np.allclose(F, F64, rtol=2e-4, atol=1e-9)
+
+    def ref(pa, pb):
+        a = np.c_[pa, np.ones(len(pa))] @ F64.T
+        b = np.c_[pb, np.ones(len(pb))] @ F64
+        num = np.abs(np.sum(np.c_[pb, np.ones(len(pb))] * a, 1))
+        samp = num ** 2 / (a[:, 0] ** 2 + a[:, 1] ** 2 + b[:, 0] ** 2 + b[:, 1] ** 2)
+        sym = num * (1 / np.hypot(a[:, 0], a[:, 1]) + 1 / np.hypot(b[:, 0], b[:, 1]))
+        return samp, sym
+    s_ref, e_ref = ref(p0[:, :2], p1n)
+    s_o = oracle.sampson_distance(p0[:, :2], p1n, F64)
+    e_o = oracle.symmetric_epipolar_distance(p0[:, :2], p1n, F64)
+    # float32 cancellation in p1^T F p0 (terms ~1e-3, result ~1e-6): percent-level on small distances
+    assert np.allclose(s_o, s_ref, rtol=2e-2, atol=2e-3)
+    assert np.allclose(e_o, e_ref, rtol=2e-2, atol=5e-3)
+    assert oracle.sampson_distance(p0[:, :2], p1[:, :2], F64).max() < 5e-3
+    assert oracle.sampson_distance(np.zeros((0, 2)), np.zeros((0, 2)), F64).size == 0

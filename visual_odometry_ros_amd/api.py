@@ -254,6 +254,46 @@ class MotionEstimator:
         return bool(rc), T.reshape(4, 4), mask[:n].astype(bool), info
 
 
+    # ---- epipolar gates (motion_estimator.cpp:538-653) ----
+    @staticmethod
+    def fundamentalFromPose(K, R10, t10):
+        """F10 = Kinv^T [t10]x R10 Kinv (motion_estimator.cpp:551-552) in float32, K = (fx, fy, cx, cy).
+        3x3 products associate as Eigen's unrolled redux does: e0 + (e1 + e2)."""
+        f = np.float32
+        K, R, t = _f32(K).reshape(4), _f32(R10).reshape(3, 3), _f32(t10).reshape(3)
+        fxi, fyi = f(1.0) / K[0], f(1.0) / K[1]
+        Kinv = np.array([[fxi, 0, -K[2] * fxi], [0, fyi, -K[3] * fyi], [0, 0, 1]], f)
+        S = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]], f)
+
+        def mul(A, B):
+            Cm = np.zeros((3, 3), f)
+            for i in range(3):
+                for j in range(3):
+                    Cm[i, j] = f(A[i, 0] * B[0, j]) + f(f(A[i, 1] * B[1, j]) + f(A[i, 2] * B[2, j]))
+            return Cm
+        return mul(mul(Kinv.T.copy(), mul(S, R)), Kinv)
+
+    def _epi(self, fn, pts0, pts1, F10):
+        pts0, pts1 = _f32(pts0).reshape(-1, 2), _f32(pts1).reshape(-1, 2)
+        if pts0.shape[0] != pts1.shape[0]:  # motion_estimator.cpp:541-542, :575-576, :625-626
+            raise VoError(-4, "pts0.size() != pts1.size()")
+        n = pts0.shape[0]
+        out = np.zeros(max(n, 1), np.float32)
+        if n:
+            self.ctx.check(fn(self.ctx.handle, _p(pts0), _p(pts1), n, _p(_f32(F10).reshape(9)), _p(out)))
+        return out[:n]
+
+    def calcSampsonDistance(self, pts0, pts1, F10=None, K=None, R10=None, t10=None):
+        """calcSampsonDistance(pts0, pts1, F10) (:572-599) or, with K/R10/t10, the camera overload (:538-570)."""
+        if F10 is None:
+            F10 = self.fundamentalFromPose(K, R10, t10)
+        return self._epi(self.lib.vo_sampson_distance, pts0, pts1, F10)
+
+    def calcSymmetricEpipolarDistance(self, pts0, pts1, K, R10, t10):
+        """motion_estimator.cpp:621-653"""
+        return self._epi(self.lib.vo_symmetric_epipolar_distance, pts0, pts1, self.fundamentalFromPose(K, R10, t10))
+
+
 class FeatureExtractor:
     """descriptorDistance (feature_extractor.cpp:338-357) for whole descriptor sets."""
 

@@ -59,6 +59,26 @@ class MotionEstimator {
     return rc == 1;
   }
 
+  // motion_estimator.cpp:572-599 (F10 overload; F10 row-major here, see reference_adapter.h for Eigen types)
+  void calcSampsonDistance(const PixelVec &pts0, const PixelVec &pts1, const Rot3 &F10, std::vector<float> &sampson_dist) {
+    if (pts0.size() != pts1.size())
+      throw std::runtime_error("Error in 'fineInliers1PointHistogram()': pts0.size() != pts1.size()");
+    sampson_dist.resize(pts0.size());
+    if (pts0.empty()) return;
+    ctx_->check(vo_sampson_distance(ctx_->get(), &pts0.data()->x, &pts1.data()->x, (int)pts0.size(), F10.data(),
+                                    sampson_dist.data()));
+  }
+  // motion_estimator.cpp:621-653 with F10 = Kinv^T [t10]x R10 Kinv computed by the caller (:636-638)
+  void calcSymmetricEpipolarDistance(const PixelVec &pts0, const PixelVec &pts1, const Rot3 &F10,
+                                     std::vector<float> &sym_epi_dist) {
+    if (pts0.size() != pts1.size())
+      throw std::runtime_error("In 'calcSymmetricEpipolarDistance()', pts0.size() != pts1.size()");
+    sym_epi_dist.resize(pts0.size());
+    if (pts0.empty()) return;
+    ctx_->check(vo_symmetric_epipolar_distance(ctx_->get(), &pts0.data()->x, &pts1.data()->x, (int)pts0.size(),
+                                               F10.data(), sym_epi_dist.data()));
+  }
+
   const vo_gn_info &lastInfo() const { return last_info_; }
 
  private:

@@ -379,3 +379,54 @@ int vo_stereo_prior_enqueue(vo_ctx *c, const float *d_Xp, const float *d_pl0, co
   VO_CHECK_HIP(c, hipGetLastError());
   return VO_OK;
 }
+
+// ---- epipolar gates: MotionEstimator::calcSampsonDistance (motion_estimator.cpp:572-599) and
+// calcSymmetricEpipolarDistance (:621-653), per-point part on a given F10 ------------------------
+// Eigen evaluates its 3-term products as e0 + (e1 + e2) (unrolled redux); the written sums of the
+// reference are left to right.
+struct EpiArgs {
+  const float *pts0, *pts1;
+  int n;
+  float F[9];
+  int mode;  // 0 Sampson, 1 symmetric epipolar
+  float *dist;
+};
+__device__ __forceinline__ float eig_dot3(float a0, float b0, float a1, float b1, float a2, float b2) {
+  return a0 * b0 + (a1 * b1 + a2 * b2);
+}
+__global__ __launch_bounds__(256) void epi_distance_kernel(EpiArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const float x0 = a.pts0[2 * i], y0 = a.pts0[2 * i + 1], x1 = a.pts1[2 * i], y1 = a.pts1[2 * i + 1];
+  float p[3], q[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) p[r] = eig_dot3(a.F[r * 3 + 0], x0, a.F[r * 3 + 1], y0, a.F[r * 3 + 2], 1.0f);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) q[r] = eig_dot3(a.F[0 * 3 + r], x1, a.F[1 * 3 + r], y1, a.F[2 * 3 + r], 1.0f);
+  float num = eig_dot3(x1, p[0], y1, p[1], 1.0f, p[2]);
+  if (a.mode == 0) {
+    num *= num;
+    const float den = ((p[0] * p[0] + p[1] * p[1]) + q[0] * q[0]) + q[1] * q[1];
+    a.dist[i] = num / den;
+  } else {
+    num = fabsf(num);
+    const float den = 1.0f / sqrtf(p[0] * p[0] + p[1] * p[1]) + 1.0f / sqrtf(q[0] * q[0] + q[1] * q[1]);
+    a.dist[i] = num * den;
+  }
+}
+int vo_epi_distance_enqueue(vo_ctx *c, int mode, const float *d_pts0, const float *d_pts1, int n, const float F10[9],
+                            float *d_dist) {
+  if (n <= 0) return VO_OK;
+  EpiArgs a;
+  a.pts0 = d_pts0;
+  a.pts1 = d_pts1;
+  a.n = n;
+  memcpy(a.F, F10, sizeof(a.F));
+  a.mode = mode;
+  a.dist = d_dist;
+  vo_prof_begin(c, VO_K_AUX);
+  hipLaunchKernelGGL(epi_distance_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, a);
+  vo_prof_end(c);
+  VO_CHECK_HIP(c, hipGetLastError());
+  return VO_OK;
+}

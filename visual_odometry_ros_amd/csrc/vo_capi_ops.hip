@@ -102,6 +102,32 @@ extern "C" int vo_calc_prior(vo_ctx *c, const float *pts0, int n_pts0, const flo
   return VO_OK;
 }
 
+// MotionEstimator::calcSampsonDistance (F10 overload, motion_estimator.cpp:572-599) and
+// calcSymmetricEpipolarDistance (:621-653)
+static int epi_distance(vo_ctx *c, int mode, const float *pts0, const float *pts1, int n, const float F10[9],
+                        float *dist) {
+  if (!c || !pts0 || !pts1 || !F10 || !dist) return VO_ERR_INVALID;
+  int rc = check_n(c, n);
+  if (rc) return rc;
+  if (n == 0) return VO_OK;
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  H2D(c->d_pts0, pts0, sizeof(float) * 2 * (size_t)n);
+  H2D(c->d_pts1, pts1, sizeof(float) * 2 * (size_t)n);
+  rc = vo_epi_distance_enqueue(c, mode, c->d_pts0, c->d_pts1, n, F10, c->d_err);
+  if (rc < 0) return rc;
+  D2H(dist, c->d_err, sizeof(float) * (size_t)n);
+  SYNC();
+  return VO_OK;
+}
+extern "C" int vo_sampson_distance(vo_ctx *c, const float *pts0, const float *pts1, int n, const float F10[9],
+                                   float *dist) {
+  return epi_distance(c, 0, pts0, pts1, n, F10, dist);
+}
+extern "C" int vo_symmetric_epipolar_distance(vo_ctx *c, const float *pts0, const float *pts1, int n,
+                                              const float F10[9], float *dist) {
+  return epi_distance(c, 1, pts0, pts1, n, F10, dist);
+}
+
 static int ensure_desc(vo_ctx *c, int na, int nb, bool need_dist) {
   const size_t need = (size_t)(na > nb ? na : nb) * 32;
   if (need > c->desc_cap) {

@@ -100,5 +100,8 @@ int vo_stereo_prior_enqueue(vo_ctx *c, const float *d_Xp, const float *d_pl0, co
                             int W, int H, float *d_pl1, float *d_pr1, float *d_scale, int32_t *d_orig,
                             uint8_t *d_stage);
 
+int vo_epi_distance_enqueue(vo_ctx *c, int mode, const float *d_pts0, const float *d_pts1, int n, const float F10[9],
+                            float *d_dist);
+
 // frame_pipeline.hip
 void vo_frame_free(vo_ctx *c);
