@@ -283,6 +283,9 @@ __global__ __launch_bounds__(64) void frame_replay_kernel(FrameArgs a) {
     frame_tail<WIN>(a, i, a.ic.mask[i], a.ic.pts_track[2 * i], a.ic.pts_track[2 * i + 1], a.k1[2 * i], a.k1[2 * i + 1],
                     a.pr_prior[2 * i], a.pr_prior[2 * i + 1], s_tt, s_tj, lane);
   }
+#ifdef IC_STAMP
+  if (lane == 0) atomicMax(&a.ic.tlist[IC_DBG_OFF + 2], (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff));
+#endif
 }
 
 // after ic_strict_kernel (sequential fallback only): step [5] of the touched features

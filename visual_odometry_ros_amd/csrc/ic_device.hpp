@@ -51,6 +51,7 @@ struct IcArgs {
   float *recV1;             // [n][IC_NELEM] last I1 value the point wrote per tap
   float *pre1;              // [n][IC_NELEM] I1 pre-state the point last ran with
   uint32_t *preM;           // [n][IC_MW] its mask
+  int *pubc;                // [n] how often the feature's record was published (monotonic across frames)
   int *jac;                 // control words of the replay: [IC_JAC_NT] #touched, [IC_JAC_OVF], [IC_JAC_VER], slots
   int *tlist;               // indices of the touched points (any order)
 };
@@ -479,28 +480,66 @@ __device__ __forceinline__ void ic_st(int *p, int v) { __hip_atomic_store(p, v, 
 
 struct IcReplayShared {
   IcShared sh;
-  uint32_t w0[IC_MAXRUN * IC_MW], w1[IC_MAXRUN * IC_MW];
+  uint32_t w[IC_MAXRUN * IC_MW];  // tap masks of the predecessors (W0 while the statics are built, else W1)
   uint8_t cls[IC_MAXRUN];
+  int src[IC_NELEM];              // nearest earlier writer per wanted tap (-1: none)
+  int pub[IC_MAXRUN];             // publication counts of the predecessors at the last look
 };
+
+// For every tap flagged in `want` (bit k of a lane = tap lane + 64 k): the nearest predecessor
+// r in [0, L) (largest r) with rs.cls[r] >= need whose mask rs.w[r] has the tap's bit; result lo + r
+// (or -1) in rs.src[tap]. Lanes scan 64 predecessors at a time (nearest first) and vote: the taps a
+// point can observe are few, the predecessors many, and the writer of an observable tap is
+// typically far back in the run (the neighbours cannot see it either).
+__device__ __forceinline__ void ic_find_writers(IcReplayShared &rs, unsigned want, int need, int lo, int L, int lane) {
+#pragma unroll
+  for (int k = 0; k < IC_K; ++k) {
+    unsigned long long todo = __ballot((want >> k) & 1u);
+    while (todo) {
+      const int l = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const int word = k < 4 ? 2 * k + (l >> 5) : 8, bit = l & 31;
+      int found = -1;
+      for (int c0 = 0; c0 < L; c0 += 64) {
+        const int r = L - 1 - c0 - lane;
+        const bool hit = r >= 0 && rs.cls[r] >= need && ((rs.w[r * IC_MW + word] >> bit) & 1u);
+        const unsigned long long b = __ballot(hit);
+        if (b) {
+          found = lo + (L - 1 - c0 - (__ffsll((long long)b) - 1));
+          break;
+        }
+      }
+      if (lane == 0) rs.src[l + 64 * k] = found;
+    }
+  }
+}
+
 // Body of the replay kernel. Returns the number of workgroups P that own list entries (this
 // workgroup handles entries blockIdx.x, blockIdx.x + P, ..), 0 if this workgroup owns none, or -1
 // when the sequential fallback was requested (IC_JAC_OVF).
 __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, int lane) {
   IcShared &sh = rs.sh;
-  uint32_t *const s_w0 = rs.w0, *const s_w1 = rs.w1;
-  uint8_t *const s_cls = rs.cls;
   const int n_touched = a.jac[IC_JAC_NT];
   if (n_touched == 0) return 0;  // nothing left the image: pass 1 already is the reference result
   const int P = min((int)gridDim.x, n_touched);
   if ((int)blockIdx.x >= P) return 0;
+  // one feature per workgroup (the usual case): everything static about it is computed once
+  const bool single = n_touched <= P;
   int *const ver = &a.jac[IC_JAC_VER];
   int *const ovf = &a.jac[IC_JAC_OVF];
   int *const slots = a.jac + IC_JAC_SLOTS;
   const IcTaps tp = ic_make_taps(lane);
+  const float fw1 = (float)(a.I1.w - 2), fh1 = (float)(a.I1.h - 2);
   int polls = 0;
 #ifdef IC_STAMP
   if (lane == 0 && blockIdx.x == 0) a.tlist[IC_DBG_OFF + 31] = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff);
 #endif
+  // statics of the current feature: run bounds, template pre-state, observable I1 taps
+  int lo = 0, L = 0;
+  bool have_statics = false, skip_pt = false;
+  IcState S0;
+  ic_state_clear(S0);
+  unsigned seen = 0;
   int result = P;
   for (int pass = 0;; ++pass) {
     // ---- look ----
@@ -515,107 +554,123 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
       break;
     }
     v = __builtin_amdgcn_readfirstlane(v);
-    __threadfence();
     int any_change = 0;
     for (int li = blockIdx.x; li < n_touched; li += P) {
       const int pt = a.tlist[li];
       __syncthreads();  // LDS of the previous list entry is free
-      // nearest clean (untouched, iterated) predecessor: 64 candidates at a time
-      int dist = -1;
-      for (int c0 = 0; c0 < IC_CAND; c0 += 64) {
-        const int q = pt - 1 - c0 - lane;
-        const bool is_clean = q >= 0 && a.cls[q] == 2 && !a.touched[q];
-        const unsigned long long bal = __ballot(is_clean);
-        if (bal) {
-          dist = c0 + __ffsll((long long)bal) - 1;
-          break;
+      const float p0x = a.pts0[2 * pt], p0y = a.pts0[2 * pt + 1];
+      if (!single || !have_statics) {
+        have_statics = true;
+        skip_pt = false;
+        // nearest clean (untouched, iterated) predecessor: 64 candidates at a time
+        int dist = -1;
+        for (int c0 = 0; c0 < IC_CAND; c0 += 64) {
+          const int q = pt - 1 - c0 - lane;
+          const bool is_clean = q >= 0 && a.cls[q] == 2 && !a.touched[q];
+          const unsigned long long bal = __ballot(is_clean);
+          if (bal) {
+            dist = c0 + __ffsll((long long)bal) - 1;
+            break;
+          }
+          if (pt - 1 - c0 - 63 <= 0) break;  // ran past index 0
         }
-        if (pt - 1 - c0 - 63 <= 0) break;  // ran past index 0
-      }
-      int lo;
-      if (dist < 0) {
-        if (pt > IC_CAND) {  // no clean point among the candidates
+        if (dist < 0 && pt > IC_CAND) skip_pt = true;  // no clean point among the candidates
+        lo = dist < 0 ? 0 : pt - 1 - dist;
+        L = pt - lo;  // predecessors lo .. pt-1
+        if (L > IC_MAXRUN) skip_pt = true;
+        if (skip_pt) {
           if (lane == 0) atomicExch(ovf, 1);
           continue;
         }
-        lo = 0;
-      } else {
-        lo = pt - 1 - dist;
-      }
-      const int L = pt - lo;  // predecessors lo .. pt-1
-      if (L > IC_MAXRUN) {
-        if (lane == 0) atomicExch(ovf, 1);
-        continue;
-      }
-      for (int i = lane; i < L * IC_MW; i += IC_T) {
-        s_w0[i] = a.recW0[(size_t)lo * IC_MW + i];
-        s_w1[i] = a.recW1[(size_t)lo * IC_MW + i];
-      }
-      for (int i = lane; i < L; i += IC_T) s_cls[i] = a.cls[lo + i];
-      __syncthreads();
-
-      IcState S;
-      ic_state_clear(S);
-      // nearest earlier writer of each of this lane's taps
-      {
-        int src0[IC_K], src1[IC_K];
-        unsigned open0 = tp.on, open1 = tp.on;  // taps still looking for a writer
-#pragma unroll
-        for (int k = 0; k < IC_K; ++k) src0[k] = src1[k] = -1;
-        for (int r = L - 1; r >= 0 && (open0 | open1); --r) {
-          const int c = s_cls[r];
-          if (c == 0) continue;
-#pragma unroll
-          for (int k = 0; k < IC_K; ++k) {
-            if (((open0 >> k) & 1u) && ic_bit_k(&s_w0[r * IC_MW], lane, k)) {
-              src0[k] = lo + r;
-              open0 &= ~(1u << k);
-            }
-            if (((open1 >> k) & 1u) && c == 2 && ic_bit_k(&s_w1[r * IC_MW], lane, k)) {
-              src1[k] = lo + r;
-              open1 &= ~(1u << k);
-            }
-          }
-        }
+        // template pre-state: only taps the feature's own template evaluation does not write
+        unsigned tseen = 0;
 #pragma unroll
         for (int k = 0; k < IC_K; ++k) {
-          const int j = lane + 64 * k;
-          if (src0[k] >= 0) {
-            const float *v0 = a.recV0 + (size_t)src0[k] * 3 * IC_NELEM;
-            S.I0[k] = v0[j];
-            S.du[k] = v0[IC_NELEM + j];
-            S.dv[k] = v0[2 * IC_NELEM + j];
-            S.m |= 1u << k;
+          const int u0 = (int)(p0x + tp.px[k]), v0 = (int)(p0y + tp.py[k]);
+          const bool valid = !(u0 < 1 || u0 >= a.I0.w - 2 || v0 < 1 || v0 >= a.I0.h - 2);
+          if (((tp.on >> k) & 1u) && !valid) tseen |= 1u << k;
+        }
+        __threadfence();  // (acquire for pass 0: pass-1 records come from the previous launch anyway)
+        for (int i = lane; i < L * IC_MW; i += IC_T) rs.w[i] = a.recW0[(size_t)lo * IC_MW + i];
+        for (int i = lane; i < L; i += IC_T) rs.cls[i] = a.cls[lo + i];
+        __syncthreads();
+        ic_find_writers(rs, tseen, 1, lo, L, lane);
+        __syncthreads();
+        ic_state_clear(S0);
+#pragma unroll
+        for (int k = 0; k < IC_K; ++k)
+          if ((tseen >> k) & 1u) {
+            const int j = lane + 64 * k;
+            const int src = rs.src[j];
+            if (src >= 0) {
+              const float *v0 = a.recV0 + (size_t)src * 3 * IC_NELEM;
+              S0.I0[k] = v0[j];
+              S0.du[k] = v0[IC_NELEM + j];
+              S0.dv[k] = v0[2 * IC_NELEM + j];
+              S0.m |= 1u << k;
+            }
           }
-          if (src1[k] >= 0) {
-            S.I1[k] = a.recV1[(size_t)src1[k] * IC_NELEM + j];
+        // Only taps that are outside the image at the feature's FIRST I1 evaluation (the prior
+        // position: static) can show their pre-state to it; every other tap is overwritten by that
+        // evaluation before anything reads it.
+        const float pux = p0x + (a.pts_prior[2 * pt] - p0x), puy = p0y + (a.pts_prior[2 * pt + 1] - p0y);
+        const float sc = a.scale[pt];
+        seen = 0;
+#pragma unroll
+        for (int k = 0; k < IC_K; ++k) {
+          const float uc = pux + tp.px[k] * sc, vc = puy + tp.py[k] * sc;
+          if (((tp.on >> k) & 1u) && (uc < 1 || uc >= fw1 || vc < 1 || vc >= fh1)) seen |= 1u << k;
+        }
+        __syncthreads();
+      } else if (skip_pt) {
+        continue;
+      }
+      // publication counts of the predecessors, read BEFORE their records (a count is bumped after
+      // the record's release): unchanged counts => unchanged records => nothing to do
+      int pc[(IC_MAXRUN + 63) / 64];
+      bool moved = pass == 0 || !single;
+#pragma unroll
+      for (int q = 0; q < (IC_MAXRUN + 63) / 64; ++q) {
+        const int i = lane + 64 * q;
+        pc[q] = i < L ? ic_ld(&a.pubc[lo + i]) : 0;
+        if (i < L && pc[q] != rs.pub[i]) moved = true;
+      }
+      if (!__any(moved)) continue;
+      __threadfence();  // acquire: the records behind the counts just read
+#pragma unroll
+      for (int q = 0; q < (IC_MAXRUN + 63) / 64; ++q) {
+        const int i = lane + 64 * q;
+        if (i < L) rs.pub[i] = pc[q];
+      }
+      for (int i = lane; i < L * IC_MW; i += IC_T) rs.w[i] = a.recW1[(size_t)lo * IC_MW + i];
+      for (int i = lane; i < L; i += IC_T) rs.cls[i] = a.cls[lo + i];
+      __syncthreads();
+      ic_find_writers(rs, seen, 2, lo, L, lane);
+      __syncthreads();
+      IcState S = S0;
+#pragma unroll
+      for (int k = 0; k < IC_K; ++k)
+        if ((seen >> k) & 1u) {
+          const int j = lane + 64 * k;
+          const int src = rs.src[j];
+          if (src >= 0) {
+            S.I1[k] = a.recV1[(size_t)src * IC_NELEM + j];
             S.m |= 0x100u << k;
           }
         }
-      }
-      // skip when the I1 pre-state is exactly the one this point last ran with (template part is static)
+      // skip when the observable I1 pre-state is exactly the one this feature last ran with
       {
         float *p1 = a.pre1 + (size_t)pt * IC_NELEM;
         uint32_t *pm = a.preM + (size_t)pt * IC_MW;
         int diff = pass == 0;
-        // Only taps that are outside the image at the point's FIRST I1 evaluation (the prior position:
-        // static) can show their pre-state to the point; every other tap is overwritten by that
-        // evaluation before anything reads it. Comparing just those taps prunes the false dependencies.
-        const float p0x = a.pts0[2 * pt], p0y = a.pts0[2 * pt + 1];
-        const float pux = p0x + (a.pts_prior[2 * pt] - p0x), puy = p0y + (a.pts_prior[2 * pt + 1] - p0y);
-        const float sc = a.scale[pt];
-        const float fw = (float)(a.I1.w - 2), fh = (float)(a.I1.h - 2);
         if (!diff) {
 #pragma unroll
-          for (int k = 0; k < IC_K; ++k) {
-            const float uc = pux + tp.px[k] * sc, vc = puy + tp.py[k] * sc;
-            const bool seen = uc < 1 || uc >= fw || vc < 1 || vc >= fh;
-            if (((tp.on >> k) & 1u) && seen) {
+          for (int k = 0; k < IC_K; ++k)
+            if ((seen >> k) & 1u) {
               const bool b0 = (S.m >> (8 + k)) & 1u;
               const int j = lane + 64 * k;
               if (b0 != ic_bit_k(pm, lane, k) || (b0 && __float_as_uint(p1[j]) != __float_as_uint(S.I1[k]))) diff = 1;
             }
-          }
         }
         if (!__any(diff)) continue;
 #ifdef IC_STAMP
@@ -629,7 +684,7 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
       int dummy = 0, n_iter = 0;
       float lx = 0.f, ly = 0.f;
       const int cls = ic_point_io<true>(a, tp, pt, lane, sh, S, dummy, lx, ly, n_iter);
-      // own I1 writes of this run of the point vs the stored record
+      // own I1 writes of this run of the feature vs the stored record
       const bool iterated = cls == 2;
       const unsigned o = iterated ? ((S.m >> 24) & tp.on) : 0u;
       uint32_t *w1 = a.recW1 + (size_t)pt * IC_MW;
@@ -643,13 +698,15 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
             changed = 1;
         }
       if (__any(changed)) {
-        // publish
+        // publish: record, release, count (release again), version
 #pragma unroll
         for (int k = 0; k < IC_K; ++k)
           if ((tp.on >> k) & 1u) v1[lane + 64 * k] = S.I1[k];
         ic_store_mask(w1, o, lane);
         if (lane == 0) a.cls[pt] = (uint8_t)cls;
-        __threadfence();  // release: every lane's record stores, then the bump
+        __threadfence();
+        if (lane == 0) atomicAdd(&a.pubc[pt], 1);
+        __threadfence();
         if (lane == 0) {
           atomicAdd(ver, 1);
 #ifdef IC_STAMP

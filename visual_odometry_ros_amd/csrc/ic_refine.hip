@@ -181,7 +181,7 @@ static int ic_args(vo_ctx *c, int slot0, int slot1, IcArgs &a, int *d_flags) {
 static int ic_records(vo_ctx *c, IcArgs &a) {
   if (!c->ic_rec) {
     const size_t N = (size_t)c->cfg.max_points;
-    const size_t bytes = N * (4 + 2 * IC_MW * 4 + 3 * IC_NELEM * 4 + IC_NELEM * 4 + IC_NELEM * 4 + IC_MW * 4) + IC_JAC_BYTES;
+    const size_t bytes = N * (4 + 4 + 2 * IC_MW * 4 + 3 * IC_NELEM * 4 + IC_NELEM * 4 + IC_NELEM * 4 + IC_MW * 4) + IC_JAC_BYTES;
     VO_CHECK_HIP(c, hipMalloc(&c->ic_rec, bytes));
     VO_CHECK_HIP(c, hipMemsetAsync(c->ic_rec, 0, bytes, c->stream));
   }
@@ -189,6 +189,7 @@ static int ic_records(vo_ctx *c, IcArgs &a) {
   uint8_t *p = (uint8_t *)c->ic_rec;
   a.jac = (int *)p;                 p += IC_JAC_BYTES;
   a.tlist = (int *)p;               p += N * 4;
+  a.pubc = (int *)p;                p += N * 4;
   a.recW0 = (uint32_t *)p;          p += N * IC_MW * 4;
   a.recW1 = (uint32_t *)p;          p += N * IC_MW * 4;
   a.preM = (uint32_t *)p;           p += N * IC_MW * 4;

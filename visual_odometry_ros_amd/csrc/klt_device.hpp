@@ -95,6 +95,32 @@ __device__ __forceinline__ KltResult klt_point(const vo_level *I, const vo_level
   int status = 1;
   float errv = 0.f;
 
+  // Tile prefetch. The template tile of a level depends only on p0, so it is fetched into
+  // registers one level ahead (in flight during the previous level's iterations); the search tile
+  // depends on the previous level's result, so it is fetched at level entry and lands while the
+  // template is being computed. Either way a level exposes the memory latency once, not twice.
+  constexpr int NT = (C::TT_H * C::TT_WD + 63) / 64;
+  constexpr int NJ = (C::TJ_H * C::TJ_WD + 63) / 64;
+  uint32_t rt[NT];
+  auto fetch_template_tile = [&](int lv) {
+    const vo_level L = I[lv];
+    const float ls = (float)(1. / (1 << lv));
+    const int fx = __builtin_amdgcn_readfirstlane((int)floorf(p0x * ls - halfWin));
+    const int fy = __builtin_amdgcn_readfirstlane((int)floorf(p0y * ls - halfWin));
+    if (fx < -WIN || fx >= L.w || fy < -WIN || fy >= L.h) return;  // the level will be skipped
+    const uint8_t *g = L.origin() + (ptrdiff_t)(fy - 1) * L.stride + ((fx - 1) & ~3);
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+      const int i = lane + 64 * q;
+      const int ii = i < C::TT_H * C::TT_WD ? i : 0;
+      const int r = ii / C::TT_WD, cdw = ii - r * C::TT_WD;
+      rt[q] = *(const uint32_t *)(g + (ptrdiff_t)r * L.stride + cdw * 4);
+    }
+  };
+#pragma unroll
+  for (int q = 0; q < NT; ++q) rt[q] = 0;
+  fetch_template_tile(max_level);
+
   for (int level = max_level; level >= 0; --level) {
     const vo_level LI = I[level];
     const vo_level LJ = J[level];
@@ -124,7 +150,31 @@ __device__ __forceinline__ KltResult klt_point(const vo_level *I, const vo_level
         status = 0;
         errv = 0.f;
       }
+      if (level > 0) fetch_template_tile(level - 1);
       continue;
+    }
+    // search tile around the initial estimate of this level (the first iteration's window)
+    uint32_t rs[NJ];
+    int tjx = 0, tjy = 0;  // image coords of search-tile byte (0,0)
+    bool tile_ok = false;
+    {
+      const int sx = __builtin_amdgcn_readfirstlane((int)floorf(nextx - halfWin));
+      const int sy = __builtin_amdgcn_readfirstlane((int)floorf(nexty - halfWin));
+#pragma unroll
+      for (int q = 0; q < NJ; ++q) rs[q] = 0;
+      if (!(sx < -WIN || sx >= LJ.w || sy < -WIN || sy >= LJ.h)) {
+        tjx = (sx - C::M) & ~3;
+        tjy = sy - C::M;
+        tile_ok = true;
+        const uint8_t *g = LJ.origin() + (ptrdiff_t)tjy * LJ.stride + tjx;
+#pragma unroll
+        for (int q = 0; q < NJ; ++q) {
+          const int i = lane + 64 * q;
+          const int ii = i < C::TJ_H * C::TJ_WD ? i : 0;
+          const int r = ii / C::TJ_WD, cdw = ii - r * C::TJ_WD;
+          rs[q] = *(const uint32_t *)(g + (ptrdiff_t)r * LJ.stride + cdw * 4);
+        }
+      }
     }
     float fa = prevx - ipx, fb = prevy - ipy;
     int iw00 = (int)rintf((1.f - fa) * (1.f - fb) * (1 << KLT_W_BITS));
@@ -136,11 +186,11 @@ __device__ __forceinline__ KltResult klt_point(const vo_level *I, const vo_level
     const int tx0 = (ipx - 1) & ~3;  // VO_PAD is a multiple of 4, so this is 4-byte aligned in memory
     const int tsh = (ipx - 1) - tx0;
     {
-      const uint8_t *g = LI.origin() + (ptrdiff_t)(ipy - 1) * LI.stride + tx0;
       __syncthreads();
-      for (int i = lane; i < C::TT_H * C::TT_WD; i += 64) {
-        const int r = i / C::TT_WD, cdw = i - r * C::TT_WD;
-        s_tt[i] = *(const uint32_t *)(g + (ptrdiff_t)r * LI.stride + cdw * 4);
+#pragma unroll
+      for (int q = 0; q < NT; ++q) {
+        const int i = lane + 64 * q;
+        if (i < C::TT_H * C::TT_WD) s_tt[i] = rt[q];  // fetched one level ahead
       }
       __syncthreads();
     }
@@ -200,6 +250,7 @@ __device__ __forceinline__ KltResult klt_point(const vo_level *I, const vo_level
         pA22 += tY[j] * tY[j];
       }
     }
+    if (level > 0) fetch_template_tile(level - 1);  // in flight during this level's iterations
     float sA11, sA12, sA22, sdummy;
     wave_sum2_i32_to_f32(pA11, pA12, sA11, sA12);
     wave_sum2_i32_to_f32(pA22, 0, sA22, sdummy);
@@ -216,8 +267,15 @@ __device__ __forceinline__ KltResult klt_point(const vo_level *I, const vo_level
     nextx -= halfWin;
     nexty -= halfWin;
     float pdx = 0.f, pdy = 0.f;
-    int tjx = 0, tjy = 0;   // image coords of search-tile byte (0,0)
-    bool tile_ok = false;
+    if (tile_ok) {
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < NJ; ++q) {
+        const int i = lane + 64 * q;
+        if (i < C::TJ_H * C::TJ_WD) s_tj[i] = rs[q];
+      }
+      __syncthreads();
+    }
 
     // bilinear difference of the current window against the template, per lane
     auto eval_diffs = [&](int inx, int iny, int w00, int w01, int w10, int w11, int (&diff)[RL]) {
