@@ -274,15 +274,14 @@ __global__ __launch_bounds__(64) void frame_replay_kernel(FrameArgs a) {
   __shared__ uint32_t s_tt[KltCfg<WIN>::TT_H * KltCfg<WIN>::TT_WD];
   __shared__ uint32_t s_tj[KltCfg<WIN>::TJ_H * KltCfg<WIN>::TJ_WD];
   const int lane = threadIdx.x;
-  const int P = ic_replay(a.ic, rs, lane);
-  if (P <= 0) return;  // no list entry here, or the sequential fallback takes over
-  __threadfence();     // this workgroup's own last results (written by lane 0) are re-read below
-  const int n_touched = a.ic.jac[IC_JAC_NT];
-  for (int li = blockIdx.x; li < n_touched; li += P) {
-    const int i = a.ic.tlist[li];
-    frame_tail<WIN>(a, i, a.ic.mask[i], a.ic.pts_track[2 * i], a.ic.pts_track[2 * i + 1], a.k1[2 * i], a.k1[2 * i + 1],
-                    a.pr_prior[2 * i], a.pr_prior[2 * i + 1], s_tt, s_tj, lane);
-  }
+  // step [5] of a feature follows its (re)computation at once: by then its record is published, so
+  // nobody waits for this wavefront, and the feature is final unless an input changes later (rare;
+  // the hook then runs again and overwrites the outputs)
+  auto tail = [&](int i, const IcResult &r) {
+    frame_tail<WIN>(a, i, r.ok, r.x, r.y, a.k1[2 * i], a.k1[2 * i + 1], a.pr_prior[2 * i], a.pr_prior[2 * i + 1], s_tt,
+                    s_tj, lane);
+  };
+  (void)ic_replay(a.ic, rs, lane, tail);
 #ifdef IC_STAMP
   if (lane == 0) atomicMax(&a.ic.tlist[IC_DBG_OFF + 2], (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff));
 #endif

@@ -52,6 +52,7 @@ struct IcArgs {
   float *pre1;              // [n][IC_NELEM] I1 pre-state the point last ran with
   uint32_t *preM;           // [n][IC_MW] its mask
   int *pubc;                // [n] how often the feature's record was published (monotonic across frames)
+  uint8_t *ready;           // [n] touched feature has published its first strict-state result (cleared by pass 1)
   int *jac;                 // control words of the replay: [IC_JAC_NT] #touched, [IC_JAC_OVF], [IC_JAC_VER], slots
   int *tlist;               // indices of the touched points (any order)
 };
@@ -386,10 +387,11 @@ __device__ IcResult ic_point(const vo_level &I0, const vo_level &I1, const IcTap
 }
 
 // ic_point on array operands: inputs of point `pt` from a.pts0 / a.pts_prior / a.scale, results to
-// a.mask / a.pts_track (the prior when the refinement is rejected) / a.flags. Returns cls.
+// a.mask / a.pts_track (the prior when the refinement is rejected) / a.flags.
 template <bool STRICT>
-__device__ __forceinline__ int ic_point_io(const IcArgs &a, const IcTaps &tp, int pt, int lane, IcShared &sh, IcState &S,
-                                           int &touched, float &last_pux, float &last_puy, int &n_iter) {
+__device__ __forceinline__ IcResult ic_point_io(const IcArgs &a, const IcTaps &tp, int pt, int lane, IcShared &sh,
+                                                IcState &S, int &touched, float &last_pux, float &last_puy,
+                                                int &n_iter) {
   const IcResult r = ic_point<STRICT>(a.I0, a.I1, tp, a.pts0[2 * pt], a.pts0[2 * pt + 1], a.pts_prior[2 * pt],
                                       a.pts_prior[2 * pt + 1], a.scale[pt], lane, sh, S, touched, last_pux, last_puy,
                                       n_iter);
@@ -399,7 +401,7 @@ __device__ __forceinline__ int ic_point_io(const IcArgs &a, const IcTaps &tp, in
     a.pts_track[2 * pt + 1] = r.y;
     a.mask[pt] = (uint8_t)r.ok;
   }
-  return r.cls;
+  return r;
 }
 
 __device__ __forceinline__ void ic_state_clear(IcState &S) {
@@ -436,6 +438,7 @@ __device__ __forceinline__ void ic_store_records(const IcArgs &a, int pt, int la
   const bool processed = cls >= 1, iterated = cls == 2;
   ic_store_mask(a.recW0 + (size_t)pt * IC_MW, processed ? ((S.m >> 16) & tp.on) : 0u, lane);
   ic_store_mask(a.recW1 + (size_t)pt * IC_MW, iterated ? ((S.m >> 24) & tp.on) : 0u, lane);
+  if (lane == 0) a.ready[pt] = 0;
   float *v0 = a.recV0 + (size_t)pt * 3 * IC_NELEM;
   float *v1 = a.recV1 + (size_t)pt * IC_NELEM;
 #pragma unroll
@@ -477,6 +480,8 @@ __device__ __forceinline__ void ic_store_records(const IcArgs &a, int pt, int la
 // exceeds IC_MAXRUN, IC_JAC_OVF is raised and ic_strict_kernel replays sequentially.
 __device__ __forceinline__ int ic_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void ic_st(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ic_ld8(const uint8_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ic_st8(uint8_t *p, uint8_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 struct IcReplayShared {
   IcShared sh;
@@ -517,7 +522,11 @@ __device__ __forceinline__ void ic_find_writers(IcReplayShared &rs, unsigned wan
 // Body of the replay kernel. Returns the number of workgroups P that own list entries (this
 // workgroup handles entries blockIdx.x, blockIdx.x + P, ..), 0 if this workgroup owns none, or -1
 // when the sequential fallback was requested (IC_JAC_OVF).
-__device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, int lane) {
+// `after_run(pt, result)` is called after every (re)computation of a feature, once its record is
+// published: the frame kernel continues with the feature's next step there instead of waiting for
+// the whole relaxation (a later recomputation, rare, calls it again).
+template <typename AfterRun>
+__device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, int lane, AfterRun after_run) {
   IcShared &sh = rs.sh;
   const int n_touched = a.jac[IC_JAC_NT];
   if (n_touched == 0) return 0;  // nothing left the image: pass 1 already is the reference result
@@ -555,6 +564,7 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
     }
     v = __builtin_amdgcn_readfirstlane(v);
     int any_change = 0;
+    bool gated = false;
     for (int li = blockIdx.x; li < n_touched; li += P) {
       const int pt = a.tlist[li];
       __syncthreads();  // LDS of the previous list entry is free
@@ -625,29 +635,86 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
       } else if (skip_pt) {
         continue;
       }
-      // publication counts of the predecessors, read BEFORE their records (a count is bumped after
-      // the record's release): unchanged counts => unchanged records => nothing to do
-      int pc[(IC_MAXRUN + 63) / 64];
-      bool moved = pass == 0 || !single;
+      // words of the 9-word tap masks that hold observable taps (usually 2 or 3): only those are staged
+      unsigned wordmask = 0;
 #pragma unroll
-      for (int q = 0; q < (IC_MAXRUN + 63) / 64; ++q) {
-        const int i = lane + 64 * q;
-        pc[q] = i < L ? ic_ld(&a.pubc[lo + i]) : 0;
-        if (i < L && pc[q] != rs.pub[i]) moved = true;
+      for (int k = 0; k < IC_K; ++k) {
+        const unsigned long long b = __ballot((seen >> k) & 1u);
+        if (k < 4) {
+          if ((uint32_t)b) wordmask |= 1u << (2 * k);
+          if ((uint32_t)(b >> 32)) wordmask |= 1u << (2 * k + 1);
+        } else if (b) {
+          wordmask |= 1u << 8;
+        }
       }
-      if (!__any(moved)) continue;
-      __threadfence();  // acquire: the records behind the counts just read
-#pragma unroll
-      for (int q = 0; q < (IC_MAXRUN + 63) / 64; ++q) {
-        const int i = lane + 64 * q;
-        if (i < L) rs.pub[i] = pc[q];
-      }
-      for (int i = lane; i < L * IC_MW; i += IC_T) rs.w[i] = a.recW1[(size_t)lo * IC_MW + i];
-      for (int i = lane; i < L; i += IC_T) rs.cls[i] = a.cls[lo + i];
-      __syncthreads();
-      ic_find_writers(rs, seen, 2, lo, L, lane);
-      __syncthreads();
       IcState S = S0;
+      bool give_up = false, unchanged = false;
+      for (int attempt = 0;; ++attempt) {
+        // publication counts of the predecessors, read BEFORE their records (a count is bumped after
+        // the record's release): unchanged counts => unchanged records => nothing to do
+        int pc[(IC_MAXRUN + 63) / 64];
+        bool moved = pass == 0 || !single || attempt > 0 || !ic_ld8(&a.ready[pt]);
+#pragma unroll
+        for (int q = 0; q < (IC_MAXRUN + 63) / 64; ++q) {
+          const int i = lane + 64 * q;
+          pc[q] = i < L ? ic_ld(&a.pubc[lo + i]) : 0;
+          if (i < L && pc[q] != rs.pub[i]) moved = true;
+        }
+        if (!__any(moved)) {
+          unchanged = true;
+          break;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the records behind the counts just read
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < (IC_MAXRUN + 63) / 64; ++q) {
+          const int i = lane + 64 * q;
+          if (i < L) rs.pub[i] = pc[q];
+        }
+        for (int w = 0; w < IC_MW; ++w)
+          if ((wordmask >> w) & 1u)
+            for (int i = lane; i < L; i += IC_T) rs.w[i * IC_MW + w] = a.recW1[(size_t)(lo + i) * IC_MW + w];
+        for (int i = lane; i < L; i += IC_T) rs.cls[i] = a.cls[lo + i];
+        __syncthreads();
+        ic_find_writers(rs, seen, 2, lo, L, lane);
+        __syncthreads();
+        // Dataflow gate: while a touched feature that this one observes has not produced its first
+        // strict-state result, a run here would only compute from pass-1 data that is about to
+        // change, and would keep this wavefront busy when the real input arrives. Poll exactly those
+        // features' flags (cheap), then look again: their publication may have changed who writes what.
+        bool wait = false;
+#pragma unroll
+        for (int k = 0; k < IC_K; ++k)
+          if ((seen >> k) & 1u) {
+            const int src = rs.src[lane + 64 * k];
+            if (src >= 0 && a.touched[src] && !ic_ld8(&a.ready[src])) wait = true;
+          }
+        if (!__any(wait)) break;
+        if (attempt >= 64) {
+          give_up = true;  // fall back to the version-driven wait
+          break;
+        }
+        for (;;) {
+          bool w2 = false;
+#pragma unroll
+          for (int k = 0; k < IC_K; ++k)
+            if ((seen >> k) & 1u) {
+              const int src = rs.src[lane + 64 * k];
+              if (src >= 0 && a.touched[src] && !ic_ld8(&a.ready[src])) w2 = true;
+            }
+          if (!__any(w2)) break;
+          if (__builtin_amdgcn_readfirstlane(ic_ld(ovf)) || ++polls > IC_SPIN_LIMIT) {
+            give_up = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(16);  // ~0.5 us: a hundred waiting wavefronts must not flood the fabric
+        }
+        if (give_up) break;
+      }
+      if (unchanged || give_up) {
+        if (give_up) gated = true;
+        continue;
+      }
 #pragma unroll
       for (int k = 0; k < IC_K; ++k)
         if ((seen >> k) & 1u) {
@@ -662,7 +729,7 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
       {
         float *p1 = a.pre1 + (size_t)pt * IC_NELEM;
         uint32_t *pm = a.preM + (size_t)pt * IC_MW;
-        int diff = pass == 0;
+        int diff = !ic_ld8(&a.ready[pt]);  // the first strict-state run is unconditional
         if (!diff) {
 #pragma unroll
           for (int k = 0; k < IC_K; ++k)
@@ -683,7 +750,18 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
       }
       int dummy = 0, n_iter = 0;
       float lx = 0.f, ly = 0.f;
-      const int cls = ic_point_io<true>(a, tp, pt, lane, sh, S, dummy, lx, ly, n_iter);
+#ifdef IC_STAMP
+      if (lane == 0 && li < 512) a.tlist[IC_DBG_OFF + 64 + 4 * li + 0] = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff);
+#endif
+      const IcResult res_pt = ic_point_io<true>(a, tp, pt, lane, sh, S, dummy, lx, ly, n_iter);
+#ifdef IC_STAMP
+      if (lane == 0 && li < 512) {
+        a.tlist[IC_DBG_OFF + 64 + 4 * li + 1] = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff);
+        a.tlist[IC_DBG_OFF + 64 + 4 * li + 2] = n_iter;
+        a.tlist[IC_DBG_OFF + 64 + 4 * li + 3] = pt;
+      }
+#endif
+      const int cls = res_pt.cls;
       // own I1 writes of this run of the feature vs the stored record
       const bool iterated = cls == 2;
       const unsigned o = iterated ? ((S.m >> 24) & tp.on) : 0u;
@@ -697,17 +775,21 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
           if (ok != ic_bit_k(w1, lane, k) || (ok && __float_as_uint(v1[lane + 64 * k]) != __float_as_uint(S.I1[k])))
             changed = 1;
         }
-      if (__any(changed)) {
+      const bool first_run = !ic_ld8(&a.ready[pt]);
+      if (__any(changed) || first_run) {
         // publish: record, release, count (release again), version
 #pragma unroll
         for (int k = 0; k < IC_K; ++k)
           if ((tp.on >> k) & 1u) v1[lane + 64 * k] = S.I1[k];
         ic_store_mask(w1, o, lane);
         if (lane == 0) a.cls[pt] = (uint8_t)cls;
-        __threadfence();
-        if (lane == 0) atomicAdd(&a.pubc[pt], 1);
-        __threadfence();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         if (lane == 0) {
+          // the count is bumped by an atomic whose result is awaited: it has been performed at the
+          // coherence point before the version moves
+          const int c = atomicAdd(&a.pubc[pt], 1);
+          asm volatile("" ::"v"(c));  // (wait for the returned value: the atomic has been performed)
+          ic_st8(&a.ready[pt], 1);
           atomicAdd(ver, 1);
 #ifdef IC_STAMP
           atomicAdd(&a.tlist[IC_DBG_OFF + 33], 1);
@@ -715,6 +797,7 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
         }
         any_change = 1;
       }
+      after_run(pt, res_pt);
     }  // touched list
     if (any_change) continue;  // look again at once: the version moved at least by our own publish
 
@@ -731,14 +814,16 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
         res = 1;
         break;
       }
-      bool ok = true;
-      for (int k = lane; k < P; k += 64) ok = ok && (ic_ld(&slots[k]) == v + 1);
-      const bool all_idle = __all(ok);
-      if (all_idle && __builtin_amdgcn_readfirstlane(ic_ld(ver)) == v) {
-        res = 0;
-        break;
+      if ((polls & 3) == 3) {  // the termination test is the expensive part of a poll: every 4th
+        bool ok = true;
+        for (int k = lane; k < P; k += 64) ok = ok && (ic_ld(&slots[k]) == v + 1);
+        const bool all_idle = __all(ok);
+        if (all_idle && __builtin_amdgcn_readfirstlane(ic_ld(ver)) == v) {
+          res = 0;
+          break;
+        }
       }
-      __builtin_amdgcn_s_sleep(4);
+      __builtin_amdgcn_s_sleep(2);
       if (++polls > IC_SPIN_LIMIT) {
         if (lane == 0) atomicExch(ovf, 1);
         res = 2;

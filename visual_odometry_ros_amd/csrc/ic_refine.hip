@@ -58,7 +58,7 @@ __global__ __launch_bounds__(IC_T) void ic_refine_kernel(IcArgs a) {
   IcState S;
   ic_state_clear(S);
   if (entry) {
-    cls = ic_point_io<false>(a, tp, pt, lane, sh, S, touched, lpx, lpy, n_iter);
+    cls = ic_point_io<false>(a, tp, pt, lane, sh, S, touched, lpx, lpy, n_iter).cls;
   } else if (lane == 0) {
     a.pts_track[2 * pt] = a.pts_prior[2 * pt];
     a.pts_track[2 * pt + 1] = a.pts_prior[2 * pt + 1];
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(IC_T) void ic_refine_kernel(IcArgs a) {
 // ---- pass 2a: parallel fixed-point replay of the touched points (ic_device.hpp: ic_replay) ----
 __global__ __launch_bounds__(IC_T) void ic_jacobi_kernel(IcArgs a) {
   __shared__ IcReplayShared rs;
-  (void)ic_replay(a, rs, threadIdx.x);
+  (void)ic_replay(a, rs, threadIdx.x, [](int, const IcResult &) {});
 }
 
 // ---- pass 2: sequential replay of the runs that contain touched points --------------
@@ -181,7 +181,7 @@ static int ic_args(vo_ctx *c, int slot0, int slot1, IcArgs &a, int *d_flags) {
 static int ic_records(vo_ctx *c, IcArgs &a) {
   if (!c->ic_rec) {
     const size_t N = (size_t)c->cfg.max_points;
-    const size_t bytes = N * (4 + 4 + 2 * IC_MW * 4 + 3 * IC_NELEM * 4 + IC_NELEM * 4 + IC_NELEM * 4 + IC_MW * 4) + IC_JAC_BYTES;
+    const size_t bytes = N * (4 + 4 + 4 + 2 * IC_MW * 4 + 3 * IC_NELEM * 4 + IC_NELEM * 4 + IC_NELEM * 4 + IC_MW * 4) + IC_JAC_BYTES;
     VO_CHECK_HIP(c, hipMalloc(&c->ic_rec, bytes));
     VO_CHECK_HIP(c, hipMemsetAsync(c->ic_rec, 0, bytes, c->stream));
   }
@@ -190,6 +190,7 @@ static int ic_records(vo_ctx *c, IcArgs &a) {
   a.jac = (int *)p;                 p += IC_JAC_BYTES;
   a.tlist = (int *)p;               p += N * 4;
   a.pubc = (int *)p;                p += N * 4;
+  a.ready = (uint8_t *)p;           p += N * 4;
   a.recW0 = (uint32_t *)p;          p += N * IC_MW * 4;
   a.recW1 = (uint32_t *)p;          p += N * IC_MW * 4;
   a.preM = (uint32_t *)p;           p += N * IC_MW * 4;
@@ -295,8 +296,8 @@ extern "C" int vo_debug_ic_jac(vo_ctx *c, int *dst) {
   ic_records(c, a);
   VO_CHECK_HIP(c, hipStreamSynchronize(c->stream));
   VO_CHECK_HIP(c, hipMemcpy(dst, a.jac, 64, hipMemcpyDeviceToHost));
-  VO_CHECK_HIP(c, hipMemcpy(dst + 16, a.tlist + IC_DBG_OFF, 256, hipMemcpyDeviceToHost));
-  VO_CHECK_HIP(c, hipMemset(a.tlist + IC_DBG_OFF, 0, 256));
+  VO_CHECK_HIP(c, hipMemcpy(dst + 16, a.tlist + IC_DBG_OFF, 256 + 4 * 4 * 512, hipMemcpyDeviceToHost));
+  VO_CHECK_HIP(c, hipMemset(a.tlist + IC_DBG_OFF, 0, 256 + 4 * 4 * 512));
   return VO_OK;
 }
 // diagnostic (IC_STAMP builds): first `k` floats of each point's pre1 row
