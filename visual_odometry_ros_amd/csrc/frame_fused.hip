@@ -8,7 +8,7 @@
 // only ever combine data of ONE feature (the reference's std::vector compactions between the
 // steps, landmark.cpp:291-332, just drop rejected features), so a feature is one gfx950
 // wavefront that walks through all four steps; the compaction happens once, at the end, in index
-// order (frame_finish_kernel). Every step of the frame is latency-bound on a handful of
+// order (prologue of the GN launch, gn_pose.hip). Every step of the frame is latency-bound on a handful of
 // stragglers (a KLT level that runs all 30 iterations, an IC point that does not converge);
 // as separate launches the frame pays the slowest feature of EVERY step plus the launch gaps,
 // fused it pays the slowest feature once.
@@ -299,67 +299,6 @@ __global__ __launch_bounds__(64) void frame_tail_kernel(FrameArgs a) {
                   a.pr_prior[2 * i], a.pr_prior[2 * i + 1], s_tt, s_tj, threadIdx.x);
 }
 
-// ---- the one compaction of the frame: survivors (stage 3) in index order + the three step counts ----
-struct FinishArgs {
-  int n;
-  const uint8_t *stage;
-  const float *Xp, *pl1, *pr1;
-  float *C_X, *C_pl1, *C_pr1;
-  int32_t *C_orig;
-  int *cnt;  // [0] survivors of [4], [1] of [4-1], [2] of [5]
-  int *ctl;        // control block: [0] error flags of this frame; cleared here for the next frame
-  int ctl_words;
-  int *hdr_flags;  // out
-};
-__global__ __launch_bounds__(1024) void frame_finish_kernel(FinishArgs a) {
-  __shared__ int s_wave[16][3];
-  __shared__ int s_base[3];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid < 3) s_base[tid] = 0;
-  __syncthreads();
-  for (int c0 = 0; c0 < a.n; c0 += 1024) {
-    const int i = c0 + tid;
-    const int st = i < a.n ? a.stage[i] : 0;
-    const unsigned long long b1 = __ballot(st >= 1), b2 = __ballot(st >= 2), b3 = __ballot(st >= 3);
-    const int below = __popcll(b3 & ((1ull << lane) - 1ull));
-    if (lane == 0) {
-      s_wave[wave][0] = __popcll(b1);
-      s_wave[wave][1] = __popcll(b2);
-      s_wave[wave][2] = __popcll(b3);
-    }
-    __syncthreads();
-    int woff = 0;
-    for (int w = 0; w < wave; ++w) woff += s_wave[w][2];
-    const int base = s_base[2];
-    if (st >= 3) {
-      const int o = base + woff + below;
-      a.C_X[3 * o] = a.Xp[3 * i];
-      a.C_X[3 * o + 1] = a.Xp[3 * i + 1];
-      a.C_X[3 * o + 2] = a.Xp[3 * i + 2];
-      a.C_pl1[2 * o] = a.pl1[2 * i];
-      a.C_pl1[2 * o + 1] = a.pl1[2 * i + 1];
-      a.C_pr1[2 * o] = a.pr1[2 * i];
-      a.C_pr1[2 * o + 1] = a.pr1[2 * i + 1];
-      a.C_orig[o] = i;
-    }
-    __syncthreads();
-    if (tid < 3) {
-      int tot = 0;
-      for (int w = 0; w < 16; ++w) tot += s_wave[w][tid];
-      s_base[tid] += tot;
-    }
-    __syncthreads();
-  }
-  if (tid < 3) a.cnt[tid] = s_base[tid];
-  // every producer / consumer of the control block ran before this kernel: report, then reset
-  if (tid == 0) {
-    *a.hdr_flags = a.ctl[0];
-    a.cnt[3] = a.ctl[16 + IC_JAC_NT];  // features the strict-border pass replayed (0 when it is off)
-  }
-  __syncthreads();
-  for (int k = tid; k < a.ctl_words; k += 1024) a.ctl[k] = 0;
-}
-
 #ifdef FRAME_STAMP
 static int *vo_frame_dbg_ptr;
 extern "C" int vo_debug_frame_stamps(vo_ctx *c, int *dst, int rows) {
@@ -371,10 +310,10 @@ extern "C" int vo_debug_frame_stamps(vo_ctx *c, int *dst, int rows) {
 #endif
 
 // ---- host side ---------------------------------------------------------------------
-// phase 0: the per-feature kernel; phase 1: replay (strict) + final compaction. Two phases so that
+// phase 0: the per-feature kernel; phase 1: the strict-border replay (nothing otherwise). Two phases so that
 // the caller can feed other streams while the long first kernel is already running.
 template <int WIN>
-static void frame_launch(vo_ctx *c, const FrameArgs &a, const FinishArgs &f, int phase) {
+static void frame_launch(vo_ctx *c, const FrameArgs &a, int phase) {
   if (phase == 0) {
     vo_prof_begin(c, VO_K_KLT);
     hipLaunchKernelGGL(frame_track_kernel<WIN>, dim3(a.n + a.n_new), dim3(64), 0, c->stream, a);
@@ -388,9 +327,7 @@ static void frame_launch(vo_ctx *c, const FrameArgs &a, const FinishArgs &f, int
     hipLaunchKernelGGL(frame_tail_kernel<WIN>, dim3(a.n), dim3(64), 0, c->stream, a);
     vo_prof_end(c);
   }
-  vo_prof_begin(c, VO_K_AUX);
-  hipLaunchKernelGGL(frame_finish_kernel, dim3(1), dim3(1024), 0, c->stream, f);
-  vo_prof_end(c);
+  // (the frame's one compaction and the control-block reset are the prologue of the GN launch, gn_pose.hip)
 }
 
 int vo_frame_fused_supported(int win) { return win == 15 || win == 21 || win == 31; }
@@ -465,12 +402,10 @@ int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, 
   a.ic.cls = b.cls;
   a.ic.last_pu = b.lastpu;
   a.ic.n = n;
-  const FinishArgs f = {n, b.stage, d_X, b.pl1, b.pr1, b.C_X, b.C_pl1, b.C_pr1, b.C_orig, b.cnt, b.ctl,
-                        (int)(vo_ic_ctl_bytes() / 4), b.hdr_flags};
   switch (prm->win) {
-    case 15: frame_launch<15>(c, a, f, phase); break;
-    case 21: frame_launch<21>(c, a, f, phase); break;
-    case 31: frame_launch<31>(c, a, f, phase); break;
+    case 15: frame_launch<15>(c, a, phase); break;
+    case 21: frame_launch<21>(c, a, phase); break;
+    case 31: frame_launch<31>(c, a, phase); break;
     default: VO_FAIL(c, VO_ERR_INVALID, "fused frame kernel not instantiated for window %d", prm->win);
   }
   VO_CHECK_HIP(c, hipGetLastError());

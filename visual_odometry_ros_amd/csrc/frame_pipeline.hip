@@ -331,13 +331,34 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
   if (n == 0 && n_new > 0) VO_FAIL(c, VO_ERR_INVALID, "new-point candidates without a track set are not supported");
   // [6] stereo pose-only BA on the survivors (T01 init = constant-velocity prior; kept on NaN);
   // [7] its epilogue marks stage 4 for inliers that pass the y > 660 gate (thres_sampson = 60)
-  RC(vo_gn_enqueue(c, true, false, f->C_X, f->C_pl1, f->C_pr1, n, &cnt[2], prm->Kl, prm->Kr, prm->T_lr,
-                   prm->thres_poseba, 0, dT_prior, f->hdr->dT, f->mG, &f->hdr->gn, true, n > 0 ? f->stage : nullptr,
-                   f->C_orig, 4, 60.0f));
+  vo_gn_frame gf;
+  memset(&gf, 0, sizeof(gf));
+  if (fused) {
+    gf.n = n;
+    gf.stage = f->stage;
+    gf.X = d_X;
+    gf.pl1 = f->F_pl1;
+    gf.pr1 = f->F_pr1;
+    gf.C_X = f->C_X;
+    gf.C_pl1 = f->C_pl1;
+    gf.C_pr1 = f->C_pr1;
+    gf.C_orig = f->C_orig;
+    gf.cnt = cnt;
+    gf.ctl = f->ctl;
+    gf.ctl_words = (int)(vo_ic_ctl_bytes() / 4);
+    gf.nt_word = vo_ic_ctl_nt_word();
+    gf.hdr_flags = &f->hdr->flags;
+    gf.res_dev = f->res_dev;
+    gf.res_host = f->res_host;  // pinned host memory is device-visible: the kernel copies the block out itself
+    gf.res_bytes = f->res_bytes;
+  }
+  RC(vo_gn_enqueue(c, true, false, f->C_X, f->C_pl1, f->C_pr1, n, fused ? nullptr : &cnt[2], prm->Kl, prm->Kr,
+                   prm->T_lr, prm->thres_poseba, 0, dT_prior, f->hdr->dT, f->mG, &f->hdr->gn, true,
+                   n > 0 ? f->stage : nullptr, f->C_orig, 4, 60.0f, fused ? &gf : nullptr));
   if (n_new > 0 && !fused) VO_CHECK_HIP(c, hipStreamWaitEvent(s, c->ev_join, 0));
   VO_TT("gn launch");
-  // one D2H of the packed block into pinned memory
-  VO_CHECK_HIP(c, hipMemcpyAsync(f->res_host, f->res_dev, f->res_bytes, hipMemcpyDeviceToHost, s));
+  // one D2H of the packed block into pinned memory (general path; the fused path's GN launch did it)
+  if (!fused) VO_CHECK_HIP(c, hipMemcpyAsync(f->res_host, f->res_dev, f->res_bytes, hipMemcpyDeviceToHost, s));
   VO_TT("memcpy");
   VO_CHECK_HIP(c, hipEventRecord(f->ev_done, s));
   VO_TT("event");

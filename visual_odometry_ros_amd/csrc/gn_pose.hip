@@ -18,6 +18,7 @@
 // The summation tree is the balanced binary tree over the GN_T thread partials
 // in natural order — the oracle's VO_SUM_TREE with tree_width = GN_T.
 #include "vo_internal.hpp"
+#include "vo_kernels.hpp"
 
 #define GN_T 512
 #define GN_NW (GN_T / 64)
@@ -46,6 +47,22 @@ struct GnArgs {
   const int32_t *orig;
   int stage_val;
   float gate_thres;
+  // optional frame mode (frame_fused.hip): the kernel first does the one compaction of the frame
+  // (survivors = stage 3, in index order, + the three step counts), reports / resets the frame's
+  // control block, and at the end copies the packed result block to pinned host memory itself:
+  // two launches (compaction, D2H blit) fewer on the critical path of every frame
+  int f_n;                  // > 0: frame mode, features in input index space
+  const uint8_t *f_stage;   // [f_n]
+  const float *f_X, *f_pl1, *f_pr1;
+  float *f_CX, *f_Cpl1, *f_Cpr1;
+  int32_t *f_Corig;
+  int *f_cnt;               // [4]
+  int *f_ctl;               // control block; [0] = error flags, [16 + f_nt_word] = replayed features
+  int f_ctl_words, f_nt_word;
+  int *f_hdr_flags;
+  const uint32_t *f_res_dev;  // packed result block (device) -> f_res_host (pinned, device-visible)
+  uint32_t *f_res_host;
+  int f_res_words;
 };
 
 // upper-triangular index of (i,j), i<=j, row-major: matches oracle UT[][]
@@ -370,7 +387,55 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int n = a.d_n ? *a.d_n : a.n;
+  int n = a.d_n ? *a.d_n : a.n;
+  if (a.f_n > 0) {
+    // ---- frame mode prologue: survivors in index order + step counts (the one compaction of the frame) ----
+    int *s_wv = (int *)s_tot;  // [8][3] wave counts, then 3 running bases at [24..26]
+    if (tid < 3) s_wv[24 + tid] = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < a.f_n; c0 += GN_T) {
+      const int i = c0 + tid;
+      const int st = i < a.f_n ? a.f_stage[i] : 0;
+      const unsigned long long b1 = __ballot(st >= 1), b2 = __ballot(st >= 2), b3 = __ballot(st >= 3);
+      const int below = __popcll(b3 & ((1ull << lane) - 1ull));
+      if (lane == 0) {
+        s_wv[wave * 3 + 0] = __popcll(b1);
+        s_wv[wave * 3 + 1] = __popcll(b2);
+        s_wv[wave * 3 + 2] = __popcll(b3);
+      }
+      __syncthreads();
+      int woff = 0;
+      for (int w = 0; w < wave; ++w) woff += s_wv[w * 3 + 2];
+      const int base = s_wv[26];
+      if (st >= 3) {
+        const int o = base + woff + below;
+        a.f_CX[3 * o] = a.f_X[3 * i];
+        a.f_CX[3 * o + 1] = a.f_X[3 * i + 1];
+        a.f_CX[3 * o + 2] = a.f_X[3 * i + 2];
+        a.f_Cpl1[2 * o] = a.f_pl1[2 * i];
+        a.f_Cpl1[2 * o + 1] = a.f_pl1[2 * i + 1];
+        a.f_Cpr1[2 * o] = a.f_pr1[2 * i];
+        a.f_Cpr1[2 * o + 1] = a.f_pr1[2 * i + 1];
+        a.f_Corig[o] = i;
+      }
+      __syncthreads();
+      if (tid < 3) {
+        int tot = 0;
+        for (int w = 0; w < GN_NW; ++w) tot += s_wv[w * 3 + tid];
+        s_wv[24 + tid] += tot;
+      }
+      __syncthreads();
+    }
+    n = s_wv[26];
+    if (tid < 3) a.f_cnt[tid] = s_wv[24 + tid];
+    // every producer / consumer of the control block ran before this kernel: report, then reset
+    if (tid == 0) {
+      *a.f_hdr_flags = a.f_ctl[0];
+      a.f_cnt[3] = a.f_ctl[16 + a.f_nt_word];
+    }
+    __syncthreads();  // (also: the compacted arrays written above are read below by other threads)
+    for (int k = tid; k < a.f_ctl_words; k += GN_T) a.f_ctl[k] = 0;
+  }
   float T10[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) T10[k] = a.d_T10 ? a.d_T10[k] : a.T10[k];
@@ -553,6 +618,11 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
       a.info->is_nan = is_nan;
     }
   }
+  if (a.f_n > 0 && a.f_res_host) {
+    // frame mode epilogue: the packed result block goes to pinned host memory from here
+    __syncthreads();  // stage marks, pose and info above are this workgroup's own stores
+    for (int k = tid; k < a.f_res_words; k += GN_T) a.f_res_host[k] = a.f_res_dev[k];
+  }
 }
 
 // ---- host side ---------------------------------------------------------------
@@ -601,9 +671,28 @@ int vo_gn_enqueue(vo_ctx *c, bool stereo, bool mono_general_inverse, const float
                   const float *dP2, int n, const int *d_n, const float Kl[4], const float Kr[4],
                   const float T_lr[16], float thres, int variant, const float T01_init[16],
                   float *d_Tout, uint8_t *d_mask, vo_gn_dev_info *d_info, bool write_init_on_nan, uint8_t *d_stage,
-                  const int32_t *d_orig, int stage_val, float gate_thres) {
+                  const int32_t *d_orig, int stage_val, float gate_thres, const vo_gn_frame *frame) {
   GnArgs a;
   memset(&a, 0, sizeof(a));
+  if (frame && frame->n > 0) {
+    a.f_n = frame->n;
+    a.f_stage = frame->stage;
+    a.f_X = frame->X;
+    a.f_pl1 = frame->pl1;
+    a.f_pr1 = frame->pr1;
+    a.f_CX = frame->C_X;
+    a.f_Cpl1 = frame->C_pl1;
+    a.f_Cpr1 = frame->C_pr1;
+    a.f_Corig = frame->C_orig;
+    a.f_cnt = frame->cnt;
+    a.f_ctl = frame->ctl;
+    a.f_ctl_words = frame->ctl_words;
+    a.f_nt_word = frame->nt_word;
+    a.f_hdr_flags = frame->hdr_flags;
+    a.f_res_dev = (const uint32_t *)frame->res_dev;
+    a.f_res_host = (uint32_t *)frame->res_host;
+    a.f_res_words = (int)((frame->res_bytes + 3) / 4);
+  }
   a.X = dX;
   a.p1 = dP1;
   a.p2 = dP2;

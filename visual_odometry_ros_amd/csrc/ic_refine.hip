@@ -202,8 +202,9 @@ static int ic_records(vo_ctx *c, IcArgs &a) {
 
 // IcArgs for the fused frame kernel: image levels and (strict border) the tap records. `ctl` is the
 // frame's own control block: ctl[0] = error flags, ctl[16..] = replay control words. It is zeroed
-// once at allocation and re-zeroed by frame_finish_kernel at the end of every frame.
+// once at allocation and re-zeroed by the GN launch (frame mode prologue) at the end of every frame.
 size_t vo_ic_ctl_bytes() { return 64 + IC_JAC_BYTES; }
+int vo_ic_ctl_nt_word() { return IC_JAC_NT; }
 int vo_ic_frame_args(vo_ctx *c, int slot0, int slot1, IcArgs *a, int *ctl, bool with_records) {
   memset(a, 0, sizeof(*a));
   int rc = ic_args(c, slot0, slot1, *a, ctl);

@@ -5,12 +5,27 @@
 #include "vo_internal.hpp"
 
 // gn_pose.hip
+// frame mode of the GN launch (fused frame path): compaction prologue + result copy-out epilogue
+struct vo_gn_frame {
+  int n;                    // features in input index space
+  const uint8_t *stage;
+  const float *X, *pl1, *pr1;
+  float *C_X, *C_pl1, *C_pr1;
+  int32_t *C_orig;
+  int *cnt;
+  int *ctl;
+  int ctl_words, nt_word;
+  int *hdr_flags;
+  const void *res_dev;
+  void *res_host;           // pinned, device-visible; null = no copy-out
+  size_t res_bytes;
+};
 int vo_gn_enqueue(vo_ctx *c, bool stereo, bool mono_general_inverse, const float *dX, const float *dP1,
                   const float *dP2, int n, const int *d_n, const float Kl[4], const float Kr[4],
                   const float T_lr[16], float thres, int variant, const float T01_init[16],
                   float *d_Tout, uint8_t *d_mask, vo_gn_dev_info *d_info, bool write_init_on_nan = false,
                   uint8_t *d_stage = nullptr, const int32_t *d_orig = nullptr, int stage_val = 0,
-                  float gate_thres = 0.f);
+                  float gate_thres = 0.f, const vo_gn_frame *frame = nullptr);
 
 // pyramid.hip
 int vo_pyr_levels_host(int w, int h, int win, int max_level);
@@ -41,6 +56,7 @@ int vo_ic_strict_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, c
 // the frame kernel's view of the IC state (ic_refine.hip); IcArgs lives in ic_device.hpp
 struct IcArgs;
 size_t vo_ic_ctl_bytes();
+int vo_ic_ctl_nt_word();
 int vo_ic_frame_args(vo_ctx *c, int slot0, int slot1, IcArgs *a, int *ctl, bool with_records);
 void vo_ic_strict_launch(vo_ctx *c, const IcArgs &a);
 
