@@ -22,6 +22,6 @@ for k in range(1, 7):
     print(f"frame {k}: replayed {g['counts'].n_replayed:4d}  looks->reruns {d[32]:4d} publishes {d[33]:4d}  quiescent at {(int(d[0]) - t0) / 100:6.1f} us, tails done at {(int(d[2]) - t0) / 100:6.1f} us")
     rows = dbg[80:].reshape(512, 4); rows = rows[rows[:, 1] > 0]
     st_, en, it = (rows[:, 0] - t0) / 100.0, (rows[:, 1] - t0) / 100.0, rows[:, 2]
-    o = np.argsort(en)[-6:]
+    o = np.argsort(en)[-14:]
     print("   last finishers (pt, start, end, iters):", [(int(rows[i, 3]), round(float(st_[i]), 1), round(float(en[i]), 1), int(it[i])) for i in o])
     print(f"   run time: mean {np.mean(en - st_):.1f} us, iters mean {it.mean():.1f}; runs with 30 iters: {(it >= 30).sum()}; first starts: {np.sort(st_)[:3].round(1)}")

@@ -276,21 +276,25 @@ struct IcResult {
   int err_flag;  // 1 ax/ay NaN, 2 patch NaN, 4 update NaN (the reference throws)
 };
 
-// One point, feature_tracker.cpp:336-503: template at pt0 in I0, refinement in I1 from the prior
-// pt1. All 64 lanes call it together with the same arguments; nothing is written to memory.
+// What a feature needs before it can iterate: the template applied to the state, the inverse of the
+// 2x2 system and the search tile in LDS. Independent of the I1 part of the state, so the strict
+// replay prepares a feature while it still waits for its I1 inputs.
+struct IcPrep {
+  int cls;  // 1: rejected before iterating (range or determinant test), 2: ready to iterate
+  float iD_A11, iD_A12, iD_A22;
+  IcTile tile;  // search tile staged in sh.tj
+};
 template <bool STRICT>
-__device__ IcResult ic_point(const vo_level &I0, const vo_level &I1, const IcTaps &tp, float pt0x, float pt0y,
-                             float pt1x, float pt1y, float scale, int lane, IcShared &sh, IcState &S, int &touched,
-                             float &last_pux, float &last_puy, int &n_iter) {
-  IcResult res;
-  res.cls = 1;
-  res.ok = 0;
-  res.x = pt1x;
-  res.y = pt1y;
-  res.err_flag = 0;
+__device__ __forceinline__ IcPrep ic_prepare(const vo_level &I0, const vo_level &I1, const IcTaps &tp, float pt0x,
+                                             float pt0y, float pt1x, float pt1y, int lane, IcShared &sh, IcState &S,
+                                             int &touched) {
+  IcPrep pr;
+  pr.cls = 1;
+  pr.iD_A11 = pr.iD_A12 = pr.iD_A22 = 0.f;
+  pr.tile.x0 = pr.tile.y0 = 0;
   float ax, ay, axay;
   ic_frac(pt0x, pt0y, ax, ay, axay);
-  if (ax < 0 || ax > 1 || ay < 0 || ay > 1) return res;
+  if (ax < 0 || ax > 1 || ay < 0 || ay > 1) return pr;
   IcTRegs rt;
   IcJRegs rj;
   ic_template_fetch(I0, pt0x, pt0y, lane, rt);
@@ -309,15 +313,37 @@ __device__ IcResult ic_point(const vo_level &I0, const vo_level &I1, const IcTap
   ic_wave_sum4(acc);
   const float A11 = acc[0], A12 = acc[1], A22 = acc[2];
   const float D = A11 * A22 - A12 * A12;
-  if (D < 1e-4f) return res;
+  if (D < 1e-4f) return pr;
   const float invD = (float)(1.0 / (double)D);
-  const float iD_A11 = A11 * invD, iD_A12 = A12 * invD, iD_A22 = A22 * invD;
+  pr.iD_A11 = A11 * invD;
+  pr.iD_A12 = A12 * invD;
+  pr.iD_A22 = A22 * invD;
+  ic_tile_commit<IC_JN, IC_JW, IC_JH>(rj, lane, sh.tj);
+  pr.tile.x0 = rj.x0;
+  pr.tile.y0 = rj.y0;
+  pr.cls = 2;
+  return pr;
+}
 
+// The iterations of one prepared feature (feature_tracker.cpp:398-503).
+template <bool STRICT>
+__device__ __forceinline__ IcResult ic_iterate(const vo_level &I1, const IcTaps &tp, const IcPrep &pr, float pt0x,
+                                               float pt0y, float pt1x, float pt1y, float scale, int lane,
+                                               const IcShared &sh, IcState &S, int &touched, float &last_pux,
+                                               float &last_puy, int &n_iter) {
+  IcResult res;
+  res.cls = pr.cls;
+  res.ok = 0;
+  res.x = pt1x;
+  res.y = pt1y;
+  res.err_flag = 0;
+  if (pr.cls != 2) return res;
+  const float iD_A11 = pr.iD_A11, iD_A12 = pr.iD_A12, iD_A22 = pr.iD_A22;
+  const IcTile tile = pr.tile;
+  float ax, ay, axay;
   float err_curr = 0.f, err_prev = 1e12f;
   float tx = pt1x - pt0x, ty = pt1y - pt0y;
   int err_flag = 0;
-  ic_tile_commit<IC_JN, IC_JW, IC_JH>(rj, lane, sh.tj);
-  const IcTile tile = {rj.x0, rj.y0};
   float sx[IC_K], sy[IC_K];
 #pragma unroll
   for (int k = 0; k < IC_K; ++k) {
@@ -384,6 +410,16 @@ __device__ IcResult ic_point(const vo_level &I0, const vo_level &I1, const IcTap
     res.y = pt0y + ty;
   }
   return res;
+}
+
+// One point, feature_tracker.cpp:336-503: template at pt0 in I0, refinement in I1 from the prior
+// pt1. All 64 lanes call it together with the same arguments; nothing is written to memory.
+template <bool STRICT>
+__device__ __forceinline__ IcResult ic_point(const vo_level &I0, const vo_level &I1, const IcTaps &tp, float pt0x,
+                                             float pt0y, float pt1x, float pt1y, float scale, int lane, IcShared &sh,
+                                             IcState &S, int &touched, float &last_pux, float &last_puy, int &n_iter) {
+  const IcPrep pr = ic_prepare<STRICT>(I0, I1, tp, pt0x, pt0y, pt1x, pt1y, lane, sh, S, touched);
+  return ic_iterate<STRICT>(I1, tp, pr, pt0x, pt0y, pt1x, pt1y, scale, lane, sh, S, touched, last_pux, last_puy, n_iter);
 }
 
 // ic_point on array operands: inputs of point `pt` from a.pts0 / a.pts_prior / a.scale, results to
@@ -549,6 +585,10 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
   IcState S0;
   ic_state_clear(S0);
   unsigned seen = 0;
+  IcPrep prep;  // single mode: the feature is prepared (template, 2x2 inverse, search tile) ahead of its inputs
+  prep.cls = 0;
+  prep.iD_A11 = prep.iD_A12 = prep.iD_A22 = 0.f;
+  prep.tile.x0 = prep.tile.y0 = 0;
   int result = P;
   for (int pass = 0;; ++pass) {
     // ---- look ----
@@ -632,6 +672,12 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
           if (((tp.on >> k) & 1u) && (uc < 1 || uc >= fw1 || vc < 1 || vc >= fh1)) seen |= 1u << k;
         }
         __syncthreads();
+        if (single) {
+          // S0 becomes the state after the feature's own template evaluation (static, like its inputs)
+          int dummy_t = 0;
+          prep = ic_prepare<true>(a.I0, a.I1, tp, p0x, p0y, a.pts_prior[2 * pt], a.pts_prior[2 * pt + 1], lane, sh, S0,
+                                  dummy_t);
+        }
       } else if (skip_pt) {
         continue;
       }
@@ -687,7 +733,9 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
         for (int k = 0; k < IC_K; ++k)
           if ((seen >> k) & 1u) {
             const int src = rs.src[lane + 64 * k];
-            if (src >= 0 && a.touched[src] && !ic_ld8(&a.ready[src])) wait = true;
+            const int sq = src >= 0 ? src : 0;
+            const int tq = a.touched[sq], rq = ic_ld8(&a.ready[sq]);  // both loads in flight together
+            if (src >= 0 && tq && !rq) wait = true;
           }
         if (!__any(wait)) break;
         if (attempt >= 64) {
@@ -700,7 +748,9 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
           for (int k = 0; k < IC_K; ++k)
             if ((seen >> k) & 1u) {
               const int src = rs.src[lane + 64 * k];
-              if (src >= 0 && a.touched[src] && !ic_ld8(&a.ready[src])) w2 = true;
+              const int sq = src >= 0 ? src : 0;
+              const int tq = a.touched[sq], rq = ic_ld8(&a.ready[sq]);
+              if (src >= 0 && tq && !rq) w2 = true;
             }
           if (!__any(w2)) break;
           if (__builtin_amdgcn_readfirstlane(ic_ld(ovf)) || ++polls > IC_SPIN_LIMIT) {
@@ -729,7 +779,7 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
       {
         float *p1 = a.pre1 + (size_t)pt * IC_NELEM;
         uint32_t *pm = a.preM + (size_t)pt * IC_MW;
-        int diff = !ic_ld8(&a.ready[pt]);  // the first strict-state run is unconditional
+        int diff = __builtin_amdgcn_readfirstlane(!ic_ld8(&a.ready[pt]));  // the first strict-state run is unconditional
         if (!diff) {
 #pragma unroll
           for (int k = 0; k < IC_K; ++k)
@@ -753,7 +803,19 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
 #ifdef IC_STAMP
       if (lane == 0 && li < 512) a.tlist[IC_DBG_OFF + 64 + 4 * li + 0] = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff);
 #endif
-      const IcResult res_pt = ic_point_io<true>(a, tp, pt, lane, sh, S, dummy, lx, ly, n_iter);
+      IcResult res_pt;
+      {
+        const float q1x = a.pts_prior[2 * pt], q1y = a.pts_prior[2 * pt + 1];
+        IcPrep pr = prep;
+        if (!single) pr = ic_prepare<true>(a.I0, a.I1, tp, p0x, p0y, q1x, q1y, lane, sh, S, dummy);
+        res_pt = ic_iterate<true>(a.I1, tp, pr, p0x, p0y, q1x, q1y, a.scale[pt], lane, sh, S, dummy, lx, ly, n_iter);
+        if (lane == 0) {
+          if (res_pt.err_flag) atomicOr(a.flags, res_pt.err_flag);
+          a.pts_track[2 * pt] = res_pt.x;
+          a.pts_track[2 * pt + 1] = res_pt.y;
+          a.mask[pt] = (uint8_t)res_pt.ok;
+        }
+      }
 #ifdef IC_STAMP
       if (lane == 0 && li < 512) {
         a.tlist[IC_DBG_OFF + 64 + 4 * li + 1] = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff);
