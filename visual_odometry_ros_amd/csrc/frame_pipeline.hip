@@ -351,6 +351,7 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
     gf.res_dev = f->res_dev;
     gf.res_host = f->res_host;  // pinned host memory is device-visible: the kernel copies the block out itself
     gf.res_bytes = f->res_bytes;
+    gf.res_late_bytes = f->off_mnew;  // header + stage bytes
   }
   RC(vo_gn_enqueue(c, true, false, f->C_X, f->C_pl1, f->C_pr1, n, fused ? nullptr : &cnt[2], prm->Kl, prm->Kr,
                    prm->T_lr, prm->thres_poseba, 0, dT_prior, f->hdr->dT, f->mG, &f->hdr->gn, true,

@@ -63,6 +63,7 @@ struct GnArgs {
   const uint32_t *f_res_dev;  // packed result block (device) -> f_res_host (pinned, device-visible)
   uint32_t *f_res_host;
   int f_res_words;
+  int f_res_late_words;     // leading words (header, stage bytes) that this kernel still changes: copied last
 };
 
 // upper-triangular index of (i,j), i<=j, row-major: matches oracle UT[][]
@@ -435,6 +436,9 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
     }
     __syncthreads();  // (also: the compacted arrays written above are read below by other threads)
     for (int k = tid; k < a.f_ctl_words; k += GN_T) a.f_ctl[k] = 0;
+    // the pixel arrays and new-point results are final: their copy to the host runs under the iterations
+    if (a.f_res_host)
+      for (int k = a.f_res_late_words + tid; k < a.f_res_words; k += GN_T) a.f_res_host[k] = a.f_res_dev[k];
   }
   float T10[16];
 #pragma unroll
@@ -621,7 +625,7 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
   if (a.f_n > 0 && a.f_res_host) {
     // frame mode epilogue: the packed result block goes to pinned host memory from here
     __syncthreads();  // stage marks, pose and info above are this workgroup's own stores
-    for (int k = tid; k < a.f_res_words; k += GN_T) a.f_res_host[k] = a.f_res_dev[k];
+    for (int k = tid; k < a.f_res_late_words; k += GN_T) a.f_res_host[k] = a.f_res_dev[k];
   }
 }
 
@@ -692,6 +696,7 @@ int vo_gn_enqueue(vo_ctx *c, bool stereo, bool mono_general_inverse, const float
     a.f_res_dev = (const uint32_t *)frame->res_dev;
     a.f_res_host = (uint32_t *)frame->res_host;
     a.f_res_words = (int)((frame->res_bytes + 3) / 4);
+    a.f_res_late_words = (int)(frame->res_late_bytes / 4);
   }
   a.X = dX;
   a.p1 = dP1;

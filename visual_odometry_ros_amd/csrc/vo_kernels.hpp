@@ -19,6 +19,7 @@ struct vo_gn_frame {
   const void *res_dev;
   void *res_host;           // pinned, device-visible; null = no copy-out
   size_t res_bytes;
+  size_t res_late_bytes;    // leading part (header + stage bytes, multiple of 16) the GN launch itself still writes
 };
 int vo_gn_enqueue(vo_ctx *c, bool stereo, bool mono_general_inverse, const float *dX, const float *dP1,
                   const float *dP2, int n, const int *d_n, const float Kl[4], const float Kr[4],
