@@ -32,15 +32,22 @@ def build(force=False, verbose=False):
     objs = []
     hdr_m = max(os.path.getmtime(h) for h in headers())
     relink = force or not os.path.exists(LIB)
+    jobs = []
     for src in sources():
         obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_m):
-            cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+            jobs.append([HIPCC] + FLAGS + ["-c", src, "-o", obj])
+    if jobs:
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
-            relink = True
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:  # one hipcc per translation unit
+            list(ex.map(run, jobs))
+        relink = True
     if relink:
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
