@@ -169,6 +169,18 @@ int vo_sampson_distance(vo_ctx *ctx, const float *pts0, const float *pts1, int n
 int vo_symmetric_epipolar_distance(vo_ctx *ctx, const float *pts0, const float *pts1, int n,
                                    const float F10[9], float *dist);
 
+/* ---- FeatureExtractor bucketing (the reference-owned part; cv::ORB::detect stays on the host) */
+/* WeightBin::reset + update, feature_extractor.h:120-135: weight[v*n_bins_u+u] = 0 for bins that hold a
+ * point (u = floor(x / u_step), only the flattened index is range-tested, as in the reference), else 1. */
+int vo_weight_bin_update(vo_ctx *ctx, const float *pts, int n, int u_step, int v_step, int n_bins_u,
+                         int n_bins_v, int32_t *weight);
+/* The flag_nonmax_ branch of extractORBwithBinning_fast, feature_extractor.cpp:241-277: per bin with
+ * weight > 0 the FIRST keypoint (detector order) of largest response; bins ascending. kp_xy / kp_response:
+ * the n keypoints cv::ORB::detect returned (n <= vo_config.max_points). idx_out may be NULL. */
+int vo_bucket_argmax(vo_ctx *ctx, const float *kp_xy, const float *kp_response, int n, float inv_u_step,
+                     float inv_v_step, int n_bins_u, int n_bins_v, const int32_t *weight, float *pts_out,
+                     int32_t *idx_out, int *n_out);
+
 /* ---- FeatureExtractor::descriptorDistance (feature_extractor.cpp:338-357) - */
 /* all-pairs 256-bit Hamming distance, dist is na x nb row-major */
 int vo_orb_hamming(vo_ctx *ctx, const uint8_t *a, int na, const uint8_t *b, int nb,

@@ -245,6 +245,30 @@ def calc_prior(pts0, Xw, Tw1, K):
     return out
 
 
+def weight_bin_init(n_cols, n_rows, n_bins_u, n_bins_v):
+    us, vs, iu, iv = C.c_int(), C.c_int(), C.c_float(), C.c_float()
+    lib().vo_ref_weight_bin_init(n_cols, n_rows, n_bins_u, n_bins_v, C.byref(us), C.byref(vs), C.byref(iu), C.byref(iv))
+    return us.value, vs.value, np.float32(iu.value), np.float32(iv.value)
+
+
+def weight_bin_update(pts, u_step, v_step, n_bins_u, n_bins_v):
+    pts = _f32(pts).reshape(-1, 2)
+    w = np.zeros(max(n_bins_u * n_bins_v, 1), np.int32)
+    lib().vo_ref_weight_bin_update(_p(pts), pts.shape[0], u_step, v_step, n_bins_u, n_bins_v, _p(w, C.c_int32))
+    return w[: n_bins_u * n_bins_v]
+
+
+def bucket_argmax(kp_xy, kp_response, inv_u_step, inv_v_step, n_bins_u, n_bins_v, weight):
+    kp, r = _f32(kp_xy).reshape(-1, 2), _f32(kp_response)
+    w = np.ascontiguousarray(weight, np.int32)
+    tot = n_bins_u * n_bins_v
+    out, idx = np.zeros((max(tot, 1), 2), np.float32), np.zeros(max(tot, 1), np.int32)
+    lib().vo_ref_bucket_argmax.restype = C.c_int
+    m = lib().vo_ref_bucket_argmax(_p(kp), _p(r), kp.shape[0], C.c_float(inv_u_step), C.c_float(inv_v_step), n_bins_u,
+                                   n_bins_v, _p(w, C.c_int32), _p(out), _p(idx, C.c_int32))
+    return out[:m].copy(), idx[:m].copy()
+
+
 def sampson_distance(pts0, pts1, F10):
     pts0, pts1, F = _f32(pts0).reshape(-1, 2), _f32(pts1).reshape(-1, 2), _f32(F10).reshape(9)
     out = np.zeros(max(pts0.shape[0], 1), np.float32)

@@ -320,3 +320,61 @@ void vo_ref_fundamental_from_pose(const float K[4], const float R10[9], const fl
   mat3_mul(KinvT, E, T);
   mat3_mul(T, Kinv, F10);
 }
+
+/* ---- feature bucketing (the reference-owned part; cv::ORB::detect stays third-party) ----
+ * WeightBin::init / reset / update (core/visual_odometry/feature_extractor.h:90-135) and the
+ * flag_nonmax_ branch of FeatureExtractor::extractORBwithBinning_fast (feature_extractor.cpp:241-277). */
+void vo_ref_weight_bin_init(int n_cols, int n_rows, int n_bins_u, int n_bins_v, int *u_step, int *v_step,
+                            float *inv_u_step, float *inv_v_step) {
+  *u_step = (int)floor((float)n_cols / (float)n_bins_u); /* :108-109 */
+  *v_step = (int)floor((float)n_rows / (float)n_bins_v);
+  *inv_u_step = 1.0f / (float)*u_step;                   /* :111-112 */
+  *inv_v_step = 1.0f / (float)*v_step;
+}
+/* reset() then update(pts): a bin that holds a tracked point gets weight 0. The reference tests only the
+ * flattened index (:130), so a point right of the last column lands in the next row: reproduced. */
+void vo_ref_weight_bin_update(const float *pts, int n, int u_step, int v_step, int n_bins_u, int n_bins_v,
+                              int32_t *weight) {
+  const int total = n_bins_u * n_bins_v;
+  for (int i = 0; i < total; ++i) weight[i] = 1;
+  for (int i = 0; i < n; ++i) {
+    const int u_idx = (int)floor((float)pts[2 * i] / (float)u_step);
+    const int v_idx = (int)floor((float)pts[2 * i + 1] / (float)v_step);
+    const int bin_idx = v_idx * n_bins_u + u_idx;
+    if (bin_idx >= 0 && bin_idx < total) weight[bin_idx] = 0;
+  }
+}
+/* one keypoint per wanted bin: the FIRST keypoint (detector order) with the largest response, bins in
+ * ascending order. Returns the number of points; idx_out[k] = index of the chosen keypoint. */
+int vo_ref_bucket_argmax(const float *kp_xy, const float *kp_response, int n, float inv_u_step, float inv_v_step,
+                         int n_bins_u, int n_bins_v, const int32_t *weight, float *pts_out, int32_t *idx_out) {
+  const int total = n_bins_u * n_bins_v;
+  int *index_max = (int *)malloc(sizeof(int) * (size_t)(total > 0 ? total : 1));
+  float *max_score = (float *)malloc(sizeof(float) * (size_t)(total > 0 ? total : 1));
+  for (int j = 0; j < total; ++j) {
+    index_max[j] = -1;
+    max_score[j] = -1.0f;
+  }
+  for (int i = 0; i < n; ++i) {
+    const unsigned int u = (unsigned int)(int)floor(kp_xy[2 * i] * inv_u_step);
+    const unsigned int v = (unsigned int)(int)floor(kp_xy[2 * i + 1] * inv_v_step);
+    if (u >= (unsigned int)n_bins_u || v >= (unsigned int)n_bins_v) continue; /* (the reference reads weight[] first: UB) */
+    const int bin_idx = (int)(v * (unsigned int)n_bins_u + u);
+    if (weight[bin_idx] == 0) continue;
+    if (max_score[bin_idx] < kp_response[i]) {
+      index_max[bin_idx] = i;
+      max_score[bin_idx] = kp_response[i];
+    }
+  }
+  int m = 0;
+  for (int j = 0; j < total; ++j)
+    if (index_max[j] > -1 && weight[j] > 0) {
+      pts_out[2 * m] = kp_xy[2 * index_max[j]];
+      pts_out[2 * m + 1] = kp_xy[2 * index_max[j] + 1];
+      idx_out[m] = index_max[j];
+      ++m;
+    }
+  free(index_max);
+  free(max_score);
+  return m;
+}

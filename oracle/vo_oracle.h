@@ -176,6 +176,14 @@ void vo_ref_symmetric_epipolar_distance(const float *pts0, const float *pts1, in
                                         float *dist);
 void vo_ref_fundamental_from_pose(const float K[4], const float R10[9], const float t10[3], float F10[9]);
 
+/* feature bucketing: feature_extractor.h:90-135 (WeightBin), feature_extractor.cpp:241-277 (arg-max per bin) */
+void vo_ref_weight_bin_init(int n_cols, int n_rows, int n_bins_u, int n_bins_v, int *u_step, int *v_step,
+                            float *inv_u_step, float *inv_v_step);
+void vo_ref_weight_bin_update(const float *pts, int n, int u_step, int v_step, int n_bins_u, int n_bins_v,
+                              int32_t *weight);
+int vo_ref_bucket_argmax(const float *kp_xy, const float *kp_response, int n, float inv_u_step, float inv_v_step,
+                         int n_bins_u, int n_bins_v, const int32_t *weight, float *pts_out, int32_t *idx_out);
+
 #ifdef __cplusplus
 }
 #endif

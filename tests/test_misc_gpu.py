@@ -96,3 +96,28 @@ def test_epipolar_distance_errors(ctx, vo):
     with pytest.raises(vo.VoError):
         me.calcSampsonDistance(np.zeros((3, 2)), np.zeros((4, 2)), F10=np.eye(3))
     assert me.calcSampsonDistance(np.zeros((0, 2)), np.zeros((0, 2)), F10=np.eye(3)).size == 0
+
+
+@pytest.mark.parametrize("n_kp,seed", [(0, 1), (1, 2), (777, 3), (8000, 4)])
+def test_bucketing_bit_exact(ctx, vo, oracle, n_kp, seed):
+    """WeightBin update + arg-max per bin (feature_extractor.h:90-135, feature_extractor.cpp:241-277) vs oracle."""
+    rng = np.random.default_rng(seed)
+    W, H, nu, nv = 1241, 376, 60, 25
+    fe = vo.FeatureExtractor(ctx)
+    fe.initParams(W, H, nu, nv)
+    us, vs, iu, iv = oracle.weight_bin_init(W, H, nu, nv)
+    assert (fe.u_step, fe.v_step) == (us, vs) and fe.inv_u_step_ == iu and fe.inv_v_step_ == iv
+    tracked = np.stack([rng.uniform(-5, W + 30, 600), rng.uniform(-5, H + 10, 600)], 1).astype(np.float32)
+    w_g = fe.updateWeightBin(tracked)
+    assert np.array_equal(w_g, oracle.weight_bin_update(tracked, us, vs, nu, nv))
+    kp = np.stack([rng.uniform(-3, W + 3, n_kp), rng.uniform(-3, H + 3, n_kp)], 1).astype(np.float32)
+    resp = (rng.integers(0, 50, n_kp).astype(np.float32) - 2) * np.float32(1e-4)  # ties, a few <= 0
+    if n_kp > 10:
+        resp[3], resp[5] = np.nan, -1.0  # never selected
+    p_g, i_g = fe.bucketKeypoints(kp, resp)
+    p_o, i_o = oracle.bucket_argmax(kp, resp, iu, iv, nu, nv, w_g)
+    assert np.array_equal(i_g, i_o) and np.array_equal(p_g.view(np.uint32), p_o.view(np.uint32))
+    if n_kp >= 777:
+        assert i_g.size > 100
+    # an empty tracked set leaves every bin wanted
+    assert fe.updateWeightBin(np.zeros((0, 2), np.float32)).sum() == nu * nv

@@ -228,3 +228,33 @@ def test_epipolar_distances_vs_float64(oracle):
     assert np.allclose(e_o, e_ref, rtol=2e-2, atol=5e-3)
     assert oracle.sampson_distance(p0[:, :2], p1[:, :2], F64).max() < 5e-3
     assert oracle.sampson_distance(np.zeros((0, 2)), np.zeros((0, 2)), F64).size == 0
+
+
+def test_bucketing_vs_python(oracle):
+    """WeightBin update and arg-max per bin (feature_extractor.h:90-135, feature_extractor.cpp:241-277)
+    against a plain-Python restatement."""
+    rng = np.random.default_rng(5)
+    W, H, nu, nv = 1241, 376, 60, 25
+    us, vs, iu, iv = oracle.weight_bin_init(W, H, nu, nv)
+    assert (us, vs) == (20, 15) and iu == np.float32(1) / np.float32(20)
+    pts = np.stack([rng.uniform(-5, W + 30, 700), rng.uniform(-5, H + 10, 700)], 1).astype(np.float32)
+    w = oracle.weight_bin_update(pts, us, vs, nu, nv)
+    w_py = np.ones(nu * nv, np.int32)
+    for x, y in pts:
+        b = int(np.floor(np.float32(y) / np.float32(vs))) * nu + int(np.floor(np.float32(x) / np.float32(us)))
+        if 0 <= b < nu * nv:
+            w_py[b] = 0
+    assert np.array_equal(w, w_py) and 0 < w.sum() < w.size
+    kp = np.stack([rng.uniform(-3, W + 3, 5000), rng.uniform(-3, H + 3, 5000)], 1).astype(np.float32)
+    resp = rng.integers(0, 40, 5000).astype(np.float32) * np.float32(1e-4)  # many ties
+    out, idx = oracle.bucket_argmax(kp, resp, iu, iv, nu, nv, w)
+    best = {}
+    for i, ((x, y), r) in enumerate(zip(kp, resp)):
+        u, v = int(np.floor(x * iu)), int(np.floor(y * iv))
+        if not (0 <= u < nu and 0 <= v < nv) or w[v * nu + u] == 0:
+            continue
+        b = v * nu + u
+        if b not in best or best[b][0] < r:
+            best[b] = (r, i)
+    exp = [best[b][1] for b in sorted(best)]
+    assert list(idx) == exp and np.array_equal(out, kp[exp])

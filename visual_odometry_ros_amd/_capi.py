@@ -46,7 +46,7 @@ SYMBOLS = [
     "vo_synchronize", "vo_set_image", "vo_set_image_device", "vo_swap_slots", "vo_pyramid_levels",
     "vo_get_level", "vo_klt_track", "vo_track", "vo_track_bidirection",
     "vo_track_bidirection_with_prior", "vo_track_with_prior", "vo_calc_prior",
-    "vo_sampson_distance", "vo_symmetric_epipolar_distance",
+    "vo_sampson_distance", "vo_symmetric_epipolar_distance", "vo_weight_bin_update", "vo_bucket_argmax",
     "vo_track_with_scale", "vo_gn_pose_mono", "vo_gn_pose_stereo", "vo_orb_hamming",
     "vo_orb_match", "vo_compact_indices", "vo_stereo_frame_set_strict_border",
     "vo_stereo_frame_enqueue", "vo_stereo_frame_result",

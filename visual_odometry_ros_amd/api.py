@@ -254,6 +254,12 @@ class MotionEstimator:
         return bool(rc), T.reshape(4, 4), mask[:n].astype(bool), info
 
 
+    def setThres1p(self, thres_1p):  # motion_estimator.cpp:655-658 (consumed by the host-side 1-point RANSAC)
+        self.thres_1p_ = float(thres_1p)
+
+    def setThres5p(self, thres_5p):  # :660-663
+        self.thres_5p_ = float(thres_5p)
+
     # ---- epipolar gates (motion_estimator.cpp:538-653) ----
     @staticmethod
     def fundamentalFromPose(K, R10, t10):
@@ -295,11 +301,61 @@ class MotionEstimator:
 
 
 class FeatureExtractor:
-    """descriptorDistance (feature_extractor.cpp:338-357) for whole descriptor sets."""
+    """descriptorDistance (feature_extractor.cpp:338-357) for whole descriptor sets, and the
+    reference-owned bucketing around cv::ORB::detect: WeightBin (feature_extractor.h:58-135) and the
+    arg-max-per-bin selection of extractORBwithBinning_fast (feature_extractor.cpp:241-277)."""
 
     def __init__(self, ctx):
         self.ctx = ctx
         self.lib = ctx.lib
+        self.n_bins_u_ = self.n_bins_v_ = 0
+
+    def initParams(self, n_cols, n_rows, n_bins_u, n_bins_v, THRES_FAST=15, radius=5):
+        """feature_extractor.cpp:26-69 minus cv::ORB::create: WeightBin::init (feature_extractor.h:90-118)."""
+        f = np.float32
+        self.n_bins_u_, self.n_bins_v_ = int(n_bins_u), int(n_bins_v)
+        self.u_step = int(np.floor(f(n_cols) / f(n_bins_u)))
+        self.v_step = int(np.floor(f(n_rows) / f(n_bins_v)))
+        self.inv_u_step_ = f(1.0) / f(self.u_step)
+        self.inv_v_step_ = f(1.0) / f(self.v_step)
+        self.weight = np.ones(self.n_bins_u_ * self.n_bins_v_, np.int32)
+
+    def resetWeightBin(self):
+        self.weight[:] = 1
+
+    def suppressCenterBins(self):
+        """feature_extractor.cpp:76-92 (host-side: a fixed pattern of a few dozen bins)"""
+        nu, nv = self.n_bins_u_, self.n_bins_v_
+        u_cent, v_cent = int(nu * 0.5), int(nv * 0.5)
+        wu, wv, wv2 = int(np.float32(0.15) * nu), int(np.float32(0.30) * nv), int(np.float32(0.15) * nv)
+        for w in range(-wv, wv + 1):
+            v_idx = nu * (w + v_cent - wv2)
+            for u in range(-wu, wu + 1):
+                self.weight[v_idx + u + u_cent] = 0
+
+    def updateWeightBin(self, fts):
+        """feature_extractor.cpp:94-98: reset, then weight 0 for every bin that holds a tracked point"""
+        pts = _f32(fts).reshape(-1, 2)
+        w = np.zeros(self.weight.size, np.int32)
+        self.ctx.check(self.ctx.lib.vo_weight_bin_update(self.ctx.handle, _p(pts), pts.shape[0], self.u_step,
+                                                         self.v_step, self.n_bins_u_, self.n_bins_v_,
+                                                         _p(w, C.c_int32)))
+        self.weight = w
+        return w
+
+    def bucketKeypoints(self, kp_xy, kp_response):
+        """The flag_nonmax_ branch of extractORBwithBinning_fast (feature_extractor.cpp:241-277) on the
+        keypoints cv::ORB::detect returned (positions, responses, detector order)."""
+        kp, r = _f32(kp_xy).reshape(-1, 2), _f32(kp_response).reshape(-1)
+        if kp.shape[0] != r.shape[0]:
+            raise VoError(-4, "keypoint positions / responses differ in length")
+        tot = self.weight.size
+        out, idx, m = np.zeros((max(tot, 1), 2), np.float32), np.zeros(max(tot, 1), np.int32), C.c_int()
+        self.ctx.check(self.ctx.lib.vo_bucket_argmax(
+            self.ctx.handle, _p(kp), _p(r), kp.shape[0], C.c_float(self.inv_u_step_), C.c_float(self.inv_v_step_),
+            self.n_bins_u_, self.n_bins_v_, _p(np.ascontiguousarray(self.weight, np.int32), C.c_int32), _p(out),
+            _p(idx, C.c_int32), C.byref(m)))
+        return out[: m.value].copy(), idx[: m.value].copy()
 
     def descriptorDistance(self, a, b):
         a, b = _u8(a).reshape(-1, 32), _u8(b).reshape(-1, 32)

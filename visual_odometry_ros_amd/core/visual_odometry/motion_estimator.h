@@ -79,6 +79,9 @@ class MotionEstimator {
                                                F10.data(), sym_epi_dist.data()));
   }
 
+  void setThres1p(float thres_1p) { thres_1p_ = thres_1p; }  // motion_estimator.cpp:655-658
+  void setThres5p(float thres_5p) { thres_5p_ = thres_5p; }  // :660-663
+
   const vo_gn_info &lastInfo() const { return last_info_; }
 
  private:
@@ -86,6 +89,7 @@ class MotionEstimator {
   bool is_stereo_mode_;
   PoseSE3 T_left2right_;
   vo_gn_info last_info_{};
+  float thres_1p_ = 0.f, thres_5p_ = 0.f;  // consumed by the host-side 1-point / 5-point RANSAC (out of scope)
   float zero_[4] = {0, 0, 0, 0};
 };
 

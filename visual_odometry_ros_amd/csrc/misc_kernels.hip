@@ -430,3 +430,127 @@ int vo_epi_distance_enqueue(vo_ctx *c, int mode, const float *d_pts0, const floa
   VO_CHECK_HIP(c, hipGetLastError());
   return VO_OK;
 }
+
+// ---- feature bucketing: WeightBin::reset/update (core/visual_odometry/feature_extractor.h:120-135) and
+// the arg-max-per-bin branch of extractORBwithBinning_fast (feature_extractor.cpp:241-277) ------------
+struct BinArgs {
+  const float *xy;        // points (update) / keypoints (arg-max)
+  const float *response;  // arg-max only
+  int n;
+  int u_step, v_step;     // update: integer steps, the reference divides
+  float inv_u, inv_v;     // arg-max: the reference multiplies by the inverse steps
+  int n_bins_u, n_bins_v;
+  int32_t *weight;        // update: out ; arg-max: in
+  unsigned long long *key;  // arg-max: one 64-bit key per bin, 0 = empty
+  float *pts_out;
+  int32_t *idx_out;
+  int *n_out;
+};
+__global__ __launch_bounds__(256) void weight_bin_update_kernel(BinArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const int u_idx = (int)floorf(a.xy[2 * i] / (float)a.u_step);
+  const int v_idx = (int)floorf(a.xy[2 * i + 1] / (float)a.v_step);
+  const int bin_idx = v_idx * a.n_bins_u + u_idx;  // only the flattened index is tested (:130)
+  if (bin_idx >= 0 && bin_idx < a.n_bins_u * a.n_bins_v) a.weight[bin_idx] = 0;
+}
+// "max_score < response" keeps the FIRST keypoint among equal responses: a 64-bit atomicMax on
+// (order-preserving response bits, ~index) selects exactly that one, in any execution order.
+__global__ __launch_bounds__(256) void bucket_key_kernel(BinArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const unsigned u = (unsigned)(int)floorf(a.xy[2 * i] * a.inv_u);
+  const unsigned v = (unsigned)(int)floorf(a.xy[2 * i + 1] * a.inv_v);
+  if (u >= (unsigned)a.n_bins_u || v >= (unsigned)a.n_bins_v) return;
+  const int bin = (int)(v * (unsigned)a.n_bins_u + u);
+  if (a.weight[bin] == 0) return;
+  float r = a.response[i];
+  if (!(-1.0f < r)) return;  // never beats the initial max_score of -1 (NaN included)
+  r = r + 0.0f;              // -0 -> +0: the reference's "<" does not tell them apart
+  const unsigned bits = __float_as_uint(r);
+  const unsigned ord = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+  const unsigned long long key = ((unsigned long long)ord << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+  atomicMax(&a.key[bin], key);
+}
+__global__ __launch_bounds__(1024) void bucket_emit_kernel(BinArgs a) {
+  __shared__ int s_wave[16];
+  __shared__ int s_base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int total = a.n_bins_u * a.n_bins_v;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < total; c0 += 1024) {
+    const int j = c0 + tid;
+    const unsigned long long key = j < total ? a.key[j] : 0ull;
+    const bool keep = key != 0ull && a.weight[j < total ? j : 0] > 0;
+    const unsigned long long bal = __ballot(keep);
+    const int below = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[wave] = __popcll(bal);
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += s_wave[w];
+    const int base = s_base;
+    if (keep) {
+      const int idx = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+      const int o = base + woff + below;
+      a.pts_out[2 * o] = a.xy[2 * idx];
+      a.pts_out[2 * o + 1] = a.xy[2 * idx + 1];
+      a.idx_out[o] = idx;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int tot = 0;
+      for (int w = 0; w < 16; ++w) tot += s_wave[w];
+      s_base = base + tot;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) *a.n_out = s_base;
+}
+int vo_weight_bin_update_enqueue(vo_ctx *c, const float *d_pts, int n, int u_step, int v_step, int n_bins_u,
+                                 int n_bins_v, int32_t *d_weight) {
+  const int total = n_bins_u * n_bins_v;
+  // reset(): every weight 1 (0x00000001 is not a byte pattern: a tiny fill kernel would do; memset D32 does)
+  VO_CHECK_HIP(c, hipMemsetD32Async((hipDeviceptr_t)d_weight, 1, (size_t)total, c->stream));
+  if (n <= 0) return VO_OK;
+  BinArgs a;
+  memset(&a, 0, sizeof(a));
+  a.xy = d_pts;
+  a.n = n;
+  a.u_step = u_step;
+  a.v_step = v_step;
+  a.n_bins_u = n_bins_u;
+  a.n_bins_v = n_bins_v;
+  a.weight = d_weight;
+  vo_prof_begin(c, VO_K_AUX);
+  hipLaunchKernelGGL(weight_bin_update_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, a);
+  vo_prof_end(c);
+  VO_CHECK_HIP(c, hipGetLastError());
+  return VO_OK;
+}
+int vo_bucket_argmax_enqueue(vo_ctx *c, const float *d_xy, const float *d_response, int n, float inv_u, float inv_v,
+                             int n_bins_u, int n_bins_v, const int32_t *d_weight, unsigned long long *d_key,
+                             float *d_pts_out, int32_t *d_idx_out, int *d_n_out) {
+  const int total = n_bins_u * n_bins_v;
+  VO_CHECK_HIP(c, hipMemsetAsync(d_key, 0, sizeof(unsigned long long) * (size_t)total, c->stream));
+  BinArgs a;
+  memset(&a, 0, sizeof(a));
+  a.xy = d_xy;
+  a.response = d_response;
+  a.n = n;
+  a.inv_u = inv_u;
+  a.inv_v = inv_v;
+  a.n_bins_u = n_bins_u;
+  a.n_bins_v = n_bins_v;
+  a.weight = (int32_t *)d_weight;
+  a.key = d_key;
+  a.pts_out = d_pts_out;
+  a.idx_out = d_idx_out;
+  a.n_out = d_n_out;
+  vo_prof_begin(c, VO_K_AUX);
+  if (n > 0) hipLaunchKernelGGL(bucket_key_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(bucket_emit_kernel, dim3(1), dim3(1024), 0, c->stream, a);
+  vo_prof_end(c);
+  VO_CHECK_HIP(c, hipGetLastError());
+  return VO_OK;
+}

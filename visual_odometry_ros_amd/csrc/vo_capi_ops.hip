@@ -128,6 +128,57 @@ extern "C" int vo_symmetric_epipolar_distance(vo_ctx *c, const float *pts0, cons
   return epi_distance(c, 1, pts0, pts1, n, F10, dist);
 }
 
+// WeightBin::reset + update (feature_extractor.h:120-135): weight[j] = 0 for bins holding a point
+extern "C" int vo_weight_bin_update(vo_ctx *c, const float *pts, int n, int u_step, int v_step, int n_bins_u,
+                                    int n_bins_v, int32_t *weight) {
+  if (!c || (n > 0 && !pts) || !weight || u_step <= 0 || v_step <= 0 || n_bins_u <= 0 || n_bins_v <= 0)
+    return VO_ERR_INVALID;
+  int rc = check_n(c, n);
+  if (rc) return rc;
+  rc = check_n(c, n_bins_u * n_bins_v);
+  if (rc) return rc;
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  if (n) H2D(c->d_pts0, pts, sizeof(float) * 2 * (size_t)n);
+  rc = vo_weight_bin_update_enqueue(c, c->d_pts0, n, u_step, v_step, n_bins_u, n_bins_v, c->d_idx);
+  if (rc < 0) return rc;
+  D2H(weight, c->d_idx, sizeof(int32_t) * (size_t)(n_bins_u * n_bins_v));
+  SYNC();
+  return VO_OK;
+}
+
+// the bucketing of FeatureExtractor::extractORBwithBinning_fast (feature_extractor.cpp:241-277) on the
+// keypoints (position, response) cv::ORB::detect returned, in detector order
+extern "C" int vo_bucket_argmax(vo_ctx *c, const float *kp_xy, const float *kp_response, int n, float inv_u_step,
+                                float inv_v_step, int n_bins_u, int n_bins_v, const int32_t *weight, float *pts_out,
+                                int32_t *idx_out, int *n_out) {
+  if (!c || (n > 0 && (!kp_xy || !kp_response)) || !weight || !pts_out || !n_out || n_bins_u <= 0 || n_bins_v <= 0)
+    return VO_ERR_INVALID;
+  int rc = check_n(c, n);
+  if (rc) return rc;
+  const int total = n_bins_u * n_bins_v;
+  rc = check_n(c, total);
+  if (rc) return rc;
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  if (n) {
+    H2D(c->d_pts0, kp_xy, sizeof(float) * 2 * (size_t)n);
+    H2D(c->d_err, kp_response, sizeof(float) * (size_t)n);
+  }
+  H2D(c->d_idx, weight, sizeof(int32_t) * (size_t)total);
+  rc = vo_bucket_argmax_enqueue(c, c->d_pts0, c->d_err, n, inv_u_step, inv_v_step, n_bins_u, n_bins_v, c->d_idx,
+                                (unsigned long long *)c->d_pts2, c->d_pts3, (int32_t *)c->d_pts1, c->d_count);
+  if (rc < 0) return rc;
+  int m = 0;
+  D2H(&m, c->d_count, sizeof(int));
+  SYNC();
+  if (m > 0) {
+    D2H(pts_out, c->d_pts3, sizeof(float) * 2 * (size_t)m);
+    if (idx_out) D2H(idx_out, c->d_pts1, sizeof(int32_t) * (size_t)m);
+    SYNC();
+  }
+  *n_out = m;
+  return VO_OK;
+}
+
 static int ensure_desc(vo_ctx *c, int na, int nb, bool need_dist) {
   const size_t need = (size_t)(na > nb ? na : nb) * 32;
   if (need > c->desc_cap) {

@@ -120,5 +120,11 @@ int vo_stereo_prior_enqueue(vo_ctx *c, const float *d_Xp, const float *d_pl0, co
 int vo_epi_distance_enqueue(vo_ctx *c, int mode, const float *d_pts0, const float *d_pts1, int n, const float F10[9],
                             float *d_dist);
 
+int vo_weight_bin_update_enqueue(vo_ctx *c, const float *d_pts, int n, int u_step, int v_step, int n_bins_u,
+                                 int n_bins_v, int32_t *d_weight);
+int vo_bucket_argmax_enqueue(vo_ctx *c, const float *d_xy, const float *d_response, int n, float inv_u, float inv_v,
+                             int n_bins_u, int n_bins_v, const int32_t *d_weight, unsigned long long *d_key,
+                             float *d_pts_out, int32_t *d_idx_out, int *d_n_out);
+
 // frame_pipeline.hip
 void vo_frame_free(vo_ctx *c);
