@@ -135,22 +135,34 @@ def main():
     eff_levels = ctx.pyramid_levels(W_, H_, WIN, MAX_LEVEL) + 1
     eff_levels_bwd = ctx.pyramid_levels(W_, H_, WIN, MAX_LEVEL - 1) + 1
 
-    def step(s, keep=None):
+    # slot roles, rotated in place of copying pyramids: previous left, current pair, prefetched pair
+    slot = {"P": 0, "CL": 1, "CR": 2, "NL": 3, "NR": 4}
+
+    def enqueue(s):
         a, b = frame_id(s), frame_id(s + 1)
         t = d_ts[(a, b)]
         pipe.enqueue_device(t["pts_l0"].data_ptr(), t["pts_r0"].data_ptr(), t["Xp"].data_ptr(), n_pts,
-                            track_sets[(a, b)]["dT_prior"], t["pts_new"].data_ptr(), N_NEW)
+                            track_sets[(a, b)]["dT_prior"], t["pts_new"].data_ptr(), N_NEW,
+                            slots=(slot["P"], slot["CL"], slot["CR"]))
         # the NEXT stereo pair does not depend on this frame's result: its pyramids are enqueued
-        # now (slots 3,4) and build while the host waits for / consumes this frame's result
+        # behind the frame and build while the host waits for / consumes this frame's result
         nb = frame_id(s + 2)
-        ctx.set_stereo_pair_device(3, d_L[nb].data_ptr(), 4, d_R[nb].data_ptr(), W_, H_, W_)
-        r = pipe.result(copy=keep is not None)  # pose / survivors of THIS frame: a sequential VO needs them
-        ctx.swap_slots(0, 1)  # current left -> previous left
-        ctx.swap_slots(1, 3)  # prefetched pair -> current pair
-        ctx.swap_slots(2, 4)
-        if keep is not None:
-            keep.append(r)
-        return r
+        ctx.set_stereo_pair_device(slot["NL"], d_L[nb].data_ptr(), slot["NR"], d_R[nb].data_ptr(), W_, H_, W_)
+
+    def run_frames(first, count, keep=None, on_result=None):
+        """`count` frames, one at a time: the result of frame s (pose, survivors — what a sequential VO
+        needs before it can go on) is received before frame s+1 is enqueued, and s+1 is enqueued at once."""
+        enqueue(first)
+        for s in range(first, first + count):
+            r = pipe.result(copy=keep is not None and len(keep) < args.cpu_frames)
+            slot["P"], slot["CL"], slot["CR"], slot["NL"], slot["NR"] = (slot["CL"], slot["NL"], slot["NR"], slot["P"],
+                                                                           slot["CR"])
+            if s + 1 < first + count:
+                enqueue(s + 1)
+            if keep is not None and len(keep) < args.cpu_frames:
+                keep.append(r)
+            if on_result is not None:
+                on_result(r)
 
     def barrier():
         if world > 1:
@@ -161,14 +173,20 @@ def main():
     ctx.set_image_device(0, d_L[frame_id(0)].data_ptr(), W_, H_, W_)
     ctx.set_stereo_pair_device(1, d_L[frame_id(1)].data_ptr(), 2, d_R[frame_id(1)].data_ptr(), W_, H_, W_)
     ctx.synchronize()
-    for s in range(args.warmup):
-        step(s)
+    if args.warmup:
+        run_frames(0, args.warmup)
     K = args.steps
     ctx.profile_enable(K * 4 + 64)
     ctx.profile_set_classes(1 << 1)  # event-bracket only the dominant kernel (frame_track_kernel)
     ctx.profile_reset()
-    klt_alg_bytes = 0
+    acc = {"bytes": 0}
     results = []
+
+    def account(r):
+        cts = r["counts"]  # features finished by the replay kernel do their step [5] there
+        acc["bytes"] += frame_kernel_bytes(WIN, n_pts, cts.n_l0l1, cts.n_refine - cts.n_replayed, N_NEW, eff_levels,
+                                           eff_levels_bwd, bool(args.strict_border))
+
     # A generational GC pass of the interpreter (tens of ms with torch loaded) inside the timed loop
     # would be charged to a few frames; the loop allocates nothing that needs it.
     gc.collect()
@@ -176,11 +194,7 @@ def main():
     gc.disable()
     barrier()
     t0 = time.perf_counter()
-    for s in range(args.warmup, args.warmup + K):
-        r = step(s, results if len(results) < args.cpu_frames else None)
-        cts = r["counts"]  # features finished by the replay kernel do their step [5] there
-        klt_alg_bytes += frame_kernel_bytes(WIN, n_pts, cts.n_l0l1, cts.n_refine - cts.n_replayed, N_NEW, eff_levels,
-                                            eff_levels_bwd, bool(args.strict_border))
+    run_frames(args.warmup, K, results, account)
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
@@ -196,7 +210,7 @@ def main():
             if n_l:
                 per_kernel[nm] = {"launches": n_l, "total_ms": round(ms, 3), "avg_us": round(1e3 * ms / n_l, 2)}
         klt_n, klt_ms = ctx.profile_get(1)
-        achieved = (klt_alg_bytes / max(klt_n, 1)) / (klt_ms / max(klt_n, 1) * 1e-3) / 1e9 if klt_n else 0.0
+        achieved = (acc["bytes"] / max(klt_n, 1)) / (klt_ms / max(klt_n, 1) * 1e-3) / 1e9 if klt_n else 0.0
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "r01_frame_pmc.json")
         if os.path.exists(pmc_path):
@@ -233,7 +247,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
-                "alg_bytes_per_launch": round(klt_alg_bytes / max(klt_n, 1)),
+                "alg_bytes_per_launch": round(acc["bytes"] / max(klt_n, 1)),
                 "avg_launch_us": round(1e3 * klt_ms / max(klt_n, 1), 2),
             },
             "kernels": per_kernel,
