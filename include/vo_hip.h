@@ -214,7 +214,7 @@ typedef struct {
 
 /* strict != 0: the frame's trackWithScale step replays border-touching points
  * with the reference's never-reset tap state (same as vo_track_with_scale's
- * strict_border). Default 0. */
+ * strict_border; 2 = sequential replay only, for validation). Default 0. */
 int vo_stereo_frame_set_strict_border(vo_ctx *ctx, int strict);
 
 /* Asynchronous: enqueues one frame on the context stream. slot_l0 must hold the

@@ -73,10 +73,11 @@ def test_stereo_frame_small_many_frames(ctx, oracle):
     _run_stream(ctx, oracle, stream, 6, False, win=15, max_level=4)
 
 
-@pytest.mark.parametrize("win,strict", [(31, True), (17, True), (17, False), (15, True)])
+@pytest.mark.parametrize("win,strict", [(31, True), (17, True), (17, False), (15, True), (21, 2)])
 def test_stereo_frame_other_windows(ctx, oracle, win, strict):
     """win 15 / 31: the other instantiations of the fused frame kernel; win 17: the general
-    one-launch-per-step path (windows the fused kernel is not instantiated for)."""
+    one-launch-per-step path (windows the fused kernel is not instantiated for); strict 2: the
+    sequential fallback of the strict-border replay does all the work."""
     K = tuple(v * 0.5 for v in S.KITTI_K)
     stream = S.StereoStream(width=620, height=188, K=K, n_u=30, n_v=12, n_new=40, seed=11 + win,
                             margin=5.0 if strict else 14.0)

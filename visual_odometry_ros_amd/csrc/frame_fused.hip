@@ -16,8 +16,8 @@
 // The one cross-feature dependency is the never-reset tap state of trackWithScale
 // (ic_refine.hip): a feature whose IC window leaves the image ("touched") is deferred after its
 // pass-1 refinement; frame_replay_kernel brings the touched features to the reference-exact
-// state (ic_replay) and then finishes step [5] for them. If that replay asks for the sequential
-// fallback, ic_strict_kernel and frame_tail_kernel do the same work in two more launches.
+// state (ic_replay) and finishes step [5] for each right after its recomputation. If that replay
+// asks for the sequential fallback, frame_fallback_kernel does the same work one run per wavefront.
 #include "ic_device.hpp"
 #include "klt_device.hpp"
 #include "vo_kernels.hpp"
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(64) void frame_track_kernel(FrameArgs a) {
       }
     }
     if (lane == 0 && rf.err_flag) atomicOr(a.ic.flags, rf.err_flag);
-    const bool deferred = a.strict && any_t;  // frame_replay_kernel (or frame_tail_kernel) finishes this feature
+    const bool deferred = a.strict && any_t;  // frame_replay_kernel (or frame_fallback_kernel) finishes this feature
     if (!valid1 || !rf.ok || deferred) {
       if (lane == 0) {
         a.pl1[2 * i] = rf.x;  // the step [4] result unless the refinement accepted
@@ -287,16 +287,22 @@ __global__ __launch_bounds__(64) void frame_replay_kernel(FrameArgs a) {
 #endif
 }
 
-// after ic_strict_kernel (sequential fallback only): step [5] of the touched features
+// sequential fallback of the replay (returns at once unless it was requested): one wavefront walks a
+// run of features, and step [5] follows each touched feature it recomputes
 template <int WIN>
-__global__ __launch_bounds__(64) void frame_tail_kernel(FrameArgs a) {
+__global__ __launch_bounds__(64) void frame_fallback_kernel(FrameArgs a) {
+  __shared__ IcShared sh;
   __shared__ uint32_t s_tt[KltCfg<WIN>::TT_H * KltCfg<WIN>::TT_WD];
   __shared__ uint32_t s_tj[KltCfg<WIN>::TJ_H * KltCfg<WIN>::TJ_WD];
   if (a.ic.jac[IC_JAC_OVF] == 0) return;
   const int i = blockIdx.x;
-  if (i >= a.n || !a.ic.touched[i] || a.ic.cls[i] == 0) return;
-  frame_tail<WIN>(a, i, a.ic.mask[i], a.ic.pts_track[2 * i], a.ic.pts_track[2 * i + 1], a.k1[2 * i], a.k1[2 * i + 1],
-                  a.pr_prior[2 * i], a.pr_prior[2 * i + 1], s_tt, s_tj, threadIdx.x);
+  if (i >= a.n) return;
+  const int lane = threadIdx.x;
+  auto tail = [&](int p, const IcResult &r) {
+    frame_tail<WIN>(a, p, r.ok, r.x, r.y, a.k1[2 * p], a.k1[2 * p + 1], a.pr_prior[2 * p], a.pr_prior[2 * p + 1], s_tt,
+                    s_tj, lane);
+  };
+  ic_strict_run(a.ic, sh, i, a.n, lane, tail);
 }
 
 #ifdef FRAME_STAMP
@@ -322,9 +328,11 @@ static void frame_launch(vo_ctx *c, const FrameArgs &a, int phase) {
   }
   if (a.strict) {
     vo_prof_begin(c, VO_K_IC);
-    hipLaunchKernelGGL(frame_replay_kernel<WIN>, dim3(a.n < IC_JGRID ? a.n : IC_JGRID), dim3(64), 0, c->stream, a);
-    vo_ic_strict_launch(c, a.ic);  // returns at once unless the replay asked for it
-    hipLaunchKernelGGL(frame_tail_kernel<WIN>, dim3(a.n), dim3(64), 0, c->stream, a);
+    if (a.strict == 2)  // validation mode: the sequential fallback does all the work
+      (void)hipMemsetAsync(&a.ic.jac[IC_JAC_OVF], 1, sizeof(int), c->stream);
+    else
+      hipLaunchKernelGGL(frame_replay_kernel<WIN>, dim3(a.n < IC_JGRID ? a.n : IC_JGRID), dim3(64), 0, c->stream, a);
+    hipLaunchKernelGGL(frame_fallback_kernel<WIN>, dim3(a.n), dim3(64), 0, c->stream, a);
     vo_prof_end(c);
   }
   // (the frame's one compaction and the control-block reset are the prologue of the GN launch, gn_pose.hip)
@@ -384,7 +392,7 @@ int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, 
   a.W = prm->width;
   a.H = prm->height;
   a.thres_err = prm->thres_err;
-  a.strict = c->frame_strict_ic ? 1 : 0;
+  a.strict = c->frame_strict_ic;  // 0 masked taps, 1 parallel replay (+ fallback), 2 sequential replay only
   a.scale = b.scale;
   a.k1 = b.k1;
   a.pr_prior = b.pr_prior;

@@ -139,7 +139,7 @@ static void inv_se3(const float T[16], float Ti[16]) {
 
 extern "C" int vo_stereo_frame_set_strict_border(vo_ctx *c, int strict) {
   if (!c) return VO_ERR_INVALID;
-  c->frame_strict_ic = strict ? 1 : 0;
+  c->frame_strict_ic = strict == 2 ? 2 : (strict ? 1 : 0);
   return VO_OK;
 }
 

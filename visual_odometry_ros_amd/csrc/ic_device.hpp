@@ -901,3 +901,75 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
   return result;
 }
 
+// ---- sequential replay of the run of features that starts at touched feature `pt` (the fallback of
+// ic_replay): one wavefront walks the run, the carried tap state lives in registers. Returns at once
+// unless `pt` is the first touched feature of its run. `after_point(p, result)` is called for every
+// touched feature replayed.
+template <typename AfterPoint>
+__device__ __forceinline__ void ic_strict_run(const IcArgs &a, IcShared &sh, int pt, int n, int lane,
+                                              AfterPoint after_point) {
+  if (!a.touched[pt]) return;
+  // head test: walk back over skipped / template-only untouched points
+  int start = 0, clean = -1;
+  for (int j = pt - 1; j >= 0; --j) {
+    const int cj = a.cls[j];
+    if (cj == 0) continue;
+    if (a.touched[j]) return;  // an earlier touched point owns this run
+    if (cj == 2) {
+      clean = j;
+      break;
+    }
+  }
+  start = clean + 1;
+  IcState S;
+  ic_state_clear(S);
+  const IcTaps tp = ic_make_taps(lane);
+  int dummy = 0, n_iter = 0;
+  if (clean >= 0) {
+    // state left behind by an untouched, iterated point: its template and its last I1 patch
+    float ax, ay, axay;
+    const float cx = a.pts0[2 * clean], cy = a.pts0[2 * clean + 1];
+    ic_frac(cx, cy, ax, ay, axay);
+    IcTRegs rt;
+    IcJRegs rj;
+    const float pux = a.last_pu[2 * clean], puy = a.last_pu[2 * clean + 1];
+    ic_template_fetch(a.I0, cx, cy, lane, rt);
+    ic_I1_fetch(a.I1, pux, puy, lane, rj);
+    ic_tile_commit<IC_TN, IC_TW, IC_TH>(rt, lane, sh.tt);
+    const IcTile tt = {rt.x0, rt.y0};
+    ic_template<true>(a.I0, tp, cx, cy, ax, ay, axay, tt, sh, S, dummy);
+    ic_frac(pux, puy, ax, ay, axay);
+    ic_tile_commit<IC_JN, IC_JW, IC_JH>(rj, lane, sh.tj);
+    const IcTile tile = {rj.x0, rj.y0};
+    float sx[IC_K], sy[IC_K];
+    const float sc = a.scale[clean];
+#pragma unroll
+    for (int k = 0; k < IC_K; ++k) {
+      sx[k] = tp.px[k] * sc;
+      sy[k] = tp.py[k] * sc;
+    }
+    ic_sample_I1<true>(a.I1, tp, sx, sy, pux, puy, ax, ay, axay, S, dummy, tile, sh);
+  }
+  for (int p = start; p < n; ++p) {
+    const int cp = a.cls[p];
+    if (cp == 0) continue;
+    const int is_touched = a.touched[p];
+    if (!is_touched) {
+      if (cp == 2) break;  // next clean point: end of the run
+      // untouched, failed the determinant test: it only rewrote the template state
+      float ax, ay, axay;
+      const float cx = a.pts0[2 * p], cy = a.pts0[2 * p + 1];
+      ic_frac(cx, cy, ax, ay, axay);
+      IcTRegs rt;
+      ic_template_fetch(a.I0, cx, cy, lane, rt);
+      ic_tile_commit<IC_TN, IC_TW, IC_TH>(rt, lane, sh.tt);
+      const IcTile tt = {rt.x0, rt.y0};
+      ic_template<true>(a.I0, tp, cx, cy, ax, ay, axay, tt, sh, S, dummy);
+      continue;
+    }
+    float lx, ly;
+    const IcResult r = ic_point_io<true>(a, tp, p, lane, sh, S, dummy, lx, ly, n_iter);
+    after_point(p, r);
+  }
+}
+

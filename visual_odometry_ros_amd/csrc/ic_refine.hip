@@ -92,77 +92,15 @@ __global__ __launch_bounds__(IC_T) void ic_jacobi_kernel(IcArgs a) {
   (void)ic_replay(a, rs, threadIdx.x, [](int, const IcResult &) {});
 }
 
-// ---- pass 2: sequential replay of the runs that contain touched points --------------
+// ---- pass 2: sequential replay of the runs that contain touched points (ic_device.hpp: ic_strict_run) ----
 __global__ __launch_bounds__(IC_T) void ic_strict_kernel(IcArgs a) {
   __shared__ IcShared sh;
   const int n = a.d_n ? *a.d_n : a.n;
   const int pt = blockIdx.x;
   if (pt >= n) return;
-  const int lane = threadIdx.x;
   // with the parallel replay in front, this kernel only runs when that did not finish
   if (a.jac && a.jac[IC_JAC_OVF] == 0) return;
-  if (!a.touched[pt]) return;
-  // head test: walk back over skipped / template-only untouched points
-  int start = 0, clean = -1;
-  for (int j = pt - 1; j >= 0; --j) {
-    const int cj = a.cls[j];
-    if (cj == 0) continue;
-    if (a.touched[j]) return;  // an earlier touched point owns this run
-    if (cj == 2) {
-      clean = j;
-      break;
-    }
-  }
-  start = clean + 1;
-  IcState S;
-  ic_state_clear(S);
-  const IcTaps tp = ic_make_taps(lane);
-  int dummy = 0, n_iter = 0;
-  if (clean >= 0) {
-    // state left behind by an untouched, iterated point: its template and its last I1 patch
-    float ax, ay, axay;
-    const float cx = a.pts0[2 * clean], cy = a.pts0[2 * clean + 1];
-    ic_frac(cx, cy, ax, ay, axay);
-    IcTRegs rt;
-    IcJRegs rj;
-    const float pux = a.last_pu[2 * clean], puy = a.last_pu[2 * clean + 1];
-    ic_template_fetch(a.I0, cx, cy, lane, rt);
-    ic_I1_fetch(a.I1, pux, puy, lane, rj);
-    ic_tile_commit<IC_TN, IC_TW, IC_TH>(rt, lane, sh.tt);
-    const IcTile tt = {rt.x0, rt.y0};
-    ic_template<true>(a.I0, tp, cx, cy, ax, ay, axay, tt, sh, S, dummy);
-    ic_frac(pux, puy, ax, ay, axay);
-    ic_tile_commit<IC_JN, IC_JW, IC_JH>(rj, lane, sh.tj);
-    const IcTile tile = {rj.x0, rj.y0};
-    float sx[IC_K], sy[IC_K];
-    const float sc = a.scale[clean];
-#pragma unroll
-    for (int k = 0; k < IC_K; ++k) {
-      sx[k] = tp.px[k] * sc;
-      sy[k] = tp.py[k] * sc;
-    }
-    ic_sample_I1<true>(a.I1, tp, sx, sy, pux, puy, ax, ay, axay, S, dummy, tile, sh);
-  }
-  for (int p = start; p < n; ++p) {
-    const int cp = a.cls[p];
-    if (cp == 0) continue;
-    const int is_touched = a.touched[p];
-    if (!is_touched) {
-      if (cp == 2) break;  // next clean point: end of the run
-      // untouched, failed the determinant test: it only rewrote the template state
-      float ax, ay, axay;
-      const float cx = a.pts0[2 * p], cy = a.pts0[2 * p + 1];
-      ic_frac(cx, cy, ax, ay, axay);
-      IcTRegs rt;
-      ic_template_fetch(a.I0, cx, cy, lane, rt);
-      ic_tile_commit<IC_TN, IC_TW, IC_TH>(rt, lane, sh.tt);
-      const IcTile tt = {rt.x0, rt.y0};
-      ic_template<true>(a.I0, tp, cx, cy, ax, ay, axay, tt, sh, S, dummy);
-      continue;
-    }
-    float lx, ly;
-    (void)ic_point_io<true>(a, tp, p, lane, sh, S, dummy, lx, ly, n_iter);
-  }
+  ic_strict_run(a, sh, pt, n, threadIdx.x, [](int, const IcResult &) {});
 }
 
 static int ic_args(vo_ctx *c, int slot0, int slot1, IcArgs &a, int *d_flags) {
