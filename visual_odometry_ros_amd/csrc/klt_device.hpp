@@ -251,9 +251,8 @@ __device__ __forceinline__ KltResult klt_point(const vo_level *I, const vo_level
       }
     }
     if (level > 0) fetch_template_tile(level - 1);  // in flight during this level's iterations
-    float sA11, sA12, sA22, sdummy;
-    wave_sum2_i32_to_f32(pA11, pA12, sA11, sA12);
-    wave_sum2_i32_to_f32(pA22, 0, sA22, sdummy);
+    float sA11, sA12, sA22;
+    wave_sum3_i32_to_f32(pA11, pA12, pA22, sA11, sA12, sA22);
     const float A11 = sA11 * FLT_SCALE;
     const float A12 = sA12 * FLT_SCALE;
     const float A22 = sA22 * FLT_SCALE;
@@ -350,7 +349,9 @@ __device__ __forceinline__ KltResult klt_point(const vo_level *I, const vo_level
       npx = nextx + halfWin;
       npy = nexty + halfWin;
       if ((double)dx * dx + (double)dy * dy <= epsilon) break;
-      if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+      // (double)|f| < 0.01 for a float f  <=>  |f| <= 0.01f : 0.01f = 0.00999999977... is the largest
+      // float below 0.01 (the next one is 0.0100000007...)
+      if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
         npx -= dx * 0.5f;
         npy -= dy * 0.5f;
         break;

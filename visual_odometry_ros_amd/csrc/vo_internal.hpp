@@ -221,6 +221,30 @@ __device__ __forceinline__ void wave_sum2_i32_to_f32(int p, int q, float &fp, fl
   fp = (float)((double)phi * 65536.0 + (double)plo);
   fq = (float)((double)qhi * 65536.0 + (double)qlo);
 }
+// three at once: six interleaved chains (16/16 halves of p, q, r), same butterfly
+__device__ __forceinline__ void wave_sum3_i32_to_f32(int p, int q, int r, float &fp, float &fq, float &fr) {
+  int v[6] = {p & 0xFFFF, p >> 16, q & 0xFFFF, q >> 16, r & 0xFFFF, r >> 16};
+#define VO_STEP6(CTRL)                                      \
+  {                                                         \
+    int t[6];                                               \
+    _Pragma("unroll") for (int k = 0; k < 6; ++k) t[k] = dpp_i32<CTRL>(v[k]); \
+    _Pragma("unroll") for (int k = 0; k < 6; ++k) v[k] += t[k];               \
+  }
+  VO_STEP6(0xB1)
+  VO_STEP6(0x4E)
+  VO_STEP6(0x141)
+  VO_STEP6(0x140)
+#undef VO_STEP6
+#pragma unroll
+  for (int k = 0; k < 6; ++k) v[k] += __builtin_amdgcn_update_dpp(0, v[k], 0x142, 0xA, 0xF, false);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) v[k] += __builtin_amdgcn_update_dpp(0, v[k], 0x143, 0xC, 0xF, false);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) v[k] = __builtin_amdgcn_readlane(v[k], 63);
+  fp = (float)((double)v[1] * 65536.0 + (double)v[0]);
+  fq = (float)((double)v[3] * 65536.0 + (double)v[2]);
+  fr = (float)((double)v[5] * 65536.0 + (double)v[4]);
+}
 // Exact 64-bit sum of 64 int32 lane values (each |v| < 2^30): split 16/16 so the
 // two int32 wave sums cannot overflow, recombine in int64.
 __device__ __forceinline__ long long wave_sum_i32_to_i64(int v) {
