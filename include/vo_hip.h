@@ -230,6 +230,47 @@ int vo_stereo_frame_result(vo_ctx *ctx, float *pts_l1, float *pts_r1, uint8_t *s
                            float dT[16], float *pts_new_r, uint8_t *mask_new,
                            vo_frame_counts *counts, vo_gn_info *gn);
 
+/* ---- steady-state mono frame ----------------------------------------------
+ * The operator sequence of MonoVO::trackImage
+ * (core/visual_odometry/mono_vo/mono_vo.cpp:739-963): prior pixel + patch scale
+ * (:739-761), trackBidirectionWithPrior (:768), trackWithScale (:779-788), the
+ * selection of the pose-only BA set (:799-826), poseOnlyBundleAdjustment
+ * (:856-867), mask_motion (:872-879) and the Sampson gate (:954-963), chained on
+ * the device. The 5-point fallback (:905-935, OpenCV calib3d) stays with the
+ * caller: counts.need_five_point says when it is due (fewer than 11 BA points,
+ * or the BA failed); stages then stop at 2 and dT01 is the prior. */
+typedef struct {
+  int width, height;
+  int win, max_level;
+  float thres_err, thres_bidirection;
+  int thres_poseba;      /* int, as the reference's poseOnlyBundleAdjustment takes it */
+  float thres_sampson;
+  float K[4];
+} vo_mono_params;
+
+typedef struct {
+  int n_klt, n_refine, n_ba, n_motion, n_final;
+  int gn_iterations;
+  int need_five_point;
+  int n_replayed;
+} vo_mono_counts;
+
+/* flags[i]: bit 0 = lm->isBundled() (prior pixel and patch scale come from the
+ * 3-D point), bit 1 = the landmark is in the class this frame hands to the
+ * pose-only BA (mono_vo.cpp:800-826). Xw is read only where a bit is set.
+ * Tcw_prev = inverse pose of the previous frame, Tcw_prior = inverse of the
+ * predicted current pose, dT01_prior = predicted motion (all row-major 4x4).
+ * The strict-border mode is the context's (vo_stereo_frame_set_strict_border). */
+int vo_mono_frame_enqueue(vo_ctx *ctx, const vo_mono_params *prm, int slot0, int slot1,
+                          const float *pts0, const float *Xw, const uint8_t *flags, int n,
+                          const float Tcw_prev[16], const float Tcw_prior[16],
+                          const float dT01_prior[16], int inputs_on_device);
+/* stage[i] = gates passed: 1 tracked, 2 refined, 3 motion inlier (or not in the
+ * BA set), 4 passed the Sampson gate. pts1 = refined pixel (stage >= 2), else the
+ * forward KLT result. */
+int vo_mono_frame_result(vo_ctx *ctx, float *pts1, float *scale, uint8_t *stage, float dT01[16],
+                         vo_mono_counts *counts, vo_gn_info *gn);
+
 /* ---- kernel timing (HIP events on the context stream) --------------------- */
 enum { VO_K_PYRAMID = 0, VO_K_KLT = 1, VO_K_IC = 2, VO_K_GN = 3, VO_K_HAMMING = 4, VO_K_AUX = 5, VO_K_COUNT = 6 };
 int vo_profile_enable(vo_ctx *ctx, int max_records);

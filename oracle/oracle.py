@@ -67,6 +67,17 @@ class FrameCounts(C.Structure):
     ]
 
 
+class MonoParams(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("win", C.c_int), ("max_level", C.c_int),
+                ("thres_err", C.c_float), ("thres_bidirection", C.c_float), ("thres_poseba", C.c_int),
+                ("thres_sampson", C.c_float), ("K", C.c_float * 4)]
+
+
+class MonoCounts(C.Structure):
+    _fields_ = [("n_klt", C.c_int), ("n_refine", C.c_int), ("n_ba", C.c_int), ("n_motion", C.c_int),
+                ("n_final", C.c_int), ("gn_iterations", C.c_int), ("need_five_point", C.c_int)]
+
+
 _lib = None
 
 
@@ -357,6 +368,34 @@ def make_stereo_params(width, height, win, max_level, thres_err, thres_bidir, th
     for i in range(16):
         p.T_lr[i] = float(T[i])
     return p
+
+
+def make_mono_params(width, height, win, max_level, thres_err, thres_bidir, thres_poseba, thres_sampson, K):
+    p = MonoParams()
+    p.width, p.height, p.win, p.max_level = width, height, win, max_level
+    p.thres_err, p.thres_bidirection, p.thres_poseba, p.thres_sampson = thres_err, thres_bidir, int(thres_poseba), thres_sampson
+    for i in range(4):
+        p.K[i] = float(K[i])
+    return p
+
+
+def mono_frame(prm, I0, I1, pts0, Xw, flags, Tcw_prev, Tcw_prior, dT01_prior, sum_mode=SUM_TREE, tree_width=512,
+               ic_border_mode=IC_MASKED, n_threads=1):
+    I0, w, h, st = _img(I0)
+    I1, _, _, _ = _img(I1)
+    pts0, Xw = _f32(pts0).reshape(-1, 2), _f32(Xw).reshape(-1, 3)
+    n = pts0.shape[0]
+    fl = np.ascontiguousarray(flags, np.uint8)
+    pts1 = np.zeros((max(n, 1), 2), np.float32)
+    scale = np.zeros(max(n, 1), np.float32)
+    stage = np.zeros(max(n, 1), np.uint8)
+    dT = np.zeros(16, np.float32)
+    counts = MonoCounts()
+    rc = lib().vo_ref_mono_frame(
+        C.byref(prm), _p(I0, C.c_uint8), _p(I1, C.c_uint8), st, _p(pts0), _p(Xw), _p(fl, C.c_uint8), n,
+        _p(_f32(Tcw_prev).reshape(16)), _p(_f32(Tcw_prior).reshape(16)), _p(_f32(dT01_prior).reshape(16)), sum_mode,
+        tree_width, ic_border_mode, n_threads, _p(pts1), _p(scale), _p(stage, C.c_uint8), _p(dT), C.byref(counts))
+    return dict(rc=rc, pts1=pts1[:n], scale=scale[:n], stage=stage[:n], dT01=dT.reshape(4, 4), counts=counts)
 
 
 def stereo_frame(prm, I0l, I1l, I1r, pts_l0, pts_r0, Xp, dT_prior, pts_new, sum_mode=SUM_TREE,

@@ -184,6 +184,23 @@ void vo_ref_weight_bin_update(const float *pts, int n, int u_step, int v_step, i
 int vo_ref_bucket_argmax(const float *kp_xy, const float *kp_response, int n, float inv_u_step, float inv_v_step,
                          int n_bins_u, int n_bins_v, const int32_t *weight, float *pts_out, int32_t *idx_out);
 
+/* ---- steady-state mono frame (oracle_mono.c; mono_vo.cpp:739-963) ---- */
+typedef struct {
+  int width, height, win, max_level;
+  float thres_err, thres_bidirection;
+  int thres_poseba; /* the reference's parameter is int-typed (motion_estimator.h:117) */
+  float thres_sampson;
+  float K[4];
+} vo_ref_mono_params;
+typedef struct {
+  int n_klt, n_refine, n_ba, n_motion, n_final, gn_iterations, need_five_point;
+} vo_ref_mono_counts;
+int vo_ref_mono_frame(const vo_ref_mono_params *prm, const uint8_t *I0, const uint8_t *I1, int stride,
+                      const float *pts0, const float *Xw, const uint8_t *flags, int n, const float Tcw_prev[16],
+                      const float Tcw_prior[16], const float dT01_prior[16], int sum_mode, int tree_width,
+                      int ic_border_mode, int n_threads, float *pts1, float *scale, uint8_t *stage,
+                      float dT01_out[16], vo_ref_mono_counts *counts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,18 @@ class FrameCounts(C.Structure):
                 ("n_replayed", C.c_int)]
 
 
+class MonoParams(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("win", C.c_int), ("max_level", C.c_int),
+                ("thres_err", C.c_float), ("thres_bidirection", C.c_float),
+                ("thres_poseba", C.c_int), ("thres_sampson", C.c_float), ("K", C.c_float * 4)]
+
+
+class MonoCounts(C.Structure):
+    _fields_ = [("n_klt", C.c_int), ("n_refine", C.c_int), ("n_ba", C.c_int),
+                ("n_motion", C.c_int), ("n_final", C.c_int), ("gn_iterations", C.c_int),
+                ("need_five_point", C.c_int), ("n_replayed", C.c_int)]
+
+
 # every symbol include/vo_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "vo_abi_version", "vo_device_count", "vo_create", "vo_destroy", "vo_last_error", "vo_stream",
@@ -50,6 +62,7 @@ SYMBOLS = [
     "vo_track_with_scale", "vo_gn_pose_mono", "vo_gn_pose_stereo", "vo_orb_hamming",
     "vo_orb_match", "vo_compact_indices", "vo_stereo_frame_set_strict_border",
     "vo_stereo_frame_enqueue", "vo_stereo_frame_result",
+    "vo_mono_frame_enqueue", "vo_mono_frame_result",
     "vo_profile_enable", "vo_profile_reset", "vo_profile_get", "vo_profile_set_classes",
     "vo_set_stereo_pair_device", "vo_set_pyramid_window_hint",
 ]

@@ -14,7 +14,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import FrameCounts, GnInfo, StereoParams, VoConfig, VoError
+from ._capi import FrameCounts, GnInfo, MonoCounts, MonoParams, StereoParams, VoConfig, VoError
 
 KLT_USE_INITIAL_FLOW = 4
 GN_CORE, GN_STANDALONE = 0, 1
@@ -463,3 +463,56 @@ class StereoFramePipeline:
             out = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in out.items()}
             out["counts"], out["gn"] = cnt, gn
         return out
+
+
+def make_mono_params(width, height, win, max_level, thres_err, thres_bidir, thres_poseba, thres_sampson, K):
+    p = MonoParams()
+    p.width, p.height, p.win, p.max_level = width, height, win, max_level
+    p.thres_err, p.thres_bidirection = thres_err, thres_bidir
+    p.thres_poseba, p.thres_sampson = int(thres_poseba), thres_sampson
+    for i in range(4):
+        p.K[i] = float(K[i])
+    return p
+
+
+class MonoFramePipeline:
+    """The steady-state mono frame (mono_vo.cpp:739-963 operator sequence) chained on the
+    device: prior + scale, trackBidirectionWithPrior, trackWithScale, pose-only BA on the
+    landmarks flagged for it, mask_motion and the Sampson gate. flags[i]: bit 0 =
+    lm->isBundled(), bit 1 = member of the class used for the pose-only BA (:800-826)."""
+
+    def __init__(self, ctx, params, strict_border=False):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.prm = params
+        self.ctx.check(self.lib.vo_stereo_frame_set_strict_border(ctx.handle, int(strict_border)))
+
+    def enqueue(self, pts0, Xw, flags, Tcw_prev, Tcw_prior, dT01_prior, slots=(0, 1)):
+        pts0 = _f32(pts0).reshape(-1, 2)
+        Xw = _f32(Xw).reshape(-1, 3)
+        flags = np.ascontiguousarray(flags, np.uint8)
+        self._n = pts0.shape[0]
+        if Xw.shape[0] != self._n or flags.shape[0] != self._n:
+            raise ValueError("pts0 / Xw / flags differ in length")
+        self.ctx.check(self.lib.vo_mono_frame_enqueue(
+            self.ctx.handle, C.byref(self.prm), slots[0], slots[1], _p(pts0), _p(Xw), _p(flags, C.c_uint8), self._n,
+            _p(_f32(Tcw_prev).reshape(16)), _p(_f32(Tcw_prior).reshape(16)), _p(_f32(dT01_prior).reshape(16)), 0))
+
+    def enqueue_device(self, d_pts0, d_Xw, d_flags, n, Tcw_prev, Tcw_prior, dT01_prior, slots=(0, 1)):
+        self._n = n
+        f = C.POINTER(C.c_float)
+        self.ctx.check(self.lib.vo_mono_frame_enqueue(
+            self.ctx.handle, C.byref(self.prm), slots[0], slots[1], C.cast(C.c_void_p(d_pts0), f),
+            C.cast(C.c_void_p(d_Xw), f), C.cast(C.c_void_p(d_flags), C.POINTER(C.c_uint8)), n,
+            _p(_f32(Tcw_prev).reshape(16)), _p(_f32(Tcw_prior).reshape(16)), _p(_f32(dT01_prior).reshape(16)), 1))
+
+    def result(self):
+        n = self._n
+        pts1 = np.zeros((max(n, 1), 2), np.float32)
+        scale = np.zeros(max(n, 1), np.float32)
+        stage = np.zeros(max(n, 1), np.uint8)
+        dT = np.zeros(16, np.float32)
+        cnt, gn = MonoCounts(), GnInfo()
+        self.ctx.check(self.lib.vo_mono_frame_result(self.ctx.handle, _p(pts1), _p(scale), _p(stage, C.c_uint8),
+                                                     _p(dT), C.byref(cnt), C.byref(gn)))
+        return dict(pts1=pts1[:n], scale=scale[:n], stage=stage[:n], dT01=dT.reshape(4, 4), counts=cnt, gn=gn)

@@ -15,7 +15,7 @@
 // stream, live counts stay in device memory (kernels take `const int* d_n` and
 // surplus workgroups exit), and the host reads ONE packed result block per
 // frame (a single D2H copy into pinned memory).
-#include "vo_internal.hpp"
+#include "frame_state.hpp"
 #include "vo_kernels.hpp"
 
 #include <stdlib.h>
@@ -28,48 +28,6 @@ static double vo_tt_last; static int vo_tt_n;
 #define VO_TT(label)
 #endif
 
-// header of the packed result block (device and pinned-host copies share the layout)
-struct vo_frame_hdr {
-  int cnt[8];  // [0]=nA [1]=nB [2]=nC [3]=features replayed by the strict-border pass
-  vo_gn_dev_info gn;
-  int flags;
-  int pad_[1];
-  float dT[16];
-};
-
-struct vo_frame_state {
-  int cap;
-  // inputs (device copies when the caller passes host pointers)
-  float *in_l0, *in_r0, *in_X, *in_new;
-  // scratch in full index space
-  float *F_scale;
-  int32_t *F_orig;
-  // compacted sets
-  float *A_pl0, *A_pl1, *A_pr1, *A_X, *A_scale, *A_ref, *A_lastpu;
-  uint8_t *A_touched, *A_cls;
-  int32_t *A_orig;
-  float *B_pl1, *B_pr1, *B_X;
-  int32_t *B_orig;
-  float *C_pl1, *C_pr1, *C_X;
-  int32_t *C_orig;
-  uint8_t *m1, *m2, *m3, *mG;
-  uint8_t *st1, *st2, *st3;
-  float *e1, *e2, *e3;
-  float *new_back;
-  int *ctl;  // fused path: error flags + replay control words (zero between frames)
-  // packed result block
-  uint8_t *res_dev, *res_host;
-  size_t res_cap;
-  // views into res_dev for the frame in flight
-  vo_frame_hdr *hdr;
-  uint8_t *stage, *mNew;
-  float *F_pl1, *F_pr1, *new_r;
-  size_t off_stage, off_mnew, off_pl1, off_pr1, off_newr, res_bytes;
-  int n, n_new;
-  bool pending;
-  hipEvent_t ev_done;  // recorded after the packed D2H: result() waits for this, not for the stream
-};
-
 template <typename T>
 static hipError_t fs_alloc(T **p, size_t n) {
   return hipMalloc((void **)p, (n ? n : 1) * sizeof(T));
@@ -77,7 +35,7 @@ static hipError_t fs_alloc(T **p, size_t n) {
 
 static size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
-static int frame_init(vo_ctx *c) {
+int vo_frame_init(vo_ctx *c) {
   if (c->frame) return VO_OK;
   vo_frame_state *f = (vo_frame_state *)calloc(1, sizeof(vo_frame_state));
   c->frame = f;
@@ -157,7 +115,7 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
   if (n_new > 0 && prm->max_level - 1 < 0) VO_FAIL(c, VO_ERR_INVALID, "trackBidirection needs max_level >= 1");
   VO_CHECK_HIP(c, hipSetDevice(c->device));
   VO_TT("setdevice");
-  RC(frame_init(c));
+  RC(vo_frame_init(c));
 #ifdef VO_TRACE_HOST
   ++vo_tt_n;
 #endif

@@ -1,0 +1,48 @@
+// frame_state.hpp — device / pinned buffers shared by the frame operators (frame_pipeline.hip: stereo,
+// frame_mono.hip: mono). Allocated once per context by vo_frame_init (capacity cfg.max_points).
+#pragma once
+#include "vo_internal.hpp"
+
+// header of the packed result block (device and pinned-host copies share the layout)
+struct vo_frame_hdr {
+  int cnt[8];  // [0]=nA [1]=nB [2]=nC [3]=features replayed by the strict-border pass
+  vo_gn_dev_info gn;
+  int flags;
+  int pad_[1];
+  float dT[16];
+};
+
+struct vo_frame_state {
+  int cap;
+  // inputs (device copies when the caller passes host pointers)
+  float *in_l0, *in_r0, *in_X, *in_new;
+  // scratch in full index space
+  float *F_scale;
+  int32_t *F_orig;
+  // compacted sets
+  float *A_pl0, *A_pl1, *A_pr1, *A_X, *A_scale, *A_ref, *A_lastpu;
+  uint8_t *A_touched, *A_cls;
+  int32_t *A_orig;
+  float *B_pl1, *B_pr1, *B_X;
+  int32_t *B_orig;
+  float *C_pl1, *C_pr1, *C_X;
+  int32_t *C_orig;
+  uint8_t *m1, *m2, *m3, *mG;
+  uint8_t *st1, *st2, *st3;
+  float *e1, *e2, *e3;
+  float *new_back;
+  int *ctl;  // fused path: error flags + replay control words (zero between frames)
+  // packed result block
+  uint8_t *res_dev, *res_host;
+  size_t res_cap;
+  // views into res_dev for the frame in flight
+  vo_frame_hdr *hdr;
+  uint8_t *stage, *mNew;
+  float *F_pl1, *F_pr1, *new_r;
+  size_t off_stage, off_mnew, off_pl1, off_pr1, off_newr, res_bytes;
+  int n, n_new;
+  bool pending;
+  hipEvent_t ev_done;  // recorded after the packed D2H: result() waits for this, not for the stream
+};
+
+int vo_frame_init(vo_ctx *c);
