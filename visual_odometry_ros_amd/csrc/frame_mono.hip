@@ -183,6 +183,9 @@ struct MonoGateArgs {
   int *ctl;                 // frame control block: reported ([0] flags, replay count) and reset here
   int ctl_words, nt_word;
   int *hdr_flags;
+  const uint32_t *res_dev;  // packed result block -> res_host (pinned, device-visible)
+  uint32_t *res_host;
+  int res_words;
 };
 __device__ __forceinline__ float mono_dot3(float a0, float b0, float a1, float b1, float a2, float b2) {
   return a0 * b0 + (a1 * b1 + a2 * b2);  // Eigen's unrolled 3-term redux
@@ -270,6 +273,11 @@ __global__ __launch_bounds__(1024) void mono_gate_kernel(MonoGateArgs a) {
     a.cnt[4] = s_cnt[4];
     a.cnt[5] = ok ? 0 : 1;
   }
+  // every header word is written by a launch of this frame (cnt[6]: compaction, gn / dT: GN, the rest
+  // above), so the block needs no clearing. It goes to pinned host memory from here (all final: earlier
+  // launches' stores, and this workgroup's own above)
+  __syncthreads();
+  for (int k = tid; k < a.res_words; k += 1024) a.res_host[k] = a.res_dev[k];
 }
 
 // ---- host side ---------------------------------------------------------------------
@@ -317,7 +325,6 @@ extern "C" int vo_mono_frame_enqueue(vo_ctx *c, const vo_mono_params *prm, int s
   f->hdr = (vo_frame_hdr *)f->res_dev;
   f->stage = f->res_dev + f->off_stage;
   f->F_pl1 = (float *)(f->res_dev + f->off_pl1);
-  VO_CHECK_HIP(c, hipMemsetAsync(f->hdr, 0, sizeof(vo_frame_hdr), s));
   if (n > 0) {
     if (slot0 < 0 || slot0 >= c->cfg.n_slots || slot1 < 0 || slot1 >= c->cfg.n_slots ||
         c->slots[slot0].n_levels <= 0 || c->slots[slot1].n_levels <= 0)
@@ -346,7 +353,8 @@ extern "C" int vo_mono_frame_enqueue(vo_ctx *c, const vo_mono_params *prm, int s
     a.thres_err = prm->thres_err;
     a.thres_bidir = prm->thres_bidirection;
     a.strict = c->frame_strict_ic;
-    a.scale = f->F_scale;
+    float *d_scale = (float *)(f->res_dev + f->off_pr1);  // written straight into the result block
+    a.scale = d_scale;
     a.k1 = f->A_pl1;
     a.Xp = f->A_X;
     a.m1 = f->m1;
@@ -355,7 +363,7 @@ extern "C" int vo_mono_frame_enqueue(vo_ctx *c, const vo_mono_params *prm, int s
     rc = vo_ic_frame_args(c, slot0, slot1, &a.ic, f->ctl, a.strict != 0);
     if (rc) return rc;
     a.ic.pts0 = d_p0;
-    a.ic.scale = f->F_scale;
+    a.ic.scale = d_scale;
     a.ic.pts_prior = f->A_pl1;
     a.ic.pts_track = f->A_ref;
     a.ic.mask = f->m2;
@@ -421,16 +429,18 @@ extern "C" int vo_mono_frame_enqueue(vo_ctx *c, const vo_mono_params *prm, int s
     g.ctl_words = (int)(vo_ic_ctl_bytes() / 4);
     g.nt_word = vo_ic_ctl_nt_word();
     g.hdr_flags = &f->hdr->flags;
+    g.res_dev = (const uint32_t *)f->res_dev;
+    g.res_host = (uint32_t *)f->res_host;
+    g.res_words = (int)((f->res_bytes + 3) / 4);
     vo_prof_begin(c, VO_K_AUX);
     hipLaunchKernelGGL(mono_gate_kernel, dim3(1), dim3(1024), 0, s, g);
     vo_prof_end(c);
-    // scale goes out with the block
-    VO_CHECK_HIP(c, hipMemcpyAsync(f->res_dev + f->off_pr1, f->F_scale, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, s));
+    VO_CHECK_HIP(c, hipGetLastError());
   } else {
+    VO_CHECK_HIP(c, hipMemsetAsync(f->hdr, 0, sizeof(vo_frame_hdr), s));
     VO_CHECK_HIP(c, hipMemcpyAsync(f->hdr->dT, dT01_prior, sizeof(float) * 16, hipMemcpyHostToDevice, s));
+    VO_CHECK_HIP(c, hipMemcpyAsync(f->res_host, f->res_dev, f->res_bytes, hipMemcpyDeviceToHost, s));
   }
-  VO_CHECK_HIP(c, hipGetLastError());
-  VO_CHECK_HIP(c, hipMemcpyAsync(f->res_host, f->res_dev, f->res_bytes, hipMemcpyDeviceToHost, s));
   VO_CHECK_HIP(c, hipEventRecord(f->ev_done, s));
   f->pending = true;
   return VO_OK;
