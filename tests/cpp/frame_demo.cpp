@@ -1,0 +1,123 @@
+// frame_demo.cpp — drives vo::StereoFramePipeline and vo::MonoFramePipeline (frame_pipeline.h) the way a
+// VO front end would: images are pushed as they arrive, one enqueue / result per frame.
+// Reads raw little-endian arrays from argv[1], writes results to argv[2].
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "visual_odometry_ros_amd/core/visual_odometry/frame_pipeline.h"
+
+template <typename T>
+static std::vector<T> rd(FILE *f, size_t n) {
+  std::vector<T> v(n);
+  if (n && fread(v.data(), sizeof(T), n, f) != n) {
+    fprintf(stderr, "short read\n");
+    exit(2);
+  }
+  return v;
+}
+template <typename T>
+static void wr(FILE *f, const T *p, size_t n) {
+  if (n) fwrite(p, sizeof(T), n, f);
+}
+static vo::PoseSE3 pose(const std::vector<float> &v) {
+  vo::PoseSE3 T;
+  for (int i = 0; i < 16; ++i) T[i] = v[i];
+  return T;
+}
+
+int main(int argc, char **argv) {
+  if (argc < 3) return 1;
+  FILE *f = fopen(argv[1], "rb");
+  if (!f) return 1;
+  int hdr[6];
+  if (fread(hdr, sizeof(int), 6, f) != 6) return 1;
+  const int w = hdr[0], h = hdr[1], n = hdr[2], n_new = hdr[3], win = hdr[4], lvl = hdr[5];
+  auto K = rd<float>(f, 4), Tlr = rd<float>(f, 16), dTp = rd<float>(f, 16);
+  auto L0 = rd<unsigned char>(f, (size_t)w * h), L1 = rd<unsigned char>(f, (size_t)w * h),
+       R1 = rd<unsigned char>(f, (size_t)w * h);
+  auto pl0 = rd<float>(f, 2 * n), pr0 = rd<float>(f, 2 * n), Xp = rd<float>(f, 3 * n), pnew = rd<float>(f, 2 * n_new);
+  auto Xw = rd<float>(f, 3 * n);
+  auto flags = rd<unsigned char>(f, n);
+  auto Tcw_prev = rd<float>(f, 16), Tcw_prior = rd<float>(f, 16);
+  fclose(f);
+
+  vo::PixelVec vl0(n), vr0(n), vnew(n_new);
+  vo::PointVec vXp(n), vXw(n);
+  for (int i = 0; i < n; ++i) {
+    vl0[i] = vo::Pixel(pl0[2 * i], pl0[2 * i + 1]);
+    vr0[i] = vo::Pixel(pr0[2 * i], pr0[2 * i + 1]);
+    vXp[i] = vo::Point(Xp[3 * i], Xp[3 * i + 1], Xp[3 * i + 2]);
+    vXw[i] = vo::Point(Xw[3 * i], Xw[3 * i + 1], Xw[3 * i + 2]);
+  }
+  for (int i = 0; i < n_new; ++i) vnew[i] = vo::Pixel(pnew[2 * i], pnew[2 * i + 1]);
+
+  FILE *o = fopen(argv[2], "wb");
+  if (!o) return 1;
+  {  // ---- stereo (thresholds of config/stereo/kitti_00_stereo.yaml) ----
+    auto ctx = std::make_shared<vo::Context>(0, w, h, n + n_new + 64, 3, lvl);
+    vo_stereo_params prm;
+    memset(&prm, 0, sizeof(prm));
+    prm.width = w;
+    prm.height = h;
+    prm.win = win;
+    prm.max_level = lvl;
+    prm.thres_err = 80.0f;
+    prm.thres_bidirection = 0.5f;
+    prm.thres_poseba = 3.0f;
+    for (int i = 0; i < 4; ++i) prm.Kl[i] = prm.Kr[i] = K[i];
+    for (int i = 0; i < 16; ++i) prm.T_lr[i] = Tlr[i];
+    vo::StereoFramePipeline pipe(ctx, prm, true);
+    pipe.setFirstImage(vo::Image(L0.data(), w, h, w));
+    pipe.pushStereoPair(vo::Image(L1.data(), w, h, w), vo::Image(R1.data(), w, h, w));
+    pipe.enqueue(vl0, vr0, vXp, pose(dTp), vnew);
+    vo::StereoFrameResult r = pipe.result();
+    int threw = 0;
+    try {
+      vo::PixelVec bad(n + 1);
+      pipe.enqueue(vl0, bad, vXp, pose(dTp), vnew);
+    } catch (const std::runtime_error &) {
+      threw = 1;
+    }
+    const int head[4] = {r.pose_ok ? 1 : 0, r.counts.n_inlier, r.gn.iterations, threw};
+    wr(o, head, 4);
+    wr(o, r.dT_pc.data(), 16);
+    wr(o, &r.pts_l1.data()->x, 2 * (size_t)n);
+    wr(o, &r.pts_r1.data()->x, 2 * (size_t)n);
+    wr(o, r.stage.data(), (size_t)n);
+    wr(o, &r.pts_new_r.data()->x, 2 * (size_t)n_new);
+    std::vector<unsigned char> mn(n_new);
+    for (int i = 0; i < n_new; ++i) mn[i] = r.mask_new[i] ? 1 : 0;
+    wr(o, mn.data(), (size_t)n_new);
+  }
+  {  // ---- mono on the left images ----
+    auto ctx = std::make_shared<vo::Context>(0, w, h, n + 64, 2, lvl);
+    vo_mono_params prm;
+    memset(&prm, 0, sizeof(prm));
+    prm.width = w;
+    prm.height = h;
+    prm.win = win;
+    prm.max_level = lvl;
+    prm.thres_err = 20.0f;
+    prm.thres_bidirection = 1.0f;
+    prm.thres_poseba = 5;
+    prm.thres_sampson = 1.0f;
+    for (int i = 0; i < 4; ++i) prm.K[i] = K[i];
+    vo::MonoFramePipeline pipe(ctx, prm, true);
+    pipe.pushImage(vo::Image(L1.data(), w, h, w));  // a frame that is dropped again by the next two pushes
+    pipe.pushImage(vo::Image(L0.data(), w, h, w));
+    pipe.pushImage(vo::Image(L1.data(), w, h, w));
+    std::vector<std::uint8_t> fl(flags.begin(), flags.end());
+    pipe.enqueue(vl0, vXw, fl, pose(Tcw_prev), pose(Tcw_prior), pose(dTp));
+    vo::MonoFrameResult r = pipe.result();
+    const int head[4] = {r.need_five_point ? 1 : 0, r.counts.n_final, r.counts.n_ba, r.gn.iterations};
+    wr(o, head, 4);
+    wr(o, r.dT01.data(), 16);
+    wr(o, &r.pts1.data()->x, 2 * (size_t)n);
+    wr(o, r.scale.data(), (size_t)n);
+    wr(o, r.stage.data(), (size_t)n);
+  }
+  fclose(o);
+  return 0;
+}

@@ -15,9 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIBDIR = os.path.join(ROOT, "visual_odometry_ros_amd", "lib")
 
 
-def _compile(tmp_path):
-    exe = str(tmp_path / "host_mirror_demo")
-    cmd = ["g++", "-std=c++17", "-O2", "-I", ROOT, os.path.join(ROOT, "tests", "cpp", "host_mirror_demo.cpp"), "-o", exe,
+def _compile(tmp_path, name="host_mirror_demo"):
+    exe = str(tmp_path / name)
+    cmd = ["g++", "-std=c++17", "-O2", "-I", ROOT, os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-o", exe,
            "-L", LIBDIR, "-lvo_hip", f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib",
            "-lamdhip64"]
     subprocess.check_call(cmd)
@@ -28,6 +28,7 @@ def test_cpp_mirror_compiles_and_links(vo, tmp_path):
     vo.load()
     exe = _compile(tmp_path)
     assert os.path.exists(exe)
+    assert os.path.exists(_compile(tmp_path, "frame_demo"))
     # the reference-typed adapter is gated on OpenCV/Eigen headers and must at least preprocess away
     subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I", ROOT, "-x", "c++",
                            os.path.join(ROOT, "visual_odometry_ros_amd", "core", "visual_odometry",
@@ -71,3 +72,75 @@ def test_cpp_mirror_matches_python_api_and_oracle(ctx, vo, oracle, tmp_path):
     rc, r_o2, m2_o2, _ = oracle.track_with_scale(img0, img1, pts0, np.ones(npt, np.float32), p_o, None,
                                                  oracle.IC_REFERENCE, oracle.SUM_TREE)
     assert np.array_equal(mv2, m2_o2) and np.array_equal(ref, r_o2)
+
+
+@pytest.mark.gpu
+def test_cpp_frame_pipelines_match_python_api(vo, tmp_path):
+    """vo::StereoFramePipeline / vo::MonoFramePipeline (frame_pipeline.h) give the Python mirrors' results
+    bit for bit (those are checked against the oracle in test_frame_gpu.py / test_mono_frame_gpu.py)."""
+    from visual_odometry_ros_amd.api import (MonoFramePipeline, StereoFramePipeline, make_mono_params,
+                                             make_stereo_params)
+    exe = _compile(tmp_path, "frame_demo")
+    W, H, win, lvl = 640, 240, 21, 4
+    K = (400.0, 400.0, 320.0, 120.0)
+    stream = S.StereoStream(width=W, height=H, K=K, n_u=24, n_v=10, n_new=30, seed=11, margin=6.0)
+    poses = stream.poses(3)
+    L0, _, _ = stream.render_pair(poses[1])
+    L1, R1, _ = stream.render_pair(poses[2])
+    ts = stream.track_set(1, poses[1], poses[2])
+    n, nn = ts["pts_l0"].shape[0], ts["pts_new"].shape[0]
+    rng = np.random.default_rng(4)
+    flags = ((rng.random(n) < 0.7).astype(np.uint8) | ((rng.random(n) < 0.8).astype(np.uint8) << 1)).astype(np.uint8)
+    dT = ts["dT_prior"].astype(np.float32)
+    Tcw_prev = np.eye(4, dtype=np.float32)
+    Tcw_prior = np.linalg.inv(dT.astype(np.float64)).astype(np.float32)
+    Xw = ts["Xp"].astype(np.float32)
+    inp, outp = tmp_path / "fin.bin", tmp_path / "fout.bin"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("6i", W, H, n, nn, win, lvl))
+        for a in (np.asarray(K, np.float32), stream.T_lr.astype(np.float32).reshape(16), dT.reshape(16), L0, L1, R1,
+                  ts["pts_l0"], ts["pts_r0"], ts["Xp"].astype(np.float32), ts["pts_new"], Xw, flags,
+                  Tcw_prev.reshape(16), Tcw_prior.reshape(16)):
+            f.write(np.ascontiguousarray(a).tobytes())
+    subprocess.check_call([exe, str(inp), str(outp)])
+    raw = open(outp, "rb").read()
+    off = 0
+
+    def take(dt, cnt):
+        nonlocal off
+        a = np.frombuffer(raw, dt, cnt, off)
+        off += a.nbytes
+        return a
+
+    # ---- stereo
+    c = vo.Context(device=0, max_width=W, max_height=H, max_points=n + nn + 64, n_slots=3, max_level=lvl)
+    try:
+        c.set_image(0, L0)
+        c.set_image(1, L1)
+        c.set_image(2, R1)
+        pipe = StereoFramePipeline(c, make_stereo_params(W, H, win, lvl, 80.0, 0.5, 3.0, K, K, stream.T_lr), True)
+        pipe.enqueue(ts["pts_l0"], ts["pts_r0"], ts["Xp"], dT, ts["pts_new"])
+        g = pipe.result()
+        head = take(np.int32, 4)
+        assert head[0] == 1 and head[1] == g["counts"].n_inlier and head[2] == g["gn"].iterations and head[3] == 1
+        assert g["counts"].n_inlier > 0.5 * n
+        assert np.array_equal(take(np.float32, 16).reshape(4, 4), g["dT"])
+        assert np.array_equal(take(np.float32, 2 * n).reshape(-1, 2), g["pts_l1"])
+        assert np.array_equal(take(np.float32, 2 * n).reshape(-1, 2), g["pts_r1"])
+        assert np.array_equal(take(np.uint8, n), g["stage"])
+        assert np.array_equal(take(np.float32, 2 * nn).reshape(-1, 2), g["pts_new_r"])
+        assert np.array_equal(take(np.uint8, nn).astype(bool), g["mask_new"])
+        # ---- mono
+        mp = MonoFramePipeline(c, make_mono_params(W, H, win, lvl, 20.0, 1.0, 5, 1.0, K), True)
+        mp.enqueue(ts["pts_l0"], Xw, flags, Tcw_prev, Tcw_prior, dT)
+        m = mp.result()
+        head = take(np.int32, 4)
+        assert head[0] == 0 and head[1] == m["counts"].n_final and head[2] == m["counts"].n_ba
+        assert head[3] == m["gn"].iterations and m["counts"].n_final > 0.5 * n
+        assert np.array_equal(take(np.float32, 16).reshape(4, 4), m["dT01"])
+        assert np.array_equal(take(np.float32, 2 * n).reshape(-1, 2), m["pts1"])
+        assert np.array_equal(take(np.float32, n), m["scale"])
+        assert np.array_equal(take(np.uint8, n), m["stage"])
+        assert off == len(raw)
+    finally:
+        c.close()
