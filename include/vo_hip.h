@@ -230,6 +230,31 @@ int vo_stereo_frame_result(vo_ctx *ctx, float *pts_l1, float *pts_r1, uint8_t *s
                            float dT[16], float *pts_new_r, uint8_t *mask_new,
                            vo_frame_counts *counts, vo_gn_info *gn);
 
+/* ---- undistortion / stereo rectification in front of the trackers ----------
+ * core/visual_odometry/camera.cpp. A context holds the maps of two cameras
+ * (cam 0 = left or the mono camera, cam 1 = right), device-resident. */
+/* Camera::generateImageUndistortMaps (camera.cpp:56-90): K = fx,fy,cx,cy ; D = k1,k2,p1,p2,k3 */
+int vo_rectify_init_mono(vo_ctx *ctx, int cam, int width, int height, const float K[4], const float D[5]);
+/* StereoCamera::generateStereoImagesUndistortAndRectifyMaps (camera.cpp:364-546): maps of cam 0 and 1;
+ * returns the rectified camera K_rect = f,f,cu,cv (getRectifiedCamera) and the rectified extrinsics
+ * (getRectifiedStereoPoseLeft2Right / Right2Left; row-major 4x4; T_rl_rect may be NULL) */
+int vo_rectify_init_stereo(vo_ctx *ctx, int width, int height, const float Kl[4], const float Dl[5],
+                           const float Kr[4], const float Dr[5], const float T_lr[16], float K_rect[4],
+                           float T_lr_rect[16], float T_rl_rect[16]);
+/* caller-made maps (what cv::remap takes as map1 / map2, CV_32FC1, width x height, tightly packed) */
+int vo_rectify_set_maps(vo_ctx *ctx, int cam, const float *map_u, const float *map_v, int width, int height);
+int vo_rectify_get_maps(vo_ctx *ctx, int cam, float *map_u, float *map_v, int *width, int *height);
+/* Camera::undistortImage / StereoCamera::rectifyStereoImages (camera.cpp:166-183, :300-336) +
+ * convertTo(CV_8UC1) (stereo_vo.cpp:420-421, mono_vo.cpp:512), fused into the pyramid build of the slot:
+ * vo_set_image* with the raw image and the camera whose map applies. The image must have the map's
+ * size (VO_ERR_SIZE otherwise, as the reference throws). */
+int vo_set_image_rectified(vo_ctx *ctx, int slot, const uint8_t *host, int width, int height, int stride, int cam);
+int vo_set_image_rectified_device(vo_ctx *ctx, int slot, const void *dev, int width, int height, int stride,
+                                  int cam);
+/* left image through cam 0's map, right image through cam 1's, one launch chain */
+int vo_set_stereo_pair_rectified_device(vo_ctx *ctx, int slot_l, const void *dev_l, int slot_r, const void *dev_r,
+                                        int width, int height, int stride);
+
 /* ---- steady-state mono frame ----------------------------------------------
  * The operator sequence of MonoVO::trackImage
  * (core/visual_odometry/mono_vo/mono_vo.cpp:739-963): prior pixel + patch scale

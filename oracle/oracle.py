@@ -423,3 +423,30 @@ def stereo_frame(prm, I0l, I1l, I1r, pts_l0, pts_r0, Xp, dT_prior, pts_new, sum_
         C.byref(counts))
     return dict(rc=rc, pts_l1=pts_l1[:n], pts_r1=pts_r1[:n], stage=stage[:n], dT=dT.reshape(4, 4),
                 pts_new_r=pnr[:nn], mask_new=mnew[:nn].astype(bool), counts=counts)
+
+
+# ---- image ingestion with flagDoUndistortion (oracle_rectify.c) ----
+def image_undistort_maps(n_cols, n_rows, K, D):
+    mu = np.zeros((n_rows, n_cols), np.float32)
+    mv = np.zeros((n_rows, n_cols), np.float32)
+    lib().vo_ref_image_undistort_maps(n_cols, n_rows, _p(_f32(K).reshape(4)), _p(_f32(D).reshape(5)), _p(mu), _p(mv))
+    return mu, mv
+
+
+def stereo_rectify_maps(n_cols, n_rows, Kl, Dl, Kr, Dr, T_lr):
+    maps = [np.zeros((n_rows, n_cols), np.float32) for _ in range(4)]
+    K_rect = np.zeros(4, np.float32)
+    T_rect = np.zeros(16, np.float32)
+    lib().vo_ref_stereo_rectify_maps(n_cols, n_rows, _p(_f32(Kl).reshape(4)), _p(_f32(Dl).reshape(5)),
+                                     _p(_f32(Kr).reshape(4)), _p(_f32(Dr).reshape(5)), _p(_f32(T_lr).reshape(16)),
+                                     _p(maps[0]), _p(maps[1]), _p(maps[2]), _p(maps[3]), _p(K_rect), _p(T_rect))
+    return dict(left=(maps[0], maps[1]), right=(maps[2], maps[3]), K_rect=K_rect, T_lr_rect=T_rect.reshape(4, 4))
+
+
+def remap_linear_u8(src, map_u, map_v):
+    src, w, h, st = _img(src)
+    map_u, map_v = _f32(map_u), _f32(map_v)
+    dh, dw = map_u.shape
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().vo_ref_remap_linear_u8(_p(src, C.c_uint8), w, h, st, _p(map_u), _p(map_v), dw, dh, _p(dst, C.c_uint8))
+    return dst

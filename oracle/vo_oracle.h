@@ -201,6 +201,23 @@ int vo_ref_mono_frame(const vo_ref_mono_params *prm, const uint8_t *I0, const ui
                       int ic_border_mode, int n_threads, float *pts1, float *scale, uint8_t *stage,
                       float dT01_out[16], vo_ref_mono_counts *counts);
 
+/* ---- image ingestion with flagDoUndistortion (oracle_rectify.c) ---- */
+/* Camera::generateImageUndistortMaps, camera.cpp:56-90. K = fx,fy,cx,cy ; D = k1,k2,p1,p2,k3 */
+void vo_ref_image_undistort_maps(int n_cols, int n_rows, const float K[4], const float D[5], float *map_u,
+                                 float *map_v);
+/* pixel-independent part of StereoCamera::generateStereoImagesUndistortAndRectifyMaps (camera.cpp:364-432,
+ * :530-535): M = R_0n * K_rect^-1, R_l0, R_r0 (row-major 3x3), K_rect = f,f,cu,cv, T_lr_rect row-major 4x4 */
+void vo_ref_stereo_rectify_setup(int n_cols, int n_rows, const float Kl[4], const float Kr[4], const float T_lr[16],
+                                 float M[9], float R_l0[9], float R_r0[9], float K_rect[4], float T_lr_rect[16]);
+/* the whole of camera.cpp:364-546 */
+void vo_ref_stereo_rectify_maps(int n_cols, int n_rows, const float Kl[4], const float Dl[5], const float Kr[4],
+                                const float Dr[5], const float T_lr[16], float *map_lu, float *map_lv, float *map_ru,
+                                float *map_rv, float K_rect[4], float T_lr_rect[16]);
+/* convertTo(CV_32FC1) -> cv::remap(float maps, INTER_LINEAR, BORDER_CONSTANT 0) -> convertTo(CV_8UC1)
+ * (camera.cpp:166-183, :300-336 ; stereo_vo.cpp:420-421 ; mono_vo.cpp:512). dst is dw x dh, tightly packed. */
+void vo_ref_remap_linear_u8(const uint8_t *src, int w, int h, int stride, const float *map_u, const float *map_v,
+                            int dw, int dh, uint8_t *dst);
+
 #ifdef __cplusplus
 }
 #endif

@@ -258,3 +258,64 @@ def test_bucketing_vs_python(oracle):
             best[b] = (r, i)
     exp = [best[b][1] for b in sorted(best)]
     assert list(idx) == exp and np.array_equal(out, kp[exp])
+
+
+def test_rectify_maps_and_remap_vs_float64(oracle):
+    """oracle_rectify.c against independent float64 numpy restatements: the undistortion map, the stereo
+    rectification (rectified rows of the two cameras see the same 3-D ray height; identity rig -> both
+    maps are the plain distortion map shifted by the 1-based pixel convention), and the remap."""
+    W, H = 160, 120
+    K, D = (150.0, 152.0, 80.5, 59.5), (-0.28, 0.07, 0.0002, -0.0001, 0.01)
+    mu, mv = oracle.image_undistort_maps(W, H, K, D)
+    u, v = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+
+    def distort(x, y, K, D):
+        r2 = x * x + y * y
+        rad = 1 + D[0] * r2 + D[1] * r2 ** 2 + D[4] * r2 ** 3
+        xd = x * rad + D[2] * 2 * x * y + D[3] * (r2 + 2 * x * x)
+        yd = y * rad + D[2] * (r2 + 2 * y * y) + D[3] * 2 * x * y
+        return K[2] + xd * K[0], K[3] + yd * K[1]
+
+    eu, ev = distort((u - K[2]) / K[0], (v - K[3]) / K[1], K, D)
+    assert np.abs(mu - eu).max() < 1e-4 and np.abs(mv - ev).max() < 1e-4
+    # remap: quantised bilinear in float64
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    out = oracle.remap_linear_u8(img, mu, mv)
+    fx, fy = np.rint(mu.astype(np.float64) * 32), np.rint(mv.astype(np.float64) * 32)
+    sx, sy = np.floor(fx / 32).astype(int), np.floor(fy / 32).astype(int)
+    ax, ay = (fx - 32 * sx) / 32, (fy - 32 * sy) / 32
+    P = np.pad(img.astype(np.float64), 2)
+
+    def S(yy, xx):
+        ok = (yy >= -2) & (yy < H + 2) & (xx >= -2) & (xx < W + 2)
+        return np.where(ok, P[np.clip(yy + 2, 0, H + 3), np.clip(xx + 2, 0, W + 3)], 0)
+
+    val = S(sy, sx) * (1 - ay) * (1 - ax) + S(sy, sx + 1) * (1 - ay) * ax + S(sy + 1, sx) * ay * (1 - ax) \
+        + S(sy + 1, sx + 1) * ay * ax
+    assert np.array_equal(out, np.clip(np.rint(val), 0, 255).astype(np.uint8))
+    # stereo: float64 restatement of camera.cpp:364-546
+    Kr, Dr = (151.0, 151.5, 79.0, 60.2), (-0.27, 0.06, 0.0, 0.0001, 0.0)
+    th = 0.02
+    T = np.eye(4)
+    T[:3, :3] = [[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]]
+    T[:3, 3] = [0.11, 0.002, -0.001]
+    r = oracle.stereo_rectify_maps(W, H, K, D, Kr, Dr, T.astype(np.float32))
+    R0r, t = T[:3, :3], T[:3, 3]
+    kn = (np.array([0, 0, 1.0]) + R0r[:, 2]) / 2
+    kn /= np.linalg.norm(kn)
+    i_n = t / np.linalg.norm(t)
+    jn = np.cross(kn, i_n)
+    jn /= np.linalg.norm(jn)
+    kn = np.cross(i_n, jn)
+    R0n = np.stack([i_n, jn, kn], axis=1)
+    f = (K[0] + Kr[0]) / 2
+    Kn = np.array([[f, 0, W / 2], [0, f, H / 2], [0, 0, 1]])
+    P0 = (R0n @ np.linalg.inv(Kn)) @ np.stack([u + 1, v + 1, np.ones_like(u)]).reshape(3, -1)
+    xl, xr = P0, R0r.T @ P0
+    elu, elv = distort(xl[0] / xl[2], xl[1] / xl[2], K, D)
+    eru, erv = distort(xr[0] / xr[2], xr[1] / xr[2], Kr, Dr)
+    for got, exp in ((r["left"][0], elu), (r["left"][1], elv), (r["right"][0], eru), (r["right"][1], erv)):
+        assert np.abs(got.reshape(-1) - (exp - 1.0)).max() < 2e-4
+    assert np.allclose(r["K_rect"], [f, f, W / 2, H / 2])
+    assert np.allclose(r["T_lr_rect"][:3, 3], R0n.T @ t, atol=1e-6) and np.allclose(r["T_lr_rect"][:3, :3], np.eye(3))

@@ -45,3 +45,25 @@ def grid_points(h, w, step=17, margin=12, jitter_seed=1):
     pts = np.stack([xs.ravel(), ys.ravel()], 1).astype(np.float64)
     pts += rng.uniform(-0.5, 0.5, pts.shape)
     return pts.astype(np.float32)
+
+
+class DeviceBuffer:
+    """A raw HIP allocation holding a copy of a numpy array (through the HIP runtime libvo_hip.so is
+    already linked to — no torch, whose bundled runtime must not be initialised after it)."""
+
+    def __init__(self, arr):
+        import ctypes as C
+        self._C = C
+        self.hip = C.CDLL("libamdhip64.so.7")
+        a = np.ascontiguousarray(arr)
+        self.ptr = C.c_void_p()
+        assert self.hip.hipMalloc(C.byref(self.ptr), C.c_size_t(a.nbytes)) == 0
+        assert self.hip.hipMemcpy(self.ptr, a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes), 1) == 0  # H2D
+
+    def data_ptr(self):
+        return self.ptr.value
+
+    def free(self):
+        if self.ptr:
+            self.hip.hipFree(self.ptr)
+            self.ptr = self._C.c_void_p()

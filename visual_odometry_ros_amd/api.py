@@ -96,6 +96,20 @@ class Context:
         self.check(self.lib.vo_set_stereo_pair_device(self._h, slot_l, C.c_void_p(ptr_l), slot_r,
                                                       C.c_void_p(ptr_r), width, height, stride))
 
+    def set_image_rectified(self, slot, img, cam=0):
+        img = _u8(img)
+        assert img.ndim == 2
+        self.check(self.lib.vo_set_image_rectified(self._h, slot, _p(img, C.c_uint8), img.shape[1], img.shape[0],
+                                                   img.strides[0], cam))
+
+    def set_image_rectified_device(self, slot, dev_ptr, width, height, stride, cam=0):
+        self.check(self.lib.vo_set_image_rectified_device(self._h, slot, C.c_void_p(dev_ptr), width, height, stride,
+                                                          cam))
+
+    def set_stereo_pair_rectified_device(self, slot_l, ptr_l, slot_r, ptr_r, width, height, stride):
+        self.check(self.lib.vo_set_stereo_pair_rectified_device(self._h, slot_l, C.c_void_p(ptr_l), slot_r,
+                                                                C.c_void_p(ptr_r), width, height, stride))
+
     def set_pyramid_window_hint(self, win):
         self.check(self.lib.vo_set_pyramid_window_hint(self._h, win))
 
@@ -516,3 +530,98 @@ class MonoFramePipeline:
         self.ctx.check(self.lib.vo_mono_frame_result(self.ctx.handle, _p(pts1), _p(scale), _p(stage, C.c_uint8),
                                                      _p(dT), C.byref(cnt), C.byref(gn)))
         return dict(pts1=pts1[:n], scale=scale[:n], stage=stage[:n], dT01=dT.reshape(4, 4), counts=cnt, gn=gn)
+
+
+class Camera:
+    """Camera (core/visual_odometry/camera.h:22-137): the distortion model, its image-undistortion map
+    (generateImageUndistortMaps, camera.cpp:56-90) and undistortImage (camera.cpp:166-183). The map lives
+    on the device (`cam` selects which of the context's two map sets); undistortImage delivers straight
+    into an image slot's pyramid, including the driver's convertTo(CV_8UC1) (mono_vo.cpp:512)."""
+
+    def __init__(self, ctx, cam=0):
+        self.ctx, self.lib, self.cam = ctx, ctx.lib, cam
+        self.initialized = False
+
+    def initParams(self, n_cols, n_rows, K, D):
+        self.n_cols, self.n_rows = int(n_cols), int(n_rows)
+        self.K, self.D = _f32(K).reshape(4), _f32(D).reshape(5)  # fx fy cx cy ; k1 k2 p1 p2 k3
+        self.ctx.check(self.lib.vo_rectify_init_mono(self.ctx.handle, self.cam, self.n_cols, self.n_rows, _p(self.K),
+                                                     _p(self.D)))
+        self.initialized = True
+
+    def fx(self): return float(self.K[0])
+    def fy(self): return float(self.K[1])
+    def cx(self): return float(self.K[2])
+    def cy(self): return float(self.K[3])
+
+    def maps(self):
+        return _get_maps(self.ctx, self.cam)
+
+    def undistortImage(self, raw, slot):
+        raw = _u8(raw)
+        if raw.size == 0 or raw.shape != (self.n_rows, self.n_cols):  # camera.cpp:168-169
+            raise VoError(-4, "undistort image: provided image has not the same size as the camera model!")
+        self.ctx.set_image_rectified(slot, raw, self.cam)
+
+
+def _get_maps(ctx, cam):
+    w, h = C.c_int(), C.c_int()
+    ctx.check(ctx.lib.vo_rectify_get_maps(ctx.handle, cam, None, None, C.byref(w), C.byref(h)))
+    mu = np.zeros((h.value, w.value), np.float32)
+    mv = np.zeros((h.value, w.value), np.float32)
+    ctx.check(ctx.lib.vo_rectify_get_maps(ctx.handle, cam, _p(mu), _p(mv), None, None))
+    return mu, mv
+
+
+class StereoCamera:
+    """StereoCamera (core/visual_odometry/camera.h:140-195): setStereoPoseLeft2Right,
+    initStereoCameraToRectify (generateStereoImagesUndistortAndRectifyMaps, camera.cpp:364-546),
+    rectifyStereoImages (camera.cpp:300-336), the rectified camera and extrinsics."""
+
+    def __init__(self, ctx):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.is_initialized_to_stereo_rectify_ = False
+        self.T_lr = np.eye(4, dtype=np.float32)
+
+    def initParams(self, n_cols, n_rows, Kl, Dl, Kr, Dr):
+        self.n_cols, self.n_rows = int(n_cols), int(n_rows)
+        self.Kl, self.Dl = _f32(Kl).reshape(4), _f32(Dl).reshape(5)
+        self.Kr, self.Dr = _f32(Kr).reshape(4), _f32(Dr).reshape(5)
+
+    def setStereoPoseLeft2Right(self, T_lr):
+        self.T_lr = _f32(T_lr).reshape(4, 4)
+
+    def initStereoCameraToRectify(self):
+        K_rect, T1, T2 = np.zeros(4, np.float32), np.zeros(16, np.float32), np.zeros(16, np.float32)
+        self.ctx.check(self.lib.vo_rectify_init_stereo(
+            self.ctx.handle, self.n_cols, self.n_rows, _p(self.Kl), _p(self.Dl), _p(self.Kr), _p(self.Dr),
+            _p(_f32(self.T_lr).reshape(16)), _p(K_rect), _p(T1), _p(T2)))
+        self.K_rect, self.T_lr_rect, self.T_rl_rect = K_rect, T1.reshape(4, 4), T2.reshape(4, 4)
+        self.is_initialized_to_stereo_rectify_ = True
+
+    def _need_init(self, where):
+        if not self.is_initialized_to_stereo_rectify_:
+            raise VoError(-1, f"In '{where}', is_initialized_to_stereo_rectify_ == false")
+
+    def getRectifiedCamera(self):
+        self._need_init("getRectifiedCamera()")
+        return self.K_rect
+
+    def getRectifiedStereoPoseLeft2Right(self):
+        self._need_init("getRectifiedStereoPoseLeft2Right()")
+        return self.T_lr_rect
+
+    def getRectifiedStereoPoseRight2Left(self):
+        self._need_init("getRectifiedStereoPoseRight2Left()")
+        return self.T_rl_rect
+
+    def maps(self):
+        return _get_maps(self.ctx, 0), _get_maps(self.ctx, 1)
+
+    def rectifyStereoImages(self, img_left, img_right, slot_l, slot_r):
+        self._need_init("rectifyStereoImages()")
+        for im in (img_left, img_right):  # camera.cpp:307, :324
+            if np.asarray(im).shape != (self.n_rows, self.n_cols):
+                raise VoError(-4, "In 'rectifyStereoImages()': provided image has not the same size as the camera model!")
+        self.ctx.set_image_rectified(slot_l, img_left, 0)
+        self.ctx.set_image_rectified(slot_r, img_right, 1)

@@ -46,6 +46,52 @@ __global__ __launch_bounds__(256) void pad_level0_kernel(PadArgs a) {
   *(uint32_t *)(dst + (size_t)py * a.dstride + q * 4) = v;
 }
 
+// level 0 of an image that goes through Camera::undistortImage / StereoCamera::rectifyStereoImages first
+// (core/visual_odometry/camera.cpp:166-183, :300-336: convertTo(CV_32FC1), cv::remap with float maps,
+// INTER_LINEAR, BORDER_CONSTANT 0; then convertTo(CV_8UC1), stereo_vo.cpp:420-421 / mono_vo.cpp:512):
+// the remap is fused into the level-0 build, the float image never exists. cv::remap's arithmetic
+// (OpenCV 4 imgproc/imgwarp.cpp) for this case: coordinates quantised to 1/32 px with cvRound
+// (sx = round-half-even(mapx * 32)), weights (32-ay)(32-ax), (32-ay)ax, ay(32-ax), ay*ax over 1024, taps
+// outside the source = 0; convertTo = round-half-even, saturated. With u8 samples every product and the
+// sum are exact in float, so the integer form below gives the same bytes.
+struct RemapArgs {
+  const uint8_t *src[2];
+  const float *mu[2], *mv[2];
+  uint8_t *dst[2];
+  int w, h, sstride, dstride;
+};
+__device__ __forceinline__ int remap_sample(const uint8_t *__restrict__ src, int w, int h, int sstride, float mu,
+                                            float mv) {
+  if (!(mu == mu) || !(mv == mv)) return 0;  // cvRound(NaN) = INT_MIN on the CPU: far outside
+  const int fxq = (int)__builtin_rintf(mu * 32.0f), fyq = (int)__builtin_rintf(mv * 32.0f);  // saturating cvt
+  const int sx = fxq >> 5, sy = fyq >> 5, ax = fxq & 31, ay = fyq & 31;
+  if (sx >= w || sx + 1 < 0 || sy >= h || sy + 1 < 0) return 0;
+  const bool x0 = sx >= 0, x1 = sx + 1 < w, y0 = sy >= 0, y1 = sy + 1 < h;
+  const uint8_t *p = src + (ptrdiff_t)sy * sstride + sx;
+  const int s00 = (x0 && y0) ? p[0] : 0, s01 = (x1 && y0) ? p[1] : 0;
+  const int s10 = (x0 && y1) ? p[sstride] : 0, s11 = (x1 && y1) ? p[sstride + 1] : 0;
+  const int sum = s00 * ((32 - ay) * (32 - ax)) + s01 * ((32 - ay) * ax) + s10 * (ay * (32 - ax)) + s11 * (ay * ax);
+  return (sum + 511 + ((sum >> 10) & 1)) >> 10;  // round half to even of sum / 1024 (<= 255)
+}
+__global__ __launch_bounds__(256) void remap_level0_kernel(RemapArgs a) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  const int py = blockIdx.y;
+  const int pw = a.w + 2 * VO_PAD;
+  if (q * 4 >= pw) return;
+  const int z = blockIdx.z;
+  const uint8_t *__restrict__ src = a.src[z];
+  const float *__restrict__ mu = a.mu[z], *__restrict__ mv = a.mv[z];
+  const int y = reflect101_dev(py - VO_PAD, a.h);
+  uint32_t v = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int x = reflect101_dev(q * 4 + k - VO_PAD, a.w);
+    const size_t o = (size_t)y * a.w + x;
+    v |= (uint32_t)remap_sample(src, a.w, a.h, a.sstride, mu[o], mv[o]) << (8 * k);
+  }
+  *(uint32_t *)(a.dst[z] + (size_t)py * a.dstride + q * 4) = v;
+}
+
 // cv::pyrDown (5-tap [1 4 6 4 1]/16 both ways, +128 >> 8) of the padded level
 // l-1 into the whole padded level l. The source border already holds the
 // REFLECT_101 extension, so interior outputs read straight through it; border
@@ -130,7 +176,7 @@ static void layout_slot(vo_ctx *c, vo_pyramid *P, int w, int h) {
 
 // Build the pyramids of one image (d_r == nullptr) or of a stereo pair.
 static int build(vo_ctx *c, int slot_l, const uint8_t *d_l, int slot_r, const uint8_t *d_r, int w, int h,
-                 int stride) {
+                 int stride, const int *cams = nullptr) {
   const int nimg = d_r ? 2 : 1;
   if (slot_l < 0 || slot_l >= c->cfg.n_slots || (d_r && (slot_r < 0 || slot_r >= c->cfg.n_slots || slot_r == slot_l)))
     VO_FAIL(c, VO_ERR_INVALID, "slot out of range");
@@ -140,8 +186,33 @@ static int build(vo_ctx *c, int slot_l, const uint8_t *d_l, int slot_r, const ui
   for (int i = 0; i < nimg; ++i) layout_slot(c, P[i], w, h);
   int top = c->cfg.max_level;
   if (c->pyr_win_hint > 0) top = vo_pyr_levels_host(w, h, c->pyr_win_hint, c->cfg.max_level);
+  if (cams)
+    for (int i = 0; i < nimg; ++i) {
+      const int k = cams[i];
+      if (k < 0 || k > 1 || !c->rect_u[k]) VO_FAIL(c, VO_ERR_INVALID, "no rectification map for camera %d", k);
+      if (c->rect_w[k] != w || c->rect_h[k] != h)  // camera.cpp:169, :307, :324
+        VO_FAIL(c, VO_ERR_SIZE, "provided image has not the same size as the camera model (%dx%d vs map %dx%d)", w, h,
+                c->rect_w[k], c->rect_h[k]);
+    }
   vo_prof_begin(c, VO_K_PYRAMID);
-  {
+  if (cams) {
+    RemapArgs a;
+    a.src[0] = d_l;
+    a.src[1] = d_r ? d_r : d_l;
+    for (int i = 0; i < 2; ++i) {
+      const int k = cams[i < nimg ? i : 0];
+      a.mu[i] = c->rect_u[k];
+      a.mv[i] = c->rect_v[k];
+    }
+    a.dst[0] = P[0]->lv[0].base;
+    a.dst[1] = d_r ? P[1]->lv[0].base : P[0]->lv[0].base;
+    a.w = w;
+    a.h = h;
+    a.sstride = stride;
+    a.dstride = P[0]->lv[0].stride;
+    dim3 grid(((w + 2 * VO_PAD + 3) / 4 + 255) / 256, h + 2 * VO_PAD, nimg);
+    hipLaunchKernelGGL(remap_level0_kernel, grid, dim3(256), 0, c->stream, a);
+  } else {
     PadArgs a;
     a.src[0] = d_l;
     a.src[1] = d_r ? d_r : d_l;
@@ -178,4 +249,13 @@ int vo_pyramid_build(vo_ctx *c, int slot, const uint8_t *d_img, int w, int h, in
 int vo_pyramid_build_pair(vo_ctx *c, int slot_l, const uint8_t *d_l, int slot_r, const uint8_t *d_r, int w, int h,
                           int stride) {
   return build(c, slot_l, d_l, slot_r, d_r, w, h, stride);
+}
+// the same with the undistortion / rectification remap of camera `cam` (cam_l, cam_r) fused into level 0
+int vo_pyramid_build_rectified(vo_ctx *c, int slot, const uint8_t *d_img, int w, int h, int stride, int cam) {
+  return build(c, slot, d_img, -1, nullptr, w, h, stride, &cam);
+}
+int vo_pyramid_build_pair_rectified(vo_ctx *c, int slot_l, const uint8_t *d_l, int slot_r, const uint8_t *d_r, int w,
+                                    int h, int stride) {
+  const int cams[2] = {0, 1};
+  return build(c, slot_l, d_l, slot_r, d_r, w, h, stride, cams);
 }

@@ -76,6 +76,9 @@ struct vo_ctx {
   unsigned prof_mask;      // bit per kernel class; 0 = all
   int prof_open;           // begin() recorded an event that end() must close
   int pyr_win_hint;        // > 0: build only the levels calcOpticalFlowPyrLK would use for this window
+  // undistortion / rectification maps (rectify.hip): camera 0 = left or mono, 1 = right
+  float *rect_u[2], *rect_v[2];
+  int rect_w[2], rect_h[2];
 };
 
 #define VO_CHECK_HIP(ctx, expr)                                                            \

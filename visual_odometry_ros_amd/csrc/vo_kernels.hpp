@@ -34,6 +34,13 @@ int vo_pyramid_build(vo_ctx *c, int slot, const uint8_t *d_img, int w, int h, in
 int vo_pyramid_build_pair(vo_ctx *c, int slot_l, const uint8_t *d_l, int slot_r, const uint8_t *d_r, int w, int h,
                           int stride);
 
+int vo_pyramid_build_rectified(vo_ctx *c, int slot, const uint8_t *d_img, int w, int h, int stride, int cam);
+int vo_pyramid_build_pair_rectified(vo_ctx *c, int slot_l, const uint8_t *d_l, int slot_r, const uint8_t *d_r, int w,
+                                    int h, int stride);
+
+// rectify.hip
+void vo_rectify_free(vo_ctx *c);
+
 // klt_track.hip
 int vo_klt_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, const float *d_pts1_init,
                    float *d_pts1, int n_max,
