@@ -73,23 +73,25 @@ __device__ __forceinline__ int remap_sample(const uint8_t *__restrict__ src, int
   const int sum = s00 * ((32 - ay) * (32 - ax)) + s01 * ((32 - ay) * ax) + s10 * (ay * (32 - ax)) + s11 * (ay * ax);
   return (sum + 511 + ((sum >> 10) & 1)) >> 10;  // round half to even of sum / 1024 (<= 255)
 }
+// One lane per padded pixel: the two map loads of a wavefront are 256 contiguous bytes each (the maps are
+// 80 % of this kernel's bytes); four neighbouring lanes then pack their bytes so that the store is a dword.
 __global__ __launch_bounds__(256) void remap_level0_kernel(RemapArgs a) {
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  const int pxp = blockIdx.x * blockDim.x + threadIdx.x;  // padded column (the padded row is a multiple of 4 wide)
   const int py = blockIdx.y;
-  const int pw = a.w + 2 * VO_PAD;
-  if (q * 4 >= pw) return;
+  const int pw = (a.w + 2 * VO_PAD + 3) & ~3;
   const int z = blockIdx.z;
-  const uint8_t *__restrict__ src = a.src[z];
-  const float *__restrict__ mu = a.mu[z], *__restrict__ mv = a.mv[z];
-  const int y = reflect101_dev(py - VO_PAD, a.h);
-  uint32_t v = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int x = reflect101_dev(q * 4 + k - VO_PAD, a.w);
+  int val = 0;
+  if (pxp < pw) {
+    const int y = reflect101_dev(py - VO_PAD, a.h);
+    const int x = reflect101_dev(pxp - VO_PAD, a.w);
     const size_t o = (size_t)y * a.w + x;
-    v |= (uint32_t)remap_sample(src, a.w, a.h, a.sstride, mu[o], mv[o]) << (8 * k);
+    val = remap_sample(a.src[z], a.w, a.h, a.sstride, a.mu[z][o], a.mv[z][o]);
   }
-  *(uint32_t *)(a.dst[z] + (size_t)py * a.dstride + q * 4) = v;
+  uint32_t v = (uint32_t)val;
+  v |= (uint32_t)__shfl_down(val, 1) << 8;
+  v |= (uint32_t)__shfl_down(val, 2) << 16;
+  v |= (uint32_t)__shfl_down(val, 3) << 24;
+  if ((threadIdx.x & 3) == 0 && pxp < pw) *(uint32_t *)(a.dst[z] + (size_t)py * a.dstride + pxp) = v;
 }
 
 // cv::pyrDown (5-tap [1 4 6 4 1]/16 both ways, +128 >> 8) of the padded level
@@ -210,7 +212,7 @@ static int build(vo_ctx *c, int slot_l, const uint8_t *d_l, int slot_r, const ui
     a.h = h;
     a.sstride = stride;
     a.dstride = P[0]->lv[0].stride;
-    dim3 grid(((w + 2 * VO_PAD + 3) / 4 + 255) / 256, h + 2 * VO_PAD, nimg);
+    dim3 grid((w + 2 * VO_PAD + 3 + 255) / 256, h + 2 * VO_PAD, nimg);
     hipLaunchKernelGGL(remap_level0_kernel, grid, dim3(256), 0, c->stream, a);
   } else {
     PadArgs a;
