@@ -450,3 +450,77 @@ def remap_linear_u8(src, map_u, map_v):
     dst = np.zeros((dh, dw), np.uint8)
     lib().vo_ref_remap_linear_u8(_p(src, C.c_uint8), w, h, st, _p(map_u), _p(map_v), dw, dh, _p(dst, C.c_uint8))
     return dst
+
+
+# ---- sparse local bundle adjustment (oracle_sba.c) ----
+class SbaDims(C.Structure):
+    _fields_ = [("n_frames", C.c_int), ("n_opt", C.c_int), ("n_points", C.c_int), ("n_obs", C.c_int),
+                ("stereo", C.c_int), ("max_iter", C.c_int), ("Kl", C.c_double * 4), ("Kr", C.c_double * 4),
+                ("T_lr", C.c_double * 16), ("thres_huber", C.c_double)]
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def sba_solve(T_jw, opt_index, X, obs_ptr, obs_frame, obs_right, obs_px, Kl, Kr=None, T_lr=None, thres_huber=0.5,
+              max_iter=10):
+    """SparseBundleAdjustmentSolver::solveForFiniteIterations on flat arrays; returns (rc, T_jw, X, avg_err)."""
+    T = _f64(T_jw).reshape(-1, 16).copy()
+    Xo = _f64(X).reshape(-1, 3).copy()
+    opt_index, obs_ptr, obs_frame = _i32(opt_index), _i32(obs_ptr), _i32(obs_frame)
+    obs_right, obs_px = _u8(obs_right), _f64(obs_px).reshape(-1, 2)
+    d = SbaDims()
+    d.n_frames, d.n_points, d.n_obs = T.shape[0], Xo.shape[0], obs_px.shape[0]
+    d.n_opt = int(opt_index.max()) + 1 if opt_index.size else 0
+    d.stereo, d.max_iter, d.thres_huber = int(Kr is not None), max_iter, thres_huber
+    Kr = Kl if Kr is None else Kr
+    Tl = np.eye(4) if T_lr is None else _f64(T_lr).reshape(4, 4)
+    for k in range(4):
+        d.Kl[k], d.Kr[k] = float(Kl[k]), float(Kr[k])
+    for k in range(16):
+        d.T_lr[k] = float(Tl.reshape(16)[k])
+    err = np.zeros(max(max_iter, 1), np.float64)
+    f = lib().vo_ref_sba_solve
+    f.restype = C.c_int
+    rc = f(C.byref(d), _p(T, C.c_double), _p(opt_index, C.c_int32), _p(Xo, C.c_double), _p(obs_ptr, C.c_int32),
+           _p(obs_frame, C.c_int32), _p(obs_right, C.c_uint8), _p(obs_px, C.c_double), _p(err, C.c_double))
+    return rc, T.reshape(-1, 4, 4), Xo, err[:max_iter]
+
+
+def sba_linearize(T_jw, X, px, right, Kl, Kr, T_lr, thres_huber=0.5):
+    d = SbaDims()
+    for k in range(4):
+        d.Kl[k], d.Kr[k] = float(Kl[k]), float(Kr[k])
+    for k in range(16):
+        d.T_lr[k] = float(_f64(T_lr).reshape(16)[k])
+    d.thres_huber = thres_huber
+    r, w, R, Q = np.zeros(2), C.c_double(), np.zeros(6), np.zeros(12)
+    lib().vo_ref_sba_linearize(C.byref(d), _p(_f64(T_jw).reshape(16), C.c_double), _p(_f64(X), C.c_double),
+                               _p(_f64(px), C.c_double), int(right), _p(r, C.c_double), C.byref(w), _p(R, C.c_double),
+                               _p(Q, C.c_double))
+    return r, w.value, R.reshape(2, 3), Q.reshape(2, 6)
+
+
+def se3_exp_f64(xi):
+    T = np.zeros(16, np.float64)
+    lib().vo_ref_se3_exp_f64(_p(_f64(xi), C.c_double), _p(T, C.c_double))
+    return T.reshape(4, 4)
+
+
+def se3_log_f64(T):
+    xi = np.zeros(6, np.float64)
+    lib().vo_ref_se3_log_f64(_p(_f64(T).reshape(16), C.c_double), _p(xi, C.c_double))
+    return xi
+
+
+def ldlt_solve_f64(A, B):
+    A = _f64(A).copy()
+    n = A.shape[0]
+    B = _f64(B).reshape(n, -1).copy()
+    lib().vo_ref_ldlt_solve_f64(n, _p(A, C.c_double), B.shape[1], _p(B, C.c_double))
+    return B

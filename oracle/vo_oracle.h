@@ -218,6 +218,32 @@ void vo_ref_stereo_rectify_maps(int n_cols, int n_rows, const float Kl[4], const
 void vo_ref_remap_linear_u8(const uint8_t *src, int w, int h, int stride, const float *map_u, const float *map_v,
                             int dw, int dh, uint8_t *dst);
 
+/* ---- sparse local bundle adjustment (oracle_sba.c) ---- */
+typedef struct {
+  int n_frames; /* frames that carry a pose (mono frames / left frames of stereo keyframes) */
+  int n_opt;    /* optimised poses; opt_index[f] in [0, n_opt) or -1 */
+  int n_points, n_obs;
+  int stereo;
+  int max_iter;
+  double Kl[4], Kr[4];
+  double T_lr[16]; /* stereo pose left -> right as the solver sees it (scaled), row-major */
+  double thres_huber;
+} vo_ref_sba_dims;
+/* Eigen::LDLT restated in double: m n x n row-major (destroyed), B n x nrhs row-major in/out */
+int vo_ref_ldlt_solve_f64(int n, double *m, int nrhs, double *B);
+void vo_ref_se3_exp_f64(const double xi[6], double T[16]);
+void vo_ref_se3_log_f64(const double T[16], double xi[6]);
+void vo_ref_sba_pose_update(double T[16], const double x[6]);
+void vo_ref_sba_linearize(const vo_ref_sba_dims *d, const double T_jw[16], const double X[3], const double px[2],
+                          int right, double r[2], double *w, double R[6], double Q[12]);
+/* SparseBundleAdjustmentSolver::solveForFiniteIterations (sparse_bundle_adjustment.cpp:150-643).
+ * T_jw: n_frames x 16 in/out; X: n_points x 3 in/out; observations of landmark i are
+ * obs_ptr[i] .. obs_ptr[i+1]-1 in the order of lmba.kfs_seen: obs_frame = index of the (left) frame,
+ * obs_right = seen in that keyframe's right image, obs_px = pixel. avg_err[max_iter] (may be NULL).
+ * returns 1 = flag_success, 0 = average error above 1 px, -1 = NaN (the reference throws) */
+int vo_ref_sba_solve(const vo_ref_sba_dims *d, double *T_jw, const int *opt_index, double *X, const int *obs_ptr,
+                     const int *obs_frame, const uint8_t *obs_right, const double *obs_px, double *avg_err);
+
 #ifdef __cplusplus
 }
 #endif

@@ -319,3 +319,108 @@ def test_rectify_maps_and_remap_vs_float64(oracle):
         assert np.abs(got.reshape(-1) - (exp - 1.0)).max() < 2e-4
     assert np.allclose(r["K_rect"], [f, f, W / 2, H / 2])
     assert np.allclose(r["T_lr_rect"][:3, 3], R0n.T @ t, atol=1e-6) and np.allclose(r["T_lr_rect"][:3, :3], np.eye(3))
+
+
+def _sba_dense_step(p, lam=1e-5, huber=0.5):
+    """One damped Gauss-Newton step of the mono problem from a dense numerically-built Jacobian."""
+    from scipy.linalg import expm
+    T, X, opt = p["T_jw"], p["X"], p["opt_index"]
+    No, M = int(opt.max()) + 1, X.shape[0]
+    fx, fy, cx, cy = p["K"]
+
+    def hat(xi):
+        S = np.zeros((4, 4))
+        S[:3, :3] = [[0, -xi[5], xi[4]], [xi[5], 0, -xi[3]], [-xi[4], xi[3], 0]]
+        S[:3, 3] = xi[:3]
+        return S
+
+    def residuals(dx):
+        r = []
+        for i in range(M):
+            Xi = X[i] + dx[6 * No + 3 * i: 6 * No + 3 * i + 3]
+            for o in range(p["obs_ptr"][i], p["obs_ptr"][i + 1]):
+                f = p["obs_frame"][o]
+                Tf = T[f] if opt[f] < 0 else expm(hat(dx[6 * opt[f]: 6 * opt[f] + 6])) @ T[f]
+                Xc = Tf[:3, :3] @ Xi + Tf[:3, 3]
+                r += [fx * Xc[0] / Xc[2] + cx - p["obs_px"][o, 0], fy * Xc[1] / Xc[2] + cy - p["obs_px"][o, 1]]
+        return np.array(r)
+
+    n = 6 * No + 3 * M
+    r0 = residuals(np.zeros(n))
+    J = np.zeros((r0.size, n))
+    eps = 1e-6
+    for k in range(n):
+        d = np.zeros(n)
+        d[k] = eps
+        J[:, k] = (residuals(d) - residuals(-d)) / (2 * eps)
+    a = np.abs(r0[0::2]) + np.abs(r0[1::2])
+    w = np.repeat(np.where(a > huber, huber / a, 1.0), 2)
+    H = J.T @ (w[:, None] * J)
+    H[np.diag_indices(n)] *= 1 + lam
+    return np.linalg.solve(H, -J.T @ (w * r0)), expm, hat
+
+
+def test_sba_oracle_vs_dense_normal_equations(oracle):
+    """oracle_sba.c (Schur-complement form, reference loop order) against a dense normal-equation solve
+    with a finite-difference Jacobian on a small mono window; se3 exp/log and the generic LDLT against
+    scipy / numpy; convergence to the noise-free ground truth."""
+    p = S.ba_window(n_kf=5, n_points=40, stereo=False, seed=3, px_noise=0.0, width=1241, height=376)
+    dx, expm, hat = _sba_dense_step(p)
+    rc, T1, X1, err = oracle.sba_solve(p["T_jw"], p["opt_index"], p["X"], p["obs_ptr"], p["obs_frame"], p["obs_right"],
+                                       p["obs_px"], p["K"], max_iter=1)
+    No = int(p["opt_index"].max()) + 1
+    for f, j in enumerate(p["opt_index"]):
+        if j >= 0:
+            assert np.abs(T1[f] - expm(hat(dx[6 * j: 6 * j + 6])) @ p["T_jw"][f]).max() < 2e-6
+    assert np.abs(X1 - (p["X"] + dx[6 * No:].reshape(-1, 3))).max() < 2e-5
+    # se3 exp / log, LDLT
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        xi = rng.normal(0, 0.3, 6)
+        T = oracle.se3_exp_f64(xi)
+        assert np.abs(T - expm(hat(xi))).max() < 1e-12 and np.abs(oracle.se3_log_f64(T) - xi).max() < 1e-10
+    assert np.abs(oracle.se3_exp_f64(np.zeros(6)) - np.eye(4)).max() == 0
+    A = rng.normal(size=(30, 30))
+    A = A @ A.T + 0.1 * np.eye(30)
+    B = rng.normal(size=(30, 3))
+    assert np.abs(oracle.ldlt_solve_f64(A, B) - np.linalg.solve(A, B)).max() < 1e-9
+    # the per-observation Jacobians (left and right image, non-trivial stereo rotation) vs finite differences
+    w = np.array([0.02, -0.015, 0.01])
+    T_lr = expm(hat(np.concatenate([[0.0537, 0.001, -0.002], w])))
+    Kl, Kr = (718.856, 718.856, 607.19, 185.21), (710.0, 712.0, 600.0, 190.0)
+    for right in (0, 1):
+        Tj = expm(hat(rng.normal(0, 0.1, 6)))
+        Xi = np.array([0.3, -0.1, 2.0]) + rng.normal(0, 0.2, 3)
+
+        def proj(Tm, Xp):
+            Xc = Tm[:3, :3] @ Xp + Tm[:3, 3]
+            if right:
+                Trl = np.linalg.inv(T_lr)
+                Xc = Trl[:3, :3] @ Xc + Trl[:3, 3]
+            K = Kr if right else Kl
+            return np.array([K[0] * Xc[0] / Xc[2] + K[2], K[1] * Xc[1] / Xc[2] + K[3]])
+
+        px = proj(Tj, Xi) + np.array([0.9, -0.4])
+        r, wgt, R, Q = oracle.sba_linearize(Tj, Xi, px, right, Kl, Kr, T_lr)
+        assert np.abs(r - (proj(Tj, Xi) - px)).max() < 1e-9 and abs(wgt - 0.5 / 1.3) < 1e-9
+        e = 1e-6
+        for k in range(3):
+            d = np.zeros(3)
+            d[k] = e
+            assert np.abs((proj(Tj, Xi + d) - proj(Tj, Xi - d)) / (2 * e) - R[:, k]).max() < 1e-5
+        for k in range(6):
+            d = np.zeros(6)
+            d[k] = e
+            num = (proj(expm(hat(d)) @ Tj, Xi) - proj(expm(hat(-d)) @ Tj, Xi)) / (2 * e)
+            assert np.abs(num - Q[:, k]).max() < 1e-4
+    # noise-free data: mono converges quadratically to the ground truth (gauge fixed by two poses); stereo
+    # converges linearly — B_[j][i] keeps only the last of a keyframe's two observations (see the header)
+    for stereo in (False, True):
+        q = S.ba_window(n_kf=7, n_points=150, stereo=stereo, seed=5, px_noise=0.0)
+        rc, T, X, err = oracle.sba_solve(q["T_jw"], q["opt_index"], q["X"], q["obs_ptr"], q["obs_frame"], q["obs_right"],
+                                         q["obs_px"], q["K"], q["K"] if stereo else None, q["T_lr"] if stereo else None)
+        assert rc == 1 and err[0] > 1.0 and np.all(np.diff(err) < 0)
+        if not stereo:
+            assert err[-1] < 1e-9 and np.abs(T - q["T_jw_true"]).max() < 1e-10 and np.abs(X - q["X_true"]).max() < 1e-9
+        else:
+            assert err[-1] < 0.1 and np.abs(T - q["T_jw_true"]).max() < 5e-3 and np.abs(X - q["X_true"]).max() < 5e-2

@@ -247,3 +247,78 @@ class StereoStream:
         return dict(pts_l0=pts.astype(np.float32), pts_r0=pr.astype(np.float32),
                     Xp=Xn.astype(np.float32), dT_prior=dT_prior.astype(np.float32),
                     dT_true=dT_true, pts_new=new.astype(np.float32))
+
+
+def ba_window(n_kf=8, n_points=600, stereo=True, seed=0, K=KITTI_K, baseline=0.537, n_fix=2, px_noise=0.3,
+              pose_noise=(0.02, 0.004), point_noise=0.05, width=1241, height=376, scale=0.1, right_only_frac=0.0,
+              T_lr=None):
+    """A local-BA window as SparseBAParameters hands it to the solver (sparse_ba_parameters.h:283-420):
+    keyframe poses T_jw relative to the first keyframe with translations scaled by 1/pose_scale (0.1), the
+    first n_fix poses fixed, landmarks in that frame and scale, per-landmark observation lists in keyframe
+    order (left observation, then the right one of the same stereo keyframe). Returns a dict with the
+    perturbed problem (T_jw, X), the ground truth and the CSR observation arrays."""
+    rng = np.random.default_rng(seed)
+    fx, fy, cx, cy = K
+    # forward-moving rig with small rotations; keyframe 0 is the reference frame
+    T_wj = [np.eye(4)]
+    for _ in range(1, n_kf):
+        w = rng.normal(0, 0.01, 3)
+        th = np.linalg.norm(w)
+        k = w / th
+        Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        dT = np.eye(4)
+        dT[:3, :3] = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+        dT[:3, 3] = [rng.normal(0, 0.03), rng.normal(0, 0.02), 0.9 + rng.normal(0, 0.05)]
+        T_wj.append(T_wj[-1] @ dT)
+    if T_lr is None:
+        T_lr = np.eye(4)
+        T_lr[0, 3] = baseline
+    T_rl = np.linalg.inv(T_lr)
+    Xw = np.stack([rng.uniform(-12, 12, n_points), rng.uniform(-3, 3, n_points),
+                   rng.uniform(4, 45, n_points)], axis=1)
+    obs_ptr, obs_frame, obs_right, obs_px, keep = [0], [], [], [], []
+    for i in range(n_points):
+        fr, rt, px = [], [], []
+        for j in range(n_kf):
+            Xc = np.linalg.inv(T_wj[j]) @ np.append(Xw[i], 1.0)
+            for right in ((0, 1) if stereo else (0,)):
+                Xr = T_rl @ Xc if right else Xc
+                if Xr[2] < 0.5:
+                    continue
+                u, v = fx * Xr[0] / Xr[2] + cx, fy * Xr[1] / Xr[2] + cy
+                if not (5 < u < width - 5 and 5 < v < height - 5):
+                    continue
+                if right == 0 and stereo and rng.random() < right_only_frac:
+                    continue  # seen in the right image only
+                fr.append(j)
+                rt.append(right)
+                px.append([u + rng.normal(0, px_noise), v + rng.normal(0, px_noise)])
+        if len(fr) >= 2:  # THRES_MINIMUM_SEEN, sparse_ba_parameters.h:308
+            keep.append(i)
+            obs_frame += fr
+            obs_right += rt
+            obs_px += px
+            obs_ptr.append(len(obs_frame))
+    Xw = Xw[keep]
+    T_jw_true = np.stack([np.linalg.inv(T) for T in T_wj])
+    T_jw_true[:, :3, 3] *= scale
+    X_true = Xw * scale
+    T_jw = T_jw_true.copy()
+    for j in range(n_fix, n_kf):
+        xi = np.concatenate([rng.normal(0, pose_noise[0] * scale, 3), rng.normal(0, pose_noise[1], 3)])
+        w = xi[3:]
+        th = np.linalg.norm(w)
+        k = w / th
+        Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        dT = np.eye(4)
+        dT[:3, :3] = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+        dT[:3, 3] = xi[:3]
+        T_jw[j] = dT @ T_jw[j]
+    X = X_true + rng.normal(0, point_noise * scale, X_true.shape) * (X_true[:, 2:3] / (10 * scale))
+    opt_index = np.array([-1] * n_fix + list(range(n_kf - n_fix)), np.int32)
+    T_lr_s = T_lr.copy()
+    T_lr_s[:3, 3] *= scale
+    return dict(T_jw=T_jw, X=X, T_jw_true=T_jw_true, X_true=X_true, opt_index=opt_index,
+                obs_ptr=np.array(obs_ptr, np.int32), obs_frame=np.array(obs_frame, np.int32),
+                obs_right=np.array(obs_right, np.uint8), obs_px=np.array(obs_px, np.float64), K=np.array(K, np.float64),
+                T_lr=T_lr_s, stereo=stereo)
