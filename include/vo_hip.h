@@ -47,7 +47,8 @@ typedef enum {
   VO_ERR_NAN_PATCH = -6,  /* feature_tracker.cpp:443,447 */
   VO_ERR_NAN_UPDATE = -7, /* feature_tracker.cpp:465 "dtu dtv nan" */
   VO_ERR_CAPACITY = -8,   /* more points / larger image than vo_config allows */
-  VO_ERR_GN_FAILED = -9   /* stereo_vo.cpp:626 "PoseOnlyStereoBA is failed!" */
+  VO_ERR_GN_FAILED = -9,  /* stereo_vo.cpp:626 "PoseOnlyStereoBA is failed!" */
+  VO_ERR_LBA_NAN = -10    /* sparse_bundle_adjustment.cpp:318,:413 "In LBA, pose becomes nan!", :613, :764 "Local BA NAN!" */
 } vo_status;
 
 /* cv::OPTFLOW_USE_INITIAL_FLOW */
@@ -295,6 +296,35 @@ int vo_mono_frame_enqueue(vo_ctx *ctx, const vo_mono_params *prm, int slot0, int
  * forward KLT result. */
 int vo_mono_frame_result(vo_ctx *ctx, float *pts1, float *scale, uint8_t *stage, float dT01[16],
                          vo_mono_counts *counts, vo_gn_info *gn);
+
+/* ---- sparse local bundle adjustment -----------------------------------------
+ * SparseBundleAdjustmentSolver::solveForFiniteIterations
+ * (core/visual_odometry/ba_solver/sparse_bundle_adjustment.cpp:150-643; called from
+ * MotionEstimator::localBundleAdjustmentSparseSolver[_Stereo], motion_estimator.cpp:1090-1340, with
+ * MAX_ITER 10 and THRES_HUBER 0.5). The problem is what SparseBAParameters holds after
+ * setPosesAndPoints (sparse_ba_parameters.h:283-440), as flat arrays, in double:
+ *   T_jw      n_frames x 16   poses (row-major 4x4) of the frames that carry one - mono keyframes or the LEFT
+ *                             frames of stereo keyframes - in the window's reference frame, translations scaled
+ *   opt_index n_frames        index in [0, n_opt) of the pose in the optimisation, or -1 when it is fixed
+ *   X         n_points x 3    landmarks (same frame and scale)
+ *   obs_ptr   n_points + 1    observations of landmark i are obs_ptr[i] .. obs_ptr[i+1]-1, in the order of
+ *                             LandmarkBA::kfs_seen
+ *   obs_frame / obs_right / obs_px   frame index (the left frame for a right-image observation), seen in the
+ *                             right image, pixel
+ * T_jw (optimised poses) and X are updated in place. avg_err (max_iter doubles, may be NULL) receives the
+ * average pixel error the reference prints per iteration. Returns 1 = flag_success, 0 = average error of the
+ * last iteration above 1 px, VO_ERR_LBA_NAN where the reference throws. n_opt <= 20. */
+typedef struct {
+  int n_frames, n_opt, n_points, n_obs;
+  int stereo;
+  int max_iter;
+  double Kl[4], Kr[4];
+  double T_lr[16]; /* stereo pose left -> right as SparseBAParameters::getStereoPose gives it (scaled) */
+  double thres_huber;
+} vo_sba_problem;
+int vo_sba_solve(vo_ctx *ctx, const vo_sba_problem *prm, double *T_jw, const int32_t *opt_index, double *X,
+                 const int32_t *obs_ptr, const int32_t *obs_frame, const uint8_t *obs_right,
+                 const double *obs_px, double *avg_err);
 
 /* ---- kernel timing (HIP events on the context stream) --------------------- */
 enum { VO_K_PYRAMID = 0, VO_K_KLT = 1, VO_K_IC = 2, VO_K_GN = 3, VO_K_HAMMING = 4, VO_K_AUX = 5, VO_K_COUNT = 6 };

@@ -52,6 +52,12 @@ class MonoCounts(C.Structure):
                 ("need_five_point", C.c_int), ("n_replayed", C.c_int)]
 
 
+class SbaProblem(C.Structure):
+    _fields_ = [("n_frames", C.c_int), ("n_opt", C.c_int), ("n_points", C.c_int), ("n_obs", C.c_int),
+                ("stereo", C.c_int), ("max_iter", C.c_int), ("Kl", C.c_double * 4), ("Kr", C.c_double * 4),
+                ("T_lr", C.c_double * 16), ("thres_huber", C.c_double)]
+
+
 # every symbol include/vo_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "vo_abi_version", "vo_device_count", "vo_create", "vo_destroy", "vo_last_error", "vo_stream",
@@ -63,7 +69,7 @@ SYMBOLS = [
     "vo_orb_match", "vo_compact_indices", "vo_stereo_frame_set_strict_border",
     "vo_stereo_frame_enqueue", "vo_stereo_frame_result",
     "vo_mono_frame_enqueue", "vo_mono_frame_result",
-    "vo_rectify_init_mono", "vo_rectify_init_stereo", "vo_rectify_set_maps", "vo_rectify_get_maps",
+    "vo_sba_solve", "vo_rectify_init_mono", "vo_rectify_init_stereo", "vo_rectify_set_maps", "vo_rectify_get_maps",
     "vo_set_image_rectified", "vo_set_image_rectified_device", "vo_set_stereo_pair_rectified_device",
     "vo_profile_enable", "vo_profile_reset", "vo_profile_get", "vo_profile_set_classes",
     "vo_set_stereo_pair_device", "vo_set_pyramid_window_hint",

@@ -14,7 +14,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import FrameCounts, GnInfo, MonoCounts, MonoParams, StereoParams, VoConfig, VoError
+from ._capi import FrameCounts, GnInfo, MonoCounts, MonoParams, SbaProblem, StereoParams, VoConfig, VoError
 
 KLT_USE_INITIAL_FLOW = 4
 GN_CORE, GN_STANDALONE = 0, 1
@@ -625,3 +625,61 @@ class StereoCamera:
                 raise VoError(-4, "In 'rectifyStereoImages()': provided image has not the same size as the camera model!")
         self.ctx.set_image_rectified(slot_l, img_left, 0)
         self.ctx.set_image_rectified(slot_r, img_right, 1)
+
+
+class SparseBundleAdjustmentSolver:
+    """SparseBundleAdjustmentSolver (core/visual_odometry/ba_solver/sparse_bundle_adjustment.h:42-158) on the
+    device. The reference configures it through setCamera / setStereoCameras, setHuberThreshold and a
+    SparseBAParameters object; here the same pieces of information arrive as arrays (see
+    include/vo_hip.h, vo_sba_solve) — the landmark / keyframe graph that SparseBAParameters walks stays
+    with the caller."""
+
+    POSE_SCALE = 10.0  # SparseBAParameters::pose_scale_ (sparse_ba_parameters.h:255)
+
+    def __init__(self, ctx, is_stereo=False):
+        self.ctx, self.lib, self.is_stereo = ctx, ctx.lib, bool(is_stereo)
+        self.Kl = self.Kr = None
+        self.T_lr = np.eye(4)
+        self.thres_huber = 0.0
+
+    def setCamera(self, K):
+        if self.is_stereo:
+            raise VoError(-1, "In 'SparseBundleAdjustmentSolver::setCamera()': Before call this function, "
+                              "'is_stereo' should be set to 'false'.")
+        self.Kl = self.Kr = np.asarray(K, np.float64).reshape(4)
+
+    def setStereoCameras(self, Kl, Kr, T_lr_scaled):
+        if not self.is_stereo:
+            raise VoError(-1, "In 'SparseBundleAdjustmentSolver::setStereoCameras()': Before call this function, "
+                              "'is_stereo' should be set to 'true'.")
+        self.Kl, self.Kr = np.asarray(Kl, np.float64).reshape(4), np.asarray(Kr, np.float64).reshape(4)
+        self.T_lr = np.asarray(T_lr_scaled, np.float64).reshape(4, 4)
+
+    def setHuberThreshold(self, thres_huber):
+        self.thres_huber = float(thres_huber)
+
+    def solveForFiniteIterations(self, MAX_ITER, T_jw, opt_index, X, obs_ptr, obs_frame, obs_right, obs_px):
+        """Returns (flag_success, T_jw, X, avg_err); raises VoError where the reference throws (NaN)."""
+        T = np.ascontiguousarray(T_jw, np.float64).reshape(-1, 16).copy()
+        Xo = np.ascontiguousarray(X, np.float64).reshape(-1, 3).copy()
+        opt_index = np.ascontiguousarray(opt_index, np.int32)
+        obs_ptr, obs_frame = np.ascontiguousarray(obs_ptr, np.int32), np.ascontiguousarray(obs_frame, np.int32)
+        obs_right, obs_px = np.ascontiguousarray(obs_right, np.uint8), np.ascontiguousarray(obs_px, np.float64).reshape(-1, 2)
+        if obs_ptr.shape[0] != Xo.shape[0] + 1 or opt_index.shape[0] != T.shape[0]:
+            raise ValueError("obs_ptr / opt_index do not match the number of landmarks / frames")
+        if obs_frame.shape[0] != obs_px.shape[0] or obs_right.shape[0] != obs_px.shape[0]:
+            raise ValueError("observation arrays differ in length")
+        p = SbaProblem()
+        p.n_frames, p.n_points, p.n_obs = T.shape[0], Xo.shape[0], obs_px.shape[0]
+        p.n_opt = int(opt_index.max()) + 1 if opt_index.size else 0
+        p.stereo, p.max_iter, p.thres_huber = int(self.is_stereo), int(MAX_ITER), self.thres_huber
+        for k in range(4):
+            p.Kl[k], p.Kr[k] = float(self.Kl[k]), float(self.Kr[k])
+        for k in range(16):
+            p.T_lr[k] = float(self.T_lr.reshape(16)[k])
+        err = np.zeros(max(int(MAX_ITER), 1), np.float64)
+        d, i32 = C.c_double, C.c_int32
+        rc = self.ctx.check(self.lib.vo_sba_solve(self.ctx.handle, C.byref(p), _p(T, d), _p(opt_index, i32), _p(Xo, d),
+                                                  _p(obs_ptr, i32), _p(obs_frame, i32), _p(obs_right, C.c_uint8),
+                                                  _p(obs_px, d), _p(err, d)))
+        return bool(rc), T.reshape(-1, 4, 4), Xo, err[: int(MAX_ITER)]

@@ -1,0 +1,803 @@
+// sba.hip — sparse local bundle adjustment on the device.
+// Reference: SparseBundleAdjustmentSolver::solveForFiniteIterations
+// (core/visual_odometry/ba_solver/sparse_bundle_adjustment.cpp:150-643), double precision
+// (_BA_Numeric, define_ba_type.h:9), fixed iteration count, constant lambda = 1e-5, Huber weights.
+//
+// The reference walks landmark -> observation and scatters 6x6 / 6x3 / 3x3 blocks into dense block
+// arrays (B_ alone is N_opt x M blocks). Here the sparsity pattern is turned into index lists once per
+// problem on the host (it does not change between iterations) and every reduction becomes a gather with
+// a fixed order, so there are no atomics and results are run-to-run identical:
+//   sba_point_kernel   one lane per landmark: C_i, b_i (the reference's sequential order), damping,
+//                      3x3 pivoted LDLT inverse, C^-1 b, and per "slot" (left observation in an optimised
+//                      keyframe) the blocks B_ji and B_ji C_i^-1
+//   sba_pose_kernel    SBA_PG wavefronts per optimised pose: A_j, a_j over the pose's observation list,
+//                      (B C^-1 b)_j over its slot list; lane-strided partial sums + butterfly
+//   sba_schur_kernel   one wavefront per block (j,k): sum of (B_ji C_i^-1) B_ki^T over the landmark pairs
+//   sba_solve_kernel   one wavefront: lower<-upper symmetrisation quirk, reduced system in LDS, Eigen-order
+//                      pivoted LDLT, x; pose updates exp(log(exp(x) exp(log T))); average error
+//   sba_update_kernel  one lane per landmark: y_i, X_i += y_i
+// Five launches per iteration, no host round trip inside the solve. The quirks listed in
+// oracle/oracle_sba.c (B assigned not accumulated, left-only Schur loops, symmetrisation overwrite,
+// calc_Qij_t_Qij_weight's zero entries) are reproduced.
+#include <vector>
+
+#include "vo_internal.hpp"
+#include "vo_kernels.hpp"
+
+#define SBA_PG 8        // partial-sum wavefronts per optimised pose
+#define SBA_MAX_OPT 20  // reduced system up to 120 x 120 in LDS
+
+struct SbaDev {
+  int n_frames, n_opt, M, n_obs, n_slots, stereo, max_iter;
+  double Kl[4], Kr[4], R_rl[9], t_rl[3], thres_huber, lambda;
+  double *T;
+  const int *opt_index;
+  double *X;
+  const int *obs_ptr, *obs_frame;
+  const uint8_t *obs_right;
+  const double *obs_px;
+  const int *slot_ptr, *slot_obs, *slot_j, *slot_bobs;
+  const int *pose_obs_ptr, *pose_obs;
+  const int *pose_slot_ptr, *pose_slot, *slot_lm;
+  const int *pair_ptr, *pair_a, *pair_b;
+  double *Cinv, *Cinvb, *b, *err_i;
+  double *Bs, *BCs;
+  double *Apart;  // n_opt * SBA_PG * 48 (36 A, 6 a, 6 BCinv_b)
+  double *S;      // n_opt * n_opt * 36
+  double *x;      // n_opt * 6
+  double *avg_err;
+  int *flags;
+};
+
+struct SbaObs {
+  double r[2], w, R[6], Q[12];
+};
+
+// one observation: residual, Huber weight, Rij (2x3), Qij (2x6); sparse_bundle_adjustment.cpp:207-300 (right
+// image) and :331-398 (left image), expression by expression
+__device__ __forceinline__ void sba_linearize(const SbaDev &d, const double *__restrict__ Tjw, const double X[3],
+                                              const double px[2], int right, SbaObs &o) {
+  double Rjw[9], tjw[3], Xij[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Rjw[i * 3 + j] = Tjw[i * 4 + j];
+    tjw[i] = Tjw[i * 4 + 3];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) Xij[i] = (Rjw[i * 3] * X[0] + (Rjw[i * 3 + 1] * X[1] + Rjw[i * 3 + 2] * X[2])) + tjw[i];
+  if (right) {
+    double RR[9], Xr[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        RR[i * 3 + j] = d.R_rl[i * 3] * Rjw[j] + (d.R_rl[i * 3 + 1] * Rjw[3 + j] + d.R_rl[i * 3 + 2] * Rjw[6 + j]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      Xr[i] = (d.R_rl[i * 3] * Xij[0] + (d.R_rl[i * 3 + 1] * Xij[1] + d.R_rl[i * 3 + 2] * Xij[2])) + d.t_rl[i];
+    const double fx = d.Kr[0], fy = d.Kr[1], cx = d.Kr[2], cy = d.Kr[3];
+    const double invz = 1.0 / Xr[2];
+    const double fxinvz = fx * invz, fyinvz = fy * invz, xinvz = Xr[0] * invz, yinvz = Xr[1] * invz;
+    const double fx_xinvz2 = fxinvz * xinvz, fy_yinvz2 = fyinvz * yinvz;
+    o.r[0] = (fx * xinvz + cx) - px[0];
+    o.r[1] = (fy * yinvz + cy) - px[1];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      o.R[c] = fxinvz * RR[c] - fx_xinvz2 * RR[6 + c];
+      o.R[3 + c] = fyinvz * RR[3 + c] - fy_yinvz2 * RR[6 + c];
+    }
+    const double dp[6] = {fxinvz, 0, -fx_xinvz2, 0, fyinvz, -fy_yinvz2};
+    const double sk[9] = {0, -Xij[2], Xij[1], Xij[2], 0, -Xij[0], -Xij[1], Xij[0], 0};
+    double nDR[6];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        o.Q[i * 6 + j] = dp[i * 3] * d.R_rl[j] + (dp[i * 3 + 1] * d.R_rl[3 + j] + dp[i * 3 + 2] * d.R_rl[6 + j]);
+        nDR[i * 3 + j] = (-dp[i * 3]) * d.R_rl[j] + ((-dp[i * 3 + 1]) * d.R_rl[3 + j] + (-dp[i * 3 + 2]) * d.R_rl[6 + j]);
+      }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        o.Q[i * 6 + 3 + j] = nDR[i * 3] * sk[j] + (nDR[i * 3 + 1] * sk[3 + j] + nDR[i * 3 + 2] * sk[6 + j]);
+  } else {
+    const double fx = d.Kl[0], fy = d.Kl[1], cx = d.Kl[2], cy = d.Kl[3];
+    const double invz = 1.0 / Xij[2];
+    const double fxinvz = fx * invz, fyinvz = fy * invz, xinvz = Xij[0] * invz, yinvz = Xij[1] * invz;
+    const double fx_xinvz2 = fxinvz * xinvz, fy_yinvz2 = fyinvz * yinvz, xinvz_yinvz = xinvz * yinvz;
+    o.r[0] = (fx * xinvz + cx) - px[0];
+    o.r[1] = (fy * yinvz + cy) - px[1];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      o.R[c] = fxinvz * Rjw[c] - fx_xinvz2 * Rjw[6 + c];
+      o.R[3 + c] = fyinvz * Rjw[3 + c] - fy_yinvz2 * Rjw[6 + c];
+    }
+    o.Q[0] = fxinvz;
+    o.Q[1] = 0;
+    o.Q[2] = -fx_xinvz2;
+    o.Q[3] = -fx * xinvz_yinvz;
+    o.Q[4] = fx * (1.0 + xinvz * xinvz);
+    o.Q[5] = -fx * yinvz;
+    o.Q[6] = 0;
+    o.Q[7] = fyinvz;
+    o.Q[8] = -fy_yinvz2;
+    o.Q[9] = -fy * (1.0 + yinvz * yinvz);
+    o.Q[10] = fy * xinvz_yinvz;
+    o.Q[11] = fy * xinvz;
+  }
+  const double absr = fabs(o.r[0]) + fabs(o.r[1]);
+  o.w = absr > d.thres_huber ? d.thres_huber / absr : 1.0;
+}
+
+// Eigen::LDLT of a 3x3 (lower, pivoting on the largest |diagonal|), solve for the identity: C^-1 as
+// C_[i].ldlt().solve(I) gives it (:460)
+__device__ __forceinline__ void sba_inv3_ldlt(const double Cin[9], double out[9]) {
+  double m[3][3];
+  int tr[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) m[i][j] = Cin[i * 3 + j];
+  double temp[3];
+  for (int k = 0; k < 3; ++k) {
+    int piv = k;
+    double best = fabs(m[k][k]);
+    for (int i = k + 1; i < 3; ++i) {
+      const double a = fabs(m[i][i]);
+      if (a > best) {
+        best = a;
+        piv = i;
+      }
+    }
+    tr[k] = piv;
+    if (piv != k) {
+      for (int j = 0; j < k; ++j) { const double t = m[k][j]; m[k][j] = m[piv][j]; m[piv][j] = t; }
+      for (int i = piv + 1; i < 3; ++i) { const double t = m[i][k]; m[i][k] = m[i][piv]; m[i][piv] = t; }
+      { const double t = m[k][k]; m[k][k] = m[piv][piv]; m[piv][piv] = t; }
+      for (int i = k + 1; i < piv; ++i) { const double t = m[i][k]; m[i][k] = m[piv][i]; m[piv][i] = t; }
+    }
+    const int rs = 3 - k - 1;
+    if (k > 0) {
+      for (int j = 0; j < k; ++j) temp[j] = m[j][j] * m[k][j];
+      double s = 0.0;
+      for (int j = 0; j < k; ++j) s += m[k][j] * temp[j];
+      m[k][k] -= s;
+      for (int i = 0; i < rs; ++i) {
+        double dd = 0.0;
+        for (int j = 0; j < k; ++j) dd += m[k + 1 + i][j] * temp[j];
+        m[k + 1 + i][k] -= dd;
+      }
+    }
+    const double akk = m[k][k];
+    if (fabs(akk) > 0.0)
+      for (int i = 0; i < rs; ++i) m[k + 1 + i][k] /= akk;
+  }
+  const double tol = 2.2250738585072014e-308;
+  for (int c = 0; c < 3; ++c) {
+    double y[3] = {c == 0 ? 1.0 : 0.0, c == 1 ? 1.0 : 0.0, c == 2 ? 1.0 : 0.0};
+    for (int k = 0; k < 3; ++k)
+      if (tr[k] != k) { const double t = y[k]; y[k] = y[tr[k]]; y[tr[k]] = t; }
+    for (int i = 0; i < 3; ++i) {
+      double s = y[i];
+      for (int j = 0; j < i; ++j) s -= m[i][j] * y[j];
+      y[i] = s;
+    }
+    for (int i = 0; i < 3; ++i) y[i] = fabs(m[i][i]) > tol ? y[i] / m[i][i] : 0.0;
+    for (int i = 2; i >= 0; --i) {
+      double s = y[i];
+      for (int j = i + 1; j < 3; ++j) s -= m[j][i] * y[j];
+      y[i] = s;
+    }
+    for (int k = 2; k >= 0; --k)
+      if (tr[k] != k) { const double t = y[k]; y[k] = y[tr[k]]; y[tr[k]] = t; }
+    for (int i = 0; i < 3; ++i) out[i * 3 + c] = y[i];
+  }
+}
+
+// ---- per landmark -------------------------------------------------------------------
+__global__ __launch_bounds__(64) void sba_point_kernel(SbaDev d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.M) return;
+  const double X[3] = {d.X[3 * i], d.X[3 * i + 1], d.X[3 * i + 2]};
+  double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0}, err = 0.0;
+  for (int o = d.obs_ptr[i]; o < d.obs_ptr[i + 1]; ++o) {
+    SbaObs L;
+    const double px[2] = {d.obs_px[2 * o], d.obs_px[2 * o + 1]};
+    sba_linearize(d, d.T + 16 * (size_t)d.obs_frame[o], X, px, d.obs_right[o], L);
+    // calc_Rij_t_Rij_weight (:911-930), b_i += -weight * (Rij^T rij)
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = r; c < 3; ++c) {
+        const double v = L.w * (L.R[r] * L.R[c] + L.R[3 + r] * L.R[3 + c]);
+        C[r * 3 + c] += v;
+        if (c != r) C[c * 3 + r] += v;
+      }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) b[r] += -(L.w * (L.R[r] * L.r[0] + L.R[3 + r] * L.r[1]));
+    err += L.r[0] * L.r[0] + L.r[1] * L.r[1];
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) C[k * 4] += d.lambda * C[k * 4];  // :454-456
+  double Ci[9];
+  sba_inv3_ldlt(C, Ci);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) d.Cinv[9 * (size_t)i + k] = Ci[k];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    d.Cinvb[3 * (size_t)i + r] = Ci[r * 3] * b[0] + (Ci[r * 3 + 1] * b[1] + Ci[r * 3 + 2] * b[2]);
+    d.b[3 * (size_t)i + r] = b[r];
+  }
+  d.err_i[i] = err;
+  // B_ji of every slot: Qij^T Rij of the LAST observation of landmark i in keyframe j (:315 / :410 assign)
+  for (int s = d.slot_ptr[i]; s < d.slot_ptr[i + 1]; ++s) {
+    const int o = d.slot_bobs[s];
+    SbaObs L;
+    const double px[2] = {d.obs_px[2 * o], d.obs_px[2 * o + 1]};
+    sba_linearize(d, d.T + 16 * (size_t)d.obs_frame[o], X, px, d.obs_right[o], L);
+    double B[18];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) B[r * 3 + c] = L.w * (L.Q[r] * L.R[c] + L.Q[6 + r] * L.R[3 + c]);
+    double *Bo = d.Bs + 18 * (size_t)s, *BCo = d.BCs + 18 * (size_t)s;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        Bo[r * 3 + c] = B[r * 3 + c];
+        BCo[r * 3 + c] = B[r * 3] * Ci[c] + (B[r * 3 + 1] * Ci[3 + c] + B[r * 3 + 2] * Ci[6 + c]);  // :471
+      }
+  }
+}
+
+__device__ __forceinline__ double sba_wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  return v;  // lane 0 holds the total
+}
+
+// ---- per optimised pose: A_j, a_j, (B C^-1 b)_j -----------------------------------------
+__global__ __launch_bounds__(64) void sba_pose_kernel(SbaDev d) {
+  const int j = blockIdx.x, g = blockIdx.y, lane = threadIdx.x;
+  double acc[48];
+#pragma unroll
+  for (int k = 0; k < 48; ++k) acc[k] = 0.0;
+  int nan_seen = 0;
+  for (int q = d.pose_obs_ptr[j] + g * 64 + lane; q < d.pose_obs_ptr[j + 1]; q += 64 * SBA_PG) {
+    const int o = d.pose_obs[q];
+    const int i = d.slot_lm[d.n_slots + o];  // landmark of observation o (second half of the array)
+    const double X[3] = {d.X[3 * i], d.X[3 * i + 1], d.X[3 * i + 2]};
+    const double px[2] = {d.obs_px[2 * o], d.obs_px[2 * o + 1]};
+    SbaObs L;
+    sba_linearize(d, d.T + 16 * (size_t)d.obs_frame[o], X, px, d.obs_right[o], L);
+    // calc_Qij_t_Qij_weight (:986-1041): written for Q(0,1) = Q(1,0) = 0; entry (0,1) stays zero
+    double wa[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) wa[k] = L.w * L.Q[k];
+    double q6[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) q6[k] = 0.0;
+    q6[0] = wa[0] * L.Q[0];
+#pragma unroll
+    for (int c = 2; c < 6; ++c) q6[c] = wa[0] * L.Q[c];
+#pragma unroll
+    for (int c = 1; c < 6; ++c) q6[6 + c] = wa[7] * L.Q[6 + c];
+#pragma unroll
+    for (int r = 2; r < 6; ++r)
+#pragma unroll
+      for (int c = r; c < 6; ++c) q6[r * 6 + c] = wa[r] * L.Q[c] + wa[6 + r] * L.Q[6 + c];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = r + 1; c < 6; ++c)
+        if (!(r == 0 && c == 1)) q6[c * 6 + r] = q6[r * 6 + c];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) {
+      acc[k] += q6[k];
+      nan_seen |= (q6[k] != q6[k]);
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) acc[36 + r] += -(L.w * (L.Q[r] * L.r[0] + L.Q[6 + r] * L.r[1]));
+  }
+  for (int q = d.pose_slot_ptr[j] + g * 64 + lane; q < d.pose_slot_ptr[j + 1]; q += 64 * SBA_PG) {
+    const int s = d.pose_slot[q], i = d.slot_lm[s];
+    const double *BC = d.BCs + 18 * (size_t)s, *b = d.b + 3 * (size_t)i;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) acc[42 + r] += BC[r * 3] * b[0] + (BC[r * 3 + 1] * b[1] + BC[r * 3 + 2] * b[2]);  // :473
+  }
+  double *out = d.Apart + 48 * ((size_t)j * SBA_PG + g);
+#pragma unroll
+  for (int k = 0; k < 48; ++k) {
+    const double t = sba_wave_sum(acc[k]);
+    if (lane == 0) out[k] = t;
+  }
+  if (__any(nan_seen) && lane == 0) atomicOr(d.flags, 1);  // :318 "In LBA, pose becomes nan!"
+}
+
+// ---- per block (j,k) of B C^-1 B^T -------------------------------------------------------
+__global__ __launch_bounds__(64) void sba_schur_kernel(SbaDev d) {
+  const int jk = blockIdx.x, lane = threadIdx.x;
+  double acc[36];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+  for (int q = d.pair_ptr[jk] + lane; q < d.pair_ptr[jk + 1]; q += 64) {
+    const double *BC = d.BCs + 18 * (size_t)d.pair_a[q], *Bk = d.Bs + 18 * (size_t)d.pair_b[q];
+    double bc[18], bk[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) {
+      bc[k] = BC[k];
+      bk[k] = Bk[k];
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+        acc[r * 6 + c] += bc[r * 3] * bk[c * 3] + (bc[r * 3 + 1] * bk[c * 3 + 1] + bc[r * 3 + 2] * bk[c * 3 + 2]);  // :489
+  }
+#pragma unroll
+  for (int k = 0; k < 36; ++k) {
+    const double t = sba_wave_sum(acc[k]);
+    if (lane == 0) d.S[36 * (size_t)jk + k] = t;
+  }
+}
+
+// ---- se3 exp / log in double (geometry_library.cpp:336-384, :442-495) ---------------------
+__device__ void sba_mat3mul(const double A[9], const double B[9], double C[9]) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3] * B[j] + (A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j]);
+}
+__device__ void sba_se3_exp(const double xi[6], double T[16]) {
+  const double v[3] = {xi[0], xi[1], xi[2]}, w[3] = {xi[3], xi[4], xi[5]};
+  const double theta = sqrt(w[0] * w[0] + (w[1] * w[1] + w[2] * w[2]));
+  const double wx[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+  double wxwx[9], V[9];
+  sba_mat3mul(wx, wx, wxwx);
+  double a, b, c, dd;
+  if (theta < 1e-9) {
+    a = 1.0;
+    b = 0.5;
+    c = 0.5;
+    dd = 0.33333333333333333333333333;
+  } else {
+    const double invtheta2 = 1.0 / (theta * theta);
+    a = sin(theta) / theta;
+    b = (1 - cos(theta)) * invtheta2;
+    c = (1 - cos(theta)) * invtheta2;
+    dd = (theta - sin(theta)) / (theta * theta * theta);
+  }
+  for (int k = 0; k < 16; ++k) T[k] = 0.0;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      const int k = i * 3 + j;
+      const double I = i == j ? 1.0 : 0.0;
+      T[i * 4 + j] = (I + a * wx[k]) + b * wxwx[k];
+      V[k] = (I + c * wx[k]) + dd * wxwx[k];
+    }
+  for (int i = 0; i < 3; ++i) T[i * 4 + 3] = V[i * 3] * v[0] + (V[i * 3 + 1] * v[1] + V[i * 3 + 2] * v[2]);
+  T[15] = 1.0;
+}
+__device__ void sba_se3_log(const double T[16], double xi[6]) {
+  double R[9], t[3], Vin[9], w[3] = {0, 0, 0};
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) R[i * 3 + j] = T[i * 4 + j];
+    t[i] = T[i * 4 + 3];
+  }
+  const double inCos = (((R[0] + R[4]) + R[8]) - 1.0) * 0.5;
+  for (int k = 0; k < 9; ++k) Vin[k] = (k == 0 || k == 4 || k == 8) ? 1.0 : 0.0;
+  if (!(inCos >= 0.999999999)) {
+    const double theta = acos(inCos);
+    const double invTheta = 1.0 / theta, invTheta2 = invTheta * invTheta;
+    const double f = theta / (2.0 * sin(theta));
+    double lnR[9];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) lnR[i * 3 + j] = f * (R[i * 3 + j] - R[j * 3 + i]);
+    w[0] = -lnR[5];
+    w[1] = lnR[2];
+    w[2] = -lnR[1];
+    const double wx[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+    double wxwx[9];
+    sba_mat3mul(wx, wx, wxwx);
+    const double A = sin(theta) * invTheta;
+    const double B = (1.0 - cos(theta)) * invTheta2;
+    const double g = invTheta2 * (1.0 - A / (2.0 * B));
+    for (int k = 0; k < 9; ++k) Vin[k] = (Vin[k] - 0.5 * wx[k]) + g * wxwx[k];
+  }
+  for (int i = 0; i < 3; ++i) xi[i] = Vin[i * 3] * t[0] + (Vin[i * 3 + 1] * t[1] + Vin[i * 3 + 2] * t[2]);
+  xi[3] = w[0];
+  xi[4] = w[1];
+  xi[5] = w[2];
+}
+// :563-575: xi = log(T); addFrontse3(xi, x) = log(exp(x) exp(xi)); T = exp(xi)
+__device__ void sba_pose_update(double *T, const double x[6]) {
+  double Tin[16], xi[6], Tjw[16], dT[16], P[16];
+  for (int k = 0; k < 16; ++k) Tin[k] = T[k];
+  sba_se3_log(Tin, xi);
+  sba_se3_exp(xi, Tjw);
+  sba_se3_exp(x, dT);
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      double s = 0.0;
+      for (int k = 0; k < 4; ++k) s += dT[i * 4 + k] * Tjw[k * 4 + j];
+      P[i * 4 + j] = s;
+    }
+  sba_se3_log(P, xi);
+  sba_se3_exp(xi, Tjw);
+  for (int k = 0; k < 16; ++k) T[k] = Tjw[k];
+}
+
+// ---- reduced system: assemble, LDLT, solve, pose update, average error (one wavefront) ------------------
+__global__ __launch_bounds__(64) void sba_solve_kernel(SbaDev d, int iter) {
+  extern __shared__ double sm[];
+  const int No = d.n_opt, n = 6 * No, lane = threadIdx.x;
+  double *m = sm;                  // n x n row-major
+  double *y = sm + (size_t)n * n;  // n
+  double *temp = y + n;            // n
+  int *tr = (int *)(temp + n);     // n
+  // Am_BCinvBt (:499-506): block (j,u) = [j == u] A_j - BCinvBt_[j][u], where BCinvBt_[u][j] for u >= j was
+  // overwritten with the transpose of block (j,u) (:495-497; diagonal blocks are transposed in place)
+  for (int e = lane; e < n * n; e += 64) {
+    const int row = e / n, col = e - row * n;
+    const int j = row / 6, r = row - 6 * j, u = col / 6, c = col - 6 * u;
+    double s;
+    if (u >= j && !(u == j))
+      s = d.S[36 * ((size_t)j * No + u) + r * 6 + c];
+    else if (u == j)
+      s = d.S[36 * ((size_t)j * No + j) + c * 6 + r];
+    else
+      s = d.S[36 * ((size_t)u * No + j) + c * 6 + r];
+    double v = -s;
+    if (j == u) {
+      double A = 0.0;
+      for (int g = 0; g < SBA_PG; ++g) A += d.Apart[48 * ((size_t)j * SBA_PG + g) + r * 6 + c];
+      if (r == c) A += d.lambda * A;  // :433-441
+      v = A - s;
+    }
+    m[e] = v;
+  }
+  for (int e = lane; e < n; e += 64) {
+    const int j = e / 6, r = e - 6 * j;
+    double a = 0.0, bcb = 0.0;
+    for (int g = 0; g < SBA_PG; ++g) {
+      a += d.Apart[48 * ((size_t)j * SBA_PG + g) + 36 + r];
+      bcb += d.Apart[48 * ((size_t)j * SBA_PG + g) + 42 + r];
+    }
+    y[e] = a - bcb;  // :508-509
+  }
+  __syncthreads();
+#define MM(i, j) m[(size_t)(i) * n + (j)]
+  // Eigen::LDLT, lower, in place; per-row inner sums in the sequential order of the CPU restatement
+  for (int k = 0; k < n; ++k) {
+    // pivot: largest |diagonal| in k..n-1, first one on ties
+    double best = -1.0;
+    int piv = n;
+    for (int i = k + lane; i < n; i += 64) {
+      const double a = fabs(MM(i, i));
+      if (a > best) {
+        best = a;
+        piv = i;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ob = __shfl_xor(best, off);
+      const int op = __shfl_xor(piv, off);
+      if (ob > best || (ob == best && op < piv)) {
+        best = ob;
+        piv = op;
+      }
+    }
+    if (lane == 0) tr[k] = piv;
+    if (piv != k) {
+      for (int j = lane; j < k; j += 64) { const double t = MM(k, j); MM(k, j) = MM(piv, j); MM(piv, j) = t; }
+      for (int i = piv + 1 + lane; i < n; i += 64) { const double t = MM(i, k); MM(i, k) = MM(i, piv); MM(i, piv) = t; }
+      for (int i = k + 1 + lane; i < piv; i += 64) { const double t = MM(i, k); MM(i, k) = MM(piv, i); MM(piv, i) = t; }
+      __syncthreads();
+      if (lane == 0) { const double t = MM(k, k); MM(k, k) = MM(piv, piv); MM(piv, piv) = t; }
+    }
+    __syncthreads();
+    const int rs = n - k - 1;
+    if (k > 0) {
+      for (int j = lane; j < k; j += 64) temp[j] = MM(j, j) * MM(k, j);
+      __syncthreads();
+      if (lane == 0) {
+        double s = 0.0;
+        for (int j = 0; j < k; ++j) s += MM(k, j) * temp[j];
+        MM(k, k) -= s;
+      }
+      for (int i = lane; i < rs; i += 64) {
+        double dd = 0.0;
+        for (int j = 0; j < k; ++j) dd += MM(k + 1 + i, j) * temp[j];
+        MM(k + 1 + i, k) -= dd;
+      }
+      __syncthreads();
+    }
+    const double akk = MM(k, k);
+    if (fabs(akk) > 0.0)
+      for (int i = lane; i < rs; i += 64) MM(k + 1 + i, k) /= akk;
+    __syncthreads();
+  }
+  // solve: x = P^T L^-T D^+ L^-1 P rhs (column-oriented sweeps: same subtraction order per entry as the row form)
+  if (lane == 0)
+    for (int k = 0; k < n; ++k)
+      if (tr[k] != k) { const double t = y[k]; y[k] = y[tr[k]]; y[tr[k]] = t; }
+  __syncthreads();
+  for (int j = 0; j < n; ++j) {
+    const double yj = y[j];
+    for (int i = j + 1 + lane; i < n; i += 64) y[i] -= MM(i, j) * yj;
+    __syncthreads();
+  }
+  const double tol = 2.2250738585072014e-308;
+  for (int i = lane; i < n; i += 64) y[i] = fabs(MM(i, i)) > tol ? y[i] / MM(i, i) : 0.0;
+  __syncthreads();
+  if (lane == 0) {
+    // L^T sweep in row form (entry j subtracts M(q,j) y_q for q = j+1.. in increasing q, the CPU order), then P^T
+    for (int j = n - 1; j >= 0; --j) {
+      double s = y[j];
+      for (int q = j + 1; q < n; ++q) s -= MM(q, j) * y[q];
+      y[j] = s;
+    }
+    for (int k = n - 1; k >= 0; --k)
+      if (tr[k] != k) { const double t = y[k]; y[k] = y[tr[k]]; y[tr[k]] = t; }
+  }
+  __syncthreads();
+#undef MM
+  for (int e = lane; e < n; e += 64) d.x[e] = y[e];
+  // pose updates (:560-576)
+  for (int f = lane; f < d.n_frames; f += 64) {
+    const int j = d.opt_index[f];
+    if (j >= 0) sba_pose_update(d.T + 16 * (size_t)f, y + 6 * j);
+  }
+  // average pixel error of this iteration's linearisation point (:594-601)
+  double e = 0.0;
+  for (int i = lane; i < d.M; i += 64) e += d.err_i[i];
+  e = sba_wave_sum(e);
+  if (lane == 0) {
+    d.avg_err[iter] = sqrt(e / (double)d.n_obs);
+    if (e != e) atomicOr(d.flags, 2);
+  }
+}
+
+// ---- y_i and the point update (:537-556, :578-579) ----------------------------------------
+__global__ __launch_bounds__(64) void sba_update_kernel(SbaDev d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.M) return;
+  double cbx[3] = {0, 0, 0};
+  for (int s = d.slot_ptr[i]; s < d.slot_ptr[i + 1]; ++s) {
+    const double *BC = d.BCs + 18 * (size_t)s, *x = d.x + 6 * d.slot_j[s];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      double t = 0.0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) t += BC[r * 3 + c] * x[r];
+      cbx[c] += t;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) d.X[3 * (size_t)i + c] += d.Cinvb[3 * (size_t)i + c] - cbx[c];
+}
+
+// ---- host side ---------------------------------------------------------------------
+struct vo_sba_state {
+  void *dev;
+  size_t cap;
+};
+
+void vo_sba_free(vo_ctx *c) {
+  if (c->sba) {
+    if (c->sba->dev) (void)hipFree(c->sba->dev);
+    delete c->sba;
+    c->sba = nullptr;
+  }
+}
+
+namespace {
+struct Arena {
+  size_t off = 0;
+  size_t take(size_t bytes) {
+    const size_t o = off;
+    off += (bytes + 255) & ~(size_t)255;
+    return o;
+  }
+};
+}  // namespace
+
+extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, const int32_t *opt_index, double *X,
+                            const int32_t *obs_ptr, const int32_t *obs_frame, const uint8_t *obs_right,
+                            const double *obs_px, double *avg_err) {
+  if (!c || !p || !T_jw || !opt_index || !X || !obs_ptr || !obs_frame || !obs_right || !obs_px) return VO_ERR_INVALID;
+  const int Nf = p->n_frames, No = p->n_opt, M = p->n_points, nobs = p->n_obs;
+  if (Nf <= 0 || No < 0 || M <= 0 || nobs <= 0 || p->max_iter < 0) VO_FAIL(c, VO_ERR_INVALID, "empty BA problem");
+  if (No > SBA_MAX_OPT) VO_FAIL(c, VO_ERR_CAPACITY, "n_opt=%d exceeds %d optimised poses", No, SBA_MAX_OPT);
+  // ---- validate the lists (device kernels index with them) and derive the gather lists ----
+  if (obs_ptr[0] != 0 || obs_ptr[M] != nobs) VO_FAIL(c, VO_ERR_SIZE, "obs_ptr does not span n_obs");
+  std::vector<int> seen_opt(No, 0);
+  for (int f = 0; f < Nf; ++f) {
+    if (opt_index[f] < -1 || opt_index[f] >= No) VO_FAIL(c, VO_ERR_INVALID, "opt_index[%d] out of range", f);
+    if (opt_index[f] >= 0 && seen_opt[opt_index[f]]++) VO_FAIL(c, VO_ERR_INVALID, "optimised pose index used twice");
+  }
+  std::vector<int> slot_ptr(M + 1, 0), slot_obs, slot_j, slot_bobs, slot_lm, obs_lm(nobs);
+  std::vector<std::vector<int>> pose_obs(No), pose_slot(No);
+  for (int i = 0; i < M; ++i) {
+    if (obs_ptr[i + 1] < obs_ptr[i]) VO_FAIL(c, VO_ERR_SIZE, "obs_ptr not monotone");
+    for (int o = obs_ptr[i]; o < obs_ptr[i + 1]; ++o) {
+      if (obs_frame[o] < 0 || obs_frame[o] >= Nf) VO_FAIL(c, VO_ERR_INVALID, "obs_frame[%d] out of range", o);
+      if (obs_right[o] && !p->stereo) VO_FAIL(c, VO_ERR_INVALID, "right-image observation in a mono problem");
+      obs_lm[o] = i;
+      const int j = opt_index[obs_frame[o]];
+      if (j >= 0) pose_obs[j].push_back(o);
+      if (j >= 0 && !obs_right[o]) {
+        // slot: left observation in an optimised keyframe; its B block is that of the last observation of
+        // this landmark in the same keyframe
+        int last = o;
+        for (int o2 = obs_ptr[i]; o2 < obs_ptr[i + 1]; ++o2)
+          if (opt_index[obs_frame[o2]] == j) last = o2;
+        pose_slot[j].push_back((int)slot_obs.size());
+        slot_obs.push_back(o);
+        slot_j.push_back(j);
+        slot_bobs.push_back(last);
+        slot_lm.push_back(i);
+      }
+    }
+    slot_ptr[i + 1] = (int)slot_obs.size();
+  }
+  const int ns = (int)slot_obs.size();
+  std::vector<int> pose_obs_ptr(No + 1, 0), pose_obs_flat, pose_slot_ptr(No + 1, 0), pose_slot_flat;
+  for (int j = 0; j < No; ++j) {
+    pose_obs_flat.insert(pose_obs_flat.end(), pose_obs[j].begin(), pose_obs[j].end());
+    pose_obs_ptr[j + 1] = (int)pose_obs_flat.size();
+    pose_slot_flat.insert(pose_slot_flat.end(), pose_slot[j].begin(), pose_slot[j].end());
+    pose_slot_ptr[j + 1] = (int)pose_slot_flat.size();
+  }
+  // pairs (:475-491): slots a, b of one landmark with list position b >= a contribute to block (j_a, j_b)
+  std::vector<std::vector<int>> pa((size_t)No * No), pb((size_t)No * No);
+  for (int i = 0; i < M; ++i)
+    for (int s = slot_ptr[i]; s < slot_ptr[i + 1]; ++s)
+      for (int s2 = s; s2 < slot_ptr[i + 1]; ++s2) {
+        const size_t jk = (size_t)slot_j[s] * No + slot_j[s2];
+        pa[jk].push_back(s);
+        pb[jk].push_back(s2);
+      }
+  std::vector<int> pair_ptr((size_t)No * No + 1, 0), pair_a, pair_b;
+  for (size_t jk = 0; jk < (size_t)No * No; ++jk) {
+    pair_a.insert(pair_a.end(), pa[jk].begin(), pa[jk].end());
+    pair_b.insert(pair_b.end(), pb[jk].begin(), pb[jk].end());
+    pair_ptr[jk + 1] = (int)pair_a.size();
+  }
+  // slot_lm carries the landmark of every slot, followed by the landmark of every observation
+  slot_lm.insert(slot_lm.end(), obs_lm.begin(), obs_lm.end());
+
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  // ---- device arena ----
+  Arena ar;
+  const size_t oT = ar.take(sizeof(double) * 16 * Nf), oOpt = ar.take(sizeof(int) * Nf), oX = ar.take(sizeof(double) * 3 * M);
+  const size_t oOp = ar.take(sizeof(int) * (M + 1)), oOf = ar.take(sizeof(int) * nobs), oOr = ar.take((size_t)nobs);
+  const size_t oPx = ar.take(sizeof(double) * 2 * nobs);
+  const size_t oSp = ar.take(sizeof(int) * (M + 1)), oSo = ar.take(sizeof(int) * (ns + 1)), oSj = ar.take(sizeof(int) * (ns + 1));
+  const size_t oSb = ar.take(sizeof(int) * (ns + 1)), oSl = ar.take(sizeof(int) * (ns + nobs + 1));
+  const size_t oPop = ar.take(sizeof(int) * (No + 1)), oPo = ar.take(sizeof(int) * (pose_obs_flat.size() + 1));
+  const size_t oPsp = ar.take(sizeof(int) * (No + 1)), oPs = ar.take(sizeof(int) * (ns + 1));
+  const size_t oPp = ar.take(sizeof(int) * ((size_t)No * No + 1)), oPa = ar.take(sizeof(int) * (pair_a.size() + 1));
+  const size_t oPb = ar.take(sizeof(int) * (pair_b.size() + 1));
+  const size_t oCinv = ar.take(sizeof(double) * 9 * M), oCinvb = ar.take(sizeof(double) * 3 * M), oB = ar.take(sizeof(double) * 3 * M);
+  const size_t oErr = ar.take(sizeof(double) * M), oBs = ar.take(sizeof(double) * 18 * (ns + 1)), oBCs = ar.take(sizeof(double) * 18 * (ns + 1));
+  const size_t oAp = ar.take(sizeof(double) * 48 * SBA_PG * (No + 1)), oS = ar.take(sizeof(double) * 36 * ((size_t)No * No + 1));
+  const size_t ox = ar.take(sizeof(double) * 6 * (No + 1)), oAvg = ar.take(sizeof(double) * (p->max_iter + 1)), oFl = ar.take(sizeof(int) * 4);
+  if (!c->sba) c->sba = new vo_sba_state{nullptr, 0};
+  if (c->sba->cap < ar.off) {
+    if (c->sba->dev) (void)hipFree(c->sba->dev);
+    c->sba->dev = nullptr;
+    c->sba->cap = 0;
+    VO_CHECK_HIP(c, hipMalloc(&c->sba->dev, ar.off + (ar.off >> 2)));
+    c->sba->cap = ar.off + (ar.off >> 2);
+  }
+  uint8_t *base = (uint8_t *)c->sba->dev;
+  hipStream_t s = c->stream;
+  VO_CHECK_HIP(c, hipStreamSynchronize(s));
+#define UP(off, ptr, bytes) \
+  if ((bytes) > 0) VO_CHECK_HIP(c, hipMemcpyAsync(base + (off), (ptr), (bytes), hipMemcpyHostToDevice, s))
+  UP(oT, T_jw, sizeof(double) * 16 * Nf);
+  UP(oOpt, opt_index, sizeof(int) * Nf);
+  UP(oX, X, sizeof(double) * 3 * M);
+  UP(oOp, obs_ptr, sizeof(int) * (M + 1));
+  UP(oOf, obs_frame, sizeof(int) * nobs);
+  UP(oOr, obs_right, (size_t)nobs);
+  UP(oPx, obs_px, sizeof(double) * 2 * nobs);
+  UP(oSp, slot_ptr.data(), sizeof(int) * (M + 1));
+  UP(oSo, slot_obs.data(), sizeof(int) * ns);
+  UP(oSj, slot_j.data(), sizeof(int) * ns);
+  UP(oSb, slot_bobs.data(), sizeof(int) * ns);
+  UP(oSl, slot_lm.data(), sizeof(int) * (ns + nobs));
+  UP(oPop, pose_obs_ptr.data(), sizeof(int) * (No + 1));
+  UP(oPo, pose_obs_flat.data(), sizeof(int) * pose_obs_flat.size());
+  UP(oPsp, pose_slot_ptr.data(), sizeof(int) * (No + 1));
+  UP(oPs, pose_slot_flat.data(), sizeof(int) * ns);
+  UP(oPp, pair_ptr.data(), sizeof(int) * ((size_t)No * No + 1));
+  UP(oPa, pair_a.data(), sizeof(int) * pair_a.size());
+  UP(oPb, pair_b.data(), sizeof(int) * pair_b.size());
+#undef UP
+  VO_CHECK_HIP(c, hipMemsetAsync(base + oFl, 0, sizeof(int) * 4, s));
+  VO_CHECK_HIP(c, hipMemsetAsync(base + oAvg, 0, sizeof(double) * (p->max_iter + 1), s));
+  SbaDev d;
+  memset(&d, 0, sizeof(d));
+  d.n_frames = Nf;
+  d.n_opt = No;
+  d.M = M;
+  d.n_obs = nobs;
+  d.n_slots = ns;
+  d.stereo = p->stereo;
+  d.max_iter = p->max_iter;
+  for (int k = 0; k < 4; ++k) {
+    d.Kl[k] = p->Kl[k];
+    d.Kr[k] = p->stereo ? p->Kr[k] : p->Kl[k];
+  }
+  // geometry::inverseSE3(T_lr) (:175, geometry_library.cpp:561-567)
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) d.R_rl[i * 3 + j] = p->stereo ? p->T_lr[j * 4 + i] : (i == j ? 1.0 : 0.0);
+  for (int i = 0; i < 3; ++i)
+    d.t_rl[i] = p->stereo ? (-d.R_rl[i * 3]) * p->T_lr[3] + ((-d.R_rl[i * 3 + 1]) * p->T_lr[7] + (-d.R_rl[i * 3 + 2]) * p->T_lr[11])
+                          : 0.0;
+  d.thres_huber = p->thres_huber;
+  d.lambda = 0.00001;  // :186
+  d.T = (double *)(base + oT);
+  d.opt_index = (const int *)(base + oOpt);
+  d.X = (double *)(base + oX);
+  d.obs_ptr = (const int *)(base + oOp);
+  d.obs_frame = (const int *)(base + oOf);
+  d.obs_right = base + oOr;
+  d.obs_px = (const double *)(base + oPx);
+  d.slot_ptr = (const int *)(base + oSp);
+  d.slot_obs = (const int *)(base + oSo);
+  d.slot_j = (const int *)(base + oSj);
+  d.slot_bobs = (const int *)(base + oSb);
+  d.slot_lm = (const int *)(base + oSl);
+  d.pose_obs_ptr = (const int *)(base + oPop);
+  d.pose_obs = (const int *)(base + oPo);
+  d.pose_slot_ptr = (const int *)(base + oPsp);
+  d.pose_slot = (const int *)(base + oPs);
+  d.pair_ptr = (const int *)(base + oPp);
+  d.pair_a = (const int *)(base + oPa);
+  d.pair_b = (const int *)(base + oPb);
+  d.Cinv = (double *)(base + oCinv);
+  d.Cinvb = (double *)(base + oCinvb);
+  d.b = (double *)(base + oB);
+  d.err_i = (double *)(base + oErr);
+  d.Bs = (double *)(base + oBs);
+  d.BCs = (double *)(base + oBCs);
+  d.Apart = (double *)(base + oAp);
+  d.S = (double *)(base + oS);
+  d.x = (double *)(base + ox);
+  d.avg_err = (double *)(base + oAvg);
+  d.flags = (int *)(base + oFl);
+  const int n = 6 * No;
+  const size_t lds = sizeof(double) * ((size_t)n * n + 2 * (size_t)n) + sizeof(int) * (size_t)n + 64;
+  if (lds > 64 * 1024)
+    VO_CHECK_HIP(c, hipFuncSetAttribute((const void *)sba_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  vo_prof_begin(c, VO_K_AUX);
+  for (int iter = 0; iter < p->max_iter; ++iter) {
+    hipLaunchKernelGGL(sba_point_kernel, dim3((M + 63) / 64), dim3(64), 0, s, d);
+    if (No > 0) {
+      hipLaunchKernelGGL(sba_pose_kernel, dim3(No, SBA_PG), dim3(64), 0, s, d);
+      hipLaunchKernelGGL(sba_schur_kernel, dim3(No * No), dim3(64), 0, s, d);
+    }
+    hipLaunchKernelGGL(sba_solve_kernel, dim3(1), dim3(64), lds, s, d, iter);
+    hipLaunchKernelGGL(sba_update_kernel, dim3((M + 63) / 64), dim3(64), 0, s, d);
+  }
+  vo_prof_end(c);
+  VO_CHECK_HIP(c, hipGetLastError());
+  int flags[4] = {0, 0, 0, 0};
+  std::vector<double> errs(p->max_iter + 1, 0.0);
+  VO_CHECK_HIP(c, hipMemcpyAsync(flags, base + oFl, sizeof(flags), hipMemcpyDeviceToHost, s));
+  VO_CHECK_HIP(c, hipMemcpyAsync(errs.data(), base + oAvg, sizeof(double) * (p->max_iter + 1), hipMemcpyDeviceToHost, s));
+  VO_CHECK_HIP(c, hipMemcpyAsync(T_jw, base + oT, sizeof(double) * 16 * Nf, hipMemcpyDeviceToHost, s));
+  VO_CHECK_HIP(c, hipMemcpyAsync(X, base + oX, sizeof(double) * 3 * M, hipMemcpyDeviceToHost, s));
+  VO_CHECK_HIP(c, hipStreamSynchronize(s));
+  if (avg_err)
+    for (int k = 0; k < p->max_iter; ++k) avg_err[k] = errs[k];
+  if (flags[0] & 1) VO_FAIL(c, VO_ERR_LBA_NAN, "In LBA, pose becomes nan!");
+  if (flags[0] & 2) VO_FAIL(c, VO_ERR_LBA_NAN, "Local BA NAN!");
+  if (p->max_iter == 0) return 1;
+  return errs[p->max_iter - 1] <= 1.0 ? 1 : 0;  // THRES_SUCCESS_AVG_ERROR (:158, :599-601)
+}

@@ -120,6 +120,7 @@ extern "C" void vo_destroy(vo_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   vo_frame_free(c);
   vo_rectify_free(c);
+  vo_sba_free(c);
   if (c->prof) {
     for (int i = 0; i < c->prof_cap; ++i) {
       (void)hipEventDestroy(c->prof[i].a);

@@ -79,6 +79,7 @@ struct vo_ctx {
   // undistortion / rectification maps (rectify.hip): camera 0 = left or mono, 1 = right
   float *rect_u[2], *rect_v[2];
   int rect_w[2], rect_h[2];
+  struct vo_sba_state *sba;  // device arena of the sparse local BA (sba.hip)
 };
 
 #define VO_CHECK_HIP(ctx, expr)                                                            \

@@ -41,6 +41,9 @@ int vo_pyramid_build_pair_rectified(vo_ctx *c, int slot_l, const uint8_t *d_l, i
 // rectify.hip
 void vo_rectify_free(vo_ctx *c);
 
+// sba.hip
+void vo_sba_free(vo_ctx *c);
+
 // klt_track.hip
 int vo_klt_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, const float *d_pts1_init,
                    float *d_pts1, int n_max,
