@@ -13,10 +13,11 @@
 //   sba_pose_kernel    SBA_PG wavefronts per optimised pose: A_j, a_j over the pose's observation list,
 //                      (B C^-1 b)_j over its slot list; lane-strided partial sums + butterfly
 //   sba_schur_kernel   one wavefront per block (j,k): sum of (B_ji C_i^-1) B_ki^T over the landmark pairs
-//   sba_solve_kernel   one wavefront: lower<-upper symmetrisation quirk, reduced system in LDS, Eigen-order
-//                      pivoted LDLT, x; pose updates exp(log(exp(x) exp(log T))); average error
+//   sba_assemble_kernel one lane per entry of the reduced system (lower<-upper symmetrisation quirk applied)
+//   sba_solve_kernel   one wavefront: pivot order from the original diagonal, permuted system in LDS, Eigen-order
+//                      LDLT, x; pose updates exp(log(exp(x) exp(log T))); average error
 //   sba_update_kernel  one lane per landmark: y_i, X_i += y_i
-// Five launches per iteration, no host round trip inside the solve. The quirks listed in
+// Six launches per iteration, no host round trip inside the solve. The quirks listed in
 // oracle/oracle_sba.c (B assigned not accumulated, left-only Schur loops, symmetrisation overwrite,
 // calc_Qij_t_Qij_weight's zero entries) are reproduced.
 #include <vector>
@@ -25,6 +26,7 @@
 #include "vo_kernels.hpp"
 
 #define SBA_PG 8        // partial-sum wavefronts per optimised pose
+#define SBA_SG 8        // partial-sum wavefronts per block of B C^-1 B^T
 #define SBA_MAX_OPT 20  // reduced system up to 120 x 120 in LDS
 
 struct SbaDev {
@@ -43,8 +45,9 @@ struct SbaDev {
   double *Cinv, *Cinvb, *b, *err_i;
   double *Bs, *BCs;
   double *Apart;  // n_opt * SBA_PG * 48 (36 A, 6 a, 6 BCinv_b)
-  double *S;      // n_opt * n_opt * 36
+  double *S;      // n_opt * n_opt * SBA_SG * 36 (partial sums; blocks below the diagonal are never used)
   double *x;      // n_opt * 6
+  double *G;      // reduced system, (6 n_opt)^2 lower triangle + 6 n_opt right-hand side
   double *avg_err;
   int *flags;
 };
@@ -319,11 +322,14 @@ __global__ __launch_bounds__(64) void sba_pose_kernel(SbaDev d) {
 
 // ---- per block (j,k) of B C^-1 B^T -------------------------------------------------------
 __global__ __launch_bounds__(64) void sba_schur_kernel(SbaDev d) {
-  const int jk = blockIdx.x, lane = threadIdx.x;
+  const int jk = blockIdx.x, g = blockIdx.y, lane = threadIdx.x;
+  // blocks below the diagonal are overwritten by the transposed upper ones (:495-497) before anything reads
+  // them: whatever an observation list in reverse keyframe order accumulates there is discarded
+  if (jk / d.n_opt > jk % d.n_opt) return;
   double acc[36];
 #pragma unroll
   for (int k = 0; k < 36; ++k) acc[k] = 0.0;
-  for (int q = d.pair_ptr[jk] + lane; q < d.pair_ptr[jk + 1]; q += 64) {
+  for (int q = d.pair_ptr[jk] + g * 64 + lane; q < d.pair_ptr[jk + 1]; q += 64 * SBA_SG) {
     const double *BC = d.BCs + 18 * (size_t)d.pair_a[q], *Bk = d.Bs + 18 * (size_t)d.pair_b[q];
     double bc[18], bk[18];
 #pragma unroll
@@ -340,7 +346,7 @@ __global__ __launch_bounds__(64) void sba_schur_kernel(SbaDev d) {
 #pragma unroll
   for (int k = 0; k < 36; ++k) {
     const double t = sba_wave_sum(acc[k]);
-    if (lane == 0) d.S[36 * (size_t)jk + k] = t;
+    if (lane == 0) d.S[36 * ((size_t)jk * SBA_SG + g) + k] = t;
   }
 }
 
@@ -429,89 +435,155 @@ __device__ void sba_pose_update(double *T, const double x[6]) {
 }
 
 // ---- reduced system: assemble, LDLT, solve, pose update, average error (one wavefront) ------------------
-__global__ __launch_bounds__(64) void sba_solve_kernel(SbaDev d, int iter) {
-  extern __shared__ double sm[];
-  const int No = d.n_opt, n = 6 * No, lane = threadIdx.x;
-  double *m = sm;                  // n x n row-major
-  double *y = sm + (size_t)n * n;  // n
-  double *temp = y + n;            // n
-  int *tr = (int *)(temp + n);     // n
-  // Am_BCinvBt (:499-506): block (j,u) = [j == u] A_j - BCinvBt_[j][u], where BCinvBt_[u][j] for u >= j was
-  // overwritten with the transpose of block (j,u) (:495-497; diagonal blocks are transposed in place)
-  for (int e = lane; e < n * n; e += 64) {
-    const int row = e / n, col = e - row * n;
-    const int j = row / 6, r = row - 6 * j, u = col / 6, c = col - 6 * u;
-    double s;
-    if (u >= j && !(u == j))
-      s = d.S[36 * ((size_t)j * No + u) + r * 6 + c];
-    else if (u == j)
-      s = d.S[36 * ((size_t)j * No + j) + c * 6 + r];
-    else
-      s = d.S[36 * ((size_t)u * No + j) + c * 6 + r];
-    double v = -s;
-    if (j == u) {
-      double A = 0.0;
-      for (int g = 0; g < SBA_PG; ++g) A += d.Apart[48 * ((size_t)j * SBA_PG + g) + r * 6 + c];
-      if (r == c) A += d.lambda * A;  // :433-441
-      v = A - s;
+// The matrix lives in LDS with M(i,j) at m[j * n + i]: the row sweeps below touch M(row, j) for consecutive
+// rows in consecutive lanes, i.e. consecutive addresses.
+#define SBA_CH 8
+// max over the 64 lanes (DPP butterfly, same pattern as wave_sum_i32 in vo_internal.hpp); all lanes get it
+__device__ __forceinline__ unsigned sba_wave_max_u32(unsigned v) {
+  int x = (int)v, t;
+  // every DPP is evaluated unconditionally (inside a select it would run under a partial EXEC mask and read
+  // zeros from the disabled lanes)
+#define SBA_UMAX_STEP(expr) \
+  t = (expr);               \
+  x = (unsigned)x > (unsigned)t ? x : t;
+  SBA_UMAX_STEP(dpp_i32<0xB1>(x))
+  SBA_UMAX_STEP(dpp_i32<0x4E>(x))
+  SBA_UMAX_STEP(dpp_i32<0x141>(x))
+  SBA_UMAX_STEP(dpp_i32<0x140>(x))
+  SBA_UMAX_STEP(__builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false))
+  SBA_UMAX_STEP(__builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false))
+#undef SBA_UMAX_STEP
+  return (unsigned)__builtin_amdgcn_readlane(x, 63);
+}
+__device__ __forceinline__ double sba_row_dot(const double *__restrict__ m, const double *__restrict__ temp, int n,
+                                              int row, int k) {
+  // sum_{j<k} M(row,j) temp[j] in increasing j (the CPU order); loads of a chunk are issued together
+  double dd = 0.0;
+  int j = 0;
+  for (; j + SBA_CH <= k; j += SBA_CH) {
+    double a[SBA_CH], t[SBA_CH];
+#pragma unroll
+    for (int q = 0; q < SBA_CH; ++q) {
+      a[q] = m[(size_t)(j + q) * n + row];
+      t[q] = temp[j + q];
     }
-    m[e] = v;
+#pragma unroll
+    for (int q = 0; q < SBA_CH; ++q) dd += a[q] * t[q];
   }
-  for (int e = lane; e < n; e += 64) {
-    const int j = e / 6, r = e - 6 * j;
+  for (; j < k; ++j) dd += m[(size_t)j * n + row] * temp[j];
+  return dd;
+}
+// entry (row, col), row >= col, of the reduced matrix Am_BCinvBt (:499-506) from the partial sums in HBM:
+// block (j,u) = [j == u] A_j - BCinvBt_[j][u], where the blocks on and below the diagonal are the transposed
+// blocks on and above it (:495-497; diagonal blocks are transposed in place)
+__device__ __forceinline__ double sba_reduced_entry(const SbaDev &d, int row, int col) {
+  const int No = d.n_opt;
+  const int j = row / 6, r = row - 6 * j, u = col / 6, c = col - 6 * u;  // u <= j
+  const double *blk = d.S + 36 * (((size_t)u * No + j) * SBA_SG);      // block (u,j), read transposed
+  const int idx = c * 6 + r;
+  double s = 0.0;
+#pragma unroll
+  for (int g = 0; g < SBA_SG; ++g) s += blk[36 * g + idx];
+  if (j != u) return -s;
+  double A = 0.0;
+#pragma unroll
+  for (int g = 0; g < SBA_PG; ++g) A += d.Apart[48 * ((size_t)j * SBA_PG + g) + r * 6 + c];
+  if (r == c) A += d.lambda * A;  // :433-441
+  return A - s;
+}
+
+// the reduced system out of the partial sums: one lane per entry of the lower triangle (and of the right-hand
+// side), so that the one-wavefront solve kernel below starts from n^2 coalesced loads instead of 16 n^2 serial ones
+__global__ __launch_bounds__(64) void sba_assemble_kernel(SbaDev d) {
+  const int n = 6 * d.n_opt;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n * n) {
+    const int row = e / n, col = e - row * n;
+    if (row >= col) d.G[e] = sba_reduced_entry(d, row, col);
+  } else if (e < n * n + n) {
+    const int q = e - n * n, j = q / 6, r = q - 6 * j;
     double a = 0.0, bcb = 0.0;
     for (int g = 0; g < SBA_PG; ++g) {
       a += d.Apart[48 * ((size_t)j * SBA_PG + g) + 36 + r];
       bcb += d.Apart[48 * ((size_t)j * SBA_PG + g) + 42 + r];
     }
-    y[e] = a - bcb;  // :508-509
+    d.G[e] = a - bcb;  // :508-509
+  }
+}
+
+__global__ __launch_bounds__(64) void sba_solve_kernel(SbaDev d, int iter) {
+  extern __shared__ double sm[];
+  const int No = d.n_opt, n = 6 * No, lane = threadIdx.x;
+  double *m = sm;                  // n x n, M(i,j) = m[j * n + i], lower triangle
+  double *y = sm + (size_t)n * n;  // n
+  double *temp = y + n;            // n
+  double *dg = temp + n;           // n: |diagonal| during the pivot pre-pass
+  int *tr = (int *)(dg + n);       // n: transpositions
+  int *sig = tr + n;               // n: position -> original index
+  const long long t_0 = (long long)__builtin_amdgcn_s_memrealtime();
+#define MM(i, j) m[(size_t)(j) * n + (i)]
+  // ---- pivot order. Eigen's LDLT looks for the largest |diagonal| among rows k.. at step k, and in its
+  // left-looking form the diagonal entries of rows > k still hold their ORIGINAL values at that point: the whole
+  // transposition sequence depends on the original diagonal only. It is computed first, the matrix is then
+  // assembled already permuted, and the factorisation runs without swaps — same operations on the same values.
+  for (int e = lane; e < n; e += 64) {
+    dg[e] = fabs(d.G[(size_t)e * n + e]);
+    sig[e] = e;
   }
   __syncthreads();
-#define MM(i, j) m[(size_t)(i) * n + (j)]
-  // Eigen::LDLT, lower, in place; per-row inner sums in the sequential order of the CPU restatement
   for (int k = 0; k < n; ++k) {
-    // pivot: largest |diagonal| in k..n-1, first one on ties
-    double best = -1.0;
-    int piv = n;
-    for (int i = k + lane; i < n; i += 64) {
-      const double a = fabs(MM(i, i));
-      if (a > best) {
-        best = a;
-        piv = i;
+    // largest, first one on ties. |d| >= 0: the IEEE bit pattern orders like an unsigned integer, so two 32-bit
+    // DPP max reductions and a ballot replace a 64-bit shuffle tree
+    const int i0 = k + lane, i1 = k + lane + 64;
+    const bool v0 = i0 < n, v1 = i1 < n;
+    const unsigned long long k0 = v0 ? (unsigned long long)__double_as_longlong(dg[i0]) : 0ull;
+    const unsigned long long k1 = v1 ? (unsigned long long)__double_as_longlong(dg[i1]) : 0ull;
+    const bool second = v1 && k1 > k0;  // within a lane the first slot wins ties (smaller index)
+    const unsigned long long key = second ? k1 : k0;
+    const unsigned hi = sba_wave_max_u32((unsigned)(key >> 32));
+    const bool c_hi = v0 && (unsigned)(key >> 32) == hi;
+    const unsigned lo = sba_wave_max_u32(c_hi ? (unsigned)key : 0u);
+    const bool cand = c_hi && (unsigned)key == lo;
+    const unsigned long long b_first = __ballot(cand && !second), b_second = __ballot(cand && second);
+    const int piv = b_first ? k + (int)__builtin_ctzll(b_first) : k + 64 + (int)__builtin_ctzll(b_second);
+    if (lane == 0) {
+      tr[k] = piv;
+      if (piv != k) {
+        const double t = dg[k];
+        dg[k] = dg[piv];
+        dg[piv] = t;
+        const int ti = sig[k];
+        sig[k] = sig[piv];
+        sig[piv] = ti;
       }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const double ob = __shfl_xor(best, off);
-      const int op = __shfl_xor(piv, off);
-      if (ob > best || (ob == best && op < piv)) {
-        best = ob;
-        piv = op;
-      }
-    }
-    if (lane == 0) tr[k] = piv;
-    if (piv != k) {
-      for (int j = lane; j < k; j += 64) { const double t = MM(k, j); MM(k, j) = MM(piv, j); MM(piv, j) = t; }
-      for (int i = piv + 1 + lane; i < n; i += 64) { const double t = MM(i, k); MM(i, k) = MM(i, piv); MM(i, piv) = t; }
-      for (int i = k + 1 + lane; i < piv; i += 64) { const double t = MM(i, k); MM(i, k) = MM(piv, i); MM(piv, i) = t; }
-      __syncthreads();
-      if (lane == 0) { const double t = MM(k, k); MM(k, k) = MM(piv, piv); MM(piv, piv) = t; }
     }
     __syncthreads();
+  }
+  // ---- assemble the permuted lower triangle: entry (i,j), i >= j, is the original lower-triangle entry between
+  // sig[i] and sig[j] (the symmetric swaps of the reference only ever move lower-triangle storage)
+#pragma unroll 4
+  for (int e = lane; e < n * n; e += 64) {  // (independent iterations: the loads of several are in flight together)
+    const int col = e / n, row = e - col * n;
+    if (row >= col) {
+      const int sr = sig[row], sc = sig[col];
+      MM(row, col) = sr >= sc ? d.G[(size_t)sr * n + sc] : d.G[(size_t)sc * n + sr];
+    }
+  }
+  for (int e = lane; e < n; e += 64) temp[e] = d.G[(size_t)n * n + e];
+  __syncthreads();
+  // P rhs: the transposition sequence applied to a vector is the gather by sig (sig went through the same swaps)
+  for (int e = lane; e < n; e += 64) y[e] = temp[sig[e]];
+  __syncthreads();
+  const long long t_1 = (long long)__builtin_amdgcn_s_memrealtime();
+  // ---- Eigen::LDLT (lower, in place) on the permuted matrix; every inner sum in the sequential order of the
+  // CPU restatement
+  for (int k = 0; k < n; ++k) {
     const int rs = n - k - 1;
     if (k > 0) {
       for (int j = lane; j < k; j += 64) temp[j] = MM(j, j) * MM(k, j);
       __syncthreads();
-      if (lane == 0) {
-        double s = 0.0;
-        for (int j = 0; j < k; ++j) s += MM(k, j) * temp[j];
-        MM(k, k) -= s;
-      }
-      for (int i = lane; i < rs; i += 64) {
-        double dd = 0.0;
-        for (int j = 0; j < k; ++j) dd += MM(k + 1 + i, j) * temp[j];
-        MM(k + 1 + i, k) -= dd;
-      }
+      // rows k (the diagonal entry) and k+1.. in one sweep: none of them reads what another writes
+      for (int t = lane; t <= rs; t += 64) MM(k + t, k) -= sba_row_dot(m, temp, n, k + t, k);
       __syncthreads();
     }
     const double akk = MM(k, k);
@@ -519,11 +591,8 @@ __global__ __launch_bounds__(64) void sba_solve_kernel(SbaDev d, int iter) {
       for (int i = lane; i < rs; i += 64) MM(k + 1 + i, k) /= akk;
     __syncthreads();
   }
-  // solve: x = P^T L^-T D^+ L^-1 P rhs (column-oriented sweeps: same subtraction order per entry as the row form)
-  if (lane == 0)
-    for (int k = 0; k < n; ++k)
-      if (tr[k] != k) { const double t = y[k]; y[k] = y[tr[k]]; y[tr[k]] = t; }
-  __syncthreads();
+  // solve: x = P^T L^-T D^+ L^-1 (P rhs)
+  // L sweep, column-oriented: entry i subtracts M(i,j) y_j in increasing j, as the row form does
   for (int j = 0; j < n; ++j) {
     const double yj = y[j];
     for (int i = j + 1 + lane; i < n; i += 64) y[i] -= MM(i, j) * yj;
@@ -532,18 +601,20 @@ __global__ __launch_bounds__(64) void sba_solve_kernel(SbaDev d, int iter) {
   const double tol = 2.2250738585072014e-308;
   for (int i = lane; i < n; i += 64) y[i] = fabs(MM(i, i)) > tol ? y[i] / MM(i, i) : 0.0;
   __syncthreads();
-  if (lane == 0) {
-    // L^T sweep in row form (entry j subtracts M(q,j) y_q for q = j+1.. in increasing q, the CPU order), then P^T
-    for (int j = n - 1; j >= 0; --j) {
-      double s = y[j];
-      for (int q = j + 1; q < n; ++q) s -= MM(q, j) * y[q];
-      y[j] = s;
-    }
-    for (int k = n - 1; k >= 0; --k)
-      if (tr[k] != k) { const double t = y[k]; y[k] = y[tr[k]]; y[tr[k]] = t; }
+  // L^T sweep, column-oriented as well: entry i subtracts M(q,i) y_q in DECREASING q (the CPU restatement's row
+  // form goes up; the difference is the rounding of an n-term sum, ~1e-16 relative)
+  for (int q = n - 1; q > 0; --q) {
+    const double yq = y[q];
+    for (int i = lane; i < q; i += 64) y[i] -= MM(q, i) * yq;
+    __syncthreads();
   }
+  // P^T: scatter back through sig
+  for (int e = lane; e < n; e += 64) temp[sig[e]] = y[e];
+  __syncthreads();
+  for (int e = lane; e < n; e += 64) y[e] = temp[e];
   __syncthreads();
 #undef MM
+  const long long t_2 = (long long)__builtin_amdgcn_s_memrealtime();
   for (int e = lane; e < n; e += 64) d.x[e] = y[e];
   // pose updates (:560-576)
   for (int f = lane; f < d.n_frames; f += 64) {
@@ -557,6 +628,10 @@ __global__ __launch_bounds__(64) void sba_solve_kernel(SbaDev d, int iter) {
   if (lane == 0) {
     d.avg_err[iter] = sqrt(e / (double)d.n_obs);
     if (e != e) atomicOr(d.flags, 2);
+    // phase durations of the last iteration in 10 ns ticks (tools/tools_sbabench.py)
+    d.flags[1] = (int)(t_1 - t_0);
+    d.flags[2] = (int)(t_2 - t_1);
+    d.flags[3] = (int)((long long)__builtin_amdgcn_s_memrealtime() - t_2);
   }
 }
 
@@ -583,7 +658,13 @@ __global__ __launch_bounds__(64) void sba_update_kernel(SbaDev d) {
 struct vo_sba_state {
   void *dev;
   size_t cap;
+  int phase_ticks[3];  // sba_solve_kernel of the last iteration: assembly, LDLT + solve, pose update (10 ns ticks)
 };
+extern "C" int vo_debug_sba_phases(vo_ctx *c, int out[3]) {
+  if (!c || !c->sba) return VO_ERR_INVALID;
+  memcpy(out, c->sba->phase_ticks, sizeof(int) * 3);
+  return VO_OK;
+}
 
 void vo_sba_free(vo_ctx *c) {
   if (c->sba) {
@@ -683,9 +764,10 @@ extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, co
   const size_t oPb = ar.take(sizeof(int) * (pair_b.size() + 1));
   const size_t oCinv = ar.take(sizeof(double) * 9 * M), oCinvb = ar.take(sizeof(double) * 3 * M), oB = ar.take(sizeof(double) * 3 * M);
   const size_t oErr = ar.take(sizeof(double) * M), oBs = ar.take(sizeof(double) * 18 * (ns + 1)), oBCs = ar.take(sizeof(double) * 18 * (ns + 1));
-  const size_t oAp = ar.take(sizeof(double) * 48 * SBA_PG * (No + 1)), oS = ar.take(sizeof(double) * 36 * ((size_t)No * No + 1));
+  const size_t oAp = ar.take(sizeof(double) * 48 * SBA_PG * (No + 1)), oS = ar.take(sizeof(double) * 36 * SBA_SG * ((size_t)No * No + 1));
+  const size_t oG = ar.take(sizeof(double) * ((size_t)36 * No * No + 6 * No + 1));
   const size_t ox = ar.take(sizeof(double) * 6 * (No + 1)), oAvg = ar.take(sizeof(double) * (p->max_iter + 1)), oFl = ar.take(sizeof(int) * 4);
-  if (!c->sba) c->sba = new vo_sba_state{nullptr, 0};
+  if (!c->sba) c->sba = new vo_sba_state{nullptr, 0, {0, 0, 0}};
   if (c->sba->cap < ar.off) {
     if (c->sba->dev) (void)hipFree(c->sba->dev);
     c->sba->dev = nullptr;
@@ -769,10 +851,11 @@ extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, co
   d.Apart = (double *)(base + oAp);
   d.S = (double *)(base + oS);
   d.x = (double *)(base + ox);
+  d.G = (double *)(base + oG);
   d.avg_err = (double *)(base + oAvg);
   d.flags = (int *)(base + oFl);
   const int n = 6 * No;
-  const size_t lds = sizeof(double) * ((size_t)n * n + 2 * (size_t)n) + sizeof(int) * (size_t)n + 64;
+  const size_t lds = sizeof(double) * ((size_t)n * n + 3 * (size_t)n) + sizeof(int) * 2 * (size_t)n + 64;
   if (lds > 64 * 1024)
     VO_CHECK_HIP(c, hipFuncSetAttribute((const void *)sba_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   vo_prof_begin(c, VO_K_AUX);
@@ -780,8 +863,9 @@ extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, co
     hipLaunchKernelGGL(sba_point_kernel, dim3((M + 63) / 64), dim3(64), 0, s, d);
     if (No > 0) {
       hipLaunchKernelGGL(sba_pose_kernel, dim3(No, SBA_PG), dim3(64), 0, s, d);
-      hipLaunchKernelGGL(sba_schur_kernel, dim3(No * No), dim3(64), 0, s, d);
+      hipLaunchKernelGGL(sba_schur_kernel, dim3(No * No, SBA_SG), dim3(64), 0, s, d);
     }
+    if (No > 0) hipLaunchKernelGGL(sba_assemble_kernel, dim3((n * n + n + 63) / 64), dim3(64), 0, s, d);
     hipLaunchKernelGGL(sba_solve_kernel, dim3(1), dim3(64), lds, s, d, iter);
     hipLaunchKernelGGL(sba_update_kernel, dim3((M + 63) / 64), dim3(64), 0, s, d);
   }
@@ -796,6 +880,7 @@ extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, co
   VO_CHECK_HIP(c, hipStreamSynchronize(s));
   if (avg_err)
     for (int k = 0; k < p->max_iter; ++k) avg_err[k] = errs[k];
+  memcpy(c->sba->phase_ticks, flags + 1, sizeof(int) * 3);
   if (flags[0] & 1) VO_FAIL(c, VO_ERR_LBA_NAN, "In LBA, pose becomes nan!");
   if (flags[0] & 2) VO_FAIL(c, VO_ERR_LBA_NAN, "Local BA NAN!");
   if (p->max_iter == 0) return 1;
