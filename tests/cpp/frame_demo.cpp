@@ -8,6 +8,7 @@
 
 #include "visual_odometry_ros_amd/core/visual_odometry/camera.h"
 #include "visual_odometry_ros_amd/core/visual_odometry/frame_pipeline.h"
+#include "visual_odometry_ros_amd/core/visual_odometry/sparse_bundle_adjustment.h"
 
 template <typename T>
 static std::vector<T> rd(FILE *f, size_t n) {
@@ -42,6 +43,17 @@ int main(int argc, char **argv) {
   auto Xw = rd<float>(f, 3 * n);
   auto flags = rd<unsigned char>(f, n);
   auto Tcw_prev = rd<float>(f, 16), Tcw_prior = rd<float>(f, 16);
+  // a local-BA window (mono)
+  int bh[3];
+  if (fread(bh, sizeof(int), 3, f) != 3) return 1;
+  const int ba_frames = bh[0], ba_points = bh[1], ba_obs = bh[2];
+  auto baT = rd<double>(f, 16 * (size_t)ba_frames);
+  auto baOpt = rd<int>(f, ba_frames);
+  auto baX = rd<double>(f, 3 * (size_t)ba_points);
+  auto baPtr = rd<int>(f, ba_points + 1), baFrame = rd<int>(f, ba_obs);
+  auto baRight = rd<unsigned char>(f, ba_obs);
+  auto baPx = rd<double>(f, 2 * (size_t)ba_obs);
+  auto baK = rd<double>(f, 4);
   fclose(f);
 
   vo::PixelVec vl0(n), vr0(n), vnew(n_new);
@@ -146,6 +158,38 @@ int main(int argc, char **argv) {
       if (vo_get_level(ctx->get(), slot, 0, lv0.data(), &gw, &gh) != VO_OK || gw != w || gh != h) return 3;
       wr(o, lv0.data(), lv0.size());
     }
+  }
+  {  // ---- SparseBundleAdjustmentSolver ----
+    auto ctx = std::make_shared<vo::Context>(0, 64, 64, 64, 2, 1);
+    vo::SparseBAProblem p;
+    p.T_jw.resize(ba_frames);
+    for (int i = 0; i < ba_frames; ++i)
+      for (int k = 0; k < 16; ++k) p.T_jw[i][k] = baT[16 * (size_t)i + k];
+    p.opt_index.assign(baOpt.begin(), baOpt.end());
+    p.X.resize(ba_points);
+    for (int i = 0; i < ba_points; ++i)
+      for (int k = 0; k < 3; ++k) p.X[i][k] = baX[3 * (size_t)i + k];
+    p.obs_ptr.assign(baPtr.begin(), baPtr.end());
+    p.obs_frame.assign(baFrame.begin(), baFrame.end());
+    p.obs_right.assign(baRight.begin(), baRight.end());
+    p.obs_px.resize(ba_obs);
+    for (int i = 0; i < ba_obs; ++i) p.obs_px[i] = {baPx[2 * (size_t)i], baPx[2 * (size_t)i + 1]};
+    vo::SparseBundleAdjustmentSolver solver(ctx, false);
+    int threw = 0;
+    try {
+      solver.setStereoCameras({1, 1, 0, 0}, {1, 1, 0, 0}, {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1});
+    } catch (const std::runtime_error &) {
+      threw = 1;
+    }
+    solver.setCamera({baK[0], baK[1], baK[2], baK[3]});
+    solver.setHuberThreshold(0.5);
+    std::vector<double> err;
+    const bool ok = solver.solveForFiniteIterations(10, p, &err);
+    const int head[2] = {ok ? 1 : 0, threw};
+    wr(o, head, 2);
+    wr(o, err.data(), err.size());
+    wr(o, p.T_jw[0].data(), 16 * (size_t)ba_frames);
+    wr(o, p.X[0].data(), 3 * (size_t)ba_points);
   }
   fclose(o);
   return 0;

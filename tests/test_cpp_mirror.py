@@ -102,6 +102,11 @@ def test_cpp_frame_pipelines_match_python_api(vo, tmp_path):
                   ts["pts_l0"], ts["pts_r0"], ts["Xp"].astype(np.float32), ts["pts_new"], Xw, flags,
                   Tcw_prev.reshape(16), Tcw_prior.reshape(16)):
             f.write(np.ascontiguousarray(a).tobytes())
+        ba = S.ba_window(n_kf=6, n_points=200, stereo=False, seed=8)
+        f.write(struct.pack("3i", ba["T_jw"].shape[0], ba["X"].shape[0], ba["obs_px"].shape[0]))
+        for a in (ba["T_jw"], ba["opt_index"], ba["X"], ba["obs_ptr"], ba["obs_frame"], ba["obs_right"], ba["obs_px"],
+                  ba["K"]):
+            f.write(np.ascontiguousarray(a).tobytes())
     subprocess.check_call([exe, str(inp), str(outp)])
     raw = open(outp, "rb").read()
     off = 0
@@ -157,6 +162,18 @@ def test_cpp_frame_pipelines_match_python_api(vo, tmp_path):
         assert np.array_equal(take(np.float32, 16).reshape(4, 4), sc.getRectifiedStereoPoseLeft2Right())
         assert np.array_equal(take(np.uint8, W * H).reshape(H, W), c.get_level(0, 0))
         assert np.array_equal(take(np.uint8, W * H).reshape(H, W), c.get_level(1, 0))
+        # ---- SparseBundleAdjustmentSolver (sparse_bundle_adjustment.h) against the Python mirror
+        from visual_odometry_ros_amd.api import SparseBundleAdjustmentSolver
+        sol = SparseBundleAdjustmentSolver(c, False)
+        sol.setCamera(ba["K"])
+        sol.setHuberThreshold(0.5)
+        ok_p, T_p, X_p, err_p = sol.solveForFiniteIterations(10, ba["T_jw"], ba["opt_index"], ba["X"], ba["obs_ptr"],
+                                                             ba["obs_frame"], ba["obs_right"], ba["obs_px"])
+        head = take(np.int32, 2)
+        assert head[0] == int(ok_p) == 1 and head[1] == 1
+        assert np.array_equal(take(np.float64, 10), err_p)
+        assert np.array_equal(take(np.float64, 16 * T_p.shape[0]).reshape(-1, 4, 4), T_p)
+        assert np.array_equal(take(np.float64, 3 * X_p.shape[0]).reshape(-1, 3), X_p)
         assert off == len(raw)
     finally:
         c.close()
