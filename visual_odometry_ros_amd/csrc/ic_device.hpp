@@ -383,7 +383,7 @@ __device__ __forceinline__ IcResult ic_iterate(const vo_level &I1, const IcTaps 
     const float e = sqrtf(e2 / v[3]);
     const float err_rate = fabsf(err_prev - e) / err_prev;
     const float dt_norm = dtu * dtu + dtv * dtv;
-    const bool is_nan = isnan(dtu + dtv) | isnan(ax + ay);
+    const bool is_nan = (int)isnan(dtu + dtv) | (int)isnan(ax + ay);  // bitwise on purpose: no branch
     const bool conv = (iter > 1) & ((err_rate <= 1e-3f) | (dt_norm <= 1e-4f));
     // every lane holds the same values: make the exit a scalar branch
     const int ex = __builtin_amdgcn_readfirstlane((is_nan ? 2 : 0) | (conv ? 1 : 0));
@@ -604,7 +604,6 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
     }
     v = __builtin_amdgcn_readfirstlane(v);
     int any_change = 0;
-    bool gated = false;
     for (int li = blockIdx.x; li < n_touched; li += P) {
       const int pt = a.tlist[li];
       __syncthreads();  // LDS of the previous list entry is free
@@ -761,10 +760,7 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
         }
         if (give_up) break;
       }
-      if (unchanged || give_up) {
-        if (give_up) gated = true;
-        continue;
-      }
+      if (unchanged || give_up) continue;
 #pragma unroll
       for (int k = 0; k < IC_K; ++k)
         if ((seen >> k) & 1u) {
