@@ -524,3 +524,49 @@ def ldlt_solve_f64(A, B):
     B = _f64(B).reshape(n, -1).copy()
     lib().vo_ref_ldlt_solve_f64(n, _p(A, C.c_double), B.shape[1], _p(B, C.c_double))
     return B
+
+
+# ---- cv::ORB::detect as FeatureExtractor configures it (oracle_orb.c) ----
+def resize_linear_exact(img, dw, dh):
+    img, w, h, st = _img(img)
+    out = np.zeros((dh, dw), np.uint8)
+    lib().vo_ref_resize_linear_exact_u8(_p(img, C.c_uint8), w, h, st, _p(out, C.c_uint8), dw, dh)
+    return out
+
+
+def fast_score_image(img, threshold):
+    img, w, h, st = _img(img)
+    out = np.zeros((h, w), np.uint8)
+    lib().vo_ref_fast_score_image(_p(img, C.c_uint8), w, h, st, int(threshold), _p(out, C.c_uint8))
+    return out
+
+
+def orb_level_sizes(w, h, scale_factor=1.2, n_levels=8, nfeatures=10000):
+    lw, lh, nper = (np.zeros(n_levels, np.int32) for _ in range(3))
+    ls = np.zeros(n_levels, np.float32)
+    lib().vo_ref_orb_level_sizes(w, h, C.c_double(scale_factor), n_levels, nfeatures, _p(lw, C.c_int32),
+                                 _p(lh, C.c_int32), _p(ls), _p(nper, C.c_int32))
+    return lw, lh, ls, nper
+
+
+def orb_detect(img, fast_threshold, nfeatures=10000, scale_factor=1.2, n_levels=8, edge_threshold=31, max_kp=60000,
+               with_levels=False):
+    img, w, h, st = _img(img)
+    xy = np.zeros((max_kp, 2), np.float32)
+    resp = np.zeros(max_kp, np.float32)
+    octv = np.zeros(max_kp, np.int32)
+    lw, lh, _, _ = orb_level_sizes(w, h, scale_factor, n_levels, nfeatures)
+    lv = np.zeros(int(np.sum(lw.astype(np.int64) * lh)), np.uint8) if with_levels else None
+    f = lib().vo_ref_orb_detect
+    f.restype = C.c_int
+    n = f(_p(img, C.c_uint8), w, h, st, nfeatures, C.c_double(scale_factor), n_levels, edge_threshold, int(fast_threshold),
+          _p(xy), _p(resp), _p(octv, C.c_int32), max_kp, _p(lv, C.c_uint8) if with_levels else None)
+    assert n >= 0
+    out = dict(xy=xy[:n].copy(), response=resp[:n].copy(), octave=octv[:n].copy())
+    if with_levels:
+        levels, off = [], 0
+        for a, b in zip(lw, lh):
+            levels.append(lv[off: off + int(a) * int(b)].reshape(int(b), int(a)))
+            off += int(a) * int(b)
+        out["levels"] = levels
+    return out

@@ -244,6 +244,15 @@ void vo_ref_sba_linearize(const vo_ref_sba_dims *d, const double T_jw[16], const
 int vo_ref_sba_solve(const vo_ref_sba_dims *d, double *T_jw, const int *opt_index, double *X, const int *obs_ptr,
                      const int *obs_frame, const uint8_t *obs_right, const double *obs_px, double *avg_err);
 
+/* ---- cv::ORB::detect as FeatureExtractor configures it (oracle_orb.c; OpenCV restated, see its header) ---- */
+void vo_ref_resize_linear_exact_u8(const uint8_t *src, int w, int h, int stride, uint8_t *dst, int dw, int dh);
+void vo_ref_fast_score_image(const uint8_t *img, int w, int h, int stride, int threshold, uint8_t *score);
+void vo_ref_orb_level_sizes(int w, int h, double scale_factor, int n_levels, int nfeatures, int *lw, int *lh,
+                            float *lscale, int *nper);
+int vo_ref_orb_detect(const uint8_t *img, int w, int h, int stride, int nfeatures, double scale_factor, int n_levels,
+                      int edge_threshold, int fast_threshold, float *kp_xy, float *kp_response, int32_t *kp_octave,
+                      int max_kp, uint8_t *levels_out);
+
 #ifdef __cplusplus
 }
 #endif

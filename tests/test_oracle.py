@@ -424,3 +424,69 @@ def test_sba_oracle_vs_dense_normal_equations(oracle):
             assert err[-1] < 1e-9 and np.abs(T - q["T_jw_true"]).max() < 1e-10 and np.abs(X - q["X_true"]).max() < 1e-9
         else:
             assert err[-1] < 0.1 and np.abs(T - q["T_jw_true"]).max() < 5e-3 and np.abs(X - q["X_true"]).max() < 5e-2
+
+
+def test_orb_detect_pieces_vs_numpy(oracle):
+    """oracle_orb.c against independent numpy restatements: FAST-9/16 corner test and score by brute force over
+    the 16 arcs, Harris response, the exact-bilinear resize against float64 bilinear (pixel-centre aligned) within
+    the 8-bit coefficient quantisation, and the detector's bookkeeping (borders, per-level quotas)."""
+    rng = np.random.default_rng(3)
+    img = np.clip(np.kron(rng.integers(0, 256, (24, 32)), np.ones((5, 5))) + rng.normal(0, 12, (120, 160)), 0, 255).astype(np.uint8)
+    t = 20
+    sc = oracle.fast_score_image(img, t)
+    off = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1),
+           (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+    H, W = img.shape
+    ring = np.stack([np.roll(np.roll(img.astype(np.int32), -dy, 0), -dx, 1) for dx, dy in off])  # ring[k][y,x] = img[y+dy, x+dx]
+    d = img.astype(np.int32)[None] - ring
+    best_dark = np.full((H, W), -999)
+    best_bright = np.full((H, W), -999)
+    for s in range(16):
+        idx = [(s + q) % 16 for q in range(9)]
+        best_dark = np.maximum(best_dark, d[idx].min(0))
+        best_bright = np.maximum(best_bright, (-d[idx]).min(0))
+    m = np.maximum(best_dark, best_bright)
+    exp = np.where(m > t, m - 1, 0)
+    exp[:3] = exp[-3:] = 0
+    exp[:, :3] = exp[:, -3:] = 0
+    assert np.array_equal(sc.astype(np.int32), exp) and (sc > 0).sum() > 50
+    # resize: same size = copy; 1.2x down within one grey level of float64 bilinear; constants preserved
+    assert np.array_equal(oracle.resize_linear_exact(img, W, H), img)
+    dw, dh = int(round(W / 1.2)), int(round(H / 1.2))
+    r = oracle.resize_linear_exact(img, dw, dh)
+    xs = np.clip((np.arange(dw) + 0.5) * (W / dw) - 0.5, 0, W - 1)
+    ys = np.clip((np.arange(dh) + 0.5) * (H / dh) - 0.5, 0, H - 1)
+    x0, y0 = np.minimum(np.floor(xs).astype(int), W - 2), np.minimum(np.floor(ys).astype(int), H - 2)
+    ax, ay = (xs - x0)[None, :], (ys - y0)[:, None]
+    f = img.astype(np.float64)
+    ref = (1 - ay) * ((1 - ax) * f[y0][:, x0] + ax * f[y0][:, x0 + 1]) + ay * ((1 - ax) * f[y0 + 1][:, x0] + ax * f[y0 + 1][:, x0 + 1])
+    assert np.abs(r.astype(np.float64) - ref).max() <= 1.5
+    assert np.all(oracle.resize_linear_exact(np.full((50, 70), 137, np.uint8), 58, 42) == 137)
+    # level sizes and quotas of cv::ORB with the reference's parameters at 1241x376
+    lw, lh, ls, nper = oracle.orb_level_sizes(1241, 376)
+    assert list(lw) == [1241, 1034, 862, 718, 598, 499, 416, 346] and list(lh) == [376, 313, 261, 218, 181, 151, 126, 105]
+    assert nper.sum() == 10000 and list(nper[:3]) == [2172, 1810, 1508]
+    # whole detector on a rendered frame
+    stream = S.StereoStream(n_u=8, n_v=4, n_new=8, seed=4)
+    L = stream.render_pair(stream.poses(1)[0])[0]
+    det = oracle.orb_detect(L, 15, with_levels=True)
+    n = det["xy"].shape[0]
+    assert n > 500 and det["octave"].max() >= 3
+    for l in range(8):
+        sel = det["octave"] == l
+        if sel.any():
+            xy = det["xy"][sel] / ls[l]
+            assert xy[:, 0].min() >= 31 - 1e-3 and xy[:, 0].max() < lw[l] - 31 and xy[:, 1].min() >= 31 - 1e-3 and xy[:, 1].max() < lh[l] - 31
+            assert sel.sum() <= nper[l] or np.isclose(np.sort(det["response"][sel])[0], np.sort(det["response"][sel])[sel.sum() - nper[l]])
+    # Harris response of one keypoint vs numpy (Sobel-like 3x3 sums over a 7x7 block)
+    k = int(np.argmax(det["octave"] == 0))
+    x0, y0 = int(det["xy"][k, 0]), int(det["xy"][k, 1])
+    I = L.astype(np.int64)
+    a = b = c = 0
+    for yy in range(y0 - 3, y0 + 4):
+        for xx in range(x0 - 3, x0 + 4):
+            Ix = (I[yy, xx + 1] - I[yy, xx - 1]) * 2 + (I[yy - 1, xx + 1] - I[yy - 1, xx - 1]) + (I[yy + 1, xx + 1] - I[yy + 1, xx - 1])
+            Iy = (I[yy + 1, xx] - I[yy - 1, xx]) * 2 + (I[yy + 1, xx - 1] - I[yy - 1, xx - 1]) + (I[yy + 1, xx + 1] - I[yy - 1, xx + 1])
+            a, b, c = a + Ix * Ix, b + Iy * Iy, c + Ix * Iy
+    sc4 = (1.0 / (4 * 7 * 255.0)) ** 4
+    assert abs(det["response"][k] - (a * b - c * c - 0.04 * (a + b) ** 2) * sc4) <= 1e-4 * abs(det["response"][k]) + 1e-12
