@@ -182,6 +182,30 @@ int vo_bucket_argmax(vo_ctx *ctx, const float *kp_xy, const float *kp_response, 
                      float inv_v_step, int n_bins_u, int n_bins_v, const int32_t *weight, float *pts_out,
                      int32_t *idx_out, int *n_out);
 
+/* ---- FeatureExtractor::extractORBwithBinning_fast: detection ----------------------
+ * `extractor_orb_->detect(img, fts)` (feature_extractor.cpp:241) on the image held by `slot`. cv::ORB is
+ * OpenCV 4 (not in the reference tree); its detection pipeline — 8-level INTER_LINEAR_EXACT pyramid, FAST-9/16
+ * with non-max suppression, runByImageBorder, retainBest on the FAST score, HarrisResponses, retainBest on the
+ * Harris response, pt *= scale — is restated (oracle/oracle_orb.c says what could not be verified here).
+ * Keypoints come back as level-0 pixel coordinates, Harris response and octave, ordered by level and then
+ * raster order (cv's own order is unspecified). Orientation is not computed (the reference does not read it). */
+typedef struct {
+  int nfeatures;        /* setMaxFeatures(10000), feature_extractor.cpp:48 */
+  double scale_factor;  /* 1.2 */
+  int n_levels;         /* 8 */
+  int edge_threshold;   /* 31 */
+  int fast_threshold;   /* THRES_FAST */
+} vo_orb_params;
+int vo_orb_detect(vo_ctx *ctx, int slot, const vo_orb_params *prm, float *kp_xy, float *kp_response,
+                  int32_t *kp_octave, int max_kp, int *n_out);
+/* test hook: pyramid level >= 1 of the last detection, tightly packed */
+int vo_orb_get_level(vo_ctx *ctx, int level, uint8_t *host, int *width, int *height);
+/* detection + the flag_nonmax_ bucketing of feature_extractor.cpp:244-277 (vo_bucket_argmax) chained on the
+ * device: only the bucketed pixels are copied back. n_detected (may be NULL) = number of keypoints before bucketing. */
+int vo_extract_orb_with_binning(vo_ctx *ctx, int slot, const vo_orb_params *prm, float inv_u_step, float inv_v_step,
+                                int n_bins_u, int n_bins_v, const int32_t *weight, float *pts_out, int *n_out,
+                                int *n_detected);
+
 /* ---- FeatureExtractor::descriptorDistance (feature_extractor.cpp:338-357) - */
 /* all-pairs 256-bit Hamming distance, dist is na x nb row-major */
 int vo_orb_hamming(vo_ctx *ctx, const uint8_t *a, int na, const uint8_t *b, int nb,

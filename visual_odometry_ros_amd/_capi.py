@@ -52,6 +52,11 @@ class MonoCounts(C.Structure):
                 ("need_five_point", C.c_int), ("n_replayed", C.c_int)]
 
 
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int), ("scale_factor", C.c_double), ("n_levels", C.c_int),
+                ("edge_threshold", C.c_int), ("fast_threshold", C.c_int)]
+
+
 class SbaProblem(C.Structure):
     _fields_ = [("n_frames", C.c_int), ("n_opt", C.c_int), ("n_points", C.c_int), ("n_obs", C.c_int),
                 ("stereo", C.c_int), ("max_iter", C.c_int), ("Kl", C.c_double * 4), ("Kr", C.c_double * 4),
@@ -69,7 +74,7 @@ SYMBOLS = [
     "vo_orb_match", "vo_compact_indices", "vo_stereo_frame_set_strict_border",
     "vo_stereo_frame_enqueue", "vo_stereo_frame_result",
     "vo_mono_frame_enqueue", "vo_mono_frame_result",
-    "vo_sba_solve", "vo_rectify_init_mono", "vo_rectify_init_stereo", "vo_rectify_set_maps", "vo_rectify_get_maps",
+    "vo_sba_solve", "vo_orb_detect", "vo_orb_get_level", "vo_extract_orb_with_binning", "vo_rectify_init_mono", "vo_rectify_init_stereo", "vo_rectify_set_maps", "vo_rectify_get_maps",
     "vo_set_image_rectified", "vo_set_image_rectified_device", "vo_set_stereo_pair_rectified_device",
     "vo_profile_enable", "vo_profile_reset", "vo_profile_get", "vo_profile_set_classes",
     "vo_set_stereo_pair_device", "vo_set_pyramid_window_hint",

@@ -14,7 +14,8 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import FrameCounts, GnInfo, MonoCounts, MonoParams, SbaProblem, StereoParams, VoConfig, VoError
+from ._capi import (FrameCounts, GnInfo, MonoCounts, MonoParams, OrbParams, SbaProblem, StereoParams, VoConfig,
+                    VoError)
 
 KLT_USE_INITIAL_FLOW = 4
 GN_CORE, GN_STANDALONE = 0, 1
@@ -333,6 +334,32 @@ class FeatureExtractor:
         self.inv_u_step_ = f(1.0) / f(self.u_step)
         self.inv_v_step_ = f(1.0) / f(self.v_step)
         self.weight = np.ones(self.n_bins_u_ * self.n_bins_v_, np.int32)
+        # extractor_orb_ settings, feature_extractor.cpp:48-56
+        self.orb = OrbParams()
+        self.orb.nfeatures, self.orb.scale_factor, self.orb.n_levels = 10000, 1.2, 8
+        self.orb.edge_threshold, self.orb.fast_threshold = 31, int(THRES_FAST)
+
+    def detect(self, slot, max_kp=60000):
+        """extractor_orb_->detect(img, fts) (feature_extractor.cpp:241) on the image in `slot`:
+        (xy, response, octave)."""
+        xy = np.zeros((max_kp, 2), np.float32)
+        resp = np.zeros(max_kp, np.float32)
+        octv = np.zeros(max_kp, np.int32)
+        n = C.c_int()
+        self.ctx.check(self.lib.vo_orb_detect(self.ctx.handle, slot, C.byref(self.orb), _p(xy), _p(resp),
+                                              _p(octv, C.c_int32), max_kp, C.byref(n)))
+        return xy[: n.value].copy(), resp[: n.value].copy(), octv[: n.value].copy()
+
+    def extractORBwithBinning_fast(self, slot):
+        """feature_extractor.cpp:211-318 with flag_nonmax_ (the branch initParams selects, :37): detection and the
+        per-bin arg-max on the device; returns pts_extracted."""
+        pts = np.zeros((self.weight.size + 1, 2), np.float32)
+        m, nd = C.c_int(), C.c_int()
+        self.ctx.check(self.lib.vo_extract_orb_with_binning(
+            self.ctx.handle, slot, C.byref(self.orb), C.c_float(self.inv_u_step_), C.c_float(self.inv_v_step_),
+            self.n_bins_u_, self.n_bins_v_, _p(self.weight, C.c_int32), _p(pts), C.byref(m), C.byref(nd)))
+        self.n_detected = nd.value
+        return pts[: m.value].copy()
 
     def resetWeightBin(self):
         self.weight[:] = 1

@@ -445,6 +445,7 @@ struct BinArgs {
   float *pts_out;
   int32_t *idx_out;
   int *n_out;
+  const int *d_n;         // arg-max: keypoint count on the device (overrides n when set)
 };
 __global__ __launch_bounds__(256) void weight_bin_update_kernel(BinArgs a) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(256) void weight_bin_update_kernel(BinArgs a) {
 // (order-preserving response bits, ~index) selects exactly that one, in any execution order.
 __global__ __launch_bounds__(256) void bucket_key_kernel(BinArgs a) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.n) return;
+  if (i >= (a.d_n ? *a.d_n : a.n)) return;
   const unsigned u = (unsigned)(int)floorf(a.xy[2 * i] * a.inv_u);
   const unsigned v = (unsigned)(int)floorf(a.xy[2 * i + 1] * a.inv_v);
   if (u >= (unsigned)a.n_bins_u || v >= (unsigned)a.n_bins_v) return;
@@ -530,7 +531,7 @@ int vo_weight_bin_update_enqueue(vo_ctx *c, const float *d_pts, int n, int u_ste
 }
 int vo_bucket_argmax_enqueue(vo_ctx *c, const float *d_xy, const float *d_response, int n, float inv_u, float inv_v,
                              int n_bins_u, int n_bins_v, const int32_t *d_weight, unsigned long long *d_key,
-                             float *d_pts_out, int32_t *d_idx_out, int *d_n_out) {
+                             float *d_pts_out, int32_t *d_idx_out, int *d_n_out, const int *d_n) {
   const int total = n_bins_u * n_bins_v;
   VO_CHECK_HIP(c, hipMemsetAsync(d_key, 0, sizeof(unsigned long long) * (size_t)total, c->stream));
   BinArgs a;
@@ -547,6 +548,7 @@ int vo_bucket_argmax_enqueue(vo_ctx *c, const float *d_xy, const float *d_respon
   a.pts_out = d_pts_out;
   a.idx_out = d_idx_out;
   a.n_out = d_n_out;
+  a.d_n = d_n;
   vo_prof_begin(c, VO_K_AUX);
   if (n > 0) hipLaunchKernelGGL(bucket_key_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, a);
   hipLaunchKernelGGL(bucket_emit_kernel, dim3(1), dim3(1024), 0, c->stream, a);

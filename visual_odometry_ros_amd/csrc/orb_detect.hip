@@ -1,0 +1,649 @@
+// orb_detect.hip — keypoint detection of FeatureExtractor::extractORBwithBinning_fast on the device
+// (SURVEY.md §8f #1): `extractor_orb_->detect(img, fts)` (core/visual_odometry/feature_extractor.cpp:241) with
+// the parameters of initParams (:30-57), chained with the bucketing of :244-277 (misc_kernels.hip).
+//
+// cv::ORB is OpenCV 4 features2d and is not in the reference tree; its algorithm is restated from the upstream
+// sources as known to the author (orb.cpp computeKeyPoints / HarrisResponses, fast.cpp FAST_t<16>,
+// fast_score.cpp cornerScore<16>, keypoint.cpp runByImageBorder / retainBest, resize.cpp INTER_LINEAR_EXACT)
+// — see oracle/oracle_orb.c for the statement of what is reproduced and of what could not be verified.
+//
+//   orb_resize_kernel   level l from level l-1, exact fixed-point bilinear (8.8 coefficients from host tables,
+//                       16.16 vertical pass, +0.5 rounding); one lane per destination pixel; 7 dependent launches
+//   orb_score_kernel    every level in one launch (blockIdx.z): FAST-9/16 test and cornerScore per pixel
+//   orb_count_kernel    one wavefront per image row inside the border: non-max suppression (strict 3x3 maximum of
+//                       the score), survivors per row and a 256-bin histogram of their scores per level
+//   orb_plan_kernel     one workgroup per level: row offsets (exclusive scan), the FAST-score cut of
+//                       retainBest(2 n_l) from the histogram
+//   orb_emit_kernel     one wavefront per row: candidates in raster order (ballot compaction at the row offset),
+//                       Harris response (7x7 block of 3x3 derivative sums, integer, as HarrisResponses) for the
+//                       candidates that pass the score cut
+//   orb_select_kernel   one workgroup per level: the response of rank n_l by 4-pass radix select (retainBest(n_l)
+//                       keeps everything >= it)
+//   orb_output_kernel   one workgroup: ordered compaction of all levels -> (x, y) * scale, response, octave
+// Everything is deterministic (integer atomics only for counts and histograms); the keypoint order is level,
+// then raster order — cv's own order after nth_element is unspecified, and the reference depends on it only
+// through exact ties of float responses in the bucketing.
+#include <cmath>
+#include <vector>
+
+#include "vo_internal.hpp"
+#include "vo_kernels.hpp"
+
+#define ORB_MAX_LEVELS 12
+
+struct OrbLevel {
+  const uint8_t *img;  // level image
+  int w, h, stride;
+  uint8_t *score;      // w x h
+  int *row_count;      // h
+  int *row_off;        // h
+  int cand_base;       // first candidate slot of the level
+  int quota;           // n_l
+  float scale;
+};
+struct OrbDev {
+  int n_levels, edge, fast_thr, cand_cap;
+  OrbLevel L[ORB_MAX_LEVELS];
+  int *hist;        // n_levels x 256
+  int *lvl_total;   // n_levels: candidates after NMS + border
+  int *lvl_cut;     // n_levels: FAST score cut
+  unsigned *lvl_rcut;  // n_levels: ordered-uint Harris cut (0 = keep all)
+  short *cx, *cy;   // candidate coordinates
+  uint8_t *cs;      // candidate FAST score
+  float *cr;        // candidate Harris response (valid when score >= cut)
+  float *out_xy, *out_resp;
+  int32_t *out_oct;
+  int *out_n;
+  int max_out;
+  int *flags;       // bit 0: candidate capacity exceeded, bit 1: output capacity exceeded
+};
+
+// ---- pyramid level: resize INTER_LINEAR_EXACT ------------------------------------------------------
+struct OrbResizeArgs {
+  const uint8_t *src;
+  int sw, sh, sstride;
+  uint8_t *dst;
+  int dw, dh;
+  const int *ox, *cx, *oy, *cy;  // per destination column / row: source offset and 8-bit weight of the next sample
+};
+__global__ __launch_bounds__(256) void orb_resize_kernel(OrbResizeArgs a) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= a.dw) return;
+  const int o = a.ox[x], a1 = a.cx[x], a0 = 256 - a1;
+  const int yo = a.oy[y], b1 = a.cy[y], b0 = 256 - b1;
+  const uint8_t *r0 = a.src + (size_t)yo * a.sstride + o, *r1 = r0 + a.sstride;
+  const unsigned h0 = (unsigned)a0 * r0[0] + (unsigned)a1 * r0[1];  // horizontal pass, 8.8
+  const unsigned h1 = (unsigned)a0 * r1[0] + (unsigned)a1 * r1[1];
+  const unsigned v = (unsigned)b0 * h0 + (unsigned)b1 * h1;          // vertical pass, 16.16
+  const unsigned r = (v + 32768u) >> 16;
+  a.dst[(size_t)y * a.dw + x] = (uint8_t)(r > 255u ? 255u : r);
+}
+
+// ---- FAST-9/16 --------------------------------------------------------------------------------------
+// 0 when the pixel is not a corner; else cornerScore<16>: max over the 16 arcs of 9 contiguous circle pixels of
+// min(v - x) and of min(x - v), floored at the threshold, minus 1
+__device__ __forceinline__ int orb_fast_score(const uint8_t *__restrict__ p, int stride, int t) {
+  const int v = p[0];
+  // the four compass points first (fast.cpp's quick reject): 9 contiguous pixels contain at least two of them
+  const int c0 = v - p[3 * stride], c4 = v - p[3], c8 = v - p[-3 * stride], c12 = v - p[-3];
+  const int nd = (c0 > t) + (c4 > t) + (c8 > t) + (c12 > t), nb = (c0 < -t) + (c4 < -t) + (c8 < -t) + (c12 < -t);
+  if (nd < 2 && nb < 2) return 0;
+  int d[16];
+  d[0] = c0;
+  d[1] = v - p[1 + 3 * stride];
+  d[2] = v - p[2 + 2 * stride];
+  d[3] = v - p[3 + stride];
+  d[4] = c4;
+  d[5] = v - p[3 - stride];
+  d[6] = v - p[2 - 2 * stride];
+  d[7] = v - p[1 - 3 * stride];
+  d[8] = c8;
+  d[9] = v - p[-1 - 3 * stride];
+  d[10] = v - p[-2 - 2 * stride];
+  d[11] = v - p[-3 - stride];
+  d[12] = c12;
+  d[13] = v - p[-3 + stride];
+  d[14] = v - p[-2 + 2 * stride];
+  d[15] = v - p[-1 + 3 * stride];
+  // min / max over every arc of 9: windows of 8 (k+1 .. k+8) extended by d[k] or d[k+9]
+  int best_lo = -1000, best_hi = 1000;  // max over arcs of min(d) ; min over arcs of max(d)
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    int mn = d[k], mx = d[k];
+#pragma unroll
+    for (int q = 1; q < 9; ++q) {
+      const int e = d[(k + q) & 15];
+      mn = mn < e ? mn : e;
+      mx = mx > e ? mx : e;
+    }
+    best_lo = best_lo > mn ? best_lo : mn;
+    best_hi = best_hi < mx ? best_hi : mx;
+  }
+  // corner iff some arc is entirely > t (best_lo > t) or entirely < -t (best_hi < -t)
+  if (!(best_lo > t || best_hi < -t)) return 0;
+  int a0 = t;
+  a0 = a0 > best_lo ? a0 : best_lo;
+  int b0 = -a0;
+  b0 = b0 < best_hi ? b0 : best_hi;
+  return -b0 - 1;
+}
+__global__ __launch_bounds__(256) void orb_score_kernel(OrbDev d) {
+  const OrbLevel &L = d.L[blockIdx.z];
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (y >= L.h || x >= L.w) return;
+  int s = 0;
+  if (x >= 3 && x < L.w - 3 && y >= 3 && y < L.h - 3) s = orb_fast_score(L.img + (size_t)y * L.stride + x, L.stride, d.fast_thr);
+  L.score[(size_t)y * L.w + x] = (uint8_t)s;
+}
+
+// strictly greater than the 8 neighbours' scores (FAST_t's non-max suppression); x, y at least 1 from the edge
+__device__ __forceinline__ int orb_is_max(const uint8_t *__restrict__ s, int w, int x, int y) {
+  const uint8_t *p = s + (size_t)y * w + x;
+  const int c = p[0];
+  if (!c) return 0;
+  return c > p[-1] && c > p[1] && c > p[-w - 1] && c > p[-w] && c > p[-w + 1] && c > p[w - 1] && c > p[w] && c > p[w + 1];
+}
+
+// rows inside the border: blockIdx.x = row - edge, blockIdx.z = level
+__global__ __launch_bounds__(64) void orb_count_kernel(OrbDev d) {
+  const OrbLevel &L = d.L[blockIdx.z];
+  const int y = (int)blockIdx.x + d.edge, lane = threadIdx.x;
+  if (L.w <= 2 * d.edge || y >= L.h - d.edge) return;  // runByImageBorder clears everything on a too-small image
+  int cnt = 0;
+  for (int x0 = d.edge; x0 < L.w - d.edge; x0 += 64) {
+    const int x = x0 + lane;
+    const int m = x < L.w - d.edge ? orb_is_max(L.score, L.w, x, y) : 0;
+    if (m) atomicAdd(&d.hist[256 * blockIdx.z + L.score[(size_t)y * L.w + x]], 1);
+    cnt += __popcll(__ballot(m));
+  }
+  if (lane == 0) L.row_count[y] = cnt;
+}
+
+// per level: exclusive scan of the row counts, level total, FAST-score cut of retainBest(2 n_l)
+__global__ __launch_bounds__(256) void orb_plan_kernel(OrbDev d) {
+  __shared__ int s_part[256];
+  __shared__ int s_run;
+  const int l = blockIdx.x, tid = threadIdx.x;
+  const OrbLevel &L = d.L[l];
+  const int y0 = d.edge, y1 = (L.w > 2 * d.edge) ? L.h - d.edge : y0;  // rows [y0, y1)
+  if (tid == 0) s_run = 0;
+  __syncthreads();
+  for (int c0 = y0; c0 < y1; c0 += 256) {
+    const int y = c0 + tid;
+    const int v = y < y1 ? L.row_count[y] : 0;
+    s_part[tid] = v;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {  // inclusive Hillis-Steele scan
+      const int t = tid >= off ? s_part[tid - off] : 0;
+      __syncthreads();
+      s_part[tid] += t;
+      __syncthreads();
+    }
+    const int base = s_run;
+    if (y < y1) L.row_off[y] = base + s_part[tid] - v;
+    __syncthreads();
+    if (tid == 255) s_run = base + s_part[255];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const int total = s_run;
+    d.lvl_total[l] = total;
+    if (total > d.cand_cap) atomicOr(d.flags, 1);
+    // retainBest(2 n_l): nothing dropped unless there are more; else keep everything >= the (2 n_l)-th best score
+    int cut = 0;
+    const int keep = 2 * L.quota;
+    if (total > keep) {
+      if (keep == 0) cut = 256;
+      else {
+        int acc = 0;
+        for (int s = 255; s >= 0; --s) {
+          acc += d.hist[256 * l + s];
+          if (acc >= keep) {
+            cut = s;
+            break;
+          }
+        }
+      }
+    }
+    d.lvl_cut[l] = cut;
+  }
+}
+
+// HarrisResponses (orb.cpp), blockSize 7, k = 0.04
+__device__ __forceinline__ float orb_harris(const uint8_t *__restrict__ img, int stride, int x0, int y0) {
+  int a = 0, b = 0, c = 0;
+  for (int yy = -3; yy <= 3; ++yy) {
+    const uint8_t *p = img + (size_t)(y0 + yy) * stride + (x0 - 3);
+#pragma unroll
+    for (int xx = 0; xx < 7; ++xx, ++p) {
+      const int Ix = ((int)p[1] - (int)p[-1]) * 2 + ((int)p[-stride + 1] - (int)p[-stride - 1]) + ((int)p[stride + 1] - (int)p[stride - 1]);
+      const int Iy = ((int)p[stride] - (int)p[-stride]) * 2 + ((int)p[stride - 1] - (int)p[-stride - 1]) + ((int)p[stride + 1] - (int)p[-stride + 1]);
+      a += Ix * Ix;
+      b += Iy * Iy;
+      c += Ix * Iy;
+    }
+  }
+  const float scale = 1.f / ((1 << 2) * 7 * 255.f);
+  const float scale_sq_sq = scale * scale * scale * scale;
+  return ((float)a * b - (float)c * c - 0.04f * ((float)a + b) * ((float)a + b)) * scale_sq_sq;
+}
+
+__global__ __launch_bounds__(64) void orb_emit_kernel(OrbDev d) {
+  const int l = blockIdx.z;
+  const OrbLevel &L = d.L[l];
+  const int y = (int)blockIdx.x + d.edge, lane = threadIdx.x;
+  if (L.w <= 2 * d.edge || y >= L.h - d.edge) return;
+  if (d.lvl_total[l] > d.cand_cap) return;  // flagged by orb_plan_kernel
+  int off = L.cand_base + L.row_off[y];
+  const int cut = d.lvl_cut[l];
+  for (int x0 = d.edge; x0 < L.w - d.edge; x0 += 64) {
+    const int x = x0 + lane;
+    const int m = x < L.w - d.edge ? orb_is_max(L.score, L.w, x, y) : 0;
+    const unsigned long long bal = __ballot(m);
+    if (m) {
+      const int o = off + __popcll(bal & ((1ull << lane) - 1ull));
+      const int s = L.score[(size_t)y * L.w + x];
+      d.cx[o] = (short)x;
+      d.cy[o] = (short)y;
+      d.cs[o] = (uint8_t)s;
+      d.cr[o] = s >= cut ? orb_harris(L.img, L.stride, x, y) : 0.f;
+    }
+    off += __popcll(bal);
+  }
+}
+
+// float -> unsigned that orders the same way (NaN aside)
+__device__ __forceinline__ unsigned orb_ord(float r) {
+  const unsigned bits = __float_as_uint(r);
+  return (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+}
+// per level: retainBest(n_l) on the Harris response: the ordered key of rank n_l (everything >= it stays)
+__global__ __launch_bounds__(256) void orb_select_kernel(OrbDev d) {
+  __shared__ int s_hist[256];
+  __shared__ unsigned s_prefix;
+  __shared__ int s_rank, s_kept;
+  const int l = blockIdx.x, tid = threadIdx.x;
+  const OrbLevel &L = d.L[l];
+  const int n = d.lvl_total[l] > d.cand_cap ? 0 : d.lvl_total[l], cut = d.lvl_cut[l];
+  // how many candidates passed the score cut
+  if (tid == 0) s_kept = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int i = tid; i < n; i += 256) mine += d.cs[L.cand_base + i] >= cut;
+  atomicAdd(&s_kept, mine);
+  __syncthreads();
+  const int kept = s_kept;
+  if (kept <= L.quota) {  // retainBest leaves the set alone
+    if (tid == 0) d.lvl_rcut[l] = L.quota == 0 && kept > 0 ? 0xFFFFFFFFu : 0u;
+    return;
+  }
+  if (L.quota == 0) {
+    if (tid == 0) d.lvl_rcut[l] = 0xFFFFFFFFu;
+    return;
+  }
+  if (tid == 0) {
+    s_prefix = 0;
+    s_rank = L.quota;  // looking for the key with exactly rank-1 keys above it
+  }
+  __syncthreads();
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    s_hist[tid] = 0;
+    __syncthreads();
+    const unsigned prefix = s_prefix;
+    const unsigned himask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+    for (int i = tid; i < n; i += 256) {
+      if (d.cs[L.cand_base + i] < cut) continue;
+      const unsigned k = orb_ord(d.cr[L.cand_base + i]);
+      if ((k & himask) == (prefix & himask)) atomicAdd(&s_hist[(k >> shift) & 255u], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int rank = s_rank, acc = 0, b = 255;
+      for (; b >= 0; --b) {
+        if (acc + s_hist[b] >= rank) break;
+        acc += s_hist[b];
+      }
+      s_rank = rank - acc;
+      s_prefix = prefix | ((unsigned)b << shift);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) d.lvl_rcut[l] = s_prefix;
+}
+
+// ordered compaction of every level's survivors (one workgroup; level, then raster order)
+__global__ __launch_bounds__(1024) void orb_output_kernel(OrbDev d) {
+  __shared__ int s_wave[16];
+  __shared__ int s_base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int l = 0; l < d.n_levels; ++l) {
+    const OrbLevel &L = d.L[l];
+    const int n = d.lvl_total[l] > d.cand_cap ? 0 : d.lvl_total[l], cut = d.lvl_cut[l];
+    const unsigned rcut = d.lvl_rcut[l];
+    for (int c0 = 0; c0 < n; c0 += 1024) {
+      const int i = c0 + tid;
+      bool keep = false;
+      float r = 0.f;
+      if (i < n) {
+        r = d.cr[L.cand_base + i];
+        keep = d.cs[L.cand_base + i] >= cut && (rcut == 0u || orb_ord(r) >= rcut);
+      }
+      const unsigned long long bal = __ballot(keep);
+      if (lane == 0) s_wave[wave] = __popcll(bal);
+      __syncthreads();
+      int woff = 0;
+      for (int w = 0; w < wave; ++w) woff += s_wave[w];
+      const int base = s_base;
+      if (keep) {
+        const int o = base + woff + __popcll(bal & ((1ull << lane) - 1ull));
+        if (o < d.max_out) {
+          const float x = (float)d.cx[L.cand_base + i], y = (float)d.cy[L.cand_base + i];
+          d.out_xy[2 * o] = l ? x * L.scale : x;  // keypoints[i].pt *= scale for level != firstLevel
+          d.out_xy[2 * o + 1] = l ? y * L.scale : y;
+          d.out_resp[o] = r;
+          d.out_oct[o] = l;
+        }
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int tot = 0;
+        for (int w = 0; w < 16; ++w) tot += s_wave[w];
+        s_base = base + tot;
+      }
+      __syncthreads();
+    }
+  }
+  if (tid == 0) {
+    if (s_base > d.max_out) atomicOr(d.flags, 2);
+    *d.out_n = s_base < d.max_out ? s_base : d.max_out;
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------
+struct vo_orb_state {
+  int w = 0, h = 0, n_levels = 0, nfeatures = 0, edge = 0;
+  double scale_factor = 0;
+  uint8_t *arena = nullptr;
+  size_t cap = 0;
+  // layout for the current configuration
+  int lw[ORB_MAX_LEVELS], lh[ORB_MAX_LEVELS], quota[ORB_MAX_LEVELS];
+  float lscale[ORB_MAX_LEVELS];
+  size_t o_img[ORB_MAX_LEVELS], o_score[ORB_MAX_LEVELS], o_rc[ORB_MAX_LEVELS], o_ro[ORB_MAX_LEVELS];
+  size_t o_tab[ORB_MAX_LEVELS][4];
+  size_t o_hist, o_total, o_cut, o_rcut, o_cx, o_cy, o_cs, o_cr, o_oxy, o_oresp, o_ooct, o_on, o_flags;
+  size_t o_keys, o_bpts, o_bidx, o_bn, o_weight;
+  int cand_cap_level = 0, cand_cap = 0, max_out = 0, max_bins = 0;
+};
+
+void vo_orb_free(vo_ctx *c) {
+  if (c->orb) {
+    if (c->orb->arena) (void)hipFree(c->orb->arena);
+    delete c->orb;
+    c->orb = nullptr;
+  }
+}
+
+// resize.cpp interpolationLinear<uchar>::getCoeffs on softdouble (= IEEE double, one rounding per operation)
+static void orb_linear_exact_coeffs(int src_size, int dst_size, std::vector<int> &ofs, std::vector<int> &c1) {
+  const double scale = (double)src_size / (double)dst_size;
+  ofs.assign(dst_size, 0);
+  c1.assign(dst_size, 0);
+  for (int v = 0; v < dst_size; ++v) {
+    const double fval = scale * ((double)v + 0.5) - 0.5;
+    const int ival = (int)std::floor(fval);
+    if (ival >= 0 && src_size > 1) {
+      if (ival < src_size - 1) {
+        ofs[v] = ival;
+        c1[v] = (int)std::lrint((fval - (double)ival) * 256.0);
+      } else {  // the last source sample with full weight, written so that the kernel never reads past the row
+        ofs[v] = src_size - 2;
+        c1[v] = 256;
+      }
+    }  // else: the first source sample with full weight (ofs 0, c1 0)
+  }
+}
+
+static int orb_prepare(vo_ctx *c, int w, int h, const vo_orb_params *p, int max_bins) {
+  if (!c->orb) c->orb = new vo_orb_state();
+  vo_orb_state *S = c->orb;
+  const bool same = S->arena && S->w == w && S->h == h && S->n_levels == p->n_levels && S->nfeatures == p->nfeatures &&
+                    S->edge == p->edge_threshold && S->scale_factor == p->scale_factor && S->max_bins >= max_bins;
+  if (same) return VO_OK;
+  S->w = w;
+  S->h = h;
+  S->n_levels = p->n_levels;
+  S->nfeatures = p->nfeatures;
+  S->edge = p->edge_threshold;
+  S->scale_factor = p->scale_factor;
+  S->max_bins = max_bins;
+  // ORB_Impl::detectAndCompute level sizes and computeKeyPoints quotas (orb.cpp)
+  for (int l = 0; l < p->n_levels; ++l) {
+    const float s = (float)std::pow(p->scale_factor, (double)l);
+    S->lscale[l] = s;
+    S->lw[l] = (int)std::lrint((double)((float)w / s));
+    S->lh[l] = (int)std::lrint((double)((float)h / s));
+    if (S->lw[l] < 8 || S->lh[l] < 8) VO_FAIL(c, VO_ERR_INVALID, "ORB level %d of a %dx%d image is too small", l, w, h);
+  }
+  {
+    const float factor = (float)(1.0 / p->scale_factor);
+    float nd = p->nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)p->n_levels));
+    int sum = 0;
+    for (int l = 0; l < p->n_levels - 1; ++l) {
+      S->quota[l] = (int)std::lrint((double)nd);
+      sum += S->quota[l];
+      nd *= factor;
+    }
+    S->quota[p->n_levels - 1] = p->nfeatures - sum > 0 ? p->nfeatures - sum : 0;
+  }
+  // arena
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = off;
+    off += (bytes + 255) & ~(size_t)255;
+    return o;
+  };
+  S->cand_cap_level = 65536;
+  S->cand_cap = S->cand_cap_level;
+  S->max_out = p->nfeatures + 4096;  // retainBest keeps ties: a little more than nfeatures can come out
+  for (int l = 0; l < p->n_levels; ++l) {
+    const size_t px = (size_t)S->lw[l] * S->lh[l];
+    S->o_img[l] = l ? take(px) : 0;
+    S->o_score[l] = take(px);
+    S->o_rc[l] = take(sizeof(int) * S->lh[l]);
+    S->o_ro[l] = take(sizeof(int) * S->lh[l]);
+    if (l) {
+      S->o_tab[l][0] = take(sizeof(int) * S->lw[l]);
+      S->o_tab[l][1] = take(sizeof(int) * S->lw[l]);
+      S->o_tab[l][2] = take(sizeof(int) * S->lh[l]);
+      S->o_tab[l][3] = take(sizeof(int) * S->lh[l]);
+    }
+  }
+  const size_t nc = (size_t)S->cand_cap_level * p->n_levels;
+  S->o_hist = take(sizeof(int) * 256 * p->n_levels);
+  S->o_total = take(sizeof(int) * p->n_levels);
+  S->o_cut = take(sizeof(int) * p->n_levels);
+  S->o_rcut = take(sizeof(unsigned) * p->n_levels);
+  S->o_flags = take(sizeof(int) * 4);
+  S->o_cx = take(sizeof(short) * nc);
+  S->o_cy = take(sizeof(short) * nc);
+  S->o_cs = take(nc);
+  S->o_cr = take(sizeof(float) * nc);
+  S->o_oxy = take(sizeof(float) * 2 * S->max_out);
+  S->o_oresp = take(sizeof(float) * S->max_out);
+  S->o_ooct = take(sizeof(int32_t) * S->max_out);
+  S->o_on = take(sizeof(int) * 4);
+  S->o_keys = take(sizeof(unsigned long long) * (size_t)(max_bins + 1));
+  S->o_bpts = take(sizeof(float) * 2 * (size_t)(max_bins + 1));
+  S->o_bidx = take(sizeof(int32_t) * (size_t)(max_bins + 1));
+  S->o_bn = take(sizeof(int) * 4);
+  S->o_weight = take(sizeof(int32_t) * (size_t)(max_bins + 1));
+  if (off > S->cap) {
+    if (S->arena) (void)hipFree(S->arena);
+    S->arena = nullptr;
+    S->cap = 0;
+    VO_CHECK_HIP(c, hipMalloc((void **)&S->arena, off));
+    S->cap = off;
+  }
+  // coefficient tables
+  VO_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+  for (int l = 1; l < p->n_levels; ++l) {
+    std::vector<int> ox, cx, oy, cy;
+    orb_linear_exact_coeffs(S->lw[l - 1], S->lw[l], ox, cx);
+    orb_linear_exact_coeffs(S->lh[l - 1], S->lh[l], oy, cy);
+    VO_CHECK_HIP(c, hipMemcpy(S->arena + S->o_tab[l][0], ox.data(), sizeof(int) * ox.size(), hipMemcpyHostToDevice));
+    VO_CHECK_HIP(c, hipMemcpy(S->arena + S->o_tab[l][1], cx.data(), sizeof(int) * cx.size(), hipMemcpyHostToDevice));
+    VO_CHECK_HIP(c, hipMemcpy(S->arena + S->o_tab[l][2], oy.data(), sizeof(int) * oy.size(), hipMemcpyHostToDevice));
+    VO_CHECK_HIP(c, hipMemcpy(S->arena + S->o_tab[l][3], cy.data(), sizeof(int) * cy.size(), hipMemcpyHostToDevice));
+  }
+  return VO_OK;
+}
+
+// enqueue the detection of the image in `slot`; results stay on the device (S->o_oxy, ...)
+static int orb_enqueue(vo_ctx *c, int slot, const vo_orb_params *p, int max_bins) {
+  if (slot < 0 || slot >= c->cfg.n_slots || c->slots[slot].n_levels <= 0) VO_FAIL(c, VO_ERR_INVALID, "slot holds no image");
+  if (p->n_levels < 1 || p->n_levels > ORB_MAX_LEVELS || p->nfeatures < 0 || p->edge_threshold < 4 ||
+      !(p->scale_factor > 1.0) || p->fast_threshold < 0 || p->fast_threshold > 254)
+    VO_FAIL(c, VO_ERR_INVALID, "ORB parameters out of range (1..%d levels, edge threshold >= 4, scale factor > 1)", ORB_MAX_LEVELS);
+  const vo_pyramid &P = c->slots[slot];
+  if (P.w > 32767 || P.h > 32767) VO_FAIL(c, VO_ERR_CAPACITY, "image too large for 16-bit candidate coordinates");
+  int rc = orb_prepare(c, P.w, P.h, p, max_bins);
+  if (rc) return rc;
+  vo_orb_state *S = c->orb;
+  hipStream_t s = c->stream;
+  uint8_t *A = S->arena;
+  OrbDev d;
+  memset(&d, 0, sizeof(d));
+  d.n_levels = p->n_levels;
+  d.edge = p->edge_threshold;
+  d.fast_thr = p->fast_threshold;
+  d.cand_cap = S->cand_cap_level;
+  for (int l = 0; l < p->n_levels; ++l) {
+    OrbLevel &L = d.L[l];
+    L.img = l ? A + S->o_img[l] : P.lv[0].origin();
+    L.w = S->lw[l];
+    L.h = S->lh[l];
+    L.stride = l ? S->lw[l] : P.lv[0].stride;
+    L.score = A + S->o_score[l];
+    L.row_count = (int *)(A + S->o_rc[l]);
+    L.row_off = (int *)(A + S->o_ro[l]);
+    L.cand_base = l * S->cand_cap_level;
+    L.quota = S->quota[l];
+    L.scale = S->lscale[l];
+  }
+  d.hist = (int *)(A + S->o_hist);
+  d.lvl_total = (int *)(A + S->o_total);
+  d.lvl_cut = (int *)(A + S->o_cut);
+  d.lvl_rcut = (unsigned *)(A + S->o_rcut);
+  d.flags = (int *)(A + S->o_flags);
+  d.cx = (short *)(A + S->o_cx);
+  d.cy = (short *)(A + S->o_cy);
+  d.cs = A + S->o_cs;
+  d.cr = (float *)(A + S->o_cr);
+  d.out_xy = (float *)(A + S->o_oxy);
+  d.out_resp = (float *)(A + S->o_oresp);
+  d.out_oct = (int32_t *)(A + S->o_ooct);
+  d.out_n = (int *)(A + S->o_on);
+  d.max_out = S->max_out;
+  // hist .. flags are contiguous in the arena: one memset
+  VO_CHECK_HIP(c, hipMemsetAsync(A + S->o_hist, 0, S->o_cx - S->o_hist, s));
+  vo_prof_begin(c, VO_K_AUX);
+  for (int l = 1; l < p->n_levels; ++l) {
+    OrbResizeArgs a;
+    a.src = d.L[l - 1].img;
+    a.sw = d.L[l - 1].w;
+    a.sh = d.L[l - 1].h;
+    a.sstride = d.L[l - 1].stride;
+    a.dst = A + S->o_img[l];
+    a.dw = S->lw[l];
+    a.dh = S->lh[l];
+    a.ox = (const int *)(A + S->o_tab[l][0]);
+    a.cx = (const int *)(A + S->o_tab[l][1]);
+    a.oy = (const int *)(A + S->o_tab[l][2]);
+    a.cy = (const int *)(A + S->o_tab[l][3]);
+    hipLaunchKernelGGL(orb_resize_kernel, dim3((a.dw + 255) / 256, a.dh), dim3(256), 0, s, a);
+  }
+  const int rows = P.h - 2 * p->edge_threshold;
+  hipLaunchKernelGGL(orb_score_kernel, dim3((P.w + 255) / 256, P.h, p->n_levels), dim3(256), 0, s, d);
+  if (rows > 0) hipLaunchKernelGGL(orb_count_kernel, dim3(rows, 1, p->n_levels), dim3(64), 0, s, d);
+  hipLaunchKernelGGL(orb_plan_kernel, dim3(p->n_levels), dim3(256), 0, s, d);
+  if (rows > 0) hipLaunchKernelGGL(orb_emit_kernel, dim3(rows, 1, p->n_levels), dim3(64), 0, s, d);
+  hipLaunchKernelGGL(orb_select_kernel, dim3(p->n_levels), dim3(256), 0, s, d);
+  hipLaunchKernelGGL(orb_output_kernel, dim3(1), dim3(1024), 0, s, d);
+  vo_prof_end(c);
+  VO_CHECK_HIP(c, hipGetLastError());
+  return VO_OK;
+}
+
+static int orb_check_flags(vo_ctx *c, int flags) {
+  if (flags & 1) VO_FAIL(c, VO_ERR_CAPACITY, "more than %d FAST corners on one pyramid level", c->orb->cand_cap_level);
+  if (flags & 2) VO_FAIL(c, VO_ERR_CAPACITY, "more keypoints than the output buffer holds");
+  return VO_OK;
+}
+
+extern "C" int vo_orb_detect(vo_ctx *c, int slot, const vo_orb_params *p, float *kp_xy, float *kp_response,
+                             int32_t *kp_octave, int max_kp, int *n_out) {
+  if (!c || !p || !n_out || max_kp < 0) return VO_ERR_INVALID;
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  int rc = orb_enqueue(c, slot, p, 0);
+  if (rc) return rc;
+  vo_orb_state *S = c->orb;
+  int n = 0, flags = 0;
+  VO_CHECK_HIP(c, hipMemcpyAsync(&n, S->arena + S->o_on, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  VO_CHECK_HIP(c, hipMemcpyAsync(&flags, S->arena + S->o_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  VO_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+  rc = orb_check_flags(c, flags);
+  if (rc) return rc;
+  if (n > max_kp) VO_FAIL(c, VO_ERR_CAPACITY, "%d keypoints, the caller's buffers hold %d", n, max_kp);
+  if (n > 0) {
+    if (kp_xy) VO_CHECK_HIP(c, hipMemcpy(kp_xy, S->arena + S->o_oxy, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost));
+    if (kp_response) VO_CHECK_HIP(c, hipMemcpy(kp_response, S->arena + S->o_oresp, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+    if (kp_octave) VO_CHECK_HIP(c, hipMemcpy(kp_octave, S->arena + S->o_ooct, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+  }
+  *n_out = n;
+  return VO_OK;
+}
+
+// test hook: level image `level` of the last detection (tightly packed)
+extern "C" int vo_orb_get_level(vo_ctx *c, int level, uint8_t *host, int *width, int *height) {
+  if (!c || !c->orb || !c->orb->arena || level < 1 || level >= c->orb->n_levels) return VO_ERR_INVALID;
+  vo_orb_state *S = c->orb;
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  VO_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+  if (host) VO_CHECK_HIP(c, hipMemcpy(host, S->arena + S->o_img[level], (size_t)S->lw[level] * S->lh[level], hipMemcpyDeviceToHost));
+  if (width) *width = S->lw[level];
+  if (height) *height = S->lh[level];
+  return VO_OK;
+}
+
+// FeatureExtractor::extractORBwithBinning_fast with flag_nonmax_ (feature_extractor.cpp:211-277): detection and
+// the per-bin arg-max chained on the device; only the bucketed pixels come back
+extern "C" int vo_extract_orb_with_binning(vo_ctx *c, int slot, const vo_orb_params *p, float inv_u_step,
+                                           float inv_v_step, int n_bins_u, int n_bins_v, const int32_t *weight,
+                                           float *pts_out, int *n_out, int *n_detected) {
+  if (!c || !p || !weight || !pts_out || !n_out || n_bins_u <= 0 || n_bins_v <= 0) return VO_ERR_INVALID;
+  const int total = n_bins_u * n_bins_v;
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  int rc = orb_enqueue(c, slot, p, total);
+  if (rc) return rc;
+  vo_orb_state *S = c->orb;
+  uint8_t *A = S->arena;
+  VO_CHECK_HIP(c, hipMemcpyAsync(A + S->o_weight, weight, sizeof(int32_t) * (size_t)total, hipMemcpyHostToDevice, c->stream));
+  rc = vo_bucket_argmax_enqueue(c, (const float *)(A + S->o_oxy), (const float *)(A + S->o_oresp), S->max_out, inv_u_step,
+                                inv_v_step, n_bins_u, n_bins_v, (const int32_t *)(A + S->o_weight),
+                                (unsigned long long *)(A + S->o_keys), (float *)(A + S->o_bpts), (int32_t *)(A + S->o_bidx),
+                                (int *)(A + S->o_bn), (const int *)(A + S->o_on));
+  if (rc < 0) return rc;
+  int m = 0, n = 0, flags = 0;
+  VO_CHECK_HIP(c, hipMemcpyAsync(&m, A + S->o_bn, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  VO_CHECK_HIP(c, hipMemcpyAsync(&n, A + S->o_on, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  VO_CHECK_HIP(c, hipMemcpyAsync(&flags, A + S->o_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  VO_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+  rc = orb_check_flags(c, flags);
+  if (rc) return rc;
+  if (m > 0) VO_CHECK_HIP(c, hipMemcpy(pts_out, A + S->o_bpts, sizeof(float) * 2 * (size_t)m, hipMemcpyDeviceToHost));
+  *n_out = m;
+  if (n_detected) *n_detected = n;
+  return VO_OK;
+}

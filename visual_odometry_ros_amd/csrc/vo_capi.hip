@@ -121,6 +121,7 @@ extern "C" void vo_destroy(vo_ctx *c) {
   vo_frame_free(c);
   vo_rectify_free(c);
   vo_sba_free(c);
+  vo_orb_free(c);
   if (c->prof) {
     for (int i = 0; i < c->prof_cap; ++i) {
       (void)hipEventDestroy(c->prof[i].a);

@@ -80,6 +80,7 @@ struct vo_ctx {
   float *rect_u[2], *rect_v[2];
   int rect_w[2], rect_h[2];
   struct vo_sba_state *sba;  // device arena of the sparse local BA (sba.hip)
+  struct vo_orb_state *orb;  // pyramid, score planes and candidate lists of the keypoint detector (orb_detect.hip)
 };
 
 #define VO_CHECK_HIP(ctx, expr)                                                            \

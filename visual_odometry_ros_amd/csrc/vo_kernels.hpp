@@ -44,6 +44,9 @@ void vo_rectify_free(vo_ctx *c);
 // sba.hip
 void vo_sba_free(vo_ctx *c);
 
+// orb_detect.hip
+void vo_orb_free(vo_ctx *c);
+
 // klt_track.hip
 int vo_klt_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, const float *d_pts1_init,
                    float *d_pts1, int n_max,
@@ -134,7 +137,7 @@ int vo_weight_bin_update_enqueue(vo_ctx *c, const float *d_pts, int n, int u_ste
                                  int n_bins_v, int32_t *d_weight);
 int vo_bucket_argmax_enqueue(vo_ctx *c, const float *d_xy, const float *d_response, int n, float inv_u, float inv_v,
                              int n_bins_u, int n_bins_v, const int32_t *d_weight, unsigned long long *d_key,
-                             float *d_pts_out, int32_t *d_idx_out, int *d_n_out);
+                             float *d_pts_out, int32_t *d_idx_out, int *d_n_out, const int *d_n = nullptr);
 
 // frame_pipeline.hip
 void vo_frame_free(vo_ctx *c);
