@@ -11,15 +11,13 @@
 //                       16.16 vertical pass, +0.5 rounding); one lane per destination pixel; 7 dependent launches
 //   orb_score_kernel    every level in one launch (blockIdx.z): FAST-9/16 test and cornerScore per pixel
 //   orb_count_kernel    one wavefront per image row inside the border: non-max suppression (strict 3x3 maximum of
-//                       the score), survivors per row and a 256-bin histogram of their scores per level
-//   orb_plan_kernel     one workgroup per level: row offsets (exclusive scan), the FAST-score cut of
-//                       retainBest(2 n_l) from the histogram
-//   orb_emit_kernel     one wavefront per row: candidates in raster order (ballot compaction at the row offset),
-//                       Harris response (7x7 block of 3x3 derivative sums, integer, as HarrisResponses) for the
-//                       candidates that pass the score cut
-//   orb_select_kernel   one workgroup per level: the response of rank n_l by 4-pass radix select (retainBest(n_l)
-//                       keeps everything >= it)
-//   orb_output_kernel   one workgroup: ordered compaction of all levels -> (x, y) * scale, response, octave
+//                       the score), survivors per row
+//   orb_plan_kernel     one workgroup per level: row offsets (exclusive scan)
+//   orb_emit_kernel     one wavefront per row: candidates in raster order (ballot compaction at the row offset)
+//   orb_harris_kernel   one lane per candidate: 7x7 block of 3x3 derivative sums, integer, as HarrisResponses
+//   orb_select_kernel   one workgroup per level: FAST-score cut of retainBest(2 n_l) from an LDS histogram, then the
+//                       response of rank n_l by 4-pass radix select (retainBest(n_l) keeps everything >= it)
+//   orb_output_kernel   one workgroup per level: ordered compaction -> (x, y) * scale, response, octave
 // Everything is deterministic (integer atomics only for counts and histograms); the keypoint order is level,
 // then raster order — cv's own order after nth_element is unspecified, and the reference depends on it only
 // through exact ties of float responses in the bucketing.
@@ -153,17 +151,16 @@ __global__ __launch_bounds__(64) void orb_count_kernel(OrbDev d) {
   for (int x0 = d.edge; x0 < L.w - d.edge; x0 += 64) {
     const int x = x0 + lane;
     const int m = x < L.w - d.edge ? orb_is_max(L.score, L.w, x, y) : 0;
-    if (m) atomicAdd(&d.hist[256 * blockIdx.z + L.score[(size_t)y * L.w + x]], 1);
     cnt += __popcll(__ballot(m));
   }
   if (lane == 0) L.row_count[y] = cnt;
 }
 
-// per level: exclusive scan of the row counts, level total, FAST-score cut of retainBest(2 n_l)
+// per level: exclusive scan of the row counts, level total
 __global__ __launch_bounds__(256) void orb_plan_kernel(OrbDev d) {
-  __shared__ int s_part[256];
+  __shared__ int s_wsum[4];
   __shared__ int s_run;
-  const int l = blockIdx.x, tid = threadIdx.x;
+  const int l = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const OrbLevel &L = d.L[l];
   const int y0 = d.edge, y1 = (L.w > 2 * d.edge) ? L.h - d.edge : y0;  // rows [y0, y1)
   if (tid == 0) s_run = 0;
@@ -171,58 +168,49 @@ __global__ __launch_bounds__(256) void orb_plan_kernel(OrbDev d) {
   for (int c0 = y0; c0 < y1; c0 += 256) {
     const int y = c0 + tid;
     const int v = y < y1 ? L.row_count[y] : 0;
-    s_part[tid] = v;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {  // inclusive Hillis-Steele scan
-      const int t = tid >= off ? s_part[tid - off] : 0;
-      __syncthreads();
-      s_part[tid] += t;
-      __syncthreads();
+    int inc = v;  // inclusive scan within the wavefront
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(inc, off);
+      if (lane >= off) inc += t;
     }
-    const int base = s_run;
-    if (y < y1) L.row_off[y] = base + s_part[tid] - v;
+    if (lane == 63) s_wsum[wave] = inc;
     __syncthreads();
-    if (tid == 255) s_run = base + s_part[255];
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += s_wsum[w];
+    const int base = s_run;
+    if (y < y1) L.row_off[y] = base + woff + inc - v;
+    __syncthreads();
+    if (tid == 255) s_run = base + woff + inc;
     __syncthreads();
   }
   if (tid == 0) {
-    const int total = s_run;
-    d.lvl_total[l] = total;
-    if (total > d.cand_cap) atomicOr(d.flags, 1);
-    // retainBest(2 n_l): nothing dropped unless there are more; else keep everything >= the (2 n_l)-th best score
-    int cut = 0;
-    const int keep = 2 * L.quota;
-    if (total > keep) {
-      if (keep == 0) cut = 256;
-      else {
-        int acc = 0;
-        for (int s = 255; s >= 0; --s) {
-          acc += d.hist[256 * l + s];
-          if (acc >= keep) {
-            cut = s;
-            break;
-          }
-        }
-      }
-    }
-    d.lvl_cut[l] = cut;
+    d.lvl_total[l] = s_run;
+    if (s_run > d.cand_cap) atomicOr(d.flags, 1);
   }
 }
 
-// HarrisResponses (orb.cpp), blockSize 7, k = 0.04
+// HarrisResponses (orb.cpp), blockSize 7, k = 0.04. The 9x9 neighbourhood is read once (81 byte loads instead of
+// 8 per tap); the sums are integers, so the order does not matter.
 __device__ __forceinline__ float orb_harris(const uint8_t *__restrict__ img, int stride, int x0, int y0) {
-  int a = 0, b = 0, c = 0;
-  for (int yy = -3; yy <= 3; ++yy) {
-    const uint8_t *p = img + (size_t)(y0 + yy) * stride + (x0 - 3);
+  int px[9][9];
 #pragma unroll
-    for (int xx = 0; xx < 7; ++xx, ++p) {
-      const int Ix = ((int)p[1] - (int)p[-1]) * 2 + ((int)p[-stride + 1] - (int)p[-stride - 1]) + ((int)p[stride + 1] - (int)p[stride - 1]);
-      const int Iy = ((int)p[stride] - (int)p[-stride]) * 2 + ((int)p[stride - 1] - (int)p[-stride - 1]) + ((int)p[stride + 1] - (int)p[-stride + 1]);
+  for (int r = 0; r < 9; ++r) {
+    const uint8_t *p = img + (size_t)(y0 - 4 + r) * stride + (x0 - 4);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) px[r][q] = p[q];
+  }
+  int a = 0, b = 0, c = 0;
+#pragma unroll
+  for (int r = 1; r < 8; ++r)
+#pragma unroll
+    for (int q = 1; q < 8; ++q) {
+      const int Ix = (px[r][q + 1] - px[r][q - 1]) * 2 + (px[r - 1][q + 1] - px[r - 1][q - 1]) + (px[r + 1][q + 1] - px[r + 1][q - 1]);
+      const int Iy = (px[r + 1][q] - px[r - 1][q]) * 2 + (px[r + 1][q - 1] - px[r - 1][q - 1]) + (px[r + 1][q + 1] - px[r - 1][q + 1]);
       a += Ix * Ix;
       b += Iy * Iy;
       c += Ix * Iy;
     }
-  }
   const float scale = 1.f / ((1 << 2) * 7 * 255.f);
   const float scale_sq_sq = scale * scale * scale * scale;
   return ((float)a * b - (float)c * c - 0.04f * ((float)a + b) * ((float)a + b)) * scale_sq_sq;
@@ -235,7 +223,6 @@ __global__ __launch_bounds__(64) void orb_emit_kernel(OrbDev d) {
   if (L.w <= 2 * d.edge || y >= L.h - d.edge) return;
   if (d.lvl_total[l] > d.cand_cap) return;  // flagged by orb_plan_kernel
   int off = L.cand_base + L.row_off[y];
-  const int cut = d.lvl_cut[l];
   for (int x0 = d.edge; x0 < L.w - d.edge; x0 += 64) {
     const int x = x0 + lane;
     const int m = x < L.w - d.edge ? orb_is_max(L.score, L.w, x, y) : 0;
@@ -246,10 +233,20 @@ __global__ __launch_bounds__(64) void orb_emit_kernel(OrbDev d) {
       d.cx[o] = (short)x;
       d.cy[o] = (short)y;
       d.cs[o] = (uint8_t)s;
-      d.cr[o] = s >= cut ? orb_harris(L.img, L.stride, x, y) : 0.f;
     }
     off += __popcll(bal);
   }
+}
+
+// Harris response of every candidate: one lane each (the candidate lists are dense, the corners are not)
+__global__ __launch_bounds__(256) void orb_harris_kernel(OrbDev d) {
+  const int l = blockIdx.y;
+  const OrbLevel &L = d.L[l];
+  const int n = d.lvl_total[l] > d.cand_cap ? 0 : d.lvl_total[l];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int o = L.cand_base + i;
+  d.cr[o] = orb_harris(L.img, L.stride, d.cx[o], d.cy[o]);
 }
 
 // float -> unsigned that orders the same way (NaN aside)
@@ -257,107 +254,149 @@ __device__ __forceinline__ unsigned orb_ord(float r) {
   const unsigned bits = __float_as_uint(r);
   return (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
 }
-// per level: retainBest(n_l) on the Harris response: the ordered key of rank n_l (everything >= it stays)
-__global__ __launch_bounds__(256) void orb_select_kernel(OrbDev d) {
+// rank-th largest bin of a 256-bin histogram in LDS: returns the bin, *above = entries in higher bins
+__device__ __forceinline__ int orb_hist_rank(const int *hist, int rank, int *above) {
+  int acc = 0, b = 255;
+  for (; b > 0; --b) {
+    if (acc + hist[b] >= rank) break;
+    acc += hist[b];
+  }
+  *above = acc;
+  return b;
+}
+// per level: the two retainBest cuts. (1) FAST score: nothing is dropped unless there are more than 2 n_l
+// candidates, else everything >= the score of rank 2 n_l stays; (2) Harris response among those: everything >= the
+// response of rank n_l (4-pass radix select on the ordered key). Also the number of survivors.
+#define ORB_ST 1024
+__global__ __launch_bounds__(ORB_ST) void orb_select_kernel(OrbDev d) {
   __shared__ int s_hist[256];
   __shared__ unsigned s_prefix;
-  __shared__ int s_rank, s_kept;
+  __shared__ int s_rank, s_cut, s_kept, s_surv;
   const int l = blockIdx.x, tid = threadIdx.x;
   const OrbLevel &L = d.L[l];
-  const int n = d.lvl_total[l] > d.cand_cap ? 0 : d.lvl_total[l], cut = d.lvl_cut[l];
-  // how many candidates passed the score cut
-  if (tid == 0) s_kept = 0;
+  const int n = d.lvl_total[l] > d.cand_cap ? 0 : d.lvl_total[l];
+  const uint8_t *cs = d.cs + L.cand_base;
+  const float *cr = d.cr + L.cand_base;
+  if (tid < 256) s_hist[tid] = 0;
+  if (tid == 0) s_surv = 0;
   __syncthreads();
-  int mine = 0;
-  for (int i = tid; i < n; i += 256) mine += d.cs[L.cand_base + i] >= cut;
-  atomicAdd(&s_kept, mine);
+  #pragma unroll 4
+  for (int i = tid; i < n; i += ORB_ST) atomicAdd(&s_hist[cs[i]], 1);
   __syncthreads();
-  const int kept = s_kept;
-  if (kept <= L.quota) {  // retainBest leaves the set alone
-    if (tid == 0) d.lvl_rcut[l] = L.quota == 0 && kept > 0 ? 0xFFFFFFFFu : 0u;
-    return;
-  }
-  if (L.quota == 0) {
-    if (tid == 0) d.lvl_rcut[l] = 0xFFFFFFFFu;
-    return;
-  }
   if (tid == 0) {
-    s_prefix = 0;
-    s_rank = L.quota;  // looking for the key with exactly rank-1 keys above it
+    int cut = 0, kept = n;
+    const int keep = 2 * L.quota;
+    if (n > keep) {
+      if (keep == 0) {
+        cut = 256;
+        kept = 0;
+      } else {
+        int above;
+        cut = orb_hist_rank(s_hist, keep, &above);
+        kept = above + s_hist[cut];
+      }
+    }
+    s_cut = cut;
+    s_kept = kept;
+    d.lvl_cut[l] = cut;
   }
   __syncthreads();
-  for (int shift = 24; shift >= 0; shift -= 8) {
-    s_hist[tid] = 0;
-    __syncthreads();
-    const unsigned prefix = s_prefix;
-    const unsigned himask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
-    for (int i = tid; i < n; i += 256) {
-      if (d.cs[L.cand_base + i] < cut) continue;
-      const unsigned k = orb_ord(d.cr[L.cand_base + i]);
-      if ((k & himask) == (prefix & himask)) atomicAdd(&s_hist[(k >> shift) & 255u], 1);
-    }
-    __syncthreads();
-    if (tid == 0) {
-      int rank = s_rank, acc = 0, b = 255;
-      for (; b >= 0; --b) {
-        if (acc + s_hist[b] >= rank) break;
-        acc += s_hist[b];
+  const int cut = s_cut, kept = s_kept;
+  unsigned rcut = 0u;  // 0 = retainBest leaves the set alone
+  if (kept > L.quota) {
+    if (L.quota == 0) {
+      rcut = 0xFFFFFFFFu;
+    } else {
+      if (tid == 0) {
+        s_prefix = 0;
+        s_rank = L.quota;
       }
-      s_rank = rank - acc;
-      s_prefix = prefix | ((unsigned)b << shift);
+      __syncthreads();
+      for (int shift = 24; shift >= 0; shift -= 8) {
+        if (tid < 256) s_hist[tid] = 0;
+        __syncthreads();
+        const unsigned prefix = s_prefix;
+        const unsigned himask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+#pragma unroll 4
+        for (int i = tid; i < n; i += ORB_ST) {
+          if (cs[i] < cut) continue;
+          const unsigned k = orb_ord(cr[i]);
+          if ((k & himask) == (prefix & himask)) atomicAdd(&s_hist[(k >> shift) & 255u], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+          int above;
+          const int b = orb_hist_rank(s_hist, s_rank, &above);
+          s_rank -= above;
+          s_prefix = prefix | ((unsigned)b << shift);
+        }
+        __syncthreads();
+      }
+      rcut = s_prefix;
     }
-    __syncthreads();
   }
-  if (tid == 0) d.lvl_rcut[l] = s_prefix;
+  int mine = 0;
+#pragma unroll 4
+  for (int i = tid; i < n; i += ORB_ST) mine += cs[i] >= cut && (rcut == 0u || orb_ord(cr[i]) >= rcut);
+  atomicAdd(&s_surv, mine);
+  __syncthreads();
+  if (tid == 0) {
+    d.lvl_rcut[l] = rcut;
+    d.hist[l] = s_surv;  // survivors of the level (the output kernel's offsets)
+  }
 }
 
-// ordered compaction of every level's survivors (one workgroup; level, then raster order)
+// ordered compaction of every level's survivors (one workgroup per level; level, then raster order)
 __global__ __launch_bounds__(1024) void orb_output_kernel(OrbDev d) {
   __shared__ int s_wave[16];
   __shared__ int s_base;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) s_base = 0;
-  __syncthreads();
-  for (int l = 0; l < d.n_levels; ++l) {
-    const OrbLevel &L = d.L[l];
-    const int n = d.lvl_total[l] > d.cand_cap ? 0 : d.lvl_total[l], cut = d.lvl_cut[l];
-    const unsigned rcut = d.lvl_rcut[l];
-    for (int c0 = 0; c0 < n; c0 += 1024) {
-      const int i = c0 + tid;
-      bool keep = false;
-      float r = 0.f;
-      if (i < n) {
-        r = d.cr[L.cand_base + i];
-        keep = d.cs[L.cand_base + i] >= cut && (rcut == 0u || orb_ord(r) >= rcut);
-      }
-      const unsigned long long bal = __ballot(keep);
-      if (lane == 0) s_wave[wave] = __popcll(bal);
-      __syncthreads();
-      int woff = 0;
-      for (int w = 0; w < wave; ++w) woff += s_wave[w];
-      const int base = s_base;
-      if (keep) {
-        const int o = base + woff + __popcll(bal & ((1ull << lane) - 1ull));
-        if (o < d.max_out) {
-          const float x = (float)d.cx[L.cand_base + i], y = (float)d.cy[L.cand_base + i];
-          d.out_xy[2 * o] = l ? x * L.scale : x;  // keypoints[i].pt *= scale for level != firstLevel
-          d.out_xy[2 * o + 1] = l ? y * L.scale : y;
-          d.out_resp[o] = r;
-          d.out_oct[o] = l;
-        }
-      }
-      __syncthreads();
-      if (tid == 0) {
-        int tot = 0;
-        for (int w = 0; w < 16; ++w) tot += s_wave[w];
-        s_base = base + tot;
-      }
-      __syncthreads();
+  const int l = blockIdx.x;
+  const OrbLevel &L = d.L[l];
+  if (tid == 0) {
+    int base = 0;
+    for (int q = 0; q < l; ++q) base += d.hist[q];
+    s_base = base;
+    if (l == d.n_levels - 1) {
+      const int total = base + d.hist[l];
+      if (total > d.max_out) atomicOr(d.flags, 2);
+      *d.out_n = total < d.max_out ? total : d.max_out;
     }
   }
-  if (tid == 0) {
-    if (s_base > d.max_out) atomicOr(d.flags, 2);
-    *d.out_n = s_base < d.max_out ? s_base : d.max_out;
+  __syncthreads();
+  const int n = d.lvl_total[l] > d.cand_cap ? 0 : d.lvl_total[l], cut = d.lvl_cut[l];
+  const unsigned rcut = d.lvl_rcut[l];
+  for (int c0 = 0; c0 < n; c0 += 1024) {
+    const int i = c0 + tid;
+    bool keep = false;
+    float r = 0.f;
+    if (i < n) {
+      r = d.cr[L.cand_base + i];
+      keep = d.cs[L.cand_base + i] >= cut && (rcut == 0u || orb_ord(r) >= rcut);
+    }
+    const unsigned long long bal = __ballot(keep);
+    if (lane == 0) s_wave[wave] = __popcll(bal);
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += s_wave[w];
+    const int base = s_base;
+    if (keep) {
+      const int o = base + woff + __popcll(bal & ((1ull << lane) - 1ull));
+      if (o < d.max_out) {
+        const float x = (float)d.cx[L.cand_base + i], y = (float)d.cy[L.cand_base + i];
+        d.out_xy[2 * o] = l ? x * L.scale : x;  // keypoints[i].pt *= scale for level != firstLevel
+        d.out_xy[2 * o + 1] = l ? y * L.scale : y;
+        d.out_resp[o] = r;
+        d.out_oct[o] = l;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int tot = 0;
+      for (int w = 0; w < 16; ++w) tot += s_wave[w];
+      s_base = base + tot;
+    }
+    __syncthreads();
   }
 }
 
@@ -374,7 +413,7 @@ struct vo_orb_state {
   size_t o_tab[ORB_MAX_LEVELS][4];
   size_t o_hist, o_total, o_cut, o_rcut, o_cx, o_cy, o_cs, o_cr, o_oxy, o_oresp, o_ooct, o_on, o_flags;
   size_t o_keys, o_bpts, o_bidx, o_bn, o_weight;
-  int cand_cap_level = 0, cand_cap = 0, max_out = 0, max_bins = 0;
+  int cand_cap_level = 0, cand_cap = 0, max_out = 0, max_bins = 0, harris_blocks = 0;
 };
 
 void vo_orb_free(vo_ctx *c) {
@@ -444,8 +483,10 @@ static int orb_prepare(vo_ctx *c, int w, int h, const vo_orb_params *p, int max_
     off += (bytes + 255) & ~(size_t)255;
     return o;
   };
-  S->cand_cap_level = 65536;
+  S->cand_cap_level = (w * (size_t)h / 16 > 65536) ? (int)(w * (size_t)h / 16) : 65536;  // NMS corners are far sparser
   S->cand_cap = S->cand_cap_level;
+  // the Harris launch covers the candidates a level can realistically hold; beyond that the tail of its grid idles
+  S->harris_blocks = S->cand_cap_level;
   S->max_out = p->nfeatures + 4096;  // retainBest keeps ties: a little more than nfeatures can come out
   for (int l = 0; l < p->n_levels; ++l) {
     const size_t px = (size_t)S->lw[l] * S->lh[l];
@@ -569,8 +610,9 @@ static int orb_enqueue(vo_ctx *c, int slot, const vo_orb_params *p, int max_bins
   if (rows > 0) hipLaunchKernelGGL(orb_count_kernel, dim3(rows, 1, p->n_levels), dim3(64), 0, s, d);
   hipLaunchKernelGGL(orb_plan_kernel, dim3(p->n_levels), dim3(256), 0, s, d);
   if (rows > 0) hipLaunchKernelGGL(orb_emit_kernel, dim3(rows, 1, p->n_levels), dim3(64), 0, s, d);
-  hipLaunchKernelGGL(orb_select_kernel, dim3(p->n_levels), dim3(256), 0, s, d);
-  hipLaunchKernelGGL(orb_output_kernel, dim3(1), dim3(1024), 0, s, d);
+  hipLaunchKernelGGL(orb_harris_kernel, dim3((S->harris_blocks + 255) / 256, p->n_levels), dim3(256), 0, s, d);
+  hipLaunchKernelGGL(orb_select_kernel, dim3(p->n_levels), dim3(ORB_ST), 0, s, d);
+  hipLaunchKernelGGL(orb_output_kernel, dim3(p->n_levels), dim3(1024), 0, s, d);
   vo_prof_end(c);
   VO_CHECK_HIP(c, hipGetLastError());
   return VO_OK;
