@@ -162,6 +162,15 @@ def test_cpp_frame_pipelines_match_python_api(vo, tmp_path):
         assert np.array_equal(take(np.float32, 16).reshape(4, 4), sc.getRectifiedStereoPoseLeft2Right())
         assert np.array_equal(take(np.uint8, W * H).reshape(H, W), c.get_level(0, 0))
         assert np.array_equal(take(np.uint8, W * H).reshape(H, W), c.get_level(1, 0))
+        # ---- FeatureExtractor::extractORBwithBinning_fast (feature_extractor.h) against the Python mirror
+        fe = vo.FeatureExtractor(c)
+        fe.initParams(W, H, 16, 8, THRES_FAST=15)
+        fe.suppressCenterBins()
+        c.set_image(0, L1)
+        pts_p = fe.extractORBwithBinning_fast(0)
+        npts = int(take(np.int32, 1)[0])
+        assert npts == pts_p.shape[0] and npts > 40
+        assert np.array_equal(take(np.float32, 2 * npts).reshape(-1, 2), pts_p)
         # ---- SparseBundleAdjustmentSolver (sparse_bundle_adjustment.h) against the Python mirror
         from visual_odometry_ros_amd.api import SparseBundleAdjustmentSolver
         sol = SparseBundleAdjustmentSolver(c, False)

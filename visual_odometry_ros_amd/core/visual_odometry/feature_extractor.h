@@ -35,6 +35,32 @@ class FeatureExtractor {
     inv_v_step_ = 1.0f / (float)v_step_;
     weight_.assign((size_t)n_bins_u * n_bins_v, 1);
   }
+  // extractor_orb_ settings of initParams (:48-56); THRES_FAST of the call above
+  void setOrbParams(int fast_threshold, int nfeatures = 10000, double scale_factor = 1.2, int n_levels = 8,
+                    int edge_threshold = 31) {
+    orb_ = vo_orb_params{nfeatures, scale_factor, n_levels, edge_threshold, fast_threshold};
+  }
+  // extractor_orb_->detect(img, fts) (:241) on the image in `slot`
+  void detect(int slot, PixelVec &kp, std::vector<float> &response, std::vector<std::int32_t> &octave,
+              int max_kp = 60000) {
+    kp.assign((size_t)max_kp, Pixel{0.f, 0.f});
+    response.assign((size_t)max_kp, 0.f);
+    octave.assign((size_t)max_kp, 0);
+    int n = 0;
+    ctx_->check(vo_orb_detect(ctx_->get(), slot, &orb_, &kp.data()->x, response.data(), octave.data(), max_kp, &n));
+    kp.resize((size_t)n);
+    response.resize((size_t)n);
+    octave.resize((size_t)n);
+  }
+  // extractORBwithBinning_fast (:211-318) with flag_nonmax_ (set by initParams, :37): detection and the per-bin
+  // arg-max chained on the device. The image is the one held by `slot`.
+  void extractORBwithBinning_fast(int slot, PixelVec &pts_extracted) {
+    pts_extracted.assign(weight_.size() + 1, Pixel{0.f, 0.f});
+    int m = 0;
+    ctx_->check(vo_extract_orb_with_binning(ctx_->get(), slot, &orb_, inv_u_step_, inv_v_step_, n_bins_u_, n_bins_v_,
+                                            weight_.data(), &pts_extracted.data()->x, &m, nullptr));
+    pts_extracted.resize((size_t)m);
+  }
   void resetWeightBin() { std::fill(weight_.begin(), weight_.end(), 1); }  // :71-74
   void suppressCenterBins() {                                              // :76-92
     const int u_cent = (int)(n_bins_u_ * 0.5), v_cent = (int)(n_bins_v_ * 0.5);
@@ -72,6 +98,7 @@ class FeatureExtractor {
   int n_bins_u_ = 0, n_bins_v_ = 0, u_step_ = 1, v_step_ = 1;
   float inv_u_step_ = 1.f, inv_v_step_ = 1.f;
   std::vector<std::int32_t> weight_;
+  vo_orb_params orb_{10000, 1.2, 8, 31, 15};
   float zero_[2] = {0.f, 0.f};
 };
 
