@@ -1,0 +1,111 @@
+"""A closed-loop stereo VO on the synthetic stream, written the way StereoVO::trackStereoImages
+(core/visual_odometry/stereo_vo/stereo_vo.cpp:392-989) is organised — every numeric step is an operator of
+libvo_hip.so, the landmark bookkeeping in between is a few numpy arrays on the host:
+
+  first frame   detect + bucket (extractORBwithBinning_fast), trackBidirection left -> right,
+                triangulate from the disparity                                   (stereo_vo.cpp:212-330)
+  every frame   [3]-[7] prior, KLT l0->l1, patch refinement, KLT l1->r1, stereo pose-only BA: ONE call
+                (StereoFramePipeline)                                            (:483-668)
+                [8] survivors = BA inliers; their 3-D points re-triangulated in the new camera frame
+                [9] updateWeightBin(survivors), extractORBwithBinning_fast       (:691-693)
+                [10] trackBidirection l1 -> r1 of the candidates, new landmarks  (:708-760)
+Keyframes, local BA and the landmark graph of the reference are not modelled: this is the odometry
+front end only. It exists to show that the operators compose into a working odometry (trajectory against
+the renderer's ground truth), not as a benchmark.
+
+usage: python examples/closed_loop_stereo.py [--frames 30]"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def triangulate(pl, pr, K, baseline):
+    """Rectified pair: depth from the horizontal disparity, point in the left camera frame."""
+    fx, fy, cx, cy = K
+    d = pl[:, 0] - pr[:, 0]
+    ok = d > 0.5
+    z = fx * baseline / np.where(ok, d, 1.0)
+    X = np.stack([(pl[:, 0] - cx) / fx * z, (pl[:, 1] - cy) / fy * z, z], 1).astype(np.float32)
+    return X, ok & (z < 80.0)
+
+
+def run(n_frames=30, seed=2, n_bins=(40, 16), thres_fast=15, verbose=False):
+    import visual_odometry_ros_amd as V
+    from visual_odometry_ros_amd import synthetic as S
+    from visual_odometry_ros_amd.api import StereoFramePipeline, make_stereo_params
+    V.load()
+    stream = S.StereoStream(seed=seed)
+    W, H, K, b = stream.width, stream.height, stream.K, stream.baseline
+    win, lvl, thr_err, thr_bidir, thr_ba = 21, 6, 80.0, 0.5, 3.0  # config/stereo/kitti_00_stereo.yaml:55-59,74
+    poses = stream.poses(n_frames)
+    ctx = V.Context(device=0, max_width=W, max_height=H, max_points=4096, n_slots=3, max_level=lvl)
+    ft, fe = V.FeatureTracker(ctx), V.FeatureExtractor(ctx)
+    fe.initParams(W, H, n_bins[0], n_bins[1], THRES_FAST=thres_fast)
+    pipe = StereoFramePipeline(ctx, make_stereo_params(W, H, win, lvl, thr_err, thr_bidir, thr_ba, K, K, stream.T_lr),
+                               strict_border=True)
+    P, CL, CR = 0, 1, 2  # slots: previous left, current left, current right
+
+    def new_landmarks(slot_l, slot_r, tracked_pts):
+        """steps [9] + [10]: bucketed detections in bins without a tracked point, stereo-matched, triangulated"""
+        fe.updateWeightBin(tracked_pts)
+        cand = fe.extractORBwithBinning_fast(slot_l)
+        if cand.shape[0] == 0:
+            return np.zeros((0, 2), np.float32), np.zeros((0, 2), np.float32), np.zeros((0, 3), np.float32)
+        pr, m = ft.trackBidirection(slot_l, slot_r, cand, win, lvl, thr_err, thr_bidir)
+        X, ok = triangulate(cand, pr, K, b)
+        keep = m & ok & (np.abs(cand[:, 1] - pr[:, 1]) < 2.0)
+        return cand[keep], pr[keep], X[keep]
+
+    L, R, _ = stream.render_pair(poses[0])
+    ctx.set_image(CL, L)
+    ctx.set_image(CR, R)
+    pts_l, pts_r, X = new_landmarks(CL, CR, np.zeros((0, 2), np.float32))
+    T_wc = [poses[0].copy()]
+    dT_prev = np.eye(4, dtype=np.float32)
+    log = []
+    for k in range(1, n_frames):
+        L, R, _ = stream.render_pair(poses[k])
+        ctx.swap_slots(P, CL)  # the current left image becomes the previous one, its pyramid stays on the device
+        ctx.set_image(CL, L)
+        ctx.set_image(CR, R)
+        pipe.enqueue(pts_l, pts_r, X, dT_prev, np.zeros((0, 2), np.float32), slots=(P, CL, CR))
+        r = pipe.result()
+        dT = r["dT"].astype(np.float64)
+        T_wc.append(T_wc[-1] @ dT)
+        inl = r["stage"] >= 4
+        pl1, pr1 = r["pts_l1"][inl], r["pts_r1"][inl]
+        Xc, ok = triangulate(pl1, pr1, K, b)  # [8]: the survivors' points in the new camera frame
+        pl1, pr1, Xc = pl1[ok], pr1[ok], Xc[ok]
+        nl, nr, nX = new_landmarks(CL, CR, pl1)
+        log.append(dict(frame=k, tracked=int(pts_l.shape[0]), inliers=int(inl.sum()), new=int(nl.shape[0]),
+                        gn_iterations=int(r["counts"].gn_iterations)))
+        if verbose:
+            print(log[-1])
+        pts_l, pts_r, X = np.concatenate([pl1, nl]), np.concatenate([pr1, nr]), np.concatenate([Xc, nX])
+        dT_prev = r["dT"].astype(np.float32)  # constant-velocity prior (stereo_vo.cpp:465-480)
+    ctx.close()
+    # trajectory error against the renderer's ground truth
+    est = np.stack([T[:3, 3] for T in T_wc])
+    gt = np.stack([T[:3, 3] for T in poses[:n_frames]])
+    path = np.sum(np.linalg.norm(np.diff(gt, axis=0), axis=1))
+    rel = [np.linalg.norm(np.linalg.inv(np.linalg.inv(poses[i - 1]) @ poses[i]) @ (np.linalg.inv(T_wc[i - 1]) @ T_wc[i]) - np.eye(4))
+           for i in range(1, n_frames)]
+    return dict(frames=n_frames, path_m=float(path), end_error_m=float(np.linalg.norm(est[-1] - gt[-1])),
+                ate_rmse_m=float(np.sqrt(np.mean(np.sum((est - gt) ** 2, axis=1)))), max_step_error=float(max(rel)),
+                mean_tracked=float(np.mean([e["tracked"] for e in log])), mean_inliers=float(np.mean([e["inliers"] for e in log])),
+                log=log)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=30)
+    ap.add_argument("--verbose", action="store_true")
+    a = ap.parse_args()
+    out = run(a.frames, verbose=a.verbose)
+    out.pop("log")
+    print(json.dumps(out))

@@ -1,0 +1,21 @@
+"""The operators composed into a closed-loop stereo odometry (examples/closed_loop_stereo.py): detection,
+bucketing, stereo matching, the chained frame operator, pose chaining — trajectory against the renderer's
+ground truth. A behavioural test, not a parity test: it guards the semantics of the outputs (stages, pixel
+arrays, pose convention) that a caller depends on."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+
+
+def test_closed_loop_stereo_follows_ground_truth(vo):
+    import closed_loop_stereo as E
+    r = E.run(n_frames=25)
+    assert r["path_m"] > 15.0
+    assert r["mean_tracked"] > 300 and r["mean_inliers"] > 0.7 * r["mean_tracked"]
+    assert r["end_error_m"] < 0.02 * r["path_m"]  # < 2 % drift over the run
+    assert r["max_step_error"] < 0.05
+    assert all(e["new"] > 0 for e in r["log"][:5])  # bins freed by lost tracks are refilled
