@@ -146,3 +146,30 @@ def test_mono_frame_rejects_bad_arguments(mono_ctx, vo):
     with pytest.raises(vo.VoError):
         pipe.enqueue(np.zeros((4, 2), np.float32), np.zeros((4, 3), np.float32), np.zeros(4, np.uint8), np.eye(4),
                      np.eye(4), np.eye(4))
+
+
+@pytest.mark.parametrize("seed", [3, 8, 15, 29])
+def test_mono_frame_strict_replay_other_scenes(mono_ctx, vo, oracle, seed):
+    """More scenes with features 4 px from the border: the strict-border replay of the mono frame against the
+    oracle's sequential walk (chains of border-touching features differ from scene to scene)."""
+    ctx = mono_ctx
+    stream = S.StereoStream(width=752, height=480, K=MONO_K, n_u=40, n_v=25, n_new=50, seed=seed, speed=0.25, margin=4.0)
+    poses = stream.poses(4)
+    I0, _, _ = stream.render_pair(poses[2])
+    I1, _, _ = stream.render_pair(poses[3])
+    ts = stream.track_set(2, poses[2], poses[3])
+    pts0 = ts["pts_l0"]
+    n = pts0.shape[0]
+    Xw, Tcw_prev, Tcw_prior, dT01 = _world(ts, seed)
+    rng = np.random.default_rng(seed)
+    flags = ((rng.random(n) < 0.6).astype(np.uint8) | ((rng.random(n) < 0.9).astype(np.uint8) << 1)).astype(np.uint8)
+    args = (752, 480, 15, 5, 20.0, 1.0, 5, 1.0, MONO_K)
+    ctx.set_image(0, I0)
+    ctx.set_image(1, I1)
+    pipe = MonoFramePipeline(ctx, make_mono_params(*args), strict_border=1)
+    pipe.enqueue(pts0, Xw, flags, Tcw_prev, Tcw_prior, dT01)
+    g = pipe.result()
+    o = oracle.mono_frame(oracle.make_mono_params(*args), I0, I1, pts0, Xw, flags, Tcw_prev, Tcw_prior, dT01,
+                          oracle.SUM_TREE, 512, oracle.IC_REFERENCE, 8)
+    _compare(g, o)
+    assert g["counts"].n_replayed > 0
