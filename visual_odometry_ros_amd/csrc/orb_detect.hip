@@ -103,17 +103,28 @@ __device__ __forceinline__ int orb_fast_score(const uint8_t *__restrict__ p, int
   d[13] = v - p[-3 + stride];
   d[14] = v - p[-2 + 2 * stride];
   d[15] = v - p[-1 + 3 * stride];
-  // min / max over every arc of 9: windows of 8 (k+1 .. k+8) extended by d[k] or d[k+9]
+  // min / max over every arc of 9 by doubling: windows of 2, 4, 8 (cyclic), then one more element
+  int lo[16], hi[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int e = d[(k + 1) & 15];
+    lo[k] = d[k] < e ? d[k] : e;
+    hi[k] = d[k] > e ? d[k] : e;
+  }
+  int lo4[16], hi4[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    lo4[k] = lo[k] < lo[(k + 2) & 15] ? lo[k] : lo[(k + 2) & 15];
+    hi4[k] = hi[k] > hi[(k + 2) & 15] ? hi[k] : hi[(k + 2) & 15];
+  }
   int best_lo = -1000, best_hi = 1000;  // max over arcs of min(d) ; min over arcs of max(d)
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    int mn = d[k], mx = d[k];
-#pragma unroll
-    for (int q = 1; q < 9; ++q) {
-      const int e = d[(k + q) & 15];
-      mn = mn < e ? mn : e;
-      mx = mx > e ? mx : e;
-    }
+    int mn = lo4[k] < lo4[(k + 4) & 15] ? lo4[k] : lo4[(k + 4) & 15];  // d[k .. k+7]
+    int mx = hi4[k] > hi4[(k + 4) & 15] ? hi4[k] : hi4[(k + 4) & 15];
+    const int e = d[(k + 8) & 15];
+    mn = mn < e ? mn : e;
+    mx = mx > e ? mx : e;
     best_lo = best_lo > mn ? best_lo : mn;
     best_hi = best_hi < mx ? best_hi : mx;
   }
