@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--strict-border", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--detect", action="store_true",
+                    help="also run the keypoint detection + bucketing of the current left image every frame "
+                         "(side stream, overlapping the frame operator); not part of the default workload")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -138,12 +141,19 @@ def main():
     # slot roles, rotated in place of copying pyramids: previous left, current pair, prefetched pair
     slot = {"P": 0, "CL": 1, "CR": 2, "NL": 3, "NR": 4}
 
+    fe = None
+    if args.detect:
+        fe = V.FeatureExtractor(ctx)
+        fe.initParams(W_, H_, N_U, N_V, THRES_FAST=15)
+
     def enqueue(s):
         a, b = frame_id(s), frame_id(s + 1)
         t = d_ts[(a, b)]
         pipe.enqueue_device(t["pts_l0"].data_ptr(), t["pts_r0"].data_ptr(), t["Xp"].data_ptr(), n_pts,
                             track_sets[(a, b)]["dT_prior"], t["pts_new"].data_ptr(), N_NEW,
                             slots=(slot["P"], slot["CL"], slot["CR"]))
+        if fe is not None:  # extractORBwithBinning_fast of the current left image, off the main chain
+            fe.enqueueExtract(slot["CL"])
         # the NEXT stereo pair does not depend on this frame's result: its pyramids are enqueued
         # behind the frame and build while the host waits for / consumes this frame's result
         nb = frame_id(s + 2)
@@ -155,6 +165,8 @@ def main():
         enqueue(first)
         for s in range(first, first + count):
             r = pipe.result(copy=keep is not None and len(keep) < args.cpu_frames)
+            if fe is not None:
+                fe.resultExtract()
             slot["P"], slot["CL"], slot["CR"], slot["NL"], slot["NR"] = (slot["CL"], slot["NL"], slot["NR"], slot["P"],
                                                                            slot["CR"])
             if s + 1 < first + count:
@@ -237,6 +249,7 @@ def main():
                             "(5 effective levels), thresholds of config/stereo/kitti_00_stereo.yaml; one "
                             "independent stream per GPU; result read back every frame",
                 "strict_border": int(args.strict_border),
+                "with_detection": bool(args.detect),
                 "distinct_frames": F,
             },
             "roofline": {

@@ -206,6 +206,13 @@ int vo_extract_orb_with_binning(vo_ctx *ctx, int slot, const vo_orb_params *prm,
                                 int n_bins_u, int n_bins_v, const int32_t *weight, float *pts_out, int *n_out,
                                 int *n_detected);
 
+/* The same, asynchronous: the kernels run on the context's side stream behind the last pyramid build (vo_set_image*),
+ * so that the detection of an image overlaps the frame operator working on it. One detection in flight per
+ * context; the image slot must stay untouched until _result() has returned. */
+int vo_extract_orb_with_binning_enqueue(vo_ctx *ctx, int slot, const vo_orb_params *prm, float inv_u_step,
+                                        float inv_v_step, int n_bins_u, int n_bins_v, const int32_t *weight);
+int vo_extract_orb_with_binning_result(vo_ctx *ctx, float *pts_out, int *n_out, int *n_detected);
+
 /* ---- FeatureExtractor::descriptorDistance (feature_extractor.cpp:338-357) - */
 /* all-pairs 256-bit Hamming distance, dist is na x nb row-major */
 int vo_orb_hamming(vo_ctx *ctx, const uint8_t *a, int na, const uint8_t *b, int nb,

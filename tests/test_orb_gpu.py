@@ -49,6 +49,10 @@ def test_orb_detect_matches_oracle_kitti_shape(ctx, vo, oracle):
     pts_o, idx_o = oracle.bucket_argmax(o["xy"], o["response"], fe.inv_u_step_, fe.inv_v_step_, 20, 12, fe.weight)
     assert fe.n_detected == o["xy"].shape[0]
     assert np.array_equal(pts.view(np.uint32), pts_o.view(np.uint32)) and 50 < pts.shape[0] <= 240
+    # asynchronous variant on the side stream, twice in a row
+    for _ in range(2):
+        fe.enqueueExtract(0)
+        assert np.array_equal(fe.resultExtract(), pts)
     # the same through the host-array entry point
     if xy.shape[0] <= 8000:  # (the shared context's per-point capacity)
         pts2, _ = fe.bucketKeypoints(xy, resp)

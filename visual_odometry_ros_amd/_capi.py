@@ -74,7 +74,8 @@ SYMBOLS = [
     "vo_orb_match", "vo_compact_indices", "vo_stereo_frame_set_strict_border",
     "vo_stereo_frame_enqueue", "vo_stereo_frame_result",
     "vo_mono_frame_enqueue", "vo_mono_frame_result",
-    "vo_sba_solve", "vo_orb_detect", "vo_orb_get_level", "vo_extract_orb_with_binning", "vo_rectify_init_mono", "vo_rectify_init_stereo", "vo_rectify_set_maps", "vo_rectify_get_maps",
+    "vo_sba_solve", "vo_orb_detect", "vo_orb_get_level", "vo_extract_orb_with_binning",
+    "vo_extract_orb_with_binning_enqueue", "vo_extract_orb_with_binning_result", "vo_rectify_init_mono", "vo_rectify_init_stereo", "vo_rectify_set_maps", "vo_rectify_get_maps",
     "vo_set_image_rectified", "vo_set_image_rectified_device", "vo_set_stereo_pair_rectified_device",
     "vo_profile_enable", "vo_profile_reset", "vo_profile_get", "vo_profile_set_classes",
     "vo_set_stereo_pair_device", "vo_set_pyramid_window_hint",

@@ -361,6 +361,22 @@ class FeatureExtractor:
         self.n_detected = nd.value
         return pts[: m.value].copy()
 
+    def enqueueExtract(self, slot):
+        """extractORBwithBinning_fast, asynchronous: runs on the context's side stream (overlaps the frame
+        operator of the same image pair); resultExtract() collects pts_extracted."""
+        self.ctx.check(self.lib.vo_extract_orb_with_binning_enqueue(
+            self.ctx.handle, slot, C.byref(self.orb), C.c_float(self.inv_u_step_), C.c_float(self.inv_v_step_),
+            self.n_bins_u_, self.n_bins_v_, _p(np.ascontiguousarray(self.weight, np.int32), C.c_int32)))
+
+    def resultExtract(self):
+        if getattr(self, "_pts_buf", None) is None or self._pts_buf.shape[0] < self.weight.size + 1:
+            self._pts_buf = np.zeros((self.weight.size + 1, 2), np.float32)
+        m, nd = C.c_int(), C.c_int()
+        self.ctx.check(self.lib.vo_extract_orb_with_binning_result(self.ctx.handle, _p(self._pts_buf), C.byref(m),
+                                                                   C.byref(nd)))
+        self.n_detected = nd.value
+        return self._pts_buf[: m.value]
+
     def resetWeightBin(self):
         self.weight[:] = 1
 

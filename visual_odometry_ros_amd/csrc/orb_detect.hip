@@ -425,10 +425,19 @@ struct vo_orb_state {
   size_t o_hist, o_total, o_cut, o_rcut, o_cx, o_cy, o_cs, o_cr, o_oxy, o_oresp, o_ooct, o_on, o_flags;
   size_t o_keys, o_bpts, o_bidx, o_bn, o_weight;
   int cand_cap_level = 0, cand_cap = 0, max_out = 0, max_bins = 0, harris_blocks = 0;
+  // asynchronous use (vo_extract_orb_with_binning_enqueue / _result): side stream, pinned result block
+  hipEvent_t ev_start = nullptr, ev_done = nullptr;
+  uint8_t *h_res = nullptr;
+  size_t h_cap = 0;
+  int pending_bins = 0;
+  bool pending = false;
 };
 
 void vo_orb_free(vo_ctx *c) {
   if (c->orb) {
+    if (c->orb->ev_start) (void)hipEventDestroy(c->orb->ev_start);
+    if (c->orb->ev_done) (void)hipEventDestroy(c->orb->ev_done);
+    if (c->orb->h_res) (void)hipHostFree(c->orb->h_res);
     if (c->orb->arena) (void)hipFree(c->orb->arena);
     delete c->orb;
     c->orb = nullptr;
@@ -698,5 +707,79 @@ extern "C" int vo_extract_orb_with_binning(vo_ctx *c, int slot, const vo_orb_par
   if (m > 0) VO_CHECK_HIP(c, hipMemcpy(pts_out, A + S->o_bpts, sizeof(float) * 2 * (size_t)m, hipMemcpyDeviceToHost));
   *n_out = m;
   if (n_detected) *n_detected = n;
+  return VO_OK;
+}
+
+// The same, asynchronous and off the main chain: the kernels run on the context's side stream behind the last
+// pyramid build, so that detection overlaps the frame operator of the same image pair (which may have been enqueued
+// before it). One detection in flight per context; `slot` must not be rebuilt before _result() returned.
+extern "C" int vo_extract_orb_with_binning_enqueue(vo_ctx *c, int slot, const vo_orb_params *p, float inv_u_step,
+                                                   float inv_v_step, int n_bins_u, int n_bins_v, const int32_t *weight) {
+  if (!c || !p || !weight || n_bins_u <= 0 || n_bins_v <= 0) return VO_ERR_INVALID;
+  const int total = n_bins_u * n_bins_v;
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  if (c->orb && c->orb->pending) VO_FAIL(c, VO_ERR_INVALID, "a detection is already in flight");
+  if (!c->orb) c->orb = new vo_orb_state();
+  vo_orb_state *S = c->orb;
+  if (!S->ev_start) {
+    VO_CHECK_HIP(c, hipEventCreateWithFlags(&S->ev_start, hipEventDisableTiming));
+    VO_CHECK_HIP(c, hipEventCreateWithFlags(&S->ev_done, hipEventDisableTiming));
+  }
+  const size_t need = 64 + sizeof(int32_t) * (size_t)total + sizeof(float) * 2 * (size_t)total;
+  if (need > S->h_cap) {
+    if (S->h_res) (void)hipHostFree(S->h_res);
+    S->h_res = nullptr;
+    S->h_cap = 0;
+    VO_CHECK_HIP(c, hipHostMalloc((void **)&S->h_res, need, hipHostMallocDefault));
+    S->h_cap = need;
+  }
+  int32_t *h_w = (int32_t *)(S->h_res + 64);
+  float *h_pts = (float *)(S->h_res + 64 + sizeof(int32_t) * (size_t)total);
+  memcpy(h_w, weight, sizeof(int32_t) * (size_t)total);
+  hipStream_t main_stream = c->stream;
+  // wait for the last pyramid build only — not for what the main stream has enqueued since (the frame operator)
+  VO_CHECK_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_pyr, 0));
+  c->stream = c->stream2;  // every launcher below enqueues on ctx->stream
+  int rc = orb_enqueue(c, slot, p, total);
+  if (rc == VO_OK) {
+    uint8_t *A = S->arena;
+    hipError_t e = hipMemcpyAsync(A + S->o_weight, h_w, sizeof(int32_t) * (size_t)total, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess)
+      rc = vo_bucket_argmax_enqueue(c, (const float *)(A + S->o_oxy), (const float *)(A + S->o_oresp), S->max_out, inv_u_step,
+                                    inv_v_step, n_bins_u, n_bins_v, (const int32_t *)(A + S->o_weight),
+                                    (unsigned long long *)(A + S->o_keys), (float *)(A + S->o_bpts),
+                                    (int32_t *)(A + S->o_bidx), (int *)(A + S->o_bn), (const int *)(A + S->o_on));
+    if (e == hipSuccess && rc == VO_OK) e = hipMemcpyAsync(S->h_res, A + S->o_bn, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && rc == VO_OK) e = hipMemcpyAsync(S->h_res + 4, A + S->o_on, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && rc == VO_OK) e = hipMemcpyAsync(S->h_res + 8, A + S->o_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && rc == VO_OK)
+      e = hipMemcpyAsync(h_pts, A + S->o_bpts, sizeof(float) * 2 * (size_t)total, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && rc == VO_OK) e = hipEventRecord(S->ev_done, c->stream);
+    if (e != hipSuccess) {
+      snprintf(c->err, sizeof(c->err), "vo_extract_orb_with_binning_enqueue: %s", hipGetErrorString(e));
+      rc = VO_ERR_HIP;
+    }
+  }
+  c->stream = main_stream;
+  if (rc < 0) return rc;
+  S->pending = true;
+  S->pending_bins = total;
+  return VO_OK;
+}
+
+extern "C" int vo_extract_orb_with_binning_result(vo_ctx *c, float *pts_out, int *n_out, int *n_detected) {
+  if (!c || !c->orb || !c->orb->pending || !pts_out || !n_out) return VO_ERR_INVALID;
+  vo_orb_state *S = c->orb;
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  VO_CHECK_HIP(c, hipEventSynchronize(S->ev_done));
+  S->pending = false;
+  const int *hdr = (const int *)S->h_res;
+  int rc = orb_check_flags(c, hdr[2]);
+  if (rc) return rc;
+  const int m = hdr[0];
+  const float *h_pts = (const float *)(S->h_res + 64 + sizeof(int32_t) * (size_t)S->pending_bins);
+  if (m > 0) memcpy(pts_out, h_pts, sizeof(float) * 2 * (size_t)m);
+  *n_out = m;
+  if (n_detected) *n_detected = hdr[1];
   return VO_OK;
 }

@@ -242,6 +242,7 @@ static int build(vo_ctx *c, int slot_l, const uint8_t *d_l, int slot_r, const ui
   vo_prof_end(c);
   for (int i = 0; i < nimg; ++i) P[i]->n_levels = nl;
   VO_CHECK_HIP(c, hipGetLastError());
+  VO_CHECK_HIP(c, hipEventRecord(c->ev_pyr, c->stream));
   return VO_OK;
 }
 

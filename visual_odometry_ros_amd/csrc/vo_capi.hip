@@ -80,6 +80,7 @@ extern "C" int vo_create(const vo_config *cfg, vo_ctx **out) {
   VO_CHECK_HIP(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
   VO_CHECK_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   VO_CHECK_HIP(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  VO_CHECK_HIP(c, hipEventCreateWithFlags(&c->ev_pyr, hipEventDisableTiming));
   const size_t N = (size_t)cfg->max_points;
   c->slots = (vo_pyramid *)calloc((size_t)cfg->n_slots, sizeof(vo_pyramid));
   for (int s = 0; s < cfg->n_slots; ++s) {
@@ -141,6 +142,7 @@ extern "C" void vo_destroy(vo_ctx *c) {
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->ev_pyr) (void)hipEventDestroy(c->ev_pyr);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   free(c);

@@ -48,6 +48,7 @@ struct vo_ctx {
   hipStream_t stream;
   hipStream_t stream2;     // side stream: work that does not depend on the main chain of a frame
   hipEvent_t ev_fork, ev_join;
+  hipEvent_t ev_pyr;       // recorded behind every pyramid build: what side-stream consumers of a slot wait for
   char err[512];
   vo_pyramid *slots;
   // per-point device buffers (capacity cfg.max_points)
