@@ -52,3 +52,29 @@ def test_product_never_imports_the_oracle():
                 # comments may mention the oracle; nothing may import, link or dlopen it
                 assert "import oracle" not in txt and "from oracle" not in txt, f
                 assert "libvo_oracle" not in txt and "vo_oracle.h" not in txt and "vo_ref_" not in txt, f
+
+
+def test_every_entry_point_rejects_null_arguments(vo):
+    """Every int-returning entry point called with a NULL context and NULL / zero arguments returns a negative
+    status (no dereference before the argument check) — runs without a GPU."""
+    lib = vo.load()
+    src = open(os.path.join(ROOT, "include", "vo_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = re.findall(r"\bint\s+(vo_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", src, flags=re.S)
+    assert len(protos) >= 40
+    for name, args in protos:
+        if name in ("vo_abi_version", "vo_device_count", "vo_pyramid_levels", "vo_create"):
+            continue
+        call = []
+        for a in (x.strip() for x in args.split(",")):
+            if "*" in a or "[" in a:
+                call.append(None)
+            elif a.startswith("double"):
+                call.append(C.c_double(0.0))
+            elif a.startswith("float"):
+                call.append(C.c_float(0.0))
+            else:
+                call.append(0)
+        f = getattr(lib, name)
+        f.restype, f.argtypes = C.c_int, None
+        assert f(*call) < 0, name
