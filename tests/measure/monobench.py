@@ -1,7 +1,7 @@
 """Throughput of the mono frame (vo_mono_frame_enqueue) at BASELINE configs[2]'s shape — 752x480,
 1000 features (40x25 buckets), win 15, 5 levels, result read back every frame — next to the CPU
 oracle on the same frames. Measurement tool (not the driver's bench line; bench.py stays on configs[1]).
-usage: python tools/tools_monobench.py [--steps 400] [--strict-border 1] [--cpu-frames 6]"""
+usage: python tests/measure/monobench.py [--steps 400] [--strict-border 1] [--cpu-frames 6]"""
 import argparse
 import gc
 import json
@@ -11,7 +11,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 MONO_K = (458.654, 457.296, 367.215, 248.375)
 
 

@@ -1,5 +1,5 @@
 """Time of FeatureExtractor::extractORBwithBinning_fast on the device (detection + bucketing, result read
-back) and of the CPU restatement. usage: python tools/tools_orbbench.py"""
+back) and of the CPU restatement. usage: python tests/measure/orbbench.py"""
 import json
 import os
 import sys
@@ -7,7 +7,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 
 def main():

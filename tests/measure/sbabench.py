@@ -1,5 +1,5 @@
 """Wall time of one local bundle adjustment (10 iterations) on the device vs the CPU restatement, and the
-largest deviation between the two. usage: python tools/tools_sbabench.py"""
+largest deviation between the two. usage: python tests/measure/sbabench.py"""
 import json
 import os
 import sys
@@ -7,7 +7,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 
 def main():

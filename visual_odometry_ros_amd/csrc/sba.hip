@@ -628,7 +628,7 @@ __global__ __launch_bounds__(64) void sba_solve_kernel(SbaDev d, int iter) {
   if (lane == 0) {
     d.avg_err[iter] = sqrt(e / (double)d.n_obs);
     if (e != e) atomicOr(d.flags, 2);
-    // phase durations of the last iteration in 10 ns ticks (tools/tools_sbabench.py)
+    // phase durations of the last iteration in 10 ns ticks (tests/measure/sbabench.py)
     d.flags[1] = (int)(t_1 - t_0);
     d.flags[2] = (int)(t_2 - t_1);
     d.flags[3] = (int)((long long)__builtin_amdgcn_s_memrealtime() - t_2);
