@@ -376,6 +376,14 @@ __device__ __forceinline__ void gn_point(GnAcc &A, const GnArgs &a, const float 
   }
 }
 
+#ifdef GN_STAMP
+__device__ long long vo_gn_stamps[8];
+extern "C" int vo_debug_gn_stamps(vo_ctx *c, long long out[8]) {
+  VO_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+  VO_CHECK_HIP(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(vo_gn_stamps), sizeof(long long) * 8));
+  return VO_OK;
+}
+#endif
 #define GN_PC 4  // points per thread kept in registers across the iterations (n <= GN_PC * GN_T: no reloads)
 
 template <bool STEREO>
@@ -388,6 +396,12 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
+#ifdef GN_STAMP
+#define GSTAMP(k) if (tid == 0) vo_gn_stamps[k] = (long long)__builtin_amdgcn_s_memrealtime();
+#else
+#define GSTAMP(k)
+#endif
+  GSTAMP(0)
   int n = a.d_n ? *a.d_n : a.n;
   if (a.f_n > 0) {
     // ---- frame mode prologue: survivors in index order + step counts (the one compaction of the frame) ----
@@ -440,6 +454,7 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
     if (a.f_res_host)
       for (int k = a.f_res_late_words + tid; k < a.f_res_words; k += GN_T) a.f_res_host[k] = a.f_res_dev[k];
   }
+  GSTAMP(1)
   float T10[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) T10[k] = a.d_T10 ? a.d_T10[k] : a.T10[k];
@@ -460,6 +475,7 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
     cP2[q][1] = (STEREO && ok) ? a.p2[2 * ii + 1] : 0.f;
   }
 
+  GSTAMP(2)
   float err_prev = 1e10f;
   int iter = 0;
   float last_err = 0, last_derr = 0, last_dnorm = 0;
@@ -585,6 +601,7 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
       break;
     }
   }
+  GSTAMP(3)
   if (a.stage) {
     for (int i = tid; i < n; i += GN_T) {
       const float gate = a.p1[2 * i + 1] > 660 ? 100.f : 0.f;
@@ -627,6 +644,7 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
     __syncthreads();  // stage marks, pose and info above are this workgroup's own stores
     for (int k = tid; k < a.f_res_late_words; k += GN_T) a.f_res_host[k] = a.f_res_dev[k];
   }
+  GSTAMP(4)
 }
 
 // ---- host side ---------------------------------------------------------------
