@@ -73,9 +73,9 @@ def test_stereo_frame_small_many_frames(ctx, oracle):
     _run_stream(ctx, oracle, stream, 6, False, win=15, max_level=4)
 
 
-@pytest.mark.parametrize("win,strict", [(31, True), (17, True), (17, False), (15, True), (21, 2)])
+@pytest.mark.parametrize("win,strict", [(31, True), (17, True), (17, False), (15, True), (13, True), (13, False), (21, 2)])
 def test_stereo_frame_other_windows(ctx, oracle, win, strict):
-    """win 15 / 31: the other instantiations of the fused frame kernel; win 17: the general
+    """win 13 / 15 / 31: the other instantiations of the fused frame kernel; win 17: the general
     one-launch-per-step path (windows the fused kernel is not instantiated for); strict 2: the
     sequential fallback of the strict-border replay does all the work."""
     K = tuple(v * 0.5 for v in S.KITTI_K)

@@ -173,3 +173,23 @@ def test_mono_frame_strict_replay_other_scenes(mono_ctx, vo, oracle, seed):
                           oracle.SUM_TREE, 512, oracle.IC_REFERENCE, 8)
     _compare(g, o)
     assert g["counts"].n_replayed > 0
+
+
+def test_mono_frame_window_13(mono_ctx, vo, oracle):
+    """window 13 (config/mono/*.yaml use 13 and 15): the other instantiation of the mono frame kernel."""
+    ctx = mono_ctx
+    I0, I1, ts = _scene(44)
+    pts0 = ts["pts_l0"]
+    n = pts0.shape[0]
+    Xw, Tcw_prev, Tcw_prior, dT01 = _world(ts, 2)
+    flags = np.full(n, 3, np.uint8)
+    args = (752, 480, 13, 5, 20.0, 1.0, 5, 1.0, MONO_K)
+    ctx.set_image(0, I0)
+    ctx.set_image(1, I1)
+    pipe = MonoFramePipeline(ctx, make_mono_params(*args), strict_border=1)
+    pipe.enqueue(pts0, Xw, flags, Tcw_prev, Tcw_prior, dT01)
+    g = pipe.result()
+    o = oracle.mono_frame(oracle.make_mono_params(*args), I0, I1, pts0, Xw, flags, Tcw_prev, Tcw_prior, dT01,
+                          oracle.SUM_TREE, 512, oracle.IC_REFERENCE, 8)
+    _compare(g, o)
+    assert g["counts"].n_final > 0.5 * n

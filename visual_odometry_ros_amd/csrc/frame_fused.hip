@@ -344,7 +344,8 @@ static void frame_launch(vo_ctx *c, const FrameArgs &a, int phase) {
   // (the frame's one compaction and the control-block reset are the prologue of the GN launch, gn_pose.hip)
 }
 
-int vo_frame_fused_supported(int win) { return win == 15 || win == 21 || win == 31; }
+// the window sizes of the reference's configurations (config/**.yaml: 13, 15, 21) and 31
+int vo_frame_fused_supported(int win) { return win == 13 || win == 15 || win == 21 || win == 31; }
 
 int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, int slot_l1, int slot_r1,
                            const float *d_l0, const float *d_r0, const float *d_X, int n, const float T_cp[16],
@@ -417,6 +418,7 @@ int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, 
   a.ic.last_pu = b.lastpu;
   a.ic.n = n;
   switch (prm->win) {
+    case 13: frame_launch<13>(c, a, phase); break;
     case 15: frame_launch<15>(c, a, phase); break;
     case 21: frame_launch<21>(c, a, phase); break;
     case 31: frame_launch<31>(c, a, phase); break;

@@ -296,8 +296,8 @@ extern "C" int vo_mono_frame_enqueue(vo_ctx *c, const vo_mono_params *prm, int s
   if (!c || !prm || !Tcw_prev || !Tcw_prior || !dT01_prior || n < 0) return VO_ERR_INVALID;
   if (n > c->cfg.max_points) VO_FAIL(c, VO_ERR_CAPACITY, "n=%d exceeds vo_config.max_points=%d", n, c->cfg.max_points);
   if (n > 0 && (!pts0 || !Xw || !flags)) return VO_ERR_INVALID;
-  if (prm->win != 15 && prm->win != 21 && prm->win != 31)
-    VO_FAIL(c, VO_ERR_INVALID, "mono frame kernel not instantiated for window %d (15, 21, 31)", prm->win);
+  if (prm->win != 13 && prm->win != 15 && prm->win != 21 && prm->win != 31)
+    VO_FAIL(c, VO_ERR_INVALID, "mono frame kernel not instantiated for window %d (13, 15, 21, 31)", prm->win);
   if (prm->max_level < 0) VO_FAIL(c, VO_ERR_INVALID, "maxLevel >= 0 violated");
   VO_CHECK_HIP(c, hipSetDevice(c->device));
   int rc = vo_frame_init(c);
@@ -372,6 +372,7 @@ extern "C" int vo_mono_frame_enqueue(vo_ctx *c, const vo_mono_params *prm, int s
     a.ic.last_pu = f->A_lastpu;
     a.ic.n = n;
     switch (prm->win) {
+      case 13: mono_launch<13>(c, a); break;
       case 15: mono_launch<15>(c, a); break;
       case 21: mono_launch<21>(c, a); break;
       default: mono_launch<31>(c, a); break;
