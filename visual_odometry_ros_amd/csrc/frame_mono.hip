@@ -20,6 +20,7 @@
 #include "frame_state.hpp"
 #include "ic_device.hpp"
 #include "klt_device.hpp"
+#include "mono_gate.hpp"
 #include "vo_kernels.hpp"
 
 struct MonoArgs {
@@ -165,121 +166,6 @@ __global__ __launch_bounds__(IC_T) void mono_fallback_kernel(IcArgs a) {
   ic_strict_run(a, sh, pt, a.n, threadIdx.x, [](int, const IcResult &) {});
 }
 
-// ---- after the GN launch: mask_motion, Sampson gate, stages, counts (one workgroup) ----
-struct MonoGateArgs {
-  int n;
-  const float *pts0, *k1, *ref;
-  const uint8_t *m1, *m2, *ba_ok, *mG;
-  const int32_t *C_orig;
-  const int *n_ba;          // survivors handed to the GN solve
-  const vo_gn_dev_info *gn;
-  float *dT;                // in: GN result T01 ; out: the prior when the 5-point fallback is needed
-  float dT_prior[16], K[4];
-  float thres_sampson;
-  uint8_t *motion;          // scratch [n]
-  uint8_t *stage;           // out
-  float *pts1;              // out
-  int *cnt;                 // out [8]: n_klt, n_refine, n_ba, n_motion, n_final, need_five_point
-  int *ctl;                 // frame control block: reported ([0] flags, replay count) and reset here
-  int ctl_words, nt_word;
-  int *hdr_flags;
-  const uint32_t *res_dev;  // packed result block -> res_host (pinned, device-visible)
-  uint32_t *res_host;
-  int res_words;
-};
-__device__ __forceinline__ float mono_dot3(float a0, float b0, float a1, float b1, float a2, float b2) {
-  return a0 * b0 + (a1 * b1 + a2 * b2);  // Eigen's unrolled 3-term redux
-}
-__global__ __launch_bounds__(1024) void mono_gate_kernel(MonoGateArgs a) {
-  __shared__ float sF[9];
-  __shared__ int s_cnt[8];
-  __shared__ int s_ok;
-  const int tid = threadIdx.x;
-  if (tid < 8) s_cnt[tid] = 0;
-  const int n_ba = *a.n_ba;
-  if (tid == 0) {
-    const int ok = n_ba > 10 && !a.gn->is_nan;  // mono_vo.cpp:838, :866
-    s_ok = ok;
-    if (!ok) {
-      for (int k = 0; k < 16; ++k) a.dT[k] = a.dT_prior[k];
-    } else {
-      // dT10 = inverseSE3_f(dT01) (geometry_library.cpp:554-560); F10 = Kinv^T [t10]x R10 Kinv (motion_estimator.cpp:551-552)
-      float R10[9], t10[3];
-      for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) R10[i * 3 + j] = a.dT[j * 4 + i];
-      const float t0 = a.dT[3], t1 = a.dT[7], t2 = a.dT[11];
-      for (int i = 0; i < 3; ++i) t10[i] = ((-R10[i * 3 + 0]) * t0 + (-R10[i * 3 + 1]) * t1) + (-R10[i * 3 + 2]) * t2;
-      const float fxi = 1.0f / a.K[0], fyi = 1.0f / a.K[1];
-      const float Kinv[9] = {fxi, 0.0f, -a.K[2] * fxi, 0.0f, fyi, -a.K[3] * fyi, 0.0f, 0.0f, 1.0f};
-      const float KinvT[9] = {Kinv[0], Kinv[3], Kinv[6], Kinv[1], Kinv[4], Kinv[7], Kinv[2], Kinv[5], Kinv[8]};
-      const float Sx[9] = {0.0f, -t10[2], t10[1], t10[2], 0.0f, -t10[0], -t10[1], t10[0], 0.0f};
-      float E[9], T[9];
-      for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j)
-          E[i * 3 + j] = mono_dot3(Sx[i * 3 + 0], R10[0 * 3 + j], Sx[i * 3 + 1], R10[1 * 3 + j], Sx[i * 3 + 2], R10[2 * 3 + j]);
-      for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j)
-          T[i * 3 + j] = mono_dot3(KinvT[i * 3 + 0], E[0 * 3 + j], KinvT[i * 3 + 1], E[1 * 3 + j], KinvT[i * 3 + 2], E[2 * 3 + j]);
-      for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j)
-          sF[i * 3 + j] = mono_dot3(T[i * 3 + 0], Kinv[0 * 3 + j], T[i * 3 + 1], Kinv[1 * 3 + j], T[i * 3 + 2], Kinv[2 * 3 + j]);
-    }
-    *a.hdr_flags = a.ctl[0];
-    a.cnt[7] = a.ctl[16 + a.nt_word];
-  }
-  // mask_motion: true for every refined feature, the BA's inlier mask for the BA set (:845, :872-879)
-  for (int i = tid; i < a.n; i += 1024) a.motion[i] = (a.m1[i] && a.m2[i]) ? 1 : 0;
-  __syncthreads();
-  const int ok = s_ok;
-  if (ok)
-    for (int c = tid; c < n_ba; c += 1024) a.motion[a.C_orig[c]] = a.mG[c];
-  __syncthreads();
-  for (int k = tid; k < a.ctl_words; k += 1024) a.ctl[k] = 0;
-  int c_klt = 0, c_ref = 0, c_mot = 0, c_fin = 0;
-  for (int i = tid; i < a.n; i += 1024) {
-    const int m1 = a.m1[i], m2 = m1 && a.m2[i];
-    int st = m1 ? (m2 ? 2 : 1) : 0;
-    const float x1 = m1 ? a.ref[2 * i] : a.k1[2 * i], y1 = m1 ? a.ref[2 * i + 1] : a.k1[2 * i + 1];
-    if (ok && m2 && a.motion[i]) {
-      st = 3;
-      // calcSampsonDistance, motion_estimator.cpp:553-569
-      const float x0 = a.pts0[2 * i], y0 = a.pts0[2 * i + 1];
-      float p[3], q[3];
-      for (int r = 0; r < 3; ++r) p[r] = mono_dot3(sF[r * 3 + 0], x0, sF[r * 3 + 1], y0, sF[r * 3 + 2], 1.0f);
-      for (int r = 0; r < 3; ++r) q[r] = mono_dot3(sF[0 * 3 + r], x1, sF[1 * 3 + r], y1, sF[2 * 3 + r], 1.0f);
-      float num = mono_dot3(x1, p[0], y1, p[1], 1.0f, p[2]);
-      num *= num;
-      const float den = ((p[0] * p[0] + p[1] * p[1]) + q[0] * q[0]) + q[1] * q[1];
-      if (num / den < a.thres_sampson) st = 4;
-    }
-    a.stage[i] = (uint8_t)st;
-    a.pts1[2 * i] = x1;
-    a.pts1[2 * i + 1] = y1;
-    c_klt += st >= 1;
-    c_ref += st >= 2;
-    c_mot += st >= 3;
-    c_fin += st >= 4;
-  }
-  atomicAdd(&s_cnt[0], c_klt);
-  atomicAdd(&s_cnt[1], c_ref);
-  atomicAdd(&s_cnt[3], c_mot);
-  atomicAdd(&s_cnt[4], c_fin);
-  __syncthreads();
-  if (tid == 0) {
-    a.cnt[0] = s_cnt[0];
-    a.cnt[1] = s_cnt[1];
-    a.cnt[2] = n_ba;
-    a.cnt[3] = s_cnt[3];
-    a.cnt[4] = s_cnt[4];
-    a.cnt[5] = ok ? 0 : 1;
-  }
-  // every header word is written by a launch of this frame (cnt[6]: compaction, gn / dT: GN, the rest
-  // above), so the block needs no clearing. It goes to pinned host memory from here (all final: earlier
-  // launches' stores, and this workgroup's own above)
-  __syncthreads();
-  for (int k = tid; k < a.res_words; k += 1024) a.res_host[k] = a.res_dev[k];
-}
-
 // ---- host side ---------------------------------------------------------------------
 static size_t m_align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
@@ -386,25 +272,9 @@ extern "C" int vo_mono_frame_enqueue(vo_ctx *c, const vo_mono_params *prm, int s
       hipLaunchKernelGGL(mono_fallback_kernel, dim3(n), dim3(IC_T), 0, s, a.ic);
       vo_prof_end(c);
     }
-    // BA set: refined && BA class && depth > 0.1, in index order (mono_vo.cpp:799-826, :846-860)
-    CompactArgsHost h;
-    h.mask = f->m1;
-    h.alive = f->m2;
-    h.tracked = f->m3;
-    h.n = n;
-    h.d_n_out = &f->hdr->cnt[6];
-    h.in2[0] = f->A_ref;
-    h.out2[0] = f->C_pl1;
-    h.in3 = f->A_X;
-    h.out3 = f->C_X;
-    h.in_i = f->F_orig;
-    h.out_i = f->C_orig;
-    rc = vo_compact_enqueue(c, h);
-    if (rc < 0) return rc;
-    // poseOnlyBundleAdjustment (class-surface variant), T01 initialised with the motion prior (:856-867)
-    rc = vo_gn_enqueue(c, false, true, f->C_X, f->C_pl1, nullptr, n, &f->hdr->cnt[6], prm->K, prm->K, nullptr,
-                       (float)prm->thres_poseba, VO_GN_VARIANT_CORE, dT01_prior, f->hdr->dT, f->mG, &f->hdr->gn, true);
-    if (rc < 0) return rc;
+    // BA set (refined && BA class && depth > 0.1, in index order; mono_vo.cpp:799-826, :846-860), pose-only BA
+    // (class-surface variant, T01 initialised with the motion prior, :856-867) and the tail of the frame: ONE launch.
+    // The GN kernel's frame-mode prologue selects and compacts the set, its epilogue is mono_gate_body.
     MonoGateArgs g;
     memset(&g, 0, sizeof(g));
     g.n = n;
@@ -416,7 +286,6 @@ extern "C" int vo_mono_frame_enqueue(vo_ctx *c, const vo_mono_params *prm, int s
     g.ba_ok = f->m3;
     g.mG = f->mG;
     g.C_orig = f->C_orig;
-    g.n_ba = &f->hdr->cnt[6];
     g.gn = &f->hdr->gn;
     g.dT = f->hdr->dT;
     memcpy(g.dT_prior, dT01_prior, sizeof(g.dT_prior));
@@ -426,16 +295,30 @@ extern "C" int vo_mono_frame_enqueue(vo_ctx *c, const vo_mono_params *prm, int s
     g.stage = f->stage;
     g.pts1 = f->F_pl1;
     g.cnt = f->hdr->cnt;
-    g.ctl = f->ctl;
-    g.ctl_words = (int)(vo_ic_ctl_bytes() / 4);
-    g.nt_word = vo_ic_ctl_nt_word();
-    g.hdr_flags = &f->hdr->flags;
     g.res_dev = (const uint32_t *)f->res_dev;
     g.res_host = (uint32_t *)f->res_host;
     g.res_words = (int)((f->res_bytes + 3) / 4);
-    vo_prof_begin(c, VO_K_AUX);
-    hipLaunchKernelGGL(mono_gate_kernel, dim3(1), dim3(1024), 0, s, g);
-    vo_prof_end(c);
+    vo_gn_frame gf;
+    memset(&gf, 0, sizeof(gf));
+    gf.n = n;
+    gf.m1 = f->m1;
+    gf.m2 = f->m2;
+    gf.m3 = f->m3;
+    gf.X = f->A_X;
+    gf.pl1 = f->A_ref;
+    gf.C_X = f->C_X;
+    gf.C_pl1 = f->C_pl1;
+    gf.C_orig = f->C_orig;
+    gf.cnt = f->hdr->cnt;
+    gf.ctl = f->ctl;
+    gf.ctl_words = (int)(vo_ic_ctl_bytes() / 4);
+    gf.nt_word = vo_ic_ctl_nt_word();
+    gf.hdr_flags = &f->hdr->flags;
+    gf.mono_gate = &g;
+    rc = vo_gn_enqueue(c, false, true, f->C_X, f->C_pl1, nullptr, n, nullptr, prm->K, prm->K, nullptr,
+                       (float)prm->thres_poseba, VO_GN_VARIANT_CORE, dT01_prior, f->hdr->dT, f->mG, &f->hdr->gn, true,
+                       nullptr, nullptr, 0, 0.f, &gf);
+    if (rc < 0) return rc;
     VO_CHECK_HIP(c, hipGetLastError());
   } else {
     VO_CHECK_HIP(c, hipMemsetAsync(f->hdr, 0, sizeof(vo_frame_hdr), s));

@@ -19,6 +19,7 @@
 // in natural order — the oracle's VO_SUM_TREE with tree_width = GN_T.
 #include "vo_internal.hpp"
 #include "vo_kernels.hpp"
+#include "mono_gate.hpp"
 
 #define GN_T 512
 #define GN_NW (GN_T / 64)
@@ -64,6 +65,9 @@ struct GnArgs {
   uint32_t *f_res_host;
   int f_res_words;
   int f_res_late_words;     // leading words (header, stage bytes) that this kernel still changes: copied last
+  const uint8_t *f_m1, *f_m2, *f_m3;  // mono frame: selection masks in place of f_stage
+  int f_mono;               // epilogue = mono_gate_body(f_gate)
+  MonoGateArgs f_gate;
 };
 
 // upper-triangular index of (i,j), i<=j, row-major: matches oracle UT[][]
@@ -410,7 +414,13 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
     __syncthreads();
     for (int c0 = 0; c0 < a.f_n; c0 += GN_T) {
       const int i = c0 + tid;
-      const int st = i < a.f_n ? a.f_stage[i] : 0;
+      int st = 0;
+      if (i < a.f_n) {
+        if (a.f_m1)  // mono: tracked / refined / member of the BA set (mono_vo.cpp:773, :788, :799-826)
+          st = a.f_m1[i] ? (a.f_m2[i] ? (a.f_m3[i] ? 3 : 2) : 1) : 0;
+        else
+          st = a.f_stage[i];
+      }
       const unsigned long long b1 = __ballot(st >= 1), b2 = __ballot(st >= 2), b3 = __ballot(st >= 3);
       const int below = __popcll(b3 & ((1ull << lane) - 1ull));
       if (lane == 0) {
@@ -429,8 +439,10 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
         a.f_CX[3 * o + 2] = a.f_X[3 * i + 2];
         a.f_Cpl1[2 * o] = a.f_pl1[2 * i];
         a.f_Cpl1[2 * o + 1] = a.f_pl1[2 * i + 1];
-        a.f_Cpr1[2 * o] = a.f_pr1[2 * i];
-        a.f_Cpr1[2 * o + 1] = a.f_pr1[2 * i + 1];
+        if (a.f_pr1) {
+          a.f_Cpr1[2 * o] = a.f_pr1[2 * i];
+          a.f_Cpr1[2 * o + 1] = a.f_pr1[2 * i + 1];
+        }
         a.f_Corig[o] = i;
       }
       __syncthreads();
@@ -639,7 +651,11 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
       a.info->is_nan = is_nan;
     }
   }
-  if (a.f_n > 0 && a.f_res_host) {
+  if (a.f_n > 0 && a.f_mono) {
+    // mono frame: mask_motion, Sampson gate, stages, counts and the copy of the result block (mono_gate.hpp)
+    __syncthreads();  // inlier mask, pose and info above are this workgroup's own stores
+    mono_gate_body(a.f_gate, tid, GN_T, n);
+  } else if (a.f_n > 0 && a.f_res_host) {
     // frame mode epilogue: the packed result block goes to pinned host memory from here
     __syncthreads();  // stage marks, pose and info above are this workgroup's own stores
     for (int k = tid; k < a.f_res_late_words; k += GN_T) a.f_res_host[k] = a.f_res_dev[k];
@@ -715,6 +731,13 @@ int vo_gn_enqueue(vo_ctx *c, bool stereo, bool mono_general_inverse, const float
     a.f_res_host = (uint32_t *)frame->res_host;
     a.f_res_words = (int)((frame->res_bytes + 3) / 4);
     a.f_res_late_words = (int)(frame->res_late_bytes / 4);
+    a.f_m1 = frame->m1;
+    a.f_m2 = frame->m2;
+    a.f_m3 = frame->m3;
+    if (frame->mono_gate) {
+      a.f_mono = 1;
+      a.f_gate = *frame->mono_gate;
+    }
   }
   a.X = dX;
   a.p1 = dP1;

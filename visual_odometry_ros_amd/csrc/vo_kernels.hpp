@@ -20,6 +20,10 @@ struct vo_gn_frame {
   void *res_host;           // pinned, device-visible; null = no copy-out
   size_t res_bytes;
   size_t res_late_bytes;    // leading part (header + stage bytes, multiple of 16) the GN launch itself still writes
+  // mono frame (frame_mono.hip): the BA set is m1 && m2 && m3 instead of stage >= 3 (counts: m1, m1 && m2, the set),
+  // and the epilogue is mono_gate_body(*mono_gate) — a MonoGateArgs, copied into the kernel arguments
+  const uint8_t *m1, *m2, *m3;
+  const struct MonoGateArgs *mono_gate;
 };
 int vo_gn_enqueue(vo_ctx *c, bool stereo, bool mono_general_inverse, const float *dX, const float *dP1,
                   const float *dP2, int n, const int *d_n, const float Kl[4], const float Kr[4],
