@@ -13,9 +13,9 @@
 // too few points or fails, counts.need_five_point is set and the frame stops after the refinement.
 //
 // As in the stereo frame (frame_fused.hip) the per-feature steps — prior, forward KLT, backward KLT,
-// bidirectional mask, IC refinement — are one wavefront of ONE launch; the strict-border replay, the
-// selection of the BA set, the GN solve and the Sampson gate follow as launches on the same stream, and
-// the host reads one packed block. stage[i] = number of gates feature i passed (1 tracked, 2 refined,
+// bidirectional mask, IC refinement — are one wavefront of ONE launch; the strict-border replay follows, then
+// ONE more launch: the GN kernel in frame mode, whose prologue selects the BA set and whose epilogue is the
+// Sampson gate (mono_gate.hpp); the host reads one packed block. stage[i] = number of gates feature i passed (1 tracked, 2 refined,
 // 3 motion inlier or not part of the BA, 4 passed the Sampson gate).
 #include "frame_state.hpp"
 #include "ic_device.hpp"
