@@ -76,5 +76,9 @@ def test_every_entry_point_rejects_null_arguments(vo):
             else:
                 call.append(0)
         f = getattr(lib, name)
+        saved = f.argtypes
         f.restype, f.argtypes = C.c_int, None
-        assert f(*call) < 0, name
+        try:
+            assert f(*call) < 0, name
+        finally:
+            f.argtypes = saved

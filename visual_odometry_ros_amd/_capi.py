@@ -101,5 +101,10 @@ def load():
     lib.vo_create.argtypes = [C.POINTER(VoConfig), C.POINTER(C.c_void_p)]
     lib.vo_destroy.argtypes = [C.c_void_p]
     lib.vo_destroy.restype = None
+    # the two per-frame calls carry declared argument types: no per-call inference, plain ints as device pointers
+    vp, ci = C.c_void_p, C.c_int
+    lib.vo_stereo_frame_enqueue.argtypes = [vp, C.POINTER(StereoParams), ci, ci, ci, vp, vp, vp, ci, vp, vp, ci, ci]
+    lib.vo_stereo_frame_result.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.POINTER(FrameCounts), C.POINTER(GnInfo)]
+    lib.vo_set_stereo_pair_device.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci]
     _lib = lib
     return lib

@@ -94,8 +94,9 @@ class Context:
         self.check(self.lib.vo_set_image_device(self._h, slot, C.c_void_p(dev_ptr), width, height, stride))
 
     def set_stereo_pair_device(self, slot_l, ptr_l, slot_r, ptr_r, width, height, stride):
-        self.check(self.lib.vo_set_stereo_pair_device(self._h, slot_l, C.c_void_p(ptr_l), slot_r,
-                                                      C.c_void_p(ptr_r), width, height, stride))
+        rc = self.lib.vo_set_stereo_pair_device(self._h, slot_l, ptr_l, slot_r, ptr_r, width, height, stride)
+        if rc < 0:
+            self.check(rc)
 
     def set_image_rectified(self, slot, img, cam=0):
         img = _u8(img)
@@ -484,13 +485,13 @@ class StereoFramePipeline:
             _p(Xp), self._n, _p(dT), _p(pts_new), self._nn, 0))
 
     def enqueue_device(self, d_pts_l0, d_pts_r0, d_Xp, n, dT_prior, d_pts_new, n_new, slots=(0, 1, 2)):
-        dT = _f32(dT_prior).reshape(16)
+        dT = dT_prior if (isinstance(dT_prior, np.ndarray) and dT_prior.dtype == np.float32 and dT_prior.flags.c_contiguous) \
+            else _f32(dT_prior)
         self._n, self._nn = n, n_new
-        f = C.POINTER(C.c_float)
-        self.ctx.check(self.lib.vo_stereo_frame_enqueue(
-            self.ctx.handle, C.byref(self.prm), slots[0], slots[1], slots[2],
-            C.cast(C.c_void_p(d_pts_l0), f), C.cast(C.c_void_p(d_pts_r0), f),
-            C.cast(C.c_void_p(d_Xp), f), n, _p(dT), C.cast(C.c_void_p(d_pts_new), f), n_new, 1))
+        rc = self.lib.vo_stereo_frame_enqueue(self.ctx.handle, self.prm, slots[0], slots[1], slots[2], d_pts_l0, d_pts_r0,
+                                              d_Xp, n, dT.ctypes.data, d_pts_new, n_new, 1)
+        if rc < 0:
+            self.ctx.check(rc)
 
     def _buffers(self, n, nn):
         key = (n, nn)
@@ -510,7 +511,9 @@ class StereoFramePipeline:
         next result() overwrites (what a frame-by-frame consumer needs; no allocations)."""
         n, nn = self._n, self._nn
         b = self._buffers(n, nn)
-        self.ctx.check(self.lib.vo_stereo_frame_result(self.ctx.handle, *self._args))
+        rc = self.lib.vo_stereo_frame_result(self.ctx.handle, *self._args)
+        if rc < 0:
+            self.ctx.check(rc)
         out = dict(pts_l1=b["pts_l1"][:n], pts_r1=b["pts_r1"][:n], stage=b["stage"][:n], dT=b["dT"].reshape(4, 4),
                    pts_new_r=b["pnr"][:nn], mask_new=b["mnew"][:nn].view(bool), counts=b["counts"], gn=b["gn"])
         if copy:
