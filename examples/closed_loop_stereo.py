@@ -9,8 +9,12 @@ libvo_hip.so, the landmark bookkeeping in between is a few numpy arrays on the h
                 [8] survivors = BA inliers; their 3-D points re-triangulated in the new camera frame
                 [9] updateWeightBin(survivors), extractORBwithBinning_fast       (:691-693)
                 [10] trackBidirection l1 -> r1 of the candidates, new landmarks  (:708-760)
-Keyframes, local BA and the landmark graph of the reference are not modelled: this is the odometry
-front end only. It exists to show that the operators compose into a working odometry (trajectory against
+With --lba every third frame becomes a stereo keyframe and the window of the last nine is bundle-adjusted
+(MotionEstimator::localBundleAdjustmentSparseSolver_Stereo, motion_estimator.cpp:1219-1340): `LocalBA` below is the
+numeric part of SparseBAParameters::setPosesAndPoints (sparse_ba_parameters.h:283-440: reference frame = first
+keyframe of the window, translations scaled by 1/10, first two keyframes fixed, landmarks seen in at least two
+keyframes) and of the solver's finalisation (sparse_bundle_adjustment.cpp:645-745), around vo_sba_solve. The
+reference's keyframe selection and landmark graph are not modelled: tracks are (id, pixel, pixel) rows. It exists to show that the operators compose into a working odometry (trajectory against
 the renderer's ground truth), not as a benchmark.
 
 usage: python examples/closed_loop_stereo.py [--frames 30]"""
@@ -34,7 +38,73 @@ def triangulate(pl, pr, K, baseline):
     return X, ok & (z < 80.0)
 
 
-def run(n_frames=30, seed=2, n_bins=(40, 16), thres_fast=15, verbose=False):
+class LocalBA:
+    """Window of stereo keyframes + the observations of the tracks on them; solve() = one local BA."""
+    POSE_SCALE = 10.0   # SparseBAParameters::pose_scale_
+    WINDOW, N_FIX = 9, 2  # kitti_00_stereo.yaml:83, motion_estimator.cpp:1245
+
+    def __init__(self, V, ctx, K, T_lr):
+        from visual_odometry_ros_amd.api import SparseBundleAdjustmentSolver
+        self.K, self.T_lr = np.asarray(K, np.float64), np.asarray(T_lr, np.float64)
+        self.solver = SparseBundleAdjustmentSolver(ctx, True)
+        T_s = self.T_lr.copy()
+        T_s[:3, 3] /= self.POSE_SCALE  # scalingPose(T_stereo_), sparse_ba_parameters.h:295-299
+        self.solver.setStereoCameras(self.K, self.K, T_s)
+        self.solver.setHuberThreshold(0.5)  # motion_estimator.cpp:1232
+        self.kf_pose, self.kf_obs = [], []  # T_wc per keyframe ; {track id: (pl, pr)} per keyframe
+        self.Xw = {}                        # track id -> world point
+
+    def add_keyframe(self, T_wc, ids, pl, pr, Xc):
+        for i, X in zip(ids, Xc):
+            if i not in self.Xw:
+                self.Xw[i] = T_wc[:3, :3] @ X + T_wc[:3, 3]
+        self.kf_pose.append(T_wc.copy())
+        self.kf_obs.append({int(i): (a, b) for i, a, b in zip(ids, pl, pr)})
+
+    def solve(self):
+        """Returns (keyframe indices of the window, their poses before, after, avg pixel error per iteration)."""
+        win = list(range(max(0, len(self.kf_pose) - self.WINDOW), len(self.kf_pose)))
+        if len(win) < 3:  # NUM_MINIMUM_REQUIRED_KEYFRAMES
+            return None
+        T_ref_w = np.linalg.inv(self.kf_pose[win[0]])  # Tjw_ref_
+        T_jw = []
+        for k in win:  # changeInvPoseWorldToRef + scalingPose
+            T = np.linalg.inv(self.kf_pose[k]) @ self.kf_pose[win[0]]
+            T[:3, 3] /= self.POSE_SCALE
+            T_jw.append(T)
+        seen = {}
+        for j, k in enumerate(win):
+            for i in self.kf_obs[k]:
+                seen.setdefault(i, []).append(j)
+        lms = [i for i, js in seen.items() if len(js) >= 2]  # THRES_MINIMUM_SEEN
+        if len(lms) < 20:
+            return None
+        X, obs_ptr, obs_frame, obs_right, obs_px = [], [0], [], [], []
+        for i in lms:
+            X.append((T_ref_w[:3, :3] @ self.Xw[i] + T_ref_w[:3, 3]) / self.POSE_SCALE)  # warpToRef + scalingPoint
+            for j in seen[i]:
+                pl, pr = self.kf_obs[win[j]][i]
+                obs_frame += [j, j]
+                obs_right += [0, 1]
+                obs_px += [pl, pr]
+            obs_ptr.append(len(obs_frame))
+        opt = np.array([-1] * self.N_FIX + list(range(len(win) - self.N_FIX)), np.int32)
+        ok, T_new, X_new, err = self.solver.solveForFiniteIterations(
+            10, np.stack(T_jw), opt, np.stack(X), np.array(obs_ptr, np.int32), np.array(obs_frame, np.int32),
+            np.array(obs_right, np.uint8), np.array(obs_px, np.float64))
+        before = [self.kf_pose[k].copy() for k in win]
+        for j, k in enumerate(win):  # recoverOriginalScalePose, changeInvPoseRefToWorld, setPose(inverse)
+            if opt[j] >= 0:
+                T = T_new[j].copy()
+                T[:3, 3] *= self.POSE_SCALE
+                self.kf_pose[k] = self.kf_pose[win[0]] @ np.linalg.inv(T)
+        T_w_ref = before[0]
+        for i, x in zip(lms, X_new):  # recoverOriginalScalePoint, warpToWorld
+            self.Xw[i] = T_w_ref[:3, :3] @ (x * self.POSE_SCALE) + T_w_ref[:3, 3]
+        return win, before, [self.kf_pose[k].copy() for k in win], err
+
+
+def run(n_frames=30, seed=2, n_bins=(40, 16), thres_fast=15, verbose=False, lba=False):
     import visual_odometry_ros_amd as V
     from visual_odometry_ros_amd import synthetic as S
     from visual_odometry_ros_amd.api import StereoFramePipeline, make_stereo_params
@@ -65,6 +135,12 @@ def run(n_frames=30, seed=2, n_bins=(40, 16), thres_fast=15, verbose=False):
     ctx.set_image(CL, L)
     ctx.set_image(CR, R)
     pts_l, pts_r, X = new_landmarks(CL, CR, np.zeros((0, 2), np.float32))
+    ids = np.arange(pts_l.shape[0])
+    next_id = ids.size
+    ba = LocalBA(V, ctx, K, stream.T_lr) if lba else None
+    ba_log = []
+    if ba:
+        ba.add_keyframe(poses[0], ids, pts_l, pts_r, X)
     T_wc = [poses[0].copy()]
     dT_prev = np.eye(4, dtype=np.float32)
     log = []
@@ -81,7 +157,23 @@ def run(n_frames=30, seed=2, n_bins=(40, 16), thres_fast=15, verbose=False):
         pl1, pr1 = r["pts_l1"][inl], r["pts_r1"][inl]
         Xc, ok = triangulate(pl1, pr1, K, b)  # [8]: the survivors' points in the new camera frame
         pl1, pr1, Xc = pl1[ok], pr1[ok], Xc[ok]
+        ids = ids[inl][ok]
+        if ba and k % 3 == 0:  # a stereo keyframe: the live tracks' observations, then the window's local BA
+            ba.add_keyframe(T_wc[-1], ids, pl1, pr1, Xc)
+            out = ba.solve()
+            if out is not None:
+                kf_win, before, after, err = out
+                gt = [poses[3 * w] for w in kf_win]
+                e0 = float(np.mean([np.linalg.norm(b[:3, 3] - g[:3, 3]) for b, g in zip(before, gt)]))
+                e1 = float(np.mean([np.linalg.norm(a_[:3, 3] - g[:3, 3]) for a_, g in zip(after, gt)]))
+                ba_log.append(dict(frame=k, keyframes=len(kf_win), err_first=float(err[0]), err_last=float(err[-1]),
+                                   kf_pos_err_before=e0, kf_pos_err_after=e1))
+                if verbose:
+                    print("LBA", ba_log[-1])
+                T_wc[-1] = ba.kf_pose[-1].copy()  # the odometry continues from the adjusted keyframe pose
         nl, nr, nX = new_landmarks(CL, CR, pl1)
+        ids = np.concatenate([ids, np.arange(next_id, next_id + nl.shape[0])])
+        next_id += nl.shape[0]
         log.append(dict(frame=k, tracked=int(pts_l.shape[0]), inliers=int(inl.sum()), new=int(nl.shape[0]),
                         gn_iterations=int(r["counts"].gn_iterations)))
         if verbose:
@@ -98,14 +190,15 @@ def run(n_frames=30, seed=2, n_bins=(40, 16), thres_fast=15, verbose=False):
     return dict(frames=n_frames, path_m=float(path), end_error_m=float(np.linalg.norm(est[-1] - gt[-1])),
                 ate_rmse_m=float(np.sqrt(np.mean(np.sum((est - gt) ** 2, axis=1)))), max_step_error=float(max(rel)),
                 mean_tracked=float(np.mean([e["tracked"] for e in log])), mean_inliers=float(np.mean([e["inliers"] for e in log])),
-                log=log)
+                log=log, lba=ba_log)
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=30)
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--lba", action="store_true", help="stereo keyframe every third frame + local BA of the window")
     a = ap.parse_args()
-    out = run(a.frames, verbose=a.verbose)
+    out = run(a.frames, verbose=a.verbose, lba=a.lba)
     out.pop("log")
     print(json.dumps(out))

@@ -19,3 +19,16 @@ def test_closed_loop_stereo_follows_ground_truth(vo):
     assert r["end_error_m"] < 0.02 * r["path_m"]  # < 2 % drift over the run
     assert r["max_step_error"] < 0.05
     assert all(e["new"] > 0 for e in r["log"][:5])  # bins freed by lost tracks are refilled
+
+
+def test_closed_loop_with_local_bundle_adjustment(vo):
+    """Every third frame a stereo keyframe, the window bundle-adjusted through vo_sba_solve (the numeric part of
+    SparseBAParameters around it is in the example): every solve lowers the window's reprojection error, keyframe
+    poses stay at the millimetre level of the odometry, the trajectory still follows the ground truth."""
+    import closed_loop_stereo as E
+    r = E.run(n_frames=22, lba=True)
+    assert len(r["lba"]) >= 5
+    for e in r["lba"]:
+        assert e["err_last"] < e["err_first"] and e["err_last"] < 1.0
+        assert e["kf_pos_err_after"] < 1.5 * e["kf_pos_err_before"] + 1e-3
+    assert r["end_error_m"] < 0.02 * r["path_m"]
