@@ -28,7 +28,8 @@
  * softdouble arithmetic (= IEEE double, one rounding per operation); horizontal pass in 8.8, vertical pass
  * 8.8 x 8.8 -> 16.16, rounded to the byte with +0.5. */
 static void linear_exact_coeffs(int src_size, int dst_size, int *ofs, int *c1, int *dst_min, int *dst_max) {
-  const double scale = (double)src_size / (double)dst_size;
+  /* interpolationLinear(inv_scale, ..): scale = softdouble::one() / softdouble(inv_scale), inv_scale = dst / src */
+  const double scale = 1.0 / ((double)dst_size / (double)src_size);
   *dst_min = 0;
   *dst_max = dst_size;
   for (int v = 0; v < dst_size; ++v) {

@@ -446,7 +446,8 @@ void vo_orb_free(vo_ctx *c) {
 
 // resize.cpp interpolationLinear<uchar>::getCoeffs on softdouble (= IEEE double, one rounding per operation)
 static void orb_linear_exact_coeffs(int src_size, int dst_size, std::vector<int> &ofs, std::vector<int> &c1) {
-  const double scale = (double)src_size / (double)dst_size;
+  // interpolationLinear(inv_scale, ..): scale = softdouble::one() / softdouble(inv_scale), inv_scale = dst / src
+  const double scale = 1.0 / ((double)dst_size / (double)src_size);
   ofs.assign(dst_size, 0);
   c1.assign(dst_size, 0);
   for (int v = 0; v < dst_size; ++v) {
