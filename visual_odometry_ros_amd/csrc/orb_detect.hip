@@ -279,6 +279,7 @@ __device__ __forceinline__ int orb_hist_rank(const int *hist, int rank, int *abo
 // candidates, else everything >= the score of rank 2 n_l stays; (2) Harris response among those: everything >= the
 // response of rank n_l (4-pass radix select on the ordered key). Also the number of survivors.
 #define ORB_ST 1024
+#define ORB_RC 16  // candidates per lane that the fast path of orb_select_kernel keeps in registers
 __global__ __launch_bounds__(ORB_ST) void orb_select_kernel(OrbDev d) {
   __shared__ int s_hist[256];
   __shared__ unsigned s_prefix;
@@ -288,6 +289,73 @@ __global__ __launch_bounds__(ORB_ST) void orb_select_kernel(OrbDev d) {
   const int n = d.lvl_total[l] > d.cand_cap ? 0 : d.lvl_total[l];
   const uint8_t *cs = d.cs + L.cand_base;
   const float *cr = d.cr + L.cand_base;
+  if (n <= ORB_RC * ORB_ST) {
+    // Fast path (every level of a KITTI-sized image): the candidates of a lane live in registers, and both cuts are
+    // found by bisection on the value — count(x >= t) over the workgroup per step, no atomics, no histogram contention
+    // (scores cluster in a few bins, responses share their leading byte).
+    __shared__ int s_part[ORB_ST / 64];
+    const int lane = tid & 63, wave = tid >> 6;
+    unsigned key[ORB_RC];  // score in pass 1, then the ordered response (0 = dropped by the score cut)
+    float resp[ORB_RC];
+#pragma unroll
+    for (int q = 0; q < ORB_RC; ++q) {
+      const int i = tid + q * ORB_ST;
+      key[q] = i < n ? (unsigned)cs[i] + 1u : 0u;  // 0 = no candidate
+      resp[q] = i < n ? cr[i] : 0.f;
+    }
+    auto count_ge = [&](unsigned t) {
+      int c = 0;
+#pragma unroll
+      for (int q = 0; q < ORB_RC; ++q) c += key[q] >= t;
+      c = wave_sum_i32(c);
+      __syncthreads();  // s_part of the previous step has been consumed
+      if (lane == 0) s_part[wave] = c;
+      __syncthreads();
+      int tot = 0;
+#pragma unroll
+      for (int w = 0; w < ORB_ST / 64; ++w) tot += s_part[w];
+      return tot;
+    };
+    // (1) retainBest(2 n_l) on the FAST score
+    int cut = 0;
+    const int keep = 2 * L.quota;
+    if (n > keep) {
+      if (keep == 0) {
+        cut = 256;
+      } else {
+        unsigned t = 0;  // largest t with count(score + 1 >= t) >= keep
+        for (int bit = 8; bit >= 0; --bit) {
+          const unsigned cand = t | (1u << bit);
+          if (count_ge(cand) >= keep) t = cand;
+        }
+        cut = (int)t - 1;
+      }
+    }
+    // (2) retainBest(n_l) on the Harris response of what is left
+#pragma unroll
+    for (int q = 0; q < ORB_RC; ++q) key[q] = (key[q] != 0u && (int)key[q] - 1 >= cut) ? orb_ord(resp[q]) : 0u;
+    const int kept = count_ge(1u);
+    unsigned rcut = 0u;
+    if (kept > L.quota) {
+      if (L.quota == 0) {
+        rcut = 0xFFFFFFFFu;
+      } else {
+        unsigned t = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+          const unsigned cand = t | (1u << bit);
+          if (count_ge(cand) >= L.quota) t = cand;
+        }
+        rcut = t;
+      }
+    }
+    const int surv = rcut == 0u ? kept : (rcut == 0xFFFFFFFFu ? count_ge(0xFFFFFFFFu) : count_ge(rcut));
+    if (tid == 0) {
+      d.lvl_cut[l] = cut;
+      d.lvl_rcut[l] = rcut;
+      d.hist[l] = surv;
+    }
+    return;
+  }
   if (tid < 256) s_hist[tid] = 0;
   if (tid == 0) s_surv = 0;
   __syncthreads();
