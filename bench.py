@@ -10,7 +10,8 @@ sequence of StereoVO::trackStereoImages (stereo_vo.cpp:483-711) — with the res
 Inputs (images and track sets) are resident in HBM before the timed region.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL gather of the totals)
+  (N > 1: one rank per GPU, RCCL gather of the totals; under torch.distributed.run the ranks are the launcher's,
+   without a launcher environment bench.py starts the N ranks itself as fresh child processes)
 
 Prints ONE JSON line on rank 0 (see DESIGN.md §Measurement for every field).
 """
@@ -50,23 +51,87 @@ def frame_kernel_bytes(win, n, n_l0l1, n_step5, n_new, levels, levels_bwd, stric
     return klt + IC_BYTES_PER_POINT * n_l0l1 + (IC_RECORD_BYTES * n if strict else 0) + POINT_IO_BYTES * (n + n_new)
 
 
-def aggregate(frames, seconds, world, device=None):
-    """Whole-job totals: every rank ran `frames` frames of its own stream in `seconds`.
-    One all_gather of {frames, seconds} (RCCL on GPUs, gloo in the CPU test): 16 B per rank.
-    Returns (total frames, max seconds over ranks)."""
+def gather_ranks(frames, seconds, seed, world, device=None):
+    """The one collective of the job: an all_gather of {frames, seconds, stream seed} per rank
+    (RCCL on GPUs, gloo in the CPU tests), 24 B per rank. Returns the per-rank list [(frames, seconds, seed)]."""
     if world <= 1:
-        return float(frames), float(seconds)
+        return [(float(frames), float(seconds), int(seed))]
     import torch
     import torch.distributed as dist
-    mine = torch.tensor([float(frames), float(seconds)], dtype=torch.float64, device=device)
+    mine = torch.tensor([float(frames), float(seconds), float(seed)], dtype=torch.float64, device=device)
     allv = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(allv, mine)
-    return sum(float(v[0]) for v in allv), max(float(v[1]) for v in allv)
+    return [(float(v[0]), float(v[1]), int(v[2])) for v in allv]
+
+
+def aggregate(frames, seconds, world, device=None):
+    """Whole-job totals: every rank ran `frames` frames of its own stream in `seconds`.
+    Returns (total frames, max seconds over ranks)."""
+    per = gather_ranks(frames, seconds, 0, world, device)
+    return sum(p[0] for p in per), max(p[1] for p in per)
 
 
 def stream_seed(rank):
     """Independent image stream per rank (stream s -> GPU s)."""
     return 2 + rank
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher environment: this (parent) process starts N FRESH child
+    interpreters, one per GPU, before it has imported torch or made any HIP call — it never touches a GPU and no
+    GPU-initialised process is ever re-exec'ed. The children rendezvous on 127.0.0.1; rank 0 prints the one JSON
+    line, which is relayed. Returns the exit code (first non-zero child code)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    # wait for all ranks; if one fails, the others would sit in the rendezvous / barrier forever: end them
+    # (rank 0 writes one line; a pipe of that size cannot fill up while we poll)
+    rc = 0
+    while any(p.poll() is None for p in procs):
+        bad = [p for p in procs if p.poll() not in (None, 0)]
+        if bad:
+            rc = bad[0].returncode
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()  # exactly the children started above
+            break
+        time.sleep(0.05)
+    out0 = procs[0].stdout.read()
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    for ln in out0.splitlines():  # the JSON line goes to stdout; library chatter of the child (gloo's connect note) to stderr
+        (sys.stdout if ln.startswith("{") else sys.stderr).write(ln + "\n")
+    sys.stdout.flush()
+    return rc
+
+
+def rendezvous_check(rank, world):
+    """--rendezvous-check: the N > 1 control flow of this file (launcher, rank environment, process group,
+    per-rank stream seeds, the gather, rank-0-only JSON) with gloo and no HIP call, so that it runs on a
+    machine without GPUs (tests/test_bench_dist.py)."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    per = gather_ranks(100 + rank, 0.5 + 0.25 * rank, stream_seed(rank), world)
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        tot, mx = sum(p[0] for p in per), max(p[1] for p in per)
+        print(json.dumps({"rendezvous_check": True, "n_gpus": world, "value": tot / mx,
+                          "per_rank": [{"frames": p[0], "seconds": p[1], "stream_seed": p[2]} for p in per]}),
+              flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -81,11 +146,19 @@ def main():
     ap.add_argument("--detect", action="store_true",
                     help="also run the keypoint detection + bucketing of the current left image every frame "
                          "(side stream, overlapping the frame operator); not part of the default workload")
+    ap.add_argument("--rendezvous-check", action="store_true",
+                    help="run only the multi-rank control flow (gloo, no GPU work) and print its JSON line")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))  # nothing GPU-related has been imported yet
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher environment has WORLD_SIZE={world}")
+    if args.rendezvous_check:
+        return rendezvous_check(rank, world)
 
     # torch first: its bundled libamdhip64.so.7 must be THE HIP runtime of the process;
     # libvo_hip.so (NEEDED libamdhip64.so.7) then binds to the already-loaded one.
@@ -215,7 +288,8 @@ def main():
     dt = time.perf_counter() - t0
     gc.enable()
 
-    tot_frames, max_dt = aggregate(K, dt, world, dev)
+    per_rank = gather_ranks(K, dt, stream_seed(rank), world, dev)
+    tot_frames, max_dt = sum(p[0] for p in per_rank), max(p[1] for p in per_rank)
 
     out = None
     if rank == 0:
@@ -268,6 +342,7 @@ def main():
                 "avg_launch_us": round(1e3 * klt_ms / max(klt_n, 1), 2),
             },
             "kernels": per_kernel,
+            "per_rank_fps": [round(p[0] / p[1], 2) for p in per_rank],
         }
 
         if world == 1 and not args.no_cpu_baseline:

@@ -26,7 +26,7 @@ def build(force=False):
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs
     )
     if force or stale:
-        subprocess.check_call(["make", "-C", _HERE, "-s"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []), stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
 

@@ -82,3 +82,15 @@ def test_every_entry_point_rejects_null_arguments(vo):
             assert f(*call) < 0, name
         finally:
             f.argtypes = saved
+
+
+def test_build_reports_what_it_compiled():
+    """__graft_entry__.build() leaves a log of the translation units it compiled (hash-stamped objects)."""
+    import json
+    from visual_odometry_ros_amd import build as B
+    B.build()
+    log = json.load(open(B.LOG))
+    assert log["translation_units"] == len(B.sources()) and isinstance(log["compiled"], list)
+    for src in B.sources():
+        obj = os.path.join(B.LIBDIR, os.path.basename(src)[:-4] + ".o")
+        assert os.path.exists(obj + ".sha")

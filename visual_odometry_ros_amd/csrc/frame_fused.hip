@@ -360,9 +360,8 @@ int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, 
   if (prm->max_level < 0 || prm->win <= 2) VO_FAIL(c, VO_ERR_INVALID, "maxLevel >= 0 && winSize > 2 violated");
   FrameArgs a;
   memset(&a, 0, sizeof(a));
-  int eff = vo_pyr_levels_host(P0.w, P0.h, prm->win, prm->max_level);
-  for (const vo_pyramid *P : {&P0, &P1, &P2})
-    if (eff > P->n_levels - 1) eff = P->n_levels - 1;
+  const int eff = vo_pyr_levels_host(P0.w, P0.h, prm->win, prm->max_level);
+  for (const vo_pyramid *P : {&P0, &P1, &P2}) VO_NEED_LEVELS(c, *P, eff);
   for (int l = 0; l <= eff; ++l) {
     a.L0[l] = P0.lv[l];
     a.L1[l] = P1.lv[l];

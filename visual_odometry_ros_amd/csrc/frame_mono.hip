@@ -189,6 +189,9 @@ extern "C" int vo_mono_frame_enqueue(vo_ctx *c, const vo_mono_params *prm, int s
   int rc = vo_frame_init(c);
   if (rc < 0) return rc;
   vo_frame_state *f = c->frame;
+  // one result block, one staging set and one completion event per context: a second frame would overwrite them
+  // while the first one's kernels still use them
+  if (f->pending) VO_FAIL(c, VO_ERR_INVALID, "a frame is already in flight: call vo_mono_frame_result first");
   hipStream_t s = c->stream;
   const float *d_p0 = pts0, *d_X = Xw;
   const uint8_t *d_fl = flags;
@@ -219,9 +222,9 @@ extern "C" int vo_mono_frame_enqueue(vo_ctx *c, const vo_mono_params *prm, int s
     if (P0.w != P1.w || P0.h != P1.h) VO_FAIL(c, VO_ERR_SIZE, "image size mismatch");
     MonoArgs a;
     memset(&a, 0, sizeof(a));
-    int eff = vo_pyr_levels_host(P0.w, P0.h, prm->win, prm->max_level);
-    if (eff > P0.n_levels - 1) eff = P0.n_levels - 1;
-    if (eff > P1.n_levels - 1) eff = P1.n_levels - 1;
+    const int eff = vo_pyr_levels_host(P0.w, P0.h, prm->win, prm->max_level);
+    VO_NEED_LEVELS(c, P0, eff);
+    VO_NEED_LEVELS(c, P1, eff);
     for (int l = 0; l <= eff; ++l) {
       a.I0[l] = P0.lv[l];
       a.I1[l] = P1.lv[l];

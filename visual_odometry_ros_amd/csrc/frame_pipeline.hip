@@ -120,6 +120,9 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
   ++vo_tt_n;
 #endif
   vo_frame_state *f = c->frame;
+  // one result block, one staging set and one completion event per context: a second frame would overwrite them
+  // while the first one's kernels still use them
+  if (f->pending) VO_FAIL(c, VO_ERR_INVALID, "a frame is already in flight: call vo_stereo_frame_result first");
   hipStream_t s = c->stream;
   const float *d_l0 = pts_l0, *d_r0 = pts_r0, *d_X = Xp, *d_new = pts_new;
   if (!inputs_on_device) {

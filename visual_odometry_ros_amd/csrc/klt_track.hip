@@ -132,9 +132,9 @@ int vo_klt_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, const f
   if (n_max <= 0) return VO_OK;
   KltArgs a;
   memset(&a, 0, sizeof(a));
-  int eff = vo_pyr_levels_host(P0.w, P0.h, win, max_level);
-  if (eff > P0.n_levels - 1) eff = P0.n_levels - 1;
-  if (eff > P1.n_levels - 1) eff = P1.n_levels - 1;
+  const int eff = vo_pyr_levels_host(P0.w, P0.h, win, max_level);
+  VO_NEED_LEVELS(c, P0, eff);
+  VO_NEED_LEVELS(c, P1, eff);
   for (int l = 0; l <= eff; ++l) {
     a.I[l] = P0.lv[l];
     a.J[l] = P1.lv[l];

@@ -100,6 +100,19 @@ struct vo_ctx {
     return (code);                                             \
   } while (0)
 
+// A call needs pyramid levels 0..eff of a slot. Fewer were built when vo_config.max_level is below the call's
+// maxLevel or when vo_set_pyramid_window_hint() named a LARGER window than the call uses (a larger window stops
+// the pyramid earlier): tracking with fewer levels than cv::buildOpticalFlowPyramid would build diverges from the
+// reference, so it is an error, not a clamp.
+#define VO_NEED_LEVELS(ctx, P, eff)                                                                                  \
+  do {                                                                                                               \
+    if ((eff) > (P).n_levels - 1)                                                                                    \
+      VO_FAIL(ctx, VO_ERR_INVALID,                                                                                   \
+              "the slot's pyramid holds levels 0..%d, this call needs 0..%d: raise vo_config.max_level, or give "    \
+              "vo_set_pyramid_window_hint the SMALLEST window in use",                                               \
+              (P).n_levels - 1, (eff));                                                                              \
+  } while (0)
+
 // ---- profiling brackets (no-ops unless vo_profile_enable was called) --------
 static inline void vo_prof_begin(vo_ctx *c, int cls) {
   c->prof_open = 0;
