@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define VO_HIP_ABI_VERSION 1
+#define VO_HIP_ABI_VERSION 2
 
 typedef enum {
   VO_OK = 0,
@@ -242,7 +242,11 @@ typedef struct {
   int n_l0l1, n_refine, n_l1r1, n_inlier, n_new_ok;
   int gn_iterations;
   int n_replayed; /* strict border: features whose refinement was replayed (their IC window left the image) */
+  int n_ba;       /* size of the pose-only BA set: survivors of [5] whose landmark is triangulated (stereo_vo.cpp:599) */
 } vo_frame_counts;
+
+/* flags[i] of a tracked feature: bit 0 = lm->isTriangulated() */
+#define VO_LM_TRIANGULATED 1
 
 /* strict != 0: the frame's trackWithScale step replays border-touching points
  * with the reference's never-reset tap state (same as vo_track_with_scale's
@@ -251,13 +255,21 @@ int vo_stereo_frame_set_strict_border(vo_ctx *ctx, int strict);
 
 /* Asynchronous: enqueues one frame on the context stream. slot_l0 must hold the
  * previous left pyramid, slot_l1 / slot_r1 the current pair. Track-set inputs
- * are DEVICE pointers when `inputs_on_device` != 0, else host pointers. */
+ * are DEVICE pointers when `inputs_on_device` != 0, else host pointers.
+ * flags[i] bit 0 (VO_LM_TRIANGULATED) = lm->isTriangulated() of feature i; NULL = every landmark is
+ * triangulated. New stereo landmarks stay untriangulated until the next keyframe (stereo_vo.cpp:736, :794), so a
+ * real track set is a mix: an untriangulated feature takes pts_l0 / pts_r0 as prior and patch scale 1
+ * (stereo_vo.cpp:490, :515-519), goes through [4], [4-1], [5] like every other, stays out of the pose-only BA
+ * (:599) with mask_motion = true (:582) and meets the y > 660 gate of [7] (:653-668). Xp[i] (the landmark in the
+ * previous left camera frame, T_pw * X) is read only where the bit is set.
+ * One frame in flight per context (VO_ERR_INVALID otherwise). */
 int vo_stereo_frame_enqueue(vo_ctx *ctx, const vo_stereo_params *prm, int slot_l0, int slot_l1,
                             int slot_r1, const float *pts_l0, const float *pts_r0,
-                            const float *Xp, int n, const float dT_prior[16],
+                            const float *Xp, const uint8_t *flags, int n, const float dT_prior[16],
                             const float *pts_new, int n_new, int inputs_on_device);
 /* Waits for the last enqueued frame and copies its results to host buffers
- * (any of which may be NULL). stage[i] = number of gates point i passed (0..4). */
+ * (any of which may be NULL). stage[i] = number of gates point i passed (0..4):
+ * 1 [4], 2 [4-1], 3 [5], 4 = in lmtrack_final (BA inlier or untriangulated, and past the gate of [7]). */
 int vo_stereo_frame_result(vo_ctx *ctx, float *pts_l1, float *pts_r1, uint8_t *stage,
                            float dT[16], float *pts_new_r, uint8_t *mask_new,
                            vo_frame_counts *counts, vo_gn_info *gn);

@@ -64,6 +64,7 @@ class FrameCounts(C.Structure):
         ("n_inlier", C.c_int),
         ("n_new_ok", C.c_int),
         ("gn_iterations", C.c_int),
+        ("n_ba", C.c_int),
     ]
 
 
@@ -399,7 +400,7 @@ def mono_frame(prm, I0, I1, pts0, Xw, flags, Tcw_prev, Tcw_prior, dT01_prior, su
 
 
 def stereo_frame(prm, I0l, I1l, I1r, pts_l0, pts_r0, Xp, dT_prior, pts_new, sum_mode=SUM_TREE,
-                 tree_width=512, ic_border_mode=IC_MASKED, n_threads=1):
+                 tree_width=512, ic_border_mode=IC_MASKED, n_threads=1, lm_flags=None):
     I0l, w, h, st = _img(I0l)
     I1l, _, _, _ = _img(I1l)
     I1r, _, _, _ = _img(I1r)
@@ -416,9 +417,12 @@ def stereo_frame(prm, I0l, I1l, I1r, pts_l0, pts_r0, Xp, dT_prior, pts_new, sum_
     mnew = np.zeros(max(nn, 1), np.uint8)
     counts = FrameCounts()
     dTp = _f32(dT_prior).reshape(16)
+    fl = None if lm_flags is None else np.ascontiguousarray(lm_flags, np.uint8)
+    assert fl is None or fl.shape[0] == n
     rc = lib().vo_ref_stereo_frame(
         C.byref(prm), _p(I0l, C.c_uint8), _p(I1l, C.c_uint8), _p(I1r, C.c_uint8), st, _p(pts_l0),
-        _p(Xp), n, _p(dTp), _p(pts_new), nn, sum_mode, tree_width, ic_border_mode, n_threads,
+        _p(Xp), None if fl is None else _p(fl, C.c_uint8), n, _p(dTp), _p(pts_new), nn, sum_mode, tree_width,
+        ic_border_mode, n_threads,
         _p(pts_l1), _p(pts_r1), _p(stage, C.c_uint8), _p(dT), _p(pnr), _p(mnew, C.c_uint8),
         C.byref(counts))
     return dict(rc=rc, pts_l1=pts_l1[:n], pts_r1=pts_r1[:n], stage=stage[:n], dT=dT.reshape(4, 4),

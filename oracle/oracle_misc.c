@@ -115,7 +115,7 @@ static void xform(const float T[16], const float X[3], float Y[3]) {
  */
 int vo_ref_stereo_frame(const vo_ref_stereo_params *prm, const uint8_t *I0l,
                         const uint8_t *I1l, const uint8_t *I1r, int stride,
-                        const float *pts_l0, const float *Xp, int n,
+                        const float *pts_l0, const float *Xp, const uint8_t *lm_flags, int n,
                         const float dT_prior[16], const float *pts_new,
                         int n_new, int sum_mode, int tree_width,
                         int ic_border_mode, int n_threads, float *pts_l1,
@@ -135,8 +135,17 @@ int vo_ref_stereo_frame(const vo_ref_stereo_params *prm, const uint8_t *I0l,
   float *aX = (float *)malloc(sizeof(float) * 3 * ((size_t)n + 1));
   float *as = (float *)malloc(sizeof(float) * ((size_t)n + 1));
   memset(counts, 0, sizeof(*counts));
-  /* [3] priors; pts_r1 holds pts_r0 on entry */
+  /* [3] priors; pts_r1 holds pts_r0 on entry. lm_flags[i] bit 0 = lm->isTriangulated() (stereo_vo.cpp:490);
+   * NULL = every landmark is triangulated */
   for (int i = 0; i < n; ++i) {
+    stage_mask[i] = 0;
+    idx[i] = i;
+    if (lm_flags && !(lm_flags[i] & 1)) { /* :515-519: prior = previous pixels, scale_tmp stays 1 */
+      scale[i] = 1.0f;
+      pts_l1[2 * i] = pts_l0[2 * i];
+      pts_l1[2 * i + 1] = pts_l0[2 * i + 1];
+      continue;
+    }
     float Xl1[3], Xr1[3];
     xform(T_cp, Xp + 3 * i, Xl1);
     xform(T_rl, Xl1, Xr1);
@@ -154,8 +163,6 @@ int vo_ref_stereo_frame(const vo_ref_stereo_params *prm, const uint8_t *I0l,
       pts_r1[2 * i] = prx;
       pts_r1[2 * i + 1] = pry;
     }
-    stage_mask[i] = 0;
-    idx[i] = i;
   }
   int cur = n;
   /* [4] l0 -> l1 */
@@ -219,32 +226,40 @@ int vo_ref_stereo_frame(const vo_ref_stereo_params *prm, const uint8_t *I0l,
   }
   cur = c;
   counts->n_l1r1 = cur;
-  /* [6] stereo pose-only BA */
+  /* [6] stereo pose-only BA on the triangulated survivors (:595-613); mask_motion starts true (:582) and is
+   * overwritten only at index_poBA (:631-638) */
+  int nba = 0;
   for (int i = 0; i < cur; ++i) {
     int o = idx[i];
-    a0[2 * i] = pts_l1[2 * o];
-    a0[2 * i + 1] = pts_l1[2 * o + 1];
-    a2[2 * i] = pts_r1[2 * o];
-    a2[2 * i + 1] = pts_r1[2 * o + 1];
-    aX[3 * i] = Xp[3 * o];
-    aX[3 * i + 1] = Xp[3 * o + 1];
-    aX[3 * i + 2] = Xp[3 * o + 2];
+    if (lm_flags && !(lm_flags[o] & 1)) continue;
+    a0[2 * nba] = pts_l1[2 * o];
+    a0[2 * nba + 1] = pts_l1[2 * o + 1];
+    a2[2 * nba] = pts_r1[2 * o];
+    a2[2 * nba + 1] = pts_r1[2 * o + 1];
+    aX[3 * nba] = Xp[3 * o];
+    aX[3 * nba + 1] = Xp[3 * o + 1];
+    aX[3 * nba + 2] = Xp[3 * o + 2];
+    ++nba;
   }
+  counts->n_ba = nba;
   memcpy(dT_out, dT_prior, sizeof(float) * 16);
   vo_ref_gn_info gi;
-  rc = vo_ref_gn_pose_stereo(aX, a0, a2, cur, prm->Kl, prm->Kr, prm->T_lr, prm->thres_poseba,
+  rc = vo_ref_gn_pose_stereo(aX, a0, a2, nba, prm->Kl, prm->Kr, prm->T_lr, prm->thres_poseba,
                              dT_out, m, sum_mode, tree_width, &gi);
   if (rc <= 0) {
     rc = -6; /* reference throws "PoseOnlyStereoBA is failed!" (:626) */
     goto fail;
   }
   counts->gn_iterations = gi.iterations;
-  /* [7] y > 660 gate (thres_sampson 60 < 100) */
+  /* [7] y > 660 gate (thres_sampson 60 < 100) on lmtrack_motion_ok (:653-668) */
   c = 0;
+  nba = 0;
   for (int i = 0; i < cur; ++i) {
     int o = idx[i];
+    int motion_ok = 1;
+    if (!(lm_flags && !(lm_flags[o] & 1))) motion_ok = m[nba++];
     float d = pts_l1[2 * o + 1] > 660 ? 100.f : 0.f;
-    if (m[i] && d < 60.0f) {
+    if (motion_ok && d < 60.0f) {
       stage_mask[o] = 4;
       ++c;
     }

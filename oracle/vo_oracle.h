@@ -157,11 +157,13 @@ typedef struct {
 typedef struct {
   int n_l0l1, n_refine, n_l1r1, n_inlier, n_new_ok;
   int gn_iterations;
+  int n_ba; /* size of the pose-only BA set (triangulated survivors of [5], stereo_vo.cpp:599) */
 } vo_ref_frame_counts;
 
 int vo_ref_stereo_frame(const vo_ref_stereo_params *prm, const uint8_t *I0l,
                         const uint8_t *I1l, const uint8_t *I1r, int stride,
                         const float *pts_l0, const float *Xp /* prev-cam */,
+                        const uint8_t *lm_flags /* bit 0 = isTriangulated(); NULL = all */,
                         int n, const float dT_prior[16] /* T_pc prior */,
                         const float *pts_new, int n_new, int sum_mode,
                         int tree_width, int ic_border_mode, int n_threads,

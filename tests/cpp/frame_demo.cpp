@@ -85,7 +85,9 @@ int main(int argc, char **argv) {
     vo::StereoFramePipeline pipe(ctx, prm, true);
     pipe.setFirstImage(vo::Image(L0.data(), w, h, w));
     pipe.pushStereoPair(vo::Image(L1.data(), w, h, w), vo::Image(R1.data(), w, h, w));
-    pipe.enqueue(vl0, vr0, vXp, pose(dTp), vnew);
+    vo::MaskVec tri(n);  // lm->isTriangulated(): bit 0 of the flag bytes (a mixed track set)
+    for (int i = 0; i < n; ++i) tri[i] = (flags[i] & 1) != 0;
+    pipe.enqueue(vl0, vr0, vXp, pose(dTp), vnew, tri);
     vo::StereoFrameResult r = pipe.result();
     int threw = 0;
     try {
@@ -94,8 +96,8 @@ int main(int argc, char **argv) {
     } catch (const std::runtime_error &) {
       threw = 1;
     }
-    const int head[4] = {r.pose_ok ? 1 : 0, r.counts.n_inlier, r.gn.iterations, threw};
-    wr(o, head, 4);
+    const int head[5] = {r.pose_ok ? 1 : 0, r.counts.n_inlier, r.gn.iterations, threw, r.counts.n_ba};
+    wr(o, head, 5);
     wr(o, r.dT_pc.data(), 16);
     wr(o, &r.pts_l1.data()->x, 2 * (size_t)n);
     wr(o, &r.pts_r1.data()->x, 2 * (size_t)n);

@@ -124,10 +124,11 @@ def test_cpp_frame_pipelines_match_python_api(vo, tmp_path):
         c.set_image(1, L1)
         c.set_image(2, R1)
         pipe = StereoFramePipeline(c, make_stereo_params(W, H, win, lvl, 80.0, 0.5, 3.0, K, K, stream.T_lr), True)
-        pipe.enqueue(ts["pts_l0"], ts["pts_r0"], ts["Xp"], dT, ts["pts_new"])
+        pipe.enqueue(ts["pts_l0"], ts["pts_r0"], ts["Xp"], dT, ts["pts_new"], lm_flags=flags & 1)
         g = pipe.result()
-        head = take(np.int32, 4)
+        head = take(np.int32, 5)
         assert head[0] == 1 and head[1] == g["counts"].n_inlier and head[2] == g["gn"].iterations and head[3] == 1
+        assert head[4] == g["counts"].n_ba and 0 < head[4] < g["counts"].n_l1r1
         assert g["counts"].n_inlier > 0.5 * n
         assert np.array_equal(take(np.float32, 16).reshape(4, 4), g["dT"])
         assert np.array_equal(take(np.float32, 2 * n).reshape(-1, 2), g["pts_l1"])

@@ -14,7 +14,9 @@ def rel_frob(A, B):
     return np.linalg.norm(np.asarray(A, np.float64) - np.asarray(B, np.float64)) / np.linalg.norm(B)
 
 
-def _run_stream(ctx, oracle, stream, n_frames, strict, win=21, max_level=6, sanity=True):
+def _run_stream(ctx, oracle, stream, n_frames, strict, win=21, max_level=6, sanity=True, untri=None):
+    """untri: fraction of the track set whose landmark is NOT triangulated (stereo_vo.cpp:490, :515-519, :599);
+    None = no flag array at all (every landmark triangulated)."""
     prm_g = make_stereo_params(stream.width, stream.height, win, max_level, 80.0, 0.5, 3.0, stream.K, stream.K,
                                stream.T_lr)
     prm_o = oracle.make_stereo_params(stream.width, stream.height, win, max_level, 80.0, 0.5, 3.0, stream.K,
@@ -29,12 +31,28 @@ def _run_stream(ctx, oracle, stream, n_frames, strict, win=21, max_level=6, sani
         ts = stream.track_set(k - 1, poses[k - 1], poses[k])
         ctx.set_image(1, L)
         ctx.set_image(2, R)
-        pipe.enqueue(ts["pts_l0"], ts["pts_r0"], ts["Xp"], ts["dT_prior"], ts["pts_new"])
+        n = ts["pts_l0"].shape[0]
+        fl = None
+        if untri is not None:
+            rng = np.random.default_rng(1000 * k + int(100 * untri))
+            fl = (rng.random(n) >= untri).astype(np.uint8)  # bit 0 = isTriangulated()
+            fl |= (rng.integers(0, 128, n).astype(np.uint8) << 1)  # the other bits are not the operator's
+            ts = dict(ts)
+            ts["Xp"] = ts["Xp"].copy()
+            ts["Xp"][(fl & 1) == 0] = np.nan  # an untriangulated landmark has no 3-D point: must never be read
+        pipe.enqueue(ts["pts_l0"], ts["pts_r0"], ts["Xp"], ts["dT_prior"], ts["pts_new"], lm_flags=fl)
         g = pipe.result()
         o = oracle.stereo_frame(prm_o, Lp, L, R, ts["pts_l0"], ts["pts_r0"], ts["Xp"], ts["dT_prior"],
                                 ts["pts_new"], oracle.SUM_TREE, GN_T,
-                                oracle.IC_REFERENCE if strict else oracle.IC_MASKED, 8)
+                                oracle.IC_REFERENCE if strict else oracle.IC_MASKED, 8, lm_flags=fl)
         assert o["rc"] == 0
+        n_tri = n if fl is None else int((fl & 1).sum())
+        assert g["counts"].n_ba == o["counts"].n_ba <= min(n_tri, g["counts"].n_l1r1)
+        if fl is not None and n_tri < n:
+            # untriangulated survivors of [5] never meet the BA: all of them are in lmtrack_final (y <= 660 here)
+            u = (fl & 1) == 0
+            assert np.array_equal(g["stage"][u] == 4, g["stage"][u] >= 3) and (g["stage"][u] == 4).any()
+            assert g["counts"].n_ba + int((g["stage"][u] >= 3).sum()) == g["counts"].n_l1r1
         # feature indices / survivors: bit-exact at every gate
         assert np.array_equal(g["stage"], o["stage"]), np.nonzero(g["stage"] != o["stage"])[0][:10]
         for f in ("n_l0l1", "n_refine", "n_l1r1", "n_inlier", "n_new_ok", "gn_iterations"):
@@ -49,13 +67,15 @@ def _run_stream(ctx, oracle, stream, n_frames, strict, win=21, max_level=6, sani
         # reference summation order: north-star tolerance
         os_ = oracle.stereo_frame(prm_o, Lp, L, R, ts["pts_l0"], ts["pts_r0"], ts["Xp"], ts["dT_prior"],
                                   ts["pts_new"], oracle.SUM_SEQ, 0,
-                                  oracle.IC_REFERENCE if strict else oracle.IC_MASKED, 8)
+                                  oracle.IC_REFERENCE if strict else oracle.IC_MASKED, 8, lm_flags=fl)
         assert rel_frob(g["dT"], os_["dT"]) < 1e-4
         assert np.array_equal(g["stage"], os_["stage"])
         # and the estimate is a sane odometry result
-        if sanity:
+        if sanity and n_tri > 0.5 * n:
             assert rel_frob(g["dT"], ts["dT_true"]) < 5e-3
             assert g["counts"].n_inlier > 0.5 * ts["pts_l0"].shape[0]
+        if n_tri == 0:  # empty BA set: the reference's loop leaves T10 alone and returns inverse(inverse(prior))
+            assert g["counts"].n_ba == 0 and np.allclose(g["dT"], ts["dT_prior"], atol=1e-6)
         ctx.swap_slots(0, 1)  # current left becomes previous left
         Lp = L
     return worst
@@ -65,6 +85,58 @@ def _run_stream(ctx, oracle, stream, n_frames, strict, win=21, max_level=6, sani
 def test_stereo_frame_kitti_shape(ctx, oracle, strict):
     stream = S.StereoStream(seed=2, margin=4.0 if strict else 16.0)
     _run_stream(ctx, oracle, stream, 3, strict)
+
+
+@pytest.mark.parametrize("untri,strict", [(0.0, True), (0.3, True), (0.3, False), (1.0, True)])
+def test_stereo_frame_untriangulated_landmarks(ctx, oracle, untri, strict):
+    """A real track set mixes triangulated and untriangulated landmarks (new stereo landmarks get their 3-D point
+    only at the next keyframe, stereo_vo.cpp:736/:794): 0 %, 30 % and 100 % untriangulated at 1241x376."""
+    stream = S.StereoStream(seed=4, margin=4.0 if strict else 16.0)
+    _run_stream(ctx, oracle, stream, 3, strict, untri=untri)
+
+
+def test_stereo_frame_untriangulated_general_path(ctx, oracle):
+    """The same branch on the one-launch-per-step path (a window the fused kernel is not instantiated for)."""
+    K = tuple(v * 0.5 for v in S.KITTI_K)
+    stream = S.StereoStream(width=620, height=188, K=K, n_u=30, n_v=12, n_new=40, seed=28, margin=5.0)
+    _run_stream(ctx, oracle, stream, 3, True, win=17, max_level=4, untri=0.4)
+
+
+def test_second_enqueue_before_result_is_refused(ctx):
+    """One result block per context: a frame in flight must be collected first."""
+    stream = S.StereoStream(width=320, height=200, K=(300.0, 300.0, 160.0, 100.0), n_u=8, n_v=5, n_new=4, seed=7)
+    prm = make_stereo_params(320, 200, 21, 3, 80.0, 0.5, 3.0, stream.K, stream.K, stream.T_lr)
+    pipe = StereoFramePipeline(ctx, prm)
+    poses = stream.poses(2)
+    L0, _, _ = stream.render_pair(poses[0])
+    L1, R1, _ = stream.render_pair(poses[1])
+    for s_, im in enumerate((L0, L1, R1)):
+        ctx.set_image(s_, im)
+    ts = stream.track_set(0, poses[0], poses[1])
+    pipe.enqueue(ts["pts_l0"], ts["pts_r0"], ts["Xp"], ts["dT_prior"], ts["pts_new"])
+    with pytest.raises(RuntimeError, match="already in flight"):
+        pipe.enqueue(ts["pts_l0"], ts["pts_r0"], ts["Xp"], ts["dT_prior"], ts["pts_new"])
+    g = pipe.result()  # the first frame is intact
+    assert g["counts"].n_inlier > 0
+
+
+def test_pyramid_shortfall_is_an_error(vo):
+    """A window hint larger than the window in use truncates the pyramid below what PyrLK with the smaller
+    window needs: an error, not a silent clamp."""
+    c = vo.Context(device=0, max_width=320, max_height=200, max_points=64, n_slots=2, max_level=5)
+    try:
+        img = np.random.default_rng(0).integers(0, 255, (200, 320), dtype=np.uint8)
+        c.set_pyramid_window_hint(31)
+        c.set_image(0, img)
+        c.set_image(1, img)
+        assert c.pyramid_levels(320, 200, 31, 5) < c.pyramid_levels(320, 200, 13, 5)
+        ft = vo.FeatureTracker(c)
+        pts = np.array([[100.0, 100.0]], np.float32)
+        ft.track(0, 1, pts, 31, 5, 80.0)  # fine: the window the hint named
+        with pytest.raises(RuntimeError, match="pyramid holds levels"):
+            ft.track(0, 1, pts, 13, 5, 80.0)
+    finally:
+        c.close()
 
 
 def test_stereo_frame_small_many_frames(ctx, oracle):

@@ -37,7 +37,7 @@ class StereoParams(C.Structure):
 class FrameCounts(C.Structure):
     _fields_ = [("n_l0l1", C.c_int), ("n_refine", C.c_int), ("n_l1r1", C.c_int),
                 ("n_inlier", C.c_int), ("n_new_ok", C.c_int), ("gn_iterations", C.c_int),
-                ("n_replayed", C.c_int)]
+                ("n_replayed", C.c_int), ("n_ba", C.c_int)]
 
 
 class MonoParams(C.Structure):
@@ -103,7 +103,7 @@ def load():
     lib.vo_destroy.restype = None
     # the two per-frame calls carry declared argument types: no per-call inference, plain ints as device pointers
     vp, ci = C.c_void_p, C.c_int
-    lib.vo_stereo_frame_enqueue.argtypes = [vp, C.POINTER(StereoParams), ci, ci, ci, vp, vp, vp, ci, vp, vp, ci, ci]
+    lib.vo_stereo_frame_enqueue.argtypes = [vp, C.POINTER(StereoParams), ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, ci, ci]
     lib.vo_stereo_frame_result.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.POINTER(FrameCounts), C.POINTER(GnInfo)]
     lib.vo_set_stereo_pair_device.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci]
     _lib = lib

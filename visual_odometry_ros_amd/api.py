@@ -474,22 +474,28 @@ class StereoFramePipeline:
         self.prm = params
         self.ctx.check(self.lib.vo_stereo_frame_set_strict_border(ctx.handle, int(strict_border)))
 
-    def enqueue(self, pts_l0, pts_r0, Xp, dT_prior, pts_new, slots=(0, 1, 2)):
+    def enqueue(self, pts_l0, pts_r0, Xp, dT_prior, pts_new, slots=(0, 1, 2), lm_flags=None):
+        """lm_flags[i] bit 0 = lm->isTriangulated() (stereo_vo.cpp:490, :599); None = every landmark is."""
         pts_l0, pts_r0 = _f32(pts_l0).reshape(-1, 2), _f32(pts_r0).reshape(-1, 2)
         Xp = _f32(Xp).reshape(-1, 3)
         dT = _f32(dT_prior).reshape(16)
         pts_new = _f32(pts_new).reshape(-1, 2)
         self._n, self._nn = pts_l0.shape[0], pts_new.shape[0]
+        fl = None
+        if lm_flags is not None:
+            fl = _u8(lm_flags).reshape(-1)
+            if fl.shape[0] != self._n:
+                raise ValueError("lm_flags.size() != pts_l0.size()")
         self.ctx.check(self.lib.vo_stereo_frame_enqueue(
             self.ctx.handle, C.byref(self.prm), slots[0], slots[1], slots[2], _p(pts_l0), _p(pts_r0),
-            _p(Xp), self._n, _p(dT), _p(pts_new), self._nn, 0))
+            _p(Xp), fl.ctypes.data if fl is not None else None, self._n, _p(dT), _p(pts_new), self._nn, 0))
 
-    def enqueue_device(self, d_pts_l0, d_pts_r0, d_Xp, n, dT_prior, d_pts_new, n_new, slots=(0, 1, 2)):
+    def enqueue_device(self, d_pts_l0, d_pts_r0, d_Xp, n, dT_prior, d_pts_new, n_new, slots=(0, 1, 2), d_lm_flags=None):
         dT = dT_prior if (isinstance(dT_prior, np.ndarray) and dT_prior.dtype == np.float32 and dT_prior.flags.c_contiguous) \
             else _f32(dT_prior)
         self._n, self._nn = n, n_new
         rc = self.lib.vo_stereo_frame_enqueue(self.ctx.handle, self.prm, slots[0], slots[1], slots[2], d_pts_l0, d_pts_r0,
-                                              d_Xp, n, dT.ctypes.data, d_pts_new, n_new, 1)
+                                              d_Xp, d_lm_flags, n, dT.ctypes.data, d_pts_new, n_new, 1)
         if rc < 0:
             self.ctx.check(rc)
 

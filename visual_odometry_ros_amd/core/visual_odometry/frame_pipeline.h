@@ -49,16 +49,22 @@ class StereoFramePipeline {
     has_cur_ = true;
   }
   // pts_l0 / pts_r0: lmtrack pixels in the previous pair; Xp: landmarks in the previous left camera frame
-  // (stereo_vo.cpp:483-494); dT_pc_prior: motion prior; pts_new: bucketed candidates of step [10].
+  // (stereo_vo.cpp:483-494); dT_pc_prior: motion prior; pts_new: bucketed candidates of step [10];
+  // triangulated[i] = lms[i]->isTriangulated() (stereo_vo.cpp:490, :599) — empty = every landmark is.
   void enqueue(const PixelVec &pts_l0, const PixelVec &pts_r0, const PointVec &Xp, const PoseSE3 &dT_pc_prior,
-               const PixelVec &pts_new) {
+               const PixelVec &pts_new, const MaskVec &triangulated = MaskVec()) {
     if (pts_l0.size() != pts_r0.size() || pts_l0.size() != Xp.size())
       throw std::runtime_error("pts_l0 / pts_r0 / Xp differ in length");
+    if (!triangulated.empty() && triangulated.size() != pts_l0.size())
+      throw std::runtime_error("triangulated.size() != pts_l0.size()");
     n_ = (int)pts_l0.size();
     n_new_ = (int)pts_new.size();
+    flags_.assign(triangulated.size(), 0);
+    for (std::size_t i = 0; i < triangulated.size(); ++i) flags_[i] = triangulated[i] ? VO_LM_TRIANGULATED : 0;
     ctx_->check(vo_stereo_frame_enqueue(ctx_->get(), &prm_, kPrev, kLeft, kRight, n_ ? &pts_l0.data()->x : zero_,
-                                        n_ ? &pts_r0.data()->x : zero_, n_ ? &Xp.data()->x : zero_, n_,
-                                        dT_pc_prior.data(), n_new_ ? &pts_new.data()->x : zero_, n_new_, 0));
+                                        n_ ? &pts_r0.data()->x : zero_, n_ ? &Xp.data()->x : zero_,
+                                        flags_.empty() ? nullptr : flags_.data(), n_, dT_pc_prior.data(),
+                                        n_new_ ? &pts_new.data()->x : zero_, n_new_, 0));
   }
   StereoFrameResult result() {
     StereoFrameResult r;
@@ -83,6 +89,7 @@ class StereoFramePipeline {
   int n_ = 0, n_new_ = 0;
   bool has_cur_ = false;
   float zero_[3] = {0.f, 0.f, 0.f};
+  std::vector<std::uint8_t> flags_;
 };
 
 // ---- mono -----------------------------------------------------------------------------------------

@@ -35,6 +35,7 @@ struct FrameArgs {
   uint8_t *m_new;              // out [n_new]    trackBidirection mask
   float thres_bidir;
   const float *Xp, *pts_l0, *pts_r0;
+  const uint8_t *lm_flags;     // [n] bit 0 = lm->isTriangulated(); null = every landmark is
   float T_cp[16], T_rl[16], Kl[4], Kr[4];
   int W, H;
   float thres_err;
@@ -124,23 +125,29 @@ __global__ __launch_bounds__(64) void frame_track_kernel(FrameArgs a) {
   float prx = 0.f, pry = 0.f, scale = 1.f, l0x = 0.f, l0y = 0.f;
   if (feat) {
     // ---- [3] priors (stereo_vo.cpp:483-522); every lane computes the same values ----
-    const float *Xi = a.Xp + 3 * i;
-    float Xl[3], Xr[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-      Xl[r] = ((a.T_cp[r * 4 + 0] * Xi[0] + a.T_cp[r * 4 + 1] * Xi[1]) + a.T_cp[r * 4 + 2] * Xi[2]) + a.T_cp[r * 4 + 3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-      Xr[r] = ((a.T_rl[r * 4 + 0] * Xl[0] + a.T_rl[r * 4 + 1] * Xl[1]) + a.T_rl[r * 4 + 2] * Xl[2]) + a.T_rl[r * 4 + 3];
-    scale = Xi[2] / Xl[2];
-    const float izl = 1.0f / Xl[2], izr = 1.0f / Xr[2];
-    float plx = a.Kl[0] * Xl[0] * izl + a.Kl[2], ply = a.Kl[1] * Xl[1] * izl + a.Kl[3];
-    prx = a.Kr[0] * Xr[0] * izr + a.Kr[2];
-    pry = a.Kr[1] * Xr[1] * izr + a.Kr[3];
     l0x = a.pts_l0[2 * i];
     l0y = a.pts_l0[2 * i + 1];
-    if (!frame_in_image(plx, ply, a.W, a.H) || !frame_in_image(prx, pry, a.W, a.H) || (double)Xl[2] < 0.1 ||
-        (double)Xr[2] < 0.1) {
+    float plx = l0x, ply = l0y;
+    bool from_prev = true;  // prior = pts_l0 / pts_r0: untriangulated landmark (:515-519) or projection unusable (:505-510)
+    if (!a.lm_flags || (a.lm_flags[i] & VO_LM_TRIANGULATED)) {
+      const float *Xi = a.Xp + 3 * i;
+      float Xl[3], Xr[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+        Xl[r] = ((a.T_cp[r * 4 + 0] * Xi[0] + a.T_cp[r * 4 + 1] * Xi[1]) + a.T_cp[r * 4 + 2] * Xi[2]) + a.T_cp[r * 4 + 3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+        Xr[r] = ((a.T_rl[r * 4 + 0] * Xl[0] + a.T_rl[r * 4 + 1] * Xl[1]) + a.T_rl[r * 4 + 2] * Xl[2]) + a.T_rl[r * 4 + 3];
+      scale = Xi[2] / Xl[2];
+      const float izl = 1.0f / Xl[2], izr = 1.0f / Xr[2];
+      plx = a.Kl[0] * Xl[0] * izl + a.Kl[2];
+      ply = a.Kl[1] * Xl[1] * izl + a.Kl[3];
+      prx = a.Kr[0] * Xr[0] * izr + a.Kr[2];
+      pry = a.Kr[1] * Xr[1] * izr + a.Kr[3];
+      from_prev = !frame_in_image(plx, ply, a.W, a.H) || !frame_in_image(prx, pry, a.W, a.H) || (double)Xl[2] < 0.1 ||
+                  (double)Xr[2] < 0.1;
+    }
+    if (from_prev) {
       plx = l0x;
       ply = l0y;
       prx = a.pts_r0[2 * i];
@@ -348,9 +355,9 @@ static void frame_launch(vo_ctx *c, const FrameArgs &a, int phase) {
 int vo_frame_fused_supported(int win) { return win == 13 || win == 15 || win == 21 || win == 31; }
 
 int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, int slot_l1, int slot_r1,
-                           const float *d_l0, const float *d_r0, const float *d_X, int n, const float T_cp[16],
-                           const float T_rl[16], const float *d_new, int n_new, const vo_frame_fused_bufs &b,
-                           int phase) {
+                           const float *d_l0, const float *d_r0, const float *d_X, const uint8_t *d_flags, int n,
+                           const float T_cp[16], const float T_rl[16], const float *d_new, int n_new,
+                           const vo_frame_fused_bufs &b, int phase) {
   if (n <= 0) return VO_OK;
   const int slots[3] = {slot_l0, slot_l1, slot_r1};
   for (int s : slots)
@@ -391,6 +398,7 @@ int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, 
   a.Xp = d_X;
   a.pts_l0 = d_l0;
   a.pts_r0 = d_r0;
+  a.lm_flags = d_flags;
   memcpy(a.T_cp, T_cp, sizeof(a.T_cp));
   memcpy(a.T_rl, T_rl, sizeof(a.T_rl));
   memcpy(a.Kl, prm->Kl, sizeof(a.Kl));

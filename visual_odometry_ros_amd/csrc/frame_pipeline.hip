@@ -50,7 +50,7 @@ int vo_frame_init(vo_ctx *c) {
   for (float **p : f1) VO_CHECK_HIP(c, fs_alloc(p, N));
   int32_t **i1[] = {&f->F_orig, &f->A_orig, &f->B_orig, &f->C_orig};
   for (int32_t **p : i1) VO_CHECK_HIP(c, fs_alloc(p, N));
-  uint8_t **u1[] = {&f->m1, &f->m2, &f->m3, &f->mG, &f->st1, &f->st2, &f->st3, &f->A_touched, &f->A_cls};
+  uint8_t **u1[] = {&f->m1, &f->m2, &f->m3, &f->mG, &f->st1, &f->st2, &f->st3, &f->A_touched, &f->A_cls, &f->in_flags};
   for (uint8_t **p : u1) VO_CHECK_HIP(c, fs_alloc(p, N));
   f->res_cap = align16(sizeof(vo_frame_hdr)) + 2 * align16(N) + 3 * align16(sizeof(float) * 2 * N);
   VO_CHECK_HIP(c, hipMalloc((void **)&f->res_dev, f->res_cap));
@@ -67,7 +67,7 @@ void vo_frame_free(vo_ctx *c) {
   void *bufs[] = {f->in_l0, f->in_r0, f->in_X, f->in_new, f->F_scale, f->F_orig, f->A_pl0, f->A_pl1, f->A_pr1,
                   f->A_X, f->A_scale, f->A_orig, f->B_pl1, f->B_pr1, f->B_X, f->B_orig, f->C_pl1, f->C_pr1,
                   f->C_X, f->C_orig, f->m1, f->m2, f->m3, f->mG, f->st1, f->st2, f->e1, f->e2, f->new_back,
-                  f->A_ref, f->A_lastpu, f->A_touched, f->A_cls, f->res_dev, f->st3, f->e3, f->ctl};
+                  f->A_ref, f->A_lastpu, f->A_touched, f->A_cls, f->res_dev, f->st3, f->e3, f->ctl, f->in_flags};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   if (f->res_host) (void)hipHostFree(f->res_host);
@@ -103,8 +103,8 @@ extern "C" int vo_stereo_frame_set_strict_border(vo_ctx *c, int strict) {
 
 extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, int slot_l1,
                                        int slot_r1, const float *pts_l0, const float *pts_r0, const float *Xp,
-                                       int n, const float dT_prior[16], const float *pts_new, int n_new,
-                                       int inputs_on_device) {
+                                       const uint8_t *flags, int n, const float dT_prior[16], const float *pts_new,
+                                       int n_new, int inputs_on_device) {
   if (!c || !prm || !dT_prior || n < 0 || n_new < 0) return VO_ERR_INVALID;
 #ifdef VO_TRACE_HOST
   vo_tt_last = vo_now_us();
@@ -125,7 +125,12 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
   if (f->pending) VO_FAIL(c, VO_ERR_INVALID, "a frame is already in flight: call vo_stereo_frame_result first");
   hipStream_t s = c->stream;
   const float *d_l0 = pts_l0, *d_r0 = pts_r0, *d_X = Xp, *d_new = pts_new;
+  const uint8_t *d_fl = flags;
   if (!inputs_on_device) {
+    if (n > 0 && flags) {
+      VO_CHECK_HIP(c, hipMemcpyAsync(f->in_flags, flags, (size_t)n, hipMemcpyHostToDevice, s));
+      d_fl = f->in_flags;
+    }
     if (n > 0) {
       VO_CHECK_HIP(c, hipMemcpyAsync(f->in_l0, pts_l0, sizeof(float) * 2 * n, hipMemcpyHostToDevice, s));
       VO_CHECK_HIP(c, hipMemcpyAsync(f->in_r0, pts_r0, sizeof(float) * 2 * n, hipMemcpyHostToDevice, s));
@@ -191,14 +196,14 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
     b.m_new = f->mNew;
     // [10] the new-point candidates are extra workgroups of the same launch
     VO_TT("setup");
-    RC(vo_frame_fused_enqueue(c, prm, slot_l0, slot_l1, slot_r1, d_l0, d_r0, d_X, n, T_cp, T_rl, d_new, n_new, b, 0));
+    RC(vo_frame_fused_enqueue(c, prm, slot_l0, slot_l1, slot_r1, d_l0, d_r0, d_X, d_fl, n, T_cp, T_rl, d_new, n_new, b, 0));
     VO_TT("track launch");
-    RC(vo_frame_fused_enqueue(c, prm, slot_l0, slot_l1, slot_r1, d_l0, d_r0, d_X, n, T_cp, T_rl, d_new, n_new, b, 1));
+    RC(vo_frame_fused_enqueue(c, prm, slot_l0, slot_l1, slot_r1, d_l0, d_r0, d_X, d_fl, n, T_cp, T_rl, d_new, n_new, b, 1));
     VO_TT("phase1");
   } else if (n > 0) {
     // general window sizes: one launch per step, compaction in between
     // [3] priors
-    RC(vo_stereo_prior_enqueue(c, d_X, d_l0, d_r0, n, T_cp, T_rl, prm->Kl, prm->Kr, W, H, f->F_pl1, f->F_pr1,
+    RC(vo_stereo_prior_enqueue(c, d_X, d_l0, d_r0, d_fl, n, T_cp, T_rl, prm->Kl, prm->Kr, W, H, f->F_pl1, f->F_pr1,
                                f->F_scale, f->F_orig, f->stage));
     // [4] l0 -> l1 ({} criteria, {} minEig); validity mask fused into the compaction
     RC(vo_klt_enqueue(c, slot_l0, slot_l1, d_l0, nullptr, f->F_pl1, n, nullptr, prm->win, prm->max_level,
@@ -292,11 +297,15 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
   if (n == 0 && n_new > 0) VO_FAIL(c, VO_ERR_INVALID, "new-point candidates without a track set are not supported");
   // [6] stereo pose-only BA on the survivors (T01 init = constant-velocity prior; kept on NaN);
   // [7] its epilogue marks stage 4 for inliers that pass the y > 660 gate (thres_sampson = 60)
+  // The GN launch's prologue selects the BA set — survivors of [5] whose landmark is triangulated (:599-613), in
+  // index order — and counts the steps; its epilogue marks stage 4 (BA inlier, or survivor outside the BA set whose
+  // mask_motion stays true, :582; both past the gate of [7]).
   vo_gn_frame gf;
   memset(&gf, 0, sizeof(gf));
-  if (fused) {
+  if (n > 0) {
     gf.n = n;
     gf.stage = f->stage;
+    gf.lm_flags = d_fl;
     gf.X = d_X;
     gf.pl1 = f->F_pl1;
     gf.pr1 = f->F_pr1;
@@ -305,18 +314,20 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
     gf.C_pr1 = f->C_pr1;
     gf.C_orig = f->C_orig;
     gf.cnt = cnt;
+    gf.hdr_flags = &f->hdr->flags;
+  }
+  if (fused) {
     gf.ctl = f->ctl;
     gf.ctl_words = (int)(vo_ic_ctl_bytes() / 4);
     gf.nt_word = vo_ic_ctl_nt_word();
-    gf.hdr_flags = &f->hdr->flags;
     gf.res_dev = f->res_dev;
     gf.res_host = f->res_host;  // pinned host memory is device-visible: the kernel copies the block out itself
     gf.res_bytes = f->res_bytes;
     gf.res_late_bytes = f->off_mnew;  // header + stage bytes
   }
-  RC(vo_gn_enqueue(c, true, false, f->C_X, f->C_pl1, f->C_pr1, n, fused ? nullptr : &cnt[2], prm->Kl, prm->Kr,
+  RC(vo_gn_enqueue(c, true, false, f->C_X, f->C_pl1, f->C_pr1, n, nullptr, prm->Kl, prm->Kr,
                    prm->T_lr, prm->thres_poseba, 0, dT_prior, f->hdr->dT, f->mG, &f->hdr->gn, true,
-                   n > 0 ? f->stage : nullptr, f->C_orig, 4, 60.0f, fused ? &gf : nullptr));
+                   n > 0 ? f->stage : nullptr, f->C_orig, 4, 60.0f, n > 0 ? &gf : nullptr));
   if (n_new > 0 && !fused) VO_CHECK_HIP(c, hipStreamWaitEvent(s, c->ev_join, 0));
   VO_TT("gn launch");
   // one D2H of the packed block into pinned memory (general path; the fused path's GN launch did it)
@@ -358,6 +369,7 @@ extern "C" int vo_stereo_frame_result(vo_ctx *c, float *pts_l1, float *pts_r1, u
     counts->n_new_ok = nnew;
     counts->gn_iterations = h->gn.iterations;
     counts->n_replayed = h->cnt[3];
+    counts->n_ba = h->cnt[4];
   }
   if (gn) {
     gn->iterations = h->gn.iterations;

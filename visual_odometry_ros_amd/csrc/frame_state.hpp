@@ -5,7 +5,7 @@
 
 // header of the packed result block (device and pinned-host copies share the layout)
 struct vo_frame_hdr {
-  int cnt[8];  // [0]=nA [1]=nB [2]=nC [3]=features replayed by the strict-border pass
+  int cnt[8];  // [0]=nA [1]=nB [2]=nC [3]=features replayed by the strict-border pass [4]=size of the pose-only BA set
   vo_gn_dev_info gn;
   int flags;
   int pad_[1];
@@ -16,6 +16,7 @@ struct vo_frame_state {
   int cap;
   // inputs (device copies when the caller passes host pointers)
   float *in_l0, *in_r0, *in_X, *in_new;
+  uint8_t *in_flags;
   // scratch in full index space
   float *F_scale;
   int32_t *F_orig;

@@ -54,10 +54,11 @@ struct GnArgs {
   // two launches (compaction, D2H blit) fewer on the critical path of every frame
   int f_n;                  // > 0: frame mode, features in input index space
   const uint8_t *f_stage;   // [f_n]
+  const uint8_t *f_lmflags; // [f_n] stereo: bit 0 = landmark triangulated (null: all); the BA set is stage 3 && triangulated
   const float *f_X, *f_pl1, *f_pr1;
   float *f_CX, *f_Cpl1, *f_Cpr1;
   int32_t *f_Corig;
-  int *f_cnt;               // [4]
+  int *f_cnt;               // [5]: three step counts, replayed features, size of the BA set
   int *f_ctl;               // control block; [0] = error flags, [16 + f_nt_word] = replayed features
   int f_ctl_words, f_nt_word;
   int *f_hdr_flags;
@@ -397,6 +398,7 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
   __shared__ float s_tot[32];
   __shared__ float s_T10[16];
   __shared__ int s_stop;
+  __shared__ int s_ba[GN_NW + 1];  // frame prologue: per-wave sizes of the BA set, then the running total
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -409,8 +411,9 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
   int n = a.d_n ? *a.d_n : a.n;
   if (a.f_n > 0) {
     // ---- frame mode prologue: survivors in index order + step counts (the one compaction of the frame) ----
-    int *s_wv = (int *)s_tot;  // [8][3] wave counts, then 3 running bases at [24..26]
+    int *s_wv = (int *)s_tot;  // [8][3] wave counts, then 3 running totals at [24..26]
     if (tid < 3) s_wv[24 + tid] = 0;
+    if (tid == 3) s_ba[GN_NW] = 0;
     __syncthreads();
     for (int c0 = 0; c0 < a.f_n; c0 += GN_T) {
       const int i = c0 + tid;
@@ -421,18 +424,22 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
         else
           st = a.f_stage[i];
       }
-      const unsigned long long b1 = __ballot(st >= 1), b2 = __ballot(st >= 2), b3 = __ballot(st >= 3);
-      const int below = __popcll(b3 & ((1ull << lane) - 1ull));
+      // stereo_vo.cpp:599: only triangulated landmarks enter the pose-only BA
+      const bool in_ba = st >= 3 && (!a.f_lmflags || (a.f_lmflags[i] & VO_LM_TRIANGULATED));
+      const unsigned long long b1 = __ballot(st >= 1), b2 = __ballot(st >= 2), b3 = __ballot(st >= 3),
+                               b4 = __ballot(in_ba);
+      const int below = __popcll(b4 & ((1ull << lane) - 1ull));
       if (lane == 0) {
         s_wv[wave * 3 + 0] = __popcll(b1);
         s_wv[wave * 3 + 1] = __popcll(b2);
         s_wv[wave * 3 + 2] = __popcll(b3);
+        s_ba[wave] = __popcll(b4);
       }
       __syncthreads();
       int woff = 0;
-      for (int w = 0; w < wave; ++w) woff += s_wv[w * 3 + 2];
-      const int base = s_wv[26];
-      if (st >= 3) {
+      for (int w = 0; w < wave; ++w) woff += s_ba[w];
+      const int base = s_ba[GN_NW];
+      if (in_ba) {
         const int o = base + woff + below;
         a.f_CX[3 * o] = a.f_X[3 * i];
         a.f_CX[3 * o + 1] = a.f_X[3 * i + 1];
@@ -450,18 +457,24 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
         int tot = 0;
         for (int w = 0; w < GN_NW; ++w) tot += s_wv[w * 3 + tid];
         s_wv[24 + tid] += tot;
+      } else if (tid == 3) {
+        int tot = 0;
+        for (int w = 0; w < GN_NW; ++w) tot += s_ba[w];
+        s_ba[GN_NW] += tot;
       }
       __syncthreads();
     }
-    n = s_wv[26];
+    n = s_ba[GN_NW];
     if (tid < 3) a.f_cnt[tid] = s_wv[24 + tid];
+    if (tid == 3) a.f_cnt[4] = n;
     // every producer / consumer of the control block ran before this kernel: report, then reset
-    if (tid == 0) {
+    if (tid == 0 && a.f_ctl) {
       *a.f_hdr_flags = a.f_ctl[0];
       a.f_cnt[3] = a.f_ctl[16 + a.f_nt_word];
     }
     __syncthreads();  // (also: the compacted arrays written above are read below by other threads)
-    for (int k = tid; k < a.f_ctl_words; k += GN_T) a.f_ctl[k] = 0;
+    if (a.f_ctl)
+      for (int k = tid; k < a.f_ctl_words; k += GN_T) a.f_ctl[k] = 0;
     // the pixel arrays and new-point results are final: their copy to the host runs under the iterations
     if (a.f_res_host)
       for (int k = a.f_res_late_words + tid; k < a.f_res_words; k += GN_T) a.f_res_host[k] = a.f_res_dev[k];
@@ -619,6 +632,13 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
       const float gate = a.p1[2 * i + 1] > 660 ? 100.f : 0.f;
       if (a.mask[i] && gate < a.gate_thres) a.stage[a.orig[i]] = (uint8_t)a.stage_val;
     }
+    // survivors of [5] outside the BA set keep mask_motion = true (stereo_vo.cpp:582) and meet the same gate
+    if (a.f_n > 0 && a.f_lmflags && !a.f_mono)
+      for (int i = tid; i < a.f_n; i += GN_T)
+        if (a.f_stage[i] == 3 && !(a.f_lmflags[i] & VO_LM_TRIANGULATED)) {
+          const float gate = a.f_pl1[2 * i + 1] > 660 ? 100.f : 0.f;
+          if (gate < a.gate_thres) a.stage[i] = (uint8_t)a.stage_val;
+        }
   }
   if (tid == 0) {
     float s = 0.0f;
@@ -715,6 +735,7 @@ int vo_gn_enqueue(vo_ctx *c, bool stereo, bool mono_general_inverse, const float
   if (frame && frame->n > 0) {
     a.f_n = frame->n;
     a.f_stage = frame->stage;
+    a.f_lmflags = frame->lm_flags;
     a.f_X = frame->X;
     a.f_pl1 = frame->pl1;
     a.f_pr1 = frame->pr1;

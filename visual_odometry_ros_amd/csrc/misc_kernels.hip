@@ -309,6 +309,7 @@ struct StereoPriorArgs {
   const float *Xp;
   const float *pts_l0;
   const float *pts_r0;
+  const uint8_t *flags;  // bit 0 = landmark triangulated; null = all
   int n;
   float T_cp[16], T_rl[16];
   float Kl[4], Kr[4];
@@ -324,6 +325,16 @@ __device__ __forceinline__ bool in_image_dev(float x, float y, int W, int H) {
 __global__ __launch_bounds__(256) void stereo_prior_kernel(StereoPriorArgs a) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
+  a.orig[i] = i;
+  a.stage[i] = 0;
+  if (a.flags && !(a.flags[i] & VO_LM_TRIANGULATED)) {  // stereo_vo.cpp:515-519
+    a.scale[i] = 1.0f;
+    a.pts_l1[2 * i] = a.pts_l0[2 * i];
+    a.pts_l1[2 * i + 1] = a.pts_l0[2 * i + 1];
+    a.pts_r1[2 * i] = a.pts_r0[2 * i];
+    a.pts_r1[2 * i + 1] = a.pts_r0[2 * i + 1];
+    return;
+  }
   const float *Xi = a.Xp + 3 * i;
   float Xl[3], Xr[3];
 #pragma unroll
@@ -348,11 +359,10 @@ __global__ __launch_bounds__(256) void stereo_prior_kernel(StereoPriorArgs a) {
     a.pts_r1[2 * i] = prx;
     a.pts_r1[2 * i + 1] = pry;
   }
-  a.orig[i] = i;
-  a.stage[i] = 0;
 }
 
-int vo_stereo_prior_enqueue(vo_ctx *c, const float *d_Xp, const float *d_pl0, const float *d_pr0, int n,
+int vo_stereo_prior_enqueue(vo_ctx *c, const float *d_Xp, const float *d_pl0, const float *d_pr0,
+                            const uint8_t *d_flags, int n,
                             const float T_cp[16], const float T_rl[16], const float Kl[4], const float Kr[4],
                             int W, int H, float *d_pl1, float *d_pr1, float *d_scale, int32_t *d_orig,
                             uint8_t *d_stage) {
@@ -361,6 +371,7 @@ int vo_stereo_prior_enqueue(vo_ctx *c, const float *d_Xp, const float *d_pl0, co
   a.Xp = d_Xp;
   a.pts_l0 = d_pl0;
   a.pts_r0 = d_pr0;
+  a.flags = d_flags;
   a.n = n;
   memcpy(a.T_cp, T_cp, sizeof(a.T_cp));
   memcpy(a.T_rl, T_rl, sizeof(a.T_rl));

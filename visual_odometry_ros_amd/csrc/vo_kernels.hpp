@@ -9,11 +9,12 @@
 struct vo_gn_frame {
   int n;                    // features in input index space
   const uint8_t *stage;
+  const uint8_t *lm_flags;  // stereo: bit 0 = landmark triangulated (null: all are); BA set = stage 3 && triangulated
   const float *X, *pl1, *pr1;
   float *C_X, *C_pl1, *C_pr1;
   int32_t *C_orig;
   int *cnt;
-  int *ctl;
+  int *ctl;                 // null (general path): no control block to report / reset
   int ctl_words, nt_word;
   int *hdr_flags;
   const void *res_dev;
@@ -92,7 +93,8 @@ struct vo_frame_fused_bufs {
 };
 int vo_frame_fused_supported(int win);
 int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, int slot_l1, int slot_r1,
-                           const float *d_l0, const float *d_r0, const float *d_X, int n, const float T_cp[16],
+                           const float *d_l0, const float *d_r0, const float *d_X, const uint8_t *d_flags, int n,
+                           const float T_cp[16],
                            const float T_rl[16], const float *d_new, int n_new, const vo_frame_fused_bufs &b,
                            int phase);
 
@@ -129,7 +131,8 @@ struct CompactArgsHost {
 int vo_compact_enqueue(vo_ctx *c, const CompactArgsHost &h);
 int vo_calc_prior_enqueue(vo_ctx *c, const float *d_pts0, int n_pts0, const float *d_Xw, int n,
                           const float T1w[16], const float K[9], float *d_out);
-int vo_stereo_prior_enqueue(vo_ctx *c, const float *d_Xp, const float *d_pl0, const float *d_pr0, int n,
+int vo_stereo_prior_enqueue(vo_ctx *c, const float *d_Xp, const float *d_pl0, const float *d_pr0,
+                            const uint8_t *d_flags, int n,
                             const float T_cp[16], const float T_rl[16], const float Kl[4], const float Kr[4],
                             int W, int H, float *d_pl1, float *d_pr1, float *d_scale, int32_t *d_orig,
                             uint8_t *d_stage);
