@@ -226,6 +226,25 @@ int vo_orb_match(vo_ctx *ctx, const uint8_t *a, int na, const uint8_t *b, int nb
 int vo_compact_indices(vo_ctx *ctx, const uint8_t *mask, const uint8_t *alive,
                        const uint8_t *tracked, int n, int32_t *index_valid, int *n_out);
 
+/* ---- track IDs (landmark.h:64, landmark.cpp:6,:29; frame.h:53, frame.cpp:15,:35) ----------------
+ * The reference numbers landmarks and frames with two process-global counters (inline static
+ * Landmark::landmark_counter_, Frame::frame_counter_). Here every vo_ctx — one image stream — owns its pair, so the
+ * streams of a batch-of-sequences process get the IDs each would get in a process of its own.
+ * Both start at 0 (vo_create). */
+int vo_ids_reset(vo_ctx *ctx, int32_t next_landmark_id, int32_t next_frame_id);
+int vo_ids_peek(const vo_ctx *ctx, int32_t *next_landmark_id, int32_t *next_frame_id);
+/* n Frame constructions in order: ids[i] = frame_counter_++. StereoFrame(cam_l, cam_r, t) is two of them, left
+ * first (frame.cpp:176-180). */
+int vo_ids_new_frames(vo_ctx *ctx, int n, int32_t *ids);
+/* Landmark constructions for the candidates i = 0..n-1 in order, where accept[i] != 0 (NULL = all), e.g. step [10]'s
+ * `mask_new[i] && Xl(2) > 0 && Xr(2) > 0` (stereo_vo.cpp:716-729): ids[i] = landmark_counter_++, -1 where rejected. */
+int vo_ids_new_landmarks(vo_ctx *ctx, const uint8_t *accept, int n, int32_t *ids, int *n_created);
+/* StereoLandmarkTracking(src, mask) / LandmarkTracking(src, mask) with their side effect (landmark.cpp:291-332,
+ * :194-231): index_valid = stable compaction of mask && alive && tracked (as vo_compact_indices), every other
+ * landmark is setUntracked() — tracked[] is in/out —, and ids_out[k] = ids[index_valid[k]] (both may be NULL). */
+int vo_compact_tracks(vo_ctx *ctx, const uint8_t *mask, const uint8_t *alive, uint8_t *tracked, const int32_t *ids,
+                      int n, int32_t *index_valid, int32_t *ids_out, int *n_out);
+
 /* ---- steady-state stereo frame -------------------------------------------
  * The operator sequence of StereoVO::trackStereoImages, steps [3]-[7] and the
  * tracking part of [10] (core/visual_odometry/stereo_vo/stereo_vo.cpp:483-711),
@@ -245,8 +264,16 @@ typedef struct {
   int n_ba;       /* size of the pose-only BA set: survivors of [5] whose landmark is triangulated (stereo_vo.cpp:599) */
 } vo_frame_counts;
 
-/* flags[i] of a tracked feature: bit 0 = lm->isTriangulated() */
+/* flags[i] of a tracked feature in the stereo frame: bit 0 = lm->isTriangulated(); bit 1 = the landmark is no
+ * longer alive or tracked (!(lm->isAlive() && lm->isTracked())): the first compaction of the frame drops it
+ * whatever the tracker says (landmark.cpp:305), so it never reaches trackWithScale or the BA. */
 #define VO_LM_TRIANGULATED 1
+#define VO_LM_DROPPED 2
+/* flags[i] in the mono frame: bit 0 = lm->isBundled(), bit 1 = member of the pose-only BA class, bit 2 = no longer
+ * alive or tracked (landmark.cpp:207) */
+#define VO_MONO_LM_BUNDLED 1
+#define VO_MONO_LM_BA_CLASS 2
+#define VO_MONO_LM_DROPPED 4
 
 /* strict != 0: the frame's trackWithScale step replays border-touching points
  * with the reference's never-reset tap state (same as vo_track_with_scale's
@@ -261,7 +288,7 @@ int vo_stereo_frame_set_strict_border(vo_ctx *ctx, int strict);
  * real track set is a mix: an untriangulated feature takes pts_l0 / pts_r0 as prior and patch scale 1
  * (stereo_vo.cpp:490, :515-519), goes through [4], [4-1], [5] like every other, stays out of the pose-only BA
  * (:599) with mask_motion = true (:582) and meets the y > 660 gate of [7] (:653-668). Xp[i] (the landmark in the
- * previous left camera frame, T_pw * X) is read only where the bit is set.
+ * previous left camera frame, T_pw * X) is read only where the bit is set. Bit 1 (VO_LM_DROPPED): see above.
  * One frame in flight per context (VO_ERR_INVALID otherwise). */
 int vo_stereo_frame_enqueue(vo_ctx *ctx, const vo_stereo_params *prm, int slot_l0, int slot_l1,
                             int slot_r1, const float *pts_l0, const float *pts_r0,
@@ -326,7 +353,8 @@ typedef struct {
 
 /* flags[i]: bit 0 = lm->isBundled() (prior pixel and patch scale come from the
  * 3-D point), bit 1 = the landmark is in the class this frame hands to the
- * pose-only BA (mono_vo.cpp:800-826). Xw is read only where a bit is set.
+ * pose-only BA (mono_vo.cpp:800-826), bit 2 = VO_MONO_LM_DROPPED (fails the first
+ * compaction, mono_vo.cpp:773 -> landmark.cpp:207). Xw is read only where bit 0 or 1 is set.
  * Tcw_prev = inverse pose of the previous frame, Tcw_prior = inverse of the
  * predicted current pose, dT01_prior = predicted motion (all row-major 4x4).
  * The strict-border mode is the context's (vo_stereo_frame_set_strict_border). */

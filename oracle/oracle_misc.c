@@ -169,6 +169,11 @@ int vo_ref_stereo_frame(const vo_ref_stereo_params *prm, const uint8_t *I0l,
   for (int i = 0; i < n; ++i) m[i] = 1;
   vo_ref_track_with_prior(I0l, I1l, W, H, stride, pts_l0, n, prm->win, prm->max_level,
                           prm->thres_err, pts_l1, m, n_threads);
+  /* StereoLandmarkTracking(lmtrack_prev, mask_l0l1), landmark.cpp:305: mask && isAlive() && isTracked();
+   * lm_flags bit 1 = the landmark is no longer alive / tracked */
+  if (lm_flags)
+    for (int i = 0; i < n; ++i)
+      if (lm_flags[i] & 2) m[i] = 0;
   int c = 0;
   for (int i = 0; i < cur; ++i)
     if (m[i]) {

@@ -65,7 +65,7 @@ int vo_ref_mono_frame(const vo_ref_mono_params *prm, const uint8_t *I0, const ui
                                       prm->thres_bidirection, pts1, m, n_threads);
   int cur = 0;
   for (int i = 0; i < n; ++i)
-    if (m[i]) {
+    if (m[i] && !(flags[i] & 4)) { /* LandmarkTracking(lmtrack_prev, mask_track), landmark.cpp:207; bit 2 = not alive / tracked */
       stage[i] = 1;
       idx[cur++] = i;
     }

@@ -36,7 +36,8 @@ def _run_stream(ctx, oracle, stream, n_frames, strict, win=21, max_level=6, sani
         if untri is not None:
             rng = np.random.default_rng(1000 * k + int(100 * untri))
             fl = (rng.random(n) >= untri).astype(np.uint8)  # bit 0 = isTriangulated()
-            fl |= (rng.integers(0, 128, n).astype(np.uint8) << 1)  # the other bits are not the operator's
+            fl |= (rng.random(n) < 0.04).astype(np.uint8) << 1  # bit 1: landmark no longer alive / tracked
+            fl |= (rng.integers(0, 64, n).astype(np.uint8) << 2)  # the other bits are not the operator's
             ts = dict(ts)
             ts["Xp"] = ts["Xp"].copy()
             ts["Xp"][(fl & 1) == 0] = np.nan  # an untriangulated landmark has no 3-D point: must never be read
@@ -48,6 +49,8 @@ def _run_stream(ctx, oracle, stream, n_frames, strict, win=21, max_level=6, sani
         assert o["rc"] == 0
         n_tri = n if fl is None else int((fl & 1).sum())
         assert g["counts"].n_ba == o["counts"].n_ba <= min(n_tri, g["counts"].n_l1r1)
+        if fl is not None:
+            assert (g["stage"][(fl & 2) != 0] == 0).all() and (fl & 2).any()  # dropped by the first compaction
         if fl is not None and n_tri < n:
             # untriangulated survivors of [5] never meet the BA: all of them are in lmtrack_final (y <= 660 here)
             u = (fl & 1) == 0

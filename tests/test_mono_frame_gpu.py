@@ -70,12 +70,14 @@ def test_mono_frame_matches_oracle(mono_ctx, vo, oracle, strict):
     Xw, Tcw_prev, Tcw_prior, dT01 = _world(ts, 5)
     rng = np.random.default_rng(7)
     flags = ((rng.random(n) < 0.7).astype(np.uint8) | ((rng.random(n) < 0.8).astype(np.uint8) << 1)).astype(np.uint8)
+    flags |= (rng.random(n) < 0.03).astype(np.uint8) << 2  # landmarks that are no longer alive / tracked (landmark.cpp:207)
     args = (752, 480, 15, 5, 20.0, 1.0, 5, 1.0, MONO_K)
     ctx.set_image(0, I0)
     ctx.set_image(1, I1)
     pipe = MonoFramePipeline(ctx, make_mono_params(*args), strict_border=strict)
     pipe.enqueue(pts0, Xw, flags, Tcw_prev, Tcw_prior, dT01)
     g = pipe.result()
+    assert (flags & 4).any() and (g["stage"][(flags & 4) != 0] == 0).all()
     border = oracle.IC_REFERENCE if strict else oracle.IC_MASKED
     prm_o = oracle.make_mono_params(*args)
     o = oracle.mono_frame(prm_o, I0, I1, pts0, Xw, flags, Tcw_prev, Tcw_prior, dT01, oracle.SUM_TREE, 512, border, 8)

@@ -449,6 +449,58 @@ def compact_indices(ctx, mask, alive=None, tracked=None):
     return idx[: cnt.value].copy()
 
 
+class TrackIds:
+    """Landmark / Frame IDs of ONE image stream and the mask-compaction constructors with their side effect.
+    The reference's counters are process-global statics (landmark.h:64, frame.h:53); here they belong to the
+    context, so several streams in one process keep the IDs each would have alone."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.lib = ctx.lib
+
+    def reset(self, next_landmark_id=0, next_frame_id=0):
+        self.ctx.check(self.lib.vo_ids_reset(self.ctx.handle, int(next_landmark_id), int(next_frame_id)))
+
+    def peek(self):
+        a, b = C.c_int32(), C.c_int32()
+        self.ctx.check(self.lib.vo_ids_peek(self.ctx.handle, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def newFrames(self, n):
+        """n Frame constructions (a StereoFrame is two: left, right — frame.cpp:176-180)."""
+        ids = np.zeros(max(n, 1), np.int32)
+        self.ctx.check(self.lib.vo_ids_new_frames(self.ctx.handle, int(n), _p(ids, C.c_int32)))
+        return ids[:n]
+
+    def newLandmarks(self, accept):
+        """One Landmark construction per accepted candidate, in candidate order (stereo_vo.cpp:716-729);
+        returns ids with -1 at the rejected candidates."""
+        accept = _u8(accept).reshape(-1)
+        n = accept.shape[0]
+        ids = np.zeros(max(n, 1), np.int32)
+        made = C.c_int()
+        self.ctx.check(self.lib.vo_ids_new_landmarks(self.ctx.handle, _p(accept, C.c_uint8), n, _p(ids, C.c_int32),
+                                                     C.byref(made)))
+        return ids[:n]
+
+    def compactTracks(self, mask, alive, tracked, ids):
+        """StereoLandmarkTracking(src, mask) / LandmarkTracking(src, mask) (landmark.cpp:291-332, :194-231):
+        returns (index_valid, tracked after the constructor's setUntracked() calls, ids of the survivors)."""
+        mask, alive = _u8(mask).reshape(-1), _u8(alive).reshape(-1)
+        tracked = _u8(tracked).reshape(-1).copy()
+        ids = np.ascontiguousarray(ids, np.int32).reshape(-1)
+        n = mask.shape[0]
+        if not (alive.shape[0] == tracked.shape[0] == ids.shape[0] == n):
+            raise VoError(-4, "lmtrack sizes differ from mask.size()")  # landmark.cpp:196-197, :293-295
+        idx = np.zeros(max(n, 1), np.int32)
+        ids_out = np.zeros(max(n, 1), np.int32)
+        cnt = C.c_int()
+        self.ctx.check(self.lib.vo_compact_tracks(
+            self.ctx.handle, _p(mask, C.c_uint8), _p(alive, C.c_uint8), _p(tracked, C.c_uint8), _p(ids, C.c_int32), n,
+            _p(idx, C.c_int32), _p(ids_out, C.c_int32), C.byref(cnt)))
+        return idx[:cnt.value].copy(), tracked, ids_out[:cnt.value].copy()
+
+
 def make_stereo_params(width, height, win, max_level, thres_err, thres_bidir, thres_poseba, Kl, Kr,
                        T_lr):
     p = StereoParams()

@@ -216,7 +216,8 @@ __global__ __launch_bounds__(64) void frame_track_kernel(FrameArgs a) {
     }
     // ---- feature, after [4] ----
     first = k;
-    const bool valid1 = frame_klt_valid(k, a.W, a.H, a.thres_err);
+    // StereoLandmarkTracking(lmtrack_prev, mask_l0l1), landmark.cpp:305: mask && isAlive() && isTracked()
+    const bool valid1 = frame_klt_valid(k, a.W, a.H, a.thres_err) && !(a.lm_flags && (a.lm_flags[i] & VO_LM_DROPPED));
     if (lane == 0) {
       a.scale[i] = scale;
       a.k1[2 * i] = k.x;

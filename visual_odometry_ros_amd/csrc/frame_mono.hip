@@ -110,6 +110,7 @@ __global__ __launch_bounds__(64) void mono_track_kernel(MonoArgs a) {
     const float thres2 = a.thres_bidir * a.thres_bidir;
     const bool inimage = fwd.x > 0 && fwd.x < a.W && fwd.y > 0 && fwd.y < a.H;
     m1 = inimage && fwd.status && fwd.err <= a.thres_err && bwd.status && bwd.err <= a.thres_err && dist2 <= thres2 * 5;
+    m1 = m1 && !(fl & VO_MONO_LM_DROPPED);  // LandmarkTracking(lmtrack_prev, mask_track), landmark.cpp:207
   }
   // ---- trackWithScale, pass 1 (taps outside the image masked) ----
   const IcTaps tp = ic_make_taps(lane);

@@ -235,6 +235,8 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
       h.klt_thres_err = prm->thres_err;
       h.klt_W = W;
       h.klt_H = H;
+      h.lm_flags = d_fl;  // landmark.cpp:305: && isAlive() && isTracked()
+      h.lm_reject = VO_LM_DROPPED;
       h.n = n;
       h.d_n_out = &cnt[0];
       h.in2[0] = d_l0;      h.out2[0] = f->A_pl0;

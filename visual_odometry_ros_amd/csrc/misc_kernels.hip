@@ -123,6 +123,8 @@ struct CompactArgs {
   const uint8_t *mask;
   const uint8_t *alive;    // optional
   const uint8_t *tracked;  // optional
+  const uint8_t *lm_flags; // optional: drop where (lm_flags[i] & lm_reject) != 0
+  int lm_reject;
   int n;
   const int *d_n;
   int32_t *index_valid;    // optional out
@@ -166,6 +168,7 @@ __global__ __launch_bounds__(1024) void compact_kernel(CompactArgs a) {
     bool keep = false;
     if (i < n) {
       keep = (!a.mask || a.mask[i]) && (!a.alive || a.alive[i]) && (!a.tracked || a.tracked[i]);
+      if (a.lm_flags) keep = keep && !(a.lm_flags[i] & a.lm_reject);
       if (a.klt_status) {
         const float x = a.klt_pts[2 * i], y = a.klt_pts[2 * i + 1];
         keep = keep && a.klt_status[i] > 0 && x > 0 && x < a.klt_W && y > 0 && y < a.klt_H;
@@ -224,6 +227,8 @@ int vo_compact_enqueue(vo_ctx *c, const CompactArgsHost &h) {
   a.mask = h.mask;
   a.alive = h.alive;
   a.tracked = h.tracked;
+  a.lm_flags = h.lm_flags;
+  a.lm_reject = h.lm_reject;
   a.n = h.n;
   a.d_n = h.d_n;
   a.index_valid = h.index_valid;

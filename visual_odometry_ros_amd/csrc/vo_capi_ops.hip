@@ -273,3 +273,61 @@ extern "C" int vo_compact_indices(vo_ctx *c, const uint8_t *mask, const uint8_t 
   *n_out = cnt;
   return VO_OK;
 }
+
+// ---- track IDs -----------------------------------------------------------------------------------
+// Landmark::landmark_counter_ (landmark.h:64; id_(landmark_counter_++) in both constructors, landmark.cpp:6, :29) and
+// Frame::frame_counter_ (frame.h:53; id_ = frame_counter_++, frame.cpp:15, :35) as state of the context.
+extern "C" int vo_ids_reset(vo_ctx *c, int32_t next_landmark_id, int32_t next_frame_id) {
+  if (!c || next_landmark_id < 0 || next_frame_id < 0) return VO_ERR_INVALID;
+  c->next_landmark_id = next_landmark_id;
+  c->next_frame_id = next_frame_id;
+  return VO_OK;
+}
+
+extern "C" int vo_ids_peek(const vo_ctx *c, int32_t *next_landmark_id, int32_t *next_frame_id) {
+  if (!c) return VO_ERR_INVALID;
+  if (next_landmark_id) *next_landmark_id = c->next_landmark_id;
+  if (next_frame_id) *next_frame_id = c->next_frame_id;
+  return VO_OK;
+}
+
+extern "C" int vo_ids_new_frames(vo_ctx *c, int n, int32_t *ids) {
+  if (!c || n < 0 || (n > 0 && !ids)) return VO_ERR_INVALID;
+  if (c->next_frame_id > INT32_MAX - n) VO_FAIL(c, VO_ERR_CAPACITY, "frame id counter would overflow");
+  for (int i = 0; i < n; ++i) ids[i] = c->next_frame_id++;
+  return VO_OK;
+}
+
+extern "C" int vo_ids_new_landmarks(vo_ctx *c, const uint8_t *accept, int n, int32_t *ids, int *n_created) {
+  if (!c || n < 0 || (n > 0 && !ids)) return VO_ERR_INVALID;
+  if (c->next_landmark_id > INT32_MAX - n) VO_FAIL(c, VO_ERR_CAPACITY, "landmark id counter would overflow");
+  int made = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!accept || accept[i]) {
+      ids[i] = c->next_landmark_id++;
+      ++made;
+    } else {
+      ids[i] = -1;
+    }
+  }
+  if (n_created) *n_created = made;
+  return VO_OK;
+}
+
+extern "C" int vo_compact_tracks(vo_ctx *c, const uint8_t *mask, const uint8_t *alive, uint8_t *tracked,
+                                 const int32_t *ids, int n, int32_t *index_valid, int32_t *ids_out, int *n_out) {
+  if (!c || !mask || !tracked || !index_valid || !n_out) return VO_ERR_INVALID;
+  int rc = vo_compact_indices(c, mask, alive, tracked, n, index_valid, n_out);  // the stable compaction, on the device
+  if (rc < 0) return rc;
+  // the constructor's `else lms[i]->setUntracked()` (landmark.cpp:211-212, :309-310): index_valid ascends
+  int k = 0;
+  for (int i = 0; i < n; ++i) {
+    if (k < *n_out && index_valid[k] == i) {
+      if (ids && ids_out) ids_out[k] = ids[i];
+      ++k;
+    } else {
+      tracked[i] = 0;
+    }
+  }
+  return VO_OK;
+}

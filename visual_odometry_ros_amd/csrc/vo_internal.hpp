@@ -80,6 +80,9 @@ struct vo_ctx {
   // undistortion / rectification maps (rectify.hip): camera 0 = left or mono, 1 = right
   float *rect_u[2], *rect_v[2];
   int rect_w[2], rect_h[2];
+  // per-stream ID counters: Landmark::landmark_counter_ (landmark.h:64) and Frame::frame_counter_ (frame.h:53) are
+  // process-global in the reference; one pair per context keeps the streams of a batch from interleaving
+  int32_t next_landmark_id, next_frame_id;
   struct vo_sba_state *sba;  // device arena of the sparse local BA (sba.hip)
   struct vo_orb_state *orb;  // pyramid, score planes and candidate lists of the keypoint detector (orb_detect.hip)
 };

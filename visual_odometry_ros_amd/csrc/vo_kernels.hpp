@@ -104,6 +104,8 @@ int vo_match_enqueue(vo_ctx *c, const uint8_t *d_a, int na, const uint8_t *d_b, 
                      int32_t *d_best, uint16_t *d_bd, uint16_t *d_sd);
 struct CompactArgsHost {
   const uint8_t *mask = nullptr, *alive = nullptr, *tracked = nullptr;
+  const uint8_t *lm_flags = nullptr;  // drop where (lm_flags[i] & lm_reject) != 0
+  int lm_reject = 0;
   int n = 0;
   const int *d_n = nullptr;
   int32_t *index_valid = nullptr;
