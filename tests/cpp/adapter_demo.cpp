@@ -1,0 +1,88 @@
+// adapter_demo.cpp — the same calls as host_mirror_demo.cpp, made through the REFERENCE-TYPED adapter
+// (reference_adapter.h: global FeatureTracker / MotionEstimator on cv::Mat, cv::Point2f, Eigen::Matrix4f,
+// CameraConstPtr), built against the type-check stand-ins of tests/typecheck_stubs/ (the image has no Eigen / OpenCV).
+// Same input file, same output layout: tests/test_cpp_mirror.py compares the two programs byte for byte, which
+// exercises the adapter's transposes, vector copies and lazily sized contexts on the GPU.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "visual_odometry_ros_amd/core/visual_odometry/reference_adapter.h"
+
+template <typename T>
+static std::vector<T> rd(FILE *f, size_t n) {
+  std::vector<T> v(n);
+  if (n && fread(v.data(), sizeof(T), n, f) != n) {
+    fprintf(stderr, "short read\n");
+    exit(2);
+  }
+  return v;
+}
+
+int main(int argc, char **argv) {
+  if (argc < 3) return 1;
+  FILE *f = fopen(argv[1], "rb");
+  if (!f) return 1;
+  int hdr[4];
+  if (fread(hdr, sizeof(int), 4, f) != 4) return 1;
+  const int n = hdr[0], w = hdr[1], h = hdr[2], npt = hdr[3];
+  auto X = rd<float>(f, 3 * n), pl = rd<float>(f, 2 * n), pr = rd<float>(f, 2 * n);
+  auto K = rd<float>(f, 4), Tlr = rd<float>(f, 16);
+  auto img0 = rd<unsigned char>(f, (size_t)w * h), img1 = rd<unsigned char>(f, (size_t)w * h);
+  auto pts0 = rd<float>(f, 2 * npt), prior = rd<float>(f, 2 * npt);
+  fclose(f);
+
+  // --- MotionEstimator on Eigen / cv types
+  PointVec Xv(n);
+  PixelVec plv(n), prv(n);
+  for (int i = 0; i < n; ++i) {
+    Xv[i] = Point(X[3 * i], X[3 * i + 1], X[3 * i + 2]);
+    plv[i] = Pixel(pl[2 * i], pl[2 * i + 1]);
+    prv[i] = Pixel(pr[2 * i], pr[2 * i + 1]);
+  }
+  PoseSE3 T_lr;  // the file is row-major; Eigen's storage is column-major: fill by (row, col)
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) T_lr(i, j) = Tlr[4 * i + j];
+  CameraConstPtr cam = std::make_shared<Camera>(K[0], K[1], K[2], K[3]);
+  MotionEstimator me(true, T_lr);
+  PoseSE3 T01 = PoseSE3::Identity();
+  MaskVec inl;
+  const bool ok = me.poseOnlyBundleAdjustment_Stereo(Xv, plv, prv, cam, cam, T_lr, 3.0f, T01, inl);
+  int threw = 0;
+  try {
+    MotionEstimator mono(false);
+    mono.poseOnlyBundleAdjustment_Stereo(Xv, plv, prv, cam, cam, T_lr, 3.0f, T01, inl);
+  } catch (const std::runtime_error &) {
+    threw = 1;
+  }
+  // --- FeatureTracker on cv::Mat
+  FeatureTracker ft;
+  PixelVec p0(npt), ptk(npt);
+  for (int i = 0; i < npt; ++i) {
+    p0[i] = Pixel(pts0[2 * i], pts0[2 * i + 1]);
+    ptk[i] = Pixel(prior[2 * i], prior[2 * i + 1]);
+  }
+  MaskVec mv;
+  const cv::Mat I0(h, w, CV_8UC1, img0.data(), (size_t)w), I1(h, w, CV_8UC1, img1.data(), (size_t)w);
+  const cv::Mat du0, dv0;  // accepted and ignored (recomputed on the device)
+  ft.trackWithPrior(I0, I1, p0, 21, 4, 80.0f, ptk, mv);
+  std::vector<float> scale(npt, 1.0f);
+  MaskVec mv2;
+  PixelVec ref = ptk;
+  ft.trackWithScale(I0, du0, dv0, I1, p0, scale, ref, mv2);
+
+  FILE *o = fopen(argv[2], "wb");
+  int oh[3] = {ok ? 1 : 0, threw, 0};
+  fwrite(oh, sizeof(int), 3, o);
+  float Trow[16];  // written row-major like host_mirror_demo's
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) Trow[4 * i + j] = T01(i, j);
+  fwrite(Trow, sizeof(float), 16, o);
+  for (int i = 0; i < n; ++i) fputc(inl[i] ? 1 : 0, o);
+  fwrite(&ptk.data()->x, sizeof(float), 2 * npt, o);
+  for (int i = 0; i < npt; ++i) fputc(mv[i] ? 1 : 0, o);
+  fwrite(&ref.data()->x, sizeof(float), 2 * npt, o);
+  for (int i = 0; i < npt; ++i) fputc(mv2[i] ? 1 : 0, o);
+  fclose(o);
+  return 0;
+}

@@ -15,9 +15,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIBDIR = os.path.join(ROOT, "visual_odometry_ros_amd", "lib")
 
 
-def _compile(tmp_path, name="host_mirror_demo"):
+STUBS = os.path.join(ROOT, "tests", "typecheck_stubs")
+
+
+def _compile(tmp_path, name="host_mirror_demo", extra=()):
     exe = str(tmp_path / name)
-    cmd = ["g++", "-std=c++17", "-O2", "-I", ROOT, os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-o", exe,
+    cmd = ["g++", "-std=c++17", "-O2", "-I", ROOT, *extra, os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-o", exe,
            "-L", LIBDIR, "-lvo_hip", f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib",
            "-lamdhip64"]
     subprocess.check_call(cmd)
@@ -29,10 +32,11 @@ def test_cpp_mirror_compiles_and_links(vo, tmp_path):
     exe = _compile(tmp_path)
     assert os.path.exists(exe)
     assert os.path.exists(_compile(tmp_path, "frame_demo"))
-    # the reference-typed adapter is gated on OpenCV/Eigen headers and must at least preprocess away
-    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I", ROOT, "-x", "c++",
-                           os.path.join(ROOT, "visual_odometry_ros_amd", "core", "visual_odometry",
-                                        "reference_adapter.h")])
+    # the reference-typed adapter, against the type-check stand-ins (tests/test_reference_adapter.py has the details)
+    assert os.path.exists(_compile(tmp_path, "adapter_demo", ADAPTER_INC))
+
+
+ADAPTER_INC = ("-I", os.path.join(STUBS, "thirdparty"), "-I", os.path.join(STUBS, "reference"))
 
 
 @pytest.mark.gpu
@@ -72,6 +76,13 @@ def test_cpp_mirror_matches_python_api_and_oracle(ctx, vo, oracle, tmp_path):
     rc, r_o2, m2_o2, _ = oracle.track_with_scale(img0, img1, pts0, np.ones(npt, np.float32), p_o, None,
                                                  oracle.IC_REFERENCE, oracle.SUM_TREE)
     assert np.array_equal(mv2, m2_o2) and np.array_equal(ref, r_o2)
+    # the reference-typed adapter (cv::Mat / cv::Point2f / column-major Eigen::Matrix4f / CameraConstPtr signatures,
+    # lazily sized contexts) makes the same calls and must produce the same bytes (its header has no GN info: word 2)
+    exe_a = _compile(tmp_path, "adapter_demo", ADAPTER_INC)
+    outa = tmp_path / "out_adapter.bin"
+    subprocess.check_call([exe_a, str(inp), str(outa)])
+    raw_a = open(outa, "rb").read()
+    assert len(raw_a) == len(raw) and raw_a[:8] == raw[:8] and raw_a[12:] == raw[12:]
 
 
 @pytest.mark.gpu
