@@ -161,6 +161,11 @@ int vo_gn_pose_stereo(vo_ctx *ctx, const float *X, const float *pts_l1, const fl
                       float thres_reproj_outlier, float T01[16], uint8_t *mask_inlier,
                       vo_gn_info *info);
 
+/* geometry::se3Exp_f (core/util/geometry_library.cpp:386-440, incl. the theta < 1e-7 branch) and inverseSE3_f
+ * (:554-560) exactly as the GN kernel evaluates them on the device, on their own: T = exp(xi), xi = (v, w);
+ * Tinv (may be NULL) = inverseSE3_f(T). Row-major. A test hook: the estimator never needs the host to call it. */
+int vo_se3_exp(vo_ctx *ctx, const float xi[6], float T[16], float Tinv[16]);
+
 /* Epipolar gates. MotionEstimator::calcSampsonDistance(pts0, pts1, F10, out)
  * (motion_estimator.cpp:572-599) and calcSymmetricEpipolarDistance (:621-653, its per-point part):
  * F10 row-major 3x3. The camera/pose overloads (:538-570) build F10 = Kinv^T [t10]x R10 Kinv on the

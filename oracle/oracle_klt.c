@@ -8,6 +8,20 @@
  *                                     SharrDerivInvoker, LKTrackerInvoker)
  *   modules/imgproc/src/pyramids.cpp (pyrDown, 5-tap [1 4 6 4 1]/16, BORDER_REFLECT_101)
  * pinned by the reference only as "OpenCV 4" (core/CMakeLists.txt:12).
+ * UPSTREAM VERSION THIS WAS WRITTEN AGAINST: the OpenCV 4.5.x line, tag 4.5.4 (the libopencv-dev of Ubuntu 22.04 /
+ * ROS 2 Humble, which is what the reference's ROS 2 nodes link). Nothing was read from disk or from the network —
+ * the restatement is from the author's knowledge of that source — so a reader with OpenCV should diff, function by
+ * function:   vo_ref_pyr_down            <-> pyramids.cpp  pyrDown_<FixPtCast<uchar,8>, ...>  (4.5.4)
+ *             vo_ref_pyramid_levels      <-> lkpyramid.cpp buildOpticalFlowPyramid: the `level != 0 && (sz.width <=
+ *                                            winSize.width || sz.height <= winSize.height)` stop
+ *             vo_ref_scharr              <-> lkpyramid.cpp calcSharrDeriv / ScharrDerivInvoker (3/10/3, s16)
+ *             klt_point (static)         <-> lkpyramid.cpp LKTrackerInvoker::operator(): W_BITS 14, descale 5 /
+ *                                            W_BITS1-5, FLT_SCALE 2^-20, the minEig test, `j > 0 && |delta + prevDelta|
+ *                                            < 0.01` back-off, the level-0-only status / err rules
+ *             vo_ref_calc_optical_flow_pyr_lk <-> calcOpticalFlowPyrLK / SparsePyrLKOpticalFlowImpl::calc: criteria
+ *                                            defaulting (maxCount clamp to [0,100], epsilon to [0,10], squared)
+ * The 4.x line changed none of these between 4.2 and 4.8 to the author's knowledge; 3.x differs in the criteria
+ * defaulting only.
  * Call sites that anchor the semantics (arguments, flags, defaulted criteria):
  *   core/visual_odometry/feature_tracker.cpp:29   track()                     defaults (30, 0.01), minEig 1e-4
  *   core/visual_odometry/feature_tracker.cpp:60,69   trackBidirection()       bwd: maxLevel-1, USE_INITIAL_FLOW, {} criteria, minEig {}=0

@@ -7,7 +7,22 @@
  * cv::ORB is OpenCV 4 features2d (modules/features2d/src/orb.cpp, fast.cpp, fast_score.cpp, keypoint.cpp;
  * modules/imgproc/src/resize.cpp for INTER_LINEAR_EXACT) and is NOT in the reference tree nor in this
  * container. What follows restates its published algorithm from the upstream sources as the author knows
- * them; nothing here could be checked against an OpenCV build:
+ * them; nothing here could be checked against an OpenCV build.
+ * UPSTREAM VERSION THIS WAS WRITTEN AGAINST: the OpenCV 4.5.x line, tag 4.5.4 (Ubuntu 22.04 / ROS 2 Humble's
+ * libopencv-dev). To diff with OpenCV at hand:
+ *   vo_ref_orb_level_sizes          <-> orb.cpp ORB_Impl::detectAndCompute: layerInfo / getScale, computeKeyPoints:
+ *                                       nfeaturesPerLevel (factor = (float)(1.0 / scaleFactor), cvRound, remainder)
+ *   vo_ref_resize_linear_exact_u8   <-> resize.cpp resize_bitExact / interpolationLinear<uchar> (INTER_LINEAR_EXACT),
+ *                                       fixedpoint.hpp ufixedpoint16 / ufixedpoint32 rounding
+ *   vo_ref_fast_score_image         <-> fast.cpp FAST_t<16> (ring offsets, the threshold_tab test, N = 9 contiguous)
+ *                                       and fast_score.cpp cornerScore<16>
+ *   non-max suppression             <-> fast.cpp FAST_t: strict `score > prev/curr/pprev neighbours` over 3x3
+ *   runByImageBorder / retainBest   <-> keypoint.cpp KeyPointsFilter (nth_element + keep the ties)
+ *   harris_response (static)        <-> orb.cpp HarrisResponses (blockSize 7, scale = 1/((1 << 2) * blockSize * 255),
+ *                                       scale_sq_sq, k = 0.04f)
+ * The level loop in 4.5.4 detects on a per-level image with an edge-threshold border copied by copyMakeBorder
+ * (BORDER_REFLECT_101) — detection results inside the border-filtered region do not depend on it.
+ * Summary of what is restated:
  *   pyramid     level 0 = the image; level l = resize(level l-1, Size(cvRound(cols/s), cvRound(rows/s)),
  *               INTER_LINEAR_EXACT), s = (float)pow(1.2, l)
  *   per level   FAST-9/16 (threshold t, non-max suppression), runByImageBorder(31), retainBest(2 n_l) on the

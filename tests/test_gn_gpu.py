@@ -28,7 +28,9 @@ def test_stereo_gn_parity(ctx, vo, oracle, n, seed):
     # same summation tree: iteration count and inlier mask identical, pose to float rounding
     assert info.iterations == info_t.iterations
     assert np.array_equal(mask, mask_t)
-    assert rel_frob(T, T_t) < 1e-6
+    # ... and the pose: the same bits (GPU == oracle(TREE) bit for bit)
+    assert np.array_equal(T.view(np.uint32), T_t.view(np.uint32)), rel_frob(T, T_t)
+    assert info.err == info_t.err and info.delta_norm == info_t.delta_norm
     # reference (sequential) order: north-star tolerance 1e-4 relative Frobenius, masks bit-exact
     assert rel_frob(T, T_s) < 1e-4
     assert np.array_equal(mask, mask_s)
@@ -52,9 +54,38 @@ def test_mono_gn_parity(ctx, vo, oracle, n, seed, variant):
     assert ok == bool(rc_s)
     assert info.iterations == info_t.iterations
     assert np.array_equal(mask, mask_t)
-    assert rel_frob(T, Tt) < 1e-6
+    assert np.array_equal(np.asarray(R).view(np.uint32), R_t.view(np.uint32)), rel_frob(T, Tt)
+    assert np.array_equal(np.asarray(t).view(np.uint32), t_t.view(np.uint32))
     assert rel_frob(T, Ts) < 1e-4
     assert np.array_equal(mask, mask_s)
+
+
+def test_se3_exp_device_unit(ctx, vo, oracle):
+    """T10: geometry::se3Exp_f / inverseSE3_f on the device alone, including the theta < 1e-7 branch that a GN run
+    only reaches by accident (geometry_library.cpp:399-405), the boundary, the double-Taylor range (< 0.25 rad) and
+    the libm range above it. Bit-exact against the oracle's restatement."""
+    rng = np.random.default_rng(3)
+    cases = [np.zeros(6), [1.0, -2.0, 3.0, 0.0, 0.0, 0.0],            # theta == 0: pure translation
+             [0.3, 0.2, -0.1, 3e-8, -4e-8, 1e-8],                      # theta = 5.1e-8 < 1e-7: small-angle branch
+             [0.3, 0.2, -0.1, 1e-7, 0.0, 0.0],                         # the boundary itself (not < 1e-7 in double)
+             [0.3, 0.2, -0.1, 9.9e-8, 0.0, 0.0], [0.3, 0.2, -0.1, 1.5e-7, 0.0, 0.0],
+             [0.05, -0.02, 0.8, 0.004, -0.01, 0.002],                  # BASELINE configs[0] motion
+             [1.0, 2.0, 3.0, 0.2, -0.1, 0.05], [0.1, 0.1, 0.1, 0.2499, 0.0, 0.0], [0.1, 0.1, 0.1, 0.25, 0.0, 0.0],
+             [0.5, -0.5, 2.0, 0.9, -1.2, 0.4], [0.0, 0.0, 0.0, 3.0, 0.5, -0.2]]
+    cases += [np.concatenate([rng.normal(0, 1, 3), rng.normal(0, 10.0 ** e, 3)]) for e in (-9, -8, -7, -6, -4, -2, -1, 0)
+              for _ in range(4)]
+    small = 0
+    for xi in cases:
+        xi = np.asarray(xi, np.float32)
+        T, Ti = vo.se3Exp_f(ctx, xi)
+        T_o = oracle.se3_exp(xi)
+        assert np.array_equal(T.view(np.uint32), T_o.view(np.uint32)), (xi, T, T_o)
+        assert np.array_equal(Ti.view(np.uint32), oracle.inverse_se3(T_o).view(np.uint32)), xi
+        theta = float(np.sqrt(np.float32(np.float32(xi[3] * xi[3] + xi[4] * xi[4]) + xi[5] * xi[5])))
+        if theta < 1e-7:
+            small += 1  # R = I + wx + wx^2/2 with a = 1, b = 0.5: rotation part is exactly I + wx (wx^2 underflows to 0)
+            assert abs(T[0, 0] - 1) < 1e-12 and T[3, 3] == 1
+    assert small >= 6
 
 
 def test_gn_noise_free_recovers_truth(ctx, vo):

@@ -79,7 +79,7 @@ SYMBOLS = [
     "vo_set_image_rectified", "vo_set_image_rectified_device", "vo_set_stereo_pair_rectified_device",
     "vo_profile_enable", "vo_profile_reset", "vo_profile_get", "vo_profile_set_classes",
     "vo_set_stereo_pair_device", "vo_set_pyramid_window_hint",
-    "vo_ids_reset", "vo_ids_peek", "vo_ids_new_frames", "vo_ids_new_landmarks", "vo_compact_tracks",
+    "vo_se3_exp", "vo_ids_reset", "vo_ids_peek", "vo_ids_new_frames", "vo_ids_new_landmarks", "vo_compact_tracks",
 ]
 
 _lib = None

@@ -449,6 +449,15 @@ def compact_indices(ctx, mask, alive=None, tracked=None):
     return idx[: cnt.value].copy()
 
 
+def se3Exp_f(ctx, xi):
+    """geometry::se3Exp_f (geometry_library.cpp:386-440) and inverseSE3_f (:554-560) as the GN kernel evaluates
+    them on the device; returns (T, inverse(T)), row-major 4x4."""
+    xi = _f32(xi).reshape(6)
+    T, Ti = np.zeros(16, np.float32), np.zeros(16, np.float32)
+    ctx.check(ctx.lib.vo_se3_exp(ctx.handle, _p(xi), _p(T), _p(Ti)))
+    return T.reshape(4, 4), Ti.reshape(4, 4)
+
+
 class TrackIds:
     """Landmark / Frame IDs of ONE image stream and the mask-compaction constructors with their side effect.
     The reference's counters are process-global statics (landmark.h:64, frame.h:53); here they belong to the

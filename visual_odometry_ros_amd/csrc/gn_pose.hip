@@ -683,6 +683,38 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
   GSTAMP(4)
 }
 
+// geometry::se3Exp_f / inverseSE3_f on their own (one lane), for the device unit test of the small-angle branch
+__global__ void se3_exp_kernel(const float *xi, float *T, float *Tinv) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float x[6], M[16];
+  for (int i = 0; i < 6; ++i) x[i] = xi[i];
+  se3_exp_dev(x, M);
+  for (int i = 0; i < 16; ++i) T[i] = M[i];
+  float Rt[9];  // inverseSE3_f, the form of the GN kernel's last step
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Rt[i * 3 + j] = M[j * 4 + i];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) Tinv[i * 4 + j] = Rt[i * 3 + j];
+    Tinv[i * 4 + 3] = ((-Rt[i * 3 + 0]) * M[3] + (-Rt[i * 3 + 1]) * M[7]) + (-Rt[i * 3 + 2]) * M[11];
+  }
+  Tinv[12] = Tinv[13] = Tinv[14] = 0.f;
+  Tinv[15] = 1.f;
+}
+
+extern "C" int vo_se3_exp(vo_ctx *c, const float xi[6], float T[16], float Tinv[16]) {
+  if (!c || !xi || !T) return VO_ERR_INVALID;
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  VO_CHECK_HIP(c, hipMemcpyAsync(c->d_mat, xi, sizeof(float) * 6, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(se3_exp_kernel, dim3(1), dim3(64), 0, c->stream, c->d_mat, c->d_mat + 8, c->d_mat + 24);
+  VO_CHECK_HIP(c, hipGetLastError());
+  float out[32];
+  VO_CHECK_HIP(c, hipMemcpyAsync(out, c->d_mat + 8, sizeof(out), hipMemcpyDeviceToHost, c->stream));
+  VO_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+  memcpy(T, out, sizeof(float) * 16);
+  if (Tinv) memcpy(Tinv, out + 16, sizeof(float) * 16);
+  return VO_OK;
+}
+
 // ---- host side ---------------------------------------------------------------
 static void inverse_se3_host(const float T[16], float Ti[16]) {
   float Rt[9];
