@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 
 WIN, MAX_LEVEL = 21, 6
 THRES_ERR, THRES_BIDIR, THRES_POSEBA = 80.0, 0.5, 3.0
-N_U, N_V, N_NEW = 60, 25, 150
+N_U, N_V, N_NEW = 60, 25, int(os.environ.get("VO_BENCH_NNEW", "150"))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 

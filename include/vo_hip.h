@@ -102,6 +102,16 @@ int vo_swap_slots(vo_ctx *ctx, int slot_a, int slot_b);
 /* Both images of a stereo pair in one call (one launch per pyramid level for the pair). */
 int vo_set_stereo_pair_device(vo_ctx *ctx, int slot_l, const void *dev_l, int slot_r, const void *dev_r,
                               int width, int height, int stride);
+/* Image ingestion on the context's SIDE stream (on != 0): vo_set_image* / vo_set_stereo_pair* enqueue their copies
+ * and pyramid chains there, concurrent with whatever the main stream runs (the frame in flight); the operators
+ * that read a slot wait for it on the device. A slot may then be rebuilt only after the result of every frame that
+ * read it has been collected (VO_ERR_INVALID otherwise). Default off: everything on one stream. */
+int vo_set_ingest_side_stream(vo_ctx *ctx, int on);
+/* Both images of a stereo pair from HOST memory without a host synchronisation (vo_set_image is synchronous):
+ * asynchronous H2D + the pyramid chain on the ingest stream. Pinned host buffers give a true asynchronous copy;
+ * the buffers must stay untouched until the frame that reads the slots has returned its result. */
+int vo_set_stereo_pair_host_async(vo_ctx *ctx, int slot_l, const uint8_t *host_l, int slot_r, const uint8_t *host_r,
+                                  int width, int height, int stride);
 /* win > 0: build only levels 0..vo_pyramid_levels(w,h,win,max_level) (what PyrLK with that window
  * can use); 0 (default): every level down to vo_config.max_level. */
 int vo_set_pyramid_window_hint(vo_ctx *ctx, int win);
@@ -299,6 +309,35 @@ int vo_stereo_frame_enqueue(vo_ctx *ctx, const vo_stereo_params *prm, int slot_l
                             int slot_r1, const float *pts_l0, const float *pts_r0,
                             const float *Xp, const uint8_t *flags, int n, const float dT_prior[16],
                             const float *pts_new, int n_new, int inputs_on_device);
+/* ---- step [10] closed on the device ------------------------------------------------------------------------
+ * In the reference the new-point candidates of a frame are extractORBwithBinning_fast(I1_left) AFTER
+ * updateWeightBin(lmtrack_final.pts_l1) (stereo_vo.cpp:691-693), i.e. they depend on this frame's BA. What depends on
+ * the BA is only WHICH bins ask for a point; the detection and the best keypoint of each bin depend on the image
+ * alone. So: vo_new_point_candidates_enqueue runs cv::ORB::detect's restatement and the per-bin arg-max for EVERY bin
+ * as soon as the image is in its slot (side stream, next to the previous frame), vo_stereo_frame_enqueue_closed
+ * tracks every bin's candidate bidirectionally next to the features (speculatively), and the BA launch's epilogue
+ * applies updateWeightBin and emits, bins ascending, exactly the candidates the reference would have extracted and
+ * tracked — no host round trip and no dependent launch behind the BA. Two tables (0 / 1) so that the detection of
+ * pair k+1 can run while frame k is in flight. */
+typedef struct {
+  int n_bins_u, n_bins_v;        /* FeatureExtractor::initParams */
+  int u_step, v_step;            /* WeightBin::init, feature_extractor.h:103-104: (int)floor(n_cols / n_bins_u), ... */
+  float inv_u_step, inv_v_step;  /* :106-107 */
+  vo_orb_params orb;
+} vo_bin_params;
+int vo_new_point_candidates_enqueue(vo_ctx *ctx, int slot, const vo_bin_params *bins, int table);
+/* test hook: waits for the table; xy[n_bins][2], has[n_bins] (either may be NULL), keypoints detected */
+int vo_new_point_candidates_get(vo_ctx *ctx, int table, float *xy, uint8_t *has, int *n_detected);
+/* vo_stereo_frame_enqueue with the candidates taken from `table` (which must hold the detection of the image in
+ * slot_l1). n must be > 0 and prm->win one of 13, 15, 21, 31. Results: vo_stereo_frame_result (pts_new_r, mask_new:
+ * room for n_bins entries; counts->n_new_ok) and vo_stereo_frame_new_points. */
+int vo_stereo_frame_enqueue_closed(vo_ctx *ctx, const vo_stereo_params *prm, int slot_l0, int slot_l1, int slot_r1,
+                                   const float *pts_l0, const float *pts_r0, const float *Xp, const uint8_t *flags,
+                                   int n, const float dT_prior[16], const vo_bin_params *bins, int table,
+                                   int inputs_on_device);
+/* after vo_stereo_frame_result of a closed frame: the candidates' left pixels (pts_l1_new; room for n_bins) */
+int vo_stereo_frame_new_points(vo_ctx *ctx, float *pts_new, int *n_new);
+
 /* Waits for the last enqueued frame and copies its results to host buffers
  * (any of which may be NULL). stage[i] = number of gates point i passed (0..4):
  * 1 [4], 2 [4-1], 3 [5], 4 = in lmtrack_final (BA inlier or untriangulated, and past the gate of [7]). */

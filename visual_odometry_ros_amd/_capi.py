@@ -57,6 +57,11 @@ class OrbParams(C.Structure):
                 ("edge_threshold", C.c_int), ("fast_threshold", C.c_int)]
 
 
+class BinParams(C.Structure):
+    _fields_ = [("n_bins_u", C.c_int), ("n_bins_v", C.c_int), ("u_step", C.c_int), ("v_step", C.c_int),
+                ("inv_u_step", C.c_float), ("inv_v_step", C.c_float), ("orb", OrbParams)]
+
+
 class SbaProblem(C.Structure):
     _fields_ = [("n_frames", C.c_int), ("n_opt", C.c_int), ("n_points", C.c_int), ("n_obs", C.c_int),
                 ("stereo", C.c_int), ("max_iter", C.c_int), ("Kl", C.c_double * 4), ("Kr", C.c_double * 4),
@@ -79,6 +84,8 @@ SYMBOLS = [
     "vo_set_image_rectified", "vo_set_image_rectified_device", "vo_set_stereo_pair_rectified_device",
     "vo_profile_enable", "vo_profile_reset", "vo_profile_get", "vo_profile_set_classes",
     "vo_set_stereo_pair_device", "vo_set_pyramid_window_hint",
+    "vo_set_ingest_side_stream", "vo_set_stereo_pair_host_async", "vo_new_point_candidates_enqueue",
+    "vo_new_point_candidates_get", "vo_stereo_frame_enqueue_closed", "vo_stereo_frame_new_points",
     "vo_se3_exp", "vo_ids_reset", "vo_ids_peek", "vo_ids_new_frames", "vo_ids_new_landmarks", "vo_compact_tracks",
 ]
 
@@ -107,5 +114,10 @@ def load():
     lib.vo_stereo_frame_enqueue.argtypes = [vp, C.POINTER(StereoParams), ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, ci, ci]
     lib.vo_stereo_frame_result.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.POINTER(FrameCounts), C.POINTER(GnInfo)]
     lib.vo_set_stereo_pair_device.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci]
+    lib.vo_set_stereo_pair_host_async.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci]
+    lib.vo_stereo_frame_enqueue_closed.argtypes = [vp, C.POINTER(StereoParams), ci, ci, ci, vp, vp, vp, vp, ci, vp,
+                                                   C.POINTER(BinParams), ci, ci]
+    lib.vo_new_point_candidates_enqueue.argtypes = [vp, ci, C.POINTER(BinParams), ci]
+    lib.vo_stereo_frame_new_points.argtypes = [vp, vp, vp]
     _lib = lib
     return lib

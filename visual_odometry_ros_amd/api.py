@@ -14,7 +14,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import (FrameCounts, GnInfo, MonoCounts, MonoParams, OrbParams, SbaProblem, StereoParams, VoConfig,
+from ._capi import (BinParams, FrameCounts, GnInfo, MonoCounts, MonoParams, OrbParams, SbaProblem, StereoParams, VoConfig,
                     VoError)
 
 KLT_USE_INITIAL_FLOW = 4
@@ -114,6 +114,16 @@ class Context:
 
     def set_pyramid_window_hint(self, win):
         self.check(self.lib.vo_set_pyramid_window_hint(self._h, win))
+
+    def set_ingest_side_stream(self, on=True):
+        """Image ingestion (copies + pyramid chains) on the side stream, concurrent with the frame in flight."""
+        self.check(self.lib.vo_set_ingest_side_stream(self._h, int(bool(on))))
+
+    def set_stereo_pair_host_async(self, slot_l, ptr_l, slot_r, ptr_r, width, height, stride):
+        """Host images (addresses; pinned memory for a true asynchronous copy) without a host synchronisation."""
+        rc = self.lib.vo_set_stereo_pair_host_async(self._h, slot_l, ptr_l, slot_r, ptr_r, width, height, stride)
+        if rc < 0:
+            self.check(rc)
 
     def swap_slots(self, a, b):
         self.check(self.lib.vo_swap_slots(self._h, a, b))
@@ -378,6 +388,30 @@ class FeatureExtractor:
         self.n_detected = nd.value
         return self._pts_buf[: m.value]
 
+    def binParams(self):
+        """The bins and detector settings as the closed step [10] takes them (vo_bin_params)."""
+        b = BinParams()
+        b.n_bins_u, b.n_bins_v, b.u_step, b.v_step = self.n_bins_u_, self.n_bins_v_, self.u_step, self.v_step
+        b.inv_u_step, b.inv_v_step = float(self.inv_u_step_), float(self.inv_v_step_)
+        b.orb = self.orb
+        return b
+
+    def enqueueCandidates(self, slot, table):
+        """Detection + best keypoint of EVERY bin for the image in `slot`, on the side stream, into table 0 / 1
+        (the image-only part of extractORBwithBinning_fast; StereoFramePipeline.enqueue_closed consumes it)."""
+        if getattr(self, "_bin_params", None) is None:
+            self._bin_params = self.binParams()
+        rc = self.lib.vo_new_point_candidates_enqueue(self.ctx.handle, slot, self._bin_params, table)
+        if rc < 0:
+            self.ctx.check(rc)
+
+    def getCandidates(self, table):
+        """test hook: (xy[n_bins, 2], has[n_bins], n_detected) of a table"""
+        nb = self.n_bins_u_ * self.n_bins_v_
+        xy, has, nd = np.zeros((nb, 2), np.float32), np.zeros(nb, np.uint8), C.c_int()
+        self.ctx.check(self.lib.vo_new_point_candidates_get(self.ctx.handle, table, _p(xy), _p(has, C.c_uint8), C.byref(nd)))
+        return xy, has.astype(bool), nd.value
+
     def resetWeightBin(self):
         self.weight[:] = 1
 
@@ -542,6 +576,7 @@ class StereoFramePipeline:
         dT = _f32(dT_prior).reshape(16)
         pts_new = _f32(pts_new).reshape(-1, 2)
         self._n, self._nn = pts_l0.shape[0], pts_new.shape[0]
+        self._closed = False
         fl = None
         if lm_flags is not None:
             fl = _u8(lm_flags).reshape(-1)
@@ -555,8 +590,37 @@ class StereoFramePipeline:
         dT = dT_prior if (isinstance(dT_prior, np.ndarray) and dT_prior.dtype == np.float32 and dT_prior.flags.c_contiguous) \
             else _f32(dT_prior)
         self._n, self._nn = n, n_new
+        self._closed = False
         rc = self.lib.vo_stereo_frame_enqueue(self.ctx.handle, self.prm, slots[0], slots[1], slots[2], d_pts_l0, d_pts_r0,
                                               d_Xp, d_lm_flags, n, dT.ctypes.data, d_pts_new, n_new, 1)
+        if rc < 0:
+            self.ctx.check(rc)
+
+    def enqueue_closed(self, pts_l0, pts_r0, Xp, dT_prior, bins, table, slots=(0, 1, 2), lm_flags=None):
+        """The frame with step [10] closed on the device: candidates = best keypoint of every bin of `table`
+        (FeatureExtractor.enqueueCandidates on the image in slots[1]), emitted for the bins lmtrack_final leaves
+        empty. `bins` = FeatureExtractor.binParams()."""
+        pts_l0, pts_r0 = _f32(pts_l0).reshape(-1, 2), _f32(pts_r0).reshape(-1, 2)
+        Xp = _f32(Xp).reshape(-1, 3)
+        dT = _f32(dT_prior).reshape(16)
+        self._n, self._nn = pts_l0.shape[0], bins.n_bins_u * bins.n_bins_v
+        self._closed = True
+        fl = None
+        if lm_flags is not None:
+            fl = _u8(lm_flags).reshape(-1)
+            if fl.shape[0] != self._n:
+                raise ValueError("lm_flags.size() != pts_l0.size()")
+        self.ctx.check(self.lib.vo_stereo_frame_enqueue_closed(
+            self.ctx.handle, self.prm, slots[0], slots[1], slots[2], pts_l0.ctypes.data, pts_r0.ctypes.data,
+            Xp.ctypes.data, fl.ctypes.data if fl is not None else None, self._n, dT.ctypes.data, bins, table, 0))
+
+    def enqueue_closed_device(self, d_pts_l0, d_pts_r0, d_Xp, n, dT_prior, bins, table, slots=(0, 1, 2), d_lm_flags=None):
+        dT = dT_prior if (isinstance(dT_prior, np.ndarray) and dT_prior.dtype == np.float32 and dT_prior.flags.c_contiguous) \
+            else _f32(dT_prior)
+        self._n, self._nn = n, bins.n_bins_u * bins.n_bins_v
+        self._closed = True
+        rc = self.lib.vo_stereo_frame_enqueue_closed(self.ctx.handle, self.prm, slots[0], slots[1], slots[2], d_pts_l0,
+                                                     d_pts_r0, d_Xp, d_lm_flags, n, dT.ctypes.data, bins, table, 1)
         if rc < 0:
             self.ctx.check(rc)
 
@@ -567,7 +631,7 @@ class StereoFramePipeline:
             self._b = dict(pts_l1=np.zeros((max(n, 1), 2), np.float32), pts_r1=np.zeros((max(n, 1), 2), np.float32),
                            stage=np.zeros(max(n, 1), np.uint8), dT=np.zeros(16, np.float32),
                            pnr=np.zeros((max(nn, 1), 2), np.float32), mnew=np.zeros(max(nn, 1), np.uint8),
-                           counts=FrameCounts(), gn=GnInfo())
+                           pnl=np.zeros((max(nn, 1), 2), np.float32), n_new=C.c_int(), counts=FrameCounts(), gn=GnInfo())
             b = self._b
             self._args = (_p(b["pts_l1"]), _p(b["pts_r1"]), _p(b["stage"], C.c_uint8), _p(b["dT"]), _p(b["pnr"]),
                           _p(b["mnew"], C.c_uint8), C.byref(b["counts"]), C.byref(b["gn"]))
@@ -581,8 +645,17 @@ class StereoFramePipeline:
         rc = self.lib.vo_stereo_frame_result(self.ctx.handle, *self._args)
         if rc < 0:
             self.ctx.check(rc)
+        closed = getattr(self, "_closed", False)
+        if closed:  # the candidates are the device's: their number and left pixels come with the result
+            self._closed = False
+            rc = self.lib.vo_stereo_frame_new_points(self.ctx.handle, b["pnl"].ctypes.data, C.addressof(b["n_new"]))
+            if rc < 0:
+                self.ctx.check(rc)
+            nn = b["n_new"].value
         out = dict(pts_l1=b["pts_l1"][:n], pts_r1=b["pts_r1"][:n], stage=b["stage"][:n], dT=b["dT"].reshape(4, 4),
                    pts_new_r=b["pnr"][:nn], mask_new=b["mnew"][:nn].view(bool), counts=b["counts"], gn=b["gn"])
+        if closed:
+            out["pts_new"] = b["pnl"][:nn]
         if copy:
             cnt, gn = FrameCounts(), GnInfo()
             C.memmove(C.byref(cnt), C.byref(b["counts"]), C.sizeof(cnt))

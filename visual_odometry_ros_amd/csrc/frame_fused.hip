@@ -31,6 +31,7 @@ struct FrameArgs {
   int n;
   int n_new;                   // new-point candidates (step [10])
   const float *pts_new;        // [n_new][2]
+  const uint8_t *cand_has;     // closed step [10]: candidate j = best keypoint of bin j, absent where cand_has[j] == 0
   float *new_r;                // out [n_new][2] forward result
   uint8_t *m_new;              // out [n_new]    trackBidirection mask
   float thres_bidir;
@@ -158,6 +159,10 @@ __global__ __launch_bounds__(64) void frame_track_kernel(FrameArgs a) {
     ix = plx;
     iy = ply;
   } else {
+    if (a.cand_has && !a.cand_has[j]) {  // a bin without a keypoint
+      if (lane == 0) a.m_new[j] = 0;
+      return;
+    }
     p0x = ix = a.pts_new[2 * j];
     p0y = iy = a.pts_new[2 * j + 1];
   }
@@ -370,6 +375,8 @@ int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, 
   memset(&a, 0, sizeof(a));
   const int eff = vo_pyr_levels_host(P0.w, P0.h, prm->win, prm->max_level);
   for (const vo_pyramid *P : {&P0, &P1, &P2}) VO_NEED_LEVELS(c, *P, eff);
+  for (int s : slots)
+    if (vo_slot_acquire(c, s) < 0) return VO_ERR_HIP;
   for (int l = 0; l <= eff; ++l) {
     a.L0[l] = P0.lv[l];
     a.L1[l] = P1.lv[l];
@@ -386,6 +393,7 @@ int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, 
   a.pts_new = d_new;
   a.new_r = b.new_r;
   a.m_new = b.m_new;
+  a.cand_has = b.cand_has;
   a.thres_bidir = prm->thres_bidirection;
 #ifdef FRAME_STAMP
   {

@@ -226,6 +226,7 @@ extern "C" int vo_mono_frame_enqueue(vo_ctx *c, const vo_mono_params *prm, int s
     const int eff = vo_pyr_levels_host(P0.w, P0.h, prm->win, prm->max_level);
     VO_NEED_LEVELS(c, P0, eff);
     VO_NEED_LEVELS(c, P1, eff);
+    if (vo_slot_acquire(c, slot0) < 0 || vo_slot_acquire(c, slot1) < 0) return VO_ERR_HIP;
     for (int l = 0; l <= eff; ++l) {
       a.I0[l] = P0.lv[l];
       a.I1[l] = P1.lv[l];
@@ -331,6 +332,10 @@ extern "C" int vo_mono_frame_enqueue(vo_ctx *c, const vo_mono_params *prm, int s
   }
   VO_CHECK_HIP(c, hipEventRecord(f->ev_done, s));
   f->pending = true;
+  c->frame_slots_busy = c->ingest_side;
+  c->frame_slot[0] = slot0;
+  c->frame_slot[1] = slot1;
+  c->frame_slot[2] = -1;
   return VO_OK;
 }
 
@@ -341,6 +346,7 @@ extern "C" int vo_mono_frame_result(vo_ctx *c, float *pts1, float *scale, uint8_
   VO_CHECK_HIP(c, hipSetDevice(c->device));
   VO_CHECK_HIP(c, hipEventSynchronize(f->ev_done));
   f->pending = false;
+  c->frame_slots_busy = 0;
   const int n = f->n;
   const vo_frame_hdr *h = (const vo_frame_hdr *)f->res_host;
   if (pts1 && n) memcpy(pts1, f->res_host + f->off_pl1, sizeof(float) * 2 * (size_t)n);

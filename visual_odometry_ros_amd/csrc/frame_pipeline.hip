@@ -42,7 +42,7 @@ int vo_frame_init(vo_ctx *c) {
   const size_t N = (size_t)c->cfg.max_points;
   f->cap = (int)N;
   float **f2[] = {&f->in_l0, &f->in_r0, &f->in_new, &f->A_pl0, &f->A_pl1, &f->A_pr1, &f->B_pl1, &f->B_pr1,
-                  &f->C_pl1, &f->C_pr1, &f->new_back, &f->A_ref, &f->A_lastpu};
+                  &f->C_pl1, &f->C_pr1, &f->new_back, &f->A_ref, &f->A_lastpu, &f->bin_r};
   for (float **p : f2) VO_CHECK_HIP(c, fs_alloc(p, 2 * N));
   float **f3[] = {&f->in_X, &f->A_X, &f->B_X, &f->C_X};
   for (float **p : f3) VO_CHECK_HIP(c, fs_alloc(p, 3 * N));
@@ -50,9 +50,10 @@ int vo_frame_init(vo_ctx *c) {
   for (float **p : f1) VO_CHECK_HIP(c, fs_alloc(p, N));
   int32_t **i1[] = {&f->F_orig, &f->A_orig, &f->B_orig, &f->C_orig};
   for (int32_t **p : i1) VO_CHECK_HIP(c, fs_alloc(p, N));
-  uint8_t **u1[] = {&f->m1, &f->m2, &f->m3, &f->mG, &f->st1, &f->st2, &f->st3, &f->A_touched, &f->A_cls, &f->in_flags};
+  uint8_t **u1[] = {&f->m1, &f->m2, &f->m3, &f->mG, &f->st1, &f->st2, &f->st3, &f->A_touched, &f->A_cls, &f->in_flags,
+                    &f->bin_m};
   for (uint8_t **p : u1) VO_CHECK_HIP(c, fs_alloc(p, N));
-  f->res_cap = align16(sizeof(vo_frame_hdr)) + 2 * align16(N) + 3 * align16(sizeof(float) * 2 * N);
+  f->res_cap = align16(sizeof(vo_frame_hdr)) + 2 * align16(N) + 4 * align16(sizeof(float) * 2 * N);
   VO_CHECK_HIP(c, hipMalloc((void **)&f->res_dev, f->res_cap));
   VO_CHECK_HIP(c, hipHostMalloc((void **)&f->res_host, f->res_cap, hipHostMallocDefault));
   VO_CHECK_HIP(c, hipEventCreateWithFlags(&f->ev_done, hipEventDisableTiming));
@@ -67,7 +68,8 @@ void vo_frame_free(vo_ctx *c) {
   void *bufs[] = {f->in_l0, f->in_r0, f->in_X, f->in_new, f->F_scale, f->F_orig, f->A_pl0, f->A_pl1, f->A_pr1,
                   f->A_X, f->A_scale, f->A_orig, f->B_pl1, f->B_pr1, f->B_X, f->B_orig, f->C_pl1, f->C_pr1,
                   f->C_X, f->C_orig, f->m1, f->m2, f->m3, f->mG, f->st1, f->st2, f->e1, f->e2, f->new_back,
-                  f->A_ref, f->A_lastpu, f->A_touched, f->A_cls, f->res_dev, f->st3, f->e3, f->ctl, f->in_flags};
+                  f->A_ref, f->A_lastpu, f->A_touched, f->A_cls, f->res_dev, f->st3, f->e3, f->ctl, f->in_flags, f->bin_r,
+                  f->bin_m};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   if (f->res_host) (void)hipHostFree(f->res_host);
@@ -101,11 +103,26 @@ extern "C" int vo_stereo_frame_set_strict_border(vo_ctx *c, int strict) {
   return VO_OK;
 }
 
-extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, int slot_l1,
-                                       int slot_r1, const float *pts_l0, const float *pts_r0, const float *Xp,
-                                       const uint8_t *flags, int n, const float dT_prior[16], const float *pts_new,
-                                       int n_new, int inputs_on_device) {
+// bp != null: the closed step [10] — the candidates are the per-bin best keypoints of table `table`
+// (vo_new_point_candidates_enqueue), all tracked speculatively, emitted by the BA launch's epilogue
+static int frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, int slot_l1, int slot_r1,
+                              const float *pts_l0, const float *pts_r0, const float *Xp, const uint8_t *flags, int n,
+                              const float dT_prior[16], const float *pts_new, int n_new, int inputs_on_device,
+                              const vo_bin_params *bp, int table) {
   if (!c || !prm || !dT_prior || n < 0 || n_new < 0) return VO_ERR_INVALID;
+  const vo_cand_table *tab = nullptr;
+  if (bp) {
+    if (n <= 0) VO_FAIL(c, VO_ERR_INVALID, "the closed step [10] needs a track set (the first frame is the caller's)");
+    if (!vo_frame_fused_supported(prm->win))
+      VO_FAIL(c, VO_ERR_INVALID, "the closed step [10] needs a window the fused frame kernel is built for (13, 15, 21, 31)");
+    tab = vo_orb_cand_table(c, table);
+    if (!tab || tab->n_bins != bp->n_bins_u * bp->n_bins_v)
+      VO_FAIL(c, VO_ERR_INVALID, "candidate table %d was not filled for %d x %d bins (vo_new_point_candidates_enqueue)", table,
+              bp->n_bins_u, bp->n_bins_v);
+    if (bp->u_step <= 0 || bp->v_step <= 0) VO_FAIL(c, VO_ERR_INVALID, "u_step / v_step must be positive");
+    n_new = tab->n_bins;
+    pts_new = tab->xy;  // device memory in either input mode
+  }
 #ifdef VO_TRACE_HOST
   vo_tt_last = vo_now_us();
 #endif
@@ -136,23 +153,36 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
       VO_CHECK_HIP(c, hipMemcpyAsync(f->in_r0, pts_r0, sizeof(float) * 2 * n, hipMemcpyHostToDevice, s));
       VO_CHECK_HIP(c, hipMemcpyAsync(f->in_X, Xp, sizeof(float) * 3 * n, hipMemcpyHostToDevice, s));
     }
-    if (n_new > 0)
+    if (n_new > 0 && !tab) {
       VO_CHECK_HIP(c, hipMemcpyAsync(f->in_new, pts_new, sizeof(float) * 2 * n_new, hipMemcpyHostToDevice, s));
+      d_new = f->in_new;
+    }
     d_l0 = f->in_l0;
     d_r0 = f->in_r0;
     d_X = f->in_X;
-    d_new = f->in_new;
   }
+  if (tab) VO_CHECK_HIP(c, hipStreamWaitEvent(s, tab->ready, 0));  // (filled on the side stream, long before)
   // ---- carve the packed result block for this frame ----
   f->n = n;
   f->n_new = n_new;
+  f->closed = tab ? 1 : 0;
+  f->table = tab;
   size_t off = align16(sizeof(vo_frame_hdr));
   f->off_stage = off;  off += align16((size_t)n);
   f->off_mnew = off;   off += align16((size_t)n_new);
+  if (tab) {  // the candidate arrays are written by the BA launch's epilogue: they belong to the part copied last
+    f->off_newr = off;  off += align16(sizeof(float) * 2 * (size_t)n_new);
+    f->off_newl = off;  off += align16(sizeof(float) * 2 * (size_t)n_new);
+  }
+  const size_t late_end = off;
   f->off_pl1 = off;    off += align16(sizeof(float) * 2 * (size_t)n);
   f->off_pr1 = off;    off += align16(sizeof(float) * 2 * (size_t)n);
-  f->off_newr = off;   off += align16(sizeof(float) * 2 * (size_t)n_new);
+  if (!tab) {
+    f->off_newr = off;  off += align16(sizeof(float) * 2 * (size_t)n_new);
+    f->off_newl = 0;
+  }
   f->res_bytes = off;
+  if (f->res_bytes > f->res_cap) VO_FAIL(c, VO_ERR_CAPACITY, "result block of %zu bytes exceeds the context's (max_points too small)", f->res_bytes);
   f->hdr = (vo_frame_hdr *)f->res_dev;
   f->stage = f->res_dev + f->off_stage;
   f->mNew = f->res_dev + f->off_mnew;
@@ -192,8 +222,9 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
     b.C_pr1 = f->C_pr1;
     b.C_orig = f->C_orig;
     b.cnt = cnt;
-    b.new_r = f->new_r;
-    b.m_new = f->mNew;
+    b.new_r = tab ? f->bin_r : f->new_r;   // closed: per-bin scratch, compacted into the block by the BA launch
+    b.m_new = tab ? f->bin_m : f->mNew;
+    b.cand_has = tab ? tab->has : nullptr;
     // [10] the new-point candidates are extra workgroups of the same launch
     VO_TT("setup");
     RC(vo_frame_fused_enqueue(c, prm, slot_l0, slot_l1, slot_r1, d_l0, d_r0, d_X, d_fl, n, T_cp, T_rl, d_new, n_new, b, 0));
@@ -325,7 +356,20 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
     gf.res_dev = f->res_dev;
     gf.res_host = f->res_host;  // pinned host memory is device-visible: the kernel copies the block out itself
     gf.res_bytes = f->res_bytes;
-    gf.res_late_bytes = f->off_mnew;  // header + stage bytes
+    gf.res_late_bytes = tab ? late_end : f->off_mnew;  // header + stage bytes (+ the candidate arrays when closed)
+    if (tab) {
+      gf.np_bins = tab->n_bins;
+      gf.np_bins_u = bp->n_bins_u;
+      gf.np_u_step = bp->u_step;
+      gf.np_v_step = bp->v_step;
+      gf.np_has = tab->has;
+      gf.np_xy = tab->xy;
+      gf.np_bin_r = f->bin_r;
+      gf.np_bin_m = f->bin_m;
+      gf.np_out_l = (float *)(f->res_dev + f->off_newl);
+      gf.np_out_r = f->new_r;
+      gf.np_out_m = f->mNew;
+    }
   }
   RC(vo_gn_enqueue(c, true, false, f->C_X, f->C_pl1, f->C_pr1, n, nullptr, prm->Kl, prm->Kr,
                    prm->T_lr, prm->thres_poseba, 0, dT_prior, f->hdr->dT, f->mG, &f->hdr->gn, true,
@@ -338,6 +382,38 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
   VO_CHECK_HIP(c, hipEventRecord(f->ev_done, s));
   VO_TT("event");
   f->pending = true;
+  c->frame_slots_busy = c->ingest_side;  // (one stream orders a rebuild behind the frame by itself)
+  c->frame_slot[0] = slot_l0;
+  c->frame_slot[1] = slot_l1;
+  c->frame_slot[2] = slot_r1;
+  return VO_OK;
+}
+
+extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, int slot_l1,
+                                       int slot_r1, const float *pts_l0, const float *pts_r0, const float *Xp,
+                                       const uint8_t *flags, int n, const float dT_prior[16], const float *pts_new,
+                                       int n_new, int inputs_on_device) {
+  return frame_enqueue_impl(c, prm, slot_l0, slot_l1, slot_r1, pts_l0, pts_r0, Xp, flags, n, dT_prior, pts_new, n_new,
+                            inputs_on_device, nullptr, 0);
+}
+
+extern "C" int vo_stereo_frame_enqueue_closed(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, int slot_l1,
+                                              int slot_r1, const float *pts_l0, const float *pts_r0, const float *Xp,
+                                              const uint8_t *flags, int n, const float dT_prior[16],
+                                              const vo_bin_params *bins, int table, int inputs_on_device) {
+  if (!bins) return VO_ERR_INVALID;
+  return frame_enqueue_impl(c, prm, slot_l0, slot_l1, slot_r1, pts_l0, pts_r0, Xp, flags, n, dT_prior, nullptr, 0,
+                            inputs_on_device, bins, table);
+}
+
+extern "C" int vo_stereo_frame_new_points(vo_ctx *c, float *pts_new, int *n_new) {
+  if (!c || !c->frame || !n_new) return VO_ERR_INVALID;
+  vo_frame_state *f = c->frame;
+  if (f->pending) VO_FAIL(c, VO_ERR_INVALID, "call vo_stereo_frame_result first");
+  if (!f->closed) VO_FAIL(c, VO_ERR_INVALID, "the last frame was not enqueued with vo_stereo_frame_enqueue_closed");
+  const vo_frame_hdr *h = (const vo_frame_hdr *)f->res_host;
+  *n_new = h->cnt[5];
+  if (pts_new && h->cnt[5] > 0) memcpy(pts_new, f->res_host + f->off_newl, sizeof(float) * 2 * (size_t)h->cnt[5]);
   return VO_OK;
 }
 
@@ -351,8 +427,14 @@ extern "C" int vo_stereo_frame_result(vo_ctx *c, float *pts_l1, float *pts_r1, u
   // keeps running
   VO_CHECK_HIP(c, hipEventSynchronize(f->ev_done));
   f->pending = false;
-  const int n = f->n, nn = f->n_new;
+  c->frame_slots_busy = 0;
   const vo_frame_hdr *h = (const vo_frame_hdr *)f->res_host;
+  const int n = f->n, nn = f->closed ? h->cnt[5] : f->n_new;  // closed: what the BA launch's epilogue emitted
+  if (f->closed && f->table) {  // the detector's capacity flags of the table this frame read
+    int rcf = f->table->h_flags[0];
+    if (rcf & 1) VO_FAIL(c, VO_ERR_CAPACITY, "more FAST corners on one pyramid level than the detector's lists hold");
+    if (rcf & 2) VO_FAIL(c, VO_ERR_CAPACITY, "more keypoints than the detector's output buffer holds");
+  }
   if (pts_l1 && n) memcpy(pts_l1, f->res_host + f->off_pl1, sizeof(float) * 2 * (size_t)n);
   if (pts_r1 && n) memcpy(pts_r1, f->res_host + f->off_pr1, sizeof(float) * 2 * (size_t)n);
   if (stage && n) memcpy(stage, f->res_host + f->off_stage, (size_t)n);

@@ -6,6 +6,7 @@
 // header of the packed result block (device and pinned-host copies share the layout)
 struct vo_frame_hdr {
   int cnt[8];  // [0]=nA [1]=nB [2]=nC [3]=features replayed by the strict-border pass [4]=size of the pose-only BA set
+               // [5]=new-point candidates emitted by the closed step [10]
   vo_gn_dev_info gn;
   int flags;
   int pad_[1];
@@ -32,6 +33,8 @@ struct vo_frame_state {
   uint8_t *st1, *st2, *st3;
   float *e1, *e2, *e3;
   float *new_back;
+  float *bin_r;     // closed step [10]: per-bin forward result / trackBidirection mask of the frame kernel
+  uint8_t *bin_m;
   int *ctl;  // fused path: error flags + replay control words (zero between frames)
   // packed result block
   uint8_t *res_dev, *res_host;
@@ -40,8 +43,10 @@ struct vo_frame_state {
   vo_frame_hdr *hdr;
   uint8_t *stage, *mNew;
   float *F_pl1, *F_pr1, *new_r;
-  size_t off_stage, off_mnew, off_pl1, off_pr1, off_newr, res_bytes;
+  size_t off_stage, off_mnew, off_pl1, off_pr1, off_newr, off_newl, res_bytes;
   int n, n_new;
+  int closed;       // the frame in flight takes its candidates from a bin table; n_new is then the number of bins
+  const struct vo_cand_table *table;
   bool pending;
   hipEvent_t ev_done;  // recorded after the packed D2H: result() waits for this, not for the stream
 };

@@ -58,7 +58,7 @@ struct GnArgs {
   const float *f_X, *f_pl1, *f_pr1;
   float *f_CX, *f_Cpl1, *f_Cpr1;
   int32_t *f_Corig;
-  int *f_cnt;               // [5]: three step counts, replayed features, size of the BA set
+  int *f_cnt;               // [6]: three step counts, replayed features, size of the BA set, new-point candidates emitted
   int *f_ctl;               // control block; [0] = error flags, [16 + f_nt_word] = replayed features
   int f_ctl_words, f_nt_word;
   int *f_hdr_flags;
@@ -66,6 +66,12 @@ struct GnArgs {
   uint32_t *f_res_host;
   int f_res_words;
   int f_res_late_words;     // leading words (header, stage bytes) that this kernel still changes: copied last
+  // closed step [10] (vo_gn_frame::np_*)
+  int np_bins, np_bins_u, np_u_step, np_v_step;
+  const uint8_t *np_has, *np_bin_m;
+  const float *np_xy, *np_bin_r;
+  float *np_out_l, *np_out_r;
+  uint8_t *np_out_m;
   const uint8_t *f_m1, *f_m2, *f_m3;  // mono frame: selection masks in place of f_stage
   int f_mono;               // epilogue = mono_gate_body(f_gate)
   MonoGateArgs f_gate;
@@ -678,6 +684,54 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
   } else if (a.f_n > 0 && a.f_res_host) {
     // frame mode epilogue: the packed result block goes to pinned host memory from here
     __syncthreads();  // stage marks, pose and info above are this workgroup's own stores
+    if (a.np_bins > 0) {
+      // ---- closed step [10]: extractor_->updateWeightBin(lmtrack_final.pts_l1) (stereo_vo.cpp:692 ->
+      // feature_extractor.h:116-135: reset to 1, then 0 for every bin that holds a final feature) and the emission of
+      // extractORBwithBinning_fast's bucketed pixels (feature_extractor.cpp:262-277: bins ascending, weight > 0) with
+      // the trackBidirection results (stereo_vo.cpp:706-711) the frame kernel computed for every bin's candidate
+      uint8_t *s_occ = (uint8_t *)s_red;  // (the partial sums are dead)
+      for (int j = tid; j < a.np_bins; j += GN_T) s_occ[j] = 0;
+      __syncthreads();
+      for (int i = tid; i < a.f_n; i += GN_T)
+        if (a.stage[i] == (uint8_t)a.stage_val) {
+          const int u_idx = (int)floorf(a.f_pl1[2 * i] / (float)a.np_u_step);
+          const int v_idx = (int)floorf(a.f_pl1[2 * i + 1] / (float)a.np_v_step);
+          const int bin_idx = v_idx * a.np_bins_u + u_idx;  // only the flattened index is range-tested (:130)
+          if (bin_idx >= 0 && bin_idx < a.np_bins) s_occ[bin_idx] = 1;
+        }
+      __syncthreads();
+      int *s_wv = (int *)s_tot;  // [GN_NW] wave counts, running total at [GN_NW]
+      if (tid == 0) s_wv[GN_NW] = 0;
+      __syncthreads();
+      for (int c0 = 0; c0 < a.np_bins; c0 += GN_T) {
+        const int j = c0 + tid;
+        const bool keep = j < a.np_bins && a.np_has[j] && !s_occ[j];
+        const unsigned long long bal = __ballot(keep);
+        const int below = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wv[wave] = __popcll(bal);
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += s_wv[w];
+        const int base = s_wv[GN_NW];
+        if (keep) {
+          const int o = base + woff + below;
+          a.np_out_l[2 * o] = a.np_xy[2 * j];
+          a.np_out_l[2 * o + 1] = a.np_xy[2 * j + 1];
+          a.np_out_r[2 * o] = a.np_bin_r[2 * j];
+          a.np_out_r[2 * o + 1] = a.np_bin_r[2 * j + 1];
+          a.np_out_m[o] = a.np_bin_m[j];
+        }
+        __syncthreads();
+        if (tid == 0) {
+          int tot = 0;
+          for (int w = 0; w < GN_NW; ++w) tot += s_wv[w];
+          s_wv[GN_NW] = base + tot;
+        }
+        __syncthreads();
+      }
+      if (tid == 0) a.f_cnt[5] = s_wv[GN_NW];
+      __syncthreads();
+    }
     for (int k = tid; k < a.f_res_late_words; k += GN_T) a.f_res_host[k] = a.f_res_dev[k];
   }
   GSTAMP(4)
@@ -784,6 +838,17 @@ int vo_gn_enqueue(vo_ctx *c, bool stereo, bool mono_general_inverse, const float
     a.f_res_host = (uint32_t *)frame->res_host;
     a.f_res_words = (int)((frame->res_bytes + 3) / 4);
     a.f_res_late_words = (int)(frame->res_late_bytes / 4);
+    a.np_bins = frame->np_bins;
+    a.np_bins_u = frame->np_bins_u;
+    a.np_u_step = frame->np_u_step;
+    a.np_v_step = frame->np_v_step;
+    a.np_has = frame->np_has;
+    a.np_xy = frame->np_xy;
+    a.np_bin_r = frame->np_bin_r;
+    a.np_bin_m = frame->np_bin_m;
+    a.np_out_l = frame->np_out_l;
+    a.np_out_r = frame->np_out_r;
+    a.np_out_m = frame->np_out_m;
     a.f_m1 = frame->m1;
     a.f_m2 = frame->m2;
     a.f_m3 = frame->m3;

@@ -109,6 +109,7 @@ static int ic_args(vo_ctx *c, int slot0, int slot1, IcArgs &a, int *d_flags) {
   const vo_pyramid &P0 = c->slots[slot0], &P1 = c->slots[slot1];
   if (P0.n_levels <= 0 || P1.n_levels <= 0) VO_FAIL(c, VO_ERR_INVALID, "slot holds no image");
   if (P0.w != P1.w || P0.h != P1.h) VO_FAIL(c, VO_ERR_SIZE, "image size mismatch");
+  if (vo_slot_acquire(c, slot0) < 0 || vo_slot_acquire(c, slot1) < 0) return VO_ERR_HIP;
   a.I0 = P0.lv[0];
   a.I1 = P1.lv[0];
   a.flags = d_flags ? d_flags : c->d_flags;

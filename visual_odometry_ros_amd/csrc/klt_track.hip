@@ -135,6 +135,7 @@ int vo_klt_enqueue(vo_ctx *c, int slot0, int slot1, const float *d_pts0, const f
   const int eff = vo_pyr_levels_host(P0.w, P0.h, win, max_level);
   VO_NEED_LEVELS(c, P0, eff);
   VO_NEED_LEVELS(c, P1, eff);
+  if (vo_slot_acquire(c, slot0) < 0 || vo_slot_acquire(c, slot1) < 0) return VO_ERR_HIP;
   for (int l = 0; l <= eff; ++l) {
     a.I[l] = P0.lv[l];
     a.J[l] = P1.lv[l];

@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256) void bucket_key_kernel(BinArgs a) {
   const unsigned v = (unsigned)(int)floorf(a.xy[2 * i + 1] * a.inv_v);
   if (u >= (unsigned)a.n_bins_u || v >= (unsigned)a.n_bins_v) return;
   const int bin = (int)(v * (unsigned)a.n_bins_u + u);
-  if (a.weight[bin] == 0) return;
+  if (a.weight && a.weight[bin] == 0) return;  // (no weights: the best keypoint of EVERY bin, gated by the consumer)
   float r = a.response[i];
   if (!(-1.0f < r)) return;  // never beats the initial max_score of -1 (NaN included)
   r = r + 0.0f;              // -0 -> +0: the reference's "<" does not tell them apart
@@ -524,6 +524,47 @@ __global__ __launch_bounds__(1024) void bucket_emit_kernel(BinArgs a) {
   }
   if (tid == 0) *a.n_out = s_base;
 }
+// per-bin table instead of the compacted list: has[bin], xy[bin] of the bin's first keypoint of largest response
+__global__ __launch_bounds__(256) void bucket_table_kernel(BinArgs a, uint8_t *has) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= a.n_bins_u * a.n_bins_v) return;
+  const unsigned long long key = a.key[j];
+  has[j] = key != 0ull ? 1 : 0;
+  float x = 0.f, y = 0.f;
+  if (key != 0ull) {
+    const int idx = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+    x = a.xy[2 * idx];
+    y = a.xy[2 * idx + 1];
+  }
+  a.pts_out[2 * j] = x;
+  a.pts_out[2 * j + 1] = y;
+}
+int vo_bucket_table_enqueue(vo_ctx *c, const float *d_xy, const float *d_response, int n_max, float inv_u, float inv_v,
+                            int n_bins_u, int n_bins_v, unsigned long long *d_key, float *d_tab_xy, uint8_t *d_tab_has,
+                            const int *d_n) {
+  const int total = n_bins_u * n_bins_v;
+  VO_CHECK_HIP(c, hipMemsetAsync(d_key, 0, sizeof(unsigned long long) * (size_t)total, c->stream));
+  BinArgs a;
+  memset(&a, 0, sizeof(a));
+  a.xy = d_xy;
+  a.response = d_response;
+  a.n = n_max;
+  a.inv_u = inv_u;
+  a.inv_v = inv_v;
+  a.n_bins_u = n_bins_u;
+  a.n_bins_v = n_bins_v;
+  a.weight = nullptr;
+  a.key = d_key;
+  a.pts_out = d_tab_xy;
+  a.d_n = d_n;
+  vo_prof_begin(c, VO_K_AUX);
+  if (n_max > 0) hipLaunchKernelGGL(bucket_key_kernel, dim3((n_max + 255) / 256), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(bucket_table_kernel, dim3((total + 255) / 256), dim3(256), 0, c->stream, a, d_tab_has);
+  vo_prof_end(c);
+  VO_CHECK_HIP(c, hipGetLastError());
+  return VO_OK;
+}
+
 int vo_weight_bin_update_enqueue(vo_ctx *c, const float *d_pts, int n, int u_step, int v_step, int n_bins_u,
                                  int n_bins_v, int32_t *d_weight) {
   const int total = n_bins_u * n_bins_v;

@@ -499,6 +499,7 @@ struct vo_orb_state {
   size_t h_cap = 0;
   int pending_bins = 0;
   bool pending = false;
+  vo_cand_table tab[2];  // closed step [10]: double-buffered so that frame k reads one while the detection of k+1 fills the other
 };
 
 void vo_orb_free(vo_ctx *c) {
@@ -507,6 +508,12 @@ void vo_orb_free(vo_ctx *c) {
     if (c->orb->ev_done) (void)hipEventDestroy(c->orb->ev_done);
     if (c->orb->h_res) (void)hipHostFree(c->orb->h_res);
     if (c->orb->arena) (void)hipFree(c->orb->arena);
+    for (vo_cand_table &t : c->orb->tab) {
+      if (t.xy) (void)hipFree(t.xy);
+      if (t.has) (void)hipFree(t.has);
+      if (t.ready) (void)hipEventDestroy(t.ready);
+      if (t.h_flags) (void)hipHostFree(t.h_flags);
+    }
     delete c->orb;
     c->orb = nullptr;
   }
@@ -640,6 +647,7 @@ static int orb_enqueue(vo_ctx *c, int slot, const vo_orb_params *p, int max_bins
   if (P.w > 32767 || P.h > 32767) VO_FAIL(c, VO_ERR_CAPACITY, "image too large for 16-bit candidate coordinates");
   int rc = orb_prepare(c, P.w, P.h, p, max_bins);
   if (rc) return rc;
+  if (vo_slot_acquire(c, slot) < 0) return VO_ERR_HIP;
   vo_orb_state *S = c->orb;
   hipStream_t s = c->stream;
   uint8_t *A = S->arena;
@@ -806,8 +814,8 @@ extern "C" int vo_extract_orb_with_binning_enqueue(vo_ctx *c, int slot, const vo
   float *h_pts = (float *)(S->h_res + 64 + sizeof(int32_t) * (size_t)total);
   memcpy(h_w, weight, sizeof(int32_t) * (size_t)total);
   hipStream_t main_stream = c->stream;
-  // wait for the last pyramid build only — not for what the main stream has enqueued since (the frame operator)
-  VO_CHECK_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_pyr, 0));
+  // the side stream waits for the slot's own build only (vo_slot_acquire in orb_enqueue) — not for what the main
+  // stream has enqueued since (the frame operator)
   c->stream = c->stream2;  // every launcher below enqueues on ctx->stream
   int rc = orb_enqueue(c, slot, p, total);
   if (rc == VO_OK) {
@@ -850,5 +858,73 @@ extern "C" int vo_extract_orb_with_binning_result(vo_ctx *c, float *pts_out, int
   if (m > 0) memcpy(pts_out, h_pts, sizeof(float) * 2 * (size_t)m);
   *n_out = m;
   if (n_detected) *n_detected = hdr[1];
+  return VO_OK;
+}
+
+// ---- closed step [10]: candidates for every bin, ahead of the frame -------------------------------------------
+// `extractor_orb_->detect(I1_left)` and the per-bin arg-max of extractORBwithBinning_fast (feature_extractor.cpp:
+// 241-277) depend on the image only — which bins they are needed for (updateWeightBin(lmtrack_final.pts_l1),
+// stereo_vo.cpp:692) is known after the frame's BA. So the best keypoint of EVERY bin is found as soon as the image
+// is on the device (side stream, overlapping the previous frame), the frame kernel tracks all of them speculatively
+// next to the features (+22 us at 1500 bins against ~100 us for a dependent launch behind the BA), and the BA launch's
+// epilogue emits those whose bin lmtrack_final left empty.
+const vo_cand_table *vo_orb_cand_table(vo_ctx *c, int table) {
+  if (!c->orb || table < 0 || table > 1 || c->orb->tab[table].n_bins <= 0) return nullptr;
+  return &c->orb->tab[table];
+}
+
+extern "C" int vo_new_point_candidates_enqueue(vo_ctx *c, int slot, const vo_bin_params *bp, int table) {
+  if (!c || !bp || table < 0 || table > 1 || bp->n_bins_u <= 0 || bp->n_bins_v <= 0) return VO_ERR_INVALID;
+  const int total = bp->n_bins_u * bp->n_bins_v;
+  if (total > 32768) VO_FAIL(c, VO_ERR_CAPACITY, "%d bins: the closed step [10] handles at most 32768", total);
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  if (!c->orb) c->orb = new vo_orb_state();
+  vo_orb_state *S = c->orb;
+  vo_cand_table &T = S->tab[table];
+  if (T.n_bins != total) {
+    if (T.xy) (void)hipFree(T.xy);
+    if (T.has) (void)hipFree(T.has);
+    T.xy = nullptr;
+    T.has = nullptr;
+    T.n_bins = 0;
+    VO_CHECK_HIP(c, hipMalloc((void **)&T.xy, sizeof(float) * 2 * (size_t)total));
+    VO_CHECK_HIP(c, hipMalloc((void **)&T.has, (size_t)total));
+    if (!T.ready) VO_CHECK_HIP(c, hipEventCreateWithFlags(&T.ready, hipEventDisableTiming));
+    if (!T.h_flags) VO_CHECK_HIP(c, hipHostMalloc((void **)&T.h_flags, 64, hipHostMallocDefault));
+    T.n_bins = total;
+  }
+  hipStream_t caller = c->stream;
+  c->stream = c->stream2;  // every launcher below enqueues on ctx->stream
+  int rc = orb_enqueue(c, slot, &bp->orb, total);
+  if (rc == VO_OK) {
+    uint8_t *A = S->arena;
+    rc = vo_bucket_table_enqueue(c, (const float *)(A + S->o_oxy), (const float *)(A + S->o_oresp), S->max_out,
+                                 bp->inv_u_step, bp->inv_v_step, bp->n_bins_u, bp->n_bins_v,
+                                 (unsigned long long *)(A + S->o_keys), T.xy, T.has, (const int *)(A + S->o_on));
+    hipError_t e = hipSuccess;
+    if (rc == VO_OK) e = hipMemcpyAsync(T.h_flags, A + S->o_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    if (rc == VO_OK && e == hipSuccess)
+      e = hipMemcpyAsync(T.h_flags + 1, A + S->o_on, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    if (rc == VO_OK && e == hipSuccess) e = hipEventRecord(T.ready, c->stream);
+    if (e != hipSuccess) {
+      snprintf(c->err, sizeof(c->err), "vo_new_point_candidates_enqueue: %s", hipGetErrorString(e));
+      rc = VO_ERR_HIP;
+    }
+  }
+  c->stream = caller;
+  return rc;
+}
+
+// test hook: the table as the frame kernel will see it (waits for its detection)
+extern "C" int vo_new_point_candidates_get(vo_ctx *c, int table, float *xy, uint8_t *has, int *n_detected) {
+  const vo_cand_table *T = c ? vo_orb_cand_table(c, table) : nullptr;
+  if (!T) return VO_ERR_INVALID;
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  VO_CHECK_HIP(c, hipEventSynchronize(T->ready));
+  int rc = orb_check_flags(c, T->h_flags[0]);
+  if (rc) return rc;
+  if (xy) VO_CHECK_HIP(c, hipMemcpy(xy, T->xy, sizeof(float) * 2 * (size_t)T->n_bins, hipMemcpyDeviceToHost));
+  if (has) VO_CHECK_HIP(c, hipMemcpy(has, T->has, (size_t)T->n_bins, hipMemcpyDeviceToHost));
+  if (n_detected) *n_detected = T->h_flags[1];
   return VO_OK;
 }

@@ -185,7 +185,15 @@ static int build(vo_ctx *c, int slot_l, const uint8_t *d_l, int slot_r, const ui
   if (w <= 0 || h <= 0 || w > c->cfg.max_width || h > c->cfg.max_height)
     VO_FAIL(c, VO_ERR_CAPACITY, "image %dx%d exceeds vo_config %dx%d", w, h, c->cfg.max_width, c->cfg.max_height);
   vo_pyramid *P[2] = {&c->slots[slot_l], d_r ? &c->slots[slot_r] : nullptr};
+  // A slot may be rebuilt only when everything that reads it has been collected: with ingestion on the side stream
+  // nothing on the device orders the rebuild behind a frame that is still in flight.
+  if (c->frame_slots_busy)
+    for (int i = 0; i < nimg; ++i)
+      for (int k = 0; k < 3; ++k)
+        if (c->frame_slot[k] == (i ? slot_r : slot_l))
+          VO_FAIL(c, VO_ERR_INVALID, "slot %d is read by the frame in flight: collect its result first", c->frame_slot[k]);
   for (int i = 0; i < nimg; ++i) layout_slot(c, P[i], w, h);
+  vo_ingest_scope ingest(c);  // launchers enqueue on c->stream: the ingest stream for the duration of this chain
   int top = c->cfg.max_level;
   if (c->pyr_win_hint > 0) top = vo_pyr_levels_host(w, h, c->pyr_win_hint, c->cfg.max_level);
   if (cams)
@@ -243,6 +251,12 @@ static int build(vo_ctx *c, int slot_l, const uint8_t *d_l, int slot_r, const ui
   for (int i = 0; i < nimg; ++i) P[i]->n_levels = nl;
   VO_CHECK_HIP(c, hipGetLastError());
   VO_CHECK_HIP(c, hipEventRecord(c->ev_pyr, c->stream));
+  const int k = c->stream == c->stream2 ? 1 : 0;
+  for (int i = 0; i < nimg; ++i) {
+    VO_CHECK_HIP(c, hipEventRecord(P[i]->ready, c->stream));
+    P[i]->seen[k] = 1;
+    P[i]->seen[1 - k] = 0;
+  }
   return VO_OK;
 }
 

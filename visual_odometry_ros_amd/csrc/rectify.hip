@@ -292,6 +292,7 @@ extern "C" int vo_set_image_rectified(vo_ctx *c, int slot, const uint8_t *host, 
     VO_FAIL(c, VO_ERR_CAPACITY, "image %dx%d exceeds vo_config %dx%d", width, height, c->cfg.max_width,
             c->cfg.max_height);
   VO_CHECK_HIP(c, hipSetDevice(c->device));
+  vo_ingest_scope ingest(c);
   SYNC();  // the previous use of the staging buffers must have drained
   for (int y = 0; y < height; ++y) memcpy(c->h_stage + (size_t)y * width, host + (size_t)y * stride, (size_t)width);
   H2D(c->d_img_stage, c->h_stage, (size_t)width * height);

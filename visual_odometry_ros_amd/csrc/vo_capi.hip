@@ -77,6 +77,7 @@ extern "C" int vo_create(const vo_config *cfg, vo_ctx **out) {
   *out = c;  // so that the caller can read the error and destroy
   VO_CHECK_HIP(c, hipSetDevice(c->device));
   VO_CHECK_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  c->stream_main = c->stream;
   VO_CHECK_HIP(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
   VO_CHECK_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   VO_CHECK_HIP(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
@@ -88,6 +89,8 @@ extern "C" int vo_create(const vo_config *cfg, vo_ctx **out) {
     P->bytes = pyramid_bytes(cfg->max_width, cfg->max_height, cfg->max_level, nullptr);
     VO_CHECK_HIP(c, hipMalloc((void **)&P->mem, P->bytes));
     P->n_levels = 0;
+    VO_CHECK_HIP(c, hipEventCreateWithFlags(&P->ready, hipEventDisableTiming));
+    P->seen[0] = P->seen[1] = 1;  // nothing built yet: nothing to wait for
   }
   VO_CHECK_HIP(c, dalloc(&c->d_pts0, 2 * N));
   VO_CHECK_HIP(c, dalloc(&c->d_pts1, 2 * N));
@@ -131,7 +134,11 @@ extern "C" void vo_destroy(vo_ctx *c) {
     free(c->prof);
   }
   if (c->slots) {
-    for (int s = 0; s < c->cfg.n_slots; ++s) (void)hipFree(c->slots[s].mem);
+    for (int s = 0; s < c->cfg.n_slots; ++s) {
+      (void)hipFree(c->slots[s].mem);
+      if (c->slots[s].stage) (void)hipFree(c->slots[s].stage);
+      if (c->slots[s].ready) (void)hipEventDestroy(c->slots[s].ready);
+    }
     free(c->slots);
   }
   void *bufs[] = {c->d_pts0, c->d_pts1, c->d_pts2, c->d_pts3, c->d_err, c->d_err2, c->d_scale, c->d_X,
@@ -285,6 +292,7 @@ extern "C" int vo_set_image(vo_ctx *c, int slot, const uint8_t *host, int width,
     VO_FAIL(c, VO_ERR_CAPACITY, "image %dx%d exceeds vo_config %dx%d", width, height, c->cfg.max_width,
             c->cfg.max_height);
   VO_CHECK_HIP(c, hipSetDevice(c->device));
+  vo_ingest_scope ingest(c);
   // the previous use of the staging buffers must have drained
   SYNC();
   for (int y = 0; y < height; ++y) memcpy(c->h_stage + (size_t)y * width, host + (size_t)y * stride, (size_t)width);
@@ -301,6 +309,36 @@ extern "C" int vo_set_stereo_pair_device(vo_ctx *c, int slot_l, const void *dev_
   VO_CHECK_HIP(c, hipSetDevice(c->device));
   return vo_pyramid_build_pair(c, slot_l, (const uint8_t *)dev_l, slot_r, (const uint8_t *)dev_r, width, height,
                                stride);
+}
+
+extern "C" int vo_set_ingest_side_stream(vo_ctx *c, int on) {
+  if (!c) return VO_ERR_INVALID;
+  c->ingest_side = on ? 1 : 0;
+  return VO_OK;
+}
+
+// Host images without a host synchronisation: H2D of both images into the slots' staging planes and the pyramid
+// chain, all on the ingest stream; the frame that reads the slots waits for the slots' events on the device.
+extern "C" int vo_set_stereo_pair_host_async(vo_ctx *c, int slot_l, const uint8_t *host_l, int slot_r,
+                                             const uint8_t *host_r, int width, int height, int stride) {
+  if (!c || !host_l || !host_r) return VO_ERR_INVALID;
+  if (slot_l < 0 || slot_l >= c->cfg.n_slots || slot_r < 0 || slot_r >= c->cfg.n_slots || slot_l == slot_r)
+    VO_FAIL(c, VO_ERR_INVALID, "slot out of range");
+  if (width <= 0 || height <= 0 || width > c->cfg.max_width || height > c->cfg.max_height || stride < width)
+    VO_FAIL(c, VO_ERR_CAPACITY, "image %dx%d exceeds vo_config %dx%d", width, height, c->cfg.max_width,
+            c->cfg.max_height);
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  vo_ingest_scope ingest(c);
+  hipStream_t s = c->stream;
+  const int slots[2] = {slot_l, slot_r};
+  const uint8_t *src[2] = {host_l, host_r};
+  for (int i = 0; i < 2; ++i) {
+    vo_pyramid &P = c->slots[slots[i]];
+    if (!P.stage) VO_CHECK_HIP(c, hipMalloc((void **)&P.stage, (size_t)c->cfg.max_width * c->cfg.max_height));
+    VO_CHECK_HIP(c, hipMemcpy2DAsync(P.stage, (size_t)width, src[i], (size_t)stride, (size_t)width, (size_t)height,
+                                     hipMemcpyHostToDevice, s));
+  }
+  return vo_pyramid_build_pair(c, slot_l, c->slots[slot_l].stage, slot_r, c->slots[slot_r].stage, width, height, width);
 }
 
 extern "C" int vo_set_pyramid_window_hint(vo_ctx *c, int win) {
@@ -323,6 +361,7 @@ extern "C" int vo_get_level(vo_ctx *c, int slot, int level, uint8_t *host, int *
   if (level < 0 || level >= P.n_levels) VO_FAIL(c, VO_ERR_INVALID, "level %d not built (%d levels)", level, P.n_levels);
   const vo_level &L = P.lv[level];
   VO_CHECK_HIP(c, hipSetDevice(c->device));
+  if (vo_slot_acquire(c, slot) < 0) return VO_ERR_HIP;
   VO_CHECK_HIP(c, hipMemcpy2DAsync(host, (size_t)L.w, L.origin(), (size_t)L.stride, (size_t)L.w, (size_t)L.h,
                                    hipMemcpyDeviceToHost, c->stream));
   SYNC();

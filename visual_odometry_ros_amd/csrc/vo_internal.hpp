@@ -28,6 +28,11 @@ struct vo_pyramid {
   int w, h;
   uint8_t *mem;    // one allocation for all levels
   size_t bytes;
+  // ordering across the context's two streams: `ready` is recorded behind every build of the slot, on the stream
+  // that built it; a consumer on the other stream waits for it once (vo_slot_acquire)
+  hipEvent_t ready;
+  uint8_t seen[2];  // [0] main stream / [1] side stream is already ordered behind the last build
+  uint8_t *stage;  // device staging for an image that arrives from the host asynchronously (allocated on demand)
 };
 
 struct vo_gn_dev_info {
@@ -45,8 +50,10 @@ struct vo_prof_rec {
 struct vo_ctx {
   vo_config cfg;
   int device;
-  hipStream_t stream;
+  hipStream_t stream;      // the stream launchers enqueue on (= stream_main, except while a side-stream chain is built)
+  hipStream_t stream_main;
   hipStream_t stream2;     // side stream: work that does not depend on the main chain of a frame
+  int ingest_side;         // vo_set_ingest_side_stream: image ingestion (H2D, pyramids) runs on the side stream
   hipEvent_t ev_fork, ev_join;
   hipEvent_t ev_pyr;       // recorded behind every pyramid build: what side-stream consumers of a slot wait for
   char err[512];
@@ -71,6 +78,8 @@ struct vo_ctx {
   void *ic_rec;            // tap records of the IC strict replay (ic_refine.hip)
   struct vo_frame_state *frame;
   int frame_strict_ic;     // replay border-touching points with the reference's sticky tap state
+  int frame_slots_busy;    // a frame is in flight and reads frame_slot[0..2]
+  int frame_slot[3];
   // profiling
   vo_prof_rec *prof;
   int prof_cap, prof_n;
@@ -115,6 +124,29 @@ struct vo_ctx {
               "vo_set_pyramid_window_hint the SMALLEST window in use",                                               \
               (P).n_levels - 1, (eff));                                                                              \
   } while (0)
+
+// Work about to be enqueued on c->stream reads the pyramid of `slot`: order it behind the slot's last build if that
+// ran on the other stream (one hipStreamWaitEvent per build and stream, nothing when both are the same stream).
+static inline int vo_slot_acquire(vo_ctx *c, int slot) {
+  vo_pyramid &P = c->slots[slot];
+  const int k = c->stream == c->stream2 ? 1 : 0;
+  if (!P.seen[k]) {
+    VO_CHECK_HIP(c, hipStreamWaitEvent(c->stream, P.ready, 0));
+    P.seen[k] = 1;
+  }
+  return VO_OK;
+}
+
+// Image ingestion (H2D + pyramid chain) enqueues on the side stream when vo_set_ingest_side_stream is on: launchers
+// use c->stream, which this scope points at the ingest stream and restores on exit.
+struct vo_ingest_scope {
+  vo_ctx *c;
+  hipStream_t saved;
+  explicit vo_ingest_scope(vo_ctx *ctx) : c(ctx), saved(ctx->stream) {
+    if (c->ingest_side && c->stream == c->stream_main) c->stream = c->stream2;
+  }
+  ~vo_ingest_scope() { c->stream = saved; }
+};
 
 // ---- profiling brackets (no-ops unless vo_profile_enable was called) --------
 static inline void vo_prof_begin(vo_ctx *c, int cls) {

@@ -25,6 +25,16 @@ struct vo_gn_frame {
   // and the epilogue is mono_gate_body(*mono_gate) — a MonoGateArgs, copied into the kernel arguments
   const uint8_t *m1, *m2, *m3;
   const struct MonoGateArgs *mono_gate;
+  // closed step [10] (stereo): updateWeightBin(lmtrack_final.pts_l1) + the emission of the bucketed candidates of the
+  // bins left empty, from the speculative per-bin results of the frame kernel
+  int np_bins;              // > 0: enabled; n_bins_u * n_bins_v
+  int np_bins_u, np_u_step, np_v_step;
+  const uint8_t *np_has;    // [np_bins] table: the bin holds a keypoint
+  const float *np_xy;       // [np_bins][2] table: its pixel
+  const float *np_bin_r;    // [np_bins][2] frame kernel: forward result of the bin's candidate
+  const uint8_t *np_bin_m;  // [np_bins]    frame kernel: trackBidirection mask of the bin's candidate
+  float *np_out_l, *np_out_r;  // compacted, bins ascending (inside the result block)
+  uint8_t *np_out_m;
 };
 int vo_gn_enqueue(vo_ctx *c, bool stereo, bool mono_general_inverse, const float *dX, const float *dP1,
                   const float *dP2, int n, const int *d_n, const float Kl[4], const float Kr[4],
@@ -85,6 +95,7 @@ struct vo_frame_fused_bufs {
   uint8_t *stage, *m2, *touched, *cls;
   float *new_r;    // new-point candidates: forward result / mask
   uint8_t *m_new;
+  const uint8_t *cand_has;  // closed step [10]: candidate j is bin j of a table, present where cand_has[j] != 0
   int *ctl;        // control block (vo_ic_ctl_bytes): error flags + replay control words
   int *hdr_flags;  // where the frame's error flags are reported
   float *C_X, *C_pl1, *C_pr1;
@@ -147,6 +158,20 @@ int vo_weight_bin_update_enqueue(vo_ctx *c, const float *d_pts, int n, int u_ste
 int vo_bucket_argmax_enqueue(vo_ctx *c, const float *d_xy, const float *d_response, int n, float inv_u, float inv_v,
                              int n_bins_u, int n_bins_v, const int32_t *d_weight, unsigned long long *d_key,
                              float *d_pts_out, int32_t *d_idx_out, int *d_n_out, const int *d_n = nullptr);
+
+int vo_bucket_table_enqueue(vo_ctx *c, const float *d_xy, const float *d_response, int n_max, float inv_u, float inv_v,
+                            int n_bins_u, int n_bins_v, unsigned long long *d_key, float *d_tab_xy, uint8_t *d_tab_has,
+                            const int *d_n);
+
+// orb_detect.hip: per-bin candidate tables of the closed step [10] (vo_new_point_candidates_enqueue)
+struct vo_cand_table {
+  float *xy;        // [n_bins][2] best keypoint of the bin (level-0 pixels)
+  uint8_t *has;     // [n_bins]    the bin holds a keypoint
+  int n_bins;       // 0 = never filled
+  hipEvent_t ready; // recorded on the side stream behind the table's kernels and the copy of its flags
+  int *h_flags;     // pinned: the detector's capacity flags of this table's detection
+};
+const vo_cand_table *vo_orb_cand_table(vo_ctx *c, int table);
 
 // frame_pipeline.hip
 void vo_frame_free(vo_ctx *c);
