@@ -1,23 +1,36 @@
 #!/usr/bin/env python3
-"""bench.py — stereo VO frames/s on the synthetic KITTI-shaped stream (BASELINE.json
-configs[1]: 1241x376, 1500 tracked features per frame), one image stream per GPU.
+"""bench.py — VO frames/s of the hot path on MI355X, one image stream per GPU.
 
-A "step" is one steady-state stereo frame through the hot path: pyramids of the new
-left/right images, trackWithPrior l0->l1, trackWithScale, trackWithPrior l1->r1,
-stereo pose-only GN, and trackBidirection of the new-point candidates — the operator
-sequence of StereoVO::trackStereoImages (stereo_vo.cpp:483-711) — with the result
-(pose, survivors) read back to the host every frame, as a sequential VO needs it.
-Inputs (images and track sets) are resident in HBM before the timed region.
+Default workload = BASELINE.json configs[1]: synthetic KITTI-shaped stereo stream, 1241x376, 1500 tracked features
+per frame (60x25 buckets), win 21, max_level 6 (5 effective levels), thresholds of config/stereo/kitti_00_stereo.yaml.
+A "step" is ONE steady-state stereo frame through the whole operator sequence of StereoVO::trackStereoImages
+(stereo_vo.cpp:483-711), in the reference's order of dependencies:
+    pyramids of the new pair -> [3] priors -> [4] trackWithPrior l0->l1 -> [4-1] trackWithScale -> [5] trackWithPrior
+    l1->r1 -> [6] stereo pose-only BA on the triangulated survivors -> [7] gate -> [10] updateWeightBin(survivors),
+    extractORBwithBinning_fast(I1_left) (keypoint detection + per-bucket arg-max), trackBidirection of the new points
+with the result (pose, survivor stages, pixels, new points) read back to the host EVERY frame, as a sequential VO
+needs it before it can go on. Step [10] is closed on the device: nothing is known to the operator
+ahead of the frame that the reference does not know either.
 
-  python bench.py --gpus N --steps K --warmup W
-  (N > 1: one rank per GPU, RCCL gather of the totals; under torch.distributed.run the ranks are the launcher's,
-   without a launcher environment bench.py starts the N ranks itself as fresh child processes)
+  python bench.py --gpus N --steps K --warmup W            (the driver's contract)
+  python bench.py --config {1,2,4}                         BASELINE configs[1] (default) / [2] mono 752x480 / [4] 4K stereo
+  N > 1: one rank per GPU, independent streams, one RCCL all_gather of the totals at the end; under
+  torch.distributed.run the ranks are the launcher's, without a launcher environment bench.py starts the N ranks
+  itself as fresh child processes (before this process has touched a GPU).
 
-Prints ONE JSON line on rank 0 (see DESIGN.md §Measurement for every field).
+Prints ONE JSON line on rank 0. `value` is measured with the images resident in HBM before the timed region;
+secondary measurements of the same run (N = 1 only) are reported next to it:
+  host_images            the same frames with BOTH images arriving from pinned host memory every frame (H2D inside the
+                         timed region, overlapped with the frame in flight)
+  sequential_step10      step [10] as three host-driven operator calls after the frame's result (updateWeightBin,
+                         extractORBwithBinning_fast, trackBidirection): what the class surface delivers without the
+                         closed operator
+  open_loop_candidates   round 1's workload: 150 candidates handed to the frame kernel before the frame (a sequential
+                         VO cannot know them then; kept for comparison only)
+See DESIGN.md §6 for every field.
 """
 import argparse
 import gc
-import ctypes as C
 import json
 import os
 import sys
@@ -28,29 +41,42 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WIN, MAX_LEVEL = 21, 6
-THRES_ERR, THRES_BIDIR, THRES_POSEBA = 80.0, 0.5, 3.0
-N_U, N_V, N_NEW = 60, 25, int(os.environ.get("VO_BENCH_NNEW", "150"))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+KITTI_K = (718.856, 718.856, 607.1928, 185.2157)
+CONFIGS = {
+    1: dict(kind="stereo", name="BASELINE configs[1]", metric="stereo VO frames/sec @1241x376, 1500 feats",
+            W=1241, H=376, K=KITTI_K, n_u=60, n_v=25, win=21, max_level=6, speed=0.8, margin=31.0,
+            thres=(80.0, 0.5, 3.0), thres_fast=15),
+    2: dict(kind="mono", name="BASELINE configs[2]", metric="mono VO frames/sec @752x480, 1000 feats",
+            W=752, H=480, K=(458.654, 457.296, 367.215, 248.375), n_u=40, n_v=25, win=15, max_level=5, speed=0.25,
+            margin=31.0, thres=(20.0, 1.0, 5, 1.0)),
+    4: dict(kind="stereo", name="BASELINE configs[4]", metric="stereo VO frames/sec @3840x2160, 8000 feats",
+            W=3840, H=2160, K=(718.856 * 3.0, 718.856 * 3.0, 1920.0, 1080.0), n_u=100, n_v=80, win=21, max_level=4,
+            speed=0.8, margin=31.0, thres=(80.0, 0.5, 3.0), thres_fast=15),
+}
+UNTRIANGULATED = 0.10  # share of the track set whose landmark has no 3-D point yet (new since the last keyframe)
+N_NEW_OPEN = 150       # candidates of the open-loop comparison workload
 
 
+# ---- algorithmic bytes -------------------------------------------------------------------------
 def klt_bytes_per_point_level(win):
-    # u8 template tile incl. Scharr halo + one u8 search tile
-    return (win + 2) ** 2 + (win + 1) ** 2
+    return (win + 2) ** 2 + (win + 1) ** 2  # u8 template tile incl. Scharr halo + one u8 search tile
 
 
-IC_BYTES_PER_POINT = 27 * 32 + 40 * 44          # u8 template tile (Sobel halo) + u8 search tile
-IC_RECORD_BYTES = (3 + 1) * 264 * 4 + 2 * 9 * 4  # strict border: tap values + tap masks written per feature
-POINT_IO_BYTES = 64                              # landmark, pixels, priors in; pixels, stage out
+IC_BYTES_8D = 25 ** 2 + 24 ** 2                  # §8(d): B_ic = N * [(25)^2 + (24)^2]
+IC_RECORD_BYTES = (3 + 1) * 264 * 4 + 2 * 9 * 4  # design, strict border only: tap values + tap masks written per feature
+POINT_IO_BYTES = 64                              # design: landmark, pixels, priors in; pixels, stage out
 
 
-def frame_kernel_bytes(win, n, n_l0l1, n_step5, n_new, levels, levels_bwd, strict):
-    """Algorithmic bytes of ONE frame_track_kernel launch (kernel table): the tiles every
-    feature has to see once per pyramid level and pass, the IC tiles, the tap records."""
-    klt = klt_bytes_per_point_level(win) * ((n + n_step5) * levels + n_new * (levels + levels_bwd))
-    return klt + IC_BYTES_PER_POINT * n_l0l1 + (IC_RECORD_BYTES * n if strict else 0) + POINT_IO_BYTES * (n + n_new)
+def frame_kernel_bytes(win, n, n_l0l1, n_step5, n_cand, levels, levels_bwd, strict):
+    """Algorithmic bytes of ONE launch of the frame kernel, split as the verdict asked: `survey_8d` is §8(d)'s per-unit
+    figure times the units the launch processes (KLT point-levels of the features' two calls and of the candidates'
+    forward + backward calls, IC tiles), `design_records` is what this design adds (strict-border tap records, point I/O)."""
+    klt = klt_bytes_per_point_level(win) * ((n + n_step5) * levels + n_cand * (levels + levels_bwd))
+    return klt + IC_BYTES_8D * n_l0l1, (IC_RECORD_BYTES * n if strict else 0) + POINT_IO_BYTES * (n + n_cand)
 
 
+# ---- the one collective --------------------------------------------------------------------------------------------
 def gather_ranks(frames, seconds, seed, world, device=None):
     """The one collective of the job: an all_gather of {frames, seconds, stream seed} per rank
     (RCCL on GPUs, gloo in the CPU tests), 24 B per rank. Returns the per-rank list [(frames, seconds, seed)]."""
@@ -134,18 +160,178 @@ def rendezvous_check(rank, world):
         dist.destroy_process_group()
 
 
+def frame_ms_stats(stamps):
+    """min / median / max of the per-frame wall time (ms) from the host time stamps taken at every result."""
+    d = np.diff(np.asarray(stamps)) * 1e3
+    if d.size == 0:
+        return None
+    return {"min": round(float(d.min()), 4), "median": round(float(np.median(d)), 4), "max": round(float(d.max()), 4),
+            "p95": round(float(np.percentile(d, 95)), 4)}
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def host_cores():
+    return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+
+# ======================================================================================================================
+class StereoBench:
+    """The stereo stream of one rank: everything resident in HBM (and, for the host-image leg, in pinned host memory)
+    before any timed region; run() drives `count` frames of one mode."""
+
+    def __init__(self, cfg, args, rank, local_rank, torch, V):
+        from visual_odometry_ros_amd import synthetic as S
+        from visual_odometry_ros_amd.api import StereoFramePipeline, make_stereo_params
+        self.cfg, self.args, self.torch, self.V = cfg, args, torch, V
+        self.W, self.H, self.win, self.max_level = cfg["W"], cfg["H"], cfg["win"], cfg["max_level"]
+        self.n_pts = cfg["n_u"] * cfg["n_v"]
+        self.dev = torch.device("cuda", local_rank)
+        self.stream = S.StereoStream(width=self.W, height=self.H, K=cfg["K"], n_u=cfg["n_u"], n_v=cfg["n_v"],
+                                     n_new=N_NEW_OPEN, seed=stream_seed(rank), speed=cfg["speed"], margin=cfg["margin"])
+        F = max(args.frames, 3)
+        self.F = F
+        self.poses = self.stream.poses(F)
+        self.imgs = [self.stream.render_pair(p)[:2] for p in self.poses]
+        # back-and-forth playback: 0,1,..,F-1,F-2,..,1,0,1,...
+        self.order = list(range(F)) + list(range(F - 2, 0, -1))
+        self.track_sets = {}
+        rng = np.random.default_rng(1000 + rank)
+        for s in range(len(self.order)):
+            a, b = self.frame_id(s), self.frame_id(s + 1)
+            if (a, b) not in self.track_sets:
+                ts = self.stream.track_set(a * 131 + b, self.poses[a], self.poses[b])
+                # bit 0 = lm->isTriangulated(): landmarks created since the last keyframe have no 3-D point yet
+                ts["flags"] = (rng.random(self.n_pts) >= UNTRIANGULATED).astype(np.uint8)
+                self.track_sets[(a, b)] = ts
+        self.d_L = [torch.from_numpy(np.ascontiguousarray(L)).to(self.dev) for L, _ in self.imgs]
+        self.d_R = [torch.from_numpy(np.ascontiguousarray(R)).to(self.dev) for _, R in self.imgs]
+        self.h_L = self.h_R = None
+        if args.host_images_leg:
+            self.h_L = [torch.from_numpy(np.ascontiguousarray(L)).pin_memory() for L, _ in self.imgs]
+            self.h_R = [torch.from_numpy(np.ascontiguousarray(R)).pin_memory() for _, R in self.imgs]
+        self.d_ts = {key: {k: torch.from_numpy(np.ascontiguousarray(ts[k])).to(self.dev)
+                           for k in ("pts_l0", "pts_r0", "Xp", "pts_new", "flags")}
+                     for key, ts in self.track_sets.items()}
+        torch.cuda.synchronize()
+        self.ctx = V.Context(device=local_rank, max_width=self.W, max_height=self.H,
+                             max_points=max(self.n_pts, N_NEW_OPEN) + 64, n_slots=5, max_level=self.max_level)
+        thr = cfg["thres"]
+        self.prm = make_stereo_params(self.W, self.H, self.win, self.max_level, thr[0], thr[1], thr[2], self.stream.K,
+                                      self.stream.K, self.stream.T_lr)
+        self.pipe = StereoFramePipeline(self.ctx, self.prm, strict_border=args.strict_border)
+        self.ctx.set_pyramid_window_hint(self.win)  # build only the levels PyrLK with this window uses
+        self.eff_levels = self.ctx.pyramid_levels(self.W, self.H, self.win, self.max_level) + 1
+        self.eff_levels_bwd = self.ctx.pyramid_levels(self.W, self.H, self.win, self.max_level - 1) + 1
+        self.fe = V.FeatureExtractor(self.ctx)
+        self.fe.initParams(self.W, self.H, cfg["n_u"], cfg["n_v"], THRES_FAST=cfg["thres_fast"])
+        self.bins = self.fe.binParams()
+        self.ft = V.FeatureTracker(self.ctx)
+        self.slot = {"P": 0, "CL": 1, "CR": 2, "NL": 3, "NR": 4}
+        self.n_bins_with_kp = {}
+
+    def frame_id(self, step):
+        return self.order[step % len(self.order)]
+
+    # ---- per-frame host code of the three modes --------------------------------------------------------------------
+    def _ingest(self, fid, host):
+        s = self.slot
+        if host:
+            self.ctx.set_stereo_pair_host_async(s["NL"], self.h_L[fid].data_ptr(), s["NR"], self.h_R[fid].data_ptr(),
+                                                self.W, self.H, self.W)
+        else:
+            self.ctx.set_stereo_pair_device(s["NL"], self.d_L[fid].data_ptr(), s["NR"], self.d_R[fid].data_ptr(),
+                                            self.W, self.H, self.W)
+
+    def _enqueue(self, step, mode, host):
+        a, b = self.frame_id(step), self.frame_id(step + 1)
+        t, s = self.d_ts[(a, b)], self.slot
+        dT = self.track_sets[(a, b)]["dT_prior"]
+        slots = (s["P"], s["CL"], s["CR"])
+        if mode == "closed":
+            self.pipe.enqueue_closed_device(t["pts_l0"].data_ptr(), t["pts_r0"].data_ptr(), t["Xp"].data_ptr(), self.n_pts,
+                                            dT, self.bins, step & 1, slots=slots, d_lm_flags=t["flags"].data_ptr())
+        elif mode == "open":
+            self.pipe.enqueue_device(t["pts_l0"].data_ptr(), t["pts_r0"].data_ptr(), t["Xp"].data_ptr(), self.n_pts, dT,
+                                     t["pts_new"].data_ptr(), N_NEW_OPEN, slots=slots, d_lm_flags=t["flags"].data_ptr())
+        else:  # sequential: the frame without candidates; step [10] follows its result
+            self.pipe.enqueue_device(t["pts_l0"].data_ptr(), t["pts_r0"].data_ptr(), t["Xp"].data_ptr(), self.n_pts, dT,
+                                     0, 0, slots=slots, d_lm_flags=t["flags"].data_ptr())
+        # the NEXT pair does not depend on this frame: its ingestion (and, closed, its keypoint detection) is enqueued
+        # behind the frame's launches and runs on the side stream while the frame is in flight
+        self._ingest(self.frame_id(step + 2), host)
+        if mode == "closed":
+            self.fe.enqueueCandidates(s["NL"], (step + 1) & 1)
+
+    def _step10_on_the_host(self, r):
+        """stereo_vo.cpp:691-711 as three operator calls: updateWeightBin(lmtrack_final.pts_l1),
+        extractORBwithBinning_fast(I1_left), trackBidirection(I1_left, I1_right, pts_l1_new)."""
+        s = self.slot
+        self.fe.updateWeightBin(r["pts_l1"][r["stage"] == 4])
+        pts_new = self.fe.extractORBwithBinning_fast(s["CL"])
+        thr = self.cfg["thres"]
+        return self.ft.trackBidirection(s["CL"], s["CR"], pts_new, self.win, self.max_level, thr[0], thr[1])
+
+    def run(self, first, count, mode, host=False, keep=None, stamps=None, on_result=None):
+        """`count` frames, one at a time: the result of frame s is received before frame s+1 is enqueued."""
+        s = self.slot
+        self._enqueue(first, mode, host)
+        for step in range(first, first + count):
+            r = self.pipe.result(copy=keep is not None and len(keep) < self.args.cpu_frames)
+            if mode == "sequential":
+                r = dict(r, new=self._step10_on_the_host(r))
+            s["P"], s["CL"], s["CR"], s["NL"], s["NR"] = s["CL"], s["NL"], s["NR"], s["P"], s["CR"]
+            if step + 1 < first + count:
+                self._enqueue(step + 1, mode, host)
+            if stamps is not None:
+                stamps.append(time.perf_counter())
+            if keep is not None and len(keep) < self.args.cpu_frames:
+                keep.append((step, r))
+            if on_result is not None:
+                on_result(step, r)
+
+    def prime(self, mode, host=False):
+        """Slots P / CL / CR for step 0 and, closed, the candidate table of CL; then a few untimed frames (lazy
+        allocations, code-object loads)."""
+        c, s = self.ctx, self.slot
+        c.synchronize()
+        c.set_ingest_side_stream(mode != "open")  # (the open-loop comparison keeps round 1's single-stream ingestion)
+        s.update({"P": 0, "CL": 1, "CR": 2, "NL": 3, "NR": 4})
+        c.set_image_device(s["P"], self.d_L[self.frame_id(0)].data_ptr(), self.W, self.H, self.W)
+        f1 = self.frame_id(1)
+        c.set_stereo_pair_device(s["CL"], self.d_L[f1].data_ptr(), s["CR"], self.d_R[f1].data_ptr(), self.W, self.H, self.W)
+        if mode == "closed":
+            self.fe.enqueueCandidates(s["CL"], 0)
+        c.synchronize()
+        PRIME = 4  # even: the table parity of step 0 stays 0
+        self.run(0, PRIME, mode, host)
+        return PRIME
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="BASELINE.json configs[i]")
     ap.add_argument("--frames", type=int, default=12, help="distinct rendered frames (played back and forth)")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--strict-border", type=int, default=1)
+    ap.add_argument("--mode", default="closed", choices=("closed", "sequential", "open"),
+                    help="how step [10] (new-point candidates) is driven in the HEADLINE loop; see the docstring")
+    ap.add_argument("--host-images", action="store_true",
+                    help="headline loop with host images (default: images resident in HBM; the host-image rate is a "
+                         "secondary field of the default run)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--detect", action="store_true",
-                    help="also run the keypoint detection + bucketing of the current left image every frame "
-                         "(side stream, overlapping the frame operator); not part of the default workload")
     ap.add_argument("--rendezvous-check", action="store_true",
                     help="run only the multi-rank control flow (gloo, no GPU work) and print its JSON line")
     args = ap.parse_args()
@@ -165,222 +351,366 @@ def main():
     import torch
     import torch.distributed as dist
     import visual_odometry_ros_amd as V  # loads libvo_hip.so (fails loudly if missing)
-    from visual_odometry_ros_amd import synthetic as S
-    from visual_odometry_ros_amd.api import StereoFramePipeline, make_stereo_params
     V.load()
-
     if world > 1:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cfg = CONFIGS[args.config]
+    secondary = world == 1 and not args.no_secondary and cfg["kind"] == "stereo" and args.config == 1
+    args.host_images_leg = args.host_images or secondary
 
-    # ---- synthetic stream (one independent sequence per rank), rendered on the host ----
-    stream = S.StereoStream(n_u=N_U, n_v=N_V, n_new=N_NEW, seed=stream_seed(rank))
-    F = max(args.frames, 3)
-    poses = stream.poses(F)
-    imgs = [stream.render_pair(p)[:2] for p in poses]
-    # back-and-forth playback: 0,1,..,F-1,F-2,..,1,0,1,...
-    order = list(range(F)) + list(range(F - 2, 0, -1))
-    W_, H_ = stream.width, stream.height
-
-    def frame_id(step):
-        return order[step % len(order)]
-
-    track_sets = {}
-    for s in range(len(order)):
-        a, b = frame_id(s), frame_id(s + 1)
-        if (a, b) not in track_sets:
-            track_sets[(a, b)] = stream.track_set(a * 131 + b, poses[a], poses[b])
-
-    # ---- everything resident in HBM before timing ----
-    d_L = [torch.from_numpy(np.ascontiguousarray(L)).to(dev) for L, _ in imgs]
-    d_R = [torch.from_numpy(np.ascontiguousarray(R)).to(dev) for _, R in imgs]
-    d_ts = {}
-    for key, ts in track_sets.items():
-        d_ts[key] = {k: torch.from_numpy(np.ascontiguousarray(ts[k])).to(dev)
-                     for k in ("pts_l0", "pts_r0", "Xp", "pts_new")}
-    torch.cuda.synchronize()
-
-    n_pts = N_U * N_V
-    ctx = V.Context(device=local_rank, max_width=W_, max_height=H_, max_points=max(n_pts, N_NEW) + 64,
-                    n_slots=5, max_level=MAX_LEVEL)
-    prm = make_stereo_params(W_, H_, WIN, MAX_LEVEL, THRES_ERR, THRES_BIDIR, THRES_POSEBA, stream.K, stream.K,
-                             stream.T_lr)
-    pipe = StereoFramePipeline(ctx, prm, strict_border=bool(args.strict_border))
-    ctx.set_pyramid_window_hint(WIN)  # build only the levels PyrLK with this window uses
-    eff_levels = ctx.pyramid_levels(W_, H_, WIN, MAX_LEVEL) + 1
-    eff_levels_bwd = ctx.pyramid_levels(W_, H_, WIN, MAX_LEVEL - 1) + 1
-
-    # slot roles, rotated in place of copying pyramids: previous left, current pair, prefetched pair
-    slot = {"P": 0, "CL": 1, "CR": 2, "NL": 3, "NR": 4}
-
-    fe = None
-    if args.detect:
-        fe = V.FeatureExtractor(ctx)
-        fe.initParams(W_, H_, N_U, N_V, THRES_FAST=15)
-
-    def enqueue(s):
-        a, b = frame_id(s), frame_id(s + 1)
-        t = d_ts[(a, b)]
-        pipe.enqueue_device(t["pts_l0"].data_ptr(), t["pts_r0"].data_ptr(), t["Xp"].data_ptr(), n_pts,
-                            track_sets[(a, b)]["dT_prior"], t["pts_new"].data_ptr(), N_NEW,
-                            slots=(slot["P"], slot["CL"], slot["CR"]))
-        if fe is not None:  # extractORBwithBinning_fast of the current left image, off the main chain
-            fe.enqueueExtract(slot["CL"])
-        # the NEXT stereo pair does not depend on this frame's result: its pyramids are enqueued
-        # behind the frame and build while the host waits for / consumes this frame's result
-        nb = frame_id(s + 2)
-        ctx.set_stereo_pair_device(slot["NL"], d_L[nb].data_ptr(), slot["NR"], d_R[nb].data_ptr(), W_, H_, W_)
-
-    def run_frames(first, count, keep=None, on_result=None):
-        """`count` frames, one at a time: the result of frame s (pose, survivors — what a sequential VO
-        needs before it can go on) is received before frame s+1 is enqueued, and s+1 is enqueued at once."""
-        enqueue(first)
-        for s in range(first, first + count):
-            r = pipe.result(copy=keep is not None and len(keep) < args.cpu_frames)
-            if fe is not None:
-                fe.resultExtract()
-            slot["P"], slot["CL"], slot["CR"], slot["NL"], slot["NR"] = (slot["CL"], slot["NL"], slot["NR"], slot["P"],
-                                                                           slot["CR"])
-            if s + 1 < first + count:
-                enqueue(s + 1)
-            if keep is not None and len(keep) < args.cpu_frames:
-                keep.append(r)
-            if on_result is not None:
-                on_result(r)
-
-    def barrier():
+    def barrier(ctx):
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         ctx.synchronize()
 
-    ctx.set_image_device(0, d_L[frame_id(0)].data_ptr(), W_, H_, W_)
-    ctx.set_stereo_pair_device(1, d_L[frame_id(1)].data_ptr(), 2, d_R[frame_id(1)].data_ptr(), W_, H_, W_)
-    ctx.synchronize()
-    # one-time initialisation, not a step: the first frames allocate the context's frame state lazily and load the
-    # code objects of every kernel; PRIME frames are pushed through before the W warmup steps the contract asks for
-    PRIME = 3
-    run_frames(0, PRIME)
-    if args.warmup:
-        run_frames(PRIME, args.warmup)
-    K = args.steps
-    ctx.profile_enable(K * 4 + 64)
-    ctx.profile_set_classes(1 << 1)  # event-bracket only the dominant kernel (frame_track_kernel)
-    ctx.profile_reset()
-    acc = {"bytes": 0}
-    results = []
-
-    def account(r):
-        cts = r["counts"]  # features finished by the replay kernel do their step [5] there
-        acc["bytes"] += frame_kernel_bytes(WIN, n_pts, cts.n_l0l1, cts.n_refine - cts.n_replayed, N_NEW, eff_levels,
-                                           eff_levels_bwd, bool(args.strict_border))
-
-    # A generational GC pass of the interpreter (tens of ms with torch loaded) inside the timed loop
-    # would be charged to a few frames; the loop allocates nothing that needs it.
-    gc.collect()
-    gc.freeze()
-    gc.disable()
-    barrier()
-    t0 = time.perf_counter()
-    run_frames(PRIME + args.warmup, K, results, account)
-    barrier()
-    dt = time.perf_counter() - t0
-    gc.enable()
-
-    per_rank = gather_ranks(K, dt, stream_seed(rank), world, dev)
-    tot_frames, max_dt = sum(p[0] for p in per_rank), max(p[1] for p in per_rank)
-
-    out = None
+    if cfg["kind"] == "mono":
+        out, ctx = run_mono(cfg, args, rank, local_rank, world, torch, V, barrier, dev)
+    else:
+        out, ctx = run_stereo(cfg, args, rank, local_rank, world, torch, V, barrier, dev, secondary)
     if rank == 0:
-        names = {0: "pyramid", 1: "frame_track", 2: "ic_replay", 3: "gn_pose", 4: "hamming", 5: "aux"}
-        per_kernel = {}
-        for cls, nm in names.items():
-            n_l, ms = ctx.profile_get(cls)
-            if n_l:
-                per_kernel[nm] = {"launches": n_l, "total_ms": round(ms, 3), "avg_us": round(1e3 * ms / n_l, 2)}
-        klt_n, klt_ms = ctx.profile_get(1)
-        achieved = (acc["bytes"] / max(klt_n, 1)) / (klt_ms / max(klt_n, 1) * 1e-3) / 1e9 if klt_n else 0.0
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_frame_pmc.json")
-        if os.path.exists(pmc_path):
-            try:
-                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "stereo VO frames/sec @1241x376, 1500 feats",
-            "value": round(tot_frames / max_dt, 2),
-            "unit": "frames/s",
-            "n_gpus": world,
-            "steps": K,
-            "warmup": args.warmup,
-            "ms_per_step": round(1e3 * max_dt / K, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u8/i32 (KLT) + f32 (IC, GN)",
-            "data": "synthetic",
-            "config": {
-                "workload": "BASELINE configs[1]: synthetic KITTI-shaped stereo stream 1241x376, 1500 tracked "
-                            "features/frame (60x25 buckets) + 150 new-point candidates, win 21, max_level 6 "
-                            "(5 effective levels), thresholds of config/stereo/kitti_00_stereo.yaml; one "
-                            "independent stream per GPU; result read back every frame",
-                "strict_border": int(args.strict_border),
-                "with_detection": bool(args.detect),
-                "distinct_frames": F,
-            },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "frame_track_kernel<21>",
-                "achieved": round(achieved, 2),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": traffic,
-                "alg_bytes_per_launch": round(acc["bytes"] / max(klt_n, 1)),
-                "avg_launch_us": round(1e3 * klt_ms / max(klt_n, 1), 2),
-            },
-            "kernels": per_kernel,
-            "per_rank_fps": [round(p[0] / p[1], 2) for p in per_rank],
-        }
-
-        if world == 1 and not args.no_cpu_baseline:
-            from oracle import oracle as O
-            prm_o = O.make_stereo_params(W_, H_, WIN, MAX_LEVEL, THRES_ERR, THRES_BIDIR, THRES_POSEBA, stream.K,
-                                         stream.K, stream.T_lr)
-            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            cores = min(cores, 16)  # the box's CPU share for one GPU; 1500 points do not feed more threads
-            border = O.IC_REFERENCE if args.strict_border else O.IC_MASKED
-            worst, stage_equal = 0.0, True
-            tcpu = 0.0
-            nf = min(args.cpu_frames, len(results))
-            for i in range(nf):
-                s = PRIME + args.warmup + i
-                a, b = frame_id(s), frame_id(s + 1)
-                ts = track_sets[(a, b)]
-                t1 = time.perf_counter()
-                o = O.stereo_frame(prm_o, imgs[a][0], imgs[b][0], imgs[b][1], ts["pts_l0"], ts["pts_r0"],
-                                   ts["Xp"], ts["dT_prior"], ts["pts_new"], O.SUM_SEQ, 0, border, cores)
-                tcpu += time.perf_counter() - t1
-                g = results[i]
-                e = float(np.linalg.norm(g["dT"].astype(np.float64) - o["dT"]) / np.linalg.norm(o["dT"]))
-                worst = max(worst, e)
-                stage_equal = stage_equal and bool(np.array_equal(g["stage"], o["stage"]))
-            out["cpu_baseline"] = {
-                "value": round(nf / tcpu, 3) if tcpu > 0 else None,
-                "unit": "frames/s",
-                "cores": cores,
-                "kind": "port",
-                "sample": f"{nf} frames of the same stream on the CPU restatement (oracle/, reference summation "
-                          f"order); PyrLK over {cores} OpenMP threads, IC and GN single-threaded as in the reference",
-            }
-            out["parity"] = {"pose_rel_frobenius_max": worst, "survivor_sets_bit_exact": stage_equal,
-                             "frames_checked": nf}
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def timed(bench_run, barrier, ctx):
+    """The steps between two barriers; the interpreter's generational GC is frozen for the loop (a gen-2 pass with torch
+    loaded costs tens of ms and would be charged to one frame; the loop allocates nothing that needs it)."""
+    gc.collect()
+    gc.freeze()
+    gc.disable()
+    barrier(ctx)
+    t0 = time.perf_counter()
+    bench_run()
+    barrier(ctx)
+    dt = time.perf_counter() - t0
+    gc.enable()
+    return dt
+
+
+def run_stereo(cfg, args, rank, local_rank, world, torch, V, barrier, dev, secondary):
+    B = StereoBench(cfg, args, rank, local_rank, torch, V)
+    ctx, K = B.ctx, args.steps
+    mode, host = args.mode, bool(args.host_images)
+    # bins that hold a keypoint, per distinct left image: the candidates the closed frame kernel tracks (bytes accounting)
+    if mode == "closed":
+        for fid in range(B.F):
+            ctx.set_image_device(3, B.d_L[fid].data_ptr(), B.W, B.H, B.W)
+            B.fe.resetWeightBin()
+            B.n_bins_with_kp[fid] = int(B.fe.extractORBwithBinning_fast(3).shape[0])
+    first = B.prime(mode, host)
+    if args.warmup:
+        B.run(first, args.warmup, mode, host)
+    first += args.warmup
+    ctx.profile_enable(K * 4 + 64)
+    ctx.profile_set_classes(1 << 1)  # event-bracket only the dominant kernel (frame_track_kernel)
+    ctx.profile_reset()
+    acc = {"b8d": 0, "bdes": 0}
+    results, stamps = [], []
+
+    def account(step, r):
+        cts = r["counts"]  # features finished by the replay kernel do their step [5] there
+        if mode == "closed":
+            n_cand = B.n_bins_with_kp[B.frame_id(step + 1)]
+        else:
+            n_cand = N_NEW_OPEN if mode == "open" else 0
+        a, b = frame_kernel_bytes(B.win, B.n_pts, cts.n_l0l1, cts.n_refine - cts.n_replayed, n_cand, B.eff_levels,
+                                  B.eff_levels_bwd, bool(args.strict_border))
+        acc["b8d"] += a
+        acc["bdes"] += b
+
+    dt = timed(lambda: B.run(first, K, mode, host, results, stamps, account), barrier, ctx)
+    if os.environ.get("VO_BENCH_DUMP"):  # per-frame wall time and replayed-feature count, for A/B analysis
+        np.save(os.environ["VO_BENCH_DUMP"], np.asarray(stamps))
+    per_rank = gather_ranks(K, dt, stream_seed(rank), world, dev)
+    tot_frames, max_dt = sum(p[0] for p in per_rank), max(p[1] for p in per_rank)
+    if rank != 0:
+        return None, ctx
+
+    klt_n, klt_ms = ctx.profile_get(1)
+    launches = max(klt_n, 1)
+    achieved = (acc["b8d"] / launches) / (klt_ms / launches * 1e-3) / 1e9 if klt_n else 0.0
+    traffic = None
+    for name in ("r02_frame_pmc.json", "r01_frame_pmc.json"):
+        pmc_path = os.path.join(ROOT, "profiles", name)
+        if args.config == 1 and os.path.exists(pmc_path):
+            try:
+                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+                break
+            except Exception:
+                traffic = None
+    step10 = {"closed": "closed on the device: per-bucket best keypoints detected from the image alone on the side stream, "
+                        "every bucket's candidate tracked inside the frame kernel, updateWeightBin + emission behind the BA",
+              "sequential": "three host-driven operator calls after the frame's result",
+              "open": "OPEN LOOP: 150 candidates known before the frame (round 1's workload; not a sequential VO)"}[mode]
+    r0 = results[0][1]["counts"] if results else None
+    out = {
+        "metric": cfg["metric"],
+        "value": round(tot_frames / max_dt, 2),
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": args.warmup,
+        "ms_per_step": round(1e3 * max_dt / K, 4),
+        "frame_ms": frame_ms_stats(stamps),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8/i32 (KLT, FAST) + f32 (IC, GN)",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{cfg['name']}: synthetic stereo stream {B.W}x{B.H}, {B.n_pts} tracked features/frame "
+                        f"({cfg['n_u']}x{cfg['n_v']} buckets, {int(100 * UNTRIANGULATED)} % of them untriangulated landmarks), "
+                        f"win {B.win}, max_level {B.max_level} ({B.eff_levels} effective levels), thresholds of "
+                        "config/stereo/kitti_00_stereo.yaml; whole operator sequence of StereoVO::trackStereoImages "
+                        "steps [3]-[7] + [10] incl. keypoint detection and bucketing; one independent stream per GPU; "
+                        "result read back every frame; track set per frame from the scene's ground truth",
+            "step10": step10,
+            "images": "pinned host memory, H2D inside the timed region" if host else "resident in HBM",
+            "strict_border": int(args.strict_border),
+            "untriangulated_fraction": UNTRIANGULATED,
+            "distinct_frames": B.F,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": f"frame_track_kernel<{B.win}>",
+            "achieved": round(achieved, 2),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": traffic,
+            "alg_bytes_per_launch": {"survey_8d": round(acc["b8d"] / launches), "design_records": round(acc["bdes"] / launches)},
+            "avg_launch_us": round(1e3 * klt_ms / launches, 2),
+            "note": "achieved = survey_8d bytes / launch duration (HIP events, live); the path is issue/latency-bound, "
+                    "the fraction is reported because the metric asks for it (DESIGN.md §6)",
+        },
+        "per_rank_fps": [round(p[0] / p[1], 2) for p in per_rank],
+    }
+    if r0 is not None:
+        out["frame_counts_first"] = {f: getattr(r0, f) for f in ("n_l0l1", "n_refine", "n_l1r1", "n_ba", "n_inlier", "n_new_ok",
+                                                                 "gn_iterations", "n_replayed")}
+    if secondary:
+        sec = {}
+        legs = [("host_images", "closed", True), ("sequential_step10", "sequential", False),
+                ("open_loop_candidates", "open", False)]
+        ctx.profile_set_classes(1 << 30)  # no event brackets in the secondary loops
+        for name, m, h in legs:
+            if (m, h) == (mode, host):
+                continue
+            f0 = B.prime(m, h)
+            B.run(f0, min(args.warmup, 10), m, h)
+            f0 += min(args.warmup, 10)
+            st = []
+            dts = timed(lambda: B.run(f0, K, m, h, None, st), barrier, ctx)
+            sec[name] = {"value": round(K / dts, 2), "unit": "frames/s", "frame_ms": frame_ms_stats(st)}
+        out["secondary"] = sec
+    if world == 1 and not args.no_cpu_baseline:
+        out.update(cpu_baseline_stereo(B, args, results, mode))
+    return out, ctx
+
+
+def cpu_baseline_stereo(B, args, results, mode):
+    """The oracle (kind "port": the build's CPU restatement of the reference path, reference summation order and border
+    semantics) on a bounded sample of the SAME frames, with the per-stage split BASELINE.md §3 promises; doubles as
+    the parity check of the timed run (pose within 1e-4 relative Frobenius, survivor stages and new points identical)."""
+    from oracle import oracle as O
+    thr = B.cfg["thres"]
+    prm_o = O.make_stereo_params(B.W, B.H, B.win, B.max_level, thr[0], thr[1], thr[2], B.stream.K, B.stream.K, B.stream.T_lr)
+    cores = min(host_cores(), 16)  # the box's CPU share for one GPU; 1500 points do not feed more threads
+    border = O.IC_REFERENCE if args.strict_border else O.IC_MASKED
+    empty = np.zeros((0, 2), np.float32)
+    worst, stage_equal, new_equal, tcpu = 0.0, True, True, 0.0
+    stages = {}
+    nf = min(args.cpu_frames, len(results))
+    us, vs, iu, iv = O.weight_bin_init(B.W, B.H, B.cfg["n_u"], B.cfg["n_v"])
+    t_pyr = 0.0
+    for step, g in results[:nf]:
+        a, b = B.frame_id(step), B.frame_id(step + 1)
+        ts = B.track_sets[(a, b)]
+        L0, (L1, R1) = B.imgs[a][0], B.imgs[b]
+        t1 = time.perf_counter()
+        cand = ts["pts_new"] if mode == "open" else empty
+        o = O.stereo_frame(prm_o, L0, L1, R1, ts["pts_l0"], ts["pts_r0"], ts["Xp"], ts["dT_prior"], cand, O.SUM_SEQ, 0, border,
+                           cores, lm_flags=ts["flags"])
+        t2 = time.perf_counter()
+        for k, v in O.stereo_frame_stage_ms().items():
+            stages[k] = stages.get(k, 0.0) + v
+        if mode != "open":  # step [10] in the reference's order, after the frame
+            w = O.weight_bin_update(o["pts_l1"][o["stage"] == 4], us, vs, B.cfg["n_u"], B.cfg["n_v"])
+            t3 = time.perf_counter()
+            d = O.orb_detect(L1, B.cfg["thres_fast"])
+            t4 = time.perf_counter()
+            pn, _ = O.bucket_argmax(d["xy"], d["response"], iu, iv, B.cfg["n_u"], B.cfg["n_v"], w)
+            t5 = time.perf_counter()
+            _, pnr, mn = O.track_bidirection(L1, R1, pn, B.win, B.max_level, thr[0], thr[1], None, cores)
+            t6 = time.perf_counter()
+            for k, v in (("update_weight_bin", t3 - t2), ("orb_detect", t4 - t3), ("bucket_argmax", t5 - t4),
+                         ("klt_new_points", t6 - t5)):
+                stages[k] = stages.get(k, 0.0) + 1e3 * v
+            tcpu += t6 - t1
+            gn = g["new"] if mode == "sequential" else (g["pts_new_r"], g["mask_new"])
+            new_equal = new_equal and bool(np.array_equal(gn[1], mn)) and bool(np.array_equal(np.asarray(gn[0]), pnr))
+            if mode == "closed":
+                new_equal = new_equal and bool(np.array_equal(g["pts_new"], pn))
+        else:
+            tcpu += t2 - t1
+            new_equal = new_equal and bool(np.array_equal(g["mask_new"], o["mask_new"]))
+        tp = time.perf_counter()
+        O.build_pyramid(L1, B.win, B.max_level)
+        t_pyr += time.perf_counter() - tp
+        e = float(np.linalg.norm(g["dT"].astype(np.float64) - o["dT"]) / np.linalg.norm(o["dT"]))
+        worst = max(worst, e)
+        stage_equal = stage_equal and bool(np.array_equal(g["stage"], o["stage"]))
+    per_stage = {k: round(v / max(nf, 1), 3) for k, v in stages.items()}
+    per_stage["pyramid_one_image"] = round(1e3 * t_pyr / max(nf, 1), 3)
+    return {
+        "cpu_baseline": {
+            "value": round(nf / tcpu, 3) if tcpu > 0 else None,
+            "unit": "frames/s",
+            "cores": cores,
+            "nproc": os.cpu_count(),
+            "cpu_model": cpu_model(),
+            "kind": "port",
+            "sample": f"{nf} frames of the same stream and workload on the CPU restatement (oracle/, reference summation "
+                      f"order and border semantics); PyrLK and the FAST score over {cores} OpenMP threads, trackWithScale and "
+                      "the BA single-threaded as in the reference",
+            "per_stage_ms": per_stage,
+            "per_stage_note": "every klt_* stage builds its two image pyramids itself, as each cv::calcOpticalFlowPyrLK call "
+                              "of the reference does (8 pyramid builds per frame; pyramid_one_image = one of them); "
+                              "track_with_scale includes the convertTo / Sobel images",
+        },
+        "parity": {"pose_rel_frobenius_max": worst, "survivor_sets_bit_exact": stage_equal,
+                   "new_points_bit_exact": new_equal, "frames_checked": nf},
+    }
+
+
+def run_mono(cfg, args, rank, local_rank, world, torch, V, barrier, dev):
+    """BASELINE configs[2]: the mono frame operator (mono_vo.cpp:739-963) at 752x480 / 1000 features / win 15 / 5 levels."""
+    from visual_odometry_ros_amd import synthetic as S
+    from visual_odometry_ros_amd.api import MonoFramePipeline, make_mono_params
+    W_, H_, WIN, LVL = cfg["W"], cfg["H"], cfg["win"], cfg["max_level"]
+    n_pts = cfg["n_u"] * cfg["n_v"]
+    stream = S.StereoStream(width=W_, height=H_, K=cfg["K"], n_u=cfg["n_u"], n_v=cfg["n_v"], n_new=50,
+                            seed=stream_seed(rank) + 1, speed=cfg["speed"], margin=cfg["margin"])
+    F = max(args.frames, 3)
+    poses = stream.poses(F)
+    imgs = [stream.render_pair(p)[0] for p in poses]
+    order = list(range(F)) + list(range(F - 2, 0, -1))
+    fid = lambda s: order[s % len(order)]  # noqa: E731
+    sets = {}
+    rng = np.random.default_rng(1)
+    for s in range(len(order)):
+        a, b = fid(s), fid(s + 1)
+        if (a, b) in sets:
+            continue
+        ts = stream.track_set(a * 131 + b, poses[a], poses[b])
+        n = ts["pts_l0"].shape[0]
+        flags = ((rng.random(n) < 0.7).astype(np.uint8) | ((rng.random(n) < 0.8).astype(np.uint8) << 1)).astype(np.uint8)
+        dT = ts["dT_prior"].astype(np.float32)
+        sets[(a, b)] = dict(pts0=ts["pts_l0"], Xw=ts["Xp"].astype(np.float32), flags=flags, Tcw_prev=np.eye(4, dtype=np.float32),
+                            Tcw_prior=np.linalg.inv(dT.astype(np.float64)).astype(np.float32), dT=dT)
+    d_I = [torch.from_numpy(np.ascontiguousarray(I)).to(dev) for I in imgs]
+    d_s = {k: {q: torch.from_numpy(np.ascontiguousarray(v[q])).to(dev) for q in ("pts0", "Xw", "flags")} for k, v in sets.items()}
+    torch.cuda.synchronize()
+    ctx = V.Context(device=local_rank, max_width=W_, max_height=H_, max_points=n_pts + 64, n_slots=3, max_level=LVL)
+    thr = cfg["thres"]
+    args_p = (W_, H_, WIN, LVL, thr[0], thr[1], thr[2], thr[3], cfg["K"])
+    pipe = MonoFramePipeline(ctx, make_mono_params(*args_p), strict_border=args.strict_border)
+    ctx.set_pyramid_window_hint(WIN)
+    ctx.set_ingest_side_stream(True)
+    eff_levels = ctx.pyramid_levels(W_, H_, WIN, LVL) + 1
+    slot = {"P": 0, "C": 1, "N": 2}
+
+    def enqueue(s):
+        k = (fid(s), fid(s + 1))
+        t, h = d_s[k], sets[k]
+        pipe.enqueue_device(t["pts0"].data_ptr(), t["Xw"].data_ptr(), t["flags"].data_ptr(), n_pts, h["Tcw_prev"],
+                            h["Tcw_prior"], h["dT"], slots=(slot["P"], slot["C"]))
+        ctx.set_image_device(slot["N"], d_I[fid(s + 2)].data_ptr(), W_, H_, W_)
+
+    def run(first, count, keep=None, stamps=None, on_result=None):
+        enqueue(first)
+        for s in range(first, first + count):
+            r = pipe.result()
+            slot["P"], slot["C"], slot["N"] = slot["C"], slot["N"], slot["P"]
+            if s + 1 < first + count:
+                enqueue(s + 1)
+            if stamps is not None:
+                stamps.append(time.perf_counter())
+            if keep is not None and len(keep) < max(args.cpu_frames, 1):
+                keep.append((s, r))
+            if on_result is not None:
+                on_result(r)
+
+    ctx.set_image_device(0, d_I[fid(0)].data_ptr(), W_, H_, W_)
+    ctx.set_image_device(1, d_I[fid(1)].data_ptr(), W_, H_, W_)
+    ctx.synchronize()
+    run(0, 4)
+    run(4, args.warmup)
+    K = args.steps
+    ctx.profile_enable(K * 4 + 64)
+    ctx.profile_set_classes(1 << 1)
+    ctx.profile_reset()
+    kept, stamps = [], []
+    acc = {"b8d": 0, "bdes": 0}
+
+    def account(r):
+        c = r["counts"]  # forward + backward PyrLK at full depth for every feature, IC for the tracked ones
+        acc["b8d"] += klt_bytes_per_point_level(WIN) * 2 * n_pts * eff_levels + IC_BYTES_8D * c.n_klt
+        acc["bdes"] += (IC_RECORD_BYTES * n_pts if args.strict_border else 0) + POINT_IO_BYTES * n_pts
+
+    first = 4 + args.warmup
+    dt = timed(lambda: run(first, K, kept, stamps, account), barrier, ctx)
+    per_rank = gather_ranks(K, dt, stream_seed(rank), world, dev)
+    tot_frames, max_dt = sum(p[0] for p in per_rank), max(p[1] for p in per_rank)
+    if rank != 0:
+        return None, ctx
+    nl, ms = ctx.profile_get(1)
+    launches = max(nl, 1)
+    achieved = (acc["b8d"] / launches) / (ms / launches * 1e-3) / 1e9 if nl else 0.0
+    out = {
+        "metric": cfg["metric"], "value": round(tot_frames / max_dt, 2), "unit": "frames/s", "n_gpus": world, "steps": K,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * max_dt / K, 4), "frame_ms": frame_ms_stats(stamps),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/i32 (KLT) + f32 (IC, GN)",
+        "data": "synthetic",
+        "config": {"workload": f"{cfg['name']}: synthetic mono stream {W_}x{H_} (left images of the stereo renderer), {n_pts} "
+                               f"tracked features/frame ({cfg['n_u']}x{cfg['n_v']} buckets), win {WIN}, max_level {LVL} "
+                               f"({eff_levels} effective levels), thresholds of config/mono/mono0.yaml; the steady state of "
+                               "MonoVO::trackImage (mono_vo.cpp:739-963: prior + scale, trackBidirectionWithPrior, "
+                               "trackWithScale, pose-only BA, mask_motion, Sampson gate); result read back every frame; the "
+                               "5-point fallback and the new-point extraction are not part of the step",
+                   "images": "resident in HBM", "strict_border": int(args.strict_border), "distinct_frames": F},
+        "roofline": {"bound": "hbm", "kernel": f"mono_track_kernel<{WIN}>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                     "alg_bytes_per_launch": {"survey_8d": round(acc["b8d"] / launches), "design_records": round(acc["bdes"] / launches)},
+                     "avg_launch_us": round(1e3 * ms / launches, 2)},
+        "per_rank_fps": [round(p[0] / p[1], 2) for p in per_rank],
+    }
+    if world == 1 and not args.no_cpu_baseline and kept:
+        from oracle import oracle as O
+        prm_o = O.make_mono_params(*args_p)
+        cores = min(host_cores(), 16)
+        border = O.IC_REFERENCE if args.strict_border else O.IC_MASKED
+        kept = kept[:args.cpu_frames]
+        ok, worst = True, 0.0
+        t0 = time.perf_counter()
+        for s, r in kept:
+            k = (fid(s), fid(s + 1))
+            h = sets[k]
+            o = O.mono_frame(prm_o, imgs[k[0]], imgs[k[1]], h["pts0"], h["Xw"], h["flags"], h["Tcw_prev"], h["Tcw_prior"],
+                             h["dT"], O.SUM_SEQ, 0, border, cores)
+            ok = ok and bool(np.array_equal(o["stage"], r["stage"]))
+            worst = max(worst, float(np.linalg.norm(r["dT01"].astype(np.float64) - o["dT01"]) / np.linalg.norm(o["dT01"])))
+        cdt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(len(kept) / cdt, 3), "unit": "frames/s", "cores": cores, "nproc": os.cpu_count(),
+                               "cpu_model": cpu_model(), "kind": "port",
+                               "sample": f"{len(kept)} frames of the same stream on the CPU restatement (oracle_mono.c)"}
+        out["parity"] = {"pose_rel_frobenius_max": worst, "survivor_sets_bit_exact": ok, "frames_checked": len(kept)}
+    return out, ctx
 
 
 if __name__ == "__main__":

@@ -429,6 +429,16 @@ def stereo_frame(prm, I0l, I1l, I1r, pts_l0, pts_r0, Xp, dT_prior, pts_new, sum_
                 pts_new_r=pnr[:nn], mask_new=mnew[:nn].astype(bool), counts=counts)
 
 
+STAGE_NAMES = ("prior", "klt_l0l1", "track_with_scale", "klt_l1r1", "pose_only_ba", "gates_compactions", "klt_new_points")
+
+
+def stereo_frame_stage_ms():
+    """Wall-clock split (ms) of the last stereo_frame call, keyed by STAGE_NAMES."""
+    out = np.zeros(8, np.float64)
+    lib().vo_ref_stereo_frame_stage_ms(_p(out, C.c_double))
+    return dict(zip(STAGE_NAMES, out[:len(STAGE_NAMES)].tolist()))
+
+
 # ---- image ingestion with flagDoUndistortion (oracle_rectify.c) ----
 def image_undistort_maps(n_cols, n_rows, K, D):
     mu = np.zeros((n_rows, n_cols), np.float32)

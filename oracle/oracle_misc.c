@@ -113,6 +113,20 @@ static void xform(const float T[16], const float X[3], float Y[3]) {
  * the caller: here the prior for such points is (pts_l0, pts_l0 - disparity)
  * — the caller passes pts_r0 through pts_r1 (in/out).
  */
+/* wall-clock split of the last vo_ref_stereo_frame call (bench.py's cpu_baseline reports it per stage):
+ * [0] priors  [1] trackWithPrior l0->l1 (builds both pyramids, as every cv::calcOpticalFlowPyrLK call does)
+ * [2] trackWithScale (incl. the convertTo / Sobel images)  [3] trackWithPrior l1->r1  [4] pose-only BA
+ * [5] gates + compactions  [6] trackBidirection of the new points */
+#include <omp.h>
+static double g_stage_ms[8];
+void vo_ref_stereo_frame_stage_ms(double out[8]) { memcpy(out, g_stage_ms, sizeof(g_stage_ms)); }
+#define STAGE_T(k)                                 \
+  do {                                             \
+    const double now_ = omp_get_wtime();           \
+    g_stage_ms[k] += 1e3 * (now_ - t_stage);       \
+    t_stage = now_;                                \
+  } while (0)
+
 int vo_ref_stereo_frame(const vo_ref_stereo_params *prm, const uint8_t *I0l,
                         const uint8_t *I1l, const uint8_t *I1r, int stride,
                         const float *pts_l0, const float *Xp, const uint8_t *lm_flags, int n,
@@ -135,6 +149,8 @@ int vo_ref_stereo_frame(const vo_ref_stereo_params *prm, const uint8_t *I0l,
   float *aX = (float *)malloc(sizeof(float) * 3 * ((size_t)n + 1));
   float *as = (float *)malloc(sizeof(float) * ((size_t)n + 1));
   memset(counts, 0, sizeof(*counts));
+  memset(g_stage_ms, 0, sizeof(g_stage_ms));
+  double t_stage = omp_get_wtime();
   /* [3] priors; pts_r1 holds pts_r0 on entry. lm_flags[i] bit 0 = lm->isTriangulated() (stereo_vo.cpp:490);
    * NULL = every landmark is triangulated */
   for (int i = 0; i < n; ++i) {
@@ -165,10 +181,12 @@ int vo_ref_stereo_frame(const vo_ref_stereo_params *prm, const uint8_t *I0l,
     }
   }
   int cur = n;
+  STAGE_T(0);
   /* [4] l0 -> l1 */
   for (int i = 0; i < n; ++i) m[i] = 1;
   vo_ref_track_with_prior(I0l, I1l, W, H, stride, pts_l0, n, prm->win, prm->max_level,
                           prm->thres_err, pts_l1, m, n_threads);
+  STAGE_T(1);
   /* StereoLandmarkTracking(lmtrack_prev, mask_l0l1), landmark.cpp:305: mask && isAlive() && isTracked();
    * lm_flags bit 1 = the landmark is no longer alive / tracked */
   if (lm_flags)
@@ -193,8 +211,10 @@ int vo_ref_stereo_frame(const vo_ref_stereo_params *prm, const uint8_t *I0l,
     as[i] = scale[o];
     m[i] = 1;
   }
+  STAGE_T(5);
   int rc = vo_ref_track_with_scale(I0l, I1l, W, H, stride, a0, as, cur, a1, m, ic_border_mode,
                                    sum_mode, NULL);
+  STAGE_T(2);
   if (rc < 0) goto fail;
   c = 0;
   for (int i = 0; i < cur; ++i) {
@@ -217,8 +237,10 @@ int vo_ref_stereo_frame(const vo_ref_stereo_params *prm, const uint8_t *I0l,
     a1[2 * i + 1] = pts_r1[2 * o + 1];
     m[i] = 1;
   }
+  STAGE_T(5);
   vo_ref_track_with_prior(I1l, I1r, W, H, stride, a0, cur, prm->win, prm->max_level,
                           prm->thres_err, a1, m, n_threads);
+  STAGE_T(3);
   c = 0;
   for (int i = 0; i < cur; ++i) {
     int o = idx[i];
@@ -249,8 +271,10 @@ int vo_ref_stereo_frame(const vo_ref_stereo_params *prm, const uint8_t *I0l,
   counts->n_ba = nba;
   memcpy(dT_out, dT_prior, sizeof(float) * 16);
   vo_ref_gn_info gi;
+  STAGE_T(5);
   rc = vo_ref_gn_pose_stereo(aX, a0, a2, nba, prm->Kl, prm->Kr, prm->T_lr, prm->thres_poseba,
                              dT_out, m, sum_mode, tree_width, &gi);
+  STAGE_T(4);
   if (rc <= 0) {
     rc = -6; /* reference throws "PoseOnlyStereoBA is failed!" (:626) */
     goto fail;
@@ -270,6 +294,7 @@ int vo_ref_stereo_frame(const vo_ref_stereo_params *prm, const uint8_t *I0l,
     }
   }
   counts->n_inlier = c;
+  STAGE_T(5);
   /* [10] new points */
   if (n_new > 0) {
     for (int i = 0; i < n_new; ++i) mask_new[i] = 1;
@@ -278,6 +303,7 @@ int vo_ref_stereo_frame(const vo_ref_stereo_params *prm, const uint8_t *I0l,
                              n_threads);
     for (int i = 0; i < n_new; ++i) counts->n_new_ok += mask_new[i];
   }
+  STAGE_T(6);
   rc = 0;
 fail:
   free(scale);

@@ -172,6 +172,10 @@ int vo_ref_stereo_frame(const vo_ref_stereo_params *prm, const uint8_t *I0l,
                         float dT_out[16], float *pts_new_r, uint8_t *mask_new,
                         vo_ref_frame_counts *counts);
 
+/* per-stage wall clock (ms) of the last vo_ref_stereo_frame call: priors, KLT l0->l1, trackWithScale, KLT l1->r1, BA,
+ * gates + compactions, new-point tracking */
+void vo_ref_stereo_frame_stage_ms(double out[8]);
+
 /* epipolar gates: motion_estimator.cpp:572-599 (Sampson), :621-653 (symmetric epipolar), :551-552 (F10) */
 void vo_ref_sampson_distance(const float *pts0, const float *pts1, int n, const float F10[9], float *dist);
 void vo_ref_symmetric_epipolar_distance(const float *pts0, const float *pts1, int n, const float F10[9],

@@ -48,6 +48,8 @@ struct FrameArgs {
   float *pr1;       // out [n][2] right pixels: the prior, replaced by the [5] result for features that reach [5]
   uint8_t *stage;   // out [n]    0 lost in [4], 1 in [4-1], 2 in [5], 3 survivor
   IcArgs ic;        // tap records / touched list / replay control (index space = input index)
+  int *sync;        // hand-shakes with the concurrent replay (vo_frame_state::sync)
+  int sync_signal;  // frame_fallback_kernel counts its workgroups in sync[1] (concurrent replay: the BA launch waits for it)
 #ifdef FRAME_STAMP
   int *dbg;         // [n + n_new][8] diagnostic stamps (s_memrealtime, 100 MHz) and iteration counts
 #endif
@@ -100,10 +102,26 @@ __device__ __forceinline__ void frame_tail(const FrameArgs &a, int i, int ok, fl
 // Both roles are "KLT, something in between, KLT", so the kernel is a two-pass loop around ONE
 // inlined copy of klt_point (its code is ~3000 instructions; one copy per call site would not fit
 // the instruction cache).
+#ifndef FRAME_WAVES_PER_EU
+#define FRAME_WAVES_PER_EU 2
+#endif
 template <int WIN>
-__global__ __launch_bounds__(64) void frame_track_kernel(FrameArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRAME_WAVES_PER_EU, FRAME_WAVES_PER_EU))) void frame_track_kernel(FrameArgs a) {
   __shared__ FrameShared<WIN> sh;
   if ((int)blockIdx.x >= a.n + a.n_new) return;
+  // Issue priority of the two roles (measured, -DFRAME_PRIO_FEAT / _CAND / -DFRAME_WAVES_PER_EU sweeps, 400 frames each,
+  // run-to-run noise ~1.5 %): candidates one step above the features 162-165 us per launch, equal 169-171 us, features
+  // above 170 us — the candidates are dispatched last (3150 workgroups, 2048 resident at 211 VGPRs) and the launch ends
+  // when the last of them does. Capping the kernel at 168 VGPRs (3 wavefronts per SIMD, everything resident at once)
+  // costs 38 spilled VGPRs: 159-166 us with the features above, 177-182 us otherwise — no better than this.
+#ifndef FRAME_PRIO_FEAT
+#define FRAME_PRIO_FEAT 0
+#define FRAME_PRIO_CAND 1
+#endif
+  if ((int)blockIdx.x >= a.n)
+    __builtin_amdgcn_s_setprio(FRAME_PRIO_CAND);
+  else
+    __builtin_amdgcn_s_setprio(FRAME_PRIO_FEAT);
   // Feature i is workgroup i: consecutive features (bucket order, i.e. image neighbours) go round-robin
   // over the 8 XCDs. The XCD-aware alternative — XCD x takes the x-th eighth of the list, a horizontal
   // band of the image that stays in its own L2 — was measured at 3840x2160 / 8000 features
@@ -223,12 +241,14 @@ __global__ __launch_bounds__(64) void frame_track_kernel(FrameArgs a) {
     first = k;
     // StereoLandmarkTracking(lmtrack_prev, mask_l0l1), landmark.cpp:305: mask && isAlive() && isTracked()
     const bool valid1 = frame_klt_valid(k, a.W, a.H, a.thres_err) && !(a.lm_flags && (a.lm_flags[i] & VO_LM_DROPPED));
+    // Everything the strict-border replay reads or rewrites goes through to memory (ic_store<true>): that kernel runs
+    // next to this one on other XCDs, and this kernel's dirty L2 lines would otherwise reach memory when IT ends.
     if (lane == 0) {
-      a.scale[i] = scale;
-      a.k1[2 * i] = k.x;
-      a.k1[2 * i + 1] = k.y;
-      a.pr_prior[2 * i] = prx;
-      a.pr_prior[2 * i + 1] = pry;
+      ic_store<true>(&a.scale[i], scale);
+      ic_store<true>(&a.k1[2 * i], k.x);
+      ic_store<true>(&a.k1[2 * i + 1], k.y);
+      ic_store<true>(&a.pr_prior[2 * i], prx);
+      ic_store<true>(&a.pr_prior[2 * i + 1], pry);
     }
     const IcTaps tp = ic_make_taps(lane);
     IcState S;
@@ -249,23 +269,23 @@ __global__ __launch_bounds__(64) void frame_track_kernel(FrameArgs a) {
     FSTAMP(2)
     FNOTE(6, n_iter)
     const int any_t = __any(touched);
-    if (a.strict) {
-      // records for the replay; pass-1 results of every point (the replay overwrites touched ones)
-      ic_store_records(a.ic, i, lane, tp, S, cls);
-      if (lane == 0) {
-        a.ic.touched[i] = (uint8_t)(any_t ? 1 : 0);
-        a.ic.cls[i] = (uint8_t)cls;
-        a.ic.last_pu[2 * i] = lpx;
-        a.ic.last_pu[2 * i + 1] = lpy;
-        a.ic.pts_track[2 * i] = rf.x;
-        a.ic.pts_track[2 * i + 1] = rf.y;
-        a.ic.mask[i] = (uint8_t)rf.ok;
-        if (any_t) a.ic.tlist[atomicAdd(&a.ic.jac[IC_JAC_NT], 1)] = i;
-      }
-    }
     if (lane == 0 && rf.err_flag) atomicOr(a.ic.flags, rf.err_flag);
     const bool deferred = a.strict && any_t;  // frame_replay_kernel (or frame_fallback_kernel) finishes this feature
-    if (!valid1 || !rf.ok || deferred) {
+    if (a.strict) {
+      // records for the replay; pass-1 results of every point (the replay overwrites touched ones)
+      ic_store_records<true>(a.ic, i, lane, tp, S, cls);
+      if (lane == 0) {
+        ic_store<true>(&a.ic.touched[i], (uint8_t)(any_t ? 1 : 0));
+        ic_store<true>(&a.ic.cls[i], (uint8_t)cls);
+        ic_store<true>(&a.ic.last_pu[2 * i], lpx);
+        ic_store<true>(&a.ic.last_pu[2 * i + 1], lpy);
+        ic_store<true>(&a.ic.pts_track[2 * i], rf.x);
+        ic_store<true>(&a.ic.pts_track[2 * i + 1], rf.y);
+        ic_store<true>(&a.ic.mask[i], (uint8_t)rf.ok);
+        if (any_t) ic_store<true>(&a.ic.tlist[atomicAdd(&a.ic.jac[IC_JAC_NT], 1)], i);
+      }
+    }
+    if (!deferred && (!valid1 || !rf.ok)) {
       if (lane == 0) {
         a.pl1[2 * i] = rf.x;  // the step [4] result unless the refinement accepted
         a.pl1[2 * i + 1] = rf.y;
@@ -273,8 +293,16 @@ __global__ __launch_bounds__(64) void frame_track_kernel(FrameArgs a) {
         a.pr1[2 * i + 1] = pry;
         a.stage[i] = valid1 ? 1 : 0;
       }
-      return;
     }
+    if (a.strict) {
+      // The replay may start as soon as every feature is past this point — the pass-1 stragglers, not the [5]
+      // stragglers, decide when. All the stores above that it depends on are write-through: wait for them, then count.
+      __builtin_amdgcn_s_waitcnt(0);
+      if (lane == 0) atomicAdd(&a.sync[0], 1);
+    }
+    // (a deferred feature's outputs — pl1, pr1, stage — are written by the replay's tail, never here: two kernels
+    // on two XCDs must not both own a byte)
+    if (!valid1 || !rf.ok || deferred) return;
     rf_ok = rf.ok;
     rfx = rf.x;
     rfy = rf.y;
@@ -286,6 +314,22 @@ __global__ __launch_bounds__(64) void frame_track_kernel(FrameArgs a) {
   (void)rf_ok;
 }
 
+// The replay runs on a stream of its own NEXT TO the frame kernel and may start as soon as every feature's pass-1
+// record and list entry exist — when the pass-1 stragglers are through, not when the last step [5] is. A replay
+// wavefront needs 278 VGPRs (a whole SIMD's second slot): 512 of them polling would take a quarter of the frame
+// kernel's residency, so ONE small wavefront does the waiting and the replay is stream-ordered behind it. The wait is
+// bounded; the frame kernel's wavefronts wait for nothing, so the count always arrives.
+__global__ __launch_bounds__(64) void frame_gate_kernel(int *word, int target, int *ovf) {
+  int polls = 0;
+  while ((int)(__builtin_amdgcn_readfirstlane(ic_ld(word)) - target) < 0) {  // (cumulative counters: wrap-safe)
+    if (++polls > IC_SPIN_LIMIT) {
+      if (threadIdx.x == 0) atomicExch(ovf, 1);  // the sequential fallback (behind both kernels) takes over
+      return;
+    }
+    __builtin_amdgcn_s_sleep(32);  // ~1 us
+  }
+}
+
 // strict border: replay of the touched features, then their step [5]
 template <int WIN>
 __global__ __launch_bounds__(64) void frame_replay_kernel(FrameArgs a) {
@@ -293,6 +337,7 @@ __global__ __launch_bounds__(64) void frame_replay_kernel(FrameArgs a) {
   __shared__ uint32_t s_tt[KltCfg<WIN>::TT_H * KltCfg<WIN>::TT_WD];
   __shared__ uint32_t s_tj[KltCfg<WIN>::TJ_H * KltCfg<WIN>::TJ_WD];
   const int lane = threadIdx.x;
+  __builtin_amdgcn_s_setprio(3);
   // step [5] of a feature follows its (re)computation at once: by then its record is published, so
   // nobody waits for this wavefront, and the feature is final unless an input changes later (rare;
   // the hook then runs again and overwrites the outputs)
@@ -313,15 +358,21 @@ __global__ __launch_bounds__(64) void frame_fallback_kernel(FrameArgs a) {
   __shared__ IcShared sh;
   __shared__ uint32_t s_tt[KltCfg<WIN>::TT_H * KltCfg<WIN>::TT_WD];
   __shared__ uint32_t s_tj[KltCfg<WIN>::TJ_H * KltCfg<WIN>::TJ_WD];
-  if (a.ic.jac[IC_JAC_OVF] == 0) return;
   const int i = blockIdx.x;
-  if (i >= a.n) return;
   const int lane = threadIdx.x;
-  auto tail = [&](int p, const IcResult &r) {
-    frame_tail<WIN>(a, p, r.ok, r.x, r.y, a.k1[2 * p], a.k1[2 * p + 1], a.pr_prior[2 * p], a.pr_prior[2 * p + 1], s_tt,
-                    s_tj, lane);
-  };
-  ic_strict_run(a.ic, sh, i, a.n, lane, tail);
+  if (a.ic.jac[IC_JAC_OVF] != 0 && i < a.n) {
+    auto tail = [&](int p, const IcResult &r) {
+      frame_tail<WIN>(a, p, r.ok, r.x, r.y, a.k1[2 * p], a.k1[2 * p + 1], a.pr_prior[2 * p], a.pr_prior[2 * p + 1], s_tt,
+                      s_tj, lane);
+    };
+    ic_strict_run(a.ic, sh, i, a.n, lane, tail);
+  }
+  // This kernel is stream-ordered behind the replay: when all of its workgroups have counted, every touched feature
+  // is final. The BA launch on the main stream waits for the count (no HIP event between the streams).
+  if (a.sync_signal) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) atomicAdd(&a.sync[1], 1);
+  }
 }
 
 #ifdef FRAME_STAMP
@@ -338,22 +389,40 @@ extern "C" int vo_debug_frame_stamps(vo_ctx *c, int *dst, int rows) {
 // phase 0: the per-feature kernel; phase 1: the strict-border replay (nothing otherwise). Two phases so that
 // the caller can feed other streams while the long first kernel is already running.
 template <int WIN>
-static void frame_launch(vo_ctx *c, const FrameArgs &a, int phase) {
+static void frame_launch(vo_ctx *c, const FrameArgs &a, int phase, int p1_target, int done_target) {
   if (phase == 0) {
     vo_prof_begin(c, VO_K_KLT);
     hipLaunchKernelGGL(frame_track_kernel<WIN>, dim3(a.n + a.n_new), dim3(64), 0, c->stream, a);
     vo_prof_end(c);
     return;
   }
-  if (a.strict) {
+  if (a.strict == 2) {  // validation mode: the sequential fallback does all the work, on the main stream
+    (void)hipMemsetAsync(&a.ic.jac[IC_JAC_OVF], 1, sizeof(int), c->stream);
+    hipLaunchKernelGGL(frame_fallback_kernel<WIN>, dim3(a.n), dim3(64), 0, c->stream, a);
+  } else if (a.strict == 3) {  // A/B: the replay stream-ordered behind the frame kernel (round 1's arrangement)
     vo_prof_begin(c, VO_K_IC);
-    if (a.strict == 2)  // validation mode: the sequential fallback does all the work
-      (void)hipMemsetAsync(&a.ic.jac[IC_JAC_OVF], 1, sizeof(int), c->stream);
-    else
-      hipLaunchKernelGGL(frame_replay_kernel<WIN>, dim3(a.n < IC_JGRID ? a.n : IC_JGRID), dim3(64), 0, c->stream, a);
+    hipLaunchKernelGGL(frame_replay_kernel<WIN>, dim3(a.n < IC_JGRID ? a.n : IC_JGRID), dim3(64), 0, c->stream, a);
     hipLaunchKernelGGL(frame_fallback_kernel<WIN>, dim3(a.n), dim3(64), 0, c->stream, a);
     vo_prof_end(c);
+  } else if (a.strict) {
+    // The replay runs on its own stream next to the frame kernel. No HIP event joins the two streams (a cross-queue
+    // event wait costs ~30 us on this stack): the replay starts behind a one-wavefront gate that polls the frame
+    // kernel's pass-1 count, and the BA launch (main stream, behind the frame kernel) polls the count of finished
+    // workgroups of the fallback kernel, which is stream-ordered behind the replay. Both counts are cumulative; the
+    // control block the replay reads was zeroed by the previous frame's BA launch, which the frame kernel (hence the
+    // first count) is stream-ordered behind.
+    FrameArgs b = a;
+    b.sync_signal = 1;
+    hipStream_t main_stream = c->stream;
+    hipLaunchKernelGGL(frame_gate_kernel, dim3(1), dim3(64), 0, c->stream3, b.sync + 0, p1_target, &b.ic.jac[IC_JAC_OVF]);
+    c->stream = c->stream3;  // (the event brackets follow c->stream)
+    vo_prof_begin(c, VO_K_IC);
+    hipLaunchKernelGGL(frame_replay_kernel<WIN>, dim3(b.n < IC_JGRID ? b.n : IC_JGRID), dim3(64), 0, c->stream3, b);
+    vo_prof_end(c);
+    c->stream = main_stream;
+    hipLaunchKernelGGL(frame_fallback_kernel<WIN>, dim3(b.n), dim3(64), 0, c->stream3, b);
   }
+  (void)done_target;
   // (the frame's one compaction and the control-block reset are the prologue of the GN launch, gn_pose.hip)
 }
 
@@ -433,11 +502,18 @@ int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, 
   a.ic.cls = b.cls;
   a.ic.last_pu = b.lastpu;
   a.ic.n = n;
+  a.sync = b.sync;
+  // running totals of the two hand-shake counters: what they will read when this frame's share has arrived
+  if (phase == 0 && a.strict) {
+    *b.sync_p1_target += n;  // (every strict frame counts, whichever replay follows)
+    if (a.strict == 1) *b.sync_done_target += n;  // one count per workgroup of the fallback kernel
+  }
+  const int p1_target = *b.sync_p1_target, done_target = *b.sync_done_target;
   switch (prm->win) {
-    case 13: frame_launch<13>(c, a, phase); break;
-    case 15: frame_launch<15>(c, a, phase); break;
-    case 21: frame_launch<21>(c, a, phase); break;
-    case 31: frame_launch<31>(c, a, phase); break;
+    case 13: frame_launch<13>(c, a, phase, p1_target, done_target); break;
+    case 15: frame_launch<15>(c, a, phase, p1_target, done_target); break;
+    case 21: frame_launch<21>(c, a, phase, p1_target, done_target); break;
+    case 31: frame_launch<31>(c, a, phase, p1_target, done_target); break;
     default: VO_FAIL(c, VO_ERR_INVALID, "fused frame kernel not instantiated for window %d", prm->win);
   }
   VO_CHECK_HIP(c, hipGetLastError());

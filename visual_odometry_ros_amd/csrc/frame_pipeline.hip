@@ -59,6 +59,8 @@ int vo_frame_init(vo_ctx *c) {
   VO_CHECK_HIP(c, hipEventCreateWithFlags(&f->ev_done, hipEventDisableTiming));
   VO_CHECK_HIP(c, hipMalloc((void **)&f->ctl, vo_ic_ctl_bytes()));
   VO_CHECK_HIP(c, hipMemsetAsync(f->ctl, 0, vo_ic_ctl_bytes(), c->stream));
+  VO_CHECK_HIP(c, hipMalloc((void **)&f->sync, 64));
+  VO_CHECK_HIP(c, hipMemsetAsync(f->sync, 0, 64, c->stream));
   return VO_OK;
 }
 
@@ -68,7 +70,7 @@ void vo_frame_free(vo_ctx *c) {
   void *bufs[] = {f->in_l0, f->in_r0, f->in_X, f->in_new, f->F_scale, f->F_orig, f->A_pl0, f->A_pl1, f->A_pr1,
                   f->A_X, f->A_scale, f->A_orig, f->B_pl1, f->B_pr1, f->B_X, f->B_orig, f->C_pl1, f->C_pr1,
                   f->C_X, f->C_orig, f->m1, f->m2, f->m3, f->mG, f->st1, f->st2, f->e1, f->e2, f->new_back,
-                  f->A_ref, f->A_lastpu, f->A_touched, f->A_cls, f->res_dev, f->st3, f->e3, f->ctl, f->in_flags, f->bin_r,
+                  f->A_ref, f->A_lastpu, f->A_touched, f->A_cls, f->res_dev, f->st3, f->e3, f->ctl, f->sync, f->in_flags, f->bin_r,
                   f->bin_m};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
@@ -99,7 +101,7 @@ static void inv_se3(const float T[16], float Ti[16]) {
 
 extern "C" int vo_stereo_frame_set_strict_border(vo_ctx *c, int strict) {
   if (!c) return VO_ERR_INVALID;
-  c->frame_strict_ic = strict == 2 ? 2 : (strict ? 1 : 0);
+  c->frame_strict_ic = (strict == 2 || strict == 3) ? strict : (strict ? 1 : 0);  // 3: the replay stream-ordered behind the frame kernel (A/B)
   return VO_OK;
 }
 
@@ -216,6 +218,9 @@ static int frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l
     b.touched = f->A_touched;
     b.cls = f->A_cls;
     b.ctl = f->ctl;
+    b.sync = f->sync;
+    b.sync_p1_target = &f->sync_p1_target;
+    b.sync_done_target = &f->sync_done_target;
     b.hdr_flags = &f->hdr->flags;
     b.C_X = f->C_X;
     b.C_pl1 = f->C_pl1;
@@ -351,6 +356,10 @@ static int frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l
   }
   if (fused) {
     gf.ctl = f->ctl;
+    if (c->frame_strict_ic == 1) {  // the replay of this frame runs on its own stream: join on the device
+      gf.join_word = f->sync + 1;
+      gf.join_target = f->sync_done_target;
+    }
     gf.ctl_words = (int)(vo_ic_ctl_bytes() / 4);
     gf.nt_word = vo_ic_ctl_nt_word();
     gf.res_dev = f->res_dev;
@@ -466,6 +475,7 @@ extern "C" int vo_stereo_frame_result(vo_ctx *c, float *pts_l1, float *pts_r1, u
   if (h->flags) {
     if (h->flags & 1) VO_FAIL(c, VO_ERR_NAN_AXAY, "ax ay nan");
     if (h->flags & 2) VO_FAIL(c, VO_ERR_NAN_PATCH, "I0 I1 / du0 dv0 nan");
+    if (h->flags & 8) VO_FAIL(c, VO_ERR_HIP, "the strict-border replay stream did not finish (device-side join timed out)");
     VO_FAIL(c, VO_ERR_NAN_UPDATE, "dtu dtv nan");
   }
   if (h->gn.is_nan) VO_FAIL(c, VO_ERR_GN_FAILED, "PoseOnlyStereoBA is failed!");

@@ -36,6 +36,11 @@ struct vo_frame_state {
   float *bin_r;     // closed step [10]: per-bin forward result / trackBidirection mask of the frame kernel
   uint8_t *bin_m;
   int *ctl;  // fused path: error flags + replay control words (zero between frames)
+  // device-side hand-shakes between the frame kernel (main stream) and the concurrent strict-border replay (its own
+  // stream), never zeroed — the host hands each frame the cumulative value to wait for:
+  //   sync[0] += 1 per feature past pass 1 (frame kernel)   sync[1] += 1 per replay workgroup that has finished
+  int *sync;
+  int sync_p1_target, sync_done_target;
   // packed result block
   uint8_t *res_dev, *res_host;
   size_t res_cap;

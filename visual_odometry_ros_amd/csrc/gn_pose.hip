@@ -52,6 +52,8 @@ struct GnArgs {
   // (survivors = stage 3, in index order, + the three step counts), reports / resets the frame's
   // control block, and at the end copies the packed result block to pinned host memory itself:
   // two launches (compaction, D2H blit) fewer on the critical path of every frame
+  const int *f_join_word;   // frame mode: wait for the concurrent replay (see vo_gn_frame)
+  int f_join_target;
   int f_n;                  // > 0: frame mode, features in input index space
   const uint8_t *f_stage;   // [f_n]
   const uint8_t *f_lmflags; // [f_n] stereo: bit 0 = landmark triangulated (null: all); the BA set is stage 3 && triangulated
@@ -414,7 +416,26 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
 #define GSTAMP(k)
 #endif
   GSTAMP(0)
+  __builtin_amdgcn_s_setprio(3);  // one workgroup on the frame's critical path, next to the side stream's kernels
   int n = a.d_n ? *a.d_n : a.n;
+  if (a.f_n > 0 && a.f_join_word) {
+    // the strict-border replay runs on a stream of its own: its last kernel counts its finished workgroups
+    if (tid == 0) {
+      int polls = 0, ok = 1;
+      while ((int)(__hip_atomic_load(a.f_join_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.f_join_target) < 0) {
+        if (++polls > (1 << 17)) {  // ~0.1 s: the replay stream is stuck; report instead of hanging
+          ok = 0;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(16);
+      }
+      s_stop = ok;
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (!s_stop && tid == 0) atomicOr(a.f_ctl, 8);  // reported through the frame's error flags
+    __syncthreads();
+  }
   if (a.f_n > 0) {
     // ---- frame mode prologue: survivors in index order + step counts (the one compaction of the frame) ----
     int *s_wv = (int *)s_tot;  // [8][3] wave counts, then 3 running totals at [24..26]
@@ -834,6 +855,8 @@ int vo_gn_enqueue(vo_ctx *c, bool stereo, bool mono_general_inverse, const float
     a.f_ctl_words = frame->ctl_words;
     a.f_nt_word = frame->nt_word;
     a.f_hdr_flags = frame->hdr_flags;
+    a.f_join_word = frame->join_word;
+    a.f_join_target = frame->join_target;
     a.f_res_dev = (const uint32_t *)frame->res_dev;
     a.f_res_host = (uint32_t *)frame->res_host;
     a.f_res_words = (int)((frame->res_bytes + 3) / 4);

@@ -20,6 +20,7 @@
 #define IC_JAC_OVF 15
 #define IC_JAC_NT 14
 #define IC_JAC_VER 13    // replay kernel: number of record publications so far
+#define IC_JAC_P1 12     // frame kernel: features whose pass-1 record (and list entry) is complete
 #define IC_JAC_SLOTS 16  // replay kernel: one "idle at version" word per workgroup
 #define IC_JGRID 512     // workgroups of the replay kernel (2 per CU: all co-resident); each strides over the touched list
 #define IC_JAC_WORDS (IC_JAC_SLOTS + IC_JGRID)
@@ -446,19 +447,31 @@ __device__ __forceinline__ void ic_state_clear(IcState &S) {
   S.m = 0;
 }
 
+// Stores that another kernel running CONCURRENTLY on another XCD reads (or overwrites) go through to memory: an
+// agent-scope atomic store is a plain store with sc1 set — no read-modify-write — and leaves no dirty line behind in
+// this XCD's L2 (each XCD has its own; a release fence would write the WHOLE L2 back, once per wavefront).
+template <bool COH, typename T>
+__device__ __forceinline__ void ic_store(T *p, T v) {
+  if (COH)
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else
+    *p = v;
+}
+
 // ---- tap records (who wrote which tap, and what) -----------------------------------
 // 264 mask bits: taps 64k..64k+63 (k < 4) go to words 2k, 2k+1; taps 256..263 to word 8.
 // `bits`: bit k of the lane = predicate of tap lane + 64 k.
+template <bool COH = false>
 __device__ __forceinline__ void ic_store_mask(uint32_t *dst, unsigned bits, int lane) {
 #pragma unroll
   for (int k = 0; k < IC_K; ++k) {
     const unsigned long long m = __ballot((bits >> k) & 1u);
     if (lane == 0) {
       if (k < 4) {
-        dst[2 * k] = (uint32_t)m;
-        dst[2 * k + 1] = (uint32_t)(m >> 32);
+        ic_store<COH>(&dst[2 * k], (uint32_t)m);
+        ic_store<COH>(&dst[2 * k + 1], (uint32_t)(m >> 32));
       } else {
-        dst[8] = (uint32_t)m;  // taps 256..263 (lanes 8.. own no tap there)
+        ic_store<COH>(&dst[8], (uint32_t)m);  // taps 256..263 (lanes 8.. own no tap there)
       }
     }
   }
@@ -468,23 +481,24 @@ __device__ __forceinline__ bool ic_bit_k(const uint32_t *w, int lane, int k) {
   return (w[k < 4 ? 2 * k + (lane >> 5) : 8] >> (lane & 31)) & 1u;
 }
 
+template <bool COH = false>
 __device__ __forceinline__ void ic_store_records(const IcArgs &a, int pt, int lane, const IcTaps &tp, const IcState &S,
                                                  int cls) {
   if (!a.recW0) return;
   const bool processed = cls >= 1, iterated = cls == 2;
-  ic_store_mask(a.recW0 + (size_t)pt * IC_MW, processed ? ((S.m >> 16) & tp.on) : 0u, lane);
-  ic_store_mask(a.recW1 + (size_t)pt * IC_MW, iterated ? ((S.m >> 24) & tp.on) : 0u, lane);
-  if (lane == 0) a.ready[pt] = 0;
+  ic_store_mask<COH>(a.recW0 + (size_t)pt * IC_MW, processed ? ((S.m >> 16) & tp.on) : 0u, lane);
+  ic_store_mask<COH>(a.recW1 + (size_t)pt * IC_MW, iterated ? ((S.m >> 24) & tp.on) : 0u, lane);
+  if (lane == 0) ic_store<COH>(&a.ready[pt], (uint8_t)0);
   float *v0 = a.recV0 + (size_t)pt * 3 * IC_NELEM;
   float *v1 = a.recV1 + (size_t)pt * IC_NELEM;
 #pragma unroll
   for (int k = 0; k < IC_K; ++k)
     if ((tp.on >> k) & 1u) {
       const int j = lane + 64 * k;
-      v0[j] = S.I0[k];
-      v0[IC_NELEM + j] = S.du[k];
-      v0[2 * IC_NELEM + j] = S.dv[k];
-      v1[j] = S.I1[k];
+      ic_store<COH>(&v0[j], S.I0[k]);
+      ic_store<COH>(&v0[IC_NELEM + j], S.du[k]);
+      ic_store<COH>(&v0[2 * IC_NELEM + j], S.dv[k]);
+      ic_store<COH>(&v1[j], S.I1[k]);
     }
 }
 

@@ -79,6 +79,7 @@ extern "C" int vo_create(const vo_config *cfg, vo_ctx **out) {
   VO_CHECK_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   c->stream_main = c->stream;
   VO_CHECK_HIP(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  VO_CHECK_HIP(c, hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
   VO_CHECK_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   VO_CHECK_HIP(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   VO_CHECK_HIP(c, hipEventCreateWithFlags(&c->ev_pyr, hipEventDisableTiming));
@@ -120,6 +121,7 @@ extern "C" int vo_create(const vo_config *cfg, vo_ctx **out) {
 extern "C" void vo_destroy(vo_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  if (c->stream3) (void)hipStreamSynchronize(c->stream3);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   vo_frame_free(c);
@@ -150,6 +152,7 @@ extern "C" void vo_destroy(vo_ctx *c) {
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->ev_pyr) (void)hipEventDestroy(c->ev_pyr);
+  if (c->stream3) (void)hipStreamDestroy(c->stream3);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   free(c);
@@ -335,8 +338,11 @@ extern "C" int vo_set_stereo_pair_host_async(vo_ctx *c, int slot_l, const uint8_
   for (int i = 0; i < 2; ++i) {
     vo_pyramid &P = c->slots[slots[i]];
     if (!P.stage) VO_CHECK_HIP(c, hipMalloc((void **)&P.stage, (size_t)c->cfg.max_width * c->cfg.max_height));
-    VO_CHECK_HIP(c, hipMemcpy2DAsync(P.stage, (size_t)width, src[i], (size_t)stride, (size_t)width, (size_t)height,
-                                     hipMemcpyHostToDevice, s));
+    if (stride == width)  // one linear copy (a 2-D copy is issued row by row: milliseconds instead of microseconds)
+      VO_CHECK_HIP(c, hipMemcpyAsync(P.stage, src[i], (size_t)width * height, hipMemcpyHostToDevice, s));
+    else
+      VO_CHECK_HIP(c, hipMemcpy2DAsync(P.stage, (size_t)width, src[i], (size_t)stride, (size_t)width, (size_t)height,
+                                       hipMemcpyHostToDevice, s));
   }
   return vo_pyramid_build_pair(c, slot_l, c->slots[slot_l].stage, slot_r, c->slots[slot_r].stage, width, height, width);
 }

@@ -53,6 +53,7 @@ struct vo_ctx {
   hipStream_t stream;      // the stream launchers enqueue on (= stream_main, except while a side-stream chain is built)
   hipStream_t stream_main;
   hipStream_t stream2;     // side stream: work that does not depend on the main chain of a frame
+  hipStream_t stream3;     // the strict-border replay of the frame in flight (runs next to the frame kernel)
   int ingest_side;         // vo_set_ingest_side_stream: image ingestion (H2D, pyramids) runs on the side stream
   hipEvent_t ev_fork, ev_join;
   hipEvent_t ev_pyr;       // recorded behind every pyramid build: what side-stream consumers of a slot wait for

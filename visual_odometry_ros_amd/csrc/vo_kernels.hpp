@@ -17,6 +17,8 @@ struct vo_gn_frame {
   int *ctl;                 // null (general path): no control block to report / reset
   int ctl_words, nt_word;
   int *hdr_flags;
+  const int *join_word;     // non-null: before anything else wait until *join_word has reached join_target (cumulative
+  int join_target;          // count of the concurrent strict-border replay's finished workgroups; bounded wait)
   const void *res_dev;
   void *res_host;           // pinned, device-visible; null = no copy-out
   size_t res_bytes;
@@ -97,6 +99,8 @@ struct vo_frame_fused_bufs {
   uint8_t *m_new;
   const uint8_t *cand_has;  // closed step [10]: candidate j is bin j of a table, present where cand_has[j] != 0
   int *ctl;        // control block (vo_ic_ctl_bytes): error flags + replay control words
+  int *sync;       // [0] features past pass 1, [1] replay workgroups finished: cumulative over the frames
+  int *sync_p1_target, *sync_done_target;  // host-side running totals (updated by the enqueue)
   int *hdr_flags;  // where the frame's error flags are reported
   float *C_X, *C_pl1, *C_pr1;
   int32_t *C_orig;
