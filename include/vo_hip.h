@@ -292,7 +292,12 @@ typedef struct {
 
 /* strict != 0: the frame's trackWithScale step replays border-touching points
  * with the reference's never-reset tap state (same as vo_track_with_scale's
- * strict_border; 2 = sequential replay only, for validation). Default 0. */
+ * strict_border; 2 = sequential replay only, for validation). Default 0.
+ * 3 (stereo frame only) = the parallel replay runs on a stream of its own NEXT TO the frame kernel and starts as
+ * soon as every feature is past its first refinement, joined on the device (no HIP event). Same results; measured
+ * on configs[1] it neither gains nor loses on average, and it needs the two queues to really run
+ * concurrently — under a tool that serialises kernels across queues (rocprofv3 --pmc) the device-side join times out
+ * and the frame returns VO_ERR_HIP. */
 int vo_stereo_frame_set_strict_border(vo_ctx *ctx, int strict);
 
 /* Asynchronous: enqueues one frame on the context stream. slot_l0 must hold the

@@ -84,7 +84,7 @@ def _run_stream(ctx, oracle, stream, n_frames, strict, win=21, max_level=6, sani
     return worst
 
 
-@pytest.mark.parametrize("strict", [False, True])
+@pytest.mark.parametrize("strict", [False, True, 3])
 def test_stereo_frame_kitti_shape(ctx, oracle, strict):
     stream = S.StereoStream(seed=2, margin=4.0 if strict else 16.0)
     _run_stream(ctx, oracle, stream, 3, strict)
@@ -148,11 +148,13 @@ def test_stereo_frame_small_many_frames(ctx, oracle):
     _run_stream(ctx, oracle, stream, 6, False, win=15, max_level=4)
 
 
-@pytest.mark.parametrize("win,strict", [(31, True), (17, True), (17, False), (15, True), (13, True), (13, False), (21, 2)])
+@pytest.mark.parametrize("win,strict", [(31, True), (17, True), (17, False), (15, True), (13, True), (13, False), (21, 2), (21, 3),
+                                        (15, 3)])
 def test_stereo_frame_other_windows(ctx, oracle, win, strict):
     """win 13 / 15 / 31: the other instantiations of the fused frame kernel; win 17: the general
     one-launch-per-step path (windows the fused kernel is not instantiated for); strict 2: the
-    sequential fallback of the strict-border replay does all the work."""
+    sequential fallback of the strict-border replay does all the work; strict 3: the parallel replay on its own stream
+    next to the frame kernel, joined on the device."""
     K = tuple(v * 0.5 for v in S.KITTI_K)
     stream = S.StereoStream(width=620, height=188, K=K, n_u=30, n_v=12, n_new=40, seed=11 + win,
                             margin=5.0 if strict else 14.0)

@@ -399,12 +399,12 @@ static void frame_launch(vo_ctx *c, const FrameArgs &a, int phase, int p1_target
   if (a.strict == 2) {  // validation mode: the sequential fallback does all the work, on the main stream
     (void)hipMemsetAsync(&a.ic.jac[IC_JAC_OVF], 1, sizeof(int), c->stream);
     hipLaunchKernelGGL(frame_fallback_kernel<WIN>, dim3(a.n), dim3(64), 0, c->stream, a);
-  } else if (a.strict == 3) {  // A/B: the replay stream-ordered behind the frame kernel (round 1's arrangement)
+  } else if (a.strict == 1) {  // the replay stream-ordered behind the frame kernel
     vo_prof_begin(c, VO_K_IC);
     hipLaunchKernelGGL(frame_replay_kernel<WIN>, dim3(a.n < IC_JGRID ? a.n : IC_JGRID), dim3(64), 0, c->stream, a);
     hipLaunchKernelGGL(frame_fallback_kernel<WIN>, dim3(a.n), dim3(64), 0, c->stream, a);
     vo_prof_end(c);
-  } else if (a.strict) {
+  } else if (a.strict == 3) {
     // The replay runs on its own stream next to the frame kernel. No HIP event joins the two streams (a cross-queue
     // event wait costs ~30 us on this stack): the replay starts behind a one-wavefront gate that polls the frame
     // kernel's pass-1 count, and the BA launch (main stream, behind the frame kernel) polls the count of finished
@@ -506,7 +506,7 @@ int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, 
   // running totals of the two hand-shake counters: what they will read when this frame's share has arrived
   if (phase == 0 && a.strict) {
     *b.sync_p1_target += n;  // (every strict frame counts, whichever replay follows)
-    if (a.strict == 1) *b.sync_done_target += n;  // one count per workgroup of the fallback kernel
+    if (a.strict == 3) *b.sync_done_target += n;  // one count per workgroup of the fallback kernel
   }
   const int p1_target = *b.sync_p1_target, done_target = *b.sync_done_target;
   switch (prm->win) {

@@ -101,7 +101,7 @@ static void inv_se3(const float T[16], float Ti[16]) {
 
 extern "C" int vo_stereo_frame_set_strict_border(vo_ctx *c, int strict) {
   if (!c) return VO_ERR_INVALID;
-  c->frame_strict_ic = (strict == 2 || strict == 3) ? strict : (strict ? 1 : 0);  // 3: the replay stream-ordered behind the frame kernel (A/B)
+  c->frame_strict_ic = (strict == 2 || strict == 3) ? strict : (strict ? 1 : 0);
   return VO_OK;
 }
 
@@ -356,7 +356,7 @@ static int frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l
   }
   if (fused) {
     gf.ctl = f->ctl;
-    if (c->frame_strict_ic == 1) {  // the replay of this frame runs on its own stream: join on the device
+    if (c->frame_strict_ic == 3) {  // the replay of this frame runs on its own stream: join on the device
       gf.join_word = f->sync + 1;
       gf.join_target = f->sync_done_target;
     }
