@@ -18,6 +18,7 @@
 #include "frame_state.hpp"
 #include "vo_kernels.hpp"
 
+#include <stddef.h>
 #include <stdlib.h>
 #ifdef VO_TRACE_HOST
 #include <chrono>
@@ -365,6 +366,9 @@ static int frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l
     gf.res_dev = f->res_dev;
     gf.res_host = f->res_host;  // pinned host memory is device-visible: the kernel copies the block out itself
     gf.res_bytes = f->res_bytes;
+    f->seq = f->seq + 1 == 0 ? 1 : f->seq + 1;
+    gf.seq = f->seq;
+    gf.seq_word = (int)(offsetof(vo_frame_hdr, seq) / 4);
     gf.res_late_bytes = tab ? late_end : f->off_mnew;  // header + stage bytes (+ the candidate arrays when closed)
     if (tab) {
       gf.np_bins = tab->n_bins;
@@ -390,6 +394,7 @@ static int frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l
   VO_TT("memcpy");
   VO_CHECK_HIP(c, hipEventRecord(f->ev_done, s));
   VO_TT("event");
+  f->seq_poll = fused;
   f->pending = true;
   c->frame_slots_busy = c->ingest_side;  // (one stream orders a rebuild behind the frame by itself)
   c->frame_slot[0] = slot_l0;
@@ -433,8 +438,22 @@ extern "C" int vo_stereo_frame_result(vo_ctx *c, float *pts_l1, float *pts_r1, u
   vo_frame_state *f = c->frame;
   VO_CHECK_HIP(c, hipSetDevice(c->device));
   // wait for THIS frame's results only: work enqueued after it (e.g. the next frame's pyramids)
-  // keeps running
-  VO_CHECK_HIP(c, hipEventSynchronize(f->ev_done));
+  // keeps running. Fused path: the BA launch writes the frame's sequence number into the pinned block after
+  // everything else; polling that word costs a microsecond where an event wait costs tens (bounded: after ~2 ms
+  // of polling, or on the general path, the event decides).
+  bool seen = false;
+  if (f->seq_poll) {
+    volatile const int *seqp = &((volatile const vo_frame_hdr *)f->res_host)->seq;
+    for (int spin = 0; spin < 2000000; ++spin) {
+      if (*seqp == f->seq) {
+        seen = true;
+        break;
+      }
+      __builtin_ia32_pause();
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  }
+  if (!seen) VO_CHECK_HIP(c, hipEventSynchronize(f->ev_done));
   f->pending = false;
   c->frame_slots_busy = 0;
   const vo_frame_hdr *h = (const vo_frame_hdr *)f->res_host;

@@ -9,7 +9,7 @@ struct vo_frame_hdr {
                // [5]=new-point candidates emitted by the closed step [10]
   vo_gn_dev_info gn;
   int flags;
-  int pad_[1];
+  int seq;  // host copy only: the frame's sequence number, written LAST by the BA launch (what vo_*_frame_result polls)
   float dT[16];
 };
 
@@ -53,6 +53,8 @@ struct vo_frame_state {
   int closed;       // the frame in flight takes its candidates from a bin table; n_new is then the number of bins
   const struct vo_cand_table *table;
   bool pending;
+  int seq;          // sequence number of the frame in flight (fused stereo path: the result is awaited by polling res_host)
+  bool seq_poll;
   hipEvent_t ev_done;  // recorded after the packed D2H: result() waits for this, not for the stream
 };
 

@@ -68,6 +68,7 @@ struct GnArgs {
   uint32_t *f_res_host;
   int f_res_words;
   int f_res_late_words;     // leading words (header, stage bytes) that this kernel still changes: copied last
+  int f_seq, f_seq_word;    // the host block's "result complete" word
   // closed step [10] (vo_gn_frame::np_*)
   int np_bins, np_bins_u, np_u_step, np_v_step;
   const uint8_t *np_has, *np_bin_m;
@@ -753,7 +754,15 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
       if (tid == 0) a.f_cnt[5] = s_wv[GN_NW];
       __syncthreads();
     }
-    for (int k = tid; k < a.f_res_late_words; k += GN_T) a.f_res_host[k] = a.f_res_dev[k];
+    for (int k = tid; k < a.f_res_late_words; k += GN_T)
+      if (k != a.f_seq_word || !a.f_seq) a.f_res_host[k] = a.f_res_dev[k];
+    if (a.f_seq) {
+      // the host polls this word instead of waiting for a HIP event (tens of microseconds of wake-up latency per
+      // frame): every store of the block above must be visible in host memory before it
+      __threadfence_system();
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(&a.f_res_host[a.f_seq_word], (uint32_t)a.f_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
   GSTAMP(4)
 }
@@ -861,6 +870,8 @@ int vo_gn_enqueue(vo_ctx *c, bool stereo, bool mono_general_inverse, const float
     a.f_res_host = (uint32_t *)frame->res_host;
     a.f_res_words = (int)((frame->res_bytes + 3) / 4);
     a.f_res_late_words = (int)(frame->res_late_bytes / 4);
+    a.f_seq = frame->seq;
+    a.f_seq_word = frame->seq_word;
     a.np_bins = frame->np_bins;
     a.np_bins_u = frame->np_bins_u;
     a.np_u_step = frame->np_u_step;

@@ -543,28 +543,48 @@ struct IcReplayShared {
 
 // For every tap flagged in `want` (bit k of a lane = tap lane + 64 k): the nearest predecessor
 // r in [0, L) (largest r) with rs.cls[r] >= need whose mask rs.w[r] has the tap's bit; result lo + r
-// (or -1) in rs.src[tap]. Lanes scan 64 predecessors at a time (nearest first) and vote: the taps a
-// point can observe are few, the predecessors many, and the writer of an observable tap is
-// typically far back in the run (the neighbours cannot see it either).
+// (or -1) in rs.src[tap].
+// ONE walk over the predecessors, nearest first, for all wanted taps together: lane w < 9 owns word w of the 9-word
+// tap masks, keeps the still unresolved wanted taps of that word in a register and ANDs it with each predecessor's
+// word (four predecessors per step, so that their LDS reads are in flight together). A tap-by-tap search — a ballot
+// loop over the predecessors per tap — cost ~5 us for the ~70 observable taps of a bottom-row feature, once per look
+// and therefore several times per link of every dependency chain; this walk costs ~1 us.
 __device__ __forceinline__ void ic_find_writers(IcReplayShared &rs, unsigned want, int need, int lo, int L, int lane) {
+  unsigned long long b[IC_K];
 #pragma unroll
   for (int k = 0; k < IC_K; ++k) {
-    unsigned long long todo = __ballot((want >> k) & 1u);
-    while (todo) {
-      const int l = __ffsll((long long)todo) - 1;
-      todo &= todo - 1;
-      const int word = k < 4 ? 2 * k + (l >> 5) : 8, bit = l & 31;
-      int found = -1;
-      for (int c0 = 0; c0 < L; c0 += 64) {
-        const int r = L - 1 - c0 - lane;
-        const bool hit = r >= 0 && rs.cls[r] >= need && ((rs.w[r * IC_MW + word] >> bit) & 1u);
-        const unsigned long long b = __ballot(hit);
-        if (b) {
-          found = lo + (L - 1 - c0 - (__ffsll((long long)b) - 1));
-          break;
-        }
+    b[k] = __ballot((want >> k) & 1u);
+    if ((want >> k) & 1u) rs.src[lane + 64 * k] = -1;
+  }
+  // word w of the wanted set: words 2k / 2k+1 = taps 64k.. / 64k+32.., word 8 = taps 256..263
+  unsigned ww = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    ww = lane == 2 * k ? (unsigned)b[k] : ww;
+    ww = lane == 2 * k + 1 ? (unsigned)(b[k] >> 32) : ww;
+  }
+  ww = lane == 8 ? (unsigned)b[4] : ww;
+  ww = lane < IC_MW ? ww : 0u;
+  const int tap0 = lane < 8 ? 64 * (lane >> 1) + 32 * (lane & 1) : 256;  // tap of bit 0 of this lane's word
+  __syncthreads();  // (one wavefront per workgroup: orders the -1 stores above before the writes below)
+  for (int c0 = 0; c0 < L; c0 += 4) {
+    if (!__any(ww != 0u)) break;
+    unsigned m[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = L - 1 - c0 - i;
+      const bool ok = r >= 0 && lane < IC_MW && rs.cls[r >= 0 ? r : 0] >= need;
+      m[i] = ok ? rs.w[(r >= 0 ? r : 0) * IC_MW + lane] : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned hit = ww & m[i];
+      ww &= ~m[i];
+      while (hit) {
+        const int bit = __ffs((int)hit) - 1;
+        hit &= hit - 1;
+        rs.src[tap0 + bit] = lo + (L - 1 - c0 - i);
       }
-      if (lane == 0) rs.src[l + 64 * k] = found;
     }
   }
 }
@@ -603,6 +623,7 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
   prep.cls = 0;
   prep.iD_A11 = prep.iD_A12 = prep.iD_A22 = 0.f;
   prep.tile.x0 = prep.tile.y0 = 0;
+  bool mine_ran = false;  // single mode: this workgroup's feature has published (== ready[pt], without the round trip)
   int result = P;
   for (int pass = 0;; ++pass) {
     // ---- look ----
@@ -789,7 +810,9 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
       {
         float *p1 = a.pre1 + (size_t)pt * IC_NELEM;
         uint32_t *pm = a.preM + (size_t)pt * IC_MW;
-        int diff = __builtin_amdgcn_readfirstlane(!ic_ld8(&a.ready[pt]));  // the first strict-state run is unconditional
+        // the first strict-state run is unconditional (single mode knows without asking memory: every global round
+        // trip between "my writers are final" and "my record is published" is on the critical path of a chain)
+        int diff = single ? (mine_ran ? 0 : 1) : __builtin_amdgcn_readfirstlane(!ic_ld8(&a.ready[pt]));
         if (!diff) {
 #pragma unroll
           for (int k = 0; k < IC_K; ++k)
@@ -839,30 +862,35 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
       const unsigned o = iterated ? ((S.m >> 24) & tp.on) : 0u;
       uint32_t *w1 = a.recW1 + (size_t)pt * IC_MW;
       float *v1 = a.recV1 + (size_t)pt * IC_NELEM;
-      int changed = a.cls[pt] != cls;
-#pragma unroll
-      for (int k = 0; k < IC_K; ++k)
-        if ((tp.on >> k) & 1u) {
-          const bool ok = (o >> k) & 1u;
-          if (ok != ic_bit_k(w1, lane, k) || (ok && __float_as_uint(v1[lane + 64 * k]) != __float_as_uint(S.I1[k])))
-            changed = 1;
-        }
-      const bool first_run = !ic_ld8(&a.ready[pt]);
-      if (__any(changed) || first_run) {
-        // publish: record, release, count (release again), version
+      const bool first_run = single ? !mine_ran : !ic_ld8(&a.ready[pt]);
+      int changed = 0;
+      if (!first_run) {  // (a first run publishes whatever it found: no need to read the pass-1 record back)
+        changed = a.cls[pt] != cls;
 #pragma unroll
         for (int k = 0; k < IC_K; ++k)
-          if ((tp.on >> k) & 1u) v1[lane + 64 * k] = S.I1[k];
-        ic_store_mask(w1, o, lane);
-        if (lane == 0) a.cls[pt] = (uint8_t)cls;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          if ((tp.on >> k) & 1u) {
+            const bool ok = (o >> k) & 1u;
+            if (ok != ic_bit_k(w1, lane, k) || (ok && __float_as_uint(v1[lane + 64 * k]) != __float_as_uint(S.I1[k])))
+              changed = 1;
+          }
+      }
+      if (first_run || __any(changed)) {
+        // publish: record (write-through stores: a release fence would write this XCD's whole L2 back, once per
+        // hand-over of every chain), wait for the stores, count, version
+#pragma unroll
+        for (int k = 0; k < IC_K; ++k)
+          if ((tp.on >> k) & 1u) ic_store<true>(&v1[lane + 64 * k], S.I1[k]);
+        ic_store_mask<true>(w1, o, lane);
+        if (lane == 0) ic_store<true>(&a.cls[pt], (uint8_t)cls);
+        __builtin_amdgcn_s_waitcnt(0);
+        mine_ran = true;
         if (lane == 0) {
-          // the count is bumped by an atomic whose result is awaited: it has been performed at the
-          // coherence point before the version moves
-          const int c = atomicAdd(&a.pubc[pt], 1);
-          asm volatile("" ::"v"(c));  // (wait for the returned value: the atomic has been performed)
+          // count, ready flag and version are issued back to back: each becomes visible after the record (the wait
+          // above), and their order among themselves does not matter — a reader that sees the flag or the version
+          // before the count only looks once more than it had to
+          __hip_atomic_fetch_add(&a.pubc[pt], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           ic_st8(&a.ready[pt], 1);
-          atomicAdd(ver, 1);
+          __hip_atomic_fetch_add(ver, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef IC_STAMP
           atomicAdd(&a.tlist[IC_DBG_OFF + 33], 1);
 #endif

@@ -22,6 +22,8 @@ struct vo_gn_frame {
   const void *res_dev;
   void *res_host;           // pinned, device-visible; null = no copy-out
   size_t res_bytes;
+  int seq;                  // != 0: written to the host block's header (word seq_word) after everything else, system scope
+  int seq_word;
   size_t res_late_bytes;    // leading part (header + stage bytes, multiple of 16) the GN launch itself still writes
   // mono frame (frame_mono.hip): the BA set is m1 && m2 && m3 instead of stage >= 3 (counts: m1, m1 && m2, the set),
   // and the epilogue is mono_gate_body(*mono_gate) — a MonoGateArgs, copied into the kernel arguments
