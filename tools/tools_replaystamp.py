@@ -1,4 +1,6 @@
-"""IC_STAMP builds: replay phases inside frame_replay_kernel on bench-like frames (strict border)."""
+"""IC_STAMP builds: per-feature timeline of the strict-border replay (frame_replay_kernel) on bench-like frames:
+for every replayed feature the final look (attempt start, writers found), the run (start, end, iterations) and the
+publication — i.e. what a link of a dependency chain is made of."""
 import sys, ctypes as C, numpy as np
 sys.path.insert(0, '.')
 import torch  # noqa: F401
@@ -13,15 +15,21 @@ ctx.set_pyramid_window_hint(21)
 for k in range(1, 7):
     Lp, Rp, _ = st.render_pair(poses[k - 1]); L, R, _ = st.render_pair(poses[k]); ts = st.track_set(k - 1, poses[k - 1], poses[k])
     ctx.set_image(0, Lp); ctx.set_image(1, L); ctx.set_image(2, R)
+    dbg = np.zeros(80 + 2048, np.int32)
     for rep in range(2):
         pipe.enqueue(ts["pts_l0"], ts["pts_r0"], ts["Xp"], ts["dT_prior"], ts["pts_new"]); g = pipe.result()
-    dbg = np.zeros(80 + 2048, np.int32)
-    ctx.lib.vo_debug_ic_jac(ctx.handle, dbg.ctypes.data_as(C.POINTER(C.c_int)))
+        ctx.lib.vo_debug_ic_jac(ctx.handle, dbg.ctypes.data_as(C.POINTER(C.c_int)))  # (the second, warm frame is kept)
     d = dbg[16:]
     t0 = int(d[31])
-    print(f"frame {k}: replayed {g['counts'].n_replayed:4d}  looks->reruns {d[32]:4d} publishes {d[33]:4d}  quiescent at {(int(d[0]) - t0) / 100:6.1f} us, tails done at {(int(d[2]) - t0) / 100:6.1f} us")
-    rows = dbg[80:].reshape(512, 4); rows = rows[rows[:, 1] > 0]
-    st_, en, it = (rows[:, 0] - t0) / 100.0, (rows[:, 1] - t0) / 100.0, rows[:, 2]
-    o = np.argsort(en)[-14:]
-    print("   last finishers (pt, start, end, iters):", [(int(rows[i, 3]), round(float(st_[i]), 1), round(float(en[i]), 1), int(it[i])) for i in o])
-    print(f"   run time: mean {np.mean(en - st_):.1f} us, iters mean {it.mean():.1f}; runs with 30 iters: {(it >= 30).sum()}; first starts: {np.sort(st_)[:3].round(1)}")
+    print(f"frame {k}: replayed {g['counts'].n_replayed:4d}  runs {d[32]:4d} publishes {d[33]:4d}  quiescent at {(int(d[0]) - t0) / 100:6.1f} us, tails done at {(int(d[2]) - t0) / 100:6.1f} us")
+    rows = dbg[80:].reshape(256, 8); rows = rows[rows[:, 1] > 0]
+    if not len(rows):
+        continue
+    us = lambda c: (rows[:, c] - t0) / 100.0
+    att, fw, rs_, re_, pub, it, natt, pt = us(4), us(5), us(0), us(1), us(6), rows[:, 2], rows[:, 7], rows[:, 3]
+    o = np.argsort(re_)
+    print("   last finishers: pt | final look starts, writers found, run starts, run ends, published | iterations, looks")
+    for i in o[-16:]:
+        print(f"     {pt[i]:5d} | {att[i]:7.1f} {fw[i]:7.1f} {rs_[i]:7.1f} {re_[i]:7.1f} {pub[i]:7.1f} | {it[i]:3d} {natt[i]:3d}")
+    print(f"   means: look->writers {np.mean(fw - att):.1f} us, writers->run start {np.mean(rs_ - fw):.1f} us, run {np.mean(re_ - rs_):.1f} us "
+          f"({it.mean():.1f} iterations), run end->published {np.mean(pub - re_):.1f} us; looks per feature {natt.mean():.1f}")

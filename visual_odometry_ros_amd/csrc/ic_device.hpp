@@ -556,25 +556,32 @@ __device__ __forceinline__ void ic_find_writers(IcReplayShared &rs, unsigned wan
     b[k] = __ballot((want >> k) & 1u);
     if ((want >> k) & 1u) rs.src[lane + 64 * k] = -1;
   }
-  // word w of the wanted set: words 2k / 2k+1 = taps 64k.. / 64k+32.., word 8 = taps 256..263
+  // Seven groups of nine lanes share the predecessors: group g walks the g-th seventh of them (nearest first), lane w
+  // of a group owns word w of the 9-word masks (words 2k / 2k+1 = taps 64k.. / 64k+32.., word 8 = taps 256..263) and
+  // the wanted taps of that word it has not met yet; a hit is merged with an LDS max (the nearest writer is the largest
+  // index). A seventh of a run is a few steps of four predecessors each, their LDS reads in flight together.
+  const int g = lane / IC_MW, w = lane - g * IC_MW;
+  const bool act = g < 7;
   unsigned ww = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    ww = lane == 2 * k ? (unsigned)b[k] : ww;
-    ww = lane == 2 * k + 1 ? (unsigned)(b[k] >> 32) : ww;
+    ww = w == 2 * k ? (unsigned)b[k] : ww;
+    ww = w == 2 * k + 1 ? (unsigned)(b[k] >> 32) : ww;
   }
-  ww = lane == 8 ? (unsigned)b[4] : ww;
-  ww = lane < IC_MW ? ww : 0u;
-  const int tap0 = lane < 8 ? 64 * (lane >> 1) + 32 * (lane & 1) : 256;  // tap of bit 0 of this lane's word
-  __syncthreads();  // (one wavefront per workgroup: orders the -1 stores above before the writes below)
-  for (int c0 = 0; c0 < L; c0 += 4) {
-    if (!__any(ww != 0u)) break;
+  ww = w == 8 ? (unsigned)b[4] : ww;
+  ww = act ? ww : 0u;
+  const int tap0 = w < 8 ? 64 * (w >> 1) + 32 * (w & 1) : 256;  // tap of bit 0 of this lane's word
+  const int chunk = (L + 6) / 7;
+  const int hi = L - 1 - g * chunk;           // nearest predecessor of this group
+  const int lo_r = hi - chunk + 1 > 0 ? hi - chunk + 1 : 0;
+  __syncthreads();  // (one wavefront per workgroup: orders the -1 stores above before the maxima below)
+  for (int c0 = 0; c0 < chunk; c0 += 4) {
     unsigned m[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int r = L - 1 - c0 - i;
-      const bool ok = r >= 0 && lane < IC_MW && rs.cls[r >= 0 ? r : 0] >= need;
-      m[i] = ok ? rs.w[(r >= 0 ? r : 0) * IC_MW + lane] : 0u;
+      const int r = hi - c0 - i;
+      const bool ok = act && r >= lo_r && rs.cls[r >= 0 ? r : 0] >= need;
+      m[i] = ok ? rs.w[(r >= 0 ? r : 0) * IC_MW + w] : 0u;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -583,7 +590,7 @@ __device__ __forceinline__ void ic_find_writers(IcReplayShared &rs, unsigned wan
       while (hit) {
         const int bit = __ffs((int)hit) - 1;
         hit &= hit - 1;
-        rs.src[tap0 + bit] = lo + (L - 1 - c0 - i);
+        atomicMax(&rs.src[tap0 + bit], lo + (hi - c0 - i));
       }
     }
   }
@@ -729,35 +736,77 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
       }
       IcState S = S0;
       bool give_up = false, unchanged = false;
+#ifdef IC_STAMP
+      int dbg_t_att = 0, dbg_t_fw = 0, dbg_n_att = 0;
+#endif
       for (int attempt = 0;; ++attempt) {
+#ifdef IC_STAMP
+        dbg_t_att = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff);
+        ++dbg_n_att;
+#endif
         // publication counts of the predecessors, read BEFORE their records (a count is bumped after
         // the record's release): unchanged counts => unchanged records => nothing to do
         int pc[(IC_MAXRUN + 63) / 64];
-        bool moved = pass == 0 || !single || attempt > 0 || !ic_ld8(&a.ready[pt]);
+        // a look that follows a wait (attempt > 0) knows that something moved: it skips the counts — one round trip
+        // less on the critical path of the chain; the stale counts only make a later idle look take place once more
+        const bool counts = attempt == 0;
+        bool moved = pass == 0 || !single || attempt > 0 || (single ? !mine_ran : !ic_ld8(&a.ready[pt]));
+        if (counts) {
 #pragma unroll
-        for (int q = 0; q < (IC_MAXRUN + 63) / 64; ++q) {
-          const int i = lane + 64 * q;
-          pc[q] = i < L ? ic_ld(&a.pubc[lo + i]) : 0;
-          if (i < L && pc[q] != rs.pub[i]) moved = true;
+          for (int q = 0; q < (IC_MAXRUN + 63) / 64; ++q) {
+            const int i = lane + 64 * q;
+            pc[q] = i < L ? ic_ld(&a.pubc[lo + i]) : 0;
+            if (i < L && pc[q] != rs.pub[i]) moved = true;
+          }
         }
         if (!__any(moved)) {
           unchanged = true;
           break;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the records behind the counts just read
+        // (the records behind the counts just read are loaded with agent-scope loads below: they go past this XCD's
+        // L2 lines that may be stale, which an acquire fence would have to invalidate wholesale, once per look)
+        __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
+        if (counts) {
 #pragma unroll
-        for (int q = 0; q < (IC_MAXRUN + 63) / 64; ++q) {
-          const int i = lane + 64 * q;
-          if (i < L) rs.pub[i] = pc[q];
+          for (int q = 0; q < (IC_MAXRUN + 63) / 64; ++q) {
+            const int i = lane + 64 * q;
+            if (i < L) rs.pub[i] = pc[q];
+          }
         }
-        for (int w = 0; w < IC_MW; ++w)
-          if ((wordmask >> w) & 1u)
-            for (int i = lane; i < L; i += IC_T) rs.w[i * IC_MW + w] = a.recW1[(size_t)(lo + i) * IC_MW + w];
-        for (int i = lane; i < L; i += IC_T) rs.cls[i] = a.cls[lo + i];
+        {
+          // every load of the look in flight together: one exposure of the memory latency (a loop that loads and
+          // stores word by word pays it once per word and 64 predecessors — six round trips for a bottom-row feature)
+          uint32_t mw[(IC_MAXRUN + 63) / 64][IC_MW];
+          int cl[(IC_MAXRUN + 63) / 64];
+#pragma unroll
+          for (int q = 0; q < (IC_MAXRUN + 63) / 64; ++q) {
+            const int i = lane + 64 * q;
+            const bool in = i < L;
+            cl[q] = in ? ic_ld8(&a.cls[lo + (in ? i : 0)]) : 0;
+#pragma unroll
+            for (int w = 0; w < IC_MW; ++w)
+              mw[q][w] = (in && ((wordmask >> w) & 1u))
+                             ? __hip_atomic_load(&a.recW1[(size_t)(lo + (in ? i : 0)) * IC_MW + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                             : 0u;
+          }
+#pragma unroll
+          for (int q = 0; q < (IC_MAXRUN + 63) / 64; ++q) {
+            const int i = lane + 64 * q;
+            if (i < L) {
+              rs.cls[i] = (uint8_t)cl[q];
+#pragma unroll
+              for (int w = 0; w < IC_MW; ++w)
+                if ((wordmask >> w) & 1u) rs.w[i * IC_MW + w] = mw[q][w];
+            }
+          }
+        }
         __syncthreads();
         ic_find_writers(rs, seen, 2, lo, L, lane);
         __syncthreads();
+#ifdef IC_STAMP
+        dbg_t_fw = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff);
+#endif
         // Dataflow gate: while a touched feature that this one observes has not produced its first
         // strict-state result, a run here would only compute from pass-1 data that is about to
         // change, and would keep this wavefront busy when the real input arrives. Poll exactly those
@@ -802,7 +851,7 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
           const int j = lane + 64 * k;
           const int src = rs.src[j];
           if (src >= 0) {
-            S.I1[k] = a.recV1[(size_t)src * IC_NELEM + j];
+            S.I1[k] = __hip_atomic_load(&a.recV1[(size_t)src * IC_NELEM + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             S.m |= 0x100u << k;
           }
         }
@@ -834,7 +883,7 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
       int dummy = 0, n_iter = 0;
       float lx = 0.f, ly = 0.f;
 #ifdef IC_STAMP
-      if (lane == 0 && li < 512) a.tlist[IC_DBG_OFF + 64 + 4 * li + 0] = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff);
+      if (lane == 0 && li < 256) a.tlist[IC_DBG_OFF + 64 + 8 * li + 0] = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff);
 #endif
       IcResult res_pt;
       {
@@ -850,10 +899,13 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
         }
       }
 #ifdef IC_STAMP
-      if (lane == 0 && li < 512) {
-        a.tlist[IC_DBG_OFF + 64 + 4 * li + 1] = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff);
-        a.tlist[IC_DBG_OFF + 64 + 4 * li + 2] = n_iter;
-        a.tlist[IC_DBG_OFF + 64 + 4 * li + 3] = pt;
+      if (lane == 0 && li < 256) {
+        a.tlist[IC_DBG_OFF + 64 + 8 * li + 4] = dbg_t_att;
+        a.tlist[IC_DBG_OFF + 64 + 8 * li + 5] = dbg_t_fw;
+        a.tlist[IC_DBG_OFF + 64 + 8 * li + 7] = dbg_n_att;
+        a.tlist[IC_DBG_OFF + 64 + 8 * li + 1] = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff);
+        a.tlist[IC_DBG_OFF + 64 + 8 * li + 2] = n_iter;
+        a.tlist[IC_DBG_OFF + 64 + 8 * li + 3] = pt;
       }
 #endif
       const int cls = res_pt.cls;
@@ -893,6 +945,7 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
           __hip_atomic_fetch_add(ver, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef IC_STAMP
           atomicAdd(&a.tlist[IC_DBG_OFF + 33], 1);
+          if (li < 256) a.tlist[IC_DBG_OFF + 64 + 8 * li + 6] = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff);
 #endif
         }
         any_change = 1;
