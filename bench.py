@@ -407,7 +407,8 @@ def run_stereo(cfg, args, rank, local_rank, world, torch, V, barrier, dev, secon
         B.run(first, args.warmup, mode, host)
     first += args.warmup
     ctx.profile_enable(K * 4 + 64)
-    ctx.profile_set_classes(1 << 1)  # event-bracket only the dominant kernel (frame_track_kernel)
+    all_classes = bool(os.environ.get("VO_BENCH_ALL_KERNELS"))  # (more event brackets: a few us per frame slower)
+    ctx.profile_set_classes(0 if all_classes else 1 << 1)  # default: event-bracket only the dominant kernel
     ctx.profile_reset()
     acc = {"b8d": 0, "bdes": 0}
     results, stamps = [], []
@@ -490,6 +491,13 @@ def run_stereo(cfg, args, rank, local_rank, world, torch, V, barrier, dev, secon
         },
         "per_rank_fps": [round(p[0] / p[1], 2) for p in per_rank],
     }
+    if all_classes:
+        names = {0: "pyramid", 1: "frame_track", 2: "ic_replay", 3: "gn_pose", 4: "hamming", 5: "aux"}
+        out["kernels"] = {}
+        for cls, nm in names.items():
+            n_l, ms = ctx.profile_get(cls)
+            if n_l:
+                out["kernels"][nm] = {"launches": n_l, "avg_us": round(1e3 * ms / n_l, 2), "us_per_frame": round(1e3 * ms / K, 2)}
     if r0 is not None:
         out["frame_counts_first"] = {f: getattr(r0, f) for f in ("n_l0l1", "n_refine", "n_l1r1", "n_ba", "n_inlier", "n_new_ok",
                                                                  "gn_iterations", "n_replayed")}

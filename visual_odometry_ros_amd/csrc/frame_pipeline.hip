@@ -172,17 +172,23 @@ static int frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l
   f->table = tab;
   size_t off = align16(sizeof(vo_frame_hdr));
   f->off_stage = off;  off += align16((size_t)n);
-  f->off_mnew = off;   off += align16((size_t)n_new);
-  if (tab) {  // the candidate arrays are written by the BA launch's epilogue: they belong to the part copied last
-    f->off_newr = off;  off += align16(sizeof(float) * 2 * (size_t)n_new);
-    f->off_newl = off;  off += align16(sizeof(float) * 2 * (size_t)n_new);
+  if (!tab) {          // open loop: the frame kernel writes the candidates' results, final before the BA launch
+    f->off_mnew = off;  off += align16((size_t)n_new);
   }
-  const size_t late_end = off;
+  const size_t late_end = off;  // header + stage bytes: what the BA launch still changes, copied last
   f->off_pl1 = off;    off += align16(sizeof(float) * 2 * (size_t)n);
   f->off_pr1 = off;    off += align16(sizeof(float) * 2 * (size_t)n);
   if (!tab) {
     f->off_newr = off;  off += align16(sizeof(float) * 2 * (size_t)n_new);
     f->off_newl = 0;
+  }
+  // closed step [10]: mnew / newr / newl are written by the BA launch's epilogue, entry by entry, to the device AND
+  // the host block; they are the tail of the block, outside both bulk copies
+  const size_t bulk_end = off;
+  if (tab) {
+    f->off_mnew = off;  off += align16((size_t)n_new);
+    f->off_newr = off;  off += align16(sizeof(float) * 2 * (size_t)n_new);
+    f->off_newl = off;  off += align16(sizeof(float) * 2 * (size_t)n_new);
   }
   f->res_bytes = off;
   if (f->res_bytes > f->res_cap) VO_FAIL(c, VO_ERR_CAPACITY, "result block of %zu bytes exceeds the context's (max_points too small)", f->res_bytes);
@@ -365,11 +371,11 @@ static int frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l
     gf.nt_word = vo_ic_ctl_nt_word();
     gf.res_dev = f->res_dev;
     gf.res_host = f->res_host;  // pinned host memory is device-visible: the kernel copies the block out itself
-    gf.res_bytes = f->res_bytes;
+    gf.res_bytes = bulk_end;
     f->seq = f->seq + 1 == 0 ? 1 : f->seq + 1;
     gf.seq = f->seq;
     gf.seq_word = (int)(offsetof(vo_frame_hdr, seq) / 4);
-    gf.res_late_bytes = tab ? late_end : f->off_mnew;  // header + stage bytes (+ the candidate arrays when closed)
+    gf.res_late_bytes = tab ? late_end : f->off_mnew;  // header + stage bytes
     if (tab) {
       gf.np_bins = tab->n_bins;
       gf.np_bins_u = bp->n_bins_u;
@@ -382,6 +388,9 @@ static int frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l
       gf.np_out_l = (float *)(f->res_dev + f->off_newl);
       gf.np_out_r = f->new_r;
       gf.np_out_m = f->mNew;
+      gf.np_host_l = (float *)(f->res_host + f->off_newl);
+      gf.np_host_r = (float *)(f->res_host + f->off_newr);
+      gf.np_host_m = f->res_host + f->off_mnew;
     }
   }
   RC(vo_gn_enqueue(c, true, false, f->C_X, f->C_pl1, f->C_pr1, n, nullptr, prm->Kl, prm->Kr,

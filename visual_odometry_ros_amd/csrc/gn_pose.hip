@@ -73,8 +73,8 @@ struct GnArgs {
   int np_bins, np_bins_u, np_u_step, np_v_step;
   const uint8_t *np_has, *np_bin_m;
   const float *np_xy, *np_bin_r;
-  float *np_out_l, *np_out_r;
-  uint8_t *np_out_m;
+  float *np_out_l, *np_out_r, *np_host_l, *np_host_r;
+  uint8_t *np_out_m, *np_host_m;
   const uint8_t *f_m1, *f_m2, *f_m3;  // mono frame: selection masks in place of f_stage
   int f_mono;               // epilogue = mono_gate_body(f_gate)
   MonoGateArgs f_gate;
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
   __shared__ float s_tot[32];
   __shared__ float s_T10[16];
   __shared__ int s_stop;
-  __shared__ int s_ba[GN_NW + 1];  // frame prologue: per-wave sizes of the BA set, then the running total
+  __shared__ int s_pcnt[4 * GN_NW * 4];  // frame prologue: per chunk and wavefront the four counts of a super-chunk
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -439,61 +439,83 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
   }
   if (a.f_n > 0) {
     // ---- frame mode prologue: survivors in index order + step counts (the one compaction of the frame) ----
-    int *s_wv = (int *)s_tot;  // [8][3] wave counts, then 3 running totals at [24..26]
-    if (tid < 3) s_wv[24 + tid] = 0;
-    if (tid == 3) s_ba[GN_NW] = 0;
+    // Super-chunks of GN_SC * GN_T features: every load of a super-chunk — the stage bytes, the landmark flags and the
+    // points themselves, selected or not — is issued before anything waits, so the memory latency is exposed once per
+    // super-chunk (one for 1500 features) instead of twice per 512 features, and two barriers replace nine.
+    constexpr int GN_SC = 4;  // chunks of GN_T features per super-chunk
+    int *s_run = (int *)s_tot;  // [4] running totals: st >= 1, >= 2, >= 3, BA set
+    if (tid < 4) s_run[tid] = 0;
     __syncthreads();
-    for (int c0 = 0; c0 < a.f_n; c0 += GN_T) {
-      const int i = c0 + tid;
-      int st = 0;
-      if (i < a.f_n) {
+    for (int c0 = 0; c0 < a.f_n; c0 += GN_SC * GN_T) {
+      int st[GN_SC], fl[GN_SC];
+      float gx[GN_SC][3], gl[GN_SC][2], gr[GN_SC][2];
+#pragma unroll
+      for (int q = 0; q < GN_SC; ++q) {
+        const int i = c0 + q * GN_T + tid;
+        const bool in = i < a.f_n;
+        const int ii = in ? i : 0;
         if (a.f_m1)  // mono: tracked / refined / member of the BA set (mono_vo.cpp:773, :788, :799-826)
-          st = a.f_m1[i] ? (a.f_m2[i] ? (a.f_m3[i] ? 3 : 2) : 1) : 0;
+          st[q] = in ? (a.f_m1[ii] ? (a.f_m2[ii] ? (a.f_m3[ii] ? 3 : 2) : 1) : 0) : 0;
         else
-          st = a.f_stage[i];
+          st[q] = in ? a.f_stage[ii] : 0;
+        fl[q] = a.f_lmflags ? a.f_lmflags[ii] : VO_LM_TRIANGULATED;
+        gx[q][0] = a.f_X[3 * ii];
+        gx[q][1] = a.f_X[3 * ii + 1];
+        gx[q][2] = a.f_X[3 * ii + 2];
+        gl[q][0] = a.f_pl1[2 * ii];
+        gl[q][1] = a.f_pl1[2 * ii + 1];
+        gr[q][0] = a.f_pr1 ? a.f_pr1[2 * ii] : 0.f;
+        gr[q][1] = a.f_pr1 ? a.f_pr1[2 * ii + 1] : 0.f;
       }
-      // stereo_vo.cpp:599: only triangulated landmarks enter the pose-only BA
-      const bool in_ba = st >= 3 && (!a.f_lmflags || (a.f_lmflags[i] & VO_LM_TRIANGULATED));
-      const unsigned long long b1 = __ballot(st >= 1), b2 = __ballot(st >= 2), b3 = __ballot(st >= 3),
-                               b4 = __ballot(in_ba);
-      const int below = __popcll(b4 & ((1ull << lane) - 1ull));
-      if (lane == 0) {
-        s_wv[wave * 3 + 0] = __popcll(b1);
-        s_wv[wave * 3 + 1] = __popcll(b2);
-        s_wv[wave * 3 + 2] = __popcll(b3);
-        s_ba[wave] = __popcll(b4);
-      }
-      __syncthreads();
-      int woff = 0;
-      for (int w = 0; w < wave; ++w) woff += s_ba[w];
-      const int base = s_ba[GN_NW];
-      if (in_ba) {
-        const int o = base + woff + below;
-        a.f_CX[3 * o] = a.f_X[3 * i];
-        a.f_CX[3 * o + 1] = a.f_X[3 * i + 1];
-        a.f_CX[3 * o + 2] = a.f_X[3 * i + 2];
-        a.f_Cpl1[2 * o] = a.f_pl1[2 * i];
-        a.f_Cpl1[2 * o + 1] = a.f_pl1[2 * i + 1];
-        if (a.f_pr1) {
-          a.f_Cpr1[2 * o] = a.f_pr1[2 * i];
-          a.f_Cpr1[2 * o + 1] = a.f_pr1[2 * i + 1];
+      bool in_ba[GN_SC];
+      int below[GN_SC];
+#pragma unroll
+      for (int q = 0; q < GN_SC; ++q) {
+        // stereo_vo.cpp:599: only triangulated landmarks enter the pose-only BA
+        in_ba[q] = st[q] >= 3 && (fl[q] & VO_LM_TRIANGULATED);
+        const unsigned long long b1 = __ballot(st[q] >= 1), b2 = __ballot(st[q] >= 2), b3 = __ballot(st[q] >= 3),
+                                 b4 = __ballot(in_ba[q]);
+        below[q] = __popcll(b4 & ((1ull << lane) - 1ull));
+        if (lane == 0) {
+          int *d = s_pcnt + (q * GN_NW + wave) * 4;
+          d[0] = __popcll(b1);
+          d[1] = __popcll(b2);
+          d[2] = __popcll(b3);
+          d[3] = __popcll(b4);
         }
-        a.f_Corig[o] = i;
       }
       __syncthreads();
-      if (tid < 3) {
+      int base = s_run[3];
+#pragma unroll
+      for (int q = 0; q < GN_SC; ++q) {
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += s_pcnt[(q * GN_NW + w) * 4 + 3];
+        if (in_ba[q]) {
+          const int i = c0 + q * GN_T + tid;
+          const int o = base + woff + below[q];
+          a.f_CX[3 * o] = gx[q][0];
+          a.f_CX[3 * o + 1] = gx[q][1];
+          a.f_CX[3 * o + 2] = gx[q][2];
+          a.f_Cpl1[2 * o] = gl[q][0];
+          a.f_Cpl1[2 * o + 1] = gl[q][1];
+          if (a.f_pr1) {
+            a.f_Cpr1[2 * o] = gr[q][0];
+            a.f_Cpr1[2 * o + 1] = gr[q][1];
+          }
+          a.f_Corig[o] = i;
+        }
+        for (int w = 0; w < GN_NW; ++w) base += s_pcnt[(q * GN_NW + w) * 4 + 3];
+      }
+      __syncthreads();
+      if (tid < 4) {
         int tot = 0;
-        for (int w = 0; w < GN_NW; ++w) tot += s_wv[w * 3 + tid];
-        s_wv[24 + tid] += tot;
-      } else if (tid == 3) {
-        int tot = 0;
-        for (int w = 0; w < GN_NW; ++w) tot += s_ba[w];
-        s_ba[GN_NW] += tot;
+        for (int k = 0; k < GN_SC * GN_NW; ++k) tot += s_pcnt[k * 4 + tid];
+        s_run[tid] += tot;
       }
       __syncthreads();
     }
-    n = s_ba[GN_NW];
-    if (tid < 3) a.f_cnt[tid] = s_wv[24 + tid];
+    n = s_run[3];
+    if (tid < 3) a.f_cnt[tid] = s_run[tid];
     if (tid == 3) a.f_cnt[4] = n;
     // every producer / consumer of the control block ran before this kernel: report, then reset
     if (tid == 0 && a.f_ctl) {
@@ -737,11 +759,21 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
         const int base = s_wv[GN_NW];
         if (keep) {
           const int o = base + woff + below;
-          a.np_out_l[2 * o] = a.np_xy[2 * j];
-          a.np_out_l[2 * o + 1] = a.np_xy[2 * j + 1];
-          a.np_out_r[2 * o] = a.np_bin_r[2 * j];
-          a.np_out_r[2 * o + 1] = a.np_bin_r[2 * j + 1];
-          a.np_out_m[o] = a.np_bin_m[j];
+          // (straight into the pinned host block: only the emitted entries cross the bus, not the arrays' capacity)
+          const float lx = a.np_xy[2 * j], ly = a.np_xy[2 * j + 1], rx = a.np_bin_r[2 * j], ry = a.np_bin_r[2 * j + 1];
+          const uint8_t mk = a.np_bin_m[j];
+          a.np_out_l[2 * o] = lx;
+          a.np_out_l[2 * o + 1] = ly;
+          a.np_out_r[2 * o] = rx;
+          a.np_out_r[2 * o + 1] = ry;
+          a.np_out_m[o] = mk;
+          if (a.np_host_l) {
+            a.np_host_l[2 * o] = lx;
+            a.np_host_l[2 * o + 1] = ly;
+            a.np_host_r[2 * o] = rx;
+            a.np_host_r[2 * o + 1] = ry;
+            a.np_host_m[o] = mk;
+          }
         }
         __syncthreads();
         if (tid == 0) {
@@ -883,6 +915,9 @@ int vo_gn_enqueue(vo_ctx *c, bool stereo, bool mono_general_inverse, const float
     a.np_out_l = frame->np_out_l;
     a.np_out_r = frame->np_out_r;
     a.np_out_m = frame->np_out_m;
+    a.np_host_l = frame->np_host_l;
+    a.np_host_r = frame->np_host_r;
+    a.np_host_m = frame->np_host_m;
     a.f_m1 = frame->m1;
     a.f_m2 = frame->m2;
     a.f_m3 = frame->m3;

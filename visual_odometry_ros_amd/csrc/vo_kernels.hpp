@@ -39,6 +39,8 @@ struct vo_gn_frame {
   const uint8_t *np_bin_m;  // [np_bins]    frame kernel: trackBidirection mask of the bin's candidate
   float *np_out_l, *np_out_r;  // compacted, bins ascending (inside the result block)
   uint8_t *np_out_m;
+  float *np_host_l, *np_host_r;  // the same places in the pinned host block (written entry by entry, not copied)
+  uint8_t *np_host_m;
 };
 int vo_gn_enqueue(vo_ctx *c, bool stereo, bool mono_general_inverse, const float *dX, const float *dP1,
                   const float *dP2, int n, const int *d_n, const float Kl[4], const float Kr[4],
