@@ -11,13 +11,14 @@ def wrap(cls, name):
         t = time.perf_counter(); r = f(*a, **k); acc[name] = acc.get(name, 0.0) + time.perf_counter() - t; acc[name + '#'] = acc.get(name + '#', 0) + 1
         return r
     setattr(cls, name, g)
-for n in ("enqueue_device", "result"): wrap(api.StereoFramePipeline, n)
-for n in ("set_stereo_pair_device", "swap_slots"): wrap(api.Context, n)
-sys.argv = ["bench.py", "--no-cpu-baseline", "--strict-border", os.environ.get("STRICT", "0"), "--steps", "400"]
+for n in ("enqueue_closed_device", "result"): wrap(api.StereoFramePipeline, n)
+for n in ("set_stereo_pair_device",): wrap(api.Context, n)
+for n in ("enqueueCandidates",): wrap(api.FeatureExtractor, n)
+sys.argv = ["bench.py", "--no-cpu-baseline", "--no-secondary", "--strict-border", os.environ.get("STRICT", "1"), "--steps", "400"]
 t0 = time.perf_counter()
 try:
     runpy.run_path("bench.py", run_name="__main__")
 except SystemExit:
     pass
-for k in ("enqueue_device", "set_stereo_pair_device", "result", "swap_slots"):
+for k in ("enqueue_closed_device", "set_stereo_pair_device", "enqueueCandidates", "result"):
     print(f"{k:26s} {1e6 * acc[k] / acc[k + '#']:8.1f} us/call  x{acc[k + '#']}", file=sys.stderr)
