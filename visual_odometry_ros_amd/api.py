@@ -492,6 +492,18 @@ def se3Exp_f(ctx, xi):
     return T.reshape(4, 4), Ti.reshape(4, 4)
 
 
+def write_trajectory(path, frame_ids, T_wc):
+    """The reference's trajectory dump (stereo_vo.cpp:55-115, mono_vo.cpp:64-125): one line per frame,
+    `<frame id> r00 r01 r02 tx r10 r11 r12 ty r20 r21 r22 tz`, fixed notation, precision 4."""
+    T = np.asarray(T_wc, np.float32).reshape(-1, 4, 4)
+    ids = list(frame_ids)
+    if len(ids) != T.shape[0]:
+        raise ValueError("ids and poses differ in length")
+    with open(path, "w") as f:  # (the reference throws "file_dir cannot be opened!" when it cannot)
+        for j, Tj in zip(ids, T):
+            f.write(str(int(j)) + "".join(" %.4f" % float(v) for v in Tj[:3].reshape(-1)) + "\n")
+
+
 class TrackIds:
     """Landmark / Frame IDs of ONE image stream and the mask-compaction constructors with their side effect.
     The reference's counters are process-global statics (landmark.h:64, frame.h:53); here they belong to the

@@ -360,7 +360,8 @@ __global__ __launch_bounds__(64) void frame_fallback_kernel(FrameArgs a) {
   __shared__ uint32_t s_tj[KltCfg<WIN>::TJ_H * KltCfg<WIN>::TJ_WD];
   const int i = blockIdx.x;
   const int lane = threadIdx.x;
-  if (a.ic.jac[IC_JAC_OVF] != 0 && i < a.n) {
+  const bool work = a.ic.jac[IC_JAC_OVF] != 0 && i < a.n;
+  if (work) {
     auto tail = [&](int p, const IcResult &r) {
       frame_tail<WIN>(a, p, r.ok, r.x, r.y, a.k1[2 * p], a.k1[2 * p + 1], a.pr_prior[2 * p], a.pr_prior[2 * p + 1], s_tt,
                       s_tj, lane);
@@ -368,9 +369,11 @@ __global__ __launch_bounds__(64) void frame_fallback_kernel(FrameArgs a) {
     ic_strict_run(a.ic, sh, i, a.n, lane, tail);
   }
   // This kernel is stream-ordered behind the replay: when all of its workgroups have counted, every touched feature
-  // is final. The BA launch on the main stream waits for the count (no HIP event between the streams).
+  // is final. The BA launch on the main stream waits for the count (no HIP event between the streams). The replay's
+  // own stores reached memory when that kernel ended; only a workgroup that did fallback work has stores to release
+  // (a release fence writes the XCD's whole L2 back: not something 1500 idle workgroups should each do).
   if (a.sync_signal) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (work) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     if (lane == 0) atomicAdd(&a.sync[1], 1);
   }
 }
