@@ -47,6 +47,28 @@ __device__ __forceinline__ int klt_descale_dot4(int a, int b, int c, int d, int 
   return klt_dot4(a, b, c, d, w00, w01, w10, w11, 1 << (n - 1)) >> n;
 }
 
+// Packed 16-bit forms of the same integer arithmetic (every sum below is exact in int32, so the grouping of the
+// terms does not change a bit of the result): pixels are 0..255, weights -1..2^14, template values and differences
+// fit int16, so one v_dot2c_i32_i16 does two multiply-adds.
+typedef short klt_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int klt_dot2(uint32_t a, uint32_t b, int acc) {
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(klt_s2, a), __builtin_bit_cast(klt_s2, b), acc, false);
+}
+// low halves of two ints as one packed pair (v_perm_b32)
+__device__ __forceinline__ uint32_t klt_pack16(int lo, int hi) {
+  return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u);
+}
+// bytes k and k+1 (k = 0..3) of the eight bytes {hi:lo}, zero-extended to a packed 16-bit pair
+__device__ __forceinline__ uint32_t klt_byte_pair(uint32_t lo, uint32_t hi, int k) {
+  return __builtin_amdgcn_perm(hi, lo, 0x0c000c00u | (uint32_t)((k + 1) << 16) | (uint32_t)k);
+}
+// bytes j, j+1 of a little-endian dword array
+template <int NW>
+__device__ __forceinline__ uint32_t klt_pair_at(const uint32_t (&w)[NW], int j) {
+  const int d = j >> 2;
+  return klt_byte_pair(w[d], w[d + 1 < NW ? d + 1 : d], j & 3);
+}
+
 // byte k of a little-endian dword array starting at byte offset `sh` (0..3) of w[0]
 template <int ND>
 __device__ __forceinline__ void align_row(const uint32_t (&w)[ND], int sh, uint32_t (&out)[ND - 1]) {
@@ -276,10 +298,24 @@ __device__ __forceinline__ KltResult klt_point(const vo_level *I, const vo_level
       __syncthreads();
     }
 
-    // bilinear difference of the current window against the template, per lane
-    auto eval_diffs = [&](int inx, int iny, int w00, int w01, int w10, int w11, int (&diff)[RL]) {
-      if (!tile_ok || inx < tjx || inx + C::SPAN + 1 > tjx + C::TJ_WD * 4 - 3 || iny < tjy ||
-          iny + WIN + 1 > tjy + C::TJ_H) {
+    // packed template (pairs of neighbouring samples; a missing odd partner is zero)
+    constexpr int NP = (RL + 1) / 2;
+    uint32_t tIp[NP], tXp[NP], tYp[NP];
+#pragma unroll
+    for (int m = 0; m < NP; ++m) {
+      const bool two = 2 * m + 1 < RL;
+      tIp[m] = klt_pack16(tI[2 * m], two ? tI[2 * m + 1] : 0);
+      tXp[m] = klt_pack16(tX[2 * m], two ? tX[2 * m + 1] : 0);
+      tYp[m] = klt_pack16(tY[2 * m], two ? tY[2 * m + 1] : 0);
+    }
+    if (!tile_ok) tjx = 0x40000000;  // (no tile yet: the first window test below reloads)
+
+    // bilinear difference of the current window against the template, per lane: dp[m] = packed pair of
+    // (J sample - template sample) for samples 2m, 2m+1 (each within +-8160)
+    auto eval_diffs = [&](int inx, int iny, int w00, int w01, int w10, int w11, uint32_t (&dp)[NP]) {
+      // window inside the staged tile <=> 0 <= inx - tjx <= slack_x and 0 <= iny - tjy <= slack_y
+      if ((unsigned)inx - (unsigned)tjx > (unsigned)(C::TJ_WD * 4 - 3 - C::SPAN - 1) ||
+          (unsigned)iny - (unsigned)tjy > (unsigned)(C::TJ_H - WIN - 1)) {
         tjx = (inx - C::M) & ~3;
         tjy = iny - C::M;
         const uint8_t *g = LJ.origin() + (ptrdiff_t)tjy * LJ.stride + tjx;
@@ -289,28 +325,35 @@ __device__ __forceinline__ KltResult klt_point(const vo_level *I, const vo_level
           s_tj[i] = *(const uint32_t *)(g + (ptrdiff_t)r * LJ.stride + cdw * 4);
         }
         __syncthreads();
-        tile_ok = true;
       }
       const int boff = (inx - tjx) + x0;
       const int dwo = boff >> 2, sh = boff & 3;
       const int trow = (iny - tjy) + (lane_on ? row : 0);
+      // (byte offset of the tile row; as v_mad_i32_i24 — the compiler's v_mul_lo_u32 is quarter rate)
+      const char *rowp = (const char *)s_tj + klt_mad24(trow, C::TJ_WD * 4, 0);
       uint32_t r0[C::ND_J - 1], r1[C::ND_J - 1];
       {
         uint32_t w0[C::ND_J], w1[C::ND_J];
 #pragma unroll
         for (int d = 0; d < C::ND_J; ++d) {
           const int cd = dwo + d < C::TJ_WD ? dwo + d : C::TJ_WD - 1;
-          w0[d] = s_tj[trow * C::TJ_WD + cd];
-          w1[d] = s_tj[(trow + 1) * C::TJ_WD + cd];
+          w0[d] = *(const uint32_t *)(rowp + cd * 4);
+          w1[d] = *(const uint32_t *)(rowp + (C::TJ_WD + cd) * 4);
         }
         align_row<C::ND_J>(w0, sh, r0);
         align_row<C::ND_J>(w1, sh, r1);
       }
+      const uint32_t w0p = klt_pack16(w00, w01), w1p = klt_pack16(w10, w11);
+      int v[2 * NP];
 #pragma unroll
-      for (int j = 0; j < RL; ++j) {
-        const int v = klt_descale_dot4(byte_at(r0, j), byte_at(r0, j + 1), byte_at(r1, j), byte_at(r1, j + 1), w00, w01, w10,
-                                       w11, KLT_W_BITS - 5);
-        diff[j] = v - tI[j];
+      for (int j = 0; j < RL; ++j)
+        v[j] = klt_dot2(klt_pair_at(r1, j), w1p, klt_dot2(klt_pair_at(r0, j), w0p, 1 << (KLT_W_BITS - 5 - 1))) >>
+               (KLT_W_BITS - 5);
+      if (RL & 1) v[2 * NP - 1] = 0;
+#pragma unroll
+      for (int m = 0; m < NP; ++m) {
+        const klt_s2 d = __builtin_bit_cast(klt_s2, klt_pack16(v[2 * m], v[2 * m + 1])) - __builtin_bit_cast(klt_s2, tIp[m]);
+        dp[m] = __builtin_bit_cast(uint32_t, d);
       }
     };
 
@@ -320,7 +363,8 @@ __device__ __forceinline__ KltResult klt_point(const vo_level *I, const vo_level
 #endif
       const int inx = __builtin_amdgcn_readfirstlane((int)floorf(nextx));
       const int iny = __builtin_amdgcn_readfirstlane((int)floorf(nexty));
-      if (inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h) {
+      // inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h
+      if ((unsigned)inx + (unsigned)WIN >= (unsigned)(LJ.w + WIN) || (unsigned)iny + (unsigned)WIN >= (unsigned)(LJ.h + WIN)) {
         if (level == 0) status = 0;
         break;
       }
@@ -330,13 +374,13 @@ __device__ __forceinline__ KltResult klt_point(const vo_level *I, const vo_level
       iw01 = (int)rintf(fa * (1.f - fb) * (1 << KLT_W_BITS));
       iw10 = (int)rintf((1.f - fa) * fb * (1 << KLT_W_BITS));
       iw11 = (1 << KLT_W_BITS) - iw00 - iw01 - iw10;
-      int diff[RL];
-      eval_diffs(inx, iny, iw00, iw01, iw10, iw11, diff);
+      uint32_t dp[NP];
+      eval_diffs(inx, iny, iw00, iw01, iw10, iw11, dp);
       int pb1 = 0, pb2 = 0;
 #pragma unroll
-      for (int k = 0; k < RL; ++k) {
-        pb1 += diff[k] * tX[k];
-        pb2 += diff[k] * tY[k];
+      for (int m = 0; m < NP; ++m) {
+        pb1 = klt_dot2(dp[m], tXp[m], pb1);
+        pb2 = klt_dot2(dp[m], tYp[m], pb2);
       }
       float sb1, sb2;
       wave_sum2_i32_to_f32(pb1, pb2, sb1, sb2);
@@ -372,11 +416,14 @@ __device__ __forceinline__ KltResult klt_point(const vo_level *I, const vo_level
         iw01 = (int)rintf(aa * (1.f - bb) * (1 << KLT_W_BITS));
         iw10 = (int)rintf((1.f - aa) * bb * (1 << KLT_W_BITS));
         iw11 = (1 << KLT_W_BITS) - iw00 - iw01 - iw10;
-        int diff[RL];
-        eval_diffs(inx, iny, iw00, iw01, iw10, iw11, diff);
+        uint32_t dp[NP];
+        eval_diffs(inx, iny, iw00, iw01, iw10, iw11, dp);
         int pe = 0;
 #pragma unroll
-        for (int k = 0; k < RL; ++k) pe += (k < nx) ? abs(diff[k]) : 0;
+        for (int k = 0; k < RL; ++k) {
+          const int dk = (k & 1) ? ((int)dp[k >> 1] >> 16) : (int)(short)(dp[k >> 1] & 0xFFFFu);
+          pe += (k < nx) ? abs(dk) : 0;
+        }
         const float errval = (float)wave_sum_i32(pe);  // < 2^24: exact
         errv = errval * 1.f / (float)(32 * WIN * WIN);
       }

@@ -271,6 +271,26 @@ __device__ __forceinline__ void wave_sum4_i32(int &a, int &b, int &c, int &d) {
 }
 // two exact (float)(int64 sum) at once: 16/16 split of both partials, one interleaved 4-way butterfly
 __device__ __forceinline__ void wave_sum2_i32_to_f32(int p, int q, float &fp, float &fq) {
+  // When every lane's partials are below 2^25 in magnitude (the usual case) the 64-lane sums fit int32: two chains
+  // instead of four, and (float)(int32) rounds once exactly like (float)(int64).
+  if (!__any((((unsigned)p + (1u << 25)) | ((unsigned)q + (1u << 25))) >> 26)) {
+#define VO_STEP2I(EXPR_P, EXPR_Q) \
+  {                               \
+    const int tp = EXPR_P, tq = EXPR_Q; \
+    p += tp;                      \
+    q += tq;                      \
+  }
+    VO_STEP2I(dpp_i32<0xB1>(p), dpp_i32<0xB1>(q))
+    VO_STEP2I(dpp_i32<0x4E>(p), dpp_i32<0x4E>(q))
+    VO_STEP2I(dpp_i32<0x141>(p), dpp_i32<0x141>(q))
+    VO_STEP2I(dpp_i32<0x140>(p), dpp_i32<0x140>(q))
+    VO_STEP2I(__builtin_amdgcn_update_dpp(0, p, 0x142, 0xA, 0xF, false), __builtin_amdgcn_update_dpp(0, q, 0x142, 0xA, 0xF, false))
+    VO_STEP2I(__builtin_amdgcn_update_dpp(0, p, 0x143, 0xC, 0xF, false), __builtin_amdgcn_update_dpp(0, q, 0x143, 0xC, 0xF, false))
+#undef VO_STEP2I
+    fp = (float)__builtin_amdgcn_readlane(p, 63);
+    fq = (float)__builtin_amdgcn_readlane(q, 63);
+    return;
+  }
   int plo = p & 0xFFFF, phi = p >> 16, qlo = q & 0xFFFF, qhi = q >> 16;
   wave_sum4_i32(plo, phi, qlo, qhi);
   fp = (float)((double)phi * 65536.0 + (double)plo);
