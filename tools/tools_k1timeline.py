@@ -39,6 +39,14 @@ for k in range(first, first + 6):
     for i in order:
         r = d[i]
         print(f"   straggler {'F' if i < n else 'C'}{i if i < n else i - n:5d}: start {us(r[0]-t0):6.1f} klt0 {us(r[1]-r[0]) if r[1] else -1:6.1f} ic {us(r[2]-r[1]) if r[2] else -1:6.1f} klt1 {us(r[3]-max(r[2], r[1])) if r[3] else -1:6.1f} end {us(end[i]-t0):6.1f} | iters klt0 {r[4]} ic {r[6]} klt1 {r[5]}")
+    if hasattr(sb.ctx.lib, "vo_debug_gn_stamps"):
+        st = (C.c_longlong * 8)()
+        try:
+            sb.ctx.lib.vo_debug_gn_stamps(sb.ctx.handle, st)
+            g = [us((st[i] & 0x7fffffff) - t0) for i in range(5)]
+            print(f"   GN kernel (same clock, us after the frame kernel's first stamp): start {g[0]:.1f} prologue end {g[1]:.1f} loads end {g[2]:.1f} iterations end {g[3]:.1f} epilogue end {g[4]:.1f}")
+        except Exception as e:
+            print("   (no GN stamps)", e)
     f = d[:n][work[:n]]
     full = f[:, 3] > 0
     print(f"   feature phase means: klt0 {us(f[:,1]-f[:,0]).mean():.1f} us ({f[:,4].mean():.1f} it), ic {us(f[f[:,2]>0,2]-f[f[:,2]>0,1]).mean():.1f} us ({f[f[:,2]>0,6].mean():.1f} it), klt1 {us(f[full,3]-f[full,2]).mean():.1f} us ({f[full,5].mean():.1f} it)")

@@ -101,6 +101,17 @@ __device__ __forceinline__ IcTaps ic_make_taps(int lane) {
   return tp;
 }
 
+// Slot k of a lane holds tap lane + 64 k: slots 0..3 always do (256 < IC_NELEM), slot 4 only on lanes 0..7. Written
+// this way the hot loops carry one lane mask instead of five.
+static_assert(IC_NELEM > 4 * IC_T && IC_NELEM <= 5 * IC_T && IC_K == 5, "tap ownership pattern");
+__device__ __forceinline__ bool ic_tap_on(const IcTaps &tp, int k) { return k < 4 ? true : ((tp.on >> 4) & 1u) != 0; }
+// a * b + c on 24-bit operands (LDS offsets): full rate, where the compiler's 64-bit multiply-add is not
+__device__ __forceinline__ int ic_mad24(int a, int b, int c) {
+  int d;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
 __device__ __forceinline__ float ic_bilin(float I1, float I2, float I3, float I4, float ax, float ay, float axay) {
   return ((axay * (((I1 - I2) - I3) + I4) + ax * (-I1 + I2)) + ay * (-I1 + I3)) + I1;
 }
@@ -207,7 +218,7 @@ __device__ __forceinline__ void ic_template(const vo_level &L0, const IcTaps &tp
   if (!STRICT) S.m &= ~0x1Fu;
 #pragma unroll
   for (int k = 0; k < IC_K; ++k) {
-    const bool on = (tp.on >> k) & 1u;
+    const bool on = ic_tap_on(tp, k);
     const float uc = pt0x + tp.px[k], vc = pt0y + tp.py[k];
     const int u0 = (int)uc, v0 = (int)vc;
     const bool valid = on && !(u0 < 1 || u0 >= W - 2 || v0 < 1 || v0 >= H - 2);
@@ -234,13 +245,14 @@ __device__ __forceinline__ void ic_sample_I1(const vo_level &L1, const IcTaps &t
   unsigned vmask = 0, gmask = 0;
 #pragma unroll
   for (int k = 0; k < IC_K; ++k) {
-    const bool on = (tp.on >> k) & 1u;
+    const bool on = ic_tap_on(tp, k);
     const float uc = pux + sx[k], vc = puy + sy[k];
     const bool valid = on && !(uc < 1 || uc >= fw || vc < 1 || vc >= fh);
     const int u0 = (int)uc, v0 = (int)vc;
     const int lx = u0 - tile.x0, ly = v0 - tile.y0;
     const bool inside = valid && (unsigned)lx < (unsigned)(IC_JW * 4 - 1) && (unsigned)ly < (unsigned)(IC_JH - 1);
-    const uint8_t *q = sb + (inside ? ly * (IC_JW * 4) + lx : 0);
+    const int off = ic_mad24(ly, IC_JW * 4, lx);  // (unconditional: inline asm under a select becomes a branch)
+    const uint8_t *q = sb + (inside ? off : 0);
     val[k] = ic_bilin((float)q[0], (float)q[1], (float)q[IC_JW * 4], (float)q[IC_JW * 4 + 1], ax, ay, axay);
     if (valid) vmask |= 1u << k;
     if (valid && !inside) gmask |= 1u << k;
@@ -365,14 +377,17 @@ __device__ __forceinline__ IcResult ic_iterate(const vo_level &I1, const IcTaps 
     last_puy = puy;
     ic_sample_I1<STRICT>(I1, tp, sx, sy, pux, puy, ax, ay, axay, S, touched, tile, sh);
     float v[4] = {0.f, 0.f, 0.f, 0.f};  // b1, b2, sum r^2, count
+    const unsigned both = S.m & (S.m >> 8);
 #pragma unroll
     for (int k = 0; k < IC_K; ++k) {
-      const bool use = ((S.m >> k) & (S.m >> (8 + k))) & 1u;
-      const float r = S.I1[k] - S.I0[k];
-      v[0] = use ? v[0] + S.du[k] * r : v[0];
-      v[1] = use ? v[1] + S.dv[k] * r : v[1];
-      v[2] = use ? v[2] + r * r : v[2];
-      v[3] = use ? v[3] + 1.0f : v[3];
+      // An unused tap adds (+-0) * finite = +-0 to sums that are never -0 (they start at +0 and x + (-x) = +0): the
+      // same bits as skipping the addition, one select instead of four.
+      const bool use = (both >> k) & 1u;
+      const float r = use ? S.I1[k] - S.I0[k] : 0.f;
+      v[0] = v[0] + S.du[k] * r;
+      v[1] = v[1] + S.dv[k] * r;
+      v[2] = v[2] + r * r;
+      v[3] = v[3] + (use ? 1.0f : 0.f);
     }
     ic_wave_sum4(v);
     ++n_iter;
