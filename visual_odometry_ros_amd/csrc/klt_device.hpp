@@ -216,8 +216,12 @@ __device__ __forceinline__ KltResult klt_point(const vo_level *I, const vo_level
       }
       __syncthreads();
     }
-    // ---- per-lane template: I, Ix, Iy at RL samples (Scharr on the fly) ----
-    int tI[RL], tX[RL], tY[RL];
+    // ---- per-lane template: I, Ix, Iy at RL samples (Scharr on the fly), as packed 16-bit pairs ----
+    // Every quantity fits int16 (pixels <= 255, column sums <= 4080, derivatives within +-4080, template <= 8160), and
+    // every sum is exact, so pairs of neighbouring columns go through v_pk_* / v_dot2 two at a time — the same
+    // integers as cv::Scharr + the bilinear taps of calcOpticalFlowPyrLK, half the instructions.
+    constexpr int NP = (RL + 1) / 2;  // pairs of samples
+    uint32_t tIp[NP], tXp[NP], tYp[NP];
     int pA11 = 0, pA12 = 0, pA22 = 0;
     {
       // tile rows row..row+3 <-> image rows ipy+row-1 .. ipy+row+2 ; bytes from column (x0) incl. halo
@@ -228,48 +232,76 @@ __device__ __forceinline__ KltResult klt_point(const vo_level *I, const vo_level
       for (int rr = 0; rr < 4; ++rr) {
         uint32_t w[C::ND_T];
         const int trow = lane_on ? row + rr : rr;
+        const char *rowp = (const char *)s_tt + klt_mad24(trow, C::TT_WD * 4, 0);
 #pragma unroll
         for (int d = 0; d < C::ND_T; ++d) {
           const int cd = dwo + d;
-          w[d] = s_tt[trow * C::TT_WD + (cd < C::TT_WD ? cd : C::TT_WD - 1)];
+          w[d] = *(const uint32_t *)(rowp + (cd < C::TT_WD ? cd : C::TT_WD - 1) * 4);
         }
         align_row<C::ND_T>(w, sh, rb[rr]);
       }
-      // column sums for the two derivative rows r=0,1 (image rows ipy+row+r)
-      int dxv[2][RL + 1], dyv[2][RL + 1];
+      constexpr int PC = (RL + 4) / 2;  // pairs of columns (RL + 3 of them, halo included)
+      constexpr int QD = (RL + 2) / 2;  // pairs of derivative samples (RL + 1 of them)
+      klt_s2 U[4][PC];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+        for (int m = 0; m < PC; ++m) U[rr][m] = __builtin_bit_cast(klt_s2, klt_pair_at(rb[rr], 2 * m));
+      // derivative samples k = 0..RL of this lane sit at image columns ipx + x0 + k: the derivative plane is
+      // zero-padded, so samples outside the image are cleared (bit k of xbits: inside)
+      const int xb = ipx + x0;
+      const int kmin = min(max(-xb, 0), RL + 1), kmax = min(max(LI.w - xb, 0), RL + 1);
+      const unsigned xbits = ((1u << kmax) - 1u) & ~((1u << kmin) - 1u);
+      uint32_t DX[2][QD], DY[2][QD];
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        int t0[RL + 3], t1[RL + 3];
+        klt_s2 t0[PC], t1[PC];
 #pragma unroll
-        for (int k = 0; k < RL + 3; ++k) {
-          const int up = byte_at(rb[r], k), ce = byte_at(rb[r + 1], k), dn = byte_at(rb[r + 2], k);
-          t0[k] = (up + dn) * 3 + ce * 10;
-          t1[k] = dn - up;
+        for (int m = 0; m < PC; ++m) {
+          t0[m] = (U[r][m] + U[r + 2][m]) * (short)3 + U[r + 1][m] * (short)10;
+          t1[m] = U[r + 2][m] - U[r][m];
         }
-        const int yy = ipy + row + r;
-        const bool yin = (yy >= 0) && (yy < LI.h);
+        const bool yin = (unsigned)(ipy + row + r) < (unsigned)LI.h;
+        const int bits = yin ? (int)xbits : 0;
 #pragma unroll
-        for (int k = 0; k < RL + 1; ++k) {
-          const int xx = ipx + x0 + k;
-          const bool in = yin && (xx >= 0) && (xx < LI.w);  // derivative plane is zero-padded
-          dxv[r][k] = in ? (t0[k + 2] - t0[k]) : 0;
-          dyv[r][k] = in ? ((t1[k + 2] + t1[k]) * 3 + t1[k + 1] * 10) : 0;
+        for (int m = 0; m < QD; ++m) {
+          const klt_s2 dx = t0[m + 1] - t0[m];
+          const klt_s2 mid = __builtin_bit_cast(
+              klt_s2, __builtin_amdgcn_alignbit(__builtin_bit_cast(uint32_t, t1[m + 1]), __builtin_bit_cast(uint32_t, t1[m]), 16));
+          const klt_s2 dy = (t1[m + 1] + t1[m]) * (short)3 + mid * (short)10;
+          // 0xFFFF per half whose sample is inside: sign-extended one-bit fields, merged
+          const uint32_t lo = (uint32_t)__builtin_amdgcn_sbfe(bits, 2 * m, 1), hi = (uint32_t)__builtin_amdgcn_sbfe(bits, 2 * m + 1, 1);
+          const uint32_t msk = (lo & 0xFFFFu) | (hi & 0xFFFF0000u);
+          DX[r][m] = __builtin_bit_cast(uint32_t, dx) & msk;
+          DY[r][m] = __builtin_bit_cast(uint32_t, dy) & msk;
         }
       }
+      const uint32_t w0p = klt_pack16(iw00, iw01), w1p = klt_pack16(iw10, iw11);
+      int vI[2 * NP], vX[2 * NP], vY[2 * NP];
 #pragma unroll
       for (int j = 0; j < RL; ++j) {
-        const int i00 = byte_at(rb[1], j + 1), i01 = byte_at(rb[1], j + 2);
-        const int i10 = byte_at(rb[2], j + 1), i11 = byte_at(rb[2], j + 2);
-        const int ival = klt_descale_dot4(i00, i01, i10, i11, iw00, iw01, iw10, iw11, KLT_W_BITS - 5);
-        const int ixval = klt_descale_dot4(dxv[0][j], dxv[0][j + 1], dxv[1][j], dxv[1][j + 1], iw00, iw01, iw10, iw11, KLT_W_BITS);
-        const int iyval = klt_descale_dot4(dyv[0][j], dyv[0][j + 1], dyv[1][j], dyv[1][j + 1], iw00, iw01, iw10, iw11, KLT_W_BITS);
+        // samples j, j+1 of a packed row: the pair itself (j even) or the halves of two neighbouring pairs (j odd)
+        auto pair_of = [&](const uint32_t(&a)[QD]) -> uint32_t {
+          return (j & 1) ? __builtin_amdgcn_alignbit(a[(j + 1) / 2], a[j / 2], 16) : a[j / 2];
+        };
+        const uint32_t i0 = ((j + 1) & 1) ? klt_pair_at(rb[1], j + 1) : __builtin_bit_cast(uint32_t, U[1][(j + 1) / 2]);
+        const uint32_t i1 = ((j + 1) & 1) ? klt_pair_at(rb[2], j + 1) : __builtin_bit_cast(uint32_t, U[2][(j + 1) / 2]);
+        vI[j] = klt_dot2(i1, w1p, klt_dot2(i0, w0p, 1 << (KLT_W_BITS - 5 - 1))) >> (KLT_W_BITS - 5);
+        const int ixval = klt_dot2(pair_of(DX[1]), w1p, klt_dot2(pair_of(DX[0]), w0p, 1 << (KLT_W_BITS - 1))) >> KLT_W_BITS;
+        const int iyval = klt_dot2(pair_of(DY[1]), w1p, klt_dot2(pair_of(DY[0]), w0p, 1 << (KLT_W_BITS - 1))) >> KLT_W_BITS;
         const bool on = j < nx;
-        tI[j] = (int)(short)ival;
-        tX[j] = on ? (int)(short)ixval : 0;
-        tY[j] = on ? (int)(short)iyval : 0;
-        pA11 += tX[j] * tX[j];
-        pA12 += tX[j] * tY[j];
-        pA22 += tY[j] * tY[j];
+        vX[j] = on ? ixval : 0;  // (all three fit int16: the reference's (short) casts change nothing)
+        vY[j] = on ? iyval : 0;
+      }
+      if (RL & 1) vI[2 * NP - 1] = vX[2 * NP - 1] = vY[2 * NP - 1] = 0;
+#pragma unroll
+      for (int m = 0; m < NP; ++m) {
+        tIp[m] = klt_pack16(vI[2 * m], vI[2 * m + 1]);
+        tXp[m] = klt_pack16(vX[2 * m], vX[2 * m + 1]);
+        tYp[m] = klt_pack16(vY[2 * m], vY[2 * m + 1]);
+        pA11 = klt_dot2(tXp[m], tXp[m], pA11);
+        pA12 = klt_dot2(tXp[m], tYp[m], pA12);
+        pA22 = klt_dot2(tYp[m], tYp[m], pA22);
       }
     }
     if (level > 0) fetch_template_tile(level - 1);  // in flight during this level's iterations
@@ -298,16 +330,6 @@ __device__ __forceinline__ KltResult klt_point(const vo_level *I, const vo_level
       __syncthreads();
     }
 
-    // packed template (pairs of neighbouring samples; a missing odd partner is zero)
-    constexpr int NP = (RL + 1) / 2;
-    uint32_t tIp[NP], tXp[NP], tYp[NP];
-#pragma unroll
-    for (int m = 0; m < NP; ++m) {
-      const bool two = 2 * m + 1 < RL;
-      tIp[m] = klt_pack16(tI[2 * m], two ? tI[2 * m + 1] : 0);
-      tXp[m] = klt_pack16(tX[2 * m], two ? tX[2 * m + 1] : 0);
-      tYp[m] = klt_pack16(tY[2 * m], two ? tY[2 * m + 1] : 0);
-    }
     if (!tile_ok) tjx = 0x40000000;  // (no tile yet: the first window test below reloads)
 
     // bilinear difference of the current window against the template, per lane: dp[m] = packed pair of
