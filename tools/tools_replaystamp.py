@@ -21,15 +21,15 @@ for k in range(1, 7):
         ctx.lib.vo_debug_ic_jac(ctx.handle, dbg.ctypes.data_as(C.POINTER(C.c_int)))  # (the second, warm frame is kept)
     d = dbg[16:]
     t0 = int(d[31])
-    print(f"frame {k}: replayed {g['counts'].n_replayed:4d}  runs {d[32]:4d} publishes {d[33]:4d}  quiescent at {(int(d[0]) - t0) / 100:6.1f} us, tails done at {(int(d[2]) - t0) / 100:6.1f} us")
+    print(f"frame {k}: replayed {g['counts'].n_replayed:4d}  runs {d[32]:4d} publishes {d[33]:4d} predicted looks {d[34]:4d}  quiescent at {(int(d[0]) - t0) / 100:6.1f} us, tails done at {(int(d[2]) - t0) / 100:6.1f} us")
     rows = dbg[80:].reshape(256, 8); rows = rows[rows[:, 1] > 0]
     if not len(rows):
         continue
     us = lambda c: (rows[:, c] - t0) / 100.0
-    att, fw, rs_, re_, pub, it, natt, pt = us(4), us(5), us(0), us(1), us(6), rows[:, 2], rows[:, 7], rows[:, 3]
+    att, fw, rs_, re_, pub, it, natt, pt = us(4), us(5), us(0), us(1), us(6), rows[:, 2], us(7), rows[:, 3]
     o = np.argsort(re_)
-    print("   last finishers: pt | final look starts, writers found, run starts, run ends, published | iterations, looks")
-    for i in o[-16:]:
-        print(f"     {pt[i]:5d} | {att[i]:7.1f} {fw[i]:7.1f} {rs_[i]:7.1f} {re_[i]:7.1f} {pub[i]:7.1f} | {it[i]:3d} {natt[i]:3d}")
+    print("   last finishers: pt | final look starts, writers found, run starts, run ends, published | iterations, loads landed")
+    for i in (o if "--all" in sys.argv else o[-16:]):
+        print(f"     {pt[i]:5d} | {att[i]:7.1f} {fw[i]:7.1f} {rs_[i]:7.1f} {re_[i]:7.1f} {pub[i]:7.1f} | {it[i]:3d} {natt[i]:7.1f}")
     print(f"   means: look->writers {np.mean(fw - att):.1f} us, writers->run start {np.mean(rs_ - fw):.1f} us, run {np.mean(re_ - rs_):.1f} us "
-          f"({it.mean():.1f} iterations), run end->published {np.mean(pub - re_):.1f} us; looks per feature {natt.mean():.1f}")
+          f"({it.mean():.1f} iterations), run end->published {np.mean(pub - re_):.1f} us; look start->loads landed {np.mean(natt - att):.1f} us")

@@ -31,6 +31,9 @@
 #ifndef IC_MAX_ITER
 #define IC_MAX_ITER 30  // feature_tracker.cpp:290
 #endif
+#ifndef IC_WAIT_SLEEP
+#define IC_WAIT_SLEEP 16  // s_sleep argument between two polls of a waiting feature's writers (~0.5 us)
+#endif
 
 struct IcArgs {
   vo_level I0, I1;
@@ -478,18 +481,20 @@ __device__ __forceinline__ void ic_store(T *p, T v) {
 // `bits`: bit k of the lane = predicate of tap lane + 64 k.
 template <bool COH = false>
 __device__ __forceinline__ void ic_store_mask(uint32_t *dst, unsigned bits, int lane) {
+  // lane w < 9 stores word w: ONE store instruction for the nine words (nine single-lane write-through stores are
+  // nine fabric writes in a row on the publishing path of every replayed feature)
+  uint32_t wv = 0;
 #pragma unroll
   for (int k = 0; k < IC_K; ++k) {
     const unsigned long long m = __ballot((bits >> k) & 1u);
-    if (lane == 0) {
-      if (k < 4) {
-        ic_store<COH>(&dst[2 * k], (uint32_t)m);
-        ic_store<COH>(&dst[2 * k + 1], (uint32_t)(m >> 32));
-      } else {
-        ic_store<COH>(&dst[8], (uint32_t)m);  // taps 256..263 (lanes 8.. own no tap there)
-      }
+    if (k < 4) {
+      wv = lane == 2 * k ? (uint32_t)m : wv;
+      wv = lane == 2 * k + 1 ? (uint32_t)(m >> 32) : wv;
+    } else {
+      wv = lane == 8 ? (uint32_t)m : wv;  // taps 256..263 (lanes 8.. own no tap there)
     }
   }
+  if (lane < IC_MW) ic_store<COH>(&dst[lane], wv);
 }
 // bit of tap lane + 64 k in a 9-word mask
 __device__ __forceinline__ bool ic_bit_k(const uint32_t *w, int lane, int k) {
@@ -554,29 +559,28 @@ struct IcReplayShared {
   uint8_t cls[IC_MAXRUN];
   int src[IC_NELEM];              // nearest earlier writer per wanted tap (-1: none)
   int pub[IC_MAXRUN];             // publication counts of the predecessors at the last look
+  uint32_t fw[64 * 6];            // ic_find_writers: per (group, word) lane the met taps and five step-number planes
 };
 
 // For every tap flagged in `want` (bit k of a lane = tap lane + 64 k): the nearest predecessor
 // r in [0, L) (largest r) with rs.cls[r] >= need whose mask rs.w[r] has the tap's bit; result lo + r
 // (or -1) in rs.src[tap].
-// ONE walk over the predecessors, nearest first, for all wanted taps together: lane w < 9 owns word w of the 9-word
-// tap masks, keeps the still unresolved wanted taps of that word in a register and ANDs it with each predecessor's
-// word (four predecessors per step, so that their LDS reads are in flight together). A tap-by-tap search — a ballot
-// loop over the predecessors per tap — cost ~5 us for the ~70 observable taps of a bottom-row feature, once per look
-// and therefore several times per link of every dependency chain; this walk costs ~1 us.
+// ONE walk over the predecessors, nearest first, for all wanted taps together. Seven groups of nine lanes share the
+// predecessors: group g walks the g-th seventh of them (nearest first), lane w of a group owns word w of the 9-word
+// masks (words 2k / 2k+1 = taps 64k.. / 64k+32.., word 8 = taps 256..263) and the wanted taps of that word it has not
+// met yet. A tap is met at most once per group, so WHERE it was met is kept bit-sliced: five 32-bit planes hold the
+// step number of every bit of the word (plane p collects the hits of the steps whose number has bit p set) — a few
+// ORs per step, no loop over the hit bits. (Earlier forms: a ballot loop over the predecessors per tap, ~5 us for the
+// ~70 observable taps of a bottom-row feature; a per-bit LDS max inside the walk, whose divergent loops ran once per
+// hit bit and group — 3.5-6 us for the same feature, on every link of the deepest dependency chains.) Each lane then
+// reads its own taps' answer: the first group, nearest first, that met the tap, and the step from that group's planes.
+#define IC_FW_GROUPS 7
 __device__ __forceinline__ void ic_find_writers(IcReplayShared &rs, unsigned want, int need, int lo, int L, int lane) {
   unsigned long long b[IC_K];
 #pragma unroll
-  for (int k = 0; k < IC_K; ++k) {
-    b[k] = __ballot((want >> k) & 1u);
-    if ((want >> k) & 1u) rs.src[lane + 64 * k] = -1;
-  }
-  // Seven groups of nine lanes share the predecessors: group g walks the g-th seventh of them (nearest first), lane w
-  // of a group owns word w of the 9-word masks (words 2k / 2k+1 = taps 64k.. / 64k+32.., word 8 = taps 256..263) and
-  // the wanted taps of that word it has not met yet; a hit is merged with an LDS max (the nearest writer is the largest
-  // index). A seventh of a run is a few steps of four predecessors each, their LDS reads in flight together.
+  for (int k = 0; k < IC_K; ++k) b[k] = __ballot((want >> k) & 1u);
   const int g = lane / IC_MW, w = lane - g * IC_MW;
-  const bool act = g < 7;
+  const bool act = g < IC_FW_GROUPS;
   unsigned ww = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -585,13 +589,13 @@ __device__ __forceinline__ void ic_find_writers(IcReplayShared &rs, unsigned wan
   }
   ww = w == 8 ? (unsigned)b[4] : ww;
   ww = act ? ww : 0u;
-  const int tap0 = w < 8 ? 64 * (w >> 1) + 32 * (w & 1) : 256;  // tap of bit 0 of this lane's word
-  const int chunk = (L + 6) / 7;
-  const int hi = L - 1 - g * chunk;           // nearest predecessor of this group
+  const int chunk = (L + IC_FW_GROUPS - 1) / IC_FW_GROUPS;  // <= 28 steps for L <= IC_MAXRUN: five planes
+  static_assert((IC_MAXRUN + IC_FW_GROUPS - 1) / IC_FW_GROUPS <= 32, "step number needs five bits");
+  const int hi = L - 1 - g * chunk;  // nearest predecessor of this group
   const int lo_r = hi - chunk + 1 > 0 ? hi - chunk + 1 : 0;
-  __syncthreads();  // (one wavefront per workgroup: orders the -1 stores above before the maxima below)
+  unsigned F = 0, P0 = 0, P1 = 0, P2 = 0, P3 = 0, P4 = 0;
   for (int c0 = 0; c0 < chunk; c0 += 4) {
-    unsigned m[4];
+    unsigned m[4], h[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = hi - c0 - i;
@@ -600,15 +604,46 @@ __device__ __forceinline__ void ic_find_writers(IcReplayShared &rs, unsigned wan
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      unsigned hit = ww & m[i];
+      h[i] = ww & m[i];
       ww &= ~m[i];
-      while (hit) {
-        const int bit = __ffs((int)hit) - 1;
-        hit &= hit - 1;
-        atomicMax(&rs.src[tap0 + bit], lo + (hi - c0 - i));
-      }
     }
+    const unsigned hall = (h[0] | h[1]) | (h[2] | h[3]);
+    F |= hall;
+    P0 |= h[1] | h[3];
+    P1 |= h[2] | h[3];
+    if (c0 & 4) P2 |= hall;
+    if (c0 & 8) P3 |= hall;
+    if (c0 & 16) P4 |= hall;
   }
+  if (act) {
+    uint32_t *o = rs.fw + lane * 6;
+    o[0] = F;
+    o[1] = P0;
+    o[2] = P1;
+    o[3] = P2;
+    o[4] = P3;
+    o[5] = P4;
+  }
+  __syncthreads();  // (one wavefront per workgroup: orders the stores above before the reads below)
+#pragma unroll
+  for (int k = 0; k < IC_K; ++k)
+    if ((want >> k) & 1u) {
+      const int wj = k < 4 ? 2 * k + (lane >> 5) : 8, bj = lane & 31;
+      unsigned f[IC_FW_GROUPS];
+#pragma unroll
+      for (int g2 = 0; g2 < IC_FW_GROUPS; ++g2) f[g2] = rs.fw[(g2 * IC_MW + wj) * 6];
+      int gs = -1;
+#pragma unroll
+      for (int g2 = IC_FW_GROUPS - 1; g2 >= 0; --g2) gs = ((f[g2] >> bj) & 1u) ? g2 : gs;  // nearest group last: it wins
+      int src = -1;
+      if (gs >= 0) {
+        const uint32_t *o = rs.fw + (gs * IC_MW + wj) * 6;
+        const int step = (int)((o[1] >> bj) & 1u) | (int)((o[2] >> bj) & 1u) << 1 | (int)((o[3] >> bj) & 1u) << 2 |
+                         (int)((o[4] >> bj) & 1u) << 3 | (int)((o[5] >> bj) & 1u) << 4;
+        src = lo + (L - 1 - gs * chunk) - step;
+      }
+      rs.src[lane + 64 * k] = src;
+    }
 }
 
 // Body of the replay kernel. Returns the number of workgroups P that own list entries (this
@@ -739,21 +774,28 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
       }
       // words of the 9-word tap masks that hold observable taps (usually 2 or 3): only those are staged
       unsigned wordmask = 0;
+      uint32_t seenw[IC_MW];  // the observable taps as mask words (wave-uniform)
 #pragma unroll
       for (int k = 0; k < IC_K; ++k) {
         const unsigned long long b = __ballot((seen >> k) & 1u);
         if (k < 4) {
+          seenw[2 * k] = (uint32_t)b;
+          seenw[2 * k + 1] = (uint32_t)(b >> 32);
           if ((uint32_t)b) wordmask |= 1u << (2 * k);
           if ((uint32_t)(b >> 32)) wordmask |= 1u << (2 * k + 1);
-        } else if (b) {
-          wordmask |= 1u << 8;
+        } else {
+          seenw[8] = (uint32_t)b;
+          if (b) wordmask |= 1u << 8;
         }
       }
       IcState S = S0;
       bool give_up = false, unchanged = false;
 #ifdef IC_STAMP
-      int dbg_t_att = 0, dbg_t_fw = 0, dbg_n_att = 0;
+      int dbg_t_att = 0, dbg_t_fw = 0, dbg_n_att = 0, dbg_t_ld = 0;
 #endif
+      float pv[IC_K] = {0.f, 0.f, 0.f, 0.f, 0.f};  // values of the predicted writers (see below)
+      int psrc[IC_K] = {-1, -1, -1, -1, -1};        // and who they are
+      bool same_writers = false;
       for (int attempt = 0;; ++attempt) {
 #ifdef IC_STAMP
         dbg_t_att = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff);
@@ -789,6 +831,13 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
             if (i < L) rs.pub[i] = pc[q];
           }
         }
+        // A look that follows the wait for this feature's writers (attempt > 0) expects to find what the previous look
+        // found, plus their new values: the values of the writers found THEN are loaded together with the masks, and
+        // when no mask (and no class) of a predecessor has changed, the writers are the same, they are all ready (the
+        // wait just saw that) and those values are the pre-state — three round trips less between a writer's
+        // publication and the start of this feature's run, on every link of every chain.
+        const bool predicted = attempt > 0;
+        same_writers = false;
         {
           // every load of the look in flight together: one exposure of the memory latency (a loop that loads and
           // stores word by word pays it once per word and 64 predecessors — six round trips for a bottom-row feature)
@@ -806,19 +855,59 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
                              : 0u;
           }
 #pragma unroll
+          for (int k = 0; k < IC_K; ++k) {
+            pv[k] = 0.f;
+            psrc[k] = -1;
+            if (predicted && ((seen >> k) & 1u)) {
+              const int j = lane + 64 * k;
+              const int src = rs.src[j];
+              psrc[k] = src;
+              if (src >= 0) pv[k] = __hip_atomic_load(&a.recV1[(size_t)src * IC_NELEM + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+#ifdef IC_STAMP
+          __builtin_amdgcn_s_waitcnt(0);
+          dbg_t_ld = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff);
+#endif
+          bool chg = !predicted;
+#pragma unroll
           for (int q = 0; q < (IC_MAXRUN + 63) / 64; ++q) {
             const int i = lane + 64 * q;
             if (i < L) {
+              if (predicted && rs.cls[i] != (uint8_t)cl[q]) chg = true;
               rs.cls[i] = (uint8_t)cl[q];
 #pragma unroll
               for (int w = 0; w < IC_MW; ++w)
-                if ((wordmask >> w) & 1u) rs.w[i * IC_MW + w] = mw[q][w];
+                if ((wordmask >> w) & 1u) {
+                  // (only the observable taps' bits decide who this feature's writers are)
+                  if (predicted && ((rs.w[i * IC_MW + w] ^ mw[q][w]) & seenw[w])) chg = true;
+                  rs.w[i * IC_MW + w] = mw[q][w];
+                }
             }
           }
+          same_writers = !__any(chg);
         }
+#ifdef IC_STAMP
+        if (same_writers) {
+          dbg_t_fw = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff);
+          if (lane == 0) atomicAdd(&a.tlist[IC_DBG_OFF + 34], 1);
+        }
+#endif
+        if (same_writers) break;  // rs.src, and pv, stand
         __syncthreads();
         ic_find_writers(rs, seen, 2, lo, L, lane);
         __syncthreads();
+        if (predicted) {
+          // masks changed, writers did not: the same shortcut
+          bool other = false;
+#pragma unroll
+          for (int k = 0; k < IC_K; ++k)
+            if (((seen >> k) & 1u) && rs.src[lane + 64 * k] != psrc[k]) other = true;
+          if (!__any(other)) {
+            same_writers = true;
+            break;
+          }
+        }
 #ifdef IC_STAMP
         dbg_t_fw = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff);
 #endif
@@ -855,7 +944,7 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
             give_up = true;
             break;
           }
-          __builtin_amdgcn_s_sleep(16);  // ~0.5 us: a hundred waiting wavefronts must not flood the fabric
+          __builtin_amdgcn_s_sleep(IC_WAIT_SLEEP);  // a hundred waiting wavefronts must not flood the fabric
         }
         if (give_up) break;
       }
@@ -866,7 +955,8 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
           const int j = lane + 64 * k;
           const int src = rs.src[j];
           if (src >= 0) {
-            S.I1[k] = __hip_atomic_load(&a.recV1[(size_t)src * IC_NELEM + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            S.I1[k] = same_writers ? pv[k]
+                                   : __hip_atomic_load(&a.recV1[(size_t)src * IC_NELEM + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             S.m |= 0x100u << k;
           }
         }
@@ -917,7 +1007,8 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
       if (lane == 0 && li < 256) {
         a.tlist[IC_DBG_OFF + 64 + 8 * li + 4] = dbg_t_att;
         a.tlist[IC_DBG_OFF + 64 + 8 * li + 5] = dbg_t_fw;
-        a.tlist[IC_DBG_OFF + 64 + 8 * li + 7] = dbg_n_att;
+        a.tlist[IC_DBG_OFF + 64 + 8 * li + 7] = dbg_t_ld;
+        (void)dbg_n_att;
         a.tlist[IC_DBG_OFF + 64 + 8 * li + 1] = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff);
         a.tlist[IC_DBG_OFF + 64 + 8 * li + 2] = n_iter;
         a.tlist[IC_DBG_OFF + 64 + 8 * li + 3] = pt;
