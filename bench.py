@@ -324,7 +324,10 @@ def main():
     ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="BASELINE.json configs[i]")
     ap.add_argument("--frames", type=int, default=12, help="distinct rendered frames (played back and forth)")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames timed on the CPU oracle (rank 0, N=1)")
-    ap.add_argument("--strict-border", type=int, default=1)
+    ap.add_argument("--strict-border", type=int, default=4,
+                    help="0 masked border taps; 1-4 the reference's never-reset tap state (identical results): 1 replay "
+                         "stream-ordered behind the frame kernel, 2 sequential replay, 3 replay next to the frame kernel, "
+                         "4 (default) 1 or 3 per frame, by the previous frame's number of replayed features")
     ap.add_argument("--mode", default="closed", choices=("closed", "sequential", "open"),
                     help="how step [10] (new-point candidates) is driven in the HEADLINE loop; see the docstring")
     ap.add_argument("--host-images", action="store_true",

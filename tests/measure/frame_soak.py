@@ -14,6 +14,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=12)
     ap.add_argument("--frames", type=int, default=12)
+    ap.add_argument("--strict", type=int, default=1, help="strict-border mode of the pipeline: 1, 3 (concurrent replay), 4 (automatic)")
     a = ap.parse_args()
     import visual_odometry_ros_amd as V
     from oracle import oracle as O
@@ -29,7 +30,7 @@ def main():
             K = S.KITTI_K if w == 1241 else (458.654, 457.296, 367.215, 248.375)
             stream = S.StereoStream(width=w, height=h, K=K, n_u=nu, n_v=nv, n_new=100, seed=seed, margin=4.0,
                                     speed=0.8 if w == 1241 else 0.3)
-            T._run_stream(ctx, O, stream, a.frames, True, win=win, max_level=6 if w == 1241 else 5, sanity=False)
+            T._run_stream(ctx, O, stream, a.frames, a.strict, win=win, max_level=6 if w == 1241 else 5, sanity=False)
             n += a.frames - 1
     print(f"{n} strict-border frames identical to the oracle at every gate ({time.time() - t0:.0f} s)")
 

@@ -90,6 +90,13 @@ def test_stereo_frame_kitti_shape(ctx, oracle, strict):
     _run_stream(ctx, oracle, stream, 3, strict)
 
 
+def test_stereo_frame_automatic_replay_mode(ctx, oracle):
+    """strict 4: the replay runs stream-ordered or next to the frame kernel depending on how many features the PREVIOUS
+    frame replayed (the first frame knows none, the later ones of this border-hugging stream do): same results."""
+    stream = S.StereoStream(seed=6, margin=4.0)
+    _run_stream(ctx, oracle, stream, 6, 4)
+
+
 @pytest.mark.parametrize("untri,strict", [(0.0, True), (0.3, True), (0.3, False), (1.0, True)])
 def test_stereo_frame_untriangulated_landmarks(ctx, oracle, untri, strict):
     """A real track set mixes triangulated and untriangulated landmarks (new stereo landmarks get their 3-D point
@@ -149,7 +156,7 @@ def test_stereo_frame_small_many_frames(ctx, oracle):
 
 
 @pytest.mark.parametrize("win,strict", [(31, True), (17, True), (17, False), (15, True), (13, True), (13, False), (21, 2), (21, 3),
-                                        (15, 3)])
+                                        (15, 3), (13, 4)])
 def test_stereo_frame_other_windows(ctx, oracle, win, strict):
     """win 13 / 15 / 31: the other instantiations of the fused frame kernel; win 17: the general
     one-launch-per-step path (windows the fused kernel is not instantiated for); strict 2: the

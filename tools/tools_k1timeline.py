@@ -17,6 +17,10 @@ first = sb.prime("closed")
 n = sb.n_pts
 nb = sb.bins.n_bins_u * sb.bins.n_bins_v
 us = lambda a: a / 100.0
+skip = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+if skip:
+    sb.run(first, skip, "closed")
+    first += skip
 for k in range(first, first + 6):
     sb.run(k, 1, "closed")
     d = np.zeros((n + nb, 8), np.int32)

@@ -102,6 +102,9 @@ __device__ __forceinline__ void frame_tail(const FrameArgs &a, int i, int ok, fl
 // Both roles are "KLT, something in between, KLT", so the kernel is a two-pass loop around ONE
 // inlined copy of klt_point (its code is ~3000 instructions; one copy per call site would not fit
 // the instruction cache).
+#ifndef IC_REPLAY_VGPRS
+#define IC_REPLAY_VGPRS 288
+#endif
 #ifndef FRAME_WAVES_PER_EU
 #define FRAME_WAVES_PER_EU 2
 #endif
@@ -282,7 +285,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRAME_WAVES_
         ic_store<true>(&a.ic.pts_track[2 * i], rf.x);
         ic_store<true>(&a.ic.pts_track[2 * i + 1], rf.y);
         ic_store<true>(&a.ic.mask[i], (uint8_t)rf.ok);
-        if (any_t) ic_store<true>(&a.ic.tlist[atomicAdd(&a.ic.jac[IC_JAC_NT], 1)], i);
+        if (any_t) {
+          const int slot = atomicAdd(&a.ic.jac[IC_JAC_NT], 1);
+          ic_store<true>(&a.ic.tlist[slot], i);
+          if (a.ic.tl2)  // concurrent replay: the entry says which frame it belongs to
+            __hip_atomic_store(&a.ic.tl2[slot], ((unsigned long long)(unsigned)a.ic.epoch << 32) | (unsigned)i, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     }
     if (!deferred && (!valid1 || !rf.ok)) {
@@ -294,11 +303,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRAME_WAVES_
         a.stage[i] = valid1 ? 1 : 0;
       }
     }
-    if (a.strict) {
-      // The replay may start as soon as every feature is past this point — the pass-1 stragglers, not the [5]
-      // stragglers, decide when. All the stores above that it depends on are write-through: wait for them, then count.
+    if (a.strict && a.ic.p1e) {
+      // Concurrent replay: it may use this feature's pass-1 data from here on. All the stores above that it depends on
+      // are write-through: wait for them, then stamp and count. (The stream-ordered replay needs neither.)
       __builtin_amdgcn_s_waitcnt(0);
-      if (lane == 0) atomicAdd(&a.sync[0], 1);
+      if (lane == 0) {
+        ic_store<true>(&a.ic.p1e[i], a.ic.epoch);  // this feature's pass-1 data are in memory
+        atomicAdd(&a.ic.p1_word[(i & (IC_P1_SHARDS - 1)) * IC_P1_STRIDE], 1);
+      }
     }
     // (a deferred feature's outputs — pl1, pr1, stage — are written by the replay's tail, never here: two kernels
     // on two XCDs must not both own a byte)
@@ -314,25 +326,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRAME_WAVES_
   (void)rf_ok;
 }
 
-// The replay runs on a stream of its own NEXT TO the frame kernel and may start as soon as every feature's pass-1
-// record and list entry exist — when the pass-1 stragglers are through, not when the last step [5] is. A replay
-// wavefront needs 278 VGPRs (a whole SIMD's second slot): 512 of them polling would take a quarter of the frame
-// kernel's residency, so ONE small wavefront does the waiting and the replay is stream-ordered behind it. The wait is
-// bounded; the frame kernel's wavefronts wait for nothing, so the count always arrives.
-__global__ __launch_bounds__(64) void frame_gate_kernel(int *word, int target, int *ovf) {
-  int polls = 0;
-  while ((int)(__builtin_amdgcn_readfirstlane(ic_ld(word)) - target) < 0) {  // (cumulative counters: wrap-safe)
-    if (++polls > IC_SPIN_LIMIT) {
-      if (threadIdx.x == 0) atomicExch(ovf, 1);  // the sequential fallback (behind both kernels) takes over
-      return;
-    }
-    __builtin_amdgcn_s_sleep(32);  // ~1 us
-  }
-}
-
 // strict border: replay of the touched features, then their step [5]
+// 288 registers at most: 512 per SIMD minus one frame-kernel wavefront (224 with the allocation granule), so that a
+// replay wavefront and a frame-kernel wavefront share a SIMD. With more (294 were used when unconstrained) a resident
+// replay wavefront keeps the whole SIMD to itself — the concurrent pool then costs the frame kernel a quarter of the
+// chip, or, started behind it, finds no room until SIMDs drain completely.
 template <int WIN>
-__global__ __launch_bounds__(64) void frame_replay_kernel(FrameArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(IC_REPLAY_VGPRS))) void frame_replay_kernel(FrameArgs a) {
   __shared__ IcReplayShared rs;
   __shared__ uint32_t s_tt[KltCfg<WIN>::TT_H * KltCfg<WIN>::TT_WD];
   __shared__ uint32_t s_tj[KltCfg<WIN>::TJ_H * KltCfg<WIN>::TJ_WD];
@@ -341,11 +341,20 @@ __global__ __launch_bounds__(64) void frame_replay_kernel(FrameArgs a) {
   // step [5] of a feature follows its (re)computation at once: by then its record is published, so
   // nobody waits for this wavefront, and the feature is final unless an input changes later (rare;
   // the hook then runs again and overwrites the outputs)
-  auto tail = [&](int i, const IcResult &r) {
-    frame_tail<WIN>(a, i, r.ok, r.x, r.y, a.k1[2 * i], a.k1[2 * i + 1], a.pr_prior[2 * i], a.pr_prior[2 * i + 1], s_tt,
-                    s_tj, lane);
-  };
-  (void)ic_replay(a.ic, rs, lane, tail);
+  if (a.ic.tl2) {
+    // next to the frame kernel (frame_launch, strict == 3): what that kernel wrote is read past the caches
+    auto tail = [&](int i, const IcResult &r) {
+      frame_tail<WIN>(a, i, r.ok, r.x, r.y, ic_ldf(&a.k1[2 * i]), ic_ldf(&a.k1[2 * i + 1]), ic_ldf(&a.pr_prior[2 * i]),
+                      ic_ldf(&a.pr_prior[2 * i + 1]), s_tt, s_tj, lane);
+    };
+    (void)ic_replay<true>(a.ic, rs, lane, tail);
+  } else {
+    auto tail = [&](int i, const IcResult &r) {
+      frame_tail<WIN>(a, i, r.ok, r.x, r.y, a.k1[2 * i], a.k1[2 * i + 1], a.pr_prior[2 * i], a.pr_prior[2 * i + 1], s_tt,
+                      s_tj, lane);
+    };
+    (void)ic_replay(a.ic, rs, lane, tail);
+  }
 #ifdef IC_STAMP
   if (lane == 0) atomicMax(&a.ic.tlist[IC_DBG_OFF + 2], (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff));
 #endif
@@ -392,7 +401,7 @@ extern "C" int vo_debug_frame_stamps(vo_ctx *c, int *dst, int rows) {
 // phase 0: the per-feature kernel; phase 1: the strict-border replay (nothing otherwise). Two phases so that
 // the caller can feed other streams while the long first kernel is already running.
 template <int WIN>
-static void frame_launch(vo_ctx *c, const FrameArgs &a, int phase, int p1_target, int done_target) {
+static void frame_launch(vo_ctx *c, const FrameArgs &a, int phase, int p1_target, int done_target, int conc_grid) {
   if (phase == 0) {
     vo_prof_begin(c, VO_K_KLT);
     hipLaunchKernelGGL(frame_track_kernel<WIN>, dim3(a.n + a.n_new), dim3(64), 0, c->stream, a);
@@ -408,23 +417,25 @@ static void frame_launch(vo_ctx *c, const FrameArgs &a, int phase, int p1_target
     hipLaunchKernelGGL(frame_fallback_kernel<WIN>, dim3(a.n), dim3(64), 0, c->stream, a);
     vo_prof_end(c);
   } else if (a.strict == 3) {
-    // The replay runs on its own stream next to the frame kernel. No HIP event joins the two streams (a cross-queue
-    // event wait costs ~30 us on this stack): the replay starts behind a one-wavefront gate that polls the frame
-    // kernel's pass-1 count, and the BA launch (main stream, behind the frame kernel) polls the count of finished
-    // workgroups of the fallback kernel, which is stream-ordered behind the replay. Both counts are cumulative; the
-    // control block the replay reads was zeroed by the previous frame's BA launch, which the frame kernel (hence the
-    // first count) is stream-ordered behind.
+    // The replay runs on its own stream NEXT TO the frame kernel, as a pool of IC_CONC_GRID resident workgroups that
+    // pick the touched features up as the frame kernel lists them (ic_replay<true>): a dependency chain starts when
+    // its members are through pass 1, not when the frame kernel's last wavefront is. No HIP event joins the two
+    // streams (a cross-queue event wait costs ~30 us on this stack): the pool synchronises with the frame kernel
+    // through the epoch stamps and the pass-1 count, and the BA launch (main stream, behind the frame kernel) polls
+    // the count of finished workgroups of the fallback kernel, which is stream-ordered behind the pool. Both counts
+    // are cumulative. (Earlier form: the whole replay behind a one-wavefront gate that waited for the LAST feature's
+    // pass 1 — no faster than stream order, the pass-1 stragglers arrive 15-30 us before the kernel ends.)
     FrameArgs b = a;
     b.sync_signal = 1;
     hipStream_t main_stream = c->stream;
-    hipLaunchKernelGGL(frame_gate_kernel, dim3(1), dim3(64), 0, c->stream3, b.sync + 0, p1_target, &b.ic.jac[IC_JAC_OVF]);
     c->stream = c->stream3;  // (the event brackets follow c->stream)
     vo_prof_begin(c, VO_K_IC);
-    hipLaunchKernelGGL(frame_replay_kernel<WIN>, dim3(b.n < IC_JGRID ? b.n : IC_JGRID), dim3(64), 0, c->stream3, b);
+    hipLaunchKernelGGL(frame_replay_kernel<WIN>, dim3(b.n < conc_grid ? b.n : conc_grid), dim3(64), 0, c->stream3, b);
     vo_prof_end(c);
     c->stream = main_stream;
     hipLaunchKernelGGL(frame_fallback_kernel<WIN>, dim3(b.n), dim3(64), 0, c->stream3, b);
   }
+  (void)p1_target;
   (void)done_target;
   // (the frame's one compaction and the control-block reset are the prologue of the GN launch, gn_pose.hip)
 }
@@ -487,7 +498,7 @@ int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, 
   a.W = prm->width;
   a.H = prm->height;
   a.thres_err = prm->thres_err;
-  a.strict = c->frame_strict_ic;  // 0 masked taps, 1 parallel replay (+ fallback), 2 sequential replay only
+  a.strict = c->frame_strict_now;  // 0 masked taps, 1 parallel replay (+ fallback), 2 sequential replay only, 3 concurrent
   a.scale = b.scale;
   a.k1 = b.k1;
   a.pr_prior = b.pr_prior;
@@ -508,15 +519,29 @@ int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, 
   a.sync = b.sync;
   // running totals of the two hand-shake counters: what they will read when this frame's share has arrived
   if (phase == 0 && a.strict) {
-    *b.sync_p1_target += n;  // (every strict frame counts, whichever replay follows)
-    if (a.strict == 3) *b.sync_done_target += n;  // one count per workgroup of the fallback kernel
+    if (a.strict == 3) {
+      *b.sync_p1_target += n;    // one count per feature past pass 1
+      *b.sync_done_target += n;  // one count per workgroup of the fallback kernel
+    }
   }
   const int p1_target = *b.sync_p1_target, done_target = *b.sync_done_target;
+  if (a.strict == 3) {
+    // concurrent replay: list entries and per-feature stamps carry the frame's epoch — the pass-1 target, which is
+    // different for every frame (and not 0)
+    a.ic.epoch = p1_target != 0 ? p1_target : 1;
+    a.ic.p1_word = b.sync + IC_P1_STRIDE;  // (the shards follow the block's first line)
+    a.ic.p1_target = p1_target;
+  } else {
+    a.ic.tl2 = nullptr;
+    a.ic.p1e = nullptr;
+  }
+  static const int cg_env = getenv("VO_CONC_GRID") ? atoi(getenv("VO_CONC_GRID")) : 0;  // (experiments)
+  const int cg = cg_env > 0 ? cg_env : (b.conc_grid > 0 ? b.conc_grid : IC_CONC_GRID);
   switch (prm->win) {
-    case 13: frame_launch<13>(c, a, phase, p1_target, done_target); break;
-    case 15: frame_launch<15>(c, a, phase, p1_target, done_target); break;
-    case 21: frame_launch<21>(c, a, phase, p1_target, done_target); break;
-    case 31: frame_launch<31>(c, a, phase, p1_target, done_target); break;
+    case 13: frame_launch<13>(c, a, phase, p1_target, done_target, cg); break;
+    case 15: frame_launch<15>(c, a, phase, p1_target, done_target, cg); break;
+    case 21: frame_launch<21>(c, a, phase, p1_target, done_target, cg); break;
+    case 31: frame_launch<31>(c, a, phase, p1_target, done_target, cg); break;
     default: VO_FAIL(c, VO_ERR_INVALID, "fused frame kernel not instantiated for window %d", prm->win);
   }
   VO_CHECK_HIP(c, hipGetLastError());

@@ -60,8 +60,9 @@ int vo_frame_init(vo_ctx *c) {
   VO_CHECK_HIP(c, hipEventCreateWithFlags(&f->ev_done, hipEventDisableTiming));
   VO_CHECK_HIP(c, hipMalloc((void **)&f->ctl, vo_ic_ctl_bytes()));
   VO_CHECK_HIP(c, hipMemsetAsync(f->ctl, 0, vo_ic_ctl_bytes(), c->stream));
-  VO_CHECK_HIP(c, hipMalloc((void **)&f->sync, 64));
-  VO_CHECK_HIP(c, hipMemsetAsync(f->sync, 0, 64, c->stream));
+  // [1] = finished workgroups of the replay's last kernel; from byte 128 on: 64 shards of the pass-1 count, 128 bytes apart
+  VO_CHECK_HIP(c, hipMalloc((void **)&f->sync, 128 + 64 * 128));
+  VO_CHECK_HIP(c, hipMemsetAsync(f->sync, 0, 128 + 64 * 128, c->stream));
   return VO_OK;
 }
 
@@ -94,6 +95,7 @@ static void inv_se3(const float T[16], float Ti[16]) {
   Ti[15] = 1;
 }
 
+#define VO_CONC_MIN_REPLAYED 16
 #define RC(x)                \
   do {                       \
     int _rc = (x);           \
@@ -102,7 +104,8 @@ static void inv_se3(const float T[16], float Ti[16]) {
 
 extern "C" int vo_stereo_frame_set_strict_border(vo_ctx *c, int strict) {
   if (!c) return VO_ERR_INVALID;
-  c->frame_strict_ic = (strict == 2 || strict == 3) ? strict : (strict ? 1 : 0);
+  c->frame_strict_ic = (strict >= 2 && strict <= 4) ? strict : (strict ? 1 : 0);
+  c->frame_strict_now = c->frame_strict_ic == 4 ? 1 : c->frame_strict_ic;
   return VO_OK;
 }
 
@@ -200,6 +203,16 @@ static int frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l
   f->new_r = (float *)(f->res_dev + f->off_newr);
   int *cnt = f->hdr->cnt;
   const bool fused = n > 0 && vo_frame_fused_supported(prm->win);
+  // Strict-border mode 4: the replay next to the frame kernel pays (a pool of resident workgroups) when there is
+  // something to replay, and a frame's border features are mostly the previous frame's — so the previous frame's count
+  // decides; the results are the same either way. The pool is sized by that count too.
+  c->frame_strict_now = c->frame_strict_ic;
+  if (c->frame_strict_ic == 4) c->frame_strict_now = (fused && f->last_replayed >= VO_CONC_MIN_REPLAYED) ? 3 : 1;
+  {
+    int g = ((f->last_replayed + 32 + 31) / 32) * 32;
+    f->conc_grid = g < 64 ? 64 : (g > 256 ? 256 : g);
+    if (c->frame_strict_ic == 3) f->conc_grid = 256;  // (fixed when asked for explicitly)
+  }
   // the fused path writes every header field itself and keeps its control block zero between frames
   if (!fused) VO_CHECK_HIP(c, hipMemsetAsync(f->hdr, 0, sizeof(vo_frame_hdr), s));  // counts, flags
 
@@ -228,6 +241,7 @@ static int frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l
     b.sync = f->sync;
     b.sync_p1_target = &f->sync_p1_target;
     b.sync_done_target = &f->sync_done_target;
+    b.conc_grid = f->conc_grid;
     b.hdr_flags = &f->hdr->flags;
     b.C_X = f->C_X;
     b.C_pl1 = f->C_pl1;
@@ -294,8 +308,8 @@ static int frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l
     }
     // [4-1] scale-compensated refinement on the compacted set (entry mask all true)
     RC(vo_ic_enqueue(c, slot_l0, slot_l1, f->A_pl0, f->A_scale, f->A_pl1, f->A_ref, nullptr, f->m2, f->A_touched,
-                     f->A_cls, f->A_lastpu, n, &cnt[0], &f->hdr->flags, c->frame_strict_ic != 0));
-    if (c->frame_strict_ic)
+                     f->A_cls, f->A_lastpu, n, &cnt[0], &f->hdr->flags, c->frame_strict_now != 0));
+    if (c->frame_strict_now)
       RC(vo_ic_strict_enqueue(c, slot_l0, slot_l1, f->A_pl0, f->A_scale, f->A_pl1, f->A_ref, f->m2, f->A_touched,
                               f->A_cls, f->A_lastpu, n, &cnt[0], &f->hdr->flags));
     {
@@ -363,7 +377,7 @@ static int frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l
   }
   if (fused) {
     gf.ctl = f->ctl;
-    if (c->frame_strict_ic == 3) {  // the replay of this frame runs on its own stream: join on the device
+    if (c->frame_strict_now == 3) {  // the replay of this frame runs on its own stream: join on the device
       gf.join_word = f->sync + 1;
       gf.join_target = f->sync_done_target;
     }
@@ -466,6 +480,7 @@ extern "C" int vo_stereo_frame_result(vo_ctx *c, float *pts_l1, float *pts_r1, u
   f->pending = false;
   c->frame_slots_busy = 0;
   const vo_frame_hdr *h = (const vo_frame_hdr *)f->res_host;
+  f->last_replayed = f->n > 0 ? h->cnt[3] : 0;
   const int n = f->n, nn = f->closed ? h->cnt[5] : f->n_new;  // closed: what the BA launch's epilogue emitted
   if (f->closed && f->table) {  // the detector's capacity flags of the table this frame read
     int rcf = f->table->h_flags[0];

@@ -41,6 +41,8 @@ struct vo_frame_state {
   //   sync[0] += 1 per feature past pass 1 (frame kernel)   sync[1] += 1 per replay workgroup that has finished
   int *sync;
   int sync_p1_target, sync_done_target;
+  int last_replayed;  // features the previous frame's replay handled (strict-border mode 4 chooses by it)
+  int conc_grid;      // workgroups of the concurrent replay's pool for the frame in flight
   // packed result block
   uint8_t *res_dev, *res_host;
   size_t res_cap;

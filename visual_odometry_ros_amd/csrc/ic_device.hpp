@@ -23,6 +23,7 @@
 #define IC_JAC_P1 12     // frame kernel: features whose pass-1 record (and list entry) is complete
 #define IC_JAC_SLOTS 16  // replay kernel: one "idle at version" word per workgroup
 #define IC_JGRID 512     // workgroups of the replay kernel (2 per CU: all co-resident); each strides over the touched list
+#define IC_CONC_GRID 256  // workgroups of the concurrent replay (one per CU, resident next to the frame kernel from its start)
 #define IC_JAC_WORDS (IC_JAC_SLOTS + IC_JGRID)
 #define IC_JAC_BYTES (((IC_JAC_WORDS * 4 + 63) / 64) * 64)
 #define IC_MAX_PASSES (1 << 14)  // a look per version bump is normal; this only guards against a hang
@@ -59,6 +60,13 @@ struct IcArgs {
   uint8_t *ready;           // [n] touched feature has published its first strict-state result (cleared by pass 1)
   int *jac;                 // control words of the replay: [IC_JAC_NT] #touched, [IC_JAC_OVF], [IC_JAC_VER], slots
   int *tlist;               // indices of the touched points (any order)
+  // concurrent replay (ic_replay<true>: the kernel that writes the pass-1 records is still running)
+  unsigned long long *tl2;  // [n] list entries {epoch << 32 | feature}, written through to memory
+  int *p1e;                 // [n] epoch stamp: the feature's pass-1 record and outputs are complete in memory
+  int epoch;                // this frame's stamp (never 0)
+  int *p1_word;             // cumulative count of features past pass 1, in IC_P1_SHARDS shards on lines of their own
+                            // (shard s at p1_word[s * IC_P1_STRIDE]; feature i counts in shard i % IC_P1_SHARDS) ...
+  int p1_target;            // ... and what their sum reads when all of this frame's have passed
 };
 
 struct IcShared {
@@ -553,6 +561,24 @@ __device__ __forceinline__ void ic_st(int *p, int v) { __hip_atomic_store(p, v, 
 __device__ __forceinline__ int ic_ld8(const uint8_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void ic_st8(uint8_t *p, uint8_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+__device__ __forceinline__ float ic_ldf(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t ic_ldu(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// a load of something the pass-1 kernel wrote: that kernel may still be running (CONC) — then only a load that goes
+// past this CU's L1 (and whatever this XCD's L2 holds from the previous frame) may be used
+template <bool CONC> __device__ __forceinline__ float ic_in(const float *p) { return CONC ? ic_ldf(p) : *p; }
+template <bool CONC> __device__ __forceinline__ uint32_t ic_in(const uint32_t *p) { return CONC ? ic_ldu(p) : *p; }
+template <bool CONC> __device__ __forceinline__ int ic_in(const uint8_t *p) { return CONC ? ic_ld8(p) : (int)*p; }
+template <bool CONC> __device__ __forceinline__ int ic_in(const int *p) { return CONC ? ic_ld(p) : *p; }
+
+// The pass-1 count is polled by the whole replay pool while 1500 wavefronts of the frame kernel add to it: as ONE word
+// it is one hot line, and an add then takes tens of microseconds to come back — time the adding wavefront spends in
+// its next s_waitcnt (measured: step [5] of every feature 1.5x slower). 64 shards, one per polling lane.
+#define IC_P1_SHARDS 64
+#define IC_P1_STRIDE 32  // ints: 128 bytes
+__device__ __forceinline__ int ic_p1_count(const IcArgs &a, int lane) {
+  return wave_sum_i32(ic_ld(&a.p1_word[(lane & (IC_P1_SHARDS - 1)) * IC_P1_STRIDE]));
+}
+
 struct IcReplayShared {
   IcShared sh;
   uint32_t w[IC_MAXRUN * IC_MW];  // tap masks of the predecessors (W0 while the statics are built, else W1)
@@ -560,7 +586,28 @@ struct IcReplayShared {
   int src[IC_NELEM];              // nearest earlier writer per wanted tap (-1: none)
   int pub[IC_MAXRUN];             // publication counts of the predecessors at the last look
   uint32_t fw[64 * 6];            // ic_find_writers: per (group, word) lane the met taps and five step-number planes
+  uint32_t s0[(4 * IC_K + 1) * IC_T];  // the feature's static pre-state (kept here, not in 21 registers, between looks)
 };
+__device__ __forceinline__ void ic_state_put(uint32_t *dst, const IcState &S, int lane) {
+#pragma unroll
+  for (int k = 0; k < IC_K; ++k) {
+    dst[(4 * k + 0) * IC_T + lane] = __float_as_uint(S.I0[k]);
+    dst[(4 * k + 1) * IC_T + lane] = __float_as_uint(S.du[k]);
+    dst[(4 * k + 2) * IC_T + lane] = __float_as_uint(S.dv[k]);
+    dst[(4 * k + 3) * IC_T + lane] = __float_as_uint(S.I1[k]);
+  }
+  dst[4 * IC_K * IC_T + lane] = S.m;
+}
+__device__ __forceinline__ void ic_state_get(const uint32_t *src, IcState &S, int lane) {
+#pragma unroll
+  for (int k = 0; k < IC_K; ++k) {
+    S.I0[k] = __uint_as_float(src[(4 * k + 0) * IC_T + lane]);
+    S.du[k] = __uint_as_float(src[(4 * k + 1) * IC_T + lane]);
+    S.dv[k] = __uint_as_float(src[(4 * k + 2) * IC_T + lane]);
+    S.I1[k] = __uint_as_float(src[(4 * k + 3) * IC_T + lane]);
+  }
+  S.m = src[4 * IC_K * IC_T + lane];
+}
 
 // For every tap flagged in `want` (bit k of a lane = tap lane + 64 k): the nearest predecessor
 // r in [0, L) (largest r) with rs.cls[r] >= need whose mask rs.w[r] has the tap's bit; result lo + r
@@ -652,15 +699,25 @@ __device__ __forceinline__ void ic_find_writers(IcReplayShared &rs, unsigned wan
 // `after_run(pt, result)` is called after every (re)computation of a feature, once its record is
 // published: the frame kernel continues with the feature's next step there instead of waiting for
 // the whole relaxation (a later recomputation, rare, calls it again).
-template <typename AfterRun>
+//
+// CONC: the replay runs NEXT TO the kernel that produces the pass-1 records (the frame kernel), as a pool of
+// workgroups that are resident from the start. List entries appear while it runs ({epoch, feature} words), a feature's
+// pass-1 data are complete in memory once its epoch stamp is (a.p1e), and a.p1_word tells when every feature has
+// passed. A workgroup touches an entry only when the entry, the feature's own stamp and the stamps of the
+// predecessors it has to look at are there; until then the entry is `pending` and the workgroup comes back to it.
+// Everything the producer wrote is read with agent-scope loads (it was stored write-through). Nothing here makes the
+// producer wait, and a waiting workgroup only ever waits for entries with a lower feature index or for the producer,
+// so the dependency chains start as soon as their members are through pass 1 instead of after the producer's last
+// wavefront. The quiescence vote additionally requires that the producer had finished before the voter's pass began.
+template <bool CONC = false, typename AfterRun>
 __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, int lane, AfterRun after_run) {
   IcShared &sh = rs.sh;
-  const int n_touched = a.jac[IC_JAC_NT];
-  if (n_touched == 0) return 0;  // nothing left the image: pass 1 already is the reference result
-  const int P = min((int)gridDim.x, n_touched);
+  int n_touched = CONC ? 0 : a.jac[IC_JAC_NT];
+  if (!CONC && n_touched == 0) return 0;  // nothing left the image: pass 1 already is the reference result
+  const int P = CONC ? (int)gridDim.x : min((int)gridDim.x, n_touched);
   if ((int)blockIdx.x >= P) return 0;
   // one feature per workgroup (the usual case): everything static about it is computed once
-  const bool single = n_touched <= P;
+  bool single = CONC ? true : n_touched <= P;
   int *const ver = &a.jac[IC_JAC_VER];
   int *const ovf = &a.jac[IC_JAC_OVF];
   int *const slots = a.jac + IC_JAC_SLOTS;
@@ -673,8 +730,6 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
   // statics of the current feature: run bounds, template pre-state, observable I1 taps
   int lo = 0, L = 0;
   bool have_statics = false, skip_pt = false;
-  IcState S0;
-  ic_state_clear(S0);
   unsigned seen = 0;
   IcPrep prep;  // single mode: the feature is prepared (template, 2x2 inverse, search tile) ahead of its inputs
   prep.cls = 0;
@@ -682,6 +737,17 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
   prep.tile.x0 = prep.tile.y0 = 0;
   bool mine_ran = false;  // single mode: this workgroup's feature has published (== ready[pt], without the round trip)
   int result = P;
+  bool producer_done = !CONC;  // (as of the beginning of the current pass)
+  if (CONC) {
+    // The control block this kernel uses is reset by the launch that ENDS the previous frame, on the producer's stream;
+    // the producer of this frame is ordered behind that launch, this kernel is not. Its first sign of life — a
+    // feature through pass 1 — is therefore what this kernel starts on.
+    const int base = a.p1_target - a.n;
+    while ((int)(ic_p1_count(a, lane) - base) <= 0) {
+      if (++polls > IC_SPIN_LIMIT) return -1;  // (the sequential fallback cannot be asked for either: nothing to do)
+      __builtin_amdgcn_s_sleep(32);
+    }
+  }
   for (int pass = 0;; ++pass) {
     // ---- look ----
     int v = ic_ld(ver);
@@ -696,25 +762,62 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
     }
     v = __builtin_amdgcn_readfirstlane(v);
     int any_change = 0;
+    bool pending = false;  // CONC: an entry of this workgroup could not be looked at yet
+    if (CONC) {
+      // "done" is read before the list length: a count read behind a finished producer is final
+      producer_done = (int)(ic_p1_count(a, lane) - a.p1_target) >= 0;
+      __builtin_amdgcn_s_waitcnt(0);
+      n_touched = __builtin_amdgcn_readfirstlane(ic_ld(&a.jac[IC_JAC_NT]));
+      if (single && n_touched > P) {  // more entries than workgroups: from here on every look rebuilds its statics
+        single = false;
+        have_statics = false;
+      }
+    }
     for (int li = blockIdx.x; li < n_touched; li += P) {
-      const int pt = a.tlist[li];
+      int pt;
+      if (CONC) {
+        const unsigned long long e = __hip_atomic_load(&a.tl2[li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int pe = __builtin_amdgcn_readfirstlane((int)(e >> 32));
+        pt = __builtin_amdgcn_readfirstlane((int)(unsigned)e);
+        // the entry itself, then the feature's own pass-1 data (the list store may overtake them)
+        if (pe != a.epoch || __builtin_amdgcn_readfirstlane(ic_ld(&a.p1e[pt])) != a.epoch) {
+          pending = true;
+          continue;
+        }
+      } else {
+        pt = a.tlist[li];
+      }
       __syncthreads();  // LDS of the previous list entry is free
       const float p0x = a.pts0[2 * pt], p0y = a.pts0[2 * pt + 1];
       if (!single || !have_statics) {
-        have_statics = true;
         skip_pt = false;
         // nearest clean (untouched, iterated) predecessor: 64 candidates at a time
         int dist = -1;
+        bool early = false;  // CONC: a predecessor nearer than the nearest clean one is not through pass 1 yet
         for (int c0 = 0; c0 < IC_CAND; c0 += 64) {
           const int q = pt - 1 - c0 - lane;
-          const bool is_clean = q >= 0 && a.cls[q] == 2 && !a.touched[q];
+          const int qq = q >= 0 ? q : 0;
+          const bool there = !CONC || ic_ld(&a.p1e[qq]) == a.epoch;
+          const bool is_clean = q >= 0 && there && ic_in<CONC>(&a.cls[qq]) == 2 && !ic_in<CONC>(&a.touched[qq]);
           const unsigned long long bal = __ballot(is_clean);
+          const unsigned long long nb = __ballot(q >= 0 && !there);
           if (bal) {
-            dist = c0 + __ffsll((long long)bal) - 1;
+            const int f = __ffsll((long long)bal) - 1;
+            dist = c0 + f;
+            if (nb & ((1ull << f) - 1ull)) early = true;
+            break;
+          }
+          if (nb) {
+            early = true;
             break;
           }
           if (pt - 1 - c0 - 63 <= 0) break;  // ran past index 0
         }
+        if (CONC && early) {
+          pending = true;
+          continue;
+        }
+        have_statics = true;
         if (dist < 0 && pt > IC_CAND) skip_pt = true;  // no clean point among the candidates
         lo = dist < 0 ? 0 : pt - 1 - dist;
         L = pt - lo;  // predecessors lo .. pt-1
@@ -731,12 +834,13 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
           const bool valid = !(u0 < 1 || u0 >= a.I0.w - 2 || v0 < 1 || v0 >= a.I0.h - 2);
           if (((tp.on >> k) & 1u) && !valid) tseen |= 1u << k;
         }
-        __threadfence();  // (acquire for pass 0: pass-1 records come from the previous launch anyway)
-        for (int i = lane; i < L * IC_MW; i += IC_T) rs.w[i] = a.recW0[(size_t)lo * IC_MW + i];
-        for (int i = lane; i < L; i += IC_T) rs.cls[i] = a.cls[lo + i];
+        if (!CONC) __threadfence();  // (acquire for pass 0: pass-1 records come from the previous launch anyway)
+        for (int i = lane; i < L * IC_MW; i += IC_T) rs.w[i] = ic_in<CONC>(&a.recW0[(size_t)lo * IC_MW + i]);
+        for (int i = lane; i < L; i += IC_T) rs.cls[i] = (uint8_t)ic_in<CONC>(&a.cls[lo + i]);
         __syncthreads();
         ic_find_writers(rs, tseen, 1, lo, L, lane);
         __syncthreads();
+        IcState S0;
         ic_state_clear(S0);
 #pragma unroll
         for (int k = 0; k < IC_K; ++k)
@@ -745,17 +849,17 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
             const int src = rs.src[j];
             if (src >= 0) {
               const float *v0 = a.recV0 + (size_t)src * 3 * IC_NELEM;
-              S0.I0[k] = v0[j];
-              S0.du[k] = v0[IC_NELEM + j];
-              S0.dv[k] = v0[2 * IC_NELEM + j];
+              S0.I0[k] = ic_in<CONC>(&v0[j]);
+              S0.du[k] = ic_in<CONC>(&v0[IC_NELEM + j]);
+              S0.dv[k] = ic_in<CONC>(&v0[2 * IC_NELEM + j]);
               S0.m |= 1u << k;
             }
           }
         // Only taps that are outside the image at the feature's FIRST I1 evaluation (the prior
         // position: static) can show their pre-state to it; every other tap is overwritten by that
         // evaluation before anything reads it.
-        const float pux = p0x + (a.pts_prior[2 * pt] - p0x), puy = p0y + (a.pts_prior[2 * pt + 1] - p0y);
-        const float sc = a.scale[pt];
+        const float pux = p0x + (ic_in<CONC>(&a.pts_prior[2 * pt]) - p0x), puy = p0y + (ic_in<CONC>(&a.pts_prior[2 * pt + 1]) - p0y);
+        const float sc = ic_in<CONC>(&a.scale[pt]);
         seen = 0;
 #pragma unroll
         for (int k = 0; k < IC_K; ++k) {
@@ -766,9 +870,10 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
         if (single) {
           // S0 becomes the state after the feature's own template evaluation (static, like its inputs)
           int dummy_t = 0;
-          prep = ic_prepare<true>(a.I0, a.I1, tp, p0x, p0y, a.pts_prior[2 * pt], a.pts_prior[2 * pt + 1], lane, sh, S0,
-                                  dummy_t);
+          prep = ic_prepare<true>(a.I0, a.I1, tp, p0x, p0y, ic_in<CONC>(&a.pts_prior[2 * pt]),
+                                  ic_in<CONC>(&a.pts_prior[2 * pt + 1]), lane, sh, S0, dummy_t);
         }
+        ic_state_put(rs.s0, S0, lane);
       } else if (skip_pt) {
         continue;
       }
@@ -788,7 +893,7 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
           if (b) wordmask |= 1u << 8;
         }
       }
-      IcState S = S0;
+      IcState S;  // (filled from rs.s0 when the run is about to start)
       bool give_up = false, unchanged = false;
 #ifdef IC_STAMP
       int dbg_t_att = 0, dbg_t_fw = 0, dbg_n_att = 0, dbg_t_ld = 0;
@@ -921,10 +1026,15 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
           if ((seen >> k) & 1u) {
             const int src = rs.src[lane + 64 * k];
             const int sq = src >= 0 ? src : 0;
-            const int tq = a.touched[sq], rq = ic_ld8(&a.ready[sq]);  // both loads in flight together
+            const int tq = ic_in<CONC>(&a.touched[sq]), rq = ic_ld8(&a.ready[sq]);  // both loads in flight together
             if (src >= 0 && tq && !rq) wait = true;
           }
         if (!__any(wait)) break;
+        if (CONC && !single) {  // this workgroup may own the awaited writer itself: come back in the next pass
+          give_up = true;
+          pending = true;
+          break;
+        }
         if (attempt >= 64) {
           give_up = true;  // fall back to the version-driven wait
           break;
@@ -936,7 +1046,7 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
             if ((seen >> k) & 1u) {
               const int src = rs.src[lane + 64 * k];
               const int sq = src >= 0 ? src : 0;
-              const int tq = a.touched[sq], rq = ic_ld8(&a.ready[sq]);
+              const int tq = ic_in<CONC>(&a.touched[sq]), rq = ic_ld8(&a.ready[sq]);
               if (src >= 0 && tq && !rq) w2 = true;
             }
           if (!__any(w2)) break;
@@ -949,6 +1059,7 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
         if (give_up) break;
       }
       if (unchanged || give_up) continue;
+      ic_state_get(rs.s0, S, lane);
 #pragma unroll
       for (int k = 0; k < IC_K; ++k)
         if ((seen >> k) & 1u) {
@@ -992,10 +1103,10 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
 #endif
       IcResult res_pt;
       {
-        const float q1x = a.pts_prior[2 * pt], q1y = a.pts_prior[2 * pt + 1];
+        const float q1x = ic_in<CONC>(&a.pts_prior[2 * pt]), q1y = ic_in<CONC>(&a.pts_prior[2 * pt + 1]);
         IcPrep pr = prep;
         if (!single) pr = ic_prepare<true>(a.I0, a.I1, tp, p0x, p0y, q1x, q1y, lane, sh, S, dummy);
-        res_pt = ic_iterate<true>(a.I1, tp, pr, p0x, p0y, q1x, q1y, a.scale[pt], lane, sh, S, dummy, lx, ly, n_iter);
+        res_pt = ic_iterate<true>(a.I1, tp, pr, p0x, p0y, q1x, q1y, ic_in<CONC>(&a.scale[pt]), lane, sh, S, dummy, lx, ly, n_iter);
         if (lane == 0) {
           if (res_pt.err_flag) atomicOr(a.flags, res_pt.err_flag);
           a.pts_track[2 * pt] = res_pt.x;
@@ -1023,13 +1134,14 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
       const bool first_run = single ? !mine_ran : !ic_ld8(&a.ready[pt]);
       int changed = 0;
       if (!first_run) {  // (a first run publishes whatever it found: no need to read the pass-1 record back)
-        changed = a.cls[pt] != cls;
+        // (the record this workgroup published itself, written through: read back the same way)
+        changed = ic_ld8(&a.cls[pt]) != cls;
 #pragma unroll
         for (int k = 0; k < IC_K; ++k)
           if ((tp.on >> k) & 1u) {
             const bool ok = (o >> k) & 1u;
-            if (ok != ic_bit_k(w1, lane, k) || (ok && __float_as_uint(v1[lane + 64 * k]) != __float_as_uint(S.I1[k])))
-              changed = 1;
+            const bool was = (ic_ldu(&w1[k < 4 ? 2 * k + (lane >> 5) : 8]) >> (lane & 31)) & 1u;
+            if (ok != was || (ok && __float_as_uint(ic_ldf(&v1[lane + 64 * k])) != __float_as_uint(S.I1[k]))) changed = 1;
           }
       }
       if (first_run || __any(changed)) {
@@ -1061,7 +1173,10 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
     if (any_change) continue;  // look again at once: the version moved at least by our own publish
 
     // ---- idle at version v: vote, then poll until the version moves or everybody is idle ----
-    if (lane == 0) ic_st(&slots[blockIdx.x], v + 1);
+    // (CONC: a vote says "nothing left for me, and the producer had finished before I looked"; without that the
+    // workgroup only waits for news: a new version, a longer list, the producer's end)
+    const bool may_vote = !CONC || (producer_done && !pending);
+    if (may_vote && lane == 0) ic_st(&slots[blockIdx.x], v + 1);
     int res;
     for (;;) {
       const int cur = __builtin_amdgcn_readfirstlane(ic_ld(ver));
@@ -1072,6 +1187,28 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
       if (cur != v) {
         res = 1;
         break;
+      }
+      if (CONC && !may_vote) {
+        const bool done_now = (int)(ic_p1_count(a, lane) - a.p1_target) >= 0;
+        const int nt_now = __builtin_amdgcn_readfirstlane(ic_ld(&a.jac[IC_JAC_NT]));
+        if (pending || nt_now != n_touched || done_now != producer_done) {
+          // (a pending entry is re-examined at the polling rate: its stamps are the only news it waits for)
+          __builtin_amdgcn_s_sleep(IC_WAIT_SLEEP);
+          if (++polls > IC_SPIN_LIMIT) {
+            if (lane == 0) atomicExch(ovf, 1);
+            res = 2;
+            break;
+          }
+          res = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(IC_WAIT_SLEEP);
+        if (++polls > IC_SPIN_LIMIT) {
+          if (lane == 0) atomicExch(ovf, 1);
+          res = 2;
+          break;
+        }
+        continue;
       }
       if ((polls & 3) == 3) {  // the termination test is the expensive part of a poll: every 4th
         bool ok = true;

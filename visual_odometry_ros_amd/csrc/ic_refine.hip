@@ -120,7 +120,7 @@ static int ic_args(vo_ctx *c, int slot0, int slot1, IcArgs &a, int *d_flags) {
 static int ic_records(vo_ctx *c, IcArgs &a) {
   if (!c->ic_rec) {
     const size_t N = (size_t)c->cfg.max_points;
-    const size_t bytes = N * (4 + 4 + 4 + 2 * IC_MW * 4 + 3 * IC_NELEM * 4 + IC_NELEM * 4 + IC_NELEM * 4 + IC_MW * 4) + IC_JAC_BYTES;
+    const size_t bytes = N * (4 + 4 + 4 + 2 * IC_MW * 4 + 3 * IC_NELEM * 4 + IC_NELEM * 4 + IC_NELEM * 4 + IC_MW * 4 + 8 + 4) + IC_JAC_BYTES;
     VO_CHECK_HIP(c, hipMalloc(&c->ic_rec, bytes));
     VO_CHECK_HIP(c, hipMemsetAsync(c->ic_rec, 0, bytes, c->stream));
   }
@@ -135,7 +135,9 @@ static int ic_records(vo_ctx *c, IcArgs &a) {
   a.preM = (uint32_t *)p;           p += N * IC_MW * 4;
   a.recV0 = (float *)p;             p += N * 3 * IC_NELEM * 4;
   a.recV1 = (float *)p;             p += N * IC_NELEM * 4;
-  a.pre1 = (float *)p;
+  a.pre1 = (float *)p;              p += N * IC_NELEM * 4;
+  a.tl2 = (unsigned long long *)p;  p += N * 8;  // (8-byte aligned: the arrays above take 5400 bytes per point)
+  a.p1e = (int *)p;
   return VO_OK;
 }
 

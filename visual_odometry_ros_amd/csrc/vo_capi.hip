@@ -79,7 +79,13 @@ extern "C" int vo_create(const vo_config *cfg, vo_ctx **out) {
   VO_CHECK_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   c->stream_main = c->stream;
   VO_CHECK_HIP(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-  VO_CHECK_HIP(c, hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
+  {
+    // the concurrent strict-border replay lives here: its workgroups must find room NEXT TO the frame kernel's, so its
+    // queue is served first when a wavefront slot frees up
+    int least = 0, greatest = 0;
+    VO_CHECK_HIP(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    VO_CHECK_HIP(c, hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, greatest));
+  }
   VO_CHECK_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   VO_CHECK_HIP(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   VO_CHECK_HIP(c, hipEventCreateWithFlags(&c->ev_pyr, hipEventDisableTiming));

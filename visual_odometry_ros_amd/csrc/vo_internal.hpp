@@ -78,7 +78,8 @@ struct vo_ctx {
   // frame pipeline state
   void *ic_rec;            // tap records of the IC strict replay (ic_refine.hip)
   struct vo_frame_state *frame;
-  int frame_strict_ic;     // replay border-touching points with the reference's sticky tap state
+  int frame_strict_ic;     // replay border-touching points with the reference's sticky tap state (as requested: 0..4)
+  int frame_strict_now;    // the stereo frame in flight: 4 (automatic) resolved to 1 or 3
   int frame_slots_busy;    // a frame is in flight and reads frame_slot[0..2]
   int frame_slot[3];
   // profiling

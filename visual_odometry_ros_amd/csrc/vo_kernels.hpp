@@ -105,6 +105,7 @@ struct vo_frame_fused_bufs {
   int *ctl;        // control block (vo_ic_ctl_bytes): error flags + replay control words
   int *sync;       // [0] features past pass 1, [1] replay workgroups finished: cumulative over the frames
   int *sync_p1_target, *sync_done_target;  // host-side running totals (updated by the enqueue)
+  int conc_grid;   // concurrent replay: workgroups of the pool
   int *hdr_flags;  // where the frame's error flags are reported
   float *C_X, *C_pl1, *C_pr1;
   int32_t *C_orig;
