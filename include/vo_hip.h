@@ -293,11 +293,14 @@ typedef struct {
 /* strict != 0: the frame's trackWithScale step replays border-touching points
  * with the reference's never-reset tap state (same as vo_track_with_scale's
  * strict_border; 2 = sequential replay only, for validation). Default 0.
- * 3 (stereo frame only) = the parallel replay runs on a stream of its own NEXT TO the frame kernel and starts as
- * soon as every feature is past its first refinement, joined on the device (no HIP event). Same results; measured
- * on configs[1] it neither gains nor loses on average, and it needs the two queues to really run
- * concurrently — under a tool that serialises kernels across queues (rocprofv3 --pmc) the device-side join times out
- * and the frame returns VO_ERR_HIP. */
+ * 3 (stereo frame only) = the parallel replay runs on a stream of its own NEXT TO the frame kernel, as a pool of
+ * resident workgroups that pick the border-touching features up as the frame kernel lists them; a dependency chain
+ * starts when its members are past their first refinement instead of behind the frame kernel's last wavefront. Joined
+ * on the device (no HIP event). The pool costs the frame kernel room, so it pays only when there is something to
+ * replay. It needs the two queues to really run concurrently: under a tool that serialises kernels across queues
+ * (rocprofv3 --pmc) its bounded waits run out and the frame returns VO_ERR_HIP — use 1 there.
+ * 4 (stereo frame only) = 1 or 3, chosen per frame: 3 when the previous frame replayed at least 16 features.
+ * Every non-zero value gives the same results (DESIGN.md §4.3 has the measurements). */
 int vo_stereo_frame_set_strict_border(vo_ctx *ctx, int strict);
 
 /* Asynchronous: enqueues one frame on the context stream. slot_l0 must hold the

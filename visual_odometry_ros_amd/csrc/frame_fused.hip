@@ -367,15 +367,34 @@ __global__ __launch_bounds__(64) void frame_fallback_kernel(FrameArgs a) {
   __shared__ IcShared sh;
   __shared__ uint32_t s_tt[KltCfg<WIN>::TT_H * KltCfg<WIN>::TT_WD];
   __shared__ uint32_t s_tj[KltCfg<WIN>::TJ_H * KltCfg<WIN>::TJ_WD];
-  const int i = blockIdx.x;
   const int lane = threadIdx.x;
-  const bool work = a.ic.jac[IC_JAC_OVF] != 0 && i < a.n;
+  // (a small grid that strides over the features: when nothing was asked for — the usual case — the launch is over
+  // in the time it takes to start and drain it, which a workgroup per feature is not)
+  bool work = a.ic.jac[IC_JAC_OVF] != 0;
+  if (work && a.sync_signal && a.ic.p1e) {
+    // Concurrent replay: this kernel is ordered behind the replay pool, not behind the frame kernel, whose pass-1
+    // data it is about to read. The pool normally ends after the frame kernel's last pass 1; it ends early only when
+    // it gave up waiting (kernels serialised across the queues by a tool): then wait here, bounded, and report.
+    int polls = 0;
+    while ((int)(ic_p1_count(a.ic, lane) - a.ic.p1_target) < 0) {
+      if (++polls > IC_SPIN_LIMIT) {
+        if (lane == 0) atomicOr(a.ic.flags, 8);  // reported as VO_ERR_HIP by vo_stereo_frame_result
+        work = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(32);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
   if (work) {
     auto tail = [&](int p, const IcResult &r) {
       frame_tail<WIN>(a, p, r.ok, r.x, r.y, a.k1[2 * p], a.k1[2 * p + 1], a.pr_prior[2 * p], a.pr_prior[2 * p + 1], s_tt,
                       s_tj, lane);
     };
-    ic_strict_run(a.ic, sh, i, a.n, lane, tail);
+    for (int i = blockIdx.x; i < a.n; i += gridDim.x) {
+      __syncthreads();
+      ic_strict_run(a.ic, sh, i, a.n, lane, tail);
+    }
   }
   // This kernel is stream-ordered behind the replay: when all of its workgroups have counted, every touched feature
   // is final. The BA launch on the main stream waits for the count (no HIP event between the streams). The replay's
@@ -398,6 +417,7 @@ extern "C" int vo_debug_frame_stamps(vo_ctx *c, int *dst, int rows) {
 #endif
 
 // ---- host side ---------------------------------------------------------------------
+static int vo_frame_fallback_grid(int n) { return n < 128 ? n : 128; }
 // phase 0: the per-feature kernel; phase 1: the strict-border replay (nothing otherwise). Two phases so that
 // the caller can feed other streams while the long first kernel is already running.
 template <int WIN>
@@ -410,11 +430,11 @@ static void frame_launch(vo_ctx *c, const FrameArgs &a, int phase, int p1_target
   }
   if (a.strict == 2) {  // validation mode: the sequential fallback does all the work, on the main stream
     (void)hipMemsetAsync(&a.ic.jac[IC_JAC_OVF], 1, sizeof(int), c->stream);
-    hipLaunchKernelGGL(frame_fallback_kernel<WIN>, dim3(a.n), dim3(64), 0, c->stream, a);
+    hipLaunchKernelGGL(frame_fallback_kernel<WIN>, dim3(a.n < 1024 ? a.n : 1024), dim3(64), 0, c->stream, a);
   } else if (a.strict == 1) {  // the replay stream-ordered behind the frame kernel
     vo_prof_begin(c, VO_K_IC);
     hipLaunchKernelGGL(frame_replay_kernel<WIN>, dim3(a.n < IC_JGRID ? a.n : IC_JGRID), dim3(64), 0, c->stream, a);
-    hipLaunchKernelGGL(frame_fallback_kernel<WIN>, dim3(a.n), dim3(64), 0, c->stream, a);
+    hipLaunchKernelGGL(frame_fallback_kernel<WIN>, dim3(vo_frame_fallback_grid(a.n)), dim3(64), 0, c->stream, a);
     vo_prof_end(c);
   } else if (a.strict == 3) {
     // The replay runs on its own stream NEXT TO the frame kernel, as a pool of IC_CONC_GRID resident workgroups that
@@ -433,7 +453,7 @@ static void frame_launch(vo_ctx *c, const FrameArgs &a, int phase, int p1_target
     hipLaunchKernelGGL(frame_replay_kernel<WIN>, dim3(b.n < conc_grid ? b.n : conc_grid), dim3(64), 0, c->stream3, b);
     vo_prof_end(c);
     c->stream = main_stream;
-    hipLaunchKernelGGL(frame_fallback_kernel<WIN>, dim3(b.n), dim3(64), 0, c->stream3, b);
+    hipLaunchKernelGGL(frame_fallback_kernel<WIN>, dim3(vo_frame_fallback_grid(b.n)), dim3(64), 0, c->stream3, b);
   }
   (void)p1_target;
   (void)done_target;
@@ -521,7 +541,7 @@ int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, 
   if (phase == 0 && a.strict) {
     if (a.strict == 3) {
       *b.sync_p1_target += n;    // one count per feature past pass 1
-      *b.sync_done_target += n;  // one count per workgroup of the fallback kernel
+      *b.sync_done_target += vo_frame_fallback_grid(n);  // one count per workgroup of the fallback kernel
     }
   }
   const int p1_target = *b.sync_p1_target, done_target = *b.sync_done_target;
