@@ -8,6 +8,6 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/cal_$C -o cal -- $ROOT/tools/pmccal > $OUT/cal_$C.log 2>&1
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/bench_$C -o bench -- python3 $ROOT/bench.py --no-cpu-baseline --steps 60 --warmup 10 > $OUT/bench_$C.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/bench_$C -o bench -- python3 $ROOT/bench.py --no-cpu-baseline --strict-border 1 --steps 60 --warmup 10 > $OUT/bench_$C.log 2>&1
 done
 ls -R $OUT | head -40
