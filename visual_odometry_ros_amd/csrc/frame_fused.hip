@@ -102,6 +102,9 @@ __device__ __forceinline__ void frame_tail(const FrameArgs &a, int i, int ok, fl
 // Both roles are "KLT, something in between, KLT", so the kernel is a two-pass loop around ONE
 // inlined copy of klt_point (its code is ~3000 instructions; one copy per call site would not fit
 // the instruction cache).
+#ifndef IC_TAIL_PRIO
+#define IC_TAIL_PRIO 0
+#endif
 #ifndef IC_REPLAY_VGPRS
 #define IC_REPLAY_VGPRS 288
 #endif
@@ -344,8 +347,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(IC_REPLAY_VGPRS)
   if (a.ic.tl2) {
     // next to the frame kernel (frame_launch, strict == 3): what that kernel wrote is read past the caches
     auto tail = [&](int i, const IcResult &r) {
+      // step [5] of a replayed feature is off the dependency chains (its record is published): it must not starve the
+      // frame-kernel wavefront it shares the SIMD with — that one would become the frame kernel's last
+      __builtin_amdgcn_s_setprio(IC_TAIL_PRIO);
       frame_tail<WIN>(a, i, r.ok, r.x, r.y, ic_ldf(&a.k1[2 * i]), ic_ldf(&a.k1[2 * i + 1]), ic_ldf(&a.pr_prior[2 * i]),
                       ic_ldf(&a.pr_prior[2 * i + 1]), s_tt, s_tj, lane);
+      __builtin_amdgcn_s_setprio(3);
     };
     (void)ic_replay<true>(a.ic, rs, lane, tail);
   } else {
