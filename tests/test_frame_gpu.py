@@ -90,6 +90,19 @@ def test_stereo_frame_kitti_shape(ctx, oracle, strict):
     _run_stream(ctx, oracle, stream, 3, strict)
 
 
+def test_concurrent_replay_with_fewer_workgroups_than_border_features():
+    """strict 3 with a pool of 8 workgroups (VO_CONC_GRID, read once per process: hence the child process) against
+    100+ border features: every workgroup owns many list entries, nothing may block on a writer the same workgroup
+    owns, entries that cannot be looked at yet are revisited."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, VO_CONC_GRID="8")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "test_stereo_frame_kitti_shape and 3"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_stereo_frame_automatic_replay_mode(ctx, oracle):
     """strict 4: the replay runs stream-ordered or next to the frame kernel depending on how many features the PREVIOUS
     frame replayed (the first frame knows none, the later ones of this border-hugging stream do): same results."""

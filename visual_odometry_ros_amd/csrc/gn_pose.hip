@@ -435,6 +435,11 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (!s_stop && tid == 0) atomicOr(a.f_ctl, 8);  // reported through the frame's error flags
+    // (word [2] of the block: replay workgroups that gave up waiting for the frame kernel; consumed here)
+    if (tid == 0 && __hip_atomic_load(a.f_join_word + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+      __hip_atomic_store(const_cast<int *>(a.f_join_word) + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      atomicOr(a.f_ctl, 8);
+    }
     __syncthreads();
   }
   if (a.f_n > 0) {

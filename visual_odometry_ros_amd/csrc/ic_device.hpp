@@ -744,7 +744,13 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
     // feature through pass 1 — is therefore what this kernel starts on.
     const int base = a.p1_target - a.n;
     while ((int)(ic_p1_count(a, lane) - base) <= 0) {
-      if (++polls > IC_SPIN_LIMIT) return -1;  // (the sequential fallback cannot be asked for either: nothing to do)
+      if (++polls > IC_SPIN_LIMIT) {
+        // The producer has not shown up (kernels serialised across the queues by a tool, most likely). The control
+        // block cannot carry the news (it may be reset after this), so a word next to the shards does: the BA launch
+        // reports it as an error instead of using pass-1 results as if nothing had to be replayed.
+        if (lane == 0) atomicAdd(&a.p1_word[-IC_P1_STRIDE + 2], 1);
+        return -1;
+      }
       __builtin_amdgcn_s_sleep(32);
     }
   }
