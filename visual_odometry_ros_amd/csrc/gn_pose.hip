@@ -83,47 +83,76 @@ struct GnArgs {
 // upper-triangular index of (i,j), i<=j, row-major: matches oracle UT[][]
 __device__ __forceinline__ constexpr int ut(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
 
+// The 29 per-thread sums of a GN iteration. Every accumulator receives its terms in the same order and with the same
+// two roundings (product, then sum) as the reference's calcJtWJ_x/_y; entries (.,2),(.,3) and (.,4),(.,5) of a row of
+// JtWJ are neighbours in a register pair so that one v_pk_mul_f32 + one v_pk_add_f32 serve two of them (the compiler's
+// own vectoriser found about half of these pairs and paid for them in register moves).
+typedef float gn_f2 __attribute__((ext_vector_type(2)));
 struct GnAcc {
-  float H[21];
-  float g[6];
+  gn_f2 h02, h04, h12, h14, h22, h24, h34, h44;  // (a,b),(a,b+1)
+  float h00, h11, h33, h55;
+  gn_f2 g23, g45;
+  float g0, g1;
   float err;
   float cnt;
 };
-
+__device__ __forceinline__ void gn_acc_clear(GnAcc &A) {
+  const gn_f2 z = {0.0f, 0.0f};
+  A.h02 = A.h04 = A.h12 = A.h14 = A.h22 = A.h24 = A.h34 = A.h44 = A.g23 = A.g45 = z;
+  A.h00 = A.h11 = A.h33 = A.h55 = A.g0 = A.g1 = A.err = A.cnt = 0.0f;
+}
+// entry k of the upper triangle (oracle UT[][] order) / of g
+__device__ __forceinline__ void gn_acc_unpack(const GnAcc &A, float (&H)[21], float (&g)[6]) {
+  H[ut(0, 0)] = A.h00;  H[ut(0, 1)] = 0.0f;  // (x rows have Jt(1) == 0, y rows Jt(0) == 0: never touched)
+  H[ut(0, 2)] = A.h02.x;  H[ut(0, 3)] = A.h02.y;  H[ut(0, 4)] = A.h04.x;  H[ut(0, 5)] = A.h04.y;
+  H[ut(1, 1)] = A.h11;  H[ut(1, 2)] = A.h12.x;  H[ut(1, 3)] = A.h12.y;  H[ut(1, 4)] = A.h14.x;  H[ut(1, 5)] = A.h14.y;
+  H[ut(2, 2)] = A.h22.x;  H[ut(2, 3)] = A.h22.y;  H[ut(2, 4)] = A.h24.x;  H[ut(2, 5)] = A.h24.y;
+  H[ut(3, 3)] = A.h33;  H[ut(3, 4)] = A.h34.x;  H[ut(3, 5)] = A.h34.y;
+  H[ut(4, 4)] = A.h44.x;  H[ut(4, 5)] = A.h44.y;  H[ut(5, 5)] = A.h55;
+  g[0] = A.g0;  g[1] = A.g1;  g[2] = A.g23.x;  g[3] = A.g23.y;  g[4] = A.g45.x;  g[5] = A.g45.y;
+}
+// rows 2..5 of a residual row's contribution (common to x and y rows): l_a = (w *) Jt(a)
+template <bool W>
+__device__ __forceinline__ void acc_row_tail(GnAcc &A, float w, gn_f2 P23, gn_f2 P45) {
+  const gn_f2 L23 = W ? w * P23 : P23, L45 = W ? w * P45 : P45;
+  A.h22 += L23.x * P23;
+  A.h24 += L23.x * P45;
+  A.h33 += L23.y * P23.y;
+  A.h34 += L23.y * P45;
+  A.h44 += L45.x * P45;
+  A.h55 += L45.y * P45.y;
+}
 // x rows: Jt(1) == 0 (calcJtWJ_x / calcJtJ_x)
 template <bool W>
 __device__ __forceinline__ void acc_row_x(GnAcc &A, float w, const float (&Jt)[6]) {
-  const int idx[5] = {0, 2, 3, 4, 5};
-#pragma unroll
-  for (int a = 0; a < 5; ++a) {
-    const float l = W ? w * Jt[idx[a]] : Jt[idx[a]];
-#pragma unroll
-    for (int b = a; b < 5; ++b) A.H[ut(idx[a], idx[b])] += l * Jt[idx[b]];
-  }
+  const gn_f2 P23 = {Jt[2], Jt[3]}, P45 = {Jt[4], Jt[5]};
+  const float l0 = W ? w * Jt[0] : Jt[0];
+  A.h00 += l0 * Jt[0];
+  A.h02 += l0 * P23;
+  A.h04 += l0 * P45;
+  acc_row_tail<W>(A, w, P23, P45);
 }
 // y rows: Jt(0) == 0 (calcJtWJ_y / calcJtJ_y)
 template <bool W>
 __device__ __forceinline__ void acc_row_y(GnAcc &A, float w, const float (&Jt)[6]) {
-#pragma unroll
-  for (int a = 1; a < 6; ++a) {
-    const float l = W ? w * Jt[a] : Jt[a];
-#pragma unroll
-    for (int b = a; b < 6; ++b) A.H[ut(a, b)] += l * Jt[b];
-  }
+  const gn_f2 P23 = {Jt[2], Jt[3]}, P45 = {Jt[4], Jt[5]};
+  const float l1 = W ? w * Jt[1] : Jt[1];
+  A.h11 += l1 * Jt[1];
+  A.h12 += l1 * P23;
+  A.h14 += l1 * P45;
+  acc_row_tail<W>(A, w, P23, P45);
 }
 __device__ __forceinline__ void acc_g_x(GnAcc &A, float s, const float (&Jt)[6]) {
-  A.g[0] -= s * Jt[0];
-  A.g[2] -= s * Jt[2];
-  A.g[3] -= s * Jt[3];
-  A.g[4] -= s * Jt[4];
-  A.g[5] -= s * Jt[5];
+  const gn_f2 P23 = {Jt[2], Jt[3]}, P45 = {Jt[4], Jt[5]};
+  A.g0 -= s * Jt[0];
+  A.g23 -= s * P23;
+  A.g45 -= s * P45;
 }
 __device__ __forceinline__ void acc_g_y(GnAcc &A, float s, const float (&Jt)[6]) {
-  A.g[1] -= s * Jt[1];
-  A.g[2] -= s * Jt[2];
-  A.g[3] -= s * Jt[3];
-  A.g[4] -= s * Jt[4];
-  A.g[5] -= s * Jt[5];
+  const gn_f2 P23 = {Jt[2], Jt[3]}, P45 = {Jt[4], Jt[5]};
+  A.g1 -= s * Jt[1];
+  A.g23 -= s * P23;
+  A.g45 -= s * P45;
 }
 
 __device__ __forceinline__ void jac_x(float (&Jt)[6], float f, float iz, float fxxiz, float xiz, float yiz) {
@@ -570,12 +599,7 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
       t10[i] = T10[i * 4 + 3];
     }
     GnAcc A;
-#pragma unroll
-    for (int k = 0; k < 21; ++k) A.H[k] = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) A.g[k] = 0.0f;
-    A.err = 0.0f;
-    A.cnt = 0.0f;
+    gn_acc_clear(A);
 
     // thread t: points t, t + GN_T, ... in ascending order
 #pragma unroll
@@ -592,10 +616,12 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
     // transposed through LDS so that a lane adds 8 neighbouring partials (three tree levels) and
     // ONE 4-way DPP butterfly per wavefront finishes the other six, instead of eight butterflies
     {
+      float AH[21], Ag[6];
+      gn_acc_unpack(A, AH, Ag);
 #pragma unroll
-      for (int k = 0; k < 21; ++k) s_red[k * GN_T + tid] = A.H[k];
+      for (int k = 0; k < 21; ++k) s_red[k * GN_T + tid] = AH[k];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) s_red[(21 + k) * GN_T + tid] = A.g[k];
+      for (int k = 0; k < 6; ++k) s_red[(21 + k) * GN_T + tid] = Ag[k];
       s_red[27 * GN_T + tid] = A.err;
       s_red[28 * GN_T + tid] = A.cnt;
     }
