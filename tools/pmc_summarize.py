@@ -48,7 +48,7 @@ def main():
                                           "note": f"sum over every kernel of the run / {frames} frames"}
     out["per_kernel_KiB_per_frame"] = {x.split("(")[0][:48]: {"fetch": round(f_per[x] * ff / frames, 1), "write": round(w_per.get(x, 0.0) * wf / frames, 1)}
                                        for x in sorted(f_per, key=lambda q: -f_per[q])[:14]}
-    out["command"] = "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace --output-format csv -- python3 bench.py --no-cpu-baseline --no-secondary --steps 60 --warmup 10 (two passes; tools/run_profiles_r02.sh)"
+    out["command"] = "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace --output-format csv -- python3 bench.py --no-cpu-baseline --strict-border 1 --no-secondary --steps 60 --warmup 10 (two passes; counter collection serialises kernels across queues, hence the stream-ordered replay; tools/run_profiles_r02.sh)"
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"{tag}_frame_pmc.json")
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(out)[:600])
