@@ -169,6 +169,24 @@ def frame_ms_stats(stamps):
             "p95": round(float(np.percentile(d, 95)), 4)}
 
 
+def replay_split(stamps, replayed):
+    """The synthetic stream is played back and forth: while the camera moves backwards no feature's refinement window
+    leaves the image, so those frames have nothing to replay; a stream that only moves forward pays the `with` figure on
+    every frame. stamps[k] is taken after frame k's result, replayed[k] is frame k's count."""
+    d = np.diff(np.asarray(stamps)) * 1e3
+    r = np.asarray(replayed[1:len(d) + 1])
+    if d.size == 0 or r.size != d.size:
+        return None
+    w = r > 0
+    out = {"frames_with_border_features": int(w.sum()), "frames_without": int((~w).sum())}
+    if w.any():
+        out["mean_ms_with"] = round(float(d[w].mean()), 4)
+        out["mean_replayed_features"] = round(float(r[w].mean()), 1)
+    if (~w).any():
+        out["mean_ms_without"] = round(float(d[~w].mean()), 4)
+    return out
+
+
 def cpu_model():
     try:
         for ln in open("/proc/cpuinfo"):
@@ -415,6 +433,7 @@ def run_stereo(cfg, args, rank, local_rank, world, torch, V, barrier, dev, secon
     ctx.profile_reset()
     acc = {"b8d": 0, "bdes": 0}
     results, stamps = [], []
+    replayed = []  # per frame: features the strict-border replay handled
 
     def account(step, r):
         cts = r["counts"]  # features finished by the replay kernel do their step [5] there
@@ -426,6 +445,7 @@ def run_stereo(cfg, args, rank, local_rank, world, torch, V, barrier, dev, secon
                                   B.eff_levels_bwd, bool(args.strict_border))
         acc["b8d"] += a
         acc["bdes"] += b
+        replayed.append(cts.n_replayed)
 
     dt = timed(lambda: B.run(first, K, mode, host, results, stamps, account), barrier, ctx)
     if os.environ.get("VO_BENCH_DUMP"):  # per-frame wall time and replayed-feature count, for A/B analysis
@@ -461,6 +481,7 @@ def run_stereo(cfg, args, rank, local_rank, world, torch, V, barrier, dev, secon
         "warmup": args.warmup,
         "ms_per_step": round(1e3 * max_dt / K, 4),
         "frame_ms": frame_ms_stats(stamps),
+        "frame_ms_by_replay": replay_split(stamps, replayed),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
