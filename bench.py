@@ -49,7 +49,7 @@ CONFIGS = {
             thres=(80.0, 0.5, 3.0), thres_fast=15),
     2: dict(kind="mono", name="BASELINE configs[2]", metric="mono VO frames/sec @752x480, 1000 feats",
             W=752, H=480, K=(458.654, 457.296, 367.215, 248.375), n_u=40, n_v=25, win=15, max_level=5, speed=0.25,
-            margin=31.0, thres=(20.0, 1.0, 5, 1.0)),
+            margin=31.0, thres=(20.0, 1.0, 5, 1.0), thres_fast=15),
     4: dict(kind="stereo", name="BASELINE configs[4]", metric="stereo VO frames/sec @3840x2160, 8000 feats",
             W=3840, H=2160, K=(718.856 * 3.0, 718.856 * 3.0, 1920.0, 1080.0), n_u=100, n_v=80, win=21, max_level=4,
             speed=0.8, margin=31.0, thres=(80.0, 0.5, 3.0), thres_fast=15),
@@ -655,14 +655,33 @@ def run_mono(cfg, args, rank, local_rank, world, torch, V, barrier, dev):
     ctx.set_pyramid_window_hint(WIN)
     ctx.set_ingest_side_stream(True)
     eff_levels = ctx.pyramid_levels(W_, H_, WIN, LVL) + 1
+    eff_levels_bwd = ctx.pyramid_levels(W_, H_, WIN, LVL - 1) + 1
     slot = {"P": 0, "C": 1, "N": 2}
+    # --mode closed (default): the frame includes its new-point step (mono_vo.cpp:977-1001) closed on the device, the
+    # candidate table of the next image is built on the side stream while the frame runs; --mode open: the frame alone
+    closed = args.mode == "closed"
+    fe = V.FeatureExtractor(ctx)
+    fe.initParams(W_, H_, cfg["n_u"], cfg["n_v"], THRES_FAST=cfg["thres_fast"])
+    bins = fe.binParams()
+    n_bins_with_kp = {}
+    if closed:
+        for f_ in range(F):
+            ctx.set_image_device(2, d_I[f_].data_ptr(), W_, H_, W_)
+            fe.resetWeightBin()
+            n_bins_with_kp[f_] = int(fe.extractORBwithBinning_fast(2).shape[0])
 
     def enqueue(s):
         k = (fid(s), fid(s + 1))
         t, h = d_s[k], sets[k]
-        pipe.enqueue_device(t["pts0"].data_ptr(), t["Xw"].data_ptr(), t["flags"].data_ptr(), n_pts, h["Tcw_prev"],
-                            h["Tcw_prior"], h["dT"], slots=(slot["P"], slot["C"]))
+        if closed:
+            pipe.enqueue_closed_device(t["pts0"].data_ptr(), t["Xw"].data_ptr(), t["flags"].data_ptr(), n_pts, h["Tcw_prev"],
+                                       h["Tcw_prior"], h["dT"], bins, s & 1, slots=(slot["P"], slot["C"]))
+        else:
+            pipe.enqueue_device(t["pts0"].data_ptr(), t["Xw"].data_ptr(), t["flags"].data_ptr(), n_pts, h["Tcw_prev"],
+                                h["Tcw_prior"], h["dT"], slots=(slot["P"], slot["C"]))
         ctx.set_image_device(slot["N"], d_I[fid(s + 2)].data_ptr(), W_, H_, W_)
+        if closed:
+            fe.enqueueCandidates(slot["N"], (s + 1) & 1)
 
     def run(first, count, keep=None, stamps=None, on_result=None):
         enqueue(first)
@@ -676,10 +695,12 @@ def run_mono(cfg, args, rank, local_rank, world, torch, V, barrier, dev):
             if keep is not None and len(keep) < max(args.cpu_frames, 1):
                 keep.append((s, r))
             if on_result is not None:
-                on_result(r)
+                on_result(s, r)
 
     ctx.set_image_device(0, d_I[fid(0)].data_ptr(), W_, H_, W_)
     ctx.set_image_device(1, d_I[fid(1)].data_ptr(), W_, H_, W_)
+    if closed:
+        fe.enqueueCandidates(1, 0)
     ctx.synchronize()
     run(0, 4)
     run(4, args.warmup)
@@ -690,10 +711,12 @@ def run_mono(cfg, args, rank, local_rank, world, torch, V, barrier, dev):
     kept, stamps = [], []
     acc = {"b8d": 0, "bdes": 0}
 
-    def account(r):
+    def account(s, r):
         c = r["counts"]  # forward + backward PyrLK at full depth for every feature, IC for the tracked ones
-        acc["b8d"] += klt_bytes_per_point_level(WIN) * 2 * n_pts * eff_levels + IC_BYTES_8D * c.n_klt
-        acc["bdes"] += (IC_RECORD_BYTES * n_pts if args.strict_border else 0) + POINT_IO_BYTES * n_pts
+        n_cand = n_bins_with_kp[fid(s + 1)] if closed else 0  # + forward / backward (maxLevel - 1) for every bin's candidate
+        acc["b8d"] += klt_bytes_per_point_level(WIN) * (2 * n_pts * eff_levels + n_cand * (eff_levels + eff_levels_bwd)) \
+            + IC_BYTES_8D * c.n_klt
+        acc["bdes"] += (IC_RECORD_BYTES * n_pts if args.strict_border else 0) + POINT_IO_BYTES * (n_pts + n_cand)
 
     first = 4 + args.warmup
     dt = timed(lambda: run(first, K, kept, stamps, account), barrier, ctx)
@@ -713,8 +736,10 @@ def run_mono(cfg, args, rank, local_rank, world, torch, V, barrier, dev):
                                f"tracked features/frame ({cfg['n_u']}x{cfg['n_v']} buckets), win {WIN}, max_level {LVL} "
                                f"({eff_levels} effective levels), thresholds of config/mono/mono0.yaml; the steady state of "
                                "MonoVO::trackImage (mono_vo.cpp:739-963: prior + scale, trackBidirectionWithPrior, "
-                               "trackWithScale, pose-only BA, mask_motion, Sampson gate); result read back every frame; the "
-                               "5-point fallback and the new-point extraction are not part of the step",
+                               "trackWithScale, pose-only BA, mask_motion, Sampson gate)"
+                               + (" + its new-point step (:977-1001: updateWeightBin, keypoint detection and bucketing, "
+                                  "trackBidirection) closed on the device" if closed else "; the new-point step is not part of it")
+                               + "; result read back every frame; the 5-point fallback is the caller's",
                    "images": "resident in HBM", "strict_border": int(args.strict_border), "distinct_frames": F},
         "roofline": {"bound": "hbm", "kernel": f"mono_track_kernel<{WIN}>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
@@ -728,7 +753,9 @@ def run_mono(cfg, args, rank, local_rank, world, torch, V, barrier, dev):
         cores = min(host_cores(), 16)
         border = O.IC_REFERENCE if args.strict_border else O.IC_MASKED
         kept = kept[:args.cpu_frames]
-        ok, worst = True, 0.0
+        ok, worst, new_ok = True, 0.0, True
+        if closed:
+            us, vs, iu, iv = O.weight_bin_init(W_, H_, cfg["n_u"], cfg["n_v"])
         t0 = time.perf_counter()
         for s, r in kept:
             k = (fid(s), fid(s + 1))
@@ -737,11 +764,20 @@ def run_mono(cfg, args, rank, local_rank, world, torch, V, barrier, dev):
                              h["dT"], O.SUM_SEQ, 0, border, cores)
             ok = ok and bool(np.array_equal(o["stage"], r["stage"]))
             worst = max(worst, float(np.linalg.norm(r["dT01"].astype(np.float64) - o["dT01"]) / np.linalg.norm(o["dT01"])))
+            if closed:  # the reference's order: after the frame, on its final set
+                w = O.weight_bin_update(o["pts1"][o["stage"] == 4], us, vs, cfg["n_u"], cfg["n_v"])
+                d = O.orb_detect(imgs[k[1]], cfg["thres_fast"])
+                cand, _ = O.bucket_argmax(d["xy"], d["response"], iu, iv, cfg["n_u"], cfg["n_v"], w)
+                _, p0n, mk = O.track_bidirection(imgs[k[1]], imgs[k[0]], cand, WIN, LVL, thr[0], thr[1], None, cores)
+                new_ok = new_ok and bool(np.array_equal(r["pts1_new"], cand) and np.array_equal(r["mask_new"], mk)
+                                         and np.array_equal(r["pts0_new"].view(np.uint32), p0n.view(np.uint32)))
         cdt = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": round(len(kept) / cdt, 3), "unit": "frames/s", "cores": cores, "nproc": os.cpu_count(),
                                "cpu_model": cpu_model(), "kind": "port",
                                "sample": f"{len(kept)} frames of the same stream on the CPU restatement (oracle_mono.c)"}
         out["parity"] = {"pose_rel_frobenius_max": worst, "survivor_sets_bit_exact": ok, "frames_checked": len(kept)}
+        if closed:
+            out["parity"]["new_points_bit_exact"] = new_ok
     return out, ctx
 
 

@@ -419,6 +419,20 @@ int vo_mono_frame_enqueue(vo_ctx *ctx, const vo_mono_params *prm, int slot0, int
  * forward KLT result. */
 int vo_mono_frame_result(vo_ctx *ctx, float *pts1, float *scale, uint8_t *stage, float dT01[16],
                          vo_mono_counts *counts, vo_gn_info *gn);
+/* The mono frame with its new-point step closed on the device (MonoVO::trackImage, mono_vo.cpp:977-1001:
+ * extractor_->updateWeightBin(lmtrack_final.pts1), extractORBwithBinning_fast(I1, ...), trackBidirection(I1, I0, ...)):
+ * `table` holds the best keypoint of every bin of the image in slot1 (vo_new_point_candidates_enqueue, from the image
+ * alone, any time before), the frame kernel back-tracks every bin's candidate, and the BA launch's epilogue emits the
+ * candidates of the bins that lmtrack_final (stage 4) leaves empty — the reference's result in the reference's order.
+ * When the BA gives no pose (counts.need_five_point) no new points are reported: that path is the caller's. */
+int vo_mono_frame_enqueue_closed(vo_ctx *ctx, const vo_mono_params *prm, int slot0, int slot1,
+                                 const float *pts0, const float *Xw, const uint8_t *flags, int n,
+                                 const float Tcw_prev[16], const float Tcw_prior[16],
+                                 const float dT01_prior[16], const vo_bin_params *bins, int table,
+                                 int inputs_on_device);
+/* After vo_mono_frame_result of a closed frame: pts1_new = the new points' pixels in I1 (bins ascending), pts0_new =
+ * their back-tracked pixels in I0, mask_new = trackBidirection's mask. Capacity: n_bins_u * n_bins_v each. */
+int vo_mono_frame_new_points(vo_ctx *ctx, float *pts1_new, float *pts0_new, uint8_t *mask_new, int *n_new);
 
 /* ---- sparse local bundle adjustment -----------------------------------------
  * SparseBundleAdjustmentSolver::solveForFiniteIterations

@@ -195,3 +195,61 @@ def test_mono_frame_window_13(mono_ctx, vo, oracle):
                           oracle.SUM_TREE, 512, oracle.IC_REFERENCE, 8)
     _compare(g, o)
     assert g["counts"].n_final > 0.5 * n
+
+
+@pytest.mark.parametrize("strict", [1, 0])
+def test_mono_frame_closed_new_point_step(vo, oracle, strict):
+    """vo_mono_frame_enqueue_closed: the new points a frame reports must be exactly what the reference's sequence gives
+    AFTER the frame — updateWeightBin(lmtrack_final.pts1), extractORBwithBinning_fast(I1), trackBidirection(I1, I0, ...)
+    (mono_vo.cpp:977-992) — although the device found every bin's best keypoint before the frame and back-tracked all
+    of them speculatively inside it. The frame itself is unchanged. Without a BA pose nothing is reported."""
+    W, H, win, lvl, nbu, nbv = 752, 480, 15, 5, 40, 25
+    ctx = vo.Context(device=0, max_width=W, max_height=H, max_points=2048, n_slots=3, max_level=lvl)
+    try:
+        I0, I1, ts = _scene(27)
+        n = ts["pts_l0"].shape[0]
+        rng = np.random.default_rng(3)
+        keep = rng.random(n) < 0.75  # a thinned track set: plenty of empty bins
+        pts0 = ts["pts_l0"][keep]
+        sub = dict(ts, Xp=ts["Xp"][keep])
+        Xw, Tcw_prev, Tcw_prior, dT01 = _world(sub, 5)
+        m = pts0.shape[0]
+        flags = ((rng.random(m) < 0.7).astype(np.uint8) | ((rng.random(m) < 0.8).astype(np.uint8) << 1)).astype(np.uint8)
+        args = (W, H, win, lvl, 20.0, 1.0, 5, 1.0, MONO_K)
+        ctx.set_image(0, I0)
+        ctx.set_image(1, I1)
+        fe = vo.FeatureExtractor(ctx)
+        fe.initParams(W, H, nbu, nbv, THRES_FAST=15)
+        bins = fe.binParams()
+        fe.enqueueCandidates(1, 0)
+        pipe = MonoFramePipeline(ctx, make_mono_params(*args), strict_border=strict)
+        pipe.enqueue_closed(pts0, Xw, flags, Tcw_prev, Tcw_prior, dT01, bins, 0)
+        g = pipe.result()
+        border = oracle.IC_REFERENCE if strict else oracle.IC_MASKED
+        prm_o = oracle.make_mono_params(*args)
+        o = oracle.mono_frame(prm_o, I0, I1, pts0, Xw, flags, Tcw_prev, Tcw_prior, dT01, oracle.SUM_TREE, 512, border, 8)
+        _compare(g, o)
+        assert g["counts"].need_five_point == 0
+        # the reference's order, on the host, one operator after the other
+        final = o["pts1"][o["stage"] == 4]
+        us, vs, iu, iv = oracle.weight_bin_init(W, H, nbu, nbv)
+        w = oracle.weight_bin_update(final, us, vs, nbu, nbv)
+        d = oracle.orb_detect(I1, 15)
+        cand, _ = oracle.bucket_argmax(d["xy"], d["response"], iu, iv, nbu, nbv, w)
+        rc, p0n, mask = oracle.track_bidirection(I1, I0, cand, win, lvl, 20.0, 1.0, None, 8)
+        assert 30 < cand.shape[0] < nbu * nbv
+        assert np.array_equal(g["pts1_new"], cand)
+        assert np.array_equal(g["mask_new"], mask) and mask.sum() > 10
+        assert np.array_equal(g["pts0_new"].view(np.uint32), p0n.view(np.uint32))
+        # the same frame again: the table and the control block are reusable
+        pipe.enqueue_closed(pts0, Xw, flags, Tcw_prev, Tcw_prior, dT01, bins, 0)
+        g2 = pipe.result()
+        assert np.array_equal(g2["pts1_new"], cand) and np.array_equal(g2["mask_new"], mask)
+        # no pose from the BA (8 landmarks in its class): the 5-point path, and the new points, are the caller's
+        f8 = np.ones(m, np.uint8)
+        f8[np.arange(8) * 61 % m] |= 2
+        pipe.enqueue_closed(pts0, Xw, f8, Tcw_prev, Tcw_prior, dT01, bins, 0)
+        g3 = pipe.result()
+        assert g3["counts"].need_five_point == 1 and g3["pts1_new"].shape[0] == 0
+    finally:
+        ctx.close()

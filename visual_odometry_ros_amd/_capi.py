@@ -78,7 +78,7 @@ SYMBOLS = [
     "vo_track_with_scale", "vo_gn_pose_mono", "vo_gn_pose_stereo", "vo_orb_hamming",
     "vo_orb_match", "vo_compact_indices", "vo_stereo_frame_set_strict_border",
     "vo_stereo_frame_enqueue", "vo_stereo_frame_result",
-    "vo_mono_frame_enqueue", "vo_mono_frame_result",
+    "vo_mono_frame_enqueue", "vo_mono_frame_result", "vo_mono_frame_enqueue_closed", "vo_mono_frame_new_points",
     "vo_sba_solve", "vo_orb_detect", "vo_orb_get_level", "vo_extract_orb_with_binning",
     "vo_extract_orb_with_binning_enqueue", "vo_extract_orb_with_binning_result", "vo_rectify_init_mono", "vo_rectify_init_stereo", "vo_rectify_set_maps", "vo_rectify_get_maps",
     "vo_set_image_rectified", "vo_set_image_rectified_device", "vo_set_stereo_pair_rectified_device",
@@ -119,5 +119,8 @@ def load():
                                                    C.POINTER(BinParams), ci, ci]
     lib.vo_new_point_candidates_enqueue.argtypes = [vp, ci, C.POINTER(BinParams), ci]
     lib.vo_stereo_frame_new_points.argtypes = [vp, vp, vp]
+    lib.vo_mono_frame_enqueue_closed.argtypes = [vp, C.POINTER(MonoParams), ci, ci, vp, vp, vp, ci, vp, vp, vp,
+                                                 C.POINTER(BinParams), ci, ci]
+    lib.vo_mono_frame_new_points.argtypes = [vp, vp, vp, vp, vp]
     _lib = lib
     return lib

@@ -718,6 +718,30 @@ class MonoFramePipeline:
             C.cast(C.c_void_p(d_Xw), f), C.cast(C.c_void_p(d_flags), C.POINTER(C.c_uint8)), n,
             _p(_f32(Tcw_prev).reshape(16)), _p(_f32(Tcw_prior).reshape(16)), _p(_f32(dT01_prior).reshape(16)), 1))
 
+    def enqueue_closed(self, pts0, Xw, flags, Tcw_prev, Tcw_prior, dT01_prior, bins, table, slots=(0, 1)):
+        """The frame with its new-point step (mono_vo.cpp:977-1001) closed on the device: candidates = best keypoint of
+        every bin of `table` (FeatureExtractor.enqueueCandidates on the image in slots[1]), back-tracked inside the frame
+        kernel, emitted for the bins lmtrack_final leaves empty. `bins` = FeatureExtractor.binParams()."""
+        pts0 = _f32(pts0).reshape(-1, 2)
+        Xw = _f32(Xw).reshape(-1, 3)
+        flags = np.ascontiguousarray(flags, np.uint8)
+        self._n = pts0.shape[0]
+        if Xw.shape[0] != self._n or flags.shape[0] != self._n:
+            raise ValueError("pts0 / Xw / flags differ in length")
+        self._closed_bins = bins.n_bins_u * bins.n_bins_v
+        self.ctx.check(self.lib.vo_mono_frame_enqueue_closed(
+            self.ctx.handle, C.byref(self.prm), slots[0], slots[1], pts0.ctypes.data, Xw.ctypes.data, flags.ctypes.data,
+            self._n, _f32(Tcw_prev).reshape(16).ctypes.data, _f32(Tcw_prior).reshape(16).ctypes.data,
+            _f32(dT01_prior).reshape(16).ctypes.data, C.byref(bins), table, 0))
+
+    def enqueue_closed_device(self, d_pts0, d_Xw, d_flags, n, Tcw_prev, Tcw_prior, dT01_prior, bins, table, slots=(0, 1)):
+        self._n = n
+        self._closed_bins = bins.n_bins_u * bins.n_bins_v
+        self.ctx.check(self.lib.vo_mono_frame_enqueue_closed(
+            self.ctx.handle, C.byref(self.prm), slots[0], slots[1], d_pts0, d_Xw, d_flags, n,
+            _f32(Tcw_prev).reshape(16).ctypes.data, _f32(Tcw_prior).reshape(16).ctypes.data,
+            _f32(dT01_prior).reshape(16).ctypes.data, C.byref(bins), table, 1))
+
     def result(self):
         n = self._n
         pts1 = np.zeros((max(n, 1), 2), np.float32)
@@ -727,7 +751,16 @@ class MonoFramePipeline:
         cnt, gn = MonoCounts(), GnInfo()
         self.ctx.check(self.lib.vo_mono_frame_result(self.ctx.handle, _p(pts1), _p(scale), _p(stage, C.c_uint8),
                                                      _p(dT), C.byref(cnt), C.byref(gn)))
-        return dict(pts1=pts1[:n], scale=scale[:n], stage=stage[:n], dT01=dT.reshape(4, 4), counts=cnt, gn=gn)
+        out = dict(pts1=pts1[:n], scale=scale[:n], stage=stage[:n], dT01=dT.reshape(4, 4), counts=cnt, gn=gn)
+        nb = getattr(self, "_closed_bins", 0)
+        if nb:  # the new points of the closed frame: pixels in I1, back-tracked pixels in I0, masks
+            self._closed_bins = 0
+            p1n, p0n = np.zeros((nb, 2), np.float32), np.zeros((nb, 2), np.float32)
+            mn, nn = np.zeros(nb, np.uint8), C.c_int()
+            self.ctx.check(self.lib.vo_mono_frame_new_points(self.ctx.handle, p1n.ctypes.data, p0n.ctypes.data,
+                                                             mn.ctypes.data, C.addressof(nn)))
+            out.update(pts1_new=p1n[:nn.value], pts0_new=p0n[:nn.value], mask_new=mn[:nn.value].view(bool))
+        return out
 
 
 class Camera:

@@ -24,6 +24,7 @@ struct StereoFrameResult {
   PoseSE3 dT_pc;                       // motion estimate (the prior when the BA failed)
   PixelVec pts_new_r;                  // step [10]: right pixels of the new-point candidates
   MaskVec mask_new;
+  PixelVec pts_new;                    // enqueueClosed only: their left pixels (the bucketed keypoints, bins ascending)
   vo_frame_counts counts;
   vo_gn_info gn;
   bool pose_ok;                        // poseOnlyBundleAdjustment_Stereo's return value
@@ -37,6 +38,9 @@ class StereoFramePipeline {
     if (ctx_->n_slots() < 3) throw std::runtime_error("StereoFramePipeline needs a context with >= 3 image slots");
     ctx_->check(vo_stereo_frame_set_strict_border(ctx_->get(), strict_border ? 1 : 0));
   }
+  // 0 masked taps, 1..4 the reference's never-reset tap state (vo_hip.h: vo_stereo_frame_set_strict_border; 4 lets the
+  // operator choose per frame where the replay of the border-touching features runs — same results)
+  void setStrictBorderMode(int mode) { ctx_->check(vo_stereo_frame_set_strict_border(ctx_->get(), mode)); }
   // First frame: only the left image is kept (stereo_vo.cpp:212-330 initialises from it).
   void setFirstImage(const Image &left) {
     ctx_->check(vo_set_image(ctx_->get(), kPrev, left.data, left.width, left.height, left.stride));
@@ -66,6 +70,30 @@ class StereoFramePipeline {
                                         flags_.empty() ? nullptr : flags_.data(), n_, dT_pc_prior.data(),
                                         n_new_ ? &pts_new.data()->x : zero_, n_new_, 0));
   }
+  // Step [10] closed on the device (stereo_vo.cpp:691-711; vo_hip.h: vo_stereo_frame_enqueue_closed). The best keypoint
+  // of every bin of the CURRENT left image goes into `table` (0 / 1) — from the image alone, so this can be called as
+  // soon as the pair is pushed, e.g. while the previous frame is still running;
+  void enqueueCandidates(const vo_bin_params &bins, int table) {
+    ctx_->check(vo_new_point_candidates_enqueue(ctx_->get(), kLeft, &bins, table));
+  }
+  // the frame then tracks every bin's candidate and reports the ones of the bins lmtrack_final leaves empty
+  // (result().pts_new = their left pixels, bins ascending).
+  void enqueueClosed(const PixelVec &pts_l0, const PixelVec &pts_r0, const PointVec &Xp, const PoseSE3 &dT_pc_prior,
+                     const vo_bin_params &bins, int table, const MaskVec &triangulated = MaskVec()) {
+    if (pts_l0.size() != pts_r0.size() || pts_l0.size() != Xp.size())
+      throw std::runtime_error("pts_l0 / pts_r0 / Xp differ in length");
+    if (!triangulated.empty() && triangulated.size() != pts_l0.size())
+      throw std::runtime_error("triangulated.size() != pts_l0.size()");
+    n_ = (int)pts_l0.size();
+    n_new_ = bins.n_bins_u * bins.n_bins_v;  // capacity; the result says how many were emitted
+    closed_ = true;
+    flags_.assign(triangulated.size(), 0);
+    for (std::size_t i = 0; i < triangulated.size(); ++i) flags_[i] = triangulated[i] ? VO_LM_TRIANGULATED : 0;
+    ctx_->check(vo_stereo_frame_enqueue_closed(ctx_->get(), &prm_, kPrev, kLeft, kRight, n_ ? &pts_l0.data()->x : zero_,
+                                               n_ ? &pts_r0.data()->x : zero_, n_ ? &Xp.data()->x : zero_,
+                                               flags_.empty() ? nullptr : flags_.data(), n_, dT_pc_prior.data(), &bins,
+                                               table, 0));
+  }
   StereoFrameResult result() {
     StereoFrameResult r;
     r.pts_l1.resize(n_);
@@ -76,8 +104,16 @@ class StereoFramePipeline {
     ctx_->check(vo_stereo_frame_result(ctx_->get(), n_ ? &r.pts_l1.data()->x : nullptr, n_ ? &r.pts_r1.data()->x : nullptr,
                                        n_ ? r.stage.data() : nullptr, r.dT_pc.data(),
                                        n_new_ ? &r.pts_new_r.data()->x : nullptr, m.data(), &r.counts, &r.gn));
-    r.mask_new.assign(n_new_, false);
-    for (int i = 0; i < n_new_; ++i) r.mask_new[i] = m[i] != 0;
+    int nn = n_new_;
+    if (closed_) {  // the candidates are the device's: their number and left pixels come with the result
+      closed_ = false;
+      r.pts_new.resize(n_new_);
+      ctx_->check(vo_stereo_frame_new_points(ctx_->get(), n_new_ ? &r.pts_new.data()->x : nullptr, &nn));
+      r.pts_new.resize(nn);
+      r.pts_new_r.resize(nn);
+    }
+    r.mask_new.assign(nn, false);
+    for (int i = 0; i < nn; ++i) r.mask_new[i] = m[i] != 0;
     r.pose_ok = !r.gn.is_nan;
     return r;
   }
@@ -87,7 +123,7 @@ class StereoFramePipeline {
   ContextPtr ctx_;
   vo_stereo_params prm_;
   int n_ = 0, n_new_ = 0;
-  bool has_cur_ = false;
+  bool has_cur_ = false, closed_ = false;
   float zero_[3] = {0.f, 0.f, 0.f};
   std::vector<std::uint8_t> flags_;
 };
@@ -101,6 +137,9 @@ struct MonoFrameResult {
   vo_mono_counts counts;
   vo_gn_info gn;
   bool need_five_point;             // mono_vo.cpp:905: the caller runs calcPose5PointsAlgorithm
+  // closed new-point step (enqueueClosed): pixels in the current image, back-tracked pixels in the previous one, masks
+  PixelVec pts1_new, pts0_new;
+  MaskVec mask_new;
 };
 
 class MonoFramePipeline {
@@ -126,6 +165,23 @@ class MonoFramePipeline {
                                       n_ ? &Xw.data()->x : zero_, n_ ? flags.data() : zero_u8_, n_, Tcw_prev.data(),
                                       Tcw_prior.data(), dT01_prior.data(), 0));
   }
+  // The new-point step closed on the device (mono_vo.cpp:977-1001; vo_hip.h: vo_mono_frame_enqueue_closed): the best
+  // keypoint of every bin of the CURRENT image goes into `table` (from the image alone, any time after pushImage),
+  void enqueueCandidates(const vo_bin_params &bins, int table) {
+    ctx_->check(vo_new_point_candidates_enqueue(ctx_->get(), kCur, &bins, table));
+  }
+  // the frame back-tracks every bin's candidate and reports the ones of the bins lmtrack_final leaves empty.
+  void enqueueClosed(const PixelVec &pts0, const PointVec &Xw, const std::vector<std::uint8_t> &flags,
+                     const PoseSE3 &Tcw_prev, const PoseSE3 &Tcw_prior, const PoseSE3 &dT01_prior,
+                     const vo_bin_params &bins, int table) {
+    if (pts0.size() != Xw.size() || pts0.size() != flags.size())
+      throw std::runtime_error("pts0 / Xw / flags differ in length");
+    n_ = (int)pts0.size();
+    n_bins_ = bins.n_bins_u * bins.n_bins_v;
+    ctx_->check(vo_mono_frame_enqueue_closed(ctx_->get(), &prm_, kPrev, kCur, n_ ? &pts0.data()->x : zero_,
+                                             n_ ? &Xw.data()->x : zero_, n_ ? flags.data() : zero_u8_, n_, Tcw_prev.data(),
+                                             Tcw_prior.data(), dT01_prior.data(), &bins, table, 0));
+  }
   MonoFrameResult result() {
     MonoFrameResult r;
     r.pts1.resize(n_);
@@ -134,6 +190,18 @@ class MonoFramePipeline {
     ctx_->check(vo_mono_frame_result(ctx_->get(), n_ ? &r.pts1.data()->x : nullptr, n_ ? r.scale.data() : nullptr,
                                      n_ ? r.stage.data() : nullptr, r.dT01.data(), &r.counts, &r.gn));
     r.need_five_point = r.counts.need_five_point != 0;
+    if (n_bins_ > 0) {
+      int nn = 0;
+      r.pts1_new.resize(n_bins_);
+      r.pts0_new.resize(n_bins_);
+      std::vector<std::uint8_t> m(n_bins_);
+      ctx_->check(vo_mono_frame_new_points(ctx_->get(), &r.pts1_new.data()->x, &r.pts0_new.data()->x, m.data(), &nn));
+      r.pts1_new.resize(nn);
+      r.pts0_new.resize(nn);
+      r.mask_new.assign(nn, false);
+      for (int i = 0; i < nn; ++i) r.mask_new[i] = m[i] != 0;
+      n_bins_ = 0;
+    }
     return r;
   }
 
@@ -141,7 +209,7 @@ class MonoFramePipeline {
   enum { kPrev = 0, kCur = 1 };
   ContextPtr ctx_;
   vo_mono_params prm_;
-  int n_ = 0;
+  int n_ = 0, n_bins_ = 0;
   int n_images_ = 0;
   float zero_[3] = {0.f, 0.f, 0.f};
   std::uint8_t zero_u8_[1] = {0};

@@ -39,6 +39,12 @@ struct MonoArgs {
   uint8_t *ba_ok;   // out [n] BA class && depth > 0.1
   int32_t *orig;    // out [n] identity (compaction keeps it)
   IcArgs ic;        // pts0, scale, pts_prior = k1, pts_track = refined, mask = m2, records
+  // closed new-point step: workgroups n .. n + n_new - 1 track the per-bin candidates (trackBidirection I1 -> I0)
+  int n_new, max_level_bwd;
+  const float *pts_new;     // [n_new][2] the table's pixels (image I1)
+  const uint8_t *cand_has;  // [n_new] the bin holds a keypoint
+  float *new_r;             // out [n_new][2] forward result (pixel in I0)
+  uint8_t *m_new;           // out [n_new] trackBidirection mask
 };
 
 template <int WIN>
@@ -52,14 +58,27 @@ template <int WIN>
 __global__ __launch_bounds__(64) void mono_track_kernel(MonoArgs a) {
   __shared__ MonoShared<WIN> sh;
   const int i = blockIdx.x;
-  if (i >= a.n) return;
+  if (i >= a.n + a.n_new) return;
   const int lane = threadIdx.x;
-  const float p0x = a.pts0[2 * i], p0y = a.pts0[2 * i + 1];
-  const int fl = a.flags[i];
+  // Workgroups n .. n + n_new - 1: the new-point candidate of bin j (mono_vo.cpp:989-991: trackBidirection(I1, I0,
+  // pts1_new, ...), feature_tracker.cpp:39-86): forward I1 -> I0 (no initial flow, minEig 1e-4), backward I0 -> I1 at
+  // maxLevel - 1 with the candidate as initial flow, validity mask. Same two-pass loop, same ONE copy of klt_point;
+  // dispatched behind the features, one step up in issue priority (the launch ends when they do, as in the stereo kernel).
+  const bool feat = i < a.n;
+  const int j = i - a.n;
+  if (!feat) {
+    if (!a.cand_has[j]) {
+      if (lane == 0) a.m_new[j] = 0;
+      return;
+    }
+    __builtin_amdgcn_s_setprio(1);
+  }
+  const float p0x = feat ? a.pts0[2 * i] : a.pts_new[2 * j], p0y = feat ? a.pts0[2 * i + 1] : a.pts_new[2 * j + 1];
+  const int fl = feat ? a.flags[i] : 0;
   // ---- prior + patch scale (mono_vo.cpp:739-761) ----
   float Xp[3] = {0.f, 0.f, 0.f};
   float prx = p0x, pry = p0y, scale = 1.0f;
-  const float *Xi = a.Xw + 3 * i;
+  const float *Xi = a.Xw + 3 * (feat ? i : 0);
   if (fl & 3) {
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -88,10 +107,13 @@ __global__ __launch_bounds__(64) void mono_track_kernel(MonoArgs a) {
   float q0x = p0x, q0y = p0y, ix = prx, iy = pry;
 #pragma nounroll
   for (int pass = 0; pass < 2; ++pass) {
-    const vo_level *I = pass == 0 ? a.I0 : a.I1;
-    const vo_level *J = pass == 0 ? a.I1 : a.I0;
-    const KltResult k = klt_point<WIN>(I, J, a.max_level, VO_KLT_USE_INITIAL_FLOW, 30, 0.01 * 0.01, 0.f, q0x, q0y, ix,
-                                       iy, sh.tt, sh.tj, lane);
+    const bool from0 = (pass == 0) == feat;  // features: I0 -> I1 then back; candidates: I1 -> I0 then back
+    const vo_level *I = from0 ? a.I0 : a.I1;
+    const vo_level *J = from0 ? a.I1 : a.I0;
+    const int lvl = (!feat && pass == 1) ? a.max_level_bwd : a.max_level;
+    const int kflags = (!feat && pass == 0) ? 0 : VO_KLT_USE_INITIAL_FLOW;
+    const float min_eig = (!feat && pass == 0) ? 1e-4f : 0.f;
+    const KltResult k = klt_point<WIN>(I, J, lvl, kflags, 30, 0.01 * 0.01, min_eig, q0x, q0y, ix, iy, sh.tt, sh.tj, lane);
     if (pass == 0) {
       fwd = k;
       q0x = k.x;
@@ -101,6 +123,20 @@ __global__ __launch_bounds__(64) void mono_track_kernel(MonoArgs a) {
     } else {
       bwd = k;
     }
+  }
+  if (!feat) {
+    // trackBidirection validity, feature_tracker.cpp:74-83
+    const float dx = bwd.x - p0x, dy = bwd.y - p0y;
+    const float dist2 = dx * dx + dy * dy;
+    const float thres2 = a.thres_bidir * a.thres_bidir;
+    bool m = fwd.x > 3 && fwd.x < a.W - 3 && fwd.y > 3 && fwd.y < a.H - 3;
+    m = m && fwd.status && bwd.status && fwd.err <= a.thres_err && bwd.err <= a.thres_err && dist2 <= thres2;
+    if (lane == 0) {
+      a.new_r[2 * j] = fwd.x;
+      a.new_r[2 * j + 1] = fwd.y;
+      a.m_new[j] = m ? 1 : 0;
+    }
+    return;
   }
   // mask, feature_tracker.cpp:130-155
   bool m1;
@@ -173,14 +209,30 @@ static size_t m_align16(size_t v) { return (v + 15) & ~(size_t)15; }
 template <int WIN>
 static void mono_launch(vo_ctx *c, const MonoArgs &a) {
   vo_prof_begin(c, VO_K_KLT);
-  hipLaunchKernelGGL(mono_track_kernel<WIN>, dim3(a.n), dim3(64), 0, c->stream, a);
+  hipLaunchKernelGGL(mono_track_kernel<WIN>, dim3(a.n + a.n_new), dim3(64), 0, c->stream, a);
   vo_prof_end(c);
 }
 
-extern "C" int vo_mono_frame_enqueue(vo_ctx *c, const vo_mono_params *prm, int slot0, int slot1, const float *pts0,
-                                     const float *Xw, const uint8_t *flags, int n, const float Tcw_prev[16],
-                                     const float Tcw_prior[16], const float dT01_prior[16], int inputs_on_device) {
+// bp != null: the closed new-point step — the candidates are the per-bin best keypoints of table `table`
+// (vo_new_point_candidates_enqueue on the image in slot1), all tracked speculatively, emitted by the BA launch's epilogue
+static int mono_enqueue_impl(vo_ctx *c, const vo_mono_params *prm, int slot0, int slot1, const float *pts0,
+                             const float *Xw, const uint8_t *flags, int n, const float Tcw_prev[16],
+                             const float Tcw_prior[16], const float dT01_prior[16], int inputs_on_device,
+                             const vo_bin_params *bp, int table) {
   if (!c || !prm || !Tcw_prev || !Tcw_prior || !dT01_prior || n < 0) return VO_ERR_INVALID;
+  const vo_cand_table *tab = nullptr;
+  int n_new = 0;
+  if (bp) {
+    if (n <= 0) VO_FAIL(c, VO_ERR_INVALID, "the closed new-point step needs a track set (the first frame is the caller's)");
+    tab = vo_orb_cand_table(c, table);
+    if (!tab || tab->n_bins != bp->n_bins_u * bp->n_bins_v)
+      VO_FAIL(c, VO_ERR_INVALID, "candidate table %d was not filled for %d x %d bins (vo_new_point_candidates_enqueue)", table,
+              bp->n_bins_u, bp->n_bins_v);
+    if (bp->u_step <= 0 || bp->v_step <= 0) VO_FAIL(c, VO_ERR_INVALID, "u_step / v_step must be positive");
+    if (prm->max_level < 1) VO_FAIL(c, VO_ERR_INVALID, "trackBidirection needs max_level >= 1");
+    n_new = tab->n_bins;
+    if (n_new > c->cfg.max_points) VO_FAIL(c, VO_ERR_CAPACITY, "%d bins exceed vo_config.max_points=%d", n_new, c->cfg.max_points);
+  }
   if (n > c->cfg.max_points) VO_FAIL(c, VO_ERR_CAPACITY, "n=%d exceeds vo_config.max_points=%d", n, c->cfg.max_points);
   if (n > 0 && (!pts0 || !Xw || !flags)) return VO_ERR_INVALID;
   if (prm->win != 13 && prm->win != 15 && prm->win != 21 && prm->win != 31)
@@ -204,14 +256,24 @@ extern "C" int vo_mono_frame_enqueue(vo_ctx *c, const vo_mono_params *prm, int s
     d_X = f->in_X;
     d_fl = f->st1;
   }
-  // packed result block: header | stage | pixels | scale
+  if (tab) VO_CHECK_HIP(c, hipStreamWaitEvent(s, tab->ready, 0));  // (filled on the side stream, long before)
+  // packed result block: header | stage | pixels | scale [| closed: new-point masks | their I0 pixels | their I1 pixels]
   f->n = n;
-  f->n_new = 0;
+  f->n_new = n_new;
+  f->closed = tab ? 1 : 0;
+  f->table = tab;
   size_t off = m_align16(sizeof(vo_frame_hdr));
   f->off_stage = off;  off += m_align16((size_t)n);
   f->off_pl1 = off;    off += m_align16(sizeof(float) * 2 * (size_t)n);
   f->off_pr1 = off;    off += m_align16(sizeof(float) * (size_t)n);  // (scale)
+  const size_t bulk_end = off;  // what the BA launch's epilogue copies to the host as a block
+  if (tab) {  // written entry by entry to the device AND the host block by the epilogue (np_emit.hpp)
+    f->off_mnew = off;  off += m_align16((size_t)n_new);
+    f->off_newr = off;  off += m_align16(sizeof(float) * 2 * (size_t)n_new);
+    f->off_newl = off;  off += m_align16(sizeof(float) * 2 * (size_t)n_new);
+  }
   f->res_bytes = off;
+  if (f->res_bytes > f->res_cap) VO_FAIL(c, VO_ERR_CAPACITY, "result block of %zu bytes exceeds the context's (max_points too small)", f->res_bytes);
   f->hdr = (vo_frame_hdr *)f->res_dev;
   f->stage = f->res_dev + f->off_stage;
   f->F_pl1 = (float *)(f->res_dev + f->off_pl1);
@@ -232,6 +294,15 @@ extern "C" int vo_mono_frame_enqueue(vo_ctx *c, const vo_mono_params *prm, int s
       a.I1[l] = P1.lv[l];
     }
     a.max_level = eff;
+    if (tab) {
+      const int effb = vo_pyr_levels_host(P0.w, P0.h, prm->win, prm->max_level - 1);
+      a.max_level_bwd = effb < eff ? effb : eff;
+      a.n_new = n_new;
+      a.pts_new = tab->xy;
+      a.cand_has = tab->has;
+      a.new_r = f->bin_r;
+      a.m_new = f->bin_m;
+    }
     a.n = n;
     a.pts0 = d_p0;
     a.Xw = d_X;
@@ -302,7 +373,23 @@ extern "C" int vo_mono_frame_enqueue(vo_ctx *c, const vo_mono_params *prm, int s
     g.cnt = f->hdr->cnt;
     g.res_dev = (const uint32_t *)f->res_dev;
     g.res_host = (uint32_t *)f->res_host;
-    g.res_words = (int)((f->res_bytes + 3) / 4);
+    g.res_words = (int)((bulk_end + 3) / 4);
+    if (tab) {
+      g.np.bins = tab->n_bins;
+      g.np.bins_u = bp->n_bins_u;
+      g.np.u_step = bp->u_step;
+      g.np.v_step = bp->v_step;
+      g.np.has = tab->has;
+      g.np.xy = tab->xy;
+      g.np.bin_r = f->bin_r;
+      g.np.bin_m = f->bin_m;
+      g.np.out_l = (float *)(f->res_dev + f->off_newl);
+      g.np.out_r = (float *)(f->res_dev + f->off_newr);
+      g.np.out_m = f->res_dev + f->off_mnew;
+      g.np.host_l = (float *)(f->res_host + f->off_newl);
+      g.np.host_r = (float *)(f->res_host + f->off_newr);
+      g.np.host_m = f->res_host + f->off_mnew;
+    }
     vo_gn_frame gf;
     memset(&gf, 0, sizeof(gf));
     gf.n = n;
@@ -336,6 +423,38 @@ extern "C" int vo_mono_frame_enqueue(vo_ctx *c, const vo_mono_params *prm, int s
   c->frame_slot[0] = slot0;
   c->frame_slot[1] = slot1;
   c->frame_slot[2] = -1;
+  return VO_OK;
+}
+
+extern "C" int vo_mono_frame_enqueue(vo_ctx *c, const vo_mono_params *prm, int slot0, int slot1, const float *pts0,
+                                     const float *Xw, const uint8_t *flags, int n, const float Tcw_prev[16],
+                                     const float Tcw_prior[16], const float dT01_prior[16], int inputs_on_device) {
+  return mono_enqueue_impl(c, prm, slot0, slot1, pts0, Xw, flags, n, Tcw_prev, Tcw_prior, dT01_prior, inputs_on_device, nullptr,
+                           0);
+}
+extern "C" int vo_mono_frame_enqueue_closed(vo_ctx *c, const vo_mono_params *prm, int slot0, int slot1, const float *pts0,
+                                            const float *Xw, const uint8_t *flags, int n, const float Tcw_prev[16],
+                                            const float Tcw_prior[16], const float dT01_prior[16],
+                                            const vo_bin_params *bins, int table, int inputs_on_device) {
+  if (!bins) return VO_ERR_INVALID;
+  return mono_enqueue_impl(c, prm, slot0, slot1, pts0, Xw, flags, n, Tcw_prev, Tcw_prior, dT01_prior, inputs_on_device, bins,
+                           table);
+}
+
+// the new points of the closed frame just received (vo_mono_frame_result first): pixels in I1 (the bucketed keypoints),
+// their back-tracked pixels in I0 and the trackBidirection masks, bins ascending. Any pointer may be null.
+extern "C" int vo_mono_frame_new_points(vo_ctx *c, float *pts1_new, float *pts0_new, uint8_t *mask_new, int *n_new) {
+  if (!c || !c->frame) return VO_ERR_INVALID;
+  vo_frame_state *f = c->frame;
+  if (f->pending) VO_FAIL(c, VO_ERR_INVALID, "call vo_mono_frame_result first");
+  const vo_frame_hdr *h = (const vo_frame_hdr *)f->res_host;
+  const int nn = f->closed ? h->cnt[6] : 0;
+  if (n_new) *n_new = nn;
+  if (nn > 0) {
+    if (pts1_new) memcpy(pts1_new, f->res_host + f->off_newl, sizeof(float) * 2 * (size_t)nn);
+    if (pts0_new) memcpy(pts0_new, f->res_host + f->off_newr, sizeof(float) * 2 * (size_t)nn);
+    if (mask_new) memcpy(mask_new, f->res_host + f->off_mnew, (size_t)nn);
+  }
   return VO_OK;
 }
 

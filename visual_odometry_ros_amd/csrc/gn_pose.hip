@@ -69,12 +69,7 @@ struct GnArgs {
   int f_res_words;
   int f_res_late_words;     // leading words (header, stage bytes) that this kernel still changes: copied last
   int f_seq, f_seq_word;    // the host block's "result complete" word
-  // closed step [10] (vo_gn_frame::np_*)
-  int np_bins, np_bins_u, np_u_step, np_v_step;
-  const uint8_t *np_has, *np_bin_m;
-  const float *np_xy, *np_bin_r;
-  float *np_out_l, *np_out_r, *np_host_l, *np_host_r;
-  uint8_t *np_out_m, *np_host_m;
+  VoNpArgs np;              // closed step [10] (vo_gn_frame::np_*)
   const uint8_t *f_m1, *f_m2, *f_m3;  // mono frame: selection masks in place of f_stage
   int f_mono;               // epilogue = mono_gate_body(f_gate)
   MonoGateArgs f_gate;
@@ -755,67 +750,18 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
   if (a.f_n > 0 && a.f_mono) {
     // mono frame: mask_motion, Sampson gate, stages, counts and the copy of the result block (mono_gate.hpp)
     __syncthreads();  // inlier mask, pose and info above are this workgroup's own stores
-    mono_gate_body(a.f_gate, tid, GN_T, n);
+    mono_gate_body(a.f_gate, tid, GN_T, n, (uint8_t *)s_red, (int *)s_tot);
   } else if (a.f_n > 0 && a.f_res_host) {
     // frame mode epilogue: the packed result block goes to pinned host memory from here
     __syncthreads();  // stage marks, pose and info above are this workgroup's own stores
-    if (a.np_bins > 0) {
-      // ---- closed step [10]: extractor_->updateWeightBin(lmtrack_final.pts_l1) (stereo_vo.cpp:692 ->
-      // feature_extractor.h:116-135: reset to 1, then 0 for every bin that holds a final feature) and the emission of
-      // extractORBwithBinning_fast's bucketed pixels (feature_extractor.cpp:262-277: bins ascending, weight > 0) with
-      // the trackBidirection results (stereo_vo.cpp:706-711) the frame kernel computed for every bin's candidate
-      uint8_t *s_occ = (uint8_t *)s_red;  // (the partial sums are dead)
-      for (int j = tid; j < a.np_bins; j += GN_T) s_occ[j] = 0;
-      __syncthreads();
-      for (int i = tid; i < a.f_n; i += GN_T)
-        if (a.stage[i] == (uint8_t)a.stage_val) {
-          const int u_idx = (int)floorf(a.f_pl1[2 * i] / (float)a.np_u_step);
-          const int v_idx = (int)floorf(a.f_pl1[2 * i + 1] / (float)a.np_v_step);
-          const int bin_idx = v_idx * a.np_bins_u + u_idx;  // only the flattened index is range-tested (:130)
-          if (bin_idx >= 0 && bin_idx < a.np_bins) s_occ[bin_idx] = 1;
-        }
-      __syncthreads();
-      int *s_wv = (int *)s_tot;  // [GN_NW] wave counts, running total at [GN_NW]
-      if (tid == 0) s_wv[GN_NW] = 0;
-      __syncthreads();
-      for (int c0 = 0; c0 < a.np_bins; c0 += GN_T) {
-        const int j = c0 + tid;
-        const bool keep = j < a.np_bins && a.np_has[j] && !s_occ[j];
-        const unsigned long long bal = __ballot(keep);
-        const int below = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) s_wv[wave] = __popcll(bal);
-        __syncthreads();
-        int woff = 0;
-        for (int w = 0; w < wave; ++w) woff += s_wv[w];
-        const int base = s_wv[GN_NW];
-        if (keep) {
-          const int o = base + woff + below;
-          // (straight into the pinned host block: only the emitted entries cross the bus, not the arrays' capacity)
-          const float lx = a.np_xy[2 * j], ly = a.np_xy[2 * j + 1], rx = a.np_bin_r[2 * j], ry = a.np_bin_r[2 * j + 1];
-          const uint8_t mk = a.np_bin_m[j];
-          a.np_out_l[2 * o] = lx;
-          a.np_out_l[2 * o + 1] = ly;
-          a.np_out_r[2 * o] = rx;
-          a.np_out_r[2 * o + 1] = ry;
-          a.np_out_m[o] = mk;
-          if (a.np_host_l) {
-            a.np_host_l[2 * o] = lx;
-            a.np_host_l[2 * o + 1] = ly;
-            a.np_host_r[2 * o] = rx;
-            a.np_host_r[2 * o + 1] = ry;
-            a.np_host_m[o] = mk;
-          }
-        }
-        __syncthreads();
-        if (tid == 0) {
-          int tot = 0;
-          for (int w = 0; w < GN_NW; ++w) tot += s_wv[w];
-          s_wv[GN_NW] = base + tot;
-        }
-        __syncthreads();
-      }
-      if (tid == 0) a.f_cnt[5] = s_wv[GN_NW];
-      __syncthreads();
+    if (a.np.bins > 0) {
+      // ---- closed step [10]: updateWeightBin(lmtrack_final.pts_l1) + emission (np_emit.hpp), with the
+      // trackBidirection results (stereo_vo.cpp:706-711) the frame kernel computed for every bin's candidate.
+      // LDS: the partial sums are dead.
+      const uint8_t *stg = a.stage;
+      const uint8_t sv = (uint8_t)a.stage_val;
+      vo_np_emit(a.np, a.f_n, a.f_pl1, [&](int i) { return stg[i] == sv; }, tid, GN_T, (uint8_t *)s_red, (int *)s_tot,
+                 &a.f_cnt[5]);
     }
     for (int k = tid; k < a.f_res_late_words; k += GN_T)
       if (k != a.f_seq_word || !a.f_seq) a.f_res_host[k] = a.f_res_dev[k];
@@ -935,20 +881,20 @@ int vo_gn_enqueue(vo_ctx *c, bool stereo, bool mono_general_inverse, const float
     a.f_res_late_words = (int)(frame->res_late_bytes / 4);
     a.f_seq = frame->seq;
     a.f_seq_word = frame->seq_word;
-    a.np_bins = frame->np_bins;
-    a.np_bins_u = frame->np_bins_u;
-    a.np_u_step = frame->np_u_step;
-    a.np_v_step = frame->np_v_step;
-    a.np_has = frame->np_has;
-    a.np_xy = frame->np_xy;
-    a.np_bin_r = frame->np_bin_r;
-    a.np_bin_m = frame->np_bin_m;
-    a.np_out_l = frame->np_out_l;
-    a.np_out_r = frame->np_out_r;
-    a.np_out_m = frame->np_out_m;
-    a.np_host_l = frame->np_host_l;
-    a.np_host_r = frame->np_host_r;
-    a.np_host_m = frame->np_host_m;
+    a.np.bins = frame->np_bins;
+    a.np.bins_u = frame->np_bins_u;
+    a.np.u_step = frame->np_u_step;
+    a.np.v_step = frame->np_v_step;
+    a.np.has = frame->np_has;
+    a.np.xy = frame->np_xy;
+    a.np.bin_r = frame->np_bin_r;
+    a.np.bin_m = frame->np_bin_m;
+    a.np.out_l = frame->np_out_l;
+    a.np.out_r = frame->np_out_r;
+    a.np.out_m = frame->np_out_m;
+    a.np.host_l = frame->np_host_l;
+    a.np.host_r = frame->np_host_r;
+    a.np.host_m = frame->np_host_m;
     a.f_m1 = frame->m1;
     a.f_m2 = frame->m2;
     a.f_m3 = frame->m3;

@@ -2,6 +2,7 @@
 // function: it runs inside the GN launch, right after the iterations, so the frame needs no further launch.
 #pragma once
 #include "vo_internal.hpp"
+#include "np_emit.hpp"
 
 // ---- after the GN iterations of a mono frame: mask_motion, Sampson gate, stages, counts, result copy-out ----
 struct MonoGateArgs {
@@ -21,13 +22,15 @@ struct MonoGateArgs {
   const uint32_t *res_dev;  // packed result block -> res_host (pinned, device-visible)
   uint32_t *res_host;
   int res_words;
+  VoNpArgs np;              // closed new-point step (mono_vo.cpp:977-1001): see np_emit.hpp; np.bins == 0: off
 };
 __device__ __forceinline__ float mono_dot3(float a0, float b0, float a1, float b1, float a2, float b2) {
   return a0 * b0 + (a1 * b1 + a2 * b2);  // Eigen's unrolled 3-term redux
 }
 // Runs as the epilogue of gn_pose_kernel<false> (frame mode, mono): `nthr` lanes of one workgroup, n_ba = size of the
 // BA set the solve just used. The caller has passed a __syncthreads() since the solve's last global stores.
-__device__ __forceinline__ void mono_gate_body(const MonoGateArgs &a, int tid, int nthr, int n_ba) {
+// s_occ / s_wv: LDS scratch of the caller for the closed new-point step (np_emit.hpp).
+__device__ __forceinline__ void mono_gate_body(const MonoGateArgs &a, int tid, int nthr, int n_ba, uint8_t *s_occ, int *s_wv) {
   __shared__ float sF[9];
   __shared__ int s_cnt[8];
   __shared__ int s_ok;
@@ -105,6 +108,16 @@ __device__ __forceinline__ void mono_gate_body(const MonoGateArgs &a, int tid, i
     a.cnt[3] = s_cnt[3];
     a.cnt[4] = s_cnt[4];
     a.cnt[5] = ok ? 0 : 1;
+    a.cnt[6] = 0;  // new points emitted (below)
+  }
+  if (a.np.bins > 0 && ok) {
+    // ---- the new points of this frame: extractor_->updateWeightBin(lmtrack_final.pts1),
+    // extractORBwithBinning_fast(I1) and trackBidirection(I1, I0, ...) (mono_vo.cpp:977-992) — the candidates were
+    // found per bin before the frame and tracked by the frame kernel; here: which bins stayed empty, and their results.
+    // (Without a pose from the BA the reference goes through the 5-point path first: the caller's, and so is this step.)
+    __syncthreads();  // the stages and pixels above are this workgroup's own stores
+    const uint8_t *stg = a.stage;
+    vo_np_emit(a.np, a.n, a.pts1, [&](int i) { return stg[i] == 4; }, tid, nthr, s_occ, s_wv, &a.cnt[6]);
   }
   // every header word is written by a launch of this frame (cnt[6]: compaction, gn / dT: GN, the rest
   // above), so the block needs no clearing. It goes to pinned host memory from here (all final: earlier

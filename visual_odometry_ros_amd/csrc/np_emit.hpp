@@ -1,0 +1,78 @@
+// np_emit.hpp — the tail of the closed step [10]: extractor_->updateWeightBin(final pixels) and the emission of the
+// bucketed candidates of the bins left empty (stereo_vo.cpp:691-711, mono_vo.cpp:977-1001), as a device function that
+// runs inside the BA launch's epilogue (gn_pose.hip: stereo frame; mono_gate.hpp: mono frame).
+#pragma once
+#include "vo_internal.hpp"
+
+struct VoNpArgs {
+  int bins;                 // > 0: enabled; n_bins_u * n_bins_v
+  int bins_u, u_step, v_step;
+  const uint8_t *has;       // [bins] table: the bin holds a keypoint
+  const float *xy;          // [bins][2] table: its pixel
+  const float *bin_r;       // [bins][2] frame kernel: tracked position of the bin's candidate in the other image
+  const uint8_t *bin_m;     // [bins]    frame kernel: trackBidirection mask of the bin's candidate
+  float *out_l, *out_r;     // compacted, bins ascending (inside the result block)
+  uint8_t *out_m;
+  float *host_l, *host_r;   // the same places in the pinned host block, or null (the caller copies the block)
+  uint8_t *host_m;
+};
+
+// `nthr` threads of ONE workgroup (a multiple of 64, at most 1024). final(i): feature i is in lmtrack_final; its pixel
+// is pix[2i], pix[2i+1]. s_occ: >= bins bytes of LDS, s_wv: >= nthr / 64 + 1 ints of LDS. Returns (to thread 0's
+// *count) the number of candidates emitted. feature_extractor.h:116-135 (updateWeightBin: reset to 1, then 0 for every
+// bin that holds a final feature; only the flattened index is range-tested, :130), feature_extractor.cpp:262-277
+// (bins ascending, weight > 0).
+template <typename Final>
+__device__ __forceinline__ void vo_np_emit(const VoNpArgs &a, int n, const float *pix, Final final, int tid, int nthr,
+                                           uint8_t *s_occ, int *s_wv, int *count) {
+  const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+  for (int j = tid; j < a.bins; j += nthr) s_occ[j] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += nthr)
+    if (final(i)) {
+      const int u_idx = (int)floorf(pix[2 * i] / (float)a.u_step);
+      const int v_idx = (int)floorf(pix[2 * i + 1] / (float)a.v_step);
+      const int bin_idx = v_idx * a.bins_u + u_idx;
+      if (bin_idx >= 0 && bin_idx < a.bins) s_occ[bin_idx] = 1;
+    }
+  __syncthreads();
+  if (tid == 0) s_wv[nw] = 0;  // running total
+  __syncthreads();
+  for (int c0 = 0; c0 < a.bins; c0 += nthr) {
+    const int j = c0 + tid;
+    const bool keep = j < a.bins && a.has[j] && !s_occ[j];
+    const unsigned long long bal = __ballot(keep);
+    const int below = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wv[wave] = __popcll(bal);
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += s_wv[w];
+    const int base = s_wv[nw];
+    if (keep) {
+      const int o = base + woff + below;
+      const float lx = a.xy[2 * j], ly = a.xy[2 * j + 1], rx = a.bin_r[2 * j], ry = a.bin_r[2 * j + 1];
+      const uint8_t mk = a.bin_m[j];
+      a.out_l[2 * o] = lx;
+      a.out_l[2 * o + 1] = ly;
+      a.out_r[2 * o] = rx;
+      a.out_r[2 * o + 1] = ry;
+      a.out_m[o] = mk;
+      if (a.host_l) {  // (straight into the pinned host block: only the emitted entries cross the bus)
+        a.host_l[2 * o] = lx;
+        a.host_l[2 * o + 1] = ly;
+        a.host_r[2 * o] = rx;
+        a.host_r[2 * o + 1] = ry;
+        a.host_m[o] = mk;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int tot = 0;
+      for (int w = 0; w < nw; ++w) tot += s_wv[w];
+      s_wv[nw] = base + tot;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) *count = s_wv[nw];
+  __syncthreads();
+}
