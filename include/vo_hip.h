@@ -299,7 +299,10 @@ typedef struct {
  * on the device (no HIP event). The pool costs the frame kernel room, so it pays only when there is something to
  * replay. It needs the two queues to really run concurrently: under a tool that serialises kernels across queues
  * (rocprofv3 --pmc) its bounded waits run out and the frame returns VO_ERR_HIP — use 1 there.
- * 4 (stereo frame only) = 1 or 3, chosen per frame: 3 when the previous frame replayed at least 16 features.
+ * 5 (stereo frame only) = the stream-ordered replay of mode 1, but on the replay stream behind a one-wavefront gate that
+ * waits for the frame kernel's last pass 1: its (normally idle) launches run under the frame kernel's tail instead of
+ * between it and the BA launch. Same conditions as 3.
+ * 4 (stereo frame only) = 3 or 1, chosen per frame: 3 when the previous frame replayed at least 16 features.
  * Every non-zero value gives the same results (DESIGN.md §4.3 has the measurements). */
 int vo_stereo_frame_set_strict_border(vo_ctx *ctx, int strict);
 

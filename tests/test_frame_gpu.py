@@ -84,7 +84,7 @@ def _run_stream(ctx, oracle, stream, n_frames, strict, win=21, max_level=6, sani
     return worst
 
 
-@pytest.mark.parametrize("strict", [False, True, 3])
+@pytest.mark.parametrize("strict", [False, True, 3, 5])
 def test_stereo_frame_kitti_shape(ctx, oracle, strict):
     stream = S.StereoStream(seed=2, margin=4.0 if strict else 16.0)
     _run_stream(ctx, oracle, stream, 3, strict)
@@ -169,7 +169,7 @@ def test_stereo_frame_small_many_frames(ctx, oracle):
 
 
 @pytest.mark.parametrize("win,strict", [(31, True), (17, True), (17, False), (15, True), (13, True), (13, False), (21, 2), (21, 3),
-                                        (15, 3), (13, 4)])
+                                        (15, 3), (13, 4), (15, 5)])
 def test_stereo_frame_other_windows(ctx, oracle, win, strict):
     """win 13 / 15 / 31: the other instantiations of the fused frame kernel; win 17: the general
     one-launch-per-step path (windows the fused kernel is not instantiated for); strict 2: the

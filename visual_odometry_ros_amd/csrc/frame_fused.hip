@@ -329,6 +329,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRAME_WAVES_
   (void)rf_ok;
 }
 
+// Gate of the "gated" arrangement (strict mode 5, what mode 4 uses for a frame that is expected to replay nothing): the
+// stream-ordered replay and its fallback sit on the replay stream behind this one wavefront, which waits until every
+// feature of the frame kernel is past pass 1 — so the two (normally idle) launches run under the frame kernel's tail
+// instead of between it and the BA launch, which joins on the device as in mode 3.
+__global__ __launch_bounds__(64) void frame_gate_kernel(IcArgs a) {
+  int polls = 0;
+  while ((int)(ic_p1_count(a, threadIdx.x) - a.p1_target) < 0) {
+    if (++polls > IC_SPIN_LIMIT) {  // the frame kernel is not running next to us: reported by the BA launch (flag 8)
+      if (threadIdx.x == 0) atomicAdd(&a.p1_word[-IC_P1_STRIDE + 2], 1);
+      return;
+    }
+    __builtin_amdgcn_s_sleep(32);  // ~1 us
+  }
+}
+
 // strict border: replay of the touched features, then their step [5]
 // 288 registers at most: 512 per SIMD minus one frame-kernel wavefront (224 with the allocation granule), so that a
 // replay wavefront and a frame-kernel wavefront share a SIMD. With more (294 were used when unconstrained) a resident
@@ -461,6 +476,18 @@ static void frame_launch(vo_ctx *c, const FrameArgs &a, int phase, int p1_target
     vo_prof_end(c);
     c->stream = main_stream;
     hipLaunchKernelGGL(frame_fallback_kernel<WIN>, dim3(vo_frame_fallback_grid(b.n)), dim3(64), 0, c->stream3, b);
+  } else if (a.strict == 5) {
+    FrameArgs b = a;
+    b.sync_signal = 1;
+    b.ic.tl2 = nullptr;  // (the replay itself is the stream-ordered one: everything it reads is complete behind the gate)
+    hipLaunchKernelGGL(frame_gate_kernel, dim3(1), dim3(64), 0, c->stream3, a.ic);
+    hipStream_t main_stream = c->stream;
+    c->stream = c->stream3;
+    vo_prof_begin(c, VO_K_IC);
+    hipLaunchKernelGGL(frame_replay_kernel<WIN>, dim3(b.n < IC_JGRID ? b.n : IC_JGRID), dim3(64), 0, c->stream3, b);
+    vo_prof_end(c);
+    c->stream = main_stream;
+    hipLaunchKernelGGL(frame_fallback_kernel<WIN>, dim3(vo_frame_fallback_grid(b.n)), dim3(64), 0, c->stream3, b);
   }
   (void)p1_target;
   (void)done_target;
@@ -546,13 +573,13 @@ int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, 
   a.sync = b.sync;
   // running totals of the two hand-shake counters: what they will read when this frame's share has arrived
   if (phase == 0 && a.strict) {
-    if (a.strict == 3) {
+    if (a.strict == 3 || a.strict == 5) {
       *b.sync_p1_target += n;    // one count per feature past pass 1
       *b.sync_done_target += vo_frame_fallback_grid(n);  // one count per workgroup of the fallback kernel
     }
   }
   const int p1_target = *b.sync_p1_target, done_target = *b.sync_done_target;
-  if (a.strict == 3) {
+  if (a.strict == 3 || a.strict == 5) {
     // concurrent replay: list entries and per-feature stamps carry the frame's epoch — the pass-1 target, which is
     // different for every frame (and not 0)
     a.ic.epoch = p1_target != 0 ? p1_target : 1;

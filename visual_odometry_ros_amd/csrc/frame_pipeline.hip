@@ -104,7 +104,7 @@ static void inv_se3(const float T[16], float Ti[16]) {
 
 extern "C" int vo_stereo_frame_set_strict_border(vo_ctx *c, int strict) {
   if (!c) return VO_ERR_INVALID;
-  c->frame_strict_ic = (strict >= 2 && strict <= 4) ? strict : (strict ? 1 : 0);
+  c->frame_strict_ic = (strict >= 2 && strict <= 5) ? strict : (strict ? 1 : 0);
   c->frame_strict_now = c->frame_strict_ic == 4 ? 1 : c->frame_strict_ic;
   return VO_OK;
 }
@@ -207,7 +207,9 @@ static int frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l
   // something to replay, and a frame's border features are mostly the previous frame's — so the previous frame's count
   // decides; the results are the same either way. The pool is sized by that count too.
   c->frame_strict_now = c->frame_strict_ic;
+  // (a frame expected to replay nothing: stream-ordered; the gated arrangement, mode 5, measures the same there)
   if (c->frame_strict_ic == 4) c->frame_strict_now = (fused && f->last_replayed >= VO_CONC_MIN_REPLAYED) ? 3 : 1;
+  if (c->frame_strict_ic == 5 && !fused) c->frame_strict_now = 1;
   {
     int g = ((f->last_replayed + 32 + 31) / 32) * 32;
     f->conc_grid = g < 64 ? 64 : (g > 256 ? 256 : g);
@@ -377,7 +379,7 @@ static int frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l
   }
   if (fused) {
     gf.ctl = f->ctl;
-    if (c->frame_strict_now == 3) {  // the replay of this frame runs on its own stream: join on the device
+    if (c->frame_strict_now == 3 || c->frame_strict_now == 5) {  // the replay runs on its own stream: join on the device
       gf.join_word = f->sync + 1;
       gf.join_target = f->sync_done_target;
     }
