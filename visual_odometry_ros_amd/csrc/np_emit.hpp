@@ -18,7 +18,7 @@ struct VoNpArgs {
 };
 
 // `nthr` threads of ONE workgroup (a multiple of 64, at most 1024). final(i): feature i is in lmtrack_final; its pixel
-// is pix[2i], pix[2i+1]. s_occ: >= bins bytes of LDS, s_wv: >= nthr / 64 + 1 ints of LDS. Returns (to thread 0's
+// is pix[2i], pix[2i+1]. s_occ: >= bins bytes of LDS, s_wv: >= 4 * nthr / 64 ints of LDS. Returns (to thread 0's
 // *count) the number of candidates emitted. feature_extractor.h:116-135 (updateWeightBin: reset to 1, then 0 for every
 // bin that holds a final feature; only the flattened index is range-tested, :130), feature_extractor.cpp:262-277
 // (bins ascending, weight > 0).
@@ -36,43 +36,55 @@ __device__ __forceinline__ void vo_np_emit(const VoNpArgs &a, int n, const float
       if (bin_idx >= 0 && bin_idx < a.bins) s_occ[bin_idx] = 1;
     }
   __syncthreads();
-  if (tid == 0) s_wv[nw] = 0;  // running total
-  __syncthreads();
-  for (int c0 = 0; c0 < a.bins; c0 += nthr) {
-    const int j = c0 + tid;
-    const bool keep = j < a.bins && a.has[j] && !s_occ[j];
-    const unsigned long long bal = __ballot(keep);
-    const int below = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) s_wv[wave] = __popcll(bal);
+  // compaction, bins ascending: four chunks of nthr bins per round (one round for <= 4 * nthr bins), two barriers a
+  // round — every thread adds up the per-wavefront counts of the round itself instead of waiting for one that does
+  constexpr int NCH = 4;
+  int base = 0;  // entries emitted by the rounds before this one (the same in every thread)
+  for (int c0 = 0; c0 < a.bins; c0 += NCH * nthr) {
+    bool keep[NCH];
+    int below[NCH];
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+      const int j = c0 + q * nthr + tid;
+      keep[q] = j < a.bins && a.has[j] && !s_occ[j];
+      const unsigned long long bal = __ballot(keep[q]);
+      below[q] = __popcll(bal & ((1ull << lane) - 1ull));
+      if (lane == 0) s_wv[q * nw + wave] = __popcll(bal);
+    }
     __syncthreads();
-    int woff = 0;
-    for (int w = 0; w < wave; ++w) woff += s_wv[w];
-    const int base = s_wv[nw];
-    if (keep) {
-      const int o = base + woff + below;
-      const float lx = a.xy[2 * j], ly = a.xy[2 * j + 1], rx = a.bin_r[2 * j], ry = a.bin_r[2 * j + 1];
-      const uint8_t mk = a.bin_m[j];
-      a.out_l[2 * o] = lx;
-      a.out_l[2 * o + 1] = ly;
-      a.out_r[2 * o] = rx;
-      a.out_r[2 * o + 1] = ry;
-      a.out_m[o] = mk;
-      if (a.host_l) {  // (straight into the pinned host block: only the emitted entries cross the bus)
-        a.host_l[2 * o] = lx;
-        a.host_l[2 * o + 1] = ly;
-        a.host_r[2 * o] = rx;
-        a.host_r[2 * o + 1] = ry;
-        a.host_m[o] = mk;
+    int off = base;  // entries in front of this thread's first chunk's wavefront
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+      int woff = 0, tot = 0;
+      for (int w = 0; w < nw; ++w) {
+        const int cw = s_wv[q * nw + w];
+        woff += w < wave ? cw : 0;
+        tot += cw;
       }
+      if (keep[q]) {
+        const int j = c0 + q * nthr + tid;
+        const int o = off + woff + below[q];
+        const float lx = a.xy[2 * j], ly = a.xy[2 * j + 1], rx = a.bin_r[2 * j], ry = a.bin_r[2 * j + 1];
+        const uint8_t mk = a.bin_m[j];
+        a.out_l[2 * o] = lx;
+        a.out_l[2 * o + 1] = ly;
+        a.out_r[2 * o] = rx;
+        a.out_r[2 * o + 1] = ry;
+        a.out_m[o] = mk;
+        if (a.host_l) {  // (straight into the pinned host block: only the emitted entries cross the bus)
+          a.host_l[2 * o] = lx;
+          a.host_l[2 * o + 1] = ly;
+          a.host_r[2 * o] = rx;
+          a.host_r[2 * o + 1] = ry;
+          a.host_m[o] = mk;
+        }
+      }
+      off += tot;
     }
-    __syncthreads();
-    if (tid == 0) {
-      int tot = 0;
-      for (int w = 0; w < nw; ++w) tot += s_wv[w];
-      s_wv[nw] = base + tot;
-    }
-    __syncthreads();
+    base = off;
+    __syncthreads();  // s_wv is reused by the next round
   }
-  if (tid == 0) *count = s_wv[nw];
+  if (tid == 0) *count = base;
+
   __syncthreads();
 }
