@@ -253,3 +253,30 @@ def test_mono_frame_closed_new_point_step(vo, oracle, strict):
         assert g3["counts"].need_five_point == 1 and g3["pts1_new"].shape[0] == 0
     finally:
         ctx.close()
+
+
+def test_mono_closed_step_argument_errors(vo):
+    ctx = vo.Context(device=0, max_width=320, max_height=200, max_points=256, n_slots=2, max_level=3)
+    try:
+        img = (np.random.default_rng(0).random((200, 320)) * 255).astype(np.uint8)
+        ctx.set_image(0, img)
+        ctx.set_image(1, img)
+        fe = vo.FeatureExtractor(ctx)
+        fe.initParams(320, 200, 8, 5, THRES_FAST=15)
+        bins = fe.binParams()
+        pipe = MonoFramePipeline(ctx, make_mono_params(320, 200, 15, 3, 20.0, 1.0, 5, 1.0, (300.0, 300.0, 160.0, 100.0)))
+        eye = np.eye(4, dtype=np.float32)
+        pts = np.full((4, 2), 100.0, np.float32)
+        X = np.ones((4, 3), np.float32)
+        fl = np.ones(4, np.uint8)
+        with pytest.raises(RuntimeError, match="was not filled"):  # no candidate table yet
+            pipe.enqueue_closed(pts, X, fl, eye, eye, eye, bins, 0)
+        fe.enqueueCandidates(1, 0)
+        with pytest.raises(RuntimeError, match="needs a track set"):
+            pipe.enqueue_closed(np.zeros((0, 2), np.float32), np.zeros((0, 3), np.float32), np.zeros(0, np.uint8), eye, eye,
+                                eye, bins, 0)
+        pipe.enqueue_closed(pts, X, fl, eye, eye, eye, bins, 0)  # and a valid call still goes through
+        g = pipe.result()
+        assert g["stage"].shape == (4,) and "pts1_new" in g
+    finally:
+        ctx.close()
