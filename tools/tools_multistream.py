@@ -48,7 +48,7 @@ def main():
                     self.dts[k] = {q: torch.from_numpy(np.ascontiguousarray(t[q])).to(dev) for q in ("pts_l0", "pts_r0", "Xp", "pts_new")}
             self.ctx = V.Context(device=0, max_width=self.W, max_height=self.H, max_points=N_U * N_V + 64, n_slots=5, max_level=LVL)
             self.pipe = StereoFramePipeline(self.ctx, make_stereo_params(self.W, self.H, WIN, LVL, 80.0, 0.5, 3.0, st.K, st.K, st.T_lr),
-                                            strict_border=bool(args.strict_border))
+                                            strict_border=int(args.strict_border))
             self.ctx.set_pyramid_window_hint(WIN)
             self.slot = {"P": 0, "CL": 1, "CR": 2, "NL": 3, "NR": 4}
             self.ctx.set_image_device(0, self.dL[fid(0)].data_ptr(), self.W, self.H, self.W)
