@@ -302,7 +302,8 @@ typedef struct {
  * 5 (stereo frame only) = the stream-ordered replay of mode 1, but on the replay stream behind a one-wavefront gate that
  * waits for the frame kernel's last pass 1: its (normally idle) launches run under the frame kernel's tail instead of
  * between it and the BA launch. Same conditions as 3.
- * 4 (stereo frame only) = 3 or 1, chosen per frame: 3 when the previous frame replayed at least 16 features.
+ * 4 (stereo frame only) = 3 or 1, chosen per frame: 3 when the previous frame replayed at least 16 features and the
+ * frame kernel is small enough (at most 4096 features + candidates) to leave the chip mostly idle in its second half.
  * Every non-zero value gives the same results (DESIGN.md §4.3 has the measurements). */
 int vo_stereo_frame_set_strict_border(vo_ctx *ctx, int strict);
 
