@@ -13,7 +13,13 @@ needs it before it can go on. Step [10] is closed on the device (DESIGN.md §4.8
 ahead of the frame that the reference does not know either.
 
   python bench.py --gpus N --steps K --warmup W            (the driver's contract)
-  python bench.py --config {1,2,4}                         BASELINE configs[1] (default) / [2] mono 752x480 / [4] 4K stereo
+  python bench.py --config {1,2,4}                         BASELINE configs[1] (default) / [2] mono 752x480 (the mono frame
+                                                           incl. its new-point step closed on the device; --mode open: the
+                                                           frame alone) / [4] 4K stereo
+  python bench.py --strict-border {0,1,2,3,4,5}            border semantics of trackWithScale: 0 masked taps; 1..5 the reference's
+                                                           never-reset tap state (identical results), differing in where the
+                                                           replay of the border-touching features runs (default 4: chosen per
+                                                           frame; vo_hip.h: vo_stereo_frame_set_strict_border)
   N > 1: one rank per GPU, independent streams, one RCCL all_gather of the totals at the end; under
   torch.distributed.run the ranks are the launcher's, without a launcher environment bench.py starts the N ranks
   itself as fresh child processes (before this process has touched a GPU).
@@ -343,9 +349,10 @@ def main():
     ap.add_argument("--frames", type=int, default=12, help="distinct rendered frames (played back and forth)")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--strict-border", type=int, default=4,
-                    help="0 masked border taps; 1-4 the reference's never-reset tap state (identical results): 1 replay "
+                    help="0 masked border taps; 1-5 the reference's never-reset tap state (identical results): 1 replay "
                          "stream-ordered behind the frame kernel, 2 sequential replay, 3 replay next to the frame kernel, "
-                         "4 (default) 1 or 3 per frame, by the previous frame's number of replayed features")
+                         "5 stream-ordered replay behind a gate on the replay stream, 4 (default) 1 or 3 per frame, by the "
+                         "previous frame's number of replayed features")
     ap.add_argument("--mode", default="closed", choices=("closed", "sequential", "open"),
                     help="how step [10] (new-point candidates) is driven in the HEADLINE loop; see the docstring")
     ap.add_argument("--host-images", action="store_true",
