@@ -104,7 +104,9 @@ class LocalBA:
         return win, before, [self.kf_pose[k].copy() for k in win], err
 
 
-def run(n_frames=30, seed=2, n_bins=(40, 16), thres_fast=15, verbose=False, lba=False):
+def run(n_frames=30, seed=2, n_bins=(40, 16), thres_fast=15, verbose=False, lba=False, closed=False, strict_border=True):
+    """closed: steps [9] + [10] inside the frame operator (enqueueCandidates on the new left image + enqueue_closed; the
+    new points come with the frame's result) instead of three operator calls after it — the same odometry, bit for bit."""
     import visual_odometry_ros_amd as V
     from visual_odometry_ros_amd import synthetic as S
     from visual_odometry_ros_amd.api import StereoFramePipeline, make_stereo_params
@@ -117,8 +119,17 @@ def run(n_frames=30, seed=2, n_bins=(40, 16), thres_fast=15, verbose=False, lba=
     ft, fe = V.FeatureTracker(ctx), V.FeatureExtractor(ctx)
     fe.initParams(W, H, n_bins[0], n_bins[1], THRES_FAST=thres_fast)
     pipe = StereoFramePipeline(ctx, make_stereo_params(W, H, win, lvl, thr_err, thr_bidir, thr_ba, K, K, stream.T_lr),
-                               strict_border=True)
+                               strict_border=strict_border)
+    bins = fe.binParams()
     P, CL, CR = 0, 1, 2  # slots: previous left, current left, current right
+
+    def landmarks_of(cand, pr, m):
+        """new stereo landmarks from bucketed keypoints, their right pixels and trackBidirection's mask"""
+        if cand.shape[0] == 0:
+            return np.zeros((0, 2), np.float32), np.zeros((0, 2), np.float32), np.zeros((0, 3), np.float32)
+        X, ok = triangulate(cand, pr, K, b)
+        keep = m & ok & (np.abs(cand[:, 1] - pr[:, 1]) < 2.0)
+        return cand[keep], pr[keep], X[keep]
 
     def new_landmarks(slot_l, slot_r, tracked_pts):
         """steps [9] + [10]: bucketed detections in bins without a tracked point, stereo-matched, triangulated"""
@@ -127,9 +138,7 @@ def run(n_frames=30, seed=2, n_bins=(40, 16), thres_fast=15, verbose=False, lba=
         if cand.shape[0] == 0:
             return np.zeros((0, 2), np.float32), np.zeros((0, 2), np.float32), np.zeros((0, 3), np.float32)
         pr, m = ft.trackBidirection(slot_l, slot_r, cand, win, lvl, thr_err, thr_bidir)
-        X, ok = triangulate(cand, pr, K, b)
-        keep = m & ok & (np.abs(cand[:, 1] - pr[:, 1]) < 2.0)
-        return cand[keep], pr[keep], X[keep]
+        return landmarks_of(cand, pr, m)
 
     L, R, _ = stream.render_pair(poses[0])
     ctx.set_image(CL, L)
@@ -149,7 +158,11 @@ def run(n_frames=30, seed=2, n_bins=(40, 16), thres_fast=15, verbose=False, lba=
         ctx.swap_slots(P, CL)  # the current left image becomes the previous one, its pyramid stays on the device
         ctx.set_image(CL, L)
         ctx.set_image(CR, R)
-        pipe.enqueue(pts_l, pts_r, X, dT_prev, np.zeros((0, 2), np.float32), slots=(P, CL, CR))
+        if closed:
+            fe.enqueueCandidates(CL, k & 1)  # from the image alone: the best keypoint of every bin
+            pipe.enqueue_closed(pts_l, pts_r, X, dT_prev, bins, k & 1, slots=(P, CL, CR))
+        else:
+            pipe.enqueue(pts_l, pts_r, X, dT_prev, np.zeros((0, 2), np.float32), slots=(P, CL, CR))
         r = pipe.result()
         dT = r["dT"].astype(np.float64)
         T_wc.append(T_wc[-1] @ dT)
@@ -171,7 +184,11 @@ def run(n_frames=30, seed=2, n_bins=(40, 16), thres_fast=15, verbose=False, lba=
                 if verbose:
                     print("LBA", ba_log[-1])
                 T_wc[-1] = ba.kf_pose[-1].copy()  # the odometry continues from the adjusted keyframe pose
-        nl, nr, nX = new_landmarks(CL, CR, pl1)
+        # [9] + [10] on lmtrack_final (stereo_vo.cpp:691-711: every stage-4 feature, triangulable or not)
+        if closed:
+            nl, nr, nX = landmarks_of(r["pts_new"], r["pts_new_r"], r["mask_new"])
+        else:
+            nl, nr, nX = new_landmarks(CL, CR, r["pts_l1"][inl])
         ids = np.concatenate([ids, np.arange(next_id, next_id + nl.shape[0])])
         next_id += nl.shape[0]
         log.append(dict(frame=k, tracked=int(pts_l.shape[0]), inliers=int(inl.sum()), new=int(nl.shape[0]),
@@ -187,7 +204,7 @@ def run(n_frames=30, seed=2, n_bins=(40, 16), thres_fast=15, verbose=False, lba=
     path = np.sum(np.linalg.norm(np.diff(gt, axis=0), axis=1))
     rel = [np.linalg.norm(np.linalg.inv(np.linalg.inv(poses[i - 1]) @ poses[i]) @ (np.linalg.inv(T_wc[i - 1]) @ T_wc[i]) - np.eye(4))
            for i in range(1, n_frames)]
-    return dict(frames=n_frames, path_m=float(path), end_error_m=float(np.linalg.norm(est[-1] - gt[-1])),
+    return dict(T_wc=np.stack(T_wc), frames=n_frames, path_m=float(path), end_error_m=float(np.linalg.norm(est[-1] - gt[-1])),
                 ate_rmse_m=float(np.sqrt(np.mean(np.sum((est - gt) ** 2, axis=1)))), max_step_error=float(max(rel)),
                 mean_tracked=float(np.mean([e["tracked"] for e in log])), mean_inliers=float(np.mean([e["inliers"] for e in log])),
                 log=log, lba=ba_log)
@@ -198,7 +215,9 @@ if __name__ == "__main__":
     ap.add_argument("--frames", type=int, default=30)
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--lba", action="store_true", help="stereo keyframe every third frame + local BA of the window")
+    ap.add_argument("--closed", action="store_true", help="steps [9] + [10] closed inside the frame operator")
     a = ap.parse_args()
-    out = run(a.frames, verbose=a.verbose, lba=a.lba)
+    out = run(a.frames, verbose=a.verbose, lba=a.lba, closed=a.closed)
     out.pop("log")
+    out.pop("T_wc")
     print(json.dumps(out))

@@ -21,6 +21,21 @@ def test_closed_loop_stereo_follows_ground_truth(vo):
     assert all(e["new"] > 0 for e in r["log"][:5])  # bins freed by lost tracks are refilled
 
 
+def test_closed_operator_gives_the_same_odometry_as_the_operator_calls(vo):
+    """The same closed loop with steps [9] + [10] inside the frame operator (per-bin candidates found before the frame,
+    tracked speculatively, emitted behind the BA; strict-border mode 4: the replay runs wherever the operator decides)
+    and as three operator calls after every frame: every new landmark, hence every track set and every pose of 20
+    frames, must be the same bits."""
+    import numpy as np
+    import closed_loop_stereo as E
+    a = E.run(n_frames=21)
+    b = E.run(n_frames=21, closed=True, strict_border=4)
+    assert [e["new"] for e in a["log"]] == [e["new"] for e in b["log"]]
+    assert [e["inliers"] for e in a["log"]] == [e["inliers"] for e in b["log"]]
+    assert np.array_equal(a["T_wc"], b["T_wc"])
+    assert b["end_error_m"] < 0.02 * b["path_m"]
+
+
 def test_closed_loop_with_local_bundle_adjustment(vo):
     """Every third frame a stereo keyframe, the window bundle-adjusted through vo_sba_solve (the numeric part of
     SparseBAParameters around it is in the example): every solve lowers the window's reprojection error, keyframe
