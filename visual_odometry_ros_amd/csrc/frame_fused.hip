@@ -589,7 +589,7 @@ int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, 
     a.ic.tl2 = nullptr;
     a.ic.p1e = nullptr;
   }
-  static const int cg_env = getenv("VO_CONC_GRID") ? atoi(getenv("VO_CONC_GRID")) : 0;  // (experiments)
+  static const int cg_env = getenv("VO_CONC_GRID") ? atoi(getenv("VO_CONC_GRID")) : 0;  // (tests/test_frame_gpu.py: a pool smaller than the list; experiments)
   const int cg = cg_env > 0 ? cg_env : (b.conc_grid > 0 ? b.conc_grid : IC_CONC_GRID);
   switch (prm->win) {
     case 13: frame_launch<13>(c, a, phase, p1_target, done_target, cg); break;
