@@ -24,7 +24,7 @@ def _oracle_step10(oracle, fe_cfg, L, R, final_pts, win, max_level, thres_err, t
     return cand, pnr, mask
 
 
-@pytest.mark.parametrize("side_ingest,strict", [(False, True), (True, True), (True, False)])
+@pytest.mark.parametrize("side_ingest,strict", [(False, True), (True, True), (True, False), (True, 4), (True, 3)])
 def test_closed_step10_matches_the_reference_sequence(vo, oracle, side_ingest, strict):
     W, H, win, lvl = 620, 188, 21, 4
     K = tuple(v * 0.5 for v in S.KITTI_K)
