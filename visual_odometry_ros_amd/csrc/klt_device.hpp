@@ -383,8 +383,10 @@ __device__ __forceinline__ KltResult klt_point(const vo_level *I, const vo_level
 #ifdef FRAME_STAMP
       ++dbg_iters;
 #endif
-      const int inx = __builtin_amdgcn_readfirstlane((int)floorf(nextx));
-      const int iny = __builtin_amdgcn_readfirstlane((int)floorf(nexty));
+      // (nextx / nexty come from wave sums: the compiler knows they are wave-uniform and branches on them with scalar
+      // code by itself; forcing them into SGPRs here costs a dozen moves and hazard nops per iteration)
+      const int inx = (int)floorf(nextx);
+      const int iny = (int)floorf(nexty);
       // inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h
       if ((unsigned)inx + (unsigned)WIN >= (unsigned)(LJ.w + WIN) || (unsigned)iny + (unsigned)WIN >= (unsigned)(LJ.h + WIN)) {
         if (level == 0) status = 0;
