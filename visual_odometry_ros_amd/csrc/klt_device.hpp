@@ -336,8 +336,9 @@ __device__ __forceinline__ KltResult klt_point(const vo_level *I, const vo_level
     // (J sample - template sample) for samples 2m, 2m+1 (each within +-8160)
     auto eval_diffs = [&](int inx, int iny, int w00, int w01, int w10, int w11, uint32_t (&dp)[NP]) {
       // window inside the staged tile <=> 0 <= inx - tjx <= slack_x and 0 <= iny - tjy <= slack_y
-      if ((unsigned)inx - (unsigned)tjx > (unsigned)(C::TJ_WD * 4 - 3 - C::SPAN - 1) ||
-          (unsigned)iny - (unsigned)tjy > (unsigned)(C::TJ_H - WIN - 1)) {
+      if (__builtin_expect((unsigned)inx - (unsigned)tjx > (unsigned)(C::TJ_WD * 4 - 3 - C::SPAN - 1) ||
+                               (unsigned)iny - (unsigned)tjy > (unsigned)(C::TJ_H - WIN - 1),
+                           0)) {
         tjx = (inx - C::M) & ~3;
         tjy = iny - C::M;
         const uint8_t *g = LJ.origin() + (ptrdiff_t)tjy * LJ.stride + tjx;
@@ -388,7 +389,7 @@ __device__ __forceinline__ KltResult klt_point(const vo_level *I, const vo_level
       const int inx = (int)floorf(nextx);
       const int iny = (int)floorf(nexty);
       // inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h
-      if ((unsigned)inx + (unsigned)WIN >= (unsigned)(LJ.w + WIN) || (unsigned)iny + (unsigned)WIN >= (unsigned)(LJ.h + WIN)) {
+      if (__builtin_expect((unsigned)inx + (unsigned)WIN >= (unsigned)(LJ.w + WIN) || (unsigned)iny + (unsigned)WIN >= (unsigned)(LJ.h + WIN), 0)) {
         if (level == 0) status = 0;
         break;
       }
@@ -416,10 +417,10 @@ __device__ __forceinline__ KltResult klt_point(const vo_level *I, const vo_level
       nexty += dy;
       npx = nextx + halfWin;
       npy = nexty + halfWin;
-      if ((double)dx * dx + (double)dy * dy <= epsilon) break;
+      if (__builtin_expect((double)dx * dx + (double)dy * dy <= epsilon, 0)) break;
       // (double)|f| < 0.01 for a float f  <=>  |f| <= 0.01f : 0.01f = 0.00999999977... is the largest
       // float below 0.01 (the next one is 0.0100000007...)
-      if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
+      if (__builtin_expect(j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f, 0)) {
         npx -= dx * 0.5f;
         npy -= dy * 0.5f;
         break;

@@ -274,7 +274,7 @@ __device__ __forceinline__ void wave_sum4_i32(int &a, int &b, int &c, int &d) {
 __device__ __forceinline__ void wave_sum2_i32_to_f32(int p, int q, float &fp, float &fq) {
   // When every lane's partials are below 2^25 in magnitude (the usual case) the 64-lane sums fit int32: two chains
   // instead of four, and (float)(int32) rounds once exactly like (float)(int64).
-  if (!__any((((unsigned)p + (1u << 25)) | ((unsigned)q + (1u << 25))) >> 26)) {
+  if (__builtin_expect(!__any((((unsigned)p + (1u << 25)) | ((unsigned)q + (1u << 25))) >> 26), 1)) {
 #define VO_STEP2I(EXPR_P, EXPR_Q) \
   {                               \
     const int tp = EXPR_P, tq = EXPR_Q; \
