@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define VO_HIP_ABI_VERSION 2
+#define VO_HIP_ABI_VERSION 3
 
 typedef enum {
   VO_OK = 0,
@@ -347,6 +347,14 @@ int vo_stereo_frame_enqueue_closed(vo_ctx *ctx, const vo_stereo_params *prm, int
                                    const float *pts_l0, const float *pts_r0, const float *Xp, const uint8_t *flags,
                                    int n, const float dT_prior[16], const vo_bin_params *bins, int table,
                                    int inputs_on_device);
+/* The closed frame on the reference's own data flow (stereo_vo.cpp:475-522, :595-613): Xw holds the landmarks in the
+ * WORLD frame (lm->get3DPoint()), T_pw = stframe_prev->getLeft()->getPoseInv(), T_cw_prior = inverseSE3_f(T_wp *
+ * dT_pc_prev), dT_prior = dT_pc_prev (the BA's initial value, :585). X_l1 = T_cw_prior X, the patch scale is
+ * (T_pw X)(2) / X_l1(2) and the BA takes Xp = T_pw X, each in Eigen's evaluation order of `R * X + t`. */
+int vo_stereo_frame_enqueue_closed_world(vo_ctx *ctx, const vo_stereo_params *prm, int slot_l0, int slot_l1, int slot_r1,
+                                         const float *pts_l0, const float *pts_r0, const float *Xw, const uint8_t *flags,
+                                         int n, const float dT_prior[16], const float T_pw[16], const float T_cw_prior[16],
+                                         const vo_bin_params *bins, int table, int inputs_on_device);
 /* after vo_stereo_frame_result of a closed frame: the candidates' left pixels (pts_l1_new; room for n_bins) */
 int vo_stereo_frame_new_points(vo_ctx *ctx, float *pts_new, int *n_new);
 
@@ -356,6 +364,72 @@ int vo_stereo_frame_new_points(vo_ctx *ctx, float *pts_new, int *n_new);
 int vo_stereo_frame_result(vo_ctx *ctx, float *pts_l1, float *pts_r1, uint8_t *stage,
                            float dT[16], float *pts_new_r, uint8_t *mask_new,
                            vo_frame_counts *counts, vo_gn_info *gn);
+
+/* ---- StereoVO: the closed loop around the frame ---------------------------------------------------------------
+ * StereoVO::trackStereoImages (core/visual_odometry/stereo_vo/stereo_vo.cpp:392-989, class surface stereo_vo.h:233-249)
+ * with the track set carried ON THE DEVICE from frame to frame: what enters frame k+1 is what frame k left behind —
+ * lmtrack_final (the stage-4 survivors in index order, :670) followed by the new landmarks of step [10] (:714-739:
+ * trackBidirection mask and both DLT depths positive, mapping::triangulateDLT = core/util/triangulate_3d.cpp:91-130
+ * with Eigen's 4x4 JacobiSVD restated), landmark ids from the context's counter (landmark.cpp:29), the previous pose
+ * and the constant-velocity prior (:475-480, frame.cpp:50-54), the keyframe rule (keyframes.cpp:217-303) and, at a
+ * keyframe, the reconstruction of lmtrack_final (:763-797) and the local bundle adjustment over the keyframe window
+ * (:802 -> motion_estimator.cpp:1207-1340, sparse_ba_parameters.h:292-466, sparse_bundle_adjustment.cpp:624-722).
+ * The first pair is the reference's initialisation (:842-949). The host sees one small result block per frame.
+ * Needs a context with >= 5 image slots (previous left, current pair, next pair) and prm.frame.win in {13,15,21,31}. */
+typedef struct vo_svo vo_svo;
+typedef struct {
+  vo_stereo_params frame;   /* Camera.*, feature_tracker.*, motion_estimator.thres_poseba_error */
+  vo_bin_params bins;       /* feature_extractor.* as FeatureExtractor::initParams derives them */
+  float kf_overlap_ratio;   /* keyframe_update.thres_alive_ratio   (StereoKeyframes::setThresOverlapRatio) */
+  float kf_rotation_deg;    /* keyframe_update.thres_rotation      (degrees; the reference multiplies by D2R) */
+  float kf_translation;     /* keyframe_update.thres_trans */
+  int kf_window;            /* keyframe_update.n_max_keyframes_in_window */
+  int strict_border;        /* vo_stereo_frame_set_strict_border */
+  int local_ba;             /* != 0: localBundleAdjustmentSparseSolver_Stereo at every keyframe (the reference's behaviour) */
+} vo_svo_params;
+typedef struct {
+  int frame_id;             /* id of the left Frame of this pair (the right one is frame_id + 1, frame.cpp:176-180) */
+  int is_first, is_keyframe, lba_ran;
+  int n_tracks_in;          /* size of the track set that entered the frame */
+  int n_final;              /* lmtrack_final.n_pts: stage-4 survivors */
+  int n_new;                /* landmarks created in step [10] */
+  int n_tracks_out;         /* n_final + n_new: the next frame's track set */
+  int n_kf_tracked;         /* survivors that belong to the last keyframe (numerator of the overlap ratio) */
+  int n_new_candidates;     /* candidates step [10] extracted (bins left empty that hold a keypoint) */
+  vo_frame_counts counts;
+  vo_gn_info gn;
+  float dT[16];             /* dT_pc_poBA */
+  float T_wc[16];           /* pose of the left camera after this call (after the local BA at a keyframe) */
+  double lba_err_first, lba_err_last; /* average pixel error of the local BA's first / last iteration */
+  int lba_landmarks, lba_observations;
+} vo_svo_frame_info;
+int vo_svo_create(vo_ctx *ctx, const vo_svo_params *prm, vo_svo **out);
+void vo_svo_destroy(vo_svo *svo);
+/* StereoVO::trackStereoImages(img_left, img_right, timestamp): synchronous. Images: tightly addressed u8, `stride`
+ * bytes per row; device pointers when on_device != 0, else host pointers (pinned memory gives a true asynchronous
+ * copy). Errors: VO_ERR_GN_FAILED = the reference's throw "PoseOnlyStereoBA is failed!" (:626), VO_ERR_LBA_NAN. */
+int vo_svo_track(vo_svo *svo, const void *left, const void *right, int stride, int on_device, double timestamp,
+                 vo_svo_frame_info *info);
+/* The same in two halves, so that a caller that already holds the NEXT pair (a recorded sequence) can hand it over
+ * while this frame is in flight: vo_svo_enqueue(k); vo_svo_prefetch(k+1); vo_svo_result(k). The prefetch builds the
+ * pair's pyramids and the per-bin candidate table on the side stream; the following vo_svo_enqueue / vo_svo_track with
+ * the SAME two pointers uses them (other pointers: the prefetch is dropped and the pair is ingested as usual). Host
+ * buffers of a prefetched pair must stay untouched until that pair's frame has returned. */
+int vo_svo_enqueue(vo_svo *svo, const void *left, const void *right, int stride, int on_device, double timestamp);
+int vo_svo_prefetch(vo_svo *svo, const void *left, const void *right, int stride, int on_device);
+int vo_svo_result(vo_svo *svo, vo_svo_frame_info *info);
+/* The track set the next frame will start from (stframe_prev_'s pts seen + related landmarks): ids, left / right
+ * pixels, world points, flags (VO_LM_TRIANGULATED, VO_LM_DROPPED, VO_LM_KF_MEMBER). Any pointer may be NULL; *n
+ * receives the size. A device-to-host copy with a synchronisation: a test / inspection hook, not part of the loop. */
+#define VO_LM_KF_MEMBER 4
+int vo_svo_get_tracks(vo_svo *svo, int32_t *ids, float *pts_l, float *pts_r, float *Xw, uint8_t *flags, int cap, int *n);
+/* step [10] of the last frame: the extracted candidates (left / right pixels, trackBidirection mask) and which of them
+ * became landmarks (stereo_vo.cpp:716-725). Capacity n_bins each. */
+int vo_svo_get_new_points(vo_svo *svo, float *pts_l, float *pts_r, uint8_t *mask_new, uint8_t *accept, int *n);
+/* mapping::triangulateDLT (triangulate_3d.cpp:91-130) for n pixel pairs on the device: X0 (first camera), X1 = R10 X0 +
+ * t10. T_10 row-major 4x4 (e.g. T_rl); K0 / K1 = fx, fy, cx, cy. */
+int vo_triangulate_dlt(vo_ctx *ctx, const float *pts0, const float *pts1, int n, const float T_10[16], const float K0[4],
+                       const float K1[4], float *X0, float *X1);
 
 /* ---- undistortion / stereo rectification in front of the trackers ----------
  * core/visual_odometry/camera.cpp. A context holds the maps of two cameras

@@ -400,7 +400,8 @@ def mono_frame(prm, I0, I1, pts0, Xw, flags, Tcw_prev, Tcw_prior, dT01_prior, su
 
 
 def stereo_frame(prm, I0l, I1l, I1r, pts_l0, pts_r0, Xp, dT_prior, pts_new, sum_mode=SUM_TREE,
-                 tree_width=512, ic_border_mode=IC_MASKED, n_threads=1, lm_flags=None):
+                 tree_width=512, ic_border_mode=IC_MASKED, n_threads=1, lm_flags=None, T_pw=None, T_cw_prior=None):
+    """T_pw / T_cw_prior given: the reference's own data flow — Xp holds WORLD points (vo_ref_stereo_frame_world)."""
     I0l, w, h, st = _img(I0l)
     I1l, _, _, _ = _img(I1l)
     I1r, _, _, _ = _img(I1r)
@@ -419,14 +420,75 @@ def stereo_frame(prm, I0l, I1l, I1r, pts_l0, pts_r0, Xp, dT_prior, pts_new, sum_
     dTp = _f32(dT_prior).reshape(16)
     fl = None if lm_flags is None else np.ascontiguousarray(lm_flags, np.uint8)
     assert fl is None or fl.shape[0] == n
-    rc = lib().vo_ref_stereo_frame(
-        C.byref(prm), _p(I0l, C.c_uint8), _p(I1l, C.c_uint8), _p(I1r, C.c_uint8), st, _p(pts_l0),
-        _p(Xp), None if fl is None else _p(fl, C.c_uint8), n, _p(dTp), _p(pts_new), nn, sum_mode, tree_width,
-        ic_border_mode, n_threads,
-        _p(pts_l1), _p(pts_r1), _p(stage, C.c_uint8), _p(dT), _p(pnr), _p(mnew, C.c_uint8),
-        C.byref(counts))
+    if T_pw is not None:
+        rc = lib().vo_ref_stereo_frame_world(
+            C.byref(prm), _p(I0l, C.c_uint8), _p(I1l, C.c_uint8), _p(I1r, C.c_uint8), st, _p(pts_l0),
+            _p(Xp), None if fl is None else _p(fl, C.c_uint8), n, _p(dTp), _p(_f32(T_pw).reshape(16)),
+            _p(_f32(T_cw_prior).reshape(16)), _p(pts_new), nn, sum_mode, tree_width, ic_border_mode, n_threads,
+            _p(pts_l1), _p(pts_r1), _p(stage, C.c_uint8), _p(dT), _p(pnr), _p(mnew, C.c_uint8), C.byref(counts))
+    else:
+        rc = lib().vo_ref_stereo_frame(
+            C.byref(prm), _p(I0l, C.c_uint8), _p(I1l, C.c_uint8), _p(I1r, C.c_uint8), st, _p(pts_l0),
+            _p(Xp), None if fl is None else _p(fl, C.c_uint8), n, _p(dTp), _p(pts_new), nn, sum_mode, tree_width,
+            ic_border_mode, n_threads,
+            _p(pts_l1), _p(pts_r1), _p(stage, C.c_uint8), _p(dT), _p(pnr), _p(mnew, C.c_uint8),
+            C.byref(counts))
     return dict(rc=rc, pts_l1=pts_l1[:n], pts_r1=pts_r1[:n], stage=stage[:n], dT=dT.reshape(4, 4),
                 pts_new_r=pnr[:nn], mask_new=mnew[:nn].astype(bool), counts=counts)
+
+
+# ---- the loop around the frame (oracle_vo.c) ----
+def mul44(A, B):
+    """Matrix4f * Matrix4f in Eigen's evaluation order (stereo_vo.cpp:479, :640)."""
+    out = np.zeros(16, np.float32)
+    lib().vo_ref_mul44(_p(_f32(A).reshape(16)), _p(_f32(B).reshape(16)), _p(out))
+    return out.reshape(4, 4)
+
+
+def inverse4x4(T):
+    out = np.zeros(16, np.float32)
+    lib().vo_ref_inverse4x4(_p(_f32(T).reshape(16)), _p(out))
+    return out.reshape(4, 4)
+
+
+def jacobi_svd4(M):
+    """JacobiSVD<MatrixXf>(M, ComputeFullV) of a 4x4: (V, singular values, sweeps)."""
+    V, sv = np.zeros(16, np.float32), np.zeros(4, np.float32)
+    sweeps = lib().vo_ref_jacobi_svd4(_p(_f32(M).reshape(16)), _p(V), _p(sv))
+    return V.reshape(4, 4), sv, sweeps
+
+
+def triangulate_dlt(pt0, pt1, R10, t10, K0, K1):
+    """mapping::triangulateDLT, two-camera overload (triangulate_3d.cpp:91-130): (X0, X1)."""
+    X0, X1 = np.zeros(3, np.float32), np.zeros(3, np.float32)
+    lib().vo_ref_triangulate_dlt(_p(_f32(pt0).reshape(2)), _p(_f32(pt1).reshape(2)), _p(_f32(R10).reshape(9)),
+                                 _p(_f32(t10).reshape(3)), _p(_f32(K0)), _p(_f32(K1)), _p(X0), _p(X1))
+    return X0, X1
+
+
+def new_landmark_accept(pts_l, pts_r, mask_new, T_rl, Kl, Kr):
+    """stereo_vo.cpp:714-739: (accept, Xl) for the candidates of step [10]."""
+    pts_l, pts_r = _f32(pts_l).reshape(-1, 2), _f32(pts_r).reshape(-1, 2)
+    n = pts_l.shape[0]
+    m = np.ascontiguousarray(mask_new, np.uint8)
+    acc, Xl = np.zeros(max(n, 1), np.uint8), np.zeros((max(n, 1), 3), np.float32)
+    if n:
+        lib().vo_ref_new_landmark_accept(_p(pts_l), _p(pts_r), _p(m, C.c_uint8), n, _p(_f32(T_rl).reshape(16)), _p(_f32(Kl)),
+                                         _p(_f32(Kr)), _p(acc, C.c_uint8), _p(Xl))
+    return acc[:n].astype(bool), Xl[:n]
+
+
+def keyframe_reconstruct(pts_l, pts_r, T_rl, Kl, Kr, T_wc, Xw):
+    """stereo_vo.cpp:763-797 (T_wc = None: the first frame, :907-941): (Xw updated, set mask)."""
+    pts_l, pts_r = _f32(pts_l).reshape(-1, 2), _f32(pts_r).reshape(-1, 2)
+    n = pts_l.shape[0]
+    X = np.zeros((max(n, 1), 3), np.float32)
+    X[:n] = _f32(Xw).reshape(-1, 3)
+    st = np.zeros(max(n, 1), np.uint8)
+    if n:
+        lib().vo_ref_keyframe_reconstruct(_p(pts_l), _p(pts_r), n, _p(_f32(T_rl).reshape(16)), _p(_f32(Kl)), _p(_f32(Kr)),
+                                          None if T_wc is None else _p(_f32(T_wc).reshape(16)), _p(X), _p(st, C.c_uint8))
+    return X[:n], st[:n].astype(bool)
 
 
 STAGE_NAMES = ("prior", "klt_l0l1", "track_with_scale", "klt_l1r1", "pose_only_ba", "gates_compactions", "klt_new_points")

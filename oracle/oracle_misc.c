@@ -127,16 +127,20 @@ void vo_ref_stereo_frame_stage_ms(double out[8]) { memcpy(out, g_stage_ms, sizeo
     t_stage = now_;                                \
   } while (0)
 
-int vo_ref_stereo_frame(const vo_ref_stereo_params *prm, const uint8_t *I0l,
+/* world != 0: the reference's own data flow (stereo_vo.cpp:475-522, :595-613) — Xp holds the landmarks in the WORLD
+ * frame, T_pw = stframe_prev->getLeft()->getPoseInv(), T_cw_prior = inverseSE3_f(T_wp * dT_pc_prev); X_l1 = T_cw_prior X,
+ * X_l0 = T_pw X (patch scale and the BA's Xp), with Eigen's evaluation order of `R * X + t` (vo_ref_xform_eig). */
+static int stereo_frame_impl(const vo_ref_stereo_params *prm, const uint8_t *I0l,
                         const uint8_t *I1l, const uint8_t *I1r, int stride,
                         const float *pts_l0, const float *Xp, const uint8_t *lm_flags, int n,
-                        const float dT_prior[16], const float *pts_new,
+                        const float dT_prior[16], const float *T_pw, const float *T_cw_prior, const float *pts_new,
                         int n_new, int sum_mode, int tree_width,
                         int ic_border_mode, int n_threads, float *pts_l1,
                         float *pts_r1, uint8_t *stage_mask, float dT_out[16],
                         float *pts_new_r, uint8_t *mask_new,
                         vo_ref_frame_counts *counts) {
   const int W = prm->width, H = prm->height;
+  const int world = T_pw != NULL;
   float T_rl[16], T_cp[16];
   vo_ref_inverse_se3(prm->T_lr, T_rl);
   vo_ref_inverse_se3(dT_prior, T_cp);
@@ -163,9 +167,17 @@ int vo_ref_stereo_frame(const vo_ref_stereo_params *prm, const uint8_t *I0l,
       continue;
     }
     float Xl1[3], Xr1[3];
-    xform(T_cp, Xp + 3 * i, Xl1);
-    xform(T_rl, Xl1, Xr1);
-    scale[i] = Xp[3 * i + 2] / Xl1[2];
+    if (world) {
+      float Xl0[3];
+      vo_ref_xform_eig(T_cw_prior, Xp + 3 * i, Xl1); /* :493 */
+      vo_ref_xform_eig(T_rl, Xl1, Xr1);              /* :494 */
+      vo_ref_xform_eig(T_pw, Xp + 3 * i, Xl0);       /* :497 */
+      scale[i] = Xl0[2] / Xl1[2];
+    } else {
+      xform(T_cp, Xp + 3 * i, Xl1);
+      xform(T_rl, Xl1, Xr1);
+      scale[i] = Xp[3 * i + 2] / Xl1[2];
+    }
     float plx, ply, prx, pry;
     project(prm->Kl, Xl1, &plx, &ply);
     project(prm->Kr, Xr1, &prx, &pry);
@@ -263,9 +275,13 @@ int vo_ref_stereo_frame(const vo_ref_stereo_params *prm, const uint8_t *I0l,
     a0[2 * nba + 1] = pts_l1[2 * o + 1];
     a2[2 * nba] = pts_r1[2 * o];
     a2[2 * nba + 1] = pts_r1[2 * o + 1];
-    aX[3 * nba] = Xp[3 * o];
-    aX[3 * nba + 1] = Xp[3 * o + 1];
-    aX[3 * nba + 2] = Xp[3 * o + 2];
+    if (world) {
+      vo_ref_xform_eig(T_pw, Xp + 3 * o, aX + 3 * nba); /* :605 Xp = T_pw * X */
+    } else {
+      aX[3 * nba] = Xp[3 * o];
+      aX[3 * nba + 1] = Xp[3 * o + 1];
+      aX[3 * nba + 2] = Xp[3 * o + 2];
+    }
     ++nba;
   }
   counts->n_ba = nba;
@@ -315,6 +331,28 @@ fail:
   free(aX);
   free(as);
   return rc;
+}
+
+int vo_ref_stereo_frame(const vo_ref_stereo_params *prm, const uint8_t *I0l, const uint8_t *I1l, const uint8_t *I1r,
+                        int stride, const float *pts_l0, const float *Xp, const uint8_t *lm_flags, int n,
+                        const float dT_prior[16], const float *pts_new, int n_new, int sum_mode, int tree_width,
+                        int ic_border_mode, int n_threads, float *pts_l1, float *pts_r1, uint8_t *stage_mask,
+                        float dT_out[16], float *pts_new_r, uint8_t *mask_new, vo_ref_frame_counts *counts) {
+  return stereo_frame_impl(prm, I0l, I1l, I1r, stride, pts_l0, Xp, lm_flags, n, dT_prior, NULL, NULL, pts_new, n_new,
+                           sum_mode, tree_width, ic_border_mode, n_threads, pts_l1, pts_r1, stage_mask, dT_out, pts_new_r,
+                           mask_new, counts);
+}
+
+int vo_ref_stereo_frame_world(const vo_ref_stereo_params *prm, const uint8_t *I0l, const uint8_t *I1l, const uint8_t *I1r,
+                              int stride, const float *pts_l0, const float *Xw, const uint8_t *lm_flags, int n,
+                              const float dT_prior[16], const float T_pw[16], const float T_cw_prior[16],
+                              const float *pts_new, int n_new, int sum_mode, int tree_width, int ic_border_mode,
+                              int n_threads, float *pts_l1, float *pts_r1, uint8_t *stage_mask, float dT_out[16],
+                              float *pts_new_r, uint8_t *mask_new, vo_ref_frame_counts *counts) {
+  if (!T_pw || !T_cw_prior) return -1;
+  return stereo_frame_impl(prm, I0l, I1l, I1r, stride, pts_l0, Xw, lm_flags, n, dT_prior, T_pw, T_cw_prior, pts_new, n_new,
+                           sum_mode, tree_width, ic_border_mode, n_threads, pts_l1, pts_r1, stage_mask, dT_out, pts_new_r,
+                           mask_new, counts);
 }
 
 /* ---- epipolar gates ---------------------------------------------------

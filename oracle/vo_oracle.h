@@ -172,6 +172,27 @@ int vo_ref_stereo_frame(const vo_ref_stereo_params *prm, const uint8_t *I0l,
                         float dT_out[16], float *pts_new_r, uint8_t *mask_new,
                         vo_ref_frame_counts *counts);
 
+/* The same frame on the reference's own data flow (stereo_vo.cpp:475-522, :595-613): landmarks in the WORLD frame,
+ * T_pw = pose inverse of the previous left frame, T_cw_prior = inverseSE3_f(T_wp * dT_pc_prev); dT_prior = dT_pc_prev. */
+int vo_ref_stereo_frame_world(const vo_ref_stereo_params *prm, const uint8_t *I0l, const uint8_t *I1l, const uint8_t *I1r,
+                              int stride, const float *pts_l0, const float *Xw, const uint8_t *lm_flags, int n,
+                              const float dT_prior[16], const float T_pw[16], const float T_cw_prior[16],
+                              const float *pts_new, int n_new, int sum_mode, int tree_width, int ic_border_mode,
+                              int n_threads, float *pts_l1, float *pts_r1, uint8_t *stage_mask, float dT_out[16],
+                              float *pts_new_r, uint8_t *mask_new, vo_ref_frame_counts *counts);
+
+/* ---- the loop around the frame (oracle_vo.c) ---- */
+void vo_ref_mul44(const float A[16], const float B[16], float C[16]);
+void vo_ref_xform_eig(const float T[16], const float X[3], float Y[3]);
+int vo_ref_jacobi_svd4(const float M[16], float V[16], float sv[4]);
+void vo_ref_dlt_projection(const float K1[4], const float R10[9], const float t10[3], float P10[12]);
+int vo_ref_triangulate_dlt(const float pt0[2], const float pt1[2], const float R10[9], const float t10[3],
+                           const float K0[4], const float K1[4], float X0[3], float X1[3]);
+int vo_ref_new_landmark_accept(const float *pts_l, const float *pts_r, const uint8_t *mask_new, int n,
+                               const float T_rl[16], const float Kl[4], const float Kr[4], uint8_t *accept, float *Xl_out);
+int vo_ref_keyframe_reconstruct(const float *pts_l, const float *pts_r, int n, const float T_rl[16], const float Kl[4],
+                                const float Kr[4], const float *T_wc, float *Xw, uint8_t *set);
+
 /* per-stage wall clock (ms) of the last vo_ref_stereo_frame call: priors, KLT l0->l1, trackWithScale, KLT l1->r1, BA,
  * gates + compactions, new-point tracking */
 void vo_ref_stereo_frame_stage_ms(double out[8]);

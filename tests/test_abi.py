@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(vo):
     assert not missing, missing
     from visual_odometry_ros_amd import _capi
     assert sorted(_capi.SYMBOLS) == declared
-    assert lib.vo_abi_version() == 2
+    assert lib.vo_abi_version() == 3
 
 
 def test_pyramid_level_rule_host_side(vo, oracle):

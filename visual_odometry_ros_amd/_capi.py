@@ -68,6 +68,20 @@ class SbaProblem(C.Structure):
                 ("T_lr", C.c_double * 16), ("thres_huber", C.c_double)]
 
 
+class SvoParams(C.Structure):
+    _fields_ = [("frame", StereoParams), ("bins", BinParams), ("kf_overlap_ratio", C.c_float),
+                ("kf_rotation_deg", C.c_float), ("kf_translation", C.c_float), ("kf_window", C.c_int),
+                ("strict_border", C.c_int), ("local_ba", C.c_int)]
+
+
+class SvoFrameInfo(C.Structure):
+    _fields_ = [("frame_id", C.c_int), ("is_first", C.c_int), ("is_keyframe", C.c_int), ("lba_ran", C.c_int),
+                ("n_tracks_in", C.c_int), ("n_final", C.c_int), ("n_new", C.c_int), ("n_tracks_out", C.c_int),
+                ("n_kf_tracked", C.c_int), ("n_new_candidates", C.c_int), ("counts", FrameCounts), ("gn", GnInfo),
+                ("dT", C.c_float * 16), ("T_wc", C.c_float * 16), ("lba_err_first", C.c_double),
+                ("lba_err_last", C.c_double), ("lba_landmarks", C.c_int), ("lba_observations", C.c_int)]
+
+
 # every symbol include/vo_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "vo_abi_version", "vo_device_count", "vo_create", "vo_destroy", "vo_last_error", "vo_stream",
@@ -86,6 +100,8 @@ SYMBOLS = [
     "vo_set_stereo_pair_device", "vo_set_pyramid_window_hint",
     "vo_set_ingest_side_stream", "vo_set_stereo_pair_host_async", "vo_new_point_candidates_enqueue",
     "vo_new_point_candidates_get", "vo_stereo_frame_enqueue_closed", "vo_stereo_frame_new_points",
+    "vo_stereo_frame_enqueue_closed_world", "vo_svo_create", "vo_svo_destroy", "vo_svo_track", "vo_svo_enqueue",
+    "vo_svo_prefetch", "vo_svo_result", "vo_svo_get_tracks", "vo_svo_get_new_points", "vo_triangulate_dlt",
     "vo_se3_exp", "vo_ids_reset", "vo_ids_peek", "vo_ids_new_frames", "vo_ids_new_landmarks", "vo_compact_tracks",
 ]
 
@@ -122,5 +138,17 @@ def load():
     lib.vo_mono_frame_enqueue_closed.argtypes = [vp, C.POINTER(MonoParams), ci, ci, vp, vp, vp, ci, vp, vp, vp,
                                                  C.POINTER(BinParams), ci, ci]
     lib.vo_mono_frame_new_points.argtypes = [vp, vp, vp, vp, vp]
+    lib.vo_stereo_frame_enqueue_closed_world.argtypes = [vp, C.POINTER(StereoParams), ci, ci, ci, vp, vp, vp, vp, ci, vp, vp,
+                                                         vp, C.POINTER(BinParams), ci, ci]
+    lib.vo_svo_create.argtypes = [vp, C.POINTER(SvoParams), C.POINTER(C.c_void_p)]
+    lib.vo_svo_destroy.argtypes = [vp]
+    lib.vo_svo_destroy.restype = None
+    lib.vo_svo_track.argtypes = [vp, vp, vp, ci, ci, C.c_double, C.POINTER(SvoFrameInfo)]
+    lib.vo_svo_enqueue.argtypes = [vp, vp, vp, ci, ci, C.c_double]
+    lib.vo_svo_prefetch.argtypes = [vp, vp, vp, ci, ci]
+    lib.vo_svo_result.argtypes = [vp, C.POINTER(SvoFrameInfo)]
+    lib.vo_svo_get_tracks.argtypes = [vp, vp, vp, vp, vp, vp, ci, vp]
+    lib.vo_svo_get_new_points.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.vo_triangulate_dlt.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp]
     _lib = lib
     return lib

@@ -14,8 +14,8 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import (BinParams, FrameCounts, GnInfo, MonoCounts, MonoParams, OrbParams, SbaProblem, StereoParams, VoConfig,
-                    VoError)
+from ._capi import (BinParams, FrameCounts, GnInfo, MonoCounts, MonoParams, OrbParams, SbaProblem, StereoParams,
+                    SvoFrameInfo, SvoParams, VoConfig, VoError)
 
 KLT_USE_INITIAL_FLOW = 4
 GN_CORE, GN_STANDALONE = 0, 1
@@ -675,6 +675,142 @@ class StereoFramePipeline:
             out = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in out.items()}
             out["counts"], out["gn"] = cnt, gn
         return out
+
+
+    def enqueue_closed_world(self, pts_l0, pts_r0, Xw, dT_prior, T_pw, T_cw_prior, bins, table, slots=(0, 1, 2), lm_flags=None):
+        """enqueue_closed on the reference's own data flow (stereo_vo.cpp:475-522): Xw = landmarks in the WORLD frame,
+        T_pw = previous pose inverse, T_cw_prior = inverseSE3_f(T_wp * dT_pc_prev)."""
+        pts_l0, pts_r0 = _f32(pts_l0).reshape(-1, 2), _f32(pts_r0).reshape(-1, 2)
+        Xw = _f32(Xw).reshape(-1, 3)
+        dT, Tp, Tc = _f32(dT_prior).reshape(16), _f32(T_pw).reshape(16), _f32(T_cw_prior).reshape(16)
+        self._n, self._nn = pts_l0.shape[0], bins.n_bins_u * bins.n_bins_v
+        self._closed = True
+        fl = None
+        if lm_flags is not None:
+            fl = _u8(lm_flags).reshape(-1)
+            if fl.shape[0] != self._n:
+                raise ValueError("lm_flags.size() != pts_l0.size()")
+        self.ctx.check(self.lib.vo_stereo_frame_enqueue_closed_world(
+            self.ctx.handle, self.prm, slots[0], slots[1], slots[2], pts_l0.ctypes.data, pts_r0.ctypes.data,
+            Xw.ctypes.data, fl.ctypes.data if fl is not None else None, self._n, dT.ctypes.data, Tp.ctypes.data,
+            Tc.ctypes.data, bins, table, 0))
+
+
+def triangulateDLT(ctx, pts0, pts1, T_10, K0, K1):
+    """mapping::triangulateDLT (core/util/triangulate_3d.cpp:91-130) for n pixel pairs: (X0, X1 = R10 X0 + t10)."""
+    pts0, pts1 = _f32(pts0).reshape(-1, 2), _f32(pts1).reshape(-1, 2)
+    if pts0.shape[0] != pts1.shape[0]:
+        raise VoError(-4, "pts0.size() != pts1.size()")  # triangulate_3d.cpp:9-10
+    n = pts0.shape[0]
+    X0, X1 = np.zeros((max(n, 1), 3), np.float32), np.zeros((max(n, 1), 3), np.float32)
+    T, K0, K1 = _f32(T_10).reshape(16), _f32(K0).reshape(4), _f32(K1).reshape(4)
+    ctx.check(ctx.lib.vo_triangulate_dlt(ctx.handle, pts0.ctypes.data, pts1.ctypes.data, n, T.ctypes.data, K0.ctypes.data,
+                                         K1.ctypes.data, X0.ctypes.data, X1.ctypes.data))
+    return X0[:n], X1[:n]
+
+
+class StereoVO:
+    """StereoVO (core/visual_odometry/stereo_vo/stereo_vo.h:233-249): trackStereoImages with the track set carried on
+    the device (include/vo_hip.h: vo_svo_*). The YAML loading of the reference's constructor is the caller's: the
+    parameters arrive as numbers. The context needs >= 5 image slots."""
+
+    def __init__(self, ctx, width, height, Kl, Kr, T_lr, n_bins_u, n_bins_v, thres_fastscore=15, window_size=21, max_level=6,
+                 thres_error=80.0, thres_bidirection=0.5, thres_poseba_error=3.0, thres_alive_ratio=0.6, thres_rotation=15.0,
+                 thres_trans=10.0, n_max_keyframes_in_window=9, strict_border=4, local_ba=True):
+        self.ctx, self.lib = ctx, ctx.lib
+        fe = FeatureExtractor(ctx)
+        fe.initParams(width, height, n_bins_u, n_bins_v, THRES_FAST=thres_fastscore)
+        p = SvoParams()
+        p.frame = make_stereo_params(width, height, window_size, max_level, thres_error, thres_bidirection, thres_poseba_error,
+                                     Kl, Kr, T_lr)
+        p.bins = fe.binParams()
+        p.kf_overlap_ratio, p.kf_rotation_deg, p.kf_translation = thres_alive_ratio, thres_rotation, thres_trans
+        p.kf_window, p.strict_border, p.local_ba = n_max_keyframes_in_window, int(strict_border), int(bool(local_ba))
+        self.prm, self.width, self.height = p, width, height
+        self._h = C.c_void_p()
+        ctx.check(self.lib.vo_svo_create(ctx.handle, C.byref(p), C.byref(self._h)))
+        self._info = SvoFrameInfo()
+        self.stats_frame = []  # AlgorithmStatistics::FrameStatistics::Twc per frame (stereo_vo.cpp:979-980)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.vo_svo_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _ptrs(left, right):
+        if isinstance(left, np.ndarray):
+            left, right = _u8(left), _u8(right)
+            if left.ndim != 2 or left.shape != right.shape:
+                raise ValueError("images must be two u8 planes of one size")
+            return left, right, left.ctypes.data, right.ctypes.data, left.strides[0], 0
+        return left, right, int(left[0]), int(right[0]), int(left[1]), 1  # (device address, stride) pairs
+
+    def _out(self):
+        i = self._info
+        T = np.array(i.T_wc, np.float32).reshape(4, 4)
+        self.stats_frame.append(T)
+        return i
+
+    def trackStereoImages(self, img_left, img_right, timestamp=0.0):
+        """numpy u8 images (host) or (device address, stride) pairs. Returns the frame's SvoFrameInfo."""
+        a, b, pl, pr, st, dev = self._ptrs(img_left, img_right)
+        self._keep = (a, b)
+        rc = self.lib.vo_svo_track(self._h, pl, pr, st, dev, float(timestamp), self._info)
+        if rc < 0:
+            self.ctx.check(rc)
+        return self._out()
+
+    def enqueue(self, img_left, img_right, timestamp=0.0):
+        a, b, pl, pr, st, dev = self._ptrs(img_left, img_right)
+        self._keep = (a, b)
+        rc = self.lib.vo_svo_enqueue(self._h, pl, pr, st, dev, float(timestamp))
+        if rc < 0:
+            self.ctx.check(rc)
+
+    def prefetch(self, img_left, img_right):
+        a, b, pl, pr, st, dev = self._ptrs(img_left, img_right)
+        self._keep_next = (a, b)
+        rc = self.lib.vo_svo_prefetch(self._h, pl, pr, st, dev)
+        if rc < 0:
+            self.ctx.check(rc)
+
+    def result(self):
+        rc = self.lib.vo_svo_result(self._h, self._info)
+        if rc < 0:
+            self.ctx.check(rc)
+        return self._out()
+
+    def getTracks(self):
+        """The track set the next frame starts from: dict(ids, pts_l, pts_r, Xw, flags)."""
+        n = C.c_int()
+        self.ctx.check(self.lib.vo_svo_get_tracks(self._h, None, None, None, None, None, 0, C.addressof(n)))
+        m = max(n.value, 1)
+        ids, pl, pr = np.zeros(m, np.int32), np.zeros((m, 2), np.float32), np.zeros((m, 2), np.float32)
+        X, fl = np.zeros((m, 3), np.float32), np.zeros(m, np.uint8)
+        self.ctx.check(self.lib.vo_svo_get_tracks(self._h, ids.ctypes.data, pl.ctypes.data, pr.ctypes.data, X.ctypes.data,
+                                                  fl.ctypes.data, m, C.addressof(n)))
+        k = n.value
+        return dict(ids=ids[:k], pts_l=pl[:k], pts_r=pr[:k], Xw=X[:k], flags=fl[:k])
+
+    def getNewPoints(self):
+        """Step [10] of the last frame: dict(pts_l, pts_r, mask_new, accept)."""
+        nb = self.prm.bins.n_bins_u * self.prm.bins.n_bins_v
+        pl, pr = np.zeros((nb, 2), np.float32), np.zeros((nb, 2), np.float32)
+        m, a, n = np.zeros(nb, np.uint8), np.zeros(nb, np.uint8), C.c_int()
+        self.ctx.check(self.lib.vo_svo_get_new_points(self._h, pl.ctypes.data, pr.ctypes.data, m.ctypes.data, a.ctypes.data,
+                                                      C.addressof(n)))
+        k = n.value
+        return dict(pts_l=pl[:k], pts_r=pr[:k], mask_new=m[:k].astype(bool), accept=a[:k].astype(bool))
+
+    def getStatistics(self):
+        return dict(stats_frame=[T.copy() for T in self.stats_frame])
 
 
 def make_mono_params(width, height, win, max_level, thres_err, thres_bidir, thres_poseba, thres_sampson, K):

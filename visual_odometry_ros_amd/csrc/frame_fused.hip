@@ -38,6 +38,8 @@ struct FrameArgs {
   const float *Xp, *pts_l0, *pts_r0;
   const uint8_t *lm_flags;     // [n] bit 0 = lm->isTriangulated(); null = every landmark is
   float T_cp[16], T_rl[16], Kl[4], Kr[4];
+  int world;        // the reference's own data flow (stereo_vo.cpp:475-522): Xp holds WORLD points, T_cp = T_cw_prior =
+  float T_pw2[4];   // inverseSE3_f(T_wp * dT_pc_prev), T_pw2 = row 2 of T_pw (X_l0(2) of the patch scale, :497-498)
   int W, H;
   float thres_err;
   int strict;
@@ -157,13 +159,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRAME_WAVES_
     if (!a.lm_flags || (a.lm_flags[i] & VO_LM_TRIANGULATED)) {
       const float *Xi = a.Xp + 3 * i;
       float Xl[3], Xr[3];
+      if (a.world) {
+        // `R * X + t` on fixed-size Eigen types: the product first, its 3-term dot products as e0 + (e1 + e2), then + t
 #pragma unroll
-      for (int r = 0; r < 3; ++r)
-        Xl[r] = ((a.T_cp[r * 4 + 0] * Xi[0] + a.T_cp[r * 4 + 1] * Xi[1]) + a.T_cp[r * 4 + 2] * Xi[2]) + a.T_cp[r * 4 + 3];
+        for (int r = 0; r < 3; ++r)
+          Xl[r] = (a.T_cp[r * 4 + 0] * Xi[0] + (a.T_cp[r * 4 + 1] * Xi[1] + a.T_cp[r * 4 + 2] * Xi[2])) + a.T_cp[r * 4 + 3];
 #pragma unroll
-      for (int r = 0; r < 3; ++r)
-        Xr[r] = ((a.T_rl[r * 4 + 0] * Xl[0] + a.T_rl[r * 4 + 1] * Xl[1]) + a.T_rl[r * 4 + 2] * Xl[2]) + a.T_rl[r * 4 + 3];
-      scale = Xi[2] / Xl[2];
+        for (int r = 0; r < 3; ++r)
+          Xr[r] = (a.T_rl[r * 4 + 0] * Xl[0] + (a.T_rl[r * 4 + 1] * Xl[1] + a.T_rl[r * 4 + 2] * Xl[2])) + a.T_rl[r * 4 + 3];
+        const float Xl0z = (a.T_pw2[0] * Xi[0] + (a.T_pw2[1] * Xi[1] + a.T_pw2[2] * Xi[2])) + a.T_pw2[3];
+        scale = Xl0z / Xl[2];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+          Xl[r] = ((a.T_cp[r * 4 + 0] * Xi[0] + a.T_cp[r * 4 + 1] * Xi[1]) + a.T_cp[r * 4 + 2] * Xi[2]) + a.T_cp[r * 4 + 3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+          Xr[r] = ((a.T_rl[r * 4 + 0] * Xl[0] + a.T_rl[r * 4 + 1] * Xl[1]) + a.T_rl[r * 4 + 2] * Xl[2]) + a.T_rl[r * 4 + 3];
+        scale = Xi[2] / Xl[2];
+      }
       const float izl = 1.0f / Xl[2], izr = 1.0f / Xr[2];
       plx = a.Kl[0] * Xl[0] * izl + a.Kl[2];
       ply = a.Kl[1] * Xl[1] * izl + a.Kl[3];
@@ -500,7 +514,7 @@ int vo_frame_fused_supported(int win) { return win == 13 || win == 15 || win == 
 int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, int slot_l1, int slot_r1,
                            const float *d_l0, const float *d_r0, const float *d_X, const uint8_t *d_flags, int n,
                            const float T_cp[16], const float T_rl[16], const float *d_new, int n_new,
-                           const vo_frame_fused_bufs &b, int phase) {
+                           const vo_frame_fused_bufs &b, int phase, const float *T_pw) {
   if (n <= 0) return VO_OK;
   const int slots[3] = {slot_l0, slot_l1, slot_r1};
   for (int s : slots)
@@ -547,6 +561,8 @@ int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, 
   a.lm_flags = d_flags;
   memcpy(a.T_cp, T_cp, sizeof(a.T_cp));
   memcpy(a.T_rl, T_rl, sizeof(a.T_rl));
+  a.world = T_pw ? 1 : 0;
+  if (T_pw) memcpy(a.T_pw2, T_pw + 8, sizeof(a.T_pw2));
   memcpy(a.Kl, prm->Kl, sizeof(a.Kl));
   memcpy(a.Kr, prm->Kr, sizeof(a.Kr));
   a.W = prm->width;

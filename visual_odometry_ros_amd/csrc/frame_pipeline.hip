@@ -112,11 +112,15 @@ extern "C" int vo_stereo_frame_set_strict_border(vo_ctx *c, int strict) {
 
 // bp != null: the closed step [10] — the candidates are the per-bin best keypoints of table `table`
 // (vo_new_point_candidates_enqueue), all tracked speculatively, emitted by the BA launch's epilogue
-static int frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, int slot_l1, int slot_r1,
-                              const float *pts_l0, const float *pts_r0, const float *Xp, const uint8_t *flags, int n,
-                              const float dT_prior[16], const float *pts_new, int n_new, int inputs_on_device,
-                              const vo_bin_params *bp, int table) {
+// T_pw / T_cw_prior != null: the reference's own data flow — Xp holds WORLD points (vo_stereo_frame_enqueue_closed_world)
+int vo_frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, int slot_l1, int slot_r1,
+                          const float *pts_l0, const float *pts_r0, const float *Xp, const uint8_t *flags, int n,
+                          const float dT_prior[16], const float *pts_new, int n_new, int inputs_on_device,
+                          const vo_bin_params *bp, int table, const float *T_pw, const float *T_cw_prior) {
   if (!c || !prm || !dT_prior || n < 0 || n_new < 0) return VO_ERR_INVALID;
+  if ((T_pw != nullptr) != (T_cw_prior != nullptr)) return VO_ERR_INVALID;
+  if (T_pw && !vo_frame_fused_supported(prm->win))
+    VO_FAIL(c, VO_ERR_INVALID, "world-frame landmarks need a window the fused frame kernel is built for (13, 15, 21, 31)");
   const vo_cand_table *tab = nullptr;
   if (bp) {
     if (n <= 0) VO_FAIL(c, VO_ERR_INVALID, "the closed step [10] needs a track set (the first frame is the caller's)");
@@ -226,6 +230,7 @@ static int frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l
   float T_rl[16], T_cp[16];
   inv_se3(prm->T_lr, T_rl);
   inv_se3(dT_prior, T_cp);
+  if (T_cw_prior) memcpy(T_cp, T_cw_prior, sizeof(T_cp));  // world points: X_l1 = T_cw_prior * X (stereo_vo.cpp:493)
 
   if (n_new > 0 && !fused) VO_CHECK_HIP(c, hipEventRecord(c->ev_fork, s));  // the new pyramids are enqueued before this point
 
@@ -259,9 +264,9 @@ static int frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l
     b.cand_has = tab ? tab->has : nullptr;
     // [10] the new-point candidates are extra workgroups of the same launch
     VO_TT("setup");
-    RC(vo_frame_fused_enqueue(c, prm, slot_l0, slot_l1, slot_r1, d_l0, d_r0, d_X, d_fl, n, T_cp, T_rl, d_new, n_new, b, 0));
+    RC(vo_frame_fused_enqueue(c, prm, slot_l0, slot_l1, slot_r1, d_l0, d_r0, d_X, d_fl, n, T_cp, T_rl, d_new, n_new, b, 0, T_pw));
     VO_TT("track launch");
-    RC(vo_frame_fused_enqueue(c, prm, slot_l0, slot_l1, slot_r1, d_l0, d_r0, d_X, d_fl, n, T_cp, T_rl, d_new, n_new, b, 1));
+    RC(vo_frame_fused_enqueue(c, prm, slot_l0, slot_l1, slot_r1, d_l0, d_r0, d_X, d_fl, n, T_cp, T_rl, d_new, n_new, b, 1, T_pw));
     VO_TT("phase1");
   } else if (n > 0) {
     // general window sizes: one launch per step, compaction in between
@@ -372,6 +377,7 @@ static int frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l
     gf.stage = f->stage;
     gf.lm_flags = d_fl;
     gf.X = d_X;
+    gf.T_pw = T_pw;
     gf.pl1 = f->F_pl1;
     gf.pr1 = f->F_pr1;
     gf.C_X = f->C_X;
@@ -436,8 +442,8 @@ extern "C" int vo_stereo_frame_enqueue(vo_ctx *c, const vo_stereo_params *prm, i
                                        int slot_r1, const float *pts_l0, const float *pts_r0, const float *Xp,
                                        const uint8_t *flags, int n, const float dT_prior[16], const float *pts_new,
                                        int n_new, int inputs_on_device) {
-  return frame_enqueue_impl(c, prm, slot_l0, slot_l1, slot_r1, pts_l0, pts_r0, Xp, flags, n, dT_prior, pts_new, n_new,
-                            inputs_on_device, nullptr, 0);
+  return vo_frame_enqueue_impl(c, prm, slot_l0, slot_l1, slot_r1, pts_l0, pts_r0, Xp, flags, n, dT_prior, pts_new, n_new,
+                               inputs_on_device, nullptr, 0, nullptr, nullptr);
 }
 
 extern "C" int vo_stereo_frame_enqueue_closed(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, int slot_l1,
@@ -445,8 +451,18 @@ extern "C" int vo_stereo_frame_enqueue_closed(vo_ctx *c, const vo_stereo_params 
                                               const uint8_t *flags, int n, const float dT_prior[16],
                                               const vo_bin_params *bins, int table, int inputs_on_device) {
   if (!bins) return VO_ERR_INVALID;
-  return frame_enqueue_impl(c, prm, slot_l0, slot_l1, slot_r1, pts_l0, pts_r0, Xp, flags, n, dT_prior, nullptr, 0,
-                            inputs_on_device, bins, table);
+  return vo_frame_enqueue_impl(c, prm, slot_l0, slot_l1, slot_r1, pts_l0, pts_r0, Xp, flags, n, dT_prior, nullptr, 0,
+                               inputs_on_device, bins, table, nullptr, nullptr);
+}
+
+extern "C" int vo_stereo_frame_enqueue_closed_world(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, int slot_l1,
+                                                    int slot_r1, const float *pts_l0, const float *pts_r0, const float *Xw,
+                                                    const uint8_t *flags, int n, const float dT_prior[16],
+                                                    const float T_pw[16], const float T_cw_prior[16],
+                                                    const vo_bin_params *bins, int table, int inputs_on_device) {
+  if (!bins || !T_pw || !T_cw_prior) return VO_ERR_INVALID;
+  return vo_frame_enqueue_impl(c, prm, slot_l0, slot_l1, slot_r1, pts_l0, pts_r0, Xw, flags, n, dT_prior, nullptr, 0,
+                               inputs_on_device, bins, table, T_pw, T_cw_prior);
 }
 
 extern "C" int vo_stereo_frame_new_points(vo_ctx *c, float *pts_new, int *n_new) {

@@ -58,6 +58,8 @@ struct GnArgs {
   const uint8_t *f_stage;   // [f_n]
   const uint8_t *f_lmflags; // [f_n] stereo: bit 0 = landmark triangulated (null: all); the BA set is stage 3 && triangulated
   const float *f_X, *f_pl1, *f_pr1;
+  int f_world;              // f_X holds world points: the BA set takes T_pw * X (stereo_vo.cpp:605), f_Tpw = rows 0..2 of T_pw
+  float f_Tpw[12];
   float *f_CX, *f_Cpl1, *f_Cpr1;
   int32_t *f_Corig;
   int *f_cnt;               // [6]: three step counts, replayed features, size of the BA set, new-point candidates emitted
@@ -491,6 +493,12 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
         gx[q][0] = a.f_X[3 * ii];
         gx[q][1] = a.f_X[3 * ii + 1];
         gx[q][2] = a.f_X[3 * ii + 2];
+        if (a.f_world) {  // Xp = T_pw.block<3,3>(0,0) * X + T_pw.block<3,1>(0,3): 3-term dot products as e0 + (e1 + e2)
+          const float x0 = gx[q][0], x1 = gx[q][1], x2 = gx[q][2];
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+            gx[q][r] = (a.f_Tpw[r * 4 + 0] * x0 + (a.f_Tpw[r * 4 + 1] * x1 + a.f_Tpw[r * 4 + 2] * x2)) + a.f_Tpw[r * 4 + 3];
+        }
         gl[q][0] = a.f_pl1[2 * ii];
         gl[q][1] = a.f_pl1[2 * ii + 1];
         gr[q][0] = a.f_pr1 ? a.f_pr1[2 * ii] : 0.f;
@@ -862,6 +870,10 @@ int vo_gn_enqueue(vo_ctx *c, bool stereo, bool mono_general_inverse, const float
     a.f_stage = frame->stage;
     a.f_lmflags = frame->lm_flags;
     a.f_X = frame->X;
+    if (frame->T_pw) {
+      a.f_world = 1;
+      memcpy(a.f_Tpw, frame->T_pw, sizeof(a.f_Tpw));
+    }
     a.f_pl1 = frame->pl1;
     a.f_pr1 = frame->pr1;
     a.f_CX = frame->C_X;

@@ -1,0 +1,858 @@
+// stereo_vo.hip — the closed loop of StereoVO::trackStereoImages around the frame operator, track set on the device.
+//
+// Reference (paths relative to the reference repository root):
+//   core/visual_odometry/stereo_vo/stereo_vo.cpp:392-989   trackStereoImages
+//     :465-480   [1] the previous frame's track set, [2] constant-velocity prior T_wp * dT_pc_prev
+//     :483-670   [3]-[7]                                      -> frame_fused.hip / gn_pose.hip (world-frame landmarks)
+//     :691-711   [10] updateWeightBin / extract / trackBidirection -> closed on the device (orb_detect.hip, np_emit.hpp)
+//     :714-739   new landmarks: mask_new && Xl(2) > 0 && Xr(2) > 0      -> svo_advance_kernel
+//     :752       setStereoPtsSeenAndRelatedLandmarks: the next track set -> svo_advance_kernel
+//     :755-797   keyframe rule + reconstruction of lmtrack_final        -> host (rule) + svo_keyframe_kernel
+//     :802       local bundle adjustment                                -> svo_local_ba (sba.hip)
+//     :842-949   the very first pair
+//   core/util/triangulate_3d.cpp:91-130   mapping::triangulateDLT (Eigen::JacobiSVD<MatrixXf>, ComputeFullV, restated)
+//   core/visual_odometry/keyframes.cpp:185-303  addNewStereoKeyframe, checkUpdateRule
+//   core/visual_odometry/frame.cpp:44-54, :176-196  setPose / setPoseDiff10 / StereoFrame ids
+//   core/visual_odometry/landmark.cpp:28-52   Landmark id = landmark_counter_++ (per context here)
+//
+// Data on the device: two track sets (current / next) of {left pixel, right pixel, world point, flags, id}; a frame reads
+// one and svo_advance_kernel writes the other behind the BA launch: survivors (stage 4) in index order, then the
+// accepted new points in bin order with ids id_base + rank. The host receives one 48-byte block per frame (counts) next to
+// the frame operator's result block, chains the pose (two 4x4 products and two inverses in the reference's order), applies
+// the keyframe rule and, at a keyframe, enqueues the reconstruction kernel on the next track set.
+#include "frame_state.hpp"
+#include "vo_kernels.hpp"
+
+#include <math.h>
+#include <stdlib.h>
+#include <time.h>
+
+#include <algorithm>
+#include <vector>
+
+int vo_frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, int slot_l1, int slot_r1,
+                          const float *pts_l0, const float *pts_r0, const float *Xp, const uint8_t *flags, int n,
+                          const float dT_prior[16], const float *pts_new, int n_new, int inputs_on_device,
+                          const vo_bin_params *bp, int table, const float *T_pw, const float *T_cw_prior);
+int vo_svo_local_ba(struct vo_svo *s, vo_svo_frame_info *info);  // stereo_vo_lba.hip
+
+#define RC(x)                \
+  do {                       \
+    int _rc = (x);           \
+    if (_rc < 0) return _rc; \
+  } while (0)
+
+#include "stereo_vo.hpp"
+
+// ---- device: Eigen::JacobiSVD<MatrixXf>(M, ComputeFullV) of a 4x4 and the DLT around it -----------------------------
+// Same operations in the same order as oracle/oracle_vo.c (which says what of Eigen 3.4.0 it restates); one lane per
+// point, the two 4x4 matrices in registers (every index below is a compile-time constant after unrolling).
+__device__ __forceinline__ void svo_rot(float &x, float &y, float c, float s) {
+  const float xi = x, yi = y;
+  x = c * xi + s * yi;
+  y = -s * xi + c * yi;
+}
+
+// V's column that belongs to the smallest singular value, as JacobiSVD leaves it in column 3 after its sort
+__device__ void svo_svd4_nullvec(const float (&M)[16], float (&v)[4]) {
+  const float FMIN = 1.17549435e-38f, FEPS = 1.1920929e-07f, FMAX = 3.40282347e+38f;
+  float W[16], V[16];
+  float scale = 0.0f;
+  bool finite = true;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float a = fabsf(M[i]);
+    if (!(a <= FMAX)) finite = false;
+    if (a > scale) scale = a;
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) V[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+  if (!finite) {  // Eigen: InvalidInput, V unset; here the identity (as the oracle)
+    v[0] = v[1] = v[2] = 0.0f;
+    v[3] = 1.0f;
+    return;
+  }
+  if (scale == 0.0f) scale = 1.0f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) W[i] = M[i] / scale;
+  const float precision = 2.0f * FEPS;
+  float max_diag = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (fabsf(W[i * 5]) > max_diag) max_diag = fabsf(W[i * 5]);
+  for (int sweeps = 1;; ++sweeps) {
+    bool finished = true;
+#pragma unroll
+    for (int p = 1; p < 4; ++p)
+#pragma unroll
+      for (int q = 0; q < p; ++q) {
+        const float pm = precision * max_diag;
+        const float threshold = FMIN > pm ? FMIN : pm;
+        if (fabsf(W[p * 4 + q]) > threshold || fabsf(W[q * 4 + p]) > threshold) {
+          finished = false;
+          float m00 = W[p * 4 + p], m01 = W[p * 4 + q], m10 = W[q * 4 + p], m11 = W[q * 4 + q];
+          float c1, s1;
+          const float t = m00 + m11;
+          const float d = m10 - m01;
+          if (fabsf(d) < FMIN) {
+            s1 = 0.0f;
+            c1 = 1.0f;
+          } else {
+            const float u = t / d;
+            const float tmp = sqrtf(1.0f + u * u);
+            s1 = 1.0f / tmp;
+            c1 = u / tmp;
+          }
+          if (!(c1 == 1.0f && s1 == 0.0f)) {
+            svo_rot(m00, m10, c1, s1);
+            svo_rot(m01, m11, c1, s1);
+          }
+          // j_right.makeJacobi(m, 0, 1)
+          float cr, sr;
+          const float deno = 2.0f * fabsf(m01);
+          if (deno < FMIN) {
+            cr = 1.0f;
+            sr = 0.0f;
+          } else {
+            const float tau = (m00 - m11) / deno;
+            const float w = sqrtf(tau * tau + 1.0f);
+            float tt;
+            if (tau > 0.0f)
+              tt = 1.0f / (tau + w);
+            else
+              tt = 1.0f / (tau - w);
+            const float sign_t = tt > 0.0f ? 1.0f : -1.0f;
+            const float n = 1.0f / sqrtf(tt * tt + 1.0f);
+            sr = -sign_t * (m01 / fabsf(m01)) * fabsf(tt) * n;
+            cr = n;
+          }
+          // j_left = rot1 * j_right.transpose(); transpose = (c, -s)
+          const float ct = cr, st = -sr;
+          const float cl = c1 * ct - s1 * st;
+          const float sl = c1 * st + s1 * ct;
+          if (!(cl == 1.0f && sl == 0.0f)) {  // rows p and q of W
+#pragma unroll
+            for (int k = 0; k < 4; ++k) svo_rot(W[p * 4 + k], W[q * 4 + k], cl, sl);
+          }
+          if (!(ct == 1.0f && st == 0.0f)) {  // columns p and q of W and of V
+#pragma unroll
+            for (int k = 0; k < 4; ++k) svo_rot(W[k * 4 + p], W[k * 4 + q], ct, st);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) svo_rot(V[k * 4 + p], V[k * 4 + q], ct, st);
+          }
+          const float a = fabsf(W[p * 4 + p]), b = fabsf(W[q * 4 + q]);
+          const float mx = a > b ? a : b;
+          if (mx > max_diag) max_diag = mx;
+        }
+      }
+    if (finished || sweeps > 1000) break;
+  }
+  float sv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) sv[i] = fabsf(W[i * 5]) * scale;
+  // selection sort, descending, first of equal maxima; only the column that ends in position 3 is needed
+  int col[4] = {0, 1, 2, 3};
+  bool stop = false;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int pos = i;
+    float best = sv[i];
+#pragma unroll
+    for (int k = i + 1; k < 4; ++k)
+      if (sv[k] > best) {
+        best = sv[k];
+        pos = k;
+      }
+    if (best == 0.0f) stop = true;
+    if (!stop) {
+#pragma unroll
+      for (int k = i + 1; k < 4; ++k)
+        if (pos == k) {
+          const float ts = sv[i];
+          sv[i] = sv[k];
+          sv[k] = ts;
+          const int tc = col[i];
+          col[i] = col[k];
+          col[k] = tc;
+        }
+    }
+  }
+  const int c3 = col[3];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = c3 == 0 ? V[r * 4 + 0] : (c3 == 1 ? V[r * 4 + 1] : (c3 == 2 ? V[r * 4 + 2] : V[r * 4 + 3]));
+}
+
+// mapping::triangulateDLT(pt0, pt1, R10, t10, cam0, cam1, X0, X1), triangulate_3d.cpp:91-130
+__device__ void svo_triangulate(const SvoCam &cam, float u0, float v0, float u1, float v1, float (&X0)[3], float (&X1)[3]) {
+  float M[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) M[i] = 0.0f;
+  M[0] = -cam.K0[0];
+  M[5] = -cam.K0[1];
+  M[2] = u0 - cam.K0[2];
+  M[6] = v0 - cam.K0[3];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    M[8 + c] = u1 * cam.P10[8 + c] - cam.P10[0 + c];
+    M[12 + c] = v1 * cam.P10[8 + c] - cam.P10[4 + c];
+  }
+  float v[4];
+  svo_svd4_nullvec(M, v);
+  X0[0] = v[0] / v[3];
+  X0[1] = v[1] / v[3];
+  X0[2] = v[2] / v[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    X1[i] = (cam.R10[i * 3 + 0] * X0[0] + (cam.R10[i * 3 + 1] * X0[1] + cam.R10[i * 3 + 2] * X0[2])) + cam.t10[i];
+}
+
+__global__ void svo_dlt_kernel(SvoCam cam, const float *p0, const float *p1, int n, float *X0, float *X1) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float a[3], b[3];
+  svo_triangulate(cam, p0[2 * i], p0[2 * i + 1], p1[2 * i], p1[2 * i + 1], a, b);
+  for (int k = 0; k < 3; ++k) {
+    X0[3 * i + k] = a[k];
+    if (X1) X1[3 * i + k] = b[k];
+  }
+}
+
+// ---- device: the next track set --------------------------------------------------------------------------------------
+struct SvoAdvArgs {
+  int n;                 // features of the frame (input index space)
+  const uint8_t *stage;  // [n] 4 = in lmtrack_final
+  const float *pl1, *pr1;
+  SvoTrackSet cur, nxt;
+  const int *n_emit;     // candidates emitted by the closed step [10] (device word of the frame's header)
+  const float *new_l, *new_r;
+  const uint8_t *new_m;
+  uint8_t *accept;       // [n_emit] out: became a landmark
+  SvoCam cam;
+  int id_base, cap;
+  SvoHdr *hdr_dev, *hdr_host;
+  int seq;
+};
+
+#define SVO_T 1024
+__global__ __launch_bounds__(SVO_T) void svo_advance_kernel(SvoAdvArgs a) {
+  __shared__ int s_wv[SVO_T / 64];
+  __shared__ int s_kf;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n_emit = *a.n_emit;
+  if (tid == 0) s_kf = 0;
+  // [10] stereo_vo.cpp:714-725: a candidate becomes a landmark iff trackBidirection accepted it and both DLT depths are positive
+  for (int j = tid; j < n_emit; j += SVO_T) {
+    uint8_t acc = 0;
+    if (a.new_m[j]) {
+      float Xl[3], Xr[3];
+      svo_triangulate(a.cam, a.new_l[2 * j], a.new_l[2 * j + 1], a.new_r[2 * j], a.new_r[2 * j + 1], Xl, Xr);
+      acc = (Xl[2] > 0 && Xr[2] > 0) ? 1 : 0;
+    }
+    a.accept[j] = acc;
+  }
+  __syncthreads();
+  // lmtrack_final (:670): the stage-4 features in index order, with their landmarks
+  int base = 0, kf = 0, ovf = 0;
+  for (int c0 = 0; c0 < a.n; c0 += SVO_T) {
+    const int i = c0 + tid;
+    const bool keep = i < a.n && a.stage[i] == 4;
+    const uint8_t fl = keep ? a.cur.flags[i] : 0;
+    const unsigned long long bal = __ballot(keep);
+    const unsigned long long bkf = __ballot(keep && (fl & VO_LM_KF_MEMBER));
+    if (lane == 0) {
+      s_wv[wave] = __popcll(bal);
+      kf += __popcll(bkf);
+    }
+    __syncthreads();
+    int woff = 0, tot = 0;
+    for (int w = 0; w < SVO_T / 64; ++w) {
+      const int cw = s_wv[w];
+      woff += w < wave ? cw : 0;
+      tot += cw;
+    }
+    if (keep) {
+      const int o = base + woff + __popcll(bal & ((1ull << lane) - 1ull));
+      if (o < a.cap) {
+        a.nxt.pts_l[2 * o] = a.pl1[2 * i];
+        a.nxt.pts_l[2 * o + 1] = a.pl1[2 * i + 1];
+        a.nxt.pts_r[2 * o] = a.pr1[2 * i];
+        a.nxt.pts_r[2 * o + 1] = a.pr1[2 * i + 1];
+        a.nxt.Xw[3 * o] = a.cur.Xw[3 * i];
+        a.nxt.Xw[3 * o + 1] = a.cur.Xw[3 * i + 1];
+        a.nxt.Xw[3 * o + 2] = a.cur.Xw[3 * i + 2];
+        a.nxt.flags[o] = fl;
+        a.nxt.ids[o] = a.cur.ids[i];
+      }
+    }
+    base += tot;
+    __syncthreads();
+  }
+  if (lane == 0 && kf) atomicAdd(&s_kf, kf);
+  const int n_surv = base;
+  // the new landmarks (:729-734), candidate order; NOT triangulated (set3DPoint is commented out at :736)
+  for (int c0 = 0; c0 < n_emit; c0 += SVO_T) {
+    const int j = c0 + tid;
+    const bool keep = j < n_emit && a.accept[j];
+    const unsigned long long bal = __ballot(keep);
+    if (lane == 0) s_wv[wave] = __popcll(bal);
+    __syncthreads();
+    int woff = 0, tot = 0;
+    for (int w = 0; w < SVO_T / 64; ++w) {
+      const int cw = s_wv[w];
+      woff += w < wave ? cw : 0;
+      tot += cw;
+    }
+    if (keep) {
+      const int o = base + woff + __popcll(bal & ((1ull << lane) - 1ull));
+      if (o < a.cap) {
+        a.nxt.pts_l[2 * o] = a.new_l[2 * j];
+        a.nxt.pts_l[2 * o + 1] = a.new_l[2 * j + 1];
+        a.nxt.pts_r[2 * o] = a.new_r[2 * j];
+        a.nxt.pts_r[2 * o + 1] = a.new_r[2 * j + 1];
+        a.nxt.Xw[3 * o] = 0.0f;
+        a.nxt.Xw[3 * o + 1] = 0.0f;
+        a.nxt.Xw[3 * o + 2] = 0.0f;
+        a.nxt.flags[o] = 0;
+        a.nxt.ids[o] = a.id_base + (o - n_surv);
+      }
+    }
+    base += tot;
+    __syncthreads();
+  }
+  if (base > a.cap) ovf = 1;
+  if (tid == 0) {
+    SvoHdr h;
+    h.n_surv = n_surv;
+    h.n_kf_tracked = s_kf;
+    h.n_new = base - n_surv;
+    h.n_next = base;
+    h.n_emit = n_emit;
+    h.overflow = ovf;
+    h.seq = 0;
+    *a.hdr_dev = h;
+    int *d = (int *)a.hdr_host;
+    const int *sfrom = (const int *)&h;
+    for (int k = 0; k < (int)(sizeof(SvoHdr) / 4); ++k)
+      if (k != (int)(offsetof(SvoHdr, seq) / 4)) d[k] = sfrom[k];
+    __threadfence_system();
+    __hip_atomic_store(&a.hdr_host->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// keyframe: reconstruction of the first n_surv entries of the (next) track set, stereo_vo.cpp:763-797 (first frame:
+// :907-941, T_wc absent: Xworld = Xl), and every entry becomes a member of the new keyframe (keyframes.cpp:200-215)
+struct SvoKfArgs {
+  SvoTrackSet ts;
+  int n_surv, n_all;
+  SvoCam cam;
+  float Kl[4], Kr[4];
+  int member;  // every entry becomes a member of this (new) keyframe
+  int has_T;
+  float T_wc[12];
+  int *n_recon;  // may be null
+};
+__global__ void svo_keyframe_kernel(SvoKfArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n_all) return;
+  uint8_t fl = a.ts.flags[i] | (a.member ? VO_LM_KF_MEMBER : 0);
+  if (i < a.n_surv) {
+    const float pl[2] = {a.ts.pts_l[2 * i], a.ts.pts_l[2 * i + 1]}, pr[2] = {a.ts.pts_r[2 * i], a.ts.pts_r[2 * i + 1]};
+    float Xl[3], Xr[3];
+    svo_triangulate(a.cam, pl[0], pl[1], pr[0], pr[1], Xl, Xr);
+    // reprojection error in both images at most 1 px (camera.cpp:208-213 projectToPixel)
+    float iz = 1.0f / Xl[2];
+    float dx = pl[0] - (a.Kl[0] * Xl[0] * iz + a.Kl[2]), dy = pl[1] - (a.Kl[1] * Xl[1] * iz + a.Kl[3]);
+    bool ok = !(dx * dx + dy * dy > 1.0f);
+    iz = 1.0f / Xr[2];
+    dx = pr[0] - (a.Kr[0] * Xr[0] * iz + a.Kr[2]);
+    dy = pr[1] - (a.Kr[1] * Xr[1] * iz + a.Kr[3]);
+    ok = ok && !(dx * dx + dy * dy > 1.0f);
+    ok = ok && Xl[2] > 0 && Xr[2] > 0;
+    if (ok) {
+      float Xw[3] = {Xl[0], Xl[1], Xl[2]};
+      if (a.has_T) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+          Xw[r] = (a.T_wc[r * 4 + 0] * Xl[0] + (a.T_wc[r * 4 + 1] * Xl[1] + a.T_wc[r * 4 + 2] * Xl[2])) + a.T_wc[r * 4 + 3];
+      }
+      a.ts.Xw[3 * i] = Xw[0];
+      a.ts.Xw[3 * i + 1] = Xw[1];
+      a.ts.Xw[3 * i + 2] = Xw[2];
+      fl |= VO_LM_TRIANGULATED;
+      if (a.n_recon) atomicAdd(a.n_recon, 1);
+    }
+  }
+  a.ts.flags[i] = fl;
+}
+
+// ---- host: small fixed-size algebra in the reference's (Eigen's) evaluation order -------------------------------------
+void svo_mul44(const float A[16], const float B[16], float C[16]) {  // Matrix4f * Matrix4f: res = a0 b0; res = a_k b_k + res
+  float R[16];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      float r = A[i * 4 + 0] * B[0 * 4 + j];
+      for (int k = 1; k < 4; ++k) r = A[i * 4 + k] * B[k * 4 + j] + r;
+      R[i * 4 + j] = r;
+    }
+  memcpy(C, R, sizeof(R));
+}
+void svo_inv_se3(const float T[16], float Ti[16]) {  // geometry::inverseSE3_f
+  float Rt[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Rt[i * 3 + j] = T[j * 4 + i];
+  const float t[3] = {T[3], T[7], T[11]};
+  float R[16];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) R[i * 4 + j] = Rt[i * 3 + j];
+    R[i * 4 + 3] = ((-Rt[i * 3 + 0]) * t[0] + (-Rt[i * 3 + 1]) * t[1]) + (-Rt[i * 3 + 2]) * t[2];
+  }
+  R[12] = R[13] = R[14] = 0;
+  R[15] = 1;
+  memcpy(Ti, R, sizeof(R));
+}
+static void svo_inv44(const float m[16], float inv[16]) {  // Matrix4f::inverse() by cofactors (as gn_pose.hip, oracle_gn.c)
+  float s0 = m[0] * m[5] - m[4] * m[1], s1 = m[0] * m[6] - m[4] * m[2], s2 = m[0] * m[7] - m[4] * m[3];
+  float s3 = m[1] * m[6] - m[5] * m[2], s4 = m[1] * m[7] - m[5] * m[3], s5 = m[2] * m[7] - m[6] * m[3];
+  float c5 = m[10] * m[15] - m[14] * m[11], c4 = m[9] * m[15] - m[13] * m[11], c3 = m[9] * m[14] - m[13] * m[10];
+  float c2 = m[8] * m[15] - m[12] * m[11], c1 = m[8] * m[14] - m[12] * m[10], c0 = m[8] * m[13] - m[12] * m[9];
+  float det = ((s0 * c5 - s1 * c4) + s2 * c3 + s3 * c2 - s4 * c1) + s5 * c0;
+  float id = 1.0f / det;
+  float r[16];
+  r[0] = ((m[5] * c5 - m[6] * c4) + m[7] * c3) * id;
+  r[1] = ((-m[1] * c5 + m[2] * c4) - m[3] * c3) * id;
+  r[2] = ((m[13] * s5 - m[14] * s4) + m[15] * s3) * id;
+  r[3] = ((-m[9] * s5 + m[10] * s4) - m[11] * s3) * id;
+  r[4] = ((-m[4] * c5 + m[6] * c2) - m[7] * c1) * id;
+  r[5] = ((m[0] * c5 - m[2] * c2) + m[3] * c1) * id;
+  r[6] = ((-m[12] * s5 + m[14] * s2) - m[15] * s1) * id;
+  r[7] = ((m[8] * s5 - m[10] * s2) + m[11] * s1) * id;
+  r[8] = ((m[4] * c4 - m[5] * c2) + m[7] * c0) * id;
+  r[9] = ((-m[0] * c4 + m[1] * c2) - m[3] * c0) * id;
+  r[10] = ((m[12] * s4 - m[13] * s2) + m[15] * s0) * id;
+  r[11] = ((-m[8] * s4 + m[9] * s2) - m[11] * s0) * id;
+  r[12] = ((-m[4] * c3 + m[5] * c1) - m[6] * c0) * id;
+  r[13] = ((m[0] * c3 - m[1] * c1) + m[2] * c0) * id;
+  r[14] = ((-m[12] * s3 + m[13] * s1) - m[14] * s0) * id;
+  r[15] = ((m[8] * s3 - m[9] * s1) + m[10] * s0) * id;
+  memcpy(inv, r, sizeof(r));
+}
+static inline float dot3e(float a0, float b0, float a1, float b1, float a2, float b2) { return a0 * b0 + (a1 * b1 + a2 * b2); }
+
+static void svo_make_cam(const float T_10[16], const float K0[4], const float K1[4], SvoCam *cam) {
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) cam->R10[i * 3 + j] = T_10[i * 4 + j];
+    cam->t10[i] = T_10[i * 4 + 3];
+  }
+  // P10 << cam1->K() * R10, cam1->K() * t10 (triangulate_3d.cpp:104)
+  const float Km[9] = {K1[0], 0.0f, K1[2], 0.0f, K1[1], K1[3], 0.0f, 0.0f, 1.0f};
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j)
+      cam->P10[i * 4 + j] = dot3e(Km[i * 3 + 0], cam->R10[0 * 3 + j], Km[i * 3 + 1], cam->R10[1 * 3 + j], Km[i * 3 + 2], cam->R10[2 * 3 + j]);
+    cam->P10[i * 4 + 3] = dot3e(Km[i * 3 + 0], cam->t10[0], Km[i * 3 + 1], cam->t10[1], Km[i * 3 + 2], cam->t10[2]);
+  }
+  memcpy(cam->K0, K0, sizeof(cam->K0));
+  memcpy(cam->K1, K1, sizeof(cam->K1));
+}
+
+extern "C" int vo_triangulate_dlt(vo_ctx *c, const float *pts0, const float *pts1, int n, const float T_10[16],
+                                  const float K0[4], const float K1[4], float *X0, float *X1) {
+  if (!c || !pts0 || !pts1 || !T_10 || !K0 || !K1 || !X0 || n < 0) return VO_ERR_INVALID;
+  if (n > c->cfg.max_points) VO_FAIL(c, VO_ERR_CAPACITY, "n=%d exceeds vo_config.max_points=%d", n, c->cfg.max_points);
+  if (n == 0) return VO_OK;
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  SvoCam cam;
+  svo_make_cam(T_10, K0, K1, &cam);
+  hipStream_t s = c->stream;
+  VO_CHECK_HIP(c, hipMemcpyAsync(c->d_pts0, pts0, sizeof(float) * 2 * n, hipMemcpyHostToDevice, s));
+  VO_CHECK_HIP(c, hipMemcpyAsync(c->d_pts1, pts1, sizeof(float) * 2 * n, hipMemcpyHostToDevice, s));
+  float *dX0 = c->d_X, *dX1 = nullptr;
+  if (X1) {  // d_pts2 / d_pts3 are neighbours of 2n floats each only by accident: use a temporary for the second output
+    VO_CHECK_HIP(c, hipMalloc((void **)&dX1, sizeof(float) * 3 * n));
+  }
+  hipLaunchKernelGGL(svo_dlt_kernel, dim3((n + 63) / 64), dim3(64), 0, s, cam, c->d_pts0, c->d_pts1, n, dX0, dX1);
+  VO_CHECK_HIP(c, hipGetLastError());
+  VO_CHECK_HIP(c, hipMemcpyAsync(X0, dX0, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, s));
+  if (X1) VO_CHECK_HIP(c, hipMemcpyAsync(X1, dX1, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, s));
+  VO_CHECK_HIP(c, hipStreamSynchronize(s));
+  if (dX1) (void)hipFree(dX1);
+  return VO_OK;
+}
+
+// ---- host: the driver -------------------------------------------------------------------------------------------------
+static int svo_alloc_ts(vo_ctx *c, SvoTrackSet *t, int cap) {
+  VO_CHECK_HIP(c, hipMalloc((void **)&t->pts_l, sizeof(float) * 2 * cap));
+  VO_CHECK_HIP(c, hipMalloc((void **)&t->pts_r, sizeof(float) * 2 * cap));
+  VO_CHECK_HIP(c, hipMalloc((void **)&t->Xw, sizeof(float) * 3 * cap));
+  VO_CHECK_HIP(c, hipMalloc((void **)&t->flags, (size_t)cap));
+  VO_CHECK_HIP(c, hipMalloc((void **)&t->ids, sizeof(int32_t) * cap));
+  return VO_OK;
+}
+static void svo_free_ts(SvoTrackSet *t) {
+  void *b[] = {t->pts_l, t->pts_r, t->Xw, t->flags, t->ids};
+  for (void *p : b)
+    if (p) (void)hipFree(p);
+  memset(t, 0, sizeof(*t));
+}
+
+extern "C" int vo_svo_create(vo_ctx *c, const vo_svo_params *prm, vo_svo **out) {
+  if (!c || !prm || !out) return VO_ERR_INVALID;
+  *out = nullptr;
+  if (c->cfg.n_slots < 5) VO_FAIL(c, VO_ERR_INVALID, "StereoVO needs a context with at least 5 image slots");
+  if (!vo_frame_fused_supported(prm->frame.win))
+    VO_FAIL(c, VO_ERR_INVALID, "StereoVO needs a window the fused frame kernel is built for (13, 15, 21, 31)");
+  const int bins = prm->bins.n_bins_u * prm->bins.n_bins_v;
+  if (bins <= 0 || bins > c->cfg.max_points) VO_FAIL(c, VO_ERR_CAPACITY, "%d bins exceed vo_config.max_points=%d", bins, c->cfg.max_points);
+  if (prm->kf_window < 1) VO_FAIL(c, VO_ERR_INVALID, "kf_window must be at least 1");
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  vo_svo *s = new vo_svo();
+  s->c = c;
+  s->prm = *prm;
+  s->cap = c->cfg.max_points;
+  int rc = VO_OK;
+  for (int k = 0; k < 2 && rc == VO_OK; ++k) rc = svo_alloc_ts(c, &s->ts[k], s->cap);
+  if (rc == VO_OK && hipMalloc((void **)&s->d_accept, (size_t)s->cap) != hipSuccess) rc = VO_ERR_HIP;
+  if (rc == VO_OK && hipMalloc((void **)&s->d_hdr, sizeof(SvoHdr)) != hipSuccess) rc = VO_ERR_HIP;
+  if (rc == VO_OK && hipHostMalloc((void **)&s->h_hdr, sizeof(SvoHdr), hipHostMallocDefault) != hipSuccess) rc = VO_ERR_HIP;
+  if (rc != VO_OK) {
+    vo_svo_destroy(s);
+    VO_FAIL(c, rc, "StereoVO: device allocation failed");
+  }
+  memset(s->h_hdr, 0, sizeof(SvoHdr));
+  float T_rl[16];
+  svo_inv_se3(prm->frame.T_lr, T_rl);
+  memcpy(s->T_rl, T_rl, sizeof(T_rl));
+  svo_make_cam(T_rl, prm->frame.Kl, prm->frame.Kr, &s->cam);
+  for (int i = 0; i < 16; ++i) s->T_wp[i] = s->dT01[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+  s->kf_rot = prm->kf_rotation_deg * (float)(3.14159265358979323846 / 180.0);  // thres_rotation * D2R
+  s->first = true;
+  for (int k = 0; k < 5; ++k) s->slot[k] = k;
+  RC(vo_stereo_frame_set_strict_border(c, prm->strict_border));
+  RC(vo_set_pyramid_window_hint(c, prm->frame.win));
+  RC(vo_set_ingest_side_stream(c, 1));
+  *out = s;
+  return VO_OK;
+}
+
+extern "C" void vo_svo_destroy(vo_svo *s) {
+  if (!s) return;
+  if (s->c) (void)hipSetDevice(s->c->device);
+  for (int k = 0; k < 2; ++k) svo_free_ts(&s->ts[k]);
+  if (s->d_accept) (void)hipFree(s->d_accept);
+  if (s->d_hdr) (void)hipFree(s->d_hdr);
+  if (s->h_hdr) (void)hipHostFree(s->h_hdr);
+  delete s;
+}
+
+enum { S_P = 0, S_CL = 1, S_CR = 2, S_NL = 3, S_NR = 4 };
+
+// the pair into the "next" slots + its candidate table (side stream)
+static int svo_ingest(vo_svo *s, const void *left, const void *right, int stride, int on_device) {
+  vo_ctx *c = s->c;
+  const int W = s->prm.frame.width, H = s->prm.frame.height;
+  if (on_device)
+    RC(vo_set_stereo_pair_device(c, s->slot[S_NL], left, s->slot[S_NR], right, W, H, stride));
+  else
+    RC(vo_set_stereo_pair_host_async(c, s->slot[S_NL], (const uint8_t *)left, s->slot[S_NR], (const uint8_t *)right, W, H, stride));
+  RC(vo_new_point_candidates_enqueue(c, s->slot[S_NL], &s->prm.bins, s->tab_next));
+  return VO_OK;
+}
+
+extern "C" int vo_svo_prefetch(vo_svo *s, const void *left, const void *right, int stride, int on_device) {
+  if (!s || !left || !right) return VO_ERR_INVALID;
+  VO_CHECK_HIP(s->c, hipSetDevice(s->c->device));
+  RC(svo_ingest(s, left, right, stride, on_device));
+  s->pre_l = left;
+  s->pre_r = right;
+  s->prefetched = true;
+  return VO_OK;
+}
+
+static int svo_first_frame(vo_svo *s);
+
+extern "C" int vo_svo_enqueue(vo_svo *s, const void *left, const void *right, int stride, int on_device, double timestamp) {
+  if (!s || !left || !right) return VO_ERR_INVALID;
+  vo_ctx *c = s->c;
+  if (s->pending) VO_FAIL(c, VO_ERR_INVALID, "a frame is already in flight: call vo_svo_result first");
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  (void)timestamp;
+  if (!(s->prefetched && s->pre_l == left && s->pre_r == right)) RC(svo_ingest(s, left, right, stride, on_device));
+  s->prefetched = false;
+  {  // prev <- curr (stereo_vo.cpp:983-985), curr <- the pair just ingested; the two freed slots take the next pair
+    const int p = s->slot[S_P], cl = s->slot[S_CL], cr = s->slot[S_CR], nl = s->slot[S_NL], nr = s->slot[S_NR];
+    s->slot[S_P] = cl;
+    s->slot[S_CL] = nl;
+    s->slot[S_CR] = nr;
+    s->slot[S_NL] = p;
+    s->slot[S_NR] = cr;
+    s->tab_cur = s->tab_next;
+    s->tab_next ^= 1;
+  }
+  // StereoFrame(cam_left, cam_right, timestamp): two Frame ids, left first (frame.cpp:176-180)
+  s->frame_id = c->next_frame_id;
+  c->next_frame_id += 2;
+  s->pending = true;
+  s->pending_first = s->first;
+  if (s->first) return svo_first_frame(s);
+  if (s->n <= 0) VO_FAIL(c, VO_ERR_GN_FAILED, "the track set is empty: PoseOnlyStereoBA is failed!");
+  // [2] T_wc_prior = T_wp * dT_pc_prev; T_cw_prior = inverseSE3_f(T_wc_prior); T_pw = getPoseInv() (stereo_vo.cpp:475-480)
+  float T_wc_prior[16], T_cw_prior[16], T_pw[16];
+  svo_mul44(s->T_wp, s->dT01, T_wc_prior);
+  svo_inv_se3(T_wc_prior, T_cw_prior);
+  svo_inv_se3(s->T_wp, T_pw);
+  const SvoTrackSet &t = s->ts[s->cur];
+  int rc = vo_frame_enqueue_impl(c, &s->prm.frame, s->slot[S_P], s->slot[S_CL], s->slot[S_CR], t.pts_l, t.pts_r, t.Xw, t.flags,
+                                 s->n, s->dT01, nullptr, 0, 1, &s->prm.bins, s->tab_cur, T_pw, T_cw_prior);
+  if (rc < 0) {
+    s->pending = false;
+    return rc;
+  }
+  vo_frame_state *f = c->frame;
+  SvoAdvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.n = s->n;
+  a.stage = f->stage;
+  a.pl1 = f->F_pl1;
+  a.pr1 = f->F_pr1;
+  a.cur = t;
+  a.nxt = s->ts[s->cur ^ 1];
+  a.n_emit = &f->hdr->cnt[5];
+  a.new_l = (const float *)(f->res_dev + f->off_newl);
+  a.new_r = f->new_r;
+  a.new_m = f->mNew;
+  a.accept = s->d_accept;
+  a.cam = s->cam;
+  a.id_base = c->next_landmark_id;
+  a.cap = s->cap;
+  a.hdr_dev = s->d_hdr;
+  a.hdr_host = s->h_hdr;
+  s->seq = s->seq + 1 == 0 ? 1 : s->seq + 1;
+  a.seq = s->seq;
+  vo_prof_begin(c, VO_K_AUX);
+  hipLaunchKernelGGL(svo_advance_kernel, dim3(1), dim3(SVO_T), 0, c->stream, a);
+  vo_prof_end(c);
+  VO_CHECK_HIP(c, hipGetLastError());
+  return VO_OK;
+}
+
+// stereo_vo.cpp:842-949 — once per stream, composed of the operators (synchronous)
+static int svo_first_frame(vo_svo *s) {
+  vo_ctx *c = s->c;
+  const vo_svo_params &p = s->prm;
+  const int bins = p.bins.n_bins_u * p.bins.n_bins_v;
+  std::vector<float> xy(2 * (size_t)bins), cand, pr;
+  std::vector<uint8_t> has(bins), m;
+  // resetWeightBin + extractORBwithBinning_fast: every bin that holds a keypoint, bins ascending = the table
+  RC(vo_new_point_candidates_get(c, s->tab_cur, xy.data(), has.data(), nullptr));
+  for (int j = 0; j < bins; ++j)
+    if (has[j]) {
+      cand.push_back(xy[2 * j]);
+      cand.push_back(xy[2 * j + 1]);
+    }
+  const int nc = (int)(cand.size() / 2);
+  pr.assign(2 * (size_t)std::max(nc, 1), 0.f);
+  m.assign((size_t)std::max(nc, 1), 1);
+  if (nc > 0)
+    RC(vo_track_bidirection(c, s->slot[S_CL], s->slot[S_CR], cand.data(), nc, p.frame.win, p.frame.max_level, p.frame.thres_err,
+                            p.frame.thres_bidirection, pr.data(), m.data()));
+  std::vector<float> pl2, pr2;
+  for (int j = 0; j < nc; ++j)
+    if (m[j]) {
+      pl2.insert(pl2.end(), {cand[2 * j], cand[2 * j + 1]});
+      pr2.insert(pr2.end(), {pr[2 * j], pr[2 * j + 1]});
+    }
+  const int n = (int)(pl2.size() / 2);
+  if (n > s->cap) VO_FAIL(c, VO_ERR_CAPACITY, "%d initial landmarks exceed vo_config.max_points=%d", n, s->cap);
+  std::vector<int32_t> ids(std::max(n, 1));
+  for (int i = 0; i < n; ++i) ids[i] = c->next_landmark_id + i;  // Landmark(pt_left, frame): id = landmark_counter_++
+  c->next_landmark_id += n;
+  SvoTrackSet &t = s->ts[s->cur];
+  hipStream_t st = c->stream;
+  if (n > 0) {
+    VO_CHECK_HIP(c, hipMemcpyAsync(t.pts_l, pl2.data(), sizeof(float) * 2 * n, hipMemcpyHostToDevice, st));
+    VO_CHECK_HIP(c, hipMemcpyAsync(t.pts_r, pr2.data(), sizeof(float) * 2 * n, hipMemcpyHostToDevice, st));
+    VO_CHECK_HIP(c, hipMemcpyAsync(t.ids, ids.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
+    VO_CHECK_HIP(c, hipMemsetAsync(t.Xw, 0, sizeof(float) * 3 * n, st));
+    VO_CHECK_HIP(c, hipMemsetAsync(t.flags, 0, (size_t)n, st));
+    SvoKfArgs k;
+    memset(&k, 0, sizeof(k));
+    k.ts = t;
+    k.n_surv = n;
+    k.n_all = n;
+    k.cam = s->cam;
+    memcpy(k.Kl, p.frame.Kl, sizeof(k.Kl));
+    memcpy(k.Kr, p.frame.Kr, sizeof(k.Kr));
+    k.has_T = 0;
+    k.member = 0;  // the first frame is not a keyframe (no checkUpdateRule on this branch)
+    hipLaunchKernelGGL(svo_keyframe_kernel, dim3((n + 255) / 256), dim3(256), 0, st, k);
+    VO_CHECK_HIP(c, hipGetLastError());
+  }
+  VO_CHECK_HIP(c, hipStreamSynchronize(st));
+  s->n = n;
+  s->first_n_cand = nc;
+  // stframe_curr->setStereoPoseByLeft(Identity, T_lr); setPoseDiff10(Identity) -> dT01_ = inverseSE3_f(Identity)
+  float I[16];
+  for (int i = 0; i < 16; ++i) I[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+  memcpy(s->T_wp, I, sizeof(I));
+  svo_inv_se3(I, s->dT01);
+  s->first = false;
+  return VO_OK;
+}
+
+static double svo_now() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+// StereoKeyframes::checkUpdateRule, keyframes.cpp:217-303
+static bool svo_keyframe_rule(const vo_svo *s, int n_tracked, const float T_wc[16]) {
+  if (s->keyframes.empty()) return true;
+  const float ratio = (float)n_tracked / (float)s->n_kf_lms;
+  if (ratio <= s->prm.kf_overlap_ratio) return true;
+  float T_kw[16], dT[16];
+  svo_inv_se3(s->keyframes.back().T_wc, T_kw);  // getPoseInv() of the last keyframe (setPose: Tcw_ = inverseSE3_f(Twc_))
+  svo_mul44(T_kw, T_wc, dT);
+  float costheta = (((dT[0] + dT[5]) + dT[10]) - 1.0f) * 0.5f;
+  if ((double)costheta >= 0.999999) costheta = (float)0.999999;
+  if ((double)costheta <= -0.999999) costheta = (float)-0.999999;
+  const float rot = acosf(costheta);
+  const float dtrans = sqrtf(dT[3] * dT[3] + (dT[7] * dT[7] + dT[11] * dT[11]));
+  return rot >= s->kf_rot || dtrans >= s->prm.kf_translation;
+}
+
+extern "C" int vo_svo_result(vo_svo *s, vo_svo_frame_info *info) {
+  if (!s || !s->pending) return VO_ERR_INVALID;
+  vo_ctx *c = s->c;
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  vo_svo_frame_info I;
+  memset(&I, 0, sizeof(I));
+  I.frame_id = s->frame_id;
+  s->pending = false;
+  if (s->pending_first) {
+    I.is_first = 1;
+    I.n_new = I.n_tracks_out = s->n;
+    I.n_new_candidates = s->first_n_cand;
+    memcpy(I.T_wc, s->T_wp, sizeof(I.T_wc));
+    for (int i = 0; i < 16; ++i) I.dT[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+    if (info) *info = I;
+    return VO_OK;
+  }
+  // the advance kernel is the frame's last launch: its block's sequence word says that everything is there
+  {
+    volatile const int *seqp = &s->h_hdr->seq;
+    const double t0 = svo_now();
+    bool seen = false;
+    for (int spin = 0;; ++spin) {
+      if (*seqp == s->seq) {
+        seen = true;
+        break;
+      }
+      if ((spin & 255) == 255 && svo_now() - t0 > 2e-3) break;
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    if (!seen) VO_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  float dT[16];
+  int rc = vo_stereo_frame_result(c, nullptr, nullptr, nullptr, dT, nullptr, nullptr, &I.counts, &I.gn);
+  if (rc < 0) return rc;
+  const SvoHdr h = *s->h_hdr;
+  if (h.overflow) VO_FAIL(c, VO_ERR_CAPACITY, "the next track set (%d) exceeds vo_config.max_points=%d", h.n_next, s->cap);
+  I.n_tracks_in = s->n;
+  I.n_final = h.n_surv;
+  I.n_new = h.n_new;
+  I.n_tracks_out = h.n_next;
+  I.n_kf_tracked = h.n_kf_tracked;
+  I.n_new_candidates = h.n_emit;
+  memcpy(I.dT, dT, sizeof(dT));
+  c->next_landmark_id += h.n_new;
+  // T_wc = T_wp * dT_pc_poBA (:640); setPoseDiff10(dT.inverse()) -> dT01_ = inverseSE3_f(dT10) (:643, frame.cpp:50-54)
+  float T_wc[16], dT10[16];
+  svo_mul44(s->T_wp, dT, T_wc);
+  svo_inv44(dT, dT10);
+  svo_inv_se3(dT10, s->dT01);
+  const int nxt = s->cur ^ 1;
+  if (svo_keyframe_rule(s, h.n_kf_tracked, T_wc)) {
+    I.is_keyframe = 1;
+    SvoKfArgs k;
+    memset(&k, 0, sizeof(k));
+    k.ts = s->ts[nxt];
+    k.n_surv = h.n_surv;  // lmtrack_final.n_pts: the landmarks pushed in [10] are not reconstructed at this keyframe
+    k.n_all = h.n_next;
+    k.cam = s->cam;
+    memcpy(k.Kl, s->prm.frame.Kl, sizeof(k.Kl));
+    memcpy(k.Kr, s->prm.frame.Kr, sizeof(k.Kr));
+    k.has_T = 1;
+    k.member = 1;
+    memcpy(k.T_wc, T_wc, sizeof(k.T_wc));
+    if (h.n_next > 0) {
+      hipLaunchKernelGGL(svo_keyframe_kernel, dim3((h.n_next + 255) / 256), dim3(256), 0, c->stream, k);
+      VO_CHECK_HIP(c, hipGetLastError());
+    }
+    SvoKeyframe kf;
+    kf.serial = s->n_keyframes++;
+    kf.frame_id = s->frame_id;
+    memcpy(kf.T_wc, T_wc, sizeof(T_wc));
+    if ((int)s->keyframes.size() == s->prm.kf_window) s->keyframes.erase(s->keyframes.begin());
+    s->keyframes.push_back(kf);
+    s->n_kf_lms = h.n_next;
+    if (s->prm.local_ba) {
+      s->cur = nxt;  // (the local BA reads and updates the track set the next frame starts from)
+      s->n = h.n_next;
+      rc = vo_svo_local_ba(s, &I);
+      if (rc < 0) return rc;
+      memcpy(T_wc, s->keyframes.back().T_wc, sizeof(T_wc));
+    }
+  }
+  s->cur = nxt;
+  s->n = h.n_next;
+  memcpy(s->T_wp, T_wc, sizeof(T_wc));
+  memcpy(I.T_wc, T_wc, sizeof(T_wc));
+  if (info) *info = I;
+  return VO_OK;
+}
+
+extern "C" int vo_svo_track(vo_svo *s, const void *left, const void *right, int stride, int on_device, double timestamp,
+                            vo_svo_frame_info *info) {
+  RC(vo_svo_enqueue(s, left, right, stride, on_device, timestamp));
+  return vo_svo_result(s, info);
+}
+
+extern "C" int vo_svo_get_tracks(vo_svo *s, int32_t *ids, float *pts_l, float *pts_r, float *Xw, uint8_t *flags, int cap,
+                                 int *n) {
+  if (!s || !n) return VO_ERR_INVALID;
+  vo_ctx *c = s->c;
+  if (s->pending) VO_FAIL(c, VO_ERR_INVALID, "call vo_svo_result first");
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  *n = s->n;
+  if (s->n > cap && (ids || pts_l || pts_r || Xw || flags)) VO_FAIL(c, VO_ERR_CAPACITY, "%d tracks, room for %d", s->n, cap);
+  VO_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+  const SvoTrackSet &t = s->ts[s->cur];
+  const size_t m = (size_t)s->n;
+  if (m == 0) return VO_OK;
+  if (ids) VO_CHECK_HIP(c, hipMemcpy(ids, t.ids, sizeof(int32_t) * m, hipMemcpyDeviceToHost));
+  if (pts_l) VO_CHECK_HIP(c, hipMemcpy(pts_l, t.pts_l, sizeof(float) * 2 * m, hipMemcpyDeviceToHost));
+  if (pts_r) VO_CHECK_HIP(c, hipMemcpy(pts_r, t.pts_r, sizeof(float) * 2 * m, hipMemcpyDeviceToHost));
+  if (Xw) VO_CHECK_HIP(c, hipMemcpy(Xw, t.Xw, sizeof(float) * 3 * m, hipMemcpyDeviceToHost));
+  if (flags) VO_CHECK_HIP(c, hipMemcpy(flags, t.flags, m, hipMemcpyDeviceToHost));
+  return VO_OK;
+}
+
+extern "C" int vo_svo_get_new_points(vo_svo *s, float *pts_l, float *pts_r, uint8_t *mask_new, uint8_t *accept, int *n) {
+  if (!s || !n) return VO_ERR_INVALID;
+  vo_ctx *c = s->c;
+  if (s->pending) VO_FAIL(c, VO_ERR_INVALID, "call vo_svo_result first");
+  if (!c->frame || !c->frame->closed) VO_FAIL(c, VO_ERR_INVALID, "no steady-state frame has run yet");
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  vo_frame_state *f = c->frame;
+  const int m = s->h_hdr->n_emit;
+  *n = m;
+  if (m <= 0) return VO_OK;
+  if (pts_l) memcpy(pts_l, f->res_host + f->off_newl, sizeof(float) * 2 * (size_t)m);
+  if (pts_r) memcpy(pts_r, f->res_host + f->off_newr, sizeof(float) * 2 * (size_t)m);
+  if (mask_new) memcpy(mask_new, f->res_host + f->off_mnew, (size_t)m);
+  if (accept) VO_CHECK_HIP(c, hipMemcpy(accept, s->d_accept, (size_t)m, hipMemcpyDeviceToHost));
+  return VO_OK;
+}

@@ -1,0 +1,67 @@
+// stereo_vo.hpp — state of the StereoVO driver (stereo_vo.hip, stereo_vo_lba.hip)
+#pragma once
+#include <vector>
+
+#include "vo_internal.hpp"
+
+struct SvoCam {  // what mapping::triangulateDLT needs (triangulate_3d.cpp:91-130), pixel-independent part precomputed
+  float P10[12];  // [K1 * R10, K1 * t10], row-major 3x4
+  float R10[9], t10[3];
+  float K0[4], K1[4];
+};
+
+struct SvoTrackSet {  // device: stframe->getPtsSeen() (left / right) + related landmarks, one entry per landmark
+  float *pts_l, *pts_r;  // [cap][2]
+  float *Xw;             // [cap][3] lm->get3DPoint() (world frame)
+  uint8_t *flags;        // [cap] VO_LM_TRIANGULATED | VO_LM_DROPPED | VO_LM_KF_MEMBER
+  int32_t *ids;          // [cap] lm->getID()
+};
+
+struct SvoHdr {  // written by svo_advance_kernel: device copy and pinned host copy
+  int n_surv, n_kf_tracked, n_new, n_next, n_emit, overflow;
+  int seq;       // host copy: written last
+  int pad;
+};
+
+struct SvoObs {  // lm->getObservationsOnKeyframes() / getRelatedKeyframePtr(): one stereo keyframe
+  int serial;
+  float pl[2], pr[2];
+};
+struct SvoLandmark {  // landmarks that were seen on a keyframe (the local BA's population)
+  float X[3];
+  bool tri, alive;
+  std::vector<SvoObs> obs;
+};
+struct SvoKeyframe {
+  int serial, frame_id;
+  float T_wc[16];
+  std::vector<int32_t> ids;  // related landmarks (filled when the local BA is on)
+};
+
+struct vo_svo {
+  vo_ctx *c = nullptr;
+  vo_svo_params prm;
+  int cap = 0;
+  SvoTrackSet ts[2] = {};
+  int cur = 0, n = 0;
+  uint8_t *d_accept = nullptr;
+  SvoHdr *d_hdr = nullptr, *h_hdr = nullptr;
+  int seq = 0;
+  SvoCam cam;
+  float T_rl[16];
+  float T_wp[16], dT01[16];  // pose of the previous left frame; its getPoseDiff01()
+  float kf_rot = 0.f;
+  bool first = true, pending = false, pending_first = false, prefetched = false;
+  const void *pre_l = nullptr, *pre_r = nullptr;
+  int slot[5];
+  int tab_cur = 0, tab_next = 0;
+  int frame_id = 0, first_n_cand = 0;
+  // keyframes
+  std::vector<SvoKeyframe> keyframes;  // the window (stereo_kfs_list_)
+  int n_keyframes = 0, n_kf_lms = 0;
+  std::vector<SvoLandmark> lms;        // by landmark id (local BA on)
+  std::vector<uint8_t> lm_known;
+};
+
+void svo_mul44(const float A[16], const float B[16], float C[16]);
+void svo_inv_se3(const float T[16], float Ti[16]);

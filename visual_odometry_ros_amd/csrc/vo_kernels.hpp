@@ -11,6 +11,7 @@ struct vo_gn_frame {
   const uint8_t *stage;
   const uint8_t *lm_flags;  // stereo: bit 0 = landmark triangulated (null: all are); BA set = stage 3 && triangulated
   const float *X, *pl1, *pr1;
+  const float *T_pw;        // non-null: X holds WORLD points, the BA takes Xp = T_pw * X (stereo_vo.cpp:605)
   float *C_X, *C_pl1, *C_pr1;
   int32_t *C_orig;
   int *cnt;
@@ -116,7 +117,7 @@ int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, 
                            const float *d_l0, const float *d_r0, const float *d_X, const uint8_t *d_flags, int n,
                            const float T_cp[16],
                            const float T_rl[16], const float *d_new, int n_new, const vo_frame_fused_bufs &b,
-                           int phase);
+                           int phase, const float *T_pw = nullptr);
 
 // misc_kernels.hip
 int vo_hamming_enqueue(vo_ctx *c, const uint8_t *d_a, int na, const uint8_t *d_b, int nb, uint16_t *d_dist);
