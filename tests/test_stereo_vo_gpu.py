@@ -103,3 +103,13 @@ def test_closed_loop_kitti_size(vo, oracle):
     log, ref = _run_both(vo, oracle, W, H, S.KITTI_K, 60, 25, frames, 21, 6, 9, lba=False, strict=4, prefetch=True, kf_overlap=0.8)
     assert log[-1][1] > 1000
     assert sum(1 for e in log if e[0]) >= 2
+
+
+def test_closed_loop_with_local_ba(vo, oracle):
+    """Keyframes every few frames (low translation threshold) so that the window reaches three keyframes and the local BA
+    runs several times; after each, poses and landmarks re-enter the loop. The device solver agrees with the CPU solver
+    to ~1e-14 in double, so the float casts — and with them every later frame — come out identical."""
+    W, H, K = 640, 240, (400.0, 400.0, 320.0, 120.0)
+    frames = _stream(W, H, K, 20, 8, 5, 0.5, 14)
+    log, ref = _run_both(vo, oracle, W, H, K, 20, 8, frames, 21, 4, 14, lba=True, strict=4, prefetch=True, kf_trans=1.2)
+    assert sum(1 for e in log if e[2]) >= 3, log
