@@ -298,7 +298,8 @@ typedef struct {
  * starts when its members are past their first refinement instead of behind the frame kernel's last wavefront. Joined
  * on the device (no HIP event). The pool costs the frame kernel room, so it pays only when there is something to
  * replay. It needs the two queues to really run concurrently: under a tool that serialises kernels across queues
- * (rocprofv3 --pmc) its bounded waits run out and the frame returns VO_ERR_HIP — use 1 there.
+ * (rocprofv3 --pmc) its bounded waits run out; the frame is then issued again with the stream-ordered replay and the
+ * context stays on it (vo_stereo_frame_recoveries).
  * 5 (stereo frame only) = the stream-ordered replay of mode 1, but on the replay stream behind a one-wavefront gate that
  * waits for the frame kernel's last pass 1: its (normally idle) launches run under the frame kernel's tail instead of
  * between it and the BA launch. Same conditions as 3.
@@ -306,6 +307,12 @@ typedef struct {
  * frame kernel is small enough (at most 4096 features + candidates) to leave the chip mostly idle in its second half.
  * Every non-zero value gives the same results (DESIGN.md §4.3 has the measurements). */
 int vo_stereo_frame_set_strict_border(vo_ctx *ctx, int strict);
+
+/* Frames of this context that vo_stereo_frame_result had to issue again because the device-side join of modes 3 / 5
+ * timed out (the replay stream did not run next to the frame kernel: a serialising tool, a shared GPU). Such a frame
+ * is re-run with the stream-ordered replay (its inputs are still on the device) and delivers the normal results; the
+ * context then stays on the stream-ordered arrangement. 0 in normal operation. */
+int vo_stereo_frame_recoveries(const vo_ctx *ctx);
 
 /* Asynchronous: enqueues one frame on the context stream. slot_l0 must hold the
  * previous left pyramid, slot_l1 / slot_r1 the current pair. Track-set inputs

@@ -106,8 +106,52 @@ def test_concurrent_replay_with_fewer_workgroups_than_border_features():
 def test_stereo_frame_automatic_replay_mode(ctx, oracle):
     """strict 4: the replay runs stream-ordered or next to the frame kernel depending on how many features the PREVIOUS
     frame replayed (the first frame knows none, the later ones of this border-hugging stream do): same results."""
+    import os
     stream = S.StereoStream(seed=6, margin=4.0)
+    before = ctx.frame_recoveries()
     _run_stream(ctx, oracle, stream, 6, 4)
+    if os.environ.get("VO_DEBUG_FAIL_JOIN"):  # (child of test_join_timeout_is_recovered_not_reported)
+        assert ctx.frame_recoveries() == before + 1  # one frame re-issued, then the context stays stream-ordered
+    else:
+        assert ctx.frame_recoveries() == before
+
+
+def _child(env_extra, k_expr):
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", k_expr],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_join_timeout_is_recovered_not_reported():
+    """The concurrent replay arrangements join the two streams on the device with bounded waits. When a join cannot be met
+    (VO_DEBUG_FAIL_JOIN: the BA launch waits for a count that never comes, as under a tool that serialises the queues) the
+    frame must NOT be lost: vo_stereo_frame_result re-issues it with the stream-ordered replay, the context stays on that
+    arrangement, and every frame equals the oracle's (fresh child process: the switch is read once)."""
+    _child({"VO_DEBUG_FAIL_JOIN": "1"}, "test_stereo_frame_automatic_replay_mode or (test_stereo_frame_kitti_shape and 3)")
+
+
+def test_strict_modes_under_serialised_kernels():
+    """AMD_SERIALIZE_KERNEL=3 (set before the child's first HIP call): every launch waits for the previous one, so the
+    replay pool never runs NEXT TO the frame kernel. Modes 3, 4 and 5 must still deliver the oracle's results."""
+    _child({"AMD_SERIALIZE_KERNEL": "3"}, "test_stereo_frame_automatic_replay_mode or (test_stereo_frame_kitti_shape and (3 or 5))")
+
+
+def test_strict_mode4_soak(ctx, oracle):
+    """60 KITTI-shaped frames in mode 4 with the features 4 px from the border (long replay chains), 5 seeds x 12 frames
+    (+ the mono-shaped stream), every gate of every frame against the oracle (tests/measure/frame_soak.py, shortened)."""
+    n = 0
+    for seed in range(100, 105):
+        stream = S.StereoStream(width=1241, height=376, K=S.KITTI_K, n_u=60, n_v=25, n_new=100, seed=seed, margin=4.0, speed=0.8)
+        _run_stream(ctx, oracle, stream, 13, 4, win=21, max_level=6, sanity=False)
+        n += 12
+    stream = S.StereoStream(width=752, height=480, K=(458.654, 457.296, 367.215, 248.375), n_u=40, n_v=25, n_new=100, seed=100,
+                            margin=4.0, speed=0.3)
+    _run_stream(ctx, oracle, stream, 7, 4, win=15, max_level=5, sanity=False)
+    assert n == 60
 
 
 @pytest.mark.parametrize("untri,strict", [(0.0, True), (0.3, True), (0.3, False), (1.0, True)])

@@ -100,7 +100,7 @@ SYMBOLS = [
     "vo_set_stereo_pair_device", "vo_set_pyramid_window_hint",
     "vo_set_ingest_side_stream", "vo_set_stereo_pair_host_async", "vo_new_point_candidates_enqueue",
     "vo_new_point_candidates_get", "vo_stereo_frame_enqueue_closed", "vo_stereo_frame_new_points",
-    "vo_stereo_frame_enqueue_closed_world", "vo_svo_create", "vo_svo_destroy", "vo_svo_track", "vo_svo_enqueue",
+    "vo_stereo_frame_enqueue_closed_world", "vo_stereo_frame_recoveries", "vo_svo_create", "vo_svo_destroy", "vo_svo_track", "vo_svo_enqueue",
     "vo_svo_prefetch", "vo_svo_result", "vo_svo_get_tracks", "vo_svo_get_new_points", "vo_triangulate_dlt",
     "vo_se3_exp", "vo_ids_reset", "vo_ids_peek", "vo_ids_new_frames", "vo_ids_new_landmarks", "vo_compact_tracks",
 ]

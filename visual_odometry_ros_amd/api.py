@@ -125,6 +125,10 @@ class Context:
         if rc < 0:
             self.check(rc)
 
+    def frame_recoveries(self):
+        """frames re-issued after a device-side join time-out (0 in normal operation)"""
+        return self.lib.vo_stereo_frame_recoveries(self._h)
+
     def swap_slots(self, a, b):
         self.check(self.lib.vo_swap_slots(self._h, a, b))
 

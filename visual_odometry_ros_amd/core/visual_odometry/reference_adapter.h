@@ -152,7 +152,8 @@ class FeatureTracker {
   }
   void calcPrior(const PixelVec &pts0, const PointVec &Xw, const PoseSE3 &Tw1, const Eigen::Matrix3f &K,
                  PixelVec &pts1_prior) {
-    lazy_.ensure(64, 64, (int)(pts0.size() > Xw.size() ? pts0.size() : Xw.size()), 1, 4);
+    // (a recreated context invalidates the cached tracker, which is bound to the old one)
+    if (lazy_.ensure(64, 64, (int)(pts0.size() > Xw.size() ? pts0.size() : Xw.size()), 1, 4)) impl_.reset();
     vo::FeatureTracker t(lazy_.get());
     vo::PixelVec out;
     t.calcPrior(vo_adapter::to_vo(pts0), vo_adapter::to_vo(Xw), vo_adapter::to_row_major(Tw1), vo_adapter::to_row_major(K),
@@ -161,9 +162,12 @@ class FeatureTracker {
   }
   // du0 / dv0 (cv::Sobel of img0, stereo_vo.cpp:549-552) are recomputed on the device from img0; the arguments are
   // accepted for source compatibility and not read.
-  void trackWithScale(const cv::Mat &img0, const cv::Mat & /*du0*/, const cv::Mat & /*dv0*/, const cv::Mat &img1,
+  void trackWithScale(const cv::Mat &img0, const cv::Mat &du0, const cv::Mat &dv0, const cv::Mat &img1,
                       const PixelVec &pts0, const std::vector<float> &scale_est, PixelVec &pts_track,
                       MaskVec &mask_valid) {
+    // the derivative images must at least be what the drivers pass: cv::Sobel of img0, i.e. img0's size
+    if (du0.rows != img0.rows || du0.cols != img0.cols || dv0.rows != img0.rows || dv0.cols != img0.cols)
+      throw std::runtime_error("trackWithScale: du0 / dv0 are not derivative images of img0 (size mismatch)");
     vo::FeatureTracker &t = impl(img0, pts0.size(), 0);
     vo::PixelVec io = vo_adapter::to_vo(pts_track);
     t.trackWithScale(vo_adapter::view(img0), vo_adapter::view(img1), vo_adapter::to_vo(pts0), scale_est, io, mask_valid);

@@ -20,6 +20,7 @@
 
 #include <stddef.h>
 #include <stdlib.h>
+#include <time.h>
 #ifdef VO_TRACE_HOST
 #include <chrono>
 static double vo_now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -57,6 +58,8 @@ int vo_frame_init(vo_ctx *c) {
   f->res_cap = align16(sizeof(vo_frame_hdr)) + 2 * align16(N) + 4 * align16(sizeof(float) * 2 * N);
   VO_CHECK_HIP(c, hipMalloc((void **)&f->res_dev, f->res_cap));
   VO_CHECK_HIP(c, hipHostMalloc((void **)&f->res_host, f->res_cap, hipHostMallocDefault));
+  memset(f->res_host, 0, f->res_cap);  // (the polled sequence word must not match by accident)
+  VO_CHECK_HIP(c, hipMemsetAsync(f->res_dev, 0, f->res_cap, c->stream));
   VO_CHECK_HIP(c, hipEventCreateWithFlags(&f->ev_done, hipEventDisableTiming));
   VO_CHECK_HIP(c, hipMalloc((void **)&f->ctl, vo_ic_ctl_bytes()));
   VO_CHECK_HIP(c, hipMemsetAsync(f->ctl, 0, vo_ic_ctl_bytes(), c->stream));
@@ -218,6 +221,7 @@ int vo_frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, i
   if (c->frame_strict_ic == 4)
     c->frame_strict_now = (fused && f->last_replayed >= VO_CONC_MIN_REPLAYED && n + n_new <= VO_CONC_MAX_WORKGROUPS) ? 3 : 1;
   if (c->frame_strict_ic == 5 && !fused) c->frame_strict_now = 1;
+  if (c->frame_conc_off && c->frame_strict_now >= 3) c->frame_strict_now = 1;  // a join timed out before: stream order
   {
     int g = ((f->last_replayed + 32 + 31) / 32) * 32;
     f->conc_grid = g < 64 ? 64 : (g > 256 ? 256 : g);
@@ -262,11 +266,39 @@ int vo_frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, i
     b.new_r = tab ? f->bin_r : f->new_r;   // closed: per-bin scratch, compacted into the block by the BA launch
     b.m_new = tab ? f->bin_m : f->mNew;
     b.cand_has = tab ? tab->has : nullptr;
+    // what vo_stereo_frame_result needs to issue this frame again (device pointers only)
+    f->again.prm = *prm;
+    f->again.slot_l0 = slot_l0;
+    f->again.slot_l1 = slot_l1;
+    f->again.slot_r1 = slot_r1;
+    f->again.l0 = d_l0;
+    f->again.r0 = d_r0;
+    f->again.X = d_X;
+    f->again.fl = d_fl;
+    f->again.pts_new = tab ? nullptr : d_new;
+    f->again.n = n;
+    f->again.n_new = tab ? 0 : n_new;
+    memcpy(f->again.dT_prior, dT_prior, sizeof(f->again.dT_prior));
+    f->again.has_bins = bp ? 1 : 0;
+    if (bp) f->again.bins = *bp;
+    f->again.table = table;
+    f->again.has_world = T_pw ? 1 : 0;
+    if (T_pw) {
+      memcpy(f->again.T_pw, T_pw, sizeof(f->again.T_pw));
+      memcpy(f->again.T_cw_prior, T_cw_prior, sizeof(f->again.T_cw_prior));
+    }
     // [10] the new-point candidates are extra workgroups of the same launch
     VO_TT("setup");
-    RC(vo_frame_fused_enqueue(c, prm, slot_l0, slot_l1, slot_r1, d_l0, d_r0, d_X, d_fl, n, T_cp, T_rl, d_new, n_new, b, 0, T_pw));
+    const int p1_before = f->sync_p1_target, done_before = f->sync_done_target;
+    int rcf = vo_frame_fused_enqueue(c, prm, slot_l0, slot_l1, slot_r1, d_l0, d_r0, d_X, d_fl, n, T_cp, T_rl, d_new, n_new, b, 0, T_pw);
     VO_TT("track launch");
-    RC(vo_frame_fused_enqueue(c, prm, slot_l0, slot_l1, slot_r1, d_l0, d_r0, d_X, d_fl, n, T_cp, T_rl, d_new, n_new, b, 1, T_pw));
+    if (rcf >= 0)
+      rcf = vo_frame_fused_enqueue(c, prm, slot_l0, slot_l1, slot_r1, d_l0, d_r0, d_X, d_fl, n, T_cp, T_rl, d_new, n_new, b, 1, T_pw);
+    if (rcf < 0) {  // nothing of this frame will count: the cumulative hand-shake targets go back
+      f->sync_p1_target = p1_before;
+      f->sync_done_target = done_before;
+      return rcf;
+    }
     VO_TT("phase1");
   } else if (n > 0) {
     // general window sizes: one launch per step, compaction in between
@@ -392,6 +424,8 @@ int vo_frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, i
     if (c->frame_strict_now == 3 || c->frame_strict_now == 5) {  // the replay runs on its own stream: join on the device
       gf.join_word = f->sync + 1;
       gf.join_target = f->sync_done_target;
+      static const bool fail_join = getenv("VO_DEBUG_FAIL_JOIN") != nullptr;  // tests: a join that cannot be met
+      if (fail_join) gf.join_target += 1 << 20;
     }
     gf.ctl_words = (int)(vo_ic_ctl_bytes() / 4);
     gf.nt_word = vo_ic_ctl_nt_word();
@@ -465,6 +499,8 @@ extern "C" int vo_stereo_frame_enqueue_closed_world(vo_ctx *c, const vo_stereo_p
                                inputs_on_device, bins, table, T_pw, T_cw_prior);
 }
 
+extern "C" int vo_stereo_frame_recoveries(const vo_ctx *c) { return c ? c->frame_recoveries : VO_ERR_INVALID; }
+
 extern "C" int vo_stereo_frame_new_points(vo_ctx *c, float *pts_new, int *n_new) {
   if (!c || !c->frame || !n_new) return VO_ERR_INVALID;
   vo_frame_state *f = c->frame;
@@ -489,19 +525,50 @@ extern "C" int vo_stereo_frame_result(vo_ctx *c, float *pts_l1, float *pts_r1, u
   bool seen = false;
   if (f->seq_poll) {
     volatile const int *seqp = &((volatile const vo_frame_hdr *)f->res_host)->seq;
-    for (int spin = 0; spin < 2000000; ++spin) {
+    timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int spin = 0;; ++spin) {
       if (*seqp == f->seq) {
         seen = true;
         break;
       }
+      if ((spin & 255) == 255) {  // ~2 ms of polling at most, then the event decides
+        timespec t1;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if ((t1.tv_sec - t0.tv_sec) * 1e9 + (t1.tv_nsec - t0.tv_nsec) > 2e6) break;
+      }
+#if defined(__x86_64__)
       __builtin_ia32_pause();
+#endif
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
   }
   if (!seen) VO_CHECK_HIP(c, hipEventSynchronize(f->ev_done));
   f->pending = false;
   c->frame_slots_busy = 0;
+  f->recovered = 0;
   const vo_frame_hdr *h = (const vo_frame_hdr *)f->res_host;
+  if ((h->flags & 8) && f->seq_poll && f->again.n > 0) {
+    // The device-side join with the replay stream timed out (the two queues did not run concurrently: a serialising tool,
+    // a busy GPU, a stalled main stream). The frame is not lost: drain both streams, re-base the hand-shake words, switch
+    // the context to the stream-ordered replay for good and issue the frame again from its (intact) device inputs.
+    VO_CHECK_HIP(c, hipStreamSynchronize(c->stream3));
+    VO_CHECK_HIP(c, hipStreamSynchronize(c->stream_main));
+    VO_CHECK_HIP(c, hipMemsetAsync(f->sync, 0, 128 + 64 * 128, c->stream_main));
+    VO_CHECK_HIP(c, hipMemsetAsync(f->ctl, 0, vo_ic_ctl_bytes(), c->stream_main));
+    f->sync_p1_target = f->sync_done_target = 0;
+    c->frame_conc_off = 1;
+    ++c->frame_recoveries;
+    const auto g = f->again;  // (by value: the enqueue below rewrites f->again)
+    int rc2 = vo_frame_enqueue_impl(c, &g.prm, g.slot_l0, g.slot_l1, g.slot_r1, g.l0, g.r0, g.X, g.fl, g.n, g.dT_prior, g.pts_new,
+                                    g.n_new, 1, g.has_bins ? &g.bins : nullptr, g.table, g.has_world ? g.T_pw : nullptr,
+                                    g.has_world ? g.T_cw_prior : nullptr);
+    if (rc2 < 0) return rc2;
+    VO_CHECK_HIP(c, hipEventSynchronize(f->ev_done));
+    f->pending = false;
+    c->frame_slots_busy = 0;
+    f->recovered = 1;
+  }
   f->last_replayed = f->n > 0 ? h->cnt[3] : 0;
   const int n = f->n, nn = f->closed ? h->cnt[5] : f->n_new;  // closed: what the BA launch's epilogue emitted
   if (f->closed && f->table) {  // the detector's capacity flags of the table this frame read
@@ -540,7 +607,7 @@ extern "C" int vo_stereo_frame_result(vo_ctx *c, float *pts_l1, float *pts_r1, u
   if (h->flags) {
     if (h->flags & 1) VO_FAIL(c, VO_ERR_NAN_AXAY, "ax ay nan");
     if (h->flags & 2) VO_FAIL(c, VO_ERR_NAN_PATCH, "I0 I1 / du0 dv0 nan");
-    if (h->flags & 8) VO_FAIL(c, VO_ERR_HIP, "the strict-border replay stream did not finish (device-side join timed out)");
+    if (h->flags & 8) VO_FAIL(c, VO_ERR_HIP, "the strict-border replay stream did not finish (device-side join timed out twice)");
     VO_FAIL(c, VO_ERR_NAN_UPDATE, "dtu dtv nan");
   }
   if (h->gn.is_nan) VO_FAIL(c, VO_ERR_GN_FAILED, "PoseOnlyStereoBA is failed!");

@@ -58,6 +58,20 @@ struct vo_frame_state {
   int seq;          // sequence number of the frame in flight (fused stereo path: the result is awaited by polling res_host)
   bool seq_poll;
   hipEvent_t ev_done;  // recorded after the packed D2H: result() waits for this, not for the stream
+  // what the frame in flight was enqueued with (device pointers): vo_stereo_frame_result re-issues the frame with the
+  // stream-ordered replay when the device-side join of the concurrent arrangements timed out
+  struct {
+    vo_stereo_params prm;
+    int slot_l0, slot_l1, slot_r1;
+    const float *l0, *r0, *X, *pts_new;
+    const uint8_t *fl;
+    int n, n_new;
+    float dT_prior[16];
+    int has_bins, table, has_world;
+    vo_bin_params bins;
+    float T_pw[16], T_cw_prior[16];
+  } again;
+  int recovered;      // the last result was produced by such a re-issue
 };
 
 int vo_frame_init(vo_ctx *c);

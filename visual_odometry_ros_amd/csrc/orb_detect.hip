@@ -26,6 +26,7 @@
 
 #include "vo_internal.hpp"
 #include "vo_kernels.hpp"
+#include "frame_state.hpp"
 
 #define ORB_MAX_LEVELS 12
 
@@ -881,6 +882,8 @@ extern "C" int vo_new_point_candidates_enqueue(vo_ctx *c, int slot, const vo_bin
   if (!c->orb) c->orb = new vo_orb_state();
   vo_orb_state *S = c->orb;
   vo_cand_table &T = S->tab[table];
+  if (c->frame && c->frame->pending && c->frame->table == &T)
+    VO_FAIL(c, VO_ERR_INVALID, "candidate table %d is read by the closed frame in flight: collect its result first", table);
   if (T.n_bins != total) {
     if (T.xy) (void)hipFree(T.xy);
     if (T.has) (void)hipFree(T.has);

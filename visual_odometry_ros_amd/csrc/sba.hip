@@ -20,6 +20,9 @@
 // Six launches per iteration, no host round trip inside the solve. The quirks listed in
 // oracle/oracle_sba.c (B assigned not accumulated, left-only Schur loops, symmetrisation overwrite,
 // calc_Qij_t_Qij_weight's zero entries) are reproduced.
+#include <stdlib.h>
+#include <time.h>
+
 #include <vector>
 
 #include "vo_internal.hpp"
@@ -689,6 +692,23 @@ extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, co
                             const int32_t *obs_ptr, const int32_t *obs_frame, const uint8_t *obs_right,
                             const double *obs_px, double *avg_err) {
   if (!c || !p || !T_jw || !opt_index || !X || !obs_ptr || !obs_frame || !obs_right || !obs_px) return VO_ERR_INVALID;
+  static const bool trace = getenv("VO_SVO_TRACE") != nullptr;
+  static double tt[4];
+  static int n_calls;
+  auto now_us = []() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return 1e6 * (double)ts.tv_sec + 1e-3 * (double)ts.tv_nsec;
+  };
+  double t_last = trace ? now_us() : 0.0;
+#define SBA_T(k)                    \
+  do {                              \
+    if (trace) {                    \
+      const double now_ = now_us(); \
+      tt[k] += now_ - t_last;       \
+      t_last = now_;                \
+    }                               \
+  } while (0)
   const int Nf = p->n_frames, No = p->n_opt, M = p->n_points, nobs = p->n_obs;
   if (Nf <= 0 || No < 0 || M <= 0 || nobs <= 0 || p->max_iter < 0) VO_FAIL(c, VO_ERR_INVALID, "empty BA problem");
   if (No > SBA_MAX_OPT) VO_FAIL(c, VO_ERR_CAPACITY, "n_opt=%d exceeds %d optimised poses", No, SBA_MAX_OPT);
@@ -750,6 +770,7 @@ extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, co
   // slot_lm carries the landmark of every slot, followed by the landmark of every observation
   slot_lm.insert(slot_lm.end(), obs_lm.begin(), obs_lm.end());
 
+  SBA_T(0);
   VO_CHECK_HIP(c, hipSetDevice(c->device));
   // ---- device arena ----
   Arena ar;
@@ -858,6 +879,7 @@ extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, co
   const size_t lds = sizeof(double) * ((size_t)n * n + 3 * (size_t)n) + sizeof(int) * 2 * (size_t)n + 64;
   if (lds > 64 * 1024)
     VO_CHECK_HIP(c, hipFuncSetAttribute((const void *)sba_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  SBA_T(1);
   vo_prof_begin(c, VO_K_AUX);
   for (int iter = 0; iter < p->max_iter; ++iter) {
     hipLaunchKernelGGL(sba_point_kernel, dim3((M + 63) / 64), dim3(64), 0, s, d);
@@ -878,6 +900,9 @@ extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, co
   VO_CHECK_HIP(c, hipMemcpyAsync(T_jw, base + oT, sizeof(double) * 16 * Nf, hipMemcpyDeviceToHost, s));
   VO_CHECK_HIP(c, hipMemcpyAsync(X, base + oX, sizeof(double) * 3 * M, hipMemcpyDeviceToHost, s));
   VO_CHECK_HIP(c, hipStreamSynchronize(s));
+  SBA_T(2);
+  if (trace && (++n_calls % 10) == 0)
+    fprintf(stderr, "[sba] per call (us): lists %.0f  upload %.0f  kernels+d2h %.0f\n", tt[0] / n_calls, tt[1] / n_calls, tt[2] / n_calls);
   if (avg_err)
     for (int k = 0; k < p->max_iter; ++k) avg_err[k] = errs[k];
   memcpy(c->sba->phase_ticks, flags + 1, sizeof(int) * 3);

@@ -557,6 +557,38 @@ static int svo_ingest(vo_svo *s, const void *left, const void *right, int stride
   return VO_OK;
 }
 
+// behind the frame's BA launch, on the same stream: the next track set + the loop's counts
+static int svo_launch_advance(vo_svo *s) {
+  vo_ctx *c = s->c;
+  vo_frame_state *f = c->frame;
+  const SvoTrackSet &t = s->ts[s->cur];
+  SvoAdvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.n = s->n;
+  a.stage = f->stage;
+  a.pl1 = f->F_pl1;
+  a.pr1 = f->F_pr1;
+  a.cur = t;
+  a.nxt = s->ts[s->cur ^ 1];
+  a.n_emit = &f->hdr->cnt[5];
+  a.new_l = (const float *)(f->res_dev + f->off_newl);
+  a.new_r = f->new_r;
+  a.new_m = f->mNew;
+  a.accept = s->d_accept;
+  a.cam = s->cam;
+  a.id_base = c->next_landmark_id;
+  a.cap = s->cap;
+  a.hdr_dev = s->d_hdr;
+  a.hdr_host = s->h_hdr;
+  s->seq = s->seq + 1 == 0 ? 1 : s->seq + 1;
+  a.seq = s->seq;
+  vo_prof_begin(c, VO_K_AUX);
+  hipLaunchKernelGGL(svo_advance_kernel, dim3(1), dim3(SVO_T), 0, c->stream, a);
+  vo_prof_end(c);
+  VO_CHECK_HIP(c, hipGetLastError());
+  return VO_OK;
+}
+
 extern "C" int vo_svo_prefetch(vo_svo *s, const void *left, const void *right, int stride, int on_device) {
   if (!s || !left || !right) return VO_ERR_INVALID;
   VO_CHECK_HIP(s->c, hipSetDevice(s->c->device));
@@ -606,32 +638,7 @@ extern "C" int vo_svo_enqueue(vo_svo *s, const void *left, const void *right, in
     s->pending = false;
     return rc;
   }
-  vo_frame_state *f = c->frame;
-  SvoAdvArgs a;
-  memset(&a, 0, sizeof(a));
-  a.n = s->n;
-  a.stage = f->stage;
-  a.pl1 = f->F_pl1;
-  a.pr1 = f->F_pr1;
-  a.cur = t;
-  a.nxt = s->ts[s->cur ^ 1];
-  a.n_emit = &f->hdr->cnt[5];
-  a.new_l = (const float *)(f->res_dev + f->off_newl);
-  a.new_r = f->new_r;
-  a.new_m = f->mNew;
-  a.accept = s->d_accept;
-  a.cam = s->cam;
-  a.id_base = c->next_landmark_id;
-  a.cap = s->cap;
-  a.hdr_dev = s->d_hdr;
-  a.hdr_host = s->h_hdr;
-  s->seq = s->seq + 1 == 0 ? 1 : s->seq + 1;
-  a.seq = s->seq;
-  vo_prof_begin(c, VO_K_AUX);
-  hipLaunchKernelGGL(svo_advance_kernel, dim3(1), dim3(SVO_T), 0, c->stream, a);
-  vo_prof_end(c);
-  VO_CHECK_HIP(c, hipGetLastError());
-  return VO_OK;
+  return svo_launch_advance(s);
 }
 
 // stereo_vo.cpp:842-949 — once per stream, composed of the operators (synchronous)
@@ -738,7 +745,7 @@ extern "C" int vo_svo_result(vo_svo *s, vo_svo_frame_info *info) {
     return VO_OK;
   }
   // the advance kernel is the frame's last launch: its block's sequence word says that everything is there
-  {
+  auto wait_advance = [&]() -> int {
     volatile const int *seqp = &s->h_hdr->seq;
     const double t0 = svo_now();
     bool seen = false;
@@ -754,10 +761,16 @@ extern "C" int vo_svo_result(vo_svo *s, vo_svo_frame_info *info) {
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     if (!seen) VO_CHECK_HIP(c, hipStreamSynchronize(c->stream));
-  }
+    return VO_OK;
+  };
+  RC(wait_advance());
   float dT[16];
   int rc = vo_stereo_frame_result(c, nullptr, nullptr, nullptr, dT, nullptr, nullptr, &I.counts, &I.gn);
   if (rc < 0) return rc;
+  if (c->frame->recovered) {  // the frame was issued again (join time-out): so is everything behind it
+    RC(svo_launch_advance(s));
+    RC(wait_advance());
+  }
   const SvoHdr h = *s->h_hdr;
   if (h.overflow) VO_FAIL(c, VO_ERR_CAPACITY, "the next track set (%d) exceeds vo_config.max_points=%d", h.n_next, s->cap);
   I.n_tracks_in = s->n;

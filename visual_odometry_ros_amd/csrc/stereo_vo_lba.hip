@@ -19,7 +19,17 @@
 
 #include <algorithm>
 
+#include <stdlib.h>
+#include <time.h>
+
 #include "stereo_vo.hpp"
+
+static double lba_now() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return 1e6 * (double)ts.tv_sec + 1e-3 * (double)ts.tv_nsec;
+}
+#define LBA_T(k)                       do {                                   if (trace) {                           const double now_ = lba_now();       tt[k] += now_ - t_last;              t_last = now_;                     }                                  } while (0)
 
 static void mul44d(const double A[16], const double B[16], double C[16]) {  // Matrix4d * Matrix4d, left to right over k
   double R[16];
@@ -60,6 +70,10 @@ int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info) {
   vo_ctx *c = s->c;
   const int n = s->n;
   SvoTrackSet &t = s->ts[s->cur];
+  static const bool trace = getenv("VO_SVO_TRACE") != nullptr;
+  static double tt[8];
+  static int n_calls;
+  double t_last = trace ? lba_now() : 0.0;
   // ---- the new keyframe's related landmarks, after the reconstruction kernel (main stream) ----
   std::vector<int32_t> ids(std::max(n, 1));
   std::vector<float> pl(2 * (size_t)std::max(n, 1)), pr(2 * (size_t)std::max(n, 1)), Xw(3 * (size_t)std::max(n, 1));
@@ -73,6 +87,7 @@ int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info) {
     VO_CHECK_HIP(c, hipMemcpyAsync(fl.data(), t.flags, (size_t)n, hipMemcpyDeviceToHost, st));
     VO_CHECK_HIP(c, hipStreamSynchronize(st));
   }
+  LBA_T(0);
   SvoKeyframe &kf = s->keyframes.back();
   kf.ids.assign(ids.begin(), ids.begin() + n);
   for (int k = 0; k < n; ++k) {  // state as of this keyframe + the observation on it
@@ -92,6 +107,7 @@ int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info) {
     o.pr[1] = pr[2 * k + 1];
     L.obs.push_back(o);
   }
+  LBA_T(1);
   const std::vector<SvoKeyframe> &win = s->keyframes;
   const int nk = (int)win.size();
   if (nk < 3) return VO_OK;  // NUM_MINIMUM_REQUIRED_KEYFRAMES (motion_estimator.cpp:1245-1253)
@@ -167,8 +183,10 @@ int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info) {
   to_d(s->prm.frame.T_lr, p.T_lr);
   for (int r = 0; r < 3; ++r) p.T_lr[r * 4 + 3] *= inv_scale;  // scalingPose(T_stereo_)
   double err[16] = {0};
+  LBA_T(2);
   int rc = vo_sba_solve(c, &p, T_jw.data(), opt.data(), X.data(), obs_ptr.data(), obs_frame.data(), obs_right.data(), px.data(), err);
   if (rc < 0) return rc;
+  LBA_T(3);
   if (info) {
     info->lba_ran = 1;
     info->lba_err_first = err[0];
@@ -204,6 +222,7 @@ int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info) {
     const float nrm = sqrtf(L.X[0] * L.X[0] + (L.X[1] * L.X[1] + L.X[2] * L.X[2]));
     if (!(nrm <= 3000)) L.alive = false;  // setDead
   }
+  LBA_T(4);
   // ---- what the BA did to the landmarks the next frame tracks ----
   for (int k = 0; k < n; ++k) {
     const SvoLandmark &L = s->lms[ids[k]];
@@ -218,5 +237,9 @@ int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info) {
     VO_CHECK_HIP(c, hipMemcpyAsync(t.flags, fl.data(), (size_t)n, hipMemcpyHostToDevice, c->stream));
     VO_CHECK_HIP(c, hipStreamSynchronize(c->stream));  // (the staging vectors go out of scope)
   }
+  LBA_T(5);
+  if (trace && (++n_calls % 10) == 0)
+    fprintf(stderr, "[lba] per call (us): d2h %.0f  db %.0f  problem %.0f  solve %.0f  finish %.0f  h2d %.0f  (M=%d obs=%d)\n",
+            tt[0] / n_calls, tt[1] / n_calls, tt[2] / n_calls, tt[3] / n_calls, tt[4] / n_calls, tt[5] / n_calls, p.n_points, p.n_obs);
   return VO_OK;
 }

@@ -361,6 +361,12 @@ extern "C" int vo_set_pyramid_window_hint(vo_ctx *c, int win) {
 
 extern "C" int vo_swap_slots(vo_ctx *c, int a, int b) {
   if (!c || a < 0 || b < 0 || a >= c->cfg.n_slots || b >= c->cfg.n_slots) return VO_ERR_INVALID;
+  // the "slot is read by the frame in flight" guard of the pyramid build goes by slot index: a swap under a frame in
+  // flight would let a side-stream rebuild overwrite memory that frame still reads
+  if (c->frame_slots_busy)
+    for (int k = 0; k < 3; ++k)
+      if (c->frame_slot[k] == a || c->frame_slot[k] == b)
+        VO_FAIL(c, VO_ERR_INVALID, "slot %d is read by the frame in flight: collect its result before swapping", c->frame_slot[k]);
   vo_pyramid t = c->slots[a];
   c->slots[a] = c->slots[b];
   c->slots[b] = t;

@@ -80,6 +80,8 @@ struct vo_ctx {
   struct vo_frame_state *frame;
   int frame_strict_ic;     // replay border-touching points with the reference's sticky tap state (as requested: 0..4)
   int frame_strict_now;    // the stereo frame in flight: 4 (automatic) resolved to 1 or 3
+  int frame_recoveries;    // frames issued again after such a time-out (vo_stereo_frame_recoveries)
+  int frame_conc_off;      // a device-side join timed out once: the concurrent arrangements (3, 5, 4 -> 3) are off for good
   int frame_slots_busy;    // a frame is in flight and reads frame_slot[0..2]
   int frame_slot[3];
   // profiling
