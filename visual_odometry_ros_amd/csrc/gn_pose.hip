@@ -179,38 +179,55 @@ __device__ __forceinline__ void swapf(float &a, float &b) {
   a = b;
   b = t;
 }
-__device__ __forceinline__ void ldlt6_solve(const float (&Ain)[36], const float (&b)[6], float (&x)[6]) {
-  float m[6][6];
-  int tr[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i)
-#pragma unroll
-    for (int j = 0; j < 6; ++j) m[i][j] = Ain[i * 6 + j];
+// Eigen's LDLT picks the pivot of step k among the diagonal entries of rows k.., and in its left-looking in-place form
+// those still hold their ORIGINAL values at that point (step k only ever writes column k): the whole transposition
+// sequence depends on the original diagonal alone. So: the sequence first (6 magnitudes, predicated swaps of 2 x 6
+// values instead of whole rows and columns), then the matrix is GATHERED already permuted — entry (i, j) of P A P^T is
+// A(perm[i], perm[j]), read from the upper-triangle sums in LDS — and the factorisation runs without a single swap: the
+// same operations on the same values as the swapping form (and as sba_solve_kernel does it for the local BA).
+// tot: the 21 upper-triangle sums in oracle UT[][] order followed by g[6]; lambda damps the diagonal (:820-822, :1051-1053).
+__device__ __forceinline__ void ldlt6_solve(const float *__restrict__ tot, float lambda, float (&x)[6]) {
+  int perm[6];
+  float mag[6], dg[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
-    int piv = k;
-    float best = fabsf(m[k][k]);
+    perm[k] = k;
+    dg[k] = tot[ut(k, k)] * (1.0f + lambda);
+    mag[k] = fabsf(dg[k]);
+  }
 #pragma unroll
-    for (int i = k + 1; i < 6; ++i) {
-      const float a = fabsf(m[i][i]);
-      if (a > best) {
-        best = a;
+  for (int k = 0; k < 5; ++k) {
+    int piv = k;
+    float best = mag[k];
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i)
+      if (mag[i] > best) {  // the first of equal maxima, as Eigen's maxCoeff
+        best = mag[i];
         piv = i;
       }
-    }
-    tr[k] = piv;
 #pragma unroll
-    for (int p = k + 1; p < 6; ++p) {
+    for (int p = k + 1; p < 6; ++p)
       if (piv == p) {
-#pragma unroll
-        for (int j = 0; j < k; ++j) swapf(m[k][j], m[p][j]);
-#pragma unroll
-        for (int i = p + 1; i < 6; ++i) swapf(m[i][k], m[i][p]);
-        swapf(m[k][k], m[p][p]);
-#pragma unroll
-        for (int i = k + 1; i < p; ++i) swapf(m[i][k], m[p][i]);
+        swapf(mag[k], mag[p]);
+        swapf(dg[k], dg[p]);
+        const int t = perm[k];
+        perm[k] = perm[p];
+        perm[p] = t;
       }
+  }
+  float m[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    m[i][i] = dg[i];
+#pragma unroll
+    for (int j = 0; j < i; ++j) {
+      const int a = perm[i], b = perm[j];
+      const int lo = a < b ? a : b, hi = a < b ? b : a;
+      m[i][j] = tot[lo * 6 - ((lo * (lo - 1)) >> 1) + (hi - lo)];  // ut(lo, hi)
     }
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
     if (k > 0) {
       float temp[6];
 #pragma unroll
@@ -233,15 +250,10 @@ __device__ __forceinline__ void ldlt6_solve(const float (&Ain)[36], const float 
       for (int i = k + 1; i < 6; ++i) m[i][k] /= akk;
     }
   }
+  // y = P b: the transposition sequence applied to a vector is the gather by perm
   float y[6];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) y[i] = b[i];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-#pragma unroll
-    for (int p = k + 1; p < 6; ++p)
-      if (tr[k] == p) swapf(y[k], y[p]);
-  }
+  for (int i = 0; i < 6; ++i) y[i] = tot[21 + perm[i]];
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     float s = y[i];
@@ -264,14 +276,14 @@ __device__ __forceinline__ void ldlt6_solve(const float (&Ain)[36], const float 
     for (int j = i + 1; j < 6; ++j) s -= m[j][i] * y[j];
     y[i] = s;
   }
+  // x = P^T y: scatter back through perm
 #pragma unroll
-  for (int k = 5; k >= 0; --k) {
+  for (int i = 0; i < 6; ++i) {
+    float v = y[0];
 #pragma unroll
-    for (int p = k + 1; p < 6; ++p)
-      if (tr[k] == p) swapf(y[k], y[p]);
+    for (int q = 1; q < 6; ++q) v = perm[q] == i ? y[q] : v;
+    x[i] = perm[0] == i ? y[0] : v;
   }
-#pragma unroll
-  for (int i = 0; i < 6; ++i) x[i] = y[i];
 }
 
 __device__ void se3_exp_dev(const float (&xi)[6], float (&T)[16]) {
@@ -653,25 +665,14 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
     // The ~1600-instruction solve is issue-bound; run by every wavefront it would compete with
     // itself for the four SIMDs of the CU.
     if (wave == 0) {
-      float tot[GN_NACC];
-#pragma unroll
-      for (int k = 0; k < GN_NACC; ++k) tot[k] = s_tot[k];
-      float JtWJ[36], g[6], dxi[6];
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) JtWJ[i * 6 + j] = tot[i <= j ? ut(i, j) : ut(j, i)];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) g[k] = tot[21 + k];
-      float err_curr = tot[27];
+      float dxi[6];
+      float err_curr = s_tot[27];
       const float inv_npts = 1.0f / (float)n;
       err_curr *= (inv_npts * 0.5f);
       if (STEREO) err_curr = sqrtf(err_curr);
       const float delta_err = fabsf(err_curr - err_prev);
       const float lambda = 0.00001f;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) JtWJ[k * 6 + k] *= (1.0f + lambda);
-      ldlt6_solve(JtWJ, g, dxi);
+      ldlt6_solve(s_tot, lambda, dxi);
       float dT[16], Tn[16];
       se3_exp_dev(dxi, dT);
 #pragma unroll
@@ -692,7 +693,7 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
       last_err = err_curr;
       last_derr = delta_err;
       last_dnorm = dnorm;
-      last_cnt = (int)tot[28];
+      last_cnt = (int)s_tot[28];
       const bool stop = dnorm < (float)1e-6 || delta_err < (float)1e-7;
       if (lane < 16) {
         float tv = Tn[0];
