@@ -662,6 +662,8 @@ struct vo_sba_state {
   void *dev;
   size_t cap;
   int phase_ticks[3];  // sba_solve_kernel of the last iteration: assembly, LDLT + solve, pose update (10 ns ticks)
+  void *stage;         // pinned host staging: the problem goes up in one copy, the results come back through it
+  size_t stage_cap;
 };
 extern "C" int vo_debug_sba_phases(vo_ctx *c, int out[3]) {
   if (!c || !c->sba) return VO_ERR_INVALID;
@@ -672,6 +674,7 @@ extern "C" int vo_debug_sba_phases(vo_ctx *c, int out[3]) {
 void vo_sba_free(vo_ctx *c) {
   if (c->sba) {
     if (c->sba->dev) (void)hipFree(c->sba->dev);
+    if (c->sba->stage) (void)hipHostFree(c->sba->stage);
     delete c->sba;
     c->sba = nullptr;
   }
@@ -719,76 +722,56 @@ extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, co
     if (opt_index[f] < -1 || opt_index[f] >= No) VO_FAIL(c, VO_ERR_INVALID, "opt_index[%d] out of range", f);
     if (opt_index[f] >= 0 && seen_opt[opt_index[f]]++) VO_FAIL(c, VO_ERR_INVALID, "optimised pose index used twice");
   }
-  std::vector<int> slot_ptr(M + 1, 0), slot_obs, slot_j, slot_bobs, slot_lm, obs_lm(nobs);
-  std::vector<std::vector<int>> pose_obs(No), pose_slot(No);
+  // Two passes over the observations, no per-list containers: pass 1 validates and counts (slots per landmark,
+  // observations / slots per optimised pose, pairs per block), pass 2 writes every list at its final place inside ONE
+  // pinned staging block laid out like the device arena, which then goes up in a single copy.
+  std::vector<int> pose_obs_cnt(No + 1, 0), pose_slot_cnt(No + 1, 0), pair_cnt((size_t)No * No + 1, 0);
+  int ns = 0;
   for (int i = 0; i < M; ++i) {
     if (obs_ptr[i + 1] < obs_ptr[i]) VO_FAIL(c, VO_ERR_SIZE, "obs_ptr not monotone");
+    int lj[2 * SBA_MAX_OPT + 64], nl = 0;  // optimised-pose index of this landmark's slots, in list order
     for (int o = obs_ptr[i]; o < obs_ptr[i + 1]; ++o) {
       if (obs_frame[o] < 0 || obs_frame[o] >= Nf) VO_FAIL(c, VO_ERR_INVALID, "obs_frame[%d] out of range", o);
       if (obs_right[o] && !p->stereo) VO_FAIL(c, VO_ERR_INVALID, "right-image observation in a mono problem");
-      obs_lm[o] = i;
       const int j = opt_index[obs_frame[o]];
-      if (j >= 0) pose_obs[j].push_back(o);
-      if (j >= 0 && !obs_right[o]) {
-        // slot: left observation in an optimised keyframe; its B block is that of the last observation of
-        // this landmark in the same keyframe
-        int last = o;
-        for (int o2 = obs_ptr[i]; o2 < obs_ptr[i + 1]; ++o2)
-          if (opt_index[obs_frame[o2]] == j) last = o2;
-        pose_slot[j].push_back((int)slot_obs.size());
-        slot_obs.push_back(o);
-        slot_j.push_back(j);
-        slot_bobs.push_back(last);
-        slot_lm.push_back(i);
+      if (j >= 0) {
+        ++pose_obs_cnt[j];
+        if (!obs_right[o]) {
+          if (nl >= (int)(sizeof(lj) / sizeof(lj[0]))) VO_FAIL(c, VO_ERR_CAPACITY, "a landmark with more than %d slots", nl);
+          lj[nl++] = j;
+          ++pose_slot_cnt[j];
+        }
       }
     }
-    slot_ptr[i + 1] = (int)slot_obs.size();
+    for (int a2 = 0; a2 < nl; ++a2)
+      for (int b2 = a2; b2 < nl; ++b2) ++pair_cnt[(size_t)lj[a2] * No + lj[b2]];
+    ns += nl;
   }
-  const int ns = (int)slot_obs.size();
-  std::vector<int> pose_obs_ptr(No + 1, 0), pose_obs_flat, pose_slot_ptr(No + 1, 0), pose_slot_flat;
-  for (int j = 0; j < No; ++j) {
-    pose_obs_flat.insert(pose_obs_flat.end(), pose_obs[j].begin(), pose_obs[j].end());
-    pose_obs_ptr[j + 1] = (int)pose_obs_flat.size();
-    pose_slot_flat.insert(pose_slot_flat.end(), pose_slot[j].begin(), pose_slot[j].end());
-    pose_slot_ptr[j + 1] = (int)pose_slot_flat.size();
-  }
-  // pairs (:475-491): slots a, b of one landmark with list position b >= a contribute to block (j_a, j_b)
-  std::vector<std::vector<int>> pa((size_t)No * No), pb((size_t)No * No);
-  for (int i = 0; i < M; ++i)
-    for (int s = slot_ptr[i]; s < slot_ptr[i + 1]; ++s)
-      for (int s2 = s; s2 < slot_ptr[i + 1]; ++s2) {
-        const size_t jk = (size_t)slot_j[s] * No + slot_j[s2];
-        pa[jk].push_back(s);
-        pb[jk].push_back(s2);
-      }
-  std::vector<int> pair_ptr((size_t)No * No + 1, 0), pair_a, pair_b;
-  for (size_t jk = 0; jk < (size_t)No * No; ++jk) {
-    pair_a.insert(pair_a.end(), pa[jk].begin(), pa[jk].end());
-    pair_b.insert(pair_b.end(), pb[jk].begin(), pb[jk].end());
-    pair_ptr[jk + 1] = (int)pair_a.size();
-  }
-  // slot_lm carries the landmark of every slot, followed by the landmark of every observation
-  slot_lm.insert(slot_lm.end(), obs_lm.begin(), obs_lm.end());
+  size_t n_pose_obs = 0, n_pairs = 0;
+  for (int j = 0; j < No; ++j) n_pose_obs += (size_t)pose_obs_cnt[j];
+  for (size_t jk = 0; jk < (size_t)No * No; ++jk) n_pairs += (size_t)pair_cnt[jk];
 
   SBA_T(0);
   VO_CHECK_HIP(c, hipSetDevice(c->device));
-  // ---- device arena ----
+  // ---- device arena (inputs first: they are one contiguous upload) ----
   Arena ar;
   const size_t oT = ar.take(sizeof(double) * 16 * Nf), oOpt = ar.take(sizeof(int) * Nf), oX = ar.take(sizeof(double) * 3 * M);
   const size_t oOp = ar.take(sizeof(int) * (M + 1)), oOf = ar.take(sizeof(int) * nobs), oOr = ar.take((size_t)nobs);
   const size_t oPx = ar.take(sizeof(double) * 2 * nobs);
   const size_t oSp = ar.take(sizeof(int) * (M + 1)), oSo = ar.take(sizeof(int) * (ns + 1)), oSj = ar.take(sizeof(int) * (ns + 1));
   const size_t oSb = ar.take(sizeof(int) * (ns + 1)), oSl = ar.take(sizeof(int) * (ns + nobs + 1));
-  const size_t oPop = ar.take(sizeof(int) * (No + 1)), oPo = ar.take(sizeof(int) * (pose_obs_flat.size() + 1));
+  const size_t oPop = ar.take(sizeof(int) * (No + 1)), oPo = ar.take(sizeof(int) * (n_pose_obs + 1));
   const size_t oPsp = ar.take(sizeof(int) * (No + 1)), oPs = ar.take(sizeof(int) * (ns + 1));
-  const size_t oPp = ar.take(sizeof(int) * ((size_t)No * No + 1)), oPa = ar.take(sizeof(int) * (pair_a.size() + 1));
-  const size_t oPb = ar.take(sizeof(int) * (pair_b.size() + 1));
+  const size_t oPp = ar.take(sizeof(int) * ((size_t)No * No + 1)), oPa = ar.take(sizeof(int) * (n_pairs + 1));
+  const size_t oPb = ar.take(sizeof(int) * (n_pairs + 1));
+  const size_t oFl = ar.take(sizeof(int) * 4), oAvg = ar.take(sizeof(double) * (p->max_iter + 1));
+  const size_t in_bytes = ar.off;  // everything up to here comes from the host
   const size_t oCinv = ar.take(sizeof(double) * 9 * M), oCinvb = ar.take(sizeof(double) * 3 * M), oB = ar.take(sizeof(double) * 3 * M);
   const size_t oErr = ar.take(sizeof(double) * M), oBs = ar.take(sizeof(double) * 18 * (ns + 1)), oBCs = ar.take(sizeof(double) * 18 * (ns + 1));
   const size_t oAp = ar.take(sizeof(double) * 48 * SBA_PG * (No + 1)), oS = ar.take(sizeof(double) * 36 * SBA_SG * ((size_t)No * No + 1));
   const size_t oG = ar.take(sizeof(double) * ((size_t)36 * No * No + 6 * No + 1));
-  const size_t ox = ar.take(sizeof(double) * 6 * (No + 1)), oAvg = ar.take(sizeof(double) * (p->max_iter + 1)), oFl = ar.take(sizeof(int) * 4);
-  if (!c->sba) c->sba = new vo_sba_state{nullptr, 0, {0, 0, 0}};
+  const size_t ox = ar.take(sizeof(double) * 6 * (No + 1));
+  if (!c->sba) c->sba = new vo_sba_state{nullptr, 0, {0, 0, 0}, nullptr, 0};
   if (c->sba->cap < ar.off) {
     if (c->sba->dev) (void)hipFree(c->sba->dev);
     c->sba->dev = nullptr;
@@ -796,33 +779,76 @@ extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, co
     VO_CHECK_HIP(c, hipMalloc(&c->sba->dev, ar.off + (ar.off >> 2)));
     c->sba->cap = ar.off + (ar.off >> 2);
   }
-  uint8_t *base = (uint8_t *)c->sba->dev;
+  const size_t out_bytes = sizeof(double) * (16 * (size_t)Nf + 3 * (size_t)M + (size_t)p->max_iter + 1) + 64;
+  const size_t stage_need = in_bytes > out_bytes ? in_bytes : out_bytes;
   hipStream_t s = c->stream;
-  VO_CHECK_HIP(c, hipStreamSynchronize(s));
-#define UP(off, ptr, bytes) \
-  if ((bytes) > 0) VO_CHECK_HIP(c, hipMemcpyAsync(base + (off), (ptr), (bytes), hipMemcpyHostToDevice, s))
-  UP(oT, T_jw, sizeof(double) * 16 * Nf);
-  UP(oOpt, opt_index, sizeof(int) * Nf);
-  UP(oX, X, sizeof(double) * 3 * M);
-  UP(oOp, obs_ptr, sizeof(int) * (M + 1));
-  UP(oOf, obs_frame, sizeof(int) * nobs);
-  UP(oOr, obs_right, (size_t)nobs);
-  UP(oPx, obs_px, sizeof(double) * 2 * nobs);
-  UP(oSp, slot_ptr.data(), sizeof(int) * (M + 1));
-  UP(oSo, slot_obs.data(), sizeof(int) * ns);
-  UP(oSj, slot_j.data(), sizeof(int) * ns);
-  UP(oSb, slot_bobs.data(), sizeof(int) * ns);
-  UP(oSl, slot_lm.data(), sizeof(int) * (ns + nobs));
-  UP(oPop, pose_obs_ptr.data(), sizeof(int) * (No + 1));
-  UP(oPo, pose_obs_flat.data(), sizeof(int) * pose_obs_flat.size());
-  UP(oPsp, pose_slot_ptr.data(), sizeof(int) * (No + 1));
-  UP(oPs, pose_slot_flat.data(), sizeof(int) * ns);
-  UP(oPp, pair_ptr.data(), sizeof(int) * ((size_t)No * No + 1));
-  UP(oPa, pair_a.data(), sizeof(int) * pair_a.size());
-  UP(oPb, pair_b.data(), sizeof(int) * pair_b.size());
-#undef UP
-  VO_CHECK_HIP(c, hipMemsetAsync(base + oFl, 0, sizeof(int) * 4, s));
-  VO_CHECK_HIP(c, hipMemsetAsync(base + oAvg, 0, sizeof(double) * (p->max_iter + 1), s));
+  VO_CHECK_HIP(c, hipStreamSynchronize(s));  // (the staging block of the previous solve has been consumed)
+  if (c->sba->stage_cap < stage_need) {
+    if (c->sba->stage) (void)hipHostFree(c->sba->stage);
+    c->sba->stage = nullptr;
+    c->sba->stage_cap = 0;
+    VO_CHECK_HIP(c, hipHostMalloc(&c->sba->stage, stage_need + (stage_need >> 2), hipHostMallocDefault));
+    c->sba->stage_cap = stage_need + (stage_need >> 2);
+  }
+  uint8_t *base = (uint8_t *)c->sba->dev;
+  uint8_t *hs = (uint8_t *)c->sba->stage;
+  memcpy(hs + oT, T_jw, sizeof(double) * 16 * Nf);
+  memcpy(hs + oOpt, opt_index, sizeof(int) * Nf);
+  memcpy(hs + oX, X, sizeof(double) * 3 * M);
+  memcpy(hs + oOp, obs_ptr, sizeof(int) * (M + 1));
+  memcpy(hs + oOf, obs_frame, sizeof(int) * nobs);
+  memcpy(hs + oOr, obs_right, (size_t)nobs);
+  memcpy(hs + oPx, obs_px, sizeof(double) * 2 * nobs);
+  memset(hs + oFl, 0, sizeof(int) * 4);
+  memset(hs + oAvg, 0, sizeof(double) * (p->max_iter + 1));
+  int *h_slot_ptr = (int *)(hs + oSp), *h_slot_obs = (int *)(hs + oSo), *h_slot_j = (int *)(hs + oSj);
+  int *h_slot_bobs = (int *)(hs + oSb), *h_slot_lm = (int *)(hs + oSl);
+  int *h_pose_obs_ptr = (int *)(hs + oPop), *h_pose_obs = (int *)(hs + oPo);
+  int *h_pose_slot_ptr = (int *)(hs + oPsp), *h_pose_slot = (int *)(hs + oPs);
+  int *h_pair_ptr = (int *)(hs + oPp), *h_pair_a = (int *)(hs + oPa), *h_pair_b = (int *)(hs + oPb);
+  h_pose_obs_ptr[0] = h_pose_slot_ptr[0] = 0;
+  for (int j = 0; j < No; ++j) {
+    h_pose_obs_ptr[j + 1] = h_pose_obs_ptr[j] + pose_obs_cnt[j];
+    h_pose_slot_ptr[j + 1] = h_pose_slot_ptr[j] + pose_slot_cnt[j];
+  }
+  h_pair_ptr[0] = 0;
+  for (size_t jk = 0; jk < (size_t)No * No; ++jk) h_pair_ptr[jk + 1] = h_pair_ptr[jk] + pair_cnt[jk];
+  {  // pass 2 (cursors start at the list heads; every list comes out in landmark order, as the nested containers gave it)
+    std::vector<int> cur_po(h_pose_obs_ptr, h_pose_obs_ptr + No), cur_ps(h_pose_slot_ptr, h_pose_slot_ptr + No);
+    std::vector<int> cur_pair(h_pair_ptr, h_pair_ptr + (size_t)No * No);
+    int sidx = 0;
+    h_slot_ptr[0] = 0;
+    for (int i = 0; i < M; ++i) {
+      const int s0 = sidx;
+      for (int o = obs_ptr[i]; o < obs_ptr[i + 1]; ++o) {
+        h_slot_lm[ns + o] = i;  // (second half of the array: the landmark of every observation)
+        const int j = opt_index[obs_frame[o]];
+        if (j < 0) continue;
+        h_pose_obs[cur_po[j]++] = o;
+        if (obs_right[o]) continue;
+        // slot: left observation in an optimised keyframe; its B block is that of the LAST observation of this
+        // landmark in the same keyframe (:315 / :410 assign, they do not accumulate)
+        int last = o;
+        for (int o2 = o + 1; o2 < obs_ptr[i + 1]; ++o2)
+          if (opt_index[obs_frame[o2]] == j) last = o2;
+        h_pose_slot[cur_ps[j]++] = sidx;
+        h_slot_obs[sidx] = o;
+        h_slot_j[sidx] = j;
+        h_slot_bobs[sidx] = last;
+        h_slot_lm[sidx] = i;
+        ++sidx;
+      }
+      // pairs (:475-491): slots a, b of one landmark with list position b >= a contribute to block (j_a, j_b)
+      for (int a2 = s0; a2 < sidx; ++a2)
+        for (int b2 = a2; b2 < sidx; ++b2) {
+          const int q = cur_pair[(size_t)h_slot_j[a2] * No + h_slot_j[b2]]++;
+          h_pair_a[q] = a2;
+          h_pair_b[q] = b2;
+        }
+      h_slot_ptr[i + 1] = sidx;
+    }
+  }
+  VO_CHECK_HIP(c, hipMemcpyAsync(base, hs, in_bytes, hipMemcpyHostToDevice, s));
   SbaDev d;
   memset(&d, 0, sizeof(d));
   d.n_frames = Nf;
@@ -895,11 +921,19 @@ extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, co
   VO_CHECK_HIP(c, hipGetLastError());
   int flags[4] = {0, 0, 0, 0};
   std::vector<double> errs(p->max_iter + 1, 0.0);
-  VO_CHECK_HIP(c, hipMemcpyAsync(flags, base + oFl, sizeof(flags), hipMemcpyDeviceToHost, s));
-  VO_CHECK_HIP(c, hipMemcpyAsync(errs.data(), base + oAvg, sizeof(double) * (p->max_iter + 1), hipMemcpyDeviceToHost, s));
-  VO_CHECK_HIP(c, hipMemcpyAsync(T_jw, base + oT, sizeof(double) * 16 * Nf, hipMemcpyDeviceToHost, s));
-  VO_CHECK_HIP(c, hipMemcpyAsync(X, base + oX, sizeof(double) * 3 * M, hipMemcpyDeviceToHost, s));
-  VO_CHECK_HIP(c, hipStreamSynchronize(s));
+  {  // results through the pinned staging block (its upload half has been consumed: the copies are stream-ordered)
+    double *o_T = (double *)hs, *o_X = o_T + 16 * (size_t)Nf, *o_e = o_X + 3 * (size_t)M;
+    int *o_f = (int *)(o_e + p->max_iter + 1);
+    VO_CHECK_HIP(c, hipMemcpyAsync(o_T, base + oT, sizeof(double) * 16 * Nf, hipMemcpyDeviceToHost, s));
+    VO_CHECK_HIP(c, hipMemcpyAsync(o_X, base + oX, sizeof(double) * 3 * M, hipMemcpyDeviceToHost, s));
+    VO_CHECK_HIP(c, hipMemcpyAsync(o_e, base + oAvg, sizeof(double) * (p->max_iter + 1), hipMemcpyDeviceToHost, s));
+    VO_CHECK_HIP(c, hipMemcpyAsync(o_f, base + oFl, sizeof(flags), hipMemcpyDeviceToHost, s));
+    VO_CHECK_HIP(c, hipStreamSynchronize(s));
+    memcpy(T_jw, o_T, sizeof(double) * 16 * Nf);
+    memcpy(X, o_X, sizeof(double) * 3 * M);
+    memcpy(errs.data(), o_e, sizeof(double) * (p->max_iter + 1));
+    memcpy(flags, o_f, sizeof(flags));
+  }
   SBA_T(2);
   if (trace && (++n_calls % 10) == 0)
     fprintf(stderr, "[sba] per call (us): lists %.0f  upload %.0f  kernels+d2h %.0f\n", tt[0] / n_calls, tt[1] / n_calls, tt[2] / n_calls);

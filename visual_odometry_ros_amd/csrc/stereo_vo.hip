@@ -540,6 +540,9 @@ extern "C" void vo_svo_destroy(vo_svo *s) {
   if (s->d_accept) (void)hipFree(s->d_accept);
   if (s->d_hdr) (void)hipFree(s->d_hdr);
   if (s->h_hdr) (void)hipHostFree(s->h_hdr);
+  void *pinned[] = {s->h_ids, s->h_pl, s->h_pr, s->h_Xw, s->h_fl};
+  for (void *p : pinned)
+    if (p) (void)hipHostFree(p);
   delete s;
 }
 

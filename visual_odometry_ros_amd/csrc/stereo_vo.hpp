@@ -23,19 +23,15 @@ struct SvoHdr {  // written by svo_advance_kernel: device copy and pinned host c
   int pad;
 };
 
-struct SvoObs {  // lm->getObservationsOnKeyframes() / getRelatedKeyframePtr(): one stereo keyframe
-  int serial;
-  float pl[2], pr[2];
-};
-struct SvoLandmark {  // landmarks that were seen on a keyframe (the local BA's population)
-  float X[3];
-  bool tri, alive;
-  std::vector<SvoObs> obs;
-};
+// Keyframe-centric storage of what the reference keeps per landmark (getObservationsOnKeyframes / getRelatedKeyframePtr):
+// a keyframe holds its related landmarks' ids and both pixels. The ids of a track set are ASCENDING (survivors keep their
+// order, new landmarks get larger ids and are appended), so the landmark population of a window and every landmark's
+// observation list come out of one merge over the window's keyframes — no per-landmark containers.
 struct SvoKeyframe {
   int serial, frame_id;
   float T_wc[16];
-  std::vector<int32_t> ids;  // related landmarks (filled when the local BA is on)
+  std::vector<int32_t> ids;   // (filled when the local BA is on)
+  std::vector<float> pl, pr;  // [n][2]
 };
 
 struct vo_svo {
@@ -59,8 +55,17 @@ struct vo_svo {
   // keyframes
   std::vector<SvoKeyframe> keyframes;  // the window (stereo_kfs_list_)
   int n_keyframes = 0, n_kf_lms = 0;
-  std::vector<SvoLandmark> lms;        // by landmark id (local BA on)
-  std::vector<uint8_t> lm_known;
+  // landmarks that were seen on a keyframe, by id (local BA on): lm->get3DPoint(), isTriangulated() (bit 0), !isAlive() (bit 1)
+  std::vector<float> lmX;
+  std::vector<uint8_t> lmS;
+  // pinned staging of the keyframe's track set (device -> host) and of what the BA changed (host -> device)
+  int32_t *h_ids = nullptr;
+  float *h_pl = nullptr, *h_pr = nullptr, *h_Xw = nullptr;
+  uint8_t *h_fl = nullptr;
+  // the BA problem, rebuilt at every keyframe into the same buffers
+  std::vector<double> ba_X, ba_px, ba_T;
+  std::vector<int32_t> ba_obs_ptr, ba_obs_frame, ba_used, ba_opt;
+  std::vector<uint8_t> ba_obs_right;
 };
 
 void svo_mul44(const float A[16], const float B[16], float C[16]);

@@ -16,6 +16,7 @@
 // addresses. Here: ascending landmark id (as oracle/stereo_vo.py).
 // The host part runs at keyframe rate on a few thousand landmarks; everything per observation is on the device (sba.hip).
 #include <math.h>
+#include <stdint.h>
 
 #include <algorithm>
 
@@ -74,81 +75,87 @@ int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info) {
   static double tt[8];
   static int n_calls;
   double t_last = trace ? lba_now() : 0.0;
-  // ---- the new keyframe's related landmarks, after the reconstruction kernel (main stream) ----
-  std::vector<int32_t> ids(std::max(n, 1));
-  std::vector<float> pl(2 * (size_t)std::max(n, 1)), pr(2 * (size_t)std::max(n, 1)), Xw(3 * (size_t)std::max(n, 1));
-  std::vector<uint8_t> fl(std::max(n, 1));
+  hipStream_t st = c->stream;
+  // ---- the new keyframe's related landmarks, after the reconstruction kernel (main stream), through pinned memory ----
+  if (!s->h_ids) {
+    const size_t cap = (size_t)s->cap;
+    VO_CHECK_HIP(c, hipHostMalloc((void **)&s->h_ids, sizeof(int32_t) * cap, hipHostMallocDefault));
+    VO_CHECK_HIP(c, hipHostMalloc((void **)&s->h_pl, sizeof(float) * 2 * cap, hipHostMallocDefault));
+    VO_CHECK_HIP(c, hipHostMalloc((void **)&s->h_pr, sizeof(float) * 2 * cap, hipHostMallocDefault));
+    VO_CHECK_HIP(c, hipHostMalloc((void **)&s->h_Xw, sizeof(float) * 3 * cap, hipHostMallocDefault));
+    VO_CHECK_HIP(c, hipHostMalloc((void **)&s->h_fl, cap, hipHostMallocDefault));
+  }
+  int32_t *ids = s->h_ids;
+  float *pl = s->h_pl, *pr = s->h_pr, *Xw = s->h_Xw;
+  uint8_t *fl = s->h_fl;
   if (n > 0) {
-    hipStream_t st = c->stream;
-    VO_CHECK_HIP(c, hipMemcpyAsync(ids.data(), t.ids, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
-    VO_CHECK_HIP(c, hipMemcpyAsync(pl.data(), t.pts_l, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, st));
-    VO_CHECK_HIP(c, hipMemcpyAsync(pr.data(), t.pts_r, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, st));
-    VO_CHECK_HIP(c, hipMemcpyAsync(Xw.data(), t.Xw, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, st));
-    VO_CHECK_HIP(c, hipMemcpyAsync(fl.data(), t.flags, (size_t)n, hipMemcpyDeviceToHost, st));
+    VO_CHECK_HIP(c, hipMemcpyAsync(ids, t.ids, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+    VO_CHECK_HIP(c, hipMemcpyAsync(pl, t.pts_l, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, st));
+    VO_CHECK_HIP(c, hipMemcpyAsync(pr, t.pts_r, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, st));
+    VO_CHECK_HIP(c, hipMemcpyAsync(Xw, t.Xw, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, st));
+    VO_CHECK_HIP(c, hipMemcpyAsync(fl, t.flags, (size_t)n, hipMemcpyDeviceToHost, st));
     VO_CHECK_HIP(c, hipStreamSynchronize(st));
   }
   LBA_T(0);
   SvoKeyframe &kf = s->keyframes.back();
-  kf.ids.assign(ids.begin(), ids.begin() + n);
-  for (int k = 0; k < n; ++k) {  // state as of this keyframe + the observation on it
-    const int id = ids[k];
-    if ((size_t)id >= s->lms.size()) s->lms.resize((size_t)id + 1 + 4096);
-    SvoLandmark &L = s->lms[id];
-    if (L.obs.empty()) L.alive = true;
-    L.X[0] = Xw[3 * k];
-    L.X[1] = Xw[3 * k + 1];
-    L.X[2] = Xw[3 * k + 2];
-    L.tri = (fl[k] & VO_LM_TRIANGULATED) != 0;
-    SvoObs o;
-    o.serial = kf.serial;
-    o.pl[0] = pl[2 * k];
-    o.pl[1] = pl[2 * k + 1];
-    o.pr[0] = pr[2 * k];
-    o.pr[1] = pr[2 * k + 1];
-    L.obs.push_back(o);
+  kf.ids.assign(ids, ids + n);
+  kf.pl.assign(pl, pl + 2 * (size_t)n);
+  kf.pr.assign(pr, pr + 2 * (size_t)n);
+  if (n > 0 && (size_t)ids[n - 1] >= s->lmS.size()) {  // (ids ascend: the last one is the largest)
+    const size_t want = (size_t)ids[n - 1] + 1 + 8192;
+    s->lmX.resize(3 * want, 0.0f);
+    s->lmS.resize(want, 0);
+  }
+  for (int k = 0; k < n; ++k) {  // the landmarks' state as of this keyframe
+    const size_t id = (size_t)ids[k];
+    s->lmX[3 * id] = Xw[3 * k];
+    s->lmX[3 * id + 1] = Xw[3 * k + 1];
+    s->lmX[3 * id + 2] = Xw[3 * k + 2];
+    s->lmS[id] = (uint8_t)((s->lmS[id] & 2) | ((fl[k] & VO_LM_TRIANGULATED) ? 1 : 0));
   }
   LBA_T(1);
-  const std::vector<SvoKeyframe> &win = s->keyframes;
+  std::vector<SvoKeyframe> &win = s->keyframes;
   const int nk = (int)win.size();
   if (nk < 3) return VO_OK;  // NUM_MINIMUM_REQUIRED_KEYFRAMES (motion_estimator.cpp:1245-1253)
   const double POSE_SCALE = 10.0, inv_scale = 1.0 / POSE_SCALE;
-  const int serial0 = win.front().serial;  // serials are consecutive inside the window
-  // ---- SparseBAParameters::setPosesAndPoints ----
-  std::vector<int32_t> lm_ids;
-  for (const SvoKeyframe &k : win)
-    for (int32_t id : k.ids)
-      if (s->lms[id].tri && s->lms[id].alive) lm_ids.push_back(id);
-  std::sort(lm_ids.begin(), lm_ids.end());
-  lm_ids.erase(std::unique(lm_ids.begin(), lm_ids.end()), lm_ids.end());
+  // ---- SparseBAParameters::setPosesAndPoints: one merge over the window's (ascending) id lists ----
   double Twj_ref[16], Tjw_ref[16];
   to_d(win.front().T_wc, Twj_ref);
   inv_se3d(Twj_ref, Tjw_ref);
-  std::vector<double> X, px;
-  std::vector<int32_t> obs_ptr(1, 0), obs_frame, used;
-  std::vector<uint8_t> obs_right;
-  X.reserve(3 * lm_ids.size());
-  for (int32_t id : lm_ids) {
-    const SvoLandmark &L = s->lms[id];
-    const size_t o0 = obs_frame.size();
-    for (const SvoObs &o : L.obs) {
-      const int j = o.serial - serial0;
-      if (j < 0 || j >= nk) continue;
+  std::vector<double> &X = s->ba_X, &px = s->ba_px, &T_jw = s->ba_T;
+  std::vector<int32_t> &obs_ptr = s->ba_obs_ptr, &obs_frame = s->ba_obs_frame, &used = s->ba_used, &opt = s->ba_opt;
+  std::vector<uint8_t> &obs_right = s->ba_obs_right;
+  X.clear();
+  px.clear();
+  obs_ptr.assign(1, 0);
+  obs_frame.clear();
+  obs_right.clear();
+  used.clear();
+  size_t cur[32] = {0};
+  if (nk > 32) VO_FAIL(c, VO_ERR_CAPACITY, "keyframe window of %d", nk);
+  for (;;) {
+    int32_t id = INT32_MAX;
+    for (int j = 0; j < nk; ++j)
+      if (cur[j] < win[j].ids.size() && win[j].ids[cur[j]] < id) id = win[j].ids[cur[j]];
+    if (id == INT32_MAX) break;
+    const bool take = (s->lmS[id] & 1) && !(s->lmS[id] & 2);  // isTriangulated() && isAlive()
+    bool any = false;
+    for (int j = 0; j < nk; ++j) {
+      if (!(cur[j] < win[j].ids.size() && win[j].ids[cur[j]] == id)) continue;
+      const size_t q = cur[j]++;
+      if (!take) continue;
+      any = true;  // (a stereo keyframe gives two observations: THRES_MINIMUM_SEEN = 2 always holds)
       obs_frame.push_back(j);
       obs_frame.push_back(j);
       obs_right.push_back(0);
       obs_right.push_back(1);
-      px.push_back((double)o.pl[0]);
-      px.push_back((double)o.pl[1]);
-      px.push_back((double)o.pr[0]);
-      px.push_back((double)o.pr[1]);
+      px.push_back((double)win[j].pl[2 * q]);
+      px.push_back((double)win[j].pl[2 * q + 1]);
+      px.push_back((double)win[j].pr[2 * q]);
+      px.push_back((double)win[j].pr[2 * q + 1]);
     }
-    if (obs_frame.size() - o0 < 2) {  // THRES_MINIMUM_SEEN (a stereo keyframe gives two observations)
-      obs_frame.resize(o0);
-      obs_right.resize(o0);
-      px.resize(2 * o0);
-      continue;
-    }
-    const double Xd[3] = {(double)L.X[0], (double)L.X[1], (double)L.X[2]};
+    if (!any) continue;
+    const double Xd[3] = {(double)s->lmX[3 * (size_t)id], (double)s->lmX[3 * (size_t)id + 1], (double)s->lmX[3 * (size_t)id + 2]};
     double Xr[3];
     xformd(Tjw_ref, Xd, Xr);  // warpToRef
     for (int k = 0; k < 3; ++k) X.push_back(Xr[k] * inv_scale);  // scalingPoint
@@ -156,8 +163,8 @@ int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info) {
     used.push_back(id);
   }
   if (used.empty()) return VO_OK;
-  std::vector<double> T_jw(16 * (size_t)nk);
-  std::vector<int32_t> opt(nk);
+  T_jw.resize(16 * (size_t)nk);
+  opt.resize(nk);
   for (int j = 0; j < nk; ++j) {
     float Tjw_f[16];
     double Tjw[16];
@@ -201,7 +208,7 @@ int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info) {
     for (int k = 0; k < 16; ++k) T[k] = T_jw[16 * j + k];
     for (int r = 0; r < 3; ++r) T[r * 4 + 3] *= POSE_SCALE;  // recoverOriginalScalePose
     mul44d(T, Tjw_ref, Tjw);                                 // changeInvPoseRefToWorld
-    to_d(s->keyframes[j].T_wc, Twj_orig);
+    to_d(win[j].T_wc, Twj_orig);
     mul44d(Twj_orig, Tjw, dT);
     const double tn = sqrt(dT[3] * dT[3] + (dT[7] * dT[7] + dT[11] * dT[11]));
     if (tn > 50) VO_FAIL(c, VO_ERR_LBA_NAN, "local BA: large update!");
@@ -209,33 +216,33 @@ int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info) {
     for (int k = 0; k < 12; ++k) Tf[k] = (float)Tjw[k];
     Tf[12] = Tf[13] = Tf[14] = 0.0f;
     Tf[15] = 1.0f;
-    svo_inv_se3(Tf, s->keyframes[j].T_wc);  // kf->setPose(inverseSE3_f(Tjw_update_float))
+    svo_inv_se3(Tf, win[j].T_wc);  // kf->setPose(inverseSE3_f(Tjw_update_float))
   }
   for (size_t i = 0; i < used.size(); ++i) {
     double xs[3] = {X[3 * i] * POSE_SCALE, X[3 * i + 1] * POSE_SCALE, X[3 * i + 2] * POSE_SCALE}, xw[3];
     xformd(Twj_ref, xs, xw);  // warpToWorld
-    SvoLandmark &L = s->lms[used[i]];
-    L.X[0] = (float)xw[0];
-    L.X[1] = (float)xw[1];
-    L.X[2] = (float)xw[2];
-    L.tri = true;  // set3DPoint
-    const float nrm = sqrtf(L.X[0] * L.X[0] + (L.X[1] * L.X[1] + L.X[2] * L.X[2]));
-    if (!(nrm <= 3000)) L.alive = false;  // setDead
+    const size_t id = (size_t)used[i];
+    float *L = &s->lmX[3 * id];
+    L[0] = (float)xw[0];
+    L[1] = (float)xw[1];
+    L[2] = (float)xw[2];
+    s->lmS[id] |= 1;  // set3DPoint
+    const float nrm = sqrtf(L[0] * L[0] + (L[1] * L[1] + L[2] * L[2]));
+    if (!(nrm <= 3000)) s->lmS[id] |= 2;  // setDead
   }
   LBA_T(4);
-  // ---- what the BA did to the landmarks the next frame tracks ----
+  // ---- what the BA did to the landmarks the next frame tracks (the pinned staging arrays go back up) ----
   for (int k = 0; k < n; ++k) {
-    const SvoLandmark &L = s->lms[ids[k]];
-    Xw[3 * k] = L.X[0];
-    Xw[3 * k + 1] = L.X[1];
-    Xw[3 * k + 2] = L.X[2];
-    if (L.tri) fl[k] |= VO_LM_TRIANGULATED;
-    if (!L.alive) fl[k] |= VO_LM_DROPPED;
+    const size_t id = (size_t)ids[k];
+    Xw[3 * k] = s->lmX[3 * id];
+    Xw[3 * k + 1] = s->lmX[3 * id + 1];
+    Xw[3 * k + 2] = s->lmX[3 * id + 2];
+    if (s->lmS[id] & 1) fl[k] |= VO_LM_TRIANGULATED;
+    if (s->lmS[id] & 2) fl[k] |= VO_LM_DROPPED;
   }
-  if (n > 0) {
-    VO_CHECK_HIP(c, hipMemcpyAsync(t.Xw, Xw.data(), sizeof(float) * 3 * n, hipMemcpyHostToDevice, c->stream));
-    VO_CHECK_HIP(c, hipMemcpyAsync(t.flags, fl.data(), (size_t)n, hipMemcpyHostToDevice, c->stream));
-    VO_CHECK_HIP(c, hipStreamSynchronize(c->stream));  // (the staging vectors go out of scope)
+  if (n > 0) {  // (stream-ordered in front of the next frame; the staging arrays are next written behind a synchronisation)
+    VO_CHECK_HIP(c, hipMemcpyAsync(t.Xw, Xw, sizeof(float) * 3 * n, hipMemcpyHostToDevice, st));
+    VO_CHECK_HIP(c, hipMemcpyAsync(t.flags, fl, (size_t)n, hipMemcpyHostToDevice, st));
   }
   LBA_T(5);
   if (trace && (++n_calls % 10) == 0)
