@@ -345,6 +345,98 @@ class StereoBench:
             if on_result is not None:
                 on_result(step, r)
 
+    # ---- the reference's own class surface: one operator call per step, host arrays in and out -----------------------
+    def class_surface_frame(self, step, slots, me, stamp):
+        """One frame as stereo_vo.cpp:483-711 calls the three classes: priors on the host, trackWithPrior, trackWithScale,
+        trackWithPrior, poseOnlyBundleAdjustment_Stereo, the y-gate, updateWeightBin, extractORBwithBinning_fast,
+        trackBidirection — numpy arrays in and out of every call, compactions on the host, images through the slot cache
+        (one upload + pyramid per image and frame; stamp None = per call, as the reference)."""
+        a, b = self.frame_id(step), self.frame_id(step + 1)
+        ts = self.track_sets[(a, b)]
+        I0l, (I1l, I1r) = self.imgs[a][0], self.imgs[b]
+        thr, W, H = self.cfg["thres"], self.W, self.H
+        f = np.float32
+        K = np.asarray(self.stream.K, f)
+        n = ts["pts_l0"].shape[0]
+        tri = (ts["flags"] & 1) != 0
+        # [3] priors and patch scale (:483-522)
+        def inv_se3(T):  # geometry::inverseSE3_f in float32, the operation order of the library's own
+            T = np.asarray(T, f)
+            Rt = T[:3, :3].T.copy()
+            o = np.eye(4, dtype=f)
+            o[:3, :3] = Rt
+            for i in range(3):
+                o[i, 3] = f(f(f(-Rt[i, 0]) * T[0, 3]) + f(f(-Rt[i, 1]) * T[1, 3])) + f(f(-Rt[i, 2]) * T[2, 3])
+            return o
+
+        def xform(T, X):  # R X + t in float32, one rounding per operation, left to right
+            return np.stack([((T[r, 0] * X[:, 0] + T[r, 1] * X[:, 1]) + T[r, 2] * X[:, 2]) + T[r, 3] for r in range(3)], 1).astype(f)
+        T_cp, T_rl = inv_se3(ts["dT_prior"]), inv_se3(self.stream.T_lr)
+        Xp = ts["Xp"].astype(f)
+        Xl1 = xform(T_cp, Xp)
+        Xr1 = xform(T_rl, Xl1)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            izl, izr = f(1.0) / Xl1[:, 2], f(1.0) / Xr1[:, 2]
+            pl = np.stack([K[0] * Xl1[:, 0] * izl + K[2], K[1] * Xl1[:, 1] * izl + K[3]], 1).astype(f)
+            pr = np.stack([K[0] * Xr1[:, 0] * izr + K[2], K[1] * Xr1[:, 1] * izr + K[3]], 1).astype(f)
+            scale = np.where(tri, Xp[:, 2] / Xl1[:, 2], f(1.0)).astype(f)
+
+        def inimg(p):
+            return (p[:, 0] >= 3) & (p[:, 1] >= 3) & (p[:, 0] < W - 3) & (p[:, 1] < H - 3)
+        ok = tri & inimg(pl) & inimg(pr) & (Xl1[:, 2] >= 0.1) & (Xr1[:, 2] >= 0.1)
+        pl1 = np.where(ok[:, None], pl, ts["pts_l0"])
+        pr1 = np.where(ok[:, None], pr, ts["pts_r0"])
+        # [4] l0 -> l1
+        s0 = slots.get(I0l, stamp)
+        s1 = slots.get(I1l, stamp, avoid=(s0,))
+        p, m = self.ft.trackWithPrior(s0, s1, ts["pts_l0"], self.win, self.max_level, thr[0], pl1)
+        m = m & ((ts["flags"] & 2) == 0)
+        i1 = np.nonzero(m)[0]
+        # [4-1] trackWithScale (the derivative images are computed on the device from I0)
+        s0 = slots.get(I0l, stamp, avoid=(s1,))
+        s1 = slots.get(I1l, stamp, avoid=(s0,))
+        p2, m2 = self.ft.trackWithScale(s0, s1, ts["pts_l0"][i1], scale[i1], p[i1], None, strict_border=bool(self.args.strict_border))
+        i2 = i1[m2]
+        # [5] l1 -> r1
+        s1 = slots.get(I1l, stamp)
+        s2 = slots.get(I1r, stamp, avoid=(s1,))
+        q, m3 = self.ft.trackWithPrior(s1, s2, p2[m2], self.win, self.max_level, thr[0], pr1[i2])
+        i3 = i2[m3]
+        pl3, pr3 = p2[m2][m3], q[m3]
+        # [6] pose-only BA on the triangulated survivors (:595-646)
+        tb = tri[i3]
+        okb, T, mask, info = me.poseOnlyBundleAdjustment_Stereo(ts["Xp"][i3][tb], pl3[tb], pr3[tb], K, K, self.stream.T_lr, thr[2],
+                                                                ts["dT_prior"])
+        motion = np.ones(i3.shape[0], bool)
+        motion[np.nonzero(tb)[0]] = mask
+        fin = motion & ~(pl3[:, 1] > 660)  # [7]
+        stage = np.zeros(n, np.uint8)
+        stage[i1] = 1
+        stage[i2] = 2
+        stage[i3] = 3
+        stage[i3[fin]] = 4
+        # [10] updateWeightBin, extractORBwithBinning_fast, trackBidirection (:691-711)
+        self.fe.updateWeightBin(pl3[fin])
+        s1 = slots.get(I1l, stamp)
+        pts_new = self.fe.extractORBwithBinning_fast(s1)
+        s1 = slots.get(I1l, stamp)
+        s2 = slots.get(I1r, stamp, avoid=(s1,))
+        pnr, mn = self.ft.trackBidirection(s1, s2, pts_new, self.win, self.max_level, thr[0], thr[1])
+        return dict(stage=stage, dT=T, pts_new=pts_new, pts_new_r=pnr, mask_new=mn)
+
+    def run_class_surface(self, first, count, cached, stamps=None):
+        from visual_odometry_ros_amd.api import ImageSlots
+        self.ctx.set_ingest_side_stream(False)
+        slots = ImageSlots(self.ctx, (0, 1, 2, 3))
+        me = self.V.MotionEstimator(self.ctx, True, self.stream.T_lr)
+        out = None
+        for step in range(first, first + count):
+            out = self.class_surface_frame(step, slots, me, (step + 1) if cached else None)
+            if stamps is not None:
+                stamps.append(time.perf_counter())
+        self.last_uploads = slots.uploads
+        return out
+
     def prime(self, mode, host=False):
         """Slots P / CL / CR for step 0 and, closed, the candidate table of CL; then a few untimed frames (lazy
         allocations, code-object loads)."""
@@ -576,6 +668,28 @@ def secondary_legs(cfg, args, rank, local_rank, torch, V, barrier):
     dts = timed(lambda: B.run(f0 + w, args.steps, "closed", False, None, st), barrier, B.ctx)
     sec["r02_ground_truth_track_sets_back_and_forth"] = {"value": round(args.steps / dts, 2), "unit": "frames/s",
                                                          "frame_ms": frame_ms_stats(st)}
+    # the reference's own class surface on the same frames: what a maintainer gets by swapping the three classes only
+    kc = min(args.steps, 100)
+    for name, cached in (("class_surface", True), ("class_surface_uploads_per_call", False)):
+        B.run_class_surface(0, 3, cached)
+        st = []
+        dts = timed(lambda: B.run_class_surface(3, kc, cached, st), barrier, B.ctx)
+        sec[name] = {"value": round(kc / dts, 2), "unit": "frames/s", "frame_ms": frame_ms_stats(st),
+                     "image_uploads_per_frame": round(B.last_uploads / kc, 2)}
+    sec["class_surface"]["note"] = ("one frame = the operator calls of stereo_vo.cpp:483-711 through FeatureTracker / MotionEstimator / "
+                                    "FeatureExtractor with host arrays in and out (priors and compactions on the host), ground-truth "
+                                    "track sets; images identified by (buffer, size, frame stamp): 3 uploads + pyramids per frame; "
+                                    "class_surface_uploads_per_call: no stamp, every call uploads and rebuilds, as the reference does")
+    # same frame through the fused operator: the survivor sets must agree
+    B.ctx.set_ingest_side_stream(True)
+    f0 = B.prime("closed", False)
+    keep = []
+    args_cpu = args.cpu_frames
+    args.cpu_frames = 1
+    B.run(f0, 1, "closed", False, keep)
+    args.cpu_frames = args_cpu
+    cs = B.run_class_surface(f0, 1, True)
+    sec["class_surface"]["survivors_equal_fused_operator"] = bool(np.array_equal(keep[0][1]["stage"], cs["stage"]))
     B.ctx.close()
     return sec
 

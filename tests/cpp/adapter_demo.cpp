@@ -64,7 +64,11 @@ int main(int argc, char **argv) {
   }
   MaskVec mv;
   const cv::Mat I0(h, w, CV_8UC1, img0.data(), (size_t)w), I1(h, w, CV_8UC1, img1.data(), (size_t)w);
-  const cv::Mat du0, dv0;  // accepted and ignored (recomputed on the device)
+  // cv::Sobel(previous_left_image_, du0, CV_32FC1, ...) of the driver: the adapter recomputes the derivatives on the device
+  // from I0 and only checks that what it is handed has I0's size
+  std::vector<float> dbuf((size_t)I0.rows * I0.cols, 0.0f);
+  const cv::Mat du0(I0.rows, I0.cols, CV_32FC1, dbuf.data(), sizeof(float) * (size_t)I0.cols);
+  const cv::Mat dv0(I0.rows, I0.cols, CV_32FC1, dbuf.data(), sizeof(float) * (size_t)I0.cols);
   ft.trackWithPrior(I0, I1, p0, 21, 4, 80.0f, ptk, mv);
   std::vector<float> scale(npt, 1.0f);
   MaskVec mv2;

@@ -46,6 +46,18 @@ int use_feature_extractor(const cv::Mat &img, const cv::Mat &da, const cv::Mat &
   return e.descriptorDistance(da, db);
 }
 
+// stereo_vo.h:233-249: the signatures the ROS nodes call (ros2/visual_odometry/stereo_vo_ros2.cpp:104-126)
+float use_stereo_vo(const cv::Mat &img_left, const cv::Mat &img_right, const double &timestamp) {
+  vo::StereoVOParams p;  // (the YAML's numbers; cv::FileStorage loading stays the caller's)
+  StereoVO svo(p);
+  svo.trackStereoImages(img_left, img_right, timestamp);
+  const StereoVO::AlgorithmStatistics &st = svo.getStatistics();
+  const PoseSE3 &Twc = st.stats_frame.back().Twc;
+  const cv::Mat &dbg = svo.getDebugImage();
+  (void)dbg;
+  return Twc(0, 3) + st.stats_execution.back().time_total + (float)st.stats_landmark.back().n_final;
+}
+
 // ---- run-time part (CPU only): the conversions ----
 static int fails = 0;
 #define EXPECT(c)                                               \

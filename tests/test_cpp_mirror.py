@@ -32,6 +32,7 @@ def test_cpp_mirror_compiles_and_links(vo, tmp_path):
     exe = _compile(tmp_path)
     assert os.path.exists(exe)
     assert os.path.exists(_compile(tmp_path, "frame_demo"))
+    assert os.path.exists(_compile(tmp_path, "stereo_vo_demo"))
     # the reference-typed adapter, against the type-check stand-ins (tests/test_reference_adapter.py has the details)
     assert os.path.exists(_compile(tmp_path, "adapter_demo", ADAPTER_INC))
 
@@ -198,3 +199,44 @@ def test_cpp_frame_pipelines_match_python_api(vo, tmp_path):
         assert off == len(raw)
     finally:
         c.close()
+
+
+@pytest.mark.gpu
+def test_cpp_stereo_vo_writes_the_python_loops_trajectory(vo, tmp_path):
+    """vo::StereoVO (core/visual_odometry/stereo_vo.h: trackStereoImages / getStatistics on POD images) over 20 pairs, with
+    the local BA and the one-frame-ahead hand-over: frame ids, keyframes, track-set sizes and poses equal to the Python
+    mirror's (api.StereoVO) bit for bit, and the trajectory file it leaves behind has the same bytes as the one written
+    from the Python loop's poses (the reference's dump format)."""
+    W, H, K = 640, 240, (400.0, 400.0, 320.0, 120.0)
+    st = S.StereoStream(width=W, height=H, K=K, n_u=20, n_v=8, seed=5, speed=0.5)
+    n = 20
+    imgs = [st.render_pair(p)[:2] for p in st.poses(n)]
+    kw = dict(thres_trans=1.2, thres_alive_ratio=0.6, thres_rotation=15.0)
+    exe = _compile(tmp_path, "stereo_vo_demo")
+    inp, outp, traj = tmp_path / "svo_in.bin", tmp_path / "svo_out.bin", tmp_path / "traj_cpp.txt"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("9i", n, W, H, 20, 8, 21, 4, 1, 1))
+        f.write(np.array(list(K) + list(np.asarray(st.T_lr, np.float32).reshape(16)) +
+                         [80.0, 0.5, 3.0, kw["thres_alive_ratio"], kw["thres_trans"], kw["thres_rotation"]], np.float32).tobytes())
+        for L, R in imgs:
+            f.write(np.ascontiguousarray(L).tobytes())
+            f.write(np.ascontiguousarray(R).tobytes())
+    subprocess.check_call([exe, str(inp), str(outp), str(traj)])
+    raw = np.fromfile(outp, np.uint8).reshape(n, 16 + 64)
+    rec = raw[:, :16].copy().view(np.int32)
+    T_cpp = raw[:, 16:].copy().view(np.float32).reshape(n, 4, 4)
+    c = vo.Context(device=0, max_width=W, max_height=H, max_points=4096, n_slots=5, max_level=4)
+    svo = vo.StereoVO(c, W, H, K, K, st.T_lr, 20, 8, thres_fastscore=15, window_size=21, max_level=4, local_ba=True, **kw)
+    ids, Ts = [], []
+    for k, (L, R) in enumerate(imgs):
+        i = svo.trackStereoImages(L, R)
+        assert (i.frame_id, i.is_keyframe, i.n_tracks_out, i.lba_ran) == tuple(int(v) for v in rec[k]), k
+        T = np.array(i.T_wc, np.float32).reshape(4, 4)
+        assert np.array_equal(T.view(np.uint32), T_cpp[k].view(np.uint32)), k
+        ids.append(i.frame_id)
+        Ts.append(T)
+    svo.close()
+    c.close()
+    assert rec[:, 3].sum() >= 3 and rec[:, 1].sum() >= 5
+    vo.write_trajectory(str(tmp_path / "traj_py.txt"), ids, np.stack(Ts))
+    assert open(traj, "rb").read() == open(tmp_path / "traj_py.txt", "rb").read()

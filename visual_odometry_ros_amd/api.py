@@ -157,6 +157,35 @@ class Context:
         return n.value, ms.value
 
 
+class ImageSlots:
+    """What stands between the reference's cv::Mat arguments and the context's image slots (the C++ classes keep the same
+    table, feature_tracker.h: slot_for): an image is identified by (buffer address, size, caller-supplied frame stamp);
+    a slot that already holds it is reused — upload and pyramid once per image and frame instead of once per operator
+    call (the reference rebuilds 8 pyramids per stereo frame) — otherwise the least recently used slot takes it.
+    stamp None: no identity, always uploaded (the reference's behaviour)."""
+
+    def __init__(self, ctx, slots):
+        self.ctx, self.slots = ctx, list(slots)
+        self.key = {s: None for s in self.slots}
+        self.clock, self.used = 0, {s: 0 for s in self.slots}
+        self.uploads = 0
+
+    def get(self, img, stamp=None, avoid=()):
+        img = _u8(img)
+        k = None if stamp is None else (img.ctypes.data, img.shape, img.strides[0], stamp)
+        self.clock += 1
+        if k is not None:
+            for s in self.slots:
+                if self.key[s] == k:
+                    self.used[s] = self.clock
+                    return s
+        s = min((q for q in self.slots if q not in avoid), key=lambda q: self.used[q])
+        self.ctx.set_image(s, img)
+        self.uploads += 1
+        self.key[s], self.used[s] = k, self.clock
+        return s
+
+
 class FeatureTracker:
     """Mirror of the reference FeatureTracker. Images live in context slots
     (set with Context.set_image) instead of cv::Mat arguments; everything else
