@@ -647,11 +647,44 @@ def run_loop(cfg, args, rank, local_rank, world, torch, V, barrier, dev, imgs, s
         "per_rank_fps": [round(p[0] / p[1], 2) for p in per_rank],
     }
     svo.close()
+    prm_svo = svo.prm
     if secondary:
         out["secondary"] = secondary_legs(cfg, args, rank, local_rank, torch, V, barrier)
+        if args.batch_S:
+            out["secondary"]["streams_per_gpu"] = batch_leg(cfg, args, local_rank, torch, V, dev, prm_svo, cap)
     if world == 1 and not args.no_cpu_baseline:
         out.update(cpu_baseline_loop(cfg, args, st, imgs, traj, V, local_rank))
     return out, ctx
+
+
+def batch_leg(cfg, args, local_rank, torch, V, dev, prm_svo, cap):
+    """S independent streams on ONE GPU through vo_batch_* (C++ host threads inside the library): aggregate and per-stream
+    frames/s for every S, and the check that a stream's poses and final track ids do not depend on its neighbours."""
+    W, H = cfg["W"], cfg["H"]
+    nf, warm = args.batch_frames, 8
+    d = [[(torch.from_numpy(np.ascontiguousarray(L)).to(dev), torch.from_numpy(np.ascontiguousarray(R)).to(dev)) for L, R in st]
+         for st in args.batch_imgs]
+    torch.cuda.synchronize()
+    Lp = [[a.data_ptr() for a, _ in st] for st in d]
+    Rp = [[b.data_ptr() for _, b in st] for st in d]
+    alone = []
+    for q in range(len(d)):  # every stream by itself: the reference result of that stream
+        b = V.StereoBatch(local_rank, 1, W, H, cap, cfg["max_level"], prm_svo)
+        alone.append(b.run([Lp[q]], [Rp[q]], W, warmup=warm))
+        b.close()
+    res = {}
+    for S in args.batch_S:
+        b = V.StereoBatch(local_rank, S, W, H, cap, cfg["max_level"], prm_svo)
+        r = b.run(Lp[:S], Rp[:S], W, warmup=warm)
+        b.close()
+        same = all(np.array_equal(r["T_wc"][q].view(np.uint32), alone[q]["T_wc"][0].view(np.uint32)) and
+                   np.array_equal(r["ids"][q], alone[q]["ids"][0]) for q in range(S))
+        per = [(nf - warm) / float(t) for t in r["seconds"]]
+        res[str(S)] = {"aggregate_fps": round(S * (nf - warm) / r["wall"], 1), "per_stream_fps_min": round(min(per), 1),
+                       "per_stream_fps_max": round(max(per), 1), "poses_and_track_ids_equal_single_stream_run": bool(same)}
+    res["note"] = (f"{nf - warm} timed frames per stream (closed loop incl. local BA = {bool(args.lba)}, strict-border mode "
+                   f"{args.strict_border}), streams of seeds 100.., a context + StereoVO + host thread per stream inside libvo_hip.so")
+    return res
 
 
 def secondary_legs(cfg, args, rank, local_rank, torch, V, barrier):
@@ -781,6 +814,10 @@ def main():
     ap.add_argument("--no-prefetch", action="store_true",
                     help="loop mode: hand every pair over only when its frame starts (no ingestion under the previous frame)")
     ap.add_argument("--render-workers", type=int, default=0, help="processes that render the synthetic stream (0 = all cores)")
+    ap.add_argument("--streams-per-gpu", default="1,2,4,8",
+                    help="loop mode, secondary leg: S independent streams on ONE GPU through the library's batch driver "
+                         "(vo_batch_*: a context, a StereoVO and a host thread per stream); comma-separated S values, '' = off")
+    ap.add_argument("--batch-frames", type=int, default=48, help="frames per stream of that leg (the first 8 untimed)")
     ap.add_argument("--host-images", action="store_true",
                     help="headline loop with host images (default: images resident in HBM; the host-image rate is a "
                          "secondary field of the default run)")
@@ -806,6 +843,8 @@ def main():
     if loop:  # (before anything GPU-related is imported: the renderer's pool forks)
         per_rank_workers = max(1, (args.render_workers or host_cores()) // max(world, 1))
         imgs = render_stream(cfg, stream_seed(rank), loop_frames_needed(args), per_rank_workers)
+        args.batch_S = [int(v) for v in args.streams_per_gpu.split(",") if v.strip()] if (world == 1 and not args.no_secondary) else []
+        args.batch_imgs = [render_stream(cfg, 100 + q, args.batch_frames, per_rank_workers) for q in range(max(args.batch_S, default=0))]
     # torch first: its bundled libamdhip64.so.7 must be THE HIP runtime of the process;
     # libvo_hip.so (NEEDED libamdhip64.so.7) then binds to the already-loaded one.
     import torch

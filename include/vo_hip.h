@@ -438,6 +438,22 @@ int vo_svo_get_new_points(vo_svo *svo, float *pts_l, float *pts_r, uint8_t *mask
 int vo_triangulate_dlt(vo_ctx *ctx, const float *pts0, const float *pts1, int n, const float T_10[16], const float K0[4],
                        const float K1[4], float *X0, float *X1);
 
+/* ---- batch of sequences on one device ---------------------------------------------------------------------
+ * S independent stereo streams on ONE GPU, each with its own context (HIP streams, slots, landmark / frame id counters:
+ * SURVEY F11), its own StereoVO and its own host thread inside the library. (BASELINE's batch mode proper is one stream
+ * per GPU; a single sequential stream is latency-bound and leaves most of an MI355X idle.) The streams share nothing.
+ * vo_batch_run: stream s tracks the pairs left[s * n_frames + k], right[...] (k = 0..n_frames-1; device pointers when
+ * on_device != 0) in order, pair k+1 handed over while frame k is in flight; the first `warmup` frames of every stream are
+ * untimed and all streams start the timed part together. Outputs (each may be NULL): T_wc [n_streams][n_frames][16],
+ * last_ids [n_streams][ids_cap] + n_ids [n_streams] (every stream's final track-set ids), seconds [n_streams] (timed
+ * wall time per stream), *wall (first start to last end). */
+typedef struct vo_batch vo_batch;
+int vo_batch_create(const vo_config *cfg, const vo_svo_params *prm, int n_streams, vo_batch **out);
+void vo_batch_destroy(vo_batch *batch);
+const char *vo_batch_last_error(const vo_batch *batch);
+int vo_batch_run(vo_batch *batch, const void *const *left, const void *const *right, int n_frames, int stride, int on_device,
+                 int warmup, float *T_wc, int32_t *last_ids, int ids_cap, int *n_ids, double *seconds, double *wall);
+
 /* ---- undistortion / stereo rectification in front of the trackers ----------
  * core/visual_odometry/camera.cpp. A context holds the maps of two cameras
  * (cam 0 = left or the mono camera, cam 1 = right), device-resident. */

@@ -101,7 +101,8 @@ SYMBOLS = [
     "vo_set_ingest_side_stream", "vo_set_stereo_pair_host_async", "vo_new_point_candidates_enqueue",
     "vo_new_point_candidates_get", "vo_stereo_frame_enqueue_closed", "vo_stereo_frame_new_points",
     "vo_stereo_frame_enqueue_closed_world", "vo_stereo_frame_recoveries", "vo_svo_create", "vo_svo_destroy", "vo_svo_track", "vo_svo_enqueue",
-    "vo_svo_prefetch", "vo_svo_result", "vo_svo_get_tracks", "vo_svo_get_new_points", "vo_triangulate_dlt",
+    "vo_svo_prefetch", "vo_svo_result", "vo_svo_get_tracks", "vo_svo_get_new_points", "vo_triangulate_dlt", "vo_batch_create", "vo_batch_destroy",
+    "vo_batch_last_error", "vo_batch_run",
     "vo_se3_exp", "vo_ids_reset", "vo_ids_peek", "vo_ids_new_frames", "vo_ids_new_landmarks", "vo_compact_tracks",
 ]
 
@@ -150,5 +151,11 @@ def load():
     lib.vo_svo_get_tracks.argtypes = [vp, vp, vp, vp, vp, vp, ci, vp]
     lib.vo_svo_get_new_points.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.vo_triangulate_dlt.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp]
+    lib.vo_batch_create.argtypes = [C.POINTER(VoConfig), C.POINTER(SvoParams), ci, C.POINTER(C.c_void_p)]
+    lib.vo_batch_destroy.argtypes = [vp]
+    lib.vo_batch_destroy.restype = None
+    lib.vo_batch_last_error.argtypes = [vp]
+    lib.vo_batch_last_error.restype = C.c_char_p
+    lib.vo_batch_run.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp]
     _lib = lib
     return lib

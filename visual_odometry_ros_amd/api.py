@@ -846,6 +846,47 @@ class StereoVO:
         return dict(stats_frame=[T.copy() for T in self.stats_frame])
 
 
+class StereoBatch:
+    """S independent stereo streams on one GPU (include/vo_hip.h: vo_batch_*): a context, a StereoVO and a host thread per
+    stream inside the library. `svo_params` = StereoVO(...).prm of a template object (or an SvoParams)."""
+
+    def __init__(self, device, n_streams, width, height, max_points, max_level, svo_params):
+        self.lib = _capi.load()
+        self.n, self.prm = int(n_streams), svo_params
+        self.cfg = VoConfig(device, width, height, max_points, 5, max_level)
+        self._h = C.c_void_p()
+        rc = self.lib.vo_batch_create(C.byref(self.cfg), C.byref(svo_params), self.n, C.byref(self._h))
+        if rc < 0:
+            raise VoError(rc, "vo_batch_create failed")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.vo_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, left_ptrs, right_ptrs, stride, warmup=0, on_device=True, ids_cap=8192):
+        """left_ptrs / right_ptrs: [n_streams][n_frames] addresses. Returns dict(T_wc, ids (list), seconds, wall)."""
+        nf = len(left_ptrs[0])
+        L = (C.c_void_p * (self.n * nf))(*[p for row in left_ptrs for p in row])
+        R = (C.c_void_p * (self.n * nf))(*[p for row in right_ptrs for p in row])
+        T = np.zeros((self.n, nf, 4, 4), np.float32)
+        ids = np.zeros((self.n, ids_cap), np.int32)
+        nid = np.zeros(self.n, np.int32)
+        sec = np.zeros(self.n, np.float64)
+        wall = C.c_double()
+        rc = self.lib.vo_batch_run(self._h, L, R, nf, int(stride), int(bool(on_device)), int(warmup), T.ctypes.data, ids.ctypes.data,
+                                   ids_cap, nid.ctypes.data, sec.ctypes.data, C.addressof(wall))
+        if rc < 0:
+            raise VoError(rc, self.lib.vo_batch_last_error(self._h).decode())
+        return dict(T_wc=T, ids=[ids[s, :nid[s]].copy() for s in range(self.n)], seconds=sec, wall=wall.value)
+
+
 def make_mono_params(width, height, win, max_level, thres_err, thres_bidir, thres_poseba, thres_sampson, K):
     p = MonoParams()
     p.width, p.height, p.win, p.max_level = width, height, win, max_level

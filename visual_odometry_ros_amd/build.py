@@ -86,7 +86,7 @@ def build(force=False, verbose=False):
             list(ex.map(run, jobs))
     relink = bool(jobs) or not os.path.exists(LIB)
     if relink:
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
