@@ -88,6 +88,40 @@ def frame_kernel_bytes(win, n, n_l0l1, n_step5, n_cand, levels, levels_bwd, stri
     return klt + IC_BYTES_8D * n_l0l1, (IC_RECORD_BYTES * n if strict else 0) + POINT_IO_BYTES * (n + n_cand)
 
 
+def stamped_counters(config):
+    """HBM traffic (PMC) and VALU instruction counts (SQ) of the dominant kernel from the committed rocprofv3 counter
+    passes — quoted only while the kernel's sources still hash to what the passes ran on (a stale file is dropped)."""
+    out = {"traffic": None, "valu_wave_instructions_per_launch": None, "counters_note": None}
+    try:
+        from visual_odometry_ros_amd.build import kernel_source_sha
+        sha = kernel_source_sha()
+    except Exception:
+        return out
+    tag = "r03" if config == 1 else f"r03_cfg{config}"
+    stale = []
+    for key, name in (("pmc", f"{tag}_frame_pmc.json"), ("sq", f"{tag}_frame_sq_counters.json")):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("kernel_source_sha") != sha:
+            stale.append(name)
+            continue
+        if key == "pmc":
+            out["traffic"] = d.get("hbm_bytes_per_launch")
+        else:
+            for k, e in d.get("kernels", {}).items():
+                if "frame_track" in k and "SQ_INSTS_VALU" in e:
+                    out["valu_wave_instructions_per_launch"] = e["SQ_INSTS_VALU"]
+                    out["sq_launch_note"] = f"{e.get('SQ_WAVES')} wavefronts per launch in the counter pass"
+    if stale:
+        out["counters_note"] = "stale (kernel sources changed since the counter pass): " + ", ".join(stale)
+    return out
+
+
 # ---- the one collective --------------------------------------------------------------------------------------------
 def gather_ranks(frames, seconds, seed, world, device=None):
     """The one collective of the job: an all_gather of {frames, seconds, stream seed} per rank
@@ -579,6 +613,19 @@ def run_loop(cfg, args, rank, local_rank, world, torch, V, barrier, dev, imgs, s
         b_des += (IC_RECORD_BYTES * n_in if strict else 0) + POINT_IO_BYTES * (n_in + n_kp_bins[k])
     achieved = ((b_req + b_spec) / launches) / (klt_ms / launches * 1e-3) / 1e9 if klt_n else 0.0
     achieved_req = (b_req / launches) / (klt_ms / launches * 1e-3) / 1e9 if klt_n else 0.0
+    counters = stamped_counters(args.config)
+    issue = None
+    if counters["valu_wave_instructions_per_launch"] and klt_n:
+        # a SIMD issues one wave64 VALU instruction per 4 cycles: 256 CUs x 4 SIMDs x clk / 4 wave-instructions per second
+        clk = 2.4e9
+        peak_issue = 256 * 4 * clk / 4.0
+        ach_issue = counters["valu_wave_instructions_per_launch"] / (klt_ms / launches * 1e-3)
+        issue = {"bound": "valu_issue", "achieved": round(ach_issue / 1e9, 1), "peak": round(peak_issue / 1e9, 1),
+                 "unit": "G wave-instructions/s", "frac": round(ach_issue / peak_issue, 4),
+                 "valu_wave_instructions_per_launch": counters["valu_wave_instructions_per_launch"],
+                 "note": "VALU wave-instructions per launch (rocprofv3 SQ_INSTS_VALU, committed counter pass on the same kernel "
+                         "sources) / live launch duration, against 1024 SIMDs x 2.4 GHz / 4; the launch is issue-bound while the "
+                         "SIMDs are full and then waits for single wavefronts (DESIGN.md §4.2)"}
     # trajectory against the renderer's ground truth (frame 0 = identity)
     T0i = np.linalg.inv(poses_gt[0])
     gt = np.stack([(T0i @ p)[:3, 3] for p in poses_gt[:len(traj)]])
@@ -634,7 +681,7 @@ def run_loop(cfg, args, rank, local_rank, world, torch, V, barrier, dev, imgs, s
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": None,
+            "traffic": counters["traffic"],
             "achieved_required_only": round(achieved_req, 2),
             "frac_required_only": round(achieved_req / HBM_PEAK_GBS, 5),
             "alg_bytes_per_launch": {"survey_8d_required": round(b_req / launches), "survey_8d_speculative": round(b_spec / launches),
@@ -644,8 +691,11 @@ def run_loop(cfg, args, rank, local_rank, world, torch, V, barrier, dev, imgs, s
                     "required_only leaves out the candidates the reference would not have tracked; the path is issue/latency-"
                     "bound, the fraction is reported because the metric asks for it (DESIGN.md §6)",
         },
+        "roofline_issue": issue,
         "per_rank_fps": [round(p[0] / p[1], 2) for p in per_rank],
     }
+    if counters["counters_note"]:
+        out["roofline"]["counters_note"] = counters["counters_note"]
     svo.close()
     prm_svo = svo.prm
     if secondary:

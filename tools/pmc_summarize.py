@@ -49,6 +49,11 @@ def main():
     out["per_kernel_KiB_per_frame"] = {x.split("(")[0][:48]: {"fetch": round(f_per[x] * ff / frames, 1), "write": round(w_per.get(x, 0.0) * wf / frames, 1)}
                                        for x in sorted(f_per, key=lambda q: -f_per[q])[:14]}
     out["command"] = "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace --output-format csv -- python3 bench.py --no-cpu-baseline --strict-border 1 --no-secondary --steps 60 --warmup 10 (two passes; counter collection serialises kernels across queues, hence the stream-ordered replay; tools/run_profiles_r02.sh)"
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from visual_odometry_ros_amd.build import kernel_source_sha
+    out["kernel_source_sha"] = kernel_source_sha()  # bench.py quotes these numbers only while the kernel's sources still hash to this
+    if len(sys.argv) > 5:
+        out["command"] = sys.argv[5]
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"{tag}_frame_pmc.json")
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(out)[:600])

@@ -36,6 +36,19 @@ def headers():
     return hs
 
 
+FRAME_KERNEL_SOURCES = ("frame_fused.hip", "klt_device.hpp", "ic_device.hpp", "vo_internal.hpp")
+
+
+def kernel_source_sha(names=FRAME_KERNEL_SOURCES):
+    """Identity of the dominant kernel's code: what profiles/*_frame_pmc.json / *_sq_counters.json were measured on.
+    bench.py reports their numbers only while this still matches (a stale counter file is dropped, not quoted)."""
+    h = hashlib.sha256()
+    for n in names:
+        with open(os.path.join(CSRC, n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def _tool_version():
     try:
         return subprocess.run([HIPCC, "--version"], capture_output=True, text=True).stdout
