@@ -334,9 +334,9 @@ __device__ __forceinline__ KltResult klt_point(const vo_level *I, const vo_level
 
     // bilinear difference of the current window against the template, per lane: dp[m] = packed pair of
     // (J sample - template sample) for samples 2m, 2m+1 (each within +-8160)
-    auto eval_diffs = [&](int inx, int iny, int w00, int w01, int w10, int w11, uint32_t (&dp)[NP]) {
+    auto eval_diffs = [&](int inx, int iny, int w00, int w01, int w10, int w11, uint32_t (&dp)[NP], bool check = true) {
       // window inside the staged tile <=> 0 <= inx - tjx <= slack_x and 0 <= iny - tjy <= slack_y
-      if (__builtin_expect((unsigned)inx - (unsigned)tjx > (unsigned)(C::TJ_WD * 4 - 3 - C::SPAN - 1) ||
+      if (check && __builtin_expect((unsigned)inx - (unsigned)tjx > (unsigned)(C::TJ_WD * 4 - 3 - C::SPAN - 1) ||
                                (unsigned)iny - (unsigned)tjy > (unsigned)(C::TJ_H - WIN - 1),
                            0)) {
         tjx = (inx - C::M) & ~3;
@@ -400,7 +400,12 @@ __device__ __forceinline__ KltResult klt_point(const vo_level *I, const vo_level
       iw10 = (int)rintf((1.f - fa) * fb * (1 << KLT_W_BITS));
       iw11 = (1 << KLT_W_BITS) - iw00 - iw01 - iw10;
       uint32_t dp[NP];
+#ifdef KLT_UNSAFE_SKIP_WINDOW_TEST_AFTER  // MEASUREMENT ONLY: an upper bound for what predicting an
+      // oscillating run and dropping its search-tile window test could save; not correct when the window leaves the tile
+      eval_diffs(inx, iny, iw00, iw01, iw10, iw11, dp, j < KLT_UNSAFE_SKIP_WINDOW_TEST_AFTER);
+#else
       eval_diffs(inx, iny, iw00, iw01, iw10, iw11, dp);
+#endif
       int pb1 = 0, pb2 = 0;
 #pragma unroll
       for (int m = 0; m < NP; ++m) {
