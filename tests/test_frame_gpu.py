@@ -111,7 +111,9 @@ def test_stereo_frame_automatic_replay_mode(ctx, oracle):
     before = ctx.frame_recoveries()
     _run_stream(ctx, oracle, stream, 6, 4)
     if os.environ.get("VO_DEBUG_FAIL_JOIN"):  # (child of test_join_timeout_is_recovered_not_reported)
-        assert ctx.frame_recoveries() == before + 1  # one frame re-issued, then the context stays stream-ordered
+        # exactly one frame of this context was ever re-issued (here or in an earlier test of the process): after it the
+        # context stays on the stream-ordered arrangement
+        assert ctx.frame_recoveries() == 1
     else:
         assert ctx.frame_recoveries() == before
 

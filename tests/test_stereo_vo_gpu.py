@@ -86,7 +86,7 @@ def _run_both(vo, oracle, W, H, K, nu, nv, frames, win, lvl, n_frames, lba, stri
         c.close()
 
 
-@pytest.mark.parametrize("strict,prefetch", [(4, False), (1, True), (0, True)])
+@pytest.mark.parametrize("strict,prefetch", [(4, False), (1, True), (0, True), (3, True)])
 def test_closed_loop_small(vo, oracle, strict, prefetch):
     W, H, K = 640, 240, (400.0, 400.0, 320.0, 120.0)
     frames = _stream(W, H, K, 20, 8, 5, 0.5, 12)
@@ -113,3 +113,16 @@ def test_closed_loop_with_local_ba(vo, oracle):
     frames = _stream(W, H, K, 20, 8, 5, 0.5, 14)
     log, ref = _run_both(vo, oracle, W, H, K, 20, 8, frames, 21, 4, 14, lba=True, strict=4, prefetch=True, kf_trans=1.2)
     assert sum(1 for e in log if e[2]) >= 3, log
+
+
+def test_closed_loop_survives_a_join_timeout():
+    """The loop in strict-border mode 3 with a device-side join that cannot be met (VO_DEBUG_FAIL_JOIN, fresh child process):
+    the first steady-state frame is issued again with the stream-ordered replay — and with it the DLT workers and the
+    epilogue that builds the next track set — and every frame still equals the CPU loop bit for bit."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, VO_DEBUG_FAIL_JOIN="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "test_closed_loop_small and 3-True"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -64,6 +64,8 @@ int vo_frame_init(vo_ctx *c) {
   VO_CHECK_HIP(c, hipMalloc((void **)&f->ctl, vo_ic_ctl_bytes()));
   VO_CHECK_HIP(c, hipMemsetAsync(f->ctl, 0, vo_ic_ctl_bytes(), c->stream));
   // [1] = finished workgroups of the replay's last kernel; from byte 128 on: 64 shards of the pass-1 count, 128 bytes apart
+  VO_CHECK_HIP(c, hipMalloc((void **)&f->adv_done, 64));
+  VO_CHECK_HIP(c, hipMemsetAsync(f->adv_done, 0, 64, c->stream));
   VO_CHECK_HIP(c, hipMalloc((void **)&f->sync, 128 + 64 * 128));
   VO_CHECK_HIP(c, hipMemsetAsync(f->sync, 0, 128 + 64 * 128, c->stream));
   return VO_OK;
@@ -76,7 +78,7 @@ void vo_frame_free(vo_ctx *c) {
                   f->A_X, f->A_scale, f->A_orig, f->B_pl1, f->B_pr1, f->B_X, f->B_orig, f->C_pl1, f->C_pr1,
                   f->C_X, f->C_orig, f->m1, f->m2, f->m3, f->mG, f->st1, f->st2, f->e1, f->e2, f->new_back,
                   f->A_ref, f->A_lastpu, f->A_touched, f->A_cls, f->res_dev, f->st3, f->e3, f->ctl, f->sync, f->in_flags, f->bin_r,
-                  f->bin_m};
+                  f->bin_m, f->adv_done};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   if (f->res_host) (void)hipHostFree(f->res_host);
@@ -105,6 +107,15 @@ static void inv_se3(const float T[16], float Ti[16]) {
     int _rc = (x);           \
     if (_rc < 0) return _rc; \
   } while (0)
+
+// StereoVO (stereo_vo.hip): the next vo_frame_enqueue_impl lets the BA launch build the next track set
+int vo_frame_set_advance(vo_ctx *c, const VoAdvArgs *adv) {
+  int rc = vo_frame_init(c);
+  if (rc < 0) return rc;
+  c->frame->adv_next = *adv;
+  c->frame->adv_next.on = 1;
+  return VO_OK;
+}
 
 extern "C" int vo_stereo_frame_set_strict_border(vo_ctx *c, int strict) {
   if (!c) return VO_ERR_INVALID;
@@ -282,6 +293,7 @@ int vo_frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, i
     f->again.has_bins = bp ? 1 : 0;
     if (bp) f->again.bins = *bp;
     f->again.table = table;
+    f->again.adv = f->adv_next;  // (consumed below)
     f->again.has_world = T_pw ? 1 : 0;
     if (T_pw) {
       memcpy(f->again.T_pw, T_pw, sizeof(f->again.T_pw));
@@ -453,6 +465,15 @@ int vo_frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, i
       gf.np_host_m = f->res_host + f->off_mnew;
     }
   }
+  VoAdvArgs adv_now = f->adv_next;
+  f->adv_next.on = 0;
+  if (adv_now.on) {
+    if (!(fused && tab)) VO_FAIL(c, VO_ERR_INVALID, "the track-set advance needs the closed frame on the fused path");
+    f->adv_total += (tab->n_bins + 63) / 64;  // one worker wavefront per 64 bins (gn_pose.hip)
+    adv_now.dlt_done = f->adv_done;
+    adv_now.dlt_target = f->adv_total;
+    gf.adv = &adv_now;
+  }
   RC(vo_gn_enqueue(c, true, false, f->C_X, f->C_pl1, f->C_pr1, n, nullptr, prm->Kl, prm->Kr,
                    prm->T_lr, prm->thres_poseba, 0, dT_prior, f->hdr->dT, f->mG, &f->hdr->gn, true,
                    n > 0 ? f->stage : nullptr, f->C_orig, 4, 60.0f, n > 0 ? &gf : nullptr));
@@ -560,6 +581,7 @@ extern "C" int vo_stereo_frame_result(vo_ctx *c, float *pts_l1, float *pts_r1, u
     c->frame_conc_off = 1;
     ++c->frame_recoveries;
     const auto g = f->again;  // (by value: the enqueue below rewrites f->again)
+    f->adv_next = g.adv;      // (StereoVO: the re-issued frame builds the next track set again)
     int rc2 = vo_frame_enqueue_impl(c, &g.prm, g.slot_l0, g.slot_l1, g.slot_r1, g.l0, g.r0, g.X, g.fl, g.n, g.dT_prior, g.pts_new,
                                     g.n_new, 1, g.has_bins ? &g.bins : nullptr, g.table, g.has_world ? g.T_pw : nullptr,
                                     g.has_world ? g.T_cw_prior : nullptr);
@@ -608,6 +630,7 @@ extern "C" int vo_stereo_frame_result(vo_ctx *c, float *pts_l1, float *pts_r1, u
     if (h->flags & 1) VO_FAIL(c, VO_ERR_NAN_AXAY, "ax ay nan");
     if (h->flags & 2) VO_FAIL(c, VO_ERR_NAN_PATCH, "I0 I1 / du0 dv0 nan");
     if (h->flags & 8) VO_FAIL(c, VO_ERR_HIP, "the strict-border replay stream did not finish (device-side join timed out twice)");
+    if (h->flags & 16) VO_FAIL(c, VO_ERR_HIP, "the triangulation workers of the BA launch did not finish");
     VO_FAIL(c, VO_ERR_NAN_UPDATE, "dtu dtv nan");
   }
   if (h->gn.is_nan) VO_FAIL(c, VO_ERR_GN_FAILED, "PoseOnlyStereoBA is failed!");

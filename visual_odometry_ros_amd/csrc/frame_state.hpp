@@ -1,6 +1,7 @@
 // frame_state.hpp — device / pinned buffers shared by the frame operators (frame_pipeline.hip: stereo,
 // frame_mono.hip: mono). Allocated once per context by vo_frame_init (capacity cfg.max_points).
 #pragma once
+#include "svo_device.hpp"
 #include "vo_internal.hpp"
 
 // header of the packed result block (device and pinned-host copies share the layout)
@@ -70,7 +71,13 @@ struct vo_frame_state {
     int has_bins, table, has_world;
     vo_bin_params bins;
     float T_pw[16], T_cw_prior[16];
+    VoAdvArgs adv;
   } again;
+  // StereoVO: what the NEXT enqueue hands to the BA launch so that its epilogue builds the next track set
+  // (vo_frame_set_advance, consumed by that enqueue); the DLT workers' cumulative completion count and its running target
+  VoAdvArgs adv_next;
+  int *adv_done;
+  int adv_total;
   int recovered;      // the last result was produced by such a re-issue
 };
 

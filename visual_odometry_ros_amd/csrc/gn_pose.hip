@@ -20,6 +20,7 @@
 #include "vo_internal.hpp"
 #include "vo_kernels.hpp"
 #include "mono_gate.hpp"
+#include "svo_device.hpp"
 
 #define GN_T 512
 #define GN_NW (GN_T / 64)
@@ -72,6 +73,7 @@ struct GnArgs {
   int f_res_late_words;     // leading words (header, stage bytes) that this kernel still changes: copied last
   int f_seq, f_seq_word;    // the host block's "result complete" word
   VoNpArgs np;              // closed step [10] (vo_gn_frame::np_*)
+  VoAdvArgs adv;            // StereoVO: the next track set (svo_device.hpp); workgroups 1.. of the launch are its DLT workers
   const uint8_t *f_m1, *f_m2, *f_m3;  // mono frame: selection masks in place of f_stage
   int f_mono;               // epilogue = mono_gate_body(f_gate)
   MonoGateArgs f_gate;
@@ -449,6 +451,26 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
+  if (blockIdx.x > 0) {
+    // ---- StereoVO, workgroups 1..: stereo_vo.cpp:721-725 for EVERY bin's candidate (speculatively, next to the
+    // iterations of workgroup 0): mapping::triangulateDLT of the candidate and its tracked right pixel, both depths
+    // positive. One wavefront per 64 bins; the verdicts are written through, then the wavefront counts itself done.
+    if (STEREO && wave == 0 && a.adv.on) {
+      const int b = ((int)blockIdx.x - 1) * 64 + lane;
+      if (b < a.np.bins) {
+        int acc = 0;
+        if (a.np.has[b] && a.np.bin_m[b]) {
+          float Xl[3], Xr[3];
+          svo_triangulate(a.adv.cam, a.np.xy[2 * b], a.np.xy[2 * b + 1], a.np.bin_r[2 * b], a.np.bin_r[2 * b + 1], Xl, Xr);
+          acc = (Xl[2] > 0 && Xr[2] > 0) ? 1 : 0;
+        }
+        __hip_atomic_store(&a.adv.acc_bin[b], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __builtin_amdgcn_s_waitcnt(0);
+      if (lane == 0) atomicAdd(a.adv.dlt_done, 1);
+    }
+    return;
+  }
 #ifdef GN_STAMP
 #define GSTAMP(k) if (tid == 0) vo_gn_stamps[k] = (long long)__builtin_amdgcn_s_memrealtime();
 #else
@@ -763,6 +785,20 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
   } else if (a.f_n > 0 && a.f_res_host) {
     // frame mode epilogue: the packed result block goes to pinned host memory from here
     __syncthreads();  // stage marks, pose and info above are this workgroup's own stores
+    if (STEREO && a.adv.on) {
+      // the DLT workers (workgroups 1..) finished long ago — they take ~15 us, the iterations above 40+; bounded anyway
+      if (tid == 0) {
+        int polls = 0;
+        while ((int)(__hip_atomic_load(a.adv.dlt_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.adv.dlt_target) < 0) {
+          if (++polls > (1 << 17)) {
+            atomicOr(a.f_hdr_flags, 16);  // reported by vo_stereo_frame_result
+            break;
+          }
+          __builtin_amdgcn_s_sleep(16);
+        }
+      }
+      __syncthreads();
+    }
     if (a.np.bins > 0) {
       // ---- closed step [10]: updateWeightBin(lmtrack_final.pts_l1) + emission (np_emit.hpp), with the
       // trackBidirection results (stereo_vo.cpp:706-711) the frame kernel computed for every bin's candidate.
@@ -771,6 +807,96 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
       const uint8_t sv = (uint8_t)a.stage_val;
       vo_np_emit(a.np, a.f_n, a.f_pl1, [&](int i) { return stg[i] == sv; }, tid, GN_T, (uint8_t *)s_red, (int *)s_tot,
                  &a.f_cnt[5]);
+    }
+    if (STEREO && a.adv.on) {
+      // ---- StereoVO: the next frame's track set. lmtrack_final (stereo_vo.cpp:670: the stage-4 features in index order,
+      // with their landmarks), then the new landmarks of step [10] (:729-734: candidate order, ids from the landmark
+      // counter, NOT triangulated: set3DPoint is commented out at :736). setStereoPtsSeenAndRelatedLandmarks (:752).
+      int *s_wv = (int *)s_tot;  // [GN_NW] + [GN_NW]: members of the last keyframe among the survivors
+      const VoAdvArgs &v = a.adv;
+      const uint8_t sv4 = (uint8_t)a.stage_val;
+      int base = 0, kf = 0;
+      for (int c0 = 0; c0 < a.f_n; c0 += GN_T) {
+        const int i = c0 + tid;
+        const bool keep = i < a.f_n && a.stage[i] == sv4;
+        const uint8_t fl = keep ? v.cur.flags[i] : 0;
+        const unsigned long long bal = __ballot(keep);
+        kf += __popcll(__ballot(keep && (fl & VO_LM_KF_MEMBER)));
+        if (lane == 0) s_wv[wave] = __popcll(bal);
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < GN_NW; ++w) {
+          const int cw = s_wv[w];
+          woff += w < wave ? cw : 0;
+          tot += cw;
+        }
+        if (keep) {
+          const int o = base + woff + __popcll(bal & ((1ull << lane) - 1ull));
+          if (o < v.cap) {
+            v.nxt.pts_l[2 * o] = a.f_pl1[2 * i];
+            v.nxt.pts_l[2 * o + 1] = a.f_pl1[2 * i + 1];
+            v.nxt.pts_r[2 * o] = a.f_pr1[2 * i];
+            v.nxt.pts_r[2 * o + 1] = a.f_pr1[2 * i + 1];
+            v.nxt.Xw[3 * o] = v.cur.Xw[3 * i];
+            v.nxt.Xw[3 * o + 1] = v.cur.Xw[3 * i + 1];
+            v.nxt.Xw[3 * o + 2] = v.cur.Xw[3 * i + 2];
+            v.nxt.flags[o] = fl;
+            v.nxt.ids[o] = v.cur.ids[i];
+          }
+        }
+        base += tot;
+        __syncthreads();
+      }
+      if (lane == 0) s_wv[GN_NW + wave] = kf;
+      const int n_surv = base;
+      const int n_emit = a.np.bins > 0 ? a.f_cnt[5] : 0;  // (thread 0's store, behind vo_np_emit's last barrier)
+      for (int c0 = 0; c0 < n_emit; c0 += GN_T) {
+        const int j = c0 + tid;
+        const bool keep = j < n_emit && a.np.out_acc[j];
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) s_wv[wave] = __popcll(bal);
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < GN_NW; ++w) {
+          const int cw = s_wv[w];
+          woff += w < wave ? cw : 0;
+          tot += cw;
+        }
+        if (keep) {
+          const int o = base + woff + __popcll(bal & ((1ull << lane) - 1ull));
+          if (o < v.cap) {
+            v.nxt.pts_l[2 * o] = a.np.out_l[2 * j];
+            v.nxt.pts_l[2 * o + 1] = a.np.out_l[2 * j + 1];
+            v.nxt.pts_r[2 * o] = a.np.out_r[2 * j];
+            v.nxt.pts_r[2 * o + 1] = a.np.out_r[2 * j + 1];
+            v.nxt.Xw[3 * o] = 0.0f;
+            v.nxt.Xw[3 * o + 1] = 0.0f;
+            v.nxt.Xw[3 * o + 2] = 0.0f;
+            v.nxt.flags[o] = 0;
+            v.nxt.ids[o] = v.id_base + (o - n_surv);
+          }
+        }
+        base += tot;
+        __syncthreads();
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int kft = 0;
+        for (int w = 0; w < GN_NW; ++w) kft += s_wv[GN_NW + w];
+        SvoHdr h;
+        h.n_surv = n_surv;
+        h.n_kf_tracked = kft;
+        h.n_new = base - n_surv;
+        h.n_next = base;
+        h.n_emit = n_emit;
+        h.overflow = base > v.cap ? 1 : 0;
+        h.seq = 0;
+        h.pad = 0;
+        *v.hdr_dev = h;
+        *v.hdr_host = h;  // (pinned; made visible by the system-scope fence in front of the frame's sequence word below)
+      }
     }
     for (int k = tid; k < a.f_res_late_words; k += GN_T)
       if (k != a.f_seq_word || !a.f_seq) a.f_res_host[k] = a.f_res_dev[k];
@@ -908,6 +1034,11 @@ int vo_gn_enqueue(vo_ctx *c, bool stereo, bool mono_general_inverse, const float
     a.np.host_l = frame->np_host_l;
     a.np.host_r = frame->np_host_r;
     a.np.host_m = frame->np_host_m;
+    if (frame->adv && frame->adv->on) {
+      a.adv = *frame->adv;
+      a.np.acc_bin = a.adv.acc_bin;
+      a.np.out_acc = a.adv.accept;
+    }
     a.f_m1 = frame->m1;
     a.f_m2 = frame->m2;
     a.f_m3 = frame->m3;
@@ -950,8 +1081,9 @@ int vo_gn_enqueue(vo_ctx *c, bool stereo, bool mono_general_inverse, const float
   a.stage_val = stage_val;
   a.gate_thres = gate_thres;
   vo_prof_begin(c, VO_K_GN);
+  const int workers = (stereo && a.adv.on) ? (a.np.bins + 63) / 64 : 0;  // StereoVO: DLT of every bin's candidate
   if (stereo)
-    hipLaunchKernelGGL(gn_pose_kernel<true>, dim3(1), dim3(GN_T), 0, c->stream, a);
+    hipLaunchKernelGGL(gn_pose_kernel<true>, dim3(1 + workers), dim3(GN_T), 0, c->stream, a);
   else
     hipLaunchKernelGGL(gn_pose_kernel<false>, dim3(1), dim3(GN_T), 0, c->stream, a);
   vo_prof_end(c);

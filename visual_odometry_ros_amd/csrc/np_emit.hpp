@@ -15,6 +15,8 @@ struct VoNpArgs {
   uint8_t *out_m;
   float *host_l, *host_r;   // the same places in the pinned host block, or null (the caller copies the block)
   uint8_t *host_m;
+  const int *acc_bin;       // StereoVO: [bins] DLT depth test of every bin's candidate (written through by the workers), or null
+  uint8_t *out_acc;         // StereoVO: [emitted] trackBidirection mask && depth test = the candidate becomes a landmark
 };
 
 // `nthr` threads of ONE workgroup (a multiple of 64, at most 1024). final(i): feature i is in lmtrack_final; its pixel
@@ -71,6 +73,7 @@ __device__ __forceinline__ void vo_np_emit(const VoNpArgs &a, int n, const float
         a.out_r[2 * o] = rx;
         a.out_r[2 * o + 1] = ry;
         a.out_m[o] = mk;
+        if (a.acc_bin) a.out_acc[o] = (mk && __hip_atomic_load(&a.acc_bin[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ? 1 : 0;
         if (a.host_l) {  // (straight into the pinned host block: only the emitted entries cross the bus)
           a.host_l[2 * o] = lx;
           a.host_l[2 * o + 1] = ly;

@@ -34,6 +34,7 @@ int vo_frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, i
                           const float *pts_l0, const float *pts_r0, const float *Xp, const uint8_t *flags, int n,
                           const float dT_prior[16], const float *pts_new, int n_new, int inputs_on_device,
                           const vo_bin_params *bp, int table, const float *T_pw, const float *T_cw_prior);
+int vo_frame_set_advance(vo_ctx *c, const VoAdvArgs *adv);          // frame_pipeline.hip
 int vo_svo_local_ba(struct vo_svo *s, vo_svo_frame_info *info);  // stereo_vo_lba.hip
 
 #define RC(x)                \
@@ -44,168 +45,6 @@ int vo_svo_local_ba(struct vo_svo *s, vo_svo_frame_info *info);  // stereo_vo_lb
 
 #include "stereo_vo.hpp"
 
-// ---- device: Eigen::JacobiSVD<MatrixXf>(M, ComputeFullV) of a 4x4 and the DLT around it -----------------------------
-// Same operations in the same order as oracle/oracle_vo.c (which says what of Eigen 3.4.0 it restates); one lane per
-// point, the two 4x4 matrices in registers (every index below is a compile-time constant after unrolling).
-__device__ __forceinline__ void svo_rot(float &x, float &y, float c, float s) {
-  const float xi = x, yi = y;
-  x = c * xi + s * yi;
-  y = -s * xi + c * yi;
-}
-
-// V's column that belongs to the smallest singular value, as JacobiSVD leaves it in column 3 after its sort
-__device__ void svo_svd4_nullvec(const float (&M)[16], float (&v)[4]) {
-  const float FMIN = 1.17549435e-38f, FEPS = 1.1920929e-07f, FMAX = 3.40282347e+38f;
-  float W[16], V[16];
-  float scale = 0.0f;
-  bool finite = true;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const float a = fabsf(M[i]);
-    if (!(a <= FMAX)) finite = false;
-    if (a > scale) scale = a;
-  }
-#pragma unroll
-  for (int i = 0; i < 16; ++i) V[i] = (i % 5 == 0) ? 1.0f : 0.0f;
-  if (!finite) {  // Eigen: InvalidInput, V unset; here the identity (as the oracle)
-    v[0] = v[1] = v[2] = 0.0f;
-    v[3] = 1.0f;
-    return;
-  }
-  if (scale == 0.0f) scale = 1.0f;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) W[i] = M[i] / scale;
-  const float precision = 2.0f * FEPS;
-  float max_diag = 0.0f;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    if (fabsf(W[i * 5]) > max_diag) max_diag = fabsf(W[i * 5]);
-  for (int sweeps = 1;; ++sweeps) {
-    bool finished = true;
-#pragma unroll
-    for (int p = 1; p < 4; ++p)
-#pragma unroll
-      for (int q = 0; q < p; ++q) {
-        const float pm = precision * max_diag;
-        const float threshold = FMIN > pm ? FMIN : pm;
-        if (fabsf(W[p * 4 + q]) > threshold || fabsf(W[q * 4 + p]) > threshold) {
-          finished = false;
-          float m00 = W[p * 4 + p], m01 = W[p * 4 + q], m10 = W[q * 4 + p], m11 = W[q * 4 + q];
-          float c1, s1;
-          const float t = m00 + m11;
-          const float d = m10 - m01;
-          if (fabsf(d) < FMIN) {
-            s1 = 0.0f;
-            c1 = 1.0f;
-          } else {
-            const float u = t / d;
-            const float tmp = sqrtf(1.0f + u * u);
-            s1 = 1.0f / tmp;
-            c1 = u / tmp;
-          }
-          if (!(c1 == 1.0f && s1 == 0.0f)) {
-            svo_rot(m00, m10, c1, s1);
-            svo_rot(m01, m11, c1, s1);
-          }
-          // j_right.makeJacobi(m, 0, 1)
-          float cr, sr;
-          const float deno = 2.0f * fabsf(m01);
-          if (deno < FMIN) {
-            cr = 1.0f;
-            sr = 0.0f;
-          } else {
-            const float tau = (m00 - m11) / deno;
-            const float w = sqrtf(tau * tau + 1.0f);
-            float tt;
-            if (tau > 0.0f)
-              tt = 1.0f / (tau + w);
-            else
-              tt = 1.0f / (tau - w);
-            const float sign_t = tt > 0.0f ? 1.0f : -1.0f;
-            const float n = 1.0f / sqrtf(tt * tt + 1.0f);
-            sr = -sign_t * (m01 / fabsf(m01)) * fabsf(tt) * n;
-            cr = n;
-          }
-          // j_left = rot1 * j_right.transpose(); transpose = (c, -s)
-          const float ct = cr, st = -sr;
-          const float cl = c1 * ct - s1 * st;
-          const float sl = c1 * st + s1 * ct;
-          if (!(cl == 1.0f && sl == 0.0f)) {  // rows p and q of W
-#pragma unroll
-            for (int k = 0; k < 4; ++k) svo_rot(W[p * 4 + k], W[q * 4 + k], cl, sl);
-          }
-          if (!(ct == 1.0f && st == 0.0f)) {  // columns p and q of W and of V
-#pragma unroll
-            for (int k = 0; k < 4; ++k) svo_rot(W[k * 4 + p], W[k * 4 + q], ct, st);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) svo_rot(V[k * 4 + p], V[k * 4 + q], ct, st);
-          }
-          const float a = fabsf(W[p * 4 + p]), b = fabsf(W[q * 4 + q]);
-          const float mx = a > b ? a : b;
-          if (mx > max_diag) max_diag = mx;
-        }
-      }
-    if (finished || sweeps > 1000) break;
-  }
-  float sv[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) sv[i] = fabsf(W[i * 5]) * scale;
-  // selection sort, descending, first of equal maxima; only the column that ends in position 3 is needed
-  int col[4] = {0, 1, 2, 3};
-  bool stop = false;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int pos = i;
-    float best = sv[i];
-#pragma unroll
-    for (int k = i + 1; k < 4; ++k)
-      if (sv[k] > best) {
-        best = sv[k];
-        pos = k;
-      }
-    if (best == 0.0f) stop = true;
-    if (!stop) {
-#pragma unroll
-      for (int k = i + 1; k < 4; ++k)
-        if (pos == k) {
-          const float ts = sv[i];
-          sv[i] = sv[k];
-          sv[k] = ts;
-          const int tc = col[i];
-          col[i] = col[k];
-          col[k] = tc;
-        }
-    }
-  }
-  const int c3 = col[3];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) v[r] = c3 == 0 ? V[r * 4 + 0] : (c3 == 1 ? V[r * 4 + 1] : (c3 == 2 ? V[r * 4 + 2] : V[r * 4 + 3]));
-}
-
-// mapping::triangulateDLT(pt0, pt1, R10, t10, cam0, cam1, X0, X1), triangulate_3d.cpp:91-130
-__device__ void svo_triangulate(const SvoCam &cam, float u0, float v0, float u1, float v1, float (&X0)[3], float (&X1)[3]) {
-  float M[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) M[i] = 0.0f;
-  M[0] = -cam.K0[0];
-  M[5] = -cam.K0[1];
-  M[2] = u0 - cam.K0[2];
-  M[6] = v0 - cam.K0[3];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    M[8 + c] = u1 * cam.P10[8 + c] - cam.P10[0 + c];
-    M[12 + c] = v1 * cam.P10[8 + c] - cam.P10[4 + c];
-  }
-  float v[4];
-  svo_svd4_nullvec(M, v);
-  X0[0] = v[0] / v[3];
-  X0[1] = v[1] / v[3];
-  X0[2] = v[2] / v[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-    X1[i] = (cam.R10[i * 3 + 0] * X0[0] + (cam.R10[i * 3 + 1] * X0[1] + cam.R10[i * 3 + 2] * X0[2])) + cam.t10[i];
-}
-
 __global__ void svo_dlt_kernel(SvoCam cam, const float *p0, const float *p1, int n, float *X0, float *X1) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -214,128 +53,6 @@ __global__ void svo_dlt_kernel(SvoCam cam, const float *p0, const float *p1, int
   for (int k = 0; k < 3; ++k) {
     X0[3 * i + k] = a[k];
     if (X1) X1[3 * i + k] = b[k];
-  }
-}
-
-// ---- device: the next track set --------------------------------------------------------------------------------------
-struct SvoAdvArgs {
-  int n;                 // features of the frame (input index space)
-  const uint8_t *stage;  // [n] 4 = in lmtrack_final
-  const float *pl1, *pr1;
-  SvoTrackSet cur, nxt;
-  const int *n_emit;     // candidates emitted by the closed step [10] (device word of the frame's header)
-  const float *new_l, *new_r;
-  const uint8_t *new_m;
-  uint8_t *accept;       // [n_emit] out: became a landmark
-  SvoCam cam;
-  int id_base, cap;
-  SvoHdr *hdr_dev, *hdr_host;
-  int seq;
-};
-
-#define SVO_T 1024
-__global__ __launch_bounds__(SVO_T) void svo_advance_kernel(SvoAdvArgs a) {
-  __shared__ int s_wv[SVO_T / 64];
-  __shared__ int s_kf;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n_emit = *a.n_emit;
-  if (tid == 0) s_kf = 0;
-  // [10] stereo_vo.cpp:714-725: a candidate becomes a landmark iff trackBidirection accepted it and both DLT depths are positive
-  for (int j = tid; j < n_emit; j += SVO_T) {
-    uint8_t acc = 0;
-    if (a.new_m[j]) {
-      float Xl[3], Xr[3];
-      svo_triangulate(a.cam, a.new_l[2 * j], a.new_l[2 * j + 1], a.new_r[2 * j], a.new_r[2 * j + 1], Xl, Xr);
-      acc = (Xl[2] > 0 && Xr[2] > 0) ? 1 : 0;
-    }
-    a.accept[j] = acc;
-  }
-  __syncthreads();
-  // lmtrack_final (:670): the stage-4 features in index order, with their landmarks
-  int base = 0, kf = 0, ovf = 0;
-  for (int c0 = 0; c0 < a.n; c0 += SVO_T) {
-    const int i = c0 + tid;
-    const bool keep = i < a.n && a.stage[i] == 4;
-    const uint8_t fl = keep ? a.cur.flags[i] : 0;
-    const unsigned long long bal = __ballot(keep);
-    const unsigned long long bkf = __ballot(keep && (fl & VO_LM_KF_MEMBER));
-    if (lane == 0) {
-      s_wv[wave] = __popcll(bal);
-      kf += __popcll(bkf);
-    }
-    __syncthreads();
-    int woff = 0, tot = 0;
-    for (int w = 0; w < SVO_T / 64; ++w) {
-      const int cw = s_wv[w];
-      woff += w < wave ? cw : 0;
-      tot += cw;
-    }
-    if (keep) {
-      const int o = base + woff + __popcll(bal & ((1ull << lane) - 1ull));
-      if (o < a.cap) {
-        a.nxt.pts_l[2 * o] = a.pl1[2 * i];
-        a.nxt.pts_l[2 * o + 1] = a.pl1[2 * i + 1];
-        a.nxt.pts_r[2 * o] = a.pr1[2 * i];
-        a.nxt.pts_r[2 * o + 1] = a.pr1[2 * i + 1];
-        a.nxt.Xw[3 * o] = a.cur.Xw[3 * i];
-        a.nxt.Xw[3 * o + 1] = a.cur.Xw[3 * i + 1];
-        a.nxt.Xw[3 * o + 2] = a.cur.Xw[3 * i + 2];
-        a.nxt.flags[o] = fl;
-        a.nxt.ids[o] = a.cur.ids[i];
-      }
-    }
-    base += tot;
-    __syncthreads();
-  }
-  if (lane == 0 && kf) atomicAdd(&s_kf, kf);
-  const int n_surv = base;
-  // the new landmarks (:729-734), candidate order; NOT triangulated (set3DPoint is commented out at :736)
-  for (int c0 = 0; c0 < n_emit; c0 += SVO_T) {
-    const int j = c0 + tid;
-    const bool keep = j < n_emit && a.accept[j];
-    const unsigned long long bal = __ballot(keep);
-    if (lane == 0) s_wv[wave] = __popcll(bal);
-    __syncthreads();
-    int woff = 0, tot = 0;
-    for (int w = 0; w < SVO_T / 64; ++w) {
-      const int cw = s_wv[w];
-      woff += w < wave ? cw : 0;
-      tot += cw;
-    }
-    if (keep) {
-      const int o = base + woff + __popcll(bal & ((1ull << lane) - 1ull));
-      if (o < a.cap) {
-        a.nxt.pts_l[2 * o] = a.new_l[2 * j];
-        a.nxt.pts_l[2 * o + 1] = a.new_l[2 * j + 1];
-        a.nxt.pts_r[2 * o] = a.new_r[2 * j];
-        a.nxt.pts_r[2 * o + 1] = a.new_r[2 * j + 1];
-        a.nxt.Xw[3 * o] = 0.0f;
-        a.nxt.Xw[3 * o + 1] = 0.0f;
-        a.nxt.Xw[3 * o + 2] = 0.0f;
-        a.nxt.flags[o] = 0;
-        a.nxt.ids[o] = a.id_base + (o - n_surv);
-      }
-    }
-    base += tot;
-    __syncthreads();
-  }
-  if (base > a.cap) ovf = 1;
-  if (tid == 0) {
-    SvoHdr h;
-    h.n_surv = n_surv;
-    h.n_kf_tracked = s_kf;
-    h.n_new = base - n_surv;
-    h.n_next = base;
-    h.n_emit = n_emit;
-    h.overflow = ovf;
-    h.seq = 0;
-    *a.hdr_dev = h;
-    int *d = (int *)a.hdr_host;
-    const int *sfrom = (const int *)&h;
-    for (int k = 0; k < (int)(sizeof(SvoHdr) / 4); ++k)
-      if (k != (int)(offsetof(SvoHdr, seq) / 4)) d[k] = sfrom[k];
-    __threadfence_system();
-    __hip_atomic_store(&a.hdr_host->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -511,6 +228,7 @@ extern "C" int vo_svo_create(vo_ctx *c, const vo_svo_params *prm, vo_svo **out) 
   int rc = VO_OK;
   for (int k = 0; k < 2 && rc == VO_OK; ++k) rc = svo_alloc_ts(c, &s->ts[k], s->cap);
   if (rc == VO_OK && hipMalloc((void **)&s->d_accept, (size_t)s->cap) != hipSuccess) rc = VO_ERR_HIP;
+  if (rc == VO_OK && hipMalloc((void **)&s->d_acc_bin, sizeof(int) * (size_t)s->cap) != hipSuccess) rc = VO_ERR_HIP;
   if (rc == VO_OK && hipMalloc((void **)&s->d_hdr, sizeof(SvoHdr)) != hipSuccess) rc = VO_ERR_HIP;
   if (rc == VO_OK && hipHostMalloc((void **)&s->h_hdr, sizeof(SvoHdr), hipHostMallocDefault) != hipSuccess) rc = VO_ERR_HIP;
   if (rc != VO_OK) {
@@ -538,6 +256,7 @@ extern "C" void vo_svo_destroy(vo_svo *s) {
   if (s->c) (void)hipSetDevice(s->c->device);
   for (int k = 0; k < 2; ++k) svo_free_ts(&s->ts[k]);
   if (s->d_accept) (void)hipFree(s->d_accept);
+  if (s->d_acc_bin) (void)hipFree(s->d_acc_bin);
   if (s->d_hdr) (void)hipFree(s->d_hdr);
   if (s->h_hdr) (void)hipHostFree(s->h_hdr);
   void *pinned[] = {s->h_ids, s->h_pl, s->h_pr, s->h_Xw, s->h_fl};
@@ -557,38 +276,6 @@ static int svo_ingest(vo_svo *s, const void *left, const void *right, int stride
   else
     RC(vo_set_stereo_pair_host_async(c, s->slot[S_NL], (const uint8_t *)left, s->slot[S_NR], (const uint8_t *)right, W, H, stride));
   RC(vo_new_point_candidates_enqueue(c, s->slot[S_NL], &s->prm.bins, s->tab_next));
-  return VO_OK;
-}
-
-// behind the frame's BA launch, on the same stream: the next track set + the loop's counts
-static int svo_launch_advance(vo_svo *s) {
-  vo_ctx *c = s->c;
-  vo_frame_state *f = c->frame;
-  const SvoTrackSet &t = s->ts[s->cur];
-  SvoAdvArgs a;
-  memset(&a, 0, sizeof(a));
-  a.n = s->n;
-  a.stage = f->stage;
-  a.pl1 = f->F_pl1;
-  a.pr1 = f->F_pr1;
-  a.cur = t;
-  a.nxt = s->ts[s->cur ^ 1];
-  a.n_emit = &f->hdr->cnt[5];
-  a.new_l = (const float *)(f->res_dev + f->off_newl);
-  a.new_r = f->new_r;
-  a.new_m = f->mNew;
-  a.accept = s->d_accept;
-  a.cam = s->cam;
-  a.id_base = c->next_landmark_id;
-  a.cap = s->cap;
-  a.hdr_dev = s->d_hdr;
-  a.hdr_host = s->h_hdr;
-  s->seq = s->seq + 1 == 0 ? 1 : s->seq + 1;
-  a.seq = s->seq;
-  vo_prof_begin(c, VO_K_AUX);
-  hipLaunchKernelGGL(svo_advance_kernel, dim3(1), dim3(SVO_T), 0, c->stream, a);
-  vo_prof_end(c);
-  VO_CHECK_HIP(c, hipGetLastError());
   return VO_OK;
 }
 
@@ -635,13 +322,27 @@ extern "C" int vo_svo_enqueue(vo_svo *s, const void *left, const void *right, in
   svo_inv_se3(T_wc_prior, T_cw_prior);
   svo_inv_se3(s->T_wp, T_pw);
   const SvoTrackSet &t = s->ts[s->cur];
+  {  // the BA launch of this frame leaves the next track set behind (gn_pose.hip: DLT workers + epilogue)
+    VoAdvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.cur = t;
+    a.nxt = s->ts[s->cur ^ 1];
+    a.acc_bin = s->d_acc_bin;
+    a.accept = s->d_accept;
+    a.cam = s->cam;
+    a.id_base = c->next_landmark_id;
+    a.cap = s->cap;
+    a.hdr_dev = s->d_hdr;
+    a.hdr_host = s->h_hdr;
+    RC(vo_frame_set_advance(c, &a));
+  }
   int rc = vo_frame_enqueue_impl(c, &s->prm.frame, s->slot[S_P], s->slot[S_CL], s->slot[S_CR], t.pts_l, t.pts_r, t.Xw, t.flags,
                                  s->n, s->dT01, nullptr, 0, 1, &s->prm.bins, s->tab_cur, T_pw, T_cw_prior);
   if (rc < 0) {
     s->pending = false;
     return rc;
   }
-  return svo_launch_advance(s);
+  return VO_OK;
 }
 
 // stereo_vo.cpp:842-949 — once per stream, composed of the operators (synchronous)
@@ -747,33 +448,10 @@ extern "C" int vo_svo_result(vo_svo *s, vo_svo_frame_info *info) {
     if (info) *info = I;
     return VO_OK;
   }
-  // the advance kernel is the frame's last launch: its block's sequence word says that everything is there
-  auto wait_advance = [&]() -> int {
-    volatile const int *seqp = &s->h_hdr->seq;
-    const double t0 = svo_now();
-    bool seen = false;
-    for (int spin = 0;; ++spin) {
-      if (*seqp == s->seq) {
-        seen = true;
-        break;
-      }
-      if ((spin & 255) == 255 && svo_now() - t0 > 2e-3) break;
-#if defined(__x86_64__)
-      __builtin_ia32_pause();
-#endif
-    }
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    if (!seen) VO_CHECK_HIP(c, hipStreamSynchronize(c->stream));
-    return VO_OK;
-  };
-  RC(wait_advance());
+  // the BA launch's epilogue wrote the loop's counts (pinned block) in front of the frame's sequence word
   float dT[16];
   int rc = vo_stereo_frame_result(c, nullptr, nullptr, nullptr, dT, nullptr, nullptr, &I.counts, &I.gn);
   if (rc < 0) return rc;
-  if (c->frame->recovered) {  // the frame was issued again (join time-out): so is everything behind it
-    RC(svo_launch_advance(s));
-    RC(wait_advance());
-  }
   const SvoHdr h = *s->h_hdr;
   if (h.overflow) VO_FAIL(c, VO_ERR_CAPACITY, "the next track set (%d) exceeds vo_config.max_points=%d", h.n_next, s->cap);
   I.n_tracks_in = s->n;

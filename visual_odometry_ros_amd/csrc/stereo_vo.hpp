@@ -2,26 +2,8 @@
 #pragma once
 #include <vector>
 
+#include "svo_device.hpp"
 #include "vo_internal.hpp"
-
-struct SvoCam {  // what mapping::triangulateDLT needs (triangulate_3d.cpp:91-130), pixel-independent part precomputed
-  float P10[12];  // [K1 * R10, K1 * t10], row-major 3x4
-  float R10[9], t10[3];
-  float K0[4], K1[4];
-};
-
-struct SvoTrackSet {  // device: stframe->getPtsSeen() (left / right) + related landmarks, one entry per landmark
-  float *pts_l, *pts_r;  // [cap][2]
-  float *Xw;             // [cap][3] lm->get3DPoint() (world frame)
-  uint8_t *flags;        // [cap] VO_LM_TRIANGULATED | VO_LM_DROPPED | VO_LM_KF_MEMBER
-  int32_t *ids;          // [cap] lm->getID()
-};
-
-struct SvoHdr {  // written by svo_advance_kernel: device copy and pinned host copy
-  int n_surv, n_kf_tracked, n_new, n_next, n_emit, overflow;
-  int seq;       // host copy: written last
-  int pad;
-};
 
 // Keyframe-centric storage of what the reference keeps per landmark (getObservationsOnKeyframes / getRelatedKeyframePtr):
 // a keyframe holds its related landmarks' ids and both pixels. The ids of a track set are ASCENDING (survivors keep their
@@ -41,6 +23,7 @@ struct vo_svo {
   SvoTrackSet ts[2] = {};
   int cur = 0, n = 0;
   uint8_t *d_accept = nullptr;
+  int *d_acc_bin = nullptr;
   SvoHdr *d_hdr = nullptr, *h_hdr = nullptr;
   int seq = 0;
   SvoCam cam;

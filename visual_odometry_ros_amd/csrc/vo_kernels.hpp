@@ -42,6 +42,7 @@ struct vo_gn_frame {
   uint8_t *np_out_m;
   float *np_host_l, *np_host_r;  // the same places in the pinned host block (written entry by entry, not copied)
   uint8_t *np_host_m;
+  const struct VoAdvArgs *adv;   // StereoVO: the epilogue also builds the next track set (svo_device.hpp)
 };
 int vo_gn_enqueue(vo_ctx *c, bool stereo, bool mono_general_inverse, const float *dX, const float *dP1,
                   const float *dP2, int n, const int *d_n, const float Kl[4], const float Kr[4],
