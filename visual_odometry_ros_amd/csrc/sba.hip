@@ -203,9 +203,7 @@ __device__ __forceinline__ void sba_inv3_ldlt(const double Cin[9], double out[9]
 }
 
 // ---- per landmark -------------------------------------------------------------------
-__global__ __launch_bounds__(64) void sba_point_kernel(SbaDev d) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= d.M) return;
+__device__ __forceinline__ void sba_point_body(const SbaDev &d, int i) {
   const double X[3] = {d.X[3 * i], d.X[3 * i + 1], d.X[3 * i + 2]};
   double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0}, err = 0.0;
   for (int o = d.obs_ptr[i]; o < d.obs_ptr[i + 1]; ++o) {
@@ -266,8 +264,7 @@ __device__ __forceinline__ double sba_wave_sum(double v) {
 }
 
 // ---- per optimised pose: A_j, a_j, (B C^-1 b)_j -----------------------------------------
-__global__ __launch_bounds__(64) void sba_pose_kernel(SbaDev d) {
-  const int j = blockIdx.x, g = blockIdx.y, lane = threadIdx.x;
+__device__ __forceinline__ void sba_pose_body(const SbaDev &d, int j, int g, int lane) {
   double acc[48];
 #pragma unroll
   for (int k = 0; k < 48; ++k) acc[k] = 0.0;
@@ -324,11 +321,9 @@ __global__ __launch_bounds__(64) void sba_pose_kernel(SbaDev d) {
 }
 
 // ---- per block (j,k) of B C^-1 B^T -------------------------------------------------------
-__global__ __launch_bounds__(64) void sba_schur_kernel(SbaDev d) {
-  const int jk = blockIdx.x, g = blockIdx.y, lane = threadIdx.x;
-  // blocks below the diagonal are overwritten by the transposed upper ones (:495-497) before anything reads
-  // them: whatever an observation list in reverse keyframe order accumulates there is discarded
-  if (jk / d.n_opt > jk % d.n_opt) return;
+// (blocks below the diagonal are overwritten by the transposed upper ones (:495-497) before anything reads them:
+// whatever an observation list in reverse keyframe order accumulates there is discarded — they are not computed)
+__device__ __forceinline__ void sba_schur_body(const SbaDev &d, int jk, int g, int lane) {
   double acc[36];
 #pragma unroll
   for (int k = 0; k < 36; ++k) acc[k] = 0.0;
@@ -351,6 +346,23 @@ __global__ __launch_bounds__(64) void sba_schur_kernel(SbaDev d) {
     const double t = sba_wave_sum(acc[k]);
     if (lane == 0) d.S[36 * ((size_t)jk * SBA_SG + g) + k] = t;
   }
+}
+
+// A_j / a_j / (B C^-1 b)_j and the blocks of B C^-1 B^T do not depend on one another: ONE launch, workgroups
+// 0 .. n_opt * SBA_PG - 1 take the pose sums, the others the blocks on and above the diagonal, row by row
+__global__ __launch_bounds__(64) void sba_pose_schur_kernel(SbaDev d) {
+  const int t = blockIdx.x, lane = threadIdx.x, No = d.n_opt;
+  const int n_pose = No * SBA_PG;
+  if (t < n_pose) {
+    sba_pose_body(d, t / SBA_PG, t % SBA_PG, lane);
+    return;
+  }
+  int u = (t - n_pose) / SBA_SG, j = 0;
+  while (u >= No - j) {
+    u -= No - j;
+    ++j;
+  }
+  sba_schur_body(d, j * No + j + u, (t - n_pose) % SBA_SG, lane);
 }
 
 // ---- se3 exp / log in double (geometry_library.cpp:336-384, :442-495) ---------------------
@@ -460,15 +472,31 @@ __device__ __forceinline__ unsigned sba_wave_max_u32(unsigned v) {
 }
 __device__ __forceinline__ double sba_row_dot(const double *__restrict__ m, const double *__restrict__ temp, int n,
                                               int row, int k) {
-  // sum_{j<k} M(row,j) temp[j] in increasing j (the CPU order); loads of a chunk are issued together
+  // sum_{j<k} M(row,j) temp[j] in increasing j (the CPU order). Software-pipelined: the LDS loads of chunk c + 1 are
+  // issued before the multiply-adds of chunk c, so a step waits for the LDS once instead of once per chunk.
   double dd = 0.0;
   int j = 0;
-  for (; j + SBA_CH <= k; j += SBA_CH) {
-    double a[SBA_CH], t[SBA_CH];
+  double a[SBA_CH], t[SBA_CH];
+  if (k >= SBA_CH) {
 #pragma unroll
     for (int q = 0; q < SBA_CH; ++q) {
-      a[q] = m[(size_t)(j + q) * n + row];
-      t[q] = temp[j + q];
+      a[q] = m[(size_t)q * n + row];
+      t[q] = temp[q];
+    }
+    for (j = SBA_CH; j + SBA_CH <= k; j += SBA_CH) {
+      double a2[SBA_CH], t2[SBA_CH];
+#pragma unroll
+      for (int q = 0; q < SBA_CH; ++q) {
+        a2[q] = m[(size_t)(j + q) * n + row];
+        t2[q] = temp[j + q];
+      }
+#pragma unroll
+      for (int q = 0; q < SBA_CH; ++q) dd += a[q] * t[q];
+#pragma unroll
+      for (int q = 0; q < SBA_CH; ++q) {
+        a[q] = a2[q];
+        t[q] = t2[q];
+      }
     }
 #pragma unroll
     for (int q = 0; q < SBA_CH; ++q) dd += a[q] * t[q];
@@ -534,7 +562,26 @@ __global__ __launch_bounds__(64) void sba_solve_kernel(SbaDev d, int iter) {
     sig[e] = e;
   }
   __syncthreads();
-  for (int k = 0; k < n; ++k) {
+  // Without exact ties among the |diagonal| values the selection order is simply their descending order: position k of
+  // the permutation holds the k-th largest — every lane counts how many values beat its own (n <= 64: one value per
+  // lane, broadcast lane by lane). n sequential steps with two reductions and a barrier each (below: the general form,
+  // kept for ties and for n > 64) were a quarter of this kernel's time.
+  bool ranked = false;
+  if (n <= 64) {
+    const double v = lane < n ? dg[lane] : -1.0;
+    int rank = 0, tie = 0;
+    for (int j = 0; j < n; ++j) {
+      const double vj = __shfl(v, j);
+      rank += (vj > v) ? 1 : 0;
+      tie |= (vj == v && j != lane) ? 1 : 0;
+    }
+    if (!__any(tie && lane < n)) {
+      if (lane < n) sig[rank] = lane;
+      ranked = true;
+    }
+    __syncthreads();
+  }
+  for (int k = 0; !ranked && k < n; ++k) {
     // largest, first one on ties. |d| >= 0: the IEEE bit pattern orders like an unsigned integer, so two 32-bit
     // DPP max reductions and a ballot replace a 64-bit shuffle tree
     const int i0 = k + lane, i1 = k + lane + 64;
@@ -564,7 +611,7 @@ __global__ __launch_bounds__(64) void sba_solve_kernel(SbaDev d, int iter) {
   }
   // ---- assemble the permuted lower triangle: entry (i,j), i >= j, is the original lower-triangle entry between
   // sig[i] and sig[j] (the symmetric swaps of the reference only ever move lower-triangle storage)
-#pragma unroll 4
+#pragma unroll 8
   for (int e = lane; e < n * n; e += 64) {  // (independent iterations: the loads of several are in flight together)
     const int col = e / n, row = e - col * n;
     if (row >= col) {
@@ -596,12 +643,28 @@ __global__ __launch_bounds__(64) void sba_solve_kernel(SbaDev d, int iter) {
   }
   // solve: x = P^T L^-T D^+ L^-1 (P rhs)
   // L sweep, column-oriented: entry i subtracts M(i,j) y_j in increasing j, as the row form does
+  const double tol = 2.2250738585072014e-308;
+  if (n <= 64) {
+    // one entry per lane, in a register: the pivot entry of a step reaches the others by a lane broadcast — no LDS
+    // round trip for y and no barrier per step (same subtractions in the same order as the loops below)
+    double yi = lane < n ? y[lane] : 0.0;
+    for (int j = 0; j < n; ++j) {
+      const double yj = __shfl(yi, j);
+      if (lane > j && lane < n) yi -= MM(lane, j) * yj;
+    }
+    if (lane < n) yi = fabs(MM(lane, lane)) > tol ? yi / MM(lane, lane) : 0.0;
+    for (int q = n - 1; q > 0; --q) {
+      const double yq = __shfl(yi, q);
+      if (lane < q) yi -= MM(q, lane) * yq;
+    }
+    if (lane < n) y[lane] = yi;
+    __syncthreads();
+  } else {
   for (int j = 0; j < n; ++j) {
     const double yj = y[j];
     for (int i = j + 1 + lane; i < n; i += 64) y[i] -= MM(i, j) * yj;
     __syncthreads();
   }
-  const double tol = 2.2250738585072014e-308;
   for (int i = lane; i < n; i += 64) y[i] = fabs(MM(i, i)) > tol ? y[i] / MM(i, i) : 0.0;
   __syncthreads();
   // L^T sweep, column-oriented as well: entry i subtracts M(q,i) y_q in DECREASING q (the CPU restatement's row
@@ -610,6 +673,7 @@ __global__ __launch_bounds__(64) void sba_solve_kernel(SbaDev d, int iter) {
     const double yq = y[q];
     for (int i = lane; i < q; i += 64) y[i] -= MM(q, i) * yq;
     __syncthreads();
+  }
   }
   // P^T: scatter back through sig
   for (int e = lane; e < n; e += 64) temp[sig[e]] = y[e];
@@ -625,8 +689,19 @@ __global__ __launch_bounds__(64) void sba_solve_kernel(SbaDev d, int iter) {
     if (j >= 0) sba_pose_update(d.T + 16 * (size_t)f, y + 6 * j);
   }
   // average pixel error of this iteration's linearisation point (:594-601)
+  // (eight loads in flight per lane and step: one at a time, this loop alone took a third of the kernel)
   double e = 0.0;
-  for (int i = lane; i < d.M; i += 64) e += d.err_i[i];
+  {
+    int i = lane;
+    for (; i + 7 * 64 < d.M; i += 8 * 64) {
+      double v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = d.err_i[i + 64 * q];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) e += v[q];
+    }
+    for (; i < d.M; i += 64) e += d.err_i[i];
+  }
   e = sba_wave_sum(e);
   if (lane == 0) {
     d.avg_err[iter] = sqrt(e / (double)d.n_obs);
@@ -639,9 +714,7 @@ __global__ __launch_bounds__(64) void sba_solve_kernel(SbaDev d, int iter) {
 }
 
 // ---- y_i and the point update (:537-556, :578-579) ----------------------------------------
-__global__ __launch_bounds__(64) void sba_update_kernel(SbaDev d) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= d.M) return;
+__device__ __forceinline__ void sba_update_body(const SbaDev &d, int i) {
   double cbx[3] = {0, 0, 0};
   for (int s = d.slot_ptr[i]; s < d.slot_ptr[i + 1]; ++s) {
     const double *BC = d.BCs + 18 * (size_t)s, *x = d.x + 6 * d.slot_j[s];
@@ -655,6 +728,15 @@ __global__ __launch_bounds__(64) void sba_update_kernel(SbaDev d) {
   }
 #pragma unroll
   for (int c = 0; c < 3; ++c) d.X[3 * (size_t)i + c] += d.Cinvb[3 * (size_t)i + c] - cbx[c];
+}
+
+// The point update of iteration k and the per-landmark linearisation of iteration k + 1 touch only landmark i (and the
+// poses the solve of iteration k left): one launch instead of two. update != 0: X_i += y_i first; point != 0: then C_i, b_i, ...
+__global__ __launch_bounds__(64) void sba_update_point_kernel(SbaDev d, int update, int point) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.M) return;
+  if (update) sba_update_body(d, i);
+  if (point) sba_point_body(d, i);
 }
 
 // ---- host side ---------------------------------------------------------------------
@@ -907,16 +989,17 @@ extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, co
     VO_CHECK_HIP(c, hipFuncSetAttribute((const void *)sba_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   SBA_T(1);
   vo_prof_begin(c, VO_K_AUX);
+  // four launches per iteration: [update of the previous iteration + per-landmark linearisation] -> [pose sums + Schur
+  // blocks] -> assembly -> solve; one last update behind the loop
   for (int iter = 0; iter < p->max_iter; ++iter) {
-    hipLaunchKernelGGL(sba_point_kernel, dim3((M + 63) / 64), dim3(64), 0, s, d);
+    hipLaunchKernelGGL(sba_update_point_kernel, dim3((M + 63) / 64), dim3(64), 0, s, d, iter > 0 ? 1 : 0, 1);
     if (No > 0) {
-      hipLaunchKernelGGL(sba_pose_kernel, dim3(No, SBA_PG), dim3(64), 0, s, d);
-      hipLaunchKernelGGL(sba_schur_kernel, dim3(No * No, SBA_SG), dim3(64), 0, s, d);
+      hipLaunchKernelGGL(sba_pose_schur_kernel, dim3(No * SBA_PG + (No * (No + 1) / 2) * SBA_SG), dim3(64), 0, s, d);
+      hipLaunchKernelGGL(sba_assemble_kernel, dim3((n * n + n + 63) / 64), dim3(64), 0, s, d);
     }
-    if (No > 0) hipLaunchKernelGGL(sba_assemble_kernel, dim3((n * n + n + 63) / 64), dim3(64), 0, s, d);
     hipLaunchKernelGGL(sba_solve_kernel, dim3(1), dim3(64), lds, s, d, iter);
-    hipLaunchKernelGGL(sba_update_kernel, dim3((M + 63) / 64), dim3(64), 0, s, d);
   }
+  if (p->max_iter > 0) hipLaunchKernelGGL(sba_update_point_kernel, dim3((M + 63) / 64), dim3(64), 0, s, d, 1, 0);
   vo_prof_end(c);
   VO_CHECK_HIP(c, hipGetLastError());
   int flags[4] = {0, 0, 0, 0};
@@ -936,7 +1019,9 @@ extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, co
   }
   SBA_T(2);
   if (trace && (++n_calls % 10) == 0)
-    fprintf(stderr, "[sba] per call (us): lists %.0f  upload %.0f  kernels+d2h %.0f\n", tt[0] / n_calls, tt[1] / n_calls, tt[2] / n_calls);
+    fprintf(stderr, "[sba] per call (us): lists %.0f  upload %.0f  kernels+d2h %.0f | solve kernel, last iteration (us): pivot+assembly %.1f  "
+                    "LDLT+solve %.1f  pose update+error %.1f\n", tt[0] / n_calls, tt[1] / n_calls, tt[2] / n_calls, flags[1] * 0.01, flags[2] * 0.01,
+            flags[3] * 0.01);
   if (avg_err)
     for (int k = 0; k < p->max_iter; ++k) avg_err[k] = errs[k];
   memcpy(c->sba->phase_ticks, flags + 1, sizeof(int) * 3);
