@@ -698,6 +698,7 @@ def run_loop(cfg, args, rank, local_rank, world, torch, V, barrier, dev, imgs, s
         out["roofline"]["counters_note"] = counters["counters_note"]
     svo.close()
     prm_svo = svo.prm
+    ctx.close()  # (its three HIP streams go away: the legs below must not share hardware queues with an idle context)
     if secondary:
         out["secondary"] = secondary_legs(cfg, args, rank, local_rank, torch, V, barrier)
         if args.batch_S:

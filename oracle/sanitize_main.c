@@ -316,5 +316,28 @@ int main(void) {
   free(I1);
   free(I2);
   printf("oracle sanitize run ok\n");
+  { /* oracle_vo.c: DLT through the restated JacobiSVD (degenerate inputs included), keyframe reconstruction, pose products */
+    const float K[4] = {300.f, 300.f, 80.f, 48.f};
+    float T_rl[16] = {1, 0, 0, -0.5f, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    float pl[2 * 8], pr[2 * 8], Xw[3 * 8], Xl[3 * 8];
+    uint8_t mk[8], acc[8], set[8];
+    for (int i = 0; i < 8; ++i) {
+      pl[2 * i] = 20.f + 15.f * i;
+      pl[2 * i + 1] = 10.f + 9.f * i;
+      pr[2 * i] = pl[2 * i] - (i == 3 ? 0.f : (i == 5 ? -4.f : 2.5f + i)); /* zero and negative disparity too */
+      pr[2 * i + 1] = pl[2 * i + 1] + 0.1f * i;
+      mk[i] = (uint8_t)(i != 6);
+      Xw[3 * i] = Xw[3 * i + 1] = Xw[3 * i + 2] = 0.f;
+    }
+    pl[0] = NAN; /* a non-finite DLT matrix: Eigen reports InvalidInput */
+    (void)vo_ref_new_landmark_accept(pl, pr, mk, 8, T_rl, K, K, acc, Xl);
+    (void)vo_ref_keyframe_reconstruct(pl, pr, 8, T_rl, K, K, T_rl, Xw, set);
+    (void)vo_ref_keyframe_reconstruct(pl, pr, 8, T_rl, K, K, NULL, Xw, set);
+    float A[16], V[16], sv[4];
+    memset(A, 0, sizeof(A));
+    (void)vo_ref_jacobi_svd4(A, V, sv); /* the zero matrix */
+    vo_ref_mul44(T_rl, T_rl, A);
+    (void)vo_ref_jacobi_svd4(A, V, sv);
+  }
   return 0;
 }
