@@ -909,7 +909,7 @@ extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, co
                             const double *obs_px, double *avg_err) {
   if (!c || !p || !T_jw || !opt_index || !X || !obs_ptr || !obs_frame || !obs_right || !obs_px) return VO_ERR_INVALID;
   static const bool trace = getenv("VO_SVO_TRACE") != nullptr;
-  static double tt[4];
+  static double tt[8];
   static int n_calls;
   auto now_us = []() {
     timespec ts;
@@ -995,7 +995,7 @@ extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, co
   const size_t out_bytes = sizeof(double) * (16 * (size_t)Nf + 3 * (size_t)M + (size_t)p->max_iter + 1) + 64;
   const size_t stage_need = in_bytes > out_bytes ? in_bytes : out_bytes;
   hipStream_t s = c->stream;
-  VO_CHECK_HIP(c, hipStreamSynchronize(s));  // (the staging block of the previous solve has been consumed)
+  // (the staging block is free: the previous solve ended with a synchronisation behind its read-back)
   if (c->sba->stage_cap < stage_need) {
     if (c->sba->stage) (void)hipHostFree(c->sba->stage);
     c->sba->stage = nullptr;
@@ -1003,6 +1003,7 @@ extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, co
     VO_CHECK_HIP(c, hipHostMalloc(&c->sba->stage, stage_need + (stage_need >> 2), hipHostMallocDefault));
     c->sba->stage_cap = stage_need + (stage_need >> 2);
   }
+  SBA_T(3);
   uint8_t *base = (uint8_t *)c->sba->dev;
   uint8_t *hs = (uint8_t *)c->sba->stage;
   memcpy(hs + oT, T_jw, sizeof(double) * 16 * Nf);
@@ -1014,6 +1015,7 @@ extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, co
   memcpy(hs + oPx, obs_px, sizeof(double) * 2 * nobs);
   memset(hs + oFl, 0, sizeof(int) * 4);
   memset(hs + oAvg, 0, sizeof(double) * (p->max_iter + 1));
+  SBA_T(4);
   int *h_slot_ptr = (int *)(hs + oSp), *h_slot_obs = (int *)(hs + oSo), *h_slot_j = (int *)(hs + oSj);
   int *h_slot_bobs = (int *)(hs + oSb), *h_slot_lm = (int *)(hs + oSl);
   int *h_pose_obs_ptr = (int *)(hs + oPop), *h_pose_obs = (int *)(hs + oPo);
@@ -1061,7 +1063,9 @@ extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, co
       h_slot_ptr[i + 1] = sidx;
     }
   }
+  SBA_T(5);
   VO_CHECK_HIP(c, hipMemcpyAsync(base, hs, in_bytes, hipMemcpyHostToDevice, s));
+  SBA_T(6);
   SbaDev d;
   memset(&d, 0, sizeof(d));
   d.n_frames = Nf;
@@ -1157,6 +1161,9 @@ extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, co
     fprintf(stderr, "[sba] per call (us): lists %.0f  upload %.0f  kernels+d2h %.0f | solve kernel, last iteration (us): pivot+assembly %.1f  "
                     "LDLT+solve %.1f  pose update+error %.1f\n", tt[0] / n_calls, tt[1] / n_calls, tt[2] / n_calls, flags[1] * 0.01, flags[2] * 0.01,
             flags[3] * 0.01);
+  if (trace && (n_calls % 10) == 0)
+    fprintf(stderr, "[sba] upload split (us): arena %.0f  memcpy to staging %.0f  lists pass 2 + order %.0f  h2d call %.0f  rest %.0f  (pairs %zu, slots %d, %zu KB)\n",
+            tt[3] / n_calls, tt[4] / n_calls, tt[5] / n_calls, tt[6] / n_calls, tt[1] / n_calls, n_pairs, ns, in_bytes >> 10);
   if (avg_err)
     for (int k = 0; k < p->max_iter; ++k) avg_err[k] = errs[k];
   memcpy(c->sba->phase_ticks, flags + 1, sizeof(int) * 3);
