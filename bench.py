@@ -848,7 +848,7 @@ def cpu_baseline_loop(cfg, args, st, imgs, traj, V, local_rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--steps", type=int, default=None, help="timed frames (default 400; 60 for --config 4, whose 4K stream is rendered first)")
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="BASELINE.json configs[i]")
     ap.add_argument("--frames", type=int, default=12, help="distinct rendered frames (played back and forth)")
@@ -877,6 +877,8 @@ def main():
     ap.add_argument("--rendezvous-check", action="store_true",
                     help="run only the multi-rank control flow (gloo, no GPU work) and print its JSON line")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 60 if args.config == 4 else 400
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))  # nothing GPU-related has been imported yet

@@ -28,6 +28,14 @@
 #include "vo_internal.hpp"
 #include "vo_kernels.hpp"
 
+#ifdef SBA_STAMP  // measurement build: per-phase maxima over the workgroups of the last iteration, 10 ns ticks
+#define SBA_TICK() ((long long)__builtin_amdgcn_s_memrealtime())
+#define SBA_STAMP_MAX(slot, t1, t0) \
+  if ((threadIdx.x & 63) == 0) atomicMax(d.flags + (slot), (int)((t1) - (t0)))
+#else
+#define SBA_TICK() 0LL
+#define SBA_STAMP_MAX(slot, t1, t0)
+#endif
 #define SBA_PG 8        // partial-sum wavefronts per optimised pose
 #define SBA_SG 8        // partial-sum wavefronts per block of B C^-1 B^T
 #define SBA_MAX_OPT 20  // reduced system up to 120 x 120 in LDS
@@ -42,11 +50,14 @@ struct SbaDev {
   const uint8_t *obs_right;
   const double *obs_px;
   const int *slot_ptr, *slot_obs, *slot_j, *slot_bobs;
-  const int *pose_obs_ptr, *pose_obs;
+  const int *pose_obs_ptr, *pose_obs, *pose_lm;  // per optimised pose: its observations and their landmarks
+  const int *opt_frame;                          // frame of optimised pose j
   const int *pose_slot_ptr, *pose_slot, *slot_lm;
   const int *pair_ptr, *pair_a, *pair_b;
-  double *Cinv, *Cinvb, *b, *err_i;
-  double *Bs, *BCs;
+  double *Cinvb, *b;
+  double *err_part;  // squared-error sum of each workgroup of the point kernel (n_err of them)
+  int n_err;
+  double *Bs, *BCs, *BCb;  // per slot: B_ji, B_ji C_i^-1 (6x3 each), (B_ji C_i^-1) b_i (6)
   double *Apart;  // n_opt * SBA_PG * 48 (36 A, 6 a, 6 BCinv_b)
   double *S;      // n_opt * n_opt * SBA_SG * 36 (partial sums; blocks below the diagonal are never used)
   double *x;      // n_opt * 6
@@ -203,58 +214,22 @@ __device__ __forceinline__ void sba_inv3_ldlt(const double Cin[9], double out[9]
 }
 
 // ---- per landmark -------------------------------------------------------------------
-__device__ __forceinline__ void sba_point_body(const SbaDev &d, int i) {
-  const double X[3] = {d.X[3 * i], d.X[3 * i + 1], d.X[3 * i + 2]};
-  double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0}, err = 0.0;
-  for (int o = d.obs_ptr[i]; o < d.obs_ptr[i + 1]; ++o) {
-    SbaObs L;
-    const double px[2] = {d.obs_px[2 * o], d.obs_px[2 * o + 1]};
-    sba_linearize(d, d.T + 16 * (size_t)d.obs_frame[o], X, px, d.obs_right[o], L);
-    // calc_Rij_t_Rij_weight (:911-930), b_i += -weight * (Rij^T rij)
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int c = r; c < 3; ++c) {
-        const double v = L.w * (L.R[r] * L.R[c] + L.R[3 + r] * L.R[3 + c]);
-        C[r * 3 + c] += v;
-        if (c != r) C[c * 3 + r] += v;
-      }
-#pragma unroll
-    for (int r = 0; r < 3; ++r) b[r] += -(L.w * (L.R[r] * L.r[0] + L.R[3 + r] * L.r[1]));
-    err += L.r[0] * L.r[0] + L.r[1] * L.r[1];
-  }
-#pragma unroll
-  for (int k = 0; k < 3; ++k) C[k * 4] += d.lambda * C[k * 4];  // :454-456
-  double Ci[9];
-  sba_inv3_ldlt(C, Ci);
-#pragma unroll
-  for (int k = 0; k < 9; ++k) d.Cinv[9 * (size_t)i + k] = Ci[k];
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    d.Cinvb[3 * (size_t)i + r] = Ci[r * 3] * b[0] + (Ci[r * 3 + 1] * b[1] + Ci[r * 3 + 2] * b[2]);
-    d.b[3 * (size_t)i + r] = b[r];
-  }
-  d.err_i[i] = err;
-  // B_ji of every slot: Qij^T Rij of the LAST observation of landmark i in keyframe j (:315 / :410 assign)
-  for (int s = d.slot_ptr[i]; s < d.slot_ptr[i + 1]; ++s) {
-    const int o = d.slot_bobs[s];
-    SbaObs L;
-    const double px[2] = {d.obs_px[2 * o], d.obs_px[2 * o + 1]};
-    sba_linearize(d, d.T + 16 * (size_t)d.obs_frame[o], X, px, d.obs_right[o], L);
-    double B[18];
-#pragma unroll
-    for (int r = 0; r < 6; ++r)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) B[r * 3 + c] = L.w * (L.Q[r] * L.R[c] + L.Q[6 + r] * L.R[3 + c]);
-    double *Bo = d.Bs + 18 * (size_t)s, *BCo = d.BCs + 18 * (size_t)s;
-#pragma unroll
-    for (int r = 0; r < 6; ++r)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        Bo[r * 3 + c] = B[r * 3 + c];
-        BCo[r * 3 + c] = B[r * 3] * Ci[c] + (B[r * 3 + 1] * Ci[3 + c] + B[r * 3 + 2] * Ci[6 + c]);  // :471
-      }
-  }
+// SBA_LQ lanes share a landmark: lane `sub` takes observations (and slots) sub, sub + 4, ... and the partial sums meet
+// in a quad butterfly — a landmark seen by all nine stereo keyframes costs 5 dependent rounds instead of 18, and a
+// wavefront's duration is that of its longest landmark. Every lane of the quad ends with the same bits (a + b == b + a).
+#define SBA_LQ 4
+#define SBA_LDS_FRAMES 32  // poses of up to this many frames are staged in LDS (a lane's pose depends on its observation)
+template <int CTRL>
+__device__ __forceinline__ double sba_dpp_f64(double v) {
+  int2 p = __builtin_bit_cast(int2, v);
+  p.x = dpp_i32<CTRL>(p.x);
+  p.y = dpp_i32<CTRL>(p.y);
+  return __builtin_bit_cast(double, p);
+}
+__device__ __forceinline__ double sba_quad_sum(double v) {  // all four lanes of the quad must be active
+  v += sba_dpp_f64<0xB1>(v);
+  v += sba_dpp_f64<0x4E>(v);
+  return v;
 }
 
 __device__ __forceinline__ double sba_wave_sum(double v) {
@@ -264,18 +239,56 @@ __device__ __forceinline__ double sba_wave_sum(double v) {
 }
 
 // ---- per optimised pose: A_j, a_j, (B C^-1 b)_j -----------------------------------------
-__device__ __forceinline__ void sba_pose_body(const SbaDev &d, int j, int g, int lane) {
+// Workgroups of SBA_WG lanes: SBA_PG (SBA_SG) of them share a pose (a block), lane-strided partial sums, a butterfly
+// per wavefront and the wavefronts' sums added in LDS — one partial per workgroup goes to HBM. With 8 x 256 lanes a
+// pose of the bench window (3 800 observations) is two dependent rounds of loads per lane.
+#define SBA_WG 256
+// sum over the workgroup, value by value: DPP butterfly inside rows of 16 lanes (two instructions move a double), the
+// SBA_WG / 16 row sums through LDS, lane k < NV adds them in row order (a 64-lane __shfl_down tree costs two
+// ds_bpermute per step and was three quarters of the kernel)
+__device__ __forceinline__ double sba_row16_sum(double v) {  // every lane must be active
+  v += sba_dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += sba_dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += sba_dpp_f64<0x141>(v);  // row_half_mirror
+  v += sba_dpp_f64<0x140>(v);  // row_mirror
+  return v;
+}
+template <int NV>
+__device__ __forceinline__ void sba_group_reduce(double (&acc)[NV], double *__restrict__ out, int tid) {
+  __shared__ double s_part[SBA_WG / 16][NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const double t = sba_row16_sum(acc[k]);
+    if ((tid & 15) == 0) s_part[tid >> 4][k] = t;
+  }
+  __syncthreads();
+  if (tid < NV) {
+    double t = s_part[0][tid];
+#pragma unroll
+    for (int w = 1; w < SBA_WG / 16; ++w) t += s_part[w][tid];
+    out[tid] = t;
+  }
+}
+
+__device__ __forceinline__ void sba_pose_body(const SbaDev &d, int j, int g, int tid) {
   double acc[48];
 #pragma unroll
   for (int k = 0; k < 48; ++k) acc[k] = 0.0;
   int nan_seen = 0;
-  for (int q = d.pose_obs_ptr[j] + g * 64 + lane; q < d.pose_obs_ptr[j + 1]; q += 64 * SBA_PG) {
-    const int o = d.pose_obs[q];
-    const int i = d.slot_lm[d.n_slots + o];  // landmark of observation o (second half of the array)
-    const double X[3] = {d.X[3 * i], d.X[3 * i + 1], d.X[3 * i + 2]};
+  const long long st0 = SBA_TICK();
+  double Tj[16];  // every observation of the list is one in the pose's own frame (wave-uniform)
+  {
+    const double *Tp = d.T + 16 * (size_t)d.opt_frame[j];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Tj[k] = Tp[k];
+  }
+  const long long st1 = SBA_TICK();
+  for (int q = d.pose_obs_ptr[j] + g * SBA_WG + tid; q < d.pose_obs_ptr[j + 1]; q += SBA_WG * SBA_PG) {
+    const int o = d.pose_obs[q], i = d.pose_lm[q];
+    const double X[3] = {d.X[3 * (size_t)i], d.X[3 * (size_t)i + 1], d.X[3 * (size_t)i + 2]};
     const double px[2] = {d.obs_px[2 * o], d.obs_px[2 * o + 1]};
     SbaObs L;
-    sba_linearize(d, d.T + 16 * (size_t)d.obs_frame[o], X, px, d.obs_right[o], L);
+    sba_linearize(d, Tj, X, px, d.obs_right[o], L);
     // calc_Qij_t_Qij_weight (:986-1041): written for Q(0,1) = Q(1,0) = 0; entry (0,1) stays zero
     double wa[12];
 #pragma unroll
@@ -305,29 +318,29 @@ __device__ __forceinline__ void sba_pose_body(const SbaDev &d, int j, int g, int
 #pragma unroll
     for (int r = 0; r < 6; ++r) acc[36 + r] += -(L.w * (L.Q[r] * L.r[0] + L.Q[6 + r] * L.r[1]));
   }
-  for (int q = d.pose_slot_ptr[j] + g * 64 + lane; q < d.pose_slot_ptr[j + 1]; q += 64 * SBA_PG) {
-    const int s = d.pose_slot[q], i = d.slot_lm[s];
-    const double *BC = d.BCs + 18 * (size_t)s, *b = d.b + 3 * (size_t)i;
+  for (int q = d.pose_slot_ptr[j] + g * SBA_WG + tid; q < d.pose_slot_ptr[j + 1]; q += SBA_WG * SBA_PG) {
+    const double *BCb = d.BCb + 6 * (size_t)d.pose_slot[q];  // (B_ji C_i^-1) b_i, formed by the point kernel (:473)
 #pragma unroll
-    for (int r = 0; r < 6; ++r) acc[42 + r] += BC[r * 3] * b[0] + (BC[r * 3 + 1] * b[1] + BC[r * 3 + 2] * b[2]);  // :473
+    for (int r = 0; r < 6; ++r) acc[42 + r] += BCb[r];
   }
-  double *out = d.Apart + 48 * ((size_t)j * SBA_PG + g);
-#pragma unroll
-  for (int k = 0; k < 48; ++k) {
-    const double t = sba_wave_sum(acc[k]);
-    if (lane == 0) out[k] = t;
-  }
-  if (__any(nan_seen) && lane == 0) atomicOr(d.flags, 1);  // :318 "In LBA, pose becomes nan!"
+  const long long st2 = SBA_TICK();
+  sba_group_reduce<48>(acc, d.Apart + 48 * ((size_t)j * SBA_PG + g), tid);
+  const long long st3 = SBA_TICK();
+  SBA_STAMP_MAX(4, st1, st0);
+  SBA_STAMP_MAX(5, st2, st1);
+  SBA_STAMP_MAX(6, st3, st2);
+  if (__any(nan_seen) && (tid & 63) == 0) atomicOr(d.flags, 1);  // :318 "In LBA, pose becomes nan!"
 }
 
 // ---- per block (j,k) of B C^-1 B^T -------------------------------------------------------
 // (blocks below the diagonal are overwritten by the transposed upper ones (:495-497) before anything reads them:
 // whatever an observation list in reverse keyframe order accumulates there is discarded — they are not computed)
-__device__ __forceinline__ void sba_schur_body(const SbaDev &d, int jk, int g, int lane) {
+__device__ __forceinline__ void sba_schur_body(const SbaDev &d, int jk, int g, int tid) {
   double acc[36];
 #pragma unroll
   for (int k = 0; k < 36; ++k) acc[k] = 0.0;
-  for (int q = d.pair_ptr[jk] + g * 64 + lane; q < d.pair_ptr[jk + 1]; q += 64 * SBA_SG) {
+  const long long st1 = SBA_TICK();
+  for (int q = d.pair_ptr[jk] + g * SBA_WG + tid; q < d.pair_ptr[jk + 1]; q += SBA_WG * SBA_SG) {
     const double *BC = d.BCs + 18 * (size_t)d.pair_a[q], *Bk = d.Bs + 18 * (size_t)d.pair_b[q];
     double bc[18], bk[18];
 #pragma unroll
@@ -341,20 +354,20 @@ __device__ __forceinline__ void sba_schur_body(const SbaDev &d, int jk, int g, i
       for (int c = 0; c < 6; ++c)
         acc[r * 6 + c] += bc[r * 3] * bk[c * 3] + (bc[r * 3 + 1] * bk[c * 3 + 1] + bc[r * 3 + 2] * bk[c * 3 + 2]);  // :489
   }
-#pragma unroll
-  for (int k = 0; k < 36; ++k) {
-    const double t = sba_wave_sum(acc[k]);
-    if (lane == 0) d.S[36 * ((size_t)jk * SBA_SG + g) + k] = t;
-  }
+  const long long st2 = SBA_TICK();
+  sba_group_reduce<36>(acc, d.S + 36 * ((size_t)jk * SBA_SG + g), tid);
+  const long long st3 = SBA_TICK();
+  SBA_STAMP_MAX(8, st2, st1);
+  SBA_STAMP_MAX(9, st3, st2);
 }
 
 // A_j / a_j / (B C^-1 b)_j and the blocks of B C^-1 B^T do not depend on one another: ONE launch, workgroups
 // 0 .. n_opt * SBA_PG - 1 take the pose sums, the others the blocks on and above the diagonal, row by row
-__global__ __launch_bounds__(64) void sba_pose_schur_kernel(SbaDev d) {
-  const int t = blockIdx.x, lane = threadIdx.x, No = d.n_opt;
+__global__ __launch_bounds__(SBA_WG) void sba_pose_schur_kernel(SbaDev d) {
+  const int t = blockIdx.x, tid = threadIdx.x, No = d.n_opt;
   const int n_pose = No * SBA_PG;
   if (t < n_pose) {
-    sba_pose_body(d, t / SBA_PG, t % SBA_PG, lane);
+    sba_pose_body(d, t / SBA_PG, t % SBA_PG, tid);
     return;
   }
   int u = (t - n_pose) / SBA_SG, j = 0;
@@ -362,7 +375,7 @@ __global__ __launch_bounds__(64) void sba_pose_schur_kernel(SbaDev d) {
     u -= No - j;
     ++j;
   }
-  sba_schur_body(d, j * No + j + u, (t - n_pose) % SBA_SG, lane);
+  sba_schur_body(d, j * No + j + u, (t - n_pose) % SBA_SG, tid);
 }
 
 // ---- se3 exp / log in double (geometry_library.cpp:336-384, :442-495) ---------------------
@@ -693,14 +706,14 @@ __global__ __launch_bounds__(64) void sba_solve_kernel(SbaDev d, int iter) {
   double e = 0.0;
   {
     int i = lane;
-    for (; i + 7 * 64 < d.M; i += 8 * 64) {
+    for (; i + 7 * 64 < d.n_err; i += 8 * 64) {
       double v[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = d.err_i[i + 64 * q];
+      for (int q = 0; q < 8; ++q) v[q] = d.err_part[i + 64 * q];
 #pragma unroll
       for (int q = 0; q < 8; ++q) e += v[q];
     }
-    for (; i < d.M; i += 64) e += d.err_i[i];
+    for (; i < d.n_err; i += 64) e += d.err_part[i];
   }
   e = sba_wave_sum(e);
   if (lane == 0) {
@@ -726,16 +739,65 @@ __device__ __forceinline__ double sba_rl(double v, int src) {
   p.y = __builtin_amdgcn_readlane(p.y, src);
   return __builtin_bit_cast(double, p);
 }
+// (one wavefront from here on: LDS accesses of a wavefront are executed in order, only the compiler has to be told)
+#define SBA_WAVE_SYNC()                                  \
+  do {                                                   \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); \
+    __builtin_amdgcn_wave_barrier();                     \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); \
+  } while (0)
+#define SBA_SOLVE_WG 512
 template <int N>
-__global__ __launch_bounds__(64) void sba_solve_reg_kernel(SbaDev d, int iter) {
-  __shared__ double sL[N * N];  // L, row-major: sL[q * N + i] = L(q, i)
+__global__ __launch_bounds__(SBA_SOLVE_WG) void sba_solve_reg_kernel(SbaDev d, int iter) {
+  __shared__ double sL[N * N + N];  // first the reduced system (lower triangle, G(i,j) at [i * N + j]; rhs behind), later L
   __shared__ double s_dg[N];
   __shared__ int s_sig[N];
-  const int lane = threadIdx.x, n = N;
+  const int tid = threadIdx.x, lane = tid & 63, n = N;
   const long long t_0 = (long long)__builtin_amdgcn_s_memrealtime();
+  // ---- the reduced system out of the partial sums (what sba_assemble_kernel does for the general kernel), by all
+  // eight wavefronts straight into LDS: entry t of the packed lower triangle, then the right-hand side
+  for (int t = tid; t < N * (N + 1) / 2 + N; t += SBA_SOLVE_WG) {
+    if (t < N * (N + 1) / 2) {
+      int row = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+      while (row * (row + 1) / 2 > t) --row;
+      while ((row + 1) * (row + 2) / 2 <= t) ++row;
+      const int col = t - row * (row + 1) / 2;
+      sL[row * N + col] = sba_reduced_entry(d, row, col);
+    } else {
+      const int q = t - N * (N + 1) / 2, j = q / 6, r = q - 6 * j;
+      double a = 0.0, bcb = 0.0;
+#pragma unroll
+      for (int g = 0; g < SBA_PG; ++g) {
+        a += d.Apart[48 * ((size_t)j * SBA_PG + g) + 36 + r];
+        bcb += d.Apart[48 * ((size_t)j * SBA_PG + g) + 42 + r];
+      }
+      sL[N * N + q] = a - bcb;  // :508-509
+    }
+  }
+  __syncthreads();
+  if (tid >= 128) return;
+  if (tid >= 64) {
+    // the second wavefront: average pixel error of this iteration's linearisation point (:594-601), next to the solve
+    double e = 0.0;
+    int i = lane;
+    for (; i + 7 * 64 < d.n_err; i += 8 * 64) {
+      double v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = d.err_part[i + 64 * q];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) e += v[q];
+    }
+    for (; i < d.n_err; i += 64) e += d.err_part[i];
+    e = sba_wave_sum(e);
+    if (lane == 0) {
+      d.avg_err[iter] = sqrt(e / (double)d.n_obs);
+      if (e != e) atomicOr(d.flags, 2);
+    }
+    return;
+  }
   // ---- pivot order (see sba_solve_kernel): descending |diagonal| unless two are exactly equal
   {
-    const double v = lane < N ? fabs(d.G[(size_t)lane * n + lane]) : -1.0;
+    const double v = lane < N ? fabs(sL[lane * N + lane]) : -1.0;
     int rank = 0, tie = 0;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
@@ -750,7 +812,7 @@ __global__ __launch_bounds__(64) void sba_solve_reg_kernel(SbaDev d, int iter) {
         s_dg[lane] = v;
         s_sig[lane] = lane;
       }
-      __syncthreads();
+      SBA_WAVE_SYNC();
       if (lane == 0)
         for (int k = 0; k < N; ++k) {  // Eigen's selection: the first of the largest among positions k.., then the swap
           int piv = k;
@@ -764,7 +826,7 @@ __global__ __launch_bounds__(64) void sba_solve_reg_kernel(SbaDev d, int iter) {
           s_sig[piv] = ti;
         }
     }
-    __syncthreads();
+    SBA_WAVE_SYNC();
   }
   // ---- this lane's row of the permuted lower triangle, and its entry of P rhs
   const int my = lane < N ? s_sig[lane] : 0;
@@ -773,26 +835,25 @@ __global__ __launch_bounds__(64) void sba_solve_reg_kernel(SbaDev d, int iter) {
   for (int j = 0; j < N; ++j) {
     const int sj = s_sig[j];
     const int hi = my > sj ? my : sj, lo = my > sj ? sj : my;
-    r[j] = (lane < N && j <= lane) ? d.G[(size_t)hi * n + lo] : 0.0;
+    r[j] = (lane < N && j <= lane) ? sL[hi * N + lo] : 0.0;
   }
-  double y = lane < N ? d.G[(size_t)n * n + my] : 0.0;
+  double y = lane < N ? sL[N * N + my] : 0.0;
+  SBA_WAVE_SYNC();  // (sL is written again below)
   const long long t_1 = (long long)__builtin_amdgcn_s_memrealtime();
-  // ---- Eigen::LDLT (lower, in place), left-looking, fully unrolled
+  // ---- Eigen::LDLT (lower, in place), left-looking, fully unrolled. (temp[j] through LDS — one store by lane k, a
+  // broadcast read by all — was measured slower than the lane broadcasts: 22 vs 17 us, two LDS round trips per step.)
   double dgl = 0.0;  // this lane's final diagonal entry D(lane)
-  double Dj[N];      // D(j) of the finished steps (wave-uniform)
+  double w[N];       // w[j] = M(j,j) * M(lane,j) once column j is final: temp[j] of step k is lane k's w[j]
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     double dd = 0.0;
 #pragma unroll
-    for (int j = 0; j < k; ++j) {
-      const double t = Dj[j] * sba_rl(r[j], k);  // temp[j] = M(j,j) * M(k,j)
-      dd += r[j] * t;                            // row `lane`: sum_{j<k} M(lane,j) temp[j], increasing j
-    }
-    if (k > 0 && lane >= k) r[k] -= dd;          // rows k (the diagonal entry) and k+1.. in one sweep
+    for (int j = 0; j < k; ++j) dd += r[j] * sba_rl(w[j], k);  // row `lane`: sum_{j<k} M(lane,j) temp[j], increasing j
+    if (k > 0 && lane >= k) r[k] -= dd;                        // rows k (the diagonal entry) and k+1.. in one sweep
     const double akk = sba_rl(r[k], k);
-    Dj[k] = akk;
     if (lane == k) dgl = akk;
     if (fabs(akk) > 0.0 && lane > k) r[k] /= akk;
+    w[k] = akk * r[k];
   }
   // ---- solve: x = P^T L^-T D^+ L^-1 (P rhs); the entry of lane i stays in a register
 #pragma unroll
@@ -805,7 +866,7 @@ __global__ __launch_bounds__(64) void sba_solve_reg_kernel(SbaDev d, int iter) {
 #pragma unroll
   for (int j = 0; j < N; ++j)
     if (lane < N && j < lane) sL[lane * N + j] = r[j];
-  __syncthreads();
+  SBA_WAVE_SYNC();
   for (int q = N - 1; q > 0; --q) {  // L^T sweep in DECREASING q, as sba_solve_kernel
     const double yq = sba_rl(y, q);  // (q is wave-uniform)
     if (lane < q) y -= sL[q * N + lane] * yq;
@@ -813,7 +874,7 @@ __global__ __launch_bounds__(64) void sba_solve_reg_kernel(SbaDev d, int iter) {
   // P^T: scatter back through sig
   double *xs = s_dg;
   if (lane < N) xs[my] = y;
-  __syncthreads();
+  SBA_WAVE_SYNC();
   const long long t_2 = (long long)__builtin_amdgcn_s_memrealtime();
   if (lane < N) d.x[lane] = xs[lane];
   // pose updates (:560-576)
@@ -821,53 +882,125 @@ __global__ __launch_bounds__(64) void sba_solve_reg_kernel(SbaDev d, int iter) {
     const int j = d.opt_index[f];
     if (j >= 0) sba_pose_update(d.T + 16 * (size_t)f, xs + 6 * j);
   }
-  // average pixel error of this iteration's linearisation point (:594-601)
-  double e = 0.0;
-  {
-    int i = lane;
-    for (; i + 7 * 64 < d.M; i += 8 * 64) {
-      double v[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = d.err_i[i + 64 * q];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) e += v[q];
-    }
-    for (; i < d.M; i += 64) e += d.err_i[i];
-  }
-  e = sba_wave_sum(e);
   if (lane == 0) {
-    d.avg_err[iter] = sqrt(e / (double)d.n_obs);
-    if (e != e) atomicOr(d.flags, 2);
     d.flags[1] = (int)(t_1 - t_0);
     d.flags[2] = (int)(t_2 - t_1);
     d.flags[3] = (int)((long long)__builtin_amdgcn_s_memrealtime() - t_2);
   }
 }
 
-// ---- y_i and the point update (:537-556, :578-579) ----------------------------------------
-__device__ __forceinline__ void sba_update_body(const SbaDev &d, int i) {
-  double cbx[3] = {0, 0, 0};
-  for (int s = d.slot_ptr[i]; s < d.slot_ptr[i + 1]; ++s) {
-    const double *BC = d.BCs + 18 * (size_t)s, *x = d.x + 6 * d.slot_j[s];
+// ---- y_i and the point update (:537-556, :578-579), then C_i, b_i, C_i^-1 and the slot blocks (:207-471) ----------
+// The point update of iteration k and the per-landmark linearisation of iteration k + 1 touch only landmark i (and the
+// poses the solve of iteration k left): one launch instead of two. update != 0: X_i += y_i first; point != 0: then
+// C_i, b_i (sums over the observations), damping, Eigen-order 3x3 LDLT inverse, C^-1 b, and per slot B_ji (Qij^T Rij of
+// the LAST observation of landmark i in keyframe j, :315 / :410 assign), B_ji C_i^-1 (:471) and (B_ji C_i^-1) b_i (:473).
+template <bool TLDS>
+__global__ __launch_bounds__(64) void sba_update_point_kernel(SbaDev d, int update, int point) {
+  __shared__ double sT[TLDS ? 16 * SBA_LDS_FRAMES : 2];
+  __shared__ double sx[6 * SBA_MAX_OPT];
+  const int lane = threadIdx.x, sub = lane & (SBA_LQ - 1);
+  const long long st0 = SBA_TICK();
+  if (TLDS)
+    for (int k = lane; k < 16 * d.n_frames; k += 64) sT[k] = d.T[k];
+  if (update)
+    for (int k = lane; k < 6 * d.n_opt; k += 64) sx[k] = d.x[k];
+  __syncthreads();
+  const int i_raw = blockIdx.x * (64 / SBA_LQ) + lane / SBA_LQ;
+  const bool live = i_raw < d.M;
+  const int i = live ? i_raw : d.M - 1;  // a surplus quad repeats the last landmark and stores nothing (DPP needs all lanes)
+  double X[3] = {d.X[3 * (size_t)i], d.X[3 * (size_t)i + 1], d.X[3 * (size_t)i + 2]};
+  const int s0 = d.slot_ptr[i], s1 = d.slot_ptr[i + 1];
+  const long long st1 = SBA_TICK();
+  if (update) {
+    double cbx[3] = {0, 0, 0};
+    for (int s = s0 + sub; s < s1; s += SBA_LQ) {
+      const double *BC = d.BCs + 18 * (size_t)s, *x = sx + 6 * d.slot_j[s];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) t += BC[r * 3 + c] * x[r];
+        cbx[c] += t;
+      }
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      double t = 0.0;
-#pragma unroll
-      for (int r = 0; r < 6; ++r) t += BC[r * 3 + c] * x[r];
-      cbx[c] += t;
+      X[c] += d.Cinvb[3 * (size_t)i + c] - sba_quad_sum(cbx[c]);
+      if (live && sub == 0) d.X[3 * (size_t)i + c] = X[c];
     }
   }
+  if (!point) return;
+  const long long st2 = SBA_TICK();
+  double Cu[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0}, err = 0.0;  // C_i: (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+  const int o1 = d.obs_ptr[i + 1];
+  for (int o = d.obs_ptr[i] + sub; o < o1; o += SBA_LQ) {
+    SbaObs L;
+    const double px[2] = {d.obs_px[2 * o], d.obs_px[2 * o + 1]};
+    const int f = d.obs_frame[o];
+    sba_linearize(d, TLDS ? sT + 16 * f : d.T + 16 * (size_t)f, X, px, d.obs_right[o], L);
+    // calc_Rij_t_Rij_weight (:911-930), b_i += -weight * (Rij^T rij)
+    int q = 0;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) d.X[3 * (size_t)i + c] += d.Cinvb[3 * (size_t)i + c] - cbx[c];
-}
-
-// The point update of iteration k and the per-landmark linearisation of iteration k + 1 touch only landmark i (and the
-// poses the solve of iteration k left): one launch instead of two. update != 0: X_i += y_i first; point != 0: then C_i, b_i, ...
-__global__ __launch_bounds__(64) void sba_update_point_kernel(SbaDev d, int update, int point) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= d.M) return;
-  if (update) sba_update_body(d, i);
-  if (point) sba_point_body(d, i);
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = r; c < 3; ++c) Cu[q++] += L.w * (L.R[r] * L.R[c] + L.R[3 + r] * L.R[3 + c]);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) b[r] += -(L.w * (L.R[r] * L.r[0] + L.R[3 + r] * L.r[1]));
+    err += L.r[0] * L.r[0] + L.r[1] * L.r[1];
+  }
+  const long long st3 = SBA_TICK();
+#pragma unroll
+  for (int k = 0; k < 6; ++k) Cu[k] = sba_quad_sum(Cu[k]);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) b[k] = sba_quad_sum(b[k]);
+  err = sba_quad_sum(err);
+  double C[9] = {Cu[0], Cu[1], Cu[2], Cu[1], Cu[3], Cu[4], Cu[2], Cu[4], Cu[5]};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) C[k * 4] += d.lambda * C[k * 4];  // :454-456
+  double Ci[9];
+  sba_inv3_ldlt(C, Ci);
+  if (live && sub == 0) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      d.Cinvb[3 * (size_t)i + r] = Ci[r * 3] * b[0] + (Ci[r * 3 + 1] * b[1] + Ci[r * 3 + 2] * b[2]);
+      d.b[3 * (size_t)i + r] = b[r];
+    }
+  }
+  const long long st4 = SBA_TICK();
+  for (int s = s0 + sub; s < s1; s += SBA_LQ) {
+    const int o = d.slot_bobs[s];
+    SbaObs L;
+    const double px[2] = {d.obs_px[2 * o], d.obs_px[2 * o + 1]};
+    const int f = d.obs_frame[o];
+    sba_linearize(d, TLDS ? sT + 16 * f : d.T + 16 * (size_t)f, X, px, d.obs_right[o], L);
+    double B[18], BC[18];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) B[r * 3 + c] = L.w * (L.Q[r] * L.R[c] + L.Q[6 + r] * L.R[3 + c]);
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) BC[r * 3 + c] = B[r * 3] * Ci[c] + (B[r * 3 + 1] * Ci[3 + c] + B[r * 3 + 2] * Ci[6 + c]);  // :471
+    if (live) {
+      double *Bo = d.Bs + 18 * (size_t)s, *BCo = d.BCs + 18 * (size_t)s, *BCbo = d.BCb + 6 * (size_t)s;
+#pragma unroll
+      for (int k = 0; k < 18; ++k) {
+        Bo[k] = B[k];
+        BCo[k] = BC[k];
+      }
+#pragma unroll
+      for (int r = 0; r < 6; ++r) BCbo[r] = BC[r * 3] * b[0] + (BC[r * 3 + 1] * b[1] + BC[r * 3 + 2] * b[2]);  // :473
+    }
+  }
+  const long long st5 = SBA_TICK();
+  SBA_STAMP_MAX(10, st1, st0);
+  SBA_STAMP_MAX(11, st2, st1);
+  SBA_STAMP_MAX(12, st3, st2);
+  SBA_STAMP_MAX(13, st4, st3);
+  SBA_STAMP_MAX(14, st5, st4);
+  const double e = sba_wave_sum(live && sub == 0 ? err : 0.0);
+  if (lane == 0) d.err_part[blockIdx.x] = e;
 }
 
 // ---- host side ---------------------------------------------------------------------
@@ -974,13 +1107,16 @@ extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, co
   const size_t oSp = ar.take(sizeof(int) * (M + 1)), oSo = ar.take(sizeof(int) * (ns + 1)), oSj = ar.take(sizeof(int) * (ns + 1));
   const size_t oSb = ar.take(sizeof(int) * (ns + 1)), oSl = ar.take(sizeof(int) * (ns + nobs + 1));
   const size_t oPop = ar.take(sizeof(int) * (No + 1)), oPo = ar.take(sizeof(int) * (n_pose_obs + 1));
+  const size_t oPl = ar.take(sizeof(int) * (n_pose_obs + 1)), oOfr = ar.take(sizeof(int) * (No + 1));
   const size_t oPsp = ar.take(sizeof(int) * (No + 1)), oPs = ar.take(sizeof(int) * (ns + 1));
   const size_t oPp = ar.take(sizeof(int) * ((size_t)No * No + 1)), oPa = ar.take(sizeof(int) * (n_pairs + 1));
   const size_t oPb = ar.take(sizeof(int) * (n_pairs + 1));
-  const size_t oFl = ar.take(sizeof(int) * 4), oAvg = ar.take(sizeof(double) * (p->max_iter + 1));
+  const size_t oFl = ar.take(sizeof(int) * 16), oAvg = ar.take(sizeof(double) * (p->max_iter + 1));
   const size_t in_bytes = ar.off;  // everything up to here comes from the host
-  const size_t oCinv = ar.take(sizeof(double) * 9 * M), oCinvb = ar.take(sizeof(double) * 3 * M), oB = ar.take(sizeof(double) * 3 * M);
-  const size_t oErr = ar.take(sizeof(double) * M), oBs = ar.take(sizeof(double) * 18 * (ns + 1)), oBCs = ar.take(sizeof(double) * 18 * (ns + 1));
+  const int n_err = (M + 64 / SBA_LQ - 1) / (64 / SBA_LQ);  // workgroups of the point kernel
+  const size_t oCinvb = ar.take(sizeof(double) * 3 * M), oB = ar.take(sizeof(double) * 3 * M);
+  const size_t oErr = ar.take(sizeof(double) * n_err), oBs = ar.take(sizeof(double) * 18 * (ns + 1)), oBCs = ar.take(sizeof(double) * 18 * (ns + 1));
+  const size_t oBCb = ar.take(sizeof(double) * 6 * (ns + 1));
   const size_t oAp = ar.take(sizeof(double) * 48 * SBA_PG * (No + 1)), oS = ar.take(sizeof(double) * 36 * SBA_SG * ((size_t)No * No + 1));
   const size_t oG = ar.take(sizeof(double) * ((size_t)36 * No * No + 6 * No + 1));
   const size_t ox = ar.take(sizeof(double) * 6 * (No + 1));
@@ -1013,12 +1149,15 @@ extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, co
   memcpy(hs + oOf, obs_frame, sizeof(int) * nobs);
   memcpy(hs + oOr, obs_right, (size_t)nobs);
   memcpy(hs + oPx, obs_px, sizeof(double) * 2 * nobs);
-  memset(hs + oFl, 0, sizeof(int) * 4);
+  memset(hs + oFl, 0, sizeof(int) * 16);
   memset(hs + oAvg, 0, sizeof(double) * (p->max_iter + 1));
   SBA_T(4);
   int *h_slot_ptr = (int *)(hs + oSp), *h_slot_obs = (int *)(hs + oSo), *h_slot_j = (int *)(hs + oSj);
   int *h_slot_bobs = (int *)(hs + oSb), *h_slot_lm = (int *)(hs + oSl);
-  int *h_pose_obs_ptr = (int *)(hs + oPop), *h_pose_obs = (int *)(hs + oPo);
+  int *h_pose_obs_ptr = (int *)(hs + oPop), *h_pose_obs = (int *)(hs + oPo), *h_pose_lm = (int *)(hs + oPl);
+  int *h_opt_frame = (int *)(hs + oOfr);
+  for (int f = 0; f < Nf; ++f)
+    if (opt_index[f] >= 0) h_opt_frame[opt_index[f]] = f;
   int *h_pose_slot_ptr = (int *)(hs + oPsp), *h_pose_slot = (int *)(hs + oPs);
   int *h_pair_ptr = (int *)(hs + oPp), *h_pair_a = (int *)(hs + oPa), *h_pair_b = (int *)(hs + oPb);
   h_pose_obs_ptr[0] = h_pose_slot_ptr[0] = 0;
@@ -1039,6 +1178,7 @@ extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, co
         h_slot_lm[ns + o] = i;  // (second half of the array: the landmark of every observation)
         const int j = opt_index[obs_frame[o]];
         if (j < 0) continue;
+        h_pose_lm[cur_po[j]] = i;
         h_pose_obs[cur_po[j]++] = o;
         if (obs_right[o]) continue;
         // slot: left observation in an optimised keyframe; its B block is that of the LAST observation of this
@@ -1101,15 +1241,18 @@ extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, co
   d.slot_lm = (const int *)(base + oSl);
   d.pose_obs_ptr = (const int *)(base + oPop);
   d.pose_obs = (const int *)(base + oPo);
+  d.pose_lm = (const int *)(base + oPl);
+  d.opt_frame = (const int *)(base + oOfr);
   d.pose_slot_ptr = (const int *)(base + oPsp);
   d.pose_slot = (const int *)(base + oPs);
   d.pair_ptr = (const int *)(base + oPp);
   d.pair_a = (const int *)(base + oPa);
   d.pair_b = (const int *)(base + oPb);
-  d.Cinv = (double *)(base + oCinv);
   d.Cinvb = (double *)(base + oCinvb);
   d.b = (double *)(base + oB);
-  d.err_i = (double *)(base + oErr);
+  d.err_part = (double *)(base + oErr);
+  d.n_err = n_err;
+  d.BCb = (double *)(base + oBCb);
   d.Bs = (double *)(base + oBs);
   d.BCs = (double *)(base + oBCs);
   d.Apart = (double *)(base + oAp);
@@ -1126,22 +1269,30 @@ extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, co
   vo_prof_begin(c, VO_K_AUX);
   // four launches per iteration: [update of the previous iteration + per-landmark linearisation] -> [pose sums + Schur
   // blocks] -> assembly -> solve; one last update behind the loop
+  const bool t_lds = Nf <= SBA_LDS_FRAMES;
+  auto launch_update_point = [&](int update, int point) {
+    if (t_lds)
+      hipLaunchKernelGGL(sba_update_point_kernel<true>, dim3(n_err), dim3(64), 0, s, d, update, point);
+    else
+      hipLaunchKernelGGL(sba_update_point_kernel<false>, dim3(n_err), dim3(64), 0, s, d, update, point);
+  };
   for (int iter = 0; iter < p->max_iter; ++iter) {
-    hipLaunchKernelGGL(sba_update_point_kernel, dim3((M + 63) / 64), dim3(64), 0, s, d, iter > 0 ? 1 : 0, 1);
-    if (No > 0) {
-      hipLaunchKernelGGL(sba_pose_schur_kernel, dim3(No * SBA_PG + (No * (No + 1) / 2) * SBA_SG), dim3(64), 0, s, d);
-      hipLaunchKernelGGL(sba_assemble_kernel, dim3((n * n + n + 63) / 64), dim3(64), 0, s, d);
-    }
+    launch_update_point(iter > 0 ? 1 : 0, 1);
     static const bool no_reg_solve = getenv("VO_SBA_LDS_SOLVE") != nullptr;  // (A/B switch: the general kernel for every n)
-    if (n == 42 && !no_reg_solve)  // the steady-state window: 9 keyframes, 7 of them optimised
-      hipLaunchKernelGGL(sba_solve_reg_kernel<42>, dim3(1), dim3(64), 0, s, d, iter);
+    const bool reg_solve = n == 42 && !no_reg_solve;  // the steady-state window: 9 keyframes, 7 of them optimised
+    if (No > 0) {
+      hipLaunchKernelGGL(sba_pose_schur_kernel, dim3(No * SBA_PG + (No * (No + 1) / 2) * SBA_SG), dim3(SBA_WG), 0, s, d);
+      if (!reg_solve) hipLaunchKernelGGL(sba_assemble_kernel, dim3((n * n + n + 63) / 64), dim3(64), 0, s, d);
+    }
+    if (reg_solve)  // (assembles the reduced system itself: three launches per iteration)
+      hipLaunchKernelGGL(sba_solve_reg_kernel<42>, dim3(1), dim3(SBA_SOLVE_WG), 0, s, d, iter);
     else
       hipLaunchKernelGGL(sba_solve_kernel, dim3(1), dim3(64), lds, s, d, iter);
   }
-  if (p->max_iter > 0) hipLaunchKernelGGL(sba_update_point_kernel, dim3((M + 63) / 64), dim3(64), 0, s, d, 1, 0);
+  if (p->max_iter > 0) launch_update_point(1, 0);
   vo_prof_end(c);
   VO_CHECK_HIP(c, hipGetLastError());
-  int flags[4] = {0, 0, 0, 0};
+  int flags[16] = {0};  // [0] error bits, [1..3] phase ticks of the solve kernel, [4..] -DSBA_STAMP phase maxima
   std::vector<double> errs(p->max_iter + 1, 0.0);
   {  // results through the pinned staging block (its upload half has been consumed: the copies are stream-ordered)
     double *o_T = (double *)hs, *o_X = o_T + 16 * (size_t)Nf, *o_e = o_X + 3 * (size_t)M;
@@ -1161,6 +1312,12 @@ extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, co
     fprintf(stderr, "[sba] per call (us): lists %.0f  upload %.0f  kernels+d2h %.0f | solve kernel, last iteration (us): pivot+assembly %.1f  "
                     "LDLT+solve %.1f  pose update+error %.1f\n", tt[0] / n_calls, tt[1] / n_calls, tt[2] / n_calls, flags[1] * 0.01, flags[2] * 0.01,
             flags[3] * 0.01);
+#ifdef SBA_STAMP
+  if (trace && (n_calls % 10) == 0)
+    fprintf(stderr, "[sba] stamps, max over workgroups (us): pose head %.1f loop %.1f reduce %.1f | schur head %.1f loop %.1f reduce %.1f | point head %.1f update %.1f obs %.1f inv %.1f slots %.1f\n",
+            flags[4] * 0.01, flags[5] * 0.01, flags[6] * 0.01, flags[7] * 0.01, flags[8] * 0.01, flags[9] * 0.01, flags[10] * 0.01,
+            flags[11] * 0.01, flags[12] * 0.01, flags[13] * 0.01, flags[14] * 0.01);
+#endif
   if (trace && (n_calls % 10) == 0)
     fprintf(stderr, "[sba] upload split (us): arena %.0f  memcpy to staging %.0f  lists pass 2 + order %.0f  h2d call %.0f  rest %.0f  (pairs %zu, slots %d, %zu KB)\n",
             tt[3] / n_calls, tt[4] / n_calls, tt[5] / n_calls, tt[6] / n_calls, tt[1] / n_calls, n_pairs, ns, in_bytes >> 10);
