@@ -893,7 +893,7 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
         h.n_emit = n_emit;
         h.overflow = base > v.cap ? 1 : 0;
         h.seq = 0;
-        h.pad = 0;
+        h.id_min = base > 0 ? v.nxt.ids[0] : v.id_base;  // (another thread's store, behind the barrier above)
         *v.hdr_dev = h;
         *v.hdr_host = h;  // (pinned; made visible by the system-scope fence in front of the frame's sequence word below)
       }

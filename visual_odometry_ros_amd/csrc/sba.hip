@@ -34,37 +34,9 @@
   if ((threadIdx.x & 63) == 0) atomicMax(d.flags + (slot), (int)((t1) - (t0)))
 #else
 #define SBA_TICK() 0LL
-#define SBA_STAMP_MAX(slot, t1, t0)
+#define SBA_STAMP_MAX(slot, t1, t0) ((void)(t1), (void)(t0))
 #endif
-#define SBA_PG 8        // partial-sum wavefronts per optimised pose
-#define SBA_SG 8        // partial-sum wavefronts per block of B C^-1 B^T
-#define SBA_MAX_OPT 20  // reduced system up to 120 x 120 in LDS
-
-struct SbaDev {
-  int n_frames, n_opt, M, n_obs, n_slots, stereo, max_iter;
-  double Kl[4], Kr[4], R_rl[9], t_rl[3], thres_huber, lambda;
-  double *T;
-  const int *opt_index;
-  double *X;
-  const int *obs_ptr, *obs_frame;
-  const uint8_t *obs_right;
-  const double *obs_px;
-  const int *slot_ptr, *slot_obs, *slot_j, *slot_bobs;
-  const int *pose_obs_ptr, *pose_obs, *pose_lm;  // per optimised pose: its observations and their landmarks
-  const int *opt_frame;                          // frame of optimised pose j
-  const int *pose_slot_ptr, *pose_slot, *slot_lm;
-  const int *pair_ptr, *pair_a, *pair_b;
-  double *Cinvb, *b;
-  double *err_part;  // squared-error sum of each workgroup of the point kernel (n_err of them)
-  int n_err;
-  double *Bs, *BCs, *BCb;  // per slot: B_ji, B_ji C_i^-1 (6x3 each), (B_ji C_i^-1) b_i (6)
-  double *Apart;  // n_opt * SBA_PG * 48 (36 A, 6 a, 6 BCinv_b)
-  double *S;      // n_opt * n_opt * SBA_SG * 36 (partial sums; blocks below the diagonal are never used)
-  double *x;      // n_opt * 6
-  double *G;      // reduced system, (6 n_opt)^2 lower triangle + 6 n_opt right-hand side
-  double *avg_err;
-  int *flags;
-};
+#include "sba_device.hpp"
 
 struct SbaObs {
   double r[2], w, R[6], Q[12];
@@ -217,7 +189,6 @@ __device__ __forceinline__ void sba_inv3_ldlt(const double Cin[9], double out[9]
 // SBA_LQ lanes share a landmark: lane `sub` takes observations (and slots) sub, sub + 4, ... and the partial sums meet
 // in a quad butterfly — a landmark seen by all nine stereo keyframes costs 5 dependent rounds instead of 18, and a
 // wavefront's duration is that of its longest landmark. Every lane of the quad ends with the same bits (a + b == b + a).
-#define SBA_LQ 4
 #define SBA_LDS_FRAMES 32  // poses of up to this many frames are staged in LDS (a lane's pose depends on its observation)
 template <int CTRL>
 __device__ __forceinline__ double sba_dpp_f64(double v) {
@@ -283,7 +254,8 @@ __device__ __forceinline__ void sba_pose_body(const SbaDev &d, int j, int g, int
     for (int k = 0; k < 16; ++k) Tj[k] = Tp[k];
   }
   const long long st1 = SBA_TICK();
-  for (int q = d.pose_obs_ptr[j] + g * SBA_WG + tid; q < d.pose_obs_ptr[j + 1]; q += SBA_WG * SBA_PG) {
+  const int po_end = d.pose_obs_end ? d.pose_obs_end[j] : d.pose_obs_ptr[j + 1];
+  for (int q = d.pose_obs_ptr[j] + g * SBA_WG + tid; q < po_end; q += SBA_WG * SBA_PG) {
     const int o = d.pose_obs[q], i = d.pose_lm[q];
     const double X[3] = {d.X[3 * (size_t)i], d.X[3 * (size_t)i + 1], d.X[3 * (size_t)i + 2]};
     const double px[2] = {d.obs_px[2 * o], d.obs_px[2 * o + 1]};
@@ -318,7 +290,8 @@ __device__ __forceinline__ void sba_pose_body(const SbaDev &d, int j, int g, int
 #pragma unroll
     for (int r = 0; r < 6; ++r) acc[36 + r] += -(L.w * (L.Q[r] * L.r[0] + L.Q[6 + r] * L.r[1]));
   }
-  for (int q = d.pose_slot_ptr[j] + g * SBA_WG + tid; q < d.pose_slot_ptr[j + 1]; q += SBA_WG * SBA_PG) {
+  const int ps_end = d.pose_slot_end ? d.pose_slot_end[j] : d.pose_slot_ptr[j + 1];
+  for (int q = d.pose_slot_ptr[j] + g * SBA_WG + tid; q < ps_end; q += SBA_WG * SBA_PG) {
     const double *BCb = d.BCb + 6 * (size_t)d.pose_slot[q];  // (B_ji C_i^-1) b_i, formed by the point kernel (:473)
 #pragma unroll
     for (int r = 0; r < 6; ++r) acc[42 + r] += BCb[r];
@@ -340,7 +313,8 @@ __device__ __forceinline__ void sba_schur_body(const SbaDev &d, int jk, int g, i
 #pragma unroll
   for (int k = 0; k < 36; ++k) acc[k] = 0.0;
   const long long st1 = SBA_TICK();
-  for (int q = d.pair_ptr[jk] + g * SBA_WG + tid; q < d.pair_ptr[jk + 1]; q += SBA_WG * SBA_SG) {
+  const int pr_end = d.pair_end ? d.pair_end[jk] : d.pair_ptr[jk + 1];
+  for (int q = d.pair_ptr[jk] + g * SBA_WG + tid; q < pr_end; q += SBA_WG * SBA_SG) {
     const double *BC = d.BCs + 18 * (size_t)d.pair_a[q], *Bk = d.Bs + 18 * (size_t)d.pair_b[q];
     double bc[18], bk[18];
 #pragma unroll
@@ -717,7 +691,7 @@ __global__ __launch_bounds__(64) void sba_solve_kernel(SbaDev d, int iter) {
   }
   e = sba_wave_sum(e);
   if (lane == 0) {
-    d.avg_err[iter] = sqrt(e / (double)d.n_obs);
+    d.avg_err[iter] = sqrt(e / (double)(d.dyn ? d.dyn[1] : d.n_obs));
     if (e != e) atomicOr(d.flags, 2);
     // phase durations of the last iteration in 10 ns ticks (tests/measure/sbabench.py)
     d.flags[1] = (int)(t_1 - t_0);
@@ -752,7 +726,7 @@ __global__ __launch_bounds__(SBA_SOLVE_WG) void sba_solve_reg_kernel(SbaDev d, i
   __shared__ double sL[N * N + N];  // first the reduced system (lower triangle, G(i,j) at [i * N + j]; rhs behind), later L
   __shared__ double s_dg[N];
   __shared__ int s_sig[N];
-  const int tid = threadIdx.x, lane = tid & 63, n = N;
+  const int tid = threadIdx.x, lane = tid & 63;
   const long long t_0 = (long long)__builtin_amdgcn_s_memrealtime();
   // ---- the reduced system out of the partial sums (what sba_assemble_kernel does for the general kernel), by all
   // eight wavefronts straight into LDS: entry t of the packed lower triangle, then the right-hand side
@@ -790,7 +764,7 @@ __global__ __launch_bounds__(SBA_SOLVE_WG) void sba_solve_reg_kernel(SbaDev d, i
     for (; i < d.n_err; i += 64) e += d.err_part[i];
     e = sba_wave_sum(e);
     if (lane == 0) {
-      d.avg_err[iter] = sqrt(e / (double)d.n_obs);
+      d.avg_err[iter] = sqrt(e / (double)(d.dyn ? d.dyn[1] : d.n_obs));
       if (e != e) atomicOr(d.flags, 2);
     }
     return;
@@ -905,9 +879,14 @@ __global__ __launch_bounds__(64) void sba_update_point_kernel(SbaDev d, int upda
   if (update)
     for (int k = lane; k < 6 * d.n_opt; k += 64) sx[k] = d.x[k];
   __syncthreads();
+  const int M = d.dyn ? d.dyn[0] : d.M;
+  if ((int)blockIdx.x * (64 / SBA_LQ) >= M) {  // (a launch sized by an upper bound of M)
+    if (point && lane == 0) d.err_part[blockIdx.x] = 0.0;
+    return;
+  }
   const int i_raw = blockIdx.x * (64 / SBA_LQ) + lane / SBA_LQ;
-  const bool live = i_raw < d.M;
-  const int i = live ? i_raw : d.M - 1;  // a surplus quad repeats the last landmark and stores nothing (DPP needs all lanes)
+  const bool live = i_raw < M;
+  const int i = live ? i_raw : M - 1;  // a surplus quad repeats the last landmark and stores nothing (DPP needs all lanes)
   double X[3] = {d.X[3 * (size_t)i], d.X[3 * (size_t)i + 1], d.X[3 * (size_t)i + 2]};
   const int s0 = d.slot_ptr[i], s1 = d.slot_ptr[i + 1];
   const long long st1 = SBA_TICK();
@@ -1037,6 +1016,67 @@ struct Arena {
 };
 }  // namespace
 
+size_t vo_sba_place_work(SbaDev *d, uint8_t *base, size_t off, size_t M, size_t ns, int No, int max_iter, int n_err) {
+  Arena ar;
+  ar.off = off;
+  const size_t oCinvb = ar.take(sizeof(double) * 3 * (M + 1)), oB = ar.take(sizeof(double) * 3 * (M + 1));
+  const size_t oErr = ar.take(sizeof(double) * (size_t)(n_err + 1));
+  const size_t oBs = ar.take(sizeof(double) * 18 * (ns + 1)), oBCs = ar.take(sizeof(double) * 18 * (ns + 1));
+  const size_t oBCb = ar.take(sizeof(double) * 6 * (ns + 1));
+  const size_t oAp = ar.take(sizeof(double) * 48 * SBA_PG * (size_t)(No + 1));
+  const size_t oS = ar.take(sizeof(double) * 36 * SBA_SG * ((size_t)No * No + 1));
+  const size_t oG = ar.take(sizeof(double) * ((size_t)36 * No * No + 6 * No + 1));
+  const size_t ox = ar.take(sizeof(double) * 6 * (size_t)(No + 1));
+  (void)max_iter;
+  if (base) {
+    d->Cinvb = (double *)(base + oCinvb);
+    d->b = (double *)(base + oB);
+    d->err_part = (double *)(base + oErr);
+    d->n_err = n_err;
+    d->Bs = (double *)(base + oBs);
+    d->BCs = (double *)(base + oBCs);
+    d->BCb = (double *)(base + oBCb);
+    d->Apart = (double *)(base + oAp);
+    d->S = (double *)(base + oS);
+    d->G = (double *)(base + oG);
+    d->x = (double *)(base + ox);
+  }
+  return ar.off;
+}
+
+// three launches per iteration in the steady-state window (four otherwise): [update of the previous iteration +
+// per-landmark linearisation] -> [pose sums + Schur blocks] -> [assembly ->] solve; one last update behind the loop
+int vo_sba_enqueue_iterations(vo_ctx *c, const SbaDev &d, int max_iter) {
+  const int No = d.n_opt, n = 6 * No, n_err = d.n_err;
+  hipStream_t s = c->stream;
+  const size_t lds = sizeof(double) * ((size_t)n * n + 3 * (size_t)n) + sizeof(int) * 2 * (size_t)n + 64;
+  if (lds > 64 * 1024)
+    VO_CHECK_HIP(c, hipFuncSetAttribute((const void *)sba_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const bool t_lds = d.n_frames <= SBA_LDS_FRAMES;
+  auto launch_update_point = [&](int update, int point) {
+    if (t_lds)
+      hipLaunchKernelGGL(sba_update_point_kernel<true>, dim3(n_err), dim3(64), 0, s, d, update, point);
+    else
+      hipLaunchKernelGGL(sba_update_point_kernel<false>, dim3(n_err), dim3(64), 0, s, d, update, point);
+  };
+  static const bool no_reg_solve = getenv("VO_SBA_LDS_SOLVE") != nullptr;  // (A/B switch: the general kernel for every n)
+  const bool reg_solve = n == 42 && !no_reg_solve;  // the steady-state window: 9 keyframes, 7 of them optimised
+  for (int iter = 0; iter < max_iter; ++iter) {
+    launch_update_point(iter > 0 ? 1 : 0, 1);
+    if (No > 0) {
+      hipLaunchKernelGGL(sba_pose_schur_kernel, dim3(No * SBA_PG + (No * (No + 1) / 2) * SBA_SG), dim3(SBA_WG), 0, s, d);
+      if (!reg_solve) hipLaunchKernelGGL(sba_assemble_kernel, dim3((n * n + n + 63) / 64), dim3(64), 0, s, d);
+    }
+    if (reg_solve)  // (assembles the reduced system itself)
+      hipLaunchKernelGGL(sba_solve_reg_kernel<42>, dim3(1), dim3(SBA_SOLVE_WG), 0, s, d, iter);
+    else
+      hipLaunchKernelGGL(sba_solve_kernel, dim3(1), dim3(64), lds, s, d, iter);
+  }
+  if (max_iter > 0) launch_update_point(1, 0);
+  VO_CHECK_HIP(c, hipGetLastError());
+  return VO_OK;
+}
+
 extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, const int32_t *opt_index, double *X,
                             const int32_t *obs_ptr, const int32_t *obs_frame, const uint8_t *obs_right,
                             const double *obs_px, double *avg_err) {
@@ -1114,12 +1154,9 @@ extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, co
   const size_t oFl = ar.take(sizeof(int) * 16), oAvg = ar.take(sizeof(double) * (p->max_iter + 1));
   const size_t in_bytes = ar.off;  // everything up to here comes from the host
   const int n_err = (M + 64 / SBA_LQ - 1) / (64 / SBA_LQ);  // workgroups of the point kernel
-  const size_t oCinvb = ar.take(sizeof(double) * 3 * M), oB = ar.take(sizeof(double) * 3 * M);
-  const size_t oErr = ar.take(sizeof(double) * n_err), oBs = ar.take(sizeof(double) * 18 * (ns + 1)), oBCs = ar.take(sizeof(double) * 18 * (ns + 1));
-  const size_t oBCb = ar.take(sizeof(double) * 6 * (ns + 1));
-  const size_t oAp = ar.take(sizeof(double) * 48 * SBA_PG * (No + 1)), oS = ar.take(sizeof(double) * 36 * SBA_SG * ((size_t)No * No + 1));
-  const size_t oG = ar.take(sizeof(double) * ((size_t)36 * No * No + 6 * No + 1));
-  const size_t ox = ar.take(sizeof(double) * 6 * (No + 1));
+  SbaDev d;
+  memset(&d, 0, sizeof(d));
+  ar.off = vo_sba_place_work(&d, nullptr, ar.off, (size_t)M, (size_t)ns, No, p->max_iter, n_err);
   if (!c->sba) c->sba = new vo_sba_state{nullptr, 0, {0, 0, 0}, nullptr, 0};
   if (c->sba->cap < ar.off) {
     if (c->sba->dev) (void)hipFree(c->sba->dev);
@@ -1206,8 +1243,7 @@ extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, co
   SBA_T(5);
   VO_CHECK_HIP(c, hipMemcpyAsync(base, hs, in_bytes, hipMemcpyHostToDevice, s));
   SBA_T(6);
-  SbaDev d;
-  memset(&d, 0, sizeof(d));
+  vo_sba_place_work(&d, base, in_bytes, (size_t)M, (size_t)ns, No, p->max_iter, n_err);
   d.n_frames = Nf;
   d.n_opt = No;
   d.M = M;
@@ -1248,48 +1284,14 @@ extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, co
   d.pair_ptr = (const int *)(base + oPp);
   d.pair_a = (const int *)(base + oPa);
   d.pair_b = (const int *)(base + oPb);
-  d.Cinvb = (double *)(base + oCinvb);
-  d.b = (double *)(base + oB);
-  d.err_part = (double *)(base + oErr);
-  d.n_err = n_err;
-  d.BCb = (double *)(base + oBCb);
-  d.Bs = (double *)(base + oBs);
-  d.BCs = (double *)(base + oBCs);
-  d.Apart = (double *)(base + oAp);
-  d.S = (double *)(base + oS);
-  d.x = (double *)(base + ox);
-  d.G = (double *)(base + oG);
   d.avg_err = (double *)(base + oAvg);
   d.flags = (int *)(base + oFl);
-  const int n = 6 * No;
-  const size_t lds = sizeof(double) * ((size_t)n * n + 3 * (size_t)n) + sizeof(int) * 2 * (size_t)n + 64;
-  if (lds > 64 * 1024)
-    VO_CHECK_HIP(c, hipFuncSetAttribute((const void *)sba_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   SBA_T(1);
   vo_prof_begin(c, VO_K_AUX);
-  // four launches per iteration: [update of the previous iteration + per-landmark linearisation] -> [pose sums + Schur
-  // blocks] -> assembly -> solve; one last update behind the loop
-  const bool t_lds = Nf <= SBA_LDS_FRAMES;
-  auto launch_update_point = [&](int update, int point) {
-    if (t_lds)
-      hipLaunchKernelGGL(sba_update_point_kernel<true>, dim3(n_err), dim3(64), 0, s, d, update, point);
-    else
-      hipLaunchKernelGGL(sba_update_point_kernel<false>, dim3(n_err), dim3(64), 0, s, d, update, point);
-  };
-  for (int iter = 0; iter < p->max_iter; ++iter) {
-    launch_update_point(iter > 0 ? 1 : 0, 1);
-    static const bool no_reg_solve = getenv("VO_SBA_LDS_SOLVE") != nullptr;  // (A/B switch: the general kernel for every n)
-    const bool reg_solve = n == 42 && !no_reg_solve;  // the steady-state window: 9 keyframes, 7 of them optimised
-    if (No > 0) {
-      hipLaunchKernelGGL(sba_pose_schur_kernel, dim3(No * SBA_PG + (No * (No + 1) / 2) * SBA_SG), dim3(SBA_WG), 0, s, d);
-      if (!reg_solve) hipLaunchKernelGGL(sba_assemble_kernel, dim3((n * n + n + 63) / 64), dim3(64), 0, s, d);
-    }
-    if (reg_solve)  // (assembles the reduced system itself: three launches per iteration)
-      hipLaunchKernelGGL(sba_solve_reg_kernel<42>, dim3(1), dim3(SBA_SOLVE_WG), 0, s, d, iter);
-    else
-      hipLaunchKernelGGL(sba_solve_kernel, dim3(1), dim3(64), lds, s, d, iter);
+  {
+    const int rc_it = vo_sba_enqueue_iterations(c, d, p->max_iter);
+    if (rc_it < 0) return rc_it;
   }
-  if (p->max_iter > 0) launch_update_point(1, 0);
   vo_prof_end(c);
   VO_CHECK_HIP(c, hipGetLastError());
   int flags[16] = {0};  // [0] error bits, [1..3] phase ticks of the solve kernel, [4..] -DSBA_STAMP phase maxima

@@ -35,7 +35,6 @@ int vo_frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, i
                           const float dT_prior[16], const float *pts_new, int n_new, int inputs_on_device,
                           const vo_bin_params *bp, int table, const float *T_pw, const float *T_cw_prior);
 int vo_frame_set_advance(vo_ctx *c, const VoAdvArgs *adv);          // frame_pipeline.hip
-int vo_svo_local_ba(struct vo_svo *s, vo_svo_frame_info *info);  // stereo_vo_lba.hip
 
 #define RC(x)                \
   do {                       \
@@ -259,9 +258,7 @@ extern "C" void vo_svo_destroy(vo_svo *s) {
   if (s->d_acc_bin) (void)hipFree(s->d_acc_bin);
   if (s->d_hdr) (void)hipFree(s->d_hdr);
   if (s->h_hdr) (void)hipHostFree(s->h_hdr);
-  void *pinned[] = {s->h_ids, s->h_pl, s->h_pr, s->h_Xw, s->h_fl};
-  for (void *p : pinned)
-    if (p) (void)hipHostFree(p);
+  vo_svo_lba_free(s);
   delete s;
 }
 
@@ -495,7 +492,7 @@ extern "C" int vo_svo_result(vo_svo *s, vo_svo_frame_info *info) {
     if (s->prm.local_ba) {
       s->cur = nxt;  // (the local BA reads and updates the track set the next frame starts from)
       s->n = h.n_next;
-      rc = vo_svo_local_ba(s, &I);
+      rc = vo_svo_local_ba(s, &I, h.id_min);
       if (rc < 0) return rc;
       memcpy(T_wc, s->keyframes.back().T_wc, sizeof(T_wc));
     }

@@ -6,14 +6,13 @@
 #include "vo_internal.hpp"
 
 // Keyframe-centric storage of what the reference keeps per landmark (getObservationsOnKeyframes / getRelatedKeyframePtr):
-// a keyframe holds its related landmarks' ids and both pixels. The ids of a track set are ASCENDING (survivors keep their
-// order, new landmarks get larger ids and are appended), so the landmark population of a window and every landmark's
-// observation list come out of one merge over the window's keyframes — no per-landmark containers.
+// a keyframe holds its related landmarks' ids and both pixels. The ids of a track set are ASCENDING and dense (survivors
+// keep their order, new landmarks get the next ids and are appended), so every container is a direct-address array.
 struct SvoKeyframe {
   int serial, frame_id;
   float T_wc[16];
-  std::vector<int32_t> ids;   // (filled when the local BA is on)
-  std::vector<float> pl, pr;  // [n][2]
+  // local BA on: the keyframe's related landmarks live in slot `ring` of the device-side keyframe ring (ids, pixels)
+  int ring = 0, n = 0, id_min = 0;  // entries, smallest (= first) landmark id
 };
 
 struct vo_svo {
@@ -38,18 +37,12 @@ struct vo_svo {
   // keyframes
   std::vector<SvoKeyframe> keyframes;  // the window (stereo_kfs_list_)
   int n_keyframes = 0, n_kf_lms = 0;
-  // landmarks that were seen on a keyframe, by id (local BA on): lm->get3DPoint(), isTriangulated() (bit 0), !isAlive() (bit 1)
-  std::vector<float> lmX;
-  std::vector<uint8_t> lmS;
-  // pinned staging of the keyframe's track set (device -> host) and of what the BA changed (host -> device)
-  int32_t *h_ids = nullptr;
-  float *h_pl = nullptr, *h_pr = nullptr, *h_Xw = nullptr;
-  uint8_t *h_fl = nullptr;
-  // the BA problem, rebuilt at every keyframe into the same buffers
-  std::vector<double> ba_X, ba_px, ba_T;
-  std::vector<int32_t> ba_obs_ptr, ba_obs_frame, ba_used, ba_opt;
-  std::vector<uint8_t> ba_obs_right;
+  // local BA on: landmark table, keyframe ring, window scratch and the solver's arena, all on the device (stereo_vo_lba.hip)
+  struct vo_svo_lba *lba = nullptr;
 };
+
+int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info, int id_min);  // stereo_vo_lba.hip
+void vo_svo_lba_free(vo_svo *s);
 
 void svo_mul44(const float A[16], const float B[16], float C[16]);
 void svo_inv_se3(const float T[16], float Ti[16]);

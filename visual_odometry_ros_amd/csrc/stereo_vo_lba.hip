@@ -1,5 +1,5 @@
 // stereo_vo_lba.hip — the local bundle adjustment of a StereoVO keyframe: the landmark / keyframe bookkeeping that
-// SparseBAParameters walks in the reference, around vo_sba_solve (sba.hip).
+// SparseBAParameters walks in the reference, around the solver kernels of sba.hip — RESIDENT ON THE DEVICE.
 //
 // Reference:
 //   core/visual_odometry/stereo_vo/stereo_vo.cpp:802            localBundleAdjustmentSparseSolver_Stereo at every keyframe
@@ -14,15 +14,27 @@
 //                                                               setBundled / setDead (|X| > 3000), "large update!" (> 50 m)
 // The reference iterates an std::unordered_set<LandmarkPtr> (sparse_ba_parameters.h:333): its landmark order depends on heap
 // addresses. Here: ascending landmark id (as oracle/stereo_vo.py).
-// The host part runs at keyframe rate on a few thousand landmarks; everything per observation is on the device (sba.hip).
+//
+// Layout. Landmark ids are dense integers handed out in order (landmark.cpp counter), a track set lists them ascending,
+// and a landmark alive at some frame was alive at every keyframe since its creation — so everything the window can
+// refer to lies in the id interval [first id of the oldest keyframe, next id to hand out). That makes every container of
+// the reference a direct-address array in HBM:
+//   landmark table   X (float3), state (bit 0 triangulated, bit 1 dead), tag (the id), slot = id mod 2^20
+//   keyframe ring    per window keyframe its related landmarks' ids and both pixels (copied from the track set)
+//   window scratch   per id of the interval: bit mask of the window keyframes that saw it, its entry index in each
+// and the BA problem is built by five small launches — mark/copy, scatter, scan (one workgroup), fill (one lane per id),
+// lists (one workgroup per gather list) — straight into the solver's arena; the solver's results go back into the
+// table and the track set by two more. The host sees nine poses, ten error values and three counts per solve. (The
+// first version merged the window's id lists on the host and uploaded 1.6 MB per keyframe: 0.41 ms of host time around
+// 0.64 ms of kernels.)
 #include <math.h>
 #include <stdint.h>
-
-#include <algorithm>
-
 #include <stdlib.h>
 #include <time.h>
 
+#include <algorithm>
+
+#include "sba_device.hpp"
 #include "stereo_vo.hpp"
 
 static double lba_now() {
@@ -30,7 +42,6 @@ static double lba_now() {
   clock_gettime(CLOCK_MONOTONIC, &ts);
   return 1e6 * (double)ts.tv_sec + 1e-3 * (double)ts.tv_nsec;
 }
-#define LBA_T(k)                       do {                                   if (trace) {                           const double now_ = lba_now();       tt[k] += now_ - t_last;              t_last = now_;                     }                                  } while (0)
 
 static void mul44d(const double A[16], const double B[16], double C[16]) {  // Matrix4d * Matrix4d, left to right over k
   double R[16];
@@ -41,13 +52,6 @@ static void mul44d(const double A[16], const double B[16], double C[16]) {  // M
       R[i * 4 + j] = r;
     }
   for (int i = 0; i < 16; ++i) C[i] = R[i];
-}
-static void xformd(const double T[16], const double X[3], double Y[3]) {  // R * X + t, 3-term dot products e0 + (e1 + e2)
-  double r[3];
-  for (int i = 0; i < 3; ++i) r[i] = (T[i * 4 + 0] * X[0] + (T[i * 4 + 1] * X[1] + T[i * 4 + 2] * X[2])) + T[i * 4 + 3];
-  Y[0] = r[0];
-  Y[1] = r[1];
-  Y[2] = r[2];
 }
 static void inv_se3d(const double T[16], double Ti[16]) {  // geometry::inverseSE3
   double Rt[9];
@@ -67,147 +71,580 @@ static void to_d(const float T[16], double D[16]) {
   D[15] = 1.0;
 }
 
-int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info) {
+// ---- device side ------------------------------------------------------------------------------------------------------
+#define LBA_KW 16            // window keyframes at most (bits of the mask that are used, entries per id in q_w)
+#define LBA_TAB_BITS 20      // landmark table: 2^20 slots, circular by id
+#define LBA_SPAN_MAX (1 << 18)  // ids the window may span
+
+struct LmTab {
+  float *X;       // [slots][3] lm->get3DPoint()
+  uint8_t *S;     // [slots] bit 0 isTriangulated(), bit 1 !isAlive()
+  int32_t *tag;   // [slots] the id the slot holds (-1: none)
+  int mask;       // slots - 1
+};
+struct LbaWin {
+  int nk, No, W, base;  // window keyframes, optimised poses, ids spanned, first id
+  int n[LBA_KW];        // related landmarks of window keyframe j
+  const int32_t *ids[LBA_KW];
+  const float *pl[LBA_KW], *pr[LBA_KW];
+  int opt[LBA_KW];      // optimised-pose index of window keyframe j, -1: fixed
+  int optf[LBA_KW];     // window keyframe of optimised pose k
+  int optmask;          // bits of the optimised window keyframes
+};
+struct LbaProb {  // the problem inside the solver's arena (non-const views of SbaDev's lists) + the builder's own arrays
+  double *T, *X, *px;
+  int *opt_index, *opt_frame, *obs_ptr, *obs_frame, *slot_ptr, *slot_j, *slot_bobs, *slot_lm;
+  uint8_t *obs_right;
+  int *pose_obs_ptr, *pose_obs_end, *pose_obs, *pose_lm, *pose_slot_ptr, *pose_slot_end, *pose_slot;
+  int *pair_ptr, *pair_end, *pair_a, *pair_b;
+  int *flags, *dyn;
+  double *avg_err;
+  int32_t *used_id;
+  int *lm_mask;
+  int *mask_w, *q_w, *pre_lm, *pre_kf, *pre_sl;  // window scratch, per id of the interval
+  int pose_obs_stride, pose_slot_stride, pair_stride, max_iter;
+};
+
+// the new keyframe: its related landmarks' state as of now (Landmark::set3DPoint / isTriangulated at keyframe time; a
+// dead landmark stays dead) and the keyframe's own copy of ids and pixels
+__global__ void lba_keyframe_kernel(SvoTrackSet ts, int n, LmTab tab, int32_t *kf_ids, float *kf_pl, float *kf_pr) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int32_t id = ts.ids[k];
+  const int t = id & tab.mask;
+  const uint8_t dead = tab.tag[t] == id ? (uint8_t)(tab.S[t] & 2) : (uint8_t)0;
+  tab.X[3 * (size_t)t] = ts.Xw[3 * k];
+  tab.X[3 * (size_t)t + 1] = ts.Xw[3 * k + 1];
+  tab.X[3 * (size_t)t + 2] = ts.Xw[3 * k + 2];
+  tab.S[t] = (uint8_t)(dead | ((ts.flags[k] & VO_LM_TRIANGULATED) ? 1 : 0));
+  tab.tag[t] = id;
+  kf_ids[k] = id;
+  kf_pl[2 * k] = ts.pts_l[2 * k];
+  kf_pl[2 * k + 1] = ts.pts_l[2 * k + 1];
+  kf_pr[2 * k] = ts.pts_r[2 * k];
+  kf_pr[2 * k + 1] = ts.pts_r[2 * k + 1];
+}
+
+// getObservationsOnKeyframes restricted to the window: which keyframes saw id, and where
+__global__ void lba_scatter_kernel(LbaWin w, int *mask_w, int *q_w) {
+  const int j = blockIdx.y, q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= w.n[j]) return;
+  const int idx = w.ids[j][q] - w.base;
+  if ((unsigned)idx >= (unsigned)w.W) return;
+  atomicOr(&mask_w[idx], 1 << j);
+  q_w[(size_t)idx * LBA_KW + j] = q;
+}
+
+// exclusive scan of one int per thread over a workgroup of 1024 (16 wavefronts); every thread gets the total too
+__device__ __forceinline__ int lba_block_scan(int v, int *s_w, int &total) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(inc, off);
+    if (lane >= off) inc += t;
+  }
+  __syncthreads();  // (s_w may still be read from the previous scan)
+  if (lane == 63) s_w[wave] = inc;
+  __syncthreads();
+  int before = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int c = s_w[k];
+    before += k < wave ? c : 0;
+    tot += c;
+  }
+  total = tot;
+  return before + inc - v;
+}
+
+// ONE workgroup: which ids of the interval enter the problem (triangulated && alive, seen by the window: a stereo
+// keyframe gives two observations, THRES_MINIMUM_SEEN = 2 always holds) and the three running counts that place them —
+// landmark index, observation pairs, slots. Also what the host would have uploaded: poses, index maps, zeroed flags.
+struct LbaHead {
+  double T_jw[16 * LBA_KW];
+};
+__global__ __launch_bounds__(1024) void lba_scan_kernel(LbaWin w, LmTab tab, LbaProb p, LbaHead h) {
+  __shared__ int s_w[16];
+  const int tid = threadIdx.x;
+  for (int k = tid; k < 16 * w.nk; k += 1024) p.T[k] = h.T_jw[k];
+  if (tid < w.nk) p.opt_index[tid] = w.opt[tid];
+  if (tid < w.No) p.opt_frame[tid] = w.optf[tid];
+  if (tid < 16) p.flags[tid] = 0;
+  if (tid <= p.max_iter) p.avg_err[tid] = 0.0;
+  const int chunk = (w.W + 1023) / 1024, i0 = tid * chunk, i1 = min(i0 + chunk, w.W);
+  int c_lm = 0, c_kf = 0, c_sl = 0;
+  for (int idx = i0; idx < i1; ++idx) {
+    int m = p.mask_w[idx];
+    if (m) {
+      const int32_t id = w.base + idx;
+      const int t = id & tab.mask;
+      const uint8_t st = tab.tag[t] == id ? tab.S[t] : (uint8_t)0;
+      if (!((st & 1) && !(st & 2))) {  // isTriangulated() && isAlive()
+        m = 0;
+        p.mask_w[idx] = 0;
+      }
+    }
+    if (m) {
+      ++c_lm;
+      c_kf += __popc(m);
+      c_sl += __popc(m & w.optmask);
+    }
+  }
+  int t_lm, t_kf, t_sl;
+  int o_lm = lba_block_scan(c_lm, s_w, t_lm);
+  int o_kf = lba_block_scan(c_kf, s_w, t_kf);
+  int o_sl = lba_block_scan(c_sl, s_w, t_sl);
+  for (int idx = i0; idx < i1; ++idx) {
+    const int m = p.mask_w[idx];
+    if (!m) continue;
+    p.pre_lm[idx] = o_lm;
+    p.pre_kf[idx] = o_kf;
+    p.pre_sl[idx] = o_sl;
+    ++o_lm;
+    o_kf += __popc(m);
+    o_sl += __popc(m & w.optmask);
+  }
+  if (tid == 0) {
+    p.dyn[0] = t_lm;
+    p.dyn[1] = 2 * t_kf;
+    p.dyn[2] = t_sl;
+    p.obs_ptr[t_lm] = 2 * t_kf;
+    p.slot_ptr[t_lm] = t_sl;
+  }
+}
+
+// one lane per id of the interval: the landmark's row of the problem. Points: warpToRef + scalingPoint in double
+// (sparse_ba_parameters.h:377-398); observations in window order, left then right (keyframes.cpp:200-215)
+struct LbaRef {
+  double Tjw_ref[16], Twj_ref[16], inv_scale, pose_scale;
+};
+__global__ void lba_fill_kernel(LbaWin w, LmTab tab, LbaProb p, LbaRef r) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= w.W) return;
+  const int m = p.mask_w[idx];
+  if (!m) return;
+  const int i = p.pre_lm[idx], kf0 = p.pre_kf[idx], s0 = p.pre_sl[idx];
+  const int32_t id = w.base + idx;
+  const int t = id & tab.mask;
+  p.used_id[i] = id;
+  p.lm_mask[i] = m;
+  const double Xd[3] = {(double)tab.X[3 * (size_t)t], (double)tab.X[3 * (size_t)t + 1], (double)tab.X[3 * (size_t)t + 2]};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double xr = (r.Tjw_ref[k * 4 + 0] * Xd[0] + (r.Tjw_ref[k * 4 + 1] * Xd[1] + r.Tjw_ref[k * 4 + 2] * Xd[2])) + r.Tjw_ref[k * 4 + 3];
+    p.X[3 * (size_t)i + k] = xr * r.inv_scale;
+  }
+  p.obs_ptr[i] = 2 * kf0;
+  p.slot_ptr[i] = s0;
+  int rr = 0, rs = 0;
+  for (int mm = m; mm; mm &= mm - 1) {
+    const int j = __ffs(mm) - 1;
+    const int q = p.q_w[(size_t)idx * LBA_KW + j];
+    const int o = 2 * (kf0 + rr);
+    p.obs_frame[o] = j;
+    p.obs_frame[o + 1] = j;
+    p.obs_right[o] = 0;
+    p.obs_right[o + 1] = 1;
+    p.px[2 * (size_t)o] = (double)w.pl[j][2 * q];
+    p.px[2 * (size_t)o + 1] = (double)w.pl[j][2 * q + 1];
+    p.px[2 * (size_t)o + 2] = (double)w.pr[j][2 * q];
+    p.px[2 * (size_t)o + 3] = (double)w.pr[j][2 * q + 1];
+    if (w.opt[j] >= 0) {  // slot: left observation in an optimised keyframe; its B block is the RIGHT observation's
+      const int s = s0 + rs;  // (the last one of the landmark in that keyframe: :315 / :410 assign)
+      p.slot_j[s] = w.opt[j];
+      p.slot_bobs[s] = o + 1;
+      p.slot_lm[s] = i;
+      ++rs;
+    }
+    ++rr;
+  }
+}
+
+// the solver's gather lists, one workgroup each: workgroups 0 .. No - 1 the observation and slot lists of an optimised
+// pose, the others the landmark pairs of a block (a, b), a <= b — compactions of the landmark sequence, in landmark
+// order like the host builder's (sba.hip)
+__global__ __launch_bounds__(1024) void lba_lists_kernel(LbaWin w, LbaProb p) {
+  __shared__ int s_w[16];
+  const int tid = threadIdx.x, M = p.dyn[0], No = w.No;
+  const int chunk = (M + 1023) / 1024, i0 = tid * chunk, i1 = min(i0 + chunk, M);
+  int u = blockIdx.x;
+  if (u < No) {
+    const int f = w.optf[u], bit = 1 << f;
+    int cnt = 0;
+    for (int i = i0; i < i1; ++i) cnt += (p.lm_mask[i] & bit) ? 1 : 0;
+    int total, off = lba_block_scan(cnt, s_w, total);
+    const int Bo = u * p.pose_obs_stride, Bs = u * p.pose_slot_stride;
+    for (int i = i0; i < i1; ++i) {
+      const int m = p.lm_mask[i];
+      if (!(m & bit)) continue;
+      const int o = p.obs_ptr[i] + 2 * __popc(m & (bit - 1));
+      p.pose_obs[Bo + 2 * off] = o;
+      p.pose_obs[Bo + 2 * off + 1] = o + 1;
+      p.pose_lm[Bo + 2 * off] = i;
+      p.pose_lm[Bo + 2 * off + 1] = i;
+      p.pose_slot[Bs + off] = p.slot_ptr[i] + __popc(m & w.optmask & (bit - 1));
+      ++off;
+    }
+    if (tid == 0) {
+      p.pose_obs_ptr[u] = Bo;
+      p.pose_obs_end[u] = Bo + 2 * total;
+      p.pose_slot_ptr[u] = Bs;
+      p.pose_slot_end[u] = Bs + total;
+    }
+    return;
+  }
+  u -= No;
+  int a = 0;
+  while (u >= No - a) {
+    u -= No - a;
+    ++a;
+  }
+  const int b = a + u, jk = a * No + b;
+  const int ba = 1 << w.optf[a], bb = 1 << w.optf[b], both = ba | bb;
+  int cnt = 0;
+  for (int i = i0; i < i1; ++i) cnt += ((p.lm_mask[i] & both) == both) ? 1 : 0;
+  int total, off = lba_block_scan(cnt, s_w, total);
+  const int Bp = jk * p.pair_stride;
+  for (int i = i0; i < i1; ++i) {
+    const int m = p.lm_mask[i];
+    if ((m & both) != both) continue;
+    const int sp = p.slot_ptr[i];
+    p.pair_a[Bp + off] = sp + __popc(m & w.optmask & (ba - 1));
+    p.pair_b[Bp + off] = sp + __popc(m & w.optmask & (bb - 1));
+    ++off;
+  }
+  if (tid == 0) {
+    p.pair_ptr[jk] = Bp;
+    p.pair_end[jk] = Bp + total;
+  }
+}
+
+// points back (sparse_bundle_adjustment.cpp:690-722): recoverOriginalScalePoint, warpToWorld, set3DPoint, setDead
+__global__ void lba_writeback_kernel(LbaProb p, LmTab tab, LbaRef r) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.dyn[0]) return;
+  const double xs[3] = {p.X[3 * (size_t)i] * r.pose_scale, p.X[3 * (size_t)i + 1] * r.pose_scale, p.X[3 * (size_t)i + 2] * r.pose_scale};
+  float L[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    L[k] = (float)((r.Twj_ref[k * 4 + 0] * xs[0] + (r.Twj_ref[k * 4 + 1] * xs[1] + r.Twj_ref[k * 4 + 2] * xs[2])) + r.Twj_ref[k * 4 + 3]);
+  const int t = p.used_id[i] & tab.mask;
+  tab.X[3 * (size_t)t] = L[0];
+  tab.X[3 * (size_t)t + 1] = L[1];
+  tab.X[3 * (size_t)t + 2] = L[2];
+  uint8_t st = (uint8_t)(tab.S[t] | 1);
+  const float nrm = sqrtf(L[0] * L[0] + (L[1] * L[1] + L[2] * L[2]));
+  if (!(nrm <= 3000)) st |= 2;
+  tab.S[t] = st;
+}
+// what the BA did to the landmarks the next frame tracks
+__global__ void lba_refresh_kernel(SvoTrackSet ts, int n, LmTab tab) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int t = ts.ids[k] & tab.mask;
+  ts.Xw[3 * k] = tab.X[3 * (size_t)t];
+  ts.Xw[3 * k + 1] = tab.X[3 * (size_t)t + 1];
+  ts.Xw[3 * k + 2] = tab.X[3 * (size_t)t + 2];
+  uint8_t fl = ts.flags[k];
+  const uint8_t st = tab.S[t];
+  if (st & 1) fl |= VO_LM_TRIANGULATED;
+  if (st & 2) fl |= VO_LM_DROPPED;
+  ts.flags[k] = fl;
+}
+
+// ---- host side --------------------------------------------------------------------------------------------------------
+struct vo_svo_lba {
+  LmTab tab = {};
+  int32_t *kf_ids[LBA_KW] = {};
+  float *kf_pl[LBA_KW] = {}, *kf_pr[LBA_KW] = {};
+  int *mask_w = nullptr, *q_w = nullptr, *pre = nullptr;  // window scratch
+  uint8_t *arena = nullptr;
+  size_t arena_cap = 0;
+  uint8_t *h_res = nullptr;  // pinned: poses, errors, flags, counts of a solve
+};
+
+void vo_svo_lba_free(vo_svo *s) {
+  vo_svo_lba *L = s->lba;
+  if (!L) return;
+  void *dev[] = {L->tab.X, L->tab.S, L->tab.tag, L->mask_w, L->q_w, L->pre, L->arena};
+  for (void *p : dev)
+    if (p) (void)hipFree(p);
+  for (int k = 0; k < LBA_KW; ++k) {
+    if (L->kf_ids[k]) (void)hipFree(L->kf_ids[k]);
+    if (L->kf_pl[k]) (void)hipFree(L->kf_pl[k]);
+    if (L->kf_pr[k]) (void)hipFree(L->kf_pr[k]);
+  }
+  if (L->h_res) (void)hipHostFree(L->h_res);
+  delete L;
+  s->lba = nullptr;
+}
+
+static int lba_init(vo_svo *s) {
+  vo_ctx *c = s->c;
+  if (s->prm.kf_window > LBA_KW) VO_FAIL(c, VO_ERR_CAPACITY, "local BA: keyframe window of %d (at most %d)", s->prm.kf_window, LBA_KW);
+  vo_svo_lba *L = new vo_svo_lba();
+  s->lba = L;
+  const size_t slots = (size_t)1 << LBA_TAB_BITS;
+  L->tab.mask = (int)(slots - 1);
+  VO_CHECK_HIP(c, hipMalloc((void **)&L->tab.X, sizeof(float) * 3 * slots));
+  VO_CHECK_HIP(c, hipMalloc((void **)&L->tab.S, slots));
+  VO_CHECK_HIP(c, hipMalloc((void **)&L->tab.tag, sizeof(int32_t) * slots));
+  VO_CHECK_HIP(c, hipMemsetAsync(L->tab.tag, 0xFF, sizeof(int32_t) * slots, c->stream));
+  VO_CHECK_HIP(c, hipMemsetAsync(L->tab.S, 0, slots, c->stream));
+  for (int k = 0; k < s->prm.kf_window; ++k) {
+    VO_CHECK_HIP(c, hipMalloc((void **)&L->kf_ids[k], sizeof(int32_t) * (size_t)s->cap));
+    VO_CHECK_HIP(c, hipMalloc((void **)&L->kf_pl[k], sizeof(float) * 2 * (size_t)s->cap));
+    VO_CHECK_HIP(c, hipMalloc((void **)&L->kf_pr[k], sizeof(float) * 2 * (size_t)s->cap));
+  }
+  VO_CHECK_HIP(c, hipMalloc((void **)&L->mask_w, sizeof(int) * (size_t)LBA_SPAN_MAX));
+  VO_CHECK_HIP(c, hipMalloc((void **)&L->q_w, sizeof(int) * (size_t)LBA_SPAN_MAX * LBA_KW));
+  VO_CHECK_HIP(c, hipMalloc((void **)&L->pre, sizeof(int) * (size_t)LBA_SPAN_MAX * 3));
+  VO_CHECK_HIP(c, hipHostMalloc((void **)&L->h_res, 4096, hipHostMallocDefault));
+  return VO_OK;
+}
+
+namespace {
+struct Arena {
+  size_t off = 0;
+  size_t take(size_t bytes) {
+    const size_t o = off;
+    off += (bytes + 255) & ~(size_t)255;
+    return o;
+  }
+};
+}  // namespace
+
+int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info, int id_min) {
   vo_ctx *c = s->c;
   const int n = s->n;
   SvoTrackSet &t = s->ts[s->cur];
   static const bool trace = getenv("VO_SVO_TRACE") != nullptr;
-  static double tt[8];
+  static double tt[4];
   static int n_calls;
-  double t_last = trace ? lba_now() : 0.0;
+  const double t_0 = trace ? lba_now() : 0.0;
   hipStream_t st = c->stream;
-  // ---- the new keyframe's related landmarks, after the reconstruction kernel (main stream), through pinned memory ----
-  if (!s->h_ids) {
-    const size_t cap = (size_t)s->cap;
-    VO_CHECK_HIP(c, hipHostMalloc((void **)&s->h_ids, sizeof(int32_t) * cap, hipHostMallocDefault));
-    VO_CHECK_HIP(c, hipHostMalloc((void **)&s->h_pl, sizeof(float) * 2 * cap, hipHostMallocDefault));
-    VO_CHECK_HIP(c, hipHostMalloc((void **)&s->h_pr, sizeof(float) * 2 * cap, hipHostMallocDefault));
-    VO_CHECK_HIP(c, hipHostMalloc((void **)&s->h_Xw, sizeof(float) * 3 * cap, hipHostMallocDefault));
-    VO_CHECK_HIP(c, hipHostMalloc((void **)&s->h_fl, cap, hipHostMallocDefault));
+  if (!s->lba) {
+    const int rc = lba_init(s);
+    if (rc < 0) return rc;
   }
-  int32_t *ids = s->h_ids;
-  float *pl = s->h_pl, *pr = s->h_pr, *Xw = s->h_Xw;
-  uint8_t *fl = s->h_fl;
-  if (n > 0) {
-    VO_CHECK_HIP(c, hipMemcpyAsync(ids, t.ids, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
-    VO_CHECK_HIP(c, hipMemcpyAsync(pl, t.pts_l, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, st));
-    VO_CHECK_HIP(c, hipMemcpyAsync(pr, t.pts_r, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, st));
-    VO_CHECK_HIP(c, hipMemcpyAsync(Xw, t.Xw, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, st));
-    VO_CHECK_HIP(c, hipMemcpyAsync(fl, t.flags, (size_t)n, hipMemcpyDeviceToHost, st));
-    VO_CHECK_HIP(c, hipStreamSynchronize(st));
-  }
-  LBA_T(0);
-  SvoKeyframe &kf = s->keyframes.back();
-  kf.ids.assign(ids, ids + n);
-  kf.pl.assign(pl, pl + 2 * (size_t)n);
-  kf.pr.assign(pr, pr + 2 * (size_t)n);
-  if (n > 0 && (size_t)ids[n - 1] >= s->lmS.size()) {  // (ids ascend: the last one is the largest)
-    const size_t want = (size_t)ids[n - 1] + 1 + 8192;
-    s->lmX.resize(3 * want, 0.0f);
-    s->lmS.resize(want, 0);
-  }
-  for (int k = 0; k < n; ++k) {  // the landmarks' state as of this keyframe
-    const size_t id = (size_t)ids[k];
-    s->lmX[3 * id] = Xw[3 * k];
-    s->lmX[3 * id + 1] = Xw[3 * k + 1];
-    s->lmX[3 * id + 2] = Xw[3 * k + 2];
-    s->lmS[id] = (uint8_t)((s->lmS[id] & 2) | ((fl[k] & VO_LM_TRIANGULATED) ? 1 : 0));
-  }
-  LBA_T(1);
+  vo_svo_lba *L = s->lba;
   std::vector<SvoKeyframe> &win = s->keyframes;
   const int nk = (int)win.size();
+  // ---- the new keyframe's related landmarks (behind the reconstruction kernel on the main stream) ----
+  SvoKeyframe &kf = win.back();
+  {
+    unsigned used = 0;
+    for (int j = 0; j + 1 < nk; ++j) used |= 1u << win[j].ring;
+    int r = 0;
+    while (used & (1u << r)) ++r;
+    kf.ring = r;
+    kf.n = n;
+    kf.id_min = id_min;
+  }
+  if (n > 0) {
+    hipLaunchKernelGGL(lba_keyframe_kernel, dim3((n + 255) / 256), dim3(256), 0, st, t, n, L->tab, L->kf_ids[kf.ring], L->kf_pl[kf.ring],
+                       L->kf_pr[kf.ring]);
+    VO_CHECK_HIP(c, hipGetLastError());
+  }
   if (nk < 3) return VO_OK;  // NUM_MINIMUM_REQUIRED_KEYFRAMES (motion_estimator.cpp:1245-1253)
   const double POSE_SCALE = 10.0, inv_scale = 1.0 / POSE_SCALE;
-  // ---- SparseBAParameters::setPosesAndPoints: one merge over the window's (ascending) id lists ----
-  double Twj_ref[16], Tjw_ref[16];
-  to_d(win.front().T_wc, Twj_ref);
-  inv_se3d(Twj_ref, Tjw_ref);
-  std::vector<double> &X = s->ba_X, &px = s->ba_px, &T_jw = s->ba_T;
-  std::vector<int32_t> &obs_ptr = s->ba_obs_ptr, &obs_frame = s->ba_obs_frame, &used = s->ba_used, &opt = s->ba_opt;
-  std::vector<uint8_t> &obs_right = s->ba_obs_right;
-  X.clear();
-  px.clear();
-  obs_ptr.assign(1, 0);
-  obs_frame.clear();
-  obs_right.clear();
-  used.clear();
-  size_t cur[32] = {0};
-  if (nk > 32) VO_FAIL(c, VO_ERR_CAPACITY, "keyframe window of %d", nk);
-  for (;;) {
-    int32_t id = INT32_MAX;
-    for (int j = 0; j < nk; ++j)
-      if (cur[j] < win[j].ids.size() && win[j].ids[cur[j]] < id) id = win[j].ids[cur[j]];
-    if (id == INT32_MAX) break;
-    const bool take = (s->lmS[id] & 1) && !(s->lmS[id] & 2);  // isTriangulated() && isAlive()
-    bool any = false;
-    for (int j = 0; j < nk; ++j) {
-      if (!(cur[j] < win[j].ids.size() && win[j].ids[cur[j]] == id)) continue;
-      const size_t q = cur[j]++;
-      if (!take) continue;
-      any = true;  // (a stereo keyframe gives two observations: THRES_MINIMUM_SEEN = 2 always holds)
-      obs_frame.push_back(j);
-      obs_frame.push_back(j);
-      obs_right.push_back(0);
-      obs_right.push_back(1);
-      px.push_back((double)win[j].pl[2 * q]);
-      px.push_back((double)win[j].pl[2 * q + 1]);
-      px.push_back((double)win[j].pr[2 * q]);
-      px.push_back((double)win[j].pr[2 * q + 1]);
+  // ---- the window ----
+  LbaWin w;
+  memset(&w, 0, sizeof(w));
+  w.nk = nk;
+  w.No = nk - 2;  // NUM_FIX_KEYFRAMES_IN_WINDOW
+  w.base = win.front().id_min;
+  const long long span = (long long)c->next_landmark_id - (long long)w.base;
+  if (span > LBA_SPAN_MAX) VO_FAIL(c, VO_ERR_CAPACITY, "local BA: the window spans %lld landmark ids (at most %d)", span, LBA_SPAN_MAX);
+  w.W = (int)span;
+  size_t E = 0, E_opt = 0;
+  int maxn = 1;
+  for (int j = 0; j < nk; ++j) {
+    w.n[j] = win[j].n;
+    w.ids[j] = L->kf_ids[win[j].ring];
+    w.pl[j] = L->kf_pl[win[j].ring];
+    w.pr[j] = L->kf_pr[win[j].ring];
+    w.opt[j] = j < 2 ? -1 : j - 2;
+    if (j >= 2) {
+      w.optf[j - 2] = j;
+      w.optmask |= 1 << j;
+      E_opt += (size_t)win[j].n;
     }
-    if (!any) continue;
-    const double Xd[3] = {(double)s->lmX[3 * (size_t)id], (double)s->lmX[3 * (size_t)id + 1], (double)s->lmX[3 * (size_t)id + 2]};
-    double Xr[3];
-    xformd(Tjw_ref, Xd, Xr);  // warpToRef
-    for (int k = 0; k < 3; ++k) X.push_back(Xr[k] * inv_scale);  // scalingPoint
-    obs_ptr.push_back((int32_t)obs_frame.size());
-    used.push_back(id);
+    E += (size_t)win[j].n;
+    maxn = std::max(maxn, win[j].n);
   }
-  if (used.empty()) return VO_OK;
-  T_jw.resize(16 * (size_t)nk);
-  opt.resize(nk);
+  if (w.W <= 0 || E == 0) return VO_OK;
+  const int No = w.No, max_iter = 10;
+  const size_t M_ub = std::min((size_t)w.W, E), nobs_ub = 2 * E, ns_ub = E_opt;
+  const int n_err = (int)((M_ub + 64 / SBA_LQ - 1) / (64 / SBA_LQ));
+  // ---- the solver's arena ----
+  Arena ar;
+  // (what the host reads back is one piece: poses | errors | flags | counts)
+  const size_t res_bytes = sizeof(double) * (16 * LBA_KW + 16) + sizeof(int) * (16 + 4);
+  const size_t oT = ar.take(res_bytes), oAvg = oT + sizeof(double) * 16 * LBA_KW, oFl = oAvg + sizeof(double) * 16, oDyn = oFl + sizeof(int) * 16;
+  const size_t oOpt = ar.take(sizeof(int) * nk), oOfr = ar.take(sizeof(int) * (No + 1));
+  const size_t oX = ar.take(sizeof(double) * 3 * (M_ub + 1)), oOp = ar.take(sizeof(int) * (M_ub + 1));
+  const size_t oOf = ar.take(sizeof(int) * (nobs_ub + 2)), oOr = ar.take(nobs_ub + 2), oPx = ar.take(sizeof(double) * 2 * (nobs_ub + 2));
+  const size_t oSp = ar.take(sizeof(int) * (M_ub + 1)), oSj = ar.take(sizeof(int) * (ns_ub + 1)), oSb = ar.take(sizeof(int) * (ns_ub + 1));
+  const size_t oSl = ar.take(sizeof(int) * (ns_ub + 1));
+  const size_t oPop = ar.take(sizeof(int) * 2 * (No + 1)), oPo = ar.take(sizeof(int) * 2 * (size_t)maxn * No);
+  const size_t oPl = ar.take(sizeof(int) * 2 * (size_t)maxn * No);
+  const size_t oPsp = ar.take(sizeof(int) * 2 * (No + 1)), oPs = ar.take(sizeof(int) * (size_t)maxn * No);
+  const size_t oPp = ar.take(sizeof(int) * 2 * ((size_t)No * No + 1)), oPa = ar.take(sizeof(int) * (size_t)maxn * No * No);
+  const size_t oPb = ar.take(sizeof(int) * (size_t)maxn * No * No);
+  const size_t oUid = ar.take(sizeof(int32_t) * (M_ub + 1)), oLm = ar.take(sizeof(int) * (M_ub + 1));
+  SbaDev d;
+  memset(&d, 0, sizeof(d));
+  const size_t in_end = ar.off;
+  ar.off = vo_sba_place_work(&d, nullptr, in_end, M_ub, ns_ub, No, max_iter, n_err);
+  if (L->arena_cap < ar.off) {
+    VO_CHECK_HIP(c, hipStreamSynchronize(st));
+    if (L->arena) (void)hipFree(L->arena);
+    L->arena = nullptr;
+    L->arena_cap = 0;
+    VO_CHECK_HIP(c, hipMalloc((void **)&L->arena, ar.off + (ar.off >> 1)));
+    L->arena_cap = ar.off + (ar.off >> 1);
+  }
+  uint8_t *base = L->arena;
+  vo_sba_place_work(&d, base, in_end, M_ub, ns_ub, No, max_iter, n_err);
+  LbaProb p;
+  memset(&p, 0, sizeof(p));
+  p.T = (double *)(base + oT);
+  p.opt_index = (int *)(base + oOpt);
+  p.opt_frame = (int *)(base + oOfr);
+  p.X = (double *)(base + oX);
+  p.obs_ptr = (int *)(base + oOp);
+  p.obs_frame = (int *)(base + oOf);
+  p.obs_right = base + oOr;
+  p.px = (double *)(base + oPx);
+  p.slot_ptr = (int *)(base + oSp);
+  p.slot_j = (int *)(base + oSj);
+  p.slot_bobs = (int *)(base + oSb);
+  p.slot_lm = (int *)(base + oSl);
+  p.pose_obs_ptr = (int *)(base + oPop);
+  p.pose_obs_end = p.pose_obs_ptr + (No + 1);
+  p.pose_obs = (int *)(base + oPo);
+  p.pose_lm = (int *)(base + oPl);
+  p.pose_slot_ptr = (int *)(base + oPsp);
+  p.pose_slot_end = p.pose_slot_ptr + (No + 1);
+  p.pose_slot = (int *)(base + oPs);
+  p.pair_ptr = (int *)(base + oPp);
+  p.pair_end = p.pair_ptr + ((size_t)No * No + 1);
+  p.pair_a = (int *)(base + oPa);
+  p.pair_b = (int *)(base + oPb);
+  p.flags = (int *)(base + oFl);
+  p.avg_err = (double *)(base + oAvg);
+  p.dyn = (int *)(base + oDyn);
+  p.used_id = (int32_t *)(base + oUid);
+  p.lm_mask = (int *)(base + oLm);
+  p.mask_w = L->mask_w;
+  p.q_w = L->q_w;
+  p.pre_lm = L->pre;
+  p.pre_kf = L->pre + LBA_SPAN_MAX;
+  p.pre_sl = L->pre + 2 * (size_t)LBA_SPAN_MAX;
+  p.pose_obs_stride = 2 * maxn;
+  p.pose_slot_stride = maxn;
+  p.pair_stride = maxn;
+  p.max_iter = max_iter;
+  // ---- poses: reference frame = first keyframe of the window (sparse_ba_parameters.h:340-375) ----
+  LbaRef ref;
+  LbaHead head;
+  memset(&head, 0, sizeof(head));
+  to_d(win.front().T_wc, ref.Twj_ref);
+  inv_se3d(ref.Twj_ref, ref.Tjw_ref);
+  ref.inv_scale = inv_scale;
+  ref.pose_scale = POSE_SCALE;
   for (int j = 0; j < nk; ++j) {
     float Tjw_f[16];
     double Tjw[16];
     svo_inv_se3(win[j].T_wc, Tjw_f);  // getPoseInv()
     to_d(Tjw_f, Tjw);
-    mul44d(Tjw, Twj_ref, &T_jw[16 * j]);  // changeInvPoseWorldToRef
-    for (int r = 0; r < 3; ++r) T_jw[16 * j + r * 4 + 3] *= inv_scale;  // scalingPose
-    opt[j] = j < 2 ? -1 : j - 2;  // NUM_FIX_KEYFRAMES_IN_WINDOW
+    mul44d(Tjw, ref.Twj_ref, &head.T_jw[16 * j]);  // changeInvPoseWorldToRef
+    for (int r = 0; r < 3; ++r) head.T_jw[16 * j + r * 4 + 3] *= inv_scale;  // scalingPose
   }
-  vo_sba_problem p;
-  memset(&p, 0, sizeof(p));
-  p.n_frames = nk;
-  p.n_opt = nk - 2;
-  p.n_points = (int)used.size();
-  p.n_obs = (int)obs_frame.size();
-  p.stereo = 1;
-  p.max_iter = 10;
-  p.thres_huber = 0.5;
+  // ---- build + solve, all on the main stream ----
+  VO_CHECK_HIP(c, hipMemsetAsync(L->mask_w, 0, sizeof(int) * (size_t)w.W, st));
+  hipLaunchKernelGGL(lba_scatter_kernel, dim3((maxn + 255) / 256, nk), dim3(256), 0, st, w, L->mask_w, L->q_w);
+  hipLaunchKernelGGL(lba_scan_kernel, dim3(1), dim3(1024), 0, st, w, L->tab, p, head);
+  hipLaunchKernelGGL(lba_fill_kernel, dim3((w.W + 255) / 256), dim3(256), 0, st, w, L->tab, p, ref);
+  hipLaunchKernelGGL(lba_lists_kernel, dim3(No + No * (No + 1) / 2), dim3(1024), 0, st, w, p);
+  VO_CHECK_HIP(c, hipGetLastError());
+  d.n_frames = nk;
+  d.n_opt = No;
+  d.stereo = 1;
+  d.max_iter = max_iter;
+  d.dyn = p.dyn;
   for (int k = 0; k < 4; ++k) {
-    p.Kl[k] = (double)s->prm.frame.Kl[k];
-    p.Kr[k] = (double)s->prm.frame.Kr[k];
+    d.Kl[k] = (double)s->prm.frame.Kl[k];
+    d.Kr[k] = (double)s->prm.frame.Kr[k];
   }
-  to_d(s->prm.frame.T_lr, p.T_lr);
-  for (int r = 0; r < 3; ++r) p.T_lr[r * 4 + 3] *= inv_scale;  // scalingPose(T_stereo_)
-  double err[16] = {0};
-  LBA_T(2);
-  int rc = vo_sba_solve(c, &p, T_jw.data(), opt.data(), X.data(), obs_ptr.data(), obs_frame.data(), obs_right.data(), px.data(), err);
-  if (rc < 0) return rc;
-  LBA_T(3);
+  {  // geometry::inverseSE3(T_lr) of the scaled stereo pose (sba.hip: vo_sba_solve)
+    double T_lr[16];
+    to_d(s->prm.frame.T_lr, T_lr);
+    for (int r = 0; r < 3; ++r) T_lr[r * 4 + 3] *= inv_scale;  // scalingPose(T_stereo_)
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) d.R_rl[i * 3 + j] = T_lr[j * 4 + i];
+    for (int i = 0; i < 3; ++i)
+      d.t_rl[i] = (-d.R_rl[i * 3]) * T_lr[3] + ((-d.R_rl[i * 3 + 1]) * T_lr[7] + (-d.R_rl[i * 3 + 2]) * T_lr[11]);
+  }
+  d.thres_huber = 0.5;
+  d.lambda = 0.00001;
+  d.T = p.T;
+  d.opt_index = p.opt_index;
+  d.opt_frame = p.opt_frame;
+  d.X = p.X;
+  d.obs_ptr = p.obs_ptr;
+  d.obs_frame = p.obs_frame;
+  d.obs_right = p.obs_right;
+  d.obs_px = p.px;
+  d.slot_ptr = p.slot_ptr;
+  d.slot_j = p.slot_j;
+  d.slot_bobs = p.slot_bobs;
+  d.slot_lm = p.slot_lm;
+  d.pose_obs_ptr = p.pose_obs_ptr;
+  d.pose_obs_end = p.pose_obs_end;
+  d.pose_obs = p.pose_obs;
+  d.pose_lm = p.pose_lm;
+  d.pose_slot_ptr = p.pose_slot_ptr;
+  d.pose_slot_end = p.pose_slot_end;
+  d.pose_slot = p.pose_slot;
+  d.pair_ptr = p.pair_ptr;
+  d.pair_end = p.pair_end;
+  d.pair_a = p.pair_a;
+  d.pair_b = p.pair_b;
+  d.avg_err = p.avg_err;
+  d.flags = p.flags;
+  vo_prof_begin(c, VO_K_AUX);
+  {
+    const int rc = vo_sba_enqueue_iterations(c, d, max_iter);
+    if (rc < 0) return rc;
+  }
+  vo_prof_end(c);
+  // ---- what the host needs: poses, errors, flags, counts ----
+  double *o_T = (double *)L->h_res, *o_e = o_T + 16 * LBA_KW;
+  int *o_f = (int *)(o_e + 16), *o_d = o_f + 16;
+  VO_CHECK_HIP(c, hipMemcpyAsync(o_T, p.T, res_bytes, hipMemcpyDeviceToHost, st));
+  const double t_1 = trace ? lba_now() : 0.0;
+  VO_CHECK_HIP(c, hipStreamSynchronize(st));
+  const double t_2 = trace ? lba_now() : 0.0;
+  if (o_d[0] <= 0) return VO_OK;  // no landmark qualifies: nothing to adjust
+  if (o_f[0] & 1) VO_FAIL(c, VO_ERR_LBA_NAN, "In LBA, pose becomes nan!");
+  if (o_f[0] & 2) VO_FAIL(c, VO_ERR_LBA_NAN, "Local BA NAN!");
   if (info) {
     info->lba_ran = 1;
-    info->lba_err_first = err[0];
-    info->lba_err_last = err[p.max_iter - 1];
-    info->lba_landmarks = p.n_points;
-    info->lba_observations = p.n_obs;
+    info->lba_err_first = o_e[0];
+    info->lba_err_last = o_e[max_iter - 1];
+    info->lba_landmarks = o_d[0];
+    info->lba_observations = o_d[1];
   }
-  // ---- sparse_bundle_adjustment.cpp:624-722: poses and points back ----
+  // ---- sparse_bundle_adjustment.cpp:624-688: poses back ----
   for (int j = 0; j < nk; ++j) {
-    if (opt[j] < 0) continue;
+    if (w.opt[j] < 0) continue;
     double T[16], Tjw[16], Twj_orig[16], dT[16];
-    for (int k = 0; k < 16; ++k) T[k] = T_jw[16 * j + k];
+    for (int k = 0; k < 16; ++k) T[k] = o_T[16 * j + k];
     for (int r = 0; r < 3; ++r) T[r * 4 + 3] *= POSE_SCALE;  // recoverOriginalScalePose
-    mul44d(T, Tjw_ref, Tjw);                                 // changeInvPoseRefToWorld
+    mul44d(T, ref.Tjw_ref, Tjw);                             // changeInvPoseRefToWorld
     to_d(win[j].T_wc, Twj_orig);
     mul44d(Twj_orig, Tjw, dT);
     const double tn = sqrt(dT[3] * dT[3] + (dT[7] * dT[7] + dT[11] * dT[11]));
@@ -218,35 +655,18 @@ int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info) {
     Tf[15] = 1.0f;
     svo_inv_se3(Tf, win[j].T_wc);  // kf->setPose(inverseSE3_f(Tjw_update_float))
   }
-  for (size_t i = 0; i < used.size(); ++i) {
-    double xs[3] = {X[3 * i] * POSE_SCALE, X[3 * i + 1] * POSE_SCALE, X[3 * i + 2] * POSE_SCALE}, xw[3];
-    xformd(Twj_ref, xs, xw);  // warpToWorld
-    const size_t id = (size_t)used[i];
-    float *L = &s->lmX[3 * id];
-    L[0] = (float)xw[0];
-    L[1] = (float)xw[1];
-    L[2] = (float)xw[2];
-    s->lmS[id] |= 1;  // set3DPoint
-    const float nrm = sqrtf(L[0] * L[0] + (L[1] * L[1] + L[2] * L[2]));
-    if (!(nrm <= 3000)) s->lmS[id] |= 2;  // setDead
+  // ---- points back into the table, and into the track set the next frame starts from (stream-ordered in front of it) ----
+  hipLaunchKernelGGL(lba_writeback_kernel, dim3((unsigned)((M_ub + 255) / 256)), dim3(256), 0, st, p, L->tab, ref);
+  if (n > 0) hipLaunchKernelGGL(lba_refresh_kernel, dim3((n + 255) / 256), dim3(256), 0, st, t, n, L->tab);
+  VO_CHECK_HIP(c, hipGetLastError());
+  if (trace) {
+    const double t_3 = lba_now();
+    tt[0] += t_1 - t_0;
+    tt[1] += t_2 - t_1;
+    tt[2] += t_3 - t_2;
+    if ((++n_calls % 10) == 0)
+      fprintf(stderr, "[lba] per call (us): host build + enqueue %.0f  device (build + solve) %.0f  write-back %.0f  (M=%d obs=%d slots=%d, span %d)\n",
+              tt[0] / n_calls, tt[1] / n_calls, tt[2] / n_calls, o_d[0], o_d[1], o_d[2], w.W);
   }
-  LBA_T(4);
-  // ---- what the BA did to the landmarks the next frame tracks (the pinned staging arrays go back up) ----
-  for (int k = 0; k < n; ++k) {
-    const size_t id = (size_t)ids[k];
-    Xw[3 * k] = s->lmX[3 * id];
-    Xw[3 * k + 1] = s->lmX[3 * id + 1];
-    Xw[3 * k + 2] = s->lmX[3 * id + 2];
-    if (s->lmS[id] & 1) fl[k] |= VO_LM_TRIANGULATED;
-    if (s->lmS[id] & 2) fl[k] |= VO_LM_DROPPED;
-  }
-  if (n > 0) {  // (stream-ordered in front of the next frame; the staging arrays are next written behind a synchronisation)
-    VO_CHECK_HIP(c, hipMemcpyAsync(t.Xw, Xw, sizeof(float) * 3 * n, hipMemcpyHostToDevice, st));
-    VO_CHECK_HIP(c, hipMemcpyAsync(t.flags, fl, (size_t)n, hipMemcpyHostToDevice, st));
-  }
-  LBA_T(5);
-  if (trace && (++n_calls % 10) == 0)
-    fprintf(stderr, "[lba] per call (us): d2h %.0f  db %.0f  problem %.0f  solve %.0f  finish %.0f  h2d %.0f  (M=%d obs=%d)\n",
-            tt[0] / n_calls, tt[1] / n_calls, tt[2] / n_calls, tt[3] / n_calls, tt[4] / n_calls, tt[5] / n_calls, p.n_points, p.n_obs);
   return VO_OK;
 }

@@ -20,7 +20,7 @@ struct SvoTrackSet {  // device: stframe->getPtsSeen() (left / right) + related 
 struct SvoHdr {  // written by the BA launch's epilogue (gn_pose.hip): device copy and pinned host copy
   int n_surv, n_kf_tracked, n_new, n_next, n_emit, overflow;
   int seq;       // host copy: written last
-  int pad;
+  int id_min;    // first (= smallest) landmark id of the next track set
 };
 
 
