@@ -848,7 +848,7 @@ def cpu_baseline_loop(cfg, args, st, imgs, traj, V, local_rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed frames (default 400; 60 for --config 4, whose 4K stream is rendered first)")
+    ap.add_argument("--steps", type=int, default=None, help="timed frames (default 400; 40 for --config 4, whose 4K stream is rendered first)")
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="BASELINE.json configs[i]")
     ap.add_argument("--frames", type=int, default=12, help="distinct rendered frames (played back and forth)")
@@ -858,8 +858,10 @@ def main():
                          "stream-ordered behind the frame kernel, 2 sequential replay, 3 replay next to the frame kernel, "
                          "5 stream-ordered replay behind a gate on the replay stream, 4 (default) 1 or 3 per frame, by the "
                          "previous frame's number of replayed features")
-    ap.add_argument("--mode", default="loop", choices=("loop", "closed", "sequential", "open"),
-                    help="loop (default): closed-loop StereoVO on a forward-driving stream; closed / sequential / open: round 2's "
+    ap.add_argument("--mode", default=None, choices=("loop", "closed", "sequential", "open"),
+                    help="loop (default for --config 1): closed-loop StereoVO on a forward-driving stream; closed (default for "
+                         "--config 4: 8000 ground-truth features per frame — the synthetic 4K stream keeps only ~3000 tracks "
+                         "alive in the loop) / sequential / open: round 2's "
                          "frame operator on ground-truth track sets, differing in how step [10] is driven; see the docstring")
     ap.add_argument("--lba", type=int, default=1, help="loop mode: local bundle adjustment at keyframes (the reference's behaviour)")
     ap.add_argument("--no-prefetch", action="store_true",
@@ -877,8 +879,10 @@ def main():
     ap.add_argument("--rendezvous-check", action="store_true",
                     help="run only the multi-rank control flow (gloo, no GPU work) and print its JSON line")
     args = ap.parse_args()
+    if args.mode is None:
+        args.mode = "closed" if args.config == 4 else "loop"
     if args.steps is None:
-        args.steps = 60 if args.config == 4 else 400
+        args.steps = 40 if (args.config == 4 and args.mode == "loop") else 400
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))  # nothing GPU-related has been imported yet

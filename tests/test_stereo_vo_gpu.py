@@ -43,7 +43,7 @@ def test_triangulate_dlt_bit_exact(vo, oracle, ctx):
 
 
 def _run_both(vo, oracle, W, H, K, nu, nv, frames, win, lvl, n_frames, lba, strict, seed=5, speed=0.5, prefetch=False,
-              kf_trans=10.0, kf_overlap=0.6):
+              kf_trans=10.0, kf_overlap=0.6, id_offset=0):
     from oracle.stereo_vo import StereoVORef
     st, imgs = frames
     ref = StereoVORef(W, H, K, K, st.T_lr, nu, nv, thres_fast=15, win=win, max_level=lvl, kf_trans=kf_trans, kf_overlap=kf_overlap,
@@ -51,6 +51,8 @@ def _run_both(vo, oracle, W, H, K, nu, nv, frames, win, lvl, n_frames, lba, stri
                       n_threads=8)
     c = vo.Context(device=0, max_width=W, max_height=H, max_points=4096, n_slots=5, max_level=lvl)
     try:
+        if id_offset:
+            vo.TrackIds(c).reset(id_offset, 0)  # the stream's landmark counter starts here (the CPU loop's at 0)
         svo = vo.StereoVO(c, W, H, K, K, st.T_lr, nu, nv, thres_fastscore=15, window_size=win, max_level=lvl, strict_border=strict,
                           local_ba=lba, thres_trans=kf_trans, thres_alive_ratio=kf_overlap)
         log = []
@@ -68,7 +70,7 @@ def _run_both(vo, oracle, W, H, K, nu, nv, frames, win, lvl, n_frames, lba, stri
             where = f"frame {k}"
             assert gi.frame_id == ri["frame_id"], where
             assert bool(gi.is_keyframe) == ri["keyframe"], where
-            assert np.array_equal(g["ids"], ref.ids), where
+            assert np.array_equal(g["ids"] - id_offset, ref.ids), where
             assert np.array_equal(_bits(g["pts_l"]), _bits(ref.pts_l)) and np.array_equal(_bits(g["pts_r"]), _bits(ref.pts_r)), where
             assert np.array_equal(g["flags"], ref.flags), where
             tri = (ref.flags & 1) != 0
@@ -113,6 +115,28 @@ def test_closed_loop_with_local_ba(vo, oracle):
     frames = _stream(W, H, K, 20, 8, 5, 0.5, 14)
     log, ref = _run_both(vo, oracle, W, H, K, 20, 8, frames, 21, 4, 14, lba=True, strict=4, prefetch=True, kf_trans=1.2)
     assert sum(1 for e in log if e[2]) >= 3, log
+
+
+def test_closed_loop_local_ba_sliding_window(vo, oracle):
+    """A keyframe every other frame for 32 frames: the window fills up (nine keyframes, seven optimised: the 42 x 42
+    register solve), then slides — keyframes leave the device-side ring, their slots are reused, the id interval of the
+    landmark table moves on — and the device-built problem still leaves the loop bit for bit on the CPU loop's state."""
+    W, H, K = 640, 240, (400.0, 400.0, 320.0, 120.0)
+    frames = _stream(W, H, K, 20, 8, 7, 0.5, 32)
+    log, ref = _run_both(vo, oracle, W, H, K, 20, 8, frames, 21, 4, 32, lba=True, strict=4, prefetch=True, kf_trans=0.9)
+    assert sum(1 for e in log if e[0]) >= 13, log      # more keyframes than the window holds
+    assert sum(1 for e in log if e[2]) >= 11, log
+
+
+def test_closed_loop_local_ba_landmark_table_wraps(vo, oracle):
+    """The device-side landmark table is addressed by id modulo its 2^21 slots: a stream whose landmark counter crosses
+    that boundary in the middle of a keyframe window (ids 2^21 - 150 ...) must give the same loop."""
+    W, H, K = 640, 240, (400.0, 400.0, 320.0, 120.0)
+    frames = _stream(W, H, K, 20, 8, 5, 0.5, 14)
+    log, ref = _run_both(vo, oracle, W, H, K, 20, 8, frames, 21, 4, 14, lba=True, strict=4, prefetch=True, kf_trans=1.2,
+                         id_offset=(1 << 21) - 150)
+    assert sum(1 for e in log if e[2]) >= 3, log
+    assert ref.ids.min() < 150 < ref.ids.max()  # live landmarks on both sides of the boundary at the end
 
 
 def test_closed_loop_survives_a_join_timeout():

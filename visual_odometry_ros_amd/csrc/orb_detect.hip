@@ -21,6 +21,7 @@
 // Everything is deterministic (integer atomics only for counts and histograms); the keypoint order is level,
 // then raster order — cv's own order after nth_element is unspecified, and the reference depends on it only
 // through exact ties of float responses in the bucketing.
+#include <stdlib.h>
 #include <cmath>
 #include <vector>
 
@@ -895,6 +896,15 @@ extern "C" int vo_new_point_candidates_enqueue(vo_ctx *c, int slot, const vo_bin
     if (!T.ready) VO_CHECK_HIP(c, hipEventCreateWithFlags(&T.ready, hipEventDisableTiming));
     if (!T.h_flags) VO_CHECK_HIP(c, hipHostMalloc((void **)&T.h_flags, 64, hipHostMallocDefault));
     T.n_bins = total;
+  }
+  {  // MEASUREMENT ONLY (VO_DEBUG_SKIP_DETECT): a table filled once keeps its content — what the frame costs without the
+     // detection under it (results are those of a stale table)
+    static const bool dbg_skip = getenv("VO_DEBUG_SKIP_DETECT") != nullptr;
+    static int dbg_filled[2] = {0, 0};
+    if (dbg_skip && dbg_filled[table]++ >= 2) {
+      VO_CHECK_HIP(c, hipEventRecord(T.ready, c->stream2));
+      return VO_OK;
+    }
   }
   hipStream_t caller = c->stream;
   c->stream = c->stream2;  // every launcher below enqueues on ctx->stream

@@ -19,11 +19,12 @@
 // and a landmark alive at some frame was alive at every keyframe since its creation — so everything the window can
 // refer to lies in the id interval [first id of the oldest keyframe, next id to hand out). That makes every container of
 // the reference a direct-address array in HBM:
-//   landmark table   X (float3), state (bit 0 triangulated, bit 1 dead), tag (the id), slot = id mod 2^20
+//   landmark table   X (float3), state (bit 0 triangulated, bit 1 dead), tag (the id), slot = id mod 2^21
 //   keyframe ring    per window keyframe its related landmarks' ids and both pixels (copied from the track set)
 //   window scratch   per id of the interval: bit mask of the window keyframes that saw it, its entry index in each
-// and the BA problem is built by five small launches — mark/copy, scatter, scan (one workgroup), fill (one lane per id),
-// lists (one workgroup per gather list) — straight into the solver's arena; the solver's results go back into the
+// and the BA problem is built by six small launches — mark/copy, scatter, qualify (one lane per id, packed counts scanned
+// per workgroup), scan (one workgroup over the workgroups' totals), fill (one lane per id), lists (one workgroup per
+// gather list) — straight into the solver's arena; the solver's results go back into the
 // table and the track set by two more. The host sees nine poses, ten error values and three counts per solve. (The
 // first version merged the window's id lists on the host and uploaded 1.6 MB per keyframe: 0.41 ms of host time around
 // 0.64 ms of kernels.)
@@ -73,8 +74,8 @@ static void to_d(const float T[16], double D[16]) {
 
 // ---- device side ------------------------------------------------------------------------------------------------------
 #define LBA_KW 16            // window keyframes at most (bits of the mask that are used, entries per id in q_w)
-#define LBA_TAB_BITS 20      // landmark table: 2^20 slots, circular by id
-#define LBA_SPAN_MAX (1 << 18)  // ids the window may span
+#define LBA_TAB_BITS 21      // landmark table: 2^21 slots, circular by id
+#define LBA_SPAN_MAX (1 << 19)  // ids the window may span
 
 struct LmTab {
   float *X;       // [slots][3] lm->get3DPoint()
@@ -101,7 +102,8 @@ struct LbaProb {  // the problem inside the solver's arena (non-const views of S
   double *avg_err;
   int32_t *used_id;
   int *lm_mask;
-  int *mask_w, *q_w, *pre_lm, *pre_kf, *pre_sl;  // window scratch, per id of the interval
+  int *mask_w, *q_w;                  // window scratch, per id of the interval
+  unsigned long long *pre, *wg_tot;   // packed running counts: inside the workgroup / of the workgroups
   int pose_obs_stride, pose_slot_stride, pair_stride, max_iter;
 };
 
@@ -158,54 +160,84 @@ __device__ __forceinline__ int lba_block_scan(int v, int *s_w, int &total) {
   return before + inc - v;
 }
 
-// ONE workgroup: which ids of the interval enter the problem (triangulated && alive, seen by the window: a stereo
-// keyframe gives two observations, THRES_MINIMUM_SEEN = 2 always holds) and the three running counts that place them —
-// landmark index, observation pairs, slots. Also what the host would have uploaded: poses, index maps, zeroed flags.
+// the same for a 64-bit value and a workgroup of NW wavefronts (three counts packed into one word)
+template <int NW>
+__device__ __forceinline__ unsigned long long lba_block_scan64(unsigned long long v, unsigned long long *s_w,
+                                                               unsigned long long &total) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned long long inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned long long t = __shfl_up(inc, off);
+    if (lane >= off) inc += t;
+  }
+  __syncthreads();
+  if (lane == 63) s_w[wave] = inc;
+  __syncthreads();
+  unsigned long long before = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < NW; ++k) {
+    const unsigned long long c = s_w[k];
+    before += k < wave ? c : 0;
+    tot += c;
+  }
+  total = tot;
+  return before + inc - v;
+}
+// three running counts place a landmark: its index, its observation pairs (one per keyframe that saw it), its slots —
+// packed as 20 + 22 + 22 bits (the host checks the bounds)
+#define LBA_PK_KF 20
+#define LBA_PK_SL 42
+#define LBA_QWG 256
+
+// one lane per id of the interval: does it enter the problem (triangulated && alive, seen by the window: a stereo
+// keyframe gives two observations, THRES_MINIMUM_SEEN = 2 always holds)? Its packed counts, scanned inside the workgroup.
+__global__ __launch_bounds__(LBA_QWG) void lba_qualify_kernel(LbaWin w, LmTab tab, LbaProb p) {
+  __shared__ unsigned long long s_w[LBA_QWG / 64];
+  const int idx = blockIdx.x * LBA_QWG + threadIdx.x;
+  int m = idx < w.W ? p.mask_w[idx] : 0;
+  if (m) {
+    const int32_t id = w.base + idx;
+    const int t = id & tab.mask;
+    const uint8_t st = tab.tag[t] == id ? tab.S[t] : (uint8_t)0;
+    if (!((st & 1) && !(st & 2))) {  // isTriangulated() && isAlive()
+      m = 0;
+      p.mask_w[idx] = 0;
+    }
+  }
+  const unsigned long long v =
+      m ? 1ull | ((unsigned long long)__popc(m) << LBA_PK_KF) | ((unsigned long long)__popc(m & w.optmask) << LBA_PK_SL) : 0ull;
+  unsigned long long total;
+  const unsigned long long ex = lba_block_scan64<LBA_QWG / 64>(v, s_w, total);
+  if (idx < w.W) p.pre[idx] = ex;
+  if (threadIdx.x == 0) p.wg_tot[blockIdx.x] = total;
+}
+
+// ONE workgroup: the workgroups' totals become offsets, the totals of the interval the problem's counts. Also what the
+// host would have uploaded: poses, index maps, zeroed flags — from the kernel arguments.
 struct LbaHead {
   double T_jw[16 * LBA_KW];
 };
-__global__ __launch_bounds__(1024) void lba_scan_kernel(LbaWin w, LmTab tab, LbaProb p, LbaHead h) {
-  __shared__ int s_w[16];
+__global__ __launch_bounds__(1024) void lba_scan_kernel(LbaWin w, LbaProb p, LbaHead h, int n_wg) {
+  __shared__ unsigned long long s_w[16];
   const int tid = threadIdx.x;
   for (int k = tid; k < 16 * w.nk; k += 1024) p.T[k] = h.T_jw[k];
   if (tid < w.nk) p.opt_index[tid] = w.opt[tid];
   if (tid < w.No) p.opt_frame[tid] = w.optf[tid];
   if (tid < 16) p.flags[tid] = 0;
   if (tid <= p.max_iter) p.avg_err[tid] = 0.0;
-  const int chunk = (w.W + 1023) / 1024, i0 = tid * chunk, i1 = min(i0 + chunk, w.W);
-  int c_lm = 0, c_kf = 0, c_sl = 0;
-  for (int idx = i0; idx < i1; ++idx) {
-    int m = p.mask_w[idx];
-    if (m) {
-      const int32_t id = w.base + idx;
-      const int t = id & tab.mask;
-      const uint8_t st = tab.tag[t] == id ? tab.S[t] : (uint8_t)0;
-      if (!((st & 1) && !(st & 2))) {  // isTriangulated() && isAlive()
-        m = 0;
-        p.mask_w[idx] = 0;
-      }
-    }
-    if (m) {
-      ++c_lm;
-      c_kf += __popc(m);
-      c_sl += __popc(m & w.optmask);
-    }
-  }
-  int t_lm, t_kf, t_sl;
-  int o_lm = lba_block_scan(c_lm, s_w, t_lm);
-  int o_kf = lba_block_scan(c_kf, s_w, t_kf);
-  int o_sl = lba_block_scan(c_sl, s_w, t_sl);
-  for (int idx = i0; idx < i1; ++idx) {
-    const int m = p.mask_w[idx];
-    if (!m) continue;
-    p.pre_lm[idx] = o_lm;
-    p.pre_kf[idx] = o_kf;
-    p.pre_sl[idx] = o_sl;
-    ++o_lm;
-    o_kf += __popc(m);
-    o_sl += __popc(m & w.optmask);
+  const int chunk = (n_wg + 1023) / 1024, i0 = tid * chunk, i1 = min(i0 + chunk, n_wg);
+  unsigned long long c = 0;
+  for (int g = i0; g < i1; ++g) c += p.wg_tot[g];
+  unsigned long long total, off = lba_block_scan64<16>(c, s_w, total);
+  for (int g = i0; g < i1; ++g) {
+    const unsigned long long t = p.wg_tot[g];
+    p.wg_tot[g] = off;
+    off += t;
   }
   if (tid == 0) {
+    const int t_lm = (int)(total & ((1ull << LBA_PK_KF) - 1)), t_kf = (int)((total >> LBA_PK_KF) & ((1ull << (LBA_PK_SL - LBA_PK_KF)) - 1));
+    const int t_sl = (int)(total >> LBA_PK_SL);
     p.dyn[0] = t_lm;
     p.dyn[1] = 2 * t_kf;
     p.dyn[2] = t_sl;
@@ -224,7 +256,9 @@ __global__ void lba_fill_kernel(LbaWin w, LmTab tab, LbaProb p, LbaRef r) {
   if (idx >= w.W) return;
   const int m = p.mask_w[idx];
   if (!m) return;
-  const int i = p.pre_lm[idx], kf0 = p.pre_kf[idx], s0 = p.pre_sl[idx];
+  const unsigned long long pk = p.pre[idx] + p.wg_tot[idx / LBA_QWG];
+  const int i = (int)(pk & ((1ull << LBA_PK_KF) - 1)), kf0 = (int)((pk >> LBA_PK_KF) & ((1ull << (LBA_PK_SL - LBA_PK_KF)) - 1));
+  const int s0 = (int)(pk >> LBA_PK_SL);
   const int32_t id = w.base + idx;
   const int t = id & tab.mask;
   p.used_id[i] = id;
@@ -358,7 +392,8 @@ struct vo_svo_lba {
   LmTab tab = {};
   int32_t *kf_ids[LBA_KW] = {};
   float *kf_pl[LBA_KW] = {}, *kf_pr[LBA_KW] = {};
-  int *mask_w = nullptr, *q_w = nullptr, *pre = nullptr;  // window scratch
+  int *mask_w = nullptr, *q_w = nullptr;  // window scratch
+  unsigned long long *pre = nullptr;
   uint8_t *arena = nullptr;
   size_t arena_cap = 0;
   uint8_t *h_res = nullptr;  // pinned: poses, errors, flags, counts of a solve
@@ -399,7 +434,7 @@ static int lba_init(vo_svo *s) {
   }
   VO_CHECK_HIP(c, hipMalloc((void **)&L->mask_w, sizeof(int) * (size_t)LBA_SPAN_MAX));
   VO_CHECK_HIP(c, hipMalloc((void **)&L->q_w, sizeof(int) * (size_t)LBA_SPAN_MAX * LBA_KW));
-  VO_CHECK_HIP(c, hipMalloc((void **)&L->pre, sizeof(int) * (size_t)LBA_SPAN_MAX * 3));
+  VO_CHECK_HIP(c, hipMalloc((void **)&L->pre, sizeof(unsigned long long) * ((size_t)LBA_SPAN_MAX + LBA_SPAN_MAX / LBA_QWG + 1)));
   VO_CHECK_HIP(c, hipHostMalloc((void **)&L->h_res, 4096, hipHostMallocDefault));
   return VO_OK;
 }
@@ -475,6 +510,8 @@ int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info, int id_min) {
     maxn = std::max(maxn, win[j].n);
   }
   if (w.W <= 0 || E == 0) return VO_OK;
+  if (w.W >= (1 << LBA_PK_KF) || E >= ((size_t)1 << (LBA_PK_SL - LBA_PK_KF)))
+    VO_FAIL(c, VO_ERR_CAPACITY, "local BA: %d ids / %zu keyframe entries exceed the packed counters", w.W, E);
   const int No = w.No, max_iter = 10;
   const size_t M_ub = std::min((size_t)w.W, E), nobs_ub = 2 * E, ns_ub = E_opt;
   const int n_err = (int)((M_ub + 64 / SBA_LQ - 1) / (64 / SBA_LQ));
@@ -540,9 +577,8 @@ int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info, int id_min) {
   p.lm_mask = (int *)(base + oLm);
   p.mask_w = L->mask_w;
   p.q_w = L->q_w;
-  p.pre_lm = L->pre;
-  p.pre_kf = L->pre + LBA_SPAN_MAX;
-  p.pre_sl = L->pre + 2 * (size_t)LBA_SPAN_MAX;
+  p.pre = L->pre;
+  p.wg_tot = L->pre + LBA_SPAN_MAX;
   p.pose_obs_stride = 2 * maxn;
   p.pose_slot_stride = maxn;
   p.pair_stride = maxn;
@@ -566,7 +602,9 @@ int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info, int id_min) {
   // ---- build + solve, all on the main stream ----
   VO_CHECK_HIP(c, hipMemsetAsync(L->mask_w, 0, sizeof(int) * (size_t)w.W, st));
   hipLaunchKernelGGL(lba_scatter_kernel, dim3((maxn + 255) / 256, nk), dim3(256), 0, st, w, L->mask_w, L->q_w);
-  hipLaunchKernelGGL(lba_scan_kernel, dim3(1), dim3(1024), 0, st, w, L->tab, p, head);
+  const int n_wg = (w.W + LBA_QWG - 1) / LBA_QWG;
+  hipLaunchKernelGGL(lba_qualify_kernel, dim3(n_wg), dim3(LBA_QWG), 0, st, w, L->tab, p);
+  hipLaunchKernelGGL(lba_scan_kernel, dim3(1), dim3(1024), 0, st, w, p, head, n_wg);
   hipLaunchKernelGGL(lba_fill_kernel, dim3((w.W + 255) / 256), dim3(256), 0, st, w, L->tab, p, ref);
   hipLaunchKernelGGL(lba_lists_kernel, dim3(No + No * (No + 1) / 2), dim3(1024), 0, st, w, p);
   VO_CHECK_HIP(c, hipGetLastError());
