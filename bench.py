@@ -531,7 +531,7 @@ LOOP_PRIME = 3  # untimed frames in front of the warm-up: the first pair (initia
 
 
 def loop_frames_needed(args):
-    return LOOP_PRIME + args.warmup + args.steps + 1  # (+1: the pair prefetched under the last timed frame)
+    return LOOP_PRIME + args.warmup + args.steps + 2  # (+2: the frame in flight at the end of the timed region, and the pair prefetched under it)
 
 
 def run_loop(cfg, args, rank, local_rank, world, torch, V, barrier, dev, imgs, secondary):
@@ -568,20 +568,30 @@ def run_loop(cfg, args, rank, local_rank, world, torch, V, barrier, dev, imgs, s
     state = {"k": 0}
     traj, infos, stamps = [], [], []
 
-    def step(keep):
-        k = state["k"]
+    def issue(k):
         svo.enqueue(*ptr[k])
         if prefetch and k + 1 < F:
             svo.prefetch(*ptr[k + 1])  # the NEXT pair does not depend on this frame: ingestion + detection under it
+
+    def step(keep):
+        # frame k is in flight (issued at the end of the previous step): collect it, send frame k + 1 off at once, and
+        # only then look at frame k's results — the caller's own work per frame runs under the next frame
+        k = state["k"]
         i = svo.result()
-        state["k"] = k + 1
         if keep:
             stamps.append(time.perf_counter())
+        if k + 1 < F and not args.no_issue_ahead:
+            issue(k + 1)
+        state["k"] = k + 1
+        if keep:
             c = i.counts
             infos.append((k, i.n_tracks_in, c.n_l0l1, c.n_refine, c.n_replayed, i.n_new_candidates, i.n_new, i.n_final,
                           i.is_keyframe, i.lba_ran, c.gn_iterations, c.n_ba))
         traj.append(np.array(i.T_wc, np.float32).reshape(4, 4))
+        if k + 1 < F and args.no_issue_ahead:
+            issue(k + 1)
 
+    issue(0)
     for _ in range(LOOP_PRIME + args.warmup):
         step(False)
     K = args.steps
@@ -594,6 +604,8 @@ def run_loop(cfg, args, rank, local_rank, world, torch, V, barrier, dev, imgs, s
             step(True)
 
     dt = timed(timed_run, barrier, ctx)
+    if state["k"] < F:
+        svo.result()  # (the frame issued by the last timed step: it ran inside the timed region, nobody reads it)
     per_rank = gather_ranks(K, dt, stream_seed(rank), world, dev)
     tot_frames, max_dt = sum(p[0] for p in per_rank), max(p[1] for p in per_rank)
     if rank != 0:
@@ -863,6 +875,8 @@ def main():
                          "--config 4: 8000 ground-truth features per frame — the synthetic 4K stream keeps only ~3000 tracks "
                          "alive in the loop) / sequential / open: round 2's "
                          "frame operator on ground-truth track sets, differing in how step [10] is driven; see the docstring")
+    ap.add_argument("--no-issue-ahead", action="store_true",
+                    help="loop mode: look at a frame's results BEFORE the next frame is sent off (round 3's first loop order)")
     ap.add_argument("--lba", type=int, default=1, help="loop mode: local bundle adjustment at keyframes (the reference's behaviour)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="loop mode: hand every pair over only when its frame starts (no ingestion under the previous frame)")

@@ -28,7 +28,7 @@ def main():
         for _ in range(3):
             pipe.enqueue(ts["pts_l0"], ts["pts_r0"], ts["Xp"], ts["dT_prior"], ts["pts_new"])
             r = pipe.result()
-        st = (C.c_longlong * 8)()
+        st = (C.c_longlong * 12)()
         ctx.check(ctx.lib.vo_debug_gn_stamps(ctx.handle, st))
         t = [st[i] for i in range(5)]
         rows.append(dict(iterations=r["counts"].gn_iterations, prologue_us=(t[1] - t[0]) / 100.0, loads_us=(t[2] - t[1]) / 100.0,

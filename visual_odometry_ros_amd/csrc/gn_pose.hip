@@ -431,10 +431,10 @@ __device__ __forceinline__ void gn_point(GnAcc &A, const GnArgs &a, const float 
 }
 
 #ifdef GN_STAMP
-__device__ long long vo_gn_stamps[8];
-extern "C" int vo_debug_gn_stamps(vo_ctx *c, long long out[8]) {
+__device__ long long vo_gn_stamps[12];
+extern "C" int vo_debug_gn_stamps(vo_ctx *c, long long out[12]) {
   VO_CHECK_HIP(c, hipStreamSynchronize(c->stream));
-  VO_CHECK_HIP(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(vo_gn_stamps), sizeof(long long) * 8));
+  VO_CHECK_HIP(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(vo_gn_stamps), sizeof(long long) * 12));
   return VO_OK;
 }
 #endif
@@ -493,6 +493,7 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
       s_stop = ok;
     }
     __syncthreads();
+    GSTAMP(5)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (!s_stop && tid == 0) atomicOr(a.f_ctl, 8);  // reported through the frame's error flags
     // (word [2] of the block: replay workgroups that gave up waiting for the frame kernel; consumed here)
@@ -799,6 +800,7 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
       }
       __syncthreads();
     }
+    GSTAMP(6)
     if (a.np.bins > 0) {
       // ---- closed step [10]: updateWeightBin(lmtrack_final.pts_l1) + emission (np_emit.hpp), with the
       // trackBidirection results (stereo_vo.cpp:706-711) the frame kernel computed for every bin's candidate.
@@ -808,6 +810,7 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
       vo_np_emit(a.np, a.f_n, a.f_pl1, [&](int i) { return stg[i] == sv; }, tid, GN_T, (uint8_t *)s_red, (int *)s_tot,
                  &a.f_cnt[5]);
     }
+    GSTAMP(7)
     if (STEREO && a.adv.on) {
       // ---- StereoVO: the next frame's track set. lmtrack_final (stereo_vo.cpp:670: the stage-4 features in index order,
       // with their landmarks), then the new landmarks of step [10] (:729-734: candidate order, ids from the landmark
@@ -898,6 +901,7 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
         *v.hdr_host = h;  // (pinned; made visible by the system-scope fence in front of the frame's sequence word below)
       }
     }
+    GSTAMP(8)
     for (int k = tid; k < a.f_res_late_words; k += GN_T)
       if (k != a.f_seq_word || !a.f_seq) a.f_res_host[k] = a.f_res_dev[k];
     if (a.f_seq) {

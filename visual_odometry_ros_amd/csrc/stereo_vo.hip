@@ -44,6 +44,10 @@ int vo_frame_set_advance(vo_ctx *c, const VoAdvArgs *adv);          // frame_pip
 
 #include "stereo_vo.hpp"
 
+#ifdef GN_STAMP
+extern "C" int vo_debug_gn_stamps(vo_ctx *c, long long out[12]);
+#endif
+
 __global__ void svo_dlt_kernel(SvoCam cam, const float *p0, const float *p1, int n, float *X0, float *X1) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -449,6 +453,24 @@ extern "C" int vo_svo_result(vo_svo *s, vo_svo_frame_info *info) {
   float dT[16];
   int rc = vo_stereo_frame_result(c, nullptr, nullptr, nullptr, dT, nullptr, nullptr, &I.counts, &I.gn);
   if (rc < 0) return rc;
+#ifdef GN_STAMP  // measurement build: phases of the BA launch in the loop (10 ns ticks), averaged under VO_SVO_TRACE
+  {
+    static const bool trace = getenv("VO_SVO_TRACE") != nullptr;
+    static double acc[8];
+    static int nacc;
+    if (trace) {
+      long long t[12];
+      if (vo_debug_gn_stamps(c, t) == VO_OK) {
+        const int order[9] = {0, 5, 1, 2, 3, 6, 7, 8, 4};  // start, joined, prologue, loads, iterations, stage+DLT wait, emit, track set, copy
+        for (int k = 0; k < 8; ++k) acc[k] += 0.01 * (double)(t[order[k + 1]] - t[order[k]]);
+        if (++nacc % 100 == 0)
+          fprintf(stderr, "[gn] per launch (us): join wait %.1f  prologue %.1f  loads %.1f  iterations %.1f  stage marks + DLT wait %.1f  "
+                          "step [10] emission %.1f  next track set %.1f  copy-out + sequence word %.1f\n",
+                  acc[0] / nacc, acc[1] / nacc, acc[2] / nacc, acc[3] / nacc, acc[4] / nacc, acc[5] / nacc, acc[6] / nacc, acc[7] / nacc);
+      }
+    }
+  }
+#endif
   const SvoHdr h = *s->h_hdr;
   if (h.overflow) VO_FAIL(c, VO_ERR_CAPACITY, "the next track set (%d) exceeds vo_config.max_points=%d", h.n_next, s->cap);
   I.n_tracks_in = s->n;
