@@ -390,9 +390,11 @@ typedef struct {
   float kf_overlap_ratio;   /* keyframe_update.thres_alive_ratio   (StereoKeyframes::setThresOverlapRatio) */
   float kf_rotation_deg;    /* keyframe_update.thres_rotation      (degrees; the reference multiplies by D2R) */
   float kf_translation;     /* keyframe_update.thres_trans */
-  int kf_window;            /* keyframe_update.n_max_keyframes_in_window */
+  int kf_window;            /* keyframe_update.n_max_keyframes_in_window (with local_ba: at most 16) */
   int strict_border;        /* vo_stereo_frame_set_strict_border */
-  int local_ba;             /* != 0: localBundleAdjustmentSparseSolver_Stereo at every keyframe (the reference's behaviour) */
+  int local_ba;             /* != 0: localBundleAdjustmentSparseSolver_Stereo at every keyframe (the reference's behaviour);
+                               landmark table, keyframe window and the BA problem live on the device (about 90 MB per
+                               StereoVO), the window may span at most 2^19 landmark ids (VO_ERR_CAPACITY beyond) */
 } vo_svo_params;
 typedef struct {
   int frame_id;             /* id of the left Frame of this pair (the right one is frame_id + 1, frame.cpp:176-180) */
