@@ -820,10 +820,12 @@ def cpu_baseline_loop(cfg, args, st, imgs, traj, V, local_rank):
     svo = V.StereoVO(ctx, cfg["W"], cfg["H"], cfg["K"], cfg["K"], st.T_lr, cfg["n_u"], cfg["n_v"], thres_fastscore=cfg["thres_fast"],
                      window_size=cfg["win"], max_level=cfg["max_level"], thres_error=thr[0], thres_bidirection=thr[1],
                      thres_poseba_error=thr[2], strict_border=args.strict_border, local_ba=bool(args.lba))
-    exact, ids_ok = True, True
-    for k in range(nf):
+    exact, ids_ok, n_lba = True, True, 0
+    nf_par = max(nf, min(args.parity_frames, len(imgs)))  # (long enough for the window to reach three keyframes: local BA)
+    for k in range(nf_par):
         gi = svo.trackStereoImages(*imgs[k])
         tree.track(*imgs[k])
+        n_lba += int(bool(gi.lba_ran))
         g = svo.getTracks()
         ids_ok = ids_ok and bool(np.array_equal(g["ids"], tree.ids))
         same = ids_ok and np.array_equal(g["pts_l"].view(np.uint32), tree.pts_l.view(np.uint32)) \
@@ -850,10 +852,10 @@ def cpu_baseline_loop(cfg, args, st, imgs, traj, V, local_rank):
             "first_frame_s": round(t_frames[0], 3),
         },
         "parity": {"pose_rel_frobenius_max": worst, "track_ids_bit_exact": ids_ok, "track_sets_and_poses_bit_exact": exact,
-                   "frames_checked": nf,
+                   "frames_checked": nf_par, "local_ba_solves_checked": n_lba, "pose_frames_checked": nf,
                    "note": "pose error: device loop against the CPU loop in the reference's summation order, both free-running; "
                            "bit-exactness: device loop against the CPU loop in the kernels' summation order (ids, pixels, flags, "
-                           "poses after every frame)"},
+                           "poses after every frame, local-BA solves included)"},
     }
 
 
@@ -865,6 +867,7 @@ def main():
     ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="BASELINE.json configs[i]")
     ap.add_argument("--frames", type=int, default=12, help="distinct rendered frames (played back and forth)")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--parity-frames", type=int, default=18, help="loop mode: frames of the bit-exact leg (device loop against the CPU loop)")
     ap.add_argument("--strict-border", type=int, default=4,
                     help="0 masked border taps; 1-5 the reference's never-reset tap state (identical results): 1 replay "
                          "stream-ordered behind the frame kernel, 2 sequential replay, 3 replay next to the frame kernel, "

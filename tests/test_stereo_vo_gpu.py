@@ -81,7 +81,7 @@ def _run_both(vo, oracle, W, H, K, nu, nv, frames, win, lvl, n_frames, lba, stri
                 npg = svo.getNewPoints()
                 assert np.array_equal(_bits(npg["pts_l"]), _bits(ri["cand"])) and np.array_equal(npg["accept"], ri["accept"]), where
                 assert np.array_equal(npg["mask_new"], ri["mask_new"]), where
-            log.append((bool(gi.is_keyframe), gi.n_tracks_out, bool(gi.lba_ran)))
+            log.append((bool(gi.is_keyframe), gi.n_tracks_out, bool(gi.lba_ran), int(gi.lba_landmarks)))
         svo.close()
         return log, ref
     finally:
@@ -105,6 +105,18 @@ def test_closed_loop_kitti_size(vo, oracle):
     log, ref = _run_both(vo, oracle, W, H, S.KITTI_K, 60, 25, frames, 21, 6, 9, lba=False, strict=4, prefetch=True, kf_overlap=0.8)
     assert log[-1][1] > 1000
     assert sum(1 for e in log if e[0]) >= 2
+
+
+def test_closed_loop_kitti_size_local_ba(vo, oracle):
+    """The same at full size with a keyframe every other frame: three local-BA solves over up to five keyframes and
+    several thousand landmarks — the device-side problem builder beyond one workgroup's worth of ids and landmarks
+    (multi-workgroup scans, gather lists with more than one landmark per lane)."""
+    from visual_odometry_ros_amd import synthetic as S
+    W, H = S.KITTI_SIZE
+    frames = _stream(W, H, S.KITTI_K, 60, 25, 2, 0.8, 10)
+    log, ref = _run_both(vo, oracle, W, H, S.KITTI_K, 60, 25, frames, 21, 6, 10, lba=True, strict=4, prefetch=True, kf_trans=1.0)
+    assert sum(1 for e in log if e[2]) >= 3, log
+    assert max(e[3] for e in log) >= 2048, log  # landmarks in the largest problem
 
 
 def test_closed_loop_with_local_ba(vo, oracle):
