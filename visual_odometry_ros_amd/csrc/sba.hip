@@ -5,21 +5,22 @@
 //
 // The reference walks landmark -> observation and scatters 6x6 / 6x3 / 3x3 blocks into dense block
 // arrays (B_ alone is N_opt x M blocks). Here the sparsity pattern is turned into index lists once per
-// problem on the host (it does not change between iterations) and every reduction becomes a gather with
-// a fixed order, so there are no atomics and results are run-to-run identical:
-//   sba_point_kernel   one lane per landmark: C_i, b_i (the reference's sequential order), damping,
-//                      3x3 pivoted LDLT inverse, C^-1 b, and per "slot" (left observation in an optimised
-//                      keyframe) the blocks B_ji and B_ji C_i^-1
-//   sba_pose_kernel    SBA_PG wavefronts per optimised pose: A_j, a_j over the pose's observation list,
-//                      (B C^-1 b)_j over its slot list; lane-strided partial sums + butterfly
-//   sba_schur_kernel   one wavefront per block (j,k): sum of (B_ji C_i^-1) B_ki^T over the landmark pairs
-//   sba_assemble_kernel one lane per entry of the reduced system (lower<-upper symmetrisation quirk applied)
-//   sba_solve_kernel   one wavefront: pivot order from the original diagonal, permuted system in LDS, Eigen-order
-//                      LDLT, x; pose updates exp(log(exp(x) exp(log T))); average error
-//   sba_update_kernel  one lane per landmark: y_i, X_i += y_i
-// Six launches per iteration, no host round trip inside the solve. The quirks listed in
-// oracle/oracle_sba.c (B assigned not accumulated, left-only Schur loops, symmetrisation overwrite,
-// calc_Qij_t_Qij_weight's zero entries) are reproduced.
+// problem (it does not change between iterations) — on the host by vo_sba_solve below, on the device by the
+// StereoVO driver (stereo_vo_lba.hip) — and every reduction becomes a gather with a fixed order, so there
+// are no atomics and results are run-to-run identical:
+//   sba_update_point_kernel  four lanes per landmark: y_i, X_i += y_i of the previous iteration; then C_i, b_i,
+//                      damping, 3x3 pivoted LDLT inverse, C^-1 b, and per "slot" (left observation in an optimised
+//                      keyframe) the blocks B_ji, B_ji C_i^-1 and (B_ji C_i^-1) b_i
+//   sba_pose_schur_kernel  SBA_PG workgroups of 256 per optimised pose: A_j, a_j over the pose's observation list,
+//                      (B C^-1 b)_j over its slot list; SBA_SG workgroups per block (j,k), j <= k: sum of
+//                      (B_ji C_i^-1) B_ki^T over the landmark pairs; lane-strided partial sums, DPP + LDS reduction
+//   sba_solve_reg_kernel<42>  the steady-state window: reduced system assembled into LDS by 512 lanes, then one
+//                      wavefront: pivot order from the original diagonal, rows of the permuted matrix in registers,
+//                      Eigen-order LDLT, x; pose updates exp(log(exp(x) exp(log T))); average error (second wavefront)
+//   sba_assemble_kernel + sba_solve_kernel  the same for any other size (one lane per entry; matrix in LDS)
+// Three launches per iteration in the steady-state window (four otherwise), no host round trip inside the solve.
+// The quirks listed in oracle/oracle_sba.c (B assigned not accumulated, left-only Schur loops, symmetrisation
+// overwrite, calc_Qij_t_Qij_weight's zero entries) are reproduced.
 #include <stdlib.h>
 #include <time.h>
 
