@@ -815,43 +815,72 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
       // ---- StereoVO: the next frame's track set. lmtrack_final (stereo_vo.cpp:670: the stage-4 features in index order,
       // with their landmarks), then the new landmarks of step [10] (:729-734: candidate order, ids from the landmark
       // counter, NOT triangulated: set3DPoint is commented out at :736). setStereoPtsSeenAndRelatedLandmarks (:752).
-      int *s_wv = (int *)s_tot;  // [GN_NW] + [GN_NW]: members of the last keyframe among the survivors
+      // Four chunks of GN_T entries per round (one round up to 2048 tracks): the keep flags of a round are gathered
+      // first, ONE barrier pair serves them all, and a thread's loads of the round are issued before its stores.
+      constexpr int NCH = 4;
+      int *s_wv = s_pcnt;  // [NCH * GN_NW] per-wavefront counts of a round + [GN_NW] members of the last keyframe among the survivors
       const VoAdvArgs &v = a.adv;
       const uint8_t sv4 = (uint8_t)a.stage_val;
       int base = 0, kf = 0;
-      for (int c0 = 0; c0 < a.f_n; c0 += GN_T) {
-        const int i = c0 + tid;
-        const bool keep = i < a.f_n && a.stage[i] == sv4;
-        const uint8_t fl = keep ? v.cur.flags[i] : 0;
-        const unsigned long long bal = __ballot(keep);
-        kf += __popcll(__ballot(keep && (fl & VO_LM_KF_MEMBER)));
-        if (lane == 0) s_wv[wave] = __popcll(bal);
-        __syncthreads();
-        int woff = 0, tot = 0;
+      for (int c0 = 0; c0 < a.f_n; c0 += NCH * GN_T) {
+        bool keep[NCH];
+        int below[NCH];
+        uint8_t fl[NCH];
 #pragma unroll
-        for (int w = 0; w < GN_NW; ++w) {
-          const int cw = s_wv[w];
-          woff += w < wave ? cw : 0;
-          tot += cw;
+        for (int q = 0; q < NCH; ++q) {
+          const int i = c0 + q * GN_T + tid;
+          keep[q] = i < a.f_n && a.stage[i] == sv4;
+          fl[q] = keep[q] ? v.cur.flags[i] : (uint8_t)0;
+          const unsigned long long bal = __ballot(keep[q]);
+          below[q] = __popcll(bal & ((1ull << lane) - 1ull));
+          kf += __popcll(__ballot(keep[q] && (fl[q] & VO_LM_KF_MEMBER)));
+          if (lane == 0) s_wv[q * GN_NW + wave] = __popcll(bal);
         }
-        if (keep) {
-          const int o = base + woff + __popcll(bal & ((1ull << lane) - 1ull));
-          if (o < v.cap) {
-            v.nxt.pts_l[2 * o] = a.f_pl1[2 * i];
-            v.nxt.pts_l[2 * o + 1] = a.f_pl1[2 * i + 1];
-            v.nxt.pts_r[2 * o] = a.f_pr1[2 * i];
-            v.nxt.pts_r[2 * o + 1] = a.f_pr1[2 * i + 1];
-            v.nxt.Xw[3 * o] = v.cur.Xw[3 * i];
-            v.nxt.Xw[3 * o + 1] = v.cur.Xw[3 * i + 1];
-            v.nxt.Xw[3 * o + 2] = v.cur.Xw[3 * i + 2];
-            v.nxt.flags[o] = fl;
-            v.nxt.ids[o] = v.cur.ids[i];
+        __syncthreads();
+        int off = base, o[NCH];
+        float pl[NCH][2], pr[NCH][2], xw[NCH][3];
+        int32_t id[NCH];
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+          int woff = 0, tot = 0;
+#pragma unroll
+          for (int w = 0; w < GN_NW; ++w) {
+            const int cw = s_wv[q * GN_NW + w];
+            woff += w < wave ? cw : 0;
+            tot += cw;
+          }
+          o[q] = off + woff + below[q];
+          off += tot;
+          if (keep[q]) {
+            const int i = c0 + q * GN_T + tid;
+            pl[q][0] = a.f_pl1[2 * i];
+            pl[q][1] = a.f_pl1[2 * i + 1];
+            pr[q][0] = a.f_pr1[2 * i];
+            pr[q][1] = a.f_pr1[2 * i + 1];
+            xw[q][0] = v.cur.Xw[3 * i];
+            xw[q][1] = v.cur.Xw[3 * i + 1];
+            xw[q][2] = v.cur.Xw[3 * i + 2];
+            id[q] = v.cur.ids[i];
           }
         }
-        base += tot;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q)
+          if (keep[q] && o[q] < v.cap) {
+            const int oo = o[q];
+            v.nxt.pts_l[2 * oo] = pl[q][0];
+            v.nxt.pts_l[2 * oo + 1] = pl[q][1];
+            v.nxt.pts_r[2 * oo] = pr[q][0];
+            v.nxt.pts_r[2 * oo + 1] = pr[q][1];
+            v.nxt.Xw[3 * oo] = xw[q][0];
+            v.nxt.Xw[3 * oo + 1] = xw[q][1];
+            v.nxt.Xw[3 * oo + 2] = xw[q][2];
+            v.nxt.flags[oo] = fl[q];
+            v.nxt.ids[oo] = id[q];
+          }
+        base = off;
         __syncthreads();
       }
-      if (lane == 0) s_wv[GN_NW + wave] = kf;
+      if (lane == 0) s_wv[NCH * GN_NW + wave] = kf;
       const int n_surv = base;
       const int n_emit = a.np.bins > 0 ? a.f_cnt[5] : 0;  // (thread 0's store, behind vo_np_emit's last barrier)
       for (int c0 = 0; c0 < n_emit; c0 += GN_T) {
@@ -887,7 +916,7 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
       __syncthreads();
       if (tid == 0) {
         int kft = 0;
-        for (int w = 0; w < GN_NW; ++w) kft += s_wv[GN_NW + w];
+        for (int w = 0; w < GN_NW; ++w) kft += s_wv[NCH * GN_NW + w];
         SvoHdr h;
         h.n_surv = n_surv;
         h.n_kf_tracked = kft;
