@@ -268,6 +268,16 @@ extern "C" void vo_svo_destroy(vo_svo *s) {
 
 enum { S_P = 0, S_CL = 1, S_CR = 2, S_NL = 3, S_NR = 4 };
 
+// VO_SVO_TRACE=1: where the host's time goes per frame (averages on stderr every 200 frames; single stream)
+static double svo_now();
+namespace {
+struct SvoHostTrace {
+  bool on = getenv("VO_SVO_TRACE") != nullptr;
+  double t_ret = 0, acc[5] = {0, 0, 0, 0, 0};  // caller between result and enqueue, enqueue, prefetch, wait in result, rest of result
+  int n = 0;
+} g_ht;
+}  // namespace
+
 // the pair into the "next" slots + its candidate table (side stream)
 static int svo_ingest(vo_svo *s, const void *left, const void *right, int stride, int on_device) {
   vo_ctx *c = s->c;
@@ -282,8 +292,10 @@ static int svo_ingest(vo_svo *s, const void *left, const void *right, int stride
 
 extern "C" int vo_svo_prefetch(vo_svo *s, const void *left, const void *right, int stride, int on_device) {
   if (!s || !left || !right) return VO_ERR_INVALID;
+  const double t_in = g_ht.on ? svo_now() : 0.0;
   VO_CHECK_HIP(s->c, hipSetDevice(s->c->device));
   RC(svo_ingest(s, left, right, stride, on_device));
+  if (g_ht.on) g_ht.acc[2] += svo_now() - t_in;
   s->pre_l = left;
   s->pre_r = right;
   s->prefetched = true;
@@ -296,6 +308,8 @@ extern "C" int vo_svo_enqueue(vo_svo *s, const void *left, const void *right, in
   if (!s || !left || !right) return VO_ERR_INVALID;
   vo_ctx *c = s->c;
   if (s->pending) VO_FAIL(c, VO_ERR_INVALID, "a frame is already in flight: call vo_svo_result first");
+  const double t_in = g_ht.on ? svo_now() : 0.0;
+  if (g_ht.on && g_ht.t_ret > 0) g_ht.acc[0] += t_in - g_ht.t_ret;
   VO_CHECK_HIP(c, hipSetDevice(c->device));
   (void)timestamp;
   if (!(s->prefetched && s->pre_l == left && s->pre_r == right)) RC(svo_ingest(s, left, right, stride, on_device));
@@ -343,6 +357,7 @@ extern "C" int vo_svo_enqueue(vo_svo *s, const void *left, const void *right, in
     s->pending = false;
     return rc;
   }
+  if (g_ht.on) g_ht.acc[1] += svo_now() - t_in;
   return VO_OK;
 }
 
@@ -451,8 +466,10 @@ extern "C" int vo_svo_result(vo_svo *s, vo_svo_frame_info *info) {
   }
   // the BA launch's epilogue wrote the loop's counts (pinned block) in front of the frame's sequence word
   float dT[16];
+  const double t_in = g_ht.on ? svo_now() : 0.0;
   int rc = vo_stereo_frame_result(c, nullptr, nullptr, nullptr, dT, nullptr, nullptr, &I.counts, &I.gn);
   if (rc < 0) return rc;
+  const double t_seen = g_ht.on ? svo_now() : 0.0;
 #ifdef GN_STAMP  // measurement build: phases of the BA launch in the loop (10 ns ticks), averaged under VO_SVO_TRACE
   {
     static const bool trace = getenv("VO_SVO_TRACE") != nullptr;
@@ -524,6 +541,18 @@ extern "C" int vo_svo_result(vo_svo *s, vo_svo_frame_info *info) {
   memcpy(s->T_wp, T_wc, sizeof(T_wc));
   memcpy(I.T_wc, T_wc, sizeof(T_wc));
   if (info) *info = I;
+  if (g_ht.on) {
+    g_ht.t_ret = svo_now();
+    if (!I.is_keyframe) {
+      g_ht.acc[3] += t_seen - t_in;
+      g_ht.acc[4] += g_ht.t_ret - t_seen;
+      ++g_ht.n;
+    }
+    if (g_ht.n > 0 && g_ht.n % 200 == 0 && !I.is_keyframe)
+      fprintf(stderr, "[svo host] per frame (us): caller between result and enqueue %.1f  enqueue %.1f  prefetch %.1f  waiting in result %.1f  "
+                      "rest of result (ordinary frames) %.1f\n",
+              1e6 * g_ht.acc[0] / g_ht.n, 1e6 * g_ht.acc[1] / g_ht.n, 1e6 * g_ht.acc[2] / g_ht.n, 1e6 * g_ht.acc[3] / g_ht.n, 1e6 * g_ht.acc[4] / g_ht.n);
+  }
   return VO_OK;
 }
 
