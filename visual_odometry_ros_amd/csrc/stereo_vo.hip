@@ -274,7 +274,7 @@ namespace {
 struct SvoHostTrace {
   bool on = getenv("VO_SVO_TRACE") != nullptr;
   double t_ret = 0, acc[5] = {0, 0, 0, 0, 0};  // caller between result and enqueue, enqueue, prefetch, wait in result, rest of result
-  int n = 0;
+  int n = 0, n_all = 0;  // ordinary frames, all steady-state frames
 } g_ht;
 }  // namespace
 
@@ -543,6 +543,7 @@ extern "C" int vo_svo_result(vo_svo *s, vo_svo_frame_info *info) {
   if (info) *info = I;
   if (g_ht.on) {
     g_ht.t_ret = svo_now();
+    ++g_ht.n_all;
     if (!I.is_keyframe) {
       g_ht.acc[3] += t_seen - t_in;
       g_ht.acc[4] += g_ht.t_ret - t_seen;
@@ -551,7 +552,8 @@ extern "C" int vo_svo_result(vo_svo *s, vo_svo_frame_info *info) {
     if (g_ht.n > 0 && g_ht.n % 200 == 0 && !I.is_keyframe)
       fprintf(stderr, "[svo host] per frame (us): caller between result and enqueue %.1f  enqueue %.1f  prefetch %.1f  waiting in result %.1f  "
                       "rest of result (ordinary frames) %.1f\n",
-              1e6 * g_ht.acc[0] / g_ht.n, 1e6 * g_ht.acc[1] / g_ht.n, 1e6 * g_ht.acc[2] / g_ht.n, 1e6 * g_ht.acc[3] / g_ht.n, 1e6 * g_ht.acc[4] / g_ht.n);
+              1e6 * g_ht.acc[0] / g_ht.n_all, 1e6 * g_ht.acc[1] / g_ht.n_all, 1e6 * g_ht.acc[2] / g_ht.n_all, 1e6 * g_ht.acc[3] / g_ht.n,
+              1e6 * g_ht.acc[4] / g_ht.n);
   }
   return VO_OK;
 }
