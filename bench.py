@@ -88,7 +88,7 @@ def frame_kernel_bytes(win, n, n_l0l1, n_step5, n_cand, levels, levels_bwd, stri
     return klt + IC_BYTES_8D * n_l0l1, (IC_RECORD_BYTES * n if strict else 0) + POINT_IO_BYTES * (n + n_cand)
 
 
-def stamped_counters(config):
+def stamped_counters(config, workload="loop"):
     """HBM traffic (PMC) and VALU instruction counts (SQ) of the dominant kernel from the committed rocprofv3 counter
     passes — quoted only while the kernel's sources still hash to what the passes ran on (a stale file is dropped)."""
     out = {"traffic": None, "valu_wave_instructions_per_launch": None, "counters_note": None}
@@ -97,7 +97,7 @@ def stamped_counters(config):
         sha = kernel_source_sha()
     except Exception:
         return out
-    tag = "r03" if config == 1 else f"r03_cfg{config}"
+    tag = ("r03" if config == 1 else f"r03_cfg{config}") + ("" if workload == "loop" else f"_{workload}")
     stale = []
     for key, name in (("pmc", f"{tag}_frame_pmc.json"), ("sq", f"{tag}_frame_sq_counters.json")):
         path = os.path.join(ROOT, "profiles", name)
@@ -120,6 +120,22 @@ def stamped_counters(config):
     if stale:
         out["counters_note"] = "stale (kernel sources changed since the counter pass): " + ", ".join(stale)
     return out
+
+
+def issue_roofline(counters, klt_ms, launches):
+    """The roofline that binds: VALU wave-instructions per launch (counter pass) / live launch duration against the chip's
+    issue rate — a SIMD issues one wave64 VALU instruction per 4 cycles: 256 CUs x 4 SIMDs x clk / 4 per second."""
+    if not counters["valu_wave_instructions_per_launch"]:
+        return None
+    clk = 2.4e9
+    peak_issue = 256 * 4 * clk / 4.0
+    ach_issue = counters["valu_wave_instructions_per_launch"] / (klt_ms / launches * 1e-3)
+    return {"bound": "valu_issue", "achieved": round(ach_issue / 1e9, 1), "peak": round(peak_issue / 1e9, 1),
+            "unit": "G wave-instructions/s", "frac": round(ach_issue / peak_issue, 4),
+            "valu_wave_instructions_per_launch": counters["valu_wave_instructions_per_launch"],
+            "note": "VALU wave-instructions per launch (rocprofv3 SQ_INSTS_VALU, committed counter pass on the same kernel "
+                    "sources) / live launch duration, against 1024 SIMDs x 2.4 GHz / 4; the launch is issue-bound while the "
+                    "SIMDs are full and then waits for single wavefronts (DESIGN.md §4.2)"}
 
 
 # ---- the one collective --------------------------------------------------------------------------------------------
@@ -626,18 +642,7 @@ def run_loop(cfg, args, rank, local_rank, world, torch, V, barrier, dev, imgs, s
     achieved = ((b_req + b_spec) / launches) / (klt_ms / launches * 1e-3) / 1e9 if klt_n else 0.0
     achieved_req = (b_req / launches) / (klt_ms / launches * 1e-3) / 1e9 if klt_n else 0.0
     counters = stamped_counters(args.config)
-    issue = None
-    if counters["valu_wave_instructions_per_launch"] and klt_n:
-        # a SIMD issues one wave64 VALU instruction per 4 cycles: 256 CUs x 4 SIMDs x clk / 4 wave-instructions per second
-        clk = 2.4e9
-        peak_issue = 256 * 4 * clk / 4.0
-        ach_issue = counters["valu_wave_instructions_per_launch"] / (klt_ms / launches * 1e-3)
-        issue = {"bound": "valu_issue", "achieved": round(ach_issue / 1e9, 1), "peak": round(peak_issue / 1e9, 1),
-                 "unit": "G wave-instructions/s", "frac": round(ach_issue / peak_issue, 4),
-                 "valu_wave_instructions_per_launch": counters["valu_wave_instructions_per_launch"],
-                 "note": "VALU wave-instructions per launch (rocprofv3 SQ_INSTS_VALU, committed counter pass on the same kernel "
-                         "sources) / live launch duration, against 1024 SIMDs x 2.4 GHz / 4; the launch is issue-bound while the "
-                         "SIMDs are full and then waits for single wavefronts (DESIGN.md §4.2)"}
+    issue = issue_roofline(counters, klt_ms, launches) if klt_n else None
     # trajectory against the renderer's ground truth (frame 0 = identity)
     T0i = np.linalg.inv(poses_gt[0])
     gt = np.stack([(T0i @ p)[:3, 3] for p in poses_gt[:len(traj)]])
@@ -1011,15 +1016,9 @@ def run_stereo(cfg, args, rank, local_rank, world, torch, V, barrier, dev, secon
     klt_n, klt_ms = ctx.profile_get(1)
     launches = max(klt_n, 1)
     achieved = (acc["b8d"] / launches) / (klt_ms / launches * 1e-3) / 1e9 if klt_n else 0.0
-    traffic = None
-    for name in ("r02_frame_pmc.json", "r01_frame_pmc.json"):
-        pmc_path = os.path.join(ROOT, "profiles", name)
-        if args.config == 1 and os.path.exists(pmc_path):
-            try:
-                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
-                break
-            except Exception:
-                traffic = None
+    # (counter passes of THIS workload on the present kernel sources, or nothing: profiles/r03[_cfgN]_closed_*.json)
+    counters = stamped_counters(args.config, "closed") if mode == "closed" else stamped_counters(0, "none")
+    traffic = counters["traffic"]
     step10 = {"closed": "closed on the device: per-bucket best keypoints detected from the image alone on the side stream, "
                         "every bucket's candidate tracked inside the frame kernel, updateWeightBin + emission behind the BA",
               "sequential": "three host-driven operator calls after the frame's result",
@@ -1066,8 +1065,11 @@ def run_stereo(cfg, args, rank, local_rank, world, torch, V, barrier, dev, secon
             "note": "achieved = survey_8d bytes / launch duration (HIP events, live); the path is issue/latency-bound, "
                     "the fraction is reported because the metric asks for it (DESIGN.md §6)",
         },
+        "roofline_issue": issue_roofline(counters, klt_ms, launches) if klt_n else None,
         "per_rank_fps": [round(p[0] / p[1], 2) for p in per_rank],
     }
+    if counters.get("counters_note"):
+        out["roofline"]["counters_note"] = counters["counters_note"]
     if all_classes:
         names = {0: "pyramid", 1: "frame_track", 2: "ic_replay", 3: "gn_pose", 4: "hamming", 5: "aux"}
         out["kernels"] = {}
