@@ -395,6 +395,9 @@ typedef struct {
   int local_ba;             /* != 0: localBundleAdjustmentSparseSolver_Stereo at every keyframe (the reference's behaviour);
                                landmark table, keyframe window and the BA problem live on the device (about 90 MB per
                                StereoVO), the window may span at most 2^19 landmark ids (VO_ERR_CAPACITY beyond) */
+  int rectify;              /* != 0: flagDoUndistortion (stereo_vo.cpp:414-427) — every incoming pair goes through the
+                               context's stereo rectification maps (vo_rectify_init_stereo / vo_rectify_set_maps first) on
+                               its way into the pyramids; frame.Kl / Kr / T_lr are then the RECTIFIED camera and extrinsics */
 } vo_svo_params;
 typedef struct {
   int frame_id;             /* id of the left Frame of this pair (the right one is frame_id + 1, frame.cpp:176-180) */

@@ -40,7 +40,10 @@ class StereoVORef:
 
     def __init__(self, width, height, Kl, Kr, T_lr, n_bins_u, n_bins_v, thres_fast=15, win=21, max_level=6, thres_err=80.0,
                  thres_bidir=0.5, thres_poseba=3.0, kf_overlap=0.6, kf_rot_deg=15.0, kf_trans=10.0, kf_window=9, lba=True,
-                 ic_border=O.IC_REFERENCE, sum_mode=O.SUM_SEQ, tree_width=0, n_threads=1):
+                 ic_border=O.IC_REFERENCE, sum_mode=O.SUM_SEQ, tree_width=0, n_threads=1, rectify_maps=None):
+        """rectify_maps = ((map_u, map_v) of the left camera, (map_u, map_v) of the right one): flagDoUndistortion
+        (stereo_vo.cpp:414-421) — every pair is remapped first; Kl / Kr / T_lr are then the rectified camera."""
+        self.rectify_maps = rectify_maps
         self.W, self.H = width, height
         self.Kl, self.Kr = np.asarray(Kl, np.float32), np.asarray(Kr, np.float32)
         self.T_lr = np.asarray(T_lr, np.float32).reshape(4, 4)
@@ -87,6 +90,9 @@ class StereoVORef:
 
     # ---- one call of trackStereoImages -----------------------------------------------------------------------------
     def track(self, L, R):
+        if self.rectify_maps is not None:  # rectifyStereoImages + convertTo(CV_8UC1)
+            L = O.remap_linear_u8(L, *self.rectify_maps[0])
+            R = O.remap_linear_u8(R, *self.rectify_maps[1])
         fid_l, _ = self._new_frame_ids()
         info = dict(frame_id=fid_l, keyframe=False, lba=None)
         if self.first:

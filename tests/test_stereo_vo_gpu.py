@@ -151,6 +151,57 @@ def test_closed_loop_local_ba_landmark_table_wraps(vo, oracle):
     assert ref.ids.min() < 150 < ref.ids.max()  # live landmarks on both sides of the boundary at the end
 
 
+def test_closed_loop_with_rectification(vo, oracle):
+    """flagDoUndistortion (stereo_vo.cpp:414-427): raw cameras with lens distortion and a slightly rotated right camera;
+    every pair goes through the stereo rectification maps on its way into the pyramids (device images and host images),
+    the loop runs on the rectified camera — against the CPU loop fed with the CPU remap of the same pairs."""
+    from oracle.stereo_vo import StereoVORef
+    from util import DeviceBuffer
+    from visual_odometry_ros_amd import synthetic as S
+    W, H, K = 640, 240, (400.0, 400.0, 320.0, 120.0)
+    st, imgs = _stream(W, H, K, 20, 8, 9, 0.5, 9)
+    Kl = np.array(K, np.float32)
+    Kr = np.array([402.0, 401.0, 318.0, 121.0], np.float32)
+    Dl = np.array([-0.08, 0.02, 0.0005, -0.0004, 0.0], np.float32)
+    Dr = np.array([-0.07, 0.015, -0.0003, 0.0006, 0.0], np.float32)
+    T_lr = (st.T_lr.astype(np.float64) @ S.se3_exp([0, 0, 0, 0.004, -0.006, 0.003])).astype(np.float32)
+    m = oracle.stereo_rectify_maps(W, H, Kl, Dl, Kr, Dr, T_lr)
+    for on_device in (True, False):
+        ref = StereoVORef(W, H, m["K_rect"], m["K_rect"], m["T_lr_rect"], 20, 8, thres_fast=15, win=21, max_level=4, kf_trans=1.2,
+                          lba=True, sum_mode=oracle.SUM_TREE, tree_width=512, ic_border=oracle.IC_REFERENCE, n_threads=8,
+                          rectify_maps=(m["left"], m["right"]))
+        c = vo.Context(device=0, max_width=W, max_height=H, max_points=4096, n_slots=5, max_level=4)
+        try:
+            cam = vo.StereoCamera(c)
+            cam.initParams(W, H, Kl, Dl, Kr, Dr)
+            cam.setStereoPoseLeft2Right(T_lr)
+            cam.initStereoCameraToRectify()
+            assert np.array_equal(_bits(cam.K_rect), _bits(m["K_rect"])) and np.array_equal(_bits(cam.T_lr_rect), _bits(m["T_lr_rect"]))
+            svo = vo.StereoVO(c, W, H, cam.K_rect, cam.K_rect, cam.T_lr_rect, 20, 8, thres_fastscore=15, window_size=21, max_level=4,
+                              strict_border=4, local_ba=True, thres_trans=1.2, rectify=True)
+            keep = []
+            for k, (L, R) in enumerate(imgs):
+                if on_device:
+                    dL, dR = DeviceBuffer(L), DeviceBuffer(R)
+                    keep.append((dL, dR))
+                    gi = svo.trackStereoImages((dL.data_ptr(), W), (dR.data_ptr(), W))
+                else:
+                    gi = svo.trackStereoImages(L, R)
+                ref.track(L, R)
+                g = svo.getTracks()
+                where = f"frame {k}, device images {on_device}"
+                assert np.array_equal(g["ids"], ref.ids), where
+                assert np.array_equal(_bits(g["pts_l"]), _bits(ref.pts_l)) and np.array_equal(_bits(g["pts_r"]), _bits(ref.pts_r)), where
+                assert np.array_equal(_bits(np.array(gi.T_wc).reshape(4, 4)), _bits(ref.T_wp)), where
+            assert len(ref.ids) > 100
+            svo.close()
+            for dL, dR in keep:
+                dL.free()
+                dR.free()
+        finally:
+            c.close()
+
+
 def test_closed_loop_survives_a_join_timeout():
     """The loop in strict-border mode 3 with a device-side join that cannot be met (VO_DEBUG_FAIL_JOIN, fresh child process):
     the first steady-state frame is issued again with the stream-ordered replay — and with it the DLT workers and the

@@ -71,7 +71,7 @@ class SbaProblem(C.Structure):
 class SvoParams(C.Structure):
     _fields_ = [("frame", StereoParams), ("bins", BinParams), ("kf_overlap_ratio", C.c_float),
                 ("kf_rotation_deg", C.c_float), ("kf_translation", C.c_float), ("kf_window", C.c_int),
-                ("strict_border", C.c_int), ("local_ba", C.c_int)]
+                ("strict_border", C.c_int), ("local_ba", C.c_int), ("rectify", C.c_int)]
 
 
 class SvoFrameInfo(C.Structure):

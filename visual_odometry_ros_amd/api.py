@@ -749,7 +749,10 @@ class StereoVO:
 
     def __init__(self, ctx, width, height, Kl, Kr, T_lr, n_bins_u, n_bins_v, thres_fastscore=15, window_size=21, max_level=6,
                  thres_error=80.0, thres_bidirection=0.5, thres_poseba_error=3.0, thres_alive_ratio=0.6, thres_rotation=15.0,
-                 thres_trans=10.0, n_max_keyframes_in_window=9, strict_border=4, local_ba=True):
+                 thres_trans=10.0, n_max_keyframes_in_window=9, strict_border=4, local_ba=True, rectify=False):
+        """rectify=True is system_flags_.flagDoUndistortion: the context's stereo rectification maps (StereoCamera.
+        initStereoCameraToRectify on the same context) are applied to every incoming pair; Kl / Kr / T_lr are then the
+        rectified camera and extrinsics (getRectifiedCamera / getRectifiedStereoPoseLeft2Right)."""
         self.ctx, self.lib = ctx, ctx.lib
         fe = FeatureExtractor(ctx)
         fe.initParams(width, height, n_bins_u, n_bins_v, THRES_FAST=thres_fastscore)
@@ -759,6 +762,7 @@ class StereoVO:
         p.bins = fe.binParams()
         p.kf_overlap_ratio, p.kf_rotation_deg, p.kf_translation = thres_alive_ratio, thres_rotation, thres_trans
         p.kf_window, p.strict_border, p.local_ba = n_max_keyframes_in_window, int(strict_border), int(bool(local_ba))
+        p.rectify = int(bool(rectify))
         self.prm, self.width, self.height = p, width, height
         self._h = C.c_void_p()
         ctx.check(self.lib.vo_svo_create(ctx.handle, C.byref(p), C.byref(self._h)))

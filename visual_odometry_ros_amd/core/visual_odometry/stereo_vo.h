@@ -46,6 +46,11 @@ struct StereoVOParams {
     float thres_rotation = 3.0f;  // DEGREES as in the YAML (the reference multiplies by D2R in its constructor)
     int n_max_keyframes_in_window = 9;
   } keyframe_update;
+  // system_flags_.flagDoUndistortion (stereo_vo.cpp:239, :414-427): Kl / Kr / T_lr above are then the RAW cameras with the
+  // distortion below (k1, k2, p1, p2, k3); the constructor makes the rectification maps on the context
+  // (StereoCamera::initStereoCameraToRectify) and the loop runs on getRectifiedCamera / getRectifiedStereoPoseLeft2Right
+  bool flagDoUndistortion = false;
+  float Dl[5] = {0, 0, 0, 0, 0}, Dr[5] = {0, 0, 0, 0, 0};
   // not in the reference
   int strict_border = 4;        // vo_stereo_frame_set_strict_border
   bool local_ba = true;         // localBundleAdjustmentSparseSolver_Stereo at keyframes (the reference always does)
@@ -88,6 +93,13 @@ class StereoVO {
       q.frame.Kr[k] = p.Kr[k];
     }
     for (int k = 0; k < 16; ++k) q.frame.T_lr[k] = p.T_lr[(size_t)k];
+    if (p.flagDoUndistortion) {
+      float K_rect[4], T_lr_rect[16];
+      ctx_->check(vo_rectify_init_stereo(ctx_->get(), p.width, p.height, p.Kl, p.Dl, p.Kr, p.Dr, q.frame.T_lr, K_rect, T_lr_rect, nullptr));
+      for (int k = 0; k < 4; ++k) q.frame.Kl[k] = q.frame.Kr[k] = K_rect[k];
+      for (int k = 0; k < 16; ++k) q.frame.T_lr[k] = T_lr_rect[k];
+      q.rectify = 1;
+    }
     // FeatureExtractor::initParams -> WeightBin::init (feature_extractor.h:90-118, feature_extractor.cpp:48-56)
     q.bins.n_bins_u = p.feature_extractor.n_bins_u;
     q.bins.n_bins_v = p.feature_extractor.n_bins_v;

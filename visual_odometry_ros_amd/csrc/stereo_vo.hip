@@ -282,10 +282,19 @@ struct SvoHostTrace {
 static int svo_ingest(vo_svo *s, const void *left, const void *right, int stride, int on_device) {
   vo_ctx *c = s->c;
   const int W = s->prm.frame.width, H = s->prm.frame.height;
-  if (on_device)
+  if (s->prm.rectify) {
+    // flagDoUndistortion (stereo_vo.cpp:414-421): rectifyStereoImages + convertTo(CV_8UC1), fused into the pyramid build
+    if (on_device) {
+      RC(vo_set_stereo_pair_rectified_device(c, s->slot[S_NL], left, s->slot[S_NR], right, W, H, stride));
+    } else {
+      RC(vo_set_image_rectified(c, s->slot[S_NL], (const uint8_t *)left, W, H, stride, 0));
+      RC(vo_set_image_rectified(c, s->slot[S_NR], (const uint8_t *)right, W, H, stride, 1));
+    }
+  } else if (on_device) {
     RC(vo_set_stereo_pair_device(c, s->slot[S_NL], left, s->slot[S_NR], right, W, H, stride));
-  else
+  } else {
     RC(vo_set_stereo_pair_host_async(c, s->slot[S_NL], (const uint8_t *)left, s->slot[S_NR], (const uint8_t *)right, W, H, stride));
+  }
   RC(vo_new_point_candidates_enqueue(c, s->slot[S_NL], &s->prm.bins, s->tab_next));
   return VO_OK;
 }
