@@ -393,8 +393,9 @@ typedef struct {
   int kf_window;            /* keyframe_update.n_max_keyframes_in_window (with local_ba: at most 16) */
   int strict_border;        /* vo_stereo_frame_set_strict_border */
   int local_ba;             /* != 0: localBundleAdjustmentSparseSolver_Stereo at every keyframe (the reference's behaviour);
-                               landmark table, keyframe window and the BA problem live on the device (about 90 MB per
-                               StereoVO), the window may span at most 2^19 landmark ids (VO_ERR_CAPACITY beyond) */
+                               the window may span at most 2^19 landmark ids (VO_ERR_CAPACITY beyond). Landmark table,
+                               keyframe window and the BA problem live on the device (about 90 MB per StereoVO from the
+                               first keyframe on, with or without the local BA: the table also serves stats_keyframe) */
   int rectify;              /* != 0: flagDoUndistortion (stereo_vo.cpp:414-427) — every incoming pair goes through the
                                context's stereo rectification maps (vo_rectify_init_stereo / vo_rectify_set_maps first) on
                                its way into the pyramids; frame.Kl / Kr / T_lr are then the RECTIFIED camera and extrinsics */
@@ -458,6 +459,13 @@ void vo_batch_destroy(vo_batch *batch);
 const char *vo_batch_last_error(const vo_batch *batch);
 int vo_batch_run(vo_batch *batch, const void *const *left, const void *const *right, int n_frames, int stride, int on_device,
                  int warmup, float *T_wc, int32_t *last_ids, int ids_cap, int *n_ids, double *seconds, double *wall);
+
+/* AlgorithmStatistics::stats_keyframe as trackStereoImages refreshes it at every keyframe (stereo_vo.cpp:805-821; read by
+ * the ROS 2 node for its trajectory and map-point topics, ros2/visual_odometry/stereo_vo_ros2.cpp:141-166): every
+ * keyframe so far, j = 0 .. count-1, with its CURRENT pose and the current 3-D points of its related landmarks (the local
+ * BA keeps changing both). mappoints may be NULL (count only); cap = room for that many points. */
+int vo_svo_keyframe_count(vo_svo *svo, int *n_keyframes);
+int vo_svo_get_keyframe(vo_svo *svo, int j, float T_wc[16], float *mappoints, int cap, int *n_points);
 
 /* ---- undistortion / stereo rectification in front of the trackers ----------
  * core/visual_odometry/camera.cpp. A context holds the maps of two cameras

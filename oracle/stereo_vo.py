@@ -67,6 +67,7 @@ class StereoVORef:
         self.pts_l, self.pts_r = np.zeros((0, 2), np.float32), np.zeros((0, 2), np.float32)
         self.Xw, self.flags = np.zeros((0, 3), np.float32), np.zeros(0, np.uint8)
         self.keyframes = []   # window: dict(serial, frame_id, T_wc, ids, pts_l, pts_r)
+        self.all_keyframes = []  # all_stkeyframes_: the same dicts, never dropped
         self.n_keyframes = 0  # all keyframes ever
         self.n_kf_lms = 0
         self.lm = {}          # landmarks seen on a keyframe: id -> dict(X, tri, alive, obs=[(serial, pl, pr)])
@@ -195,6 +196,7 @@ class StereoVORef:
             if len(self.keyframes) == self.kf_window:
                 self.keyframes.pop(0)
             self.keyframes.append(kf)
+            self.all_keyframes.append(kf)
             self.n_kf_lms = int(ids.shape[0])
             for k in range(ids.shape[0]):  # the landmark table: state as of this keyframe + the observation on it
                 e = self.lm.setdefault(int(ids[k]), dict(X=None, tri=False, alive=True, obs=[]))
@@ -213,6 +215,15 @@ class StereoVORef:
         self.ids, self.pts_l, self.pts_r, self.Xw, self.flags = ids, pl, pr, Xw, fl
         self.T_wp = T_wc
         info["n_tracks"] = int(ids.shape[0])
+
+    def keyframe_stats(self):
+        """AlgorithmStatistics::stats_keyframe as trackStereoImages refreshes it at every keyframe (stereo_vo.cpp:805-821):
+        every keyframe so far with its CURRENT pose and the current 3-D points of its related landmarks."""
+        out = []
+        for kf in self.all_keyframes:
+            X = [self.lm[int(i)]["X"] for i in kf["ids"]]
+            out.append((kf["T_wc"].copy(), np.stack(X).astype(np.float32) if X else np.zeros((0, 3), np.float32)))
+        return out
 
     # ---- local BA over the keyframe window ---------------------------------------------------------------------
     def lba_problem(self):

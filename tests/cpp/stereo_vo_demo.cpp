@@ -3,7 +3,8 @@
 // non-zero prefetch flag the pairs are handed over one frame ahead (enqueue / prefetch / result).
 // Input (argv[1]): int32 n_frames, w, h, n_bins_u, n_bins_v, win, max_level, prefetch, local_ba; float K[4], T_lr[16],
 // thres_error, thres_bidirection, thres_poseba, thres_alive_ratio, thres_trans, thres_rotation; then n_frames x (left, right).
-// Output (argv[2]): per frame: int32 frame_id, is_keyframe, n_tracks_out, lba_ran; float T_wc[16]. argv[3]: trajectory file.
+// Output (argv[2]): per frame: int32 frame_id, is_keyframe, n_tracks_out, lba_ran; float T_wc[16]; then stats_keyframe as the
+// ROS 2 node reads it: int32 n_keyframes, per keyframe float Twc[16], int32 n_points, float mappoints[n][3]. argv[3]: trajectory file.
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -42,6 +43,7 @@ int main(int argc, char **argv) {
   p.keyframe_update.thres_trans = fl[24];
   p.keyframe_update.thres_rotation = fl[25];
   p.local_ba = hdr[8] != 0;
+  p.keyframe_statistics = true;  // (the reference's behaviour: rewritten at every keyframe)
   p.trajectory_path = argv[3];
   const bool prefetch = hdr[7] != 0;
   FILE *o = fopen(argv[2], "wb");
@@ -64,6 +66,16 @@ int main(int argc, char **argv) {
       fwrite(svo.getStatistics().stats_frame.back().Twc.data(), sizeof(float), 16, o);
     }
     if ((int)svo.getStatistics().stats_execution.size() != n || (int)svo.getStatistics().stats_landmark.size() != n) return 3;  // F12
+    svo.refreshKeyframeStatistics();  // (the frames since the last keyframe changed nothing; the call must agree with what is there)
+    const auto &kfs = svo.getStatistics().stats_keyframe;
+    const int nk = (int)kfs.size();
+    fwrite(&nk, sizeof(int), 1, o);
+    for (const auto &k : kfs) {
+      const int np = (int)k.mappoints.size();
+      fwrite(k.Twc.data(), sizeof(float), 16, o);
+      fwrite(&np, sizeof(int), 1, o);
+      if (np) fwrite(k.mappoints.data(), sizeof(float), 3 * (size_t)np, o);
+    }
   } catch (const std::exception &e) {
     fprintf(stderr, "stereo_vo_demo: %s\n", e.what());
     fclose(o);

@@ -222,7 +222,8 @@ def test_cpp_stereo_vo_writes_the_python_loops_trajectory(vo, tmp_path):
             f.write(np.ascontiguousarray(L).tobytes())
             f.write(np.ascontiguousarray(R).tobytes())
     subprocess.check_call([exe, str(inp), str(outp), str(traj)])
-    raw = np.fromfile(outp, np.uint8).reshape(n, 16 + 64)
+    blob = np.fromfile(outp, np.uint8)
+    raw, tail = blob[:n * 80].reshape(n, 16 + 64), blob[n * 80:].tobytes()
     rec = raw[:, :16].copy().view(np.int32)
     T_cpp = raw[:, 16:].copy().view(np.float32).reshape(n, 4, 4)
     c = vo.Context(device=0, max_width=W, max_height=H, max_points=4096, n_slots=5, max_level=4)
@@ -235,6 +236,16 @@ def test_cpp_stereo_vo_writes_the_python_loops_trajectory(vo, tmp_path):
         assert np.array_equal(T.view(np.uint32), T_cpp[k].view(np.uint32)), k
         ids.append(i.frame_id)
         Ts.append(T)
+    # stats_keyframe (what the ROS 2 node publishes): the C++ class's against the Python mirror's, byte for byte
+    kfs = svo.getKeyframes()
+    (nk,), off = struct.unpack_from("i", tail, 0), 4
+    assert nk == len(kfs) >= 5
+    for T, X in kfs:
+        T_c = np.frombuffer(tail, np.float32, 16, off).reshape(4, 4); off += 64
+        (m,) = struct.unpack_from("i", tail, off); off += 4
+        X_c = np.frombuffer(tail, np.float32, 3 * m, off).reshape(m, 3); off += 12 * m
+        assert np.array_equal(T_c.view(np.uint32), T.view(np.uint32)) and np.array_equal(X_c.view(np.uint32), X.view(np.uint32))
+    assert off == len(tail)
     svo.close()
     c.close()
     assert rec[:, 3].sum() >= 3 and rec[:, 1].sum() >= 5

@@ -82,6 +82,11 @@ def _run_both(vo, oracle, W, H, K, nu, nv, frames, win, lvl, n_frames, lba, stri
                 assert np.array_equal(_bits(npg["pts_l"]), _bits(ri["cand"])) and np.array_equal(npg["accept"], ri["accept"]), where
                 assert np.array_equal(npg["mask_new"], ri["mask_new"]), where
             log.append((bool(gi.is_keyframe), gi.n_tracks_out, bool(gi.lba_ran), int(gi.lba_landmarks)))
+            if gi.is_keyframe or k == n_frames - 1:  # stats_keyframe: every keyframe's current pose and map points
+                gk, rk = svo.getKeyframes(), ref.keyframe_stats()
+                assert len(gk) == len(rk), where
+                for j, ((Tg, Xg), (Tr, Xr)) in enumerate(zip(gk, rk)):
+                    assert np.array_equal(_bits(Tg), _bits(Tr)) and np.array_equal(_bits(Xg), _bits(Xr)), (where, j)
         svo.close()
         return log, ref
     finally:

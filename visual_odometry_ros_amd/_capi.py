@@ -74,6 +74,7 @@ class SvoParams(C.Structure):
                 ("strict_border", C.c_int), ("local_ba", C.c_int), ("rectify", C.c_int)]
 
 
+
 class SvoFrameInfo(C.Structure):
     _fields_ = [("frame_id", C.c_int), ("is_first", C.c_int), ("is_keyframe", C.c_int), ("lba_ran", C.c_int),
                 ("n_tracks_in", C.c_int), ("n_final", C.c_int), ("n_new", C.c_int), ("n_tracks_out", C.c_int),
@@ -101,7 +102,7 @@ SYMBOLS = [
     "vo_set_ingest_side_stream", "vo_set_stereo_pair_host_async", "vo_new_point_candidates_enqueue",
     "vo_new_point_candidates_get", "vo_stereo_frame_enqueue_closed", "vo_stereo_frame_new_points",
     "vo_stereo_frame_enqueue_closed_world", "vo_stereo_frame_recoveries", "vo_svo_create", "vo_svo_destroy", "vo_svo_track", "vo_svo_enqueue",
-    "vo_svo_prefetch", "vo_svo_result", "vo_svo_get_tracks", "vo_svo_get_new_points", "vo_triangulate_dlt", "vo_batch_create", "vo_batch_destroy",
+    "vo_svo_prefetch", "vo_svo_result", "vo_svo_get_tracks", "vo_svo_get_new_points", "vo_svo_keyframe_count", "vo_svo_get_keyframe", "vo_triangulate_dlt", "vo_batch_create", "vo_batch_destroy",
     "vo_batch_last_error", "vo_batch_run",
     "vo_se3_exp", "vo_ids_reset", "vo_ids_peek", "vo_ids_new_frames", "vo_ids_new_landmarks", "vo_compact_tracks",
 ]
@@ -150,6 +151,8 @@ def load():
     lib.vo_svo_result.argtypes = [vp, C.POINTER(SvoFrameInfo)]
     lib.vo_svo_get_tracks.argtypes = [vp, vp, vp, vp, vp, vp, ci, vp]
     lib.vo_svo_get_new_points.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.vo_svo_keyframe_count.argtypes = [vp, vp]
+    lib.vo_svo_get_keyframe.argtypes = [vp, ci, vp, vp, ci, vp]
     lib.vo_triangulate_dlt.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp]
     lib.vo_batch_create.argtypes = [C.POINTER(VoConfig), C.POINTER(SvoParams), ci, C.POINTER(C.c_void_p)]
     lib.vo_batch_destroy.argtypes = [vp]

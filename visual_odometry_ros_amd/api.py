@@ -846,8 +846,23 @@ class StereoVO:
         k = n.value
         return dict(pts_l=pl[:k], pts_r=pr[:k], mask_new=m[:k].astype(bool), accept=a[:k].astype(bool))
 
+    def getKeyframes(self):
+        """AlgorithmStatistics::stats_keyframe as of now (stereo_vo.cpp:805-821): [(T_wc, mappoints [n][3])] for every
+        keyframe so far — current poses, current 3-D points of the related landmarks."""
+        n = C.c_int()
+        self.ctx.check(self.lib.vo_svo_keyframe_count(self._h, C.addressof(n)))
+        out = []
+        for j in range(n.value):
+            T, m = np.zeros(16, np.float32), C.c_int()
+            self.ctx.check(self.lib.vo_svo_get_keyframe(self._h, j, T.ctypes.data, None, 0, C.addressof(m)))
+            X = np.zeros((max(m.value, 1), 3), np.float32)
+            if m.value:
+                self.ctx.check(self.lib.vo_svo_get_keyframe(self._h, j, None, X.ctypes.data, m.value, C.addressof(m)))
+            out.append((T.reshape(4, 4), X[:m.value]))
+        return out
+
     def getStatistics(self):
-        return dict(stats_frame=[T.copy() for T in self.stats_frame])
+        return dict(stats_frame=[T.copy() for T in self.stats_frame], stats_keyframe=self.getKeyframes())
 
 
 class StereoBatch:

@@ -345,11 +345,17 @@ class StereoVO {
     };
     using LandmarkStatistics = vo::StereoVO::AlgorithmStatistics::LandmarkStatistics;
     using ExecutionStatistics = vo::StereoVO::AlgorithmStatistics::ExecutionStatistics;
+    struct KeyframeStatistics {  // stereo_vo_ros2.cpp:141-166: keyframe trajectory and map-point cloud
+      PoseSE3 Twc;
+      PointVec mappoints;
+    };
     std::vector<LandmarkStatistics> stats_landmark;
     std::vector<FrameStatistics> stats_frame;
+    std::vector<KeyframeStatistics> stats_keyframe;
     std::vector<ExecutionStatistics> stats_execution;
   };
 
+  // (vo::StereoVOParams::keyframe_statistics = true gives the reference's behaviour: stats_keyframe rewritten at every keyframe)
   explicit StereoVO(const vo::StereoVOParams &p, int device = 0)
       : ctx_(std::make_shared<vo::Context>(device, p.width, p.height,
                                            2 * p.feature_extractor.n_bins_u * p.feature_extractor.n_bins_v + 1024, 5,
@@ -368,6 +374,16 @@ class StereoVO {
     stat_.stats_frame.push_back(f);
     stat_.stats_landmark.push_back(s.stats_landmark.back());
     stat_.stats_execution.push_back(s.stats_execution.back());
+    if (impl_.lastFrameInfo().is_keyframe && !s.stats_keyframe.empty()) {  // (filled by the implementation when asked for)
+      stat_.stats_keyframe.resize(s.stats_keyframe.size());
+      for (size_t j = 0; j < s.stats_keyframe.size(); ++j) {
+        vo_adapter::from_row_major(s.stats_keyframe[j].Twc, stat_.stats_keyframe[j].Twc);
+        stat_.stats_keyframe[j].mappoints.resize(s.stats_keyframe[j].mappoints.size());
+        for (size_t i = 0; i < s.stats_keyframe[j].mappoints.size(); ++i)
+          stat_.stats_keyframe[j].mappoints[i] = Point(s.stats_keyframe[j].mappoints[i].x, s.stats_keyframe[j].mappoints[i].y,
+                                                       s.stats_keyframe[j].mappoints[i].z);
+      }
+    }
   }
   const AlgorithmStatistics &getStatistics() const { return stat_; }
   const cv::Mat &getDebugImage() { return img_debug_; }

@@ -52,6 +52,10 @@ struct StereoVOParams {
   bool flagDoUndistortion = false;
   float Dl[5] = {0, 0, 0, 0, 0}, Dr[5] = {0, 0, 0, 0, 0};
   // not in the reference
+  // stats_keyframe: the reference rewrites EVERY keyframe's pose and map points at every keyframe (stereo_vo.cpp:805-821,
+  // a cost that grows with the length of the run). true: the same here (one gather + copy per keyframe so far, at every
+  // keyframe); false: stats_keyframe stays empty and refreshKeyframeStatistics() fills it when the caller wants it
+  bool keyframe_statistics = false;
   int strict_border = 4;        // vo_stereo_frame_set_strict_border
   bool local_ba = true;         // localBundleAdjustmentSparseSolver_Stereo at keyframes (the reference always does)
   std::string trajectory_path;  // F9: non-empty = write the frame poses there on destruction (the reference's format)
@@ -73,6 +77,11 @@ class StereoVO {
     struct ExecutionStatistics {
       float time_track = 0.0f, time_1p = 0.0f, time_5p = 0.0f, time_localba = 0.0f, time_new = 0.0f, time_total = 0.0f;  // [ms]
     };
+    struct KeyframeStatistics {  // what the ROS 2 node publishes as trajectory and map points (stereo_vo_ros2.cpp:141-166)
+      PoseSE3 Twc;
+      PointVec mappoints;
+    };
+    std::vector<KeyframeStatistics> stats_keyframe;
     std::vector<LandmarkStatistics> stats_landmark;
     std::vector<FrameStatistics> stats_frame;
     std::vector<ExecutionStatistics> stats_execution;
@@ -163,6 +172,19 @@ class StereoVO {
   }
 
   const AlgorithmStatistics &getStatistics() const { return stat_; }
+  // stats_keyframe as of now: every keyframe's current pose and the current 3-D points of its related landmarks
+  void refreshKeyframeStatistics() {
+    int nk = 0;
+    ctx_->check(vo_svo_keyframe_count(svo_, &nk));
+    stat_.stats_keyframe.resize((size_t)nk);
+    for (int j = 0; j < nk; ++j) {
+      AlgorithmStatistics::KeyframeStatistics &k = stat_.stats_keyframe[(size_t)j];
+      int n = 0;
+      ctx_->check(vo_svo_get_keyframe(svo_, j, k.Twc.data(), nullptr, 0, &n));
+      k.mappoints.resize((size_t)n);
+      if (n) ctx_->check(vo_svo_get_keyframe(svo_, j, nullptr, reinterpret_cast<float *>(k.mappoints.data()), n, &n));
+    }
+  }
   const vo_svo_frame_info &lastFrameInfo() const { return last_; }
   // stframe_prev_'s tracked pixels and landmarks (ids, flags: VO_LM_*), for inspection
   void getTracks(std::vector<std::int32_t> &ids, PixelVec &pts_l, PixelVec &pts_r, PointVec &Xw, std::vector<std::uint8_t> &flags) {
@@ -209,6 +231,7 @@ class StereoVO {
     AlgorithmStatistics::ExecutionStatistics e;
     e.time_total = e.time_track = ms;
     stat_.stats_execution.push_back(e);
+    if (prm_.keyframe_statistics && info.is_keyframe) refreshKeyframeStatistics();
   }
 
   ContextPtr ctx_;

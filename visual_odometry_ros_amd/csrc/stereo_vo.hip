@@ -537,8 +537,8 @@ extern "C" int vo_svo_result(vo_svo *s, vo_svo_frame_info *info) {
     if ((int)s->keyframes.size() == s->prm.kf_window) s->keyframes.erase(s->keyframes.begin());
     s->keyframes.push_back(kf);
     s->n_kf_lms = h.n_next;
-    if (s->prm.local_ba) {
-      s->cur = nxt;  // (the local BA reads and updates the track set the next frame starts from)
+    {
+      s->cur = nxt;  // (the keyframe bookkeeping and the local BA read and update the track set the next frame starts from)
       s->n = h.n_next;
       rc = vo_svo_local_ba(s, &I, h.id_min);
       if (rc < 0) return rc;

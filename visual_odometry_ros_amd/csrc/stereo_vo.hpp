@@ -11,8 +11,9 @@
 struct SvoKeyframe {
   int serial, frame_id;
   float T_wc[16];
-  // local BA on: the keyframe's related landmarks live in slot `ring` of the device-side keyframe ring (ids, pixels)
+  // the keyframe's related landmarks live in slot `ring` of the device-side keyframe ring (ids, pixels)
   int ring = 0, n = 0, id_min = 0;  // entries, smallest (= first) landmark id
+  int global = 0;                   // index among all keyframes of the stream (stats_keyframe)
 };
 
 struct vo_svo {
@@ -37,8 +38,16 @@ struct vo_svo {
   // keyframes
   std::vector<SvoKeyframe> keyframes;  // the window (stereo_kfs_list_)
   int n_keyframes = 0, n_kf_lms = 0;
-  // local BA on: landmark table, keyframe ring, window scratch and the solver's arena, all on the device (stereo_vo_lba.hip)
+  // landmark table, keyframe ring, window scratch and the solver's arena, all on the device (stereo_vo_lba.hip)
   struct vo_svo_lba *lba = nullptr;
+  // all_stkeyframes_ (stats_keyframe): every keyframe's current pose (host) and where its related landmarks' ids are kept
+  // on the device (a pool that only grows)
+  struct SvoKfAll {
+    float T_wc[16];
+    int n;
+    const int32_t *d_ids;
+  };
+  std::vector<SvoKfAll> kf_all;
 };
 
 int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info, int id_min);  // stereo_vo_lba.hip

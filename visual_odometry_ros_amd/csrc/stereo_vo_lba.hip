@@ -109,7 +109,7 @@ struct LbaProb {  // the problem inside the solver's arena (non-const views of S
 
 // the new keyframe: its related landmarks' state as of now (Landmark::set3DPoint / isTriangulated at keyframe time; a
 // dead landmark stays dead) and the keyframe's own copy of ids and pixels
-__global__ void lba_keyframe_kernel(SvoTrackSet ts, int n, LmTab tab, int32_t *kf_ids, float *kf_pl, float *kf_pr) {
+__global__ void lba_keyframe_kernel(SvoTrackSet ts, int n, LmTab tab, int32_t *kf_ids, float *kf_pl, float *kf_pr, int32_t *all_ids) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const int32_t id = ts.ids[k];
@@ -121,6 +121,7 @@ __global__ void lba_keyframe_kernel(SvoTrackSet ts, int n, LmTab tab, int32_t *k
   tab.S[t] = (uint8_t)(dead | ((ts.flags[k] & VO_LM_TRIANGULATED) ? 1 : 0));
   tab.tag[t] = id;
   kf_ids[k] = id;
+  all_ids[k] = id;  // (the keyframe's related landmarks, kept for good: stats_keyframe)
   kf_pl[2 * k] = ts.pts_l[2 * k];
   kf_pl[2 * k + 1] = ts.pts_l[2 * k + 1];
   kf_pr[2 * k] = ts.pts_r[2 * k];
@@ -387,7 +388,21 @@ __global__ void lba_refresh_kernel(SvoTrackSet ts, int n, LmTab tab) {
   ts.flags[k] = fl;
 }
 
+// stats_keyframe[j].mappoints: the CURRENT 3-D points of a keyframe's related landmarks (a slot taken over by a later id
+// — 2^21 landmarks on — reads as the origin)
+__global__ void lba_mappoints_kernel(const int32_t *ids, int n, LmTab tab, float *out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int32_t id = ids[k];
+  const int t = id & tab.mask;
+  const bool ok = tab.tag[t] == id;
+  out[3 * k] = ok ? tab.X[3 * (size_t)t] : 0.0f;
+  out[3 * k + 1] = ok ? tab.X[3 * (size_t)t + 1] : 0.0f;
+  out[3 * k + 2] = ok ? tab.X[3 * (size_t)t + 2] : 0.0f;
+}
+
 // ---- host side --------------------------------------------------------------------------------------------------------
+#define LBA_POOL_CHUNK ((size_t)4 << 20)  // ids per chunk of the all-keyframes pool (16 MB)
 struct vo_svo_lba {
   LmTab tab = {};
   int32_t *kf_ids[LBA_KW] = {};
@@ -397,6 +412,9 @@ struct vo_svo_lba {
   uint8_t *arena = nullptr;
   size_t arena_cap = 0;
   uint8_t *h_res = nullptr;  // pinned: poses, errors, flags, counts of a solve
+  std::vector<int32_t *> pool;  // all keyframes' id lists, chunk by chunk
+  size_t pool_used = 0;         // ids used in the last chunk
+  float *d_map = nullptr;       // staging of one keyframe's map points
 };
 
 void vo_svo_lba_free(vo_svo *s) {
@@ -411,13 +429,16 @@ void vo_svo_lba_free(vo_svo *s) {
     if (L->kf_pr[k]) (void)hipFree(L->kf_pr[k]);
   }
   if (L->h_res) (void)hipHostFree(L->h_res);
+  for (int32_t *p : L->pool)
+    if (p) (void)hipFree(p);
+  if (L->d_map) (void)hipFree(L->d_map);
   delete L;
   s->lba = nullptr;
 }
 
 static int lba_init(vo_svo *s) {
   vo_ctx *c = s->c;
-  if (s->prm.kf_window > LBA_KW) VO_FAIL(c, VO_ERR_CAPACITY, "local BA: keyframe window of %d (at most %d)", s->prm.kf_window, LBA_KW);
+  if (s->prm.kf_window > LBA_KW) VO_FAIL(c, VO_ERR_CAPACITY, "keyframe window of %d (at most %d)", s->prm.kf_window, LBA_KW);
   vo_svo_lba *L = new vo_svo_lba();
   s->lba = L;
   const size_t slots = (size_t)1 << LBA_TAB_BITS;
@@ -436,6 +457,7 @@ static int lba_init(vo_svo *s) {
   VO_CHECK_HIP(c, hipMalloc((void **)&L->q_w, sizeof(int) * (size_t)LBA_SPAN_MAX * LBA_KW));
   VO_CHECK_HIP(c, hipMalloc((void **)&L->pre, sizeof(unsigned long long) * ((size_t)LBA_SPAN_MAX + LBA_SPAN_MAX / LBA_QWG + 1)));
   VO_CHECK_HIP(c, hipHostMalloc((void **)&L->h_res, 4096, hipHostMallocDefault));
+  VO_CHECK_HIP(c, hipMalloc((void **)&L->d_map, sizeof(float) * 3 * (size_t)s->cap));
   return VO_OK;
 }
 
@@ -476,12 +498,28 @@ int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info, int id_min) {
     kf.ring = r;
     kf.n = n;
     kf.id_min = id_min;
+    kf.global = (int)s->kf_all.size();
+  }
+  {  // all_stkeyframes_: the keyframe's related landmarks go into the pool that only grows
+    if (L->pool.empty() || L->pool_used + (size_t)n > LBA_POOL_CHUNK) {
+      int32_t *chunk = nullptr;
+      VO_CHECK_HIP(c, hipMalloc((void **)&chunk, sizeof(int32_t) * LBA_POOL_CHUNK));
+      L->pool.push_back(chunk);
+      L->pool_used = 0;
+    }
+    vo_svo::SvoKfAll rec;
+    memcpy(rec.T_wc, kf.T_wc, sizeof(rec.T_wc));
+    rec.n = n;
+    rec.d_ids = L->pool.back() + L->pool_used;
+    L->pool_used += (size_t)n;
+    s->kf_all.push_back(rec);
   }
   if (n > 0) {
     hipLaunchKernelGGL(lba_keyframe_kernel, dim3((n + 255) / 256), dim3(256), 0, st, t, n, L->tab, L->kf_ids[kf.ring], L->kf_pl[kf.ring],
-                       L->kf_pr[kf.ring]);
+                       L->kf_pr[kf.ring], const_cast<int32_t *>(s->kf_all.back().d_ids));
     VO_CHECK_HIP(c, hipGetLastError());
   }
+  if (!s->prm.local_ba) return VO_OK;
   if (nk < 3) return VO_OK;  // NUM_MINIMUM_REQUIRED_KEYFRAMES (motion_estimator.cpp:1245-1253)
   const double POSE_SCALE = 10.0, inv_scale = 1.0 / POSE_SCALE;
   // ---- the window ----
@@ -692,6 +730,7 @@ int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info, int id_min) {
     Tf[12] = Tf[13] = Tf[14] = 0.0f;
     Tf[15] = 1.0f;
     svo_inv_se3(Tf, win[j].T_wc);  // kf->setPose(inverseSE3_f(Tjw_update_float))
+    memcpy(s->kf_all[win[j].global].T_wc, win[j].T_wc, sizeof(win[j].T_wc));
   }
   // ---- points back into the table, and into the track set the next frame starts from (stream-ordered in front of it) ----
   hipLaunchKernelGGL(lba_writeback_kernel, dim3((unsigned)((M_ub + 255) / 256)), dim3(256), 0, st, p, L->tab, ref);
@@ -706,5 +745,29 @@ int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info, int id_min) {
       fprintf(stderr, "[lba] per call (us): host build + enqueue %.0f  device (build + solve) %.0f  write-back %.0f  (M=%d obs=%d slots=%d, span %d)\n",
               tt[0] / n_calls, tt[1] / n_calls, tt[2] / n_calls, o_d[0], o_d[1], o_d[2], w.W);
   }
+  return VO_OK;
+}
+
+extern "C" int vo_svo_keyframe_count(vo_svo *s, int *n_keyframes) {
+  if (!s || !n_keyframes) return VO_ERR_INVALID;
+  *n_keyframes = (int)s->kf_all.size();
+  return VO_OK;
+}
+
+extern "C" int vo_svo_get_keyframe(vo_svo *s, int j, float T_wc[16], float *mappoints, int cap, int *n_points) {
+  if (!s || j < 0 || j >= (int)s->kf_all.size()) return VO_ERR_INVALID;
+  vo_ctx *c = s->c;
+  if (s->pending) VO_FAIL(c, VO_ERR_INVALID, "call vo_svo_result first");
+  const vo_svo::SvoKfAll &k = s->kf_all[j];
+  if (T_wc) memcpy(T_wc, k.T_wc, sizeof(k.T_wc));
+  if (n_points) *n_points = k.n;
+  if (!mappoints || k.n == 0) return VO_OK;
+  if (k.n > cap) VO_FAIL(c, VO_ERR_CAPACITY, "keyframe %d has %d related landmarks, room for %d", j, k.n, cap);
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  vo_svo_lba *L = s->lba;
+  hipLaunchKernelGGL(lba_mappoints_kernel, dim3((k.n + 255) / 256), dim3(256), 0, c->stream, k.d_ids, k.n, L->tab, L->d_map);
+  VO_CHECK_HIP(c, hipGetLastError());
+  VO_CHECK_HIP(c, hipMemcpyAsync(mappoints, L->d_map, sizeof(float) * 3 * (size_t)k.n, hipMemcpyDeviceToHost, c->stream));
+  VO_CHECK_HIP(c, hipStreamSynchronize(c->stream));
   return VO_OK;
 }
