@@ -57,6 +57,20 @@ float use_stereo_vo(const cv::Mat &img_left, const cv::Mat &img_right, const dou
   (void)dbg;
   return Twc(0, 3) + st.stats_execution.back().time_total + (float)st.stats_landmark.back().n_final;
 }
+// the ROS 2 node as it stands (ros2/visual_odometry/stereo_vo_ros2.cpp:18-20, :104-166): constructed from (mode, YAML path),
+// publishes the last pose, the keyframes' trajectory and their map points
+float use_stereo_vo_like_the_ros2_node(const cv::Mat &img_left, const cv::Mat &img_right, const double &timestamp) {
+  StereoVO svo(std::string("rosbag"), std::string("/tmp/config/stereo/exp_stereo2.yaml"));
+  svo.trackStereoImages(img_left, img_right, timestamp);
+  const StereoVO::AlgorithmStatistics &stat = svo.getStatistics();
+  float s = stat.stats_frame.back().Twc(2, 3);
+  for (size_t j = 0; j < stat.stats_keyframe.size(); ++j) {
+    PoseSE3 Twc = stat.stats_keyframe[j].Twc;
+    s += Twc(0, 3);
+    for (const auto &x : stat.stats_keyframe[j].mappoints) s += x(2);
+  }
+  return s;
+}
 
 // ---- run-time part (CPU only): the conversions ----
 static int fails = 0;

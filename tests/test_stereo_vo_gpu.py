@@ -218,3 +218,44 @@ def test_closed_loop_survives_a_join_timeout():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
                         "test_closed_loop_small and 3-True"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_from_yaml_runs_the_references_configuration(vo, oracle, tmp_path):
+    """StereoVO.from_yaml: a configuration file in the reference's format (OpenCV FileStorage YAML) for the small synthetic
+    rig — with flagDoUndistortion = 1 and lens distortion — drives the loop; the CPU loop gets the same numbers by hand."""
+    from oracle.stereo_vo import StereoVORef
+    from visual_odometry_ros_amd import synthetic as S
+    W, H, K = 640, 240, (400.0, 400.0, 320.0, 120.0)
+    st, imgs = _stream(W, H, K, 20, 8, 11, 0.5, 7)
+    Dl, Dr = [-0.05, 0.01, 0.0003, -0.0002, 0.0], [-0.04, 0.012, -0.0002, 0.0004, 0.0]
+    T_lr = np.asarray(st.T_lr, np.float32)
+    cam = lambda side, D: "".join(f"Camera.{side}.{k}: {v}\n" for k, v in (  # noqa: E731
+        ("fx", K[0]), ("fy", K[1]), ("cx", K[2]), ("cy", K[3]), ("k1", D[0]), ("k2", D[1]), ("p1", D[2]), ("p2", D[3]), ("k3", D[4]),
+        ("width", W), ("height", H)))
+    text = ("%YAML:1.0\nflagDoUndistortion: 1\n" + cam("left", Dl) + cam("right", Dr) +
+            "T_lr: !!opencv-matrix\n  rows: 4\n  cols: 4\n  dt: f\n  data: [" + ",".join(repr(float(v)) for v in T_lr.reshape(-1)) + "]\n"
+            "feature_tracker.thres_error: 80.0\nfeature_tracker.thres_bidirection: 0.5\nfeature_tracker.thres_sampson: 60.0\n"
+            "feature_tracker.window_size: 21\nfeature_tracker.max_level: 4\nmap_update.thres_parallax: 1.0\n"
+            "feature_extractor.n_features: 2000\nfeature_extractor.n_bins_u: 20\nfeature_extractor.n_bins_v: 8\n"
+            "feature_extractor.thres_fastscore: 15.0\nfeature_extractor.radius: 5.0\nmotion_estimator.thres_1p_error: 120.0\n"
+            "motion_estimator.thres_5p_error: 1.0\nmotion_estimator.thres_poseba_error: 3.0\nkeyframe_update.thres_alive_ratio: 0.6\n"
+            "keyframe_update.thres_mean_parallax: 1.0\nkeyframe_update.thres_trans: 1.2\nkeyframe_update.thres_rotation: 15.0\n"
+            "keyframe_update.n_max_keyframes_in_window: 9\n")
+    path = tmp_path / "rig.yaml"
+    path.write_text(text)
+    m = oracle.stereo_rectify_maps(W, H, np.array(K, np.float32), np.array(Dl, np.float32), np.array(K, np.float32),
+                                   np.array(Dr, np.float32), T_lr)
+    ref = StereoVORef(W, H, m["K_rect"], m["K_rect"], m["T_lr_rect"], 20, 8, thres_fast=15, win=21, max_level=4, kf_trans=1.2,
+                      lba=True, sum_mode=oracle.SUM_TREE, tree_width=512, ic_border=oracle.IC_REFERENCE, n_threads=8,
+                      rectify_maps=(m["left"], m["right"]))
+    svo = vo.StereoVO.from_yaml(str(path))
+    try:
+        assert svo.config["flagDoUndistortion"] == 1 and svo.prm.rectify == 1 and svo.prm.kf_window == 9
+        for k, (L, R) in enumerate(imgs):
+            gi = svo.trackStereoImages(L, R)
+            ref.track(L, R)
+            g = svo.getTracks()
+            assert np.array_equal(g["ids"], ref.ids) and np.array_equal(_bits(g["pts_l"]), _bits(ref.pts_l)), k
+            assert np.array_equal(_bits(np.array(gi.T_wc).reshape(4, 4)), _bits(ref.T_wp)), k
+    finally:
+        svo.close()

@@ -769,10 +769,48 @@ class StereoVO:
         self._info = SvoFrameInfo()
         self.stats_frame = []  # AlgorithmStatistics::FrameStatistics::Twc per frame (stereo_vo.cpp:979-980)
 
+    @classmethod
+    def from_yaml(cls, path, device=0, **overrides):
+        """StereoVO(mode = "rosbag", directory_intrinsic = path) of the reference (stereo_vo.cpp:15-57, :118-280): the
+        object configured by one of its config/stereo/*.yaml files. The context is created here (sized by the file) and
+        closed with the object. With flagDoUndistortion the pairs go through the rectification maps and the loop runs on
+        the rectified camera (:414-427); without, on the raw cameras and T_lr of the file. `overrides`: keyword
+        arguments of the constructor that the file does not know (strict_border, local_ba)."""
+        from . import config as _config
+        cfg = _config.load_stereo_config(path)
+        cl, cr = cfg["camera"]["left"], cfg["camera"]["right"]
+        W, H = cl["width"], cl["height"]
+        fe, ft, me, ku = cfg["feature_extractor"], cfg["feature_tracker"], cfg["motion_estimator"], cfg["keyframe_update"]
+        ctx = Context(device=device, max_width=W, max_height=H, max_points=2 * fe["n_bins_u"] * fe["n_bins_v"] + 1024, n_slots=5,
+                      max_level=ft["max_level"])
+        try:
+            Kl, Kr, T_lr, rectify = cl["K"], cr["K"], cfg["T_lr"], False
+            if cfg["flagDoUndistortion"]:
+                cam = StereoCamera(ctx)
+                cam.initParams(W, H, cl["K"], cl["D"], cr["K"], cr["D"])
+                cam.setStereoPoseLeft2Right(cfg["T_lr"])
+                cam.initStereoCameraToRectify()
+                Kl = Kr = cam.getRectifiedCamera()
+                T_lr, rectify = cam.getRectifiedStereoPoseLeft2Right(), True
+            obj = cls(ctx, W, H, Kl, Kr, T_lr, fe["n_bins_u"], fe["n_bins_v"], thres_fastscore=fe["thres_fastscore"],
+                      window_size=ft["window_size"], max_level=ft["max_level"], thres_error=ft["thres_error"],
+                      thres_bidirection=ft["thres_bidirection"], thres_poseba_error=me["thres_poseba_error"],
+                      thres_alive_ratio=ku["thres_alive_ratio"], thres_rotation=ku["thres_rotation"], thres_trans=ku["thres_trans"],
+                      n_max_keyframes_in_window=ku["n_max_keyframes_in_window"], rectify=rectify, **overrides)
+        except Exception:
+            ctx.close()
+            raise
+        obj._own_ctx, obj.config = ctx, cfg
+        return obj
+
     def close(self):
         if getattr(self, "_h", None):
             self.lib.vo_svo_destroy(self._h)
             self._h = C.c_void_p()
+        own = getattr(self, "_own_ctx", None)
+        if own is not None:
+            self._own_ctx = None
+            own.close()
 
     def __del__(self):
         try:

@@ -41,6 +41,7 @@
 #include "feature_tracker.h"
 #include "motion_estimator.h"
 #include "stereo_vo.h"
+#include "stereo_vo_config.h"
 
 namespace vo_adapter {
 
@@ -355,6 +356,9 @@ class StereoVO {
     std::vector<ExecutionStatistics> stats_execution;
   };
 
+  // the reference's constructor (stereo_vo.h:233, stereo_vo.cpp:6-57): mode "rosbag" + the path of a config/stereo/*.yaml
+  // file; stats_keyframe is rewritten at every keyframe, as there
+  StereoVO(std::string mode, std::string directory_intrinsic) : StereoVO(with_statistics(vo::stereoVOParamsForMode(mode, directory_intrinsic))) {}
   // (vo::StereoVOParams::keyframe_statistics = true gives the reference's behaviour: stats_keyframe rewritten at every keyframe)
   explicit StereoVO(const vo::StereoVOParams &p, int device = 0)
       : ctx_(std::make_shared<vo::Context>(device, p.width, p.height,
@@ -390,6 +394,10 @@ class StereoVO {
   vo::StereoVO &device() { return impl_; }
 
  private:
+  static vo::StereoVOParams with_statistics(vo::StereoVOParams p) {
+    p.keyframe_statistics = true;
+    return p;
+  }
   vo::ContextPtr ctx_;
   vo::StereoVO impl_;
   AlgorithmStatistics stat_;
