@@ -2,6 +2,8 @@
 (oracle/stereo_vo.py): what enters frame k+1 is what frame k left behind — survivors, new landmarks (DLT), ids, poses,
 keyframes — and both sides run FREE (no state is copied from one to the other), so every frame's track set must come
 out bit for bit for the comparison to hold at the end."""
+import os
+
 import numpy as np
 import pytest
 
@@ -259,3 +261,49 @@ def test_from_yaml_runs_the_references_configuration(vo, oracle, tmp_path):
             assert np.array_equal(_bits(np.array(gi.T_wc).reshape(4, 4)), _bits(ref.T_wp)), k
     finally:
         svo.close()
+
+
+def test_sequence_runner_example(vo, tmp_path):
+    """examples/run_stereo_sequence.py: PNG pairs on disk + a configuration file of the reference's format -> the reference's
+    trajectory file; the same bytes as the in-process loop over the same arrays."""
+    import subprocess
+    import sys
+    PIL = pytest.importorskip("PIL.Image")
+    W, H, K = 640, 240, (400.0, 400.0, 320.0, 120.0)
+    st, imgs = _stream(W, H, K, 20, 8, 13, 0.5, 7)
+    dl, dr = tmp_path / "image_0", tmp_path / "image_1"
+    dl.mkdir()
+    dr.mkdir()
+    for k, (L, R) in enumerate(imgs):
+        PIL.fromarray(L).save(dl / f"{k:06d}.png")
+        PIL.fromarray(R).save(dr / f"{k:06d}.png")
+    T_lr = np.asarray(st.T_lr, np.float32)
+    cam = lambda side: "".join(f"Camera.{side}.{k}: {v}\n" for k, v in (  # noqa: E731
+        ("fx", K[0]), ("fy", K[1]), ("cx", K[2]), ("cy", K[3]), ("k1", 0.0), ("k2", 0.0), ("p1", 0.0), ("p2", 0.0), ("k3", 0.0),
+        ("width", W), ("height", H)))
+    cfg = tmp_path / "rig.yaml"
+    cfg.write_text("%YAML:1.0\nflagDoUndistortion: 0\n" + cam("left") + cam("right") +
+                   "T_lr: !!opencv-matrix\n  rows: 4\n  cols: 4\n  dt: f\n  data: [" + ",".join(repr(float(v)) for v in T_lr.reshape(-1)) + "]\n"
+                   "feature_tracker.thres_error: 80.0\nfeature_tracker.thres_bidirection: 0.5\nfeature_tracker.thres_sampson: 60.0\n"
+                   "feature_tracker.window_size: 21\nfeature_tracker.max_level: 4\nmap_update.thres_parallax: 1.0\n"
+                   "feature_extractor.n_features: 2000\nfeature_extractor.n_bins_u: 20\nfeature_extractor.n_bins_v: 8\n"
+                   "feature_extractor.thres_fastscore: 15.0\nfeature_extractor.radius: 5.0\nmotion_estimator.thres_1p_error: 120.0\n"
+                   "motion_estimator.thres_5p_error: 1.0\nmotion_estimator.thres_poseba_error: 3.0\nkeyframe_update.thres_alive_ratio: 0.6\n"
+                   "keyframe_update.thres_mean_parallax: 1.0\nkeyframe_update.thres_trans: 1.2\nkeyframe_update.thres_rotation: 15.0\n"
+                   "keyframe_update.n_max_keyframes_in_window: 9\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out, kf = tmp_path / "traj.txt", tmp_path / "kf.txt"
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "run_stereo_sequence.py"), "--config", str(cfg), "--left", str(dl),
+                        "--right", str(dr), "--trajectory", str(out), "--keyframes", str(kf)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    svo = vo.StereoVO.from_yaml(str(cfg))
+    ids, Ts = [], []
+    for L, R in imgs:
+        i = svo.trackStereoImages(L, R)
+        ids.append(i.frame_id)
+        Ts.append(np.array(i.T_wc, np.float32).reshape(4, 4))
+    kfs = svo.getKeyframes()
+    svo.close()
+    vo.write_trajectory(str(tmp_path / "ref.txt"), ids, np.stack(Ts))
+    assert open(out, "rb").read() == open(tmp_path / "ref.txt", "rb").read()
+    assert len(open(out).read().splitlines()) == 7 and len(open(kf).read().splitlines()) == len(kfs) >= 2
