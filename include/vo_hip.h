@@ -393,9 +393,11 @@ typedef struct {
   int kf_window;            /* keyframe_update.n_max_keyframes_in_window (with local_ba: at most 16) */
   int strict_border;        /* vo_stereo_frame_set_strict_border */
   int local_ba;             /* != 0: localBundleAdjustmentSparseSolver_Stereo at every keyframe (the reference's behaviour);
-                               the window may span at most 2^19 landmark ids (VO_ERR_CAPACITY beyond). Landmark table,
-                               keyframe window and the BA problem live on the device (about 90 MB per StereoVO from the
-                               first keyframe on, with or without the local BA: the table also serves stats_keyframe) */
+                               the window may span at most 2^24 landmark ids — the distance from the oldest landmark
+                               still tracked at the window's oldest keyframe to the newest, ~80 000 frames of a track
+                               that never dies (VO_ERR_CAPACITY beyond). Landmark table, keyframe window and the BA
+                               problem live on the device (about 310 MB per StereoVO from the first keyframe on, with or
+                               without the local BA: the table also serves stats_keyframe) */
   int rectify;              /* != 0: flagDoUndistortion (stereo_vo.cpp:414-427) — every incoming pair goes through the
                                context's stereo rectification maps (vo_rectify_init_stereo / vo_rectify_set_maps first) on
                                its way into the pyramids; frame.Kl / Kr / T_lr are then the RECTIFIED camera and extrinsics */

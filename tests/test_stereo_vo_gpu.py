@@ -45,7 +45,7 @@ def test_triangulate_dlt_bit_exact(vo, oracle, ctx):
 
 
 def _run_both(vo, oracle, W, H, K, nu, nv, frames, win, lvl, n_frames, lba, strict, seed=5, speed=0.5, prefetch=False,
-              kf_trans=10.0, kf_overlap=0.6, id_offset=0):
+              kf_trans=10.0, kf_overlap=0.6, id_offset=0, id_jump=None):
     from oracle.stereo_vo import StereoVORef
     st, imgs = frames
     ref = StereoVORef(W, H, K, K, st.T_lr, nu, nv, thres_fast=15, win=win, max_level=lvl, kf_trans=kf_trans, kf_overlap=kf_overlap,
@@ -60,6 +60,10 @@ def _run_both(vo, oracle, W, H, K, nu, nv, frames, win, lvl, n_frames, lba, stri
         log = []
         for k in range(n_frames):
             L, R = imgs[k]
+            if id_jump and k == id_jump[0]:  # both landmark counters leap ahead: the ids are labels, the interval is not
+                nl, nf = vo.TrackIds(c).peek()
+                vo.TrackIds(c).reset(nl + id_jump[1], nf)
+                ref.landmark_counter += id_jump[1]
             if prefetch:
                 svo.enqueue(L, R)
                 if k + 1 < n_frames:
@@ -148,12 +152,12 @@ def test_closed_loop_local_ba_sliding_window(vo, oracle):
 
 
 def test_closed_loop_local_ba_landmark_table_wraps(vo, oracle):
-    """The device-side landmark table is addressed by id modulo its 2^21 slots: a stream whose landmark counter crosses
-    that boundary in the middle of a keyframe window (ids 2^21 - 150 ...) must give the same loop."""
+    """The device-side landmark table is addressed by id modulo its 2^24 slots: a stream whose landmark counter crosses
+    that boundary in the middle of a keyframe window (ids 2^24 - 150 ...) must give the same loop."""
     W, H, K = 640, 240, (400.0, 400.0, 320.0, 120.0)
     frames = _stream(W, H, K, 20, 8, 5, 0.5, 14)
     log, ref = _run_both(vo, oracle, W, H, K, 20, 8, frames, 21, 4, 14, lba=True, strict=4, prefetch=True, kf_trans=1.2,
-                         id_offset=(1 << 21) - 150)
+                         id_offset=(1 << 24) - 150)
     assert sum(1 for e in log if e[2]) >= 3, log
     assert ref.ids.min() < 150 < ref.ids.max()  # live landmarks on both sides of the boundary at the end
 
@@ -207,6 +211,18 @@ def test_closed_loop_with_rectification(vo, oracle):
                 dR.free()
         finally:
             c.close()
+
+
+def test_closed_loop_local_ba_wide_id_interval(vo, oracle):
+    """The window's id interval is set by its oldest landmark still alive: a leap of 300 000 in the landmark counter in the
+    middle of the run makes the interval wider than the window scratch's first allocation (2^18 ids) — it has to grow, and
+    the builder's scans run over an interval that is almost empty."""
+    W, H, K = 640, 240, (400.0, 400.0, 320.0, 120.0)
+    frames = _stream(W, H, K, 20, 8, 5, 0.5, 14)
+    log, ref = _run_both(vo, oracle, W, H, K, 20, 8, frames, 21, 4, 14, lba=True, strict=4, prefetch=True, kf_trans=1.2,
+                         id_jump=(4, 300000))
+    assert sum(1 for e in log if e[2]) >= 3, log
+    assert ref.ids.min() < 1000 and ref.ids.max() > 300000  # landmarks from both sides of the leap are still tracked
 
 
 def test_closed_loop_survives_a_join_timeout():

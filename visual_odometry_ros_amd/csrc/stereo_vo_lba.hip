@@ -19,7 +19,7 @@
 // and a landmark alive at some frame was alive at every keyframe since its creation — so everything the window can
 // refer to lies in the id interval [first id of the oldest keyframe, next id to hand out). That makes every container of
 // the reference a direct-address array in HBM:
-//   landmark table   X (float3), state (bit 0 triangulated, bit 1 dead), tag (the id), slot = id mod 2^21
+//   landmark table   X (float3), state (bit 0 triangulated, bit 1 dead), tag (the id), slot = id mod 2^24
 //   keyframe ring    per window keyframe its related landmarks' ids and both pixels (copied from the track set)
 //   window scratch   per id of the interval: bit mask of the window keyframes that saw it, its entry index in each
 // and the BA problem is built by six small launches — mark/copy, scatter, qualify (one lane per id, packed counts scanned
@@ -74,8 +74,12 @@ static void to_d(const float T[16], double D[16]) {
 
 // ---- device side ------------------------------------------------------------------------------------------------------
 #define LBA_KW 16            // window keyframes at most (bits of the mask that are used, entries per id in q_w)
-#define LBA_TAB_BITS 21      // landmark table: 2^21 slots, circular by id
-#define LBA_SPAN_MAX (1 << 19)  // ids the window may span
+#define LBA_TAB_BITS 24      // landmark table: 2^24 slots (285 MB), circular by id
+// ids the window may span: from the first id of the oldest keyframe to the next id to hand out — set by the OLDEST landmark
+// still tracked at the oldest keyframe (a track that never dies keeps the interval growing at ~200 ids per frame: 2^24 ids
+// are ~80 000 frames). The window scratch grows with it (68 bytes per id of the interval).
+#define LBA_SPAN_MAX (1 << LBA_TAB_BITS)
+#define LBA_SPAN_FIRST (1 << 18)
 
 struct LmTab {
   float *X;       // [slots][3] lm->get3DPoint()
@@ -389,7 +393,7 @@ __global__ void lba_refresh_kernel(SvoTrackSet ts, int n, LmTab tab) {
 }
 
 // stats_keyframe[j].mappoints: the CURRENT 3-D points of a keyframe's related landmarks (a slot taken over by a later id
-// — 2^21 landmarks on — reads as the origin)
+// — 2^24 landmarks on — reads as the origin)
 __global__ void lba_mappoints_kernel(const int32_t *ids, int n, LmTab tab, float *out) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
@@ -407,8 +411,9 @@ struct vo_svo_lba {
   LmTab tab = {};
   int32_t *kf_ids[LBA_KW] = {};
   float *kf_pl[LBA_KW] = {}, *kf_pr[LBA_KW] = {};
-  int *mask_w = nullptr, *q_w = nullptr;  // window scratch
+  int *mask_w = nullptr, *q_w = nullptr;  // window scratch, for span_cap ids
   unsigned long long *pre = nullptr;
+  size_t span_cap = 0;
   uint8_t *arena = nullptr;
   size_t arena_cap = 0;
   uint8_t *h_res = nullptr;  // pinned: poses, errors, flags, counts of a solve
@@ -453,9 +458,6 @@ static int lba_init(vo_svo *s) {
     VO_CHECK_HIP(c, hipMalloc((void **)&L->kf_pl[k], sizeof(float) * 2 * (size_t)s->cap));
     VO_CHECK_HIP(c, hipMalloc((void **)&L->kf_pr[k], sizeof(float) * 2 * (size_t)s->cap));
   }
-  VO_CHECK_HIP(c, hipMalloc((void **)&L->mask_w, sizeof(int) * (size_t)LBA_SPAN_MAX));
-  VO_CHECK_HIP(c, hipMalloc((void **)&L->q_w, sizeof(int) * (size_t)LBA_SPAN_MAX * LBA_KW));
-  VO_CHECK_HIP(c, hipMalloc((void **)&L->pre, sizeof(unsigned long long) * ((size_t)LBA_SPAN_MAX + LBA_SPAN_MAX / LBA_QWG + 1)));
   VO_CHECK_HIP(c, hipHostMalloc((void **)&L->h_res, 4096, hipHostMallocDefault));
   VO_CHECK_HIP(c, hipMalloc((void **)&L->d_map, sizeof(float) * 3 * (size_t)s->cap));
   return VO_OK;
@@ -531,6 +533,21 @@ int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info, int id_min) {
   const long long span = (long long)c->next_landmark_id - (long long)w.base;
   if (span > LBA_SPAN_MAX) VO_FAIL(c, VO_ERR_CAPACITY, "local BA: the window spans %lld landmark ids (at most %d)", span, LBA_SPAN_MAX);
   w.W = (int)span;
+  if ((size_t)w.W > L->span_cap) {  // the window scratch follows the interval (rarely: it doubles)
+    size_t want = L->span_cap ? L->span_cap : (size_t)LBA_SPAN_FIRST;
+    while (want < (size_t)w.W) want *= 2;
+    VO_CHECK_HIP(c, hipStreamSynchronize(st));
+    void *old[] = {L->mask_w, L->q_w, L->pre};
+    for (void *q : old)
+      if (q) (void)hipFree(q);
+    L->mask_w = L->q_w = nullptr;
+    L->pre = nullptr;
+    L->span_cap = 0;
+    VO_CHECK_HIP(c, hipMalloc((void **)&L->mask_w, sizeof(int) * want));
+    VO_CHECK_HIP(c, hipMalloc((void **)&L->q_w, sizeof(int) * want * LBA_KW));
+    VO_CHECK_HIP(c, hipMalloc((void **)&L->pre, sizeof(unsigned long long) * (want + want / LBA_QWG + 1)));
+    L->span_cap = want;
+  }
   size_t E = 0, E_opt = 0;
   int maxn = 1;
   for (int j = 0; j < nk; ++j) {
@@ -548,8 +565,8 @@ int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info, int id_min) {
     maxn = std::max(maxn, win[j].n);
   }
   if (w.W <= 0 || E == 0) return VO_OK;
-  if (w.W >= (1 << LBA_PK_KF) || E >= ((size_t)1 << (LBA_PK_SL - LBA_PK_KF)))
-    VO_FAIL(c, VO_ERR_CAPACITY, "local BA: %d ids / %zu keyframe entries exceed the packed counters", w.W, E);
+  if (E >= ((size_t)1 << LBA_PK_KF))  // (landmarks <= keyframe entries; pairs and slots <= entries: 20 / 22 / 22 bits)
+    VO_FAIL(c, VO_ERR_CAPACITY, "local BA: %zu keyframe entries exceed the packed counters", E);
   const int No = w.No, max_iter = 10;
   const size_t M_ub = std::min((size_t)w.W, E), nobs_ub = 2 * E, ns_ub = E_opt;
   const int n_err = (int)((M_ub + 64 / SBA_LQ - 1) / (64 / SBA_LQ));
@@ -616,7 +633,7 @@ int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info, int id_min) {
   p.mask_w = L->mask_w;
   p.q_w = L->q_w;
   p.pre = L->pre;
-  p.wg_tot = L->pre + LBA_SPAN_MAX;
+  p.wg_tot = L->pre + L->span_cap;
   p.pose_obs_stride = 2 * maxn;
   p.pose_slot_stride = maxn;
   p.pair_stride = maxn;
