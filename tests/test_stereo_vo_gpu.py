@@ -225,6 +225,38 @@ def test_closed_loop_local_ba_wide_id_interval(vo, oracle):
     assert ref.ids.min() < 1000 and ref.ids.max() > 300000  # landmarks from both sides of the leap are still tracked
 
 
+def test_closed_loop_is_deterministic(vo):
+    """Sixty frames with the concurrent replay (mode 4), the DLT workers, the device-built local BA (atomics in its scatter,
+    a window that fills and slides): two runs give the same bits — poses of every frame, final ids, every keyframe's pose and
+    map points."""
+    W, H, K = 640, 240, (400.0, 400.0, 320.0, 120.0)
+    st, imgs = _stream(W, H, K, 20, 8, 21, 0.5, 60)
+    runs = []
+    for _ in range(2):
+        c = vo.Context(device=0, max_width=W, max_height=H, max_points=4096, n_slots=5, max_level=4)
+        try:
+            svo = vo.StereoVO(c, W, H, K, K, st.T_lr, 20, 8, thres_fastscore=15, window_size=21, max_level=4, strict_border=4,
+                              local_ba=True, thres_trans=0.9)
+            Ts, n_lba = [], 0
+            for k in range(60):
+                svo.enqueue(*imgs[k])
+                if k + 1 < 60:
+                    svo.prefetch(*imgs[k + 1])
+                i = svo.result()
+                Ts.append(np.array(i.T_wc, np.float32))
+                n_lba += int(bool(i.lba_ran))
+            runs.append((np.stack(Ts), svo.getTracks()["ids"].copy(), svo.getKeyframes(), n_lba))
+            svo.close()
+        finally:
+            c.close()
+    (Ta, ia, ka, la), (Tb, ib, kb, lb) = runs
+    assert la == lb >= 20
+    assert np.array_equal(_bits(Ta), _bits(Tb)) and np.array_equal(ia, ib) and len(ka) == len(kb)
+    for (T1, X1), (T2, X2) in zip(ka, kb):
+        assert np.array_equal(_bits(T1), _bits(T2)) and np.array_equal(_bits(X1), _bits(X2))
+    assert np.isfinite(Ta).all() and abs(Ta[-1][11] - 0.5 * 59) < 1.5  # (z of the last pose: 0.5 m per frame)
+
+
 def test_closed_loop_survives_a_join_timeout():
     """The loop in strict-border mode 3 with a device-side join that cannot be met (VO_DEBUG_FAIL_JOIN, fresh child process):
     the first steady-state frame is issued again with the stream-ordered replay — and with it the DLT workers and the
