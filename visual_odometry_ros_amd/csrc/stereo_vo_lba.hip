@@ -485,7 +485,10 @@ int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info, int id_min) {
   hipStream_t st = c->stream;
   if (!s->lba) {
     const int rc = lba_init(s);
-    if (rc < 0) return rc;
+    if (rc < 0) {  // (nothing half-built stays behind: the next keyframe tries again)
+      vo_svo_lba_free(s);
+      return rc;
+    }
   }
   vo_svo_lba *L = s->lba;
   std::vector<SvoKeyframe> &win = s->keyframes;
