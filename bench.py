@@ -718,11 +718,48 @@ def run_loop(cfg, args, rank, local_rank, world, torch, V, barrier, dev, imgs, s
     ctx.close()  # (its three HIP streams go away: the legs below must not share hardware queues with an idle context)
     if secondary:
         out["secondary"] = secondary_legs(cfg, args, rank, local_rank, torch, V, barrier)
+        out["secondary"]["loop_host_images"] = host_image_loop_leg(cfg, args, local_rank, V, barrier, st, imgs, cap, traj)
         if args.batch_S:
             out["secondary"]["streams_per_gpu"] = batch_leg(cfg, args, local_rank, torch, V, dev, prm_svo, cap)
     if world == 1 and not args.no_cpu_baseline:
         out.update(cpu_baseline_loop(cfg, args, st, imgs, traj, V, local_rank))
     return out, ctx
+
+
+def host_image_loop_leg(cfg, args, local_rank, V, barrier, st, imgs, cap, traj):
+    """The headline loop as the reference's boundary hands the images over: cv::Mat-like HOST arrays into trackStereoImages
+    (here: enqueue / prefetch / result with numpy arrays), every pair crossing PCIe inside the timed region."""
+    W, H, thr = cfg["W"], cfg["H"], cfg["thres"]
+    ctx = V.Context(device=local_rank, max_width=W, max_height=H, max_points=cap, n_slots=5, max_level=cfg["max_level"])
+    svo = V.StereoVO(ctx, W, H, cfg["K"], cfg["K"], st.T_lr, cfg["n_u"], cfg["n_v"], thres_fastscore=cfg["thres_fast"],
+                     window_size=cfg["win"], max_level=cfg["max_level"], thres_error=thr[0], thres_bidirection=thr[1],
+                     thres_poseba_error=thr[2], strict_border=args.strict_border, local_ba=bool(args.lba))
+    host = [(np.ascontiguousarray(L), np.ascontiguousarray(R)) for L, R in imgs]
+    F, pre = len(host), LOOP_PRIME + args.warmup
+    K = min(args.steps, F - pre - 2)
+    same = [True]
+
+    def issue(k):
+        svo.enqueue(*host[k])
+        if k + 1 < F:
+            svo.prefetch(*host[k + 1])
+
+    def run(k0, n, check):
+        for k in range(k0, k0 + n):
+            i = svo.result()
+            if k + 1 < F:
+                issue(k + 1)
+            if check and k < len(traj):
+                same[0] = same[0] and bool(np.array_equal(np.array(i.T_wc, np.float32).view(np.uint32), traj[k].reshape(-1).view(np.uint32)))
+
+    issue(0)
+    run(0, pre, False)
+    dt = timed(lambda: run(pre, K, True), barrier, ctx)
+    svo.result()
+    svo.close()
+    ctx.close()
+    return {"value": round(K / dt, 2), "unit": "frames/s", "frames": K, "poses_equal_resident_run": same[0],
+            "note": "pageable host arrays in, 2 x %d KB per frame over PCIe on the ingest stream under the frame in flight" % (W * H // 1024)}
 
 
 def batch_leg(cfg, args, local_rank, torch, V, dev, prm_svo, cap):
