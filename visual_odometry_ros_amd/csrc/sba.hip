@@ -875,11 +875,6 @@ __global__ __launch_bounds__(64) void sba_update_point_kernel(SbaDev d, int upda
   __shared__ double sx[6 * SBA_MAX_OPT];
   const int lane = threadIdx.x, sub = lane & (SBA_LQ - 1);
   const long long st0 = SBA_TICK();
-  if (TLDS)
-    for (int k = lane; k < 16 * d.n_frames; k += 64) sT[k] = d.T[k];
-  if (update)
-    for (int k = lane; k < 6 * d.n_opt; k += 64) sx[k] = d.x[k];
-  __syncthreads();
   const int M = d.dyn ? d.dyn[0] : d.M;
   if ((int)blockIdx.x * (64 / SBA_LQ) >= M) {  // (a launch sized by an upper bound of M)
     if (point && lane == 0) d.err_part[blockIdx.x] = 0.0;
@@ -888,8 +883,15 @@ __global__ __launch_bounds__(64) void sba_update_point_kernel(SbaDev d, int upda
   const int i_raw = blockIdx.x * (64 / SBA_LQ) + lane / SBA_LQ;
   const bool live = i_raw < M;
   const int i = live ? i_raw : M - 1;  // a surplus quad repeats the last landmark and stores nothing (DPP needs all lanes)
+  // (the landmark's own loads are issued next to the staging of poses and x: one round of latency instead of two)
   double X[3] = {d.X[3 * (size_t)i], d.X[3 * (size_t)i + 1], d.X[3 * (size_t)i + 2]};
   const int s0 = d.slot_ptr[i], s1 = d.slot_ptr[i + 1];
+  const int o0 = d.obs_ptr[i], o1 = d.obs_ptr[i + 1];
+  if (TLDS)
+    for (int k = lane; k < 16 * d.n_frames; k += 64) sT[k] = d.T[k];
+  if (update)
+    for (int k = lane; k < 6 * d.n_opt; k += 64) sx[k] = d.x[k];
+  __syncthreads();
   const long long st1 = SBA_TICK();
   if (update) {
     double cbx[3] = {0, 0, 0};
@@ -912,8 +914,7 @@ __global__ __launch_bounds__(64) void sba_update_point_kernel(SbaDev d, int upda
   if (!point) return;
   const long long st2 = SBA_TICK();
   double Cu[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0}, err = 0.0;  // C_i: (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
-  const int o1 = d.obs_ptr[i + 1];
-  for (int o = d.obs_ptr[i] + sub; o < o1; o += SBA_LQ) {
+  for (int o = o0 + sub; o < o1; o += SBA_LQ) {
     SbaObs L;
     const double px[2] = {d.obs_px[2 * o], d.obs_px[2 * o + 1]};
     const int f = d.obs_frame[o];
