@@ -468,6 +468,9 @@ int vo_batch_run(vo_batch *batch, const void *const *left, const void *const *ri
  * BA keeps changing both). mappoints may be NULL (count only); cap = room for that many points. */
 int vo_svo_keyframe_count(vo_svo *svo, int *n_keyframes);
 int vo_svo_get_keyframe(vo_svo *svo, int j, float T_wc[16], float *mappoints, int cap, int *n_points);
+/* all of them at once (what trackStereoImages rewrites at every keyframe): T_wc [n_keyframes][16], n_points [n_keyframes],
+ * mappoints [total][3] in keyframe order; any of the three may be NULL; *total_points = sum of n_points */
+int vo_svo_get_keyframes(vo_svo *svo, float *T_wc, int32_t *n_points, float *mappoints, size_t cap_points, size_t *total_points);
 
 /* ---- undistortion / stereo rectification in front of the trackers ----------
  * core/visual_odometry/camera.cpp. A context holds the maps of two cameras

@@ -93,6 +93,8 @@ def _run_both(vo, oracle, W, H, K, nu, nv, frames, win, lvl, n_frames, lba, stri
                 assert len(gk) == len(rk), where
                 for j, ((Tg, Xg), (Tr, Xr)) in enumerate(zip(gk, rk)):
                     assert np.array_equal(_bits(Tg), _bits(Tr)) and np.array_equal(_bits(Xg), _bits(Xr)), (where, j)
+                T1, X1 = svo.getKeyframe(len(gk) - 1)  # (the one-keyframe getter against the all-at-once one)
+                assert np.array_equal(_bits(T1), _bits(gk[-1][0])) and np.array_equal(_bits(X1), _bits(gk[-1][1])), where
         svo.close()
         return log, ref
     finally:

@@ -887,17 +887,27 @@ class StereoVO:
     def getKeyframes(self):
         """AlgorithmStatistics::stats_keyframe as of now (stereo_vo.cpp:805-821): [(T_wc, mappoints [n][3])] for every
         keyframe so far — current poses, current 3-D points of the related landmarks."""
-        n = C.c_int()
+        n, tot = C.c_int(), C.c_size_t()
         self.ctx.check(self.lib.vo_svo_keyframe_count(self._h, C.addressof(n)))
-        out = []
-        for j in range(n.value):
-            T, m = np.zeros(16, np.float32), C.c_int()
-            self.ctx.check(self.lib.vo_svo_get_keyframe(self._h, j, T.ctypes.data, None, 0, C.addressof(m)))
-            X = np.zeros((max(m.value, 1), 3), np.float32)
-            if m.value:
-                self.ctx.check(self.lib.vo_svo_get_keyframe(self._h, j, None, X.ctypes.data, m.value, C.addressof(m)))
-            out.append((T.reshape(4, 4), X[:m.value]))
-        return out
+        nk = n.value
+        if nk == 0:
+            return []
+        T, cnt = np.zeros((nk, 16), np.float32), np.zeros(nk, np.int32)
+        self.ctx.check(self.lib.vo_svo_get_keyframes(self._h, T.ctypes.data, cnt.ctypes.data, None, 0, C.addressof(tot)))
+        X = np.zeros((max(tot.value, 1), 3), np.float32)
+        if tot.value:
+            self.ctx.check(self.lib.vo_svo_get_keyframes(self._h, None, None, X.ctypes.data, tot.value, C.addressof(tot)))
+        off = np.concatenate([[0], np.cumsum(cnt)])
+        return [(T[j].reshape(4, 4).copy(), X[off[j]:off[j + 1]].copy()) for j in range(nk)]
+
+    def getKeyframe(self, j):
+        """One keyframe of stats_keyframe: (T_wc, mappoints)."""
+        T, m = np.zeros(16, np.float32), C.c_int()
+        self.ctx.check(self.lib.vo_svo_get_keyframe(self._h, int(j), T.ctypes.data, None, 0, C.addressof(m)))
+        X = np.zeros((max(m.value, 1), 3), np.float32)
+        if m.value:
+            self.ctx.check(self.lib.vo_svo_get_keyframe(self._h, int(j), None, X.ctypes.data, m.value, C.addressof(m)))
+        return T.reshape(4, 4), X[:m.value]
 
     def getStatistics(self):
         return dict(stats_frame=[T.copy() for T in self.stats_frame], stats_keyframe=self.getKeyframes())

@@ -177,12 +177,19 @@ class StereoVO {
     int nk = 0;
     ctx_->check(vo_svo_keyframe_count(svo_, &nk));
     stat_.stats_keyframe.resize((size_t)nk);
+    if (nk == 0) return;
+    std::vector<float> T((size_t)nk * 16);
+    std::vector<std::int32_t> cnt((size_t)nk);
+    std::size_t total = 0;
+    ctx_->check(vo_svo_get_keyframes(svo_, T.data(), cnt.data(), nullptr, 0, &total));
+    std::vector<Point> all(total);  // one gather + one copy for all keyframes
+    if (total) ctx_->check(vo_svo_get_keyframes(svo_, nullptr, nullptr, reinterpret_cast<float *>(all.data()), total, &total));
+    std::size_t off = 0;
     for (int j = 0; j < nk; ++j) {
       AlgorithmStatistics::KeyframeStatistics &k = stat_.stats_keyframe[(size_t)j];
-      int n = 0;
-      ctx_->check(vo_svo_get_keyframe(svo_, j, k.Twc.data(), nullptr, 0, &n));
-      k.mappoints.resize((size_t)n);
-      if (n) ctx_->check(vo_svo_get_keyframe(svo_, j, nullptr, reinterpret_cast<float *>(k.mappoints.data()), n, &n));
+      for (int q = 0; q < 16; ++q) k.Twc[(size_t)q] = T[(size_t)j * 16 + (size_t)q];
+      k.mappoints.assign(all.begin() + (std::ptrdiff_t)off, all.begin() + (std::ptrdiff_t)(off + (std::size_t)cnt[(size_t)j]));
+      off += (std::size_t)cnt[(size_t)j];
     }
   }
   const vo_svo_frame_info &lastFrameInfo() const { return last_; }

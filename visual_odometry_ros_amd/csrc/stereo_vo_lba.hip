@@ -420,6 +420,9 @@ struct vo_svo_lba {
   std::vector<int32_t *> pool;  // all keyframes' id lists, chunk by chunk
   size_t pool_used = 0;         // ids used in the last chunk
   float *d_map = nullptr;       // staging of one keyframe's map points
+  float *d_map_all = nullptr;   // staging of all keyframes' map points (vo_svo_get_keyframes)
+  size_t map_all_cap = 0;       // points
+  std::vector<size_t> pool_fill;  // ids used in every chunk
 };
 
 void vo_svo_lba_free(vo_svo *s) {
@@ -437,6 +440,7 @@ void vo_svo_lba_free(vo_svo *s) {
   for (int32_t *p : L->pool)
     if (p) (void)hipFree(p);
   if (L->d_map) (void)hipFree(L->d_map);
+  if (L->d_map_all) (void)hipFree(L->d_map_all);
   delete L;
   s->lba = nullptr;
 }
@@ -510,6 +514,7 @@ int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info, int id_min) {
       int32_t *chunk = nullptr;
       VO_CHECK_HIP(c, hipMalloc((void **)&chunk, sizeof(int32_t) * LBA_POOL_CHUNK));
       L->pool.push_back(chunk);
+      L->pool_fill.push_back(0);
       L->pool_used = 0;
     }
     vo_svo::SvoKfAll rec;
@@ -517,6 +522,7 @@ int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info, int id_min) {
     rec.n = n;
     rec.d_ids = L->pool.back() + L->pool_used;
     L->pool_used += (size_t)n;
+    L->pool_fill.back() = L->pool_used;
     s->kf_all.push_back(rec);
   }
   if (n > 0) {
@@ -788,6 +794,47 @@ extern "C" int vo_svo_get_keyframe(vo_svo *s, int j, float T_wc[16], float *mapp
   hipLaunchKernelGGL(lba_mappoints_kernel, dim3((k.n + 255) / 256), dim3(256), 0, c->stream, k.d_ids, k.n, L->tab, L->d_map);
   VO_CHECK_HIP(c, hipGetLastError());
   VO_CHECK_HIP(c, hipMemcpyAsync(mappoints, L->d_map, sizeof(float) * 3 * (size_t)k.n, hipMemcpyDeviceToHost, c->stream));
+  VO_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+  return VO_OK;
+}
+
+// the same for ALL keyframes at once — what the reference does at every keyframe (stereo_vo.cpp:813-821): one gather per
+// pool chunk and one copy instead of a launch, a copy and a synchronisation per keyframe
+extern "C" int vo_svo_get_keyframes(vo_svo *s, float *T_wc, int32_t *n_points, float *mappoints, size_t cap_points,
+                                    size_t *total_points) {
+  if (!s) return VO_ERR_INVALID;
+  vo_ctx *c = s->c;
+  if (s->pending) VO_FAIL(c, VO_ERR_INVALID, "call vo_svo_result first");
+  size_t total = 0;
+  for (size_t j = 0; j < s->kf_all.size(); ++j) {
+    if (T_wc) memcpy(T_wc + 16 * j, s->kf_all[j].T_wc, sizeof(float) * 16);
+    if (n_points) n_points[j] = s->kf_all[j].n;
+    total += (size_t)s->kf_all[j].n;
+  }
+  if (total_points) *total_points = total;
+  if (!mappoints || total == 0) return VO_OK;
+  if (total > cap_points) VO_FAIL(c, VO_ERR_CAPACITY, "%zu map points, room for %zu", total, cap_points);
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  vo_svo_lba *L = s->lba;
+  if (L->map_all_cap < total) {
+    VO_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    if (L->d_map_all) (void)hipFree(L->d_map_all);
+    L->d_map_all = nullptr;
+    L->map_all_cap = 0;
+    const size_t want = total + (total >> 1) + 4096;
+    VO_CHECK_HIP(c, hipMalloc((void **)&L->d_map_all, sizeof(float) * 3 * want));
+    L->map_all_cap = want;
+  }
+  size_t off = 0;  // (keyframes lie in the pool in their order, a keyframe never straddles two chunks)
+  for (size_t q = 0; q < L->pool.size(); ++q) {
+    const size_t m = L->pool_fill[q];
+    if (!m) continue;
+    hipLaunchKernelGGL(lba_mappoints_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, L->pool[q], (int)m, L->tab,
+                       L->d_map_all + 3 * off);
+    off += m;
+  }
+  VO_CHECK_HIP(c, hipGetLastError());
+  VO_CHECK_HIP(c, hipMemcpyAsync(mappoints, L->d_map_all, sizeof(float) * 3 * total, hipMemcpyDeviceToHost, c->stream));
   VO_CHECK_HIP(c, hipStreamSynchronize(c->stream));
   return VO_OK;
 }
