@@ -511,15 +511,25 @@ class StereoBench:
 def _render_one(job):
     from visual_odometry_ros_amd import synthetic as S
     cfg, seed, k, n = job
-    st = S.StereoStream(width=cfg["W"], height=cfg["H"], K=cfg["K"], n_u=cfg["n_u"], n_v=cfg["n_v"], seed=seed, speed=cfg["speed"])
+    st = S.StereoStream(width=cfg["W"], height=cfg["H"], K=cfg["K"], n_u=cfg["n_u"], n_v=cfg["n_v"], seed=seed, speed=cfg["speed"],
+                        z_end=scene_length(cfg, n))
     L, R, _ = st.render_pair(st.poses(n)[k])
     return k, L, R
+
+
+def scene_length(cfg, n_frames):
+    """The synthetic corridor ends in a wall at 600 m (the scene every round rendered): a forward-driving stream longer
+    than ~700 frames at 0.8 m per frame would drive into it — the tracks die, the loop ends like the reference's would
+    ('large update!'). Longer streams get a longer corridor (the images of the first 600 m stay what they were, apart from
+    what is visible of the far wall)."""
+    need = n_frames * float(cfg["speed"]) + 150.0
+    return 600.0 if need <= 600.0 else float(int(need / 100.0 + 1) * 100)
 
 
 def render_stream(cfg, seed, n, workers):
     """The n stereo pairs of a stream (numpy u8), rendered by a process pool. MUST run before this process touches a
     GPU (the pool forks). A cache under /tmp keeps repeated runs of the same box (profiling passes) from re-rendering."""
-    key = f"{cfg['W']}x{cfg['H']}_{seed}_{cfg['speed']}_{n}"
+    key = f"{cfg['W']}x{cfg['H']}_{seed}_{cfg['speed']}_{n}" + ("" if scene_length(cfg, n) == 600.0 else f"_z{int(scene_length(cfg, n))}")
     cache = os.path.join(os.environ.get("VO_BENCH_CACHE", "/tmp"), f"vo_bench_stream_{key}.npz")
     if os.path.exists(cache):
         try:

@@ -211,12 +211,14 @@ class StereoStream:
 
     def __init__(self, width=KITTI_SIZE[0], height=KITTI_SIZE[1], K=KITTI_K,
                  baseline=KITTI_BASELINE, n_u=60, n_v=25, n_new=150, seed=2, speed=0.8,
-                 depth_noise=0.01, prior_noise=(0.02, 0.002), margin=31.0):
+                 depth_noise=0.01, prior_noise=(0.02, 0.002), margin=31.0, z_end=600.0):
+        """z_end: the corridor's end wall [m] — a forward-driving stream of n frames needs n * speed well below it."""
         self.width, self.height, self.K, self.baseline = width, height, K, baseline
         self.n_u, self.n_v, self.n_new = n_u, n_v, n_new
         self.seed, self.speed = seed, speed
         self.depth_noise, self.prior_noise, self.margin = depth_noise, prior_noise, margin
-        self.scene = CorridorScene(seed=seed)
+        self.scene = CorridorScene(seed=seed, z_end=z_end)
+        self.z_end = z_end
         self.T_lr = stereo_T_lr(baseline)
 
     def poses(self, n_frames):
