@@ -723,6 +723,12 @@ int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info, int id_min) {
     if (rc < 0) return rc;
   }
   vo_prof_end(c);
+  // ---- points back into the table, and into the track set the next frame starts from: enqueued right behind the
+  // iterations, before the host looks at anything (a solve that ends in NaN or a "large update" ends the run as in the
+  // reference; what it left in the table is then nobody's input; with no landmark in the problem both kernels do nothing) ----
+  hipLaunchKernelGGL(lba_writeback_kernel, dim3((unsigned)((M_ub + 255) / 256)), dim3(256), 0, st, p, L->tab, ref);
+  if (n > 0) hipLaunchKernelGGL(lba_refresh_kernel, dim3((n + 255) / 256), dim3(256), 0, st, t, n, L->tab);
+  VO_CHECK_HIP(c, hipGetLastError());
   // ---- what the host needs: poses, errors, flags, counts ----
   double *o_T = (double *)L->h_res, *o_e = o_T + 16 * LBA_KW;
   int *o_f = (int *)(o_e + 16), *o_d = o_f + 16;
@@ -758,10 +764,6 @@ int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info, int id_min) {
     svo_inv_se3(Tf, win[j].T_wc);  // kf->setPose(inverseSE3_f(Tjw_update_float))
     memcpy(s->kf_all[win[j].global].T_wc, win[j].T_wc, sizeof(win[j].T_wc));
   }
-  // ---- points back into the table, and into the track set the next frame starts from (stream-ordered in front of it) ----
-  hipLaunchKernelGGL(lba_writeback_kernel, dim3((unsigned)((M_ub + 255) / 256)), dim3(256), 0, st, p, L->tab, ref);
-  if (n > 0) hipLaunchKernelGGL(lba_refresh_kernel, dim3((n + 255) / 256), dim3(256), 0, st, t, n, L->tab);
-  VO_CHECK_HIP(c, hipGetLastError());
   if (trace) {
     const double t_3 = lba_now();
     tt[0] += t_1 - t_0;
