@@ -380,6 +380,8 @@ class StereoBench:
     def run(self, first, count, mode, host=False, keep=None, stamps=None, on_result=None):
         """`count` frames, one at a time: the result of frame s is received before frame s+1 is enqueued."""
         s = self.slot
+        if count <= 0:
+            return
         self._enqueue(first, mode, host)
         for step in range(first, first + count):
             r = self.pipe.result(copy=keep is not None and len(keep) < self.args.cpu_frames)
@@ -848,7 +850,7 @@ def cpu_baseline_loop(cfg, args, st, imgs, traj, V, local_rank):
     order next to a second device run (bit-exact track sets: ids, pixels, flags, poses)."""
     from oracle import oracle as O
     from oracle.stereo_vo import StereoVORef
-    nf = max(2, min(args.cpu_frames + 1, len(imgs)))
+    nf = max(2, min(args.cpu_frames + 1, len(imgs), len(traj)))  # (the device poses of these frames are compared)
     thr = cfg["thres"]
     cores = cpu_threads_for_baseline(O, imgs[0][0], imgs[0][1], cfg)
     border = O.IC_REFERENCE if args.strict_border else O.IC_MASKED
@@ -1286,6 +1288,8 @@ def run_mono(cfg, args, rank, local_rank, world, torch, V, barrier, dev):
             fe.enqueueCandidates(slot["N"], (s + 1) & 1)
 
     def run(first, count, keep=None, stamps=None, on_result=None):
+        if count <= 0:
+            return
         enqueue(first)
         for s in range(first, first + count):
             r = pipe.result()

@@ -36,3 +36,16 @@ def test_default_bench_line_shortened():
     assert s["loop_host_images"]["poses_equal_resident_run"] and s["loop_host_images"]["value"] > 100
     assert s["streams_per_gpu"]["2"]["poses_and_track_ids_equal_single_stream_run"]
     assert d["loop"]["keyframes"] >= 5 and d["loop"]["lba_runs"] >= 3 and d["loop"]["end_point_error_m"] < 1.0
+
+
+@pytest.mark.parametrize("flags", [["--steps", "5", "--warmup", "0"], ["--steps", "1", "--warmup", "0", "--no-secondary"],
+                                   ["--config", "2", "--steps", "2", "--warmup", "0"], ["--mode", "closed", "--steps", "2", "--warmup", "0"]])
+def test_bench_with_very_few_steps(flags):
+    """Whatever K and W the caller picks: one JSON line (a warm-up of zero frames once left a frame in flight)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-frames", "2", "--parity-frames", "4", "--streams-per-gpu", ""] + flags,
+                       capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and d["steps"] == int(flags[flags.index("--steps") + 1]) and "roofline" in d
