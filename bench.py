@@ -675,6 +675,7 @@ def run_loop(cfg, args, rank, local_rank, world, torch, V, barrier, dev, imgs, s
         "frame_ms_by_kind": {
             "keyframes": int(kfm.sum()), "mean_ms_keyframe": round(float(d_ms[kfm].mean()), 4) if kfm.any() else None,
             "mean_ms_other": round(float(d_ms[~kfm].mean()), 4) if (~kfm).any() else None,
+            "keyframe_ms_first_12": [round(float(v), 4) for v in d_ms[kfm][:12]],
             "frames_with_border_features": int((replayed[1:] > 0).sum()), "mean_replayed_features": round(float(replayed.mean()), 1)},
         "higher_is_better": True,
         "scaling": "weak",

@@ -314,6 +314,21 @@ int vo_stereo_frame_set_strict_border(vo_ctx *ctx, int strict);
  * context then stays on the stream-ordered arrangement. 0 in normal operation. */
 int vo_stereo_frame_recoveries(const vo_ctx *ctx);
 
+/* ---- test / measurement hooks of one context ----------------------------------------------------------------
+ * The library reads no switch from the environment (VO_SVO_TRACE, which only prints timings, is the exception); a test or
+ * a measurement script sets these per context. Every value defaults to 0 = normal operation.
+ *   VO_DBG_FAIL_JOIN      != 0: the device-side join of strict-border modes 3 / 5 waits for a count that never comes
+ *                         (as under a tool that serialises the queues) — exercises the re-issue path
+ *   VO_DBG_CONC_GRID      > 0: workgroups of the concurrent replay's pool (a pool smaller than the list)
+ *   VO_DBG_SBA_LDS_SOLVE  != 0: the local BA's general dense solve (matrix in LDS) for every window size
+ *   VO_DBG_SKIP_DETECT    != 0: a candidate table filled twice keeps its content (what a frame costs without the
+ *                         detection under it; the results are those of a stale table) */
+enum { VO_DBG_FAIL_JOIN = 0, VO_DBG_CONC_GRID = 1, VO_DBG_SBA_LDS_SOLVE = 2, VO_DBG_SKIP_DETECT = 3, VO_DBG_COUNT = 8 };
+int vo_debug_set(vo_ctx *ctx, int key, int value);
+/* Device and pinned-host allocations made on behalf of this context so far (vo_create included). A steady-state frame —
+ * keyframes and their local BA included — makes none: tests/test_stereo_vo_gpu.py asserts it. */
+int vo_debug_allocation_count(const vo_ctx *ctx, long long *count);
+
 /* Asynchronous: enqueues one frame on the context stream. slot_l0 must hold the
  * previous left pyramid, slot_l1 / slot_r1 the current pair. Track-set inputs
  * are DEVICE pointers when `inputs_on_device` != 0, else host pointers.
@@ -396,8 +411,9 @@ typedef struct {
                                the window may span at most 2^24 landmark ids — the distance from the oldest landmark
                                still tracked at the window's oldest keyframe to the newest, ~80 000 frames of a track
                                that never dies (VO_ERR_CAPACITY beyond). Landmark table, keyframe window and the BA
-                               problem live on the device (about 310 MB per StereoVO from the first keyframe on, with or
-                               without the local BA: the table also serves stats_keyframe) */
+                               problem live on the device, allocated by vo_svo_create (vo_svo_device_bytes: ~32 MB at
+                               configs[1]); the table doubles with the ids handed out (17 B per landmark ever created,
+                               like the reference's all_landmarks_; beyond 2^24 the oldest read as the origin) */
   int rectify;              /* != 0: flagDoUndistortion (stereo_vo.cpp:414-427) — every incoming pair goes through the
                                context's stereo rectification maps (vo_rectify_init_stereo / vo_rectify_set_maps first) on
                                its way into the pyramids; frame.Kl / Kr / T_lr are then the RECTIFIED camera and extrinsics */
@@ -471,6 +487,9 @@ int vo_svo_get_keyframe(vo_svo *svo, int j, float T_wc[16], float *mappoints, in
 /* all of them at once (what trackStereoImages rewrites at every keyframe): T_wc [n_keyframes][16], n_points [n_keyframes],
  * mappoints [total][3] in keyframe order; any of the three may be NULL; *total_points = sum of n_points */
 int vo_svo_get_keyframes(vo_svo *svo, float *T_wc, int32_t *n_points, float *mappoints, size_t cap_points, size_t *total_points);
+/* Device memory this StereoVO holds for its keyframes (landmark table, keyframe ring, keyframe pool, the local BA's window
+ * scratch and arena): ~32 MB at BASELINE configs[1] (max_points 4024, window of 9), all of it allocated by vo_svo_create. */
+int vo_svo_device_bytes(const vo_svo *svo, size_t *bytes);
 
 /* ---- undistortion / stereo rectification in front of the trackers ----------
  * core/visual_odometry/camera.cpp. A context holds the maps of two cameras

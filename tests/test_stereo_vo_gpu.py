@@ -154,8 +154,9 @@ def test_closed_loop_local_ba_sliding_window(vo, oracle):
 
 
 def test_closed_loop_local_ba_landmark_table_wraps(vo, oracle):
-    """The device-side landmark table is addressed by id modulo its 2^24 slots: a stream whose landmark counter crosses
-    that boundary in the middle of a keyframe window (ids 2^24 - 150 ...) must give the same loop."""
+    """The device-side landmark table is addressed by id modulo its size (2^18 slots at first, doubling up to 2^24): a stream
+    whose landmark counter crosses a multiple of every such size in the middle of a keyframe window (ids 2^24 - 150 ...)
+    must give the same loop."""
     W, H, K = 640, 240, (400.0, 400.0, 320.0, 120.0)
     frames = _stream(W, H, K, 20, 8, 5, 0.5, 14)
     log, ref = _run_both(vo, oracle, W, H, K, 20, 8, frames, 21, 4, 14, lba=True, strict=4, prefetch=True, kf_trans=1.2,
@@ -217,14 +218,95 @@ def test_closed_loop_with_rectification(vo, oracle):
 
 def test_closed_loop_local_ba_wide_id_interval(vo, oracle):
     """The window's id interval is set by its oldest landmark still alive: a leap of 300 000 in the landmark counter in the
-    middle of the run makes the interval wider than the window scratch's first allocation (2^18 ids) — it has to grow, and
-    the builder's scans run over an interval that is almost empty."""
+    middle of the run makes the interval wider than the window scratch's first allocation and than the landmark table's
+    first size (2^18 slots) — both have to grow (the table re-hashed), and the builder's scans run over an interval that
+    is almost empty."""
     W, H, K = 640, 240, (400.0, 400.0, 320.0, 120.0)
     frames = _stream(W, H, K, 20, 8, 5, 0.5, 14)
     log, ref = _run_both(vo, oracle, W, H, K, 20, 8, frames, 21, 4, 14, lba=True, strict=4, prefetch=True, kf_trans=1.2,
                          id_jump=(4, 300000))
     assert sum(1 for e in log if e[2]) >= 3, log
     assert ref.ids.min() < 1000 and ref.ids.max() > 300000  # landmarks from both sides of the leap are still tracked
+
+
+def test_closed_loop_kitti_size_sliding_window(vo, oracle):
+    """Steady state at full size: 1241x376 / 60x25 buckets with a keyframe every other frame for 24 frames — the window
+    fills (nine keyframes, seven optimised: the 42 x 42 register solve on several thousand landmarks), slides, ring slots
+    are reused — every frame's track set, flags, world points, pose and every keyframe's map points against the CPU loop."""
+    from visual_odometry_ros_amd import synthetic as S
+    W, H = S.KITTI_SIZE
+    frames = _stream(W, H, S.KITTI_K, 60, 25, 2, 0.8, 24)
+    log, ref = _run_both(vo, oracle, W, H, S.KITTI_K, 60, 25, frames, 21, 6, 24, lba=True, strict=4, prefetch=True, kf_trans=1.0)
+    assert sum(1 for e in log if e[0]) >= 11, log          # more keyframes than the window holds
+    assert sum(1 for e in log if e[2]) >= 9, log
+    assert max(e[3] for e in log) >= 4000, log             # landmarks in the largest problem (nine keyframes)
+
+
+def test_closed_loop_config5(vo, oracle):
+    """BASELINE configs[4] as a closed loop: 3840x2160, 100x80 buckets, win 21, 5-level pyramid — vo_svo_* on four frames
+    (first pair, three steady-state frames, two keyframes with reconstruction) against the CPU loop."""
+    from oracle.stereo_vo import StereoVORef
+    W, H, K = 3840, 2160, (718.856 * 3.0, 718.856 * 3.0, 1920.0, 1080.0)
+    st, imgs = _stream(W, H, K, 100, 80, 2, 0.8, 4)
+    ref = StereoVORef(W, H, K, K, st.T_lr, 100, 80, thres_fast=15, win=21, max_level=4, kf_trans=1.0, lba=False,
+                      sum_mode=oracle.SUM_TREE, tree_width=512, ic_border=oracle.IC_REFERENCE, n_threads=16)
+    c = vo.Context(device=0, max_width=W, max_height=H, max_points=2 * 8000 + 1024, n_slots=5, max_level=4)
+    try:
+        svo = vo.StereoVO(c, W, H, K, K, st.T_lr, 100, 80, thres_fastscore=15, window_size=21, max_level=4, strict_border=4,
+                          local_ba=False, thres_trans=1.0)
+        n_kf = 0
+        for k, (L, R) in enumerate(imgs):
+            gi = svo.trackStereoImages(L, R)
+            ri = ref.track(L, R)
+            g = svo.getTracks()
+            where = f"frame {k}"
+            assert bool(gi.is_keyframe) == ri["keyframe"], where
+            assert np.array_equal(g["ids"], ref.ids), where
+            assert np.array_equal(_bits(g["pts_l"]), _bits(ref.pts_l)) and np.array_equal(_bits(g["pts_r"]), _bits(ref.pts_r)), where
+            assert np.array_equal(g["flags"], ref.flags), where
+            tri = (ref.flags & 1) != 0
+            assert np.array_equal(_bits(g["Xw"][tri]), _bits(ref.Xw[tri])), where
+            assert np.array_equal(_bits(np.array(gi.T_wc).reshape(4, 4)), _bits(ref.T_wp)), where
+            n_kf += int(bool(gi.is_keyframe))
+        assert len(ref.ids) > 4000 and n_kf >= 2
+        svo.close()
+    finally:
+        c.close()
+
+
+def test_steady_state_frames_allocate_nothing(vo):
+    """Everything a stream's keyframes need — landmark table, keyframe ring, keyframe pool, the local BA's window scratch
+    and arena — is allocated by vo_svo_create: between frame 2 and frame 60 of a loop with a keyframe every other frame
+    (the first keyframe, the growing window, the first solve, the full window, the sliding one) the context makes not one
+    device or pinned allocation. Also: what a StereoVO holds for its keyframes at BASELINE configs[1] sizes."""
+    W, H, K = 640, 240, (400.0, 400.0, 320.0, 120.0)
+    st, imgs = _stream(W, H, K, 20, 8, 21, 0.5, 61)
+    c = vo.Context(device=0, max_width=W, max_height=H, max_points=4096, n_slots=5, max_level=4)
+    try:
+        svo = vo.StereoVO(c, W, H, K, K, st.T_lr, 20, 8, thres_fastscore=15, window_size=21, max_level=4, strict_border=4,
+                          local_ba=True, thres_trans=0.9)
+        n_at_2, n_lba, n_kf = None, 0, 0
+        for k in range(61):
+            i = svo.trackStereoImages(*imgs[k])   # host images, no look-ahead: what the reference's caller does
+            n_lba += int(bool(i.lba_ran))
+            n_kf += int(bool(i.is_keyframe))
+            if k == 2:
+                n_at_2 = c.allocation_count()
+        assert n_kf >= 20 and n_lba >= 18
+        assert c.allocation_count() == n_at_2, (n_at_2, c.allocation_count())
+        svo.close()
+    finally:
+        c.close()
+    from visual_odometry_ros_amd import synthetic as S
+    W, H = S.KITTI_SIZE
+    c = vo.Context(device=0, max_width=W, max_height=H, max_points=2 * 1500 + 1024, n_slots=5, max_level=6)
+    try:
+        svo = vo.StereoVO(c, W, H, S.KITTI_K, S.KITTI_K, S.stereo_T_lr(), 60, 25, thres_fastscore=15, window_size=21, max_level=6,
+                          strict_border=4, local_ba=True)
+        assert svo.deviceBytes() <= 40 << 20, svo.deviceBytes()   # (was 310 MB: a 2^24-slot landmark table)
+        svo.close()
+    finally:
+        c.close()
 
 
 def test_closed_loop_is_deterministic(vo):

@@ -103,7 +103,7 @@ SYMBOLS = [
     "vo_new_point_candidates_get", "vo_stereo_frame_enqueue_closed", "vo_stereo_frame_new_points",
     "vo_stereo_frame_enqueue_closed_world", "vo_stereo_frame_recoveries", "vo_svo_create", "vo_svo_destroy", "vo_svo_track", "vo_svo_enqueue",
     "vo_svo_prefetch", "vo_svo_result", "vo_svo_get_tracks", "vo_svo_get_new_points", "vo_svo_keyframe_count", "vo_svo_get_keyframe", "vo_svo_get_keyframes", "vo_triangulate_dlt", "vo_batch_create", "vo_batch_destroy",
-    "vo_batch_last_error", "vo_batch_run",
+    "vo_batch_last_error", "vo_batch_run", "vo_debug_set", "vo_debug_allocation_count", "vo_svo_device_bytes",
     "vo_se3_exp", "vo_ids_reset", "vo_ids_peek", "vo_ids_new_frames", "vo_ids_new_landmarks", "vo_compact_tracks",
 ]
 
@@ -154,6 +154,9 @@ def load():
     lib.vo_svo_keyframe_count.argtypes = [vp, vp]
     lib.vo_svo_get_keyframe.argtypes = [vp, ci, vp, vp, ci, vp]
     lib.vo_svo_get_keyframes.argtypes = [vp, vp, vp, vp, C.c_size_t, vp]
+    lib.vo_svo_device_bytes.argtypes = [vp, vp]
+    lib.vo_debug_set.argtypes = [vp, ci, ci]
+    lib.vo_debug_allocation_count.argtypes = [vp, vp]
     lib.vo_triangulate_dlt.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp]
     lib.vo_batch_create.argtypes = [C.POINTER(VoConfig), C.POINTER(SvoParams), ci, C.POINTER(C.c_void_p)]
     lib.vo_batch_destroy.argtypes = [vp]

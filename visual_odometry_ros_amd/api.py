@@ -10,6 +10,7 @@ MaskVec; matrices are row-major numpy arrays.
 Everything here calls libvo_hip.so. Nothing falls back to numpy or the oracle.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -49,6 +50,23 @@ class Context:
                 self._h = C.c_void_p()
             raise VoError(rc, msg)
         self.cfg = cfg
+        # test / measurement switches (include/vo_hip.h: vo_debug_set). The library itself reads no environment variable;
+        # this mirror hands the ones the test-suite and tools/ set to the context it creates.
+        for key, name in enumerate(("VO_DEBUG_FAIL_JOIN", "VO_CONC_GRID", "VO_SBA_LDS_SOLVE", "VO_DEBUG_SKIP_DETECT")):
+            v = os.environ.get(name)
+            if v:
+                self.debug_set(key, int(v) if v.lstrip("-").isdigit() else 1)
+
+    DBG_FAIL_JOIN, DBG_CONC_GRID, DBG_SBA_LDS_SOLVE, DBG_SKIP_DETECT = 0, 1, 2, 3
+
+    def debug_set(self, key, value):
+        self.check(self.lib.vo_debug_set(self._h, int(key), int(value)))
+
+    def allocation_count(self):
+        """Device + pinned allocations made for this context so far (a steady-state frame makes none)."""
+        n = C.c_longlong(0)
+        self.check(self.lib.vo_debug_allocation_count(self._h, C.byref(n)))
+        return n.value
 
     def close(self):
         if getattr(self, "_h", None):
@@ -770,18 +788,21 @@ class StereoVO:
         self.stats_frame = []  # AlgorithmStatistics::FrameStatistics::Twc per frame (stereo_vo.cpp:979-980)
 
     @classmethod
-    def from_yaml(cls, path, device=0, **overrides):
+    def from_yaml(cls, path, device=0, max_points=None, **overrides):
         """StereoVO(mode = "rosbag", directory_intrinsic = path) of the reference (stereo_vo.cpp:15-57, :118-280): the
         object configured by one of its config/stereo/*.yaml files. The context is created here (sized by the file) and
         closed with the object. With flagDoUndistortion the pairs go through the rectification maps and the loop runs on
         the rectified camera (:414-427); without, on the raw cameras and T_lr of the file. `overrides`: keyword
-        arguments of the constructor that the file does not know (strict_border, local_ba)."""
+        arguments of the constructor that the file does not know (strict_border, local_ba). `max_points`: capacity of a
+        track set (default 2 * bins + 1024; the reference has no such bound — several survivors may share a bin while
+        every empty bin adds a landmark — so a caller that sees VO_ERR_CAPACITY raises it)."""
         from . import config as _config
         cfg = _config.load_stereo_config(path)
         cl, cr = cfg["camera"]["left"], cfg["camera"]["right"]
         W, H = cl["width"], cl["height"]
         fe, ft, me, ku = cfg["feature_extractor"], cfg["feature_tracker"], cfg["motion_estimator"], cfg["keyframe_update"]
-        ctx = Context(device=device, max_width=W, max_height=H, max_points=2 * fe["n_bins_u"] * fe["n_bins_v"] + 1024, n_slots=5,
+        cap = int(max_points) if max_points else 2 * fe["n_bins_u"] * fe["n_bins_v"] + 1024
+        ctx = Context(device=device, max_width=W, max_height=H, max_points=cap, n_slots=5,
                       max_level=ft["max_level"])
         try:
             Kl, Kr, T_lr, rectify = cl["K"], cr["K"], cfg["T_lr"], False
@@ -831,7 +852,7 @@ class StereoVO:
         i = self._info
         T = np.array(i.T_wc, np.float32).reshape(4, 4)
         self.stats_frame.append(T)
-        return i
+        return SvoFrameInfo.from_buffer_copy(i)  # (the caller's own copy: a stored info must not change with the next frame)
 
     def trackStereoImages(self, img_left, img_right, timestamp=0.0):
         """numpy u8 images (host) or (device address, stride) pairs. Returns the frame's SvoFrameInfo."""
@@ -883,6 +904,12 @@ class StereoVO:
                                                       C.addressof(n)))
         k = n.value
         return dict(pts_l=pl[:k], pts_r=pr[:k], mask_new=m[:k].astype(bool), accept=a[:k].astype(bool))
+
+    def deviceBytes(self):
+        """Device memory held for this stream's keyframes (table, ring, pool, the local BA's scratch and arena)."""
+        n = C.c_size_t(0)
+        self.ctx.check(self.lib.vo_svo_device_bytes(self._h, C.byref(n)))
+        return n.value
 
     def getKeyframes(self):
         """AlgorithmStatistics::stats_keyframe as of now (stereo_vo.cpp:805-821): [(T_wc, mappoints [n][3])] for every

@@ -46,9 +46,6 @@ extern "C" int vo_batch_create(const vo_config *cfg, const vo_svo_params *prm, i
   for (int s = 0; s < n_streams; ++s) {
     int rc = vo_create(cfg, &b->ctx[s]);
     if (rc == VO_OK) rc = vo_svo_create(b->ctx[s], &q, &b->svo[s]);
-    // MEASUREMENT SWITCH (VO_BATCH_ONE_STREAM=1): ingestion of the next pair on the context's main stream — one HIP stream
-    // per context instead of two, so that S contexts do not share hardware queues
-    if (rc == VO_OK && n_streams > 1 && getenv("VO_BATCH_ONE_STREAM")) rc = vo_set_ingest_side_stream(b->ctx[s], 0);
     if (rc != VO_OK) {
       vo_batch_destroy(b);
       return rc;

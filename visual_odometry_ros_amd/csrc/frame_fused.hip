@@ -549,7 +549,7 @@ int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, 
 #ifdef FRAME_STAMP
   {
     static int *dbg = nullptr;
-    if (!dbg) (void)hipMalloc((void **)&dbg, sizeof(int) * 8 * (size_t)(2 * c->cfg.max_points));
+    if (!dbg) (void)vo_dev_malloc(c, (void **)&dbg, sizeof(int) * 8 * (size_t)(2 * c->cfg.max_points));
     if (phase == 0) (void)hipMemsetAsync(dbg, 0, sizeof(int) * 8 * (size_t)(n + n_new), c->stream);
     a.dbg = dbg;
     vo_frame_dbg_ptr = dbg;
@@ -605,8 +605,8 @@ int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, 
     a.ic.tl2 = nullptr;
     a.ic.p1e = nullptr;
   }
-  static const int cg_env = getenv("VO_CONC_GRID") ? atoi(getenv("VO_CONC_GRID")) : 0;  // (tests/test_frame_gpu.py: a pool smaller than the list; experiments)
-  const int cg = cg_env > 0 ? cg_env : (b.conc_grid > 0 ? b.conc_grid : IC_CONC_GRID);
+  const int cg_dbg = c->dbg[VO_DBG_CONC_GRID];  // (tests/test_frame_gpu.py: a pool smaller than the list; experiments)
+  const int cg = cg_dbg > 0 ? cg_dbg : (b.conc_grid > 0 ? b.conc_grid : IC_CONC_GRID);
   switch (prm->win) {
     case 13: frame_launch<13>(c, a, phase, p1_target, done_target, cg); break;
     case 15: frame_launch<15>(c, a, phase, p1_target, done_target, cg); break;

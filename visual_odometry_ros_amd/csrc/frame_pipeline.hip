@@ -31,8 +31,8 @@ static double vo_tt_last; static int vo_tt_n;
 #endif
 
 template <typename T>
-static hipError_t fs_alloc(T **p, size_t n) {
-  return hipMalloc((void **)p, (n ? n : 1) * sizeof(T));
+static hipError_t fs_alloc(vo_ctx *c, T **p, size_t n) {
+  return vo_dev_malloc(c, (void **)p, (n ? n : 1) * sizeof(T));
 }
 
 static size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
@@ -45,28 +45,28 @@ int vo_frame_init(vo_ctx *c) {
   f->cap = (int)N;
   float **f2[] = {&f->in_l0, &f->in_r0, &f->in_new, &f->A_pl0, &f->A_pl1, &f->A_pr1, &f->B_pl1, &f->B_pr1,
                   &f->C_pl1, &f->C_pr1, &f->new_back, &f->A_ref, &f->A_lastpu, &f->bin_r};
-  for (float **p : f2) VO_CHECK_HIP(c, fs_alloc(p, 2 * N));
+  for (float **p : f2) VO_CHECK_HIP(c, fs_alloc(c, p, 2 * N));
   float **f3[] = {&f->in_X, &f->A_X, &f->B_X, &f->C_X};
-  for (float **p : f3) VO_CHECK_HIP(c, fs_alloc(p, 3 * N));
+  for (float **p : f3) VO_CHECK_HIP(c, fs_alloc(c, p, 3 * N));
   float **f1[] = {&f->F_scale, &f->A_scale, &f->e1, &f->e2, &f->e3};
-  for (float **p : f1) VO_CHECK_HIP(c, fs_alloc(p, N));
+  for (float **p : f1) VO_CHECK_HIP(c, fs_alloc(c, p, N));
   int32_t **i1[] = {&f->F_orig, &f->A_orig, &f->B_orig, &f->C_orig};
-  for (int32_t **p : i1) VO_CHECK_HIP(c, fs_alloc(p, N));
+  for (int32_t **p : i1) VO_CHECK_HIP(c, fs_alloc(c, p, N));
   uint8_t **u1[] = {&f->m1, &f->m2, &f->m3, &f->mG, &f->st1, &f->st2, &f->st3, &f->A_touched, &f->A_cls, &f->in_flags,
                     &f->bin_m};
-  for (uint8_t **p : u1) VO_CHECK_HIP(c, fs_alloc(p, N));
+  for (uint8_t **p : u1) VO_CHECK_HIP(c, fs_alloc(c, p, N));
   f->res_cap = align16(sizeof(vo_frame_hdr)) + 2 * align16(N) + 4 * align16(sizeof(float) * 2 * N);
-  VO_CHECK_HIP(c, hipMalloc((void **)&f->res_dev, f->res_cap));
-  VO_CHECK_HIP(c, hipHostMalloc((void **)&f->res_host, f->res_cap, hipHostMallocDefault));
+  VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&f->res_dev, f->res_cap));
+  VO_CHECK_HIP(c, vo_host_malloc(c, (void **)&f->res_host, f->res_cap, hipHostMallocDefault));
   memset(f->res_host, 0, f->res_cap);  // (the polled sequence word must not match by accident)
   VO_CHECK_HIP(c, hipMemsetAsync(f->res_dev, 0, f->res_cap, c->stream));
   VO_CHECK_HIP(c, hipEventCreateWithFlags(&f->ev_done, hipEventDisableTiming));
-  VO_CHECK_HIP(c, hipMalloc((void **)&f->ctl, vo_ic_ctl_bytes()));
+  VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&f->ctl, vo_ic_ctl_bytes()));
   VO_CHECK_HIP(c, hipMemsetAsync(f->ctl, 0, vo_ic_ctl_bytes(), c->stream));
   // [1] = finished workgroups of the replay's last kernel; from byte 128 on: 64 shards of the pass-1 count, 128 bytes apart
-  VO_CHECK_HIP(c, hipMalloc((void **)&f->adv_done, 64));
+  VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&f->adv_done, 64));
   VO_CHECK_HIP(c, hipMemsetAsync(f->adv_done, 0, 64, c->stream));
-  VO_CHECK_HIP(c, hipMalloc((void **)&f->sync, 128 + 64 * 128));
+  VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&f->sync, 128 + 64 * 128));
   VO_CHECK_HIP(c, hipMemsetAsync(f->sync, 0, 128 + 64 * 128, c->stream));
   return VO_OK;
 }
@@ -127,10 +127,25 @@ extern "C" int vo_stereo_frame_set_strict_border(vo_ctx *c, int strict) {
 // bp != null: the closed step [10] — the candidates are the per-bin best keypoints of table `table`
 // (vo_new_point_candidates_enqueue), all tracked speculatively, emitted by the BA launch's epilogue
 // T_pw / T_cw_prior != null: the reference's own data flow — Xp holds WORLD points (vo_stereo_frame_enqueue_closed_world)
+static int vo_frame_enqueue_body(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, int slot_l1, int slot_r1,
+                                 const float *pts_l0, const float *pts_r0, const float *Xp, const uint8_t *flags, int n,
+                                 const float dT_prior[16], const float *pts_new, int n_new, int inputs_on_device,
+                                 const vo_bin_params *bp, int table, const float *T_pw, const float *T_cw_prior);
 int vo_frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, int slot_l1, int slot_r1,
                           const float *pts_l0, const float *pts_r0, const float *Xp, const uint8_t *flags, int n,
                           const float dT_prior[16], const float *pts_new, int n_new, int inputs_on_device,
                           const vo_bin_params *bp, int table, const float *T_pw, const float *T_cw_prior) {
+  const int rc = vo_frame_enqueue_body(c, prm, slot_l0, slot_l1, slot_r1, pts_l0, pts_r0, Xp, flags, n, dT_prior, pts_new, n_new,
+                                       inputs_on_device, bp, table, T_pw, T_cw_prior);
+  // a track-set advance armed by vo_frame_set_advance belongs to THIS enqueue, whether it got as far as the BA launch or
+  // not: it never stays armed for a later frame of this context (its track sets may be gone by then)
+  if (c && c->frame) c->frame->adv_next.on = 0;
+  return rc;
+}
+static int vo_frame_enqueue_body(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, int slot_l1, int slot_r1,
+                                 const float *pts_l0, const float *pts_r0, const float *Xp, const uint8_t *flags, int n,
+                                 const float dT_prior[16], const float *pts_new, int n_new, int inputs_on_device,
+                                 const vo_bin_params *bp, int table, const float *T_pw, const float *T_cw_prior) {
   if (!c || !prm || !dT_prior || n < 0 || n_new < 0) return VO_ERR_INVALID;
   if ((T_pw != nullptr) != (T_cw_prior != nullptr)) return VO_ERR_INVALID;
   if (T_pw && !vo_frame_fused_supported(prm->win))
@@ -436,8 +451,7 @@ int vo_frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, i
     if (c->frame_strict_now == 3 || c->frame_strict_now == 5) {  // the replay runs on its own stream: join on the device
       gf.join_word = f->sync + 1;
       gf.join_target = f->sync_done_target;
-      static const bool fail_join = getenv("VO_DEBUG_FAIL_JOIN") != nullptr;  // tests: a join that cannot be met
-      if (fail_join) gf.join_target += 1 << 20;
+      if (c->dbg[VO_DBG_FAIL_JOIN]) gf.join_target += 1 << 20;  // tests: a join that cannot be met
     }
     gf.ctl_words = (int)(vo_ic_ctl_bytes() / 4);
     gf.nt_word = vo_ic_ctl_nt_word();
@@ -467,16 +481,18 @@ int vo_frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, i
   }
   VoAdvArgs adv_now = f->adv_next;
   f->adv_next.on = 0;
+  int adv_workers = 0;
   if (adv_now.on) {
     if (!(fused && tab)) VO_FAIL(c, VO_ERR_INVALID, "the track-set advance needs the closed frame on the fused path");
-    f->adv_total += (tab->n_bins + 63) / 64;  // one worker wavefront per 64 bins (gn_pose.hip)
+    adv_workers = (tab->n_bins + 63) / 64;  // one worker wavefront per 64 bins (gn_pose.hip)
     adv_now.dlt_done = f->adv_done;
-    adv_now.dlt_target = f->adv_total;
+    adv_now.dlt_target = f->adv_total + adv_workers;
     gf.adv = &adv_now;
   }
   RC(vo_gn_enqueue(c, true, false, f->C_X, f->C_pl1, f->C_pr1, n, nullptr, prm->Kl, prm->Kr,
                    prm->T_lr, prm->thres_poseba, 0, dT_prior, f->hdr->dT, f->mG, &f->hdr->gn, true,
                    n > 0 ? f->stage : nullptr, f->C_orig, 4, 60.0f, n > 0 ? &gf : nullptr));
+  f->adv_total += adv_workers;  // (cumulative, like the word the workers count in: only a launch that went out counts)
   if (n_new > 0 && !fused) VO_CHECK_HIP(c, hipStreamWaitEvent(s, c->ev_join, 0));
   VO_TT("gn launch");
   // one D2H of the packed block into pinned memory (general path; the fused path's GN launch did it)
@@ -521,6 +537,17 @@ extern "C" int vo_stereo_frame_enqueue_closed_world(vo_ctx *c, const vo_stereo_p
 }
 
 extern "C" int vo_stereo_frame_recoveries(const vo_ctx *c) { return c ? c->frame_recoveries : VO_ERR_INVALID; }
+
+extern "C" int vo_debug_set(vo_ctx *c, int key, int value) {
+  if (!c || key < 0 || key >= VO_DBG_COUNT) return VO_ERR_INVALID;
+  c->dbg[key] = value;
+  return VO_OK;
+}
+extern "C" int vo_debug_allocation_count(const vo_ctx *c, long long *count) {
+  if (!c || !count) return VO_ERR_INVALID;
+  *count = c->n_allocs;
+  return VO_OK;
+}
 
 extern "C" int vo_stereo_frame_new_points(vo_ctx *c, float *pts_new, int *n_new) {
   if (!c || !c->frame || !n_new) return VO_ERR_INVALID;

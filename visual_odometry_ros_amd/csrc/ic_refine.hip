@@ -121,7 +121,7 @@ static int ic_records(vo_ctx *c, IcArgs &a) {
   if (!c->ic_rec) {
     const size_t N = (size_t)c->cfg.max_points;
     const size_t bytes = N * (4 + 4 + 4 + 2 * IC_MW * 4 + 3 * IC_NELEM * 4 + IC_NELEM * 4 + IC_NELEM * 4 + IC_MW * 4 + 8 + 4) + IC_JAC_BYTES;
-    VO_CHECK_HIP(c, hipMalloc(&c->ic_rec, bytes));
+    VO_CHECK_HIP(c, vo_dev_malloc(c, &c->ic_rec, bytes));
     VO_CHECK_HIP(c, hipMemsetAsync(c->ic_rec, 0, bytes, c->stream));
   }
   const size_t N = (size_t)c->cfg.max_points;

@@ -622,7 +622,7 @@ static int orb_prepare(vo_ctx *c, int w, int h, const vo_orb_params *p, int max_
     if (S->arena) (void)hipFree(S->arena);
     S->arena = nullptr;
     S->cap = 0;
-    VO_CHECK_HIP(c, hipMalloc((void **)&S->arena, off));
+    VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&S->arena, off));
     S->cap = off;
   }
   // coefficient tables
@@ -809,7 +809,7 @@ extern "C" int vo_extract_orb_with_binning_enqueue(vo_ctx *c, int slot, const vo
     if (S->h_res) (void)hipHostFree(S->h_res);
     S->h_res = nullptr;
     S->h_cap = 0;
-    VO_CHECK_HIP(c, hipHostMalloc((void **)&S->h_res, need, hipHostMallocDefault));
+    VO_CHECK_HIP(c, vo_host_malloc(c, (void **)&S->h_res, need, hipHostMallocDefault));
     S->h_cap = need;
   }
   int32_t *h_w = (int32_t *)(S->h_res + 64);
@@ -891,20 +891,17 @@ extern "C" int vo_new_point_candidates_enqueue(vo_ctx *c, int slot, const vo_bin
     T.xy = nullptr;
     T.has = nullptr;
     T.n_bins = 0;
-    VO_CHECK_HIP(c, hipMalloc((void **)&T.xy, sizeof(float) * 2 * (size_t)total));
-    VO_CHECK_HIP(c, hipMalloc((void **)&T.has, (size_t)total));
+    VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&T.xy, sizeof(float) * 2 * (size_t)total));
+    VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&T.has, (size_t)total));
     if (!T.ready) VO_CHECK_HIP(c, hipEventCreateWithFlags(&T.ready, hipEventDisableTiming));
-    if (!T.h_flags) VO_CHECK_HIP(c, hipHostMalloc((void **)&T.h_flags, 64, hipHostMallocDefault));
+    if (!T.h_flags) VO_CHECK_HIP(c, vo_host_malloc(c, (void **)&T.h_flags, 64, hipHostMallocDefault));
     T.n_bins = total;
   }
-  {  // MEASUREMENT ONLY (VO_DEBUG_SKIP_DETECT): a table filled once keeps its content — what the frame costs without the
-     // detection under it (results are those of a stale table)
-    static const bool dbg_skip = getenv("VO_DEBUG_SKIP_DETECT") != nullptr;
-    static int dbg_filled[2] = {0, 0};
-    if (dbg_skip && dbg_filled[table]++ >= 2) {
-      VO_CHECK_HIP(c, hipEventRecord(T.ready, c->stream2));
-      return VO_OK;
-    }
+  // MEASUREMENT ONLY (vo_debug_set VO_DBG_SKIP_DETECT): a table filled twice keeps its content — what the frame costs
+  // without the detection under it (results are those of a stale table)
+  if (c->dbg[VO_DBG_SKIP_DETECT] && T.dbg_filled++ >= 2) {
+    VO_CHECK_HIP(c, hipEventRecord(T.ready, c->stream2));
+    return VO_OK;
   }
   hipStream_t caller = c->stream;
   c->stream = c->stream2;  // every launcher below enqueues on ctx->stream

@@ -172,8 +172,8 @@ static int rect_alloc(vo_ctx *c, int cam, int w, int h) {
     VO_FAIL(c, VO_ERR_CAPACITY, "map %dx%d exceeds vo_config %dx%d", w, h, c->cfg.max_width, c->cfg.max_height);
   if (!c->rect_u[cam]) {
     const size_t bytes = sizeof(float) * (size_t)c->cfg.max_width * c->cfg.max_height;
-    VO_CHECK_HIP(c, hipMalloc((void **)&c->rect_u[cam], bytes));
-    VO_CHECK_HIP(c, hipMalloc((void **)&c->rect_v[cam], bytes));
+    VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&c->rect_u[cam], bytes));
+    VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&c->rect_v[cam], bytes));
   }
   c->rect_w[cam] = w;
   c->rect_h[cam] = h;

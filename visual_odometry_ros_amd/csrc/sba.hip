@@ -1061,17 +1061,27 @@ int vo_sba_enqueue_iterations(vo_ctx *c, const SbaDev &d, int max_iter) {
     else
       hipLaunchKernelGGL(sba_update_point_kernel<false>, dim3(n_err), dim3(64), 0, s, d, update, point);
   };
-  static const bool no_reg_solve = getenv("VO_SBA_LDS_SOLVE") != nullptr;  // (A/B switch: the general kernel for every n)
-  const bool reg_solve = n == 42 && !no_reg_solve;  // the steady-state window: 9 keyframes, 7 of them optimised
+  // every window of up to ten keyframes (1..8 optimised poses) takes the register solve: three launches per iteration
+  // (vo_debug_set VO_DBG_SBA_LDS_SOLVE: the general kernel for every n, an A/B switch)
+  const bool reg_solve = No >= 1 && No <= 8 && !c->dbg[VO_DBG_SBA_LDS_SOLVE];
   for (int iter = 0; iter < max_iter; ++iter) {
     launch_update_point(iter > 0 ? 1 : 0, 1);
     if (No > 0) {
       hipLaunchKernelGGL(sba_pose_schur_kernel, dim3(No * SBA_PG + (No * (No + 1) / 2) * SBA_SG), dim3(SBA_WG), 0, s, d);
       if (!reg_solve) hipLaunchKernelGGL(sba_assemble_kernel, dim3((n * n + n + 63) / 64), dim3(64), 0, s, d);
     }
-    if (reg_solve)  // (assembles the reduced system itself)
-      hipLaunchKernelGGL(sba_solve_reg_kernel<42>, dim3(1), dim3(SBA_SOLVE_WG), 0, s, d, iter);
-    else
+    if (reg_solve) {  // (assembles the reduced system itself)
+      switch (No) {
+        case 1: hipLaunchKernelGGL(sba_solve_reg_kernel<6>, dim3(1), dim3(SBA_SOLVE_WG), 0, s, d, iter); break;
+        case 2: hipLaunchKernelGGL(sba_solve_reg_kernel<12>, dim3(1), dim3(SBA_SOLVE_WG), 0, s, d, iter); break;
+        case 3: hipLaunchKernelGGL(sba_solve_reg_kernel<18>, dim3(1), dim3(SBA_SOLVE_WG), 0, s, d, iter); break;
+        case 4: hipLaunchKernelGGL(sba_solve_reg_kernel<24>, dim3(1), dim3(SBA_SOLVE_WG), 0, s, d, iter); break;
+        case 5: hipLaunchKernelGGL(sba_solve_reg_kernel<30>, dim3(1), dim3(SBA_SOLVE_WG), 0, s, d, iter); break;
+        case 6: hipLaunchKernelGGL(sba_solve_reg_kernel<36>, dim3(1), dim3(SBA_SOLVE_WG), 0, s, d, iter); break;
+        case 7: hipLaunchKernelGGL(sba_solve_reg_kernel<42>, dim3(1), dim3(SBA_SOLVE_WG), 0, s, d, iter); break;
+        default: hipLaunchKernelGGL(sba_solve_reg_kernel<48>, dim3(1), dim3(SBA_SOLVE_WG), 0, s, d, iter); break;
+      }
+    } else
       hipLaunchKernelGGL(sba_solve_kernel, dim3(1), dim3(64), lds, s, d, iter);
   }
   if (max_iter > 0) launch_update_point(1, 0);
@@ -1164,7 +1174,7 @@ extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, co
     if (c->sba->dev) (void)hipFree(c->sba->dev);
     c->sba->dev = nullptr;
     c->sba->cap = 0;
-    VO_CHECK_HIP(c, hipMalloc(&c->sba->dev, ar.off + (ar.off >> 2)));
+    VO_CHECK_HIP(c, vo_dev_malloc(c, &c->sba->dev, ar.off + (ar.off >> 2)));
     c->sba->cap = ar.off + (ar.off >> 2);
   }
   const size_t out_bytes = sizeof(double) * (16 * (size_t)Nf + 3 * (size_t)M + (size_t)p->max_iter + 1) + 64;
@@ -1175,7 +1185,7 @@ extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, co
     if (c->sba->stage) (void)hipHostFree(c->sba->stage);
     c->sba->stage = nullptr;
     c->sba->stage_cap = 0;
-    VO_CHECK_HIP(c, hipHostMalloc(&c->sba->stage, stage_need + (stage_need >> 2), hipHostMallocDefault));
+    VO_CHECK_HIP(c, vo_host_malloc(c, &c->sba->stage, stage_need + (stage_need >> 2), hipHostMallocDefault));
     c->sba->stage_cap = stage_need + (stage_need >> 2);
   }
   SBA_T(3);

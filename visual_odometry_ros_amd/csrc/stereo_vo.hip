@@ -185,26 +185,22 @@ extern "C" int vo_triangulate_dlt(vo_ctx *c, const float *pts0, const float *pts
   hipStream_t s = c->stream;
   VO_CHECK_HIP(c, hipMemcpyAsync(c->d_pts0, pts0, sizeof(float) * 2 * n, hipMemcpyHostToDevice, s));
   VO_CHECK_HIP(c, hipMemcpyAsync(c->d_pts1, pts1, sizeof(float) * 2 * n, hipMemcpyHostToDevice, s));
-  float *dX0 = c->d_X, *dX1 = nullptr;
-  if (X1) {  // d_pts2 / d_pts3 are neighbours of 2n floats each only by accident: use a temporary for the second output
-    VO_CHECK_HIP(c, hipMalloc((void **)&dX1, sizeof(float) * 3 * n));
-  }
+  float *dX0 = c->d_X, *dX1 = X1 ? c->d_X2 : nullptr;
   hipLaunchKernelGGL(svo_dlt_kernel, dim3((n + 63) / 64), dim3(64), 0, s, cam, c->d_pts0, c->d_pts1, n, dX0, dX1);
   VO_CHECK_HIP(c, hipGetLastError());
   VO_CHECK_HIP(c, hipMemcpyAsync(X0, dX0, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, s));
   if (X1) VO_CHECK_HIP(c, hipMemcpyAsync(X1, dX1, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, s));
   VO_CHECK_HIP(c, hipStreamSynchronize(s));
-  if (dX1) (void)hipFree(dX1);
   return VO_OK;
 }
 
 // ---- host: the driver -------------------------------------------------------------------------------------------------
 static int svo_alloc_ts(vo_ctx *c, SvoTrackSet *t, int cap) {
-  VO_CHECK_HIP(c, hipMalloc((void **)&t->pts_l, sizeof(float) * 2 * cap));
-  VO_CHECK_HIP(c, hipMalloc((void **)&t->pts_r, sizeof(float) * 2 * cap));
-  VO_CHECK_HIP(c, hipMalloc((void **)&t->Xw, sizeof(float) * 3 * cap));
-  VO_CHECK_HIP(c, hipMalloc((void **)&t->flags, (size_t)cap));
-  VO_CHECK_HIP(c, hipMalloc((void **)&t->ids, sizeof(int32_t) * cap));
+  VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&t->pts_l, sizeof(float) * 2 * cap));
+  VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&t->pts_r, sizeof(float) * 2 * cap));
+  VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&t->Xw, sizeof(float) * 3 * cap));
+  VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&t->flags, (size_t)cap));
+  VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&t->ids, sizeof(int32_t) * cap));
   return VO_OK;
 }
 static void svo_free_ts(SvoTrackSet *t) {
@@ -230,10 +226,10 @@ extern "C" int vo_svo_create(vo_ctx *c, const vo_svo_params *prm, vo_svo **out) 
   s->cap = c->cfg.max_points;
   int rc = VO_OK;
   for (int k = 0; k < 2 && rc == VO_OK; ++k) rc = svo_alloc_ts(c, &s->ts[k], s->cap);
-  if (rc == VO_OK && hipMalloc((void **)&s->d_accept, (size_t)s->cap) != hipSuccess) rc = VO_ERR_HIP;
-  if (rc == VO_OK && hipMalloc((void **)&s->d_acc_bin, sizeof(int) * (size_t)s->cap) != hipSuccess) rc = VO_ERR_HIP;
-  if (rc == VO_OK && hipMalloc((void **)&s->d_hdr, sizeof(SvoHdr)) != hipSuccess) rc = VO_ERR_HIP;
-  if (rc == VO_OK && hipHostMalloc((void **)&s->h_hdr, sizeof(SvoHdr), hipHostMallocDefault) != hipSuccess) rc = VO_ERR_HIP;
+  if (rc == VO_OK && vo_dev_malloc(c, (void **)&s->d_accept, (size_t)s->cap) != hipSuccess) rc = VO_ERR_HIP;
+  if (rc == VO_OK && vo_dev_malloc(c, (void **)&s->d_acc_bin, sizeof(int) * (size_t)s->cap) != hipSuccess) rc = VO_ERR_HIP;
+  if (rc == VO_OK && vo_dev_malloc(c, (void **)&s->d_hdr, sizeof(SvoHdr)) != hipSuccess) rc = VO_ERR_HIP;
+  if (rc == VO_OK && vo_host_malloc(c, (void **)&s->h_hdr, sizeof(SvoHdr), hipHostMallocDefault) != hipSuccess) rc = VO_ERR_HIP;
   if (rc != VO_OK) {
     vo_svo_destroy(s);
     VO_FAIL(c, rc, "StereoVO: device allocation failed");
@@ -247,9 +243,16 @@ extern "C" int vo_svo_create(vo_ctx *c, const vo_svo_params *prm, vo_svo **out) 
   s->kf_rot = prm->kf_rotation_deg * (float)(3.14159265358979323846 / 180.0);  // thres_rotation * D2R
   s->first = true;
   for (int k = 0; k < 5; ++k) s->slot[k] = k;
-  RC(vo_stereo_frame_set_strict_border(c, prm->strict_border));
-  RC(vo_set_pyramid_window_hint(c, prm->frame.win));
-  RC(vo_set_ingest_side_stream(c, 1));
+  // the keyframes' device storage (landmark table, keyframe ring, the local BA's scratch and arena) is made here, so that a
+  // failure surfaces at construction and no keyframe ever allocates
+  rc = vo_svo_lba_init(s);
+  if (rc >= 0) rc = vo_stereo_frame_set_strict_border(c, prm->strict_border);
+  if (rc >= 0) rc = vo_set_pyramid_window_hint(c, prm->frame.win);
+  if (rc >= 0) rc = vo_set_ingest_side_stream(c, 1);
+  if (rc < 0) {  // (the context's error text is the failing call's)
+    vo_svo_destroy(s);
+    return rc;
+  }
   *out = s;
   return VO_OK;
 }
@@ -257,6 +260,7 @@ extern "C" int vo_svo_create(vo_ctx *c, const vo_svo_params *prm, vo_svo **out) 
 extern "C" void vo_svo_destroy(vo_svo *s) {
   if (!s) return;
   if (s->c) (void)hipSetDevice(s->c->device);
+  if (s->c && s->c->frame) memset(&s->c->frame->adv_next, 0, sizeof(s->c->frame->adv_next));  // (points into the track sets freed below)
   for (int k = 0; k < 2; ++k) svo_free_ts(&s->ts[k]);
   if (s->d_accept) (void)hipFree(s->d_accept);
   if (s->d_acc_bin) (void)hipFree(s->d_acc_bin);
@@ -268,15 +272,9 @@ extern "C" void vo_svo_destroy(vo_svo *s) {
 
 enum { S_P = 0, S_CL = 1, S_CR = 2, S_NL = 3, S_NR = 4 };
 
-// VO_SVO_TRACE=1: where the host's time goes per frame (averages on stderr every 200 frames; single stream)
+// VO_SVO_TRACE=1: where the host's time goes per frame (vo_svo::ht, averages on stderr every 200 frames)
 static double svo_now();
-namespace {
-struct SvoHostTrace {
-  bool on = getenv("VO_SVO_TRACE") != nullptr;
-  double t_ret = 0, acc[5] = {0, 0, 0, 0, 0};  // caller between result and enqueue, enqueue, prefetch, wait in result, rest of result
-  int n = 0, n_all = 0;  // ordinary frames, all steady-state frames
-} g_ht;
-}  // namespace
+static const bool g_trace = getenv("VO_SVO_TRACE") != nullptr;  // (read once, never written: the accumulators are per StereoVO)
 
 // the pair into the "next" slots + its candidate table (side stream)
 static int svo_ingest(vo_svo *s, const void *left, const void *right, int stride, int on_device) {
@@ -301,10 +299,10 @@ static int svo_ingest(vo_svo *s, const void *left, const void *right, int stride
 
 extern "C" int vo_svo_prefetch(vo_svo *s, const void *left, const void *right, int stride, int on_device) {
   if (!s || !left || !right) return VO_ERR_INVALID;
-  const double t_in = g_ht.on ? svo_now() : 0.0;
+  const double t_in = g_trace ? svo_now() : 0.0;
   VO_CHECK_HIP(s->c, hipSetDevice(s->c->device));
   RC(svo_ingest(s, left, right, stride, on_device));
-  if (g_ht.on) g_ht.acc[2] += svo_now() - t_in;
+  if (g_trace) s->ht.acc[2] += svo_now() - t_in;
   s->pre_l = left;
   s->pre_r = right;
   s->prefetched = true;
@@ -317,11 +315,37 @@ extern "C" int vo_svo_enqueue(vo_svo *s, const void *left, const void *right, in
   if (!s || !left || !right) return VO_ERR_INVALID;
   vo_ctx *c = s->c;
   if (s->pending) VO_FAIL(c, VO_ERR_INVALID, "a frame is already in flight: call vo_svo_result first");
-  const double t_in = g_ht.on ? svo_now() : 0.0;
-  if (g_ht.on && g_ht.t_ret > 0) g_ht.acc[0] += t_in - g_ht.t_ret;
+  const double t_in = g_trace ? svo_now() : 0.0;
+  if (g_trace && s->ht.t_ret > 0) s->ht.acc[0] += t_in - s->ht.t_ret;
   VO_CHECK_HIP(c, hipSetDevice(c->device));
   (void)timestamp;
+  // what can be refused is refused before any state changes (an empty track set is the reference's throw at :626)
+  if (!s->first && s->n <= 0) VO_FAIL(c, VO_ERR_GN_FAILED, "the track set is empty: PoseOnlyStereoBA is failed!");
+  // the pair goes into the NEXT slots and the next candidate table: nothing the loop reads changes if this fails
   if (!(s->prefetched && s->pre_l == left && s->pre_r == right)) RC(svo_ingest(s, left, right, stride, on_device));
+  // from here on the driver's state moves; every error return below puts it back (slots, tables, both id counters), so
+  // that the caller can hand the pair over again — or another one — and track against the right previous image
+  struct {
+    int slot[5], tab_cur, tab_next, frame_id;
+    int32_t next_frame_id, next_landmark_id;
+  } keep;
+  memcpy(keep.slot, s->slot, sizeof(keep.slot));
+  keep.tab_cur = s->tab_cur;
+  keep.tab_next = s->tab_next;
+  keep.frame_id = s->frame_id;
+  keep.next_frame_id = c->next_frame_id;
+  keep.next_landmark_id = c->next_landmark_id;
+  auto undo = [&](int rc) {
+    memcpy(s->slot, keep.slot, sizeof(keep.slot));
+    s->tab_cur = keep.tab_cur;
+    s->tab_next = keep.tab_next;
+    s->frame_id = keep.frame_id;
+    c->next_frame_id = keep.next_frame_id;
+    c->next_landmark_id = keep.next_landmark_id;
+    s->pending = false;
+    s->pending_first = false;
+    return rc;
+  };
   s->prefetched = false;
   {  // prev <- curr (stereo_vo.cpp:983-985), curr <- the pair just ingested; the two freed slots take the next pair
     const int p = s->slot[S_P], cl = s->slot[S_CL], cr = s->slot[S_CR], nl = s->slot[S_NL], nr = s->slot[S_NR];
@@ -336,10 +360,13 @@ extern "C" int vo_svo_enqueue(vo_svo *s, const void *left, const void *right, in
   // StereoFrame(cam_left, cam_right, timestamp): two Frame ids, left first (frame.cpp:176-180)
   s->frame_id = c->next_frame_id;
   c->next_frame_id += 2;
-  s->pending = true;
-  s->pending_first = s->first;
-  if (s->first) return svo_first_frame(s);
-  if (s->n <= 0) VO_FAIL(c, VO_ERR_GN_FAILED, "the track set is empty: PoseOnlyStereoBA is failed!");
+  if (s->first) {
+    const int rc = svo_first_frame(s);
+    if (rc < 0) return undo(rc);
+    s->pending = true;
+    s->pending_first = true;
+    return VO_OK;
+  }
   // [2] T_wc_prior = T_wp * dT_pc_prev; T_cw_prior = inverseSE3_f(T_wc_prior); T_pw = getPoseInv() (stereo_vo.cpp:475-480)
   float T_wc_prior[16], T_cw_prior[16], T_pw[16];
   svo_mul44(s->T_wp, s->dT01, T_wc_prior);
@@ -358,15 +385,15 @@ extern "C" int vo_svo_enqueue(vo_svo *s, const void *left, const void *right, in
     a.cap = s->cap;
     a.hdr_dev = s->d_hdr;
     a.hdr_host = s->h_hdr;
-    RC(vo_frame_set_advance(c, &a));
+    const int rc = vo_frame_set_advance(c, &a);
+    if (rc < 0) return undo(rc);
   }
   int rc = vo_frame_enqueue_impl(c, &s->prm.frame, s->slot[S_P], s->slot[S_CL], s->slot[S_CR], t.pts_l, t.pts_r, t.Xw, t.flags,
                                  s->n, s->dT01, nullptr, 0, 1, &s->prm.bins, s->tab_cur, T_pw, T_cw_prior);
-  if (rc < 0) {
-    s->pending = false;
-    return rc;
-  }
-  if (g_ht.on) g_ht.acc[1] += svo_now() - t_in;
+  if (rc < 0) return undo(rc);
+  s->pending = true;
+  s->pending_first = false;
+  if (g_trace) s->ht.acc[1] += svo_now() - t_in;
   return VO_OK;
 }
 
@@ -475,16 +502,15 @@ extern "C" int vo_svo_result(vo_svo *s, vo_svo_frame_info *info) {
   }
   // the BA launch's epilogue wrote the loop's counts (pinned block) in front of the frame's sequence word
   float dT[16];
-  const double t_in = g_ht.on ? svo_now() : 0.0;
+  const double t_in = g_trace ? svo_now() : 0.0;
   int rc = vo_stereo_frame_result(c, nullptr, nullptr, nullptr, dT, nullptr, nullptr, &I.counts, &I.gn);
   if (rc < 0) return rc;
-  const double t_seen = g_ht.on ? svo_now() : 0.0;
+  const double t_seen = g_trace ? svo_now() : 0.0;
 #ifdef GN_STAMP  // measurement build: phases of the BA launch in the loop (10 ns ticks), averaged under VO_SVO_TRACE
   {
-    static const bool trace = getenv("VO_SVO_TRACE") != nullptr;
-    static double acc[8];
-    static int nacc;
-    if (trace) {
+    double *acc = s->gn_acc;
+    int &nacc = s->gn_nacc;
+    if (g_trace) {
       long long t[12];
       if (vo_debug_gn_stamps(c, t) == VO_OK) {
         const int order[9] = {0, 5, 1, 2, 3, 6, 7, 8, 4};  // start, joined, prologue, loads, iterations, stage+DLT wait, emit, track set, copy
@@ -550,19 +576,19 @@ extern "C" int vo_svo_result(vo_svo *s, vo_svo_frame_info *info) {
   memcpy(s->T_wp, T_wc, sizeof(T_wc));
   memcpy(I.T_wc, T_wc, sizeof(T_wc));
   if (info) *info = I;
-  if (g_ht.on) {
-    g_ht.t_ret = svo_now();
-    ++g_ht.n_all;
+  if (g_trace) {
+    s->ht.t_ret = svo_now();
+    ++s->ht.n_all;
     if (!I.is_keyframe) {
-      g_ht.acc[3] += t_seen - t_in;
-      g_ht.acc[4] += g_ht.t_ret - t_seen;
-      ++g_ht.n;
+      s->ht.acc[3] += t_seen - t_in;
+      s->ht.acc[4] += s->ht.t_ret - t_seen;
+      ++s->ht.n;
     }
-    if (g_ht.n > 0 && g_ht.n % 200 == 0 && !I.is_keyframe)
+    if (s->ht.n > 0 && s->ht.n % 200 == 0 && !I.is_keyframe)
       fprintf(stderr, "[svo host] per frame (us): caller between result and enqueue %.1f  enqueue %.1f  prefetch %.1f  waiting in result %.1f  "
                       "rest of result (ordinary frames) %.1f\n",
-              1e6 * g_ht.acc[0] / g_ht.n_all, 1e6 * g_ht.acc[1] / g_ht.n_all, 1e6 * g_ht.acc[2] / g_ht.n_all, 1e6 * g_ht.acc[3] / g_ht.n,
-              1e6 * g_ht.acc[4] / g_ht.n);
+              1e6 * s->ht.acc[0] / s->ht.n_all, 1e6 * s->ht.acc[1] / s->ht.n_all, 1e6 * s->ht.acc[2] / s->ht.n_all, 1e6 * s->ht.acc[3] / s->ht.n,
+              1e6 * s->ht.acc[4] / s->ht.n);
   }
   return VO_OK;
 }

@@ -48,10 +48,21 @@ struct vo_svo {
     const int32_t *d_ids;
   };
   std::vector<SvoKfAll> kf_all;
+  // VO_SVO_TRACE=1: where the host's time goes per frame (per StereoVO; averages on stderr every 200 frames)
+  struct {
+    double t_ret = 0, acc[5] = {0, 0, 0, 0, 0};  // caller between result and enqueue, enqueue, prefetch, wait in result, rest of result
+    int n = 0, n_all = 0;                        // ordinary frames, all steady-state frames
+  } ht;
+#ifdef GN_STAMP
+  double gn_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int gn_nacc = 0;
+#endif
 };
 
-int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info, int id_min);  // stereo_vo_lba.hip
+int vo_svo_lba_init(vo_svo *s);  // stereo_vo_lba.hip: landmark table, keyframe ring, window scratch, solver arena — all at construction
+int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info, int id_min);
 void vo_svo_lba_free(vo_svo *s);
+size_t vo_svo_lba_bytes(const vo_svo *s);
 
 void svo_mul44(const float A[16], const float B[16], float C[16]);
 void svo_inv_se3(const float T[16], float Ti[16]);

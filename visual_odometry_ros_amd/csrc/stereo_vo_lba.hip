@@ -73,13 +73,18 @@ static void to_d(const float T[16], double D[16]) {
 }
 
 // ---- device side ------------------------------------------------------------------------------------------------------
-#define LBA_KW 16            // window keyframes at most (bits of the mask that are used, entries per id in q_w)
-#define LBA_TAB_BITS 24      // landmark table: 2^24 slots (285 MB), circular by id
+#define LBA_KW 16            // window keyframes at most (bits of the mask that are used)
+// landmark table: 2^k slots (17 B each), addressed by id mod 2^k with the id kept as a tag. k starts at LBA_TAB_FIRST_BITS
+// and follows the ids the stream has handed out (every landmark ever created stays readable for stats_keyframe, like the
+// reference's all_landmarks_) up to LBA_TAB_BITS; beyond that the oldest ids are overwritten (they read as the origin).
+#define LBA_TAB_FIRST_BITS 18
+#define LBA_TAB_BITS 24
 // ids the window may span: from the first id of the oldest keyframe to the next id to hand out — set by the OLDEST landmark
 // still tracked at the oldest keyframe (a track that never dies keeps the interval growing at ~200 ids per frame: 2^24 ids
-// are ~80 000 frames). The window scratch grows with it (68 bytes per id of the interval).
+// are ~80 000 frames). The window scratch (12 + 4 kf_window bytes per id of the interval) is sized at construction for
+// LBA_SPAN_FIRST ids (or twice the window's capacity, if that is more) and doubles when an interval outgrows it.
 #define LBA_SPAN_MAX (1 << LBA_TAB_BITS)
-#define LBA_SPAN_FIRST (1 << 18)
+#define LBA_SPAN_FIRST (1 << 16)
 
 struct LmTab {
   float *X;       // [slots][3] lm->get3DPoint()
@@ -89,6 +94,7 @@ struct LmTab {
 };
 struct LbaWin {
   int nk, No, W, base;  // window keyframes, optimised poses, ids spanned, first id
+  int kw;               // entries per id in q_w (= kf_window of the stream)
   int n[LBA_KW];        // related landmarks of window keyframe j
   const int32_t *ids[LBA_KW];
   const float *pl[LBA_KW], *pr[LBA_KW];
@@ -139,7 +145,7 @@ __global__ void lba_scatter_kernel(LbaWin w, int *mask_w, int *q_w) {
   const int idx = w.ids[j][q] - w.base;
   if ((unsigned)idx >= (unsigned)w.W) return;
   atomicOr(&mask_w[idx], 1 << j);
-  q_w[(size_t)idx * LBA_KW + j] = q;
+  q_w[(size_t)idx * w.kw + j] = q;
 }
 
 // exclusive scan of one int per thread over a workgroup of 1024 (16 wavefronts); every thread gets the total too
@@ -261,6 +267,7 @@ __global__ void lba_fill_kernel(LbaWin w, LmTab tab, LbaProb p, LbaRef r) {
   if (idx >= w.W) return;
   const int m = p.mask_w[idx];
   if (!m) return;
+  p.mask_w[idx] = 0;  // (last reader: the scratch is all zero again when the next solve scatters into it)
   const unsigned long long pk = p.pre[idx] + p.wg_tot[idx / LBA_QWG];
   const int i = (int)(pk & ((1ull << LBA_PK_KF) - 1)), kf0 = (int)((pk >> LBA_PK_KF) & ((1ull << (LBA_PK_SL - LBA_PK_KF)) - 1));
   const int s0 = (int)(pk >> LBA_PK_SL);
@@ -279,7 +286,7 @@ __global__ void lba_fill_kernel(LbaWin w, LmTab tab, LbaProb p, LbaRef r) {
   int rr = 0, rs = 0;
   for (int mm = m; mm; mm &= mm - 1) {
     const int j = __ffs(mm) - 1;
-    const int q = p.q_w[(size_t)idx * LBA_KW + j];
+    const int q = p.q_w[(size_t)idx * w.kw + j];
     const int o = 2 * (kf0 + rr);
     p.obs_frame[o] = j;
     p.obs_frame[o + 1] = j;
@@ -405,17 +412,54 @@ __global__ void lba_mappoints_kernel(const int32_t *ids, int n, LmTab tab, float
   out[3 * k + 2] = ok ? tab.X[3 * (size_t)t + 2] : 0.0f;
 }
 
+// the table doubles: every held id moves to id mod (new size) — a multiple of the old size, so no two collide
+__global__ void lba_tab_rehash_kernel(LmTab o, LmTab n) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > o.mask) return;
+  const int32_t id = o.tag[t];
+  if (id == -1) return;
+  const int u = id & n.mask;
+  n.X[3 * (size_t)u] = o.X[3 * (size_t)t];
+  n.X[3 * (size_t)u + 1] = o.X[3 * (size_t)t + 1];
+  n.X[3 * (size_t)u + 2] = o.X[3 * (size_t)t + 2];
+  n.S[u] = o.S[t];
+  n.tag[u] = id;
+}
+
 // ---- host side --------------------------------------------------------------------------------------------------------
-#define LBA_POOL_CHUNK ((size_t)4 << 20)  // ids per chunk of the all-keyframes pool (16 MB)
+#define LBA_POOL_CHUNK ((size_t)1 << 20)  // ids per chunk of the all-keyframes pool (4 MB: ~500 keyframes of 2000 landmarks)
+namespace {
+struct Arena {
+  size_t off = 0;
+  size_t take(size_t bytes) {
+    const size_t o = off;
+    off += (bytes + 255) & ~(size_t)255;
+    return o;
+  }
+};
+// Where everything lies inside the solver's arena: fixed at construction from the window's capacity (kf_window keyframes of
+// at most `cap` related landmarks each), so that a keyframe never allocates and the kernels' arguments repeat from solve to
+// solve. The counts of a real problem are far below these bounds (landmarks <= keyframe entries).
+struct LbaLayout {
+  size_t res_bytes, oT, oAvg, oFl, oDyn, oOpt, oOfr, oX, oOp, oOf, oOr, oPx, oSp, oSj, oSb, oSl, oPop, oPo, oPl, oPsp, oPs, oPp,
+      oPa, oPb, oUid, oLm, in_end, total;
+  size_t E_max, Eopt_max;
+  int No_max, maxn, n_err_max;
+};
+}  // namespace
+
 struct vo_svo_lba {
   LmTab tab = {};
+  int tab_bits = 0;
+  long long id_lo = 0;  // smallest landmark id this stream has put into the table (valid once a keyframe exists)
+  bool id_seen = false;
   int32_t *kf_ids[LBA_KW] = {};
   float *kf_pl[LBA_KW] = {}, *kf_pr[LBA_KW] = {};
-  int *mask_w = nullptr, *q_w = nullptr;  // window scratch, for span_cap ids
+  int *mask_w = nullptr, *q_w = nullptr;  // window scratch, for span_cap ids; mask_w is all zero between two solves
   unsigned long long *pre = nullptr;
   size_t span_cap = 0;
   uint8_t *arena = nullptr;
-  size_t arena_cap = 0;
+  LbaLayout lay = {};
   uint8_t *h_res = nullptr;  // pinned: poses, errors, flags, counts of a solve
   std::vector<int32_t *> pool;  // all keyframes' id lists, chunk by chunk
   size_t pool_used = 0;         // ids used in the last chunk
@@ -423,6 +467,9 @@ struct vo_svo_lba {
   float *d_map_all = nullptr;   // staging of all keyframes' map points (vo_svo_get_keyframes)
   size_t map_all_cap = 0;       // points
   std::vector<size_t> pool_fill;  // ids used in every chunk
+  // VO_SVO_TRACE: host build + enqueue, device, write-back (us), per StereoVO
+  double tt[4] = {0, 0, 0, 0};
+  int n_calls = 0;
 };
 
 void vo_svo_lba_free(vo_svo *s) {
@@ -445,226 +492,172 @@ void vo_svo_lba_free(vo_svo *s) {
   s->lba = nullptr;
 }
 
-static int lba_init(vo_svo *s) {
+static int lba_tab_alloc(vo_ctx *c, LmTab *t, int bits) {
+  const size_t slots = (size_t)1 << bits;
+  memset(t, 0, sizeof(*t));
+  t->mask = (int)(slots - 1);
+  VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&t->X, sizeof(float) * 3 * slots));
+  VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&t->S, slots));
+  VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&t->tag, sizeof(int32_t) * slots));
+  VO_CHECK_HIP(c, hipMemsetAsync(t->tag, 0xFF, sizeof(int32_t) * slots, c->stream));
+  VO_CHECK_HIP(c, hipMemsetAsync(t->S, 0, slots, c->stream));
+  return VO_OK;
+}
+static void lba_tab_release(LmTab *t) {
+  void *dev[] = {t->X, t->S, t->tag};
+  for (void *p : dev)
+    if (p) (void)hipFree(p);
+  memset(t, 0, sizeof(*t));
+}
+// the table follows the ids handed out so far (rarely: it doubles; never inside a steady stretch of less than 2^18 ids)
+static int lba_tab_reserve(vo_svo *s, long long id_hi) {
   vo_ctx *c = s->c;
-  if (s->prm.kf_window > LBA_KW) VO_FAIL(c, VO_ERR_CAPACITY, "keyframe window of %d (at most %d)", s->prm.kf_window, LBA_KW);
-  vo_svo_lba *L = new vo_svo_lba();
-  s->lba = L;
-  const size_t slots = (size_t)1 << LBA_TAB_BITS;
-  L->tab.mask = (int)(slots - 1);
-  VO_CHECK_HIP(c, hipMalloc((void **)&L->tab.X, sizeof(float) * 3 * slots));
-  VO_CHECK_HIP(c, hipMalloc((void **)&L->tab.S, slots));
-  VO_CHECK_HIP(c, hipMalloc((void **)&L->tab.tag, sizeof(int32_t) * slots));
-  VO_CHECK_HIP(c, hipMemsetAsync(L->tab.tag, 0xFF, sizeof(int32_t) * slots, c->stream));
-  VO_CHECK_HIP(c, hipMemsetAsync(L->tab.S, 0, slots, c->stream));
-  for (int k = 0; k < s->prm.kf_window; ++k) {
-    VO_CHECK_HIP(c, hipMalloc((void **)&L->kf_ids[k], sizeof(int32_t) * (size_t)s->cap));
-    VO_CHECK_HIP(c, hipMalloc((void **)&L->kf_pl[k], sizeof(float) * 2 * (size_t)s->cap));
-    VO_CHECK_HIP(c, hipMalloc((void **)&L->kf_pr[k], sizeof(float) * 2 * (size_t)s->cap));
+  vo_svo_lba *L = s->lba;
+  int bits = L->tab_bits;
+  while (bits < LBA_TAB_BITS && id_hi - L->id_lo > ((long long)1 << bits)) ++bits;
+  if (bits == L->tab_bits) return VO_OK;
+  LmTab nt;
+  const int rc = lba_tab_alloc(c, &nt, bits);
+  if (rc < 0) {
+    lba_tab_release(&nt);
+    return rc;
   }
-  VO_CHECK_HIP(c, hipHostMalloc((void **)&L->h_res, 4096, hipHostMallocDefault));
-  VO_CHECK_HIP(c, hipMalloc((void **)&L->d_map, sizeof(float) * 3 * (size_t)s->cap));
+  hipLaunchKernelGGL(lba_tab_rehash_kernel, dim3((unsigned)((L->tab.mask + 256) / 256)), dim3(256), 0, c->stream, L->tab, nt);
+  VO_CHECK_HIP(c, hipGetLastError());
+  VO_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+  lba_tab_release(&L->tab);
+  L->tab = nt;
+  L->tab_bits = bits;
+  return VO_OK;
+}
+static int lba_scratch_reserve(vo_svo *s, size_t ids) {
+  vo_ctx *c = s->c;
+  vo_svo_lba *L = s->lba;
+  if (ids <= L->span_cap) return VO_OK;
+  size_t want = L->span_cap ? L->span_cap : (size_t)LBA_SPAN_FIRST;
+  while (want < ids) want *= 2;
+  if (L->span_cap) VO_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+  void *old[] = {L->mask_w, L->q_w, L->pre};
+  for (void *q : old)
+    if (q) (void)hipFree(q);
+  L->mask_w = L->q_w = nullptr;
+  L->pre = nullptr;
+  L->span_cap = 0;
+  VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&L->mask_w, sizeof(int) * want));
+  VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&L->q_w, sizeof(int) * want * (size_t)s->prm.kf_window));
+  VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&L->pre, sizeof(unsigned long long) * (want + want / LBA_QWG + 1)));
+  VO_CHECK_HIP(c, hipMemsetAsync(L->mask_w, 0, sizeof(int) * want, c->stream));  // (lba_fill_kernel re-zeroes what a solve set)
+  L->span_cap = want;
+  return VO_OK;
+}
+static int lba_pool_reserve(vo_svo *s, size_t n) {
+  vo_svo_lba *L = s->lba;
+  if (!L->pool.empty() && L->pool_used + n <= LBA_POOL_CHUNK) return VO_OK;
+  int32_t *chunk = nullptr;
+  VO_CHECK_HIP(s->c, vo_dev_malloc(s->c, (void **)&chunk, sizeof(int32_t) * LBA_POOL_CHUNK));
+  L->pool.push_back(chunk);
+  L->pool_fill.push_back(0);
+  L->pool_used = 0;
   return VO_OK;
 }
 
-namespace {
-struct Arena {
-  size_t off = 0;
-  size_t take(size_t bytes) {
-    const size_t o = off;
-    off += (bytes + 255) & ~(size_t)255;
-    return o;
-  }
-};
-}  // namespace
-
-int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info, int id_min) {
-  vo_ctx *c = s->c;
-  const int n = s->n;
-  SvoTrackSet &t = s->ts[s->cur];
-  static const bool trace = getenv("VO_SVO_TRACE") != nullptr;
-  static double tt[4];
-  static int n_calls;
-  const double t_0 = trace ? lba_now() : 0.0;
-  hipStream_t st = c->stream;
-  if (!s->lba) {
-    const int rc = lba_init(s);
-    if (rc < 0) {  // (nothing half-built stays behind: the next keyframe tries again)
-      vo_svo_lba_free(s);
-      return rc;
-    }
-  }
-  vo_svo_lba *L = s->lba;
-  std::vector<SvoKeyframe> &win = s->keyframes;
-  const int nk = (int)win.size();
-  // ---- the new keyframe's related landmarks (behind the reconstruction kernel on the main stream) ----
-  SvoKeyframe &kf = win.back();
-  {
-    unsigned used = 0;
-    for (int j = 0; j + 1 < nk; ++j) used |= 1u << win[j].ring;
-    int r = 0;
-    while (used & (1u << r)) ++r;
-    kf.ring = r;
-    kf.n = n;
-    kf.id_min = id_min;
-    kf.global = (int)s->kf_all.size();
-  }
-  {  // all_stkeyframes_: the keyframe's related landmarks go into the pool that only grows
-    if (L->pool.empty() || L->pool_used + (size_t)n > LBA_POOL_CHUNK) {
-      int32_t *chunk = nullptr;
-      VO_CHECK_HIP(c, hipMalloc((void **)&chunk, sizeof(int32_t) * LBA_POOL_CHUNK));
-      L->pool.push_back(chunk);
-      L->pool_fill.push_back(0);
-      L->pool_used = 0;
-    }
-    vo_svo::SvoKfAll rec;
-    memcpy(rec.T_wc, kf.T_wc, sizeof(rec.T_wc));
-    rec.n = n;
-    rec.d_ids = L->pool.back() + L->pool_used;
-    L->pool_used += (size_t)n;
-    L->pool_fill.back() = L->pool_used;
-    s->kf_all.push_back(rec);
-  }
-  if (n > 0) {
-    hipLaunchKernelGGL(lba_keyframe_kernel, dim3((n + 255) / 256), dim3(256), 0, st, t, n, L->tab, L->kf_ids[kf.ring], L->kf_pl[kf.ring],
-                       L->kf_pr[kf.ring], const_cast<int32_t *>(s->kf_all.back().d_ids));
-    VO_CHECK_HIP(c, hipGetLastError());
-  }
-  if (!s->prm.local_ba) return VO_OK;
-  if (nk < 3) return VO_OK;  // NUM_MINIMUM_REQUIRED_KEYFRAMES (motion_estimator.cpp:1245-1253)
-  const double POSE_SCALE = 10.0, inv_scale = 1.0 / POSE_SCALE;
-  // ---- the window ----
-  LbaWin w;
-  memset(&w, 0, sizeof(w));
-  w.nk = nk;
-  w.No = nk - 2;  // NUM_FIX_KEYFRAMES_IN_WINDOW
-  w.base = win.front().id_min;
-  const long long span = (long long)c->next_landmark_id - (long long)w.base;
-  if (span > LBA_SPAN_MAX) VO_FAIL(c, VO_ERR_CAPACITY, "local BA: the window spans %lld landmark ids (at most %d)", span, LBA_SPAN_MAX);
-  w.W = (int)span;
-  if ((size_t)w.W > L->span_cap) {  // the window scratch follows the interval (rarely: it doubles)
-    size_t want = L->span_cap ? L->span_cap : (size_t)LBA_SPAN_FIRST;
-    while (want < (size_t)w.W) want *= 2;
-    VO_CHECK_HIP(c, hipStreamSynchronize(st));
-    void *old[] = {L->mask_w, L->q_w, L->pre};
-    for (void *q : old)
-      if (q) (void)hipFree(q);
-    L->mask_w = L->q_w = nullptr;
-    L->pre = nullptr;
-    L->span_cap = 0;
-    VO_CHECK_HIP(c, hipMalloc((void **)&L->mask_w, sizeof(int) * want));
-    VO_CHECK_HIP(c, hipMalloc((void **)&L->q_w, sizeof(int) * want * LBA_KW));
-    VO_CHECK_HIP(c, hipMalloc((void **)&L->pre, sizeof(unsigned long long) * (want + want / LBA_QWG + 1)));
-    L->span_cap = want;
-  }
-  size_t E = 0, E_opt = 0;
-  int maxn = 1;
-  for (int j = 0; j < nk; ++j) {
-    w.n[j] = win[j].n;
-    w.ids[j] = L->kf_ids[win[j].ring];
-    w.pl[j] = L->kf_pl[win[j].ring];
-    w.pr[j] = L->kf_pr[win[j].ring];
-    w.opt[j] = j < 2 ? -1 : j - 2;
-    if (j >= 2) {
-      w.optf[j - 2] = j;
-      w.optmask |= 1 << j;
-      E_opt += (size_t)win[j].n;
-    }
-    E += (size_t)win[j].n;
-    maxn = std::max(maxn, win[j].n);
-  }
-  if (w.W <= 0 || E == 0) return VO_OK;
-  if (E >= ((size_t)1 << LBA_PK_KF))  // (landmarks <= keyframe entries; pairs and slots <= entries: 20 / 22 / 22 bits)
-    VO_FAIL(c, VO_ERR_CAPACITY, "local BA: %zu keyframe entries exceed the packed counters", E);
-  const int No = w.No, max_iter = 10;
-  const size_t M_ub = std::min((size_t)w.W, E), nobs_ub = 2 * E, ns_ub = E_opt;
-  const int n_err = (int)((M_ub + 64 / SBA_LQ - 1) / (64 / SBA_LQ));
-  // ---- the solver's arena ----
+static void lba_make_layout(LbaLayout *l, int kf_window, int cap) {
   Arena ar;
+  const int No = std::max(kf_window - 2, 1);
+  const size_t E = (size_t)kf_window * cap, E_opt = (size_t)No * cap, M_ub = E, nobs_ub = 2 * E, ns_ub = E_opt, maxn = (size_t)cap;
+  l->E_max = E;
+  l->Eopt_max = E_opt;
+  l->No_max = No;
+  l->maxn = cap;
+  l->n_err_max = (int)((M_ub + 64 / SBA_LQ - 1) / (64 / SBA_LQ));
   // (what the host reads back is one piece: poses | errors | flags | counts)
-  const size_t res_bytes = sizeof(double) * (16 * LBA_KW + 16) + sizeof(int) * (16 + 4);
-  const size_t oT = ar.take(res_bytes), oAvg = oT + sizeof(double) * 16 * LBA_KW, oFl = oAvg + sizeof(double) * 16, oDyn = oFl + sizeof(int) * 16;
-  const size_t oOpt = ar.take(sizeof(int) * nk), oOfr = ar.take(sizeof(int) * (No + 1));
-  const size_t oX = ar.take(sizeof(double) * 3 * (M_ub + 1)), oOp = ar.take(sizeof(int) * (M_ub + 1));
-  const size_t oOf = ar.take(sizeof(int) * (nobs_ub + 2)), oOr = ar.take(nobs_ub + 2), oPx = ar.take(sizeof(double) * 2 * (nobs_ub + 2));
-  const size_t oSp = ar.take(sizeof(int) * (M_ub + 1)), oSj = ar.take(sizeof(int) * (ns_ub + 1)), oSb = ar.take(sizeof(int) * (ns_ub + 1));
-  const size_t oSl = ar.take(sizeof(int) * (ns_ub + 1));
-  const size_t oPop = ar.take(sizeof(int) * 2 * (No + 1)), oPo = ar.take(sizeof(int) * 2 * (size_t)maxn * No);
-  const size_t oPl = ar.take(sizeof(int) * 2 * (size_t)maxn * No);
-  const size_t oPsp = ar.take(sizeof(int) * 2 * (No + 1)), oPs = ar.take(sizeof(int) * (size_t)maxn * No);
-  const size_t oPp = ar.take(sizeof(int) * 2 * ((size_t)No * No + 1)), oPa = ar.take(sizeof(int) * (size_t)maxn * No * No);
-  const size_t oPb = ar.take(sizeof(int) * (size_t)maxn * No * No);
-  const size_t oUid = ar.take(sizeof(int32_t) * (M_ub + 1)), oLm = ar.take(sizeof(int) * (M_ub + 1));
+  l->res_bytes = sizeof(double) * (16 * LBA_KW + 16) + sizeof(int) * (16 + 4);
+  l->oT = ar.take(l->res_bytes);
+  l->oAvg = l->oT + sizeof(double) * 16 * LBA_KW;
+  l->oFl = l->oAvg + sizeof(double) * 16;
+  l->oDyn = l->oFl + sizeof(int) * 16;
+  l->oOpt = ar.take(sizeof(int) * LBA_KW);
+  l->oOfr = ar.take(sizeof(int) * (No + 1));
+  l->oX = ar.take(sizeof(double) * 3 * (M_ub + 1));
+  l->oOp = ar.take(sizeof(int) * (M_ub + 1));
+  l->oOf = ar.take(sizeof(int) * (nobs_ub + 2));
+  l->oOr = ar.take(nobs_ub + 2);
+  l->oPx = ar.take(sizeof(double) * 2 * (nobs_ub + 2));
+  l->oSp = ar.take(sizeof(int) * (M_ub + 1));
+  l->oSj = ar.take(sizeof(int) * (ns_ub + 1));
+  l->oSb = ar.take(sizeof(int) * (ns_ub + 1));
+  l->oSl = ar.take(sizeof(int) * (ns_ub + 1));
+  l->oPop = ar.take(sizeof(int) * 2 * (No + 1));
+  l->oPo = ar.take(sizeof(int) * 2 * maxn * No);
+  l->oPl = ar.take(sizeof(int) * 2 * maxn * No);
+  l->oPsp = ar.take(sizeof(int) * 2 * (No + 1));
+  l->oPs = ar.take(sizeof(int) * maxn * No);
+  l->oPp = ar.take(sizeof(int) * 2 * ((size_t)No * No + 1));
+  l->oPa = ar.take(sizeof(int) * maxn * No * No);
+  l->oPb = ar.take(sizeof(int) * maxn * No * No);
+  l->oUid = ar.take(sizeof(int32_t) * (M_ub + 1));
+  l->oLm = ar.take(sizeof(int) * (M_ub + 1));
+  l->in_end = ar.off;
+  SbaDev d;
+  l->total = vo_sba_place_work(&d, nullptr, l->in_end, M_ub, ns_ub, No, 10, l->n_err_max);
+}
+
+// Build + solve + write-back of one window, enqueued on the main stream: the builder's five launches, the solver's
+// iterations, the two write-back launches. Returns where the result piece (poses | errors | flags | counts) lies.
+static int lba_enqueue(vo_svo *s, const LbaWin &w, int maxn, size_t M_ub, const LbaHead &head, const LbaRef &ref, const SvoTrackSet &t,
+                       int n, int max_iter, const double **res) {
+  vo_ctx *c = s->c;
+  vo_svo_lba *L = s->lba;
+  const LbaLayout &lay = L->lay;
+  hipStream_t st = c->stream;
+  const int nk = w.nk, No = w.No;
+  const double inv_scale = ref.inv_scale;
+  const int n_err = std::max(1, (int)((M_ub + 64 / SBA_LQ - 1) / (64 / SBA_LQ)));
+  // ---- the solver's arena: fixed offsets ----
   SbaDev d;
   memset(&d, 0, sizeof(d));
-  const size_t in_end = ar.off;
-  ar.off = vo_sba_place_work(&d, nullptr, in_end, M_ub, ns_ub, No, max_iter, n_err);
-  if (L->arena_cap < ar.off) {
-    VO_CHECK_HIP(c, hipStreamSynchronize(st));
-    if (L->arena) (void)hipFree(L->arena);
-    L->arena = nullptr;
-    L->arena_cap = 0;
-    VO_CHECK_HIP(c, hipMalloc((void **)&L->arena, ar.off + (ar.off >> 1)));
-    L->arena_cap = ar.off + (ar.off >> 1);
-  }
   uint8_t *base = L->arena;
-  vo_sba_place_work(&d, base, in_end, M_ub, ns_ub, No, max_iter, n_err);
+  vo_sba_place_work(&d, base, lay.in_end, lay.E_max, lay.Eopt_max, lay.No_max, max_iter, lay.n_err_max);
+  d.n_err = n_err;
   LbaProb p;
   memset(&p, 0, sizeof(p));
-  p.T = (double *)(base + oT);
-  p.opt_index = (int *)(base + oOpt);
-  p.opt_frame = (int *)(base + oOfr);
-  p.X = (double *)(base + oX);
-  p.obs_ptr = (int *)(base + oOp);
-  p.obs_frame = (int *)(base + oOf);
-  p.obs_right = base + oOr;
-  p.px = (double *)(base + oPx);
-  p.slot_ptr = (int *)(base + oSp);
-  p.slot_j = (int *)(base + oSj);
-  p.slot_bobs = (int *)(base + oSb);
-  p.slot_lm = (int *)(base + oSl);
-  p.pose_obs_ptr = (int *)(base + oPop);
-  p.pose_obs_end = p.pose_obs_ptr + (No + 1);
-  p.pose_obs = (int *)(base + oPo);
-  p.pose_lm = (int *)(base + oPl);
-  p.pose_slot_ptr = (int *)(base + oPsp);
-  p.pose_slot_end = p.pose_slot_ptr + (No + 1);
-  p.pose_slot = (int *)(base + oPs);
-  p.pair_ptr = (int *)(base + oPp);
-  p.pair_end = p.pair_ptr + ((size_t)No * No + 1);
-  p.pair_a = (int *)(base + oPa);
-  p.pair_b = (int *)(base + oPb);
-  p.flags = (int *)(base + oFl);
-  p.avg_err = (double *)(base + oAvg);
-  p.dyn = (int *)(base + oDyn);
-  p.used_id = (int32_t *)(base + oUid);
-  p.lm_mask = (int *)(base + oLm);
+  p.T = (double *)(base + lay.oT);
+  p.opt_index = (int *)(base + lay.oOpt);
+  p.opt_frame = (int *)(base + lay.oOfr);
+  p.X = (double *)(base + lay.oX);
+  p.obs_ptr = (int *)(base + lay.oOp);
+  p.obs_frame = (int *)(base + lay.oOf);
+  p.obs_right = base + lay.oOr;
+  p.px = (double *)(base + lay.oPx);
+  p.slot_ptr = (int *)(base + lay.oSp);
+  p.slot_j = (int *)(base + lay.oSj);
+  p.slot_bobs = (int *)(base + lay.oSb);
+  p.slot_lm = (int *)(base + lay.oSl);
+  p.pose_obs_ptr = (int *)(base + lay.oPop);
+  p.pose_obs_end = p.pose_obs_ptr + (lay.No_max + 1);
+  p.pose_obs = (int *)(base + lay.oPo);
+  p.pose_lm = (int *)(base + lay.oPl);
+  p.pose_slot_ptr = (int *)(base + lay.oPsp);
+  p.pose_slot_end = p.pose_slot_ptr + (lay.No_max + 1);
+  p.pose_slot = (int *)(base + lay.oPs);
+  p.pair_ptr = (int *)(base + lay.oPp);
+  p.pair_end = p.pair_ptr + ((size_t)lay.No_max * lay.No_max + 1);
+  p.pair_a = (int *)(base + lay.oPa);
+  p.pair_b = (int *)(base + lay.oPb);
+  p.flags = (int *)(base + lay.oFl);
+  p.avg_err = (double *)(base + lay.oAvg);
+  p.dyn = (int *)(base + lay.oDyn);
+  p.used_id = (int32_t *)(base + lay.oUid);
+  p.lm_mask = (int *)(base + lay.oLm);
   p.mask_w = L->mask_w;
   p.q_w = L->q_w;
   p.pre = L->pre;
   p.wg_tot = L->pre + L->span_cap;
-  p.pose_obs_stride = 2 * maxn;
-  p.pose_slot_stride = maxn;
-  p.pair_stride = maxn;
+  p.pose_obs_stride = 2 * lay.maxn;
+  p.pose_slot_stride = lay.maxn;
+  p.pair_stride = lay.maxn;
   p.max_iter = max_iter;
-  // ---- poses: reference frame = first keyframe of the window (sparse_ba_parameters.h:340-375) ----
-  LbaRef ref;
-  LbaHead head;
-  memset(&head, 0, sizeof(head));
-  to_d(win.front().T_wc, ref.Twj_ref);
-  inv_se3d(ref.Twj_ref, ref.Tjw_ref);
-  ref.inv_scale = inv_scale;
-  ref.pose_scale = POSE_SCALE;
-  for (int j = 0; j < nk; ++j) {
-    float Tjw_f[16];
-    double Tjw[16];
-    svo_inv_se3(win[j].T_wc, Tjw_f);  // getPoseInv()
-    to_d(Tjw_f, Tjw);
-    mul44d(Tjw, ref.Twj_ref, &head.T_jw[16 * j]);  // changeInvPoseWorldToRef
-    for (int r = 0; r < 3; ++r) head.T_jw[16 * j + r * 4 + 3] *= inv_scale;  // scalingPose
-  }
-  // ---- build + solve, all on the main stream ----
-  VO_CHECK_HIP(c, hipMemsetAsync(L->mask_w, 0, sizeof(int) * (size_t)w.W, st));
+  // ---- build + solve, all on the main stream (mask_w is zero on entry: lba_fill_kernel clears what it has read) ----
   hipLaunchKernelGGL(lba_scatter_kernel, dim3((maxn + 255) / 256, nk), dim3(256), 0, st, w, L->mask_w, L->q_w);
   const int n_wg = (w.W + LBA_QWG - 1) / LBA_QWG;
   hipLaunchKernelGGL(lba_qualify_kernel, dim3(n_wg), dim3(LBA_QWG), 0, st, w, L->tab, p);
@@ -727,12 +720,210 @@ int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info, int id_min) {
   // iterations, before the host looks at anything (a solve that ends in NaN or a "large update" ends the run as in the
   // reference; what it left in the table is then nobody's input; with no landmark in the problem both kernels do nothing) ----
   hipLaunchKernelGGL(lba_writeback_kernel, dim3((unsigned)((M_ub + 255) / 256)), dim3(256), 0, st, p, L->tab, ref);
-  if (n > 0) hipLaunchKernelGGL(lba_refresh_kernel, dim3((n + 255) / 256), dim3(256), 0, st, t, n, L->tab);
+  hipLaunchKernelGGL(lba_refresh_kernel, dim3((std::max(n, 1) + 255) / 256), dim3(256), 0, st, t, n, L->tab);
   VO_CHECK_HIP(c, hipGetLastError());
+  *res = p.T;
+  return VO_OK;
+}
+
+// The first launch of a kernel costs the runtime 50-100 us (function lookup, kernel object, argument pool), and a local BA
+// is ~12 different kernels — one register solve per window size among them: a stream's first solves used to cost 1-2 ms
+// extra each. Every one of them is launched here once per window size on an EMPTY window (no keyframe entries, an id
+// interval of one: every launch runs its code path and touches nothing but the zeroed arena).
+static int lba_warm_up(vo_svo *s) {
+  vo_ctx *c = s->c;
+  vo_svo_lba *L = s->lba;
+  VO_CHECK_HIP(c, hipMemsetAsync(L->arena, 0, L->lay.total, c->stream));
+  LbaHead head;
+  LbaRef ref;
+  memset(&head, 0, sizeof(head));
+  memset(&ref, 0, sizeof(ref));
+  for (int k = 0; k < 4; ++k) ref.Tjw_ref[5 * k] = ref.Twj_ref[5 * k] = 1.0;
+  ref.inv_scale = 0.1;
+  ref.pose_scale = 10.0;
+  for (int nk = 3; nk <= s->prm.kf_window; ++nk) {
+    LbaWin w;
+    memset(&w, 0, sizeof(w));
+    w.nk = nk;
+    w.No = nk - 2;
+    w.kw = s->prm.kf_window;
+    w.W = 1;
+    for (int j = 0; j < nk; ++j) {
+      w.ids[j] = L->kf_ids[0];
+      w.pl[j] = L->kf_pl[0];
+      w.pr[j] = L->kf_pr[0];
+      w.opt[j] = j < 2 ? -1 : j - 2;
+      if (j >= 2) {
+        w.optf[j - 2] = j;
+        w.optmask |= 1 << j;
+      }
+      for (int k = 0; k < 4; ++k) head.T_jw[16 * j + 5 * k] = 1.0;
+    }
+    const double *res = nullptr;
+    const int rc = lba_enqueue(s, w, 1, 1, head, ref, s->ts[0], 0, 1, &res);
+    if (rc < 0) return rc;
+  }
+  hipLaunchKernelGGL(lba_keyframe_kernel, dim3(1), dim3(256), 0, c->stream, s->ts[0], 0, L->tab, L->kf_ids[0], L->kf_pl[0], L->kf_pr[0],
+                     L->pool.back());
+  VO_CHECK_HIP(c, hipGetLastError());
+  return VO_OK;
+}
+
+// Everything the keyframes of a stream will need, allocated when the StereoVO is made (vo_svo_create): a keyframe — the
+// first one, a growing window, the first solve — allocates nothing. (Grown later, each by doubling: the table past
+// 2^18 landmark ids, the window scratch past its first interval, the keyframe pool every 2^20 related landmarks.)
+int vo_svo_lba_init(vo_svo *s) {
+  vo_ctx *c = s->c;
+  if (s->prm.kf_window > LBA_KW) VO_FAIL(c, VO_ERR_CAPACITY, "keyframe window of %d (at most %d)", s->prm.kf_window, LBA_KW);
+  vo_svo_lba *L = new vo_svo_lba();
+  s->lba = L;
+  L->tab_bits = LBA_TAB_FIRST_BITS;
+  int rc = lba_tab_alloc(c, &L->tab, L->tab_bits);
+  if (rc < 0) return rc;
+  for (int k = 0; k < s->prm.kf_window; ++k) {
+    VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&L->kf_ids[k], sizeof(int32_t) * (size_t)s->cap));
+    VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&L->kf_pl[k], sizeof(float) * 2 * (size_t)s->cap));
+    VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&L->kf_pr[k], sizeof(float) * 2 * (size_t)s->cap));
+  }
+  VO_CHECK_HIP(c, vo_host_malloc(c, (void **)&L->h_res, 4096, hipHostMallocDefault));
+  VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&L->d_map, sizeof(float) * 3 * (size_t)s->cap));
+  rc = lba_pool_reserve(s, (size_t)s->cap);
+  if (rc < 0) return rc;
+  if (s->prm.local_ba && s->prm.kf_window >= 3) {
+    lba_make_layout(&L->lay, s->prm.kf_window, s->cap);
+    VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&L->arena, L->lay.total));
+    size_t first = (size_t)LBA_SPAN_FIRST;
+    while (first < 2 * (size_t)s->prm.kf_window * (size_t)s->cap) first *= 2;
+    rc = lba_scratch_reserve(s, first);
+    if (rc < 0) return rc;
+    rc = lba_warm_up(s);
+    if (rc < 0) return rc;
+  }
+  VO_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+  return VO_OK;
+}
+
+size_t vo_svo_lba_bytes(const vo_svo *s) {  // device memory held for the keyframes of this stream (test / report hook)
+  const vo_svo_lba *L = s->lba;
+  if (!L) return 0;
+  size_t b = ((size_t)L->tab.mask + 1) * 17 + (size_t)s->prm.kf_window * (size_t)s->cap * 20 + sizeof(float) * 3 * (size_t)s->cap;
+  b += L->pool.size() * LBA_POOL_CHUNK * sizeof(int32_t) + L->map_all_cap * 12;
+  if (L->arena) b += L->lay.total;
+  b += L->span_cap * (12 + 4 * (size_t)s->prm.kf_window) + (L->span_cap / LBA_QWG + 1) * 8;
+  return b;
+}
+
+int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info, int id_min) {
+  vo_ctx *c = s->c;
+  const int n = s->n;
+  SvoTrackSet &t = s->ts[s->cur];
+  static const bool trace = getenv("VO_SVO_TRACE") != nullptr;
+  const double t_0 = trace ? lba_now() : 0.0;
+  hipStream_t st = c->stream;
+  vo_svo_lba *L = s->lba;
+  if (!L) VO_FAIL(c, VO_ERR_INVALID, "StereoVO: the keyframe storage was not initialised");
+  std::vector<SvoKeyframe> &win = s->keyframes;
+  const int nk = (int)win.size();
+  // ---- the new keyframe's related landmarks (behind the reconstruction kernel on the main stream) ----
+  SvoKeyframe &kf = win.back();
+  {
+    unsigned used = 0;
+    for (int j = 0; j + 1 < nk; ++j) used |= 1u << win[j].ring;
+    int r = 0;
+    while (used & (1u << r)) ++r;
+    kf.ring = r;
+    kf.n = n;
+    kf.id_min = id_min;
+    kf.global = (int)s->kf_all.size();
+  }
+  if (n > 0) {  // the table holds every id from the stream's first landmark on
+    if (!L->id_seen || (long long)id_min < L->id_lo) L->id_lo = id_min;
+    L->id_seen = true;
+    const int rc = lba_tab_reserve(s, (long long)c->next_landmark_id);
+    if (rc < 0) return rc;
+  }
+  {  // all_stkeyframes_: the keyframe's related landmarks go into the pool that only grows
+    const int rc = lba_pool_reserve(s, (size_t)n);
+    if (rc < 0) return rc;
+    vo_svo::SvoKfAll rec;
+    memcpy(rec.T_wc, kf.T_wc, sizeof(rec.T_wc));
+    rec.n = n;
+    rec.d_ids = L->pool.back() + L->pool_used;
+    L->pool_used += (size_t)n;
+    L->pool_fill.back() = L->pool_used;
+    s->kf_all.push_back(rec);
+  }
+  if (n > 0) {
+    hipLaunchKernelGGL(lba_keyframe_kernel, dim3((n + 255) / 256), dim3(256), 0, st, t, n, L->tab, L->kf_ids[kf.ring], L->kf_pl[kf.ring],
+                       L->kf_pr[kf.ring], const_cast<int32_t *>(s->kf_all.back().d_ids));
+    VO_CHECK_HIP(c, hipGetLastError());
+  }
+  if (!s->prm.local_ba) return VO_OK;
+  if (nk < 3) return VO_OK;  // NUM_MINIMUM_REQUIRED_KEYFRAMES (motion_estimator.cpp:1245-1253)
+  const double POSE_SCALE = 10.0, inv_scale = 1.0 / POSE_SCALE;
+  const LbaLayout &lay = L->lay;
+  // ---- the window ----
+  LbaWin w;
+  memset(&w, 0, sizeof(w));
+  w.nk = nk;
+  w.No = nk - 2;  // NUM_FIX_KEYFRAMES_IN_WINDOW
+  w.kw = s->prm.kf_window;
+  w.base = win.front().id_min;
+  const long long span = (long long)c->next_landmark_id - (long long)w.base;
+  if (span > LBA_SPAN_MAX) VO_FAIL(c, VO_ERR_CAPACITY, "local BA: the window spans %lld landmark ids (at most %d)", span, LBA_SPAN_MAX);
+  w.W = (int)span;
+  {  // the window scratch follows the interval (rarely: it doubles)
+    const int rc = lba_scratch_reserve(s, (size_t)std::max(w.W, 0));
+    if (rc < 0) return rc;
+  }
+  size_t E = 0, E_opt = 0;
+  int maxn = 1;
+  for (int j = 0; j < nk; ++j) {
+    w.n[j] = win[j].n;
+    w.ids[j] = L->kf_ids[win[j].ring];
+    w.pl[j] = L->kf_pl[win[j].ring];
+    w.pr[j] = L->kf_pr[win[j].ring];
+    w.opt[j] = j < 2 ? -1 : j - 2;
+    if (j >= 2) {
+      w.optf[j - 2] = j;
+      w.optmask |= 1 << j;
+      E_opt += (size_t)win[j].n;
+    }
+    E += (size_t)win[j].n;
+    maxn = std::max(maxn, win[j].n);
+  }
+  if (w.W <= 0 || E == 0) return VO_OK;
+  if (E >= ((size_t)1 << LBA_PK_KF))  // (landmarks <= keyframe entries; pairs and slots <= entries: 20 / 22 / 22 bits)
+    VO_FAIL(c, VO_ERR_CAPACITY, "local BA: %zu keyframe entries exceed the packed counters", E);
+  if (E > lay.E_max || E_opt > lay.Eopt_max || maxn > lay.maxn || nk - 2 > lay.No_max)  // (cannot happen: n <= cap, nk <= kf_window)
+    VO_FAIL(c, VO_ERR_CAPACITY, "local BA: the window (%zu entries) exceeds the arena laid out at construction", E);
+  const int max_iter = 10;
+  const size_t M_ub = std::min((size_t)w.W, E);
+  // ---- poses: reference frame = first keyframe of the window (sparse_ba_parameters.h:340-375) ----
+  LbaRef ref;
+  LbaHead head;
+  memset(&head, 0, sizeof(head));
+  to_d(win.front().T_wc, ref.Twj_ref);
+  inv_se3d(ref.Twj_ref, ref.Tjw_ref);
+  ref.inv_scale = inv_scale;
+  ref.pose_scale = POSE_SCALE;
+  for (int j = 0; j < nk; ++j) {
+    float Tjw_f[16];
+    double Tjw[16];
+    svo_inv_se3(win[j].T_wc, Tjw_f);  // getPoseInv()
+    to_d(Tjw_f, Tjw);
+    mul44d(Tjw, ref.Twj_ref, &head.T_jw[16 * j]);  // changeInvPoseWorldToRef
+    for (int r = 0; r < 3; ++r) head.T_jw[16 * j + r * 4 + 3] *= inv_scale;  // scalingPose
+  }
+  const double *res_dev = nullptr;
+  {
+    const int rc = lba_enqueue(s, w, maxn, M_ub, head, ref, t, n, max_iter, &res_dev);
+    if (rc < 0) return rc;
+  }
   // ---- what the host needs: poses, errors, flags, counts ----
   double *o_T = (double *)L->h_res, *o_e = o_T + 16 * LBA_KW;
   int *o_f = (int *)(o_e + 16), *o_d = o_f + 16;
-  VO_CHECK_HIP(c, hipMemcpyAsync(o_T, p.T, res_bytes, hipMemcpyDeviceToHost, st));
+  VO_CHECK_HIP(c, hipMemcpyAsync(o_T, res_dev, lay.res_bytes, hipMemcpyDeviceToHost, st));
   const double t_1 = trace ? lba_now() : 0.0;
   VO_CHECK_HIP(c, hipStreamSynchronize(st));
   const double t_2 = trace ? lba_now() : 0.0;
@@ -766,13 +957,19 @@ int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info, int id_min) {
   }
   if (trace) {
     const double t_3 = lba_now();
-    tt[0] += t_1 - t_0;
-    tt[1] += t_2 - t_1;
-    tt[2] += t_3 - t_2;
-    if ((++n_calls % 10) == 0)
+    L->tt[0] += t_1 - t_0;
+    L->tt[1] += t_2 - t_1;
+    L->tt[2] += t_3 - t_2;
+    if ((++L->n_calls % 10) == 0)
       fprintf(stderr, "[lba] per call (us): host build + enqueue %.0f  device (build + solve) %.0f  write-back %.0f  (M=%d obs=%d slots=%d, span %d)\n",
-              tt[0] / n_calls, tt[1] / n_calls, tt[2] / n_calls, o_d[0], o_d[1], o_d[2], w.W);
+              L->tt[0] / L->n_calls, L->tt[1] / L->n_calls, L->tt[2] / L->n_calls, o_d[0], o_d[1], o_d[2], w.W);
   }
+  return VO_OK;
+}
+
+extern "C" int vo_svo_device_bytes(const vo_svo *s, size_t *bytes) {
+  if (!s || !bytes) return VO_ERR_INVALID;
+  *bytes = vo_svo_lba_bytes(s);
   return VO_OK;
 }
 
@@ -824,7 +1021,7 @@ extern "C" int vo_svo_get_keyframes(vo_svo *s, float *T_wc, int32_t *n_points, f
     L->d_map_all = nullptr;
     L->map_all_cap = 0;
     const size_t want = total + (total >> 1) + 4096;
-    VO_CHECK_HIP(c, hipMalloc((void **)&L->d_map_all, sizeof(float) * 3 * want));
+    VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&L->d_map_all, sizeof(float) * 3 * want));
     L->map_all_cap = want;
   }
   size_t off = 0;  // (keyframes lie in the pool in their order, a keyframe never straddles two chunks)

@@ -28,8 +28,8 @@ extern "C" int vo_synchronize(vo_ctx *ctx) {
 }
 
 template <typename T>
-static hipError_t dalloc(T **p, size_t n) {
-  return hipMalloc((void **)p, n * sizeof(T));
+static hipError_t dalloc(vo_ctx *c, T **p, size_t n) {
+  return vo_dev_malloc(c, (void **)p, n * sizeof(T));
 }
 
 static size_t pyramid_bytes(int w, int h, int max_level, vo_pyramid *P) {
@@ -94,32 +94,33 @@ extern "C" int vo_create(const vo_config *cfg, vo_ctx **out) {
   for (int s = 0; s < cfg->n_slots; ++s) {
     vo_pyramid *P = &c->slots[s];
     P->bytes = pyramid_bytes(cfg->max_width, cfg->max_height, cfg->max_level, nullptr);
-    VO_CHECK_HIP(c, hipMalloc((void **)&P->mem, P->bytes));
+    VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&P->mem, P->bytes));
     P->n_levels = 0;
     VO_CHECK_HIP(c, hipEventCreateWithFlags(&P->ready, hipEventDisableTiming));
     P->seen[0] = P->seen[1] = 1;  // nothing built yet: nothing to wait for
   }
-  VO_CHECK_HIP(c, dalloc(&c->d_pts0, 2 * N));
-  VO_CHECK_HIP(c, dalloc(&c->d_pts1, 2 * N));
-  VO_CHECK_HIP(c, dalloc(&c->d_pts2, 2 * N));
-  VO_CHECK_HIP(c, dalloc(&c->d_pts3, 2 * N));
-  VO_CHECK_HIP(c, dalloc(&c->d_err, N));
-  VO_CHECK_HIP(c, dalloc(&c->d_err2, N));
-  VO_CHECK_HIP(c, dalloc(&c->d_scale, N));
-  VO_CHECK_HIP(c, dalloc(&c->d_X, 3 * N));
-  VO_CHECK_HIP(c, dalloc(&c->d_status, N));
-  VO_CHECK_HIP(c, dalloc(&c->d_status2, N));
-  VO_CHECK_HIP(c, dalloc(&c->d_mask, N));
-  VO_CHECK_HIP(c, dalloc(&c->d_mask2, N));
-  VO_CHECK_HIP(c, dalloc(&c->d_idx, N));
-  VO_CHECK_HIP(c, dalloc(&c->d_count, 16));
-  VO_CHECK_HIP(c, dalloc(&c->d_mat, 256));
-  VO_CHECK_HIP(c, dalloc(&c->d_gninfo, 4));
-  VO_CHECK_HIP(c, dalloc(&c->d_flags, 16));
+  VO_CHECK_HIP(c, dalloc(c, &c->d_pts0, 2 * N));
+  VO_CHECK_HIP(c, dalloc(c, &c->d_pts1, 2 * N));
+  VO_CHECK_HIP(c, dalloc(c, &c->d_pts2, 2 * N));
+  VO_CHECK_HIP(c, dalloc(c, &c->d_pts3, 2 * N));
+  VO_CHECK_HIP(c, dalloc(c, &c->d_err, N));
+  VO_CHECK_HIP(c, dalloc(c, &c->d_err2, N));
+  VO_CHECK_HIP(c, dalloc(c, &c->d_scale, N));
+  VO_CHECK_HIP(c, dalloc(c, &c->d_X, 3 * N));
+  VO_CHECK_HIP(c, dalloc(c, &c->d_X2, 3 * N));
+  VO_CHECK_HIP(c, dalloc(c, &c->d_status, N));
+  VO_CHECK_HIP(c, dalloc(c, &c->d_status2, N));
+  VO_CHECK_HIP(c, dalloc(c, &c->d_mask, N));
+  VO_CHECK_HIP(c, dalloc(c, &c->d_mask2, N));
+  VO_CHECK_HIP(c, dalloc(c, &c->d_idx, N));
+  VO_CHECK_HIP(c, dalloc(c, &c->d_count, 16));
+  VO_CHECK_HIP(c, dalloc(c, &c->d_mat, 256));
+  VO_CHECK_HIP(c, dalloc(c, &c->d_gninfo, 4));
+  VO_CHECK_HIP(c, dalloc(c, &c->d_flags, 16));
   VO_CHECK_HIP(c, hipMemsetAsync(c->d_flags, 0, 16 * sizeof(int), c->stream));
   c->h_stage_bytes = (size_t)cfg->max_width * cfg->max_height + 64 * N + 4096;
-  VO_CHECK_HIP(c, hipHostMalloc((void **)&c->h_stage, c->h_stage_bytes, hipHostMallocDefault));
-  VO_CHECK_HIP(c, hipMalloc((void **)&c->d_img_stage, (size_t)cfg->max_width * cfg->max_height));
+  VO_CHECK_HIP(c, vo_host_malloc(c, (void **)&c->h_stage, c->h_stage_bytes, hipHostMallocDefault));
+  VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&c->d_img_stage, (size_t)cfg->max_width * cfg->max_height));
   VO_CHECK_HIP(c, hipStreamSynchronize(c->stream));
   return VO_OK;
 }
@@ -149,7 +150,7 @@ extern "C" void vo_destroy(vo_ctx *c) {
     }
     free(c->slots);
   }
-  void *bufs[] = {c->d_pts0, c->d_pts1, c->d_pts2, c->d_pts3, c->d_err, c->d_err2, c->d_scale, c->d_X,
+  void *bufs[] = {c->d_pts0, c->d_pts1, c->d_pts2, c->d_pts3, c->d_err, c->d_err2, c->d_scale, c->d_X, c->d_X2,
                   c->d_status, c->d_status2, c->d_mask, c->d_mask2, c->d_idx, c->d_count, c->d_mat,
                   c->d_gninfo, c->d_flags, c->d_img_stage, c->d_desc_a, c->d_desc_b, c->d_dist, c->ic_rec};
   for (void *b : bufs)
@@ -343,7 +344,7 @@ extern "C" int vo_set_stereo_pair_host_async(vo_ctx *c, int slot_l, const uint8_
   const uint8_t *src[2] = {host_l, host_r};
   for (int i = 0; i < 2; ++i) {
     vo_pyramid &P = c->slots[slots[i]];
-    if (!P.stage) VO_CHECK_HIP(c, hipMalloc((void **)&P.stage, (size_t)c->cfg.max_width * c->cfg.max_height));
+    if (!P.stage) VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&P.stage, (size_t)c->cfg.max_width * c->cfg.max_height));
     if (stride == width)  // one linear copy (a 2-D copy is issued row by row: milliseconds instead of microseconds)
       VO_CHECK_HIP(c, hipMemcpyAsync(P.stage, src[i], (size_t)width * height, hipMemcpyHostToDevice, s));
     else

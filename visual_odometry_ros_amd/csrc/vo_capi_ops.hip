@@ -186,8 +186,8 @@ static int ensure_desc(vo_ctx *c, int na, int nb, bool need_dist) {
     if (c->d_desc_b) (void)hipFree(c->d_desc_b);
     c->d_desc_a = c->d_desc_b = nullptr;
     c->desc_cap = 0;
-    VO_CHECK_HIP(c, hipMalloc((void **)&c->d_desc_a, need));
-    VO_CHECK_HIP(c, hipMalloc((void **)&c->d_desc_b, need));
+    VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&c->d_desc_a, need));
+    VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&c->d_desc_b, need));
     c->desc_cap = need;
   }
   if (need_dist) {
@@ -196,7 +196,7 @@ static int ensure_desc(vo_ctx *c, int na, int nb, bool need_dist) {
       if (c->d_dist) (void)hipFree(c->d_dist);
       c->d_dist = nullptr;
       c->dist_cap = 0;
-      VO_CHECK_HIP(c, hipMalloc((void **)&c->d_dist, nd));
+      VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&c->d_dist, nd));
       c->dist_cap = nd;
     }
   }

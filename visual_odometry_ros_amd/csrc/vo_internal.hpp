@@ -60,7 +60,7 @@ struct vo_ctx {
   char err[512];
   vo_pyramid *slots;
   // per-point device buffers (capacity cfg.max_points)
-  float *d_pts0, *d_pts1, *d_pts2, *d_pts3, *d_err, *d_err2, *d_scale, *d_X;
+  float *d_pts0, *d_pts1, *d_pts2, *d_pts3, *d_err, *d_err2, *d_scale, *d_X, *d_X2;
   uint8_t *d_status, *d_status2, *d_mask, *d_mask2;
   int32_t *d_idx;
   int *d_count;
@@ -98,7 +98,21 @@ struct vo_ctx {
   int32_t next_landmark_id, next_frame_id;
   struct vo_sba_state *sba;  // device arena of the sparse local BA (sba.hip)
   struct vo_orb_state *orb;  // pyramid, score planes and candidate lists of the keypoint detector (orb_detect.hip)
+  // every device / pinned allocation made on behalf of this context (vo_dev_malloc / vo_host_malloc): what
+  // vo_debug_allocation_count reports, so that a test can assert that a steady-state frame allocates nothing
+  long long n_allocs;
+  // vo_debug_set: test / measurement switches of THIS context (never read from the environment inside the library)
+  int dbg[VO_DBG_COUNT];
 };
+
+static inline hipError_t vo_dev_malloc(vo_ctx *c, void **p, size_t bytes) {
+  if (c) ++c->n_allocs;
+  return hipMalloc(p, bytes);
+}
+static inline hipError_t vo_host_malloc(vo_ctx *c, void **p, size_t bytes, unsigned flags) {
+  if (c) ++c->n_allocs;
+  return hipHostMalloc(p, bytes, flags);
+}
 
 #define VO_CHECK_HIP(ctx, expr)                                                            \
   do {                                                                                     \

@@ -181,6 +181,7 @@ struct vo_cand_table {
   int n_bins;       // 0 = never filled
   hipEvent_t ready; // recorded on the side stream behind the table's kernels and the copy of its flags
   int *h_flags;     // pinned: the detector's capacity flags of this table's detection
+  int dbg_filled;   // (VO_DBG_SKIP_DETECT only)
 };
 const vo_cand_table *vo_orb_cand_table(vo_ctx *c, int table);
 
