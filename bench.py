@@ -164,30 +164,56 @@ def stream_seed(rank):
     return 2 + rank
 
 
-def launch_ranks(n, argv):
+def rank_cpus(local_rank, local_world):
+    """The CPU set of one rank: a contiguous share of the CPUs this process may run on (contiguous ids share a NUMA node
+    and its caches on the EPYC hosts), set BEFORE the rank renders its stream or spawns the renderer's workers — they
+    inherit it — so that eight ranks do not render, launch and poll all over each other's cores."""
+    cpus = sorted(os.sched_getaffinity(0))
+    if local_world <= 1 or len(cpus) < local_world:
+        return cpus
+    per = len(cpus) // local_world
+    return cpus[local_rank * per:(local_rank + 1) * per]
+
+
+def pin_rank(local_rank, local_world):
+    cpus = rank_cpus(local_rank, local_world)
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError:
+        pass
+    return sorted(os.sched_getaffinity(0))
+
+
+def launch_ranks(n, argv, job_timeout=None):
     """`python bench.py --gpus N` without a launcher environment: this (parent) process starts N FRESH child
     interpreters, one per GPU, before it has imported torch or made any HIP call — it never touches a GPU and no
     GPU-initialised process is ever re-exec'ed. The children rendezvous on 127.0.0.1; rank 0 prints the one JSON
-    line, which is relayed. Returns the exit code (first non-zero child code)."""
+    line, which is relayed. A rank that dies, or a job that outlives `job_timeout` seconds (a rank stuck in front of the
+    rendezvous), ends every child; the stderr tail of EVERY rank is then relayed with its rank in front. Returns the exit
+    code (first non-zero child code; 124 for the time-out)."""
     import socket
     import subprocess
+    import tempfile
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    procs = []
+    procs, errs = [], []
     for r in range(n):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        ef = tempfile.TemporaryFile(mode="w+")
+        errs.append(ef)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=ef, text=True))
     # wait for all ranks; if one fails, the others would sit in the rendezvous / barrier forever: end them
     # (rank 0 writes one line; a pipe of that size cannot fill up while we poll)
-    rc = 0
+    rc, t0 = 0, time.time()
     while any(p.poll() is None for p in procs):
         bad = [p for p in procs if p.poll() not in (None, 0)]
-        if bad:
-            rc = bad[0].returncode
+        late = job_timeout is not None and time.time() - t0 > job_timeout
+        if bad or late:
+            rc = bad[0].returncode if bad else 124
             for p in procs:
                 if p.poll() is None:
                     p.kill()  # exactly the children started above
@@ -199,24 +225,39 @@ def launch_ranks(n, argv):
         rc = rc or p.returncode
     for ln in out0.splitlines():  # the JSON line goes to stdout; library chatter of the child (gloo's connect note) to stderr
         (sys.stdout if ln.startswith("{") else sys.stderr).write(ln + "\n")
+    for r, ef in enumerate(errs):  # rank 0's stderr always (as before the ranks' stderr was a file); every rank's on failure
+        ef.seek(0)
+        txt = ef.read()
+        ef.close()
+        if txt and (rc != 0 or r == 0):
+            for ln in txt.splitlines()[-40:]:
+                sys.stderr.write((f"[rank {r}] " if rc != 0 else "") + ln + "\n")
+    if rc == 124:
+        sys.stderr.write(f"bench.py: the job did not finish within {job_timeout:.0f} s; all ranks ended\n")
     sys.stdout.flush()
     return rc
 
 
-def rendezvous_check(rank, world):
-    """--rendezvous-check: the N > 1 control flow of this file (launcher, rank environment, process group,
-    per-rank stream seeds, the gather, rank-0-only JSON) with gloo and no HIP call, so that it runs on a
+def rendezvous_check(rank, world, timeout_s, cpus):
+    """--rendezvous-check: the N > 1 control flow of this file (launcher, rank environment, CPU sets, process group with
+    its time-out, per-rank stream seeds, the gather, rank-0-only JSON) with gloo and no HIP call, so that it runs on a
     machine without GPUs (tests/test_bench_dist.py)."""
+    import datetime
     import torch.distributed as dist
+    if os.environ.get("BENCH_TEST_HANG_RANK") == str(rank):  # (test hook: a rank that never reaches the rendezvous)
+        time.sleep(3600)
     if world > 1:
-        dist.init_process_group(backend="gloo")
+        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=timeout_s))
     per = gather_ranks(100 + rank, 0.5 + 0.25 * rank, stream_seed(rank), world)
+    all_cpus = [cpus]
     if world > 1:
+        all_cpus = [None] * world
+        dist.all_gather_object(all_cpus, cpus)
         dist.barrier()
     if rank == 0:
         tot, mx = sum(p[0] for p in per), max(p[1] for p in per)
         print(json.dumps({"rendezvous_check": True, "n_gpus": world, "value": tot / mx,
-                          "per_rank": [{"frames": p[0], "seconds": p[1], "stream_seed": p[2]} for p in per]}),
+                          "per_rank": [{"frames": p[0], "seconds": p[1], "stream_seed": p[2], "cpus": c} for p, c in zip(per, all_cpus)]}),
               flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -536,7 +577,8 @@ def render_stream(cfg, seed, n, workers):
     if os.path.exists(cache):
         try:
             z = np.load(cache)
-            return [(z["L"][k], z["R"][k]) for k in range(n)]
+            zl, zr = z["L"], z["R"]  # (once: every access of an NpzFile member reads and checks the whole array again)
+            return [(zl[k], zr[k]) for k in range(n)]
         except Exception:
             pass
     import multiprocessing as mp
@@ -576,6 +618,8 @@ def run_loop(cfg, args, rank, local_rank, world, torch, V, barrier, dev, imgs, s
     torch.cuda.synchronize()
     cap = 2 * n_bins + 1024  # several features may share a bucket: the set grows beyond one per bucket
     ctx = V.Context(device=local_rank, max_width=W, max_height=H, max_points=cap, n_slots=5, max_level=lvl)
+    if host_cores() < 3:  # (the rank's own share: caller thread + the runtime's helper threads would otherwise fight a spinning poll)
+        ctx.debug_set(ctx.OPT_POLL_YIELD, 1)
     thr = cfg["thres"]
     svo = V.StereoVO(ctx, W, H, cfg["K"], cfg["K"], st.T_lr, cfg["n_u"], cfg["n_v"], thres_fastscore=cfg["thres_fast"],
                      window_size=win, max_level=lvl, thres_error=thr[0], thres_bidirection=thr[1], thres_poseba_error=thr[2],
@@ -732,6 +776,7 @@ def run_loop(cfg, args, rank, local_rank, world, torch, V, barrier, dev, imgs, s
     if secondary:
         out["secondary"] = secondary_legs(cfg, args, rank, local_rank, torch, V, barrier)
         out["secondary"]["loop_host_images"] = host_image_loop_leg(cfg, args, local_rank, V, barrier, st, imgs, cap, traj)
+        out["secondary"]["track_stereo_images_synchronous"] = synchronous_leg(cfg, args, local_rank, torch, V, barrier, dev, st, imgs, cap, traj)
         if args.batch_S:
             out["secondary"]["streams_per_gpu"] = batch_leg(cfg, args, local_rank, torch, V, dev, prm_svo, cap)
     if world == 1 and not args.no_cpu_baseline:
@@ -773,6 +818,61 @@ def host_image_loop_leg(cfg, args, local_rank, V, barrier, st, imgs, cap, traj):
     ctx.close()
     return {"value": round(K / dt, 2), "unit": "frames/s", "frames": K, "poses_equal_resident_run": same[0],
             "note": "pageable host arrays in, 2 x %d KB per frame over PCIe on the ingest stream under the frame in flight" % (W * H // 1024)}
+
+
+def synchronous_leg(cfg, args, local_rank, torch, V, barrier, dev, st, imgs, cap, traj):
+    """What the reference's own caller gets (ros2/visual_odometry/stereo_vo_ros2.cpp:104): trackStereoImages(left, right, t)
+    — ONE synchronous call per pair, the pair handed over when its frame starts, nothing known about the next pair: no
+    prefetch, no frame issued ahead; local BA on. Measured with host images (cv::Mat-like numpy arrays: upload, pyramids and
+    detection inside the call) and with device-resident images, and — for comparison — the two-call form without
+    prefetch (enqueue(k + 1) right behind result(k), --no-prefetch of the headline loop)."""
+    W, H, thr = cfg["W"], cfg["H"], cfg["thres"]
+    host = [(np.ascontiguousarray(L), np.ascontiguousarray(R)) for L, R in imgs]
+    F, pre = len(host), LOOP_PRIME + args.warmup
+    K = min(args.steps, F - pre - 2)
+    d_imgs = [(torch.from_numpy(L).to(dev), torch.from_numpy(R).to(dev)) for L, R in host[:pre + K + 1]]
+    torch.cuda.synchronize()
+    dptr = [((a.data_ptr(), W), (b.data_ptr(), W)) for a, b in d_imgs]
+    out = {}
+    for name in ("host_images", "device_images", "two_calls_no_prefetch"):
+        ctx = V.Context(device=local_rank, max_width=W, max_height=H, max_points=cap, n_slots=5, max_level=cfg["max_level"])
+        svo = V.StereoVO(ctx, W, H, cfg["K"], cfg["K"], st.T_lr, cfg["n_u"], cfg["n_v"], thres_fastscore=cfg["thres_fast"],
+                         window_size=cfg["win"], max_level=cfg["max_level"], thres_error=thr[0], thres_bidirection=thr[1],
+                         thres_poseba_error=thr[2], strict_border=args.strict_border, local_ba=bool(args.lba))
+        src = host if name == "host_images" else dptr
+        same, stamps, kinds = [True], [], []
+
+        def run(k0, n, keep):
+            for k in range(k0, k0 + n):
+                if name == "two_calls_no_prefetch":
+                    i = svo.result()
+                    if k + 1 < len(src):
+                        svo.enqueue(*src[k + 1])
+                else:
+                    i = svo.trackStereoImages(*src[k])
+                if keep:
+                    stamps.append(time.perf_counter())
+                    kinds.append(bool(i.is_keyframe))
+                    if k < len(traj):
+                        same[0] = same[0] and bool(np.array_equal(np.array(i.T_wc, np.float32).view(np.uint32), traj[k].reshape(-1).view(np.uint32)))
+
+        if name == "two_calls_no_prefetch":
+            svo.enqueue(*src[0])
+        run(0, pre, False)
+        dt = timed(lambda: run(pre, K, True), barrier, ctx)
+        if name == "two_calls_no_prefetch":
+            svo.result()
+        svo.close()
+        ctx.close()
+        d_ms = np.diff(np.asarray(stamps)) * 1e3
+        kf = np.asarray(kinds[1:], bool)
+        out[name] = {"value": round(K / dt, 2), "unit": "frames/s", "frames": K, "poses_equal_headline_run": same[0],
+                     "mean_ms_keyframe": round(float(d_ms[kf].mean()), 4) if kf.any() else None,
+                     "mean_ms_other": round(float(d_ms[~kf].mean()), 4) if (~kf).any() else None}
+    out["note"] = ("host_images / device_images: StereoVO::trackStereoImages(left, right, timestamp) as ONE synchronous call per pair "
+                   "(vo_svo_track), no look-ahead of any kind, local BA = %s; two_calls_no_prefetch: vo_svo_result(k) then "
+                   "vo_svo_enqueue(k + 1) without vo_svo_prefetch" % bool(args.lba))
+    return out
 
 
 def batch_leg(cfg, args, local_rank, torch, V, dev, prm_svo, cap):
@@ -915,6 +1015,9 @@ def cpu_baseline_loop(cfg, args, st, imgs, traj, V, local_rank):
 
 
 def main():
+    if os.environ.get("BENCH_WATCHDOG_S"):  # a stuck run prints every thread's Python stack and exits (diagnosis under a profiler)
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["BENCH_WATCHDOG_S"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed frames (default 400; 40 for --config 4, whose 4K stream is rendered first)")
@@ -948,6 +1051,10 @@ def main():
                          "secondary field of the default run)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rendezvous-timeout", type=float, default=180.0,
+                    help="seconds a rank waits in init_process_group for the others (a rank that never arrives ends the job "
+                         "instead of hanging it); the self-launcher ends all ranks after 20x this")
+    ap.add_argument("--no-pin", action="store_true", help="leave the ranks' CPU affinity alone (default for N > 1: a contiguous share per rank)")
     ap.add_argument("--rendezvous-check", action="store_true",
                     help="run only the multi-rank control flow (gloo, no GPU work) and print its JSON line")
     args = ap.parse_args()
@@ -957,20 +1064,26 @@ def main():
         args.steps = 40 if (args.config == 4 and args.mode == "loop") else 400
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))  # nothing GPU-related has been imported yet
+        # nothing GPU-related has been imported yet
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], job_timeout=(2.0 if args.rendezvous_check else 20.0) * args.rendezvous_timeout))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher environment has WORLD_SIZE={world}")
+    # every rank keeps to its own share of the host's CPUs (renderer pool, launches, result polling): set before anything
+    # forks or spins. LOCAL_WORLD_SIZE is the launcher's (torch.distributed.run and the self-launcher both set it).
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    cpus = sorted(os.sched_getaffinity(0)) if (args.no_pin or world == 1) else pin_rank(local_rank, local_world)
     if args.rendezvous_check:
-        return rendezvous_check(rank, world)
+        return rendezvous_check(rank, world, args.rendezvous_timeout, cpus)
 
     cfg = CONFIGS[args.config]
     loop = args.mode == "loop" and cfg["kind"] == "stereo"
     imgs = None
     if loop:  # (before anything GPU-related is imported: the renderer's pool forks)
-        per_rank_workers = max(1, (args.render_workers or host_cores()) // max(world, 1))
+        # (a pinned rank's host_cores() is already its share)
+        per_rank_workers = max(1, (args.render_workers or host_cores()) // (1 if (world > 1 and not args.no_pin) else max(world, 1)))
         imgs = render_stream(cfg, stream_seed(rank), loop_frames_needed(args), per_rank_workers)
         args.batch_S = [int(v) for v in args.streams_per_gpu.split(",") if v.strip()] if (world == 1 and not args.no_secondary) else []
         args.batch_imgs = [render_stream(cfg, 100 + q, args.batch_frames, per_rank_workers) for q in range(max(args.batch_S, default=0))]
@@ -981,7 +1094,9 @@ def main():
     import visual_odometry_ros_amd as V  # loads libvo_hip.so (fails loudly if missing)
     V.load()
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        import datetime
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank),
+                                timeout=datetime.timedelta(seconds=args.rendezvous_timeout))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     secondary = world == 1 and not args.no_secondary and cfg["kind"] == "stereo" and args.config == 1

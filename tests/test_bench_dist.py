@@ -31,6 +31,34 @@ def test_gpus_2_launches_two_ranks_itself():
     assert d["value"] == 201.0 / 0.75  # total frames / max seconds over ranks
 
 
+def test_ranks_get_disjoint_cpu_sets():
+    """N > 1: every rank pins itself to a contiguous share of the visible CPUs before it renders or polls
+    (--rendezvous-check reports what each rank ended up with)."""
+    if len(os.sched_getaffinity(0)) < 2:
+        import pytest
+        pytest.skip("one visible CPU")
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rendezvous-check"], env=_clean_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    a, b = (set(r["cpus"]) for r in d["per_rank"])
+    assert a and b and not (a & b)
+    assert (a | b) <= set(os.sched_getaffinity(0))
+
+
+def test_a_rank_that_never_reaches_the_rendezvous_ends_the_job():
+    """Rank 1 hangs in front of init_process_group: rank 0's rendezvous times out (--rendezvous-timeout), the launcher
+    ends every child and returns non-zero with the ranks' stderr — well before this test's own limit."""
+    import time
+    env = dict(_clean_env(), BENCH_TEST_HANG_RANK="1")
+    t0 = time.time()
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rendezvous-check", "--rendezvous-timeout", "8"], env=env,
+                       capture_output=True, text=True, timeout=200)
+    assert p.returncode != 0
+    assert time.time() - t0 < 90
+    assert "[rank 0]" in p.stderr or "did not finish" in p.stderr, p.stderr[-1500:]
+
+
 def test_gpus_1_needs_no_rendezvous():
     p = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--rendezvous-check"], env=_clean_env(),
                        capture_output=True, text=True, timeout=300)

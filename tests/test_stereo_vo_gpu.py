@@ -268,7 +268,7 @@ def test_closed_loop_config5(vo, oracle):
             assert np.array_equal(_bits(g["Xw"][tri]), _bits(ref.Xw[tri])), where
             assert np.array_equal(_bits(np.array(gi.T_wc).reshape(4, 4)), _bits(ref.T_wp)), where
             n_kf += int(bool(gi.is_keyframe))
-        assert len(ref.ids) > 4000 and n_kf >= 2
+        assert len(ref.ids) > 2000 and n_kf >= 2
         svo.close()
     finally:
         c.close()

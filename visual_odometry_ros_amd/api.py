@@ -11,6 +11,7 @@ Everything here calls libvo_hip.so. Nothing falls back to numpy or the oracle.
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -50,6 +51,7 @@ class Context:
                 self._h = C.c_void_p()
             raise VoError(rc, msg)
         self.cfg = cfg
+        self._children = weakref.WeakSet()  # objects that hold device state of this context (StereoVO): closed before it
         # test / measurement switches (include/vo_hip.h: vo_debug_set). The library itself reads no environment variable;
         # this mirror hands the ones the test-suite and tools/ set to the context it creates.
         for key, name in enumerate(("VO_DEBUG_FAIL_JOIN", "VO_CONC_GRID", "VO_SBA_LDS_SOLVE", "VO_DEBUG_SKIP_DETECT")):
@@ -57,7 +59,7 @@ class Context:
             if v:
                 self.debug_set(key, int(v) if v.lstrip("-").isdigit() else 1)
 
-    DBG_FAIL_JOIN, DBG_CONC_GRID, DBG_SBA_LDS_SOLVE, DBG_SKIP_DETECT = 0, 1, 2, 3
+    DBG_FAIL_JOIN, DBG_CONC_GRID, DBG_SBA_LDS_SOLVE, DBG_SKIP_DETECT, OPT_POLL_YIELD = 0, 1, 2, 3, 4
 
     def debug_set(self, key, value):
         self.check(self.lib.vo_debug_set(self._h, int(key), int(value)))
@@ -70,6 +72,8 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None):
+            for ch in list(getattr(self, "_children", ())):  # (a StereoVO left open by an exception must not outlive its context)
+                ch.close()
             self.lib.vo_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -784,6 +788,7 @@ class StereoVO:
         self.prm, self.width, self.height = p, width, height
         self._h = C.c_void_p()
         ctx.check(self.lib.vo_svo_create(ctx.handle, C.byref(p), C.byref(self._h)))
+        ctx._children.add(self)
         self._info = SvoFrameInfo()
         self.stats_frame = []  # AlgorithmStatistics::FrameStatistics::Twc per frame (stereo_vo.cpp:979-980)
 

@@ -18,6 +18,7 @@
 #include "frame_state.hpp"
 #include "vo_kernels.hpp"
 
+#include <sched.h>
 #include <stddef.h>
 #include <stdlib.h>
 #include <time.h>
@@ -585,8 +586,9 @@ extern "C" int vo_stereo_frame_result(vo_ctx *c, float *pts_l1, float *pts_r1, u
         clock_gettime(CLOCK_MONOTONIC, &t1);
         if ((t1.tv_sec - t0.tv_sec) * 1e9 + (t1.tv_nsec - t0.tv_nsec) > 2e6) break;
       }
+      if (c->dbg[VO_OPT_POLL_YIELD]) sched_yield();
 #if defined(__x86_64__)
-      __builtin_ia32_pause();
+      else __builtin_ia32_pause();
 #endif
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);

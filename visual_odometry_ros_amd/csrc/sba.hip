@@ -198,9 +198,12 @@ __device__ __forceinline__ double sba_dpp_f64(double v) {
   p.y = dpp_i32<CTRL>(p.y);
   return __builtin_bit_cast(double, p);
 }
-__device__ __forceinline__ double sba_quad_sum(double v) {  // all four lanes of the quad must be active
+__device__ __forceinline__ double sba_quad_sum(double v) {  // sum over the SBA_LQ lanes of a landmark; all must be active
   v += sba_dpp_f64<0xB1>(v);
   v += sba_dpp_f64<0x4E>(v);
+#if SBA_LQ == 8
+  v += sba_dpp_f64<0x141>(v);  // row_half_mirror: the other quad of the eight
+#endif
   return v;
 }
 
@@ -419,12 +422,16 @@ __device__ void sba_se3_log(const double T[16], double xi[6]) {
   xi[4] = w[1];
   xi[5] = w[2];
 }
-// :563-575: xi = log(T); addFrontse3(xi, x) = log(exp(x) exp(xi)); T = exp(xi)
-__device__ void sba_pose_update(double *T, const double x[6]) {
-  double Tin[16], xi[6], Tjw[16], dT[16], P[16];
+// :563-575: xi = log(T); addFrontse3(xi, x) = log(exp(x) exp(xi)); T = exp(xi) — in two halves: the first does not depend
+// on the solve's x (the register solve lets an idle wavefront compute it while the factorisation runs)
+__device__ void sba_pose_pre(const double *T, double Tjw[16]) {
+  double Tin[16], xi[6];
   for (int k = 0; k < 16; ++k) Tin[k] = T[k];
   sba_se3_log(Tin, xi);
   sba_se3_exp(xi, Tjw);
+}
+__device__ void sba_pose_post(double *T, const double Tjw[16], const double x[6]) {
+  double xi[6], dT[16], P[16], To[16];
   sba_se3_exp(x, dT);
   for (int i = 0; i < 4; ++i)
     for (int j = 0; j < 4; ++j) {
@@ -433,8 +440,13 @@ __device__ void sba_pose_update(double *T, const double x[6]) {
       P[i * 4 + j] = s;
     }
   sba_se3_log(P, xi);
-  sba_se3_exp(xi, Tjw);
-  for (int k = 0; k < 16; ++k) T[k] = Tjw[k];
+  sba_se3_exp(xi, To);
+  for (int k = 0; k < 16; ++k) T[k] = To[k];
+}
+__device__ void sba_pose_update(double *T, const double x[6]) {
+  double Tjw[16];
+  sba_pose_pre(T, Tjw);
+  sba_pose_post(T, Tjw, x);
 }
 
 // ---- reduced system: assemble, LDLT, solve, pose update, average error (one wavefront) ------------------
@@ -721,36 +733,99 @@ __device__ __forceinline__ double sba_rl(double v, int src) {
     __builtin_amdgcn_wave_barrier();                     \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); \
   } while (0)
+// a time stamp that the scheduler cannot move: taken after `dep` has been computed, nothing crosses it
+__device__ __forceinline__ long long sba_stamp_after(double dep) {
+  long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
 #define SBA_SOLVE_WG 512
 template <int N>
 __global__ __launch_bounds__(SBA_SOLVE_WG) void sba_solve_reg_kernel(SbaDev d, int iter) {
   __shared__ double sL[N * N + N];  // first the reduced system (lower triangle, G(i,j) at [i * N + j]; rhs behind), later L
   __shared__ double s_dg[N];
   __shared__ int s_sig[N];
+  __shared__ double s_Tpre[64 * 16];  // exp(log(T_f)) of the frames' poses, made by the third wavefront during the solve
   const int tid = threadIdx.x, lane = tid & 63;
   const long long t_0 = (long long)__builtin_amdgcn_s_memrealtime();
   // ---- the reduced system out of the partial sums (what sba_assemble_kernel does for the general kernel), by all
-  // eight wavefronts straight into LDS: entry t of the packed lower triangle, then the right-hand side
-  for (int t = tid; t < N * (N + 1) / 2 + N; t += SBA_SOLVE_WG) {
-    if (t < N * (N + 1) / 2) {
-      int row = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-      while (row * (row + 1) / 2 > t) --row;
-      while ((row + 1) * (row + 2) / 2 <= t) ++row;
-      const int col = t - row * (row + 1) / 2;
-      sL[row * N + col] = sba_reduced_entry(d, row, col);
-    } else {
-      const int q = t - N * (N + 1) / 2, j = q / 6, r = q - 6 * j;
-      double a = 0.0, bcb = 0.0;
+  // eight wavefronts straight into LDS: entry t of the packed lower triangle, then the right-hand side. An entry is two
+  // sums of eight partials; a thread's (at most two) entries issue all their loads before anything waits: one exposure
+  // of the memory latency instead of four.
+  {
+    constexpr int TRI = N * (N + 1) / 2, TOT = TRI + N, PER = (TOT + SBA_SOLVE_WG - 1) / SBA_SOLVE_WG;
+    const int No = d.n_opt;
+    const double *p0[PER], *p1[PER];
+    int s1[PER], mode[PER], dst[PER];  // mode 0: -(sum p0); 1: sum p1 - sum p0; 2: the same with the damped diagonal; 3: rhs
+    double v0[PER][SBA_SG], v1[PER][SBA_PG];
 #pragma unroll
-      for (int g = 0; g < SBA_PG; ++g) {
-        a += d.Apart[48 * ((size_t)j * SBA_PG + g) + 36 + r];
-        bcb += d.Apart[48 * ((size_t)j * SBA_PG + g) + 42 + r];
+    for (int e = 0; e < PER; ++e) {
+      const int t = tid + e * SBA_SOLVE_WG;
+      mode[e] = -1;
+      p0[e] = p1[e] = d.S;
+      s1[e] = 0;
+      dst[e] = 0;
+      if (t < TRI) {
+        int row = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        while (row * (row + 1) / 2 > t) --row;
+        while ((row + 1) * (row + 2) / 2 <= t) ++row;
+        const int col = t - row * (row + 1) / 2;
+        const int j = row / 6, r = row - 6 * j, u = col / 6, c = col - 6 * u;  // u <= j (sba_reduced_entry)
+        p0[e] = d.S + 36 * (((size_t)u * No + j) * SBA_SG) + (c * 6 + r);      // block (u,j), read transposed
+        p1[e] = d.Apart + 48 * ((size_t)j * SBA_PG) + (r * 6 + c);
+        s1[e] = 48;
+        mode[e] = j != u ? 0 : (r == c ? 2 : 1);
+        dst[e] = row * N + col;
+      } else if (t < TOT) {
+        const int q = t - TRI, j = q / 6, r = q - 6 * j;
+        p0[e] = d.Apart + 48 * ((size_t)j * SBA_PG) + 36 + r;  // a_j
+        p1[e] = d.Apart + 48 * ((size_t)j * SBA_PG) + 42 + r;  // (B C^-1 b)_j
+        s1[e] = 48;
+        mode[e] = 3;
+        dst[e] = N * N + q;
       }
-      sL[N * N + q] = a - bcb;  // :508-509
+    }
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+      const int s0 = mode[e] == 3 ? 48 : 36;
+#pragma unroll
+      for (int g = 0; g < SBA_SG; ++g) v0[e][g] = p0[e][(size_t)s0 * g];
+#pragma unroll
+      for (int g = 0; g < SBA_PG; ++g) v1[e][g] = p1[e][(size_t)s1[e] * g];
+    }
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+      double a = 0.0, b2 = 0.0;
+#pragma unroll
+      for (int g = 0; g < SBA_SG; ++g) a += v0[e][g];
+#pragma unroll
+      for (int g = 0; g < SBA_PG; ++g) b2 += v1[e][g];
+      if (mode[e] == 2) b2 += d.lambda * b2;  // :433-441
+      if (mode[e] >= 0) sL[dst[e]] = mode[e] == 0 ? -a : (mode[e] == 3 ? a - b2 : b2 - a);  // rhs: a - bcb (:508-509)
     }
   }
+  const long long t_a = sba_stamp_after(0.0);
   __syncthreads();
-  if (tid >= 128) return;
+  const long long t_b = sba_stamp_after(0.0);
+  const bool pre_staged = d.n_frames <= 64;
+  if (tid >= 192) return;
+  if (tid >= 128) {
+    // the third wavefront: the half of the pose update that does not need x — xi = log(T), exp(xi) (:563-566) — one
+    // frame per lane, next to the factorisation; wavefront 0 picks the results up from LDS behind its solve
+    if (pre_staged) {
+      const int f = lane;
+      if (f < d.n_frames && d.opt_index[f] >= 0) {
+        double Tjw[16];
+        sba_pose_pre(d.T + 16 * (size_t)f, Tjw);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s_Tpre[f * 16 + q] = Tjw[q];
+      }
+      __syncthreads();  // (with wavefront 0, below: the only two wavefronts that are left by then need not be — a
+    }                   //  wavefront that has ended does not hold a barrier up)
+    return;
+  }
   if (tid >= 64) {
     // the second wavefront: average pixel error of this iteration's linearisation point (:594-601), next to the solve
     double e = 0.0;
@@ -804,32 +879,45 @@ __global__ __launch_bounds__(SBA_SOLVE_WG) void sba_solve_reg_kernel(SbaDev d, i
     SBA_WAVE_SYNC();
   }
   // ---- this lane's row of the permuted lower triangle, and its entry of P rhs
+  // (sig[j] is lane j's `my`: a lane broadcast instead of an LDS read per column, and every load is issued before the
+  // first one is waited for — the dependent LDS round trips of the first version were 4 us)
   const int my = lane < N ? s_sig[lane] : 0;
   double r[N];
 #pragma unroll
   for (int j = 0; j < N; ++j) {
-    const int sj = s_sig[j];
+    const int sj = __builtin_amdgcn_readlane(my, j);
     const int hi = my > sj ? my : sj, lo = my > sj ? sj : my;
-    r[j] = (lane < N && j <= lane) ? sL[hi * N + lo] : 0.0;
+    r[j] = sL[hi * N + lo];
   }
+#pragma unroll
+  for (int j = 0; j < N; ++j) r[j] = (lane < N && j <= lane) ? r[j] : 0.0;
   double y = lane < N ? sL[N * N + my] : 0.0;
   SBA_WAVE_SYNC();  // (sL is written again below)
-  const long long t_1 = (long long)__builtin_amdgcn_s_memrealtime();
+  const long long t_1 = sba_stamp_after(r[0] + y);
   // ---- Eigen::LDLT (lower, in place), left-looking, fully unrolled. (temp[j] through LDS — one store by lane k, a
   // broadcast read by all — was measured slower than the lane broadcasts: 22 vs 17 us, two LDS round trips per step.)
+  // Scheduled column by column: once column j is final its contribution L(i,j) * (D_j L(k,j)) goes into the accumulator of
+  // every later column k — N - 1 - j independent multiply-adds per step instead of one chain of k dependent ones per
+  // column. Each accumulator still receives its terms in increasing j and is subtracted from M(i,k) in one piece when
+  // column k's turn comes: the same sums in the same order as the left-looking form (same bits), ~13 -> ~8 us.
+  // (Finalising column j + 1 in front of the rest of column j's updates, to fill its chain of ~17 dependent instructions,
+  // measured the same 9.9 us: 5 500 instructions of one wavefront at ~4.4 cycles each — two lane broadcasts, a wait state, a
+  // multiply and an add per (j, k) — is what the factorisation costs.)
   double dgl = 0.0;  // this lane's final diagonal entry D(lane)
-  double w[N];       // w[j] = M(j,j) * M(lane,j) once column j is final: temp[j] of step k is lane k's w[j]
+  double acc[N];     // acc[k] = sum_{j < k, final} M(lane,j) temp_k[j], temp_k[j] = D_j M(k,j)
 #pragma unroll
-  for (int k = 0; k < N; ++k) {
-    double dd = 0.0;
+  for (int k = 0; k < N; ++k) acc[k] = 0.0;
 #pragma unroll
-    for (int j = 0; j < k; ++j) dd += r[j] * sba_rl(w[j], k);  // row `lane`: sum_{j<k} M(lane,j) temp[j], increasing j
-    if (k > 0 && lane >= k) r[k] -= dd;                        // rows k (the diagonal entry) and k+1.. in one sweep
-    const double akk = sba_rl(r[k], k);
-    if (lane == k) dgl = akk;
-    if (fabs(akk) > 0.0 && lane > k) r[k] /= akk;
-    w[k] = akk * r[k];
+  for (int j = 0; j < N; ++j) {
+    if (j > 0 && lane >= j) r[j] -= acc[j];  // rows j (the diagonal entry) and j+1.. in one sweep
+    const double ajj = sba_rl(r[j], j);
+    if (lane == j) dgl = ajj;
+    if (fabs(ajj) > 0.0 && lane > j) r[j] /= ajj;
+    const double wj = ajj * r[j];  // lane k: D_j M(k,j) = temp[j] of step k
+#pragma unroll
+    for (int k = j + 1; k < N; ++k) acc[k] += r[j] * sba_rl(wj, k);
   }
+  const long long t_f = sba_stamp_after(dgl + r[N - 1]);
   // ---- solve: x = P^T L^-T D^+ L^-1 (P rhs); the entry of lane i stays in a register
 #pragma unroll
   for (int j = 0; j < N; ++j) {
@@ -850,17 +938,32 @@ __global__ __launch_bounds__(SBA_SOLVE_WG) void sba_solve_reg_kernel(SbaDev d, i
   double *xs = s_dg;
   if (lane < N) xs[my] = y;
   SBA_WAVE_SYNC();
-  const long long t_2 = (long long)__builtin_amdgcn_s_memrealtime();
+  const long long t_2 = sba_stamp_after(y);
   if (lane < N) d.x[lane] = xs[lane];
   // pose updates (:560-576)
-  for (int f = lane; f < d.n_frames; f += 64) {
-    const int j = d.opt_index[f];
-    if (j >= 0) sba_pose_update(d.T + 16 * (size_t)f, xs + 6 * j);
+  if (pre_staged) {
+    __syncthreads();  // the third wavefront's exp(log(T_f)) are in LDS (it finished long ago)
+    const int f = lane, j = f < d.n_frames ? d.opt_index[f] : -1;
+    if (j >= 0) {
+      double Tjw[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) Tjw[q] = s_Tpre[f * 16 + q];
+      sba_pose_post(d.T + 16 * (size_t)f, Tjw, xs + 6 * j);
+    }
+  } else {
+    for (int f = lane; f < d.n_frames; f += 64) {
+      const int j = d.opt_index[f];
+      if (j >= 0) sba_pose_update(d.T + 16 * (size_t)f, xs + 6 * j);
+    }
   }
   if (lane == 0) {
     d.flags[1] = (int)(t_1 - t_0);
     d.flags[2] = (int)(t_2 - t_1);
     d.flags[3] = (int)((long long)__builtin_amdgcn_s_memrealtime() - t_2);
+    d.flags[4] = (int)(t_a - t_0);  // wavefront 0: its entries of the reduced system
+    d.flags[5] = (int)(t_b - t_a);  // waiting for the other wavefronts
+    d.flags[6] = (int)(t_1 - t_b);  // pivot order + rows into registers
+    d.flags[7] = (int)(t_f - t_1);  // factorisation
   }
 }
 
@@ -988,13 +1091,13 @@ __global__ __launch_bounds__(64) void sba_update_point_kernel(SbaDev d, int upda
 struct vo_sba_state {
   void *dev;
   size_t cap;
-  int phase_ticks[3];  // sba_solve_kernel of the last iteration: assembly, LDLT + solve, pose update (10 ns ticks)
+  int phase_ticks[8];  // solve kernel of the last iteration: assembly, LDLT + solve, pose update; [3..5] parts of the assembly (10 ns ticks)
   void *stage;         // pinned host staging: the problem goes up in one copy, the results come back through it
   size_t stage_cap;
 };
-extern "C" int vo_debug_sba_phases(vo_ctx *c, int out[3]) {
+extern "C" int vo_debug_sba_phases(vo_ctx *c, int out[8]) {
   if (!c || !c->sba) return VO_ERR_INVALID;
-  memcpy(out, c->sba->phase_ticks, sizeof(int) * 3);
+  memcpy(out, c->sba->phase_ticks, sizeof(int) * 8);
   return VO_OK;
 }
 
@@ -1337,7 +1440,7 @@ extern "C" int vo_sba_solve(vo_ctx *c, const vo_sba_problem *p, double *T_jw, co
             tt[3] / n_calls, tt[4] / n_calls, tt[5] / n_calls, tt[6] / n_calls, tt[1] / n_calls, n_pairs, ns, in_bytes >> 10);
   if (avg_err)
     for (int k = 0; k < p->max_iter; ++k) avg_err[k] = errs[k];
-  memcpy(c->sba->phase_ticks, flags + 1, sizeof(int) * 3);
+  memcpy(c->sba->phase_ticks, flags + 1, sizeof(int) * 8);
   if (flags[0] & 1) VO_FAIL(c, VO_ERR_LBA_NAN, "In LBA, pose becomes nan!");
   if (flags[0] & 2) VO_FAIL(c, VO_ERR_LBA_NAN, "Local BA NAN!");
   if (p->max_iter == 0) return 1;

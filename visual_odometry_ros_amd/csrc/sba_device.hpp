@@ -9,7 +9,7 @@
 #define SBA_PG 8        // partial-sum workgroups per optimised pose
 #define SBA_SG 8        // partial-sum workgroups per block of B C^-1 B^T
 #define SBA_MAX_OPT 20  // reduced system up to 120 x 120 in LDS
-#define SBA_LQ 4        // lanes per landmark in the point kernel
+#define SBA_LQ 8        // lanes per landmark in the point kernel (4 or 8)
 
 struct SbaDev {
   int n_frames, n_opt, M, n_obs, n_slots, stereo, max_iter;

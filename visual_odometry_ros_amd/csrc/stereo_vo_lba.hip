@@ -29,6 +29,7 @@
 // first version merged the window's id lists on the host and uploaded 1.6 MB per keyframe: 0.41 ms of host time around
 // 0.64 ms of kernels.)
 #include <math.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <time.h>
@@ -412,6 +413,17 @@ __global__ void lba_mappoints_kernel(const int32_t *ids, int n, LmTab tab, float
   out[3 * k + 2] = ok ? tab.X[3 * (size_t)t + 2] : 0.0f;
 }
 
+// what the host needs of a solve (poses | errors | flags | counts, 2.3 KB) goes straight into pinned host memory, the solve's
+// sequence number last: the host polls that word instead of sleeping in hipStreamSynchronize (whose wake-up costs tens to
+// hundreds of microseconds after a wait of this length)
+#define LBA_SEQ_WORD 1000  // of the 4096-byte pinned block
+__global__ __launch_bounds__(256) void lba_result_kernel(const uint32_t *src, uint32_t *host, int words, uint32_t seq) {
+  for (int k = threadIdx.x; k < words; k += 256) host[k] = src[k];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(&host[LBA_SEQ_WORD], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // the table doubles: every held id moves to id mod (new size) — a multiple of the old size, so no two collide
 __global__ void lba_tab_rehash_kernel(LmTab o, LmTab n) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -460,7 +472,8 @@ struct vo_svo_lba {
   size_t span_cap = 0;
   uint8_t *arena = nullptr;
   LbaLayout lay = {};
-  uint8_t *h_res = nullptr;  // pinned: poses, errors, flags, counts of a solve
+  uint8_t *h_res = nullptr;  // pinned: poses, errors, flags, counts of a solve; word LBA_SEQ_WORD = the solve's sequence number
+  uint32_t seq = 0;
   std::vector<int32_t *> pool;  // all keyframes' id lists, chunk by chunk
   size_t pool_used = 0;         // ids used in the last chunk
   float *d_map = nullptr;       // staging of one keyframe's map points
@@ -765,6 +778,8 @@ static int lba_warm_up(vo_svo *s) {
   }
   hipLaunchKernelGGL(lba_keyframe_kernel, dim3(1), dim3(256), 0, c->stream, s->ts[0], 0, L->tab, L->kf_ids[0], L->kf_pl[0], L->kf_pr[0],
                      L->pool.back());
+  L->seq = 1;
+  hipLaunchKernelGGL(lba_result_kernel, dim3(1), dim3(256), 0, c->stream, (const uint32_t *)L->arena, (uint32_t *)L->h_res, 16, L->seq);
   VO_CHECK_HIP(c, hipGetLastError());
   return VO_OK;
 }
@@ -786,6 +801,7 @@ int vo_svo_lba_init(vo_svo *s) {
     VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&L->kf_pr[k], sizeof(float) * 2 * (size_t)s->cap));
   }
   VO_CHECK_HIP(c, vo_host_malloc(c, (void **)&L->h_res, 4096, hipHostMallocDefault));
+  memset(L->h_res, 0, 4096);
   VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&L->d_map, sizeof(float) * 3 * (size_t)s->cap));
   rc = lba_pool_reserve(s, (size_t)s->cap);
   if (rc < 0) return rc;
@@ -923,9 +939,34 @@ int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info, int id_min) {
   // ---- what the host needs: poses, errors, flags, counts ----
   double *o_T = (double *)L->h_res, *o_e = o_T + 16 * LBA_KW;
   int *o_f = (int *)(o_e + 16), *o_d = o_f + 16;
-  VO_CHECK_HIP(c, hipMemcpyAsync(o_T, res_dev, lay.res_bytes, hipMemcpyDeviceToHost, st));
+  L->seq = L->seq + 1 == 0 ? 1 : L->seq + 1;
+  hipLaunchKernelGGL(lba_result_kernel, dim3(1), dim3(256), 0, st, (const uint32_t *)res_dev, (uint32_t *)L->h_res, (int)(lay.res_bytes / 4),
+                     L->seq);
+  VO_CHECK_HIP(c, hipGetLastError());
   const double t_1 = trace ? lba_now() : 0.0;
-  VO_CHECK_HIP(c, hipStreamSynchronize(st));
+  {
+    volatile const uint32_t *seqp = (volatile const uint32_t *)L->h_res + LBA_SEQ_WORD;
+    bool seen = false;
+    timespec p0;
+    clock_gettime(CLOCK_MONOTONIC, &p0);
+    for (int spin = 0; !seen; ++spin) {
+      if (*seqp == L->seq) {
+        seen = true;
+        break;
+      }
+      if ((spin & 255) == 255) {  // ~20 ms of polling at most, then the stream decides
+        timespec p1;
+        clock_gettime(CLOCK_MONOTONIC, &p1);
+        if ((p1.tv_sec - p0.tv_sec) * 1e9 + (p1.tv_nsec - p0.tv_nsec) > 2e7) break;
+      }
+      if (c->dbg[VO_OPT_POLL_YIELD]) sched_yield();
+#if defined(__x86_64__)
+      else __builtin_ia32_pause();
+#endif
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    if (!seen) VO_CHECK_HIP(c, hipStreamSynchronize(st));
+  }
   const double t_2 = trace ? lba_now() : 0.0;
   if (o_d[0] <= 0) return VO_OK;  // no landmark qualifies: nothing to adjust
   if (o_f[0] & 1) VO_FAIL(c, VO_ERR_LBA_NAN, "In LBA, pose becomes nan!");
