@@ -575,6 +575,69 @@ int vo_mono_frame_enqueue_closed(vo_ctx *ctx, const vo_mono_params *prm, int slo
  * their back-tracked pixels in I0, mask_new = trackBidirection's mask. Capacity: n_bins_u * n_bins_v each. */
 int vo_mono_frame_new_points(vo_ctx *ctx, float *pts1_new, float *pts0_new, uint8_t *mask_new, int *n_new);
 
+/* ---- MonoVO: the closed loop around the mono frame -------------------------------------------------------------
+ * MonoVO::trackImage (core/visual_odometry/mono_vo/mono_vo.cpp:496-1194, class surface mono_vo.h:235-243, :267) with the
+ * track set carried ON THE DEVICE: per landmark the pixel seen, id, world point, flags (VO_LM_TRIANGULATED | VO_LM_DROPPED |
+ * VO_LM_KF_MEMBER | VO_LM_BUNDLED), its first observation and frame, age, the parallax of its newest observation
+ * (landmark.cpp:76-135), its first keyframe observation and their number. The first image creates one landmark per bucketed
+ * keypoint (:528-561); the second is the initialisation (:562-696); then the steady state (:698-1019: prior and patch scale
+ * from bundled landmarks, trackBidirectionWithPrior, trackWithScale, pose-only BA on the bundled / triangulated
+ * landmarks, Sampson gate, new points back-tracked into the previous image); at the end of every call the keyframe rule
+ * (keyframes.cpp:47-126), and at a keyframe addNewKeyframe (:30-45), the reconstruction of landmarks seen on more than
+ * two keyframes (:1032-1076) and the mono local BA (motion_estimator.cpp:1090-1205, sparse_ba_parameters.h:292-466 with
+ * one observation per keyframe and at least two window keyframes per landmark; setBundled / setDead on the way back).
+ * The 5-point / essential-matrix pose (MotionEstimator::calcPose5PointsAlgorithm, motion_estimator.cpp:21-203: OpenCV
+ * calib3d, out of scope per SURVEY §2) is a CALLER HOOK: called at the initialisation and whenever the pose-only BA
+ * yields no pose (:909-949). pts0 / pts1: n pixel pairs (previous, current image); K = fx, fy, cx, cy; outputs R10
+ * (row-major 3x3), t10 (any length; the driver rescales it as the reference does) and mask[n] (inliers). Return non-zero
+ * on success; 0 ends the call with VO_ERR_GN_FAILED (the reference throws).
+ * Needs a context with >= 3 image slots and prm.frame.win in {13, 15, 21, 31}. */
+#define VO_LM_BUNDLED 8
+typedef int (*vo_five_point_fn)(void *user, const float *pts0, const float *pts1, int n, const float K[4], float R10[9],
+                                float t10[3], uint8_t *mask);
+typedef struct vo_mvo vo_mvo;
+typedef struct {
+  vo_mono_params frame;     /* Camera.*, feature_tracker.* (incl. thres_sampson), motion_estimator.thres_poseba_error */
+  vo_bin_params bins;       /* feature_extractor.* as FeatureExtractor::initParams derives them */
+  float kf_overlap_ratio;   /* keyframe_update.thres_overlap_ratio */
+  float kf_rotation_deg;    /* keyframe_update.thres_rotation (degrees) */
+  float kf_translation;     /* keyframe_update.thres_translation */
+  int kf_window;            /* keyframe_update.n_max_keyframes_in_window (at most 16) */
+  float thres_parallax_deg; /* map_update.thres_parallax (degrees; the reference multiplies by D2R) */
+  int strict_border;        /* trackWithScale's never-reset tap state: 0 masked taps, 1 reference-exact, 2 sequential replay */
+  int local_ba;             /* != 0: localBundleAdjustmentSparseSolver at every keyframe */
+  int rectify;              /* != 0: flagDoUndistortion (mono_vo.cpp:509-513) — images go through camera 0's undistortion
+                               map (vo_rectify_init_mono first) on their way into the pyramid */
+  vo_five_point_fn five_point;
+  void *five_point_user;
+} vo_mvo_params;
+typedef struct {
+  int frame_id;             /* Frame id of this image (the context's frame counter) */
+  int is_first, is_init, is_keyframe, lba_ran, used_five_point;
+  int n_tracks_in, n_final, n_new, n_tracks_out, n_kf_tracked, n_reconstructed;
+  vo_mono_counts counts;
+  vo_gn_info gn;
+  float dT01[16];           /* motion previous -> current camera as the frame used it */
+  float T_wc[16];           /* pose after this call (after the local BA at a keyframe) */
+  double lba_err_first, lba_err_last;
+  int lba_landmarks, lba_observations;
+} vo_mvo_frame_info;
+int vo_mvo_create(vo_ctx *ctx, const vo_mvo_params *prm, vo_mvo **out);
+void vo_mvo_destroy(vo_mvo *mvo);
+/* MonoVO::trackImage(img, timestamp): synchronous. Image: u8, `stride` bytes per row, device pointer when on_device != 0. */
+int vo_mvo_track(vo_mvo *mvo, const void *img, int stride, int on_device, double timestamp, vo_mvo_frame_info *info);
+/* the same in halves, and the next image handed over early (pyramid + per-bin candidate table on the side stream) */
+int vo_mvo_enqueue(vo_mvo *mvo, const void *img, int stride, int on_device, double timestamp);
+int vo_mvo_prefetch(vo_mvo *mvo, const void *img, int stride, int on_device);
+int vo_mvo_result(vo_mvo *mvo, vo_mvo_frame_info *info);
+/* frame_prev_'s related landmarks (test / inspection hook): any pointer may be NULL. cos_parallax: cosine of
+ * Landmark::getLastParallax() (2 = no second observation yet) */
+int vo_mvo_get_tracks(vo_mvo *mvo, int32_t *ids, float *pts, float *Xw, uint8_t *flags, int32_t *age, float *cos_parallax, int cap,
+                      int *n);
+/* stats_keyframe (mono_vo.cpp:1130-1155), as vo_svo_keyframe_count / vo_svo_get_keyframes */
+int vo_mvo_keyframe_count(vo_mvo *mvo, int *n_keyframes);
+int vo_mvo_get_keyframes(vo_mvo *mvo, float *T_wc, int32_t *n_points, float *mappoints, size_t cap_points, size_t *total_points);
+
 /* ---- sparse local bundle adjustment -----------------------------------------
  * SparseBundleAdjustmentSolver::solveForFiniteIterations
  * (core/visual_odometry/ba_solver/sparse_bundle_adjustment.cpp:150-643; called from

@@ -491,6 +491,23 @@ def keyframe_reconstruct(pts_l, pts_r, T_rl, Kl, Kr, T_wc, Xw):
     return X[:n], st[:n].astype(bool)
 
 
+def parallax(p0, p1, K, T_cw_first, T_wc_last):
+    """landmark.cpp:100-121: (parallax, clamped cos) of the newest observation w.r.t. the oldest one."""
+    c = C.c_float(0)
+    lib().vo_ref_parallax.restype = C.c_float
+    a = lib().vo_ref_parallax(_p(_f32(p0).reshape(2)), _p(_f32(p1).reshape(2)), _p(_f32(K)), _p(_f32(T_cw_first).reshape(16)),
+                              _p(_f32(T_wc_last).reshape(16)), C.byref(c))
+    return np.float32(a), np.float32(c.value)
+
+
+def mono_reconstruct(pt0, pt1, T_w0, T_1w, K, keyframe_rule):
+    """mono_vo.cpp:669-686 (keyframe_rule False) / :1041-1073 (True): (reconstructed?, Xworld)."""
+    X = np.zeros(3, np.float32)
+    ok = lib().vo_ref_mono_reconstruct(_p(_f32(pt0).reshape(2)), _p(_f32(pt1).reshape(2)), _p(_f32(T_w0).reshape(16)),
+                                       _p(_f32(T_1w).reshape(16)), _p(_f32(K)), int(bool(keyframe_rule)), _p(X))
+    return bool(ok), X
+
+
 STAGE_NAMES = ("prior", "klt_l0l1", "track_with_scale", "klt_l1r1", "pose_only_ba", "gates_compactions", "klt_new_points")
 
 

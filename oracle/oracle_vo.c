@@ -288,3 +288,59 @@ int vo_ref_keyframe_reconstruct(const float *pts_l, const float *pts_r, int n, c
   }
   return cnt;
 }
+
+/* ---- MonoVO (mono_vo.cpp) -------------------------------------------------------------------------------------------- */
+
+/* Landmark::addObservationAndRelatedFrame, landmark.cpp:100-121: the parallax of the newest observation p1 (seen from a
+ * frame of pose T_wc_last) with respect to the oldest one p0 (frame of inverse pose T_cw_first): T01 =
+ * front()->getPoseInv() * back()->getPose(); bearings through fxinv / fyinv (camera.cpp:28-29); x1 = R01 * x1 (Eigen's
+ * 3-term redux); costheta = x0.dot(x1) / (|x0| |x1|), pushed inside (-1, 1) by the two tests of :113-116; acosf. */
+float vo_ref_parallax(const float p0[2], const float p1[2], const float K[4], const float T_cw_first[16],
+                      const float T_wc_last[16], float *cos_out) {
+  float T01[16];
+  vo_ref_mul44(T_cw_first, T_wc_last, T01);
+  const float fxinv = 1.0f / K[0], fyinv = 1.0f / K[1];
+  const float x0[3] = {(p0[0] - K[2]) * fxinv, (p0[1] - K[3]) * fyinv, 1.0f};
+  const float x1[3] = {(p1[0] - K[2]) * fxinv, (p1[1] - K[3]) * fyinv, 1.0f};
+  float r[3];
+  for (int i = 0; i < 3; ++i) r[i] = dot3e(T01[i * 4 + 0], x1[0], T01[i * 4 + 1], x1[1], T01[i * 4 + 2], x1[2]);
+  const float dot = dot3e(x0[0], r[0], x0[1], r[1], x0[2], r[2]);
+  const float n0 = sqrtf(dot3e(x0[0], x0[0], x0[1], x0[1], x0[2], x0[2]));
+  const float n1 = sqrtf(dot3e(r[0], r[0], r[1], r[1], r[2], r[2]));
+  float c = dot / (n0 * n1);
+  if (c >= 1.0f) c = 0.99999f;
+  if (c <= -1.0f) c = -0.99999f;
+  if (cos_out) *cos_out = c;
+  return acosf(c);
+}
+
+/* MonoVO's two reconstructions of a landmark from its first and its last observation (mapping::triangulateDLT, one camera):
+ *   keyframe_rule = 0  mono_vo.cpp:669-686 (initialisation): T10 = T1w * Tw0, X0(2) > 0 -> Xworld = Tw0 * X0
+ *   keyframe_rule = 1  mono_vo.cpp:1041-1073 (new keyframe): additionally both reprojection errors at most 1 px (squared,
+ *                      compared with the double 1.0) and X1(2) > 0
+ * Returns 1 and Xw when the landmark is reconstructed. */
+int vo_ref_mono_reconstruct(const float pt0[2], const float pt1[2], const float T_w0[16], const float T_1w[16],
+                            const float K[4], int keyframe_rule, float Xw[3]) {
+  float T10[16];
+  vo_ref_mul44(T_1w, T_w0, T10);
+  const float R[9] = {T10[0], T10[1], T10[2], T10[4], T10[5], T10[6], T10[8], T10[9], T10[10]};
+  const float t[3] = {T10[3], T10[7], T10[11]};
+  float X0[3], X1[3], px, py;
+  vo_ref_triangulate_dlt(pt0, pt1, R, t, K, K, X0, X1);
+  if (keyframe_rule) {
+    project_px(K, X0, &px, &py);
+    float dx = pt0[0] - px, dy = pt0[1] - py;
+    float d2 = dx * dx + dy * dy;
+    if ((double)d2 > 1.0) return 0;
+    project_px(K, X1, &px, &py);
+    dx = pt1[0] - px;
+    dy = pt1[1] - py;
+    d2 = dx * dx + dy * dy;
+    if ((double)d2 > 1.0) return 0;
+    if (!(X0[2] > 0 && X1[2] > 0)) return 0;
+  } else if (!(X0[2] > 0)) {
+    return 0;
+  }
+  vo_ref_xform_eig(T_w0, X0, Xw);
+  return 1;
+}

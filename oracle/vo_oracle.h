@@ -192,6 +192,12 @@ int vo_ref_new_landmark_accept(const float *pts_l, const float *pts_r, const uin
                                const float T_rl[16], const float Kl[4], const float Kr[4], uint8_t *accept, float *Xl_out);
 int vo_ref_keyframe_reconstruct(const float *pts_l, const float *pts_r, int n, const float T_rl[16], const float Kl[4],
                                 const float Kr[4], const float *T_wc, float *Xw, uint8_t *set);
+/* MonoVO: landmark.cpp:100-121 (parallax of the newest observation w.r.t. the oldest), mono_vo.cpp:669-686 / :1041-1073
+ * (reconstruction of a landmark from its first and last observation) */
+float vo_ref_parallax(const float p0[2], const float p1[2], const float K[4], const float T_cw_first[16],
+                      const float T_wc_last[16], float *cos_out);
+int vo_ref_mono_reconstruct(const float pt0[2], const float pt1[2], const float T_w0[16], const float T_1w[16],
+                            const float K[4], int keyframe_rule, float Xw[3]);
 
 /* per-stage wall clock (ms) of the last vo_ref_stereo_frame call: priors, KLT l0->l1, trackWithScale, KLT l1->r1, BA,
  * gates + compactions, new-point tracking */

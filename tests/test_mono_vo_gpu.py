@@ -1,0 +1,99 @@
+"""The closed loop of MonoVO::trackImage (mono_vo.cpp:496-1194) on the device (vo_mvo_*) against its CPU restatement
+(oracle/mono_vo.py), both running FREE next to each other: the first image, the initialisation with the 5-point hook,
+steady-state frames, keyframes with reconstruction and the mono local BA — ids, pixels, flags (triangulated / bundled /
+dead / keyframe member), world points, ages, parallaxes and the pose after every frame."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+MONO_K = (458.654, 457.296, 367.215, 248.375)
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+class TruePoseHook:
+    """Stands for calcPose5PointsAlgorithm: the scene's true relative pose of frame k against k - 1 (any length of t10), every
+    pair an inlier. `k` is set by the test before each frame."""
+
+    def __init__(self, poses):
+        self.poses, self.k, self.calls = poses, 0, 0
+
+    def __call__(self, pts0, pts1):
+        self.calls += 1
+        T10 = np.linalg.inv(self.poses[self.k]) @ self.poses[self.k - 1]
+        return True, T10[:3, :3].astype(np.float32), T10[:3, 3].astype(np.float32), np.ones(len(pts0), bool)
+
+
+def _run_both(vo, oracle, n_frames, lba, strict, kf_trans, seed=5, prefetch=False, W=752, H=480, nu=40, nv=25, win=15, lvl=5):
+    from oracle.mono_vo import MonoVORef
+    from visual_odometry_ros_amd import synthetic as S
+    st = S.StereoStream(width=W, height=H, K=MONO_K, n_u=nu, n_v=nv, seed=seed, speed=0.25)
+    poses = st.poses(n_frames)
+    imgs = [st.render_pair(p)[0] for p in poses]
+    hook_g, hook_r = TruePoseHook(poses), TruePoseHook(poses)
+    ref = MonoVORef(W, H, MONO_K, nu, nv, hook_r, thres_fast=15, win=win, max_level=lvl, thres_err=20.0, thres_bidir=1.0, thres_poseba=5,
+                    thres_sampson=1.0, thres_parallax_deg=1.0, kf_trans=kf_trans, lba=lba, sum_mode=oracle.SUM_TREE, tree_width=512,
+                    ic_border=oracle.IC_REFERENCE if strict else oracle.IC_MASKED, n_threads=8)
+    c = vo.Context(device=0, max_width=W, max_height=H, max_points=2 * nu * nv + 512, n_slots=3, max_level=lvl)
+    log = []
+    try:
+        mvo = vo.MonoVO(c, W, H, MONO_K, nu, nv, hook_g, thres_fastscore=15, window_size=win, max_level=lvl, thres_error=20.0,
+                        thres_bidirection=1.0, thres_poseba_error=5, thres_sampson=1.0, thres_parallax=1.0, thres_translation=kf_trans,
+                        strict_border=strict, local_ba=lba)
+        for k in range(n_frames):
+            hook_g.k = hook_r.k = k
+            if prefetch:
+                mvo.enqueue(imgs[k])
+                if k + 1 < n_frames:
+                    mvo.prefetch(imgs[k + 1])
+                gi = mvo.result()
+            else:
+                gi = mvo.trackImage(imgs[k])
+            ri = ref.track(imgs[k])
+            g = mvo.getTracks()
+            where = f"frame {k}"
+            assert gi.frame_id == ri["frame_id"], where
+            assert bool(gi.is_keyframe) == ri["keyframe"], where
+            assert np.array_equal(g["ids"], ref.ids), where
+            assert np.array_equal(_bits(g["pts"]), _bits(ref.pts)), where
+            assert np.array_equal(g["flags"], ref.flags()), where
+            tri = (g["flags"] & 1) != 0
+            assert np.array_equal(_bits(g["Xw"][tri]), _bits(ref.Xw()[tri])), where
+            assert np.array_equal(g["age"], np.array([ref.lm[int(i)]["age"] for i in ref.ids], np.int32)), where
+            cos_ref = np.array([ref.lm[int(i)]["cos_last"] if ref.lm[int(i)]["age"] > 1 else 2.0 for i in ref.ids], np.float32)
+            assert np.array_equal(_bits(g["cos_parallax"]), _bits(cos_ref)), where
+            assert np.array_equal(_bits(np.array(gi.T_wc).reshape(4, 4)), _bits(ref.frames[k]["T_wc"])), where
+            if k > 0:
+                assert (gi.n_final, gi.n_new) == (ri["n_final"], ri["n_new"]), where
+            assert bool(gi.used_five_point) == ri["five_point"], where
+            log.append((bool(gi.is_keyframe), gi.n_tracks_out, bool(gi.lba_ran), int(gi.lba_landmarks), bool(gi.used_five_point)))
+            if gi.is_keyframe or k == n_frames - 1:
+                gk, rk = mvo.getKeyframes(), ref.keyframe_stats()
+                assert len(gk) == len(rk), where
+                for j, ((Tg, Xg), (Tr, Xr)) in enumerate(zip(gk, rk)):
+                    assert np.array_equal(_bits(Tg), _bits(Tr)) and np.array_equal(_bits(Xg), _bits(Xr)), (where, j)
+        assert hook_g.calls == hook_r.calls
+        mvo.close()
+        return log, ref
+    finally:
+        c.close()
+
+
+def test_mono_loop_small(vo, oracle):
+    """Eight frames without the local BA: first image, initialisation, six steady-state frames, keyframes."""
+    log, ref = _run_both(vo, oracle, 8, lba=False, strict=1, kf_trans=2.5)
+    assert log[0][0] and sum(1 for e in log if e[0]) >= 3
+    assert log[1][4] and not any(e[4] for e in log[2:])  # the 5-point hook at the initialisation only
+    assert log[-1][1] > 300
+
+
+def test_mono_loop_config3_local_ba(vo, oracle):
+    """BASELINE configs[2] as a closed loop: 752x480, 40x25 buckets, win 15, 5 levels — 14 frames, a keyframe every two or
+    three of them, the mono local BA from the third keyframe on (landmarks become bundled, the priors and the pose-only BA's
+    class switch to them), the next image handed over early."""
+    log, ref = _run_both(vo, oracle, 14, lba=True, strict=1, kf_trans=2.5, prefetch=True)
+    assert sum(1 for e in log if e[0]) >= 4, log
+    assert sum(1 for e in log if e[2]) >= 2, log
+    assert any(ref.lm[int(i)]["bundled"] for i in ref.ids)

@@ -8,4 +8,4 @@ reference's FeatureTracker / MotionEstimator operator interface.
 from ._capi import VoError, load, LIB_PATH  # noqa: F401
 from .api import (Context, FeatureTracker, MotionEstimator, FeatureExtractor,  # noqa: F401
                   StereoFramePipeline, MonoFramePipeline, Camera, StereoCamera,
-                  SparseBundleAdjustmentSolver, TrackIds, se3Exp_f, write_trajectory, StereoVO, triangulateDLT, ImageSlots, StereoBatch)
+                  SparseBundleAdjustmentSolver, TrackIds, se3Exp_f, write_trajectory, StereoVO, MonoVO, triangulateDLT, ImageSlots, StereoBatch)

@@ -83,6 +83,25 @@ class SvoFrameInfo(C.Structure):
                 ("lba_err_last", C.c_double), ("lba_landmarks", C.c_int), ("lba_observations", C.c_int)]
 
 
+FIVE_POINT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float),
+                            C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint8))
+
+
+class MvoParams(C.Structure):
+    _fields_ = [("frame", MonoParams), ("bins", BinParams), ("kf_overlap_ratio", C.c_float), ("kf_rotation_deg", C.c_float),
+                ("kf_translation", C.c_float), ("kf_window", C.c_int), ("thres_parallax_deg", C.c_float),
+                ("strict_border", C.c_int), ("local_ba", C.c_int), ("rectify", C.c_int), ("five_point", FIVE_POINT_FN),
+                ("five_point_user", C.c_void_p)]
+
+
+class MvoFrameInfo(C.Structure):
+    _fields_ = [("frame_id", C.c_int), ("is_first", C.c_int), ("is_init", C.c_int), ("is_keyframe", C.c_int), ("lba_ran", C.c_int),
+                ("used_five_point", C.c_int), ("n_tracks_in", C.c_int), ("n_final", C.c_int), ("n_new", C.c_int),
+                ("n_tracks_out", C.c_int), ("n_kf_tracked", C.c_int), ("n_reconstructed", C.c_int), ("counts", MonoCounts),
+                ("gn", GnInfo), ("dT01", C.c_float * 16), ("T_wc", C.c_float * 16), ("lba_err_first", C.c_double),
+                ("lba_err_last", C.c_double), ("lba_landmarks", C.c_int), ("lba_observations", C.c_int)]
+
+
 # every symbol include/vo_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "vo_abi_version", "vo_device_count", "vo_create", "vo_destroy", "vo_last_error", "vo_stream",
@@ -103,6 +122,8 @@ SYMBOLS = [
     "vo_new_point_candidates_get", "vo_stereo_frame_enqueue_closed", "vo_stereo_frame_new_points",
     "vo_stereo_frame_enqueue_closed_world", "vo_stereo_frame_recoveries", "vo_svo_create", "vo_svo_destroy", "vo_svo_track", "vo_svo_enqueue",
     "vo_svo_prefetch", "vo_svo_result", "vo_svo_get_tracks", "vo_svo_get_new_points", "vo_svo_keyframe_count", "vo_svo_get_keyframe", "vo_svo_get_keyframes", "vo_triangulate_dlt", "vo_batch_create", "vo_batch_destroy",
+    "vo_mvo_create", "vo_mvo_destroy", "vo_mvo_track", "vo_mvo_enqueue", "vo_mvo_prefetch", "vo_mvo_result", "vo_mvo_get_tracks",
+    "vo_mvo_keyframe_count", "vo_mvo_get_keyframes",
     "vo_batch_last_error", "vo_batch_run", "vo_debug_set", "vo_debug_allocation_count", "vo_svo_device_bytes",
     "vo_se3_exp", "vo_ids_reset", "vo_ids_peek", "vo_ids_new_frames", "vo_ids_new_landmarks", "vo_compact_tracks",
 ]
@@ -155,6 +176,16 @@ def load():
     lib.vo_svo_get_keyframe.argtypes = [vp, ci, vp, vp, ci, vp]
     lib.vo_svo_get_keyframes.argtypes = [vp, vp, vp, vp, C.c_size_t, vp]
     lib.vo_svo_device_bytes.argtypes = [vp, vp]
+    lib.vo_mvo_create.argtypes = [vp, C.POINTER(MvoParams), C.POINTER(C.c_void_p)]
+    lib.vo_mvo_destroy.argtypes = [vp]
+    lib.vo_mvo_destroy.restype = None
+    lib.vo_mvo_track.argtypes = [vp, vp, ci, ci, C.c_double, C.POINTER(MvoFrameInfo)]
+    lib.vo_mvo_enqueue.argtypes = [vp, vp, ci, ci, C.c_double]
+    lib.vo_mvo_prefetch.argtypes = [vp, vp, ci, ci]
+    lib.vo_mvo_result.argtypes = [vp, C.POINTER(MvoFrameInfo)]
+    lib.vo_mvo_get_tracks.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, vp]
+    lib.vo_mvo_keyframe_count.argtypes = [vp, vp]
+    lib.vo_mvo_get_keyframes.argtypes = [vp, vp, vp, vp, C.c_size_t, vp]
     lib.vo_debug_set.argtypes = [vp, ci, ci]
     lib.vo_debug_allocation_count.argtypes = [vp, vp]
     lib.vo_triangulate_dlt.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp]

@@ -16,8 +16,8 @@ import weakref
 import numpy as np
 
 from . import _capi
-from ._capi import (BinParams, FrameCounts, GnInfo, MonoCounts, MonoParams, OrbParams, SbaProblem, StereoParams,
-                    SvoFrameInfo, SvoParams, VoConfig, VoError)
+from ._capi import (FIVE_POINT_FN, BinParams, FrameCounts, GnInfo, MonoCounts, MonoParams, MvoFrameInfo, MvoParams, OrbParams,
+                    SbaProblem, StereoParams, SvoFrameInfo, SvoParams, VoConfig, VoError)
 
 KLT_USE_INITIAL_FLOW = 4
 GN_CORE, GN_STANDALONE = 0, 1
@@ -1223,3 +1223,134 @@ class SparseBundleAdjustmentSolver:
                                                   _p(obs_ptr, i32), _p(obs_frame, i32), _p(obs_right, C.c_uint8),
                                                   _p(obs_px, d), _p(err, d)))
         return bool(rc), T.reshape(-1, 4, 4), Xo, err[: int(MAX_ITER)]
+
+
+class MonoVO:
+    """MonoVO (core/visual_odometry/mono_vo/mono_vo.h:235-243, :267): trackImage(img, timestamp) / getStatistics(), the track
+    set, the keyframes and the mono local BA carried on the device (vo_mvo_*). `five_point(pts0, pts1) -> (ok, R10, t10,
+    mask)` stands for MotionEstimator::calcPose5PointsAlgorithm (OpenCV calib3d: the caller's; called for the second image
+    and whenever the pose-only BA yields no pose)."""
+
+    def __init__(self, ctx, width, height, K, n_bins_u, n_bins_v, five_point, thres_fastscore=15, window_size=15, max_level=5,
+                 thres_error=20.0, thres_bidirection=1.0, thres_poseba_error=5, thres_sampson=1.0, thres_parallax=1.0,
+                 thres_overlap_ratio=0.7, thres_rotation=3.0, thres_translation=3.0, n_max_keyframes_in_window=9, strict_border=1,
+                 local_ba=True, rectify=False):
+        self.ctx, self.lib = ctx, ctx.lib
+        fe = FeatureExtractor(ctx)
+        fe.initParams(width, height, n_bins_u, n_bins_v, THRES_FAST=thres_fastscore)
+        p = MvoParams()
+        p.frame = make_mono_params(width, height, window_size, max_level, thres_error, thres_bidirection, thres_poseba_error,
+                                   thres_sampson, K)
+        p.bins = fe.binParams()
+        p.kf_overlap_ratio, p.kf_rotation_deg, p.kf_translation = thres_overlap_ratio, thres_rotation, thres_translation
+        p.kf_window, p.thres_parallax_deg = n_max_keyframes_in_window, thres_parallax
+        p.strict_border, p.local_ba, p.rectify = int(strict_border), int(bool(local_ba)), int(bool(rectify))
+        self._user_hook = five_point
+
+        def _hook(user, p0, p1, n, Kp, R10, t10, mask):
+            a0 = np.ctypeslib.as_array(p0, shape=(max(n, 1), 2))[:n].copy()
+            a1 = np.ctypeslib.as_array(p1, shape=(max(n, 1), 2))[:n].copy()
+            try:
+                ok, R, t, m = self._user_hook(a0, a1)
+            except Exception:  # (an exception must not cross the C boundary: the call fails like the reference's throw)
+                return 0
+            if not ok:
+                return 0
+            np.ctypeslib.as_array(R10, shape=(9,))[:] = np.asarray(R, np.float32).reshape(9)
+            np.ctypeslib.as_array(t10, shape=(3,))[:] = np.asarray(t, np.float32).reshape(3)
+            if n:
+                np.ctypeslib.as_array(mask, shape=(n,))[:] = np.asarray(m, bool).astype(np.uint8)
+            return 1
+
+        self._cb = FIVE_POINT_FN(_hook)  # (kept alive with the object)
+        p.five_point = self._cb
+        p.five_point_user = None
+        self.prm, self.width, self.height = p, width, height
+        self._h = C.c_void_p()
+        ctx.check(self.lib.vo_mvo_create(ctx.handle, C.byref(p), C.byref(self._h)))
+        ctx._children.add(self)
+        self._info = MvoFrameInfo()
+        self.stats_frame = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.vo_mvo_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _ptr(img):
+        if isinstance(img, np.ndarray):
+            img = _u8(img)
+            if img.ndim != 2:
+                raise ValueError("the image must be one u8 plane")
+            return img, img.ctypes.data, img.strides[0], 0
+        return img, int(img[0]), int(img[1]), 1  # (device address, stride)
+
+    def _out(self):
+        self.stats_frame.append(np.array(self._info.T_wc, np.float32).reshape(4, 4))
+        return MvoFrameInfo.from_buffer_copy(self._info)
+
+    def trackImage(self, img, timestamp=0.0):
+        a, p, st, dev = self._ptr(img)
+        self._keep = a
+        rc = self.lib.vo_mvo_track(self._h, p, st, dev, float(timestamp), self._info)
+        if rc < 0:
+            self.ctx.check(rc)
+        return self._out()
+
+    def enqueue(self, img, timestamp=0.0):
+        a, p, st, dev = self._ptr(img)
+        self._keep = a
+        rc = self.lib.vo_mvo_enqueue(self._h, p, st, dev, float(timestamp))
+        if rc < 0:
+            self.ctx.check(rc)
+
+    def prefetch(self, img):
+        a, p, st, dev = self._ptr(img)
+        self._keep_next = a
+        rc = self.lib.vo_mvo_prefetch(self._h, p, st, dev)
+        if rc < 0:
+            self.ctx.check(rc)
+
+    def result(self):
+        rc = self.lib.vo_mvo_result(self._h, self._info)
+        if rc < 0:
+            self.ctx.check(rc)
+        return self._out()
+
+    def getTracks(self):
+        """frame_prev_'s related landmarks: dict(ids, pts, Xw, flags, age, cos_parallax)."""
+        n = C.c_int()
+        self.ctx.check(self.lib.vo_mvo_get_tracks(self._h, None, None, None, None, None, None, 0, C.addressof(n)))
+        m = max(n.value, 1)
+        ids, pts, X = np.zeros(m, np.int32), np.zeros((m, 2), np.float32), np.zeros((m, 3), np.float32)
+        fl, age, cp = np.zeros(m, np.uint8), np.zeros(m, np.int32), np.zeros(m, np.float32)
+        self.ctx.check(self.lib.vo_mvo_get_tracks(self._h, ids.ctypes.data, pts.ctypes.data, X.ctypes.data, fl.ctypes.data,
+                                                  age.ctypes.data, cp.ctypes.data, m, C.addressof(n)))
+        k = n.value
+        return dict(ids=ids[:k], pts=pts[:k], Xw=X[:k], flags=fl[:k], age=age[:k], cos_parallax=cp[:k])
+
+    def getKeyframes(self):
+        """stats_keyframe (mono_vo.cpp:1130-1155): [(T_wc, mappoints)] of every keyframe so far, current values."""
+        n, tot = C.c_int(), C.c_size_t()
+        self.ctx.check(self.lib.vo_mvo_keyframe_count(self._h, C.addressof(n)))
+        nk = n.value
+        if nk == 0:
+            return []
+        T, cnt = np.zeros((nk, 16), np.float32), np.zeros(nk, np.int32)
+        self.ctx.check(self.lib.vo_mvo_get_keyframes(self._h, T.ctypes.data, cnt.ctypes.data, None, 0, C.addressof(tot)))
+        X = np.zeros((max(tot.value, 1), 3), np.float32)
+        if tot.value:
+            self.ctx.check(self.lib.vo_mvo_get_keyframes(self._h, None, None, X.ctypes.data, tot.value, C.addressof(tot)))
+        off = np.concatenate([[0], np.cumsum(cnt)])
+        return [(T[j].reshape(4, 4).copy(), X[off[j]:off[j + 1]].copy()) for j in range(nk)]
+
+    def getStatistics(self):
+        """AlgorithmStatistics: stats_frame (pose per frame as it was when the frame returned)."""
+        return dict(stats_frame=list(self.stats_frame))

@@ -1,0 +1,1087 @@
+// mono_vo.hip — the closed loop of MonoVO::trackImage around the mono frame operator, track set on the device.
+//
+// Reference (paths relative to the reference repository root):
+//   core/visual_odometry/mono_vo/mono_vo.cpp:496-1194   trackImage
+//     :528-561    the first image: extract, one landmark per pixel, pose I, setPoseDiff10(T_init), T_init.t = (0, 0, -1)
+//     :562-696    the second image: FeatureTracker::track, 5-point pose (OpenCV calib3d: a CALLER HOOK), Sampson
+//                 gate, |dt10| = 1, new points back-tracked into I0, reconstruction of landmarks with enough parallax
+//     :698-1019   steady state                                      -> frame_mono.hip / gn_pose.hip (vo_mono_frame_*)
+//     :909-949    the 5-point fallback                              -> the same hook, host-driven operator calls
+//     :1022-1157  keyframe rule, addNewKeyframe, reconstruction of landmarks seen on more than two keyframes, local BA
+//   core/visual_odometry/landmark.cpp:76-135   addObservationAndRelatedFrame: age, parallax w.r.t. the oldest observation
+//   core/visual_odometry/keyframes.cpp:30-126  addNewKeyframe, checkUpdateRule
+//   core/visual_odometry/motion_estimator.cpp:1090-1205 + ba_solver/sparse_ba_parameters.h:292-466 (mono mode) +
+//   ba_solver/sparse_bundle_adjustment.cpp:624-722                   -> stereo_vo_lba.hip (one observation per keyframe) + sba.hip
+//
+// Data on the device. Two track sets (current / next), one entry per landmark of frame_prev_: the pixel seen, the id, the
+// world point, flags (triangulated | dead | member of the last keyframe | bundled), and what Landmark keeps for its own
+// decisions: the FIRST observation (pixel + frame), the age, the parallax of the newest observation (as its cosine: the
+// reference compares acosf(c) with a threshold — the host turns that threshold into the largest float c that passes
+// its own acosf, so the device never evaluates acosf), and the first observation on a keyframe + their number. A ring of
+// frame poses (T_wc and T_cw, 2^14 frames) serves "related_frames_.front()->getPoseInv()"; the poses of window keyframes
+// are refreshed in it after every local BA. `mvo_advance_kernel` builds the next set behind every frame (survivors in index
+// order, then the new landmarks), `mvo_keyframe_kernel` does addNewKeyframe + reconstruction, the landmark table / keyframe
+// ring / local BA are stereo_vo_lba.hip's in mono mode. The host chains the pose, applies the keyframe rule and calls
+// the hook.
+#include "frame_state.hpp"
+#include "vo_kernels.hpp"
+
+#include <math.h>
+#include <sched.h>
+#include <stdlib.h>
+#include <time.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "stereo_vo.hpp"
+
+#define RC(x)                \
+  do {                       \
+    int _rc = (x);           \
+    if (_rc < 0) return _rc; \
+  } while (0)
+
+#define MVO_FRAME_RING (1 << 14)
+#define MVO_COS_NONE 2.0f  // no parallax yet (last_parallax_ = 0): never passes the threshold
+
+struct MvoSet {
+  SvoTrackSet t;     // pts_l = pts_r = the pixel seen; Xw; flags; ids (what stereo_vo_lba.hip reads)
+  float *p_first;    // [cap][2] observations_.front()
+  int32_t *f_first;  // [cap]    index of related_frames_.front()
+  int32_t *age;      // [cap]
+  float *cos_last;   // [cap]    cos of last_parallax_ (MVO_COS_NONE: none)
+  int32_t *n_kf;     // [cap]    observations_on_keyframes_.size()
+  float *p_kf_first; // [cap][2] observations_on_keyframes_.front()
+  int32_t *kf_first; // [cap]    frame index of related_keyframes_.front()
+};
+struct MvoHdr {
+  int n_surv, n_new, n_next, n_kf_tracked, id_min, overflow, n_recon, pad;
+  uint32_t seq;
+};
+
+// Matrix4f * Matrix4f in Eigen's evaluation order (as svo_mul44), rows 0..2 only
+__device__ __forceinline__ void mvo_mul34(const float *A, const float *B, float (&C)[12]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float r = A[i * 4 + 0] * B[0 * 4 + j];
+#pragma unroll
+      for (int k = 1; k < 4; ++k) r = A[i * 4 + k] * B[k * 4 + j] + r;
+      C[i * 4 + j] = r;
+    }
+}
+__device__ __forceinline__ float mvo_dot3(float a0, float b0, float a1, float b1, float a2, float b2) { return a0 * b0 + (a1 * b1 + a2 * b2); }
+
+// landmark.cpp:100-116: cos of the parallax between the oldest observation p0 (frame of inverse pose Tcw0) and the newest p1
+// (frame of pose Twc1), pushed inside (-1, 1)
+__device__ __forceinline__ float mvo_parallax_cos(float p0x, float p0y, float p1x, float p1y, const float K[4], const float *Tcw0,
+                                                  const float *Twc1) {
+  float T01[12];
+  mvo_mul34(Tcw0, Twc1, T01);
+  const float fxinv = 1.0f / K[0], fyinv = 1.0f / K[1];
+  const float x0[3] = {(p0x - K[2]) * fxinv, (p0y - K[3]) * fyinv, 1.0f};
+  const float x1[3] = {(p1x - K[2]) * fxinv, (p1y - K[3]) * fyinv, 1.0f};
+  float r[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) r[i] = mvo_dot3(T01[i * 4 + 0], x1[0], T01[i * 4 + 1], x1[1], T01[i * 4 + 2], x1[2]);
+  const float dot = mvo_dot3(x0[0], r[0], x0[1], r[1], x0[2], r[2]);
+  const float n0 = sqrtf(mvo_dot3(x0[0], x0[0], x0[1], x0[1], x0[2], x0[2]));
+  const float n1 = sqrtf(mvo_dot3(r[0], r[0], r[1], r[1], r[2], r[2]));
+  float c = dot / (n0 * n1);
+  if (c >= 1.0f) c = 0.99999f;
+  if (c <= -1.0f) c = -0.99999f;
+  return c;
+}
+
+// mapping::triangulateDLT for one camera with T10 = T1w * Tw0 (mono_vo.cpp:672-678, :1046-1052); true + Xworld = Tw0 * X0 when
+// the landmark is reconstructed (keyframe_rule: both reprojections within 1 px and both depths positive, :1054-1073;
+// otherwise X0(2) > 0, :680)
+__device__ bool mvo_reconstruct(float p0x, float p0y, float p1x, float p1y, const float *Tw0, const float *T1w, const float K[4],
+                                bool keyframe_rule, float (&Xw)[3]) {
+  float T10[12];
+  mvo_mul34(T1w, Tw0, T10);
+  SvoCam cam;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) cam.R10[i * 3 + j] = T10[i * 4 + j];
+    cam.t10[i] = T10[i * 4 + 3];
+  }
+  const float Km[9] = {K[0], 0.0f, K[2], 0.0f, K[1], K[3], 0.0f, 0.0f, 1.0f};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      cam.P10[i * 4 + j] = mvo_dot3(Km[i * 3 + 0], cam.R10[0 * 3 + j], Km[i * 3 + 1], cam.R10[1 * 3 + j], Km[i * 3 + 2], cam.R10[2 * 3 + j]);
+    cam.P10[i * 4 + 3] = mvo_dot3(Km[i * 3 + 0], cam.t10[0], Km[i * 3 + 1], cam.t10[1], Km[i * 3 + 2], cam.t10[2]);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) cam.K0[k] = cam.K1[k] = K[k];
+  float X0[3], X1[3];
+  svo_triangulate(cam, p0x, p0y, p1x, p1y, X0, X1);
+  if (keyframe_rule) {
+    float iz = 1.0f / X0[2];
+    float dx = p0x - (K[0] * X0[0] * iz + K[2]), dy = p0y - (K[1] * X0[1] * iz + K[3]);
+    if (dx * dx + dy * dy > 1.0f) return false;
+    iz = 1.0f / X1[2];
+    dx = p1x - (K[0] * X1[0] * iz + K[2]);
+    dy = p1y - (K[1] * X1[1] * iz + K[3]);
+    if (dx * dx + dy * dy > 1.0f) return false;
+    if (!(X0[2] > 0 && X1[2] > 0)) return false;
+  } else if (!(X0[2] > 0)) {
+    return false;
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) Xw[r] = (Tw0[r * 4 + 0] * X0[0] + (Tw0[r * 4 + 1] * X0[1] + Tw0[r * 4 + 2] * X0[2])) + Tw0[r * 4 + 3];
+  return true;
+}
+
+// exclusive scan of one int per thread over a workgroup of 1024; every thread gets the total
+__device__ __forceinline__ int mvo_block_scan(int v, int *s_w, int &total) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(inc, off);
+    if (lane >= off) inc += t;
+  }
+  __syncthreads();
+  if (lane == 63) s_w[wave] = inc;
+  __syncthreads();
+  int before = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int c = s_w[k];
+    before += k < wave ? c : 0;
+    tot += c;
+  }
+  total = tot;
+  return before + inc - v;
+}
+
+// ---- the next track set: lmtrack_final in index order (addObservationAndRelatedFrame for each: age, parallax), then the new
+// landmarks Landmark(p0_new, frame_prev_) + observation (p1_new, frame_curr) (mono_vo.cpp:964-1018) ----------------------
+struct MvoAdvArgs {
+  MvoSet cur, nxt;
+  int n, cap;
+  const uint8_t *stage;    // [n] 4 = in lmtrack_final
+  const float *pts1;       // [n][2] pixel in the current image
+  const float *cand1, *cand0;  // new points: pixel in I1, back-tracked pixel in I0
+  const uint8_t *mnew;
+  int m;                   // candidates emitted
+  int id_base, f;          // first new landmark id, index of the current frame
+  float K[4];
+  float T_obs[16];         // pose of the current frame as the survivors' observation sees it (identity at initialisation)
+  float T_wc[16], T_cw[16];  // pose of the current frame (what the new landmarks see, and the frame table's entry f)
+  float *frameT;           // [ring][32]
+  MvoHdr *hdr_dev, *hdr_host;
+  uint32_t seq;
+};
+__global__ __launch_bounds__(1024) void mvo_advance_kernel(MvoAdvArgs a) {
+  __shared__ int s_w[16];
+  __shared__ int s_kft[16];
+  const int tid = threadIdx.x;
+  if (tid < 16) {  // the frame table's entry of this frame (T_wc | T_cw)
+    a.frameT[(size_t)(a.f & (MVO_FRAME_RING - 1)) * 32 + tid] = a.T_wc[tid];
+    a.frameT[(size_t)(a.f & (MVO_FRAME_RING - 1)) * 32 + 16 + tid] = a.T_cw[tid];
+  }
+  int base = 0, kft = 0;
+  for (int c0 = 0; c0 < a.n; c0 += 1024) {
+    const int k = c0 + tid;
+    const int ok = (k < a.n && a.stage[k] == 4) ? 1 : 0;
+    int total;
+    const int pos = base + mvo_block_scan(ok, s_w, total);
+    if (ok && pos < a.cap) {
+      const float px = a.pts1[2 * k], py = a.pts1[2 * k + 1];
+      a.nxt.t.pts_l[2 * pos] = px;
+      a.nxt.t.pts_l[2 * pos + 1] = py;
+      a.nxt.t.ids[pos] = a.cur.t.ids[k];
+      const uint8_t fl = a.cur.t.flags[k];
+      a.nxt.t.flags[pos] = fl;
+      kft += (fl & VO_LM_KF_MEMBER) ? 1 : 0;
+      a.nxt.t.Xw[3 * pos] = a.cur.t.Xw[3 * k];
+      a.nxt.t.Xw[3 * pos + 1] = a.cur.t.Xw[3 * k + 1];
+      a.nxt.t.Xw[3 * pos + 2] = a.cur.t.Xw[3 * k + 2];
+      const float p0x = a.cur.p_first[2 * k], p0y = a.cur.p_first[2 * k + 1];
+      const int f0 = a.cur.f_first[k];
+      a.nxt.p_first[2 * pos] = p0x;
+      a.nxt.p_first[2 * pos + 1] = p0y;
+      a.nxt.f_first[pos] = f0;
+      a.nxt.age[pos] = a.cur.age[k] + 1;
+      a.nxt.n_kf[pos] = a.cur.n_kf[k];
+      a.nxt.p_kf_first[2 * pos] = a.cur.p_kf_first[2 * k];
+      a.nxt.p_kf_first[2 * pos + 1] = a.cur.p_kf_first[2 * k + 1];
+      a.nxt.kf_first[pos] = a.cur.kf_first[k];
+      // (f0 < f: that entry of the frame table was written by an earlier launch)
+      a.nxt.cos_last[pos] = mvo_parallax_cos(p0x, p0y, px, py, a.K, a.frameT + (size_t)(f0 & (MVO_FRAME_RING - 1)) * 32 + 16, a.T_obs);
+    }
+    base += total;
+  }
+  const int n_surv = base;
+  for (int c0 = 0; c0 < a.m; c0 += 1024) {
+    const int j = c0 + tid;
+    const int ok = (j < a.m && a.mnew[j]) ? 1 : 0;
+    int total;
+    const int r = base + mvo_block_scan(ok, s_w, total);
+    if (ok && r < a.cap) {
+      const float p0x = a.cand0[2 * j], p0y = a.cand0[2 * j + 1], p1x = a.cand1[2 * j], p1y = a.cand1[2 * j + 1];
+      a.nxt.t.pts_l[2 * r] = p1x;
+      a.nxt.t.pts_l[2 * r + 1] = p1y;
+      a.nxt.t.ids[r] = a.id_base + (r - n_surv);
+      a.nxt.t.flags[r] = 0;
+      a.nxt.t.Xw[3 * r] = a.nxt.t.Xw[3 * r + 1] = a.nxt.t.Xw[3 * r + 2] = 0.0f;
+      a.nxt.p_first[2 * r] = p0x;
+      a.nxt.p_first[2 * r + 1] = p0y;
+      a.nxt.f_first[r] = a.f - 1;
+      a.nxt.age[r] = 2;
+      a.nxt.n_kf[r] = 0;
+      a.nxt.p_kf_first[2 * r] = a.nxt.p_kf_first[2 * r + 1] = 0.0f;
+      a.nxt.kf_first[r] = -1;
+      a.nxt.cos_last[r] = mvo_parallax_cos(p0x, p0y, p1x, p1y, a.K, a.frameT + (size_t)((a.f - 1) & (MVO_FRAME_RING - 1)) * 32 + 16, a.T_wc);
+    }
+    base += total;
+  }
+  // members of the last keyframe among the survivors (numerator of the tracking ratio, keyframes.cpp:62-76)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) kft += __shfl_down(kft, off);
+  __syncthreads();
+  if ((tid & 63) == 0) s_kft[tid >> 6] = kft;
+  __syncthreads();
+  if (tid == 0) {
+    int t = 0;
+    for (int k = 0; k < 16; ++k) t += s_kft[k];
+    MvoHdr h;
+    h.n_surv = n_surv;
+    h.n_new = base - n_surv;
+    h.n_next = base < a.cap ? base : a.cap;
+    h.n_kf_tracked = t;
+    h.overflow = base > a.cap ? 1 : 0;
+    h.n_recon = 0;
+    h.pad = 0;
+    h.seq = 0;
+    h.id_min = a.id_base;
+    *a.hdr_dev = h;
+    *a.hdr_host = h;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) {
+    if (base > 0) {
+      const int id0 = a.nxt.t.ids[0];  // (another thread's store, behind the barrier)
+      a.hdr_dev->id_min = id0;
+      a.hdr_host->id_min = id0;
+      __threadfence_system();
+    }
+    __hip_atomic_store(&a.hdr_host->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// reconstruction at the initialisation (mono_vo.cpp:660-687): every landmark of lmtrack_final that is not triangulated and
+// whose newest observation has enough parallax — from its first and last observation and their frames' poses
+struct MvoRecArgs {
+  MvoSet s;
+  int n, f;
+  float K[4], T_cw[16], cos_thres;
+  const float *frameT;
+  int *n_recon;
+};
+__global__ void mvo_init_reconstruct_kernel(MvoRecArgs a) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= a.n) return;
+  const uint8_t fl = a.s.t.flags[k];
+  if ((fl & VO_LM_TRIANGULATED) || !(a.s.cos_last[k] <= a.cos_thres)) return;
+  float Xw[3];
+  const float *Tw0 = a.frameT + (size_t)(a.s.f_first[k] & (MVO_FRAME_RING - 1)) * 32;
+  if (mvo_reconstruct(a.s.p_first[2 * k], a.s.p_first[2 * k + 1], a.s.t.pts_l[2 * k], a.s.t.pts_l[2 * k + 1], Tw0, a.T_cw, a.K, false, Xw)) {
+    a.s.t.Xw[3 * k] = Xw[0];
+    a.s.t.Xw[3 * k + 1] = Xw[1];
+    a.s.t.Xw[3 * k + 2] = Xw[2];
+    a.s.t.flags[k] = fl | VO_LM_TRIANGULATED;
+    if (a.n_recon) atomicAdd(a.n_recon, 1);
+  }
+}
+
+// a new keyframe (keyframes.cpp:30-45 addNewKeyframe: every related landmark gets the observation on it; mono_vo.cpp:
+// 1032-1076: landmarks that are alive, not triangulated, with enough parallax and seen on MORE than two keyframes are
+// reconstructed from their first and last keyframe observation)
+__global__ void mvo_keyframe_kernel(MvoRecArgs a) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= a.n) return;
+  uint8_t fl = a.s.t.flags[k] | VO_LM_KF_MEMBER;
+  const int nk = a.s.n_kf[k] + 1;
+  a.s.n_kf[k] = nk;
+  const float px = a.s.t.pts_l[2 * k], py = a.s.t.pts_l[2 * k + 1];
+  float p0x = a.s.p_kf_first[2 * k], p0y = a.s.p_kf_first[2 * k + 1];
+  int f0 = a.s.kf_first[k];
+  if (nk == 1) {
+    a.s.p_kf_first[2 * k] = p0x = px;
+    a.s.p_kf_first[2 * k + 1] = p0y = py;
+    a.s.kf_first[k] = f0 = a.f;
+  }
+  if (!(fl & VO_LM_DROPPED) && !(fl & VO_LM_TRIANGULATED) && a.s.cos_last[k] <= a.cos_thres && nk > 2) {
+    float Xw[3];
+    // (the first keyframe's CURRENT pose: the local BA may have moved it; frameT is refreshed after every solve)
+    const float *Tw0 = a.frameT + (size_t)(f0 & (MVO_FRAME_RING - 1)) * 32;
+    if (mvo_reconstruct(p0x, p0y, px, py, Tw0, a.T_cw, a.K, true, Xw)) {
+      a.s.t.Xw[3 * k] = Xw[0];
+      a.s.t.Xw[3 * k + 1] = Xw[1];
+      a.s.t.Xw[3 * k + 2] = Xw[2];
+      fl |= VO_LM_TRIANGULATED;
+      if (a.n_recon) atomicAdd(a.n_recon, 1);
+    }
+  }
+  a.s.t.flags[k] = fl;
+}
+
+// what the next frame's operator reads per landmark (vo_mono_frame_enqueue): bit 0 isBundled(), bit 1 member of the class
+// the pose-only BA takes (bundled with more than five window keyframes, triangulated otherwise: mono_vo.cpp:800-826), bit
+// 2 dead (LandmarkTracking's isAlive() filter, landmark.cpp:251)
+__global__ void mvo_opflags_kernel(const uint8_t *flags, int n, int many_keyframes, uint8_t *op) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const uint8_t fl = flags[k];
+  uint8_t o = (fl & VO_LM_BUNDLED) ? 1 : 0;
+  if (fl & (many_keyframes ? VO_LM_BUNDLED : VO_LM_TRIANGULATED)) o |= 2;
+  if (fl & VO_LM_DROPPED) o |= 4;
+  op[k] = o;
+}
+
+// the local BA moved keyframes: their entries of the frame table
+struct MvoPoseArgs {
+  int n, f[16];
+  float T[16][32];
+};
+__global__ void mvo_pose_put_kernel(MvoPoseArgs a, float *frameT) {
+  const int j = blockIdx.x, t = threadIdx.x;
+  if (j < a.n && t < 32) frameT[(size_t)(a.f[j] & (MVO_FRAME_RING - 1)) * 32 + t] = a.T[j][t];
+}
+
+// ---- host -------------------------------------------------------------------------------------------------------------
+struct vo_mvo {
+  vo_ctx *c = nullptr;
+  vo_mvo_params prm;
+  int cap = 0;
+  vo_svo core;  // keyframe window, landmark table, keyframe ring, local BA (stereo_vo_lba.hip in mono mode)
+  MvoSet ts[2] = {};
+  int cur = 0, n = 0;
+  uint8_t *d_op = nullptr;
+  float *d_frameT = nullptr;
+  MvoHdr *d_hdr = nullptr, *h_hdr = nullptr;
+  uint32_t seq = 0;
+  int *d_nrec = nullptr;
+  // uploads of the host-driven paths (initialisation, 5-point fallback)
+  uint8_t *d_stage = nullptr, *d_mnew = nullptr;
+  float *d_pts1 = nullptr, *d_cand1 = nullptr, *d_cand0 = nullptr;
+  bool got_first = false, init_done = false, pending = false, prefetched = false;
+  const void *pre = nullptr;
+  int pend_kind = 0;  // 0 first image, 1 initialisation, 2 steady state
+  int slot[3] = {0, 1, 2};  // previous, current, next
+  int tab_cur = 0, tab_next = 0;
+  int f = -1;        // index of the current frame (0, 1, ...) — Frame ids come from the context's counter
+  int frame_id = 0;
+  float T_wp[16], dT01[16];  // frame_prev_: pose, getPoseDiff01()
+  std::vector<int> kf_frame;  // frame index of every window keyframe (parallel to core.keyframes)
+  float cos_thres = -2.0f;
+  vo_mvo_frame_info info;
+};
+
+extern void svo_mul44(const float A[16], const float B[16], float C[16]);
+extern void svo_inv_se3(const float T[16], float Ti[16]);
+
+static void mvo_eye(float T[16]) {
+  for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+}
+static inline float dot3e(float a0, float b0, float a1, float b1, float a2, float b2) { return a0 * b0 + (a1 * b1 + a2 * b2); }
+// F10 = Kinv^T [t10]x R10 Kinv (motion_estimator.cpp:551-552), Eigen's product order (as mono_gate.hpp)
+static void mvo_fundamental(const float K[4], const float R10[9], const float t10[3], float F[9]) {
+  const float fxi = 1.0f / K[0], fyi = 1.0f / K[1];
+  const float Kinv[9] = {fxi, 0.0f, -K[2] * fxi, 0.0f, fyi, -K[3] * fyi, 0.0f, 0.0f, 1.0f};
+  const float KinvT[9] = {Kinv[0], Kinv[3], Kinv[6], Kinv[1], Kinv[4], Kinv[7], Kinv[2], Kinv[5], Kinv[8]};
+  const float Sx[9] = {0.0f, -t10[2], t10[1], t10[2], 0.0f, -t10[0], -t10[1], t10[0], 0.0f};
+  float E[9], T[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) E[i * 3 + j] = dot3e(Sx[i * 3 + 0], R10[0 * 3 + j], Sx[i * 3 + 1], R10[1 * 3 + j], Sx[i * 3 + 2], R10[2 * 3 + j]);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) T[i * 3 + j] = dot3e(KinvT[i * 3 + 0], E[0 * 3 + j], KinvT[i * 3 + 1], E[1 * 3 + j], KinvT[i * 3 + 2], E[2 * 3 + j]);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) F[i * 3 + j] = dot3e(T[i * 3 + 0], Kinv[0 * 3 + j], T[i * 3 + 1], Kinv[1 * 3 + j], T[i * 3 + 2], Kinv[2 * 3 + j]);
+}
+// the largest float c with acosf(c) >= thres (this host's acosf, the one the reference's comparison would use): the device
+// compares cosines. acosf falls monotonically, so a bisection over the ordered float patterns finds it.
+static float mvo_cos_threshold(float thres) {
+  if (!(thres > 0.0f)) return 1.0f;
+  auto key = [](float v) {
+    int32_t b;
+    memcpy(&b, &v, 4);
+    return b < 0 ? (int64_t)INT32_MIN - (int64_t)b : (int64_t)b;  // monotone in v
+  };
+  auto unkey = [](int64_t k) {
+    int32_t b = k < 0 ? (int32_t)((int64_t)INT32_MIN - k) : (int32_t)k;
+    float v;
+    memcpy(&v, &b, 4);
+    return v;
+  };
+  int64_t lo = key(-1.0f), hi = key(1.0f);  // acosf(lo) = pi >= thres (thres <= pi), acosf(hi) = 0 < thres
+  if (!(acosf(-1.0f) >= thres)) return -2.0f;
+  while (hi - lo > 1) {
+    const int64_t mid = lo + (hi - lo) / 2;
+    if (acosf(unkey(mid)) >= thres)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return unkey(lo);
+}
+
+static int mvo_alloc_set(vo_ctx *c, MvoSet *t, int cap) {
+  const size_t n = (size_t)cap;
+  VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&t->t.pts_l, sizeof(float) * 2 * n));
+  t->t.pts_r = t->t.pts_l;
+  VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&t->t.Xw, sizeof(float) * 3 * n));
+  VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&t->t.flags, n));
+  VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&t->t.ids, sizeof(int32_t) * n));
+  VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&t->p_first, sizeof(float) * 2 * n));
+  VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&t->f_first, sizeof(int32_t) * n));
+  VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&t->age, sizeof(int32_t) * n));
+  VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&t->cos_last, sizeof(float) * n));
+  VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&t->n_kf, sizeof(int32_t) * n));
+  VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&t->p_kf_first, sizeof(float) * 2 * n));
+  VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&t->kf_first, sizeof(int32_t) * n));
+  return VO_OK;
+}
+static void mvo_free_set(MvoSet *t) {
+  void *b[] = {t->t.pts_l, t->t.Xw, t->t.flags, t->t.ids, t->p_first, t->f_first, t->age, t->cos_last, t->n_kf, t->p_kf_first, t->kf_first};
+  for (void *p : b)
+    if (p) (void)hipFree(p);
+  memset(t, 0, sizeof(*t));
+}
+
+extern "C" void vo_mvo_destroy(vo_mvo *s) {
+  if (!s) return;
+  if (s->c) (void)hipSetDevice(s->c->device);
+  if (s->c) (void)hipStreamSynchronize(s->c->stream);
+  for (int k = 0; k < 2; ++k) mvo_free_set(&s->ts[k]);
+  void *b[] = {s->d_op, s->d_frameT, s->d_hdr, s->d_nrec, s->d_stage, s->d_mnew, s->d_pts1, s->d_cand1, s->d_cand0};
+  for (void *p : b)
+    if (p) (void)hipFree(p);
+  if (s->h_hdr) (void)hipHostFree(s->h_hdr);
+  vo_svo_lba_free(&s->core);
+  delete s;
+}
+
+extern "C" int vo_mvo_create(vo_ctx *c, const vo_mvo_params *prm, vo_mvo **out) {
+  if (!c || !prm || !out) return VO_ERR_INVALID;
+  *out = nullptr;
+  if (c->cfg.n_slots < 3) VO_FAIL(c, VO_ERR_INVALID, "MonoVO needs a context with at least 3 image slots");
+  if (!prm->five_point) VO_FAIL(c, VO_ERR_INVALID, "MonoVO needs the 5-point pose hook (calcPose5PointsAlgorithm is the caller's)");
+  const int w = prm->frame.win;
+  if (w != 13 && w != 15 && w != 21 && w != 31) VO_FAIL(c, VO_ERR_INVALID, "MonoVO needs a window the mono frame kernel is built for (13, 15, 21, 31)");
+  const int bins = prm->bins.n_bins_u * prm->bins.n_bins_v;
+  if (bins <= 0 || bins > c->cfg.max_points) VO_FAIL(c, VO_ERR_CAPACITY, "%d bins exceed vo_config.max_points=%d", bins, c->cfg.max_points);
+  if (prm->kf_window < 1) VO_FAIL(c, VO_ERR_INVALID, "kf_window must be at least 1");
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  vo_mvo *s = new vo_mvo();
+  s->c = c;
+  s->prm = *prm;
+  s->cap = c->cfg.max_points;
+  memset(&s->info, 0, sizeof(s->info));
+  int rc = VO_OK;
+  for (int k = 0; k < 2 && rc == VO_OK; ++k) rc = mvo_alloc_set(c, &s->ts[k], s->cap);
+  auto dm = [&](void **p, size_t bytes) {
+    if (rc == VO_OK && vo_dev_malloc(c, p, bytes) != hipSuccess) rc = VO_ERR_HIP;
+  };
+  dm((void **)&s->d_op, (size_t)s->cap);
+  dm((void **)&s->d_frameT, sizeof(float) * 32 * (size_t)MVO_FRAME_RING);
+  dm((void **)&s->d_hdr, sizeof(MvoHdr));
+  dm((void **)&s->d_nrec, 64);
+  dm((void **)&s->d_stage, (size_t)s->cap);
+  dm((void **)&s->d_mnew, (size_t)s->cap);
+  dm((void **)&s->d_pts1, sizeof(float) * 2 * (size_t)s->cap);
+  dm((void **)&s->d_cand1, sizeof(float) * 2 * (size_t)s->cap);
+  dm((void **)&s->d_cand0, sizeof(float) * 2 * (size_t)s->cap);
+  if (rc == VO_OK && vo_host_malloc(c, (void **)&s->h_hdr, sizeof(MvoHdr), hipHostMallocDefault) != hipSuccess) rc = VO_ERR_HIP;
+  if (rc == VO_OK) {
+    memset(s->h_hdr, 0, sizeof(MvoHdr));
+    // the keyframe storage: a vo_svo in mono mode (one observation per keyframe entry, bundled flags)
+    vo_svo &k = s->core;
+    k.c = c;
+    memset(&k.prm, 0, sizeof(k.prm));
+    k.prm.kf_window = prm->kf_window;
+    k.prm.local_ba = prm->local_ba;
+    for (int i = 0; i < 4; ++i) k.prm.frame.Kl[i] = k.prm.frame.Kr[i] = prm->frame.K[i];
+    mvo_eye(k.prm.frame.T_lr);
+    k.cap = s->cap;
+    k.mono = 1;
+    k.ts[0] = s->ts[0].t;
+    k.ts[1] = s->ts[1].t;
+    rc = vo_svo_lba_init(&k);
+  }
+  if (rc >= 0) rc = vo_stereo_frame_set_strict_border(c, prm->strict_border ? (prm->strict_border == 2 ? 2 : 1) : 0);
+  if (rc >= 0) rc = vo_set_pyramid_window_hint(c, prm->frame.win);
+  if (rc >= 0) rc = vo_set_ingest_side_stream(c, 1);
+  if (rc < 0) {
+    if (rc == VO_ERR_HIP && !c->err[0]) snprintf(c->err, sizeof(c->err), "MonoVO: device allocation failed");
+    vo_mvo_destroy(s);
+    return rc;
+  }
+  mvo_eye(s->T_wp);
+  mvo_eye(s->dT01);
+  const float thres = prm->thres_parallax_deg * (float)(3.14159265358979323846 / 180.0);  // map_update.thres_parallax * D2R
+  s->cos_thres = mvo_cos_threshold(thres);
+  *out = s;
+  return VO_OK;
+}
+
+static int mvo_ingest(vo_mvo *s, const void *img, int stride, int on_device) {
+  vo_ctx *c = s->c;
+  const int W = s->prm.frame.width, H = s->prm.frame.height, slot = s->slot[2];
+  if (s->prm.rectify) {  // flagDoUndistortion (mono_vo.cpp:509-513): undistortImage + convertTo(CV_8UC1), fused into the pyramid build
+    if (on_device)
+      RC(vo_set_image_rectified_device(c, slot, img, W, H, stride, 0));
+    else
+      RC(vo_set_image_rectified(c, slot, (const uint8_t *)img, W, H, stride, 0));
+  } else if (on_device) {
+    RC(vo_set_image_device(c, slot, img, W, H, stride));
+  } else {
+    RC(vo_set_image(c, slot, (const uint8_t *)img, W, H, stride));
+  }
+  RC(vo_new_point_candidates_enqueue(c, slot, &s->prm.bins, s->tab_next));
+  return VO_OK;
+}
+
+extern "C" int vo_mvo_prefetch(vo_mvo *s, const void *img, int stride, int on_device) {
+  if (!s || !img) return VO_ERR_INVALID;
+  VO_CHECK_HIP(s->c, hipSetDevice(s->c->device));
+  RC(mvo_ingest(s, img, stride, on_device));
+  s->pre = img;
+  s->prefetched = true;
+  return VO_OK;
+}
+
+// wait for the advance kernel's counts (pinned block, sequence word last)
+static int mvo_wait_hdr(vo_mvo *s) {
+  vo_ctx *c = s->c;
+  volatile const uint32_t *seqp = &s->h_hdr->seq;
+  timespec p0;
+  clock_gettime(CLOCK_MONOTONIC, &p0);
+  for (int spin = 0;; ++spin) {
+    if (*seqp == s->seq) break;
+    if ((spin & 255) == 255) {
+      timespec p1;
+      clock_gettime(CLOCK_MONOTONIC, &p1);
+      if ((p1.tv_sec - p0.tv_sec) * 1e9 + (p1.tv_nsec - p0.tv_nsec) > 2e7) {
+        VO_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+        break;
+      }
+    }
+    if (c->dbg[VO_OPT_POLL_YIELD]) sched_yield();
+#if defined(__x86_64__)
+    else __builtin_ia32_pause();
+#endif
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  return VO_OK;
+}
+
+// the next track set behind a frame; stage / pts1 / new points are DEVICE arrays. T_obs: what the survivors' observation
+// sees as the frame's pose. Leaves cur / n on the new set and the counts in *h.
+static int mvo_advance(vo_mvo *s, const uint8_t *stage, const float *pts1, const float *cand1, const float *cand0, const uint8_t *mnew,
+                       int m, const float T_obs[16], const float T_wc[16], MvoHdr *h) {
+  vo_ctx *c = s->c;
+  MvoAdvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.cur = s->ts[s->cur];
+  a.nxt = s->ts[s->cur ^ 1];
+  a.n = s->n;
+  a.cap = s->cap;
+  a.stage = stage;
+  a.pts1 = pts1;
+  a.cand1 = cand1;
+  a.cand0 = cand0;
+  a.mnew = mnew;
+  a.m = m;
+  a.id_base = c->next_landmark_id;
+  a.f = s->f;
+  memcpy(a.K, s->prm.frame.K, sizeof(a.K));
+  memcpy(a.T_obs, T_obs, sizeof(a.T_obs));
+  memcpy(a.T_wc, T_wc, sizeof(a.T_wc));
+  svo_inv_se3(T_wc, a.T_cw);
+  a.frameT = s->d_frameT;
+  a.hdr_dev = s->d_hdr;
+  a.hdr_host = s->h_hdr;
+  s->seq = s->seq + 1 == 0 ? 1 : s->seq + 1;
+  a.seq = s->seq;
+  hipLaunchKernelGGL(mvo_advance_kernel, dim3(1), dim3(1024), 0, c->stream, a);
+  VO_CHECK_HIP(c, hipGetLastError());
+  RC(mvo_wait_hdr(s));
+  *h = *s->h_hdr;
+  if (h->overflow) VO_FAIL(c, VO_ERR_CAPACITY, "the next track set exceeds vo_config.max_points=%d", s->cap);
+  c->next_landmark_id += h->n_new;
+  s->cur ^= 1;
+  s->n = h->n_next;
+  return VO_OK;
+}
+
+// Keyframes::checkUpdateRule, keyframes.cpp:47-126
+static bool mvo_keyframe_rule(const vo_mvo *s, int n_tracked, const float T_wc[16]) {
+  const vo_svo &k = s->core;
+  if (k.keyframes.empty()) return true;
+  const float ratio = (float)n_tracked / (float)k.n_kf_lms;
+  if (ratio <= s->prm.kf_overlap_ratio) return true;
+  float T_kw[16], dT[16];
+  svo_inv_se3(k.keyframes.back().T_wc, T_kw);
+  svo_mul44(T_kw, T_wc, dT);
+  float costheta = (((dT[0] + dT[5]) + dT[10]) - 1.0f) * 0.5f;
+  if (costheta >= 0.999999f) costheta = 0.999999f;
+  if (costheta <= -0.999999f) costheta = -0.999999f;
+  const float rot = acosf(costheta);
+  const float dtrans = sqrtf(dT[3] * dT[3] + (dT[7] * dT[7] + dT[11] * dT[11]));
+  const float kf_rot = s->prm.kf_rotation_deg * (float)(3.14159265358979323846 / 180.0);
+  return rot >= kf_rot || dtrans >= s->prm.kf_translation;
+}
+
+// the end of trackImage (mono_vo.cpp:1021-1163): keyframe rule, keyframe work, frame_prev_ <- frame_curr
+static int mvo_finish_frame(vo_mvo *s, const MvoHdr &h, float T_wc[16], vo_mvo_frame_info *I) {
+  vo_ctx *c = s->c;
+  vo_svo &k = s->core;
+  hipStream_t st = c->stream;
+  const int n = s->n;
+  I->n_kf_tracked = h.n_kf_tracked;
+  if (mvo_keyframe_rule(s, h.n_kf_tracked, T_wc)) {
+    I->is_keyframe = 1;
+    MvoRecArgs a;
+    memset(&a, 0, sizeof(a));
+    a.s = s->ts[s->cur];
+    a.n = n;
+    a.f = s->f;
+    memcpy(a.K, s->prm.frame.K, sizeof(a.K));
+    svo_inv_se3(T_wc, a.T_cw);
+    a.cos_thres = s->cos_thres;
+    a.frameT = s->d_frameT;
+    a.n_recon = nullptr;
+    if (n > 0) {
+      hipLaunchKernelGGL(mvo_keyframe_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a);
+      VO_CHECK_HIP(c, hipGetLastError());
+    }
+    SvoKeyframe kf;
+    kf.serial = k.n_keyframes++;
+    kf.frame_id = s->frame_id;
+    memcpy(kf.T_wc, T_wc, sizeof(kf.T_wc));
+    if ((int)k.keyframes.size() == s->prm.kf_window) {
+      k.keyframes.erase(k.keyframes.begin());
+      s->kf_frame.erase(s->kf_frame.begin());
+    }
+    k.keyframes.push_back(kf);
+    s->kf_frame.push_back(s->f);
+    k.n_kf_lms = n;
+    k.cur = s->cur;
+    k.n = n;
+    vo_svo_frame_info li;
+    memset(&li, 0, sizeof(li));
+    const int rc = vo_svo_local_ba(&k, &li, h.id_min);
+    if (rc < 0) return rc;
+    if (li.lba_ran) {
+      I->lba_ran = 1;
+      I->lba_err_first = li.lba_err_first;
+      I->lba_err_last = li.lba_err_last;
+      I->lba_landmarks = li.lba_landmarks;
+      I->lba_observations = li.lba_observations;
+      // kf->setPose(...) of the optimised keyframes: their entries of the frame table, and this frame's pose
+      MvoPoseArgs p;
+      memset(&p, 0, sizeof(p));
+      for (size_t j = 2; j < k.keyframes.size() && p.n < 16; ++j) {
+        p.f[p.n] = s->kf_frame[j];
+        memcpy(p.T[p.n], k.keyframes[j].T_wc, sizeof(float) * 16);
+        svo_inv_se3(k.keyframes[j].T_wc, p.T[p.n] + 16);
+        ++p.n;
+      }
+      if (p.n > 0) {
+        hipLaunchKernelGGL(mvo_pose_put_kernel, dim3(p.n), dim3(32), 0, st, p, s->d_frameT);
+        VO_CHECK_HIP(c, hipGetLastError());
+      }
+      memcpy(T_wc, k.keyframes.back().T_wc, sizeof(float) * 16);
+    }
+  }
+  if (n > 0) {  // the operator flags of the next frame (the keyframe count decides the pose-only BA's class)
+    hipLaunchKernelGGL(mvo_opflags_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s->ts[s->cur].t.flags, n, (int)(k.keyframes.size() > 5), s->d_op);
+    VO_CHECK_HIP(c, hipGetLastError());
+  }
+  memcpy(s->T_wp, T_wc, sizeof(float) * 16);
+  memcpy(I->T_wc, T_wc, sizeof(float) * 16);
+  I->n_tracks_out = n;
+  return VO_OK;
+}
+
+// new points driven from the host (initialisation, 5-point fallback): updateWeightBin(final pixels), the table's best keypoint
+// of every bin left empty, trackBidirection(I1, I0) — uploaded for the advance kernel. Returns the number of candidates.
+static int mvo_host_new_points(vo_mvo *s, const std::vector<float> &final_px, int *m_out) {
+  vo_ctx *c = s->c;
+  const vo_bin_params &b = s->prm.bins;
+  const int bins = b.n_bins_u * b.n_bins_v;
+  std::vector<float> xy(2 * (size_t)bins), cand, p0;
+  std::vector<uint8_t> has(bins), occ(bins, 0), m;
+  RC(vo_new_point_candidates_get(c, s->tab_cur, xy.data(), has.data(), nullptr));
+  for (size_t i = 0; i + 1 < final_px.size(); i += 2) {  // WeightBin::update, feature_extractor.h:116-135
+    const int u = (int)floorf(final_px[i] / (float)b.u_step), v = (int)floorf(final_px[i + 1] / (float)b.v_step);
+    const int bin = v * b.n_bins_u + u;
+    if (bin >= 0 && bin < bins) occ[bin] = 1;
+  }
+  for (int j = 0; j < bins; ++j)
+    if (has[j] && !occ[j]) {
+      cand.push_back(xy[2 * j]);
+      cand.push_back(xy[2 * j + 1]);
+    }
+  const int nc = (int)(cand.size() / 2);
+  *m_out = nc;
+  if (nc == 0) return VO_OK;
+  p0.assign(2 * (size_t)nc, 0.f);
+  m.assign((size_t)nc, 1);
+  RC(vo_track_bidirection(c, s->slot[1], s->slot[0], cand.data(), nc, s->prm.frame.win, s->prm.frame.max_level, s->prm.frame.thres_err,
+                          s->prm.frame.thres_bidirection, p0.data(), m.data()));
+  hipStream_t st = c->stream;
+  VO_CHECK_HIP(c, hipMemcpyAsync(s->d_cand1, cand.data(), sizeof(float) * 2 * nc, hipMemcpyHostToDevice, st));
+  VO_CHECK_HIP(c, hipMemcpyAsync(s->d_cand0, p0.data(), sizeof(float) * 2 * nc, hipMemcpyHostToDevice, st));
+  VO_CHECK_HIP(c, hipMemcpyAsync(s->d_mnew, m.data(), (size_t)nc, hipMemcpyHostToDevice, st));
+  VO_CHECK_HIP(c, hipStreamSynchronize(st));  // (the vectors go out of scope)
+  return VO_OK;
+}
+
+// mono_vo.cpp:528-561
+static int mvo_first_image(vo_mvo *s, vo_mvo_frame_info *I) {
+  vo_ctx *c = s->c;
+  const int bins = s->prm.bins.n_bins_u * s->prm.bins.n_bins_v;
+  std::vector<float> xy(2 * (size_t)bins), pts;
+  std::vector<uint8_t> has(bins);
+  RC(vo_new_point_candidates_get(c, s->tab_cur, xy.data(), has.data(), nullptr));  // resetWeightBin + extractORBwithBinning_fast
+  for (int j = 0; j < bins; ++j)
+    if (has[j]) {
+      pts.push_back(xy[2 * j]);
+      pts.push_back(xy[2 * j + 1]);
+    }
+  const int n = (int)(pts.size() / 2);
+  if (n > s->cap) VO_FAIL(c, VO_ERR_CAPACITY, "%d initial landmarks exceed vo_config.max_points=%d", n, s->cap);
+  MvoSet &t = s->ts[s->cur];
+  hipStream_t st = c->stream;
+  float I4[16];
+  mvo_eye(I4);
+  if (n > 0) {
+    std::vector<int32_t> ids(n), zero(n, 0), age(n, 1), neg(n, -1);
+    std::vector<float> cosn(n, MVO_COS_NONE);
+    for (int i = 0; i < n; ++i) ids[i] = c->next_landmark_id + i;
+    c->next_landmark_id += n;
+    VO_CHECK_HIP(c, hipMemcpyAsync(t.t.pts_l, pts.data(), sizeof(float) * 2 * n, hipMemcpyHostToDevice, st));
+    VO_CHECK_HIP(c, hipMemcpyAsync(t.p_first, pts.data(), sizeof(float) * 2 * n, hipMemcpyHostToDevice, st));
+    VO_CHECK_HIP(c, hipMemcpyAsync(t.t.ids, ids.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
+    VO_CHECK_HIP(c, hipMemsetAsync(t.t.Xw, 0, sizeof(float) * 3 * n, st));
+    VO_CHECK_HIP(c, hipMemsetAsync(t.t.flags, 0, (size_t)n, st));
+    VO_CHECK_HIP(c, hipMemcpyAsync(t.f_first, zero.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
+    VO_CHECK_HIP(c, hipMemcpyAsync(t.age, age.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
+    VO_CHECK_HIP(c, hipMemcpyAsync(t.cos_last, cosn.data(), sizeof(float) * n, hipMemcpyHostToDevice, st));
+    VO_CHECK_HIP(c, hipMemsetAsync(t.n_kf, 0, sizeof(int32_t) * n, st));
+    VO_CHECK_HIP(c, hipMemsetAsync(t.p_kf_first, 0, sizeof(float) * 2 * n, st));
+    VO_CHECK_HIP(c, hipMemcpyAsync(t.kf_first, neg.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
+    VO_CHECK_HIP(c, hipStreamSynchronize(st));
+  }
+  {  // the frame table's entry 0: pose I
+    MvoPoseArgs p;
+    memset(&p, 0, sizeof(p));
+    p.n = 1;
+    p.f[0] = 0;
+    memcpy(p.T[0], I4, sizeof(I4));
+    memcpy(p.T[0] + 16, I4, sizeof(I4));
+    hipLaunchKernelGGL(mvo_pose_put_kernel, dim3(1), dim3(32), 0, st, p, s->d_frameT);
+    VO_CHECK_HIP(c, hipGetLastError());
+  }
+  s->n = n;
+  // frame_curr->setPose(Identity); setPoseDiff10(T_init), T_init.t = (0, 0, -1) -> dT01_ = inverseSE3_f(T_init)
+  float T_init[16];
+  mvo_eye(T_init);
+  T_init[11] = -1.0f;
+  svo_inv_se3(T_init, s->dT01);
+  s->got_first = true;
+  I->is_first = 1;
+  I->n_new = n;
+  MvoHdr h;
+  memset(&h, 0, sizeof(h));
+  h.id_min = n > 0 ? c->next_landmark_id - n : c->next_landmark_id;
+  return mvo_finish_frame(s, h, I4, I);
+}
+
+// mono_vo.cpp:562-696 — host-driven, once per stream
+static int mvo_second_image(vo_mvo *s, vo_mvo_frame_info *I) {
+  vo_ctx *c = s->c;
+  const vo_mono_params &p = s->prm.frame;
+  const int n = s->n;
+  if (n <= 0) VO_FAIL(c, VO_ERR_GN_FAILED, "MonoVO initialisation: the first image gave no landmark");
+  hipStream_t st = c->stream;
+  std::vector<float> pts0(2 * (size_t)n), pts1(2 * (size_t)n, 0.f), p0k, p1k;
+  std::vector<uint8_t> mask(n, 1), stage(n, 0), m5;
+  VO_CHECK_HIP(c, hipMemcpyAsync(pts0.data(), s->ts[s->cur].t.pts_l, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, st));
+  VO_CHECK_HIP(c, hipStreamSynchronize(st));
+  RC(vo_track(c, s->slot[0], s->slot[1], pts0.data(), n, p.win, p.max_level, p.thres_err, pts1.data(), mask.data()));
+  std::vector<int> idx;
+  for (int i = 0; i < n; ++i)
+    if (mask[i]) {
+      idx.push_back(i);
+      p0k.insert(p0k.end(), {pts0[2 * i], pts0[2 * i + 1]});
+      p1k.insert(p1k.end(), {pts1[2 * i], pts1[2 * i + 1]});
+    }
+  const int nk = (int)idx.size();
+  float R10[9], t10[3];
+  m5.assign((size_t)std::max(nk, 1), 0);
+  if (!s->prm.five_point(s->prm.five_point_user, p0k.data(), p1k.data(), nk, p.K, R10, t10, m5.data()))
+    VO_FAIL(c, VO_ERR_GN_FAILED, "calcPose5PointsAlgorithm() is failed.");
+  float F[9];
+  mvo_fundamental(p.K, R10, t10, F);
+  std::vector<float> dist((size_t)std::max(nk, 1)), fin;
+  if (nk > 0) RC(vo_sampson_distance(c, p0k.data(), p1k.data(), nk, F, dist.data()));
+
+  for (int q = 0; q < nk; ++q)
+    if (m5[q] && dist[q] < p.thres_sampson) {
+      stage[idx[q]] = 4;
+      fin.insert(fin.end(), {p1k[2 * q], p1k[2 * q + 1]});
+
+    }
+  // dt10 = dt10 / dt10.norm() * 1.0f; dT10; dT01 = inverseSE3_f(dT10); pose = Twc_prev * dT01 (:606-612)
+  const float nrm = sqrtf(t10[0] * t10[0] + (t10[1] * t10[1] + t10[2] * t10[2]));
+  float dT10[16], dT01[16], T_wc[16], I4[16];
+  mvo_eye(dT10);
+  mvo_eye(I4);
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) dT10[i * 4 + j] = R10[i * 3 + j];
+    dT10[i * 4 + 3] = t10[i] / nrm * 1.0f;
+  }
+  svo_inv_se3(dT10, dT01);
+  svo_mul44(s->T_wp, dT01, T_wc);
+  svo_inv_se3(dT10, s->dT01);  // setPoseDiff10(dT10)
+  int m = 0;
+  RC(mvo_host_new_points(s, fin, &m));
+  VO_CHECK_HIP(c, hipMemcpyAsync(s->d_stage, stage.data(), (size_t)n, hipMemcpyHostToDevice, st));
+  VO_CHECK_HIP(c, hipMemcpyAsync(s->d_pts1, pts1.data(), sizeof(float) * 2 * n, hipMemcpyHostToDevice, st));
+  VO_CHECK_HIP(c, hipStreamSynchronize(st));
+  MvoHdr h;
+  // (the observations of lmtrack_final are added before the frame's pose is set, :602-603 vs :611: they see the identity)
+  RC(mvo_advance(s, s->d_stage, s->d_pts1, s->d_cand1, s->d_cand0, s->d_mnew, m, I4, T_wc, &h));
+  {  // :660-687
+    MvoRecArgs a;
+    memset(&a, 0, sizeof(a));
+    a.s = s->ts[s->cur];
+    a.n = s->n;
+    a.f = s->f;
+    memcpy(a.K, p.K, sizeof(a.K));
+    svo_inv_se3(T_wc, a.T_cw);
+    a.cos_thres = s->cos_thres;
+    a.frameT = s->d_frameT;
+    a.n_recon = s->d_nrec;
+    VO_CHECK_HIP(c, hipMemsetAsync(s->d_nrec, 0, sizeof(int), st));
+    if (s->n > 0) hipLaunchKernelGGL(mvo_init_reconstruct_kernel, dim3((s->n + 255) / 256), dim3(256), 0, st, a);
+    VO_CHECK_HIP(c, hipGetLastError());
+    RC(vo_svo_lba_update_points(&s->core, s->ts[s->cur].t, s->n));  // (landmarks of keyframe 0 that just got their point)
+    int nrec = 0;
+    VO_CHECK_HIP(c, hipMemcpyAsync(&nrec, s->d_nrec, sizeof(int), hipMemcpyDeviceToHost, st));
+    VO_CHECK_HIP(c, hipStreamSynchronize(st));
+    I->n_reconstructed = nrec;
+  }
+  s->init_done = true;
+  I->is_init = 1;
+  I->used_five_point = 1;
+  I->n_tracks_in = n;
+  I->n_final = h.n_surv;
+  I->n_new = h.n_new;
+  memcpy(I->dT01, dT01, sizeof(dT01));
+  return mvo_finish_frame(s, h, T_wc, I);
+}
+
+extern "C" int vo_mvo_enqueue(vo_mvo *s, const void *img, int stride, int on_device, double timestamp) {
+  if (!s || !img) return VO_ERR_INVALID;
+  vo_ctx *c = s->c;
+  if (s->pending) VO_FAIL(c, VO_ERR_INVALID, "a frame is already in flight: call vo_mvo_result first");
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  (void)timestamp;
+  if (s->init_done && s->n <= 0) VO_FAIL(c, VO_ERR_GN_FAILED, "the track set is empty");
+  if (!(s->prefetched && s->pre == img)) RC(mvo_ingest(s, img, stride, on_device));
+  s->prefetched = false;
+  const int keep_slot[3] = {s->slot[0], s->slot[1], s->slot[2]}, keep_tc = s->tab_cur, keep_tn = s->tab_next;
+  {  // previous <- current, current <- the image just ingested, the freed slot takes the next one
+    const int p = s->slot[0];
+    s->slot[0] = s->slot[1];
+    s->slot[1] = s->slot[2];
+    s->slot[2] = p;
+    s->tab_cur = s->tab_next;
+    s->tab_next ^= 1;
+  }
+  if (s->init_done) {
+    // mono_vo.cpp:726-734: Twc_prev, Tcw_prev, dT01_prior = getPoseDiff01(), Tcw_prior = inverseSE3_f(Twc_prev * dT01_prior)
+    float Tcw_prev[16], Twc_prior[16], Tcw_prior[16];
+    svo_inv_se3(s->T_wp, Tcw_prev);
+    svo_mul44(s->T_wp, s->dT01, Twc_prior);
+    svo_inv_se3(Twc_prior, Tcw_prior);
+    const MvoSet &t = s->ts[s->cur];
+    const int rc = vo_mono_frame_enqueue_closed(c, &s->prm.frame, s->slot[0], s->slot[1], t.t.pts_l, t.t.Xw, s->d_op, s->n, Tcw_prev,
+                                                Tcw_prior, s->dT01, &s->prm.bins, s->tab_cur, 1);
+    if (rc < 0) {
+      memcpy(s->slot, keep_slot, sizeof(keep_slot));
+      s->tab_cur = keep_tc;
+      s->tab_next = keep_tn;
+      return rc;
+    }
+  }
+  s->frame_id = c->next_frame_id;  // Frame(cam, timestamp): id = frame_counter_++ (frame.cpp:22-41)
+  c->next_frame_id += 1;
+  ++s->f;
+  s->pend_kind = !s->got_first ? 0 : (!s->init_done ? 1 : 2);
+  s->pending = true;
+  return VO_OK;
+}
+
+// mono_vo.cpp:909-949: the pose-only BA gave nothing — 5-point pose with the previous motion's length, the hook's mask as
+// mask_motion, Sampson gate, new points: host-driven operator calls on the frame's device results
+static int mvo_fallback(vo_mvo *s, float dT01[16], float dT10[16], int *m_new, vo_mvo_frame_info *I) {
+  vo_ctx *c = s->c;
+  const vo_mono_params &p = s->prm.frame;
+  vo_frame_state *f = c->frame;
+  const int n = s->n;
+  hipStream_t st = c->stream;
+  std::vector<float> pts0(2 * (size_t)n), pts1(2 * (size_t)n), p0k, p1k;
+  std::vector<uint8_t> stage(n);
+  VO_CHECK_HIP(c, hipMemcpyAsync(pts0.data(), s->ts[s->cur].t.pts_l, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, st));
+  VO_CHECK_HIP(c, hipStreamSynchronize(st));
+  memcpy(pts1.data(), f->res_host + f->off_pl1, sizeof(float) * 2 * (size_t)n);
+  memcpy(stage.data(), f->res_host + f->off_stage, (size_t)n);
+  std::vector<int> idx;
+  for (int i = 0; i < n; ++i)
+    if (stage[i] >= 2) {
+      idx.push_back(i);
+      p0k.insert(p0k.end(), {pts0[2 * i], pts0[2 * i + 1]});
+      p1k.insert(p1k.end(), {pts1[2 * i], pts1[2 * i + 1]});
+    }
+  const int nk = (int)idx.size();
+  float R10[9], t10[3];
+  std::vector<uint8_t> mm((size_t)std::max(nk, 1), 0);
+  if (!s->prm.five_point(s->prm.five_point_user, p0k.data(), p1k.data(), nk, p.K, R10, t10, mm.data()))
+    VO_FAIL(c, VO_ERR_GN_FAILED, "'calcPose5PointsAlgorithm()' is failed. Terminate the algorithm.");
+  const float scale = sqrtf(s->dT01[3] * s->dT01[3] + (s->dT01[7] * s->dT01[7] + s->dT01[11] * s->dT01[11]));
+  const float nrm = sqrtf(t10[0] * t10[0] + (t10[1] * t10[1] + t10[2] * t10[2]));
+  mvo_eye(dT10);
+  const float sc = scale / nrm;
+  float ts[3];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) dT10[i * 4 + j] = R10[i * 3 + j];
+    dT10[i * 4 + 3] = ts[i] = sc * t10[i];
+  }
+  svo_inv_se3(dT10, dT01);
+  // lmtrack_motion = lmtrack_scaleok[mask_motion]; Sampson gate with dT10 (:951-963)
+  std::vector<float> q0, q1, fin;
+  std::vector<int> qi;
+  for (int q = 0; q < nk; ++q)
+    if (mm[q]) {
+      qi.push_back(idx[q]);
+      q0.insert(q0.end(), {p0k[2 * q], p0k[2 * q + 1]});
+      q1.insert(q1.end(), {p1k[2 * q], p1k[2 * q + 1]});
+    }
+  float F[9];
+  mvo_fundamental(p.K, R10, ts, F);
+  std::vector<float> dist((size_t)std::max((int)qi.size(), 1));
+  if (!qi.empty()) RC(vo_sampson_distance(c, q0.data(), q1.data(), (int)qi.size(), F, dist.data()));
+  std::fill(stage.begin(), stage.end(), 0);
+  for (size_t q = 0; q < qi.size(); ++q)
+    if (dist[q] < p.thres_sampson) {
+      stage[qi[q]] = 4;
+      fin.insert(fin.end(), {q1[2 * q], q1[2 * q + 1]});
+    }
+  RC(mvo_host_new_points(s, fin, m_new));
+  VO_CHECK_HIP(c, hipMemcpyAsync(s->d_stage, stage.data(), (size_t)n, hipMemcpyHostToDevice, st));
+  VO_CHECK_HIP(c, hipMemcpyAsync(s->d_pts1, pts1.data(), sizeof(float) * 2 * n, hipMemcpyHostToDevice, st));
+  VO_CHECK_HIP(c, hipStreamSynchronize(st));
+  I->used_five_point = 1;
+  return VO_OK;
+}
+
+extern "C" int vo_mvo_result(vo_mvo *s, vo_mvo_frame_info *info) {
+  if (!s || !s->pending) return VO_ERR_INVALID;
+  vo_ctx *c = s->c;
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  s->pending = false;
+  vo_mvo_frame_info I;
+  memset(&I, 0, sizeof(I));
+  I.frame_id = s->frame_id;
+  int rc = VO_OK;
+  if (s->pend_kind == 0) {
+    rc = mvo_first_image(s, &I);
+  } else if (s->pend_kind == 1) {
+    rc = mvo_second_image(s, &I);
+  } else {
+    float dT01[16], dT10[16], T_wc[16];
+    rc = vo_mono_frame_result(c, nullptr, nullptr, nullptr, dT01, &I.counts, &I.gn);
+    if (rc < 0) return rc;
+    vo_frame_state *f = c->frame;
+    const vo_frame_hdr *fh = (const vo_frame_hdr *)f->res_host;
+    I.n_tracks_in = s->n;
+    const uint8_t *stage = f->res_dev + f->off_stage, *mnew = f->res_dev + f->off_mnew;
+    const float *pts1 = (const float *)(f->res_dev + f->off_pl1);
+    const float *cand1 = (const float *)(f->res_dev + f->off_newl), *cand0 = (const float *)(f->res_dev + f->off_newr);
+    int m = fh->cnt[6];
+    if (I.counts.need_five_point) {
+      rc = mvo_fallback(s, dT01, dT10, &m, &I);
+      if (rc < 0) return rc;
+      stage = s->d_stage;
+      pts1 = s->d_pts1;
+      cand1 = s->d_cand1;
+      cand0 = s->d_cand0;
+      mnew = s->d_mnew;
+    } else {
+      svo_inv_se3(dT01, dT10);  // dT10 = inverseSE3_f(dT01) (:881)
+    }
+    svo_mul44(s->T_wp, dT01, T_wc);  // frame_curr->setPose(Twc_prev * dT01)
+    svo_inv_se3(dT10, s->dT01);      // setPoseDiff10(dT10): dT01_ = inverseSE3_f(dT10)
+    MvoHdr h;
+    rc = mvo_advance(s, stage, pts1, cand1, cand0, mnew, m, T_wc, T_wc, &h);
+    if (rc < 0) return rc;
+    I.n_final = h.n_surv;
+    I.n_new = h.n_new;
+    memcpy(I.dT01, dT01, sizeof(dT01));
+    rc = mvo_finish_frame(s, h, T_wc, &I);
+  }
+  if (rc < 0) return rc;
+  s->info = I;
+  if (info) *info = I;
+  return VO_OK;
+}
+
+extern "C" int vo_mvo_track(vo_mvo *s, const void *img, int stride, int on_device, double timestamp, vo_mvo_frame_info *info) {
+  RC(vo_mvo_enqueue(s, img, stride, on_device, timestamp));
+  return vo_mvo_result(s, info);
+}
+
+extern "C" int vo_mvo_get_tracks(vo_mvo *s, int32_t *ids, float *pts, float *Xw, uint8_t *flags, int32_t *age, float *cos_parallax,
+                                 int cap, int *n) {
+  if (!s || !n) return VO_ERR_INVALID;
+  vo_ctx *c = s->c;
+  if (s->pending) VO_FAIL(c, VO_ERR_INVALID, "call vo_mvo_result first");
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  *n = s->n;
+  if (s->n > cap && (ids || pts || Xw || flags || age || cos_parallax)) VO_FAIL(c, VO_ERR_CAPACITY, "%d tracks, room for %d", s->n, cap);
+  VO_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+  const MvoSet &t = s->ts[s->cur];
+  const size_t m = (size_t)s->n;
+  if (m == 0) return VO_OK;
+  if (ids) VO_CHECK_HIP(c, hipMemcpy(ids, t.t.ids, sizeof(int32_t) * m, hipMemcpyDeviceToHost));
+  if (pts) VO_CHECK_HIP(c, hipMemcpy(pts, t.t.pts_l, sizeof(float) * 2 * m, hipMemcpyDeviceToHost));
+  if (Xw) VO_CHECK_HIP(c, hipMemcpy(Xw, t.t.Xw, sizeof(float) * 3 * m, hipMemcpyDeviceToHost));
+  if (flags) VO_CHECK_HIP(c, hipMemcpy(flags, t.t.flags, m, hipMemcpyDeviceToHost));
+  if (age) VO_CHECK_HIP(c, hipMemcpy(age, t.age, sizeof(int32_t) * m, hipMemcpyDeviceToHost));
+  if (cos_parallax) VO_CHECK_HIP(c, hipMemcpy(cos_parallax, t.cos_last, sizeof(float) * m, hipMemcpyDeviceToHost));
+  return VO_OK;
+}
+
+extern "C" int vo_mvo_keyframe_count(vo_mvo *s, int *n_keyframes) {
+  if (!s) return VO_ERR_INVALID;
+  return vo_svo_keyframe_count(&s->core, n_keyframes);
+}
+extern "C" int vo_mvo_get_keyframes(vo_mvo *s, float *T_wc, int32_t *n_points, float *mappoints, size_t cap_points, size_t *total_points) {
+  if (!s) return VO_ERR_INVALID;
+  if (s->pending) VO_FAIL(s->c, VO_ERR_INVALID, "call vo_mvo_result first");
+  return vo_svo_get_keyframes(&s->core, T_wc, n_points, mappoints, cap_points, total_points);
+}

@@ -40,6 +40,7 @@ struct vo_svo {
   int n_keyframes = 0, n_kf_lms = 0;
   // landmark table, keyframe ring, window scratch and the solver's arena, all on the device (stereo_vo_lba.hip)
   struct vo_svo_lba *lba = nullptr;
+  int mono = 0;  // the keyframe storage serves a MonoVO (mono_vo.hip): one observation per keyframe entry, bundled flags
   // all_stkeyframes_ (stats_keyframe): every keyframe's current pose (host) and where its related landmarks' ids are kept
   // on the device (a pool that only grows)
   struct SvoKfAll {
@@ -63,6 +64,7 @@ int vo_svo_lba_init(vo_svo *s);  // stereo_vo_lba.hip: landmark table, keyframe 
 int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info, int id_min);
 void vo_svo_lba_free(vo_svo *s);
 size_t vo_svo_lba_bytes(const vo_svo *s);
+int vo_svo_lba_update_points(vo_svo *s, const SvoTrackSet &ts, int n);  // a landmark got its 3-D point outside a keyframe
 
 void svo_mul44(const float A[16], const float B[16], float C[16]);
 void svo_inv_se3(const float T[16], float Ti[16]);

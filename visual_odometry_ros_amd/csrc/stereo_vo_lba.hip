@@ -96,6 +96,8 @@ struct LmTab {
 struct LbaWin {
   int nk, No, W, base;  // window keyframes, optimised poses, ids spanned, first id
   int kw;               // entries per id in q_w (= kf_window of the stream)
+  int opk;              // observations per keyframe entry: 2 (stereo: left, right) or 1 (MonoVO's window: one camera, and a
+                        // landmark then needs two window keyframes, THRES_MINIMUM_SEEN of sparse_ba_parameters.h:313)
   int n[LBA_KW];        // related landmarks of window keyframe j
   const int32_t *ids[LBA_KW];
   const float *pl[LBA_KW], *pr[LBA_KW];
@@ -129,7 +131,7 @@ __global__ void lba_keyframe_kernel(SvoTrackSet ts, int n, LmTab tab, int32_t *k
   tab.X[3 * (size_t)t] = ts.Xw[3 * k];
   tab.X[3 * (size_t)t + 1] = ts.Xw[3 * k + 1];
   tab.X[3 * (size_t)t + 2] = ts.Xw[3 * k + 2];
-  tab.S[t] = (uint8_t)(dead | ((ts.flags[k] & VO_LM_TRIANGULATED) ? 1 : 0));
+  tab.S[t] = (uint8_t)(dead | ((ts.flags[k] & VO_LM_TRIANGULATED) ? 1 : 0) | ((ts.flags[k] & VO_LM_BUNDLED) ? 4 : 0));
   tab.tag[t] = id;
   kf_ids[k] = id;
   all_ids[k] = id;  // (the keyframe's related landmarks, kept for good: stats_keyframe)
@@ -137,6 +139,20 @@ __global__ void lba_keyframe_kernel(SvoTrackSet ts, int n, LmTab tab, int32_t *k
   kf_pl[2 * k + 1] = ts.pts_l[2 * k + 1];
   kf_pr[2 * k] = ts.pts_r[2 * k];
   kf_pr[2 * k + 1] = ts.pts_r[2 * k + 1];
+}
+
+// Landmark::set3DPoint outside a keyframe (MonoVO's initialisation, mono_vo.cpp:660-687): landmarks that a keyframe already
+// put into the table take their new point and state; the others enter the table at their first keyframe
+__global__ void lba_table_update_kernel(SvoTrackSet ts, int n, LmTab tab) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int32_t id = ts.ids[k];
+  const int t = id & tab.mask;
+  if (tab.tag[t] != id) return;
+  tab.X[3 * (size_t)t] = ts.Xw[3 * k];
+  tab.X[3 * (size_t)t + 1] = ts.Xw[3 * k + 1];
+  tab.X[3 * (size_t)t + 2] = ts.Xw[3 * k + 2];
+  tab.S[t] = (uint8_t)((tab.S[t] & 2) | ((ts.flags[k] & VO_LM_TRIANGULATED) ? 1 : 0) | ((ts.flags[k] & VO_LM_BUNDLED) ? 4 : 0));
 }
 
 // getObservationsOnKeyframes restricted to the window: which keyframes saw id, and where
@@ -212,7 +228,7 @@ __global__ __launch_bounds__(LBA_QWG) void lba_qualify_kernel(LbaWin w, LmTab ta
     const int32_t id = w.base + idx;
     const int t = id & tab.mask;
     const uint8_t st = tab.tag[t] == id ? tab.S[t] : (uint8_t)0;
-    if (!((st & 1) && !(st & 2))) {  // isTriangulated() && isAlive()
+    if (!((st & 1) && !(st & 2)) || w.opk * __popc(m) < 2) {  // isTriangulated() && isAlive(); kfs_seen.size() >= 2
       m = 0;
       p.mask_w[idx] = 0;
     }
@@ -251,9 +267,9 @@ __global__ __launch_bounds__(1024) void lba_scan_kernel(LbaWin w, LbaProb p, Lba
     const int t_lm = (int)(total & ((1ull << LBA_PK_KF) - 1)), t_kf = (int)((total >> LBA_PK_KF) & ((1ull << (LBA_PK_SL - LBA_PK_KF)) - 1));
     const int t_sl = (int)(total >> LBA_PK_SL);
     p.dyn[0] = t_lm;
-    p.dyn[1] = 2 * t_kf;
+    p.dyn[1] = w.opk * t_kf;
     p.dyn[2] = t_sl;
-    p.obs_ptr[t_lm] = 2 * t_kf;
+    p.obs_ptr[t_lm] = w.opk * t_kf;
     p.slot_ptr[t_lm] = t_sl;
   }
 }
@@ -282,25 +298,27 @@ __global__ void lba_fill_kernel(LbaWin w, LmTab tab, LbaProb p, LbaRef r) {
     const double xr = (r.Tjw_ref[k * 4 + 0] * Xd[0] + (r.Tjw_ref[k * 4 + 1] * Xd[1] + r.Tjw_ref[k * 4 + 2] * Xd[2])) + r.Tjw_ref[k * 4 + 3];
     p.X[3 * (size_t)i + k] = xr * r.inv_scale;
   }
-  p.obs_ptr[i] = 2 * kf0;
+  p.obs_ptr[i] = w.opk * kf0;
   p.slot_ptr[i] = s0;
   int rr = 0, rs = 0;
   for (int mm = m; mm; mm &= mm - 1) {
     const int j = __ffs(mm) - 1;
     const int q = p.q_w[(size_t)idx * w.kw + j];
-    const int o = 2 * (kf0 + rr);
+    const int o = w.opk * (kf0 + rr);
     p.obs_frame[o] = j;
-    p.obs_frame[o + 1] = j;
     p.obs_right[o] = 0;
-    p.obs_right[o + 1] = 1;
     p.px[2 * (size_t)o] = (double)w.pl[j][2 * q];
     p.px[2 * (size_t)o + 1] = (double)w.pl[j][2 * q + 1];
-    p.px[2 * (size_t)o + 2] = (double)w.pr[j][2 * q];
-    p.px[2 * (size_t)o + 3] = (double)w.pr[j][2 * q + 1];
-    if (w.opt[j] >= 0) {  // slot: left observation in an optimised keyframe; its B block is the RIGHT observation's
-      const int s = s0 + rs;  // (the last one of the landmark in that keyframe: :315 / :410 assign)
+    if (w.opk == 2) {
+      p.obs_frame[o + 1] = j;
+      p.obs_right[o + 1] = 1;
+      p.px[2 * (size_t)o + 2] = (double)w.pr[j][2 * q];
+      p.px[2 * (size_t)o + 3] = (double)w.pr[j][2 * q + 1];
+    }
+    if (w.opt[j] >= 0) {  // slot: left observation in an optimised keyframe; its B block is the LAST observation's of the
+      const int s = s0 + rs;  // landmark in that keyframe (:315 / :410 assign): the right one of a stereo keyframe
       p.slot_j[s] = w.opt[j];
-      p.slot_bobs[s] = o + 1;
+      p.slot_bobs[s] = o + w.opk - 1;
       p.slot_lm[s] = i;
       ++rs;
     }
@@ -325,17 +343,17 @@ __global__ __launch_bounds__(1024) void lba_lists_kernel(LbaWin w, LbaProb p) {
     for (int i = i0; i < i1; ++i) {
       const int m = p.lm_mask[i];
       if (!(m & bit)) continue;
-      const int o = p.obs_ptr[i] + 2 * __popc(m & (bit - 1));
-      p.pose_obs[Bo + 2 * off] = o;
-      p.pose_obs[Bo + 2 * off + 1] = o + 1;
-      p.pose_lm[Bo + 2 * off] = i;
-      p.pose_lm[Bo + 2 * off + 1] = i;
+      const int o = p.obs_ptr[i] + w.opk * __popc(m & (bit - 1));
+      for (int e = 0; e < w.opk; ++e) {
+        p.pose_obs[Bo + w.opk * off + e] = o + e;
+        p.pose_lm[Bo + w.opk * off + e] = i;
+      }
       p.pose_slot[Bs + off] = p.slot_ptr[i] + __popc(m & w.optmask & (bit - 1));
       ++off;
     }
     if (tid == 0) {
       p.pose_obs_ptr[u] = Bo;
-      p.pose_obs_end[u] = Bo + 2 * total;
+      p.pose_obs_end[u] = Bo + w.opk * total;
       p.pose_slot_ptr[u] = Bs;
       p.pose_slot_end[u] = Bs + total;
     }
@@ -382,11 +400,14 @@ __global__ void lba_writeback_kernel(LbaProb p, LmTab tab, LbaRef r) {
   tab.X[3 * (size_t)t + 2] = L[2];
   uint8_t st = (uint8_t)(tab.S[t] | 1);
   const float nrm = sqrtf(L[0] * L[0] + (L[1] * L[1] + L[2] * L[2]));
-  if (!(nrm <= 3000)) st |= 2;
+  if (!(nrm <= 3000))
+    st |= 2;  // setDead
+  else
+    st |= 4;  // setBundled (read by the mono driver only: isBundled() decides its priors and its pose-only BA set)
   tab.S[t] = st;
 }
 // what the BA did to the landmarks the next frame tracks
-__global__ void lba_refresh_kernel(SvoTrackSet ts, int n, LmTab tab) {
+__global__ void lba_refresh_kernel(SvoTrackSet ts, int n, LmTab tab, int mono) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const int t = ts.ids[k] & tab.mask;
@@ -397,6 +418,7 @@ __global__ void lba_refresh_kernel(SvoTrackSet ts, int n, LmTab tab) {
   const uint8_t st = tab.S[t];
   if (st & 1) fl |= VO_LM_TRIANGULATED;
   if (st & 2) fl |= VO_LM_DROPPED;
+  if (mono && (st & 4)) fl |= VO_LM_BUNDLED;
   ts.flags[k] = fl;
 }
 
@@ -680,7 +702,7 @@ static int lba_enqueue(vo_svo *s, const LbaWin &w, int maxn, size_t M_ub, const 
   VO_CHECK_HIP(c, hipGetLastError());
   d.n_frames = nk;
   d.n_opt = No;
-  d.stereo = 1;
+  d.stereo = s->mono ? 0 : 1;
   d.max_iter = max_iter;
   d.dyn = p.dyn;
   for (int k = 0; k < 4; ++k) {
@@ -733,7 +755,7 @@ static int lba_enqueue(vo_svo *s, const LbaWin &w, int maxn, size_t M_ub, const 
   // iterations, before the host looks at anything (a solve that ends in NaN or a "large update" ends the run as in the
   // reference; what it left in the table is then nobody's input; with no landmark in the problem both kernels do nothing) ----
   hipLaunchKernelGGL(lba_writeback_kernel, dim3((unsigned)((M_ub + 255) / 256)), dim3(256), 0, st, p, L->tab, ref);
-  hipLaunchKernelGGL(lba_refresh_kernel, dim3((std::max(n, 1) + 255) / 256), dim3(256), 0, st, t, n, L->tab);
+  hipLaunchKernelGGL(lba_refresh_kernel, dim3((std::max(n, 1) + 255) / 256), dim3(256), 0, st, t, n, L->tab, s->mono);
   VO_CHECK_HIP(c, hipGetLastError());
   *res = p.T;
   return VO_OK;
@@ -760,6 +782,7 @@ static int lba_warm_up(vo_svo *s) {
     w.nk = nk;
     w.No = nk - 2;
     w.kw = s->prm.kf_window;
+    w.opk = s->mono ? 1 : 2;
     w.W = 1;
     for (int j = 0; j < nk; ++j) {
       w.ids[j] = L->kf_ids[0];
@@ -816,6 +839,14 @@ int vo_svo_lba_init(vo_svo *s) {
     if (rc < 0) return rc;
   }
   VO_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+  return VO_OK;
+}
+
+int vo_svo_lba_update_points(vo_svo *s, const SvoTrackSet &ts, int n) {
+  vo_ctx *c = s->c;
+  if (!s->lba || n <= 0) return VO_OK;
+  hipLaunchKernelGGL(lba_table_update_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, ts, n, s->lba->tab);
+  VO_CHECK_HIP(c, hipGetLastError());
   return VO_OK;
 }
 
@@ -884,6 +915,7 @@ int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info, int id_min) {
   w.nk = nk;
   w.No = nk - 2;  // NUM_FIX_KEYFRAMES_IN_WINDOW
   w.kw = s->prm.kf_window;
+  w.opk = s->mono ? 1 : 2;
   w.base = win.front().id_min;
   const long long span = (long long)c->next_landmark_id - (long long)w.base;
   if (span > LBA_SPAN_MAX) VO_FAIL(c, VO_ERR_CAPACITY, "local BA: the window spans %lld landmark ids (at most %d)", span, LBA_SPAN_MAX);
