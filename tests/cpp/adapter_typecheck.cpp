@@ -57,6 +57,25 @@ float use_stereo_vo(const cv::Mat &img_left, const cv::Mat &img_right, const dou
   (void)dbg;
   return Twc(0, 3) + st.stats_execution.back().time_total + (float)st.stats_landmark.back().n_final;
 }
+// mono_vo.h:235-243, :267: what ros1/visual_odometry/mono_vo_ros1.cpp calls (:49 Landmark::setPatch, :60 the constructor
+// from (mode, YAML path), :123 trackImage, :126-190 the statistics, :199 getDebugImage) — plus the one binding the
+// integration adds: the reference's own calcPose5PointsAlgorithm as the 5-point solver
+float use_mono_vo(const cv::Mat &img, const double &timestamp) {
+  Landmark::setPatch(7);
+  MonoVO mvo("rosbag", "config/mono/mono0.yaml");
+  mvo.setFivePointSolver([](const PixelVec &pts0, const PixelVec &pts1, const Eigen::Matrix3f &K, Rot3 &R10, Pos3 &t10, MaskVec &mask) {
+    (void)pts0, (void)pts1, (void)K, (void)R10, (void)t10, (void)mask;  // motion_estimator_->calcPose5PointsAlgorithm(pts0, pts1, cam, R10, t10, X0, mask)
+    return true;
+  });
+  mvo.trackImage(img, timestamp);
+  const MonoVO::AlgorithmStatistics &st = mvo.getStatistics();
+  const PoseSE3 &Twc = st.stats_frame.back().Twc;
+  const cv::Mat &dbg = mvo.getDebugImage();
+  (void)dbg;
+  float acc = Twc(0, 3) + st.stats_execution.back().time_total + (float)st.stats_landmark.back().n_final + st.stats_landmark.back().avg_parallax;
+  for (const auto &kf : st.stats_keyframe) acc += kf.Twc(2, 3) + (kf.mappoints.empty() ? 0.0f : kf.mappoints[0](2));
+  return acc;
+}
 // the ROS 2 node as it stands (ros2/visual_odometry/stereo_vo_ros2.cpp:18-20, :104-166): constructed from (mode, YAML path),
 // publishes the last pose, the keyframes' trajectory and their map points
 float use_stereo_vo_like_the_ros2_node(const cv::Mat &img_left, const cv::Mat &img_right, const double &timestamp) {

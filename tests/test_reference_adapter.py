@@ -33,6 +33,35 @@ def test_adapter_type_checks_against_the_reference_own_headers():
         assert "/root/reference/" + h in r.stderr
 
 
+def test_ros_include_paths_resolve_to_the_adapter(tmp_path):
+    """The ROS nodes include core/visual_odometry/stereo_vo/stereo_vo.h (ros2/visual_odometry/stereo_vo_ros2.h:28,
+    ros1/.../stereo_vo_ros1.h:31), core/visual_odometry/mono_vo/mono_vo.h (ros1/.../mono_vo_ros1.h:32) and call
+    Landmark::setPatch: with visual_odometry_ros_amd/ros_include in front of the reference root those three names give the
+    libvo_hip-backed classes — what the nodes' own lines need type-checks against them."""
+    src = tmp_path / "ros_side.cpp"
+    src.write_text('''
+#include "core/visual_odometry/stereo_vo/stereo_vo.h"
+#include "core/visual_odometry/mono_vo/mono_vo.h"
+#include "core/visual_odometry/landmark.h"
+#include <memory>
+// ros2/visual_odometry/stereo_vo_ros2.cpp:18-20, :104; ros1/visual_odometry/mono_vo_ros1.cpp:49, :60, :123
+double node(const cv::Mat &l, const cv::Mat &r, double t, const std::string &dir) {
+  Landmark::setPatch(7);
+  std::unique_ptr<StereoVO> stereo_vo_ = std::make_unique<StereoVO>("rosbag", dir);
+  stereo_vo_->trackStereoImages(l, r, t);
+  std::unique_ptr<MonoVO> mono_vo_ = std::make_unique<MonoVO>("rosbag", dir);
+  mono_vo_->trackImage(l, t);
+  const StereoVO::AlgorithmStatistics &stat = stereo_vo_->getStatistics();
+  const MonoVO::AlgorithmStatistics &ms = mono_vo_->getStatistics();
+  return stat.stats_frame.back().Twc(0, 3) + ms.stats_frame.back().Twc(1, 3) + stat.stats_landmark.back().avg_age;
+}
+''')
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "visual_odometry_ros_amd", "ros_include"),
+                        "-I", os.path.join(STUBS, "reference"), "-I", ROOT, "-I", os.path.join(STUBS, "thirdparty"), "-fsyntax-only", str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
+
+
 def test_adapter_layout_conversions_round_trip(tmp_path, vo):
     """Column-major Eigen::Matrix4f -> row-major C ABI -> back, on a NON-symmetric matrix (a symmetric one would hide
     a missing transpose); runs on the CPU: no GPU entry point is called."""

@@ -27,6 +27,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <stdexcept>
 #include <vector>
@@ -40,6 +41,8 @@
 #include "feature_extractor.h"
 #include "feature_tracker.h"
 #include "motion_estimator.h"
+#include "mono_vo.h"
+#include "mono_vo_config.h"
 #include "stereo_vo.h"
 #include "stereo_vo_config.h"
 
@@ -402,6 +405,124 @@ class StereoVO {
   vo::StereoVO impl_;
   AlgorithmStatistics stat_;
   cv::Mat img_debug_;
+};
+
+
+// ===== MonoVO (core/visual_odometry/mono_vo/mono_vo.h:235-243, :267) =====================================================
+// MonoVO(mode, directory_intrinsic), trackImage(const cv::Mat&, const double&), getStatistics(), getDebugImage() with the
+// reference's signatures; the loop runs in libvo_hip.so (vo::MonoVO, mono_vo.h next to this file). The 5-point pose is the
+// one piece the library does not contain (OpenCV calib3d): bind MonoVO::setFivePointSolver to the reference's
+// own MotionEstimator::calcPose5PointsAlgorithm (motion_estimator.cpp:21-203 + findCorrectRT, kept from the reference tree)
+// before the first trackImage — INTEGRATION.md shows the three lines. getDebugImage() returns an empty image.
+class MonoVO {
+ public:
+  struct AlgorithmStatistics {  // the members the ROS node reads (ros1/visual_odometry/mono_vo_ros1.cpp:123-190)
+    struct FrameStatistics {
+      PoseSE3 Twc, Tcw, dT_01, dT_10;
+      PointVec mappoints;
+    };
+    using LandmarkStatistics = vo::MonoVO::AlgorithmStatistics::LandmarkStatistics;
+    using ExecutionStatistics = vo::MonoVO::AlgorithmStatistics::ExecutionStatistics;
+    struct KeyframeStatistics {
+      PoseSE3 Twc;
+      PointVec mappoints;
+    };
+    std::vector<LandmarkStatistics> stats_landmark;
+    std::vector<FrameStatistics> stats_frame;
+    std::vector<KeyframeStatistics> stats_keyframe;
+    std::vector<ExecutionStatistics> stats_execution;
+  };
+  // calcPose5PointsAlgorithm(pts0, pts1, cam, R10, t10, X0, mask) on the reference's types (X0 is unused by trackImage)
+  using FivePointSolver = std::function<bool(const PixelVec &pts0, const PixelVec &pts1, const Eigen::Matrix3f &K, Rot3 &R10, Pos3 &t10,
+                                             MaskVec &mask_inlier)>;
+
+  MonoVO(std::string mode, std::string directory_intrinsic) : MonoVO(with_statistics(vo::monoVOParamsForMode(mode, directory_intrinsic))) {}
+  explicit MonoVO(const vo::MonoVOParams &p, int device = 0)
+      : ctx_(std::make_shared<vo::Context>(device, p.width, p.height,
+                                           2 * p.feature_extractor.n_bins_u * p.feature_extractor.n_bins_v + 1024, 3,
+                                           p.feature_tracker.max_level)),
+        impl_(ctx_, p, [this](const vo::PixelVec &a, const vo::PixelVec &b, const float K[4], float R10[9], float t10[3],
+                              std::vector<std::uint8_t> &mask) { return this->five_point(a, b, K, R10, t10, mask); }) {}
+  ~MonoVO() noexcept(false) {}
+
+  void setFivePointSolver(FivePointSolver f) { solver_ = std::move(f); }
+
+  void trackImage(const cv::Mat &img, const double &timestamp) {
+    impl_.trackImage(vo_adapter::view(img), timestamp);
+    const auto &s = impl_.getStatistics();
+    AlgorithmStatistics::FrameStatistics f;
+    vo_adapter::from_row_major(s.stats_frame.back().Twc, f.Twc);
+    vo_adapter::from_row_major(s.stats_frame.back().Tcw, f.Tcw);
+    vo_adapter::from_row_major(s.stats_frame.back().dT_01, f.dT_01);
+    vo_adapter::from_row_major(s.stats_frame.back().dT_10, f.dT_10);
+    stat_.stats_frame.push_back(f);
+    stat_.stats_landmark.push_back(s.stats_landmark.back());
+    stat_.stats_execution.push_back(s.stats_execution.back());
+    if (impl_.lastFrameInfo().is_keyframe && !s.stats_keyframe.empty()) {
+      stat_.stats_keyframe.resize(s.stats_keyframe.size());
+      for (size_t j = 0; j < s.stats_keyframe.size(); ++j) {
+        vo_adapter::from_row_major(s.stats_keyframe[j].Twc, stat_.stats_keyframe[j].Twc);
+        stat_.stats_keyframe[j].mappoints.resize(s.stats_keyframe[j].mappoints.size());
+        for (size_t i = 0; i < s.stats_keyframe[j].mappoints.size(); ++i)
+          stat_.stats_keyframe[j].mappoints[i] = Point(s.stats_keyframe[j].mappoints[i].x, s.stats_keyframe[j].mappoints[i].y,
+                                                       s.stats_keyframe[j].mappoints[i].z);
+      }
+    }
+  }
+  const AlgorithmStatistics &getStatistics() const { return stat_; }
+  const cv::Mat &getDebugImage() { return img_debug_; }
+  vo::MonoVO &device() { return impl_; }
+
+ private:
+  static vo::MonoVOParams with_statistics(vo::MonoVOParams p) {
+    p.keyframe_statistics = true;
+    return p;
+  }
+  bool five_point(const vo::PixelVec &a, const vo::PixelVec &b, const float K[4], float R10[9], float t10[3], std::vector<std::uint8_t> &mask) {
+    if (!solver_) throw std::runtime_error("MonoVO: setFivePointSolver was not called (calcPose5PointsAlgorithm is the caller's)");
+    PixelVec p0, p1;
+    vo_adapter::from_vo(a, p0);
+    vo_adapter::from_vo(b, p1);
+    Eigen::Matrix3f Km;  // (element-wise: the type-check stand-in for Eigen has no comma initialiser)
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) Km(i, j) = 0.0f;
+    Km(0, 0) = K[0];
+    Km(0, 2) = K[2];
+    Km(1, 1) = K[1];
+    Km(1, 2) = K[3];
+    Km(2, 2) = 1.0f;
+    Rot3 R;
+    Pos3 t;
+    MaskVec m(a.size(), true);
+    if (!solver_(p0, p1, Km, R, t, m)) return false;
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) R10[i * 3 + j] = R(i, j);
+      t10[i] = t(i);
+    }
+    for (size_t i = 0; i < mask.size() && i < m.size(); ++i) mask[i] = m[i] ? 1 : 0;
+    return true;
+  }
+  vo::ContextPtr ctx_;
+  vo::MonoVO impl_;
+  FivePointSolver solver_;
+  AlgorithmStatistics stat_;
+  cv::Mat img_debug_;
+};
+
+// ===== Landmark::setPatch (core/visual_odometry/landmark.h:67-86) =========================================================
+// The ROS 1 nodes call it once before they construct the VO object (ros1/visual_odometry/stereo_vo_ros1.cpp:41,
+// mono_vo_ros1.cpp:49). In the reference the pattern it fills is read at one place only — the first observation of a
+// landmark copies it into a local vector that is dropped again (landmark.cpp:88-98) — so it has no effect on any result;
+// the call is accepted and the pattern kept, for source compatibility.
+class Landmark {
+ public:
+  inline static PixelVec patt_ = PixelVec();
+  static void setPatch(int half_win_sz) {
+    const int win_sz = 2 * half_win_sz + 1;
+    patt_.clear();
+    for (int v = 0; v < win_sz; ++v)
+      for (int u = !(v & 0x01); u < win_sz; u += 2) patt_.push_back(Pixel((float)(u - half_win_sz), (float)(v - half_win_sz)));
+  }
 };
 
 #endif  // VO_AMD_REFERENCE_ADAPTER_H_
