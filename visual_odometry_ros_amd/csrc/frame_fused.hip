@@ -29,6 +29,7 @@ struct FrameArgs {
   int max_level;               // effective OpenCV maxLevel
   int max_level_bwd;           // effective maxLevel of the candidates' backward track (maxLevel - 1 requested)
   int n;
+  int wg_off;                  // workgroup b of the launch is feature / candidate b + wg_off (the candidates as a launch of their own)
   int n_new;                   // new-point candidates (step [10])
   const float *pts_new;        // [n_new][2]
   const uint8_t *cand_has;     // closed step [10]: candidate j = best keypoint of bin j, absent where cand_has[j] == 0
@@ -116,7 +117,7 @@ __device__ __forceinline__ void frame_tail(const FrameArgs &a, int i, int ok, fl
 template <int WIN>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRAME_WAVES_PER_EU, FRAME_WAVES_PER_EU))) void frame_track_kernel(FrameArgs a) {
   __shared__ FrameShared<WIN> sh;
-  if ((int)blockIdx.x >= a.n + a.n_new) return;
+  if ((int)blockIdx.x + a.wg_off >= a.n + a.n_new) return;
   // Issue priority of the two roles (measured, -DFRAME_PRIO_FEAT / _CAND / -DFRAME_WAVES_PER_EU sweeps, 400 frames each,
   // run-to-run noise ~1.5 %): candidates one step above the features 162-165 us per launch, equal 169-171 us, features
   // above 170 us — the candidates are dispatched last (3150 workgroups, 2048 resident at 211 VGPRs) and the launch ends
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRAME_WAVES_
 #define FRAME_PRIO_FEAT 0
 #define FRAME_PRIO_CAND 1
 #endif
-  if ((int)blockIdx.x >= a.n)
+  if ((int)blockIdx.x + a.wg_off >= a.n)
     __builtin_amdgcn_s_setprio(FRAME_PRIO_CAND);
   else
     __builtin_amdgcn_s_setprio(FRAME_PRIO_FEAT);
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRAME_WAVES_
   // (tools/tools_config5.py): 795 us instead of 603 us per launch. The kernel is bound by the slowest
   // wavefronts, slow features cluster in image regions (borders, low texture), and a band per XCD
   // concentrates them on one eighth of the chip; round-robin spreads them.
-  const int i = blockIdx.x;
+  const int i = blockIdx.x + a.wg_off;
   const int lane = threadIdx.x;
   const bool feat = i < a.n;
   const int j = i - a.n;  // candidate index (new-point role)
@@ -457,11 +458,19 @@ static int vo_frame_fallback_grid(int n) { return n < 128 ? n : 128; }
 // phase 0: the per-feature kernel; phase 1: the strict-border replay (nothing otherwise). Two phases so that
 // the caller can feed other streams while the long first kernel is already running.
 template <int WIN>
-static void frame_launch(vo_ctx *c, const FrameArgs &a, int phase, int p1_target, int done_target, int conc_grid) {
+static void frame_launch(vo_ctx *c, const FrameArgs &a, int phase, int p1_target, int done_target, int conc_grid, int split_cands) {
   if (phase == 0) {
     vo_prof_begin(c, VO_K_KLT);
-    hipLaunchKernelGGL(frame_track_kernel<WIN>, dim3(a.n + a.n_new), dim3(64), 0, c->stream, a);
+    hipLaunchKernelGGL(frame_track_kernel<WIN>, dim3(split_cands ? a.n : a.n + a.n_new), dim3(64), 0, c->stream, a);
     vo_prof_end(c);
+    return;
+  }
+  if (phase == 2) {  // the candidates as a launch of their own (on c->stream: the caller's side stream, behind the detector)
+    if (a.n_new > 0) {
+      FrameArgs b = a;
+      b.wg_off = a.n;
+      hipLaunchKernelGGL(frame_track_kernel<WIN>, dim3(a.n_new), dim3(64), 0, c->stream, b);
+    }
     return;
   }
   if (a.strict == 2) {  // validation mode: the sequential fallback does all the work, on the main stream
@@ -608,10 +617,10 @@ int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, 
   const int cg_dbg = c->dbg[VO_DBG_CONC_GRID];  // (tests/test_frame_gpu.py: a pool smaller than the list; experiments)
   const int cg = cg_dbg > 0 ? cg_dbg : (b.conc_grid > 0 ? b.conc_grid : IC_CONC_GRID);
   switch (prm->win) {
-    case 13: frame_launch<13>(c, a, phase, p1_target, done_target, cg); break;
-    case 15: frame_launch<15>(c, a, phase, p1_target, done_target, cg); break;
-    case 21: frame_launch<21>(c, a, phase, p1_target, done_target, cg); break;
-    case 31: frame_launch<31>(c, a, phase, p1_target, done_target, cg); break;
+    case 13: frame_launch<13>(c, a, phase, p1_target, done_target, cg, b.split_cands); break;
+    case 15: frame_launch<15>(c, a, phase, p1_target, done_target, cg, b.split_cands); break;
+    case 21: frame_launch<21>(c, a, phase, p1_target, done_target, cg, b.split_cands); break;
+    case 31: frame_launch<31>(c, a, phase, p1_target, done_target, cg, b.split_cands); break;
     default: VO_FAIL(c, VO_ERR_INVALID, "fused frame kernel not instantiated for window %d", prm->win);
   }
   VO_CHECK_HIP(c, hipGetLastError());

@@ -118,6 +118,19 @@ int vo_frame_set_advance(vo_ctx *c, const VoAdvArgs *adv) {
   return VO_OK;
 }
 
+// StereoVO (stereo_vo.hip), trackStereoImages without look-ahead: the pair is in its slots but its keypoints are not
+// detected yet. The next vo_frame_enqueue_impl (closed frame on the fused path) then
+//   main stream:  frame kernel, features only -> replay -> ... BA launch
+//   side stream:  detection + per-bin table of slot_l1 -> frame kernel, candidates only
+// joined by one event in front of the BA launch — the 165 us detector chain runs under the features' tracking instead of
+// in front of it. Same results: the same kernels on the same inputs, in two launches instead of one.
+int vo_frame_set_deferred_detection(vo_ctx *c) {
+  int rc = vo_frame_init(c);
+  if (rc < 0) return rc;
+  c->frame->defer_detect = 1;
+  return VO_OK;
+}
+
 extern "C" int vo_stereo_frame_set_strict_border(vo_ctx *c, int strict) {
   if (!c) return VO_ERR_INVALID;
   c->frame_strict_ic = (strict >= 2 && strict <= 5) ? strict : (strict ? 1 : 0);
@@ -140,7 +153,10 @@ int vo_frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, i
                                        inputs_on_device, bp, table, T_pw, T_cw_prior);
   // a track-set advance armed by vo_frame_set_advance belongs to THIS enqueue, whether it got as far as the BA launch or
   // not: it never stays armed for a later frame of this context (its track sets may be gone by then)
-  if (c && c->frame) c->frame->adv_next.on = 0;
+  if (c && c->frame) {
+    c->frame->adv_next.on = 0;
+    c->frame->defer_detect = 0;
+  }
   return rc;
 }
 static int vo_frame_enqueue_body(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, int slot_l1, int slot_r1,
@@ -157,6 +173,12 @@ static int vo_frame_enqueue_body(vo_ctx *c, const vo_stereo_params *prm, int slo
     if (!vo_frame_fused_supported(prm->win))
       VO_FAIL(c, VO_ERR_INVALID, "the closed step [10] needs a window the fused frame kernel is built for (13, 15, 21, 31)");
     tab = vo_orb_cand_table(c, table);
+    if (c->frame && c->frame->defer_detect && (!tab || tab->n_bins != bp->n_bins_u * bp->n_bins_v)) {
+      // deferred detection into a table that does not exist yet (the stream's second frame): detect now, in stream order
+      c->frame->defer_detect = 0;
+      RC(vo_new_point_candidates_enqueue(c, slot_l1, bp, table));
+      tab = vo_orb_cand_table(c, table);
+    }
     if (!tab || tab->n_bins != bp->n_bins_u * bp->n_bins_v)
       VO_FAIL(c, VO_ERR_INVALID, "candidate table %d was not filled for %d x %d bins (vo_new_point_candidates_enqueue)", table,
               bp->n_bins_u, bp->n_bins_v);
@@ -202,7 +224,11 @@ static int vo_frame_enqueue_body(vo_ctx *c, const vo_stereo_params *prm, int slo
     d_r0 = f->in_r0;
     d_X = f->in_X;
   }
-  if (tab) VO_CHECK_HIP(c, hipStreamWaitEvent(s, tab->ready, 0));  // (filled on the side stream, long before)
+  // (the table is filled on the side stream, long before — unless its detection is deferred: then only the candidates'
+  // launch, on the side stream itself, reads it)
+  const bool split = tab && c->frame->defer_detect && vo_frame_fused_supported(prm->win) && n > 0 && c->ingest_side;
+  if (tab && c->frame->defer_detect && !split) RC(vo_new_point_candidates_enqueue(c, slot_l1, bp, table));  // (cannot overlap: now)
+  if (tab && !split) VO_CHECK_HIP(c, hipStreamWaitEvent(s, tab->ready, 0));
   // ---- carve the packed result block for this frame ----
   f->n = n;
   f->n_new = n_new;
@@ -293,6 +319,7 @@ static int vo_frame_enqueue_body(vo_ctx *c, const vo_stereo_params *prm, int slo
     b.new_r = tab ? f->bin_r : f->new_r;   // closed: per-bin scratch, compacted into the block by the BA launch
     b.m_new = tab ? f->bin_m : f->mNew;
     b.cand_has = tab ? tab->has : nullptr;
+    b.split_cands = split ? 1 : 0;
     // what vo_stereo_frame_result needs to issue this frame again (device pointers only)
     f->again.prm = *prm;
     f->again.slot_l0 = slot_l0;
@@ -322,6 +349,18 @@ static int vo_frame_enqueue_body(vo_ctx *c, const vo_stereo_params *prm, int slo
     VO_TT("track launch");
     if (rcf >= 0)
       rcf = vo_frame_fused_enqueue(c, prm, slot_l0, slot_l1, slot_r1, d_l0, d_r0, d_X, d_fl, n, T_cp, T_rl, d_new, n_new, b, 1, T_pw);
+    if (rcf >= 0 && split) {
+      // the features are on their way: now the detector chain of the current left image and, behind it on the same (side)
+      // stream, the candidates' launch; the BA launch waits for both through ev_join
+      rcf = vo_new_point_candidates_enqueue(c, slot_l1, bp, table);
+      if (rcf >= 0) {
+        c->stream = c->stream2;
+        rcf = vo_frame_fused_enqueue(c, prm, slot_l0, slot_l1, slot_r1, d_l0, d_r0, d_X, d_fl, n, T_cp, T_rl, d_new, n_new, b, 2, T_pw);
+        c->stream = s;
+        if (rcf >= 0 && hipEventRecord(c->ev_join, c->stream2) != hipSuccess) rcf = VO_ERR_HIP;
+        if (rcf >= 0 && hipStreamWaitEvent(s, c->ev_join, 0) != hipSuccess) rcf = VO_ERR_HIP;
+      }
+    }
     if (rcf < 0) {  // nothing of this frame will count: the cumulative hand-shake targets go back
       f->sync_p1_target = p1_before;
       f->sync_done_target = done_before;

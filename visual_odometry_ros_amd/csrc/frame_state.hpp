@@ -76,6 +76,10 @@ struct vo_frame_state {
   // StereoVO: what the NEXT enqueue hands to the BA launch so that its epilogue builds the next track set
   // (vo_frame_set_advance, consumed by that enqueue); the DLT workers' cumulative completion count and its running target
   VoAdvArgs adv_next;
+  // StereoVO's synchronous call (no pair handed over early): the NEXT enqueue starts the features' part of the frame
+  // kernel at once, runs the keypoint detection of slot_l1 on the side stream next to it and tracks the candidates as a
+  // launch of their own behind the detection (vo_frame_set_deferred_detection, consumed by that enqueue)
+  int defer_detect;
   int *adv_done;
   int adv_total;
   int recovered;      // the last result was produced by such a re-issue

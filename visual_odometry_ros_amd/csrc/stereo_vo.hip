@@ -35,6 +35,7 @@ int vo_frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, i
                           const float dT_prior[16], const float *pts_new, int n_new, int inputs_on_device,
                           const vo_bin_params *bp, int table, const float *T_pw, const float *T_cw_prior);
 int vo_frame_set_advance(vo_ctx *c, const VoAdvArgs *adv);          // frame_pipeline.hip
+int vo_frame_set_deferred_detection(vo_ctx *c);
 
 #define RC(x)                \
   do {                       \
@@ -276,8 +277,9 @@ enum { S_P = 0, S_CL = 1, S_CR = 2, S_NL = 3, S_NR = 4 };
 static double svo_now();
 static const bool g_trace = getenv("VO_SVO_TRACE") != nullptr;  // (read once, never written: the accumulators are per StereoVO)
 
-// the pair into the "next" slots + its candidate table (side stream)
-static int svo_ingest(vo_svo *s, const void *left, const void *right, int stride, int on_device) {
+// the pair into the "next" slots + its candidate table (side stream); detect = false: the images and pyramids only (the
+// synchronous call defers the detection to the frame's enqueue, where it runs next to the features' tracking)
+static int svo_ingest(vo_svo *s, const void *left, const void *right, int stride, int on_device, bool detect = true) {
   vo_ctx *c = s->c;
   const int W = s->prm.frame.width, H = s->prm.frame.height;
   if (s->prm.rectify) {
@@ -293,7 +295,7 @@ static int svo_ingest(vo_svo *s, const void *left, const void *right, int stride
   } else {
     RC(vo_set_stereo_pair_host_async(c, s->slot[S_NL], (const uint8_t *)left, s->slot[S_NR], (const uint8_t *)right, W, H, stride));
   }
-  RC(vo_new_point_candidates_enqueue(c, s->slot[S_NL], &s->prm.bins, s->tab_next));
+  if (detect) RC(vo_new_point_candidates_enqueue(c, s->slot[S_NL], &s->prm.bins, s->tab_next));
   return VO_OK;
 }
 
@@ -322,7 +324,14 @@ extern "C" int vo_svo_enqueue(vo_svo *s, const void *left, const void *right, in
   // what can be refused is refused before any state changes (an empty track set is the reference's throw at :626)
   if (!s->first && s->n <= 0) VO_FAIL(c, VO_ERR_GN_FAILED, "the track set is empty: PoseOnlyStereoBA is failed!");
   // the pair goes into the NEXT slots and the next candidate table: nothing the loop reads changes if this fails
-  if (!(s->prefetched && s->pre_l == left && s->pre_r == right)) RC(svo_ingest(s, left, right, stride, on_device));
+  // No pair handed over early (trackStereoImages as the reference's caller uses it): the images and pyramids go in now, the
+  // keypoint detection is deferred into the frame's enqueue, where it runs on the side stream NEXT TO the features' tracking
+  // and the candidates follow as a launch of their own (frame_pipeline.hip: vo_frame_set_deferred_detection)
+  bool deferred = false;
+  if (!(s->prefetched && s->pre_l == left && s->pre_r == right)) {
+    deferred = !s->first && s->c->ingest_side;
+    RC(svo_ingest(s, left, right, stride, on_device, !deferred));
+  }
   // from here on the driver's state moves; every error return below puts it back (slots, tables, both id counters), so
   // that the caller can hand the pair over again — or another one — and track against the right previous image
   struct {
@@ -385,7 +394,8 @@ extern "C" int vo_svo_enqueue(vo_svo *s, const void *left, const void *right, in
     a.cap = s->cap;
     a.hdr_dev = s->d_hdr;
     a.hdr_host = s->h_hdr;
-    const int rc = vo_frame_set_advance(c, &a);
+    int rc = vo_frame_set_advance(c, &a);
+    if (rc >= 0 && deferred) rc = vo_frame_set_deferred_detection(c);
     if (rc < 0) return undo(rc);
   }
   int rc = vo_frame_enqueue_impl(c, &s->prm.frame, s->slot[S_P], s->slot[S_CL], s->slot[S_CR], t.pts_l, t.pts_r, t.Xw, t.flags,

@@ -108,6 +108,7 @@ struct vo_frame_fused_bufs {
   int *sync;       // [0] features past pass 1, [1] replay workgroups finished: cumulative over the frames
   int *sync_p1_target, *sync_done_target;  // host-side running totals (updated by the enqueue)
   int conc_grid;   // concurrent replay: workgroups of the pool
+  int split_cands; // phase 0 launches the features only; the candidates follow as phase 2 (behind a detection still in flight)
   int *hdr_flags;  // where the frame's error flags are reported
   float *C_X, *C_pl1, *C_pr1;
   int32_t *C_orig;
