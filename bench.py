@@ -97,11 +97,16 @@ def stamped_counters(config, workload="loop"):
         sha = kernel_source_sha()
     except Exception:
         return out
-    tag = ("r03" if config == 1 else f"r03_cfg{config}") + ("" if workload == "loop" else f"_{workload}")
     stale = []
-    for key, name in (("pmc", f"{tag}_frame_pmc.json"), ("sq", f"{tag}_frame_sq_counters.json")):
-        path = os.path.join(ROOT, "profiles", name)
-        if not os.path.exists(path):
+    for key, suffix in (("pmc", "_frame_pmc.json"), ("sq", "_frame_sq_counters.json")):
+        path = name = None
+        for rnd in ("r04", "r03"):  # the newest round's pass that exists
+            tag = (rnd if config == 1 else f"{rnd}_cfg{config}") + ("" if workload == "loop" else f"_{workload}")
+            if os.path.exists(os.path.join(ROOT, "profiles", tag + suffix)):
+                name = tag + suffix
+                path = os.path.join(ROOT, "profiles", name)
+                break
+        if path is None:
             continue
         try:
             d = json.load(open(path))

@@ -1113,6 +1113,10 @@ __device__ __forceinline__ int ic_replay(const IcArgs &a, IcReplayShared &rs, in
         IcPrep pr = prep;
         if (!single) pr = ic_prepare<true>(a.I0, a.I1, tp, p0x, p0y, q1x, q1y, lane, sh, S, dummy);
         res_pt = ic_iterate<true>(a.I1, tp, pr, p0x, p0y, q1x, q1y, ic_in<CONC>(&a.scale[pt]), lane, sh, S, dummy, lx, ly, n_iter);
+#ifdef IC_REPLAY_EXTRA_SLEEP  // measurement build: every replayed iteration made LONGER by s_sleep(IC_REPLAY_EXTRA_SLEEP) — 64 cycles
+        // each — to read off how much of an iteration's cost is on the frame's critical path
+        for (int q = 0; q < n_iter; ++q) __builtin_amdgcn_s_sleep(IC_REPLAY_EXTRA_SLEEP);
+#endif
         if (lane == 0) {
           if (res_pt.err_flag) atomicOr(a.flags, res_pt.err_flag);
           a.pts_track[2 * pt] = res_pt.x;
