@@ -26,7 +26,7 @@ class TruePoseHook:
         return True, T10[:3, :3].astype(np.float32), T10[:3, 3].astype(np.float32), np.ones(len(pts0), bool)
 
 
-def _run_both(vo, oracle, n_frames, lba, strict, kf_trans, seed=5, prefetch=False, W=752, H=480, nu=40, nv=25, win=15, lvl=5):
+def _run_both(vo, oracle, n_frames, lba, strict, kf_trans, seed=5, prefetch=False, W=752, H=480, nu=40, nv=25, win=15, lvl=5, parallax_deg=1.0):
     from oracle.mono_vo import MonoVORef
     from visual_odometry_ros_amd import synthetic as S
     st = S.StereoStream(width=W, height=H, K=MONO_K, n_u=nu, n_v=nv, seed=seed, speed=0.25)
@@ -34,13 +34,13 @@ def _run_both(vo, oracle, n_frames, lba, strict, kf_trans, seed=5, prefetch=Fals
     imgs = [st.render_pair(p)[0] for p in poses]
     hook_g, hook_r = TruePoseHook(poses), TruePoseHook(poses)
     ref = MonoVORef(W, H, MONO_K, nu, nv, hook_r, thres_fast=15, win=win, max_level=lvl, thres_err=20.0, thres_bidir=1.0, thres_poseba=5,
-                    thres_sampson=1.0, thres_parallax_deg=1.0, kf_trans=kf_trans, lba=lba, sum_mode=oracle.SUM_TREE, tree_width=512,
+                    thres_sampson=1.0, thres_parallax_deg=parallax_deg, kf_trans=kf_trans, lba=lba, sum_mode=oracle.SUM_TREE, tree_width=512,
                     ic_border=oracle.IC_REFERENCE if strict else oracle.IC_MASKED, n_threads=8)
     c = vo.Context(device=0, max_width=W, max_height=H, max_points=2 * nu * nv + 512, n_slots=3, max_level=lvl)
     log = []
     try:
         mvo = vo.MonoVO(c, W, H, MONO_K, nu, nv, hook_g, thres_fastscore=15, window_size=win, max_level=lvl, thres_error=20.0,
-                        thres_bidirection=1.0, thres_poseba_error=5, thres_sampson=1.0, thres_parallax=1.0, thres_translation=kf_trans,
+                        thres_bidirection=1.0, thres_poseba_error=5, thres_sampson=1.0, thres_parallax=parallax_deg, thres_translation=kf_trans,
                         strict_border=strict, local_ba=lba)
         for k in range(n_frames):
             hook_g.k = hook_r.k = k
@@ -97,3 +97,14 @@ def test_mono_loop_config3_local_ba(vo, oracle):
     assert sum(1 for e in log if e[0]) >= 4, log
     assert sum(1 for e in log if e[2]) >= 2, log
     assert any(ref.lm[int(i)]["bundled"] for i in ref.ids)
+
+
+def test_mono_loop_five_point_fallback(vo, oracle):
+    """The pose-only BA has nothing to work with (a parallax threshold no landmark reaches: nothing is ever triangulated), so
+    every steady-state frame takes the 5-point path of mono_vo.cpp:909-949 — the hook's pose with the previous motion's length,
+    the hook's mask as mask_motion, the Sampson gate and the new points driven from the host — and the loop still equals the
+    CPU loop after every frame."""
+    log, ref = _run_both(vo, oracle, 6, lba=True, strict=1, kf_trans=2.5, parallax_deg=80.0)
+    assert all(e[4] for e in log[1:]), log  # the hook at the initialisation and at every frame after it
+    assert not any(ref.lm[int(i)]["tri"] for i in ref.ids)
+    assert log[-1][1] > 300
