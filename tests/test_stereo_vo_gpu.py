@@ -352,6 +352,11 @@ def test_closed_loop_survives_a_join_timeout():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
                         "test_closed_loop_small and 3-True"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    # the synchronous call (no prefetch): the BA launch's device-side join on the candidates' own launch cannot be met either —
+    # the frame is issued again with everything in stream order
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "test_closed_loop_small and 4-False"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_from_yaml_runs_the_references_configuration(vo, oracle, tmp_path):

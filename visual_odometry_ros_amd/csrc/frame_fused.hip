@@ -30,6 +30,8 @@ struct FrameArgs {
   int max_level_bwd;           // effective maxLevel of the candidates' backward track (maxLevel - 1 requested)
   int n;
   int wg_off;                  // workgroup b of the launch is feature / candidate b + wg_off (the candidates as a launch of their own)
+  int *cand_done;              // non-null (candidates' own launch): results are written through and every candidate workgroup
+                               // counts itself here when it is done — the BA launch, running meanwhile, joins on the count
   int n_new;                   // new-point candidates (step [10])
   const float *pts_new;        // [n_new][2]
   const uint8_t *cand_has;     // closed step [10]: candidate j = best keypoint of bin j, absent where cand_has[j] == 0
@@ -199,7 +201,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRAME_WAVES_
     iy = ply;
   } else {
     if (a.cand_has && !a.cand_has[j]) {  // a bin without a keypoint
-      if (lane == 0) a.m_new[j] = 0;
+      if (lane == 0) {
+        if (a.cand_done) {
+          ic_st8(&a.m_new[j], 0);
+          __builtin_amdgcn_s_waitcnt(0);
+          __hip_atomic_fetch_add(a.cand_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          a.m_new[j] = 0;
+        }
+      }
       return;
     }
     p0x = ix = a.pts_new[2 * j];
@@ -240,9 +250,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRAME_WAVES_
       bool m = first.x > 3 && first.x < a.W - 3 && first.y > 3 && first.y < a.H - 3;
       m = m && first.status && k.status && first.err <= a.thres_err && k.err <= a.thres_err && dist2 <= thres2;
       if (lane == 0) {
-        a.new_r[2 * j] = first.x;
-        a.new_r[2 * j + 1] = first.y;
-        a.m_new[j] = m ? 1 : 0;
+        if (a.cand_done) {  // (read by a kernel that is running: write-through, then the count)
+          ic_store<true>(&a.new_r[2 * j], first.x);
+          ic_store<true>(&a.new_r[2 * j + 1], first.y);
+          ic_st8(&a.m_new[j], (uint8_t)(m ? 1 : 0));
+          __builtin_amdgcn_s_waitcnt(0);
+          __hip_atomic_fetch_add(a.cand_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          a.new_r[2 * j] = first.x;
+          a.new_r[2 * j + 1] = first.y;
+          a.m_new[j] = m ? 1 : 0;
+        }
       }
       return;
     }
@@ -458,7 +476,8 @@ static int vo_frame_fallback_grid(int n) { return n < 128 ? n : 128; }
 // phase 0: the per-feature kernel; phase 1: the strict-border replay (nothing otherwise). Two phases so that
 // the caller can feed other streams while the long first kernel is already running.
 template <int WIN>
-static void frame_launch(vo_ctx *c, const FrameArgs &a, int phase, int p1_target, int done_target, int conc_grid, int split_cands) {
+static void frame_launch(vo_ctx *c, const FrameArgs &a, int phase, int p1_target, int done_target, int conc_grid, int split_cands,
+                         int *cand_done) {
   if (phase == 0) {
     vo_prof_begin(c, VO_K_KLT);
     hipLaunchKernelGGL(frame_track_kernel<WIN>, dim3(split_cands ? a.n : a.n + a.n_new), dim3(64), 0, c->stream, a);
@@ -469,6 +488,7 @@ static void frame_launch(vo_ctx *c, const FrameArgs &a, int phase, int p1_target
     if (a.n_new > 0) {
       FrameArgs b = a;
       b.wg_off = a.n;
+      b.cand_done = cand_done;
       hipLaunchKernelGGL(frame_track_kernel<WIN>, dim3(a.n_new), dim3(64), 0, c->stream, b);
     }
     return;
@@ -617,10 +637,10 @@ int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, 
   const int cg_dbg = c->dbg[VO_DBG_CONC_GRID];  // (tests/test_frame_gpu.py: a pool smaller than the list; experiments)
   const int cg = cg_dbg > 0 ? cg_dbg : (b.conc_grid > 0 ? b.conc_grid : IC_CONC_GRID);
   switch (prm->win) {
-    case 13: frame_launch<13>(c, a, phase, p1_target, done_target, cg, b.split_cands); break;
-    case 15: frame_launch<15>(c, a, phase, p1_target, done_target, cg, b.split_cands); break;
-    case 21: frame_launch<21>(c, a, phase, p1_target, done_target, cg, b.split_cands); break;
-    case 31: frame_launch<31>(c, a, phase, p1_target, done_target, cg, b.split_cands); break;
+    case 13: frame_launch<13>(c, a, phase, p1_target, done_target, cg, b.split_cands, b.cand_done); break;
+    case 15: frame_launch<15>(c, a, phase, p1_target, done_target, cg, b.split_cands, b.cand_done); break;
+    case 21: frame_launch<21>(c, a, phase, p1_target, done_target, cg, b.split_cands, b.cand_done); break;
+    case 31: frame_launch<31>(c, a, phase, p1_target, done_target, cg, b.split_cands, b.cand_done); break;
     default: VO_FAIL(c, VO_ERR_INVALID, "fused frame kernel not instantiated for window %d", prm->win);
   }
   VO_CHECK_HIP(c, hipGetLastError());

@@ -67,6 +67,8 @@ int vo_frame_init(vo_ctx *c) {
   // [1] = finished workgroups of the replay's last kernel; from byte 128 on: 64 shards of the pass-1 count, 128 bytes apart
   VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&f->adv_done, 64));
   VO_CHECK_HIP(c, hipMemsetAsync(f->adv_done, 0, 64, c->stream));
+  VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&f->cand_done, 64));
+  VO_CHECK_HIP(c, hipMemsetAsync(f->cand_done, 0, 64, c->stream));
   VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&f->sync, 128 + 64 * 128));
   VO_CHECK_HIP(c, hipMemsetAsync(f->sync, 0, 128 + 64 * 128, c->stream));
   return VO_OK;
@@ -79,7 +81,7 @@ void vo_frame_free(vo_ctx *c) {
                   f->A_X, f->A_scale, f->A_orig, f->B_pl1, f->B_pr1, f->B_X, f->B_orig, f->C_pl1, f->C_pr1,
                   f->C_X, f->C_orig, f->m1, f->m2, f->m3, f->mG, f->st1, f->st2, f->e1, f->e2, f->new_back,
                   f->A_ref, f->A_lastpu, f->A_touched, f->A_cls, f->res_dev, f->st3, f->e3, f->ctl, f->sync, f->in_flags, f->bin_r,
-                  f->bin_m, f->adv_done};
+                  f->bin_m, f->adv_done, f->cand_done};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   if (f->res_host) (void)hipHostFree(f->res_host);
@@ -226,7 +228,7 @@ static int vo_frame_enqueue_body(vo_ctx *c, const vo_stereo_params *prm, int slo
   }
   // (the table is filled on the side stream, long before — unless its detection is deferred: then only the candidates'
   // launch, on the side stream itself, reads it)
-  const bool split = tab && c->frame->defer_detect && vo_frame_fused_supported(prm->win) && n > 0 && c->ingest_side;
+  const bool split = tab && c->frame->defer_detect && vo_frame_fused_supported(prm->win) && n > 0 && c->ingest_side && !c->frame_conc_off;
   if (tab && c->frame->defer_detect && !split) RC(vo_new_point_candidates_enqueue(c, slot_l1, bp, table));  // (cannot overlap: now)
   if (tab && !split) VO_CHECK_HIP(c, hipStreamWaitEvent(s, tab->ready, 0));
   // ---- carve the packed result block for this frame ----
@@ -290,6 +292,7 @@ static int vo_frame_enqueue_body(vo_ctx *c, const vo_stereo_params *prm, int slo
   if (T_cw_prior) memcpy(T_cp, T_cw_prior, sizeof(T_cp));  // world points: X_l1 = T_cw_prior * X (stereo_vo.cpp:493)
 
   if (n_new > 0 && !fused) VO_CHECK_HIP(c, hipEventRecord(c->ev_fork, s));  // the new pyramids are enqueued before this point
+  bool cand_joined = false;  // the candidates went out as a launch of their own on the side stream: the BA launch joins them
 
   if (fused) {
     // steps [3] .. [5] of a feature are one wavefront of ONE launch (frame_fused.hip)
@@ -320,6 +323,7 @@ static int vo_frame_enqueue_body(vo_ctx *c, const vo_stereo_params *prm, int slo
     b.m_new = tab ? f->bin_m : f->mNew;
     b.cand_has = tab ? tab->has : nullptr;
     b.split_cands = split ? 1 : 0;
+    b.cand_done = split ? f->cand_done : nullptr;
     // what vo_stereo_frame_result needs to issue this frame again (device pointers only)
     f->again.prm = *prm;
     f->again.slot_l0 = slot_l0;
@@ -357,8 +361,13 @@ static int vo_frame_enqueue_body(vo_ctx *c, const vo_stereo_params *prm, int slo
         c->stream = c->stream2;
         rcf = vo_frame_fused_enqueue(c, prm, slot_l0, slot_l1, slot_r1, d_l0, d_r0, d_X, d_fl, n, T_cp, T_rl, d_new, n_new, b, 2, T_pw);
         c->stream = s;
-        if (rcf >= 0 && hipEventRecord(c->ev_join, c->stream2) != hipSuccess) rcf = VO_ERR_HIP;
-        if (rcf >= 0 && hipStreamWaitEvent(s, c->ev_join, 0) != hipSuccess) rcf = VO_ERR_HIP;
+        // (no event: the BA launch joins the candidates on the device — its DLT workers and its epilogue wait for the
+        // count of finished candidate workgroups, bounded; a cross-queue event pair in front of the BA launch kept its
+        // iterations from running under the detection)
+        if (rcf >= 0) {
+          cand_joined = true;
+          f->cand_total += n_new;  // (cumulative, like the word the candidate workgroups count in)
+        }
       }
     }
     if (rcf < 0) {  // nothing of this frame will count: the cumulative hand-shake targets go back
@@ -517,6 +526,11 @@ static int vo_frame_enqueue_body(vo_ctx *c, const vo_stereo_params *prm, int slo
       gf.np_host_l = (float *)(f->res_host + f->off_newl);
       gf.np_host_r = (float *)(f->res_host + f->off_newr);
       gf.np_host_m = f->res_host + f->off_mnew;
+      if (cand_joined) {
+        gf.np_cand_done = f->cand_done;
+        gf.np_cand_target = f->cand_total;
+        if (c->dbg[VO_DBG_FAIL_JOIN]) gf.np_cand_target += 1 << 20;  // tests: a join that cannot be met
+      }
     }
   }
   VoAdvArgs adv_now = f->adv_next;
@@ -642,7 +656,10 @@ extern "C" int vo_stereo_frame_result(vo_ctx *c, float *pts_l1, float *pts_r1, u
     // a busy GPU, a stalled main stream). The frame is not lost: drain both streams, re-base the hand-shake words, switch
     // the context to the stream-ordered replay for good and issue the frame again from its (intact) device inputs.
     VO_CHECK_HIP(c, hipStreamSynchronize(c->stream3));
+    VO_CHECK_HIP(c, hipStreamSynchronize(c->stream2));
     VO_CHECK_HIP(c, hipStreamSynchronize(c->stream_main));
+    VO_CHECK_HIP(c, hipMemsetAsync(f->cand_done, 0, 64, c->stream_main));
+    f->cand_total = 0;
     VO_CHECK_HIP(c, hipMemsetAsync(f->sync, 0, 128 + 64 * 128, c->stream_main));
     VO_CHECK_HIP(c, hipMemsetAsync(f->ctl, 0, vo_ic_ctl_bytes(), c->stream_main));
     f->sync_p1_target = f->sync_done_target = 0;

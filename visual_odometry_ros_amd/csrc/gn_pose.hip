@@ -457,11 +457,19 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
     // positive. One wavefront per 64 bins; the verdicts are written through, then the wavefront counts itself done.
     if (STEREO && wave == 0 && a.adv.on) {
       const int b = ((int)blockIdx.x - 1) * 64 + lane;
+      if (a.np.cand_done) {  // the candidates' own launch may still be running (synchronous call): bounded join
+        int ok = 1;
+        if (lane == 0) ok = vo_np_wait_candidates(a.np) ? 1 : 0;
+        ok = __builtin_amdgcn_readfirstlane(ok);
+        if (!ok && lane == 0) atomicOr(a.f_hdr_flags, 8);  // (0.1 s later than the prologue's report: straight into the header;
+                                                           //  the frame is then issued again in stream order)
+      }
       if (b < a.np.bins) {
         int acc = 0;
-        if (a.np.has[b] && a.np.bin_m[b]) {
+        if (vo_np_ld8(a.np, &a.np.has[b]) && vo_np_ld8(a.np, &a.np.bin_m[b])) {
           float Xl[3], Xr[3];
-          svo_triangulate(a.adv.cam, a.np.xy[2 * b], a.np.xy[2 * b + 1], a.np.bin_r[2 * b], a.np.bin_r[2 * b + 1], Xl, Xr);
+          svo_triangulate(a.adv.cam, vo_np_ldf(a.np, &a.np.xy[2 * b]), vo_np_ldf(a.np, &a.np.xy[2 * b + 1]), vo_np_ldf(a.np, &a.np.bin_r[2 * b]),
+                          vo_np_ldf(a.np, &a.np.bin_r[2 * b + 1]), Xl, Xr);
           acc = (Xl[2] > 0 && Xr[2] > 0) ? 1 : 0;
         }
         __hip_atomic_store(&a.adv.acc_bin[b], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -801,6 +809,10 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
       __syncthreads();
     }
     GSTAMP(6)
+    if (a.np.bins > 0 && a.np.cand_done) {  // (the candidates' own launch: see VoNpArgs::cand_done)
+      if (tid == 0 && !vo_np_wait_candidates(a.np)) atomicOr(a.f_hdr_flags, 8);
+      __syncthreads();
+    }
     if (a.np.bins > 0) {
       // ---- closed step [10]: updateWeightBin(lmtrack_final.pts_l1) + emission (np_emit.hpp), with the
       // trackBidirection results (stereo_vo.cpp:706-711) the frame kernel computed for every bin's candidate.
@@ -1067,6 +1079,8 @@ int vo_gn_enqueue(vo_ctx *c, bool stereo, bool mono_general_inverse, const float
     a.np.host_l = frame->np_host_l;
     a.np.host_r = frame->np_host_r;
     a.np.host_m = frame->np_host_m;
+    a.np.cand_done = frame->np_cand_done;
+    a.np.cand_target = frame->np_cand_target;
     if (frame->adv && frame->adv->on) {
       a.adv = *frame->adv;
       a.np.acc_bin = a.adv.acc_bin;

@@ -15,6 +15,9 @@ struct VoNpArgs {
   uint8_t *out_m;
   float *host_l, *host_r;   // the same places in the pinned host block, or null (the caller copies the block)
   uint8_t *host_m;
+  const int *cand_done;     // non-null: the candidates are tracked by a launch of their own that may still be RUNNING (the
+  int cand_target;          // synchronous call): wait until *cand_done has reached cand_target (cumulative, bounded), then read
+                            // has / xy / bin_r / bin_m past the caches — they were written while this kernel ran
   const int *acc_bin;       // StereoVO: [bins] DLT depth test of every bin's candidate (written through by the workers), or null
   uint8_t *out_acc;         // StereoVO: [emitted] trackBidirection mask && depth test = the candidate becomes a landmark
 };
@@ -24,6 +27,22 @@ struct VoNpArgs {
 // *count) the number of candidates emitted. feature_extractor.h:116-135 (updateWeightBin: reset to 1, then 0 for every
 // bin that holds a final feature; only the flattened index is range-tested, :130), feature_extractor.cpp:262-277
 // (bins ascending, weight > 0).
+// bounded device-side join on the candidates' launch (one lane polls; true = arrived)
+__device__ __forceinline__ bool vo_np_wait_candidates(const VoNpArgs &a) {
+  int polls = 0;
+  while ((int)(__hip_atomic_load(a.cand_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.cand_target) < 0) {
+    if (++polls > (1 << 17)) return false;  // ~0.1 s: the side stream does not run next to this kernel
+    __builtin_amdgcn_s_sleep(16);
+  }
+  return true;
+}
+__device__ __forceinline__ int vo_np_ld8(const VoNpArgs &a, const uint8_t *p) {
+  return a.cand_done ? (int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (int)*p;
+}
+__device__ __forceinline__ float vo_np_ldf(const VoNpArgs &a, const float *p) {
+  return a.cand_done ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+
 template <typename Final>
 __device__ __forceinline__ void vo_np_emit(const VoNpArgs &a, int n, const float *pix, Final final, int tid, int nthr,
                                            uint8_t *s_occ, int *s_wv, int *count) {
@@ -48,7 +67,7 @@ __device__ __forceinline__ void vo_np_emit(const VoNpArgs &a, int n, const float
 #pragma unroll
     for (int q = 0; q < NCH; ++q) {
       const int j = c0 + q * nthr + tid;
-      keep[q] = j < a.bins && a.has[j] && !s_occ[j];
+      keep[q] = j < a.bins && vo_np_ld8(a, &a.has[j >= a.bins ? 0 : j]) && !s_occ[j];
       const unsigned long long bal = __ballot(keep[q]);
       below[q] = __popcll(bal & ((1ull << lane) - 1ull));
       if (lane == 0) s_wv[q * nw + wave] = __popcll(bal);
@@ -66,8 +85,9 @@ __device__ __forceinline__ void vo_np_emit(const VoNpArgs &a, int n, const float
       if (keep[q]) {
         const int j = c0 + q * nthr + tid;
         const int o = off + woff + below[q];
-        const float lx = a.xy[2 * j], ly = a.xy[2 * j + 1], rx = a.bin_r[2 * j], ry = a.bin_r[2 * j + 1];
-        const uint8_t mk = a.bin_m[j];
+        const float lx = vo_np_ldf(a, &a.xy[2 * j]), ly = vo_np_ldf(a, &a.xy[2 * j + 1]);
+        const float rx = vo_np_ldf(a, &a.bin_r[2 * j]), ry = vo_np_ldf(a, &a.bin_r[2 * j + 1]);
+        const uint8_t mk = (uint8_t)vo_np_ld8(a, &a.bin_m[j]);
         a.out_l[2 * o] = lx;
         a.out_l[2 * o + 1] = ly;
         a.out_r[2 * o] = rx;

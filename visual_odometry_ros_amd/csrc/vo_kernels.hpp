@@ -42,6 +42,8 @@ struct vo_gn_frame {
   uint8_t *np_out_m;
   float *np_host_l, *np_host_r;  // the same places in the pinned host block (written entry by entry, not copied)
   uint8_t *np_host_m;
+  const int *np_cand_done;  // VoNpArgs::cand_done / cand_target
+  int np_cand_target;
   const struct VoAdvArgs *adv;   // StereoVO: the epilogue also builds the next track set (svo_device.hpp)
 };
 int vo_gn_enqueue(vo_ctx *c, bool stereo, bool mono_general_inverse, const float *dX, const float *dP1,
@@ -109,6 +111,7 @@ struct vo_frame_fused_bufs {
   int *sync_p1_target, *sync_done_target;  // host-side running totals (updated by the enqueue)
   int conc_grid;   // concurrent replay: workgroups of the pool
   int split_cands; // phase 0 launches the features only; the candidates follow as phase 2 (behind a detection still in flight)
+  int *cand_done;  // phase 2: cumulative count of finished candidate workgroups (the BA launch joins on it), or null
   int *hdr_flags;  // where the frame's error flags are reported
   float *C_X, *C_pl1, *C_pr1;
   int32_t *C_orig;
