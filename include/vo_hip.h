@@ -478,6 +478,8 @@ typedef struct vo_batch vo_batch;
 int vo_batch_create(const vo_config *cfg, const vo_svo_params *prm, int n_streams, vo_batch **out);
 void vo_batch_destroy(vo_batch *batch);
 const char *vo_batch_last_error(const vo_batch *batch);
+/* vo_debug_set on every stream's context (measurement switches, e.g. VO_DBG_SKIP_DETECT) */
+int vo_batch_debug_set(vo_batch *batch, int key, int value);
 int vo_batch_run(vo_batch *batch, const void *const *left, const void *const *right, int n_frames, int stride, int on_device,
                  int warmup, float *T_wc, int32_t *last_ids, int ids_cap, int *n_ids, double *seconds, double *wall);
 

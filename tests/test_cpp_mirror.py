@@ -33,6 +33,7 @@ def test_cpp_mirror_compiles_and_links(vo, tmp_path):
     assert os.path.exists(exe)
     assert os.path.exists(_compile(tmp_path, "frame_demo"))
     assert os.path.exists(_compile(tmp_path, "stereo_vo_demo"))
+    assert os.path.exists(_compile(tmp_path, "mono_vo_demo"))
     # the reference-typed adapter, against the type-check stand-ins (tests/test_reference_adapter.py has the details)
     assert os.path.exists(_compile(tmp_path, "adapter_demo", ADAPTER_INC))
 
@@ -251,3 +252,55 @@ def test_cpp_stereo_vo_writes_the_python_loops_trajectory(vo, tmp_path):
     assert rec[:, 3].sum() >= 3 and rec[:, 1].sum() >= 5
     vo.write_trajectory(str(tmp_path / "traj_py.txt"), ids, np.stack(Ts))
     assert open(traj, "rb").read() == open(tmp_path / "traj_py.txt", "rb").read()
+
+
+@pytest.mark.gpu
+def test_cpp_mono_vo_matches_python_mirror(vo, tmp_path):
+    """vo::MonoVO (core/visual_odometry/mono_vo.h) over 12 images, its 5-point callable fed from the file, against the
+    Python mirror on the same library: frame ids, keyframe decisions, track counts, local-BA runs, the hook's use, pose
+    bits and stats_keyframe (poses + map points) byte for byte."""
+    K = (458.654, 457.296, 367.215, 248.375)
+    W, H, nu, nv, n = 752, 480, 40, 25, 12
+    st = S.StereoStream(width=W, height=H, K=K, n_u=nu, n_v=nv, seed=5, speed=0.25)
+    poses = st.poses(n)
+    imgs = [st.render_pair(p)[0] for p in poses]
+    T10 = np.stack([np.eye(4)] + [np.linalg.inv(poses[k]) @ poses[k - 1] for k in range(1, n)]).astype(np.float32)
+    exe = _compile(tmp_path, "mono_vo_demo")
+    inp, outp = tmp_path / "mvo_in.bin", tmp_path / "mvo_out.bin"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("8i", n, W, H, nu, nv, 15, 5, 1))
+        f.write(np.array(list(K) + [20.0, 1.0, 5.0, 1.0, 1.0, 2.5], np.float32).tobytes())
+        f.write(T10.tobytes())
+        for im in imgs:
+            f.write(np.ascontiguousarray(im).tobytes())
+    subprocess.check_call([exe, str(inp), str(outp)])
+    blob = np.fromfile(outp, np.uint8)
+    raw, tail = blob[:n * 84].reshape(n, 20 + 64), blob[n * 84:].tobytes()
+    rec = raw[:, :20].copy().view(np.int32)
+    T_cpp = raw[:, 20:].copy().view(np.float32).reshape(n, 4, 4)
+    state = {"k": 0}
+
+    def hook(p0, p1):
+        T = T10[state["k"]]
+        return True, T[:3, :3], T[:3, 3], np.ones(len(p0), bool)
+
+    c = vo.Context(device=0, max_width=W, max_height=H, max_points=2 * nu * nv + 512, n_slots=3, max_level=5)
+    mvo = vo.MonoVO(c, W, H, K, nu, nv, hook, thres_fastscore=15, window_size=15, max_level=5, thres_error=20.0, thres_bidirection=1.0,
+                    thres_poseba_error=5, thres_sampson=1.0, thres_parallax=1.0, thres_translation=2.5, strict_border=1, local_ba=True)
+    for k, im in enumerate(imgs):
+        state["k"] = k
+        i = mvo.trackImage(im)
+        assert (i.frame_id, i.is_keyframe, i.n_tracks_out, i.lba_ran, i.used_five_point) == tuple(int(v) for v in rec[k]), k
+        assert np.array_equal(np.array(i.T_wc, np.float32).view(np.uint32), T_cpp[k].reshape(-1).view(np.uint32)), k
+    kfs = mvo.getKeyframes()
+    (nk,), off = struct.unpack_from("i", tail, 0), 4
+    assert nk == len(kfs) >= 3
+    for T, X in kfs:
+        T_c = np.frombuffer(tail, np.float32, 16, off).reshape(4, 4); off += 64
+        (m,) = struct.unpack_from("i", tail, off); off += 4
+        X_c = np.frombuffer(tail, np.float32, 3 * m, off).reshape(m, 3); off += 12 * m
+        assert np.array_equal(T_c.view(np.uint32), T.view(np.uint32)) and np.array_equal(X_c.view(np.uint32), X.view(np.uint32))
+    assert off == len(tail)
+    mvo.close()
+    c.close()
+    assert rec[:, 3].sum() >= 1 and rec[1, 4] == 1

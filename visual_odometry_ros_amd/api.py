@@ -969,6 +969,10 @@ class StereoBatch:
         except Exception:
             pass
 
+    def debug_set(self, key, value):
+        if self.lib.vo_batch_debug_set(self._h, int(key), int(value)) < 0:
+            raise VoError(-1, "vo_batch_debug_set failed")
+
     def run(self, left_ptrs, right_ptrs, stride, warmup=0, on_device=True, ids_cap=8192):
         """left_ptrs / right_ptrs: [n_streams][n_frames] addresses. Returns dict(T_wc, ids (list), seconds, wall)."""
         nf = len(left_ptrs[0])

@@ -60,6 +60,15 @@ extern "C" int vo_batch_create(const vo_config *cfg, const vo_svo_params *prm, i
 // (all threads meet at a barrier behind them). T_wc (may be NULL): [n_streams][n_frames][16]; last_ids (may be NULL):
 // [n_streams][ids_cap] the ids of every stream's final track set, n_ids[s] their number; seconds[s]: wall time of stream
 // s's timed frames; *wall: first start to last end over all streams.
+extern "C" int vo_batch_debug_set(vo_batch *b, int key, int value) {
+  if (!b) return VO_ERR_INVALID;
+  for (int s = 0; s < b->n; ++s) {
+    const int rc = vo_debug_set(b->ctx[s], key, value);
+    if (rc < 0) return rc;
+  }
+  return VO_OK;
+}
+
 extern "C" int vo_batch_run(vo_batch *b, const void *const *left, const void *const *right, int n_frames, int stride,
                             int on_device, int warmup, float *T_wc, int32_t *last_ids, int ids_cap, int *n_ids,
                             double *seconds, double *wall) {

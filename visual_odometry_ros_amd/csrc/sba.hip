@@ -994,11 +994,56 @@ __global__ __launch_bounds__(64) void sba_update_point_kernel(SbaDev d, int upda
     for (int k = lane; k < 16 * d.n_frames; k += 64) sT[k] = d.T[k];
   if (update)
     for (int k = lane; k < 6 * d.n_opt; k += 64) sx[k] = d.x[k];
+  // Everything a landmark's lane group will read next is known once the four pointers above are: the slot blocks of the
+  // update, the landmark's observations (SBA_NPRE rounds of SBA_LQ: 24 observations cover a nine-keyframe stereo window) and
+  // the slots' observation indices go out as ONE batch here — the first version met them as five to seven dependent rounds
+  // of loads, each a microsecond on a wavefront with nothing else to do. Indices are clamped into the landmark's own range
+  // (every landmark has observations; the arrays have a spare entry for a landmark without slots); what a lane does not own
+  // is loaded and not used. The arithmetic and its order per lane are unchanged.
+  constexpr int SBA_NPRE = 3;
+  const int sA = s0 + sub;
+  const bool hasA = sA < s1;
+  const int sL = hasA ? sA : s0;  // (what is loaded for a lane without a slot: the landmark's first, or the spare entry)
+  double preBC[18];
+  int pre_j = 0, pre_bobs = o0;
+  double preCb[3] = {0, 0, 0};
+  if (update) {
+    const double *BC = d.BCs + 18 * (size_t)sL;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) preBC[k] = BC[k];
+    pre_j = d.slot_j[sL];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) preCb[c] = d.Cinvb[3 * (size_t)i + c];
+  }
+  double pre_px[SBA_NPRE][2];
+  int pre_f[SBA_NPRE], pre_r[SBA_NPRE];
+  if (point) {
+#pragma unroll
+    for (int q = 0; q < SBA_NPRE; ++q) {
+      const int o = max(min(o0 + sub + SBA_LQ * q, o1 - 1), 0);
+      pre_px[q][0] = d.obs_px[2 * o];
+      pre_px[q][1] = d.obs_px[2 * o + 1];
+      pre_f[q] = d.obs_frame[o];
+      pre_r[q] = d.obs_right[o];
+    }
+    pre_bobs = d.slot_bobs[sL];
+  }
   __syncthreads();
+  __builtin_amdgcn_sched_barrier(0);  // (the batch above stays above: the scheduler would sink the loads to their uses)
   const long long st1 = SBA_TICK();
   if (update) {
     double cbx[3] = {0, 0, 0};
-    for (int s = s0 + sub; s < s1; s += SBA_LQ) {
+    if (hasA) {
+      const double *x = sx + 6 * pre_j;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) t += preBC[r * 3 + c] * x[r];
+        cbx[c] += t;
+      }
+    }
+    for (int s = sA + SBA_LQ; s < s1; s += SBA_LQ) {
       const double *BC = d.BCs + 18 * (size_t)s, *x = sx + 6 * d.slot_j[s];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -1010,18 +1055,21 @@ __global__ __launch_bounds__(64) void sba_update_point_kernel(SbaDev d, int upda
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      X[c] += d.Cinvb[3 * (size_t)i + c] - sba_quad_sum(cbx[c]);
+      X[c] += preCb[c] - sba_quad_sum(cbx[c]);
       if (live && sub == 0) d.X[3 * (size_t)i + c] = X[c];
     }
   }
   if (!point) return;
   const long long st2 = SBA_TICK();
+  // the first slot's observation (index known since the batch): on its way while the observations are linearised
+  const int ob = hasA ? pre_bobs : o0;
+  const double slot_px[2] = {d.obs_px[2 * ob], d.obs_px[2 * ob + 1]};
+  const int slot_f = d.obs_frame[ob], slot_r = d.obs_right[ob];
+  __builtin_amdgcn_sched_barrier(0);
   double Cu[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0}, err = 0.0;  // C_i: (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
-  for (int o = o0 + sub; o < o1; o += SBA_LQ) {
+  auto one_obs = [&](const double px[2], int f, int right) {
     SbaObs L;
-    const double px[2] = {d.obs_px[2 * o], d.obs_px[2 * o + 1]};
-    const int f = d.obs_frame[o];
-    sba_linearize(d, TLDS ? sT + 16 * f : d.T + 16 * (size_t)f, X, px, d.obs_right[o], L);
+    sba_linearize(d, TLDS ? sT + 16 * f : d.T + 16 * (size_t)f, X, px, right, L);
     // calc_Rij_t_Rij_weight (:911-930), b_i += -weight * (Rij^T rij)
     int q = 0;
 #pragma unroll
@@ -1031,6 +1079,13 @@ __global__ __launch_bounds__(64) void sba_update_point_kernel(SbaDev d, int upda
 #pragma unroll
     for (int r = 0; r < 3; ++r) b[r] += -(L.w * (L.R[r] * L.r[0] + L.R[3 + r] * L.r[1]));
     err += L.r[0] * L.r[0] + L.r[1] * L.r[1];
+  };
+#pragma unroll
+  for (int q = 0; q < SBA_NPRE; ++q)
+    if (o0 + sub + SBA_LQ * q < o1) one_obs(pre_px[q], pre_f[q], pre_r[q]);
+  for (int o = o0 + sub + SBA_LQ * SBA_NPRE; o < o1; o += SBA_LQ) {
+    const double px[2] = {d.obs_px[2 * o], d.obs_px[2 * o + 1]};
+    one_obs(px, d.obs_frame[o], d.obs_right[o]);
   }
   const long long st3 = SBA_TICK();
 #pragma unroll
@@ -1051,12 +1106,9 @@ __global__ __launch_bounds__(64) void sba_update_point_kernel(SbaDev d, int upda
     }
   }
   const long long st4 = SBA_TICK();
-  for (int s = s0 + sub; s < s1; s += SBA_LQ) {
-    const int o = d.slot_bobs[s];
+  auto one_slot = [&](int s, const double px[2], int f, int right) {
     SbaObs L;
-    const double px[2] = {d.obs_px[2 * o], d.obs_px[2 * o + 1]};
-    const int f = d.obs_frame[o];
-    sba_linearize(d, TLDS ? sT + 16 * f : d.T + 16 * (size_t)f, X, px, d.obs_right[o], L);
+    sba_linearize(d, TLDS ? sT + 16 * f : d.T + 16 * (size_t)f, X, px, right, L);
     double B[18], BC[18];
 #pragma unroll
     for (int r = 0; r < 6; ++r)
@@ -1076,6 +1128,12 @@ __global__ __launch_bounds__(64) void sba_update_point_kernel(SbaDev d, int upda
 #pragma unroll
       for (int r = 0; r < 6; ++r) BCbo[r] = BC[r * 3] * b[0] + (BC[r * 3 + 1] * b[1] + BC[r * 3 + 2] * b[2]);  // :473
     }
+  };
+  if (hasA) one_slot(sA, slot_px, slot_f, slot_r);
+  for (int s = sA + SBA_LQ; s < s1; s += SBA_LQ) {
+    const int o = d.slot_bobs[s];
+    const double px[2] = {d.obs_px[2 * o], d.obs_px[2 * o + 1]};
+    one_slot(s, px, d.obs_frame[o], d.obs_right[o]);
   }
   const long long st5 = SBA_TICK();
   SBA_STAMP_MAX(10, st1, st0);
