@@ -19,8 +19,8 @@
 // reference compares acosf(c) with a threshold — the host turns that threshold into the largest float c that passes
 // its own acosf, so the device never evaluates acosf), and the first observation on a keyframe + their number. A ring of
 // frame poses (T_wc and T_cw, 2^14 frames) serves "related_frames_.front()->getPoseInv()"; the poses of window keyframes
-// are refreshed in it after every local BA. `mvo_advance_kernel` builds the next set behind every frame (survivors in index
-// order, then the new landmarks), `mvo_keyframe_kernel` does addNewKeyframe + reconstruction, the landmark table / keyframe
+// are refreshed in it after every local BA. The advance step builds the next set behind every frame (survivors in index
+// order, then the new landmarks: `mvo_advance_scan_kernel` + `mvo_advance_work_kernel`), `mvo_keyframe_kernel` does addNewKeyframe + reconstruction, the landmark table / keyframe
 // ring / local BA are stereo_vo_lba.hip's in mono mode. The host chains the pose, applies the keyframe rule and calls
 // the hook.
 #include "frame_state.hpp"
@@ -178,8 +178,12 @@ struct MvoAdvArgs {
   float *frameT;           // [ring][32]
   MvoHdr *hdr_dev, *hdr_host;
   uint32_t seq;
+  int *pos_s, *pos_n;      // [cap] scratch: where survivor k / new point j goes in the next set (-1: nowhere)
 };
-__global__ __launch_bounds__(1024) void mvo_advance_kernel(MvoAdvArgs a) {
+// Two launches: the ORDER (one workgroup: which entries survive and where they go — a scan — the counts and the sequence word
+// the host waits for) and the WORK (one lane per entry, any number of workgroups: the copies and the parallaxes, nothing
+// serial). The first version did both in the one workgroup: 18.6 us, most of it dependent rounds of loads behind the scans.
+__global__ __launch_bounds__(1024) void mvo_advance_scan_kernel(MvoAdvArgs a) {
   __shared__ int s_w[16];
   __shared__ int s_kft[16];
   const int tid = threadIdx.x;
@@ -187,20 +191,64 @@ __global__ __launch_bounds__(1024) void mvo_advance_kernel(MvoAdvArgs a) {
     a.frameT[(size_t)(a.f & (MVO_FRAME_RING - 1)) * 32 + tid] = a.T_wc[tid];
     a.frameT[(size_t)(a.f & (MVO_FRAME_RING - 1)) * 32 + 16 + tid] = a.T_cw[tid];
   }
-  int base = 0, kft = 0;
+  int base = 0, kft = 0, id_first = a.id_base;
   for (int c0 = 0; c0 < a.n; c0 += 1024) {
     const int k = c0 + tid;
     const int ok = (k < a.n && a.stage[k] == 4) ? 1 : 0;
     int total;
     const int pos = base + mvo_block_scan(ok, s_w, total);
-    if (ok && pos < a.cap) {
+    if (k < a.n) a.pos_s[k] = (ok && pos < a.cap) ? pos : -1;
+    if (ok) {
+      kft += (a.cur.t.flags[k] & VO_LM_KF_MEMBER) ? 1 : 0;
+      if (pos == 0) a.hdr_dev->id_min = a.cur.t.ids[k];  // (the next set's first id; overwritten below when there is no survivor)
+    }
+    base += total;
+  }
+  const int n_surv = base;
+  for (int c0 = 0; c0 < a.m; c0 += 1024) {
+    const int j = c0 + tid;
+    const int ok = (j < a.m && a.mnew[j]) ? 1 : 0;
+    int total;
+    const int r = base + mvo_block_scan(ok, s_w, total);
+    if (j < a.m) a.pos_n[j] = (ok && r < a.cap) ? r : -1;
+    base += total;
+  }
+  (void)id_first;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) kft += __shfl_down(kft, off);
+  __syncthreads();
+  if ((tid & 63) == 0) s_kft[tid >> 6] = kft;
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) {
+    int t = 0;
+    for (int k = 0; k < 16; ++k) t += s_kft[k];
+    MvoHdr h;
+    h.n_surv = n_surv;
+    h.n_new = base - n_surv;
+    h.n_next = base < a.cap ? base : a.cap;
+    h.n_kf_tracked = t;
+    h.overflow = base > a.cap ? 1 : 0;
+    h.n_recon = 0;
+    h.pad = 0;
+    h.seq = 0;
+    h.id_min = n_surv > 0 ? a.hdr_dev->id_min : a.id_base;  // (another thread's store, behind the fence and the barrier)
+    *a.hdr_dev = h;
+    *a.hdr_host = h;
+    __threadfence_system();
+    __hip_atomic_store(&a.hdr_host->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+__global__ __launch_bounds__(256) void mvo_advance_work_kernel(MvoAdvArgs a) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < a.n) {
+    const int k = g, pos = a.pos_s[k];
+    if (pos >= 0) {
       const float px = a.pts1[2 * k], py = a.pts1[2 * k + 1];
       a.nxt.t.pts_l[2 * pos] = px;
       a.nxt.t.pts_l[2 * pos + 1] = py;
       a.nxt.t.ids[pos] = a.cur.t.ids[k];
-      const uint8_t fl = a.cur.t.flags[k];
-      a.nxt.t.flags[pos] = fl;
-      kft += (fl & VO_LM_KF_MEMBER) ? 1 : 0;
+      a.nxt.t.flags[pos] = a.cur.t.flags[k];
       a.nxt.t.Xw[3 * pos] = a.cur.t.Xw[3 * k];
       a.nxt.t.Xw[3 * pos + 1] = a.cur.t.Xw[3 * k + 1];
       a.nxt.t.Xw[3 * pos + 2] = a.cur.t.Xw[3 * k + 2];
@@ -217,65 +265,26 @@ __global__ __launch_bounds__(1024) void mvo_advance_kernel(MvoAdvArgs a) {
       // (f0 < f: that entry of the frame table was written by an earlier launch)
       a.nxt.cos_last[pos] = mvo_parallax_cos(p0x, p0y, px, py, a.K, a.frameT + (size_t)(f0 & (MVO_FRAME_RING - 1)) * 32 + 16, a.T_obs);
     }
-    base += total;
+    return;
   }
-  const int n_surv = base;
-  for (int c0 = 0; c0 < a.m; c0 += 1024) {
-    const int j = c0 + tid;
-    const int ok = (j < a.m && a.mnew[j]) ? 1 : 0;
-    int total;
-    const int r = base + mvo_block_scan(ok, s_w, total);
-    if (ok && r < a.cap) {
-      const float p0x = a.cand0[2 * j], p0y = a.cand0[2 * j + 1], p1x = a.cand1[2 * j], p1y = a.cand1[2 * j + 1];
-      a.nxt.t.pts_l[2 * r] = p1x;
-      a.nxt.t.pts_l[2 * r + 1] = p1y;
-      a.nxt.t.ids[r] = a.id_base + (r - n_surv);
-      a.nxt.t.flags[r] = 0;
-      a.nxt.t.Xw[3 * r] = a.nxt.t.Xw[3 * r + 1] = a.nxt.t.Xw[3 * r + 2] = 0.0f;
-      a.nxt.p_first[2 * r] = p0x;
-      a.nxt.p_first[2 * r + 1] = p0y;
-      a.nxt.f_first[r] = a.f - 1;
-      a.nxt.age[r] = 2;
-      a.nxt.n_kf[r] = 0;
-      a.nxt.p_kf_first[2 * r] = a.nxt.p_kf_first[2 * r + 1] = 0.0f;
-      a.nxt.kf_first[r] = -1;
-      a.nxt.cos_last[r] = mvo_parallax_cos(p0x, p0y, p1x, p1y, a.K, a.frameT + (size_t)((a.f - 1) & (MVO_FRAME_RING - 1)) * 32 + 16, a.T_wc);
-    }
-    base += total;
-  }
-  // members of the last keyframe among the survivors (numerator of the tracking ratio, keyframes.cpp:62-76)
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) kft += __shfl_down(kft, off);
-  __syncthreads();
-  if ((tid & 63) == 0) s_kft[tid >> 6] = kft;
-  __syncthreads();
-  if (tid == 0) {
-    int t = 0;
-    for (int k = 0; k < 16; ++k) t += s_kft[k];
-    MvoHdr h;
-    h.n_surv = n_surv;
-    h.n_new = base - n_surv;
-    h.n_next = base < a.cap ? base : a.cap;
-    h.n_kf_tracked = t;
-    h.overflow = base > a.cap ? 1 : 0;
-    h.n_recon = 0;
-    h.pad = 0;
-    h.seq = 0;
-    h.id_min = a.id_base;
-    *a.hdr_dev = h;
-    *a.hdr_host = h;
-  }
-  __threadfence_system();
-  __syncthreads();
-  if (tid == 0) {
-    if (base > 0) {
-      const int id0 = a.nxt.t.ids[0];  // (another thread's store, behind the barrier)
-      a.hdr_dev->id_min = id0;
-      a.hdr_host->id_min = id0;
-      __threadfence_system();
-    }
-    __hip_atomic_store(&a.hdr_host->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+  const int j = g - a.n;
+  if (j >= a.m) return;
+  const int r = a.pos_n[j];
+  if (r < 0) return;
+  const float p0x = a.cand0[2 * j], p0y = a.cand0[2 * j + 1], p1x = a.cand1[2 * j], p1y = a.cand1[2 * j + 1];
+  a.nxt.t.pts_l[2 * r] = p1x;
+  a.nxt.t.pts_l[2 * r + 1] = p1y;
+  a.nxt.t.ids[r] = a.id_base + (r - a.hdr_dev->n_surv);
+  a.nxt.t.flags[r] = 0;
+  a.nxt.t.Xw[3 * r] = a.nxt.t.Xw[3 * r + 1] = a.nxt.t.Xw[3 * r + 2] = 0.0f;
+  a.nxt.p_first[2 * r] = p0x;
+  a.nxt.p_first[2 * r + 1] = p0y;
+  a.nxt.f_first[r] = a.f - 1;
+  a.nxt.age[r] = 2;
+  a.nxt.n_kf[r] = 0;
+  a.nxt.p_kf_first[2 * r] = a.nxt.p_kf_first[2 * r + 1] = 0.0f;
+  a.nxt.kf_first[r] = -1;
+  a.nxt.cos_last[r] = mvo_parallax_cos(p0x, p0y, p1x, p1y, a.K, a.frameT + (size_t)((a.f - 1) & (MVO_FRAME_RING - 1)) * 32 + 16, a.T_wc);
 }
 
 // reconstruction at the initialisation (mono_vo.cpp:660-687): every landmark of lmtrack_final that is not triangulated and
@@ -371,6 +380,7 @@ struct vo_mvo {
   MvoHdr *d_hdr = nullptr, *h_hdr = nullptr;
   uint32_t seq = 0;
   int *d_nrec = nullptr;
+  int *d_pos = nullptr;  // [2 cap] the advance step's scratch
   // uploads of the host-driven paths (initialisation, 5-point fallback)
   uint8_t *d_stage = nullptr, *d_mnew = nullptr;
   float *d_pts1 = nullptr, *d_cand1 = nullptr, *d_cand0 = nullptr;
@@ -463,7 +473,7 @@ extern "C" void vo_mvo_destroy(vo_mvo *s) {
   if (s->c) (void)hipSetDevice(s->c->device);
   if (s->c) (void)hipStreamSynchronize(s->c->stream);
   for (int k = 0; k < 2; ++k) mvo_free_set(&s->ts[k]);
-  void *b[] = {s->d_op, s->d_frameT, s->d_hdr, s->d_nrec, s->d_stage, s->d_mnew, s->d_pts1, s->d_cand1, s->d_cand0};
+  void *b[] = {s->d_op, s->d_frameT, s->d_hdr, s->d_nrec, s->d_pos, s->d_stage, s->d_mnew, s->d_pts1, s->d_cand1, s->d_cand0};
   for (void *p : b)
     if (p) (void)hipFree(p);
   if (s->h_hdr) (void)hipHostFree(s->h_hdr);
@@ -496,6 +506,7 @@ extern "C" int vo_mvo_create(vo_ctx *c, const vo_mvo_params *prm, vo_mvo **out) 
   dm((void **)&s->d_frameT, sizeof(float) * 32 * (size_t)MVO_FRAME_RING);
   dm((void **)&s->d_hdr, sizeof(MvoHdr));
   dm((void **)&s->d_nrec, 64);
+  dm((void **)&s->d_pos, sizeof(int) * 2 * (size_t)s->cap);
   dm((void **)&s->d_stage, (size_t)s->cap);
   dm((void **)&s->d_mnew, (size_t)s->cap);
   dm((void **)&s->d_pts1, sizeof(float) * 2 * (size_t)s->cap);
@@ -613,7 +624,10 @@ static int mvo_advance(vo_mvo *s, const uint8_t *stage, const float *pts1, const
   a.hdr_host = s->h_hdr;
   s->seq = s->seq + 1 == 0 ? 1 : s->seq + 1;
   a.seq = s->seq;
-  hipLaunchKernelGGL(mvo_advance_kernel, dim3(1), dim3(1024), 0, c->stream, a);
+  a.pos_s = s->d_pos;
+  a.pos_n = s->d_pos + s->cap;
+  hipLaunchKernelGGL(mvo_advance_scan_kernel, dim3(1), dim3(1024), 0, c->stream, a);
+  hipLaunchKernelGGL(mvo_advance_work_kernel, dim3((unsigned)((s->n + m + 255) / 256 + 1)), dim3(256), 0, c->stream, a);
   VO_CHECK_HIP(c, hipGetLastError());
   RC(mvo_wait_hdr(s));
   *h = *s->h_hdr;
