@@ -899,14 +899,18 @@ def batch_leg(cfg, args, local_rank, torch, V, dev, prm_svo, cap):
     for S in args.batch_S:
         b = V.StereoBatch(local_rank, S, W, H, cap, cfg["max_level"], prm_svo)
         r = b.run(Lp[:S], Rp[:S], W, warmup=warm)
+        mode = b.strict_border()
         b.close()
         same = all(np.array_equal(r["T_wc"][q].view(np.uint32), alone[q]["T_wc"][0].view(np.uint32)) and
                    np.array_equal(r["ids"][q], alone[q]["ids"][0]) for q in range(S))
         per = [(nf - warm) / float(t) for t in r["seconds"]]
         res[str(S)] = {"aggregate_fps": round(S * (nf - warm) / r["wall"], 1), "per_stream_fps_min": round(min(per), 1),
-                       "per_stream_fps_max": round(max(per), 1), "poses_and_track_ids_equal_single_stream_run": bool(same)}
-    res["note"] = (f"{nf - warm} timed frames per stream (closed loop incl. local BA = {bool(args.lba)}, strict-border mode "
-                   f"{args.strict_border}), streams of seeds 100.., a context + StereoVO + host thread per stream inside libvo_hip.so")
+                       "per_stream_fps_max": round(max(per), 1), "poses_and_track_ids_equal_single_stream_run": bool(same),
+                       "strict_border_mode": mode}
+    res["note"] = (f"{nf - warm} timed frames per stream (closed loop incl. local BA = {bool(args.lba)}; strict-border mode "
+                   f"{args.strict_border} asked for, strict_border_mode = what the streams ran with: the arrangements with a replay "
+                   "next to the frame kernel become the stream-ordered one when S > 1, same bits), streams of seeds 100.., a "
+                   "context + StereoVO + host thread per stream inside libvo_hip.so")
     return res
 
 

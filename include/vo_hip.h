@@ -480,6 +480,9 @@ void vo_batch_destroy(vo_batch *batch);
 const char *vo_batch_last_error(const vo_batch *batch);
 /* vo_debug_set on every stream's context (measurement switches, e.g. VO_DBG_SKIP_DETECT) */
 int vo_batch_debug_set(vo_batch *batch, int key, int value);
+/* The strict-border arrangement the batch's streams run with: prm->strict_border, except that the arrangements with a
+ * replay next to the frame kernel (3, 4, 5) become the stream-ordered one (1, same results) when n_streams > 1. */
+int vo_batch_strict_border(const vo_batch *batch);
 int vo_batch_run(vo_batch *batch, const void *const *left, const void *const *right, int n_frames, int stride, int on_device,
                  int warmup, float *T_wc, int32_t *last_ids, int ids_cap, int *n_ids, double *seconds, double *wall);
 

@@ -124,7 +124,7 @@ SYMBOLS = [
     "vo_svo_prefetch", "vo_svo_result", "vo_svo_get_tracks", "vo_svo_get_new_points", "vo_svo_keyframe_count", "vo_svo_get_keyframe", "vo_svo_get_keyframes", "vo_triangulate_dlt", "vo_batch_create", "vo_batch_destroy",
     "vo_mvo_create", "vo_mvo_destroy", "vo_mvo_track", "vo_mvo_enqueue", "vo_mvo_prefetch", "vo_mvo_result", "vo_mvo_get_tracks",
     "vo_mvo_keyframe_count", "vo_mvo_get_keyframes",
-    "vo_batch_last_error", "vo_batch_run", "vo_debug_set", "vo_batch_debug_set", "vo_debug_allocation_count", "vo_svo_device_bytes",
+    "vo_batch_last_error", "vo_batch_run", "vo_debug_set", "vo_batch_debug_set", "vo_batch_strict_border", "vo_debug_allocation_count", "vo_svo_device_bytes",
     "vo_se3_exp", "vo_ids_reset", "vo_ids_peek", "vo_ids_new_frames", "vo_ids_new_landmarks", "vo_compact_tracks",
 ]
 
@@ -188,6 +188,7 @@ def load():
     lib.vo_mvo_get_keyframes.argtypes = [vp, vp, vp, vp, C.c_size_t, vp]
     lib.vo_debug_set.argtypes = [vp, ci, ci]
     lib.vo_batch_debug_set.argtypes = [vp, ci, ci]
+    lib.vo_batch_strict_border.argtypes = [vp]
     lib.vo_debug_allocation_count.argtypes = [vp, vp]
     lib.vo_triangulate_dlt.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp]
     lib.vo_batch_create.argtypes = [C.POINTER(VoConfig), C.POINTER(SvoParams), ci, C.POINTER(C.c_void_p)]

@@ -973,6 +973,10 @@ class StereoBatch:
         if self.lib.vo_batch_debug_set(self._h, int(key), int(value)) < 0:
             raise VoError(-1, "vo_batch_debug_set failed")
 
+    def strict_border(self):
+        """The replay arrangement the streams run with (3, 4, 5 become the stream-ordered 1 when S > 1, same results)."""
+        return int(self.lib.vo_batch_strict_border(self._h))
+
     def run(self, left_ptrs, right_ptrs, stride, warmup=0, on_device=True, ids_cap=8192):
         """left_ptrs / right_ptrs: [n_streams][n_frames] addresses. Returns dict(T_wc, ids (list), seconds, wall)."""
         nf = len(left_ptrs[0])

@@ -12,7 +12,7 @@
 #include "stereo_vo.hpp"
 
 struct vo_batch {
-  int device = 0, n = 0;
+  int device = 0, n = 0, strict_border = 0;  // strict_border: the replay arrangement the streams run with
   std::vector<vo_ctx *> ctx;
   std::vector<vo_svo *> svo;
   char err[512] = {0};
@@ -29,6 +29,8 @@ extern "C" void vo_batch_destroy(vo_batch *b) {
 
 extern "C" const char *vo_batch_last_error(const vo_batch *b) { return b ? b->err : "null batch"; }
 
+extern "C" int vo_batch_strict_border(const vo_batch *b) { return b ? b->strict_border : VO_ERR_INVALID; }
+
 extern "C" int vo_batch_create(const vo_config *cfg, const vo_svo_params *prm, int n_streams, vo_batch **out) {
   if (!cfg || !prm || !out || n_streams <= 0 || n_streams > 64) return VO_ERR_INVALID;
   *out = nullptr;
@@ -43,6 +45,7 @@ extern "C" int vo_batch_create(const vo_config *cfg, const vo_svo_params *prm, i
   // than one stream: the stream-ordered replay (same results by construction).
   vo_svo_params q = *prm;
   if (n_streams > 1 && q.strict_border >= 3) q.strict_border = 1;
+  b->strict_border = q.strict_border;
   for (int s = 0; s < n_streams; ++s) {
     int rc = vo_create(cfg, &b->ctx[s]);
     if (rc == VO_OK) rc = vo_svo_create(b->ctx[s], &q, &b->svo[s]);
