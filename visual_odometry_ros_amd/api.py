@@ -54,12 +54,13 @@ class Context:
         self._children = weakref.WeakSet()  # objects that hold device state of this context (StereoVO): closed before it
         # test / measurement switches (include/vo_hip.h: vo_debug_set). The library itself reads no environment variable;
         # this mirror hands the ones the test-suite and tools/ set to the context it creates.
-        for key, name in enumerate(("VO_DEBUG_FAIL_JOIN", "VO_CONC_GRID", "VO_SBA_LDS_SOLVE", "VO_DEBUG_SKIP_DETECT")):
+        for key, name in ((0, "VO_DEBUG_FAIL_JOIN"), (1, "VO_CONC_GRID"), (2, "VO_SBA_LDS_SOLVE"), (3, "VO_DEBUG_SKIP_DETECT"),
+                          (5, "VO_MVO_HOST_ADVANCE")):
             v = os.environ.get(name)
             if v:
                 self.debug_set(key, int(v) if v.lstrip("-").isdigit() else 1)
 
-    DBG_FAIL_JOIN, DBG_CONC_GRID, DBG_SBA_LDS_SOLVE, DBG_SKIP_DETECT, OPT_POLL_YIELD = 0, 1, 2, 3, 4
+    DBG_FAIL_JOIN, DBG_CONC_GRID, DBG_SBA_LDS_SOLVE, DBG_SKIP_DETECT, OPT_POLL_YIELD, DBG_MVO_HOST_ADVANCE = 0, 1, 2, 3, 4, 5
 
     def debug_set(self, key, value):
         self.check(self.lib.vo_debug_set(self._h, int(key), int(value)))

@@ -418,6 +418,7 @@ static int mono_enqueue_impl(vo_ctx *c, const vo_mono_params *prm, int slot0, in
     VO_CHECK_HIP(c, hipMemcpyAsync(f->res_host, f->res_dev, f->res_bytes, hipMemcpyDeviceToHost, s));
   }
   VO_CHECK_HIP(c, hipEventRecord(f->ev_done, s));
+  f->known_done = false;
   f->pending = true;
   c->frame_slots_busy = c->ingest_side;
   c->frame_slot[0] = slot0;
@@ -463,7 +464,8 @@ extern "C" int vo_mono_frame_result(vo_ctx *c, float *pts1, float *scale, uint8_
   if (!c || !c->frame || !c->frame->pending) return VO_ERR_INVALID;
   vo_frame_state *f = c->frame;
   VO_CHECK_HIP(c, hipSetDevice(c->device));
-  VO_CHECK_HIP(c, hipEventSynchronize(f->ev_done));
+  if (!f->known_done) VO_CHECK_HIP(c, hipEventSynchronize(f->ev_done));
+  f->known_done = false;
   f->pending = false;
   c->frame_slots_busy = 0;
   const int n = f->n;

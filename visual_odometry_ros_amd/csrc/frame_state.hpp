@@ -58,6 +58,7 @@ struct vo_frame_state {
   bool pending;
   int seq;          // sequence number of the frame in flight (fused stereo path: the result is awaited by polling res_host)
   bool seq_poll;
+  bool known_done;  // the caller has seen a later launch of the same stream finish: the result call need not wait
   hipEvent_t ev_done;  // recorded after the packed D2H: result() waits for this, not for the stream
   // what the frame in flight was enqueued with (device pointers): vo_stereo_frame_result re-issues the frame with the
   // stream-ordered replay when the device-side join of the concurrent arrangements timed out

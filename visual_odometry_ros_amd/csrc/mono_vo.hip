@@ -179,15 +179,57 @@ struct MvoAdvArgs {
   MvoHdr *hdr_dev, *hdr_host;
   uint32_t seq;
   int *pos_s, *pos_n;      // [cap] scratch: where survivor k / new point j goes in the next set (-1: nowhere)
+  // Chained behind the frame's BA launch (no host round trip in between): the frame's own header says how many candidates were
+  // emitted and what the pose-only BA found; T_wc = T_wp * dT01 (frame_curr->setPose(Twc_prev * dT01), mono_vo.cpp:883) is
+  // formed here, with the host's operation order. A frame that needs the 5-point fallback (or failed) is left to the host.
+  const vo_frame_hdr *fh;  // null: m, T_obs, T_wc, T_cw above are the host's
+  float T_wp[16];
 };
+__device__ __forceinline__ bool mvo_chain_skip(const vo_frame_hdr *fh) { return fh->cnt[5] != 0 || fh->flags != 0; }
 // Two launches: the ORDER (one workgroup: which entries survive and where they go — a scan — the counts and the sequence word
 // the host waits for) and the WORK (one lane per entry, any number of workgroups: the copies and the parallaxes, nothing
 // serial). The first version did both in the one workgroup: 18.6 us, most of it dependent rounds of loads behind the scans.
 __global__ __launch_bounds__(1024) void mvo_advance_scan_kernel(MvoAdvArgs a) {
   __shared__ int s_w[16];
   __shared__ int s_kft[16];
+  __shared__ float s_T[16];
   const int tid = threadIdx.x;
-  if (tid < 16) {  // the frame table's entry of this frame (T_wc | T_cw)
+  if (a.fh) {
+    if (mvo_chain_skip(a.fh)) {  // the host takes this frame (5-point fallback / error): nothing of the next set is built
+      if (tid == 0) {
+        MvoHdr h;
+        memset(&h, 0, sizeof(h));
+        h.pad = 1;
+        *a.hdr_dev = h;
+        *a.hdr_host = h;
+        __threadfence_system();
+        __hip_atomic_store(&a.hdr_host->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      return;
+    }
+    a.m = a.fh->cnt[6];
+    if (tid < 16) {  // svo_mul44(T_wp, dT01), element by element
+      const int i = tid >> 2, j = tid & 3;
+      const float *B = a.fh->dT;
+      float r = a.T_wp[i * 4 + 0] * B[0 * 4 + j];
+#pragma unroll
+      for (int k = 1; k < 4; ++k) r = a.T_wp[i * 4 + k] * B[k * 4 + j] + r;
+      s_T[tid] = r;
+    }
+    __syncthreads();
+    if (tid < 16) {  // svo_inv_se3 of it
+      const int i = tid >> 2, j = tid & 3;
+      float v;
+      if (i == 3)
+        v = j == 3 ? 1.0f : 0.0f;
+      else if (j < 3)
+        v = s_T[j * 4 + i];
+      else
+        v = ((-s_T[0 * 4 + i]) * s_T[3] + (-s_T[1 * 4 + i]) * s_T[7]) + (-s_T[2 * 4 + i]) * s_T[11];
+      a.frameT[(size_t)(a.f & (MVO_FRAME_RING - 1)) * 32 + tid] = s_T[tid];
+      a.frameT[(size_t)(a.f & (MVO_FRAME_RING - 1)) * 32 + 16 + tid] = v;
+    }
+  } else if (tid < 16) {  // the frame table's entry of this frame (T_wc | T_cw)
     a.frameT[(size_t)(a.f & (MVO_FRAME_RING - 1)) * 32 + tid] = a.T_wc[tid];
     a.frameT[(size_t)(a.f & (MVO_FRAME_RING - 1)) * 32 + 16 + tid] = a.T_cw[tid];
   }
@@ -241,6 +283,20 @@ __global__ __launch_bounds__(1024) void mvo_advance_scan_kernel(MvoAdvArgs a) {
 }
 __global__ __launch_bounds__(256) void mvo_advance_work_kernel(MvoAdvArgs a) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  float T_obs[16], T_wc[16];
+  if (a.fh) {
+    if (mvo_chain_skip(a.fh)) return;
+    a.m = a.fh->cnt[6];
+    const float *Tf = a.frameT + (size_t)(a.f & (MVO_FRAME_RING - 1)) * 32;  // (the order launch's)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) T_obs[k] = T_wc[k] = Tf[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      T_obs[k] = a.T_obs[k];
+      T_wc[k] = a.T_wc[k];
+    }
+  }
   if (g < a.n) {
     const int k = g, pos = a.pos_s[k];
     if (pos >= 0) {
@@ -263,7 +319,7 @@ __global__ __launch_bounds__(256) void mvo_advance_work_kernel(MvoAdvArgs a) {
       a.nxt.p_kf_first[2 * pos + 1] = a.cur.p_kf_first[2 * k + 1];
       a.nxt.kf_first[pos] = a.cur.kf_first[k];
       // (f0 < f: that entry of the frame table was written by an earlier launch)
-      a.nxt.cos_last[pos] = mvo_parallax_cos(p0x, p0y, px, py, a.K, a.frameT + (size_t)(f0 & (MVO_FRAME_RING - 1)) * 32 + 16, a.T_obs);
+      a.nxt.cos_last[pos] = mvo_parallax_cos(p0x, p0y, px, py, a.K, a.frameT + (size_t)(f0 & (MVO_FRAME_RING - 1)) * 32 + 16, T_obs);
     }
     return;
   }
@@ -284,7 +340,7 @@ __global__ __launch_bounds__(256) void mvo_advance_work_kernel(MvoAdvArgs a) {
   a.nxt.n_kf[r] = 0;
   a.nxt.p_kf_first[2 * r] = a.nxt.p_kf_first[2 * r + 1] = 0.0f;
   a.nxt.kf_first[r] = -1;
-  a.nxt.cos_last[r] = mvo_parallax_cos(p0x, p0y, p1x, p1y, a.K, a.frameT + (size_t)((a.f - 1) & (MVO_FRAME_RING - 1)) * 32 + 16, a.T_wc);
+  a.nxt.cos_last[r] = mvo_parallax_cos(p0x, p0y, p1x, p1y, a.K, a.frameT + (size_t)((a.f - 1) & (MVO_FRAME_RING - 1)) * 32 + 16, T_wc);
 }
 
 // reconstruction at the initialisation (mono_vo.cpp:660-687): every landmark of lmtrack_final that is not triangulated and
@@ -387,6 +443,7 @@ struct vo_mvo {
   bool got_first = false, init_done = false, pending = false, prefetched = false;
   const void *pre = nullptr;
   int pend_kind = 0;  // 0 first image, 1 initialisation, 2 steady state
+  bool chained = false;  // the advance step of the frame in flight went out with it
   int slot[3] = {0, 1, 2};  // previous, current, next
   int tab_cur = 0, tab_next = 0;
   int f = -1;        // index of the current frame (0, 1, ...) — Frame ids come from the context's counter
@@ -597,9 +654,10 @@ static int mvo_wait_hdr(vo_mvo *s) {
 }
 
 // the next track set behind a frame; stage / pts1 / new points are DEVICE arrays. T_obs: what the survivors' observation
-// sees as the frame's pose. Leaves cur / n on the new set and the counts in *h.
-static int mvo_advance(vo_mvo *s, const uint8_t *stage, const float *pts1, const float *cand1, const float *cand0, const uint8_t *mnew,
-                       int m, const float T_obs[16], const float T_wc[16], MvoHdr *h) {
+// sees as the frame's pose. `chain` (the frame's device header): the launches go out right behind the frame's BA launch and
+// take the candidates' number and the pose from it (T_obs / T_wc are not read, m = the largest number there can be).
+static int mvo_advance_launch(vo_mvo *s, const uint8_t *stage, const float *pts1, const float *cand1, const float *cand0,
+                              const uint8_t *mnew, int m, const float *T_obs, const float *T_wc, const vo_frame_hdr *chain) {
   vo_ctx *c = s->c;
   MvoAdvArgs a;
   memset(&a, 0, sizeof(a));
@@ -616,9 +674,14 @@ static int mvo_advance(vo_mvo *s, const uint8_t *stage, const float *pts1, const
   a.id_base = c->next_landmark_id;
   a.f = s->f;
   memcpy(a.K, s->prm.frame.K, sizeof(a.K));
-  memcpy(a.T_obs, T_obs, sizeof(a.T_obs));
-  memcpy(a.T_wc, T_wc, sizeof(a.T_wc));
-  svo_inv_se3(T_wc, a.T_cw);
+  if (chain) {
+    a.fh = chain;
+    memcpy(a.T_wp, s->T_wp, sizeof(a.T_wp));
+  } else {
+    memcpy(a.T_obs, T_obs, sizeof(a.T_obs));
+    memcpy(a.T_wc, T_wc, sizeof(a.T_wc));
+    svo_inv_se3(T_wc, a.T_cw);
+  }
   a.frameT = s->d_frameT;
   a.hdr_dev = s->d_hdr;
   a.hdr_host = s->h_hdr;
@@ -629,13 +692,24 @@ static int mvo_advance(vo_mvo *s, const uint8_t *stage, const float *pts1, const
   hipLaunchKernelGGL(mvo_advance_scan_kernel, dim3(1), dim3(1024), 0, c->stream, a);
   hipLaunchKernelGGL(mvo_advance_work_kernel, dim3((unsigned)((s->n + m + 255) / 256 + 1)), dim3(256), 0, c->stream, a);
   VO_CHECK_HIP(c, hipGetLastError());
+  return VO_OK;
+}
+// ... and its counts: leaves cur / n on the new set
+static int mvo_advance_collect(vo_mvo *s, MvoHdr *h) {
+  vo_ctx *c = s->c;
   RC(mvo_wait_hdr(s));
   *h = *s->h_hdr;
+  if (h->pad) return VO_OK;  // (chained behind a frame the host has to finish: nothing was built)
   if (h->overflow) VO_FAIL(c, VO_ERR_CAPACITY, "the next track set exceeds vo_config.max_points=%d", s->cap);
   c->next_landmark_id += h->n_new;
   s->cur ^= 1;
   s->n = h->n_next;
   return VO_OK;
+}
+static int mvo_advance(vo_mvo *s, const uint8_t *stage, const float *pts1, const float *cand1, const float *cand0, const uint8_t *mnew,
+                       int m, const float T_obs[16], const float T_wc[16], MvoHdr *h) {
+  RC(mvo_advance_launch(s, stage, pts1, cand1, cand0, mnew, m, T_obs, T_wc, nullptr));
+  return mvo_advance_collect(s, h);
 }
 
 // Keyframes::checkUpdateRule, keyframes.cpp:47-126
@@ -946,6 +1020,15 @@ extern "C" int vo_mvo_enqueue(vo_mvo *s, const void *img, int stride, int on_dev
   c->next_frame_id += 1;
   ++s->f;
   s->pend_kind = !s->got_first ? 0 : (!s->init_done ? 1 : 2);
+  s->chained = false;
+  if (s->init_done && !c->dbg[VO_DBG_MVO_HOST_ADVANCE]) {
+    // the next track set right behind the BA launch: the advance reads the frame's header on the device (vo_mvo_result waits
+    // for its counts only — one host round trip per frame)
+    vo_frame_state *f = c->frame;
+    s->chained = mvo_advance_launch(s, f->res_dev + f->off_stage, (const float *)(f->res_dev + f->off_pl1),
+                                    (const float *)(f->res_dev + f->off_newl), (const float *)(f->res_dev + f->off_newr),
+                                    f->res_dev + f->off_mnew, f->n_new, nullptr, nullptr, f->hdr) >= 0;  // (else: from vo_mvo_result)
+  }
   s->pending = true;
   return VO_OK;
 }
@@ -1028,6 +1111,16 @@ extern "C" int vo_mvo_result(vo_mvo *s, vo_mvo_frame_info *info) {
     rc = mvo_second_image(s, &I);
   } else {
     float dT01[16], dT10[16], T_wc[16];
+    MvoHdr h;
+    memset(&h, 0, sizeof(h));
+    if (s->chained) {  // (the frame's own block is complete by then: the advance is stream-ordered behind the BA launch)
+      rc = mvo_advance_collect(s, &h);
+      if (rc < 0) {
+        (void)vo_mono_frame_result(c, nullptr, nullptr, nullptr, dT01, &I.counts, &I.gn);
+        return rc;
+      }
+      c->frame->known_done = true;  // (the word just seen was written behind the frame's last launch)
+    }
     rc = vo_mono_frame_result(c, nullptr, nullptr, nullptr, dT01, &I.counts, &I.gn);
     if (rc < 0) return rc;
     vo_frame_state *f = c->frame;
@@ -1050,9 +1143,10 @@ extern "C" int vo_mvo_result(vo_mvo *s, vo_mvo_frame_info *info) {
     }
     svo_mul44(s->T_wp, dT01, T_wc);  // frame_curr->setPose(Twc_prev * dT01)
     svo_inv_se3(dT10, s->dT01);      // setPoseDiff10(dT10): dT01_ = inverseSE3_f(dT10)
-    MvoHdr h;
-    rc = mvo_advance(s, stage, pts1, cand1, cand0, mnew, m, T_wc, T_wc, &h);
-    if (rc < 0) return rc;
+    if (!s->chained || h.pad) {
+      rc = mvo_advance(s, stage, pts1, cand1, cand0, mnew, m, T_wc, T_wc, &h);
+      if (rc < 0) return rc;
+    }
     I.n_final = h.n_surv;
     I.n_new = h.n_new;
     memcpy(I.dT01, dT01, sizeof(dT01));
