@@ -1390,7 +1390,7 @@ def run_mono_loop(cfg, args, rank, local_rank, world, torch, V, barrier, dev, im
     hook = TruePoseHook(poses_gt)
     kw = dict(thres_fastscore=cfg["thres_fast"], window_size=win, max_level=lvl, thres_error=thr[0], thres_bidirection=thr[1],
               thres_poseba_error=thr[2], thres_sampson=thr[3], thres_parallax=1.0, thres_translation=cfg.get("kf_trans", 3.0),
-              strict_border=1 if args.strict_border else 0, local_ba=bool(args.lba))
+              strict_border=int(args.strict_border), local_ba=bool(args.lba))
     mvo = V.MonoVO(ctx, W, H, cfg["K"], cfg["n_u"], cfg["n_v"], hook, **kw)
     eff_levels = ctx.pyramid_levels(W, H, win, lvl) + 1
     eff_levels_bwd = ctx.pyramid_levels(W, H, win, lvl - 1) + 1
@@ -1475,7 +1475,7 @@ def run_mono_loop(cfg, args, rank, local_rank, world, torch, V, barrier, dev, im
                                + (", mono local BA over the keyframe window" if args.lba else "; local BA off (--lba 0)")
                                + "; first image + initialisation (5-point pose from a caller hook) happen before the timed frames",
                    "track_set": "closed loop", "playback": "forward", "images": "resident in HBM", "local_ba": bool(args.lba),
-                   "strict_border": int(bool(args.strict_border)), "next_image": "prefetched (vo_mvo_prefetch)" if prefetch else "with its frame"},
+                   "strict_border": int(args.strict_border), "next_image": "prefetched (vo_mvo_prefetch)" if prefetch else "with its frame"},
         "loop": {"mean_tracks_in": round(float(I[:, 1].mean()), 1), "mean_final": round(float(I[:, 6].mean()), 1),
                  "mean_new_landmarks": round(float(I[:, 5].mean()), 1), "mean_ba_set": round(float(I[:, 10].mean()), 1),
                  "mean_gn_iterations": round(float(I[:, 9].mean()), 2), "keyframes": int((I[:, 7] > 0).sum()), "lba_runs": int((I[:, 8] > 0).sum()),

@@ -89,11 +89,13 @@ def test_mono_loop_small(vo, oracle):
     assert log[-1][1] > 300
 
 
-def test_mono_loop_config3_local_ba(vo, oracle):
+@pytest.mark.parametrize("strict", [1, 4])
+def test_mono_loop_config3_local_ba(vo, oracle, strict):
     """BASELINE configs[2] as a closed loop: 752x480, 40x25 buckets, win 15, 5 levels — 14 frames, a keyframe every two or
     three of them, the mono local BA from the third keyframe on (landmarks become bundled, the priors and the pose-only BA's
-    class switch to them), the next image handed over early."""
-    log, ref = _run_both(vo, oracle, 14, lba=True, strict=1, kf_trans=2.5, prefetch=True)
+    class switch to them), the next image handed over early. strict 4: the strict-border replay next to the frame kernel
+    whenever the previous frame replayed something."""
+    log, ref = _run_both(vo, oracle, 14, lba=True, strict=strict, kf_trans=2.5, prefetch=True)
     assert sum(1 for e in log if e[0]) >= 4, log
     assert sum(1 for e in log if e[2]) >= 2, log
     assert any(ref.lm[int(i)]["bundled"] for i in ref.ids)

@@ -13,7 +13,9 @@
 // too few points or fails, counts.need_five_point is set and the frame stops after the refinement.
 //
 // As in the stereo frame (frame_fused.hip) the per-feature steps — prior, forward KLT, backward KLT,
-// bidirectional mask, IC refinement — are one wavefront of ONE launch; the strict-border replay follows, then
+// bidirectional mask, IC refinement — are one wavefront of ONE launch; the strict-border replay follows — stream-ordered
+// (strict-border 1) or, as for stereo, as a pool of resident workgroups on a stream of its own NEXT TO the frame kernel
+// (strict-border 3; 4 chooses per frame), joined by the BA launch on the device — then
 // ONE more launch: the GN kernel in frame mode, whose prologue selects the BA set and whose epilogue is the
 // Sampson gate (mono_gate.hpp); the host reads one packed block. stage[i] = number of gates feature i passed (1 tracked, 2 refined,
 // 3 motion inlier or not part of the BA, 4 passed the Sampson gate).
@@ -45,6 +47,12 @@ struct MonoArgs {
   const uint8_t *cand_has;  // [n_new] the bin holds a keypoint
   float *new_r;             // out [n_new][2] forward result (pixel in I0)
   uint8_t *m_new;           // out [n_new] trackBidirection mask
+};
+// the replay's launches: the IC arguments and the hand-shake with the BA launch (vo_frame_state::sync)
+struct MonoReplayArgs {
+  IcArgs ic;
+  int *sync;        // sync[1]: finished workgroups of mono_fallback_kernel, cumulative
+  int sync_signal;  // concurrent replay: count there (the BA launch on the main stream waits for it)
 };
 
 template <int WIN>
@@ -165,42 +173,94 @@ __global__ __launch_bounds__(64) void mono_track_kernel(MonoArgs a) {
     cls = rf.cls;
   }
   const int any_t = __any(touched);
-  if (a.strict) ic_store_records(a.ic, i, lane, tp, S, cls);
+  // Everything the strict-border replay reads or rewrites goes through to memory (ic_store<true>): with the concurrent
+  // arrangement that kernel runs next to this one on other XCDs (frame_fused.hip has the same stores for the same reason).
+  if (a.strict) ic_store_records<true>(a.ic, i, lane, tp, S, cls);
   if (lane == 0) {
-    a.scale[i] = scale;
-    a.k1[2 * i] = fwd.x;
-    a.k1[2 * i + 1] = fwd.y;
     a.Xp[3 * i] = Xp[0];
     a.Xp[3 * i + 1] = Xp[1];
     a.Xp[3 * i + 2] = Xp[2];
     a.m1[i] = m1 ? 1 : 0;
     a.ba_ok[i] = ((fl & 2) && Xp[2] > 0.1f) ? 1 : 0;  // mono_vo.cpp:808-809 / :821-822
     a.orig[i] = i;
-    a.ic.pts_track[2 * i] = rf.x;
-    a.ic.pts_track[2 * i + 1] = rf.y;
-    a.ic.mask[i] = (uint8_t)rf.ok;
     if (rf.err_flag) atomicOr(a.ic.flags, rf.err_flag);
     if (a.strict) {
-      a.ic.touched[i] = (uint8_t)(any_t ? 1 : 0);
-      a.ic.cls[i] = (uint8_t)cls;
-      a.ic.last_pu[2 * i] = lpx;
-      a.ic.last_pu[2 * i + 1] = lpy;
-      if (any_t) a.ic.tlist[atomicAdd(&a.ic.jac[IC_JAC_NT], 1)] = i;
+      ic_store<true>(&a.scale[i], scale);
+      ic_store<true>(&a.k1[2 * i], fwd.x);
+      ic_store<true>(&a.k1[2 * i + 1], fwd.y);
+      ic_store<true>(&a.ic.pts_track[2 * i], rf.x);
+      ic_store<true>(&a.ic.pts_track[2 * i + 1], rf.y);
+      ic_store<true>(&a.ic.mask[i], (uint8_t)rf.ok);
+      ic_store<true>(&a.ic.touched[i], (uint8_t)(any_t ? 1 : 0));
+      ic_store<true>(&a.ic.cls[i], (uint8_t)cls);
+      ic_store<true>(&a.ic.last_pu[2 * i], lpx);
+      ic_store<true>(&a.ic.last_pu[2 * i + 1], lpy);
+      if (any_t) {
+        const int slot = atomicAdd(&a.ic.jac[IC_JAC_NT], 1);
+        ic_store<true>(&a.ic.tlist[slot], i);
+        if (a.ic.tl2)  // concurrent replay: the entry says which frame it belongs to
+          __hip_atomic_store(&a.ic.tl2[slot], ((unsigned long long)(unsigned)a.ic.epoch << 32) | (unsigned)i, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      a.scale[i] = scale;
+      a.k1[2 * i] = fwd.x;
+      a.k1[2 * i + 1] = fwd.y;
+      a.ic.pts_track[2 * i] = rf.x;
+      a.ic.pts_track[2 * i + 1] = rf.y;
+      a.ic.mask[i] = (uint8_t)rf.ok;
+    }
+  }
+  if (a.strict && a.ic.p1e) {
+    // Concurrent replay: it may use this feature's pass-1 data from here on. The stores it depends on are write-through:
+    // wait for them, then stamp and count.
+    __builtin_amdgcn_s_waitcnt(0);
+    if (lane == 0) {
+      ic_store<true>(&a.ic.p1e[i], a.ic.epoch);
+      atomicAdd(&a.ic.p1_word[(i & (IC_P1_SHARDS - 1)) * IC_P1_STRIDE], 1);
     }
   }
 }
 
-// strict border: the touched features (ic_replay), then the sequential fallback if it was requested
-__global__ __launch_bounds__(IC_T) void mono_replay_kernel(IcArgs a) {
+// strict border: the touched features (ic_replay), then the sequential fallback if it was requested.
+// (Register cap as frame_replay_kernel's: a replay wavefront shares its SIMD with frame-kernel wavefronts.)
+__global__ __launch_bounds__(IC_T) __attribute__((amdgpu_num_vgpr(288))) void mono_replay_kernel(MonoReplayArgs a) {
   __shared__ IcReplayShared rs;
-  (void)ic_replay(a, rs, threadIdx.x, [](int, const IcResult &) {});
+  if (a.ic.tl2) {  // next to the frame kernel: what that kernel wrote is read past the caches
+    __builtin_amdgcn_s_setprio(3);
+    (void)ic_replay<true>(a.ic, rs, threadIdx.x, [](int, const IcResult &) {});
+  } else {
+    (void)ic_replay(a.ic, rs, threadIdx.x, [](int, const IcResult &) {});
+  }
 }
-__global__ __launch_bounds__(IC_T) void mono_fallback_kernel(IcArgs a) {
+__global__ __launch_bounds__(IC_T) void mono_fallback_kernel(MonoReplayArgs a) {
   __shared__ IcShared sh;
-  if (a.jac[IC_JAC_OVF] == 0) return;
-  const int pt = blockIdx.x;
-  if (pt >= a.n) return;
-  ic_strict_run(a, sh, pt, a.n, threadIdx.x, [](int, const IcResult &) {});
+  const int lane = threadIdx.x;
+  bool work = a.ic.jac[IC_JAC_OVF] != 0;
+  if (work && a.sync_signal && a.ic.p1e) {
+    // Concurrent replay: ordered behind the replay pool, not behind the frame kernel whose pass-1 data this is about to
+    // read. The pool normally ends after the frame kernel's last pass 1; when it gave up early: wait here, bounded, report.
+    int polls = 0;
+    while ((int)(ic_p1_count(a.ic, lane) - a.ic.p1_target) < 0) {
+      if (++polls > IC_SPIN_LIMIT) {
+        if (lane == 0) atomicOr(a.ic.flags, 8);  // the frame is issued again by vo_mono_frame_result
+        work = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(32);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  if (work)
+    for (int pt = blockIdx.x; pt < a.ic.n; pt += gridDim.x) {
+      __syncthreads();
+      ic_strict_run(a.ic, sh, pt, a.ic.n, lane, [](int, const IcResult &) {});
+    }
+  // stream-ordered behind the replay: when all of its workgroups have counted, every touched feature is final
+  if (a.sync_signal) {
+    if (work) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) atomicAdd(&a.sync[1], 1);
+  }
 }
 
 // ---- host side ---------------------------------------------------------------------
@@ -314,7 +374,20 @@ static int mono_enqueue_impl(vo_ctx *c, const vo_mono_params *prm, int slot0, in
     a.H = prm->height;
     a.thres_err = prm->thres_err;
     a.thres_bidir = prm->thres_bidirection;
-    a.strict = c->frame_strict_ic;
+    // Strict-border arrangement of this frame (as frame_pipeline.hip): 4 takes the replay next to the frame kernel when the
+    // previous frame replayed something and the launch fits the chip; the gated arrangement (5) is the stereo frame's only.
+    int strict = c->frame_strict_ic;
+    if (strict == 4) strict = (f->last_replayed >= VO_CONC_MIN_REPLAYED && n + n_new <= VO_CONC_MAX_WORKGROUPS) ? 3 : 1;
+    if (strict == 5) strict = 1;
+    if (c->frame_conc_off && strict >= 3) strict = 1;  // a join timed out before: stream order
+    c->frame_strict_now = strict;
+    a.strict = strict;
+    {
+      int g = ((f->last_replayed + 32 + 31) / 32) * 32;
+      f->conc_grid = g < 64 ? 64 : (g > 256 ? 256 : g);
+      if (c->frame_strict_ic == 3) f->conc_grid = 256;
+      if (c->dbg[VO_DBG_CONC_GRID] > 0) f->conc_grid = c->dbg[VO_DBG_CONC_GRID];
+    }
     float *d_scale = (float *)(f->res_dev + f->off_pr1);  // written straight into the result block
     a.scale = d_scale;
     a.k1 = f->A_pl1;
@@ -333,20 +406,69 @@ static int mono_enqueue_impl(vo_ctx *c, const vo_mono_params *prm, int slot0, in
     a.ic.cls = f->A_cls;
     a.ic.last_pu = f->A_lastpu;
     a.ic.n = n;
+    const int fb_grid = n < 128 ? n : 128;
+    const int p1_before = f->sync_p1_target, done_before = f->sync_done_target;
+    if (strict == 3) {
+      // running totals of the two hand-shake counters, and the frame's epoch (the pass-1 target: different for every frame)
+      f->sync_p1_target += n;
+      f->sync_done_target += fb_grid;
+      a.ic.epoch = f->sync_p1_target != 0 ? f->sync_p1_target : 1;
+      a.ic.p1_word = f->sync + IC_P1_STRIDE;
+      a.ic.p1_target = f->sync_p1_target;
+    } else {
+      a.ic.tl2 = nullptr;
+      a.ic.p1e = nullptr;
+    }
+    // what vo_mono_frame_result needs to issue this frame again (device pointers only)
+    f->again_mono.prm = *prm;
+    f->again_mono.slot0 = slot0;
+    f->again_mono.slot1 = slot1;
+    f->again_mono.n = n;
+    f->again_mono.pts0 = d_p0;
+    f->again_mono.Xw = d_X;
+    f->again_mono.flags = d_fl;
+    memcpy(f->again_mono.Tcw_prev, Tcw_prev, sizeof(f->again_mono.Tcw_prev));
+    memcpy(f->again_mono.Tcw_prior, Tcw_prior, sizeof(f->again_mono.Tcw_prior));
+    memcpy(f->again_mono.dT01_prior, dT01_prior, sizeof(f->again_mono.dT01_prior));
+    f->again_mono.has_bins = bp ? 1 : 0;
+    if (bp) f->again_mono.bins = *bp;
+    f->again_mono.table = table;
     switch (prm->win) {
       case 13: mono_launch<13>(c, a); break;
       case 15: mono_launch<15>(c, a); break;
       case 21: mono_launch<21>(c, a); break;
       default: mono_launch<31>(c, a); break;
     }
-    if (a.strict) {
-      vo_prof_begin(c, VO_K_IC);
-      if (a.strict == 2)
-        (void)hipMemsetAsync(&a.ic.jac[IC_JAC_OVF], 1, sizeof(int), s);
-      else
-        hipLaunchKernelGGL(mono_replay_kernel, dim3(n < IC_JGRID ? n : IC_JGRID), dim3(IC_T), 0, s, a.ic);
-      hipLaunchKernelGGL(mono_fallback_kernel, dim3(n), dim3(IC_T), 0, s, a.ic);
-      vo_prof_end(c);
+    if (strict) {
+      MonoReplayArgs r;
+      memset(&r, 0, sizeof(r));
+      r.ic = a.ic;
+      r.sync = f->sync;
+      if (strict == 3) {
+        // The replay on its own stream next to the frame kernel, as a pool of resident workgroups that pick the touched
+        // features up as the frame kernel lists them (ic_replay<true>); the fallback behind it counts its workgroups in
+        // sync[1], the BA launch on the main stream waits for that count. No HIP event joins the streams (frame_fused.hip).
+        r.sync_signal = 1;
+        c->stream = c->stream3;
+        vo_prof_begin(c, VO_K_IC);
+        hipLaunchKernelGGL(mono_replay_kernel, dim3(n < f->conc_grid ? n : f->conc_grid), dim3(IC_T), 0, c->stream3, r);
+        vo_prof_end(c);
+        c->stream = s;
+        hipLaunchKernelGGL(mono_fallback_kernel, dim3(fb_grid), dim3(IC_T), 0, c->stream3, r);
+      } else {
+        vo_prof_begin(c, VO_K_IC);
+        if (strict == 2)
+          (void)hipMemsetAsync(&a.ic.jac[IC_JAC_OVF], 1, sizeof(int), s);
+        else
+          hipLaunchKernelGGL(mono_replay_kernel, dim3(n < IC_JGRID ? n : IC_JGRID), dim3(IC_T), 0, s, r);
+        hipLaunchKernelGGL(mono_fallback_kernel, dim3(strict == 2 ? (n < 1024 ? n : 1024) : fb_grid), dim3(IC_T), 0, s, r);
+        vo_prof_end(c);
+      }
+    }
+    if (hipGetLastError() != hipSuccess) {  // nothing of this frame will count: the cumulative targets go back
+      f->sync_p1_target = p1_before;
+      f->sync_done_target = done_before;
+      VO_FAIL(c, VO_ERR_HIP, "launch of the mono frame failed");
     }
     // BA set (refined && BA class && depth > 0.1, in index order; mono_vo.cpp:799-826, :846-860), pose-only BA
     // (class-surface variant, T01 initialised with the motion prior, :856-867) and the tail of the frame: ONE launch.
@@ -406,6 +528,11 @@ static int mono_enqueue_impl(vo_ctx *c, const vo_mono_params *prm, int slot0, in
     gf.ctl_words = (int)(vo_ic_ctl_bytes() / 4);
     gf.nt_word = vo_ic_ctl_nt_word();
     gf.hdr_flags = &f->hdr->flags;
+    if (strict == 3) {  // the replay runs on its own stream: join on the device
+      gf.join_word = f->sync + 1;
+      gf.join_target = f->sync_done_target;
+      if (c->dbg[VO_DBG_FAIL_JOIN]) gf.join_target += 1 << 20;  // tests: a join that cannot be met
+    }
     gf.mono_gate = &g;
     rc = vo_gn_enqueue(c, false, true, f->C_X, f->C_pl1, nullptr, n, nullptr, prm->K, prm->K, nullptr,
                        (float)prm->thres_poseba, VO_GN_VARIANT_CORE, dT01_prior, f->hdr->dT, f->mG, &f->hdr->gn, true,
@@ -468,8 +595,30 @@ extern "C" int vo_mono_frame_result(vo_ctx *c, float *pts1, float *scale, uint8_
   f->known_done = false;
   f->pending = false;
   c->frame_slots_busy = 0;
+  f->recovered = 0;
   const int n = f->n;
   const vo_frame_hdr *h = (const vo_frame_hdr *)f->res_host;
+  if ((h->flags & 8) && n > 0 && c->frame_strict_now == 3) {
+    // The device-side join with the replay stream timed out (the two queues did not run concurrently: a serialising tool,
+    // a busy GPU). As for the stereo frame: drain the streams, re-base the hand-shake words, switch the context to the
+    // stream-ordered replay for good and issue the frame again from its (intact) device inputs.
+    VO_CHECK_HIP(c, hipStreamSynchronize(c->stream3));
+    VO_CHECK_HIP(c, hipStreamSynchronize(c->stream_main));
+    VO_CHECK_HIP(c, hipMemsetAsync(f->sync, 0, 128 + 64 * 128, c->stream_main));
+    VO_CHECK_HIP(c, hipMemsetAsync(f->ctl, 0, vo_ic_ctl_bytes(), c->stream_main));
+    f->sync_p1_target = f->sync_done_target = 0;
+    c->frame_conc_off = 1;
+    ++c->frame_recoveries;
+    const auto g = f->again_mono;
+    const int rc2 = mono_enqueue_impl(c, &g.prm, g.slot0, g.slot1, g.pts0, g.Xw, g.flags, g.n, g.Tcw_prev, g.Tcw_prior, g.dT01_prior, 1,
+                                      g.has_bins ? &g.bins : nullptr, g.table);
+    if (rc2 < 0) return rc2;
+    VO_CHECK_HIP(c, hipEventSynchronize(f->ev_done));
+    f->pending = false;
+    c->frame_slots_busy = 0;
+    f->recovered = 1;
+  }
+  f->last_replayed = n > 0 ? h->cnt[7] : 0;
   if (pts1 && n) memcpy(pts1, f->res_host + f->off_pl1, sizeof(float) * 2 * (size_t)n);
   if (scale && n) memcpy(scale, f->res_host + f->off_pr1, sizeof(float) * (size_t)n);
   if (stage && n) memcpy(stage, f->res_host + f->off_stage, (size_t)n);
@@ -495,6 +644,7 @@ extern "C" int vo_mono_frame_result(vo_ctx *c, float *pts1, float *scale, uint8_
   if (h->flags) {
     if (h->flags & 1) VO_FAIL(c, VO_ERR_NAN_AXAY, "ax ay nan");
     if (h->flags & 2) VO_FAIL(c, VO_ERR_NAN_PATCH, "I0 I1 / du0 dv0 nan");
+    if (h->flags & 8) VO_FAIL(c, VO_ERR_HIP, "the strict-border replay stream did not finish (device-side join timed out twice)");
     VO_FAIL(c, VO_ERR_NAN_UPDATE, "dtu dtv nan");
   }
   return VO_OK;

@@ -103,8 +103,7 @@ static void inv_se3(const float T[16], float Ti[16]) {
   Ti[15] = 1;
 }
 
-#define VO_CONC_MIN_REPLAYED 16
-#define VO_CONC_MAX_WORKGROUPS 4096  // twice the frame kernel's resident wavefronts on 256 compute units
+// (VO_CONC_MIN_REPLAYED / VO_CONC_MAX_WORKGROUPS: frame_state.hpp)
 #define RC(x)                \
   do {                       \
     int _rc = (x);           \

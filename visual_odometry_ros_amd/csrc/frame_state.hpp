@@ -74,6 +74,15 @@ struct vo_frame_state {
     float T_pw[16], T_cw_prior[16];
     VoAdvArgs adv;
   } again;
+  // the same for the mono frame (vo_mono_frame_result)
+  struct {
+    vo_mono_params prm;
+    int slot0, slot1, n, has_bins, table;
+    const float *pts0, *Xw;
+    const uint8_t *flags;
+    float Tcw_prev[16], Tcw_prior[16], dT01_prior[16];
+    vo_bin_params bins;
+  } again_mono;
   // StereoVO: what the NEXT enqueue hands to the BA launch so that its epilogue builds the next track set
   // (vo_frame_set_advance, consumed by that enqueue); the DLT workers' cumulative completion count and its running target
   VoAdvArgs adv_next;
@@ -87,5 +96,10 @@ struct vo_frame_state {
   int adv_total;
   int recovered;      // the last result was produced by such a re-issue
 };
+
+// strict-border mode 4 takes the concurrent replay for a frame when the previous one replayed at least this many features
+// and the frame kernel is not many times the chip's resident wavefronts (frame_pipeline.hip, frame_mono.hip)
+#define VO_CONC_MIN_REPLAYED 16
+#define VO_CONC_MAX_WORKGROUPS 4096  // twice the frame kernel's resident wavefronts on 256 compute units
 
 int vo_frame_init(vo_ctx *c);

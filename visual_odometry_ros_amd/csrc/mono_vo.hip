@@ -586,7 +586,7 @@ extern "C" int vo_mvo_create(vo_ctx *c, const vo_mvo_params *prm, vo_mvo **out) 
     k.ts[1] = s->ts[1].t;
     rc = vo_svo_lba_init(&k);
   }
-  if (rc >= 0) rc = vo_stereo_frame_set_strict_border(c, prm->strict_border ? (prm->strict_border == 2 ? 2 : 1) : 0);
+  if (rc >= 0) rc = vo_stereo_frame_set_strict_border(c, prm->strict_border);
   if (rc >= 0) rc = vo_set_pyramid_window_hint(c, prm->frame.win);
   if (rc >= 0) rc = vo_set_ingest_side_stream(c, 1);
   if (rc < 0) {
