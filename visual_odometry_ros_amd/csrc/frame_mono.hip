@@ -30,6 +30,8 @@ struct MonoArgs {
   int max_level, n;
   const float *pts0, *Xw;
   const uint8_t *flags;
+  int flag_mode;  // 0: operator flags (vo_hip.h); 1 / 2: a MonoVO track set's flags (VO_LM_*), the pose-only BA's class =
+                  // triangulated / bundled landmarks (mono_vo.cpp:800-826)
   float Tcw_prev[16], Tcw_prior[16], K[4];
   int W, H;
   float thres_err, thres_bidir;
@@ -82,7 +84,13 @@ __global__ __launch_bounds__(64) void mono_track_kernel(MonoArgs a) {
     __builtin_amdgcn_s_setprio(1);
   }
   const float p0x = feat ? a.pts0[2 * i] : a.pts_new[2 * j], p0y = feat ? a.pts0[2 * i + 1] : a.pts_new[2 * j + 1];
-  const int fl = feat ? a.flags[i] : 0;
+  int fl = feat ? a.flags[i] : 0;
+  if (a.flag_mode && feat) {
+    const int t = fl;
+    fl = (t & VO_LM_BUNDLED) ? 1 : 0;
+    if (t & (a.flag_mode == 2 ? VO_LM_BUNDLED : VO_LM_TRIANGULATED)) fl |= 2;
+    if (t & VO_LM_DROPPED) fl |= VO_MONO_LM_DROPPED;
+  }
   // ---- prior + patch scale (mono_vo.cpp:739-761) ----
   float Xp[3] = {0.f, 0.f, 0.f};
   float prx = p0x, pry = p0y, scale = 1.0f;
@@ -273,6 +281,22 @@ static void mono_launch(vo_ctx *c, const MonoArgs &a) {
   vo_prof_end(c);
 }
 
+// MonoVO (mono_vo.hip): the next vo_mono_frame_enqueue* lets the BA launch build the next track set (mvo_advance_body)
+int vo_mono_frame_set_advance(vo_ctx *c, const MvoAdvArgs *adv) {
+  int rc = vo_frame_init(c);
+  if (rc < 0) return rc;
+  c->frame->mvo_adv = *adv;
+  c->frame->mvo_adv_on = 1;
+  return VO_OK;
+}
+
+int vo_mono_frame_set_track_flags(vo_ctx *c, int mode) {
+  int rc = vo_frame_init(c);
+  if (rc < 0) return rc;
+  c->frame->mono_flag_mode = mode;
+  return VO_OK;
+}
+
 // bp != null: the closed new-point step — the candidates are the per-bin best keypoints of table `table`
 // (vo_new_point_candidates_enqueue on the image in slot1), all tracked speculatively, emitted by the BA launch's epilogue
 static int mono_enqueue_impl(vo_ctx *c, const vo_mono_params *prm, int slot0, int slot1, const float *pts0,
@@ -305,6 +329,10 @@ static int mono_enqueue_impl(vo_ctx *c, const vo_mono_params *prm, int slot0, in
   // one result block, one staging set and one completion event per context: a second frame would overwrite them
   // while the first one's kernels still use them
   if (f->pending) VO_FAIL(c, VO_ERR_INVALID, "a frame is already in flight: call vo_mono_frame_result first");
+  // a track-set advance armed by vo_mono_frame_set_advance belongs to THIS enqueue, whether it gets as far as the BA launch or not
+  const int adv_on = f->mvo_adv_on, flag_mode = f->mono_flag_mode;
+  f->mvo_adv_on = 0;
+  f->mono_flag_mode = 0;
   hipStream_t s = c->stream;
   const float *d_p0 = pts0, *d_X = Xw;
   const uint8_t *d_fl = flags;
@@ -367,6 +395,7 @@ static int mono_enqueue_impl(vo_ctx *c, const vo_mono_params *prm, int slot0, in
     a.pts0 = d_p0;
     a.Xw = d_X;
     a.flags = d_fl;
+    a.flag_mode = flag_mode;
     memcpy(a.Tcw_prev, Tcw_prev, sizeof(a.Tcw_prev));
     memcpy(a.Tcw_prior, Tcw_prior, sizeof(a.Tcw_prior));
     memcpy(a.K, prm->K, sizeof(a.K));
@@ -433,6 +462,9 @@ static int mono_enqueue_impl(vo_ctx *c, const vo_mono_params *prm, int slot0, in
     f->again_mono.has_bins = bp ? 1 : 0;
     if (bp) f->again_mono.bins = *bp;
     f->again_mono.table = table;
+    f->again_mono.adv_on = adv_on;
+    f->again_mono.flag_mode = flag_mode;
+    if (adv_on) f->again_mono.adv = f->mvo_adv;
     switch (prm->win) {
       case 13: mono_launch<13>(c, a); break;
       case 15: mono_launch<15>(c, a); break;
@@ -512,6 +544,16 @@ static int mono_enqueue_impl(vo_ctx *c, const vo_mono_params *prm, int slot0, in
       g.np.host_r = (float *)(f->res_host + f->off_newr);
       g.np.host_m = f->res_host + f->off_mnew;
     }
+    g.hdr_flags = &f->hdr->flags;
+    if (adv_on) {
+      g.adv_on = 1;
+      g.adv = f->mvo_adv;
+      g.adv.stage = g.stage;
+      g.adv.pts1 = g.pts1;
+      g.adv.cand1 = g.np.out_l;
+      g.adv.cand0 = g.np.out_r;
+      g.adv.mnew = g.np.out_m;
+    }
     vo_gn_frame gf;
     memset(&gf, 0, sizeof(gf));
     gf.n = n;
@@ -557,16 +599,18 @@ static int mono_enqueue_impl(vo_ctx *c, const vo_mono_params *prm, int slot0, in
 extern "C" int vo_mono_frame_enqueue(vo_ctx *c, const vo_mono_params *prm, int slot0, int slot1, const float *pts0,
                                      const float *Xw, const uint8_t *flags, int n, const float Tcw_prev[16],
                                      const float Tcw_prior[16], const float dT01_prior[16], int inputs_on_device) {
-  return mono_enqueue_impl(c, prm, slot0, slot1, pts0, Xw, flags, n, Tcw_prev, Tcw_prior, dT01_prior, inputs_on_device, nullptr,
-                           0);
+  const int rc = mono_enqueue_impl(c, prm, slot0, slot1, pts0, Xw, flags, n, Tcw_prev, Tcw_prior, dT01_prior, inputs_on_device, nullptr, 0);
+  if (c && c->frame) c->frame->mvo_adv_on = c->frame->mono_flag_mode = 0;
+  return rc;
 }
 extern "C" int vo_mono_frame_enqueue_closed(vo_ctx *c, const vo_mono_params *prm, int slot0, int slot1, const float *pts0,
                                             const float *Xw, const uint8_t *flags, int n, const float Tcw_prev[16],
                                             const float Tcw_prior[16], const float dT01_prior[16],
                                             const vo_bin_params *bins, int table, int inputs_on_device) {
   if (!bins) return VO_ERR_INVALID;
-  return mono_enqueue_impl(c, prm, slot0, slot1, pts0, Xw, flags, n, Tcw_prev, Tcw_prior, dT01_prior, inputs_on_device, bins,
-                           table);
+  const int rc = mono_enqueue_impl(c, prm, slot0, slot1, pts0, Xw, flags, n, Tcw_prev, Tcw_prior, dT01_prior, inputs_on_device, bins, table);
+  if (c && c->frame) c->frame->mvo_adv_on = c->frame->mono_flag_mode = 0;
+  return rc;
 }
 
 // the new points of the closed frame just received (vo_mono_frame_result first): pixels in I1 (the bucketed keypoints),
@@ -610,6 +654,11 @@ extern "C" int vo_mono_frame_result(vo_ctx *c, float *pts1, float *scale, uint8_
     c->frame_conc_off = 1;
     ++c->frame_recoveries;
     const auto g = f->again_mono;
+    f->mono_flag_mode = g.flag_mode;
+    if (g.adv_on) {  // (MonoVO: the re-issued frame builds the next track set again)
+      f->mvo_adv = g.adv;
+      f->mvo_adv_on = 1;
+    }
     const int rc2 = mono_enqueue_impl(c, &g.prm, g.slot0, g.slot1, g.pts0, g.Xw, g.flags, g.n, g.Tcw_prev, g.Tcw_prior, g.dT01_prior, 1,
                                       g.has_bins ? &g.bins : nullptr, g.table);
     if (rc2 < 0) return rc2;

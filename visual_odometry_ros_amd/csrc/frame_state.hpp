@@ -1,6 +1,7 @@
 // frame_state.hpp — device / pinned buffers shared by the frame operators (frame_pipeline.hip: stereo,
 // frame_mono.hip: mono). Allocated once per context by vo_frame_init (capacity cfg.max_points).
 #pragma once
+#include "mvo_device.hpp"
 #include "svo_device.hpp"
 #include "vo_internal.hpp"
 
@@ -82,7 +83,14 @@ struct vo_frame_state {
     const uint8_t *flags;
     float Tcw_prev[16], Tcw_prior[16], dT01_prior[16];
     vo_bin_params bins;
+    int adv_on, flag_mode;
+    MvoAdvArgs adv;
   } again_mono;
+  // MonoVO: what the NEXT mono enqueue hands to the BA launch so that its epilogue builds the next track set
+  // (vo_mono_frame_set_advance, consumed by that enqueue)
+  MvoAdvArgs mvo_adv;
+  int mvo_adv_on;
+  int mono_flag_mode;  // the NEXT mono enqueue's flag bytes are track-set flags (VO_LM_*): 1 BA class = triangulated, 2 = bundled
   // StereoVO: what the NEXT enqueue hands to the BA launch so that its epilogue builds the next track set
   // (vo_frame_set_advance, consumed by that enqueue); the DLT workers' cumulative completion count and its running target
   VoAdvArgs adv_next;

@@ -78,6 +78,7 @@ struct GnArgs {
   int f_mono;               // epilogue = mono_gate_body(f_gate)
   MonoGateArgs f_gate;
 };
+static_assert(sizeof(GnArgs) <= 3072, "kernel arguments of the BA launch: keep well below the 4 KB segment");
 
 // upper-triangular index of (i,j), i<=j, row-major: matches oracle UT[][]
 __device__ __forceinline__ constexpr int ut(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
@@ -790,7 +791,7 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
   if (a.f_n > 0 && a.f_mono) {
     // mono frame: mask_motion, Sampson gate, stages, counts and the copy of the result block (mono_gate.hpp)
     __syncthreads();  // inlier mask, pose and info above are this workgroup's own stores
-    mono_gate_body(a.f_gate, tid, GN_T, n, (uint8_t *)s_red, (int *)s_tot);
+    mono_gate_body<GN_T>(a.f_gate, tid, n, (uint8_t *)s_red, (int *)s_tot);
   } else if (a.f_n > 0 && a.f_res_host) {
     // frame mode epilogue: the packed result block goes to pinned host memory from here
     __syncthreads();  // stage marks, pose and info above are this workgroup's own stores

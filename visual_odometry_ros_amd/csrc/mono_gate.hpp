@@ -2,6 +2,7 @@
 // function: it runs inside the GN launch, right after the iterations, so the frame needs no further launch.
 #pragma once
 #include "vo_internal.hpp"
+#include "mvo_device.hpp"
 #include "np_emit.hpp"
 
 // ---- after the GN iterations of a mono frame: mask_motion, Sampson gate, stages, counts, result copy-out ----
@@ -23,6 +24,11 @@ struct MonoGateArgs {
   uint32_t *res_host;
   int res_words;
   VoNpArgs np;              // closed new-point step (mono_vo.cpp:977-1001): see np_emit.hpp; np.bins == 0: off
+  // MonoVO (mono_vo.hip): the next track set is built here, behind everything else (mvo_advance_body); its stage / pixel /
+  // new-point pointers are filled in from the fields above by the enqueue
+  int adv_on;
+  const int *hdr_flags;     // the frame's error flags (a frame that failed is the host's to finish)
+  MvoAdvArgs adv;
 };
 __device__ __forceinline__ float mono_dot3(float a0, float b0, float a1, float b1, float a2, float b2) {
   return a0 * b0 + (a1 * b1 + a2 * b2);  // Eigen's unrolled 3-term redux
@@ -30,7 +36,9 @@ __device__ __forceinline__ float mono_dot3(float a0, float b0, float a1, float b
 // Runs as the epilogue of gn_pose_kernel<false> (frame mode, mono): `nthr` lanes of one workgroup, n_ba = size of the
 // BA set the solve just used. The caller has passed a __syncthreads() since the solve's last global stores.
 // s_occ / s_wv: LDS scratch of the caller for the closed new-point step (np_emit.hpp).
-__device__ __forceinline__ void mono_gate_body(const MonoGateArgs &a, int tid, int nthr, int n_ba, uint8_t *s_occ, int *s_wv) {
+template <int NTHR>
+__device__ __forceinline__ void mono_gate_body(const MonoGateArgs &a, int tid, int n_ba, uint8_t *s_occ, int *s_wv) {
+  constexpr int nthr = NTHR;
   __shared__ float sF[9];
   __shared__ int s_cnt[8];
   __shared__ int s_ok;
@@ -124,5 +132,7 @@ __device__ __forceinline__ void mono_gate_body(const MonoGateArgs &a, int tid, i
   // launches' stores, and this workgroup's own above)
   __syncthreads();
   for (int k = tid; k < a.res_words; k += nthr) a.res_host[k] = a.res_dev[k];
+  if (a.adv_on)  // (cnt[6], the stages, pixels and new points: this workgroup's stores, behind the barrier above)
+    mvo_advance_body<NTHR / 64>(a.adv, a.dT, !ok || *a.hdr_flags != 0, a.np.bins > 0 ? a.cnt[6] : 0, tid);
 }
 

@@ -34,66 +34,17 @@
 #include <algorithm>
 #include <vector>
 
+#include "mvo_device.hpp"
 #include "stereo_vo.hpp"
+
+int vo_mono_frame_set_advance(vo_ctx *c, const MvoAdvArgs *adv);  // frame_mono.hip
+int vo_mono_frame_set_track_flags(vo_ctx *c, int mode);
 
 #define RC(x)                \
   do {                       \
     int _rc = (x);           \
     if (_rc < 0) return _rc; \
   } while (0)
-
-#define MVO_FRAME_RING (1 << 14)
-#define MVO_COS_NONE 2.0f  // no parallax yet (last_parallax_ = 0): never passes the threshold
-
-struct MvoSet {
-  SvoTrackSet t;     // pts_l = pts_r = the pixel seen; Xw; flags; ids (what stereo_vo_lba.hip reads)
-  float *p_first;    // [cap][2] observations_.front()
-  int32_t *f_first;  // [cap]    index of related_frames_.front()
-  int32_t *age;      // [cap]
-  float *cos_last;   // [cap]    cos of last_parallax_ (MVO_COS_NONE: none)
-  int32_t *n_kf;     // [cap]    observations_on_keyframes_.size()
-  float *p_kf_first; // [cap][2] observations_on_keyframes_.front()
-  int32_t *kf_first; // [cap]    frame index of related_keyframes_.front()
-};
-struct MvoHdr {
-  int n_surv, n_new, n_next, n_kf_tracked, id_min, overflow, n_recon, pad;
-  uint32_t seq;
-};
-
-// Matrix4f * Matrix4f in Eigen's evaluation order (as svo_mul44), rows 0..2 only
-__device__ __forceinline__ void mvo_mul34(const float *A, const float *B, float (&C)[12]) {
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float r = A[i * 4 + 0] * B[0 * 4 + j];
-#pragma unroll
-      for (int k = 1; k < 4; ++k) r = A[i * 4 + k] * B[k * 4 + j] + r;
-      C[i * 4 + j] = r;
-    }
-}
-__device__ __forceinline__ float mvo_dot3(float a0, float b0, float a1, float b1, float a2, float b2) { return a0 * b0 + (a1 * b1 + a2 * b2); }
-
-// landmark.cpp:100-116: cos of the parallax between the oldest observation p0 (frame of inverse pose Tcw0) and the newest p1
-// (frame of pose Twc1), pushed inside (-1, 1)
-__device__ __forceinline__ float mvo_parallax_cos(float p0x, float p0y, float p1x, float p1y, const float K[4], const float *Tcw0,
-                                                  const float *Twc1) {
-  float T01[12];
-  mvo_mul34(Tcw0, Twc1, T01);
-  const float fxinv = 1.0f / K[0], fyinv = 1.0f / K[1];
-  const float x0[3] = {(p0x - K[2]) * fxinv, (p0y - K[3]) * fyinv, 1.0f};
-  const float x1[3] = {(p1x - K[2]) * fxinv, (p1y - K[3]) * fyinv, 1.0f};
-  float r[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) r[i] = mvo_dot3(T01[i * 4 + 0], x1[0], T01[i * 4 + 1], x1[1], T01[i * 4 + 2], x1[2]);
-  const float dot = mvo_dot3(x0[0], r[0], x0[1], r[1], x0[2], r[2]);
-  const float n0 = sqrtf(mvo_dot3(x0[0], x0[0], x0[1], x0[1], x0[2], x0[2]));
-  const float n1 = sqrtf(mvo_dot3(r[0], r[0], r[1], r[1], r[2], r[2]));
-  float c = dot / (n0 * n1);
-  if (c >= 1.0f) c = 0.99999f;
-  if (c <= -1.0f) c = -0.99999f;
-  return c;
-}
 
 // mapping::triangulateDLT for one camera with T10 = T1w * Tw0 (mono_vo.cpp:672-678, :1046-1052); true + Xworld = Tw0 * X0 when
 // the landmark is reconstructed (keyframe_rule: both reprojections within 1 px and both depths positive, :1054-1073;
@@ -138,111 +89,31 @@ __device__ bool mvo_reconstruct(float p0x, float p0y, float p1x, float p1y, cons
   return true;
 }
 
-// exclusive scan of one int per thread over a workgroup of 1024; every thread gets the total
-__device__ __forceinline__ int mvo_block_scan(int v, int *s_w, int &total) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int inc = v;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int t = __shfl_up(inc, off);
-    if (lane >= off) inc += t;
-  }
-  __syncthreads();
-  if (lane == 63) s_w[wave] = inc;
-  __syncthreads();
-  int before = 0, tot = 0;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int c = s_w[k];
-    before += k < wave ? c : 0;
-    tot += c;
-  }
-  total = tot;
-  return before + inc - v;
-}
-
-// ---- the next track set: lmtrack_final in index order (addObservationAndRelatedFrame for each: age, parallax), then the new
-// landmarks Landmark(p0_new, frame_prev_) + observation (p1_new, frame_curr) (mono_vo.cpp:964-1018) ----------------------
-struct MvoAdvArgs {
-  MvoSet cur, nxt;
-  int n, cap;
-  const uint8_t *stage;    // [n] 4 = in lmtrack_final
-  const float *pts1;       // [n][2] pixel in the current image
-  const float *cand1, *cand0;  // new points: pixel in I1, back-tracked pixel in I0
-  const uint8_t *mnew;
-  int m;                   // candidates emitted
-  int id_base, f;          // first new landmark id, index of the current frame
-  float K[4];
-  float T_obs[16];         // pose of the current frame as the survivors' observation sees it (identity at initialisation)
-  float T_wc[16], T_cw[16];  // pose of the current frame (what the new landmarks see, and the frame table's entry f)
-  float *frameT;           // [ring][32]
-  MvoHdr *hdr_dev, *hdr_host;
-  uint32_t seq;
-  int *pos_s, *pos_n;      // [cap] scratch: where survivor k / new point j goes in the next set (-1: nowhere)
-  // Chained behind the frame's BA launch (no host round trip in between): the frame's own header says how many candidates were
-  // emitted and what the pose-only BA found; T_wc = T_wp * dT01 (frame_curr->setPose(Twc_prev * dT01), mono_vo.cpp:883) is
-  // formed here, with the host's operation order. A frame that needs the 5-point fallback (or failed) is left to the host.
-  const vo_frame_hdr *fh;  // null: m, T_obs, T_wc, T_cw above are the host's
-  float T_wp[16];
-};
-__device__ __forceinline__ bool mvo_chain_skip(const vo_frame_hdr *fh) { return fh->cnt[5] != 0 || fh->flags != 0; }
-// Two launches: the ORDER (one workgroup: which entries survive and where they go — a scan — the counts and the sequence word
-// the host waits for) and the WORK (one lane per entry, any number of workgroups: the copies and the parallaxes, nothing
-// serial). The first version did both in the one workgroup: 18.6 us, most of it dependent rounds of loads behind the scans.
+// The advance step as launches of its own (initialisation, 5-point fallback, VO_DBG_MVO_HOST_ADVANCE; a steady-state frame
+// has it in its BA launch's epilogue: mvo_advance_body, mvo_device.hpp). Two launches: the ORDER (one workgroup: which entries
+// survive and where they go — a scan — the counts and the sequence word the host waits for) and the WORK (one lane per entry,
+// any number of workgroups: the copies and the parallaxes, nothing serial).
 __global__ __launch_bounds__(1024) void mvo_advance_scan_kernel(MvoAdvArgs a) {
   __shared__ int s_w[16];
   __shared__ int s_kft[16];
-  __shared__ float s_T[16];
+  __shared__ int s_idmin;
   const int tid = threadIdx.x;
-  if (a.fh) {
-    if (mvo_chain_skip(a.fh)) {  // the host takes this frame (5-point fallback / error): nothing of the next set is built
-      if (tid == 0) {
-        MvoHdr h;
-        memset(&h, 0, sizeof(h));
-        h.pad = 1;
-        *a.hdr_dev = h;
-        *a.hdr_host = h;
-        __threadfence_system();
-        __hip_atomic_store(&a.hdr_host->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-      return;
-    }
-    a.m = a.fh->cnt[6];
-    if (tid < 16) {  // svo_mul44(T_wp, dT01), element by element
-      const int i = tid >> 2, j = tid & 3;
-      const float *B = a.fh->dT;
-      float r = a.T_wp[i * 4 + 0] * B[0 * 4 + j];
-#pragma unroll
-      for (int k = 1; k < 4; ++k) r = a.T_wp[i * 4 + k] * B[k * 4 + j] + r;
-      s_T[tid] = r;
-    }
-    __syncthreads();
-    if (tid < 16) {  // svo_inv_se3 of it
-      const int i = tid >> 2, j = tid & 3;
-      float v;
-      if (i == 3)
-        v = j == 3 ? 1.0f : 0.0f;
-      else if (j < 3)
-        v = s_T[j * 4 + i];
-      else
-        v = ((-s_T[0 * 4 + i]) * s_T[3] + (-s_T[1 * 4 + i]) * s_T[7]) + (-s_T[2 * 4 + i]) * s_T[11];
-      a.frameT[(size_t)(a.f & (MVO_FRAME_RING - 1)) * 32 + tid] = s_T[tid];
-      a.frameT[(size_t)(a.f & (MVO_FRAME_RING - 1)) * 32 + 16 + tid] = v;
-    }
-  } else if (tid < 16) {  // the frame table's entry of this frame (T_wc | T_cw)
+  if (tid < 16) {  // the frame table's entry of this frame (T_wc | T_cw)
     a.frameT[(size_t)(a.f & (MVO_FRAME_RING - 1)) * 32 + tid] = a.T_wc[tid];
     a.frameT[(size_t)(a.f & (MVO_FRAME_RING - 1)) * 32 + 16 + tid] = a.T_cw[tid];
   }
-  int base = 0, kft = 0, id_first = a.id_base;
+  if (tid == 0) s_idmin = a.id_base;
+  __syncthreads();
+  int base = 0, kft = 0;
   for (int c0 = 0; c0 < a.n; c0 += 1024) {
     const int k = c0 + tid;
     const int ok = (k < a.n && a.stage[k] == 4) ? 1 : 0;
     int total;
-    const int pos = base + mvo_block_scan(ok, s_w, total);
+    const int pos = base + mvo_block_scan<16>(ok, s_w, total);
     if (k < a.n) a.pos_s[k] = (ok && pos < a.cap) ? pos : -1;
     if (ok) {
       kft += (a.cur.t.flags[k] & VO_LM_KF_MEMBER) ? 1 : 0;
-      if (pos == 0) a.hdr_dev->id_min = a.cur.t.ids[k];  // (the next set's first id; overwritten below when there is no survivor)
+      if (pos == 0) s_idmin = a.cur.t.ids[k];
     }
     base += total;
   }
@@ -251,16 +122,13 @@ __global__ __launch_bounds__(1024) void mvo_advance_scan_kernel(MvoAdvArgs a) {
     const int j = c0 + tid;
     const int ok = (j < a.m && a.mnew[j]) ? 1 : 0;
     int total;
-    const int r = base + mvo_block_scan(ok, s_w, total);
+    const int r = base + mvo_block_scan<16>(ok, s_w, total);
     if (j < a.m) a.pos_n[j] = (ok && r < a.cap) ? r : -1;
     base += total;
   }
-  (void)id_first;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) kft += __shfl_down(kft, off);
-  __syncthreads();
   if ((tid & 63) == 0) s_kft[tid >> 6] = kft;
-  __threadfence();
   __syncthreads();
   if (tid == 0) {
     int t = 0;
@@ -274,7 +142,7 @@ __global__ __launch_bounds__(1024) void mvo_advance_scan_kernel(MvoAdvArgs a) {
     h.n_recon = 0;
     h.pad = 0;
     h.seq = 0;
-    h.id_min = n_surv > 0 ? a.hdr_dev->id_min : a.id_base;  // (another thread's store, behind the fence and the barrier)
+    h.id_min = s_idmin;  // (the next set's first id; the first new id when nothing survived)
     *a.hdr_dev = h;
     *a.hdr_host = h;
     __threadfence_system();
@@ -283,64 +151,25 @@ __global__ __launch_bounds__(1024) void mvo_advance_scan_kernel(MvoAdvArgs a) {
 }
 __global__ __launch_bounds__(256) void mvo_advance_work_kernel(MvoAdvArgs a) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  float T_obs[16], T_wc[16];
-  if (a.fh) {
-    if (mvo_chain_skip(a.fh)) return;
-    a.m = a.fh->cnt[6];
-    const float *Tf = a.frameT + (size_t)(a.f & (MVO_FRAME_RING - 1)) * 32;  // (the order launch's)
-#pragma unroll
-    for (int k = 0; k < 16; ++k) T_obs[k] = T_wc[k] = Tf[k];
-  } else {
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      T_obs[k] = a.T_obs[k];
-      T_wc[k] = a.T_wc[k];
-    }
-  }
   if (g < a.n) {
-    const int k = g, pos = a.pos_s[k];
+    const int pos = a.pos_s[g];
     if (pos >= 0) {
-      const float px = a.pts1[2 * k], py = a.pts1[2 * k + 1];
-      a.nxt.t.pts_l[2 * pos] = px;
-      a.nxt.t.pts_l[2 * pos + 1] = py;
-      a.nxt.t.ids[pos] = a.cur.t.ids[k];
-      a.nxt.t.flags[pos] = a.cur.t.flags[k];
-      a.nxt.t.Xw[3 * pos] = a.cur.t.Xw[3 * k];
-      a.nxt.t.Xw[3 * pos + 1] = a.cur.t.Xw[3 * k + 1];
-      a.nxt.t.Xw[3 * pos + 2] = a.cur.t.Xw[3 * k + 2];
-      const float p0x = a.cur.p_first[2 * k], p0y = a.cur.p_first[2 * k + 1];
-      const int f0 = a.cur.f_first[k];
-      a.nxt.p_first[2 * pos] = p0x;
-      a.nxt.p_first[2 * pos + 1] = p0y;
-      a.nxt.f_first[pos] = f0;
-      a.nxt.age[pos] = a.cur.age[k] + 1;
-      a.nxt.n_kf[pos] = a.cur.n_kf[k];
-      a.nxt.p_kf_first[2 * pos] = a.cur.p_kf_first[2 * k];
-      a.nxt.p_kf_first[2 * pos + 1] = a.cur.p_kf_first[2 * k + 1];
-      a.nxt.kf_first[pos] = a.cur.kf_first[k];
-      // (f0 < f: that entry of the frame table was written by an earlier launch)
-      a.nxt.cos_last[pos] = mvo_parallax_cos(p0x, p0y, px, py, a.K, a.frameT + (size_t)(f0 & (MVO_FRAME_RING - 1)) * 32 + 16, T_obs);
+      float T[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) T[k] = a.T_obs[k];
+      mvo_put_survivor(a, g, pos, a.pts1[2 * g], a.pts1[2 * g + 1], T);
     }
     return;
   }
   const int j = g - a.n;
   if (j >= a.m) return;
   const int r = a.pos_n[j];
-  if (r < 0) return;
-  const float p0x = a.cand0[2 * j], p0y = a.cand0[2 * j + 1], p1x = a.cand1[2 * j], p1y = a.cand1[2 * j + 1];
-  a.nxt.t.pts_l[2 * r] = p1x;
-  a.nxt.t.pts_l[2 * r + 1] = p1y;
-  a.nxt.t.ids[r] = a.id_base + (r - a.hdr_dev->n_surv);
-  a.nxt.t.flags[r] = 0;
-  a.nxt.t.Xw[3 * r] = a.nxt.t.Xw[3 * r + 1] = a.nxt.t.Xw[3 * r + 2] = 0.0f;
-  a.nxt.p_first[2 * r] = p0x;
-  a.nxt.p_first[2 * r + 1] = p0y;
-  a.nxt.f_first[r] = a.f - 1;
-  a.nxt.age[r] = 2;
-  a.nxt.n_kf[r] = 0;
-  a.nxt.p_kf_first[2 * r] = a.nxt.p_kf_first[2 * r + 1] = 0.0f;
-  a.nxt.kf_first[r] = -1;
-  a.nxt.cos_last[r] = mvo_parallax_cos(p0x, p0y, p1x, p1y, a.K, a.frameT + (size_t)((a.f - 1) & (MVO_FRAME_RING - 1)) * 32 + 16, T_wc);
+  if (r >= 0) {
+    float T[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) T[k] = a.T_wc[k];
+    mvo_put_new(a, r, a.id_base + (r - a.hdr_dev->n_surv), a.cand0[2 * j], a.cand0[2 * j + 1], a.cand1[2 * j], a.cand1[2 * j + 1], T);
+  }
 }
 
 // reconstruction at the initialisation (mono_vo.cpp:660-687): every landmark of lmtrack_final that is not triangulated and
@@ -400,19 +229,6 @@ __global__ void mvo_keyframe_kernel(MvoRecArgs a) {
   a.s.t.flags[k] = fl;
 }
 
-// what the next frame's operator reads per landmark (vo_mono_frame_enqueue): bit 0 isBundled(), bit 1 member of the class
-// the pose-only BA takes (bundled with more than five window keyframes, triangulated otherwise: mono_vo.cpp:800-826), bit
-// 2 dead (LandmarkTracking's isAlive() filter, landmark.cpp:251)
-__global__ void mvo_opflags_kernel(const uint8_t *flags, int n, int many_keyframes, uint8_t *op) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n) return;
-  const uint8_t fl = flags[k];
-  uint8_t o = (fl & VO_LM_BUNDLED) ? 1 : 0;
-  if (fl & (many_keyframes ? VO_LM_BUNDLED : VO_LM_TRIANGULATED)) o |= 2;
-  if (fl & VO_LM_DROPPED) o |= 4;
-  op[k] = o;
-}
-
 // the local BA moved keyframes: their entries of the frame table
 struct MvoPoseArgs {
   int n, f[16];
@@ -431,7 +247,6 @@ struct vo_mvo {
   vo_svo core;  // keyframe window, landmark table, keyframe ring, local BA (stereo_vo_lba.hip in mono mode)
   MvoSet ts[2] = {};
   int cur = 0, n = 0;
-  uint8_t *d_op = nullptr;
   float *d_frameT = nullptr;
   MvoHdr *d_hdr = nullptr, *h_hdr = nullptr;
   uint32_t seq = 0;
@@ -443,7 +258,7 @@ struct vo_mvo {
   bool got_first = false, init_done = false, pending = false, prefetched = false;
   const void *pre = nullptr;
   int pend_kind = 0;  // 0 first image, 1 initialisation, 2 steady state
-  bool chained = false;  // the advance step of the frame in flight went out with it
+  bool chained = false;  // the advance step of the frame in flight is part of its BA launch
   int slot[3] = {0, 1, 2};  // previous, current, next
   int tab_cur = 0, tab_next = 0;
   int f = -1;        // index of the current frame (0, 1, ...) — Frame ids come from the context's counter
@@ -530,7 +345,7 @@ extern "C" void vo_mvo_destroy(vo_mvo *s) {
   if (s->c) (void)hipSetDevice(s->c->device);
   if (s->c) (void)hipStreamSynchronize(s->c->stream);
   for (int k = 0; k < 2; ++k) mvo_free_set(&s->ts[k]);
-  void *b[] = {s->d_op, s->d_frameT, s->d_hdr, s->d_nrec, s->d_pos, s->d_stage, s->d_mnew, s->d_pts1, s->d_cand1, s->d_cand0};
+  void *b[] = {s->d_frameT, s->d_hdr, s->d_nrec, s->d_pos, s->d_stage, s->d_mnew, s->d_pts1, s->d_cand1, s->d_cand0};
   for (void *p : b)
     if (p) (void)hipFree(p);
   if (s->h_hdr) (void)hipHostFree(s->h_hdr);
@@ -559,7 +374,6 @@ extern "C" int vo_mvo_create(vo_ctx *c, const vo_mvo_params *prm, vo_mvo **out) 
   auto dm = [&](void **p, size_t bytes) {
     if (rc == VO_OK && vo_dev_malloc(c, p, bytes) != hipSuccess) rc = VO_ERR_HIP;
   };
-  dm((void **)&s->d_op, (size_t)s->cap);
   dm((void **)&s->d_frameT, sizeof(float) * 32 * (size_t)MVO_FRAME_RING);
   dm((void **)&s->d_hdr, sizeof(MvoHdr));
   dm((void **)&s->d_nrec, 64);
@@ -653,42 +467,40 @@ static int mvo_wait_hdr(vo_mvo *s) {
   return VO_OK;
 }
 
-// the next track set behind a frame; stage / pts1 / new points are DEVICE arrays. T_obs: what the survivors' observation
-// sees as the frame's pose. `chain` (the frame's device header): the launches go out right behind the frame's BA launch and
-// take the candidates' number and the pose from it (T_obs / T_wc are not read, m = the largest number there can be).
+// the next track set behind a frame; stage / pts1 / new points are DEVICE arrays. What does not depend on who runs the step:
+static void mvo_advance_args(vo_mvo *s, MvoAdvArgs *a, const uint8_t *stage, const float *pts1, const float *cand1, const float *cand0,
+                             const uint8_t *mnew, int m, int f) {
+  memset(a, 0, sizeof(*a));
+  a->cur = s->ts[s->cur];
+  a->nxt = s->ts[s->cur ^ 1];
+  a->n = s->n;
+  a->cap = s->cap;
+  a->stage = stage;
+  a->pts1 = pts1;
+  a->cand1 = cand1;
+  a->cand0 = cand0;
+  a->mnew = mnew;
+  a->m = m;
+  a->id_base = s->c->next_landmark_id;
+  a->f = f;
+  memcpy(a->K, s->prm.frame.K, sizeof(a->K));
+  a->frameT = s->d_frameT;
+  a->hdr_dev = s->d_hdr;
+  a->hdr_host = s->h_hdr;
+  s->seq = s->seq + 1 == 0 ? 1 : s->seq + 1;
+  a->seq = s->seq;
+  a->pos_s = s->d_pos;
+  a->pos_n = s->d_pos + s->cap;
+}
+// ... as launches of its own (initialisation, 5-point fallback). T_obs: what the survivors' observation sees as the frame's pose.
 static int mvo_advance_launch(vo_mvo *s, const uint8_t *stage, const float *pts1, const float *cand1, const float *cand0,
-                              const uint8_t *mnew, int m, const float *T_obs, const float *T_wc, const vo_frame_hdr *chain) {
+                              const uint8_t *mnew, int m, const float *T_obs, const float *T_wc) {
   vo_ctx *c = s->c;
   MvoAdvArgs a;
-  memset(&a, 0, sizeof(a));
-  a.cur = s->ts[s->cur];
-  a.nxt = s->ts[s->cur ^ 1];
-  a.n = s->n;
-  a.cap = s->cap;
-  a.stage = stage;
-  a.pts1 = pts1;
-  a.cand1 = cand1;
-  a.cand0 = cand0;
-  a.mnew = mnew;
-  a.m = m;
-  a.id_base = c->next_landmark_id;
-  a.f = s->f;
-  memcpy(a.K, s->prm.frame.K, sizeof(a.K));
-  if (chain) {
-    a.fh = chain;
-    memcpy(a.T_wp, s->T_wp, sizeof(a.T_wp));
-  } else {
-    memcpy(a.T_obs, T_obs, sizeof(a.T_obs));
-    memcpy(a.T_wc, T_wc, sizeof(a.T_wc));
-    svo_inv_se3(T_wc, a.T_cw);
-  }
-  a.frameT = s->d_frameT;
-  a.hdr_dev = s->d_hdr;
-  a.hdr_host = s->h_hdr;
-  s->seq = s->seq + 1 == 0 ? 1 : s->seq + 1;
-  a.seq = s->seq;
-  a.pos_s = s->d_pos;
-  a.pos_n = s->d_pos + s->cap;
+  mvo_advance_args(s, &a, stage, pts1, cand1, cand0, mnew, m, s->f);
+  memcpy(a.T_obs, T_obs, sizeof(a.T_obs));
+  memcpy(a.T_wc, T_wc, sizeof(a.T_wc));
+  svo_inv_se3(T_wc, a.T_cw);
   hipLaunchKernelGGL(mvo_advance_scan_kernel, dim3(1), dim3(1024), 0, c->stream, a);
   hipLaunchKernelGGL(mvo_advance_work_kernel, dim3((unsigned)((s->n + m + 255) / 256 + 1)), dim3(256), 0, c->stream, a);
   VO_CHECK_HIP(c, hipGetLastError());
@@ -699,7 +511,7 @@ static int mvo_advance_collect(vo_mvo *s, MvoHdr *h) {
   vo_ctx *c = s->c;
   RC(mvo_wait_hdr(s));
   *h = *s->h_hdr;
-  if (h->pad) return VO_OK;  // (chained behind a frame the host has to finish: nothing was built)
+  if (h->pad) return VO_OK;  // (inside the BA launch of a frame the host has to finish: nothing was built)
   if (h->overflow) VO_FAIL(c, VO_ERR_CAPACITY, "the next track set exceeds vo_config.max_points=%d", s->cap);
   c->next_landmark_id += h->n_new;
   s->cur ^= 1;
@@ -708,7 +520,7 @@ static int mvo_advance_collect(vo_mvo *s, MvoHdr *h) {
 }
 static int mvo_advance(vo_mvo *s, const uint8_t *stage, const float *pts1, const float *cand1, const float *cand0, const uint8_t *mnew,
                        int m, const float T_obs[16], const float T_wc[16], MvoHdr *h) {
-  RC(mvo_advance_launch(s, stage, pts1, cand1, cand0, mnew, m, T_obs, T_wc, nullptr));
+  RC(mvo_advance_launch(s, stage, pts1, cand1, cand0, mnew, m, T_obs, T_wc));
   return mvo_advance_collect(s, h);
 }
 
@@ -791,10 +603,6 @@ static int mvo_finish_frame(vo_mvo *s, const MvoHdr &h, float T_wc[16], vo_mvo_f
       }
       memcpy(T_wc, k.keyframes.back().T_wc, sizeof(float) * 16);
     }
-  }
-  if (n > 0) {  // the operator flags of the next frame (the keyframe count decides the pose-only BA's class)
-    hipLaunchKernelGGL(mvo_opflags_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s->ts[s->cur].t.flags, n, (int)(k.keyframes.size() > 5), s->d_op);
-    VO_CHECK_HIP(c, hipGetLastError());
   }
   memcpy(s->T_wp, T_wc, sizeof(float) * 16);
   memcpy(I->T_wc, T_wc, sizeof(float) * 16);
@@ -1007,7 +815,21 @@ extern "C" int vo_mvo_enqueue(vo_mvo *s, const void *img, int stride, int on_dev
     svo_mul44(s->T_wp, s->dT01, Twc_prior);
     svo_inv_se3(Twc_prior, Tcw_prior);
     const MvoSet &t = s->ts[s->cur];
-    const int rc = vo_mono_frame_enqueue_closed(c, &s->prm.frame, s->slot[0], s->slot[1], t.t.pts_l, t.t.Xw, s->d_op, s->n, Tcw_prev,
+    s->chained = false;
+    if (!c->dbg[VO_DBG_MVO_HOST_ADVANCE]) {
+      // the next track set is the last thing the frame's BA launch does (mvo_advance_body): the pixels, stages and new points
+      // are the launch's own (mono_gate.hpp fills them in), the pose is formed there from this one — vo_mvo_result waits for
+      // the step's counts only, one host round trip per frame and no launch behind the BA launch
+      MvoAdvArgs a;
+      mvo_advance_args(s, &a, nullptr, nullptr, nullptr, nullptr, nullptr, 0, s->f + 1);
+      memcpy(a.T_wp, s->T_wp, sizeof(a.T_wp));
+      s->chained = vo_mono_frame_set_advance(c, &a) >= 0;
+    }
+    // the operator's flag byte (bit 0 lm->isBundled(): prior and scale from the 3-D point; bit 1: the class the pose-only BA
+    // takes — bundled with more than five window keyframes, triangulated otherwise, mono_vo.cpp:800-826; bit 2: dead,
+    // landmark.cpp:251) is read off the track set's flags by the frame kernel itself
+    RC(vo_mono_frame_set_track_flags(c, s->core.keyframes.size() > 5 ? 2 : 1));
+    const int rc = vo_mono_frame_enqueue_closed(c, &s->prm.frame, s->slot[0], s->slot[1], t.t.pts_l, t.t.Xw, t.t.flags, s->n, Tcw_prev,
                                                 Tcw_prior, s->dT01, &s->prm.bins, s->tab_cur, 1);
     if (rc < 0) {
       memcpy(s->slot, keep_slot, sizeof(keep_slot));
@@ -1020,15 +842,7 @@ extern "C" int vo_mvo_enqueue(vo_mvo *s, const void *img, int stride, int on_dev
   c->next_frame_id += 1;
   ++s->f;
   s->pend_kind = !s->got_first ? 0 : (!s->init_done ? 1 : 2);
-  s->chained = false;
-  if (s->init_done && !c->dbg[VO_DBG_MVO_HOST_ADVANCE]) {
-    // the next track set right behind the BA launch: the advance reads the frame's header on the device (vo_mvo_result waits
-    // for its counts only — one host round trip per frame)
-    vo_frame_state *f = c->frame;
-    s->chained = mvo_advance_launch(s, f->res_dev + f->off_stage, (const float *)(f->res_dev + f->off_pl1),
-                                    (const float *)(f->res_dev + f->off_newl), (const float *)(f->res_dev + f->off_newr),
-                                    f->res_dev + f->off_mnew, f->n_new, nullptr, nullptr, f->hdr) >= 0;  // (else: from vo_mvo_result)
-  }
+  if (!s->init_done) s->chained = false;
   s->pending = true;
   return VO_OK;
 }
@@ -1113,13 +927,13 @@ extern "C" int vo_mvo_result(vo_mvo *s, vo_mvo_frame_info *info) {
     float dT01[16], dT10[16], T_wc[16];
     MvoHdr h;
     memset(&h, 0, sizeof(h));
-    if (s->chained) {  // (the frame's own block is complete by then: the advance is stream-ordered behind the BA launch)
+    if (s->chained) {  // (the frame's own block is complete by then: the advance is the BA launch's last step)
       rc = mvo_advance_collect(s, &h);
       if (rc < 0) {
         (void)vo_mono_frame_result(c, nullptr, nullptr, nullptr, dT01, &I.counts, &I.gn);
         return rc;
       }
-      c->frame->known_done = true;  // (the word just seen was written behind the frame's last launch)
+      c->frame->known_done = true;  // (the word just seen is the last store of the frame's last launch)
     }
     rc = vo_mono_frame_result(c, nullptr, nullptr, nullptr, dT01, &I.counts, &I.gn);
     if (rc < 0) return rc;
