@@ -293,17 +293,17 @@ typedef struct {
 /* strict != 0: the frame's trackWithScale step replays border-touching points
  * with the reference's never-reset tap state (same as vo_track_with_scale's
  * strict_border; 2 = sequential replay only, for validation). Default 0.
- * 3 (stereo frame only) = the parallel replay runs on a stream of its own NEXT TO the frame kernel, as a pool of
+ * 3 (stereo and mono frames) = the parallel replay runs on a stream of its own NEXT TO the frame kernel, as a pool of
  * resident workgroups that pick the border-touching features up as the frame kernel lists them; a dependency chain
  * starts when its members are past their first refinement instead of behind the frame kernel's last wavefront. Joined
  * on the device (no HIP event). The pool costs the frame kernel room, so it pays only when there is something to
  * replay. It needs the two queues to really run concurrently: under a tool that serialises kernels across queues
  * (rocprofv3 --pmc) its bounded waits run out; the frame is then issued again with the stream-ordered replay and the
  * context stays on it (vo_stereo_frame_recoveries).
- * 5 (stereo frame only) = the stream-ordered replay of mode 1, but on the replay stream behind a one-wavefront gate that
+ * 5 (stereo frame only; the mono frame takes 1) = the stream-ordered replay of mode 1, but on the replay stream behind a one-wavefront gate that
  * waits for the frame kernel's last pass 1: its (normally idle) launches run under the frame kernel's tail instead of
  * between it and the BA launch. Same conditions as 3.
- * 4 (stereo frame only) = 3 or 1, chosen per frame: 3 when the previous frame replayed at least 16 features and the
+ * 4 (stereo and mono frames) = 3 or 1, chosen per frame: 3 when the previous frame replayed at least 16 features and the
  * frame kernel is small enough (at most 4096 features + candidates) to leave the chip mostly idle in its second half.
  * Every non-zero value gives the same results (DESIGN.md §4.3 has the measurements). */
 int vo_stereo_frame_set_strict_border(vo_ctx *ctx, int strict);
@@ -612,7 +612,9 @@ typedef struct {
   float kf_translation;     /* keyframe_update.thres_translation */
   int kf_window;            /* keyframe_update.n_max_keyframes_in_window (at most 16) */
   float thres_parallax_deg; /* map_update.thres_parallax (degrees; the reference multiplies by D2R) */
-  int strict_border;        /* trackWithScale's never-reset tap state: 0 masked taps, 1 reference-exact, 2 sequential replay */
+  int strict_border;        /* trackWithScale's never-reset tap state: 0 masked taps; 1..4 reference-exact — 1 the replay stream-ordered
+                               behind the frame kernel, 2 sequential replay only (validation), 3 the replay next to the frame
+                               kernel joined on the device, 4 = 3 or 1 per frame (vo_stereo_frame_set_strict_border); same results */
   int local_ba;             /* != 0: localBundleAdjustmentSparseSolver at every keyframe */
   int rectify;              /* != 0: flagDoUndistortion (mono_vo.cpp:509-513) — images go through camera 0's undistortion
                                map (vo_rectify_init_mono first) on their way into the pyramid */

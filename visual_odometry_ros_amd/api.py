@@ -1242,7 +1242,7 @@ class MonoVO:
 
     def __init__(self, ctx, width, height, K, n_bins_u, n_bins_v, five_point, thres_fastscore=15, window_size=15, max_level=5,
                  thres_error=20.0, thres_bidirection=1.0, thres_poseba_error=5, thres_sampson=1.0, thres_parallax=1.0,
-                 thres_overlap_ratio=0.7, thres_rotation=3.0, thres_translation=3.0, n_max_keyframes_in_window=9, strict_border=1,
+                 thres_overlap_ratio=0.7, thres_rotation=3.0, thres_translation=3.0, n_max_keyframes_in_window=9, strict_border=4,
                  local_ba=True, rectify=False):
         self.ctx, self.lib = ctx, ctx.lib
         fe = FeatureExtractor(ctx)

@@ -48,7 +48,7 @@ struct MonoVOParams {
   bool flagDoUndistortion = false;  // mono_vo.cpp:509-513: D = k1, k2, p1, p2, k3
   float D[5] = {0, 0, 0, 0, 0};
   // not in the reference
-  int strict_border = 1;
+  int strict_border = 4;  // vo_stereo_frame_set_strict_border (4: the replay next to the frame kernel when it pays; same results as 1)
   bool local_ba = true;
   bool keyframe_statistics = false;  // stats_keyframe rewritten at every keyframe (RECORD_KEYFRAME_STAT, mono_vo.cpp:1130-1155)
 };
