@@ -788,10 +788,18 @@ __global__ __launch_bounds__(GN_T) void gn_pose_kernel(GnArgs a) {
       a.info->is_nan = is_nan;
     }
   }
-  if (a.f_n > 0 && a.f_mono) {
-    // mono frame: mask_motion, Sampson gate, stages, counts and the copy of the result block (mono_gate.hpp)
-    __syncthreads();  // inlier mask, pose and info above are this workgroup's own stores
-    mono_gate_body<GN_T>(a.f_gate, tid, n, (uint8_t *)s_red, (int *)s_tot);
+  bool gate_done = false;
+  if constexpr (!STEREO) {
+    if (a.f_n > 0 && a.f_mono) {
+      // mono frame: mask_motion, Sampson gate, stages, counts, the copy of the result block and MonoVO's next track set
+      // (mono_gate.hpp). (Compiled into the mono kernel only: with the gate's arguments referenced from the stereo kernel
+      // too, that one kept a 1.9 KB copy of its argument block in scratch memory — 45 us per frame.)
+      __syncthreads();  // inlier mask, pose and info above are this workgroup's own stores
+      mono_gate_body<GN_T>(a.f_gate, tid, n, (uint8_t *)s_red, (int *)s_tot);
+      gate_done = true;
+    }
+  }
+  if (gate_done) {
   } else if (a.f_n > 0 && a.f_res_host) {
     // frame mode epilogue: the packed result block goes to pinned host memory from here
     __syncthreads();  // stage marks, pose and info above are this workgroup's own stores

@@ -810,6 +810,7 @@ __global__ __launch_bounds__(SBA_SOLVE_WG) void sba_solve_reg_kernel(SbaDev d, i
   __syncthreads();
   const long long t_b = sba_stamp_after(0.0);
   const bool pre_staged = d.n_frames <= 64;
+  const bool deliver = d.res_host && pre_staged && iter == d.max_iter - 1;  // (uniform: see SbaDev::res_host)
   if (tid >= 192) return;
   if (tid >= 128) {
     // the third wavefront: the half of the pose update that does not need x — xi = log(T), exp(xi) (:563-566) — one
@@ -843,6 +844,7 @@ __global__ __launch_bounds__(SBA_SOLVE_WG) void sba_solve_reg_kernel(SbaDev d, i
       d.avg_err[iter] = sqrt(e / (double)(d.dyn ? d.dyn[1] : d.n_obs));
       if (e != e) atomicOr(d.flags, 2);
     }
+    if (deliver) __syncthreads();  // (the error and its flag are part of what wavefront 0 sends to the host behind this barrier)
     return;
   }
   // ---- pivot order (see sba_solve_kernel): descending |diagonal| unless two are exactly equal
@@ -955,6 +957,14 @@ __global__ __launch_bounds__(SBA_SOLVE_WG) void sba_solve_reg_kernel(SbaDev d, i
       const int j = d.opt_index[f];
       if (j >= 0) sba_pose_update(d.T + 16 * (size_t)f, xs + 6 * j);
     }
+  }
+  if (deliver) {
+    // the last iteration's solve: poses, errors, flags and counts are final (the launches behind this one move points only)
+    SBA_WAVE_SYNC();  // (this wavefront's own pose stores above)
+    for (int k = lane; k < d.res_words; k += 64)
+      if (k != d.res_seq_word) d.res_host[k] = d.res_src[k];
+    __threadfence_system();
+    if (lane == 0) __hip_atomic_store(&d.res_host[d.res_seq_word], d.res_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   if (lane == 0) {
     d.flags[1] = (int)(t_1 - t_0);
@@ -1207,6 +1217,11 @@ size_t vo_sba_place_work(SbaDev *d, uint8_t *base, size_t off, size_t M, size_t 
   return ar.off;
 }
 
+static bool sba_reg_solve(const vo_ctx *c, int No) { return No >= 1 && No <= 8 && !c->dbg[VO_DBG_SBA_LDS_SOLVE]; }
+bool vo_sba_delivers_result(const vo_ctx *c, const SbaDev &d) {
+  return d.res_host && d.max_iter > 0 && sba_reg_solve(c, d.n_opt) && d.n_frames <= 64;
+}
+
 // three launches per iteration in the steady-state window (four otherwise): [update of the previous iteration +
 // per-landmark linearisation] -> [pose sums + Schur blocks] -> [assembly ->] solve; one last update behind the loop
 int vo_sba_enqueue_iterations(vo_ctx *c, const SbaDev &d, int max_iter) {
@@ -1224,7 +1239,7 @@ int vo_sba_enqueue_iterations(vo_ctx *c, const SbaDev &d, int max_iter) {
   };
   // every window of up to ten keyframes (1..8 optimised poses) takes the register solve: three launches per iteration
   // (vo_debug_set VO_DBG_SBA_LDS_SOLVE: the general kernel for every n, an A/B switch)
-  const bool reg_solve = No >= 1 && No <= 8 && !c->dbg[VO_DBG_SBA_LDS_SOLVE];
+  const bool reg_solve = sba_reg_solve(c, No);
   for (int iter = 0; iter < max_iter; ++iter) {
     launch_update_point(iter > 0 ? 1 : 0, 1);
     if (No > 0) {

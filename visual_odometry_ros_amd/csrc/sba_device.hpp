@@ -40,7 +40,16 @@ struct SbaDev {
   double *G;      // reduced system, (6 n_opt)^2 lower triangle + 6 n_opt right-hand side
   double *avg_err;
   int *flags;     // [0] error bits (1: pose NaN, 2: error NaN), [1..3] phase ticks of the solve kernel, [4..15] stamps
+  // non-null (the StereoVO / MonoVO local BA, stereo_vo_lba.hip): what the host needs of the solve — res_words words at
+  // res_src: poses | errors | flags | counts, all final behind the last iteration's solve — goes to pinned host memory from
+  // THAT kernel, the sequence number last (word res_seq_word): the host has it while the final point update and the
+  // write-back launches still run (vo_sba_delivers_result says whether the solve kernel in use does this)
+  uint32_t *res_host;
+  const uint32_t *res_src;
+  int res_words, res_seq_word;
+  uint32_t res_seq;
 };
+bool vo_sba_delivers_result(const vo_ctx *c, const SbaDev &d);
 
 // bytes of the solver's own work areas for at most M landmarks, ns slots, No optimised poses (256-byte aligned pieces),
 // and their placement inside an arena starting at `base` + `off`: fills the work pointers of d, returns the new offset

@@ -639,8 +639,10 @@ static void lba_make_layout(LbaLayout *l, int kf_window, int cap) {
 
 // Build + solve + write-back of one window, enqueued on the main stream: the builder's five launches, the solver's
 // iterations, the two write-back launches. Returns where the result piece (poses | errors | flags | counts) lies.
+// seq != 0: the solver's last kernel sends the result piece to L->h_res itself, sequence word last, when it can
+// (*delivered; otherwise the caller launches lba_result_kernel behind everything).
 static int lba_enqueue(vo_svo *s, const LbaWin &w, int maxn, size_t M_ub, const LbaHead &head, const LbaRef &ref, const SvoTrackSet &t,
-                       int n, int max_iter, const double **res) {
+                       int n, int max_iter, const double **res, uint32_t seq = 0, bool *delivered = nullptr) {
   vo_ctx *c = s->c;
   vo_svo_lba *L = s->lba;
   const LbaLayout &lay = L->lay;
@@ -745,6 +747,15 @@ static int lba_enqueue(vo_svo *s, const LbaWin &w, int maxn, size_t M_ub, const 
   d.pair_b = p.pair_b;
   d.avg_err = p.avg_err;
   d.flags = p.flags;
+  if (seq) {
+    d.res_host = (uint32_t *)L->h_res;
+    d.res_src = (const uint32_t *)p.T;
+    d.res_words = (int)(lay.res_bytes / 4);
+    d.res_seq_word = LBA_SEQ_WORD;
+    d.res_seq = seq;
+    if (delivered) *delivered = vo_sba_delivers_result(c, d);
+    if (!vo_sba_delivers_result(c, d)) d.res_host = nullptr;
+  }
   vo_prof_begin(c, VO_K_AUX);
   {
     const int rc = vo_sba_enqueue_iterations(c, d, max_iter);
@@ -964,16 +975,20 @@ int vo_svo_local_ba(vo_svo *s, vo_svo_frame_info *info, int id_min) {
     for (int r = 0; r < 3; ++r) head.T_jw[16 * j + r * 4 + 3] *= inv_scale;  // scalingPose
   }
   const double *res_dev = nullptr;
+  bool delivered = false;
+  L->seq = L->seq + 1 == 0 ? 1 : L->seq + 1;
   {
-    const int rc = lba_enqueue(s, w, maxn, M_ub, head, ref, t, n, max_iter, &res_dev);
+    const int rc = lba_enqueue(s, w, maxn, M_ub, head, ref, t, n, max_iter, &res_dev, L->seq, &delivered);
     if (rc < 0) return rc;
   }
-  // ---- what the host needs: poses, errors, flags, counts ----
+  // ---- what the host needs: poses, errors, flags, counts — sent by the last iteration's solve kernel itself (the host works
+  // on them, and on the next frame's enqueue, while the final point update and the write-back launches run), or by a launch
+  // behind everything when that kernel is not the one in use ----
   double *o_T = (double *)L->h_res, *o_e = o_T + 16 * LBA_KW;
   int *o_f = (int *)(o_e + 16), *o_d = o_f + 16;
-  L->seq = L->seq + 1 == 0 ? 1 : L->seq + 1;
-  hipLaunchKernelGGL(lba_result_kernel, dim3(1), dim3(256), 0, st, (const uint32_t *)res_dev, (uint32_t *)L->h_res, (int)(lay.res_bytes / 4),
-                     L->seq);
+  if (!delivered)
+    hipLaunchKernelGGL(lba_result_kernel, dim3(1), dim3(256), 0, st, (const uint32_t *)res_dev, (uint32_t *)L->h_res, (int)(lay.res_bytes / 4),
+                       L->seq);
   VO_CHECK_HIP(c, hipGetLastError());
   const double t_1 = trace ? lba_now() : 0.0;
   {
