@@ -13,7 +13,8 @@ mkdir -p $OUT/pmc $OUT/sq
 cd /tmp && export TMPDIR=/tmp
 B="python3 $ROOT/bench.py --no-cpu-baseline --no-secondary"
 # the stream is rendered once (worker pool, before anything touches the GPU) and cached under /tmp: do that outside the profiler
-timeout 600 $B --steps 20 --warmup 5 > $OUT/prerender.log 2>&1
+timeout 600 $B > $OUT/prerender.log 2>&1                      # (the default command's own stream length first)
+timeout 600 $B --steps 20 --warmup 5 >> $OUT/prerender.log 2>&1
 timeout 600 $B --strict-border 1 --steps 60 --warmup 10 >> $OUT/prerender.log 2>&1   # (every stream length used below goes into the render cache outside the profiler:
 timeout 600 $B --strict-border 1 --steps 40 --warmup 10 >> $OUT/prerender.log 2>&1   #  a renderer pool forked under rocprofv3 --pmc does not come back)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_default -o bench -- $B > $OUT/stats_default.log 2>&1
