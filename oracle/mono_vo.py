@@ -43,7 +43,11 @@ class MonoVORef:
 
     def __init__(self, width, height, K, n_bins_u, n_bins_v, five_point, thres_fast=15, win=15, max_level=5, thres_err=20.0,
                  thres_bidir=1.0, thres_poseba=5, thres_sampson=1.0, thres_parallax_deg=1.0, kf_overlap=0.7, kf_rot_deg=3.0,
-                 kf_trans=3.0, kf_window=9, lba=True, ic_border=O.IC_REFERENCE, sum_mode=O.SUM_SEQ, tree_width=0, n_threads=1):
+                 kf_trans=3.0, kf_window=9, lba=True, ic_border=O.IC_REFERENCE, sum_mode=O.SUM_SEQ, tree_width=0, n_threads=1,
+                 undistort_maps=None):
+        """undistort_maps = (map_u, map_v) of the camera: flagDoUndistortion (mono_vo.cpp:509-513) — every image goes through
+        cam_->undistortImage + convertTo(CV_8UC1) first."""
+        self.undistort_maps = undistort_maps
         self.W, self.H, self.K = width, height, np.asarray(K, np.float32)
         self.nu, self.nv, self.thres_fast = n_bins_u, n_bins_v, thres_fast
         self.win, self.max_level = win, max_level
@@ -113,6 +117,8 @@ class MonoVORef:
 
     # ---- one call of trackImage ----------------------------------------------------------------------------------
     def track(self, img):
+        if self.undistort_maps is not None:
+            img = O.remap_linear_u8(img, *self.undistort_maps)
         f = self.frame_counter
         self.frame_counter += 1
         self.frames.append(dict(T_wc=np.eye(4, dtype=np.float32), dT01=np.eye(4, dtype=np.float32)))

@@ -26,7 +26,8 @@ class TruePoseHook:
         return True, T10[:3, :3].astype(np.float32), T10[:3, 3].astype(np.float32), np.ones(len(pts0), bool)
 
 
-def _run_both(vo, oracle, n_frames, lba, strict, kf_trans, seed=5, prefetch=False, W=752, H=480, nu=40, nv=25, win=15, lvl=5, parallax_deg=1.0):
+def _run_both(vo, oracle, n_frames, lba, strict, kf_trans, seed=5, prefetch=False, W=752, H=480, nu=40, nv=25, win=15, lvl=5, parallax_deg=1.0,
+              distortion=None):
     from oracle.mono_vo import MonoVORef
     from visual_odometry_ros_amd import synthetic as S
     st = S.StereoStream(width=W, height=H, K=MONO_K, n_u=nu, n_v=nv, seed=seed, speed=0.25)
@@ -35,13 +36,17 @@ def _run_both(vo, oracle, n_frames, lba, strict, kf_trans, seed=5, prefetch=Fals
     hook_g, hook_r = TruePoseHook(poses), TruePoseHook(poses)
     ref = MonoVORef(W, H, MONO_K, nu, nv, hook_r, thres_fast=15, win=win, max_level=lvl, thres_err=20.0, thres_bidir=1.0, thres_poseba=5,
                     thres_sampson=1.0, thres_parallax_deg=parallax_deg, kf_trans=kf_trans, lba=lba, sum_mode=oracle.SUM_TREE, tree_width=512,
-                    ic_border=oracle.IC_REFERENCE if strict else oracle.IC_MASKED, n_threads=8)
+                    ic_border=oracle.IC_REFERENCE if strict else oracle.IC_MASKED, n_threads=8,
+                    undistort_maps=oracle.image_undistort_maps(W, H, MONO_K, distortion) if distortion is not None else None)
     c = vo.Context(device=0, max_width=W, max_height=H, max_points=2 * nu * nv + 512, n_slots=3, max_level=lvl)
     log = []
     try:
+        if distortion is not None:  # flagDoUndistortion: the camera's undistortion map on the device, images remapped on their way in
+            cam = vo.Camera(c, 0)
+            cam.initParams(W, H, MONO_K, distortion)
         mvo = vo.MonoVO(c, W, H, MONO_K, nu, nv, hook_g, thres_fastscore=15, window_size=win, max_level=lvl, thres_error=20.0,
                         thres_bidirection=1.0, thres_poseba_error=5, thres_sampson=1.0, thres_parallax=parallax_deg, thres_translation=kf_trans,
-                        strict_border=strict, local_ba=lba)
+                        strict_border=strict, local_ba=lba, rectify=distortion is not None)
         for k in range(n_frames):
             hook_g.k = hook_r.k = k
             if prefetch:
@@ -110,3 +115,22 @@ def test_mono_loop_five_point_fallback(vo, oracle):
     assert all(e[4] for e in log[1:]), log  # the hook at the initialisation and at every frame after it
     assert not any(ref.lm[int(i)]["tri"] for i in ref.ids)
     assert log[-1][1] > 300
+
+
+def test_mono_loop_sliding_window(vo, oracle):
+    """34 frames with a keyframe every two of them: the nine-keyframe window fills and slides (ring slots of the oldest
+    keyframes are reused, the frame-pose entries of optimised keyframes are rewritten after every solve), the 42 x 42 register
+    solve runs in mono mode, landmarks are bundled again and again — against the CPU loop after every frame. The concurrent
+    strict-border replay is on whenever the previous frame replayed something."""
+    log, ref = _run_both(vo, oracle, 34, lba=True, strict=4, kf_trans=0.4, prefetch=True)
+    assert sum(1 for e in log if e[0]) >= 14, log
+    assert sum(1 for e in log if e[2]) >= 10, log
+    assert max(e[3] for e in log) > 1500  # landmarks in the largest problem
+
+
+def test_mono_loop_with_undistortion(vo, oracle):
+    """flagDoUndistortion (mono_vo.cpp:509-513): raw images with lens distortion, remapped through the camera's undistortion
+    map on their way into the pyramid (device) / by the restated cam_->undistortImage (CPU loop)."""
+    D = np.array([-0.12, 0.03, 0.0005, -0.0008, 0.0], np.float32)
+    log, ref = _run_both(vo, oracle, 10, lba=True, strict=4, kf_trans=2.5, distortion=D)
+    assert sum(1 for e in log if e[0]) >= 3 and log[-1][1] > 300, log
