@@ -26,6 +26,9 @@ ahead of the frame that the reference does not know either.
                                                            never-reset tap state (identical results), differing in where the
                                                            replay of the border-touching features runs (default 4: chosen per
                                                            frame; vo_hip.h: vo_stereo_frame_set_strict_border)
+  python bench.py --host-loop {library,python}             closed loops: the per-frame calls result(k) / enqueue(k + 1) /
+                                                           prefetch(k + 2) by the library's sequence loop (vo_svo_run / vo_mvo_run,
+                                                           default) or by this interpreter through ctypes
   N > 1: one rank per GPU, independent streams, one RCCL all_gather of the totals at the end; under
   torch.distributed.run the ranks are the launcher's, without a launcher environment bench.py starts the N ranks
   itself as fresh child processes (before this process has touched a GPU).
@@ -668,17 +671,44 @@ def run_loop(cfg, args, rank, local_rank, world, torch, V, barrier, dev, imgs, s
         if k + 1 < F and args.no_issue_ahead:
             issue(k + 1)
 
-    issue(0)
-    for _ in range(LOOP_PRIME + args.warmup):
-        step(False)
+    # Who drives the loop: the library (vo_svo_run — result(k), enqueue(k + 1), prefetch(k + 2) in compiled code, as the
+    # reference's caller is) or this interpreter (the same three calls per frame through ctypes: ~5 us more per frame)
+    lib_loop = args.host_loop == "library" and prefetch and not args.no_issue_ahead
     K = args.steps
+
+    def collect(out, keep, k0):
+        for j, i in enumerate(out):
+            if keep:
+                c = i.counts
+                infos.append((k0 + j, i.n_tracks_in, c.n_l0l1, c.n_refine, c.n_replayed, i.n_new_candidates, i.n_new, i.n_final,
+                              i.is_keyframe, i.lba_ran, c.gn_iterations, c.n_ba))
+            traj.append(np.array(i.T_wc, np.float32).reshape(4, 4))
+
+    if lib_loop:
+        n0 = LOOP_PRIME + args.warmup
+        if n0 > 0:
+            collect(svo.runSequence(ptr, 0, n0)[0], False, 0)
+        else:
+            issue(0)
+        state["k"] = n0
+    else:
+        issue(0)
+        for _ in range(LOOP_PRIME + args.warmup):
+            step(False)
     ctx.profile_enable(K * 4 + 64)
     ctx.profile_set_classes(1 << 1)
     ctx.profile_reset()
 
     def timed_run():
-        for _ in range(K):
-            step(True)
+        if lib_loop:
+            k0 = state["k"]
+            out, st_k = svo.runSequence(ptr, k0, k0 + K)
+            stamps.extend(st_k.tolist())
+            collect(out, True, k0)
+            state["k"] = k0 + K
+        else:
+            for _ in range(K):
+                step(True)
 
     dt = timed(timed_run, barrier, ctx)
     if state["k"] < F:
@@ -742,6 +772,8 @@ def run_loop(cfg, args, rank, local_rank, world, torch, V, barrier, dev, imgs, s
             "playback": "forward",
             "local_ba": bool(args.lba),
             "prefetch_next_pair": prefetch,
+            "host_loop": "library (vo_svo_run: result(k), enqueue(k + 1), prefetch(k + 2) per frame in compiled code)" if lib_loop
+                         else "python (the same three calls per frame through ctypes)",
             "images": "resident in HBM",
             "strict_border": int(args.strict_border),
             "frames_rendered": F,
@@ -1035,6 +1067,9 @@ def main():
     ap.add_argument("--frames", type=int, default=12, help="distinct rendered frames (played back and forth)")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--parity-frames", type=int, default=18, help="loop mode: frames of the bit-exact leg (device loop against the CPU loop)")
+    ap.add_argument("--host-loop", choices=("library", "python"), default="library",
+                    help="closed-loop modes: who calls result / enqueue / prefetch per frame — the library's sequence loop "
+                         "(vo_svo_run / vo_mvo_run, compiled, as the reference's caller is) or this interpreter through ctypes")
     ap.add_argument("--strict-border", type=int, default=4,
                     help="0 masked border taps; 1-5 the reference's never-reset tap state (identical results): 1 replay "
                          "stream-ordered behind the frame kernel, 2 sequential replay, 3 replay next to the frame kernel, "
@@ -1428,14 +1463,37 @@ def run_mono_loop(cfg, args, rank, local_rank, world, torch, V, barrier, dev, im
                           c.gn_iterations, c.n_ba, i.used_five_point))
         traj.append(np.array(i.T_wc, np.float32).reshape(4, 4))
 
+    # (the library's sequence loop behind the initialisation: the 5-point hook is fed the frame index from here)
+    lib_loop = args.host_loop == "library" and prefetch
     issue(0)
-    for _ in range(LOOP_PRIME + args.warmup):
+    for _ in range(LOOP_PRIME):
         step(False)
     K = args.steps
+
+    def lib_frames(n, keep):
+        k0 = state["k"]
+        out, st_k = mvo.runSequence(ptr, k0, k0 + n)
+        for j, i in enumerate(out):
+            if i.used_five_point:
+                raise RuntimeError("the 5-point fallback inside the library loop: the hook was not told the frame index (--host-loop python)")
+            if keep:
+                c = i.counts
+                infos.append((k0 + j, i.n_tracks_in, c.n_klt, c.n_refine, c.n_replayed, i.n_new, i.n_final, i.is_keyframe, i.lba_ran,
+                              c.gn_iterations, c.n_ba, i.used_five_point))
+            traj.append(np.array(i.T_wc, np.float32).reshape(4, 4))
+        if keep:
+            stamps.extend(st_k.tolist())
+        state["k"] = k0 + n
+
+    if lib_loop and args.warmup > 0:
+        lib_frames(args.warmup, False)
+    else:
+        for _ in range(args.warmup):
+            step(False)
     ctx.profile_enable(K * 4 + 64)
     ctx.profile_set_classes(1 << 1)
     ctx.profile_reset()
-    dt = timed(lambda: [step(True) for _ in range(K)], barrier, ctx)
+    dt = timed((lambda: lib_frames(K, True)) if lib_loop else (lambda: [step(True) for _ in range(K)]), barrier, ctx)
     if state["k"] < F:
         hook.k = state["k"]
         mvo.result()
@@ -1475,7 +1533,8 @@ def run_mono_loop(cfg, args, rank, local_rank, world, torch, V, barrier, dev, im
                                + (", mono local BA over the keyframe window" if args.lba else "; local BA off (--lba 0)")
                                + "; first image + initialisation (5-point pose from a caller hook) happen before the timed frames",
                    "track_set": "closed loop", "playback": "forward", "images": "resident in HBM", "local_ba": bool(args.lba),
-                   "strict_border": int(args.strict_border), "next_image": "prefetched (vo_mvo_prefetch)" if prefetch else "with its frame"},
+                   "strict_border": int(args.strict_border), "next_image": "prefetched (vo_mvo_prefetch)" if prefetch else "with its frame",
+                   "host_loop": "library (vo_mvo_run)" if lib_loop else "python (ctypes calls per frame)"},
         "loop": {"mean_tracks_in": round(float(I[:, 1].mean()), 1), "mean_final": round(float(I[:, 6].mean()), 1),
                  "mean_new_landmarks": round(float(I[:, 5].mean()), 1), "mean_ba_set": round(float(I[:, 10].mean()), 1),
                  "mean_gn_iterations": round(float(I[:, 9].mean()), 2), "keyframes": int((I[:, 7] > 0).sum()), "lba_runs": int((I[:, 8] > 0).sum()),

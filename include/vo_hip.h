@@ -455,6 +455,13 @@ int vo_svo_track(vo_svo *svo, const void *left, const void *right, int stride, i
 int vo_svo_enqueue(vo_svo *svo, const void *left, const void *right, int stride, int on_device, double timestamp);
 int vo_svo_prefetch(vo_svo *svo, const void *left, const void *right, int stride, int on_device);
 int vo_svo_result(vo_svo *svo, vo_svo_frame_info *info);
+/* A recorded sequence through the same three calls, the loop on this side of the ABI: collects frames k_begin .. k_end - 1
+ * of the n_total pairs left[k] / right[k] — vo_svo_result(k), then at once vo_svo_enqueue(k + 1) and vo_svo_prefetch(k + 2).
+ * k_begin == 0 starts the sequence; otherwise frame k_begin is the one a previous call left in flight, and frame k_end is
+ * in flight on return (when there is one; collect it with vo_svo_result or the next vo_svo_run). infos (may be NULL):
+ * [k_end - k_begin]; stamps (may be NULL): CLOCK_MONOTONIC seconds at which each frame's result was in hand. */
+int vo_svo_run(vo_svo *svo, const void *const *left, const void *const *right, int n_total, int stride, int on_device,
+               int k_begin, int k_end, vo_svo_frame_info *infos, double *stamps);
 /* The track set the next frame will start from (stframe_prev_'s pts seen + related landmarks): ids, left / right
  * pixels, world points, flags (VO_LM_TRIANGULATED, VO_LM_DROPPED, VO_LM_KF_MEMBER). Any pointer may be NULL; *n
  * receives the size. A device-to-host copy with a synchronisation: a test / inspection hook, not part of the loop. */
@@ -636,6 +643,10 @@ int vo_mvo_create(vo_ctx *ctx, const vo_mvo_params *prm, vo_mvo **out);
 void vo_mvo_destroy(vo_mvo *mvo);
 /* MonoVO::trackImage(img, timestamp): synchronous. Image: u8, `stride` bytes per row, device pointer when on_device != 0. */
 int vo_mvo_track(vo_mvo *mvo, const void *img, int stride, int on_device, double timestamp, vo_mvo_frame_info *info);
+/* A recorded sequence through vo_mvo_result(k) / vo_mvo_enqueue(k + 1) / vo_mvo_prefetch(k + 2), the loop on this side of the ABI
+ * (see vo_svo_run). The 5-point hook is called from inside as usual. */
+int vo_mvo_run(vo_mvo *mvo, const void *const *img, int n_total, int stride, int on_device, int k_begin, int k_end,
+               vo_mvo_frame_info *infos, double *stamps);
 /* the same in halves, and the next image handed over early (pyramid + per-bin candidate table on the side stream) */
 int vo_mvo_enqueue(vo_mvo *mvo, const void *img, int stride, int on_device, double timestamp);
 int vo_mvo_prefetch(vo_mvo *mvo, const void *img, int stride, int on_device);

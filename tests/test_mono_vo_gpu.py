@@ -134,3 +134,50 @@ def test_mono_loop_with_undistortion(vo, oracle):
     D = np.array([-0.12, 0.03, 0.0005, -0.0008, 0.0], np.float32)
     log, ref = _run_both(vo, oracle, 10, lba=True, strict=4, kf_trans=2.5, distortion=D)
     assert sum(1 for e in log if e[0]) >= 3 and log[-1][1] > 300, log
+
+
+def test_mono_run_sequence_equals_the_three_calls(vo):
+    """vo_mvo_run (the sequence loop inside the library) against the same sequence driven call by call: poses, keyframe
+    decisions, final ids and ages — the same bits."""
+    from util import DeviceBuffer
+    from visual_odometry_ros_amd import synthetic as S
+    W, H, n = 752, 480, 16
+    st = S.StereoStream(width=W, height=H, K=MONO_K, n_u=40, n_v=25, seed=5, speed=0.25)
+    poses = st.poses(n)
+    bufs = [DeviceBuffer(st.render_pair(p)[0]) for p in poses]
+    imgs = [(b.data_ptr(), W) for b in bufs]
+    runs = []
+    try:
+        for mode in ("calls", "library"):
+            hook = TruePoseHook(poses)
+            hook.k = 1  # (the initialisation is the only call: the stream never needs the fallback)
+            c = vo.Context(device=0, max_width=W, max_height=H, max_points=2512, n_slots=3, max_level=5)
+            try:
+                mvo = vo.MonoVO(c, W, H, MONO_K, 40, 25, hook, thres_translation=1.0, strict_border=4, local_ba=True)
+                infos = []
+                if mode == "calls":
+                    mvo.enqueue(imgs[0])
+                    mvo.prefetch(imgs[1])
+                    for k in range(n):
+                        infos.append(mvo.result())
+                        if k + 1 < n:
+                            mvo.enqueue(imgs[k + 1])
+                            if k + 2 < n:
+                                mvo.prefetch(imgs[k + 2])
+                else:
+                    for a, b in ((0, 3), (3, n)):
+                        out, stamps = mvo.runSequence(imgs, a, b)
+                        infos += out
+                assert hook.calls == 1 and not any(i.used_five_point for i in infos[2:])
+                g = mvo.getTracks()
+                runs.append((np.stack([np.array(i.T_wc, np.float32) for i in infos]), [int(i.is_keyframe) for i in infos],
+                             [int(i.lba_ran) for i in infos], g["ids"].copy(), g["age"].copy()))
+                mvo.close()
+            finally:
+                c.close()
+    finally:
+        for b in bufs:
+            b.free()
+    (Ta, ka, la, ia, aa), (Tb, kb, lb, ib, ab) = runs
+    assert np.array_equal(_bits(Ta), _bits(Tb)) and ka == kb and la == lb and np.array_equal(ia, ib) and np.array_equal(aa, ab)
+    assert sum(la) >= 2

@@ -341,6 +341,53 @@ def test_closed_loop_is_deterministic(vo):
     assert np.isfinite(Ta).all() and abs(Ta[-1][11] - 0.5 * 59) < 1.5  # (z of the last pose: 0.5 m per frame)
 
 
+def test_run_sequence_equals_the_three_calls(vo):
+    """vo_svo_run (the sequence loop inside the library: result(k), enqueue(k + 1), prefetch(k + 2)), called in three pieces,
+    against the same sequence driven call by call from here: poses of every frame, keyframe decisions, final ids — the same
+    bits (device images; local BA and the concurrent replay on)."""
+    from util import DeviceBuffer
+    W, H, K, n = 640, 240, (400.0, 400.0, 320.0, 120.0), 24
+    st, imgs = _stream(W, H, K, 20, 8, 9, 0.5, n)
+    bufs = [(DeviceBuffer(L), DeviceBuffer(R)) for L, R in imgs]
+    pairs = [((a.data_ptr(), W), (b.data_ptr(), W)) for a, b in bufs]
+    runs = []
+    try:
+        for mode in ("calls", "library"):
+            c = vo.Context(device=0, max_width=W, max_height=H, max_points=4096, n_slots=5, max_level=4)
+            try:
+                svo = vo.StereoVO(c, W, H, K, K, st.T_lr, 20, 8, thres_fastscore=15, window_size=21, max_level=4, strict_border=4,
+                                  local_ba=True, thres_trans=0.9)
+                infos = []
+                if mode == "calls":
+                    svo.enqueue(*pairs[0])
+                    svo.prefetch(*pairs[1])
+                    for k in range(n):
+                        infos.append(svo.result())
+                        if k + 1 < n:
+                            svo.enqueue(*pairs[k + 1])
+                            if k + 2 < n:
+                                svo.prefetch(*pairs[k + 2])
+                else:
+                    for a, b in ((0, 5), (5, 6), (6, n)):
+                        out, stamps = svo.runSequence(pairs, a, b)
+                        assert len(out) == b - a and (np.diff(stamps) > 0).all()
+                        infos += out
+                    with pytest.raises(vo.VoError):
+                        svo.runSequence(pairs, 3, 4)  # nothing in flight any more
+                runs.append((np.stack([np.array(i.T_wc, np.float32) for i in infos]), [int(i.is_keyframe) for i in infos],
+                             [int(i.lba_ran) for i in infos], svo.getTracks()["ids"].copy()))
+                svo.close()
+            finally:
+                c.close()
+    finally:
+        for a, b in bufs:
+            a.free()
+            b.free()
+    (Ta, ka, la, ia), (Tb, kb, lb, ib) = runs
+    assert np.array_equal(_bits(Ta), _bits(Tb)) and ka == kb and la == lb and np.array_equal(ia, ib)
+    assert sum(la) >= 5
+
+
 def test_closed_loop_survives_a_join_timeout():
     """The loop in strict-border mode 3 with a device-side join that cannot be met (VO_DEBUG_FAIL_JOIN, fresh child process):
     the first steady-state frame is issued again with the stream-ordered replay — and with it the DLT workers and the

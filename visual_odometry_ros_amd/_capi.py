@@ -120,9 +120,9 @@ SYMBOLS = [
     "vo_set_stereo_pair_device", "vo_set_pyramid_window_hint",
     "vo_set_ingest_side_stream", "vo_set_stereo_pair_host_async", "vo_new_point_candidates_enqueue",
     "vo_new_point_candidates_get", "vo_stereo_frame_enqueue_closed", "vo_stereo_frame_new_points",
-    "vo_stereo_frame_enqueue_closed_world", "vo_stereo_frame_recoveries", "vo_svo_create", "vo_svo_destroy", "vo_svo_track", "vo_svo_enqueue",
+    "vo_stereo_frame_enqueue_closed_world", "vo_stereo_frame_recoveries", "vo_svo_create", "vo_svo_destroy", "vo_svo_track", "vo_svo_run", "vo_svo_enqueue",
     "vo_svo_prefetch", "vo_svo_result", "vo_svo_get_tracks", "vo_svo_get_new_points", "vo_svo_keyframe_count", "vo_svo_get_keyframe", "vo_svo_get_keyframes", "vo_triangulate_dlt", "vo_batch_create", "vo_batch_destroy",
-    "vo_mvo_create", "vo_mvo_destroy", "vo_mvo_track", "vo_mvo_enqueue", "vo_mvo_prefetch", "vo_mvo_result", "vo_mvo_get_tracks",
+    "vo_mvo_create", "vo_mvo_destroy", "vo_mvo_track", "vo_mvo_run", "vo_mvo_enqueue", "vo_mvo_prefetch", "vo_mvo_result", "vo_mvo_get_tracks",
     "vo_mvo_keyframe_count", "vo_mvo_get_keyframes",
     "vo_batch_last_error", "vo_batch_run", "vo_debug_set", "vo_batch_debug_set", "vo_batch_strict_border", "vo_debug_allocation_count", "vo_svo_device_bytes",
     "vo_se3_exp", "vo_ids_reset", "vo_ids_peek", "vo_ids_new_frames", "vo_ids_new_landmarks", "vo_compact_tracks",
@@ -167,6 +167,7 @@ def load():
     lib.vo_svo_destroy.argtypes = [vp]
     lib.vo_svo_destroy.restype = None
     lib.vo_svo_track.argtypes = [vp, vp, vp, ci, ci, C.c_double, C.POINTER(SvoFrameInfo)]
+    lib.vo_svo_run.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, vp, vp]
     lib.vo_svo_enqueue.argtypes = [vp, vp, vp, ci, ci, C.c_double]
     lib.vo_svo_prefetch.argtypes = [vp, vp, vp, ci, ci]
     lib.vo_svo_result.argtypes = [vp, C.POINTER(SvoFrameInfo)]
@@ -180,6 +181,7 @@ def load():
     lib.vo_mvo_destroy.argtypes = [vp]
     lib.vo_mvo_destroy.restype = None
     lib.vo_mvo_track.argtypes = [vp, vp, ci, ci, C.c_double, C.POINTER(MvoFrameInfo)]
+    lib.vo_mvo_run.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, vp]
     lib.vo_mvo_enqueue.argtypes = [vp, vp, ci, ci, C.c_double]
     lib.vo_mvo_prefetch.argtypes = [vp, vp, ci, ci]
     lib.vo_mvo_result.argtypes = [vp, C.POINTER(MvoFrameInfo)]

@@ -889,6 +889,27 @@ class StereoVO:
             self.ctx.check(rc)
         return self._out()
 
+    def runSequence(self, pairs, k_begin=0, k_end=None):
+        """A recorded sequence of (device address, stride) pairs — [((left, stride), (right, stride)), ...] — through the loop
+        inside the library (vo_svo_run): frames k_begin .. k_end - 1 are collected; frame k_end is left in flight for the next
+        call (or result()). Returns (list of SvoFrameInfo, numpy array of CLOCK_MONOTONIC stamps)."""
+        n = len(pairs)
+        k_end = n if k_end is None else int(k_end)
+        if getattr(self, "_seq_key", None) != id(pairs):
+            self._seq_L = (C.c_void_p * n)(*[int(p[0][0]) for p in pairs])
+            self._seq_R = (C.c_void_p * n)(*[int(p[1][0]) for p in pairs])
+            self._seq_key, self._seq_stride = id(pairs), int(pairs[0][0][1])
+        m = k_end - int(k_begin)
+        infos = (SvoFrameInfo * max(m, 1))()
+        stamps = np.zeros(max(m, 1), np.float64)
+        rc = self.lib.vo_svo_run(self._h, self._seq_L, self._seq_R, n, self._seq_stride, 1, int(k_begin), k_end, infos, stamps.ctypes.data)
+        if rc < 0:
+            self.ctx.check(rc)
+        out = [SvoFrameInfo.from_buffer_copy(infos[j]) for j in range(m)]
+        for i in out:
+            self.stats_frame.append(np.array(i.T_wc, np.float32).reshape(4, 4))
+        return out, stamps[:m]
+
     def getTracks(self):
         """The track set the next frame starts from: dict(ids, pts_l, pts_r, Xw, flags)."""
         n = C.c_int()
@@ -1332,6 +1353,25 @@ class MonoVO:
         if rc < 0:
             self.ctx.check(rc)
         return self._out()
+
+    def runSequence(self, images, k_begin=0, k_end=None):
+        """A recorded sequence of (device address, stride) images through the loop inside the library (vo_mvo_run): frames
+        k_begin .. k_end - 1 are collected, frame k_end is left in flight. Returns (list of MvoFrameInfo, stamps)."""
+        n = len(images)
+        k_end = n if k_end is None else int(k_end)
+        if getattr(self, "_seq_key", None) != id(images):
+            self._seq_I = (C.c_void_p * n)(*[int(p[0]) for p in images])
+            self._seq_key, self._seq_stride = id(images), int(images[0][1])
+        m = k_end - int(k_begin)
+        infos = (MvoFrameInfo * max(m, 1))()
+        stamps = np.zeros(max(m, 1), np.float64)
+        rc = self.lib.vo_mvo_run(self._h, self._seq_I, n, self._seq_stride, 1, int(k_begin), k_end, infos, stamps.ctypes.data)
+        if rc < 0:
+            self.ctx.check(rc)
+        out = [MvoFrameInfo.from_buffer_copy(infos[j]) for j in range(m)]
+        for i in out:
+            self.stats_frame.append(np.array(i.T_wc, np.float32).reshape(4, 4))
+        return out, stamps[:m]
 
     def getTracks(self):
         """frame_prev_'s related landmarks: dict(ids, pts, Xw, flags, age, cos_parallax)."""

@@ -977,6 +977,37 @@ extern "C" int vo_mvo_track(vo_mvo *s, const void *img, int stride, int on_devic
   return vo_mvo_result(s, info);
 }
 
+// A recorded sequence through the loop, driven from here (vo_svo_run's twin): collects frames k_begin .. k_end - 1 of the
+// n_total images — vo_mvo_result(k), then at once vo_mvo_enqueue(k + 1) and vo_mvo_prefetch(k + 2). k_begin == 0 starts the
+// sequence; otherwise frame k_begin is the one a previous call left in flight; frame k_end is in flight on return.
+extern "C" int vo_mvo_run(vo_mvo *s, const void *const *img, int n_total, int stride, int on_device, int k_begin, int k_end,
+                          vo_mvo_frame_info *infos, double *stamps) {
+  if (!s || !img || n_total <= 0 || k_begin < 0 || k_end > n_total || k_begin >= k_end) return VO_ERR_INVALID;
+  vo_ctx *c = s->c;
+  if (k_begin == 0) {
+    if (s->pending) VO_FAIL(c, VO_ERR_INVALID, "a frame is already in flight: call vo_mvo_result first");
+    RC(vo_mvo_enqueue(s, img[0], stride, on_device, 0.0));
+    if (n_total > 1) RC(vo_mvo_prefetch(s, img[1], stride, on_device));
+  } else if (!s->pending) {
+    VO_FAIL(c, VO_ERR_INVALID, "vo_mvo_run: frame %d is not in flight", k_begin);
+  }
+  vo_mvo_frame_info info;
+  for (int k = k_begin; k < k_end; ++k) {
+    RC(vo_mvo_result(s, &info));
+    if (stamps) {
+      timespec ts;
+      clock_gettime(CLOCK_MONOTONIC, &ts);
+      stamps[k - k_begin] = (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+    }
+    if (k + 1 < n_total) {
+      RC(vo_mvo_enqueue(s, img[k + 1], stride, on_device, 0.05 * (k + 1)));
+      if (k + 2 < n_total) RC(vo_mvo_prefetch(s, img[k + 2], stride, on_device));
+    }
+    if (infos) infos[k - k_begin] = info;
+  }
+  return VO_OK;
+}
+
 extern "C" int vo_mvo_get_tracks(vo_mvo *s, int32_t *ids, float *pts, float *Xw, uint8_t *flags, int32_t *age, float *cos_parallax,
                                  int cap, int *n) {
   if (!s || !n) return VO_ERR_INVALID;

@@ -609,6 +609,40 @@ extern "C" int vo_svo_track(vo_svo *s, const void *left, const void *right, int 
   return vo_svo_result(s, info);
 }
 
+// A recorded sequence through the loop, driven from here (the reference's caller is compiled code too: a ROS node's
+// callback; a caller that holds the whole sequence hands every pair over one frame early). Collects frames k_begin ..
+// k_end - 1 of the n_total pairs: frame k's result, then at once vo_svo_enqueue(k + 1) and vo_svo_prefetch(k + 2) — the
+// caller's per-frame work (here: one copy of the info block and a time stamp) runs under the next frame. k_begin == 0
+// starts the sequence (nothing may be in flight); otherwise frame k_begin is the one a previous call left in flight; on
+// return frame k_end is in flight (when there is one).
+extern "C" int vo_svo_run(vo_svo *s, const void *const *left, const void *const *right, int n_total, int stride, int on_device,
+                          int k_begin, int k_end, vo_svo_frame_info *infos, double *stamps) {
+  if (!s || !left || !right || n_total <= 0 || k_begin < 0 || k_end > n_total || k_begin >= k_end) return VO_ERR_INVALID;
+  vo_ctx *c = s->c;
+  if (k_begin == 0) {
+    if (s->pending) VO_FAIL(c, VO_ERR_INVALID, "a frame is already in flight: call vo_svo_result first");
+    RC(vo_svo_enqueue(s, left[0], right[0], stride, on_device, 0.0));
+    if (n_total > 1) RC(vo_svo_prefetch(s, left[1], right[1], stride, on_device));
+  } else if (!s->pending) {
+    VO_FAIL(c, VO_ERR_INVALID, "vo_svo_run: frame %d is not in flight", k_begin);
+  }
+  vo_svo_frame_info info;
+  for (int k = k_begin; k < k_end; ++k) {
+    RC(vo_svo_result(s, &info));
+    if (stamps) {
+      timespec ts;
+      clock_gettime(CLOCK_MONOTONIC, &ts);
+      stamps[k - k_begin] = (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+    }
+    if (k + 1 < n_total) {
+      RC(vo_svo_enqueue(s, left[k + 1], right[k + 1], stride, on_device, 0.1 * (k + 1)));
+      if (k + 2 < n_total) RC(vo_svo_prefetch(s, left[k + 2], right[k + 2], stride, on_device));
+    }
+    if (infos) infos[k - k_begin] = info;
+  }
+  return VO_OK;
+}
+
 extern "C" int vo_svo_get_tracks(vo_svo *s, int32_t *ids, float *pts_l, float *pts_r, float *Xw, uint8_t *flags, int cap,
                                  int *n) {
   if (!s || !n) return VO_ERR_INVALID;
