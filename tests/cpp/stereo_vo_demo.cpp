@@ -51,7 +51,21 @@ int main(int argc, char **argv) {
   try {
     auto ctx = std::make_shared<vo::Context>(0, w, h, 4096, 5, p.feature_tracker.max_level);
     vo::StereoVO svo(ctx, p);
-    for (int k = 0; k < n; ++k) {
+    if (hdr[7] == 2) {  // the whole sequence through the loop inside the library
+      std::vector<vo::Image> il, ir;
+      for (int k = 0; k < n; ++k) {
+        il.emplace_back(L[k].data(), w, h, w);
+        ir.emplace_back(R[k].data(), w, h, w);
+      }
+      svo.trackSequence(il, ir);
+      for (int k = 0; k < n; ++k) {
+        const vo_svo_frame_info &i = svo.sequenceInfos()[(size_t)k];
+        const int rec[4] = {i.frame_id, i.is_keyframe, i.n_tracks_out, i.lba_ran};
+        fwrite(rec, sizeof(int), 4, o);
+        fwrite(svo.getStatistics().stats_frame[(size_t)k].Twc.data(), sizeof(float), 16, o);
+      }
+    }
+    for (int k = 0; k < n && hdr[7] != 2; ++k) {
       const vo::Image il(L[k].data(), w, h, w), ir(R[k].data(), w, h, w);
       if (prefetch) {
         svo.enqueueStereoImages(il, ir, 0.1 * k);

@@ -203,11 +203,13 @@ def test_cpp_frame_pipelines_match_python_api(vo, tmp_path):
 
 
 @pytest.mark.gpu
-def test_cpp_stereo_vo_writes_the_python_loops_trajectory(vo, tmp_path):
+@pytest.mark.parametrize("hand_over", [1, 2])
+def test_cpp_stereo_vo_writes_the_python_loops_trajectory(vo, tmp_path, hand_over):
     """vo::StereoVO (core/visual_odometry/stereo_vo.h: trackStereoImages / getStatistics on POD images) over 20 pairs, with
     the local BA and the one-frame-ahead hand-over: frame ids, keyframes, track-set sizes and poses equal to the Python
     mirror's (api.StereoVO) bit for bit, and the trajectory file it leaves behind has the same bytes as the one written
-    from the Python loop's poses (the reference's dump format)."""
+    from the Python loop's poses (the reference's dump format). hand_over 1: enqueue / prefetch / result called per frame by the
+    program; 2: trackSequence (vo_svo_run, the loop inside the library)."""
     W, H, K = 640, 240, (400.0, 400.0, 320.0, 120.0)
     st = S.StereoStream(width=W, height=H, K=K, n_u=20, n_v=8, seed=5, speed=0.5)
     n = 20
@@ -216,7 +218,7 @@ def test_cpp_stereo_vo_writes_the_python_loops_trajectory(vo, tmp_path):
     exe = _compile(tmp_path, "stereo_vo_demo")
     inp, outp, traj = tmp_path / "svo_in.bin", tmp_path / "svo_out.bin", tmp_path / "traj_cpp.txt"
     with open(inp, "wb") as f:
-        f.write(struct.pack("9i", n, W, H, 20, 8, 21, 4, 1, 1))
+        f.write(struct.pack("9i", n, W, H, 20, 8, 21, 4, hand_over, 1))
         f.write(np.array(list(K) + list(np.asarray(st.T_lr, np.float32).reshape(16)) +
                          [80.0, 0.5, 3.0, kw["thres_alive_ratio"], kw["thres_trans"], kw["thres_rotation"]], np.float32).tobytes())
         for L, R in imgs:

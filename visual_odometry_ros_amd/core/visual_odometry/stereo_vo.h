@@ -171,6 +171,28 @@ class StereoVO {
     push_statistics(info, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_enq_).count());
   }
 
+  // A recorded sequence (host images, all of one stride) through the three calls above, the loop inside the library
+  // (vo_svo_run): every pair is handed over one frame early. One statistics record per frame, as trackStereoImages leaves it.
+  void trackSequence(const std::vector<Image> &left, const std::vector<Image> &right) {
+    const size_t n = left.size() < right.size() ? left.size() : right.size();
+    if (n == 0) return;
+    std::vector<const void *> L(n), R(n);
+    for (size_t k = 0; k < n; ++k) {
+      L[k] = left[k].data;
+      R[k] = right[k].data;
+    }
+    std::vector<vo_svo_frame_info> &infos = sequence_infos_;
+    infos.assign(n, vo_svo_frame_info());
+    std::vector<double> stamps(n);
+    const auto t0 = std::chrono::steady_clock::now();
+    ctx_->check(vo_svo_run(svo_, L.data(), R.data(), (int)n, left[0].stride, 0, 0, (int)n, infos.data(), stamps.data()));
+    const float total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    for (size_t k = 0; k < n; ++k)
+      push_statistics(infos[k], k == 0 ? total - (float)(1e3 * (stamps[n - 1] - stamps[0])) : (float)(1e3 * (stamps[k] - stamps[k - 1])));
+  }
+
+  const std::vector<vo_svo_frame_info> &sequenceInfos() const { return sequence_infos_; }  // (of the last trackSequence)
+
   const AlgorithmStatistics &getStatistics() const { return stat_; }
   // stats_keyframe as of now: every keyframe's current pose and the current 3-D points of its related landmarks
   void refreshKeyframeStatistics() {
@@ -248,6 +270,7 @@ class StereoVO {
   std::vector<int> frame_ids_;
   vo_svo_frame_info last_{};
   std::chrono::steady_clock::time_point t_enq_;
+  std::vector<vo_svo_frame_info> sequence_infos_;
 };
 
 }  // namespace vo
