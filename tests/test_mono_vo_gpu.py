@@ -181,3 +181,37 @@ def test_mono_run_sequence_equals_the_three_calls(vo):
     (Ta, ka, la, ia, aa), (Tb, kb, lb, ib, ab) = runs
     assert np.array_equal(_bits(Ta), _bits(Tb)) and ka == kb and la == lb and np.array_equal(ia, ib) and np.array_equal(aa, ab)
     assert sum(la) >= 2
+
+
+def test_mono_loop_survives_a_join_timeout(vo):
+    """The loop with the concurrent replay and a device-side join that cannot be met (VO_DBG_FAIL_JOIN): the first frame that takes
+    the concurrent arrangement times out, is issued again in stream order (its track-set advance then runs as launches of its
+    own), and the loop goes on — the same poses, ids and ages as an undisturbed run."""
+    from util import DeviceBuffer
+    from visual_odometry_ros_amd import synthetic as S
+    W, H, n = 752, 480, 9
+    st = S.StereoStream(width=W, height=H, K=MONO_K, n_u=40, n_v=25, seed=5, speed=0.25)
+    poses = st.poses(n)
+    bufs = [DeviceBuffer(st.render_pair(p)[0]) for p in poses]
+    imgs = [(b.data_ptr(), W) for b in bufs]
+    runs = []
+    try:
+        for fail in (0, 1):
+            hook = TruePoseHook(poses)
+            hook.k = 1
+            c = vo.Context(device=0, max_width=W, max_height=H, max_points=2512, n_slots=3, max_level=5)
+            try:
+                c.debug_set(c.DBG_FAIL_JOIN, fail)
+                mvo = vo.MonoVO(c, W, H, MONO_K, 40, 25, hook, thres_translation=1.0, strict_border=3, local_ba=True)
+                infos = [mvo.trackImage(im) for im in imgs]
+                g = mvo.getTracks()
+                runs.append((np.stack([np.array(i.T_wc, np.float32) for i in infos]), g["ids"].copy(), g["age"].copy(), c.frame_recoveries()))
+                mvo.close()
+            finally:
+                c.close()
+    finally:
+        for b in bufs:
+            b.free()
+    (Ta, ia, aa, ra), (Tb, ib, ab, rb) = runs
+    assert ra == 0 and rb == 1
+    assert np.array_equal(_bits(Ta), _bits(Tb)) and np.array_equal(ia, ib) and np.array_equal(aa, ab)

@@ -462,9 +462,7 @@ static int mono_enqueue_impl(vo_ctx *c, const vo_mono_params *prm, int slot0, in
     f->again_mono.has_bins = bp ? 1 : 0;
     if (bp) f->again_mono.bins = *bp;
     f->again_mono.table = table;
-    f->again_mono.adv_on = adv_on;
     f->again_mono.flag_mode = flag_mode;
-    if (adv_on) f->again_mono.adv = f->mvo_adv;
     switch (prm->win) {
       case 13: mono_launch<13>(c, a); break;
       case 15: mono_launch<15>(c, a); break;
@@ -655,10 +653,8 @@ extern "C" int vo_mono_frame_result(vo_ctx *c, float *pts1, float *scale, uint8_
     ++c->frame_recoveries;
     const auto g = f->again_mono;
     f->mono_flag_mode = g.flag_mode;
-    if (g.adv_on) {  // (MonoVO: the re-issued frame builds the next track set again)
-      f->mvo_adv = g.adv;
-      f->mvo_adv_on = 1;
-    }
+    // (MonoVO: the first attempt's BA launch reported "not built" for the next track set — the frame had failed — and the host
+    // has that report by now: the advance of the re-issued frame is the host's, as launches of its own)
     const int rc2 = mono_enqueue_impl(c, &g.prm, g.slot0, g.slot1, g.pts0, g.Xw, g.flags, g.n, g.Tcw_prev, g.Tcw_prior, g.dT01_prior, 1,
                                       g.has_bins ? &g.bins : nullptr, g.table);
     if (rc2 < 0) return rc2;

@@ -83,8 +83,7 @@ struct vo_frame_state {
     const uint8_t *flags;
     float Tcw_prev[16], Tcw_prior[16], dT01_prior[16];
     vo_bin_params bins;
-    int adv_on, flag_mode;
-    MvoAdvArgs adv;
+    int flag_mode;
   } again_mono;
   // MonoVO: what the NEXT mono enqueue hands to the BA launch so that its epilogue builds the next track set
   // (vo_mono_frame_set_advance, consumed by that enqueue)

@@ -455,6 +455,7 @@ static int mvo_wait_hdr(vo_mvo *s) {
       clock_gettime(CLOCK_MONOTONIC, &p1);
       if ((p1.tv_sec - p0.tv_sec) * 1e9 + (p1.tv_nsec - p0.tv_nsec) > 2e7) {
         VO_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+        if (*seqp != s->seq) VO_FAIL(c, VO_ERR_HIP, "MonoVO: the track-set advance of the frame did not report (sequence word %u, expected %u)", *seqp, s->seq);
         break;
       }
     }
