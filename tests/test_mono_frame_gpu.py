@@ -99,6 +99,30 @@ def test_mono_frame_matches_oracle(mono_ctx, vo, oracle, strict):
     assert ctx.frame_recoveries() == 0
 
 
+@pytest.mark.parametrize("win,strict", [(13, 1), (21, 3), (31, 1), (31, 3)])
+def test_mono_frame_other_windows(mono_ctx, vo, oracle, win, strict):
+    """The other window sizes the mono frame kernel is built for (config/**.yaml use 13, 15, 21; 31 is the largest KLT window
+    of the operator tests), stream-ordered and concurrent replay."""
+    ctx = mono_ctx
+    I0, I1, ts = _scene(23)
+    pts0 = ts["pts_l0"]
+    n = pts0.shape[0]
+    Xw, Tcw_prev, Tcw_prior, dT01 = _world(ts, 4)
+    rng = np.random.default_rng(11)
+    flags = ((rng.random(n) < 0.7).astype(np.uint8) | ((rng.random(n) < 0.8).astype(np.uint8) << 1)).astype(np.uint8)
+    args = (752, 480, win, 4, 20.0, 1.0, 5, 1.0, MONO_K)
+    ctx.set_image(0, I0)
+    ctx.set_image(1, I1)
+    pipe = MonoFramePipeline(ctx, make_mono_params(*args), strict_border=strict)
+    pipe.enqueue(pts0, Xw, flags, Tcw_prev, Tcw_prior, dT01)
+    g = pipe.result()
+    o = oracle.mono_frame(oracle.make_mono_params(*args), I0, I1, pts0, Xw, flags, Tcw_prev, Tcw_prior, dT01, oracle.SUM_TREE, 512,
+                          oracle.IC_REFERENCE, 8)
+    _compare(g, o)
+    assert g["counts"].n_final > 0.4 * n and g["counts"].n_replayed > 0
+    assert ctx.frame_recoveries() == 0
+
+
 def test_mono_frame_join_timeout_is_recovered(vo, oracle):
     """The concurrent replay's device-side join cannot be met (VO_DBG_FAIL_JOIN: the BA launch waits for a count that never
     comes, as under a tool that serialises the queues): the frame is issued again with the stream-ordered replay — same
