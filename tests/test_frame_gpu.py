@@ -97,7 +97,7 @@ def test_concurrent_replay_with_fewer_workgroups_than_border_features():
     import os
     import subprocess
     import sys
-    env = dict(os.environ, VO_CONC_GRID="8")
+    env = dict(os.environ, VO_TEST_SWITCHES="1", VO_CONC_GRID="8")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
                         "test_stereo_frame_kitti_shape and 3"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
@@ -133,7 +133,7 @@ def test_join_timeout_is_recovered_not_reported():
     (VO_DEBUG_FAIL_JOIN: the BA launch waits for a count that never comes, as under a tool that serialises the queues) the
     frame must NOT be lost: vo_stereo_frame_result re-issues it with the stream-ordered replay, the context stays on that
     arrangement, and every frame equals the oracle's (fresh child process: the switch is read once)."""
-    _child({"VO_DEBUG_FAIL_JOIN": "1"}, "test_stereo_frame_automatic_replay_mode or (test_stereo_frame_kitti_shape and 3)")
+    _child({"VO_TEST_SWITCHES": "1", "VO_DEBUG_FAIL_JOIN": "1"}, "test_stereo_frame_automatic_replay_mode or (test_stereo_frame_kitti_shape and 3)")
 
 
 def test_strict_modes_under_serialised_kernels():

@@ -136,6 +136,70 @@ def test_mono_loop_with_undistortion(vo, oracle):
     assert sum(1 for e in log if e[0]) >= 3 and log[-1][1] > 300, log
 
 
+# ---- against the CPU loop in the REFERENCE's summation order (see tests/test_stereo_vo_gpu.py: _vs_reference_order) -----------
+# Measured (CPU, SUM_SEQ loop against SUM_TREE loop, tools/tools_seq_vs_tree.py --mono): ids, flags, keyframe decisions equal for
+# frames 0..21 of 24 at 752x480 with the mono local BA; frame 22 differs by one landmark (1832 against 1833 entries; equal again
+# at frame 23: the landmark dies); poses within 8.3e-5 (the mono scale is fixed once, at the initialisation, so differences only add up).
+_MONO_SEQ_FORK_FRAME = 22
+
+
+@pytest.fixture(scope="module")
+def mono_seq_report(vo, oracle):
+    from oracle.mono_vo import MonoVORef
+    from visual_odometry_ros_amd import synthetic as S
+    W, H, nu, nv, win, lvl, n_frames = 752, 480, 40, 25, 15, 5, 24
+    st = S.StereoStream(width=W, height=H, K=MONO_K, n_u=nu, n_v=nv, seed=5, speed=0.25)
+    poses = st.poses(n_frames)
+    imgs = [st.render_pair(p)[0] for p in poses]
+    hook_g, hook_r = TruePoseHook(poses), TruePoseHook(poses)
+    ref = MonoVORef(W, H, MONO_K, nu, nv, hook_r, thres_fast=15, win=win, max_level=lvl, thres_err=20.0, thres_bidir=1.0, thres_poseba=5,
+                    thres_sampson=1.0, thres_parallax_deg=1.0, kf_trans=2.5, lba=True, sum_mode=oracle.SUM_SEQ, tree_width=0,
+                    ic_border=oracle.IC_REFERENCE, n_threads=8)
+    c = vo.Context(device=0, max_width=W, max_height=H, max_points=2 * nu * nv + 512, n_slots=3, max_level=lvl)
+    rep = dict(ids_equal=[], flags_equal=[], kf_equal=[], pose_rel=[], lba=0)
+    try:
+        mvo = vo.MonoVO(c, W, H, MONO_K, nu, nv, hook_g, thres_fastscore=15, window_size=win, max_level=lvl, thres_error=20.0,
+                        thres_bidirection=1.0, thres_poseba_error=5, thres_sampson=1.0, thres_parallax=1.0, thres_translation=2.5,
+                        strict_border=4, local_ba=True)
+        for k in range(n_frames):
+            hook_g.k = hook_r.k = k
+            mvo.enqueue(imgs[k])
+            if k + 1 < n_frames:
+                mvo.prefetch(imgs[k + 1])
+            gi = mvo.result()
+            ri = ref.track(imgs[k])
+            g = mvo.getTracks()
+            same = np.array_equal(g["ids"], ref.ids)
+            rep["ids_equal"].append(bool(same))
+            rep["flags_equal"].append(bool(same and np.array_equal(g["flags"], ref.flags())))
+            rep["kf_equal"].append(bool(gi.is_keyframe) == ri["keyframe"])
+            Tg, Tr = np.array(gi.T_wc, np.float64).reshape(4, 4), ref.frames[k]["T_wc"].astype(np.float64)
+            rep["pose_rel"].append(float(np.linalg.norm(Tg - Tr) / np.linalg.norm(Tr)))
+            rep["lba"] += int(bool(gi.lba_ran))
+        mvo.close()
+    finally:
+        c.close()
+    return rep
+
+
+def test_mono_loop_vs_reference_order(mono_seq_report):
+    """24 free-running frames at 752x480 with the mono local BA against the CPU loop in the REFERENCE's summation order: pose
+    within 1e-4 and the same keyframe decision at every frame, ids and flags equal up to the measured fork (frame 22)."""
+    r = mono_seq_report
+    assert max(r["pose_rel"]) < 1e-4, r["pose_rel"]
+    assert all(r["kf_equal"]), r["kf_equal"]
+    assert r["lba"] >= 4
+    first = next((k for k, e in enumerate(r["ids_equal"]) if not e), len(r["ids_equal"]))
+    assert first >= _MONO_SEQ_FORK_FRAME, (first, r["ids_equal"])
+    assert all(r["flags_equal"][:_MONO_SEQ_FORK_FRAME])
+
+
+@pytest.mark.xfail(strict=True, reason="mono track ids against the reference's summation order differ at frame 22 of 24 (752x480, mono local "
+                   "BA): one landmark more in the kernels' order (1833 against 1832), gone again at frame 23; poses within 8.3e-5")
+def test_mono_loop_ids_vs_reference_order_every_frame(mono_seq_report):
+    assert all(mono_seq_report["ids_equal"]), mono_seq_report["ids_equal"]
+
+
 def test_mono_run_sequence_equals_the_three_calls(vo):
     """vo_mvo_run (the sequence loop inside the library) against the same sequence driven call by call: poses, keyframe
     decisions, final ids and ages — the same bits."""

@@ -52,13 +52,18 @@ class Context:
             raise VoError(rc, msg)
         self.cfg = cfg
         self._children = weakref.WeakSet()  # objects that hold device state of this context (StereoVO): closed before it
-        # test / measurement switches (include/vo_hip.h: vo_debug_set). The library itself reads no environment variable;
-        # this mirror hands the ones the test-suite and tools/ set to the context it creates.
-        for key, name in ((0, "VO_DEBUG_FAIL_JOIN"), (1, "VO_CONC_GRID"), (2, "VO_SBA_LDS_SOLVE"), (3, "VO_DEBUG_SKIP_DETECT"),
-                          (5, "VO_MVO_HOST_ADVANCE")):
-            v = os.environ.get(name)
-            if v:
-                self.debug_set(key, int(v) if v.lstrip("-").isdigit() else 1)
+        # test / measurement switches (include/vo_hip.h: vo_debug_set). Neither the library nor this mirror reads them from
+        # the environment in normal use: only a process started with VO_TEST_SWITCHES=1 (the test-suite's child processes,
+        # tools/) has the variables below applied to the contexts it creates, and `debug_switches` says which are active
+        # (bench.py reports them).
+        self.debug_switches = {}
+        if os.environ.get("VO_TEST_SWITCHES") == "1":
+            for key, name in ((0, "VO_DEBUG_FAIL_JOIN"), (1, "VO_CONC_GRID"), (2, "VO_SBA_LDS_SOLVE"), (3, "VO_DEBUG_SKIP_DETECT"),
+                              (5, "VO_MVO_HOST_ADVANCE")):
+                v = os.environ.get(name)
+                if v:
+                    self.debug_set(key, int(v) if v.lstrip("-").isdigit() else 1)
+                    self.debug_switches[name] = v
 
     DBG_FAIL_JOIN, DBG_CONC_GRID, DBG_SBA_LDS_SOLVE, DBG_SKIP_DETECT, OPT_POLL_YIELD, DBG_MVO_HOST_ADVANCE = 0, 1, 2, 3, 4, 5
 
@@ -895,10 +900,21 @@ class StereoVO:
         call (or result()). Returns (list of SvoFrameInfo, numpy array of CLOCK_MONOTONIC stamps)."""
         n = len(pairs)
         k_end = n if k_end is None else int(k_end)
-        if getattr(self, "_seq_key", None) != id(pairs):
+        # The address arrays are kept between calls on the SAME list object (held here, so its id cannot be reused) of the
+        # same length, and the entries this call hands to the library (k_begin .. k_end + 1) are compared with them: a list
+        # that was changed in place, or another list, rebuilds the arrays.
+        L, R = getattr(self, "_seq_L", None), getattr(self, "_seq_R", None)
+        fresh = getattr(self, "_seq_ref", None) is not pairs or L is None or len(L) != n
+        if not fresh:
+            for k in range(max(int(k_begin), 0), min(k_end + 2, n)):
+                if L[k] != int(pairs[k][0][0]) or R[k] != int(pairs[k][1][0]):
+                    fresh = True
+                    break
+        if fresh:
             self._seq_L = (C.c_void_p * n)(*[int(p[0][0]) for p in pairs])
             self._seq_R = (C.c_void_p * n)(*[int(p[1][0]) for p in pairs])
-            self._seq_key, self._seq_stride = id(pairs), int(pairs[0][0][1])
+            self._seq_ref = pairs
+        self._seq_stride = int(pairs[0][0][1])
         m = k_end - int(k_begin)
         infos = (SvoFrameInfo * max(m, 1))()
         stamps = np.zeros(max(m, 1), np.float64)
@@ -1359,9 +1375,17 @@ class MonoVO:
         k_begin .. k_end - 1 are collected, frame k_end is left in flight. Returns (list of MvoFrameInfo, stamps)."""
         n = len(images)
         k_end = n if k_end is None else int(k_end)
-        if getattr(self, "_seq_key", None) != id(images):
+        I = getattr(self, "_seq_I", None)  # kept between calls on the same, unchanged list only (as StereoVO.runSequence)
+        fresh = getattr(self, "_seq_ref", None) is not images or I is None or len(I) != n
+        if not fresh:
+            for k in range(max(int(k_begin), 0), min(k_end + 2, n)):
+                if I[k] != int(images[k][0]):
+                    fresh = True
+                    break
+        if fresh:
             self._seq_I = (C.c_void_p * n)(*[int(p[0]) for p in images])
-            self._seq_key, self._seq_stride = id(images), int(images[0][1])
+            self._seq_ref = images
+        self._seq_stride = int(images[0][1])
         m = k_end - int(k_begin)
         infos = (MvoFrameInfo * max(m, 1))()
         stamps = np.zeros(max(m, 1), np.float64)
