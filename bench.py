@@ -147,10 +147,13 @@ def issue_roofline(counters, klt_ms, launches):
 
 
 # ---- the one collective --------------------------------------------------------------------------------------------
+FORCE_COLLECTIVE = False  # --force-collective: the process group and the gather also with ONE rank (the RCCL path on a 1-GPU box)
+
+
 def gather_ranks(frames, seconds, seed, world, device=None):
     """The one collective of the job: an all_gather of {frames, seconds, stream seed} per rank
     (RCCL on GPUs, gloo in the CPU tests), 24 B per rank. Returns the per-rank list [(frames, seconds, seed)]."""
-    if world <= 1:
+    if world <= 1 and not FORCE_COLLECTIVE:
         return [(float(frames), float(seconds), int(seed))]
     import torch
     import torch.distributed as dist
@@ -1144,6 +1147,9 @@ def main():
                     help="seconds a rank waits in init_process_group for the others (a rank that never arrives ends the job "
                          "instead of hanging it); the self-launcher ends all ranks after 20x this")
     ap.add_argument("--no-pin", action="store_true", help="leave the ranks' CPU affinity alone (default for N > 1: a contiguous share per rank)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N = 1 only: create the nccl (RCCL) process group with one rank and run the end-of-job all_gather "
+                         "through it anyway — the code path N > 1 takes, executed on a 1-GPU box (tests/test_bench_gpu.py)")
     ap.add_argument("--rendezvous-check", action="store_true",
                     help="run only the multi-rank control flow (gloo, no GPU work) and print its JSON line")
     args = ap.parse_args()
@@ -1186,9 +1192,18 @@ def main():
     import torch.distributed as dist
     import visual_odometry_ros_amd as V  # loads libvo_hip.so (fails loudly if missing)
     V.load()
-    if world > 1:
+    global FORCE_COLLECTIVE
+    FORCE_COLLECTIVE = bool(args.force_collective) and world == 1
+    collective = world > 1 or FORCE_COLLECTIVE
+    if collective:
         import datetime
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank),
+        if world == 1 and "MASTER_ADDR" not in os.environ:  # (no launcher: a rendezvous of one on the loopback interface)
+            import socket
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(so.getsockname()[1])
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world,
                                 timeout=datetime.timedelta(seconds=args.rendezvous_timeout))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -1196,7 +1211,7 @@ def main():
     args.host_images_leg = args.host_images or (secondary and not loop)
 
     def barrier(ctx):
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
         ctx.synchronize()
@@ -1210,10 +1225,11 @@ def main():
     else:
         out, ctx = run_stereo(cfg, args, rank, local_rank, world, torch, V, barrier, dev, secondary)
     if rank == 0:
+        out["collective"] = "nccl" if collective else "none"
         print(json.dumps(out), flush=True)
     if ctx is not None:
         ctx.close()
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
 
 

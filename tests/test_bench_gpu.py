@@ -49,3 +49,22 @@ def test_bench_with_very_few_steps(flags):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["value"] > 0 and d["steps"] == int(flags[flags.index("--steps") + 1]) and "roofline" in d
+
+
+def test_rccl_process_group_and_gather_with_one_rank():
+    """The N > 1 path of bench.py — init_process_group("nccl") with the rendezvous time-out, dist.barrier around the timed region,
+    the device-tensor all_gather of gather_ranks, destroy_process_group — executed on THIS one GPU with a world of one rank
+    (--force-collective; a fresh child process, nothing re-exec'ed): the first RCCL communicator this code creates is not the one
+    on the driver's 8-GPU node. N > 1 itself stays unmeasured on hardware."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-collective", "--steps", "2", "--warmup", "0",
+                        "--no-secondary", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["collective"] == "nccl" and d["n_gpus"] == 1 and len(d["per_rank_fps"]) == 1
+    assert abs(d["per_rank_fps"][0] - d["value"]) <= 0.02 * d["value"]
