@@ -1,0 +1,202 @@
+// pyr_tile.hpp — the whole PyrLK pyramid of an image (or a stereo pair) in ONE launch: pyr_build_kernel.
+//
+// What it replaces: cv::buildOpticalFlowPyramid inside every cv::calcOpticalFlowPyrLK call of the reference
+// (core/visual_odometry/feature_tracker.cpp:29,60,69,108,117,186 -> OpenCV 4 video/lkpyramid.cpp, imgproc/pyramids.cpp:
+// copyMakeBorder(BORDER_REFLECT_101) per level, pyrDown = 5-tap [1 4 6 4 1]/16 both ways, (sum + 128) >> 8) — and rounds
+// 1-4 of this repository, which built a slot's pyramid with one launch per level (pad_level0_kernel + 4 x pyr_down_kernel:
+// 5 dependent launches, 38 us per pair next to a frame in flight; profiles/r04_a_*).
+//
+// Level l+1 depends on level l only through a 5x5 neighbourhood, so a workgroup that owns a T x T tile of the TOP level
+// can produce its piece of every level by itself: it stages the base-level region its tile depends on in LDS
+// ((64 + 3 (2^nl - 1))^2 bytes at most: 109 x 109 for four levels), reduces it level by level in LDS — recomputing the
+// halo its neighbours also compute instead of waiting for them — and writes, per level, the pixels it OWNS (a 64 >> k
+// tile of level k, dword stores) plus their mirror images in the level's REFLECT_101 border (byte stores). No workgroup
+// waits for another one, no level goes through HBM between its producer and its consumer, one launch.
+//
+// Bits: the same integer sums in any order — identical to pad_level0_kernel / pyr_down_kernel and oracle_klt.c.
+//
+// Plain C++ apart from __global__ / __shared__ / __syncthreads / threadIdx / blockIdx: tests/emu/ runs this file's
+// kernel on CPU threads against the oracle's pyramid (borders included) in the CPU suite.
+#pragma once
+#include "vo_layout.hpp"
+
+#define PYR_NL_MAX 4   // levels produced above the launch's base level (deeper pyramids chain a second launch)
+#define PYR_T0 64      // edge of the base-level tile a workgroup owns (top-level tile: PYR_T0 >> nl)
+#define PYR_NT 256
+#define PYR_S0 112     // LDS row strides of the level regions (region edges 109, 53, 25, 11, 4 at most)
+#define PYR_S1 56
+#define PYR_S2 28
+#define PYR_S3 12
+#define PYR_S4 4
+
+struct PyrTileArgs {
+  const uint8_t *src[2];            // base-level image: the caller's image, or the origin of an already padded level
+  int sstride[2];
+  vo_level L[2][PYR_NL_MAX + 1];    // [image][0] the base level's plane (written when write_base), [1..nl] the levels produced
+  int nl;                           // levels above the base (0..PYR_NL_MAX)
+  int write_base;                   // 1: the base level is copied into L[.][0], border included
+  int tiles_x, tiles_y;             // tiles of the top level, T x T each
+  int T;                            // PYR_T0 >> nl
+};
+
+// geometry of one axis of one workgroup: per level k (0 = base) the region held in LDS [lo, lo + size) and the owned
+// interval [o0, o1) (clipped to the image)
+struct PyrAxis {
+  int lo[PYR_NL_MAX + 1], size[PYR_NL_MAX + 1], o0[PYR_NL_MAX + 1], o1[PYR_NL_MAX + 1];
+};
+__device__ inline void pyr_axis(int tile, int T, int nl, const int *dim /* per level */, PyrAxis *A) {
+  int lo = tile * T, hi = lo + T;  // top level: exactly the owned tile
+  for (int k = nl; k >= 0; --k) {
+    A->lo[k] = lo;
+    A->size[k] = hi - lo;
+    const int sh = nl - k;
+    int o0 = (tile * T) << sh, o1 = ((tile + 1) * T) << sh;
+    if (o0 > dim[k]) o0 = dim[k];
+    if (o1 > dim[k]) o1 = dim[k];
+    A->o0[k] = o0;
+    A->o1[k] = o1;
+    hi = 2 * hi + 1;  // taps 2x-2 .. 2x+2 of the last needed column
+    lo = 2 * lo - 2;
+  }
+}
+
+__device__ inline uint8_t *pyr_lds_level(uint8_t *a0, uint8_t *a1, uint8_t *a2, uint8_t *a3, uint8_t *a4, int k) {
+  return k == 0 ? a0 : (k == 1 ? a1 : (k == 2 ? a2 : (k == 3 ? a3 : a4)));
+}
+__device__ inline int pyr_lds_stride(int k) {
+  return k == 0 ? PYR_S0 : (k == 1 ? PYR_S1 : (k == 2 ? PYR_S2 : (k == 3 ? PYR_S3 : PYR_S4)));
+}
+
+__global__ __launch_bounds__(PYR_NT) void pyr_build_kernel(PyrTileArgs a) {
+  __shared__ uint8_t s_l0[109 * PYR_S0];
+  __shared__ uint8_t s_l1[53 * PYR_S1];
+  __shared__ uint8_t s_l2[25 * PYR_S2];
+  __shared__ uint8_t s_l3[11 * PYR_S3];
+  __shared__ uint8_t s_l4[4 * PYR_S4];
+  // mirror lists: the padded coordinates of a level's border whose REFLECT_101 source lies in this workgroup's owned
+  // interval — (destination padded coordinate, source coordinate), per level and axis; a border is VO_PAD wide on each side
+  __shared__ short s_mdst[PYR_NL_MAX + 1][2][2 * VO_PAD];
+  __shared__ short s_msrc[PYR_NL_MAX + 1][2][2 * VO_PAD];
+  __shared__ int s_mcnt[PYR_NL_MAX + 1][2];
+
+  // the workgroup's geometry, per axis and level: in LDS because it is indexed by the level (as private arrays it went to
+  // scratch memory: 224 bytes per lane)
+  __shared__ PyrAxis s_axis[2];
+  __shared__ int s_dim[2][PYR_NL_MAX + 1];
+
+  const int tid = threadIdx.x, z = blockIdx.z;
+  const int nl = a.nl;
+  if (tid < 2) {
+    const int tile = tid == 0 ? (int)blockIdx.x % a.tiles_x : (int)blockIdx.x / a.tiles_x;
+    for (int k = 0; k <= nl; ++k) s_dim[tid][k] = tid == 0 ? a.L[z][k].w : a.L[z][k].h;
+    pyr_axis(tile, a.T, nl, s_dim[tid], &s_axis[tid]);
+  }
+  if (tid < 2 * (PYR_NL_MAX + 1)) s_mcnt[tid >> 1][tid & 1] = 0;
+  __syncthreads();
+  const PyrAxis &X = s_axis[0], &Y = s_axis[1];
+  const int *wk = s_dim[0], *hk = s_dim[1];
+
+  // ---- stage the base-level region (only pixels inside the image are ever read back: taps are reflected first) -------
+  {
+    const uint8_t *__restrict__ src = a.src[z];
+    const int ss = a.sstride[z], sx = X.size[0], sy = Y.size[0], n = sx * sy;
+    for (int i = tid; i < n; i += PYR_NT) {
+      const int ry = i / sx, rx = i - ry * sx;
+      const int x = X.lo[0] + rx, y = Y.lo[0] + ry;
+      if (x >= 0 && x < wk[0] && y >= 0 && y < hk[0]) s_l0[ry * PYR_S0 + rx] = src[(size_t)y * ss + x];
+    }
+  }
+  // ---- the mirror lists of every level (2 * VO_PAD border coordinates per level and axis) --------------------------------
+  for (int i = tid; i < (nl + 1) * 2 * (2 * VO_PAD); i += PYR_NT) {
+    const int k = i / (4 * VO_PAD), r = i - k * (4 * VO_PAD), axis = r / (2 * VO_PAD), q = r - axis * (2 * VO_PAD);
+    const int dim = axis ? hk[k] : wk[k];
+    const int p = q < VO_PAD ? q - VO_PAD : dim + (q - VO_PAD);  // -VO_PAD .. -1, dim .. dim + VO_PAD - 1
+    const int s = vo_reflect101(p, dim);
+    const int o0 = axis ? Y.o0[k] : X.o0[k], o1 = axis ? Y.o1[k] : X.o1[k];
+    if (s >= o0 && s < o1) {
+      const int e = atomicAdd(&s_mcnt[k][axis], 1);
+      s_mdst[k][axis][e] = (short)p;
+      s_msrc[k][axis][e] = (short)s;
+    }
+  }
+  __syncthreads();
+
+  // ---- level k + 1 from level k, in LDS ------------------------------------------------------------------------
+  for (int k = 0; k < nl; ++k) {
+    const uint8_t *S = pyr_lds_level(s_l0, s_l1, s_l2, s_l3, s_l4, k);
+    uint8_t *D = pyr_lds_level(s_l0, s_l1, s_l2, s_l3, s_l4, k + 1);
+    const int ssd = pyr_lds_stride(k), dsd = pyr_lds_stride(k + 1);
+    const int sx = X.size[k + 1], sy = Y.size[k + 1], n = sx * sy;
+    const int sw = wk[k], sh = hk[k], dw = wk[k + 1], dh = hk[k + 1];
+    const int slx = X.lo[k], sly = Y.lo[k];
+    for (int i = tid; i < n; i += PYR_NT) {
+      const int ry = i / sx, rx = i - ry * sx;
+      const int x = X.lo[k + 1] + rx, y = Y.lo[k + 1] + ry;
+      if (x < 0 || x >= dw || y < 0 || y >= dh) continue;
+      int cx[5], cy[5];
+      if (2 * x - 2 >= 0 && 2 * x + 2 < sw) {
+#pragma unroll
+        for (int c = 0; c < 5; ++c) cx[c] = 2 * x - 2 + c - slx;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 5; ++c) cx[c] = vo_reflect101(2 * x - 2 + c, sw) - slx;
+      }
+      if (2 * y - 2 >= 0 && 2 * y + 2 < sh) {
+#pragma unroll
+        for (int r = 0; r < 5; ++r) cy[r] = (2 * y - 2 + r - sly) * ssd;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 5; ++r) cy[r] = (vo_reflect101(2 * y - 2 + r, sh) - sly) * ssd;
+      }
+      int s = 0;
+#pragma unroll
+      for (int r = 0; r < 5; ++r) {
+        const int wgt = (r == 0 || r == 4) ? 1 : ((r == 1 || r == 3) ? 4 : 6);
+        const uint8_t *row = S + cy[r];
+        s += wgt * ((int)row[cx[0]] + 4 * (int)row[cx[1]] + 6 * (int)row[cx[2]] + 4 * (int)row[cx[3]] + (int)row[cx[4]]);
+      }
+      D[ry * dsd + rx] = (uint8_t)((s + 128) >> 8);
+    }
+    __syncthreads();
+  }
+
+  // ---- write what this workgroup owns of every level ----------------------------------------------------------------
+  for (int k = a.write_base ? 0 : 1; k <= nl; ++k) {
+    const uint8_t *S = pyr_lds_level(s_l0, s_l1, s_l2, s_l3, s_l4, k);
+    const int ssd = pyr_lds_stride(k);
+    const vo_level Lv = a.L[z][k];
+    uint8_t *org = Lv.base + (size_t)VO_PAD * Lv.stride + VO_PAD;  // pixel (0, 0)
+    const int x0 = X.o0[k], x1 = X.o1[k], y0 = Y.o0[k], y1 = Y.o1[k];
+    const int nx = x1 - x0, ny = y1 - y0;
+    if (nx <= 0 || ny <= 0) continue;
+    const int lx = X.lo[k], ly = Y.lo[k];
+    // (a) the owned pixels themselves: x0 is a multiple of 4 and the plane's pixel (0, 0) is 4-byte aligned -> dword stores
+    const int ndw = (nx + 3) >> 2;
+    for (int i = tid; i < ndw * ny; i += PYR_NT) {
+      const int ry = i / ndw, j = i - ry * ndw;
+      const int x = x0 + 4 * j, y = y0 + ry;
+      const uint8_t *sp = S + (y - ly) * ssd + (x - lx);
+      uint8_t *dp = org + (ptrdiff_t)y * Lv.stride + x;
+      if (x + 3 < x1) {
+        const uint32_t v = (uint32_t)sp[0] | ((uint32_t)sp[1] << 8) | ((uint32_t)sp[2] << 16) | ((uint32_t)sp[3] << 24);
+        *(uint32_t *)dp = v;
+      } else {  // the image's last columns: the bytes behind them are border pixels (another interval's mirror images)
+        for (int q = 0; x + q < x1; ++q) dp[q] = sp[q];
+      }
+    }
+    // (b) their mirror images in the border: mirror rows x (owned + mirror columns), owned rows x mirror columns
+    const int mx = s_mcnt[k][0], my = s_mcnt[k][1];
+    const int wide = nx + mx;
+    for (int i = tid; i < my * wide; i += PYR_NT) {
+      const int e = i / wide, c = i - e * wide;
+      const int py = s_mdst[k][1][e], sy = s_msrc[k][1][e];
+      const int px = c < nx ? x0 + c : s_mdst[k][0][c - nx], sx = c < nx ? x0 + c : s_msrc[k][0][c - nx];
+      org[(ptrdiff_t)py * Lv.stride + px] = S[(sy - ly) * ssd + (sx - lx)];
+    }
+    for (int i = tid; i < ny * mx; i += PYR_NT) {
+      const int ry = i / mx, e = i - ry * mx;
+      const int y = y0 + ry, px = s_mdst[k][0][e], sx = s_msrc[k][0][e];
+      org[(ptrdiff_t)y * Lv.stride + px] = S[(y - ly) * ssd + (sx - lx)];
+    }
+  }
+}

@@ -15,36 +15,13 @@
 // allocation), row stride a multiple of 64 B so that every row starts on a
 // cache-line boundary and tile rows can be fetched with aligned dword loads.
 //
-// Both kernels are HBM/L2 streaming kernels: one thread produces 4 horizontally
-// adjacent bytes and stores one dword; consecutive lanes store consecutive
-// dwords (256 B per wave-instruction).
+// Round 5: one launch per pyramid — pyr_build_kernel (pyr_tile.hpp) stages a base-level region
+// in LDS and produces its tile of EVERY level, border included; the per-level kernels of rounds
+// 1-4 (pad_level0_kernel, pyr_down_kernel: five dependent launches per pair) are gone. The
+// rectifying ingestion keeps its own level-0 kernel (remap_level0_kernel) in front of it.
 #include "vo_internal.hpp"
 #include "vo_kernels.hpp"
-
-struct PadArgs {
-  const uint8_t *src[2];
-  uint8_t *dst[2];
-  int w, h, sstride, dstride;
-};
-
-// level 0: copy the source image into the padded plane, REFLECT_101 border.
-__global__ __launch_bounds__(256) void pad_level0_kernel(PadArgs a) {
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;  // dword index within a padded row
-  const int py = blockIdx.y;                            // padded row
-  const int pw = a.w + 2 * VO_PAD;
-  if (q * 4 >= pw) return;
-  const uint8_t *__restrict__ src = a.src[blockIdx.z];
-  uint8_t *__restrict__ dst = a.dst[blockIdx.z];
-  const int y = reflect101_dev(py - VO_PAD, a.h);
-  const uint8_t *srow = src + (size_t)y * a.sstride;
-  uint32_t v = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int x = reflect101_dev(q * 4 + k - VO_PAD, a.w);
-    v |= (uint32_t)srow[x] << (8 * k);
-  }
-  *(uint32_t *)(dst + (size_t)py * a.dstride + q * 4) = v;
-}
+#include "pyr_plan.hpp"
 
 // level 0 of an image that goes through Camera::undistortImage / StereoCamera::rectifyStereoImages first
 // (core/visual_odometry/camera.cpp:166-183, :300-336: convertTo(CV_32FC1), cv::remap with float maps,
@@ -92,60 +69,6 @@ __global__ __launch_bounds__(256) void remap_level0_kernel(RemapArgs a) {
   v |= (uint32_t)__shfl_down(val, 2) << 16;
   v |= (uint32_t)__shfl_down(val, 3) << 24;
   if ((threadIdx.x & 3) == 0 && pxp < pw) *(uint32_t *)(a.dst[z] + (size_t)py * a.dstride + pxp) = v;
-}
-
-// cv::pyrDown (5-tap [1 4 6 4 1]/16 both ways, +128 >> 8) of the padded level
-// l-1 into the whole padded level l. The source border already holds the
-// REFLECT_101 extension, so interior outputs read straight through it; border
-// outputs are the pyrDown value at the reflected coordinate (the same bytes
-// copyMakeBorder would copy), recomputed instead of waiting for the interior.
-struct DownArgs {
-  vo_level S[2], D[2];
-};
-__device__ __forceinline__ int pyr_tap5(const uint8_t *p) {
-  return (int)p[0] + 4 * (int)p[1] + 6 * (int)p[2] + 4 * (int)p[3] + (int)p[4];
-}
-__global__ __launch_bounds__(256) void pyr_down_kernel(DownArgs a) {
-  const vo_level S = a.S[blockIdx.z], D = a.D[blockIdx.z];
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  const int py = blockIdx.y;
-  const int pw = D.w + 2 * VO_PAD;
-  if (q * 4 >= pw) return;
-  const uint8_t *so = S.origin();
-  const int y = reflect101_dev(py - VO_PAD, D.h);
-  uint32_t v = 0;
-  const int px0 = q * 4 - VO_PAD;
-  if (px0 >= 0 && px0 + 3 < D.w) {
-    // interior fast path: 4 outputs share source columns 2*px0-2 .. 2*px0+8
-    int col[11];
-#pragma unroll
-    for (int c = 0; c < 11; ++c) col[c] = 0;
-#pragma unroll
-    for (int r = 0; r < 5; ++r) {
-      const int wgt = (r == 0 || r == 4) ? 1 : ((r == 1 || r == 3) ? 4 : 6);
-      const uint8_t *row = so + (ptrdiff_t)(2 * y + r - 2) * S.stride + (2 * px0 - 2);
-#pragma unroll
-      for (int c = 0; c < 11; ++c) col[c] += wgt * (int)row[c];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int s = col[2 * k] + 4 * col[2 * k + 1] + 6 * col[2 * k + 2] + 4 * col[2 * k + 3] + col[2 * k + 4];
-      v |= (uint32_t)((s + 128) >> 8) << (8 * k);
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int x = reflect101_dev(px0 + k, D.w);
-      int s = 0;
-#pragma unroll
-      for (int r = 0; r < 5; ++r) {
-        const int wgt = (r == 0 || r == 4) ? 1 : ((r == 1 || r == 3) ? 4 : 6);
-        s += wgt * pyr_tap5(so + (ptrdiff_t)(2 * y + r - 2) * S.stride + (2 * x - 2));
-      }
-      v |= (uint32_t)((s + 128) >> 8) << (8 * k);
-    }
-  }
-  *(uint32_t *)(D.base + (size_t)py * D.stride + q * 4) = v;
 }
 
 // effective maxLevel of buildOpticalFlowPyramid
@@ -222,31 +145,15 @@ static int build(vo_ctx *c, int slot_l, const uint8_t *d_l, int slot_r, const ui
     a.dstride = P[0]->lv[0].stride;
     dim3 grid((w + 2 * VO_PAD + 3 + 255) / 256, h + 2 * VO_PAD, nimg);
     hipLaunchKernelGGL(remap_level0_kernel, grid, dim3(256), 0, c->stream, a);
-  } else {
-    PadArgs a;
-    a.src[0] = d_l;
-    a.src[1] = d_r ? d_r : d_l;
-    a.dst[0] = P[0]->lv[0].base;
-    a.dst[1] = d_r ? P[1]->lv[0].base : P[0]->lv[0].base;
-    a.w = w;
-    a.h = h;
-    a.sstride = stride;
-    a.dstride = P[0]->lv[0].stride;
-    dim3 grid(((w + 2 * VO_PAD + 3) / 4 + 255) / 256, h + 2 * VO_PAD, nimg);
-    hipLaunchKernelGGL(pad_level0_kernel, grid, dim3(256), 0, c->stream, a);
   }
-  int nl = 1;
-  for (int l = 1; l <= top && l < VO_MAX_LEVELS; ++l) {
-    DownArgs a;
-    a.S[0] = P[0]->lv[l - 1];
-    a.D[0] = P[0]->lv[l];
-    a.S[1] = d_r ? P[1]->lv[l - 1] : a.S[0];
-    a.D[1] = d_r ? P[1]->lv[l] : a.D[0];
-    if (a.S[0].w < 2 || a.S[0].h < 2) break;
-    dim3 grid(((a.D[0].w + 2 * VO_PAD + 3) / 4 + 255) / 256, a.D[0].h + 2 * VO_PAD, nimg);
-    hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(256), 0, c->stream, a);
-    ++nl;
-  }
+  // every level (and, unless the remap wrote it, level 0 with its border) by ONE launch per PYR_NL_MAX levels
+  vo_level L[2][VO_MAX_LEVELS];
+  for (int i = 0; i < nimg; ++i) memcpy(L[i], P[i]->lv, sizeof(L[i]));
+  const uint8_t *src[2] = {d_l, d_r ? d_r : d_l};
+  hipStream_t st = c->stream;
+  const int nl = pyr_plan_and_launch(L, nimg, src, stride, top, cams != nullptr, [&](const PyrTileArgs &a, int groups) {
+    hipLaunchKernelGGL(pyr_build_kernel, dim3(groups, 1, nimg), dim3(PYR_NT), 0, st, a);
+  });
   vo_prof_end(c);
   for (int i = 0; i < nimg; ++i) P[i]->n_levels = nl;
   VO_CHECK_HIP(c, hipGetLastError());

@@ -11,16 +11,8 @@
 
 #include "../../include/vo_hip.h"
 
-#define VO_PAD 40          // border (pixels) around every pyramid level: >= winSize + tile halo + 4-byte alignment slack (winSize <= 31)
-#define VO_MAX_LEVELS 10
+#include "vo_layout.hpp"   // VO_PAD, VO_MAX_LEVELS, vo_level, vo_reflect101
 #define VO_WAVE 64
-
-struct vo_level {
-  uint8_t *base;   // start of the padded allocation
-  int w, h;        // image size at this level
-  int stride;      // bytes per padded row (multiple of 64)
-  __host__ __device__ const uint8_t *origin() const { return base + (size_t)VO_PAD * stride + VO_PAD; }
-};
 
 struct vo_pyramid {
   vo_level lv[VO_MAX_LEVELS];
@@ -356,10 +348,6 @@ __device__ __forceinline__ float wave_sum_i32_to_f32(int v) {
   return (float)((double)shi * 65536.0 + (double)slo);
 }
 
-__device__ __forceinline__ int reflect101_dev(int p, int n) {
-  if (n == 1) return 0;
-  while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
-  return p;
-}
+__device__ __forceinline__ int reflect101_dev(int p, int n) { return vo_reflect101(p, n); }
 #endif  // __HIPCC__
 

@@ -1,0 +1,23 @@
+// vo_layout.hpp — the padded pyramid-level layout and the REFLECT_101 index map, shared by every kernel file and — as
+// plain C++ — by the CPU emulation harness of the tile kernels (tests/emu/). No HIP header is needed to read this file;
+// `__host__` / `__device__` are the includer's (hip_runtime.h, or empty in the harness).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#define VO_PAD 40          // border (pixels) around every pyramid level: >= winSize + tile halo + 4-byte alignment slack (winSize <= 31)
+#define VO_MAX_LEVELS 10
+
+struct vo_level {
+  uint8_t *base;   // start of the padded allocation
+  int w, h;        // image size at this level
+  int stride;      // bytes per padded row (multiple of 64)
+  __host__ __device__ const uint8_t *origin() const { return base + (size_t)VO_PAD * stride + VO_PAD; }
+};
+
+// cv::BORDER_REFLECT_101 (gfedcb|abcdefgh|gfedcba), any distance
+__host__ __device__ inline int vo_reflect101(int p, int n) {
+  if (n == 1) return 0;
+  while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
+  return p;
+}
