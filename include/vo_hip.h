@@ -326,10 +326,12 @@ int vo_stereo_frame_recoveries(const vo_ctx *ctx);
  *   VO_OPT_POLL_YIELD     != 0: the result polls (a pinned word written last by the frame's BA launch / the local BA) give the
  *                         CPU up between looks (sched_yield) instead of spinning — for hosts where the ranks or streams
  *                         outnumber the idle cores (8 ranks on a few cores: a spinning rank keeps another one's launches waiting)
+ *   VO_DBG_STAGED_DETECT  != 0: the per-bin candidate table of the closed step [10] by the per-stage detector kernels (19
+ *                         launches) instead of the two tile kernels — the same table, bit for bit (tests compare the two)
  *   VO_DBG_MVO_HOST_ADVANCE != 0: MonoVO launches a frame's advance step (the next track set) from vo_mvo_result, behind the
  *                         frame's result, instead of chaining it behind the BA launch in vo_mvo_enqueue (measurement) */
 enum { VO_DBG_FAIL_JOIN = 0, VO_DBG_CONC_GRID = 1, VO_DBG_SBA_LDS_SOLVE = 2, VO_DBG_SKIP_DETECT = 3, VO_OPT_POLL_YIELD = 4,
-       VO_DBG_MVO_HOST_ADVANCE = 5, VO_DBG_COUNT = 8 };
+       VO_DBG_MVO_HOST_ADVANCE = 5, VO_DBG_STAGED_DETECT = 6, VO_DBG_COUNT = 8 };
 int vo_debug_set(vo_ctx *ctx, int key, int value);
 /* Device and pinned-host allocations made on behalf of this context so far (vo_create included). A steady-state frame —
  * keyframes and their local BA included — makes none: tests/test_stereo_vo_gpu.py asserts it. */

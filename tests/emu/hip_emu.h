@@ -92,3 +92,15 @@ static void emu_launch(Kernel k, dim3 grid, dim3 block, Args... args) {
   pthread_barrier_destroy(&emu_block_barrier);
   for (unsigned w = 0; w < (nt + 63) / 64; ++w) pthread_barrier_destroy(&emu_wave_barrier[w]);
 }
+
+// ---- what csrc/orb_device.hpp / orb_tile.hpp ask their includer for -----------------------------------------------------
+#include <math.h>
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+static inline int orb_wave_sum(int v) { return emu_wave_sum_i32(v); }
+static uint8_t emu_dyn_lds[160 * 1024] __attribute__((aligned(16)));
+#define ORB_DYN_LDS(name) uint8_t *name = emu_dyn_lds
+#define ORB_LD_AGENT(p) __atomic_load_n((p), __ATOMIC_SEQ_CST)
+#define ORB_ST_AGENT(p, v) __atomic_store_n((p), (v), __ATOMIC_SEQ_CST)
+#define ORB_ATOMIC_INC_AGENT(p) __atomic_fetch_add((p), 1, __ATOMIC_SEQ_CST)
+#define ORB_FENCE_RELEASE() __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#define ORB_FENCE_ACQUIRE() __atomic_thread_fence(__ATOMIC_SEQ_CST)

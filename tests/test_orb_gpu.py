@@ -93,3 +93,70 @@ def test_orb_detect_other_shapes(vo, oracle):
             assert e.code == -8
     finally:
         c.close()
+
+
+def _table(ctx, vo, oracle, img, thr, nbu, nbv, check_oracle=True, **orb):
+    """The per-bin candidate table of the closed step [10] (vo_new_point_candidates_enqueue) by the two tile kernels
+    (orb_tile.hpp) and by the per-stage kernels (VO_DBG_STAGED_DETECT): both against the oracle's detection + arg-max per bin
+    with every weight 1, and against each other."""
+    fe = vo.FeatureExtractor(ctx)
+    fe.initParams(img.shape[1], img.shape[0], nbu, nbv, THRES_FAST=thr)
+    for k, v in orb.items():
+        setattr(fe.orb, k, v)
+    fe._bin_params = None
+    ctx.set_image(0, img)
+    out = []
+    for staged in (0, 1, 0):  # (the tile kernels again behind the per-stage ones: they find the counters as those left them)
+        ctx.debug_set(ctx.DBG_STAGED_DETECT, staged)
+        try:
+            fe.enqueueCandidates(0, staged)
+            out.append(fe.getCandidates(staged))
+        finally:
+            ctx.debug_set(ctx.DBG_STAGED_DETECT, 0)
+    fe.enqueueCandidates(0, 0)  # and once more: the tile kernels leave their counters and keys zeroed
+    out.append(fe.getCandidates(0))
+    for xy, has, nd in out[1:]:
+        assert nd == out[0][2] and np.array_equal(has, out[0][1]) and np.array_equal(xy.view(np.uint32), out[0][0].view(np.uint32))
+    if check_oracle:
+        d = oracle.orb_detect(img, thr, nfeatures=fe.orb.nfeatures, scale_factor=fe.orb.scale_factor, n_levels=fe.orb.n_levels,
+                              edge_threshold=fe.orb.edge_threshold, max_kp=400000)
+        cand, _ = oracle.bucket_argmax(d["xy"], d["response"], fe.inv_u_step_, fe.inv_v_step_, nbu, nbv, np.ones(nbu * nbv, np.int32))
+        xy, has, nd = out[0]
+        assert nd == d["xy"].shape[0]
+        assert int(has.sum()) == cand.shape[0] and np.array_equal(xy[has].view(np.uint32), cand.view(np.uint32))
+        assert np.all(xy[~has] == 0)
+    return out[0]
+
+
+def test_candidate_table_by_tile_kernels_kitti_shape(ctx, vo, oracle):
+    img = _frame(4)
+    xy, has, nd = _table(ctx, vo, oracle, img, 15, 60, 25)
+    assert nd > 5000 and has.sum() > 500
+    _table(ctx, vo, oracle, _frame(9), 7, 60, 25, nfeatures=600)       # both retainBest cuts bite; 16 candidates per lane
+    _table(ctx, vo, oracle, img, 40, 20, 12)                           # few corners, no cut
+    _table(ctx, vo, oracle, img, 10, 20, 12, nfeatures=0)              # nothing may come out
+    _table(ctx, vo, oracle, img, 12, 20, 12, n_levels=3, scale_factor=1.5, edge_threshold=16)
+    _table(ctx, vo, oracle, img, 12, 20, 12, n_levels=12, scale_factor=1.1)
+
+
+def test_candidate_table_by_tile_kernels_other_shapes(vo, oracle):
+    c = vo.Context(device=0, max_width=752, max_height=480, max_points=2048, n_slots=2, max_level=4)
+    try:
+        _table(c, vo, oracle, _frame(5, 752, 480), 20, 40, 25)
+        xy, has, nd = _table(c, vo, oracle, np.full((480, 752), 90, np.uint8), 20, 20, 12)
+        assert nd == 0 and not has.any()
+        rng = np.random.default_rng(0)  # white noise: levels of more than 16 384 candidates (histogram + radix select inside orb_finish_kernel)
+        noise = rng.integers(0, 256, (480, 752), dtype=np.uint8)
+        _table(c, vo, oracle, noise, 20, 40, 25)
+        _table(c, vo, oracle, _frame(3, 620, 188), 15, 30, 12)
+        _table(c, vo, oracle, _frame(3, 333, 251), 15, 10, 8)
+    finally:
+        c.close()
+
+
+def test_candidate_table_by_tile_kernels_4k(ctx5, vo, oracle):
+    """3840 x 2160 (BASELINE configs[4]): 5440 workgroups of the tile kernel, level lists of several ten thousand candidates."""
+    st = S.StereoStream(width=3840, height=2160, K=(718.856 * 3.0, 718.856 * 3.0, 1920.0, 1080.0), n_u=100, n_v=80, seed=2)
+    img = st.render_pair(st.poses(1)[0])[0]
+    xy, has, nd = _table(ctx5, vo, oracle, img, 15, 100, 80)
+    assert has.sum() > 3000

@@ -61,3 +61,67 @@ def test_pyramid_tile_kernel_every_padded_byte(oracle, emu_pyr, tmp_path, w, h, 
             ys = np.array([_reflect(p - PAD, lh) for p in range(lh + 2 * PAD)])
             xs = np.array([_reflect(p - PAD, lw) for p in range(lw + 2 * PAD)])
             assert np.array_equal(plane[:, :lw + 2 * PAD], ref[l][ys][:, xs]), (i, l)
+
+
+@pytest.fixture(scope="module")
+def emu_orb(tmp_path_factory):
+    return _compile(tmp_path_factory, "emu_orb")
+
+
+def _frame(seed, w, h):
+    from visual_odometry_ros_amd import synthetic as S
+    st = S.StereoStream(width=w, height=h, n_u=8, n_v=4, n_new=8, seed=seed)
+    return st.render_pair(st.poses(1)[0])[0]
+
+
+def _noise(w, h):
+    return np.random.default_rng(0).integers(0, 256, (h, w), dtype=np.uint8)
+
+
+ORB_CASES = [  # image, FAST threshold, bins, ORB overrides, tile
+    (lambda: _frame(4, 1241, 376), 15, (60, 25), {}, None),
+    (lambda: _frame(9, 1241, 376), 7, (60, 25), dict(nfeatures=600), None),      # both cuts bite; 16 candidates per lane
+    (lambda: _frame(4, 1241, 376), 10, (20, 12), dict(nfeatures=0), None),
+    (lambda: _frame(4, 1241, 376), 12, (20, 12), dict(n_levels=3, scale_factor=1.5, edge_threshold=16), None),
+    (lambda: _frame(5, 752, 480), 20, (40, 25), {}, None),
+    (lambda: np.full((480, 752), 90, np.uint8), 20, (20, 12), {}, None),
+    (lambda: _noise(752, 480), 20, (40, 25), {}, None),                          # levels beyond 16 384 candidates
+    (lambda: _frame(3, 640, 240), 15, (20, 8), {}, (64, 48)),                     # another tile size
+]
+
+
+@pytest.mark.parametrize("case", range(len(ORB_CASES)))
+def test_orb_tile_kernels_table(oracle, emu_orb, tmp_path, case):
+    """orb_tile_kernel + orb_finish_kernel (the per-bin candidate table of the closed step [10] in two launches): keypoint
+    count, which bins hold a keypoint and the pixel of each bin's best keypoint against cv::ORB::detect restated
+    (oracle_orb.c) + the arg-max per bin of extractORBwithBinning_fast; the counters and keys are left zeroed."""
+    import struct
+    make, thr, (nbu, nbv), orb, tile = ORB_CASES[case]
+    img = make()
+    h, w = img.shape
+    prm = dict(nfeatures=10000, scale_factor=1.2, n_levels=8, edge_threshold=31)
+    prm.update(orb)
+    f = np.float32
+    iu = f(1.0) / f(int(np.floor(f(w) / f(nbu))))  # FeatureExtractor::initParams (feature_extractor.cpp:30-57)
+    iv = f(1.0) / f(int(np.floor(f(h) / f(nbv))))
+    fin, fout = tmp_path / "in.raw", tmp_path / "out.bin"
+    fin.write_bytes(img.tobytes())
+    args = [emu_orb, str(w), str(h), str(prm["n_levels"]), repr(prm["scale_factor"]), str(prm["nfeatures"]), str(prm["edge_threshold"]),
+            str(thr), str(nbu), str(nbv), "%08x" % iu.view(np.uint32), "%08x" % iv.view(np.uint32), str(fin), str(fout)]
+    if tile:
+        args += [str(tile[0]), str(tile[1])]
+    subprocess.check_call(args)
+    raw = fout.read_bytes()
+    assert struct.unpack_from("i", raw, 0)[0] == 1  # the plan fits
+    flags, n_det, dirty, nx, ny, lds, nb, cap = struct.unpack_from("8i", raw, 4)
+    off = 36
+    xy = np.frombuffer(raw, np.float32, 2 * nb, off).reshape(nb, 2)
+    off += 8 * nb
+    has = np.frombuffer(raw, np.uint8, nb, off)
+    d = oracle.orb_detect(img, thr, nfeatures=prm["nfeatures"], scale_factor=prm["scale_factor"], n_levels=prm["n_levels"],
+                          edge_threshold=prm["edge_threshold"], max_kp=400000)
+    cand, _ = oracle.bucket_argmax(d["xy"], d["response"], iu, iv, nbu, nbv, np.ones(nbu * nbv, np.int32))
+    assert (flags, dirty) == (0, 0) and lds <= 64 * 1024
+    assert n_det == d["xy"].shape[0]
+    assert set(np.unique(has).tolist()) <= {0, 1} and int(has.sum()) == cand.shape[0]
+    assert np.array_equal(xy[has == 1].view(np.uint32), cand.view(np.uint32)) and np.all(xy[has == 0] == 0)

@@ -59,13 +59,13 @@ class Context:
         self.debug_switches = {}
         if os.environ.get("VO_TEST_SWITCHES") == "1":
             for key, name in ((0, "VO_DEBUG_FAIL_JOIN"), (1, "VO_CONC_GRID"), (2, "VO_SBA_LDS_SOLVE"), (3, "VO_DEBUG_SKIP_DETECT"),
-                              (5, "VO_MVO_HOST_ADVANCE")):
+                              (5, "VO_MVO_HOST_ADVANCE"), (6, "VO_STAGED_DETECT")):
                 v = os.environ.get(name)
                 if v:
                     self.debug_set(key, int(v) if v.lstrip("-").isdigit() else 1)
                     self.debug_switches[name] = v
 
-    DBG_FAIL_JOIN, DBG_CONC_GRID, DBG_SBA_LDS_SOLVE, DBG_SKIP_DETECT, OPT_POLL_YIELD, DBG_MVO_HOST_ADVANCE = 0, 1, 2, 3, 4, 5
+    DBG_FAIL_JOIN, DBG_CONC_GRID, DBG_SBA_LDS_SOLVE, DBG_SKIP_DETECT, OPT_POLL_YIELD, DBG_MVO_HOST_ADVANCE, DBG_STAGED_DETECT = 0, 1, 2, 3, 4, 5, 6
 
     def debug_set(self, key, value):
         self.check(self.lib.vo_debug_set(self._h, int(key), int(value)))

@@ -29,34 +29,15 @@
 #include "vo_kernels.hpp"
 #include "frame_state.hpp"
 
-#define ORB_MAX_LEVELS 12
-
-struct OrbLevel {
-  const uint8_t *img;  // level image
-  int w, h, stride;
-  uint8_t *score;      // w x h
-  int *row_count;      // h
-  int *row_off;        // h
-  int cand_base;       // first candidate slot of the level
-  int quota;           // n_l
-  float scale;
-};
-struct OrbDev {
-  int n_levels, edge, fast_thr, cand_cap;
-  OrbLevel L[ORB_MAX_LEVELS];
-  int *hist;        // n_levels x 256
-  int *lvl_total;   // n_levels: candidates after NMS + border
-  int *lvl_cut;     // n_levels: FAST score cut
-  unsigned *lvl_rcut;  // n_levels: ordered-uint Harris cut (0 = keep all)
-  short *cx, *cy;   // candidate coordinates
-  uint8_t *cs;      // candidate FAST score
-  float *cr;        // candidate Harris response (valid when score >= cut)
-  float *out_xy, *out_resp;
-  int32_t *out_oct;
-  int *out_n;
-  int max_out;
-  int *flags;       // bit 0: candidate capacity exceeded, bit 1: output capacity exceeded
-};
+// what orb_device.hpp / orb_tile.hpp ask their includer for (tests/emu/ provides CPU stand-ins of the same names)
+__device__ __forceinline__ int orb_wave_sum(int v) { return wave_sum_i32(v); }
+#define ORB_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) uint8_t name[]
+#define ORB_LD_AGENT(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define ORB_ST_AGENT(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define ORB_ATOMIC_INC_AGENT(p) __hip_atomic_fetch_add((p), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define ORB_FENCE_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+#define ORB_FENCE_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#include "orb_tile.hpp"
 
 // ---- pyramid level: resize INTER_LINEAR_EXACT ------------------------------------------------------
 struct OrbResizeArgs {
@@ -79,65 +60,6 @@ __global__ __launch_bounds__(256) void orb_resize_kernel(OrbResizeArgs a) {
   a.dst[(size_t)y * a.dw + x] = (uint8_t)(r > 255u ? 255u : r);
 }
 
-// ---- FAST-9/16 --------------------------------------------------------------------------------------
-// 0 when the pixel is not a corner; else cornerScore<16>: max over the 16 arcs of 9 contiguous circle pixels of
-// min(v - x) and of min(x - v), floored at the threshold, minus 1
-__device__ __forceinline__ int orb_fast_score(const uint8_t *__restrict__ p, int stride, int t) {
-  const int v = p[0];
-  // the four compass points first (fast.cpp's quick reject): 9 contiguous pixels contain at least two of them
-  const int c0 = v - p[3 * stride], c4 = v - p[3], c8 = v - p[-3 * stride], c12 = v - p[-3];
-  const int nd = (c0 > t) + (c4 > t) + (c8 > t) + (c12 > t), nb = (c0 < -t) + (c4 < -t) + (c8 < -t) + (c12 < -t);
-  if (nd < 2 && nb < 2) return 0;
-  int d[16];
-  d[0] = c0;
-  d[1] = v - p[1 + 3 * stride];
-  d[2] = v - p[2 + 2 * stride];
-  d[3] = v - p[3 + stride];
-  d[4] = c4;
-  d[5] = v - p[3 - stride];
-  d[6] = v - p[2 - 2 * stride];
-  d[7] = v - p[1 - 3 * stride];
-  d[8] = c8;
-  d[9] = v - p[-1 - 3 * stride];
-  d[10] = v - p[-2 - 2 * stride];
-  d[11] = v - p[-3 - stride];
-  d[12] = c12;
-  d[13] = v - p[-3 + stride];
-  d[14] = v - p[-2 + 2 * stride];
-  d[15] = v - p[-1 + 3 * stride];
-  // min / max over every arc of 9 by doubling: windows of 2, 4, 8 (cyclic), then one more element
-  int lo[16], hi[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int e = d[(k + 1) & 15];
-    lo[k] = d[k] < e ? d[k] : e;
-    hi[k] = d[k] > e ? d[k] : e;
-  }
-  int lo4[16], hi4[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    lo4[k] = lo[k] < lo[(k + 2) & 15] ? lo[k] : lo[(k + 2) & 15];
-    hi4[k] = hi[k] > hi[(k + 2) & 15] ? hi[k] : hi[(k + 2) & 15];
-  }
-  int best_lo = -1000, best_hi = 1000;  // max over arcs of min(d) ; min over arcs of max(d)
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    int mn = lo4[k] < lo4[(k + 4) & 15] ? lo4[k] : lo4[(k + 4) & 15];  // d[k .. k+7]
-    int mx = hi4[k] > hi4[(k + 4) & 15] ? hi4[k] : hi4[(k + 4) & 15];
-    const int e = d[(k + 8) & 15];
-    mn = mn < e ? mn : e;
-    mx = mx > e ? mx : e;
-    best_lo = best_lo > mn ? best_lo : mn;
-    best_hi = best_hi < mx ? best_hi : mx;
-  }
-  // corner iff some arc is entirely > t (best_lo > t) or entirely < -t (best_hi < -t)
-  if (!(best_lo > t || best_hi < -t)) return 0;
-  int a0 = t;
-  a0 = a0 > best_lo ? a0 : best_lo;
-  int b0 = -a0;
-  b0 = b0 < best_hi ? b0 : best_hi;
-  return -b0 - 1;
-}
 __global__ __launch_bounds__(256) void orb_score_kernel(OrbDev d) {
   const OrbLevel &L = d.L[blockIdx.z];
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
@@ -145,14 +67,6 @@ __global__ __launch_bounds__(256) void orb_score_kernel(OrbDev d) {
   int s = 0;
   if (x >= 3 && x < L.w - 3 && y >= 3 && y < L.h - 3) s = orb_fast_score(L.img + (size_t)y * L.stride + x, L.stride, d.fast_thr);
   L.score[(size_t)y * L.w + x] = (uint8_t)s;
-}
-
-// strictly greater than the 8 neighbours' scores (FAST_t's non-max suppression); x, y at least 1 from the edge
-__device__ __forceinline__ int orb_is_max(const uint8_t *__restrict__ s, int w, int x, int y) {
-  const uint8_t *p = s + (size_t)y * w + x;
-  const int c = p[0];
-  if (!c) return 0;
-  return c > p[-1] && c > p[1] && c > p[-w - 1] && c > p[-w] && c > p[-w + 1] && c > p[w - 1] && c > p[w] && c > p[w + 1];
 }
 
 // rows inside the border: blockIdx.x = row - edge, blockIdx.z = level
@@ -203,32 +117,6 @@ __global__ __launch_bounds__(256) void orb_plan_kernel(OrbDev d) {
   }
 }
 
-// HarrisResponses (orb.cpp), blockSize 7, k = 0.04. The 9x9 neighbourhood is read once (81 byte loads instead of
-// 8 per tap); the sums are integers, so the order does not matter.
-__device__ __forceinline__ float orb_harris(const uint8_t *__restrict__ img, int stride, int x0, int y0) {
-  int px[9][9];
-#pragma unroll
-  for (int r = 0; r < 9; ++r) {
-    const uint8_t *p = img + (size_t)(y0 - 4 + r) * stride + (x0 - 4);
-#pragma unroll
-    for (int q = 0; q < 9; ++q) px[r][q] = p[q];
-  }
-  int a = 0, b = 0, c = 0;
-#pragma unroll
-  for (int r = 1; r < 8; ++r)
-#pragma unroll
-    for (int q = 1; q < 8; ++q) {
-      const int Ix = (px[r][q + 1] - px[r][q - 1]) * 2 + (px[r - 1][q + 1] - px[r - 1][q - 1]) + (px[r + 1][q + 1] - px[r + 1][q - 1]);
-      const int Iy = (px[r + 1][q] - px[r - 1][q]) * 2 + (px[r + 1][q - 1] - px[r - 1][q - 1]) + (px[r + 1][q + 1] - px[r - 1][q + 1]);
-      a += Ix * Ix;
-      b += Iy * Iy;
-      c += Ix * Iy;
-    }
-  const float scale = 1.f / ((1 << 2) * 7 * 255.f);
-  const float scale_sq_sq = scale * scale * scale * scale;
-  return ((float)a * b - (float)c * c - 0.04f * ((float)a + b) * ((float)a + b)) * scale_sq_sq;
-}
-
 __global__ __launch_bounds__(64) void orb_emit_kernel(OrbDev d) {
   const int l = blockIdx.z;
   const OrbLevel &L = d.L[l];
@@ -262,100 +150,43 @@ __global__ __launch_bounds__(256) void orb_harris_kernel(OrbDev d) {
   d.cr[o] = orb_harris(L.img, L.stride, d.cx[o], d.cy[o]);
 }
 
-// float -> unsigned that orders the same way (NaN aside)
-__device__ __forceinline__ unsigned orb_ord(float r) {
-  const unsigned bits = __float_as_uint(r);
-  return (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
-}
-// rank-th largest bin of a 256-bin histogram in LDS: returns the bin, *above = entries in higher bins
-__device__ __forceinline__ int orb_hist_rank(const int *hist, int rank, int *above) {
-  int acc = 0, b = 255;
-  for (; b > 0; --b) {
-    if (acc + hist[b] >= rank) break;
-    acc += hist[b];
-  }
-  *above = acc;
-  return b;
-}
 // per level: the two retainBest cuts. (1) FAST score: nothing is dropped unless there are more than 2 n_l
 // candidates, else everything >= the score of rank 2 n_l stays; (2) Harris response among those: everything >= the
-// response of rank n_l (4-pass radix select on the ordered key). Also the number of survivors.
-#define ORB_ST 1024
-#define ORB_RC 16  // candidates per lane that the fast path of orb_select_kernel keeps in registers
+// response of rank n_l. Also the number of survivors. Levels of up to 16 384 candidates (every level of a KITTI-sized
+// image): orb_select_regs (orb_device.hpp), the candidates in registers; beyond that an LDS histogram and a 4-pass radix
+// select on the ordered key.
+template <int NQ>
+__device__ __forceinline__ void orb_select_fast(const OrbDev &d, int l, int n, OrbSelShared *S) {
+  const OrbLevel &L = d.L[l];
+  unsigned key[NQ];
+  int cut, surv;
+  unsigned rcut;
+  orb_select_regs<NQ>(d.cs + L.cand_base, d.cr + L.cand_base, n, L.quota, S, key, &cut, &rcut, &surv);
+  if (threadIdx.x == 0) {
+    d.lvl_cut[l] = cut;
+    d.lvl_rcut[l] = rcut;
+    d.hist[l] = surv;
+  }
+}
 __global__ __launch_bounds__(ORB_ST) void orb_select_kernel(OrbDev d) {
   __shared__ int s_hist[256];
   __shared__ unsigned s_prefix;
   __shared__ int s_rank, s_cut, s_kept, s_surv;
+  __shared__ OrbSelShared s_sel;
   const int l = blockIdx.x, tid = threadIdx.x;
   const OrbLevel &L = d.L[l];
   const int n = d.lvl_total[l] > d.cand_cap ? 0 : d.lvl_total[l];
   const uint8_t *cs = d.cs + L.cand_base;
   const float *cr = d.cr + L.cand_base;
   if (n <= ORB_RC * ORB_ST) {
-    // Fast path (every level of a KITTI-sized image): the candidates of a lane live in registers, and both cuts are
-    // found by bisection on the value — count(x >= t) over the workgroup per step, no atomics, no histogram contention
-    // (scores cluster in a few bins, responses share their leading byte).
-    __shared__ int s_part[ORB_ST / 64];
-    const int lane = tid & 63, wave = tid >> 6;
-    unsigned key[ORB_RC];  // score in pass 1, then the ordered response (0 = dropped by the score cut)
-    float resp[ORB_RC];
-#pragma unroll
-    for (int q = 0; q < ORB_RC; ++q) {
-      const int i = tid + q * ORB_ST;
-      key[q] = i < n ? (unsigned)cs[i] + 1u : 0u;  // 0 = no candidate
-      resp[q] = i < n ? cr[i] : 0.f;
-    }
-    auto count_ge = [&](unsigned t) {
-      int c = 0;
-#pragma unroll
-      for (int q = 0; q < ORB_RC; ++q) c += key[q] >= t;
-      c = wave_sum_i32(c);
-      __syncthreads();  // s_part of the previous step has been consumed
-      if (lane == 0) s_part[wave] = c;
-      __syncthreads();
-      int tot = 0;
-#pragma unroll
-      for (int w = 0; w < ORB_ST / 64; ++w) tot += s_part[w];
-      return tot;
-    };
-    // (1) retainBest(2 n_l) on the FAST score
-    int cut = 0;
-    const int keep = 2 * L.quota;
-    if (n > keep) {
-      if (keep == 0) {
-        cut = 256;
-      } else {
-        unsigned t = 0;  // largest t with count(score + 1 >= t) >= keep
-        for (int bit = 8; bit >= 0; --bit) {
-          const unsigned cand = t | (1u << bit);
-          if (count_ge(cand) >= keep) t = cand;
-        }
-        cut = (int)t - 1;
-      }
-    }
-    // (2) retainBest(n_l) on the Harris response of what is left
-#pragma unroll
-    for (int q = 0; q < ORB_RC; ++q) key[q] = (key[q] != 0u && (int)key[q] - 1 >= cut) ? orb_ord(resp[q]) : 0u;
-    const int kept = count_ge(1u);
-    unsigned rcut = 0u;
-    if (kept > L.quota) {
-      if (L.quota == 0) {
-        rcut = 0xFFFFFFFFu;
-      } else {
-        unsigned t = 0;
-        for (int bit = 31; bit >= 0; --bit) {
-          const unsigned cand = t | (1u << bit);
-          if (count_ge(cand) >= L.quota) t = cand;
-        }
-        rcut = t;
-      }
-    }
-    const int surv = rcut == 0u ? kept : (rcut == 0xFFFFFFFFu ? count_ge(0xFFFFFFFFu) : count_ge(rcut));
-    if (tid == 0) {
-      d.lvl_cut[l] = cut;
-      d.lvl_rcut[l] = rcut;
-      d.hist[l] = surv;
-    }
+    if (n <= 2 * ORB_ST)
+      orb_select_fast<2>(d, l, n, &s_sel);
+    else if (n <= 4 * ORB_ST)
+      orb_select_fast<4>(d, l, n, &s_sel);
+    else if (n <= 8 * ORB_ST)
+      orb_select_fast<8>(d, l, n, &s_sel);
+    else
+      orb_select_fast<ORB_RC>(d, l, n, &s_sel);
     return;
   }
   if (tid < 256) s_hist[tid] = 0;
@@ -502,6 +333,10 @@ struct vo_orb_state {
   int pending_bins = 0;
   bool pending = false;
   vo_cand_table tab[2];  // closed step [10]: double-buffered so that frame k reads one while the detection of k+1 fills the other
+  // the tile kernels of the per-bin table (orb_tile.hpp): plan of the current configuration, its tables in the arena
+  OrbTilePlan plan;
+  size_t o_gx = 0, o_gy = 0, o_tx[ORB_MAX_LEVELS] = {0}, o_ty[ORB_MAX_LEVELS] = {0}, o_surv = 0, o_done = 0, o_devflags = 0;
+  bool tile_clean = false;  // lvl_total / done / keys are zero (the tile kernels leave them so; the per-stage kernels do not)
 };
 
 void vo_orb_free(vo_ctx *c) {
@@ -521,27 +356,6 @@ void vo_orb_free(vo_ctx *c) {
   }
 }
 
-// resize.cpp interpolationLinear<uchar>::getCoeffs on softdouble (= IEEE double, one rounding per operation)
-static void orb_linear_exact_coeffs(int src_size, int dst_size, std::vector<int> &ofs, std::vector<int> &c1) {
-  // interpolationLinear(inv_scale, ..): scale = softdouble::one() / softdouble(inv_scale), inv_scale = dst / src
-  const double scale = 1.0 / ((double)dst_size / (double)src_size);
-  ofs.assign(dst_size, 0);
-  c1.assign(dst_size, 0);
-  for (int v = 0; v < dst_size; ++v) {
-    const double fval = scale * ((double)v + 0.5) - 0.5;
-    const int ival = (int)std::floor(fval);
-    if (ival >= 0 && src_size > 1) {
-      if (ival < src_size - 1) {
-        ofs[v] = ival;
-        c1[v] = (int)std::lrint((fval - (double)ival) * 256.0);
-      } else {  // the last source sample with full weight, written so that the kernel never reads past the row
-        ofs[v] = src_size - 2;
-        c1[v] = 256;
-      }
-    }  // else: the first source sample with full weight (ofs 0, c1 0)
-  }
-}
-
 static int orb_prepare(vo_ctx *c, int w, int h, const vo_orb_params *p, int max_bins) {
   if (!c->orb) c->orb = new vo_orb_state();
   vo_orb_state *S = c->orb;
@@ -556,24 +370,9 @@ static int orb_prepare(vo_ctx *c, int w, int h, const vo_orb_params *p, int max_
   S->scale_factor = p->scale_factor;
   S->max_bins = max_bins;
   // ORB_Impl::detectAndCompute level sizes and computeKeyPoints quotas (orb.cpp)
-  for (int l = 0; l < p->n_levels; ++l) {
-    const float s = (float)std::pow(p->scale_factor, (double)l);
-    S->lscale[l] = s;
-    S->lw[l] = (int)std::lrint((double)((float)w / s));
-    S->lh[l] = (int)std::lrint((double)((float)h / s));
+  orb_level_layout(w, h, p->n_levels, p->scale_factor, p->nfeatures, S->lw, S->lh, S->lscale, S->quota);
+  for (int l = 0; l < p->n_levels; ++l)
     if (S->lw[l] < 8 || S->lh[l] < 8) VO_FAIL(c, VO_ERR_INVALID, "ORB level %d of a %dx%d image is too small", l, w, h);
-  }
-  {
-    const float factor = (float)(1.0 / p->scale_factor);
-    float nd = p->nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)p->n_levels));
-    int sum = 0;
-    for (int l = 0; l < p->n_levels - 1; ++l) {
-      S->quota[l] = (int)std::lrint((double)nd);
-      sum += S->quota[l];
-      nd *= factor;
-    }
-    S->quota[p->n_levels - 1] = p->nfeatures - sum > 0 ? p->nfeatures - sum : 0;
-  }
   // arena
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -618,6 +417,21 @@ static int orb_prepare(vo_ctx *c, int w, int h, const vo_orb_params *p, int max_
   S->o_bidx = take(sizeof(int32_t) * (size_t)(max_bins + 1));
   S->o_bn = take(sizeof(int) * 4);
   S->o_weight = take(sizeof(int32_t) * (size_t)(max_bins + 1));
+  // the tile kernels' plan of this configuration (orb_plan.hpp); 48 x 32 level-0 pixels per workgroup: 312 workgroups at
+  // 1241 x 376, 36 KB of LDS each
+  orb_tile_plan(S->lw, S->lh, p->n_levels, p->edge_threshold, 48, 32, 64 * 1024, &S->plan);
+  if (S->plan.ok) {
+    S->o_gx = take(sizeof(OrbSpan) * S->plan.gx.size());
+    S->o_gy = take(sizeof(OrbSpan) * S->plan.gy.size());
+    for (int l = 1; l < p->n_levels; ++l) {
+      S->o_tx[l] = take(sizeof(int) * S->plan.tabx[l].size());
+      S->o_ty[l] = take(sizeof(int) * S->plan.taby[l].size());
+    }
+    S->o_surv = take(sizeof(int) * ORB_MAX_LEVELS);
+    S->o_done = take(sizeof(int) * 4);
+    S->o_devflags = take(sizeof(int) * 4);
+  }
+  S->tile_clean = false;
   if (off > S->cap) {
     if (S->arena) (void)hipFree(S->arena);
     S->arena = nullptr;
@@ -636,6 +450,98 @@ static int orb_prepare(vo_ctx *c, int w, int h, const vo_orb_params *p, int max_
     VO_CHECK_HIP(c, hipMemcpy(S->arena + S->o_tab[l][2], oy.data(), sizeof(int) * oy.size(), hipMemcpyHostToDevice));
     VO_CHECK_HIP(c, hipMemcpy(S->arena + S->o_tab[l][3], cy.data(), sizeof(int) * cy.size(), hipMemcpyHostToDevice));
   }
+  if (S->plan.ok) {
+    VO_CHECK_HIP(c, hipMemcpy(S->arena + S->o_gx, S->plan.gx.data(), sizeof(OrbSpan) * S->plan.gx.size(), hipMemcpyHostToDevice));
+    VO_CHECK_HIP(c, hipMemcpy(S->arena + S->o_gy, S->plan.gy.data(), sizeof(OrbSpan) * S->plan.gy.size(), hipMemcpyHostToDevice));
+    for (int l = 1; l < p->n_levels; ++l) {
+      VO_CHECK_HIP(c, hipMemcpy(S->arena + S->o_tx[l], S->plan.tabx[l].data(), sizeof(int) * S->plan.tabx[l].size(), hipMemcpyHostToDevice));
+      VO_CHECK_HIP(c, hipMemcpy(S->arena + S->o_ty[l], S->plan.taby[l].data(), sizeof(int) * S->plan.taby[l].size(), hipMemcpyHostToDevice));
+    }
+  }
+  return VO_OK;
+}
+
+// The per-bin candidate table of the image in `slot` by the two tile kernels (orb_tile.hpp), on c->stream. Needs
+// S->plan.ok. Leaves lvl_total / done / keys zeroed, as it needs them.
+static int orb_tile_enqueue(vo_ctx *c, int slot, const vo_bin_params *bp, vo_cand_table &T) {
+  const vo_orb_params *p = &bp->orb;
+  if (slot < 0 || slot >= c->cfg.n_slots || c->slots[slot].n_levels <= 0) VO_FAIL(c, VO_ERR_INVALID, "slot holds no image");
+  const vo_pyramid &P = c->slots[slot];
+  const int total = bp->n_bins_u * bp->n_bins_v;
+  int rc = orb_prepare(c, P.w, P.h, p, total);
+  if (rc) return rc;
+  vo_orb_state *S = c->orb;
+  if (!S->plan.ok) return 1;  // (the caller takes the per-stage kernels)
+  if (vo_slot_acquire(c, slot) < 0) return VO_ERR_HIP;
+  hipStream_t s = c->stream;
+  uint8_t *A = S->arena;
+  if (!S->tile_clean) {  // (once after the per-stage kernels ran on this arena, never in a steady stream)
+    VO_CHECK_HIP(c, hipMemsetAsync(A + S->o_total, 0, sizeof(int) * p->n_levels, s));
+    VO_CHECK_HIP(c, hipMemsetAsync(A + S->o_done, 0, sizeof(int) * 4, s));
+    VO_CHECK_HIP(c, hipMemsetAsync(A + S->o_keys, 0, sizeof(unsigned long long) * (size_t)(S->max_bins + 1), s));
+    S->tile_clean = true;
+  }
+  OrbTileArgs a;
+  memset(&a, 0, sizeof(a));
+  a.img = P.lv[0].origin();
+  a.stride = P.lv[0].stride;
+  a.n_levels = p->n_levels;
+  a.nx = S->plan.nx;
+  a.ny = S->plan.ny;
+  a.fast_thr = p->fast_threshold;
+  a.cand_cap = S->cand_cap_level;
+  a.stash_off = S->plan.stash_off;
+  a.stash_cap = S->plan.stash_cap;
+  a.gx = (const OrbSpan *)(A + S->o_gx);
+  a.gy = (const OrbSpan *)(A + S->o_gy);
+  for (int l = 0; l < p->n_levels; ++l) {
+    OrbTileLevel &L = a.L[l];
+    L.w = S->lw[l];
+    L.h = S->lh[l];
+    L.lds_off = S->plan.lds_off[l];
+    L.lds_stride = S->plan.lds_stride[l];
+    L.sc_off = S->plan.sc_off[l];
+    L.sc_stride = S->plan.sc_stride[l];
+    L.cand_base = l * S->cand_cap_level;
+    L.tabx = l ? (const int *)(A + S->o_tx[l]) : nullptr;
+    L.taby = l ? (const int *)(A + S->o_ty[l]) : nullptr;
+  }
+  a.lvl_total = (int *)(A + S->o_total);
+  a.cx = (short *)(A + S->o_cx);
+  a.cy = (short *)(A + S->o_cy);
+  a.cs = A + S->o_cs;
+  a.cr = (float *)(A + S->o_cr);
+  OrbFinishArgs f;
+  memset(&f, 0, sizeof(f));
+  f.n_levels = p->n_levels;
+  f.cand_cap = S->cand_cap_level;
+  f.max_out = S->max_out;
+  for (int l = 0; l < p->n_levels; ++l) {
+    f.cand_base[l] = l * S->cand_cap_level;
+    f.quota[l] = S->quota[l];
+    f.scale[l] = S->lscale[l];
+  }
+  f.lvl_total = a.lvl_total;
+  f.cx = a.cx;
+  f.cy = a.cy;
+  f.cs = a.cs;
+  f.cr = a.cr;
+  f.surv = (int *)(A + S->o_surv);
+  f.done = (int *)(A + S->o_done);
+  f.key = (unsigned long long *)(A + S->o_keys);
+  f.n_bins_u = bp->n_bins_u;
+  f.n_bins_v = bp->n_bins_v;
+  f.inv_u = bp->inv_u_step;
+  f.inv_v = bp->inv_v_step;
+  f.tab_xy = T.xy;
+  f.tab_has = T.has;
+  f.host_flags = T.h_flags;
+  f.dev_flags = (int *)(A + S->o_devflags);
+  vo_prof_begin(c, VO_K_AUX);
+  hipLaunchKernelGGL(orb_tile_kernel, dim3(a.nx * a.ny), dim3(ORB_TILE_NT), (size_t)S->plan.lds_bytes, s, a);
+  hipLaunchKernelGGL(orb_finish_kernel, dim3(p->n_levels), dim3(ORB_ST), 0, s, f);
+  vo_prof_end(c);
+  VO_CHECK_HIP(c, hipGetLastError());
   return VO_OK;
 }
 
@@ -688,6 +594,7 @@ static int orb_enqueue(vo_ctx *c, int slot, const vo_orb_params *p, int max_bins
   d.max_out = S->max_out;
   // hist .. flags are contiguous in the arena: one memset
   VO_CHECK_HIP(c, hipMemsetAsync(A + S->o_hist, 0, S->o_cx - S->o_hist, s));
+  S->tile_clean = false;  // (level totals and, with the bucketing behind this, the keys are left as they come out)
   vo_prof_begin(c, VO_K_AUX);
   for (int l = 1; l < p->n_levels; ++l) {
     OrbResizeArgs a;
@@ -905,7 +812,24 @@ extern "C" int vo_new_point_candidates_enqueue(vo_ctx *c, int slot, const vo_bin
   }
   hipStream_t caller = c->stream;
   c->stream = c->stream2;  // every launcher below enqueues on ctx->stream
-  int rc = orb_enqueue(c, slot, &bp->orb, total);
+  // two launches (orb_tile.hpp) wherever the configuration fits them — every configuration of the reference does;
+  // VO_DBG_STAGED_DETECT forces the per-stage kernels (19 launches), the same table bit for bit
+  int rc = 1;
+  if (!c->dbg[VO_DBG_STAGED_DETECT]) {
+    rc = orb_tile_enqueue(c, slot, bp, T);
+    if (rc == VO_OK) {
+      hipError_t e = hipEventRecord(T.ready, c->stream);
+      if (e != hipSuccess) {
+        snprintf(c->err, sizeof(c->err), "vo_new_point_candidates_enqueue: %s", hipGetErrorString(e));
+        rc = VO_ERR_HIP;
+      }
+    }
+  }
+  if (rc <= 0) {
+    c->stream = caller;
+    return rc;
+  }
+  rc = orb_enqueue(c, slot, &bp->orb, total);
   if (rc == VO_OK) {
     uint8_t *A = S->arena;
     rc = vo_bucket_table_enqueue(c, (const float *)(A + S->o_oxy), (const float *)(A + S->o_oresp), S->max_out,
