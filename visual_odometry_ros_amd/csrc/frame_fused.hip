@@ -619,8 +619,8 @@ int vo_frame_fused_enqueue(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, 
   // running totals of the two hand-shake counters: what they will read when this frame's share has arrived
   if (phase == 0 && a.strict) {
     if (a.strict == 3 || a.strict == 5) {
-      *b.sync_p1_target += n;    // one count per feature past pass 1
-      *b.sync_done_target += vo_frame_fallback_grid(n);  // one count per workgroup of the fallback kernel
+      vo_wrap_add(*b.sync_p1_target, n);    // one count per feature past pass 1
+      vo_wrap_add(*b.sync_done_target, vo_frame_fallback_grid(n));  // one count per workgroup of the fallback kernel
     }
   }
   const int p1_target = *b.sync_p1_target, done_target = *b.sync_done_target;

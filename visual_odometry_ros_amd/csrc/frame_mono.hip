@@ -439,8 +439,8 @@ static int mono_enqueue_impl(vo_ctx *c, const vo_mono_params *prm, int slot0, in
     const int p1_before = f->sync_p1_target, done_before = f->sync_done_target;
     if (strict == 3) {
       // running totals of the two hand-shake counters, and the frame's epoch (the pass-1 target: different for every frame)
-      f->sync_p1_target += n;
-      f->sync_done_target += fb_grid;
+      vo_wrap_add(f->sync_p1_target, n);
+      vo_wrap_add(f->sync_done_target, fb_grid);
       a.ic.epoch = f->sync_p1_target != 0 ? f->sync_p1_target : 1;
       a.ic.p1_word = f->sync + IC_P1_STRIDE;
       a.ic.p1_target = f->sync_p1_target;

@@ -365,7 +365,7 @@ static int vo_frame_enqueue_body(vo_ctx *c, const vo_stereo_params *prm, int slo
         // iterations from running under the detection)
         if (rcf >= 0) {
           cand_joined = true;
-          f->cand_total += n_new;  // (cumulative, like the word the candidate workgroups count in)
+          vo_wrap_add(f->cand_total, n_new);  // (cumulative, like the word the candidate workgroups count in)
         }
       }
     }
@@ -539,13 +539,13 @@ static int vo_frame_enqueue_body(vo_ctx *c, const vo_stereo_params *prm, int slo
     if (!(fused && tab)) VO_FAIL(c, VO_ERR_INVALID, "the track-set advance needs the closed frame on the fused path");
     adv_workers = (tab->n_bins + 63) / 64;  // one worker wavefront per 64 bins (gn_pose.hip)
     adv_now.dlt_done = f->adv_done;
-    adv_now.dlt_target = f->adv_total + adv_workers;
+    adv_now.dlt_target = (int)((unsigned)f->adv_total + (unsigned)adv_workers);
     gf.adv = &adv_now;
   }
   RC(vo_gn_enqueue(c, true, false, f->C_X, f->C_pl1, f->C_pr1, n, nullptr, prm->Kl, prm->Kr,
                    prm->T_lr, prm->thres_poseba, 0, dT_prior, f->hdr->dT, f->mG, &f->hdr->gn, true,
                    n > 0 ? f->stage : nullptr, f->C_orig, 4, 60.0f, n > 0 ? &gf : nullptr));
-  f->adv_total += adv_workers;  // (cumulative, like the word the workers count in: only a launch that went out counts)
+  vo_wrap_add(f->adv_total, adv_workers);  // (cumulative, like the word the workers count in: only a launch that went out counts)
   if (n_new > 0 && !fused) VO_CHECK_HIP(c, hipStreamWaitEvent(s, c->ev_join, 0));
   VO_TT("gn launch");
   // one D2H of the packed block into pinned memory (general path; the fused path's GN launch did it)

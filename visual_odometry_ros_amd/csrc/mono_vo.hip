@@ -96,8 +96,9 @@ __device__ bool mvo_reconstruct(float p0x, float p0y, float p1x, float p1y, cons
 __global__ __launch_bounds__(1024) void mvo_advance_scan_kernel(MvoAdvArgs a) {
   __shared__ int s_w[16];
   __shared__ int s_kft[16];
-  __shared__ int s_idmin;
+  __shared__ int s_idmin, s_old;
   const int tid = threadIdx.x;
+  if (tid == 0) s_old = 0;
   if (tid < 16) {  // the frame table's entry of this frame (T_wc | T_cw)
     a.frameT[(size_t)(a.f & (MVO_FRAME_RING - 1)) * 32 + tid] = a.T_wc[tid];
     a.frameT[(size_t)(a.f & (MVO_FRAME_RING - 1)) * 32 + 16 + tid] = a.T_cw[tid];
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(1024) void mvo_advance_scan_kernel(MvoAdvArgs a) {
     if (ok) {
       kft += (a.cur.t.flags[k] & VO_LM_KF_MEMBER) ? 1 : 0;
       if (pos == 0) s_idmin = a.cur.t.ids[k];
+      if (a.f - a.cur.f_first[k] >= MVO_FRAME_RING) s_old = 1;  // (as mvo_advance_body)
     }
     base += total;
   }
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(1024) void mvo_advance_scan_kernel(MvoAdvArgs a) {
     h.n_new = base - n_surv;
     h.n_next = base < a.cap ? base : a.cap;
     h.n_kf_tracked = t;
-    h.overflow = base > a.cap ? 1 : 0;
+    h.overflow = (base > a.cap ? 1 : 0) | (s_old ? 2 : 0);
     h.n_recon = 0;
     h.pad = 0;
     h.seq = 0;
@@ -513,6 +515,9 @@ static int mvo_advance_collect(vo_mvo *s, MvoHdr *h) {
   RC(mvo_wait_hdr(s));
   *h = *s->h_hdr;
   if (h->pad) return VO_OK;  // (inside the BA launch of a frame the host has to finish: nothing was built)
+  if (h->overflow & 2)
+    VO_FAIL(c, VO_ERR_CAPACITY, "a landmark has been tracked for %d frames or more: the pose of its first observation has left the frame-pose ring",
+            MVO_FRAME_RING);
   if (h->overflow) VO_FAIL(c, VO_ERR_CAPACITY, "the next track set exceeds vo_config.max_points=%d", s->cap);
   c->next_landmark_id += h->n_new;
   s->cur ^= 1;
@@ -799,8 +804,21 @@ extern "C" int vo_mvo_enqueue(vo_mvo *s, const void *img, int stride, int on_dev
   (void)timestamp;
   if (s->init_done && s->n <= 0) VO_FAIL(c, VO_ERR_GN_FAILED, "the track set is empty");
   if (!(s->prefetched && s->pre == img)) RC(mvo_ingest(s, img, stride, on_device));
-  s->prefetched = false;
+  // from here on the driver's state moves; every error return below puts ALL of it back (slots, tables, the advance step's
+  // sequence number, the prefetch mark — as vo_svo_enqueue does), so that the caller can hand the image over again
   const int keep_slot[3] = {s->slot[0], s->slot[1], s->slot[2]}, keep_tc = s->tab_cur, keep_tn = s->tab_next;
+  const uint32_t keep_seq = s->seq;
+  const bool keep_pre = s->prefetched, keep_chained = s->chained;
+  auto undo = [&](int rc) {
+    memcpy(s->slot, keep_slot, sizeof(keep_slot));
+    s->tab_cur = keep_tc;
+    s->tab_next = keep_tn;
+    s->seq = keep_seq;
+    s->prefetched = keep_pre;
+    s->chained = keep_chained;
+    return rc;
+  };
+  s->prefetched = false;
   {  // previous <- current, current <- the image just ingested, the freed slot takes the next one
     const int p = s->slot[0];
     s->slot[0] = s->slot[1];
@@ -829,15 +847,11 @@ extern "C" int vo_mvo_enqueue(vo_mvo *s, const void *img, int stride, int on_dev
     // the operator's flag byte (bit 0 lm->isBundled(): prior and scale from the 3-D point; bit 1: the class the pose-only BA
     // takes — bundled with more than five window keyframes, triangulated otherwise, mono_vo.cpp:800-826; bit 2: dead,
     // landmark.cpp:251) is read off the track set's flags by the frame kernel itself
-    RC(vo_mono_frame_set_track_flags(c, s->core.keyframes.size() > 5 ? 2 : 1));
-    const int rc = vo_mono_frame_enqueue_closed(c, &s->prm.frame, s->slot[0], s->slot[1], t.t.pts_l, t.t.Xw, t.t.flags, s->n, Tcw_prev,
-                                                Tcw_prior, s->dT01, &s->prm.bins, s->tab_cur, 1);
-    if (rc < 0) {
-      memcpy(s->slot, keep_slot, sizeof(keep_slot));
-      s->tab_cur = keep_tc;
-      s->tab_next = keep_tn;
-      return rc;
-    }
+    int rc = vo_mono_frame_set_track_flags(c, s->core.keyframes.size() > 5 ? 2 : 1);
+    if (rc < 0) return undo(rc);
+    rc = vo_mono_frame_enqueue_closed(c, &s->prm.frame, s->slot[0], s->slot[1], t.t.pts_l, t.t.Xw, t.t.flags, s->n, Tcw_prev, Tcw_prior,
+                                      s->dT01, &s->prm.bins, s->tab_cur, 1);
+    if (rc < 0) return undo(rc);
   }
   s->frame_id = c->next_frame_id;  // Frame(cam, timestamp): id = frame_counter_++ (frame.cpp:22-41)
   c->next_frame_id += 1;
@@ -911,6 +925,9 @@ static int mvo_fallback(vo_mvo *s, float dT01[16], float dT10[16], int *m_new, v
   return VO_OK;
 }
 
+// An error return of vo_mvo_result ENDS THE STREAM, as the reference's throw ends the node (mono_vo.cpp:909-949 "Terminate the
+// algorithm"; include/vo_hip.h says so): the frame is no longer in flight, track set and pose are where the failing step left
+// them, and the next call reports "not in flight". A refused vo_mvo_enqueue, by contrast, leaves everything as it was.
 extern "C" int vo_mvo_result(vo_mvo *s, vo_mvo_frame_info *info) {
   if (!s || !s->pending) return VO_ERR_INVALID;
   vo_ctx *c = s->c;

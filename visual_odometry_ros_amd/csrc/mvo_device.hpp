@@ -155,7 +155,7 @@ __device__ __forceinline__ void mvo_advance_body(const MvoAdvArgs &a, const floa
   __shared__ int s_w[NW];
   __shared__ int s_kft[NW];
   __shared__ float s_T[32];
-  __shared__ int s_idmin;
+  __shared__ int s_idmin, s_old;
   constexpr int NT = NW * 64;
   if (skip) {
     if (tid == 0) {
@@ -174,7 +174,10 @@ __device__ __forceinline__ void mvo_advance_body(const MvoAdvArgs &a, const floa
       for (int k = 1; k < 4; ++k) r = a.T_wp[i * 4 + k] * dT01[k * 4 + j] + r;
       s_T[tid] = r;
     }
-    if (tid == 0) s_idmin = a.id_base;
+    if (tid == 0) {
+      s_idmin = a.id_base;
+      s_old = 0;
+    }
     __syncthreads();
     if (tid < 16) {  // svo_inv_se3 of it; both into the frame table
       const int i = tid >> 2, j = tid & 3;
@@ -199,6 +202,8 @@ __device__ __forceinline__ void mvo_advance_body(const MvoAdvArgs &a, const floa
       if (ok) {
         kft += (a.cur.t.flags[k] & VO_LM_KF_MEMBER) ? 1 : 0;
         if (pos == 0) s_idmin = a.cur.t.ids[k];
+        // the frame-pose ring holds MVO_FRAME_RING frames: an older first observation would read another frame's pose
+        if (a.f - a.cur.f_first[k] >= MVO_FRAME_RING) s_old = 1;
         if (pos < a.cap) mvo_put_survivor(a, k, pos, a.pts1[2 * k], a.pts1[2 * k + 1], s_T);
       }
       base += total;
@@ -224,7 +229,7 @@ __device__ __forceinline__ void mvo_advance_body(const MvoAdvArgs &a, const floa
       h.n_new = base - n_surv;
       h.n_next = base < a.cap ? base : a.cap;
       h.n_kf_tracked = t;
-      h.overflow = base > a.cap ? 1 : 0;
+      h.overflow = (base > a.cap ? 1 : 0) | (s_old ? 2 : 0);
       h.n_recon = 0;
       h.pad = 0;
       h.seq = 0;

@@ -158,6 +158,11 @@ struct vo_ingest_scope {
   ~vo_ingest_scope() { c->stream = saved; }
 };
 
+// The cumulative hand-shake targets (features past pass 1, finished fallback workgroups, candidate workgroups, DLT workers)
+// grow by a few thousand per frame for the life of a stream and are compared by wrapped difference on the device; on the
+// host they wrap the same way — through unsigned arithmetic, a signed `+=` would be undefined behaviour after ~5e5 frames.
+static inline void vo_wrap_add(int &x, int n) { x = (int)((unsigned)x + (unsigned)n); }
+
 // ---- profiling brackets (no-ops unless vo_profile_enable was called) --------
 static inline void vo_prof_begin(vo_ctx *c, int cls) {
   c->prof_open = 0;
