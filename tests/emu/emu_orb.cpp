@@ -42,6 +42,7 @@ int main(int argc, char **argv) {
   OrbTileArgs a;
   memset(&a, 0, sizeof(a));
   a.img = img.data();
+  a.img_end = img.data() + img.size();
   a.stride = w;
   a.n_levels = nl;
   a.nx = P.nx;
@@ -61,6 +62,8 @@ int main(int argc, char **argv) {
     L.sc_off = P.sc_off[l];
     L.sc_stride = P.sc_stride[l];
     L.cand_base = l * cand_cap;
+    L.tx_off = P.tx_off[l];
+    L.ty_off = P.ty_off[l];
     L.tabx = l ? P.tabx[l].data() : nullptr;
     L.taby = l ? P.taby[l].data() : nullptr;
   }

@@ -96,7 +96,7 @@ static void emu_launch(Kernel k, dim3 grid, dim3 block, Args... args) {
 // ---- what csrc/orb_device.hpp / orb_tile.hpp ask their includer for -----------------------------------------------------
 #include <math.h>
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
-static inline int orb_wave_sum(int v) { return emu_wave_sum_i32(v); }
+static inline int orb_wave_count(bool p) { return emu_wave_sum_i32(p ? 1 : 0); }
 static uint8_t emu_dyn_lds[160 * 1024] __attribute__((aligned(16)));
 #define ORB_DYN_LDS(name) uint8_t *name = emu_dyn_lds
 #define ORB_LD_AGENT(p) __atomic_load_n((p), __ATOMIC_SEQ_CST)

@@ -159,4 +159,4 @@ def test_candidate_table_by_tile_kernels_4k(ctx5, vo, oracle):
     st = S.StereoStream(width=3840, height=2160, K=(718.856 * 3.0, 718.856 * 3.0, 1920.0, 1080.0), n_u=100, n_v=80, seed=2)
     img = st.render_pair(st.poses(1)[0])[0]
     xy, has, nd = _table(ctx5, vo, oracle, img, 15, 100, 80)
-    assert has.sum() > 3000
+    assert has.sum() > 1500

@@ -30,7 +30,7 @@
 #include "frame_state.hpp"
 
 // what orb_device.hpp / orb_tile.hpp ask their includer for (tests/emu/ provides CPU stand-ins of the same names)
-__device__ __forceinline__ int orb_wave_sum(int v) { return wave_sum_i32(v); }
+__device__ __forceinline__ int orb_wave_count(bool p) { return __popcll(__ballot(p)); }
 #define ORB_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) uint8_t name[]
 #define ORB_LD_AGENT(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define ORB_ST_AGENT(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -159,9 +159,10 @@ template <int NQ>
 __device__ __forceinline__ void orb_select_fast(const OrbDev &d, int l, int n, OrbSelShared *S) {
   const OrbLevel &L = d.L[l];
   unsigned key[NQ];
+  float resp[NQ];
   int cut, surv;
   unsigned rcut;
-  orb_select_regs<NQ>(d.cs + L.cand_base, d.cr + L.cand_base, n, L.quota, S, key, &cut, &rcut, &surv);
+  orb_select_regs<NQ>(d.cs + L.cand_base, d.cr + L.cand_base, n, L.quota, S, key, resp, &cut, &rcut, &surv);
   if (threadIdx.x == 0) {
     d.lvl_cut[l] = cut;
     d.lvl_rcut[l] = rcut;
@@ -484,6 +485,7 @@ static int orb_tile_enqueue(vo_ctx *c, int slot, const vo_bin_params *bp, vo_can
   OrbTileArgs a;
   memset(&a, 0, sizeof(a));
   a.img = P.lv[0].origin();
+  a.img_end = P.lv[0].base + (size_t)P.lv[0].stride * (size_t)(P.lv[0].h + 2 * VO_PAD);
   a.stride = P.lv[0].stride;
   a.n_levels = p->n_levels;
   a.nx = S->plan.nx;
@@ -503,6 +505,8 @@ static int orb_tile_enqueue(vo_ctx *c, int slot, const vo_bin_params *bp, vo_can
     L.sc_off = S->plan.sc_off[l];
     L.sc_stride = S->plan.sc_stride[l];
     L.cand_base = l * S->cand_cap_level;
+    L.tx_off = S->plan.tx_off[l];
+    L.ty_off = S->plan.ty_off[l];
     L.tabx = l ? (const int *)(A + S->o_tx[l]) : nullptr;
     L.taby = l ? (const int *)(A + S->o_ty[l]) : nullptr;
   }

@@ -5,7 +5,8 @@
 // fast_score.cpp / keypoint.cpp — third party, not in the reference tree).
 //
 // Plain C++ apart from __device__ / __shared__ / __syncthreads / atomics; the includer provides
-//   int orb_wave_sum(int)   sum over the caller's wavefront, every lane gets it (vo_internal.hpp: wave_sum_i32)
+//   int orb_wave_count(bool)   number of lanes of the caller's wavefront whose argument is true, the same value in every
+//                              lane (on the device: the population count of the compare's lane mask — scalar instructions)
 // so that tests/emu/ can run the same text on CPU threads.
 #pragma once
 #include <stdint.h>
@@ -171,10 +172,9 @@ struct OrbSelShared {
 // count(key >= t) over the workgroup; `phase` advances by one per call (uniform). One barrier.
 template <int NQ>
 __device__ __forceinline__ int orb_count_ge(const unsigned (&key)[NQ], unsigned t, OrbSelShared *S, int &phase) {
-  int c = 0;
+  int c = 0;  // (wave-uniform: a compare and a scalar population count per register, no cross-lane reduction)
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) c += key[q] >= t;
-  c = orb_wave_sum(c);
+  for (int q = 0; q < NQ; ++q) c += orb_wave_count(key[q] >= t);
   const int slot = phase % 3;
   if ((threadIdx.x & 63) == 0 && c) atomicAdd(&S->cnt[slot], c);
   __syncthreads();
@@ -231,9 +231,9 @@ __device__ __forceinline__ unsigned orb_kth_largest(const unsigned (&key)[NQ], i
 // else 0; *cut, *rcut, *surv as orb_select_kernel always reported them.
 template <int NQ>
 __device__ __forceinline__ void orb_select_regs(const uint8_t *__restrict__ cs, const float *__restrict__ cr, int n, int quota,
-                                                OrbSelShared *S, unsigned (&key)[NQ], int *cut_out, unsigned *rcut_out, int *surv_out) {
+                                                OrbSelShared *S, unsigned (&key)[NQ], float (&resp)[NQ], int *cut_out, unsigned *rcut_out,
+                                                int *surv_out) {
   const int tid = threadIdx.x;
-  float resp[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     const int i = tid + q * ORB_ST;

@@ -64,6 +64,7 @@ struct OrbTilePlan {
   int n_levels = 0, nx = 0, ny = 0;
   int lds_off[ORB_MAX_LEVELS], lds_stride[ORB_MAX_LEVELS];  // image regions
   int sc_off[ORB_MAX_LEVELS], sc_stride[ORB_MAX_LEVELS];    // score tiles (owned + 1 ring)
+  int tx_off[ORB_MAX_LEVELS], ty_off[ORB_MAX_LEVELS];       // level >= 1: the region's slices of the coefficient tables (ints)
   int stash_off = 0, stash_cap = 0;                         // candidates of one workgroup (8 bytes each)
   int lds_bytes = 0;
   std::vector<OrbSpan> gx, gy;                              // [level * nx + i], [level * ny + j]
@@ -141,9 +142,17 @@ static inline void orb_tile_plan(const int *lw, const int *lh, int n_levels, int
       if (s.own1 - s.own0 > oh) oh = s.own1 - s.own0;
     }
     P->lds_off[l] = off;
-    P->lds_stride[l] = (rw + 3) & ~3;
+    P->lds_stride[l] = l ? (rw + 3) & ~3 : (rw + 15) & ~15;  // (level 0 is staged in 16-byte pieces)
     off += P->lds_stride[l] * rh;
     off = (off + 15) & ~15;
+    P->tx_off[l] = P->ty_off[l] = 0;
+    if (l) {
+      P->tx_off[l] = off;
+      off += 4 * rw;
+      P->ty_off[l] = off;
+      off += 4 * rh;
+      off = (off + 15) & ~15;
+    }
     P->sc_stride[l] = (ow + 2 + 3) & ~3;
     P->sc_off[l] = 0;
     stash += ((ow + 1) / 2) * ((oh + 1) / 2);  // strict 3x3 maxima in an ow x oh rectangle: at most one per 2x2 cell

@@ -23,10 +23,11 @@
 // Reference: extractor_orb_->detect + the arg-max-per-bin branch of FeatureExtractor::extractORBwithBinning_fast
 // (core/visual_odometry/feature_extractor.cpp:241-277); cv::ORB restated as in oracle/oracle_orb.c.
 //
-// Plain C++ apart from the HIP keywords; the includer provides orb_wave_sum (orb_device.hpp), ORB_DYN_LDS (the
+// Plain C++ apart from the HIP keywords; the includer provides orb_wave_count (orb_device.hpp), ORB_DYN_LDS (the
 // dynamic LDS array), __umulhi and the agent-scope load / store / fence spellings below — tests/emu/ runs both kernels
 // on CPU threads against the oracle.
 #pragma once
+#include "vo_layout.hpp"
 #include "orb_device.hpp"
 #include "orb_plan.hpp"
 
@@ -37,11 +38,12 @@ struct OrbTileLevel {
   int lds_off, lds_stride;   // image region of the level in LDS
   int sc_off, sc_stride;     // score tile (owned pixels + one ring)
   int cand_base;             // first slot of the level's candidate list
-  int pad;
+  int tx_off, ty_off;        // level >= 1: where the region's slices of tabx / taby are staged in LDS
   const int *tabx, *taby;    // level >= 1: (source offset << 16) | weight of the next sample, per destination column / row
 };
 struct OrbTileArgs {
   const uint8_t *img;        // level 0 (any stride; the pyramid slot's padded plane or the caller's image)
+  const uint8_t *img_end;    // one past the last byte that may be read (16-byte pieces stop there)
   int stride;
   int n_levels, nx, ny, fast_thr, cand_cap;
   int stash_off, stash_cap;
@@ -53,14 +55,6 @@ struct OrbTileArgs {
   float *cr;
 };
 
-// i / d and i % d for 0 <= i < 2^16 by a multiplication (m = 2^32 / d rounded up): the tile loops run over rectangles
-// of a few thousand elements whose width is only known at run time
-__device__ __forceinline__ unsigned orb_magic(int d) { return d > 1 ? 0xFFFFFFFFu / (unsigned)d + 1u : 0u; }
-__device__ __forceinline__ void orb_divmod(int i, int d, unsigned m, int &q, int &r) {
-  q = d > 1 ? (int)__umulhi((unsigned)i, m) : i;
-  r = i - q * d;
-}
-
 __global__ __launch_bounds__(ORB_TILE_NT) void orb_tile_kernel(OrbTileArgs a) {
   ORB_DYN_LDS(lds);
   __shared__ OrbSpan s_x[ORB_MAX_LEVELS], s_y[ORB_MAX_LEVELS];
@@ -68,6 +62,7 @@ __global__ __launch_bounds__(ORB_TILE_NT) void orb_tile_kernel(OrbTileArgs a) {
   __shared__ int s_pre_sc[ORB_MAX_LEVELS + 1], s_pre_own[ORB_MAX_LEVELS + 1];  // running pixel counts: score rectangles, owned rectangles
   __shared__ int s_cnt[ORB_MAX_LEVELS], s_base[ORB_MAX_LEVELS];
   __shared__ int s_nstash;
+  __shared__ int s_pre_tab[2 * ORB_MAX_LEVELS + 1];  // running entry counts of the table slices: (level, x), (level, y), ...
 
   const int tid = threadIdx.x, nl = a.n_levels;
   const int ti = (int)blockIdx.x % a.nx, tj = (int)blockIdx.x / a.nx;
@@ -76,9 +71,9 @@ __global__ __launch_bounds__(ORB_TILE_NT) void orb_tile_kernel(OrbTileArgs a) {
     s_x[tid] = x;
     s_y[tid] = y;
     s_cnt[tid] = 0;
-    s_mreg[tid] = orb_magic(x.reg1 - x.reg0);
-    s_msc[tid] = orb_magic(x.own1 - x.own0 + 2);
-    s_mown[tid] = orb_magic(x.own1 - x.own0);
+    s_mreg[tid] = vo_magic(x.reg1 - x.reg0);
+    s_msc[tid] = vo_magic(x.own1 - x.own0 + 2);
+    s_mown[tid] = vo_magic(x.own1 - x.own0);
   }
   if (tid == 0) s_nstash = 0;
   __syncthreads();
@@ -95,24 +90,87 @@ __global__ __launch_bounds__(ORB_TILE_NT) void orb_tile_kernel(OrbTileArgs a) {
     }
     s_pre_sc[nl] = psc;
     s_pre_own[nl] = pown;
+    int pt = 0;
+    for (int l = 1; l < nl; ++l) {
+      s_pre_tab[2 * l - 2] = pt;
+      pt += s_x[l].reg1 > s_x[l].reg0 ? s_x[l].reg1 - s_x[l].reg0 : 0;
+      s_pre_tab[2 * l - 1] = pt;
+      pt += s_y[l].reg1 > s_y[l].reg0 ? s_y[l].reg1 - s_y[l].reg0 : 0;
+    }
+    s_pre_tab[nl > 1 ? 2 * nl - 2 : 0] = pt;
   }
-  // ---- level 0: the region from the image --------------------------------------------------------------------------------
+  // ---- level 0: the region from the image, in 16-byte pieces — every load of a thread in flight before its first LDS
+  // store (with about one workgroup per compute unit a dependent load costs its whole latency: the first version, one
+  // byte per load in a loop, spent 25 of its 60 us here and as much on the coefficient tables read inside the loops below)
   {
     const int x0 = s_x[0].reg0, y0 = s_y[0].reg0, rw = s_x[0].reg1 - x0, rh = s_y[0].reg1 - y0;
     if (rw > 0 && rh > 0) {
       uint8_t *D = lds + a.L[0].lds_off;
       const int ds = a.L[0].lds_stride;
-      const unsigned m = s_mreg[0];
+      const int nch = (rw + 15) >> 4, total = nch * rh;
+      const unsigned m = vo_magic(nch);
       const uint8_t *__restrict__ src = a.img + (size_t)y0 * a.stride + x0;
-      for (int i = tid; i < rw * rh; i += ORB_TILE_NT) {
-        int ry, rx;
-        orb_divmod(i, rw, m, ry, rx);
-        D[ry * ds + rx] = src[(size_t)ry * a.stride + rx];
+      for (int i0 = 0; i0 < total; i0 += 4 * ORB_TILE_NT) {
+        vo_u128 v[4];
+        int dst[4], tail[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {  // no branch between the loads: a piece that must not be read reads the image's first bytes
+          const int i = i0 + tid + q * ORB_TILE_NT;
+          int ry, c;
+          vo_divmod(i < total ? i : 0, nch, m, ry, c);
+          const uint8_t *p = src + (size_t)ry * a.stride + 16 * c;
+          const bool safe = i < total && p + 16 <= a.img_end;
+          dst[q] = safe ? ry * ds + 16 * c : -1;
+          tail[q] = (i < total && !safe) ? i : -1;
+          const vo_u128_unaligned u = *(const vo_u128_unaligned *)(safe ? p : a.img);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[q].v[e] = u.v[e];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (dst[q] >= 0) *(vo_u128 *)(D + dst[q]) = v[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {  // pieces that reach past the last readable byte (a caller's image, its last rows): byte by byte
+          if (tail[q] < 0) continue;
+          int ry, c;
+          vo_divmod(tail[q], nch, m, ry, c);
+          const uint8_t *p = src + (size_t)ry * a.stride + 16 * c;
+          for (int e = 0; e < 16 && p + e < a.img_end; ++e) D[ry * ds + 16 * c + e] = p[e];
+        }
       }
     }
   }
   __syncthreads();
   if (s_pre_own[nl] == 0) return;  // (a tile inside the border strip owns nothing on any level)
+  // ---- the regions' slices of the resize coefficient tables -> LDS (one batch of loads, as above) ---------------------------
+  {
+    const int total = s_pre_tab[nl > 1 ? 2 * nl - 2 : 0];
+    for (int i0 = 0; i0 < total; i0 += 4 * ORB_TILE_NT) {
+      int val[4], *dstp[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = i0 + tid + q * ORB_TILE_NT;
+        dstp[q] = nullptr;
+        val[q] = 0;
+        if (i < total) {
+          int sgm = 0;
+          while (i >= s_pre_tab[sgm + 1]) ++sgm;
+          const int l = (sgm >> 1) + 1, k = i - s_pre_tab[sgm];
+          if (sgm & 1) {
+            val[q] = a.L[l].taby[s_y[l].reg0 + k];
+            dstp[q] = (int *)(lds + a.L[l].ty_off) + k;
+          } else {
+            val[q] = a.L[l].tabx[s_x[l].reg0 + k];
+            dstp[q] = (int *)(lds + a.L[l].tx_off) + k;
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (dstp[q]) *dstp[q] = val[q];
+    }
+  }
+  __syncthreads();
 
   // ---- levels 1 .. n-1: cv::resize INTER_LINEAR_EXACT of the previous level's region, in LDS -------------------------------
   for (int l = 1; l < nl; ++l) {
@@ -122,12 +180,12 @@ __global__ __launch_bounds__(ORB_TILE_NT) void orb_tile_kernel(OrbTileArgs a) {
       uint8_t *D = lds + a.L[l].lds_off;
       const int ss = a.L[l - 1].lds_stride, ds = a.L[l].lds_stride;
       const int sx0 = s_x[l - 1].reg0, sy0 = s_y[l - 1].reg0;
-      const int *__restrict__ tabx = a.L[l].tabx, *__restrict__ taby = a.L[l].taby;
+      const int *tabx = (const int *)(lds + a.L[l].tx_off), *taby = (const int *)(lds + a.L[l].ty_off);
       const unsigned m = s_mreg[l];
       for (int i = tid; i < rw * rh; i += ORB_TILE_NT) {
         int ry, rx;
-        orb_divmod(i, rw, m, ry, rx);
-        const int tx = tabx[x0 + rx], ty = taby[y0 + ry];
+        vo_divmod(i, rw, m, ry, rx);
+        const int tx = tabx[rx], ty = taby[ry];
         const int a1 = tx & 0xFFFF, a0 = 256 - a1, b1 = ty & 0xFFFF, b0 = 256 - b1;
         const uint8_t *r0 = S + ((ty >> 16) - sy0) * ss + ((tx >> 16) - sx0), *r1 = r0 + ss;
         const unsigned h0 = (unsigned)a0 * r0[0] + (unsigned)a1 * r0[1];  // horizontal pass, 8.8
@@ -148,7 +206,7 @@ __global__ __launch_bounds__(ORB_TILE_NT) void orb_tile_kernel(OrbTileArgs a) {
       while (i >= s_pre_sc[l + 1]) ++l;
       const int sw = s_x[l].own1 - s_x[l].own0 + 2;
       int sy, sx;
-      orb_divmod(i - s_pre_sc[l], sw, s_msc[l], sy, sx);
+      vo_divmod(i - s_pre_sc[l], sw, s_msc[l], sy, sx);
       const int x = s_x[l].own0 - 1 + sx, y = s_y[l].own0 - 1 + sy;
       const int st = a.L[l].lds_stride;
       const uint8_t *p = lds + a.L[l].lds_off + (y - s_y[l].reg0) * st + (x - s_x[l].reg0);
@@ -166,7 +224,7 @@ __global__ __launch_bounds__(ORB_TILE_NT) void orb_tile_kernel(OrbTileArgs a) {
       while (i >= s_pre_own[l + 1]) ++l;
       const int ow = s_x[l].own1 - s_x[l].own0;
       int oy, ox;
-      orb_divmod(i - s_pre_own[l], ow, s_mown[l], oy, ox);
+      vo_divmod(i - s_pre_own[l], ow, s_mown[l], oy, ox);
       const int scs = a.L[l].sc_stride;
       const uint8_t *p = lds + a.L[l].sc_off + (oy + 1) * scs + (ox + 1);
       const int c = p[0];
@@ -240,15 +298,20 @@ __device__ __forceinline__ void orb_finish_vote(const OrbFinishArgs &a, int l, i
 template <int NQ>
 __device__ __forceinline__ int orb_finish_level(const OrbFinishArgs &a, int l, int n, OrbSelShared *S) {
   unsigned key[NQ];
+  float resp[NQ];
+  int xy[NQ];  // the candidates' coordinates: loaded with their scores and responses, in one batch in front of the selection
   int cut, surv;
   unsigned rcut;
   const int base = a.cand_base[l];
-  orb_select_regs<NQ>(a.cs + base, a.cr + base, n, a.quota[l], S, key, &cut, &rcut, &surv);
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     const int i = (int)threadIdx.x + q * ORB_ST;
-    if (key[q] != 0u) orb_finish_vote(a, l, a.cx[base + i], a.cy[base + i], a.cr[base + i]);
+    xy[q] = i < n ? ((int)(unsigned short)a.cx[base + i] | ((int)(unsigned short)a.cy[base + i] << 16)) : 0;
   }
+  orb_select_regs<NQ>(a.cs + base, a.cr + base, n, a.quota[l], S, key, resp, &cut, &rcut, &surv);
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+    if (key[q] != 0u) orb_finish_vote(a, l, xy[q] & 0xFFFF, (int)((unsigned)xy[q] >> 16), resp[q]);
   return surv;
 }
 
@@ -353,11 +416,21 @@ __global__ __launch_bounds__(ORB_ST) void orb_finish_kernel(OrbFinishArgs a) {
   __syncthreads();
   if (!s_last) return;
   ORB_FENCE_ACQUIRE();
+  // (every load below is issued before the first one is used: the other workgroups' results come from memory)
+  const int nb = a.n_bins_u * a.n_bins_v;
+  unsigned long long kk[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) kk[q] = (tid + q * ORB_ST) < nb ? ORB_LD_AGENT(&a.key[tid + q * ORB_ST]) : 0ull;
+  if (tid < a.n_levels) {
+    s_hist[tid] = ORB_LD_AGENT(&a.surv[tid]);
+    s_hist[ORB_MAX_LEVELS + tid] = ORB_LD_AGENT(&a.lvl_total[tid]);
+  }
+  __syncthreads();
   if (tid == 0) {
     int tot = 0, flags = 0;
     for (int q = 0; q < a.n_levels; ++q) {
-      tot += ORB_LD_AGENT(&a.surv[q]);
-      if (ORB_LD_AGENT(&a.lvl_total[q]) > a.cand_cap) flags |= 1;  // more corners on a level than its list holds
+      tot += s_hist[q];
+      if (s_hist[ORB_MAX_LEVELS + q] > a.cand_cap) flags |= 1;  // more corners on a level than its list holds
     }
     if (tot > a.max_out) flags |= 2;  // (the general path's output buffer: kept so that both paths report alike)
     const int n_out = tot < a.max_out ? tot : a.max_out;
@@ -368,19 +441,30 @@ __global__ __launch_bounds__(ORB_ST) void orb_finish_kernel(OrbFinishArgs a) {
     ORB_ST_AGENT(a.done, 0);
   }
   if (tid < a.n_levels) ORB_ST_AGENT(&a.lvl_total[tid], 0);
-  const int nb = a.n_bins_u * a.n_bins_v;
-  for (int j = tid; j < nb; j += ORB_ST) {
-    const unsigned long long k = ORB_LD_AGENT(&a.key[j]);
-    float x = 0.f, y = 0.f;
-    if (k != 0ull) {
-      const unsigned pos = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
-      const int lv = (int)(pos >> 28), py = (int)((pos >> 14) & 0x3FFFu), px = (int)(pos & 0x3FFFu);
-      x = lv ? (float)px * a.scale[lv] : (float)px;
-      y = lv ? (float)py * a.scale[lv] : (float)py;
-      ORB_ST_AGENT(&a.key[j], 0ull);
+  for (int j0 = 0; j0 < nb; j0 += 2 * ORB_ST) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int j = j0 + tid + q * ORB_ST;
+      if (j >= nb) continue;
+      const unsigned long long k = kk[q];
+      float x = 0.f, y = 0.f;
+      if (k != 0ull) {
+        const unsigned pos = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
+        const int lv = (int)(pos >> 28), py = (int)((pos >> 14) & 0x3FFFu), px = (int)(pos & 0x3FFFu);
+        x = lv ? (float)px * a.scale[lv] : (float)px;
+        y = lv ? (float)py * a.scale[lv] : (float)py;
+        ORB_ST_AGENT(&a.key[j], 0ull);
+      }
+      a.tab_has[j] = k != 0ull ? 1 : 0;
+      a.tab_xy[2 * j] = x;
+      a.tab_xy[2 * j + 1] = y;
     }
-    a.tab_has[j] = k != 0ull ? 1 : 0;
-    a.tab_xy[2 * j] = x;
-    a.tab_xy[2 * j + 1] = y;
+    if (j0 + 2 * ORB_ST < nb) {  // (more than 2048 bins: the next two keys of this thread)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int j = j0 + 2 * ORB_ST + tid + q * ORB_ST;
+        kk[q] = j < nb ? ORB_LD_AGENT(&a.key[j]) : 0ull;
+      }
+    }
   }
 }

@@ -68,7 +68,7 @@ __device__ inline int pyr_lds_stride(int k) {
 }
 
 __global__ __launch_bounds__(PYR_NT) void pyr_build_kernel(PyrTileArgs a) {
-  __shared__ uint8_t s_l0[109 * PYR_S0];
+  __shared__ __attribute__((aligned(16))) uint8_t s_l0[109 * PYR_S0];
   __shared__ uint8_t s_l1[53 * PYR_S1];
   __shared__ uint8_t s_l2[25 * PYR_S2];
   __shared__ uint8_t s_l3[11 * PYR_S3];
@@ -83,6 +83,8 @@ __global__ __launch_bounds__(PYR_NT) void pyr_build_kernel(PyrTileArgs a) {
   // scratch memory: 224 bytes per lane)
   __shared__ PyrAxis s_axis[2];
   __shared__ int s_dim[2][PYR_NL_MAX + 1];
+  // magic reciprocals (vo_divmod) of the run-time widths the loops below divide by, per level
+  __shared__ unsigned s_m_size[PYR_NL_MAX + 1], s_m_ndw[PYR_NL_MAX + 1], s_m_wide[PYR_NL_MAX + 1], s_m_mx[PYR_NL_MAX + 1];
 
   const int tid = threadIdx.x, z = blockIdx.z;
   const int nl = a.nl;
@@ -96,14 +98,61 @@ __global__ __launch_bounds__(PYR_NT) void pyr_build_kernel(PyrTileArgs a) {
   const PyrAxis &X = s_axis[0], &Y = s_axis[1];
   const int *wk = s_dim[0], *hk = s_dim[1];
 
+  if (tid <= nl) s_m_size[tid] = vo_magic(X.size[tid]);
   // ---- stage the base-level region (only pixels inside the image are ever read back: taps are reflected first) -------
+  // 16-byte pieces, every load of a thread in flight before its first LDS store: with one workgroup per compute unit a
+  // dependent load costs its full latency (first version, one byte per load in a loop: 40 us of the kernel's 65)
   {
     const uint8_t *__restrict__ src = a.src[z];
-    const int ss = a.sstride[z], sx = X.size[0], sy = Y.size[0], n = sx * sy;
-    for (int i = tid; i < n; i += PYR_NT) {
-      const int ry = i / sx, rx = i - ry * sx;
-      const int x = X.lo[0] + rx, y = Y.lo[0] + ry;
-      if (x >= 0 && x < wk[0] && y >= 0 && y < hk[0]) s_l0[ry * PYR_S0 + rx] = src[(size_t)y * ss + x];
+    const int ss = a.sstride[z], x0 = X.lo[0], y0 = Y.lo[0], sx = X.size[0], sy = Y.size[0], w0 = wk[0], h0 = hk[0];
+    const int nch = (sx + 15) >> 4, total = nch * sy;  // at most 7 x 109 pieces: three per thread
+    const unsigned m = vo_magic(nch);
+    // (a) pieces that lie inside an image row: one 16-byte load each, no branch between a thread's loads (a piece that is
+    //     not loaded reads a harmless address instead: the row start of an in-image row, or nothing when the image is
+    //     narrower than a piece)
+    vo_u128 v[3];
+    int dst[3], edge[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int i = tid + q * PYR_NT;
+      int ry, c;
+      vo_divmod(i < total ? i : 0, nch, m, ry, c);
+      const int y = y0 + ry, x = x0 + 16 * c;
+      const bool row = i < total && y >= 0 && y < h0;
+      const bool in = row && x >= 0 && x + 16 <= w0;
+      dst[q] = in ? ry * PYR_S0 + 16 * c : -1;
+      edge[q] = (row && !in && x + 16 > 0 && x < w0) ? i : -1;  // straddles the first or last column: (b)
+      const uint8_t *p = src + (ptrdiff_t)(row ? y : 0) * ss + (in ? x : 0);
+      if (w0 >= 16) {
+        const vo_u128_unaligned u = *(const vo_u128_unaligned *)p;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[q].v[e] = u.v[e];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      if (dst[q] >= 0) *(vo_u128 *)(s_l0 + dst[q]) = v[q];
+    // (b) the pieces at the image's first and last column (tiles at the image edge only), byte by byte; a byte outside the
+    //     image is never read back (taps are reflected into the image first)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      if (edge[q] < 0) continue;
+      int ry, c;
+      vo_divmod(edge[q], nch, m, ry, c);
+      const int y = y0 + ry, x = x0 + 16 * c;
+      const uint8_t *rowp = src + (ptrdiff_t)y * ss;
+      uint8_t bytes[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        int xb = x + e;
+        xb = xb < 0 ? 0 : (xb >= w0 ? w0 - 1 : xb);  // (clamped: every load is a valid one, all sixteen go out together)
+        bytes[e] = rowp[xb];
+      }
+      vo_u128 wv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        wv.v[e] = (uint32_t)bytes[4 * e] | ((uint32_t)bytes[4 * e + 1] << 8) | ((uint32_t)bytes[4 * e + 2] << 16) | ((uint32_t)bytes[4 * e + 3] << 24);
+      *(vo_u128 *)(s_l0 + ry * PYR_S0 + 16 * c) = wv;
     }
   }
   // ---- the mirror lists of every level (2 * VO_PAD border coordinates per level and axis) --------------------------------
@@ -120,6 +169,13 @@ __global__ __launch_bounds__(PYR_NT) void pyr_build_kernel(PyrTileArgs a) {
     }
   }
   __syncthreads();
+  if (tid <= nl) {  // (read by the write phase, behind at least one more barrier)
+    const int nx = X.o1[tid] - X.o0[tid];
+    s_m_ndw[tid] = vo_magic((nx + 3) >> 2);
+    s_m_wide[tid] = vo_magic(nx + s_mcnt[tid][0]);
+    s_m_mx[tid] = vo_magic(s_mcnt[tid][0]);
+  }
+  if (nl == 0) __syncthreads();
 
   // ---- level k + 1 from level k, in LDS ------------------------------------------------------------------------
   for (int k = 0; k < nl; ++k) {
@@ -129,8 +185,10 @@ __global__ __launch_bounds__(PYR_NT) void pyr_build_kernel(PyrTileArgs a) {
     const int sx = X.size[k + 1], sy = Y.size[k + 1], n = sx * sy;
     const int sw = wk[k], sh = hk[k], dw = wk[k + 1], dh = hk[k + 1];
     const int slx = X.lo[k], sly = Y.lo[k];
+    const unsigned msx = s_m_size[k + 1];
     for (int i = tid; i < n; i += PYR_NT) {
-      const int ry = i / sx, rx = i - ry * sx;
+      int ry, rx;
+      vo_divmod(i, sx, msx, ry, rx);
       const int x = X.lo[k + 1] + rx, y = Y.lo[k + 1] + ry;
       if (x < 0 || x >= dw || y < 0 || y >= dh) continue;
       int cx[5], cy[5];
@@ -172,8 +230,10 @@ __global__ __launch_bounds__(PYR_NT) void pyr_build_kernel(PyrTileArgs a) {
     const int lx = X.lo[k], ly = Y.lo[k];
     // (a) the owned pixels themselves: x0 is a multiple of 4 and the plane's pixel (0, 0) is 4-byte aligned -> dword stores
     const int ndw = (nx + 3) >> 2;
+    const unsigned m_ndw = s_m_ndw[k], m_wide = s_m_wide[k], m_mx = s_m_mx[k];
     for (int i = tid; i < ndw * ny; i += PYR_NT) {
-      const int ry = i / ndw, j = i - ry * ndw;
+      int ry, j;
+      vo_divmod(i, ndw, m_ndw, ry, j);
       const int x = x0 + 4 * j, y = y0 + ry;
       const uint8_t *sp = S + (y - ly) * ssd + (x - lx);
       uint8_t *dp = org + (ptrdiff_t)y * Lv.stride + x;
@@ -188,13 +248,15 @@ __global__ __launch_bounds__(PYR_NT) void pyr_build_kernel(PyrTileArgs a) {
     const int mx = s_mcnt[k][0], my = s_mcnt[k][1];
     const int wide = nx + mx;
     for (int i = tid; i < my * wide; i += PYR_NT) {
-      const int e = i / wide, c = i - e * wide;
+      int e, c;
+      vo_divmod(i, wide, m_wide, e, c);
       const int py = s_mdst[k][1][e], sy = s_msrc[k][1][e];
       const int px = c < nx ? x0 + c : s_mdst[k][0][c - nx], sx = c < nx ? x0 + c : s_msrc[k][0][c - nx];
       org[(ptrdiff_t)py * Lv.stride + px] = S[(sy - ly) * ssd + (sx - lx)];
     }
     for (int i = tid; i < ny * mx; i += PYR_NT) {
-      const int ry = i / mx, e = i - ry * mx;
+      int ry, e;
+      vo_divmod(i, mx, m_mx, ry, e);
       const int y = y0 + ry, px = s_mdst[k][0][e], sx = s_msrc[k][0][e];
       org[(ptrdiff_t)y * Lv.stride + px] = S[(y - ly) * ssd + (sx - lx)];
     }

@@ -21,3 +21,20 @@ __host__ __device__ inline int vo_reflect101(int p, int n) {
   while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
   return p;
 }
+
+// i / d and i % d for 0 <= i * d < 2^32 by a multiplication (m = 2^32 / d rounded up): the tile kernels run over
+// rectangles of a few thousand elements whose width is only known at run time (a software division costs ~40 instructions)
+__host__ __device__ inline unsigned vo_magic(int d) { return d > 1 ? 0xFFFFFFFFu / (unsigned)d + 1u : 0u; }
+__device__ inline void vo_divmod(int i, int d, unsigned m, int &q, int &r) {
+  q = d > 1 ? (int)__umulhi((unsigned)i, m) : i;
+  r = i - q * d;
+}
+
+// 16 bytes from an address of any alignment (global memory takes unaligned dword accesses on gfx950; the compiler is told
+// so by the packed type)
+struct __attribute__((packed, aligned(1))) vo_u128_unaligned {
+  uint32_t v[4];
+};
+struct __attribute__((aligned(16))) vo_u128 {
+  uint32_t v[4];
+};
