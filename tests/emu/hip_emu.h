@@ -63,7 +63,7 @@ static inline int emu_wave_sum_i32(int v) {
   emu_wave_scratch[tid] = v;
   pthread_barrier_wait(&emu_wave_barrier[wave]);
   int s = 0;
-  for (int l = 0; l < 64; ++l) s += emu_wave_scratch[(wave << 6) + l];
+  for (int l = 0; l < 64 && (wave << 6) + l < (int)blockDim.x; ++l) s += emu_wave_scratch[(wave << 6) + l];
   pthread_barrier_wait(&emu_wave_barrier[wave]);
   return s;
 }
@@ -97,8 +97,39 @@ static void emu_launch(Kernel k, dim3 grid, dim3 block, Args... args) {
 #include <math.h>
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline int orb_wave_count(bool p) { return emu_wave_sum_i32(p ? 1 : 0); }
+static int emu_wave_scratch2[64 * 64];
+static inline int orb_wave_rank(bool p, int *n) {
+  const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  emu_wave_scratch[tid] = p ? 1 : 0;
+  pthread_barrier_wait(&emu_wave_barrier[wave]);
+  int r = 0, tot = 0;
+  for (int l = 0; l < 64 && (wave << 6) + l < (int)blockDim.x; ++l) {
+    if (l < lane) r += emu_wave_scratch[(wave << 6) + l];
+    tot += emu_wave_scratch[(wave << 6) + l];
+  }
+  pthread_barrier_wait(&emu_wave_barrier[wave]);
+  *n = tot;
+  return r;
+}
+static inline int orb_wave_first(int v, bool p) {
+  const int tid = (int)threadIdx.x, wave = tid >> 6;
+  emu_wave_scratch[tid] = p ? 1 : 0;
+  emu_wave_scratch2[tid] = v;
+  pthread_barrier_wait(&emu_wave_barrier[wave]);
+  int out = 0;
+  for (int l = 0; l < 64 && (wave << 6) + l < (int)blockDim.x; ++l)
+    if (emu_wave_scratch[(wave << 6) + l]) {
+      out = emu_wave_scratch2[(wave << 6) + l];
+      break;
+    }
+  pthread_barrier_wait(&emu_wave_barrier[wave]);
+  return out;
+}
 static uint8_t emu_dyn_lds[160 * 1024] __attribute__((aligned(16)));
 #define ORB_DYN_LDS(name) uint8_t *name = emu_dyn_lds
+#define ORB_SET_PRIO()
+static inline int __mul24(int a, int b) { return (int)((long long)((a << 8) >> 8) * ((b << 8) >> 8)); }
+static inline unsigned __umul24(unsigned a, unsigned b) { return (unsigned)((unsigned long long)(a & 0xFFFFFFu) * (b & 0xFFFFFFu)); }
 #define ORB_LD_AGENT(p) __atomic_load_n((p), __ATOMIC_SEQ_CST)
 #define ORB_ST_AGENT(p, v) __atomic_store_n((p), (v), __ATOMIC_SEQ_CST)
 #define ORB_ATOMIC_INC_AGENT(p) __atomic_fetch_add((p), 1, __ATOMIC_SEQ_CST)

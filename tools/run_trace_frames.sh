@@ -9,6 +9,6 @@ B="python3 $ROOT/bench.py --no-cpu-baseline --no-secondary $*"
 timeout 600 $B > $OUT/prerender.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT -o tr -- $B > $OUT/log.txt 2>&1
 f=$(ls $OUT/*kernel_trace.csv $OUT/*/*kernel_trace.csv 2>/dev/null | tail -1)
-python3 $ROOT/tools/tools_trace_frames.py $f $FIRST $COUNT > $OUT/timeline.txt 2>&1
+python3 $ROOT/tools/tools_trace_frames.py $f $FIRST $COUNT all > $OUT/timeline.txt 2>&1
 grep -h "^{" $OUT/log.txt | tail -1 | cut -c1-120
 rm -f $f

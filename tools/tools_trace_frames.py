@@ -8,7 +8,7 @@ def main():
     path = sys.argv[1]
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 200
     count = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-    skip = ("pyr_down", "orb_", "bucket_", "pad_level0", "__amd_rocclr", "remap_")
+    skip = ("__amd_rocclr",) if len(sys.argv) > 4 and sys.argv[4] == "all" else ("pyr_", "orb_", "bucket_", "__amd_rocclr", "remap_")
     rows = []
     with open(path) as f:
         for r in csv.DictReader(f):

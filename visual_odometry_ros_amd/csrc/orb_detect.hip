@@ -31,7 +31,17 @@
 
 // what orb_device.hpp / orb_tile.hpp ask their includer for (tests/emu/ provides CPU stand-ins of the same names)
 __device__ __forceinline__ int orb_wave_count(bool p) { return __popcll(__ballot(p)); }
+__device__ __forceinline__ int orb_wave_rank(bool p, int *n) {
+  const unsigned long long m = __ballot(p);
+  *n = __popcll(m);
+  return __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+}
+__device__ __forceinline__ int orb_wave_first(int v, bool p) {
+  const unsigned long long m = __ballot(p);
+  return m ? __shfl(v, __ffsll((long long)m) - 1) : 0;
+}
 #define ORB_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) uint8_t name[]
+#define ORB_SET_PRIO() __builtin_amdgcn_s_setprio(3)
 #define ORB_LD_AGENT(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define ORB_ST_AGENT(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define ORB_ATOMIC_INC_AGENT(p) __hip_atomic_fetch_add((p), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)

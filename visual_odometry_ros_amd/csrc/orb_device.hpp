@@ -7,6 +7,8 @@
 // Plain C++ apart from __device__ / __shared__ / __syncthreads / atomics; the includer provides
 //   int orb_wave_count(bool)   number of lanes of the caller's wavefront whose argument is true, the same value in every
 //                              lane (on the device: the population count of the compare's lane mask — scalar instructions)
+//   int orb_wave_rank(bool, int *n)   number of lower lanes whose argument is true; *n: all lanes' (every lane calls it)
+//   int orb_wave_first(int v, bool)   v of the lowest lane whose second argument is true (every lane calls it)
 // so that tests/emu/ can run the same text on CPU threads.
 #pragma once
 #include <stdint.h>
@@ -191,6 +193,8 @@ template <int NQ>
 __device__ __forceinline__ unsigned orb_kth_largest(const unsigned (&key)[NQ], int k, int kept, int nbits, OrbSelShared *S, int &phase) {
   unsigned t = 0;
   int cnt_t = kept, above = 0;  // count(key >= max(t, 1)), count(key >= t + 2^(bit + 1))
+#pragma unroll 1  // (unrolled, the 9 + 32 steps of four instantiations were 18 000 instructions of straight-line code that ran
+                  //  once: every step an instruction-cache miss, ~1 us per step instead of ~0.3)
   for (int bit = nbits - 1; bit >= 0; --bit) {
     const unsigned cand = t | (1u << bit);
     const int c = orb_count_ge<NQ>(key, cand, S, phase);

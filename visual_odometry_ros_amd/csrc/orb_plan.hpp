@@ -170,7 +170,25 @@ static inline void orb_tile_plan(const int *lw, const int *lh, int n_levels, int
   }
   P->stash_off = off;
   P->stash_cap = stash + 16;
-  off += 8 * P->stash_cap;
+  // the same place first holds the list of pixels that pass FAST's compass-point test (4 bytes each, at most every pixel of
+  // the score rectangles), then the candidates (8 bytes each)
+  {
+    int sc_px = 0;
+    for (int l = 0; l < n_levels; ++l) {
+      int ow = 0, oh = 0;
+      for (int i = 0; i < P->nx; ++i) {
+        const OrbSpan &s = P->gx[(size_t)l * P->nx + i];
+        if (s.own1 - s.own0 > ow) ow = s.own1 - s.own0;
+      }
+      for (int j = 0; j < P->ny; ++j) {
+        const OrbSpan &s = P->gy[(size_t)l * P->ny + j];
+        if (s.own1 - s.own0 > oh) oh = s.own1 - s.own0;
+      }
+      if (ow > 0 && oh > 0) sc_px += (ow + 2) * (oh + 2);
+    }
+    const int need = 4 * sc_px > 8 * P->stash_cap ? 4 * sc_px : 8 * P->stash_cap;
+    off += (need + 15) & ~15;
+  }
   P->lds_bytes = off;
   P->ok = off <= lds_limit && stash < 65536;
 }

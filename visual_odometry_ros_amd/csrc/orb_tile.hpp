@@ -23,15 +23,22 @@
 // Reference: extractor_orb_->detect + the arg-max-per-bin branch of FeatureExtractor::extractORBwithBinning_fast
 // (core/visual_odometry/feature_extractor.cpp:241-277); cv::ORB restated as in oracle/oracle_orb.c.
 //
-// Plain C++ apart from the HIP keywords; the includer provides orb_wave_count (orb_device.hpp), ORB_DYN_LDS (the
-// dynamic LDS array), __umulhi and the agent-scope load / store / fence spellings below — tests/emu/ runs both kernels
+// Plain C++ apart from the HIP keywords; the includer provides orb_wave_count (orb_device.hpp), orb_wave_rank / orb_wave_first (below), ORB_DYN_LDS (the
+// dynamic LDS array), ORB_SET_PRIO, __umulhi / __mul24 / __umul24 and the agent-scope load / store / fence spellings below — tests/emu/ runs both kernels
 // on CPU threads against the oracle.
 #pragma once
 #include "vo_layout.hpp"
 #include "orb_device.hpp"
 #include "orb_plan.hpp"
 
-#define ORB_TILE_NT 256
+#ifndef TILE_STAMP_AT
+#define TILE_STAMP_AT(k)  // (tools/tileprobe.hip defines it: phase time stamps of one workgroup, measurement builds only)
+#endif
+
+#ifndef ORB_TILE_NT
+#define ORB_TILE_NT 512  // two wavefronts per SIMD: every phase is a chain of dependent LDS reads (with one: 52 us per workgroup,
+                         // tools/tileprobe.hip); four would not fit next to the frame kernel's wavefronts on a SIMD
+#endif
 
 struct OrbTileLevel {
   int w, h;
@@ -62,10 +69,18 @@ __global__ __launch_bounds__(ORB_TILE_NT) void orb_tile_kernel(OrbTileArgs a) {
   __shared__ int s_pre_sc[ORB_MAX_LEVELS + 1], s_pre_own[ORB_MAX_LEVELS + 1];  // running pixel counts: score rectangles, owned rectangles
   __shared__ int s_cnt[ORB_MAX_LEVELS], s_base[ORB_MAX_LEVELS];
   __shared__ int s_nstash;
+  __shared__ int s_stash_lvl[ORB_MAX_LEVELS];  // first stash entry of a level's part
   __shared__ int s_pre_tab[2 * ORB_MAX_LEVELS + 1];  // running entry counts of the table slices: (level, x), (level, y), ...
 
+  // The per-level table of the kernel arguments, copied to LDS by ONE batch of loads: indexed by a level that is not a
+  // compile-time constant, every access to it in the argument segment was a memory round trip of its own (1-1.5 us each —
+  // per level in the resize and non-max loops, per pixel where the level differs between lanes: 30 of the first version's 40 us)
+  __shared__ OrbTileLevel s_L[ORB_MAX_LEVELS];
   const int tid = threadIdx.x, nl = a.n_levels;
   const int ti = (int)blockIdx.x % a.nx, tj = (int)blockIdx.x / a.nx;
+  ORB_SET_PRIO();  // a short kernel next to the frame kernel's long-lived wavefronts: its instructions go first
+  TILE_STAMP_AT(0);
+  if (tid < nl * (int)(sizeof(OrbTileLevel) / sizeof(int))) ((int *)s_L)[tid] = ((const int *)a.L)[tid];
   if (tid < nl) {
     const OrbSpan x = a.gx[tid * a.nx + ti], y = a.gy[tid * a.ny + tj];
     s_x[tid] = x;
@@ -77,15 +92,18 @@ __global__ __launch_bounds__(ORB_TILE_NT) void orb_tile_kernel(OrbTileArgs a) {
   }
   if (tid == 0) s_nstash = 0;
   __syncthreads();
+  TILE_STAMP_AT(1);
   if (tid == 0) {
-    int psc = 0, pown = 0;
+    int psc = 0, pown = 0, pst = 0;
     for (int l = 0; l < nl; ++l) {
       s_pre_sc[l] = psc;
       s_pre_own[l] = pown;
+      s_stash_lvl[l] = pst;
       const int ow = s_x[l].own1 - s_x[l].own0, oh = s_y[l].own1 - s_y[l].own0;
       if (ow > 0 && oh > 0) {
         psc += (ow + 2) * (oh + 2);
         pown += ow * oh;
+        pst += ((ow + 1) >> 1) * ((oh + 1) >> 1);  // strict 3x3 maxima in an ow x oh rectangle: at most one per 2x2 cell
       }
     }
     s_pre_sc[nl] = psc;
@@ -105,8 +123,8 @@ __global__ __launch_bounds__(ORB_TILE_NT) void orb_tile_kernel(OrbTileArgs a) {
   {
     const int x0 = s_x[0].reg0, y0 = s_y[0].reg0, rw = s_x[0].reg1 - x0, rh = s_y[0].reg1 - y0;
     if (rw > 0 && rh > 0) {
-      uint8_t *D = lds + a.L[0].lds_off;
-      const int ds = a.L[0].lds_stride;
+      uint8_t *D = lds + s_L[0].lds_off;
+      const int ds = s_L[0].lds_stride;
       const int nch = (rw + 15) >> 4, total = nch * rh;
       const unsigned m = vo_magic(nch);
       const uint8_t *__restrict__ src = a.img + (size_t)y0 * a.stride + x0;
@@ -141,6 +159,7 @@ __global__ __launch_bounds__(ORB_TILE_NT) void orb_tile_kernel(OrbTileArgs a) {
     }
   }
   __syncthreads();
+  TILE_STAMP_AT(2);
   if (s_pre_own[nl] == 0) return;  // (a tile inside the border strip owns nothing on any level)
   // ---- the regions' slices of the resize coefficient tables -> LDS (one batch of loads, as above) ---------------------------
   {
@@ -157,11 +176,11 @@ __global__ __launch_bounds__(ORB_TILE_NT) void orb_tile_kernel(OrbTileArgs a) {
           while (i >= s_pre_tab[sgm + 1]) ++sgm;
           const int l = (sgm >> 1) + 1, k = i - s_pre_tab[sgm];
           if (sgm & 1) {
-            val[q] = a.L[l].taby[s_y[l].reg0 + k];
-            dstp[q] = (int *)(lds + a.L[l].ty_off) + k;
+            val[q] = s_L[l].taby[s_y[l].reg0 + k];
+            dstp[q] = (int *)(lds + s_L[l].ty_off) + k;
           } else {
-            val[q] = a.L[l].tabx[s_x[l].reg0 + k];
-            dstp[q] = (int *)(lds + a.L[l].tx_off) + k;
+            val[q] = s_L[l].tabx[s_x[l].reg0 + k];
+            dstp[q] = (int *)(lds + s_L[l].tx_off) + k;
           }
         }
       }
@@ -171,93 +190,181 @@ __global__ __launch_bounds__(ORB_TILE_NT) void orb_tile_kernel(OrbTileArgs a) {
     }
   }
   __syncthreads();
+  TILE_STAMP_AT(3);
 
   // ---- levels 1 .. n-1: cv::resize INTER_LINEAR_EXACT of the previous level's region, in LDS -------------------------------
   for (int l = 1; l < nl; ++l) {
     const int x0 = s_x[l].reg0, y0 = s_y[l].reg0, rw = s_x[l].reg1 - x0, rh = s_y[l].reg1 - y0;
     if (rw > 0 && rh > 0) {
-      const uint8_t *S = lds + a.L[l - 1].lds_off;
-      uint8_t *D = lds + a.L[l].lds_off;
-      const int ss = a.L[l - 1].lds_stride, ds = a.L[l].lds_stride;
+      const uint8_t *S = lds + s_L[l - 1].lds_off;
+      uint8_t *D = lds + s_L[l].lds_off;
+      const int ss = s_L[l - 1].lds_stride, ds = s_L[l].lds_stride;
       const int sx0 = s_x[l - 1].reg0, sy0 = s_y[l - 1].reg0;
-      const int *tabx = (const int *)(lds + a.L[l].tx_off), *taby = (const int *)(lds + a.L[l].ty_off);
-      const unsigned m = s_mreg[l];
-      for (int i = tid; i < rw * rh; i += ORB_TILE_NT) {
-        int ry, rx;
-        vo_divmod(i, rw, m, ry, rx);
-        const int tx = tabx[rx], ty = taby[ry];
-        const int a1 = tx & 0xFFFF, a0 = 256 - a1, b1 = ty & 0xFFFF, b0 = 256 - b1;
-        const uint8_t *r0 = S + ((ty >> 16) - sy0) * ss + ((tx >> 16) - sx0), *r1 = r0 + ss;
-        const unsigned h0 = (unsigned)a0 * r0[0] + (unsigned)a1 * r0[1];  // horizontal pass, 8.8
-        const unsigned h1 = (unsigned)a0 * r1[0] + (unsigned)a1 * r1[1];
-        const unsigned v = (unsigned)b0 * h0 + (unsigned)b1 * h1;          // vertical pass, 16.16
-        const unsigned r = (v + 32768u) >> 16;
-        D[ry * ds + rx] = (uint8_t)(r > 255u ? 255u : r);
+      const int *tabx = (const int *)(lds + s_L[l].tx_off), *taby = (const int *)(lds + s_L[l].ty_off);
+      // lanes along a row, wavefronts over the rows, four rows per lane and pass: a lane's column terms (source offset,
+      // horizontal weights) are loop constants, a row's terms are the same in every lane, no division, products through the
+      // 24-bit multiplier. (One flattened output at a time with a division each: 300 issue cycles per wavefront and output —
+      // the phase was VALU-bound whatever the number of wavefronts, 15 of the kernel's 40 us.)
+      const int lane = tid & 63, wave = tid >> 6;
+      constexpr int NW = ORB_TILE_NT / 64;
+      for (int c0 = 0; c0 < rw; c0 += 64) {
+        const int c = c0 + lane;
+        const bool col = c < rw;
+        const int tx = tabx[col ? c : 0];
+        const int xo = (tx >> 16) - sx0;
+        const unsigned a1 = (unsigned)(tx & 0xFFFF), a0 = 256u - a1;
+        for (int r0 = wave; r0 < rh; r0 += 4 * NW) {
+          int ty[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) ty[q] = taby[r0 + q * NW < rh ? r0 + q * NW : 0];
+          unsigned p00[4], p01[4], p10[4], p11[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint8_t *p = S + __mul24((ty[q] >> 16) - sy0, ss) + xo;
+            p00[q] = p[0];
+            p01[q] = p[1];
+            p10[q] = p[ss];
+            p11[q] = p[ss + 1];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int ry = r0 + q * NW;
+            const unsigned b1 = (unsigned)(ty[q] & 0xFFFF), b0 = 256u - b1;
+            const unsigned h0 = __umul24(a0, p00[q]) + __umul24(a1, p01[q]);  // horizontal pass, 8.8
+            const unsigned h1 = __umul24(a0, p10[q]) + __umul24(a1, p11[q]);
+            const unsigned v = __umul24(b0, h0) + __umul24(b1, h1);            // vertical pass, 16.16 (b <= 256, h <= 65280: 24-bit products)
+            const unsigned r = (v + 32768u) >> 16;
+            if (col && ry < rh) D[__mul24(ry, ds) + c] = (uint8_t)(r > 255u ? 255u : r);
+          }
+        }
       }
     }
     __syncthreads();
+    if (l == 1) TILE_STAMP_AT(4);
   }
+  TILE_STAMP_AT(5);
 
-  // ---- FAST score of the owned pixels and one ring around them, all levels in one pass ---------------------------------------
+  // ---- FAST score of the owned pixels and one ring around them, all levels together, in two passes: (a) the compass-point
+  // test of fast.cpp on every pixel — most fail it and get score 0; the others are listed; (b) the 16-point test and
+  // cornerScore on the listed pixels, one per lane with no idle lanes (in one pass a wavefront ran the ~150 instructions of
+  // (b) in nearly every step for the few lanes that needed it: 10.5 of the kernel's 40 us)
+  unsigned *plist = (unsigned *)(lds + a.stash_off);  // (the stash's place: it is not in use yet)
   {
-    const int total = s_pre_sc[nl];
+    const int total = s_pre_sc[nl], thr = a.fast_thr;
     int l = 0;
-    for (int i = tid; i < total; i += ORB_TILE_NT) {
-      while (i >= s_pre_sc[l + 1]) ++l;
-      const int sw = s_x[l].own1 - s_x[l].own0 + 2;
-      int sy, sx;
-      vo_divmod(i - s_pre_sc[l], sw, s_msc[l], sy, sx);
-      const int x = s_x[l].own0 - 1 + sx, y = s_y[l].own0 - 1 + sy;
-      const int st = a.L[l].lds_stride;
-      const uint8_t *p = lds + a.L[l].lds_off + (y - s_y[l].reg0) * st + (x - s_x[l].reg0);
-      lds[a.L[l].sc_off + sy * a.L[l].sc_stride + sx] = (uint8_t)orb_fast_score(p, st, a.fast_thr);
+    for (int i0 = 0; i0 < total; i0 += 4 * ORB_TILE_NT) {
+      bool pass[4];
+      unsigned ent[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = i0 + tid + q * ORB_TILE_NT;
+        pass[q] = false;
+        ent[q] = 0;
+        if (i < total) {
+          while (i >= s_pre_sc[l + 1]) ++l;
+          const int sw = s_x[l].own1 - s_x[l].own0 + 2;
+          int sy, sx;
+          vo_divmod(i - s_pre_sc[l], sw, s_msc[l], sy, sx);
+          const int st = s_L[l].lds_stride;
+          const uint8_t *p = lds + s_L[l].lds_off + __mul24(s_y[l].own0 - 1 + sy - s_y[l].reg0, st) + (s_x[l].own0 - 1 + sx - s_x[l].reg0);
+          const int v = p[0], c0 = v - p[3 * st], c4 = v - p[3], c8 = v - p[-3 * st], c12 = v - p[-3];
+          const int nd = (c0 > thr) + (c4 > thr) + (c8 > thr) + (c12 > thr), nb = (c0 < -thr) + (c4 < -thr) + (c8 < -thr) + (c12 < -thr);
+          pass[q] = nd >= 2 || nb >= 2;
+          ent[q] = (unsigned)l | ((unsigned)sy << 8) | ((unsigned)sx << 20);
+          if (!pass[q]) lds[s_L[l].sc_off + __mul24(sy, s_L[l].sc_stride) + sx] = 0;
+        }
+      }
+      int r[4], tot = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int nq;
+        r[q] = tot + orb_wave_rank(pass[q], &nq);
+        tot += nq;
+      }
+      int base = 0;
+      if ((tid & 63) == 0 && tot) base = atomicAdd(&s_nstash, tot);
+      base = orb_wave_first(base, (tid & 63) == 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (pass[q]) plist[base + r[q]] = ent[q];
     }
   }
   __syncthreads();
+  {
+    const int n = s_nstash, thr = a.fast_thr;
+    for (int e = tid; e < n; e += ORB_TILE_NT) {
+      const unsigned w = plist[e];
+      const int l = (int)(w & 0xFFu), sy = (int)((w >> 8) & 0xFFFu), sx = (int)(w >> 20);
+      const int st = s_L[l].lds_stride;
+      const uint8_t *p = lds + s_L[l].lds_off + __mul24(s_y[l].own0 - 1 + sy - s_y[l].reg0, st) + (s_x[l].own0 - 1 + sx - s_x[l].reg0);
+      lds[s_L[l].sc_off + __mul24(sy, s_L[l].sc_stride) + sx] = (uint8_t)orb_fast_score(p, st, thr);
+    }
+  }
+  __syncthreads();
+  TILE_STAMP_AT(6);
 
   // ---- strict 3x3 maxima of the score among the owned pixels -> the workgroup's stash -------------------------------------------
+  // all levels in one flattened pass (a pass per level left most lanes idle on the small levels: 8 x 2048 slots for 4 800
+  // pixels); a maximum takes its rank within its level by an LDS atomic. The stash is partitioned by level (a level's part
+  // holds one entry per 2x2 cell of its owned rectangle: cannot overflow), so the rank is the slot.
   unsigned *stash = (unsigned *)(lds + a.stash_off);
   {
     const int total = s_pre_own[nl];
     int l = 0;
-    for (int i = tid; i < total; i += ORB_TILE_NT) {
-      while (i >= s_pre_own[l + 1]) ++l;
-      const int ow = s_x[l].own1 - s_x[l].own0;
-      int oy, ox;
-      vo_divmod(i - s_pre_own[l], ow, s_mown[l], oy, ox);
-      const int scs = a.L[l].sc_stride;
-      const uint8_t *p = lds + a.L[l].sc_off + (oy + 1) * scs + (ox + 1);
-      const int c = p[0];
-      if (c && c > p[-1] && c > p[1] && c > p[-scs - 1] && c > p[-scs] && c > p[-scs + 1] && c > p[scs - 1] && c > p[scs] && c > p[scs + 1]) {
-        const int rank = atomicAdd(&s_cnt[l], 1);
-        const int e = atomicAdd(&s_nstash, 1);
-        if (e < a.stash_cap) {  // (cannot fail: the stash holds one entry per 2x2 cell of every owned rectangle)
+    for (int i0 = 0; i0 < total; i0 += 4 * ORB_TILE_NT) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = i0 + tid + q * ORB_TILE_NT;
+        if (i >= total) continue;
+        while (i >= s_pre_own[l + 1]) ++l;
+        const int ow = s_x[l].own1 - s_x[l].own0, scs = s_L[l].sc_stride;
+        int oy, ox;
+        vo_divmod(i - s_pre_own[l], ow, s_mown[l], oy, ox);
+        const uint8_t *p = lds + s_L[l].sc_off + __mul24(oy + 1, scs) + (ox + 1);
+        const int c = p[0];
+        if (c && c > p[-1] && c > p[1] && c > p[-scs - 1] && c > p[-scs] && c > p[-scs + 1] && c > p[scs - 1] && c > p[scs] && c > p[scs + 1]) {
+          const int e = s_stash_lvl[l] + atomicAdd(&s_cnt[l], 1);
           stash[2 * e] = (unsigned)(s_x[l].own0 + ox) | ((unsigned)(s_y[l].own0 + oy) << 16);
-          stash[2 * e + 1] = (unsigned)l | ((unsigned)c << 8) | ((unsigned)rank << 16);
+          stash[2 * e + 1] = (unsigned)l | ((unsigned)c << 8);
         }
       }
     }
   }
   __syncthreads();
+  TILE_STAMP_AT(7);
   if (tid < nl) s_base[tid] = s_cnt[tid] ? atomicAdd(&a.lvl_total[tid], s_cnt[tid]) : 0;
+  if (tid == 0) {  // running candidate counts: the flat index of the loop below -> (level, rank)
+    int run = 0;
+    for (int l = 0; l < nl; ++l) {
+      s_pre_sc[l] = run;
+      run += s_cnt[l];
+    }
+    s_pre_sc[nl] = run;
+  }
   __syncthreads();
+  TILE_STAMP_AT(8);
 
   // ---- Harris response of every stashed candidate, then out to the level's list ------------------------------------------------
   {
-    const int n = s_nstash < a.stash_cap ? s_nstash : a.stash_cap;
-    for (int e = tid; e < n; e += ORB_TILE_NT) {
+    const int n = s_pre_sc[nl];
+    int l = 0;
+    for (int i = tid; i < n; i += ORB_TILE_NT) {
+      while (i >= s_pre_sc[l + 1]) ++l;
+      const int rank = i - s_pre_sc[l], e = s_stash_lvl[l] + rank;
       const unsigned w0 = stash[2 * e], w1 = stash[2 * e + 1];
-      const int x = (int)(w0 & 0xFFFFu), y = (int)(w0 >> 16), l = (int)(w1 & 0xFFu), c = (int)((w1 >> 8) & 0xFFu), rank = (int)(w1 >> 16);
+      const int x = (int)(w0 & 0xFFFFu), y = (int)(w0 >> 16), c = (int)((w1 >> 8) & 0xFFu);
       const int idx = s_base[l] + rank;
       if (idx >= a.cand_cap) continue;  // the level's list is full: orb_finish_kernel reports it (lvl_total > cand_cap)
-      const float r = orb_harris(lds + a.L[l].lds_off, a.L[l].lds_stride, x - s_x[l].reg0, y - s_y[l].reg0);
-      const int o = a.L[l].cand_base + idx;
+      const float r = orb_harris(lds + s_L[l].lds_off, s_L[l].lds_stride, x - s_x[l].reg0, y - s_y[l].reg0);
+      const int o = s_L[l].cand_base + idx;
       a.cx[o] = (short)x;
       a.cy[o] = (short)y;
       a.cs[o] = (uint8_t)c;
       a.cr[o] = r;
     }
   }
+  TILE_STAMP_AT(9);
+  for (int k = 10; k < 16; ++k) TILE_STAMP_AT(k);
 }
 
 // ---- second launch: cuts, per-bin arg-max, table -----------------------------------------------------------------------------------
@@ -320,8 +427,13 @@ __global__ __launch_bounds__(ORB_ST) void orb_finish_kernel(OrbFinishArgs a) {
   __shared__ int s_hist[256];
   __shared__ unsigned s_prefix;
   __shared__ int s_rank, s_cut, s_kept, s_surv, s_last;
+  __shared__ float s_scale[ORB_MAX_LEVELS];
   const int l = blockIdx.x, tid = threadIdx.x;
+  ORB_SET_PRIO();
+  TILE_STAMP_AT(0);
+  if (tid < a.n_levels) s_scale[tid] = a.scale[tid];  // (the table is decoded with a per-bin level: not from the argument segment)
   const int total = a.lvl_total[l];
+  TILE_STAMP_AT(1);
   const int n = total > a.cand_cap ? 0 : total;
   int surv = 0;
   if (n <= 2 * ORB_ST) {
@@ -406,6 +518,7 @@ __global__ __launch_bounds__(ORB_ST) void orb_finish_kernel(OrbFinishArgs a) {
     surv = s_surv;
   }
   // ---- the last workgroup to get here turns the keys into the table -----------------------------------------------------------
+  TILE_STAMP_AT(2);
   ORB_FENCE_RELEASE();  // every thread: its votes have been performed ...
   __syncthreads();      // ... before thread 0 takes the workgroup's ticket
   if (tid == 0) {
@@ -414,6 +527,7 @@ __global__ __launch_bounds__(ORB_ST) void orb_finish_kernel(OrbFinishArgs a) {
     s_last = (ORB_ATOMIC_INC_AGENT(a.done) == a.n_levels - 1) ? 1 : 0;
   }
   __syncthreads();
+  TILE_STAMP_AT(3);
   if (!s_last) return;
   ORB_FENCE_ACQUIRE();
   // (every load below is issued before the first one is used: the other workgroups' results come from memory)
@@ -451,8 +565,8 @@ __global__ __launch_bounds__(ORB_ST) void orb_finish_kernel(OrbFinishArgs a) {
       if (k != 0ull) {
         const unsigned pos = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
         const int lv = (int)(pos >> 28), py = (int)((pos >> 14) & 0x3FFFu), px = (int)(pos & 0x3FFFu);
-        x = lv ? (float)px * a.scale[lv] : (float)px;
-        y = lv ? (float)py * a.scale[lv] : (float)py;
+        x = lv ? (float)px * s_scale[lv] : (float)px;
+        y = lv ? (float)py * s_scale[lv] : (float)py;
         ORB_ST_AGENT(&a.key[j], 0ull);
       }
       a.tab_has[j] = k != 0ull ? 1 : 0;

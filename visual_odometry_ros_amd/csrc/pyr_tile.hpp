@@ -20,9 +20,19 @@
 #pragma once
 #include "vo_layout.hpp"
 
+#ifndef TILE_STAMP_AT
+#define TILE_STAMP_AT(k)  // (tools/tileprobe.hip defines it: phase time stamps of one workgroup, measurement builds only)
+#endif
+
+#ifndef PYR_SET_PRIO
+#define PYR_SET_PRIO()  // (pyramid.hip: s_setprio 3)
+#endif
+
 #define PYR_NL_MAX 4   // levels produced above the launch's base level (deeper pyramids chain a second launch)
 #define PYR_T0 64      // edge of the base-level tile a workgroup owns (top-level tile: PYR_T0 >> nl)
-#define PYR_NT 256
+#ifndef PYR_NT
+#define PYR_NT 1024  // four wavefronts per SIMD: the level loops are chains of dependent LDS reads (one wavefront per SIMD: 16 us per workgroup, tools/tileprobe.hip)
+#endif
 #define PYR_S0 112     // LDS row strides of the level regions (region edges 109, 53, 25, 11, 4 at most)
 #define PYR_S1 56
 #define PYR_S2 28
@@ -86,17 +96,28 @@ __global__ __launch_bounds__(PYR_NT) void pyr_build_kernel(PyrTileArgs a) {
   // magic reciprocals (vo_divmod) of the run-time widths the loops below divide by, per level
   __shared__ unsigned s_m_size[PYR_NL_MAX + 1], s_m_ndw[PYR_NL_MAX + 1], s_m_wide[PYR_NL_MAX + 1], s_m_mx[PYR_NL_MAX + 1];
 
+  // this image's level descriptors, copied from the kernel arguments by ONE batch of loads (indexed by image and level they
+  // are memory accesses, one round trip each when made one after the other)
+  __shared__ vo_level s_lv[PYR_NL_MAX + 1];
   const int tid = threadIdx.x, z = blockIdx.z;
   const int nl = a.nl;
-  if (tid < 2) {
-    const int tile = tid == 0 ? (int)blockIdx.x % a.tiles_x : (int)blockIdx.x / a.tiles_x;
-    for (int k = 0; k <= nl; ++k) s_dim[tid][k] = tid == 0 ? a.L[z][k].w : a.L[z][k].h;
-    pyr_axis(tile, a.T, nl, s_dim[tid], &s_axis[tid]);
+  PYR_SET_PRIO();  // (a short kernel in front of, or next to, a frame's long-lived wavefronts)
+  TILE_STAMP_AT(0);
+  {
+    constexpr int NW = (int)(sizeof(vo_level) / sizeof(int)) * (PYR_NL_MAX + 1);
+    if (tid < NW) ((int *)s_lv)[tid] = ((const int *)a.L[z])[tid];
   }
   if (tid < 2 * (PYR_NL_MAX + 1)) s_mcnt[tid >> 1][tid & 1] = 0;
   __syncthreads();
+  if (tid < 2) {
+    const int tile = tid == 0 ? (int)blockIdx.x % a.tiles_x : (int)blockIdx.x / a.tiles_x;
+    for (int k = 0; k <= nl; ++k) s_dim[tid][k] = tid == 0 ? s_lv[k].w : s_lv[k].h;
+    pyr_axis(tile, a.T, nl, s_dim[tid], &s_axis[tid]);
+  }
+  __syncthreads();
   const PyrAxis &X = s_axis[0], &Y = s_axis[1];
   const int *wk = s_dim[0], *hk = s_dim[1];
+  TILE_STAMP_AT(1);
 
   if (tid <= nl) s_m_size[tid] = vo_magic(X.size[tid]);
   // ---- stage the base-level region (only pixels inside the image are ever read back: taps are reflected first) -------
@@ -105,15 +126,16 @@ __global__ __launch_bounds__(PYR_NT) void pyr_build_kernel(PyrTileArgs a) {
   {
     const uint8_t *__restrict__ src = a.src[z];
     const int ss = a.sstride[z], x0 = X.lo[0], y0 = Y.lo[0], sx = X.size[0], sy = Y.size[0], w0 = wk[0], h0 = hk[0];
-    const int nch = (sx + 15) >> 4, total = nch * sy;  // at most 7 x 109 pieces: three per thread
+    const int nch = (sx + 15) >> 4, total = nch * sy;  // at most 7 x 109 pieces
     const unsigned m = vo_magic(nch);
     // (a) pieces that lie inside an image row: one 16-byte load each, no branch between a thread's loads (a piece that is
     //     not loaded reads a harmless address instead: the row start of an in-image row, or nothing when the image is
     //     narrower than a piece)
-    vo_u128 v[3];
-    int dst[3], edge[3];
+    constexpr int NP = (7 * 109 + PYR_NT - 1) / PYR_NT;  // pieces per thread
+    vo_u128 v[NP];
+    int dst[NP], edge[NP];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < NP; ++q) {
       const int i = tid + q * PYR_NT;
       int ry, c;
       vo_divmod(i < total ? i : 0, nch, m, ry, c);
@@ -130,12 +152,12 @@ __global__ __launch_bounds__(PYR_NT) void pyr_build_kernel(PyrTileArgs a) {
       }
     }
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
+    for (int q = 0; q < NP; ++q)
       if (dst[q] >= 0) *(vo_u128 *)(s_l0 + dst[q]) = v[q];
     // (b) the pieces at the image's first and last column (tiles at the image edge only), byte by byte; a byte outside the
     //     image is never read back (taps are reflected into the image first)
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < NP; ++q) {
       if (edge[q] < 0) continue;
       int ry, c;
       vo_divmod(edge[q], nch, m, ry, c);
@@ -155,6 +177,7 @@ __global__ __launch_bounds__(PYR_NT) void pyr_build_kernel(PyrTileArgs a) {
       *(vo_u128 *)(s_l0 + ry * PYR_S0 + 16 * c) = wv;
     }
   }
+  TILE_STAMP_AT(2);
   // ---- the mirror lists of every level (2 * VO_PAD border coordinates per level and axis) --------------------------------
   for (int i = tid; i < (nl + 1) * 2 * (2 * VO_PAD); i += PYR_NT) {
     const int k = i / (4 * VO_PAD), r = i - k * (4 * VO_PAD), axis = r / (2 * VO_PAD), q = r - axis * (2 * VO_PAD);
@@ -176,6 +199,7 @@ __global__ __launch_bounds__(PYR_NT) void pyr_build_kernel(PyrTileArgs a) {
     s_m_mx[tid] = vo_magic(s_mcnt[tid][0]);
   }
   if (nl == 0) __syncthreads();
+  TILE_STAMP_AT(3);
 
   // ---- level k + 1 from level k, in LDS ------------------------------------------------------------------------
   for (int k = 0; k < nl; ++k) {
@@ -216,13 +240,15 @@ __global__ __launch_bounds__(PYR_NT) void pyr_build_kernel(PyrTileArgs a) {
       D[ry * dsd + rx] = (uint8_t)((s + 128) >> 8);
     }
     __syncthreads();
+    if (k == 0) TILE_STAMP_AT(4);
   }
+  TILE_STAMP_AT(5);
 
   // ---- write what this workgroup owns of every level ----------------------------------------------------------------
   for (int k = a.write_base ? 0 : 1; k <= nl; ++k) {
     const uint8_t *S = pyr_lds_level(s_l0, s_l1, s_l2, s_l3, s_l4, k);
     const int ssd = pyr_lds_stride(k);
-    const vo_level Lv = a.L[z][k];
+    const vo_level Lv = s_lv[k];
     uint8_t *org = Lv.base + (size_t)VO_PAD * Lv.stride + VO_PAD;  // pixel (0, 0)
     const int x0 = X.o0[k], x1 = X.o1[k], y0 = Y.o0[k], y1 = Y.o1[k];
     const int nx = x1 - x0, ny = y1 - y0;
@@ -260,5 +286,7 @@ __global__ __launch_bounds__(PYR_NT) void pyr_build_kernel(PyrTileArgs a) {
       const int y = y0 + ry, px = s_mdst[k][0][e], sx = s_msrc[k][0][e];
       org[(ptrdiff_t)y * Lv.stride + px] = S[(y - ly) * ssd + (sx - lx)];
     }
+    if (k == 0) TILE_STAMP_AT(6);
   }
+  TILE_STAMP_AT(7);
 }

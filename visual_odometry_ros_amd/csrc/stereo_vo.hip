@@ -282,6 +282,17 @@ static const bool g_trace = getenv("VO_SVO_TRACE") != nullptr;  // (read once, n
 static int svo_ingest(vo_svo *s, const void *left, const void *right, int stride, int on_device, bool detect = true) {
   vo_ctx *c = s->c;
   const int W = s->prm.frame.width, H = s->prm.frame.height;
+  // A pair that comes WITH its frame (no look-ahead: detect == false) is ingested on the main stream: the frame kernel, which
+  // is enqueued right behind it, then needs no cross-queue wait for the pyramids (an event pair between two queues costs
+  // ~15-30 us on this stack); the detector on the side stream is the one that waits for the slot's event — it has the slack.
+  struct IngestHere {
+    vo_ctx *c;
+    int keep;
+    IngestHere(vo_ctx *ctx, bool main_stream) : c(ctx), keep(ctx->ingest_side) {
+      if (main_stream) c->ingest_side = 0;
+    }
+    ~IngestHere() { c->ingest_side = keep; }
+  } here(c, !detect);
   if (s->prm.rectify) {
     // flagDoUndistortion (stereo_vo.cpp:414-421): rectifyStereoImages + convertTo(CV_8UC1), fused into the pyramid build
     if (on_device) {
