@@ -35,6 +35,9 @@ static int emu_wave_scratch[64 * 64];
 static inline void __syncthreads() { pthread_barrier_wait(&emu_block_barrier); }
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+#define VO_ALIGNBYTE(hi, lo, n) ((uint32_t)(((((uint64_t)(uint32_t)(hi)) << 32) | (uint32_t)(lo)) >> (8 * ((n) & 3))))
+
 template <class T>
 static inline T atomicAdd(T *p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 template <class T>
@@ -95,7 +98,6 @@ static void emu_launch(Kernel k, dim3 grid, dim3 block, Args... args) {
 
 // ---- what csrc/orb_device.hpp / orb_tile.hpp ask their includer for -----------------------------------------------------
 #include <math.h>
-static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline int orb_wave_count(bool p) { return emu_wave_sum_i32(p ? 1 : 0); }
 static int emu_wave_scratch2[64 * 64];
 static inline int orb_wave_rank(bool p, int *n) {

@@ -18,6 +18,7 @@ __device__ int g_stamp_block;
   } while (0)
 #endif
 
+#define VO_ALIGNBYTE(hi, lo, n) __builtin_amdgcn_alignbyte((hi), (lo), (n))
 #include "vo_layout.hpp"
 __device__ __forceinline__ int orb_wave_count(bool p) { return __popcll(__ballot(p)); }
 __device__ __forceinline__ int orb_wave_rank(bool p, int *n) {
@@ -49,6 +50,21 @@ __device__ __forceinline__ int orb_wave_first(int v, bool p) {
     }                                                                          \
   } while (0)
 
+// what the shader clock is while this probe runs: a chain of dependent adds timed by the constant 100 MHz counter
+// (s_memrealtime) and by the shader clock counter (s_memtime)
+__global__ void clock_kernel(unsigned long long *out, int n) {
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_readcyclecounter();
+  int v = threadIdx.x;
+  for (int i = 0; i < n; ++i) {
+    asm volatile("v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1" : "+v"(v));
+  }
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime(), c1 = __builtin_readcyclecounter();
+  if (threadIdx.x == 0) {
+    out[0] = r1 - r0;
+    out[1] = c1 - c0;
+    out[2] = (unsigned long long)v;
+  }
+}
 static void stamp_block(int b) {
 #ifdef TILE_STAMP
   CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_block), &b, sizeof(int)));
@@ -62,7 +78,9 @@ static void print_stamps(const char *what, int n) {
   CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamp), sizeof(h)));
   printf("%s phases of one workgroup (us):", what);
   for (int k = 1; k < n; ++k) printf(" %.2f", (double)(h[k] - h[k - 1]) * 0.01);
-  printf("  | total %.2f\n", (double)(h[n - 1] - h[0]) * 0.01);
+  printf("  | total %.2f", (double)(h[n - 1] - h[0]) * 0.01);
+  if (n == 10) printf("  | FAST compass pass %.2f, full test %.2f", (double)(h[10] - h[5]) * 0.01, (double)(h[6] - h[10]) * 0.01);
+  printf("\n");
 #else
   (void)what;
   (void)n;
@@ -109,6 +127,16 @@ int main(int argc, char **argv) {
   }
   hipStream_t st;
   CK(hipStreamCreate(&st));
+  {
+    unsigned long long *d_clk, h_clk[3];
+    CK(hipMalloc(&d_clk, 64));
+    for (int rep = 0; rep < 2; ++rep) {
+      hipLaunchKernelGGL(clock_kernel, dim3(1), dim3(64), 0, st, d_clk, 25000);
+      CK(hipMemcpy(h_clk, d_clk, sizeof(h_clk), hipMemcpyDeviceToHost));
+      printf("clock probe: 100000 dependent v_add in %.1f us = %.2f ns each; shader-clock counter advanced %llu (%.2f per add; %.0f MHz if it counts shader cycles)\n",
+             h_clk[0] * 0.01, h_clk[0] * 10.0 / 100000.0, h_clk[1], (double)h_clk[1] / 100000.0, (double)h_clk[1] / (h_clk[0] * 0.01));
+    }
+  }
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));

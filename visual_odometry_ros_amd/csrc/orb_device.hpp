@@ -136,6 +136,39 @@ __device__ __forceinline__ float orb_harris(const uint8_t *__restrict__ img, int
   return ((float)a * b - (float)c * c - 0.04f * ((float)a + b) * ((float)a + b)) * scale_sq_sq;
 }
 
+// the same from an image in LDS whose rows start at 4-byte-aligned addresses (orb_tile.hpp): the nine bytes of a row come
+// from three ALIGNED dword reads (a misaligned wide LDS read is several times slower: vo_layout.hpp, vo_bytes4)
+__device__ __forceinline__ float orb_harris_lds(const uint8_t *__restrict__ img4, int stride, int x0, int y0) {
+  int px[9][9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const int off = (y0 - 4 + r) * stride + (x0 - 4), sh = off & 3;
+    const uint32_t *w = (const uint32_t *)(img4 + (off & ~3));
+    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+    const uint32_t lo = VO_ALIGNBYTE(w1, w0, sh), hi = VO_ALIGNBYTE(w2, w1, sh);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      px[r][q] = (int)((lo >> (8 * q)) & 255u);
+      px[r][4 + q] = (int)((hi >> (8 * q)) & 255u);
+    }
+    px[r][8] = (int)((w2 >> (8 * sh)) & 255u);
+  }
+  int a = 0, b = 0, c = 0;
+#pragma unroll
+  for (int r = 1; r < 8; ++r)
+#pragma unroll
+    for (int q = 1; q < 8; ++q) {
+      const int Ix = (px[r][q + 1] - px[r][q - 1]) * 2 + (px[r - 1][q + 1] - px[r - 1][q - 1]) + (px[r + 1][q + 1] - px[r + 1][q - 1]);
+      const int Iy = (px[r + 1][q] - px[r - 1][q]) * 2 + (px[r + 1][q - 1] - px[r - 1][q - 1]) + (px[r + 1][q + 1] - px[r - 1][q + 1]);
+      a += Ix * Ix;
+      b += Iy * Iy;
+      c += Ix * Iy;
+    }
+  const float scale = 1.f / ((1 << 2) * 7 * 255.f);
+  const float scale_sq_sq = scale * scale * scale * scale;
+  return ((float)a * b - (float)c * c - 0.04f * ((float)a + b) * ((float)a + b)) * scale_sq_sq;
+}
+
 // float -> unsigned that orders the same way (NaN aside)
 __device__ __forceinline__ unsigned orb_ord(float r) {
   const unsigned bits = __float_as_uint(r);

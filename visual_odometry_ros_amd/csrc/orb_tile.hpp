@@ -220,11 +220,13 @@ __global__ __launch_bounds__(ORB_TILE_NT) void orb_tile_kernel(OrbTileArgs a) {
           unsigned p00[4], p01[4], p10[4], p11[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const uint8_t *p = S + __mul24((ty[q] >> 16) - sy0, ss) + xo;
-            p00[q] = p[0];
-            p01[q] = p[1];
-            p10[q] = p[ss];
-            p11[q] = p[ss + 1];
+            // (the two source pixels of a row by aligned dword reads: vo_bytes4)
+            const int o = __mul24((ty[q] >> 16) - sy0, ss) + xo;
+            const uint32_t v0 = vo_bytes4(S, o), v1 = vo_bytes4(S, o + ss);
+            p00[q] = v0 & 255u;
+            p01[q] = (v0 >> 8) & 255u;
+            p10[q] = v1 & 255u;
+            p11[q] = (v1 >> 8) & 255u;
           }
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -290,6 +292,7 @@ __global__ __launch_bounds__(ORB_TILE_NT) void orb_tile_kernel(OrbTileArgs a) {
     }
   }
   __syncthreads();
+  TILE_STAMP_AT(10);
   {
     const int n = s_nstash, thr = a.fast_thr;
     for (int e = tid; e < n; e += ORB_TILE_NT) {
@@ -320,9 +323,14 @@ __global__ __launch_bounds__(ORB_TILE_NT) void orb_tile_kernel(OrbTileArgs a) {
         const int ow = s_x[l].own1 - s_x[l].own0, scs = s_L[l].sc_stride;
         int oy, ox;
         vo_divmod(i - s_pre_own[l], ow, s_mown[l], oy, ox);
-        const uint8_t *p = lds + s_L[l].sc_off + __mul24(oy + 1, scs) + (ox + 1);
-        const int c = p[0];
-        if (c && c > p[-1] && c > p[1] && c > p[-scs - 1] && c > p[-scs] && c > p[-scs + 1] && c > p[scs - 1] && c > p[scs] && c > p[scs + 1]) {
+        // the 3x3 neighbourhood by aligned dword reads (vo_bytes4): bytes 0..2 of each word are the row's three scores
+        const uint8_t *sc = lds + s_L[l].sc_off;
+        const int o = __mul24(oy + 1, scs) + ox;  // (the centre's left neighbour)
+        const uint32_t ra = vo_bytes4(sc, o - scs), rb = vo_bytes4(sc, o), rc = vo_bytes4(sc, o + scs);
+        const int c = (int)((rb >> 8) & 255u);
+        const int m0 = (int)(ra & 255u), m1 = (int)((ra >> 8) & 255u), m2 = (int)((ra >> 16) & 255u), m3 = (int)(rb & 255u),
+                  m4 = (int)((rb >> 16) & 255u), m5 = (int)(rc & 255u), m6 = (int)((rc >> 8) & 255u), m7 = (int)((rc >> 16) & 255u);
+        if (c && c > m0 && c > m1 && c > m2 && c > m3 && c > m4 && c > m5 && c > m6 && c > m7) {
           const int e = s_stash_lvl[l] + atomicAdd(&s_cnt[l], 1);
           stash[2 * e] = (unsigned)(s_x[l].own0 + ox) | ((unsigned)(s_y[l].own0 + oy) << 16);
           stash[2 * e + 1] = (unsigned)l | ((unsigned)c << 8);
@@ -355,7 +363,7 @@ __global__ __launch_bounds__(ORB_TILE_NT) void orb_tile_kernel(OrbTileArgs a) {
       const int x = (int)(w0 & 0xFFFFu), y = (int)(w0 >> 16), c = (int)((w1 >> 8) & 0xFFu);
       const int idx = s_base[l] + rank;
       if (idx >= a.cand_cap) continue;  // the level's list is full: orb_finish_kernel reports it (lvl_total > cand_cap)
-      const float r = orb_harris(lds + s_L[l].lds_off, s_L[l].lds_stride, x - s_x[l].reg0, y - s_y[l].reg0);
+      const float r = orb_harris_lds(lds + s_L[l].lds_off, s_L[l].lds_stride, x - s_x[l].reg0, y - s_y[l].reg0);
       const int o = s_L[l].cand_base + idx;
       a.cx[o] = (short)x;
       a.cy[o] = (short)y;
@@ -364,7 +372,6 @@ __global__ __launch_bounds__(ORB_TILE_NT) void orb_tile_kernel(OrbTileArgs a) {
     }
   }
   TILE_STAMP_AT(9);
-  for (int k = 10; k < 16; ++k) TILE_STAMP_AT(k);
 }
 
 // ---- second launch: cuts, per-bin arg-max, table -----------------------------------------------------------------------------------

@@ -78,11 +78,11 @@ __device__ inline int pyr_lds_stride(int k) {
 }
 
 __global__ __launch_bounds__(PYR_NT) void pyr_build_kernel(PyrTileArgs a) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_l0[109 * PYR_S0];
-  __shared__ uint8_t s_l1[53 * PYR_S1];
-  __shared__ uint8_t s_l2[25 * PYR_S2];
-  __shared__ uint8_t s_l3[11 * PYR_S3];
-  __shared__ uint8_t s_l4[4 * PYR_S4];
+  __shared__ __attribute__((aligned(16))) uint8_t s_l0[109 * PYR_S0 + 16];
+  __shared__ __attribute__((aligned(16))) uint8_t s_l1[53 * PYR_S1 + 16];
+  __shared__ __attribute__((aligned(16))) uint8_t s_l2[25 * PYR_S2 + 16];
+  __shared__ __attribute__((aligned(16))) uint8_t s_l3[11 * PYR_S3 + 16];
+  __shared__ __attribute__((aligned(16))) uint8_t s_l4[4 * PYR_S4 + 16];
   // mirror lists: the padded coordinates of a level's border whose REFLECT_101 source lies in this workgroup's owned
   // interval — (destination padded coordinate, source coordinate), per level and axis; a border is VO_PAD wide on each side
   __shared__ short s_mdst[PYR_NL_MAX + 1][2][2 * VO_PAD];
@@ -264,8 +264,7 @@ __global__ __launch_bounds__(PYR_NT) void pyr_build_kernel(PyrTileArgs a) {
       const uint8_t *sp = S + (y - ly) * ssd + (x - lx);
       uint8_t *dp = org + (ptrdiff_t)y * Lv.stride + x;
       if (x + 3 < x1) {
-        const uint32_t v = (uint32_t)sp[0] | ((uint32_t)sp[1] << 8) | ((uint32_t)sp[2] << 16) | ((uint32_t)sp[3] << 24);
-        *(uint32_t *)dp = v;
+        *(uint32_t *)dp = vo_bytes4(S, (y - ly) * ssd + (x - lx));  // (aligned dword reads: the region's column offset is even, not a multiple of 4)
       } else {  // the image's last columns: the bytes behind them are border pixels (another interval's mirror images)
         for (int q = 0; x + q < x1; ++q) dp[q] = sp[q];
       }

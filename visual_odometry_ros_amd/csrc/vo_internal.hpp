@@ -11,6 +11,7 @@
 
 #include "../../include/vo_hip.h"
 
+#define VO_ALIGNBYTE(hi, lo, n) __builtin_amdgcn_alignbyte((hi), (lo), (n))
 #include "vo_layout.hpp"   // VO_PAD, VO_MAX_LEVELS, vo_level, vo_reflect101
 #define VO_WAVE 64
 

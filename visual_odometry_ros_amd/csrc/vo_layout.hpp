@@ -38,3 +38,13 @@ struct __attribute__((packed, aligned(1))) vo_u128_unaligned {
 struct __attribute__((aligned(16))) vo_u128 {
   uint32_t v[4];
 };
+
+// Four consecutive bytes at any byte offset of a 4-byte-aligned array, by two ALIGNED dword reads and a byte shift. For LDS:
+// a multi-byte ds_read at a misaligned address (what the compiler makes of two adjacent byte loads) is several times slower
+// on gfx950 than aligned reads — measured in tools/tileprobe.hip: the detector's resize phase 20 us with merged misaligned
+// 16-bit reads, 11 us with separate byte reads. VO_ALIGNBYTE(hi, lo, n) = bytes n .. n + 3 of the 8 bytes (hi : lo): the
+// includer's (v_alignbyte_b32 on the device).
+__device__ inline uint32_t vo_bytes4(const uint8_t *base4, int off) {
+  const uint32_t *w = (const uint32_t *)(base4 + (off & ~3));
+  return VO_ALIGNBYTE(w[1], w[0], off & 3);
+}
