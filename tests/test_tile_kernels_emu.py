@@ -34,8 +34,8 @@ def _reflect(p, n):
     return p
 
 
-@pytest.mark.parametrize("w,h,top,nimg", [(333, 251, 4, 2), (64, 48, 6, 1), (47, 33, 6, 1), (1241, 376, 4, 1), (640, 240, 3, 1),
-                                          (752, 480, 5, 1), (90, 70, 1, 1), (65, 65, 0, 1), (130, 40, 2, 1)])
+@pytest.mark.parametrize("w,h,top,nimg", [(333, 251, 4, 2), (64, 48, 6, 1), (47, 33, 6, 1), (1241, 376, 4, 1), (160, 120, 3, 1),
+                                          (200, 150, 5, 1), (90, 70, 1, 1), (65, 65, 0, 1), (130, 40, 2, 1)])
 def test_pyramid_tile_kernel_every_padded_byte(oracle, emu_pyr, tmp_path, w, h, top, nimg):
     """pyr_build_kernel: every byte of every padded level plane — the level itself and its REFLECT_101 border, 40 pixels wide,
     also where a level is narrower than the border (several reflections) and where the pyramid needs a second launch (more
@@ -78,15 +78,15 @@ def _noise(w, h):
     return np.random.default_rng(0).integers(0, 256, (h, w), dtype=np.uint8)
 
 
-ORB_CASES = [  # image, FAST threshold, bins, ORB overrides, tile
+ORB_CASES = [  # image, FAST threshold, bins, ORB overrides, tile (one case at full size; the others smaller: the harness runs OS threads)
     (lambda: _frame(4, 1241, 376), 15, (60, 25), {}, None),
-    (lambda: _frame(9, 1241, 376), 7, (60, 25), dict(nfeatures=600), None),      # both cuts bite; 16 candidates per lane
-    (lambda: _frame(4, 1241, 376), 10, (20, 12), dict(nfeatures=0), None),
-    (lambda: _frame(4, 1241, 376), 12, (20, 12), dict(n_levels=3, scale_factor=1.5, edge_threshold=16), None),
-    (lambda: _frame(5, 752, 480), 20, (40, 25), {}, None),
-    (lambda: np.full((480, 752), 90, np.uint8), 20, (20, 12), {}, None),
-    (lambda: _noise(752, 480), 20, (40, 25), {}, None),                          # levels beyond 16 384 candidates
-    (lambda: _frame(3, 640, 240), 15, (20, 8), {}, (64, 48)),                     # another tile size
+    (lambda: _frame(9, 620, 188), 7, (30, 12), dict(nfeatures=300), None),        # both cuts bite
+    (lambda: _frame(4, 620, 188), 10, (20, 12), dict(nfeatures=0), None),
+    (lambda: _frame(4, 620, 188), 12, (20, 12), dict(n_levels=3, scale_factor=1.5, edge_threshold=16), None),
+    (lambda: _frame(5, 376, 240), 20, (20, 12), {}, None),
+    (lambda: np.full((240, 376), 90, np.uint8), 20, (20, 12), {}, None),
+    (lambda: _noise(600, 320), 20, (30, 16), {}, None),                          # levels beyond 16 384 candidates
+    (lambda: _frame(3, 640, 240), 15, (20, 8), {}, (40, 24)),                     # another tile size
 ]
 
 
