@@ -65,9 +65,17 @@ CONFIGS = {
     2: dict(kind="mono", name="BASELINE configs[2]", metric="mono VO frames/sec @752x480, 1000 feats",
             W=752, H=480, K=(458.654, 457.296, 367.215, 248.375), n_u=40, n_v=25, win=15, max_level=5, speed=0.25,
             margin=31.0, thres=(20.0, 1.0, 5, 1.0), thres_fast=15),
+    # configs[4]: the KITTI rig's field of view at three times the resolution. The camera advances a third of configs[1]'s
+    # distance per frame (a 4K camera at three times the frame rate): the per-frame flow in PIXELS then equals configs[1]'s —
+    # what 5 pyramid levels x a 21-pixel window can follow — and the track set fills the 100 x 80 buckets (at 0.8 m per frame
+    # half of the tracks died every frame and the stream carried ~3000 of the 8000, every frame a keyframe: round 4).
     4: dict(kind="stereo", name="BASELINE configs[4]", metric="stereo VO frames/sec @3840x2160, 8000 feats",
             W=3840, H=2160, K=(718.856 * 3.0, 718.856 * 3.0, 1920.0, 1080.0), n_u=100, n_v=80, win=21, max_level=4,
-            speed=0.8, margin=31.0, thres=(80.0, 0.5, 3.0), thres_fast=15),
+            speed=0.8 / 3.0, tex_scale=1.0 / 3.0, margin=31.0, thres=(80.0, 0.5, 3.0), thres_fast=15,
+            # feature_tracker.thres_sampson above 100: step [7] of the reference drops every feature below image row 660
+            # (stereo_vo.cpp:659, a constant) — never at KITTI's 376 rows, 70 % of a 2160-row image: with the KITTI value (60) a 4K
+            # stream cannot hold more than ~3900 of its 8000 buckets (measured). The YAML parameter is the reference's own switch.
+            thres_sampson=120.0),
 }
 UNTRIANGULATED = 0.10  # share of the track set whose landmark has no 3-D point yet (new since the last keyframe)
 N_NEW_OPEN = 150       # candidates of the open-loop comparison workload
@@ -345,7 +353,8 @@ class StereoBench:
         self.n_pts = cfg["n_u"] * cfg["n_v"]
         self.dev = torch.device("cuda", local_rank)
         self.stream = S.StereoStream(width=self.W, height=self.H, K=cfg["K"], n_u=cfg["n_u"], n_v=cfg["n_v"],
-                                     n_new=N_NEW_OPEN, seed=stream_seed(rank), speed=cfg["speed"], margin=cfg["margin"])
+                                     n_new=N_NEW_OPEN, seed=stream_seed(rank), speed=cfg["speed"], margin=cfg["margin"],
+                                     tex_scale=cfg.get("tex_scale", 1.0))
         F = max(args.frames, 3)
         self.F = F
         self.poses = self.stream.poses(F)
@@ -566,7 +575,7 @@ def _render_one(job):
     from visual_odometry_ros_amd import synthetic as S
     cfg, seed, k, n = job
     st = S.StereoStream(width=cfg["W"], height=cfg["H"], K=cfg["K"], n_u=cfg["n_u"], n_v=cfg["n_v"], seed=seed, speed=cfg["speed"],
-                        z_end=scene_length(cfg, n))
+                        z_end=scene_length(cfg, n), tex_scale=cfg.get("tex_scale", 1.0))
     L, R, _ = st.render_pair(st.poses(n)[k])
     return k, L, R
 
@@ -583,7 +592,8 @@ def scene_length(cfg, n_frames):
 def render_stream(cfg, seed, n, workers):
     """The n stereo pairs of a stream (numpy u8), rendered by a process pool. MUST run before this process touches a
     GPU (the pool forks). A cache under /tmp keeps repeated runs of the same box (profiling passes) from re-rendering."""
-    key = f"{cfg['W']}x{cfg['H']}_{seed}_{cfg['speed']}_{n}" + ("" if scene_length(cfg, n) == 600.0 else f"_z{int(scene_length(cfg, n))}")
+    key = f"{cfg['W']}x{cfg['H']}_{seed}_{cfg['speed']:.4f}_{n}" + ("" if scene_length(cfg, n) == 600.0 else f"_z{int(scene_length(cfg, n))}") \
+        + ("" if cfg.get("tex_scale", 1.0) == 1.0 else f"_t{cfg['tex_scale']:.3f}")
     cache = os.path.join(os.environ.get("VO_BENCH_CACHE", "/tmp"), f"vo_bench_stream_{key}.npz")
     if os.path.exists(cache):
         try:
@@ -640,7 +650,7 @@ def run_loop(cfg, args, rank, local_rank, world, torch, V, barrier, dev, imgs, s
     thr = cfg["thres"]
     svo = V.StereoVO(ctx, W, H, cfg["K"], cfg["K"], st.T_lr, cfg["n_u"], cfg["n_v"], thres_fastscore=cfg["thres_fast"],
                      window_size=win, max_level=lvl, thres_error=thr[0], thres_bidirection=thr[1], thres_poseba_error=thr[2],
-                     strict_border=args.strict_border, local_ba=bool(args.lba))
+                     strict_border=args.strict_border, local_ba=bool(args.lba), thres_sampson=cfg.get("thres_sampson", 60.0))
     eff_levels = ctx.pyramid_levels(W, H, win, lvl) + 1
     eff_levels_bwd = ctx.pyramid_levels(W, H, win, lvl - 1) + 1
     # bins that hold a keypoint, per left image: the candidates the frame kernel tracks speculatively (bytes accounting)
@@ -782,7 +792,10 @@ def run_loop(cfg, args, rank, local_rank, world, torch, V, barrier, dev, imgs, s
                         f"{lvl} ({eff_levels} effective levels), thresholds of config/stereo/kitti_00_stereo.yaml; whole operator "
                         "sequence steps [1]-[12] incl. keypoint detection, bucketing, new landmarks (DLT), keyframe rule, "
                         "reconstruction" + (" and local BA" if args.lba else "") + "; one independent stream per GPU; result "
-                        "read back every frame",
+                        "read back every frame"
+                        + (f"; texture cells x {cfg['tex_scale']:.3f} (the same detail per pixel as configs[1])" if cfg.get("tex_scale", 1.0) != 1.0 else "")
+                        + (f"; feature_tracker.thres_sampson {cfg['thres_sampson']:g} (> 100: the reference's row-660 gate of step [7] never "
+                           "fires, as it never does on a 376-row image)" if "thres_sampson" in cfg else ""),
             "track_set": "closed loop",
             "playback": "forward",
             "local_ba": bool(args.lba),
@@ -848,7 +861,7 @@ def growing_window_leg(cfg, args, local_rank, V, barrier, st, ptr, cap):
     ctx = V.Context(device=local_rank, max_width=W, max_height=H, max_points=cap, n_slots=5, max_level=cfg["max_level"])
     svo = V.StereoVO(ctx, W, H, cfg["K"], cfg["K"], st.T_lr, cfg["n_u"], cfg["n_v"], thres_fastscore=cfg["thres_fast"],
                      window_size=cfg["win"], max_level=cfg["max_level"], thres_error=thr[0], thres_bidirection=thr[1],
-                     thres_poseba_error=thr[2], strict_border=args.strict_border, local_ba=bool(args.lba))
+                     thres_poseba_error=thr[2], strict_border=args.strict_border, local_ba=bool(args.lba), thres_sampson=cfg.get("thres_sampson", 60.0))
     pre = LOOP_PRIME_GROWING + min(args.warmup, 5)
     K = min(20, len(ptr) - pre - 2)
     svo.runSequence(ptr, 0, pre)
@@ -876,7 +889,7 @@ def host_image_loop_leg(cfg, args, local_rank, V, barrier, st, imgs, cap, traj):
     ctx = V.Context(device=local_rank, max_width=W, max_height=H, max_points=cap, n_slots=5, max_level=cfg["max_level"])
     svo = V.StereoVO(ctx, W, H, cfg["K"], cfg["K"], st.T_lr, cfg["n_u"], cfg["n_v"], thres_fastscore=cfg["thres_fast"],
                      window_size=cfg["win"], max_level=cfg["max_level"], thres_error=thr[0], thres_bidirection=thr[1],
-                     thres_poseba_error=thr[2], strict_border=args.strict_border, local_ba=bool(args.lba))
+                     thres_poseba_error=thr[2], strict_border=args.strict_border, local_ba=bool(args.lba), thres_sampson=cfg.get("thres_sampson", 60.0))
     host = [(np.ascontiguousarray(L), np.ascontiguousarray(R)) for L, R in imgs]
     F, pre = len(host), LOOP_PRIME + args.warmup
     K = min(args.steps, F - pre - 2)
@@ -923,7 +936,7 @@ def synchronous_leg(cfg, args, local_rank, torch, V, barrier, dev, st, imgs, cap
         ctx = V.Context(device=local_rank, max_width=W, max_height=H, max_points=cap, n_slots=5, max_level=cfg["max_level"])
         svo = V.StereoVO(ctx, W, H, cfg["K"], cfg["K"], st.T_lr, cfg["n_u"], cfg["n_v"], thres_fastscore=cfg["thres_fast"],
                          window_size=cfg["win"], max_level=cfg["max_level"], thres_error=thr[0], thres_bidirection=thr[1],
-                         thres_poseba_error=thr[2], strict_border=args.strict_border, local_ba=bool(args.lba))
+                         thres_poseba_error=thr[2], strict_border=args.strict_border, local_ba=bool(args.lba), thres_sampson=cfg.get("thres_sampson", 60.0))
         src = host if name == "host_images" else dptr
         same, stamps, kinds = [True], [], []
 
@@ -1048,7 +1061,8 @@ def cpu_baseline_loop(cfg, args, st, imgs, traj, V, local_rank):
     def make(sum_mode, tw):
         return StereoVORef(cfg["W"], cfg["H"], cfg["K"], cfg["K"], st.T_lr, cfg["n_u"], cfg["n_v"], thres_fast=cfg["thres_fast"],
                            win=cfg["win"], max_level=cfg["max_level"], thres_err=thr[0], thres_bidir=thr[1], thres_poseba=thr[2],
-                           lba=bool(args.lba), ic_border=border, sum_mode=sum_mode, tree_width=tw, n_threads=cores)
+                           lba=bool(args.lba), ic_border=border, sum_mode=sum_mode, tree_width=tw, n_threads=cores,
+                           thres_sampson=cfg.get("thres_sampson", 60.0))
     ref = make(O.SUM_SEQ, 0)
     t_frames, worst = [], 0.0
     for k in range(nf):
@@ -1063,7 +1077,7 @@ def cpu_baseline_loop(cfg, args, st, imgs, traj, V, local_rank):
                     n_slots=5, max_level=cfg["max_level"])
     svo = V.StereoVO(ctx, cfg["W"], cfg["H"], cfg["K"], cfg["K"], st.T_lr, cfg["n_u"], cfg["n_v"], thres_fastscore=cfg["thres_fast"],
                      window_size=cfg["win"], max_level=cfg["max_level"], thres_error=thr[0], thres_bidirection=thr[1],
-                     thres_poseba_error=thr[2], strict_border=args.strict_border, local_ba=bool(args.lba))
+                     thres_poseba_error=thr[2], strict_border=args.strict_border, local_ba=bool(args.lba), thres_sampson=cfg.get("thres_sampson", 60.0))
     exact, ids_ok, n_lba = True, True, 0
     nf_par = max(nf, min(args.parity_frames, len(imgs)))  # (long enough for the window to reach three keyframes: local BA)
     for k in range(nf_par):

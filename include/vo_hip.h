@@ -270,6 +270,9 @@ typedef struct {
   float thres_err, thres_bidirection, thres_poseba;
   float Kl[4], Kr[4];
   float T_lr[16];
+  float thres_sampson;  /* feature_tracker.thres_sampson (stereo_vo.cpp:245, :395): step [7] keeps a feature whose "distance" —
+                           100 for pts_l1.y > 660, else 0 (:653-668: the epipolar distance itself is commented out in the reference) —
+                           is below it. 60 in kitti_00_stereo.yaml, 0.5 in most others: the same gate; above 100 it never fires */
 } vo_stereo_params;
 
 typedef struct {

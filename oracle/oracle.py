@@ -53,6 +53,7 @@ class StereoParams(C.Structure):
         ("Kl", C.c_float * 4),
         ("Kr", C.c_float * 4),
         ("T_lr", C.c_float * 16),
+        ("thres_sampson", C.c_float),
     ]
 
 
@@ -358,8 +359,9 @@ def compact_indices(mask, alive=None, tracked=None):
 
 
 def make_stereo_params(width, height, win, max_level, thres_err, thres_bidir, thres_poseba, Kl,
-                       Kr, T_lr):
+                       Kr, T_lr, thres_sampson=60.0):
     p = StereoParams()
+    p.thres_sampson = thres_sampson  # feature_tracker.thres_sampson (60 in kitti_00_stereo.yaml)
     p.width, p.height, p.win, p.max_level = width, height, win, max_level
     p.thres_err, p.thres_bidirection, p.thres_poseba = thres_err, thres_bidir, thres_poseba
     for i in range(4):

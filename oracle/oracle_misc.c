@@ -296,7 +296,7 @@ static int stereo_frame_impl(const vo_ref_stereo_params *prm, const uint8_t *I0l
     goto fail;
   }
   counts->gn_iterations = gi.iterations;
-  /* [7] y > 660 gate (thres_sampson 60 < 100) on lmtrack_motion_ok (:653-668) */
+  /* [7] y > 660 gate (THRES_SAMPSON = feature_tracker.thres_sampson, 60 in kitti_00_stereo.yaml) on lmtrack_motion_ok (:653-668) */
   c = 0;
   nba = 0;
   for (int i = 0; i < cur; ++i) {
@@ -304,7 +304,7 @@ static int stereo_frame_impl(const vo_ref_stereo_params *prm, const uint8_t *I0l
     int motion_ok = 1;
     if (!(lm_flags && !(lm_flags[o] & 1))) motion_ok = m[nba++];
     float d = pts_l1[2 * o + 1] > 660 ? 100.f : 0.f;
-    if (motion_ok && d < 60.0f) {
+    if (motion_ok && d < prm->thres_sampson) {
       stage_mask[o] = 4;
       ++c;
     }

@@ -151,6 +151,7 @@ int main(void) {
     sp.thres_err = 80.f;
     sp.thres_bidirection = 0.5f;
     sp.thres_poseba = 3.f;
+    sp.thres_sampson = 60.f;
     memcpy(sp.Kl, K, sizeof(K));
     memcpy(sp.Kr, K, sizeof(K));
     memcpy(sp.T_lr, T_lr, sizeof(T_lr));

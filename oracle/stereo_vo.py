@@ -40,7 +40,7 @@ class StereoVORef:
 
     def __init__(self, width, height, Kl, Kr, T_lr, n_bins_u, n_bins_v, thres_fast=15, win=21, max_level=6, thres_err=80.0,
                  thres_bidir=0.5, thres_poseba=3.0, kf_overlap=0.6, kf_rot_deg=15.0, kf_trans=10.0, kf_window=9, lba=True,
-                 ic_border=O.IC_REFERENCE, sum_mode=O.SUM_SEQ, tree_width=0, n_threads=1, rectify_maps=None):
+                 ic_border=O.IC_REFERENCE, sum_mode=O.SUM_SEQ, tree_width=0, n_threads=1, rectify_maps=None, thres_sampson=60.0):
         """rectify_maps = ((map_u, map_v) of the left camera, (map_u, map_v) of the right one): flagDoUndistortion
         (stereo_vo.cpp:414-421) — every pair is remapped first; Kl / Kr / T_lr are then the rectified camera."""
         self.rectify_maps = rectify_maps
@@ -51,7 +51,7 @@ class StereoVORef:
         self.nu, self.nv, self.thres_fast = n_bins_u, n_bins_v, thres_fast
         self.win, self.max_level = win, max_level
         self.thr = (thres_err, thres_bidir, thres_poseba)
-        self.prm = O.make_stereo_params(width, height, win, max_level, thres_err, thres_bidir, thres_poseba, Kl, Kr, T_lr)
+        self.prm = O.make_stereo_params(width, height, win, max_level, thres_err, thres_bidir, thres_poseba, Kl, Kr, T_lr, thres_sampson)
         self.us, self.vs, self.iu, self.iv = O.weight_bin_init(width, height, n_bins_u, n_bins_v)
         self.kf_overlap = np.float32(kf_overlap)
         self.kf_rot = np.float32(np.float32(kf_rot_deg) * D2R)

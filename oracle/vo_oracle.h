@@ -152,6 +152,7 @@ typedef struct {
   float thres_err, thres_bidirection, thres_poseba;
   float Kl[4], Kr[4];
   float T_lr[16];
+  float thres_sampson; /* feature_tracker.thres_sampson: the y > 660 gate of [7] (stereo_vo.cpp:653-668) */
 } vo_ref_stereo_params;
 
 typedef struct {

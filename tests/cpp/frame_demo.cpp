@@ -80,6 +80,7 @@ int main(int argc, char **argv) {
     prm.thres_err = 80.0f;
     prm.thres_bidirection = 0.5f;
     prm.thres_poseba = 3.0f;
+    prm.thres_sampson = 60.0f;
     for (int i = 0; i < 4; ++i) prm.Kl[i] = prm.Kr[i] = K[i];
     for (int i = 0; i < 16; ++i) prm.T_lr[i] = Tlr[i];
     vo::StereoFramePipeline pipe(ctx, prm, true);

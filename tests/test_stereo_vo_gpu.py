@@ -317,17 +317,21 @@ def test_closed_loop_kitti_size_ids_vs_reference_order_every_frame(seq_report):
 
 
 def test_closed_loop_config5(vo, oracle):
-    """BASELINE configs[4] as a closed loop: 3840x2160, 100x80 buckets, win 21, 5-level pyramid — vo_svo_* on four frames
-    (first pair, three steady-state frames, two keyframes with reconstruction) against the CPU loop."""
+    """BASELINE configs[4] as a closed loop, the stream bench.py --config 4 runs: 3840x2160, 100x80 buckets, win 21, 5-level
+    pyramid, a third of configs[1]'s distance per frame and a third of its texture cell sizes (the same flow and detail per
+    pixel), feature_tracker.thres_sampson = 120 (the reference's row-660 gate of step [7] would drop 70 % of a 2160-row image
+    every frame: stereo_vo.cpp:659) — vo_svo_* on six frames against the CPU loop while the track set fills up (4000+ landmarks)."""
     from oracle.stereo_vo import StereoVORef
+    from visual_odometry_ros_amd import synthetic as S
     W, H, K = 3840, 2160, (718.856 * 3.0, 718.856 * 3.0, 1920.0, 1080.0)
-    st, imgs = _stream(W, H, K, 100, 80, 2, 0.8, 4)
-    ref = StereoVORef(W, H, K, K, st.T_lr, 100, 80, thres_fast=15, win=21, max_level=4, kf_trans=1.0, lba=False,
-                      sum_mode=oracle.SUM_TREE, tree_width=512, ic_border=oracle.IC_REFERENCE, n_threads=16)
+    st = S.StereoStream(width=W, height=H, K=K, n_u=100, n_v=80, seed=2, speed=0.8 / 3.0, tex_scale=1.0 / 3.0)
+    imgs = [st.render_pair(p)[:2] for p in st.poses(6)]
+    ref = StereoVORef(W, H, K, K, st.T_lr, 100, 80, thres_fast=15, win=21, max_level=4, kf_trans=0.5, lba=False,
+                      sum_mode=oracle.SUM_TREE, tree_width=512, ic_border=oracle.IC_REFERENCE, n_threads=16, thres_sampson=120.0)
     c = vo.Context(device=0, max_width=W, max_height=H, max_points=2 * 8000 + 1024, n_slots=5, max_level=4)
     try:
         svo = vo.StereoVO(c, W, H, K, K, st.T_lr, 100, 80, thres_fastscore=15, window_size=21, max_level=4, strict_border=4,
-                          local_ba=False, thres_trans=1.0)
+                          local_ba=False, thres_trans=0.5, thres_sampson=120.0)
         n_kf = 0
         for k, (L, R) in enumerate(imgs):
             gi = svo.trackStereoImages(L, R)
@@ -342,7 +346,8 @@ def test_closed_loop_config5(vo, oracle):
             assert np.array_equal(_bits(g["Xw"][tri]), _bits(ref.Xw[tri])), where
             assert np.array_equal(_bits(np.array(gi.T_wc).reshape(4, 4)), _bits(ref.T_wp)), where
             n_kf += int(bool(gi.is_keyframe))
-        assert len(ref.ids) > 2000 and n_kf >= 2
+        print("config5 track set sizes:", len(ref.ids), "keyframes", n_kf)
+        assert len(ref.ids) > 4000 and n_kf >= 2  # (six frames in; the stream settles near 6900 after ~50: bench.py --config 4)
         svo.close()
     finally:
         c.close()

@@ -31,7 +31,7 @@ class StereoParams(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("win", C.c_int), ("max_level", C.c_int),
                 ("thres_err", C.c_float), ("thres_bidirection", C.c_float),
                 ("thres_poseba", C.c_float), ("Kl", C.c_float * 4), ("Kr", C.c_float * 4),
-                ("T_lr", C.c_float * 16)]
+                ("T_lr", C.c_float * 16), ("thres_sampson", C.c_float)]
 
 
 class FrameCounts(C.Structure):

@@ -618,8 +618,9 @@ class TrackIds:
 
 
 def make_stereo_params(width, height, win, max_level, thres_err, thres_bidir, thres_poseba, Kl, Kr,
-                       T_lr):
+                       T_lr, thres_sampson=60.0):
     p = StereoParams()
+    p.thres_sampson = thres_sampson  # feature_tracker.thres_sampson (60 in kitti_00_stereo.yaml)
     p.width, p.height, p.win, p.max_level = width, height, win, max_level
     p.thres_err, p.thres_bidirection, p.thres_poseba = thres_err, thres_bidir, thres_poseba
     T = _f32(T_lr).reshape(16)
@@ -777,7 +778,7 @@ class StereoVO:
 
     def __init__(self, ctx, width, height, Kl, Kr, T_lr, n_bins_u, n_bins_v, thres_fastscore=15, window_size=21, max_level=6,
                  thres_error=80.0, thres_bidirection=0.5, thres_poseba_error=3.0, thres_alive_ratio=0.6, thres_rotation=15.0,
-                 thres_trans=10.0, n_max_keyframes_in_window=9, strict_border=4, local_ba=True, rectify=False):
+                 thres_trans=10.0, n_max_keyframes_in_window=9, strict_border=4, local_ba=True, rectify=False, thres_sampson=60.0):
         """rectify=True is system_flags_.flagDoUndistortion: the context's stereo rectification maps (StereoCamera.
         initStereoCameraToRectify on the same context) are applied to every incoming pair; Kl / Kr / T_lr are then the
         rectified camera and extrinsics (getRectifiedCamera / getRectifiedStereoPoseLeft2Right)."""
@@ -786,7 +787,7 @@ class StereoVO:
         fe.initParams(width, height, n_bins_u, n_bins_v, THRES_FAST=thres_fastscore)
         p = SvoParams()
         p.frame = make_stereo_params(width, height, window_size, max_level, thres_error, thres_bidirection, thres_poseba_error,
-                                     Kl, Kr, T_lr)
+                                     Kl, Kr, T_lr, thres_sampson)
         p.bins = fe.binParams()
         p.kf_overlap_ratio, p.kf_rotation_deg, p.kf_translation = thres_alive_ratio, thres_rotation, thres_trans
         p.kf_window, p.strict_border, p.local_ba = n_max_keyframes_in_window, int(strict_border), int(bool(local_ba))
@@ -826,6 +827,7 @@ class StereoVO:
                 T_lr, rectify = cam.getRectifiedStereoPoseLeft2Right(), True
             obj = cls(ctx, W, H, Kl, Kr, T_lr, fe["n_bins_u"], fe["n_bins_v"], thres_fastscore=fe["thres_fastscore"],
                       window_size=ft["window_size"], max_level=ft["max_level"], thres_error=ft["thres_error"],
+                      thres_sampson=ft["thres_sampson"],
                       thres_bidirection=ft["thres_bidirection"], thres_poseba_error=me["thres_poseba_error"],
                       thres_alive_ratio=ku["thres_alive_ratio"], thres_rotation=ku["thres_rotation"], thres_trans=ku["thres_trans"],
                       n_max_keyframes_in_window=ku["n_max_keyframes_in_window"], rectify=rectify, **overrides)

@@ -97,6 +97,7 @@ class StereoVO {
     q.frame.thres_err = p.feature_tracker.thres_error;
     q.frame.thres_bidirection = p.feature_tracker.thres_bidirection;
     q.frame.thres_poseba = p.motion_estimator.thres_poseba_error;
+    q.frame.thres_sampson = p.feature_tracker.thres_sampson;
     for (int k = 0; k < 4; ++k) {
       q.frame.Kl[k] = p.Kl[k];
       q.frame.Kr[k] = p.Kr[k];

@@ -544,7 +544,7 @@ static int vo_frame_enqueue_body(vo_ctx *c, const vo_stereo_params *prm, int slo
   }
   RC(vo_gn_enqueue(c, true, false, f->C_X, f->C_pl1, f->C_pr1, n, nullptr, prm->Kl, prm->Kr,
                    prm->T_lr, prm->thres_poseba, 0, dT_prior, f->hdr->dT, f->mG, &f->hdr->gn, true,
-                   n > 0 ? f->stage : nullptr, f->C_orig, 4, 60.0f, n > 0 ? &gf : nullptr));
+                   n > 0 ? f->stage : nullptr, f->C_orig, 4, prm->thres_sampson, n > 0 ? &gf : nullptr));
   vo_wrap_add(f->adv_total, adv_workers);  // (cumulative, like the word the workers count in: only a launch that went out counts)
   if (n_new > 0 && !fused) VO_CHECK_HIP(c, hipStreamWaitEvent(s, c->ev_join, 0));
   VO_TT("gn launch");

@@ -211,13 +211,15 @@ class StereoStream:
 
     def __init__(self, width=KITTI_SIZE[0], height=KITTI_SIZE[1], K=KITTI_K,
                  baseline=KITTI_BASELINE, n_u=60, n_v=25, n_new=150, seed=2, speed=0.8,
-                 depth_noise=0.01, prior_noise=(0.02, 0.002), margin=31.0, z_end=600.0):
-        """z_end: the corridor's end wall [m] — a forward-driving stream of n frames needs n * speed well below it."""
+                 depth_noise=0.01, prior_noise=(0.02, 0.002), margin=31.0, z_end=600.0, tex_scale=1.0):
+        """z_end: the corridor's end wall [m] — a forward-driving stream of n frames needs n * speed well below it.
+        tex_scale: factor on the texture's cell sizes (1/3 for a camera of three times the focal length: the same detail per PIXEL)."""
         self.width, self.height, self.K, self.baseline = width, height, K, baseline
         self.n_u, self.n_v, self.n_new = n_u, n_v, n_new
         self.seed, self.speed = seed, speed
         self.depth_noise, self.prior_noise, self.margin = depth_noise, prior_noise, margin
-        self.scene = CorridorScene(seed=seed, z_end=z_end)
+        self.scene = CorridorScene(seed=seed, z_end=z_end) if tex_scale == 1.0 else \
+            CorridorScene(seed=seed, z_end=z_end, cells=tuple(c * tex_scale for c in (0.035, 0.09, 0.24, 0.65, 1.8, 5.0)))
         self.z_end = z_end
         self.T_lr = stereo_T_lr(baseline)
 
