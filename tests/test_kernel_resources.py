@@ -51,3 +51,28 @@ def test_hot_kernels_use_no_scratch_memory():
             allowed = 16 if "sba_solve_reg" in k else 0
             for v in hit:
                 assert v["ScratchSize [bytes/lane]"] <= allowed and v["VGPRs Spill"] == 0, (src, k, v)
+
+
+# Kernels of the ingestion chain run IN FRONT of a frame kernel while, in the concurrent strict-border arrangements, the replay
+# pool of that frame is already resident and waiting for it — one 276-register wavefront on a SIMD of every compute unit, which
+# leaves 512 - 276 = 236 registers there. A workgroup's wavefronts are spread evenly over the four SIMDs, so a side-chain kernel
+# must satisfy (lanes / 256) x registers (in units of 8) <= 236, or it cannot be placed anywhere until the pool's bounded waits
+# run out (round 5: orb_finish_kernel at 79 registers x 1024 lanes held a mono frame back for 134 ms).
+SIDE_CHAIN = {
+    "pyramid.hip": (("pyr_build_kernel", 512), ("remap_level0_kernel", 256)),
+    "orb_detect.hip": (("orb_tile_kernel", 512), ("orb_finish_kernel", 512), ("orb_select_kernel", 512), ("orb_output_kernel", 1024),
+                       ("orb_score_kernel", 256), ("orb_harris_kernel", 256)),
+}
+
+
+@pytest.mark.skipif(not os.path.exists(B.HIPCC), reason="no hipcc")
+def test_side_chain_kernels_fit_next_to_the_replay_pool():
+    with ThreadPoolExecutor(2) as ex:
+        res = dict(zip(SIDE_CHAIN, ex.map(_usage, SIDE_CHAIN)))
+    for src, kernels in SIDE_CHAIN.items():
+        for k, lanes in kernels:
+            hit = [v for n, v in res[src].items() if k in n]
+            assert hit, (src, k, sorted(res[src]))
+            for v in hit:
+                per_simd = (lanes // 256 if lanes >= 256 else 1) * ((v["VGPRs"] + 7) // 8 * 8)
+                assert per_simd <= 236 and v["ScratchSize [bytes/lane]"] == 0 and v["VGPRs Spill"] == 0, (src, k, lanes, v)

@@ -41,7 +41,7 @@ __device__ __forceinline__ int orb_wave_first(int v, bool p) {
   return m ? __shfl(v, __ffsll((long long)m) - 1) : 0;
 }
 #define ORB_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) uint8_t name[]
-#define ORB_SET_PRIO() __builtin_amdgcn_s_setprio(3)
+#define ORB_SET_PRIO()  // (s_setprio 3 for these short kernels next to the frame kernel: measured, no change — DESIGN.md facts table)
 #define ORB_LD_AGENT(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define ORB_ST_AGENT(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define ORB_ATOMIC_INC_AGENT(p) __hip_atomic_fetch_add((p), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -169,10 +169,9 @@ template <int NQ>
 __device__ __forceinline__ void orb_select_fast(const OrbDev &d, int l, int n, OrbSelShared *S) {
   const OrbLevel &L = d.L[l];
   unsigned key[NQ];
-  float resp[NQ];
   int cut, surv;
   unsigned rcut;
-  orb_select_regs<NQ>(d.cs + L.cand_base, d.cr + L.cand_base, n, L.quota, S, key, resp, &cut, &rcut, &surv);
+  orb_select_regs<NQ>(d.cs + L.cand_base, d.cr + L.cand_base, n, L.quota, S, key, &cut, &rcut, &surv);
   if (threadIdx.x == 0) {
     d.lvl_cut[l] = cut;
     d.lvl_rcut[l] = rcut;
@@ -190,12 +189,12 @@ __global__ __launch_bounds__(ORB_ST) void orb_select_kernel(OrbDev d) {
   const uint8_t *cs = d.cs + L.cand_base;
   const float *cr = d.cr + L.cand_base;
   if (n <= ORB_RC * ORB_ST) {
-    if (n <= 2 * ORB_ST)
-      orb_select_fast<2>(d, l, n, &s_sel);
-    else if (n <= 4 * ORB_ST)
+    if (n <= 4 * ORB_ST)
       orb_select_fast<4>(d, l, n, &s_sel);
     else if (n <= 8 * ORB_ST)
       orb_select_fast<8>(d, l, n, &s_sel);
+    else if (n <= 16 * ORB_ST)
+      orb_select_fast<16>(d, l, n, &s_sel);
     else
       orb_select_fast<ORB_RC>(d, l, n, &s_sel);
     return;

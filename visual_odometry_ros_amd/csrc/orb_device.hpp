@@ -174,6 +174,8 @@ __device__ __forceinline__ unsigned orb_ord(float r) {
   const unsigned bits = __float_as_uint(r);
   return (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
 }
+// ... and back (exact: the map is a bijection on the bit patterns)
+__device__ __forceinline__ float orb_unord(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
 // rank-th largest bin of a 256-bin histogram in LDS: returns the bin, *above = entries in higher bins
 __device__ __forceinline__ int orb_hist_rank(const int *hist, int rank, int *above) {
   int acc = 0, b = 255;
@@ -190,11 +192,16 @@ __device__ __forceinline__ int orb_hist_rank(const int *hist, int rank, int *abo
 // candidates in the registers of one workgroup (NQ per thread, key 0 = no candidate) the n-th largest key is found by
 // bisection on the VALUE: count(key >= t) over the workgroup per step — no sort, no atomics on the data, any order of the
 // candidates. Round 5: one barrier per step instead of two (three rotating count words), the per-thread compare loop
-// sized by the level's candidate count (NQ = 2, 4, 8, 16), and an early exit — as soon as the undecided value interval
+// sized by the level's candidate count (NQ = 4, 8, 16, 32), and an early exit — as soon as the undecided value interval
 // holds at most 64 keys they are gathered and ranked against each other by one wavefront (typically after 10-14 of the
 // 32 steps of a float key). Round 4's form took 28.6 us per image at 1241 x 376 (profiles/r04_a_*: orb_select_kernel).
-#define ORB_ST 1024      // threads of a selecting workgroup
-#define ORB_RC 16        // candidates per thread it can hold in registers
+// 512 lanes: two wavefronts per SIMD. (1024 lanes = four per SIMD: at more than 56 registers per lane such a workgroup cannot be
+// placed on a compute unit where a wavefront of the strict-border replay pool — 276 registers — waits for its frame kernel,
+// and while that pool waits it has one on EVERY compute unit: orb_finish_kernel at 79 registers held a mono frame back for the
+// 134 ms of the pool's bounded waits, then the frame was re-issued. The compiler offers no way to cap the registers below the
+// occupancy-8 budget of 64; tests/test_kernel_resources.py checks lanes / 256 x registers <= 236 for the side-chain kernels.)
+#define ORB_ST 512       // threads of a selecting workgroup
+#define ORB_RC 32        // candidates per thread it can hold in registers
 #define ORB_GATHER 64
 
 struct OrbSelShared {
@@ -264,18 +271,19 @@ __device__ __forceinline__ unsigned orb_kth_largest(const unsigned (&key)[NQ], i
 }
 
 // both cuts of one level with its candidates in registers. cs / cr: the level's candidate scores and responses, n of
-// them (n <= NQ * ORB_ST). On return key[q] = ordered response of candidate tid + q * ORB_ST if it survives both cuts,
-// else 0; *cut, *rcut, *surv as orb_select_kernel always reported them.
+// them (n <= NQ * ORB_ST). On return key[q] = ordered response (orb_ord; orb_unord gives the response back) of candidate
+// tid + q * ORB_ST if it survives both cuts, else 0; *cut, *rcut, *surv as orb_select_kernel always reported them.
+// Register budget: ONE array of NQ live across the barriers — the scores during the first cut, the ordered responses (loaded
+// behind it) during the second. With scores, responses and coordinates all held from the start a 1024-lane workgroup needed
+// 79 registers per lane and no longer fitted next to a wavefront of the strict-border replay pool (orb_tile.hpp).
 template <int NQ>
 __device__ __forceinline__ void orb_select_regs(const uint8_t *__restrict__ cs, const float *__restrict__ cr, int n, int quota,
-                                                OrbSelShared *S, unsigned (&key)[NQ], float (&resp)[NQ], int *cut_out, unsigned *rcut_out,
-                                                int *surv_out) {
+                                                OrbSelShared *S, unsigned (&key)[NQ], int *cut_out, unsigned *rcut_out, int *surv_out) {
   const int tid = threadIdx.x;
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     const int i = tid + q * ORB_ST;
     key[q] = i < n ? (unsigned)cs[i] + 1u : 0u;  // pass 1: score + 1 (0 = no candidate)
-    resp[q] = i < n ? cr[i] : 0.f;
   }
   if (tid < 3) S->cnt[tid] = 0;
   __syncthreads();
@@ -291,7 +299,11 @@ __device__ __forceinline__ void orb_select_regs(const uint8_t *__restrict__ cs, 
   }
   // (2) retainBest(n_l) on the Harris response of what is left
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) key[q] = (key[q] != 0u && (int)key[q] - 1 >= cut) ? orb_ord(resp[q]) : 0u;
+  for (int q = 0; q < NQ; ++q) {
+    const int i = tid + q * ORB_ST;
+    const bool keep_q = key[q] != 0u && (int)key[q] - 1 >= cut;
+    key[q] = keep_q ? orb_ord(cr[i]) : 0u;  // (i < n where keep_q holds)
+  }
   const int kept = orb_count_ge<NQ>(key, 1u, S, phase);
   unsigned rcut = 0u;  // 0 = retainBest leaves the set alone
   int surv = kept;

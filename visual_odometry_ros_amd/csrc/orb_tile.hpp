@@ -412,20 +412,25 @@ __device__ __forceinline__ void orb_finish_vote(const OrbFinishArgs &a, int l, i
 template <int NQ>
 __device__ __forceinline__ int orb_finish_level(const OrbFinishArgs &a, int l, int n, OrbSelShared *S) {
   unsigned key[NQ];
-  float resp[NQ];
-  int xy[NQ];  // the candidates' coordinates: loaded with their scores and responses, in one batch in front of the selection
   int cut, surv;
   unsigned rcut;
   const int base = a.cand_base[l];
+  orb_select_regs<NQ>(a.cs + base, a.cr + base, n, a.quota[l], S, key, &cut, &rcut, &surv);
+  // (the coordinates are loaded now, not with the scores: see orb_select_regs)
+  constexpr int NB = NQ < 4 ? NQ : 4;  // (four candidates' coordinates in flight at a time: registers)
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const int i = (int)threadIdx.x + q * ORB_ST;
-    xy[q] = i < n ? ((int)(unsigned short)a.cx[base + i] | ((int)(unsigned short)a.cy[base + i] << 16)) : 0;
+  for (int q0 = 0; q0 < NQ; q0 += NB) {
+    int x[NB], y[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const int i = (int)threadIdx.x + (q0 + q) * ORB_ST;
+      x[q] = key[q0 + q] != 0u ? a.cx[base + i] : 0;
+      y[q] = key[q0 + q] != 0u ? a.cy[base + i] : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+      if (key[q0 + q] != 0u) orb_finish_vote(a, l, x[q], y[q], orb_unord(key[q0 + q]));
   }
-  orb_select_regs<NQ>(a.cs + base, a.cr + base, n, a.quota[l], S, key, resp, &cut, &rcut, &surv);
-#pragma unroll
-  for (int q = 0; q < NQ; ++q)
-    if (key[q] != 0u) orb_finish_vote(a, l, xy[q] & 0xFFFF, (int)((unsigned)xy[q] >> 16), resp[q]);
   return surv;
 }
 
@@ -443,12 +448,12 @@ __global__ __launch_bounds__(ORB_ST) void orb_finish_kernel(OrbFinishArgs a) {
   TILE_STAMP_AT(1);
   const int n = total > a.cand_cap ? 0 : total;
   int surv = 0;
-  if (n <= 2 * ORB_ST) {
-    surv = orb_finish_level<2>(a, l, n, &s_sel);
-  } else if (n <= 4 * ORB_ST) {
+  if (n <= 4 * ORB_ST) {
     surv = orb_finish_level<4>(a, l, n, &s_sel);
   } else if (n <= 8 * ORB_ST) {
     surv = orb_finish_level<8>(a, l, n, &s_sel);
+  } else if (n <= 16 * ORB_ST) {
+    surv = orb_finish_level<16>(a, l, n, &s_sel);
   } else if (n <= ORB_RC * ORB_ST) {
     surv = orb_finish_level<ORB_RC>(a, l, n, &s_sel);
   } else {

@@ -31,7 +31,7 @@
 #define PYR_NL_MAX 4   // levels produced above the launch's base level (deeper pyramids chain a second launch)
 #define PYR_T0 64      // edge of the base-level tile a workgroup owns (top-level tile: PYR_T0 >> nl)
 #ifndef PYR_NT
-#define PYR_NT 1024  // four wavefronts per SIMD: the level loops are chains of dependent LDS reads (one wavefront per SIMD: 16 us per workgroup, tools/tileprobe.hip)
+#define PYR_NT 512  // two wavefronts per SIMD (tools/tileprobe.hip: 26 us per launch with one, 17 with four — but a workgroup of four per SIMD does not fit next to a wavefront of the strict-border replay pool, which is resident on every compute unit while it waits for the frame kernel)
 #endif
 #define PYR_S0 112     // LDS row strides of the level regions (region edges 109, 53, 25, 11, 4 at most)
 #define PYR_S1 56

@@ -21,7 +21,7 @@
 // rectifying ingestion keeps its own level-0 kernel (remap_level0_kernel) in front of it.
 #include "vo_internal.hpp"
 #include "vo_kernels.hpp"
-#define PYR_SET_PRIO() __builtin_amdgcn_s_setprio(3)
+#define PYR_SET_PRIO()
 #include "pyr_plan.hpp"
 
 // level 0 of an image that goes through Camera::undistortImage / StereoCamera::rectifyStereoImages first
