@@ -99,6 +99,13 @@ def frame_kernel_bytes(win, n, n_l0l1, n_step5, n_cand, levels, levels_bwd, stri
     return klt + IC_BYTES_8D * n_l0l1, (IC_RECORD_BYTES * n if strict else 0) + POINT_IO_BYTES * (n + n_cand)
 
 
+def bins_with_keypoints(fe, slot):
+    """Bins of the image in `slot` that hold a keypoint (bytes accounting of the speculative candidates), through the same two
+    launches the loop uses (the candidate table: table 0, which the loop overwrites before it reads it)."""
+    fe.enqueueCandidates(slot, 0)
+    return int(fe.getCandidates(0)[1].sum())
+
+
 def stamped_counters(config, workload="loop"):
     """HBM traffic (PMC) and VALU instruction counts (SQ) of the dominant kernel from the committed rocprofv3 counter
     passes — quoted only while the kernel's sources still hash to what the passes ran on (a stale file is dropped)."""
@@ -659,8 +666,7 @@ def run_loop(cfg, args, rank, local_rank, world, torch, V, barrier, dev, imgs, s
     n_kp_bins = []
     for k in range(F):
         ctx.set_image_device(4, d_L[k].data_ptr(), W, H, W)
-        fe.resetWeightBin()
-        n_kp_bins.append(int(fe.extractORBwithBinning_fast(4).shape[0]))
+        n_kp_bins.append(bins_with_keypoints(fe, 4))
     ctx.synchronize()
     ptr = [((d_L[k].data_ptr(), W), (d_R[k].data_ptr(), W)) for k in range(F)]
     prefetch = not args.no_prefetch
@@ -1509,8 +1515,7 @@ def run_mono_loop(cfg, args, rank, local_rank, world, torch, V, barrier, dev, im
     n_kp_bins = []
     for k in range(F):
         ctx.set_image_device(2, d_I[k].data_ptr(), W, H, W)
-        fe.resetWeightBin()
-        n_kp_bins.append(int(fe.extractORBwithBinning_fast(2).shape[0]))
+        n_kp_bins.append(bins_with_keypoints(fe, 2))
     ctx.synchronize()
     ptr = [(d_I[k].data_ptr(), W) for k in range(F)]
     prefetch = not args.no_prefetch

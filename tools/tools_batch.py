@@ -16,6 +16,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=48)
     ap.add_argument("--S", default="1,2,4,8")
+    ap.add_argument("--lba", default="0,1")
+    ap.add_argument("--strict", default="0,1,4")
     a = ap.parse_args()
     cfg = bench.CONFIGS[1]
     Ss = [int(v) for v in a.S.split(",")]
@@ -33,13 +35,15 @@ def main():
     cap = 2 * cfg["n_u"] * cfg["n_v"] + 1024
     stt = S.StereoStream(width=W, height=H, K=cfg["K"], n_u=cfg["n_u"], n_v=cfg["n_v"], seed=2, speed=cfg["speed"])
     thr = cfg["thres"]
-    for lba in (0, 1):
-        for strict in (0, 1, 4):
+    for lba in [int(v) for v in a.lba.split(",")]:
+        for strict in [int(v) for v in a.strict.split(",")]:
             c0 = V.Context(device=0, max_width=W, max_height=H, max_points=cap, n_slots=5, max_level=cfg["max_level"])
             svo = V.StereoVO(c0, W, H, cfg["K"], cfg["K"], stt.T_lr, cfg["n_u"], cfg["n_v"], thres_fastscore=cfg["thres_fast"], window_size=cfg["win"],
                              max_level=cfg["max_level"], thres_error=thr[0], thres_bidirection=thr[1], thres_poseba_error=thr[2],
                              strict_border=strict, local_ba=bool(lba))
             prm = svo.prm
+            svo.close()
+            c0.close()  # (its HIP streams must not hold hardware queues while the batch runs)
             row = []
             for Sn in Ss:
                 b = V.StereoBatch(0, Sn, W, H, cap, cfg["max_level"], prm)
@@ -47,8 +51,6 @@ def main():
                 r = b.run(Lp[:Sn], Rp[:Sn], W, warmup=8)
                 b.close()
                 row.append(round(Sn * (a.frames - 8) / r["wall"]))
-            svo.close()
-            c0.close()
             print(f"lba {lba} strict {strict}: aggregate fps for S={Ss}: {row}", flush=True)
 
 
