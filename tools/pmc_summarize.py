@@ -1,4 +1,4 @@
-"""Turns the two rocprofv3 --pmc passes of tools/run_profiles_r02.sh (FETCH_SIZE, WRITE_SIZE; counter_collection CSVs)
+"""Turns the two rocprofv3 --pmc passes of tools/run_profiles.sh (FETCH_SIZE, WRITE_SIZE; counter_collection CSVs)
 into profiles/<tag>_frame_pmc.json: HBM bytes per launch of the dominant kernel and per frame over all kernels, with the
 unit / gfx950 corrections calibrated by tools/pmccal.hip on this access pattern (1 GiB moved once with one dword per
 lane: FETCH_SIZE counts KiB/2 for such loads, WRITE_SIZE KiB — the same x2 the microarchitecture guide gives).
@@ -48,7 +48,7 @@ def main():
                                           "note": f"sum over every kernel of the run / {frames} frames"}
     out["per_kernel_KiB_per_frame"] = {x.split("(")[0][:48]: {"fetch": round(f_per[x] * ff / frames, 1), "write": round(w_per.get(x, 0.0) * wf / frames, 1)}
                                        for x in sorted(f_per, key=lambda q: -f_per[q])[:14]}
-    out["command"] = "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace --output-format csv -- python3 bench.py --no-cpu-baseline --strict-border 1 --no-secondary --steps 60 --warmup 10 (two passes; counter collection serialises kernels across queues, hence the stream-ordered replay; tools/run_profiles_r02.sh)"
+    out["command"] = "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace --output-format csv -- python3 bench.py --no-cpu-baseline --strict-border 1 --no-secondary --steps 60 --warmup 10 (two passes; counter collection serialises kernels across queues, hence the stream-ordered replay; tools/run_profiles.sh)"
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from visual_odometry_ros_amd.build import kernel_source_sha
     out["kernel_source_sha"] = kernel_source_sha()  # bench.py quotes these numbers only while the kernel's sources still hash to this

@@ -1,4 +1,4 @@
-"""Per-kernel averages of the SQ counter passes of tools/run_pmc_sq.sh (counter_collection CSVs) -> profiles/<tag>_frame_sq_counters.json
+"""Per-kernel averages of the SQ counter passes of tools/run_profiles.sh / run_pmc_sq.sh (counter_collection CSVs) -> profiles/<tag>_frame_sq_counters.json
 usage: python tools/sq_summarize.py <dir with a/ and b/> <tag>"""
 import csv
 import glob
@@ -25,7 +25,7 @@ def main():
     out = {"units": "per launch averages; SQ cycle counters in quad-cycles (MI355X_MICROARCH.md)", "kernels": {}}
     for sub in ("a", "b"):
         for k, cs in load(os.path.join(d, sub)).items():
-            if not any(x in k for x in ("frame_track", "frame_replay", "gn_pose", "orb_score", "orb_select", "svo_", "sba_")):
+            if not any(x in k for x in ("frame_track", "frame_replay", "gn_pose", "orb_tile", "orb_finish", "pyr_build", "svo_", "sba_")):
                 continue
             e = out["kernels"].setdefault(k, {})
             for name, (tot, n) in cs.items():
