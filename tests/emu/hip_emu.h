@@ -135,5 +135,6 @@ static inline unsigned __umul24(unsigned a, unsigned b) { return (unsigned)((uns
 #define ORB_LD_AGENT(p) __atomic_load_n((p), __ATOMIC_SEQ_CST)
 #define ORB_ST_AGENT(p, v) __atomic_store_n((p), (v), __ATOMIC_SEQ_CST)
 #define ORB_ATOMIC_INC_AGENT(p) __atomic_fetch_add((p), 1, __ATOMIC_SEQ_CST)
+#define ORB_ATOMIC_ADD_AGENT(p, v) __atomic_fetch_add((p), (v), __ATOMIC_SEQ_CST)
 #define ORB_FENCE_RELEASE() __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define ORB_FENCE_ACQUIRE() __atomic_thread_fence(__ATOMIC_SEQ_CST)

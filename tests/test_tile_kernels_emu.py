@@ -87,6 +87,10 @@ ORB_CASES = [  # image, FAST threshold, bins, ORB overrides, tile (one case at f
     (lambda: np.full((240, 376), 90, np.uint8), 20, (20, 12), {}, None),
     (lambda: _noise(600, 320), 20, (30, 16), {}, None),                          # levels beyond 16 384 candidates
     (lambda: _frame(3, 640, 240), 15, (20, 8), {}, (40, 24)),                     # another tile size
+    (lambda: _noise(600, 320), 20, (30, 16), {}, (48, 32, 3, 16384, 5)),          # three finishing workgroups per level, five histogram copies
+    (lambda: _frame(9, 620, 188), 7, (30, 12), dict(nfeatures=300), (48, 32, 2, 16384, 2)),
+    (lambda: _frame(4, 620, 188), 10, (20, 12), {}, (48, 32, 2, 64)),             # more first-cut survivors than the list holds: radix path
+    (lambda: _frame(6, 640, 240), 15, (20, 8), {}, (56, 48, 2, 16384, 3)),        # the large images' tile (80 KB of LDS)
 ]
 
 
@@ -109,7 +113,7 @@ def test_orb_tile_kernels_table(oracle, emu_orb, tmp_path, case):
     args = [emu_orb, str(w), str(h), str(prm["n_levels"]), repr(prm["scale_factor"]), str(prm["nfeatures"]), str(prm["edge_threshold"]),
             str(thr), str(nbu), str(nbv), "%08x" % iu.view(np.uint32), "%08x" % iv.view(np.uint32), str(fin), str(fout)]
     if tile:
-        args += [str(tile[0]), str(tile[1])]
+        args += [str(v) for v in tile]  # (tile_w, tile_h[, finishing workgroups per level, capacity of a level's survivor list[, histogram copies]])
     subprocess.check_call(args)
     raw = fout.read_bytes()
     assert struct.unpack_from("i", raw, 0)[0] == 1  # the plan fits
@@ -121,7 +125,7 @@ def test_orb_tile_kernels_table(oracle, emu_orb, tmp_path, case):
     d = oracle.orb_detect(img, thr, nfeatures=prm["nfeatures"], scale_factor=prm["scale_factor"], n_levels=prm["n_levels"],
                           edge_threshold=prm["edge_threshold"], max_kp=400000)
     cand, _ = oracle.bucket_argmax(d["xy"], d["response"], iu, iv, nbu, nbv, np.ones(nbu * nbv, np.int32))
-    assert (flags, dirty) == (0, 0) and lds <= 64 * 1024
+    assert (flags, dirty) == (0, 0) and lds <= (96 if tile and tile[0] > 48 else 64) * 1024
     assert n_det == d["xy"].shape[0]
     assert set(np.unique(has).tolist()) <= {0, 1} and int(has.sum()) == cand.shape[0]
     assert np.array_equal(xy[has == 1].view(np.uint32), cand.view(np.uint32)) and np.all(xy[has == 0] == 0)

@@ -35,6 +35,7 @@ __device__ __forceinline__ int orb_wave_first(int v, bool p) {
 #define ORB_LD_AGENT(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define ORB_ST_AGENT(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define ORB_ATOMIC_INC_AGENT(p) __hip_atomic_fetch_add((p), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define ORB_ATOMIC_ADD_AGENT(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define ORB_FENCE_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
 #define ORB_FENCE_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
 #define PYR_SET_PRIO() __builtin_amdgcn_s_setprio(3)
@@ -168,12 +169,18 @@ int main(int argc, char **argv) {
   float lscale[ORB_MAX_LEVELS];
   orb_level_layout(w, h, nl, 1.2, nfeatures, lw, lh, lscale, quota);
   OrbTilePlan P;
-  orb_tile_plan(lw, lh, nl, edge, 48, 32, 64 * 1024, &P);
+  const int tile_w = getenv("TILE_W") ? atoi(getenv("TILE_W")) : 48, tile_h = getenv("TILE_H") ? atoi(getenv("TILE_H")) : 32;
+  orb_tile_plan(lw, lh, nl, edge, tile_w, tile_h, 160 * 1024, &P);
+  if (!P.ok) {
+    printf("tile %d x %d: the plan does not fit\n", tile_w, tile_h);
+    return 1;
+  }
+  if (P.lds_bytes > 64 * 1024) CK(hipFuncSetAttribute((const void *)orb_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P.lds_bytes));
   if (!P.ok) {
     printf("plan does not fit\n");
     return 0;
   }
-  const int cand_cap = 65536, nbins = nbu * nbv;
+  const int cand_cap = (((size_t)w * h / 16 > 65536 ? (int)((size_t)w * h / 16) : 65536) + 15) & ~15, nbins = nbu * nbv;
   auto dalloc = [&](size_t bytes, const void *init) {
     void *p;
     CK(hipMalloc(&p, bytes));
@@ -212,6 +219,9 @@ int main(int argc, char **argv) {
     T.taby = l ? (const int *)dalloc(sizeof(int) * P.taby[l].size(), P.taby[l].data()) : nullptr;
   }
   a.lvl_total = (int *)dalloc(sizeof(int) * nl, nullptr);
+  a.hist_copies = getenv("HIST_COPIES") ? atoi(getenv("HIST_COPIES")) : (P.nx * P.ny / 64 < 1 ? 1 : (P.nx * P.ny / 64 > 64 ? 64 : P.nx * P.ny / 64));
+  const size_t hist_bytes = sizeof(int) * 256 * ORB_MAX_LEVELS * (size_t)a.hist_copies;
+  a.hist = (int *)dalloc(hist_bytes, nullptr);
   a.cx = (short *)dalloc(sizeof(short) * (size_t)cand_cap * nl, nullptr);
   a.cy = (short *)dalloc(sizeof(short) * (size_t)cand_cap * nl, nullptr);
   a.cs = (uint8_t *)dalloc((size_t)cand_cap * nl, nullptr);
@@ -227,6 +237,15 @@ int main(int argc, char **argv) {
     f.scale[l] = lscale[l];
   }
   f.lvl_total = a.lvl_total;
+  f.parts = getenv("FINISH_PARTS") ? atoi(getenv("FINISH_PARTS")) : (int)(((size_t)w * h / 40 + 8191) / 8192);
+  if (f.parts < 1) f.parts = 1;
+  if (f.parts > 32) f.parts = 32;
+  f.cidx_cap = ORB_RC * ORB_ST;
+  f.hist = a.hist;
+  f.hist_copies = a.hist_copies;
+  f.cidx = (int *)dalloc(sizeof(int) * (size_t)f.cidx_cap * ORB_MAX_LEVELS, nullptr);
+  f.lvl_cnt = (int *)dalloc(sizeof(int) * 2 * ORB_MAX_LEVELS, nullptr);
+  f.lvl_done = f.lvl_cnt + ORB_MAX_LEVELS;
   f.cx = a.cx;
   f.cy = a.cy;
   f.cs = a.cs;
@@ -246,7 +265,7 @@ int main(int argc, char **argv) {
   f.dev_flags = (int *)dalloc(16, nullptr);
   auto det = [&](int which) {
     if (which & 1) hipLaunchKernelGGL(orb_tile_kernel, dim3(a.nx * a.ny), dim3(ORB_TILE_NT), (size_t)P.lds_bytes, st, a);
-    if (which & 2) hipLaunchKernelGGL(orb_finish_kernel, dim3(nl), dim3(ORB_ST), 0, st, f);
+    if (which & 2) hipLaunchKernelGGL(orb_finish_kernel, dim3(nl * f.parts), dim3(ORB_ST), 0, st, f);
   };
   for (int k = 0; k < 5; ++k) det(3);
   CK(hipStreamSynchronize(st));
@@ -266,6 +285,7 @@ int main(int argc, char **argv) {
   CK(hipEventElapsedTime(&ms, e0, e1));
   printf("orb_tile_kernel alone, back to back: %.2f us per launch\n", 1e3 * ms / reps);
   CK(hipMemsetAsync(a.lvl_total, 0, sizeof(int) * nl, st));
+  CK(hipMemsetAsync(a.hist, 0, hist_bytes, st));
   // each alone: the tile kernel needs its counters zeroed by the finish kernel, so time (tile + finish) - finish via a third run
   std::vector<int> totals(nl);
   stamp_block(a.nx * (a.ny / 2) + a.nx / 2);
@@ -282,14 +302,19 @@ int main(int argc, char **argv) {
   print_stamps("orb_finish_kernel (level 0)", 4);
   // finish alone, repeatedly (the lists stay what they are: restore the totals in front of every launch)
   int *d_tot = (int *)dalloc(sizeof(int) * nl, totals.data());
+  int *d_hist = (int *)dalloc(hist_bytes, nullptr);
+  det(1);  // (the finish launch above zeroed the counters and the histogram: fill them again and keep a copy)
+  CK(hipMemcpyAsync(d_hist, a.hist, hist_bytes, hipMemcpyDeviceToDevice, st));
+  det(2);
   CK(hipEventRecord(e0, st));
   for (int k = 0; k < reps; ++k) {
     CK(hipMemcpyAsync(a.lvl_total, d_tot, sizeof(int) * nl, hipMemcpyDeviceToDevice, st));
+    CK(hipMemcpyAsync(a.hist, d_hist, hist_bytes, hipMemcpyDeviceToDevice, st));
     det(2);
   }
   CK(hipEventRecord(e1, st));
   CK(hipEventSynchronize(e1));
   CK(hipEventElapsedTime(&ms, e0, e1));
-  printf("orb_finish_kernel (+ one 32-byte copy): %.2f us per launch\n", 1e3 * ms / reps);
+  printf("orb_finish_kernel x %d workgroups per level (+ two small copies): %.2f us per launch\n", f.parts, 1e3 * ms / reps);
   return 0;
 }

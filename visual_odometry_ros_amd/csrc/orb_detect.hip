@@ -45,6 +45,7 @@ __device__ __forceinline__ int orb_wave_first(int v, bool p) {
 #define ORB_LD_AGENT(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define ORB_ST_AGENT(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define ORB_ATOMIC_INC_AGENT(p) __hip_atomic_fetch_add((p), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define ORB_ATOMIC_ADD_AGENT(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define ORB_FENCE_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
 #define ORB_FENCE_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
 #include "orb_tile.hpp"
@@ -345,7 +346,8 @@ struct vo_orb_state {
   vo_cand_table tab[2];  // closed step [10]: double-buffered so that frame k reads one while the detection of k+1 fills the other
   // the tile kernels of the per-bin table (orb_tile.hpp): plan of the current configuration, its tables in the arena
   OrbTilePlan plan;
-  size_t o_gx = 0, o_gy = 0, o_tx[ORB_MAX_LEVELS] = {0}, o_ty[ORB_MAX_LEVELS] = {0}, o_surv = 0, o_done = 0, o_devflags = 0;
+  size_t o_gx = 0, o_gy = 0, o_tx[ORB_MAX_LEVELS] = {0}, o_ty[ORB_MAX_LEVELS] = {0}, o_surv = 0, o_done = 0, o_devflags = 0, o_thist = 0, o_cidx = 0, o_lcnt = 0;
+  int finish_parts = 1, hist_copies = 1;
   bool tile_clean = false;  // lvl_total / done / keys are zero (the tile kernels leave them so; the per-stage kernels do not)
 };
 
@@ -391,6 +393,7 @@ static int orb_prepare(vo_ctx *c, int w, int h, const vo_orb_params *p, int max_
     return o;
   };
   S->cand_cap_level = (w * (size_t)h / 16 > 65536) ? (int)(w * (size_t)h / 16) : 65536;  // NMS corners are far sparser
+  S->cand_cap_level = (S->cand_cap_level + 15) & ~15;  // (orb_finish_kernel reads a level's scores four to a word)
   S->cand_cap = S->cand_cap_level;
   // the Harris launch covers the candidates a level can realistically hold; beyond that the tail of its grid idles
   S->harris_blocks = S->cand_cap_level;
@@ -430,6 +433,15 @@ static int orb_prepare(vo_ctx *c, int w, int h, const vo_orb_params *p, int max_
   // the tile kernels' plan of this configuration (orb_plan.hpp); 48 x 32 level-0 pixels per workgroup: 312 workgroups at
   // 1241 x 376, 36 KB of LDS each
   orb_tile_plan(S->lw, S->lh, p->n_levels, p->edge_threshold, 48, 32, 64 * 1024, &S->plan);
+  if (S->plan.ok && S->plan.nx * S->plan.ny > 1024) {
+    // a large image has workgroups to spare: larger tiles recompute less halo (staged / owned pixels 2.9 instead of 3.8 at
+    // 3840 x 2160; 80 KB of LDS, two workgroups per compute unit): 360 against 425 us for the two launches (tools/tileprobe.hip)
+    OrbTilePlan big;
+    orb_tile_plan(S->lw, S->lh, p->n_levels, p->edge_threshold, 56, 48, 96 * 1024, &big);
+    if (big.ok) S->plan = big;
+  }
+  if (S->plan.ok && S->plan.lds_bytes > 64 * 1024)
+    VO_CHECK_HIP(c, hipFuncSetAttribute((const void *)orb_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S->plan.lds_bytes));
   if (S->plan.ok) {
     S->o_gx = take(sizeof(OrbSpan) * S->plan.gx.size());
     S->o_gy = take(sizeof(OrbSpan) * S->plan.gy.size());
@@ -438,6 +450,17 @@ static int orb_prepare(vo_ctx *c, int w, int h, const vo_orb_params *p, int max_
       S->o_ty[l] = take(sizeof(int) * S->plan.taby[l].size());
     }
     S->o_surv = take(sizeof(int) * ORB_MAX_LEVELS);
+    S->hist_copies = S->plan.nx * S->plan.ny / 64;
+    if (S->hist_copies < 1) S->hist_copies = 1;
+    if (S->hist_copies > 64) S->hist_copies = 64;
+    S->o_thist = take(sizeof(int) * 256 * ORB_MAX_LEVELS * (size_t)S->hist_copies);
+    S->o_cidx = take(sizeof(int) * (size_t)ORB_RC * ORB_ST * ORB_MAX_LEVELS);
+    S->o_lcnt = take(sizeof(int) * 2 * ORB_MAX_LEVELS);
+    // workgroups per level of orb_finish_kernel: a slice of at most ~8 000 candidates each on the fullest level one can expect
+    // (a 3 x 3 maximum per ~40 pixels on a textured image): 1 at 1241 x 376, 26 at 3840 x 2160
+    S->finish_parts = (int)((w * (size_t)h / 40 + 8191) / 8192);
+    if (S->finish_parts < 1) S->finish_parts = 1;
+    if (S->finish_parts > 32) S->finish_parts = 32;
     S->o_done = take(sizeof(int) * 4);
     S->o_devflags = take(sizeof(int) * 4);
   }
@@ -488,6 +511,8 @@ static int orb_tile_enqueue(vo_ctx *c, int slot, const vo_bin_params *bp, vo_can
   if (!S->tile_clean) {  // (once after the per-stage kernels ran on this arena, never in a steady stream)
     VO_CHECK_HIP(c, hipMemsetAsync(A + S->o_total, 0, sizeof(int) * p->n_levels, s));
     VO_CHECK_HIP(c, hipMemsetAsync(A + S->o_done, 0, sizeof(int) * 4, s));
+    VO_CHECK_HIP(c, hipMemsetAsync(A + S->o_thist, 0, sizeof(int) * 256 * ORB_MAX_LEVELS * (size_t)S->hist_copies, s));
+    VO_CHECK_HIP(c, hipMemsetAsync(A + S->o_lcnt, 0, sizeof(int) * 2 * ORB_MAX_LEVELS, s));
     VO_CHECK_HIP(c, hipMemsetAsync(A + S->o_keys, 0, sizeof(unsigned long long) * (size_t)(S->max_bins + 1), s));
     S->tile_clean = true;
   }
@@ -520,6 +545,8 @@ static int orb_tile_enqueue(vo_ctx *c, int slot, const vo_bin_params *bp, vo_can
     L.taby = l ? (const int *)(A + S->o_ty[l]) : nullptr;
   }
   a.lvl_total = (int *)(A + S->o_total);
+  a.hist = (int *)(A + S->o_thist);
+  a.hist_copies = S->hist_copies;
   a.cx = (short *)(A + S->o_cx);
   a.cy = (short *)(A + S->o_cy);
   a.cs = A + S->o_cs;
@@ -535,6 +562,13 @@ static int orb_tile_enqueue(vo_ctx *c, int slot, const vo_bin_params *bp, vo_can
     f.scale[l] = S->lscale[l];
   }
   f.lvl_total = a.lvl_total;
+  f.parts = S->finish_parts;
+  f.cidx_cap = ORB_RC * ORB_ST;
+  f.hist = a.hist;
+  f.hist_copies = a.hist_copies;
+  f.cidx = (int *)(A + S->o_cidx);
+  f.lvl_cnt = (int *)(A + S->o_lcnt);
+  f.lvl_done = f.lvl_cnt + ORB_MAX_LEVELS;
   f.cx = a.cx;
   f.cy = a.cy;
   f.cs = a.cs;
@@ -552,7 +586,7 @@ static int orb_tile_enqueue(vo_ctx *c, int slot, const vo_bin_params *bp, vo_can
   f.dev_flags = (int *)(A + S->o_devflags);
   vo_prof_begin(c, VO_K_AUX);
   hipLaunchKernelGGL(orb_tile_kernel, dim3(a.nx * a.ny), dim3(ORB_TILE_NT), (size_t)S->plan.lds_bytes, s, a);
-  hipLaunchKernelGGL(orb_finish_kernel, dim3(p->n_levels), dim3(ORB_ST), 0, s, f);
+  hipLaunchKernelGGL(orb_finish_kernel, dim3(p->n_levels * f.parts), dim3(ORB_ST), 0, s, f);
   vo_prof_end(c);
   VO_CHECK_HIP(c, hipGetLastError());
   return VO_OK;

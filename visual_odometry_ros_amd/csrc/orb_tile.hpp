@@ -57,6 +57,9 @@ struct OrbTileArgs {
   const OrbSpan *gx, *gy;    // [level * nx + tile column], [level * ny + tile row]
   OrbTileLevel L[ORB_MAX_LEVELS];
   int *lvl_total;            // per level: candidates so far (zero before the launch)
+  int *hist;                 // [copy][level][256] candidates per FAST score (zero before the launch; orb_finish_kernel's first cut)
+  int hist_copies;           // workgroup b adds to copy b % hist_copies: at 3840 x 2160 600 000 memory atomics on the few hundred
+                             // words of ONE copy took 200 us of the launch (tools/tileprobe.hip), spread over 64 copies they are free
   short *cx, *cy;
   uint8_t *cs;
   float *cr;
@@ -369,22 +372,38 @@ __global__ __launch_bounds__(ORB_TILE_NT) void orb_tile_kernel(OrbTileArgs a) {
       a.cy[o] = (short)y;
       a.cs[o] = (uint8_t)c;
       a.cr[o] = r;
+#ifndef TILE_NO_HIST  // (measurement builds of tools/tileprobe.hip)
+      // (no use of the returned value: a fire-and-forget memory atomic)
+      ORB_ATOMIC_ADD_AGENT(&a.hist[(((int)blockIdx.x % a.hist_copies) * nl + l) * 256 + c], 1);
+#endif
     }
   }
   TILE_STAMP_AT(9);
 }
 
 // ---- second launch: cuts, per-bin arg-max, table -----------------------------------------------------------------------------------
+// `parts` workgroups per level. Every one of them knows the level's FIRST cut at once — the tile kernel left a histogram of the
+// scores it emitted — and packs the indices of its slice's survivors into the level's list (counts by lane-mask population
+// counts, one memory atomic per workgroup and round to reserve the places). The LAST of a level's workgroups to get there
+// (a ticket; nobody waits) loads the survivors' responses into registers, finds the second cut by orb_kth_largest and votes;
+// the last LEVEL to finish turns the keys into the table. A 3840 x 2160 image has > 100 000 candidates on level 0: one
+// workgroup walking them five times (round 5's first version: histogram + four radix passes) took 650 us.
 struct OrbFinishArgs {
   int n_levels, cand_cap, max_out;
+  int parts;                 // workgroups per level
+  int cidx_cap;              // survivors of the first cut a level's list holds (= what one workgroup's registers hold)
   int cand_base[ORB_MAX_LEVELS], quota[ORB_MAX_LEVELS];
   float scale[ORB_MAX_LEVELS];
   int *lvl_total;            // in: candidates per level; zeroed on exit
+  int *hist;                 // in: [copy][level][256] candidates per score; zeroed on exit
+  int hist_copies;
+  int *cidx;                 // [level][cidx_cap] scratch: indices of the first cut's survivors
+  int *lvl_cnt, *lvl_done;   // [level] survivors listed so far / workgroups of the level that have finished (zero; zeroed on exit)
   const short *cx, *cy;
   const uint8_t *cs;
   const float *cr;
   int *surv;                 // [n_levels] survivors per level (scratch)
-  int *done;                 // workgroups finished (zero before the launch, zeroed on exit)
+  int *done;                 // levels finished (zero before the launch, zeroed on exit)
   unsigned long long *key;   // [n_bins] (zero before the launch, zeroed on exit)
   int n_bins_u, n_bins_v;
   float inv_u, inv_v;
@@ -409,27 +428,53 @@ __device__ __forceinline__ void orb_finish_vote(const OrbFinishArgs &a, int l, i
   atomicMax(&a.key[v * (unsigned)a.n_bins_u + u], ((unsigned long long)ord << 32) | (unsigned long long)(0xFFFFFFFFu - pos));
 }
 
+// The level's last workgroup: m survivors of the first cut are listed in ci[0, m) (any order). retainBest(quota) on their
+// Harris responses — everything >= the quota-th largest stays — and the votes. Returns the number that stayed.
+// One register array live across the barriers (the ordered responses); indices and coordinates are loaded again for the votes.
 template <int NQ>
-__device__ __forceinline__ int orb_finish_level(const OrbFinishArgs &a, int l, int n, OrbSelShared *S) {
+__device__ __forceinline__ int orb_finish_survivors(const OrbFinishArgs &a, int l, int m, const int *ci, OrbSelShared *S) {
+  const int tid = threadIdx.x, base = a.cand_base[l], quota = a.quota[l];
   unsigned key[NQ];
-  int cut, surv;
-  unsigned rcut;
-  const int base = a.cand_base[l];
-  orb_select_regs<NQ>(a.cs + base, a.cr + base, n, a.quota[l], S, key, &cut, &rcut, &surv);
-  // (the coordinates are loaded now, not with the scores: see orb_select_regs)
-  constexpr int NB = NQ < 4 ? NQ : 4;  // (four candidates' coordinates in flight at a time: registers)
+  {
+    constexpr int NB = NQ < 8 ? NQ : 8;  // (indices of eight survivors in flight, then their responses)
 #pragma unroll
-  for (int q0 = 0; q0 < NQ; q0 += NB) {
-    int x[NB], y[NB];
+    for (int q0 = 0; q0 < NQ; q0 += NB) {
+      int idx[NB];
 #pragma unroll
-    for (int q = 0; q < NB; ++q) {
-      const int i = (int)threadIdx.x + (q0 + q) * ORB_ST;
-      x[q] = key[q0 + q] != 0u ? a.cx[base + i] : 0;
-      y[q] = key[q0 + q] != 0u ? a.cy[base + i] : 0;
+      for (int q = 0; q < NB; ++q) {
+        const int j = tid + (q0 + q) * ORB_ST;
+        idx[q] = j < m ? ORB_LD_AGENT(&ci[j]) : -1;
+      }
+#pragma unroll
+      for (int q = 0; q < NB; ++q) key[q0 + q] = idx[q] >= 0 ? orb_ord(a.cr[base + idx[q]]) : 0u;
+    }
+  }
+  if (tid < 3) S->cnt[tid] = 0;
+  __syncthreads();
+  int phase = 0;
+  unsigned rcut = 0u;  // 0 = retainBest leaves the set alone
+  int surv = orb_count_ge<NQ>(key, 1u, S, phase);  // (= m unless a response is NaN: key 0)
+  if (surv > quota) {
+    if (quota == 0)
+      rcut = 0xFFFFFFFFu;
+    else
+      rcut = orb_kth_largest<NQ>(key, quota, surv, 32, S, phase);
+    surv = orb_count_ge<NQ>(key, rcut, S, phase);
+  }
+  constexpr int NV = NQ < 4 ? NQ : 4;  // (four survivors' coordinates in flight at a time: registers)
+#pragma unroll
+  for (int q0 = 0; q0 < NQ; q0 += NV) {
+    int x[NV], y[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const bool in = key[q0 + q] != 0u && key[q0 + q] >= rcut;
+      const int idx = in ? ORB_LD_AGENT(&ci[tid + (q0 + q) * ORB_ST]) : 0;
+      x[q] = in ? a.cx[base + idx] : 0;
+      y[q] = in ? a.cy[base + idx] : 0;
     }
 #pragma unroll
-    for (int q = 0; q < NB; ++q)
-      if (key[q0 + q] != 0u) orb_finish_vote(a, l, x[q], y[q], orb_unord(key[q0 + q]));
+    for (int q = 0; q < NV; ++q)
+      if (key[q0 + q] != 0u && key[q0 + q] >= rcut) orb_finish_vote(a, l, x[q], y[q], orb_unord(key[q0 + q]));
   }
   return surv;
 }
@@ -438,54 +483,128 @@ __global__ __launch_bounds__(ORB_ST) void orb_finish_kernel(OrbFinishArgs a) {
   __shared__ OrbSelShared s_sel;
   __shared__ int s_hist[256];
   __shared__ unsigned s_prefix;
-  __shared__ int s_rank, s_cut, s_kept, s_surv, s_last;
+  __shared__ int s_rank, s_cut, s_kept, s_surv, s_last, s_m;
+  __shared__ int s_wtot[ORB_ST / 64], s_wbase[ORB_ST / 64];
   __shared__ float s_scale[ORB_MAX_LEVELS];
-  const int l = blockIdx.x, tid = threadIdx.x;
+  const int l = (int)blockIdx.x / a.parts, part = (int)blockIdx.x - l * a.parts, tid = threadIdx.x;
   ORB_SET_PRIO();
   TILE_STAMP_AT(0);
   if (tid < a.n_levels) s_scale[tid] = a.scale[tid];  // (the table is decoded with a per-bin level: not from the argument segment)
   const int total = a.lvl_total[l];
+  {  // the level's histogram: the sum of the tile kernel's copies (two threads per score, every load in flight together)
+    int part_sum = 0;
+    for (int k = tid >> 8; k < a.hist_copies; k += ORB_ST / 256) part_sum += a.hist[(k * a.n_levels + l) * 256 + (tid & 255)];
+    if (tid < 256) s_hist[tid] = 0;
+    __syncthreads();
+    if (part_sum) atomicAdd(&s_hist[tid & 255], part_sum);
+  }
   TILE_STAMP_AT(1);
   const int n = total > a.cand_cap ? 0 : total;
-  int surv = 0;
-  if (n <= 4 * ORB_ST) {
-    surv = orb_finish_level<4>(a, l, n, &s_sel);
-  } else if (n <= 8 * ORB_ST) {
-    surv = orb_finish_level<8>(a, l, n, &s_sel);
-  } else if (n <= 16 * ORB_ST) {
-    surv = orb_finish_level<16>(a, l, n, &s_sel);
-  } else if (n <= ORB_RC * ORB_ST) {
-    surv = orb_finish_level<ORB_RC>(a, l, n, &s_sel);
-  } else {
-    // a level of more than 16 384 candidates (4K images): LDS histogram for the score cut, 4-pass radix select on the
-    // ordered response (the general path's orb_select_kernel, unchanged), then the votes from memory
-    const uint8_t *cs = a.cs + a.cand_base[l];
-    const float *cr = a.cr + a.cand_base[l];
-    const int quota = a.quota[l];
-    if (tid < 256) s_hist[tid] = 0;
-    if (tid == 0) s_surv = 0;
-    __syncthreads();
-    for (int i = tid; i < n; i += ORB_ST) atomicAdd(&s_hist[cs[i]], 1);
-    __syncthreads();
-    if (tid == 0) {
-      int cut = 0, kept = n;
-      const int keep = 2 * quota;
-      if (n > keep) {
-        if (keep == 0) {
-          cut = 256;
-          kept = 0;
-        } else {
-          int above;
-          cut = orb_hist_rank(s_hist, keep, &above);
-          kept = above + s_hist[cut];
+  const int quota = a.quota[l];
+  const uint8_t *cs = a.cs + a.cand_base[l];
+  const float *cr = a.cr + a.cand_base[l];
+  int *ci = a.cidx + l * a.cidx_cap;
+  __syncthreads();
+  // (1) retainBest(2 n_l) on the FAST score: the value of rank 2 n_l from the histogram; kept = what is at or above it
+  if (tid == 0) {
+    int cut = 0, kept = n;
+    const int keep = 2 * quota;
+    if (n > keep) {
+      if (keep == 0) {
+        cut = 256;
+        kept = 0;
+      } else {
+        int above;
+        cut = orb_hist_rank(s_hist, keep, &above);
+        kept = above + s_hist[cut];
+      }
+    }
+    s_cut = cut;
+    s_kept = kept;
+  }
+  __syncthreads();
+  const int cut = s_cut, kept = s_kept;
+  const bool listed = kept <= a.cidx_cap;  // (the same for every workgroup of the level: same inputs)
+  if (listed) {
+    // this workgroup's slice of the level's scores, four to a word (cand_base and cand_cap are multiples of 16); a round
+    // = four words per thread
+    const uint32_t *cs32 = (const uint32_t *)cs;
+    const int words = (n + 3) >> 2;
+    const int w0 = (int)(((long long)words * part) / a.parts), w1 = (int)(((long long)words * (part + 1)) / a.parts);
+    const int wave = tid >> 6;
+    for (int wb = w0; wb < w1; wb += 4 * ORB_ST) {
+      uint32_t v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int w = wb + tid + q * ORB_ST;
+        v[q] = w < w1 ? cs32[w] : 0u;
+      }
+      int wtot = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int w = wb + tid + q * ORB_ST;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const bool in = w < w1 && 4 * w + b < n && (int)((v[q] >> (8 * b)) & 255u) >= cut;
+          wtot += orb_wave_count(in);
         }
       }
-      s_cut = cut;
-      s_kept = kept;
+      if ((tid & 63) == 0) s_wtot[wave] = wtot;
+      __syncthreads();
+      if (tid == 0) {
+        int tot = 0;
+        for (int k = 0; k < ORB_ST / 64; ++k) tot += s_wtot[k];
+        int g = tot ? ORB_ATOMIC_ADD_AGENT(&a.lvl_cnt[l], tot) : 0;
+        for (int k = 0; k < ORB_ST / 64; ++k) {
+          s_wbase[k] = g;
+          g += s_wtot[k];
+        }
+      }
+      __syncthreads();
+      int run = s_wbase[wave];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int w = wb + tid + q * ORB_ST;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const bool in = w < w1 && 4 * w + b < n && (int)((v[q] >> (8 * b)) & 255u) >= cut;
+          int cnt;
+          const int r = orb_wave_rank(in, &cnt);
+          if (in && run + r < a.cidx_cap) ORB_ST_AGENT(&ci[run + r], 4 * w + b);
+          run += cnt;
+        }
+      }
+      // (no barrier here: s_wtot / s_wbase are written again behind the next round's first barrier, which every thread
+      // reaches after it has read them)
     }
+  }
+  // ---- the level's ticket: the last of its workgroups goes on ---------------------------------------------------------------------
+  ORB_FENCE_RELEASE();  // every thread: its list entries have been performed ...
+  __syncthreads();      // ... before thread 0 takes the workgroup's ticket
+  if (tid == 0) s_last = (ORB_ATOMIC_INC_AGENT(&a.lvl_done[l]) == a.parts - 1) ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;
+  ORB_FENCE_ACQUIRE();
+  int surv = 0;
+  if (listed) {
+    if (tid == 0) s_m = ORB_LD_AGENT(&a.lvl_cnt[l]);
     __syncthreads();
-    const int cut = s_cut, kept = s_kept;
+    const int m = s_m < a.cidx_cap ? s_m : a.cidx_cap;  // (= kept)
+    if (m <= 4 * ORB_ST) {
+      surv = orb_finish_survivors<4>(a, l, m, ci, &s_sel);
+    } else if (m <= 8 * ORB_ST) {
+      surv = orb_finish_survivors<8>(a, l, m, ci, &s_sel);
+    } else if (m <= 16 * ORB_ST) {
+      surv = orb_finish_survivors<16>(a, l, m, ci, &s_sel);
+    } else {
+      surv = orb_finish_survivors<ORB_RC>(a, l, m, ci, &s_sel);
+    }
+  } else {
+    // more survivors of the first cut than a workgroup's registers hold (a score tie of tens of thousands): 4-pass radix
+    // select on the ordered response straight from the level's arrays (the general path's orb_select_kernel), then the votes
     unsigned rcut = 0u;
+    if (tid == 0) s_surv = 0;
+    __syncthreads();
     if (kept > quota) {
       if (quota == 0) {
         rcut = 0xFFFFFFFFu;
@@ -529,10 +648,16 @@ __global__ __launch_bounds__(ORB_ST) void orb_finish_kernel(OrbFinishArgs a) {
     __syncthreads();
     surv = s_surv;
   }
-  // ---- the last workgroup to get here turns the keys into the table -----------------------------------------------------------
+  // the level's words go back to zero for the next image (every workgroup of the level has read them: it holds the last ticket)
+  for (int k = tid >> 8; k < a.hist_copies; k += ORB_ST / 256) ORB_ST_AGENT(&a.hist[(k * a.n_levels + l) * 256 + (tid & 255)], 0);
+  if (tid == 0) {
+    ORB_ST_AGENT(&a.lvl_cnt[l], 0);
+    ORB_ST_AGENT(&a.lvl_done[l], 0);
+  }
+  // ---- the last LEVEL to get here turns the keys into the table ---------------------------------------------------------------
   TILE_STAMP_AT(2);
   ORB_FENCE_RELEASE();  // every thread: its votes have been performed ...
-  __syncthreads();      // ... before thread 0 takes the workgroup's ticket
+  __syncthreads();      // ... before thread 0 takes the level's ticket
   if (tid == 0) {
     ORB_ST_AGENT(&a.surv[l], surv);
     ORB_FENCE_RELEASE();
