@@ -125,10 +125,12 @@ int vo_frame_set_advance(vo_ctx *c, const VoAdvArgs *adv) {
 //   side stream:  detection + per-bin table of slot_l1 -> frame kernel, candidates only
 // joined by one event in front of the BA launch — the 165 us detector chain runs under the features' tracking instead of
 // in front of it. Same results: the same kernels on the same inputs, in two launches instead of one.
-int vo_frame_set_deferred_detection(vo_ctx *c) {
+// issued != 0: the detection is already on the side stream (started from the image itself, in front of the pair's pyramids:
+// vo_new_point_candidates_enqueue_image) — only the candidates' launch follows it there.
+int vo_frame_set_deferred_detection(vo_ctx *c, int issued) {
   int rc = vo_frame_init(c);
   if (rc < 0) return rc;
-  c->frame->defer_detect = 1;
+  c->frame->defer_detect = issued ? 2 : 1;
   return VO_OK;
 }
 
@@ -228,7 +230,7 @@ static int vo_frame_enqueue_body(vo_ctx *c, const vo_stereo_params *prm, int slo
   // (the table is filled on the side stream, long before — unless its detection is deferred: then only the candidates'
   // launch, on the side stream itself, reads it)
   const bool split = tab && c->frame->defer_detect && vo_frame_fused_supported(prm->win) && n > 0 && c->ingest_side && !c->frame_conc_off;
-  if (tab && c->frame->defer_detect && !split) RC(vo_new_point_candidates_enqueue(c, slot_l1, bp, table));  // (cannot overlap: now)
+  if (tab && c->frame->defer_detect == 1 && !split) RC(vo_new_point_candidates_enqueue(c, slot_l1, bp, table));  // (cannot overlap: now)
   if (tab && !split) VO_CHECK_HIP(c, hipStreamWaitEvent(s, tab->ready, 0));
   // ---- carve the packed result block for this frame ----
   f->n = n;
@@ -355,7 +357,7 @@ static int vo_frame_enqueue_body(vo_ctx *c, const vo_stereo_params *prm, int slo
     if (rcf >= 0 && split) {
       // the features are on their way: now the detector chain of the current left image and, behind it on the same (side)
       // stream, the candidates' launch; the BA launch waits for both through ev_join
-      rcf = vo_new_point_candidates_enqueue(c, slot_l1, bp, table);
+      if (c->frame->defer_detect == 1) rcf = vo_new_point_candidates_enqueue(c, slot_l1, bp, table);  // (2: already there)
       if (rcf >= 0) {
         c->stream = c->stream2;
         rcf = vo_frame_fused_enqueue(c, prm, slot_l0, slot_l1, slot_r1, d_l0, d_r0, d_X, d_fl, n, T_cp, T_rl, d_new, n_new, b, 2, T_pw);

@@ -496,16 +496,18 @@ static int orb_prepare(vo_ctx *c, int w, int h, const vo_orb_params *p, int max_
 
 // The per-bin candidate table of the image in `slot` by the two tile kernels (orb_tile.hpp), on c->stream. Needs
 // S->plan.ok. Leaves lvl_total / done / keys zeroed, as it needs them.
-static int orb_tile_enqueue(vo_ctx *c, int slot, const vo_bin_params *bp, vo_cand_table &T) {
+// src != null: level 0 is read from that image (device memory, src_stride bytes per row, w x h) instead of the slot's plane
+static int orb_tile_enqueue(vo_ctx *c, int slot, const vo_bin_params *bp, vo_cand_table &T, const uint8_t *src = nullptr,
+                            int src_stride = 0, int src_w = 0, int src_h = 0) {
   const vo_orb_params *p = &bp->orb;
-  if (slot < 0 || slot >= c->cfg.n_slots || c->slots[slot].n_levels <= 0) VO_FAIL(c, VO_ERR_INVALID, "slot holds no image");
-  const vo_pyramid &P = c->slots[slot];
+  if (!src && (slot < 0 || slot >= c->cfg.n_slots || c->slots[slot].n_levels <= 0)) VO_FAIL(c, VO_ERR_INVALID, "slot holds no image");
+  const int img_w = src ? src_w : c->slots[slot].w, img_h = src ? src_h : c->slots[slot].h;
   const int total = bp->n_bins_u * bp->n_bins_v;
-  int rc = orb_prepare(c, P.w, P.h, p, total);
+  int rc = orb_prepare(c, img_w, img_h, p, total);
   if (rc) return rc;
   vo_orb_state *S = c->orb;
   if (!S->plan.ok) return 1;  // (the caller takes the per-stage kernels)
-  if (vo_slot_acquire(c, slot) < 0) return VO_ERR_HIP;
+  if (!src && vo_slot_acquire(c, slot) < 0) return VO_ERR_HIP;
   hipStream_t s = c->stream;
   uint8_t *A = S->arena;
   if (!S->tile_clean) {  // (once after the per-stage kernels ran on this arena, never in a steady stream)
@@ -518,9 +520,16 @@ static int orb_tile_enqueue(vo_ctx *c, int slot, const vo_bin_params *bp, vo_can
   }
   OrbTileArgs a;
   memset(&a, 0, sizeof(a));
-  a.img = P.lv[0].origin();
-  a.img_end = P.lv[0].base + (size_t)P.lv[0].stride * (size_t)(P.lv[0].h + 2 * VO_PAD);
-  a.stride = P.lv[0].stride;
+  if (src) {
+    a.img = src;
+    a.img_end = src + (size_t)src_stride * (size_t)(src_h - 1) + (size_t)src_w;
+    a.stride = src_stride;
+  } else {
+    const vo_pyramid &P = c->slots[slot];
+    a.img = P.lv[0].origin();
+    a.img_end = P.lv[0].base + (size_t)P.lv[0].stride * (size_t)(P.lv[0].h + 2 * VO_PAD);
+    a.stride = P.lv[0].stride;
+  }
   a.n_levels = p->n_levels;
   a.nx = S->plan.nx;
   a.ny = S->plan.ny;
@@ -829,7 +838,17 @@ const vo_cand_table *vo_orb_cand_table(vo_ctx *c, int table) {
   return &c->orb->tab[table];
 }
 
+static int cand_table_enqueue(vo_ctx *c, int slot, const vo_bin_params *bp, int table, const uint8_t *src, int src_stride, int src_w,
+                              int src_h);
 extern "C" int vo_new_point_candidates_enqueue(vo_ctx *c, int slot, const vo_bin_params *bp, int table) {
+  return cand_table_enqueue(c, slot, bp, table, nullptr, 0, 0, 0);
+}
+int vo_new_point_candidates_enqueue_image(vo_ctx *c, const uint8_t *dev_img, int stride, int w, int h, const vo_bin_params *bp, int table) {
+  if (!dev_img || stride < w || w <= 0 || h <= 0) return VO_ERR_INVALID;
+  return cand_table_enqueue(c, -1, bp, table, dev_img, stride, w, h);
+}
+static int cand_table_enqueue(vo_ctx *c, int slot, const vo_bin_params *bp, int table, const uint8_t *src, int src_stride, int src_w,
+                              int src_h) {
   if (!c || !bp || table < 0 || table > 1 || bp->n_bins_u <= 0 || bp->n_bins_v <= 0) return VO_ERR_INVALID;
   const int total = bp->n_bins_u * bp->n_bins_v;
   if (total > 32768) VO_FAIL(c, VO_ERR_CAPACITY, "%d bins: the closed step [10] handles at most 32768", total);
@@ -857,13 +876,14 @@ extern "C" int vo_new_point_candidates_enqueue(vo_ctx *c, int slot, const vo_bin
     VO_CHECK_HIP(c, hipEventRecord(T.ready, c->stream2));
     return VO_OK;
   }
+  if (src && c->dbg[VO_DBG_STAGED_DETECT]) return 1;  // (the per-stage kernels read a slot)
   hipStream_t caller = c->stream;
   c->stream = c->stream2;  // every launcher below enqueues on ctx->stream
   // two launches (orb_tile.hpp) wherever the configuration fits them — every configuration of the reference does;
   // VO_DBG_STAGED_DETECT forces the per-stage kernels (19 launches), the same table bit for bit
   int rc = 1;
   if (!c->dbg[VO_DBG_STAGED_DETECT]) {
-    rc = orb_tile_enqueue(c, slot, bp, T);
+    rc = orb_tile_enqueue(c, slot, bp, T, src, src_stride, src_w, src_h);
     if (rc == VO_OK) {
       hipError_t e = hipEventRecord(T.ready, c->stream);
       if (e != hipSuccess) {
@@ -872,7 +892,7 @@ extern "C" int vo_new_point_candidates_enqueue(vo_ctx *c, int slot, const vo_bin
       }
     }
   }
-  if (rc <= 0) {
+  if (rc <= 0 || src) {  // (src: only the tile kernels read an image that is not a slot)
     c->stream = caller;
     return rc;
   }

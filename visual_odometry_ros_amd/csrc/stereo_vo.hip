@@ -35,7 +35,7 @@ int vo_frame_enqueue_impl(vo_ctx *c, const vo_stereo_params *prm, int slot_l0, i
                           const float dT_prior[16], const float *pts_new, int n_new, int inputs_on_device,
                           const vo_bin_params *bp, int table, const float *T_pw, const float *T_cw_prior);
 int vo_frame_set_advance(vo_ctx *c, const VoAdvArgs *adv);          // frame_pipeline.hip
-int vo_frame_set_deferred_detection(vo_ctx *c);
+int vo_frame_set_deferred_detection(vo_ctx *c, int issued);
 
 #define RC(x)                \
   do {                       \
@@ -338,10 +338,29 @@ extern "C" int vo_svo_enqueue(vo_svo *s, const void *left, const void *right, in
   // No pair handed over early (trackStereoImages as the reference's caller uses it): the images and pyramids go in now, the
   // keypoint detection is deferred into the frame's enqueue, where it runs on the side stream NEXT TO the features' tracking
   // and the candidates follow as a launch of their own (frame_pipeline.hip: vo_frame_set_deferred_detection)
-  bool deferred = false;
+  bool deferred = false, issued = false;
   if (!(s->prefetched && s->pre_l == left && s->pre_r == right)) {
     deferred = !s->first && s->c->ingest_side;
-    RC(svo_ingest(s, left, right, stride, on_device, !deferred));
+    if (deferred && !s->prm.rectify && s->n > 0 && vo_orb_cand_table(c, s->tab_next)) {
+      // the detector needs the left IMAGE, not its pyramid: it starts now, on the side stream — from the caller's device image at
+      // once, from the slot's staging plane as soon as a host image's upload is queued — while the main stream builds the pyramids
+      if (on_device) {
+        const int rc = vo_new_point_candidates_enqueue_image(c, (const uint8_t *)left, stride, s->prm.frame.width, s->prm.frame.height,
+                                                             &s->prm.bins, s->tab_next);
+        if (rc < 0) return rc;
+        issued = rc == VO_OK;
+      } else {
+        c->early_bins = &s->prm.bins;
+        c->early_table = s->tab_next;
+        c->early_issued = 0;
+      }
+    }
+    const int rc_in = svo_ingest(s, left, right, stride, on_device, !deferred);
+    if (c->early_bins) {
+      issued = c->early_issued != 0;
+      c->early_bins = nullptr;
+    }
+    RC(rc_in);
   }
   // from here on the driver's state moves; every error return below puts it back (slots, tables, both id counters), so
   // that the caller can hand the pair over again — or another one — and track against the right previous image
@@ -406,7 +425,7 @@ extern "C" int vo_svo_enqueue(vo_svo *s, const void *left, const void *right, in
     a.hdr_dev = s->d_hdr;
     a.hdr_host = s->h_hdr;
     int rc = vo_frame_set_advance(c, &a);
-    if (rc >= 0 && deferred) rc = vo_frame_set_deferred_detection(c);
+    if (rc >= 0 && deferred) rc = vo_frame_set_deferred_detection(c, issued ? 1 : 0);
     if (rc < 0) return undo(rc);
   }
   int rc = vo_frame_enqueue_impl(c, &s->prm.frame, s->slot[S_P], s->slot[S_CL], s->slot[S_CR], t.pts_l, t.pts_r, t.Xw, t.flags,

@@ -350,6 +350,15 @@ extern "C" int vo_set_stereo_pair_host_async(vo_ctx *c, int slot_l, const uint8_
     else
       VO_CHECK_HIP(c, hipMemcpy2DAsync(P.stage, (size_t)width, src[i], (size_t)stride, (size_t)width, (size_t)height,
                                        hipMemcpyHostToDevice, s));
+    if (i == 0 && c->early_bins && s != c->stream2) {
+      // StereoVO's synchronous call: the left image is on its way — its keypoint detection follows it on the side stream (one
+      // event), under the right image's upload and the pair's pyramids
+      VO_CHECK_HIP(c, hipEventRecord(c->ev_fork, s));
+      VO_CHECK_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+      const int rc = vo_new_point_candidates_enqueue_image(c, P.stage, width, width, height, c->early_bins, c->early_table);
+      if (rc < 0) return rc;
+      c->early_issued = rc == VO_OK ? 1 : 0;
+    }
   }
   return vo_pyramid_build_pair(c, slot_l, c->slots[slot_l].stage, slot_r, c->slots[slot_r].stage, width, height, width);
 }

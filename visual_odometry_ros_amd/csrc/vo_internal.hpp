@@ -48,6 +48,10 @@ struct vo_ctx {
   hipStream_t stream2;     // side stream: work that does not depend on the main chain of a frame
   hipStream_t stream3;     // the strict-border replay of the frame in flight (runs next to the frame kernel)
   int ingest_side;         // vo_set_ingest_side_stream: image ingestion (H2D, pyramids) runs on the side stream
+  // StereoVO's synchronous call with host images: the detection of the LEFT image is started from its staging plane as soon
+  // as that upload is queued (vo_set_stereo_pair_host_async), not behind the pair's pyramids; armed per call, consumed there
+  const vo_bin_params *early_bins;
+  int early_table, early_issued;
   hipEvent_t ev_fork, ev_join;
   hipEvent_t ev_pyr;       // recorded behind every pyramid build: what side-stream consumers of a slot wait for
   char err[512];
