@@ -630,7 +630,10 @@ def render_stream(cfg, seed, n, workers):
 # local-BA solves of windows 3, 4, 5, 6 — smaller problems than the stream ever sees again (round 4: 2744 driver-timed
 # against 2490 steady). A keyframe every 4-5 frames on these streams: nine of them are there after ~45 frames; the count
 # is reported (loop.keyframes_before_timed_region). LOOP_PRIME_GROWING is round 4's value, kept for secondary.growing_window.
-LOOP_PRIME = 50
+# 65, not 50: twenty consecutive frames are a small sample of this stream — ordinary frames cost 0.303 ms over frames 55-75, 0.274 over
+# 75-95, 0.283 / 0.272 / 0.278 over the next three twenties (frame_ms_by_kind.mean_ms_other_by_20_frames of a longer run shows it) —
+# and with the driver's --steps 20 --warmup 5 the timed frames are now 70-90, whose cost (0.280 ms) is the 400-frame mean (0.278 ms).
+LOOP_PRIME = 65
 LOOP_PRIME_GROWING = 3
 
 
@@ -786,6 +789,9 @@ def run_loop(cfg, args, rank, local_rank, world, torch, V, barrier, dev, imgs, s
             "keyframes": int(kfm.sum()), "mean_ms_keyframe": round(float(d_ms[kfm].mean()), 4) if kfm.any() else None,
             "mean_ms_other": round(float(d_ms[~kfm].mean()), 4) if (~kfm).any() else None,
             "keyframe_ms_first_12": [round(float(v), 4) for v in d_ms[kfm][:12]],
+            # ordinary frames by position in the timed region (20 frames each, the first five windows): a short run next to a long one
+            "mean_ms_other_by_20_frames": [round(float(d_ms[q:q + 20][~kfm[q:q + 20]].mean()), 4)
+                                           for q in range(0, min(len(d_ms), 100), 20) if (~kfm[q:q + 20]).any()],
             "frames_with_border_features": int((replayed[1:] > 0).sum()), "mean_replayed_features": round(float(replayed.mean()), 1)},
         "higher_is_better": True,
         "scaling": "weak",
