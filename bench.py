@@ -1076,11 +1076,12 @@ def cpu_baseline_loop(cfg, args, st, imgs, traj, V, local_rank):
                            lba=bool(args.lba), ic_border=border, sum_mode=sum_mode, tree_width=tw, n_threads=cores,
                            thres_sampson=cfg.get("thres_sampson", 60.0))
     ref = make(O.SUM_SEQ, 0)
-    t_frames, worst = [], 0.0
+    t_frames, worst, seq_ids = [], 0.0, []
     for k in range(nf):
         t0 = time.perf_counter()
         ref.track(*imgs[k])
         t_frames.append(time.perf_counter() - t0)
+        seq_ids.append(np.array(ref.ids, copy=True))
         Tg, To = traj[k].astype(np.float64), ref.T_wp.astype(np.float64)
         worst = max(worst, float(np.linalg.norm(Tg - To) / np.linalg.norm(To)))
     # bit-exact leg: a second device run of the first nf frames against the oracle in the kernels' summation order
@@ -1090,7 +1091,7 @@ def cpu_baseline_loop(cfg, args, st, imgs, traj, V, local_rank):
     svo = V.StereoVO(ctx, cfg["W"], cfg["H"], cfg["K"], cfg["K"], st.T_lr, cfg["n_u"], cfg["n_v"], thres_fastscore=cfg["thres_fast"],
                      window_size=cfg["win"], max_level=cfg["max_level"], thres_error=thr[0], thres_bidirection=thr[1],
                      thres_poseba_error=thr[2], strict_border=args.strict_border, local_ba=bool(args.lba), thres_sampson=cfg.get("thres_sampson", 60.0))
-    exact, ids_ok, n_lba = True, True, 0
+    exact, ids_ok, n_lba, seq_equal = True, True, 0, 0
     nf_par = max(nf, min(args.parity_frames, len(imgs)))  # (long enough for the window to reach three keyframes: local BA)
     for k in range(nf_par):
         gi = svo.trackStereoImages(*imgs[k])
@@ -1098,6 +1099,8 @@ def cpu_baseline_loop(cfg, args, st, imgs, traj, V, local_rank):
         n_lba += int(bool(gi.lba_ran))
         g = svo.getTracks()
         ids_ok = ids_ok and bool(np.array_equal(g["ids"], tree.ids))
+        if k < nf and seq_equal == k and np.array_equal(g["ids"], seq_ids[k]):
+            seq_equal = k + 1  # (leading frames whose ids also equal the loop's in the REFERENCE's summation order)
         same = ids_ok and np.array_equal(g["pts_l"].view(np.uint32), tree.pts_l.view(np.uint32)) \
             and np.array_equal(g["pts_r"].view(np.uint32), tree.pts_r.view(np.uint32)) and np.array_equal(g["flags"], tree.flags) \
             and np.array_equal(np.array(gi.T_wc, np.float32).view(np.uint32), tree.T_wp.reshape(-1).view(np.uint32))
@@ -1123,9 +1126,12 @@ def cpu_baseline_loop(cfg, args, st, imgs, traj, V, local_rank):
         },
         "parity": {"pose_rel_frobenius_max": worst, "track_ids_bit_exact": ids_ok, "track_sets_and_poses_bit_exact": exact,
                    "frames_checked": nf_par, "local_ba_solves_checked": n_lba, "pose_frames_checked": nf,
+                   "track_ids_bit_exact_vs_reference_order": f"{seq_equal} of the first {nf} frames",
                    "note": "pose error: device loop against the CPU loop in the reference's summation order, both free-running; "
                            "bit-exactness: device loop against the CPU loop in the kernels' summation order (ids, pixels, flags, "
-                           "poses after every frame, local-BA solves included)"},
+                           "poses after every frame, local-BA solves included); track ids against the reference-order loop: equal "
+                           "until the two free-running loops part at one feature's inlier gate (frame 9 of 24 on this stream: "
+                           "tests/test_stereo_vo_gpu.py, DESIGN.md \u00a72)"},
     }
 
 
