@@ -49,6 +49,8 @@ struct MonoArgs {
   const uint8_t *cand_has;  // [n_new] the bin holds a keypoint
   float *new_r;             // out [n_new][2] forward result (pixel in I0)
   uint8_t *m_new;           // out [n_new] trackBidirection mask
+  int wg_off;               // workgroup b of the launch is feature / candidate b + wg_off (the candidates as a launch of their own)
+  int *cand_done;           // non-null (candidates' own launch): results are written through and every candidate workgroup counts itself
 };
 // the replay's launches: the IC arguments and the hand-shake with the BA launch (vo_frame_state::sync)
 struct MonoReplayArgs {
@@ -67,7 +69,7 @@ struct MonoShared {
 template <int WIN>
 __global__ __launch_bounds__(64) void mono_track_kernel(MonoArgs a) {
   __shared__ MonoShared<WIN> sh;
-  const int i = blockIdx.x;
+  const int i = blockIdx.x + a.wg_off;
   if (i >= a.n + a.n_new) return;
   const int lane = threadIdx.x;
   // Workgroups n .. n + n_new - 1: the new-point candidate of bin j (mono_vo.cpp:989-991: trackBidirection(I1, I0,
@@ -78,7 +80,15 @@ __global__ __launch_bounds__(64) void mono_track_kernel(MonoArgs a) {
   const int j = i - a.n;
   if (!feat) {
     if (!a.cand_has[j]) {
-      if (lane == 0) a.m_new[j] = 0;
+      if (lane == 0) {
+        if (a.cand_done) {  // (read by the BA launch, which may be running: write-through, then the count)
+          ic_st8(&a.m_new[j], 0);
+          __builtin_amdgcn_s_waitcnt(0);
+          __hip_atomic_fetch_add(a.cand_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          a.m_new[j] = 0;
+        }
+      }
       return;
     }
     __builtin_amdgcn_s_setprio(1);
@@ -148,9 +158,17 @@ __global__ __launch_bounds__(64) void mono_track_kernel(MonoArgs a) {
     bool m = fwd.x > 3 && fwd.x < a.W - 3 && fwd.y > 3 && fwd.y < a.H - 3;
     m = m && fwd.status && bwd.status && fwd.err <= a.thres_err && bwd.err <= a.thres_err && dist2 <= thres2;
     if (lane == 0) {
-      a.new_r[2 * j] = fwd.x;
-      a.new_r[2 * j + 1] = fwd.y;
-      a.m_new[j] = m ? 1 : 0;
+      if (a.cand_done) {
+        ic_store<true>(&a.new_r[2 * j], fwd.x);
+        ic_store<true>(&a.new_r[2 * j + 1], fwd.y);
+        ic_st8(&a.m_new[j], (uint8_t)(m ? 1 : 0));
+        __builtin_amdgcn_s_waitcnt(0);
+        __hip_atomic_fetch_add(a.cand_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        a.new_r[2 * j] = fwd.x;
+        a.new_r[2 * j + 1] = fwd.y;
+        a.m_new[j] = m ? 1 : 0;
+      }
     }
     return;
   }
@@ -274,11 +292,27 @@ __global__ __launch_bounds__(IC_T) void mono_fallback_kernel(MonoReplayArgs a) {
 // ---- host side ---------------------------------------------------------------------
 static size_t m_align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
+// phase 0: features (+ candidates unless split); phase 2: the candidates as a launch of their own on c->stream (the side stream)
 template <int WIN>
-static void mono_launch(vo_ctx *c, const MonoArgs &a) {
-  vo_prof_begin(c, VO_K_KLT);
-  hipLaunchKernelGGL(mono_track_kernel<WIN>, dim3(a.n + a.n_new), dim3(64), 0, c->stream, a);
-  vo_prof_end(c);
+static void mono_launch(vo_ctx *c, const MonoArgs &a, int phase, bool split, int *cand_done) {
+  if (phase == 0) {
+    vo_prof_begin(c, VO_K_KLT);
+    hipLaunchKernelGGL(mono_track_kernel<WIN>, dim3(split ? a.n : a.n + a.n_new), dim3(64), 0, c->stream, a);
+    vo_prof_end(c);
+  } else if (a.n_new > 0) {
+    MonoArgs b = a;
+    b.wg_off = a.n;
+    b.cand_done = cand_done;
+    hipLaunchKernelGGL(mono_track_kernel<WIN>, dim3(a.n_new), dim3(64), 0, c->stream, b);
+  }
+}
+static void mono_launch_any(vo_ctx *c, int win, const MonoArgs &a, int phase, bool split, int *cand_done) {
+  switch (win) {
+    case 13: mono_launch<13>(c, a, phase, split, cand_done); break;
+    case 15: mono_launch<15>(c, a, phase, split, cand_done); break;
+    case 21: mono_launch<21>(c, a, phase, split, cand_done); break;
+    default: mono_launch<31>(c, a, phase, split, cand_done); break;
+  }
 }
 
 // MonoVO (mono_vo.hip): the next vo_mono_frame_enqueue* lets the BA launch build the next track set (mvo_advance_body)
@@ -309,6 +343,14 @@ static int mono_enqueue_impl(vo_ctx *c, const vo_mono_params *prm, int slot0, in
   if (bp) {
     if (n <= 0) VO_FAIL(c, VO_ERR_INVALID, "the closed new-point step needs a track set (the first frame is the caller's)");
     tab = vo_orb_cand_table(c, table);
+    if (c->frame && c->frame->defer_detect && (!tab || tab->n_bins != bp->n_bins_u * bp->n_bins_v)) {
+      c->frame->defer_detect = 0;  // deferred detection into a table that does not exist yet: detect now, in stream order
+      {
+        const int rcd = vo_new_point_candidates_enqueue(c, slot1, bp, table);
+        if (rcd < 0) return rcd;
+      }
+      tab = vo_orb_cand_table(c, table);
+    }
     if (!tab || tab->n_bins != bp->n_bins_u * bp->n_bins_v)
       VO_FAIL(c, VO_ERR_INVALID, "candidate table %d was not filled for %d x %d bins (vo_new_point_candidates_enqueue)", table,
               bp->n_bins_u, bp->n_bins_v);
@@ -330,9 +372,15 @@ static int mono_enqueue_impl(vo_ctx *c, const vo_mono_params *prm, int slot0, in
   // while the first one's kernels still use them
   if (f->pending) VO_FAIL(c, VO_ERR_INVALID, "a frame is already in flight: call vo_mono_frame_result first");
   // a track-set advance armed by vo_mono_frame_set_advance belongs to THIS enqueue, whether it gets as far as the BA launch or not
-  const int adv_on = f->mvo_adv_on, flag_mode = f->mono_flag_mode;
+  const int adv_on = f->mvo_adv_on, flag_mode = f->mono_flag_mode, defer = f->defer_detect;
   f->mvo_adv_on = 0;
   f->mono_flag_mode = 0;
+  f->defer_detect = 0;
+  f->mono_split = 0;
+  // MonoVO's synchronous call (vo_frame_set_deferred_detection): the features' part of the frame kernel goes out at once, the
+  // keypoint detection of slot1 (defer == 1; 2: already on the side stream) and the candidates' launch follow on the side
+  // stream, the BA launch joins them on the device (frame_pipeline.hip has the stereo form)
+  const bool split = tab && defer && n > 0 && c->ingest_side && !c->frame_conc_off;
   hipStream_t s = c->stream;
   const float *d_p0 = pts0, *d_X = Xw;
   const uint8_t *d_fl = flags;
@@ -344,7 +392,11 @@ static int mono_enqueue_impl(vo_ctx *c, const vo_mono_params *prm, int slot0, in
     d_X = f->in_X;
     d_fl = f->st1;
   }
-  if (tab) VO_CHECK_HIP(c, hipStreamWaitEvent(s, tab->ready, 0));  // (filled on the side stream, long before)
+  if (tab && defer == 1 && !split) {  // (cannot overlap: now)
+    const int rcd = vo_new_point_candidates_enqueue(c, slot1, bp, table);
+    if (rcd < 0) return rcd;
+  }
+  if (tab && !split) VO_CHECK_HIP(c, hipStreamWaitEvent(s, tab->ready, 0));  // (filled on the side stream, long before)
   // packed result block: header | stage | pixels | scale [| closed: new-point masks | their I0 pixels | their I1 pixels]
   f->n = n;
   f->n_new = n_new;
@@ -463,12 +515,7 @@ static int mono_enqueue_impl(vo_ctx *c, const vo_mono_params *prm, int slot0, in
     if (bp) f->again_mono.bins = *bp;
     f->again_mono.table = table;
     f->again_mono.flag_mode = flag_mode;
-    switch (prm->win) {
-      case 13: mono_launch<13>(c, a); break;
-      case 15: mono_launch<15>(c, a); break;
-      case 21: mono_launch<21>(c, a); break;
-      default: mono_launch<31>(c, a); break;
-    }
+    mono_launch_any(c, prm->win, a, 0, split, nullptr);
     if (strict) {
       MonoReplayArgs r;
       memset(&r, 0, sizeof(r));
@@ -494,6 +541,24 @@ static int mono_enqueue_impl(vo_ctx *c, const vo_mono_params *prm, int slot0, in
         hipLaunchKernelGGL(mono_fallback_kernel, dim3(strict == 2 ? (n < 1024 ? n : 1024) : fb_grid), dim3(IC_T), 0, s, r);
         vo_prof_end(c);
       }
+    }
+    if (split && hipGetLastError() == hipSuccess) {
+      // the features (and the replay) are on their way: now the detector of the current image — unless it is there already —
+      // and, behind it on the side stream, the candidates' launch; no event: the BA launch's epilogue waits for their count
+      int rcd = defer == 1 ? vo_new_point_candidates_enqueue(c, slot1, bp, table) : VO_OK;
+      if (rcd >= 0) {
+        c->stream = c->stream2;
+        if (vo_slot_acquire(c, slot0) < 0 || vo_slot_acquire(c, slot1) < 0) rcd = VO_ERR_HIP;
+        if (rcd >= 0) mono_launch_any(c, prm->win, a, 2, true, f->cand_done);
+        c->stream = s;
+      }
+      if (rcd < 0) {
+        f->sync_p1_target = p1_before;
+        f->sync_done_target = done_before;
+        return rcd;
+      }
+      vo_wrap_add(f->cand_total, n_new);  // (cumulative, like the word the candidate workgroups count in)
+      f->mono_split = 1;
     }
     if (hipGetLastError() != hipSuccess) {  // nothing of this frame will count: the cumulative targets go back
       f->sync_p1_target = p1_before;
@@ -541,6 +606,10 @@ static int mono_enqueue_impl(vo_ctx *c, const vo_mono_params *prm, int slot0, in
       g.np.host_l = (float *)(f->res_host + f->off_newl);
       g.np.host_r = (float *)(f->res_host + f->off_newr);
       g.np.host_m = f->res_host + f->off_mnew;
+      if (f->mono_split) {
+        g.np.cand_done = f->cand_done;
+        g.np.cand_target = f->cand_total;
+      }
     }
     g.hdr_flags = &f->hdr->flags;
     if (adv_on) {
@@ -640,12 +709,15 @@ extern "C" int vo_mono_frame_result(vo_ctx *c, float *pts1, float *scale, uint8_
   f->recovered = 0;
   const int n = f->n;
   const vo_frame_hdr *h = (const vo_frame_hdr *)f->res_host;
-  if ((h->flags & 8) && n > 0 && c->frame_strict_now == 3) {
+  if ((h->flags & 8) && n > 0 && (c->frame_strict_now == 3 || f->mono_split)) {
     // The device-side join with the replay stream timed out (the two queues did not run concurrently: a serialising tool,
     // a busy GPU). As for the stereo frame: drain the streams, re-base the hand-shake words, switch the context to the
     // stream-ordered replay for good and issue the frame again from its (intact) device inputs.
     VO_CHECK_HIP(c, hipStreamSynchronize(c->stream3));
+    VO_CHECK_HIP(c, hipStreamSynchronize(c->stream2));
     VO_CHECK_HIP(c, hipStreamSynchronize(c->stream_main));
+    VO_CHECK_HIP(c, hipMemsetAsync(f->cand_done, 0, 64, c->stream_main));
+    f->cand_total = 0;
     VO_CHECK_HIP(c, hipMemsetAsync(f->sync, 0, 128 + 64 * 128, c->stream_main));
     VO_CHECK_HIP(c, hipMemsetAsync(f->ctl, 0, vo_ic_ctl_bytes(), c->stream_main));
     f->sync_p1_target = f->sync_done_target = 0;

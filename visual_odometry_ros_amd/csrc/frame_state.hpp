@@ -97,6 +97,7 @@ struct vo_frame_state {
   // kernel at once, runs the keypoint detection of slot_l1 on the side stream next to it and tracks the candidates as a
   // launch of their own behind the detection (vo_frame_set_deferred_detection, consumed by that enqueue)
   int defer_detect;
+  int mono_split;   // the mono frame in flight tracks its candidates as a launch of their own (a join that can time out)
   int *cand_done;   // cumulative count of finished workgroups of the candidates' own launches (device word, never zeroed)
   int cand_total;   // what it reads when every such launch so far has finished
   int *adv_done;

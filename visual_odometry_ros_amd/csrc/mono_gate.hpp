@@ -123,6 +123,9 @@ __device__ __forceinline__ void mono_gate_body(const MonoGateArgs &a, int tid, i
     // extractORBwithBinning_fast(I1) and trackBidirection(I1, I0, ...) (mono_vo.cpp:977-992) — the candidates were
     // found per bin before the frame and tracked by the frame kernel; here: which bins stayed empty, and their results.
     // (Without a pose from the BA the reference goes through the 5-point path first: the caller's, and so is this step.)
+    if (a.np.cand_done) {  // the candidates' own launch (MonoVO's synchronous call) may still be running: bounded join
+      if (tid == 0 && !vo_np_wait_candidates(a.np)) atomicOr(const_cast<int *>(a.hdr_flags), 8);
+    }
     __syncthreads();  // the stages and pixels above are this workgroup's own stores
     const uint8_t *stg = a.stage;
     vo_np_emit(a.np, a.n, a.pts1, [&](int i) { return stg[i] == 4; }, tid, nthr, s_occ, s_wv, &a.cnt[6]);

@@ -38,6 +38,7 @@
 #include "stereo_vo.hpp"
 
 int vo_mono_frame_set_advance(vo_ctx *c, const MvoAdvArgs *adv);  // frame_mono.hip
+int vo_frame_set_deferred_detection(vo_ctx *c, int issued);         // frame_pipeline.hip
 int vo_mono_frame_set_track_flags(vo_ctx *c, int mode);
 
 #define RC(x)                \
@@ -418,9 +419,19 @@ extern "C" int vo_mvo_create(vo_ctx *c, const vo_mvo_params *prm, vo_mvo **out) 
   return VO_OK;
 }
 
-static int mvo_ingest(vo_mvo *s, const void *img, int stride, int on_device) {
+// detect = false (MonoVO's synchronous call in the steady state): the image and its pyramid only, on the MAIN stream — the frame
+// kernel behind it needs no cross-queue wait — and the detection is the frame enqueue's (vo_frame_set_deferred_detection)
+static int mvo_ingest(vo_mvo *s, const void *img, int stride, int on_device, bool detect = true) {
   vo_ctx *c = s->c;
   const int W = s->prm.frame.width, H = s->prm.frame.height, slot = s->slot[2];
+  struct IngestHere {
+    vo_ctx *c;
+    int keep;
+    IngestHere(vo_ctx *ctx, bool main_stream) : c(ctx), keep(ctx->ingest_side) {
+      if (main_stream) c->ingest_side = 0;
+    }
+    ~IngestHere() { c->ingest_side = keep; }
+  } here(c, !detect);
   if (s->prm.rectify) {  // flagDoUndistortion (mono_vo.cpp:509-513): undistortImage + convertTo(CV_8UC1), fused into the pyramid build
     if (on_device)
       RC(vo_set_image_rectified_device(c, slot, img, W, H, stride, 0));
@@ -431,7 +442,7 @@ static int mvo_ingest(vo_mvo *s, const void *img, int stride, int on_device) {
   } else {
     RC(vo_set_image(c, slot, (const uint8_t *)img, W, H, stride));
   }
-  RC(vo_new_point_candidates_enqueue(c, slot, &s->prm.bins, s->tab_next));
+  if (detect) RC(vo_new_point_candidates_enqueue(c, slot, &s->prm.bins, s->tab_next));
   return VO_OK;
 }
 
@@ -803,7 +814,23 @@ extern "C" int vo_mvo_enqueue(vo_mvo *s, const void *img, int stride, int on_dev
   VO_CHECK_HIP(c, hipSetDevice(c->device));
   (void)timestamp;
   if (s->init_done && s->n <= 0) VO_FAIL(c, VO_ERR_GN_FAILED, "the track set is empty");
-  if (!(s->prefetched && s->pre == img)) RC(mvo_ingest(s, img, stride, on_device));
+  // No image handed over early (trackImage as the reference's caller uses it), steady state: the image and its pyramid go in now
+  // on the main stream; the keypoint detection runs on the side stream NEXT TO the features' tracking — from the caller's device
+  // image it starts at once, before the pyramid is queued — and the candidates follow as a launch of their own (frame_mono.hip)
+  int deferred = 0;
+  if (!(s->prefetched && s->pre == img)) {
+    const bool defer = s->init_done && s->n > 0 && c->ingest_side;
+    if (defer) {
+      deferred = 1;
+      if (on_device && !s->prm.rectify && vo_orb_cand_table(c, s->tab_next)) {
+        const int rc = vo_new_point_candidates_enqueue_image(c, (const uint8_t *)img, stride, s->prm.frame.width, s->prm.frame.height,
+                                                             &s->prm.bins, s->tab_next);
+        if (rc < 0) return rc;
+        if (rc == VO_OK) deferred = 2;
+      }
+    }
+    RC(mvo_ingest(s, img, stride, on_device, !defer));
+  }
   // from here on the driver's state moves; every error return below puts ALL of it back (slots, tables, the advance step's
   // sequence number, the prefetch mark — as vo_svo_enqueue does), so that the caller can hand the image over again
   const int keep_slot[3] = {s->slot[0], s->slot[1], s->slot[2]}, keep_tc = s->tab_cur, keep_tn = s->tab_next;
@@ -848,6 +875,7 @@ extern "C" int vo_mvo_enqueue(vo_mvo *s, const void *img, int stride, int on_dev
     // takes — bundled with more than five window keyframes, triangulated otherwise, mono_vo.cpp:800-826; bit 2: dead,
     // landmark.cpp:251) is read off the track set's flags by the frame kernel itself
     int rc = vo_mono_frame_set_track_flags(c, s->core.keyframes.size() > 5 ? 2 : 1);
+    if (rc >= 0 && deferred) rc = vo_frame_set_deferred_detection(c, deferred == 2 ? 1 : 0);
     if (rc < 0) return undo(rc);
     rc = vo_mono_frame_enqueue_closed(c, &s->prm.frame, s->slot[0], s->slot[1], t.t.pts_l, t.t.Xw, t.t.flags, s->n, Tcw_prev, Tcw_prior,
                                       s->dT01, &s->prm.bins, s->tab_cur, 1);
@@ -866,6 +894,8 @@ extern "C" int vo_mvo_enqueue(vo_mvo *s, const void *img, int stride, int on_dev
 // mask_motion, Sampson gate, new points: host-driven operator calls on the frame's device results
 static int mvo_fallback(vo_mvo *s, float dT01[16], float dT10[16], int *m_new, vo_mvo_frame_info *I) {
   vo_ctx *c = s->c;
+  // (a frame whose candidates were a launch of their own and whose BA gave nothing did not join them: they may still run)
+  if (c->frame && c->frame->mono_split) VO_CHECK_HIP(c, hipStreamSynchronize(c->stream2));
   const vo_mono_params &p = s->prm.frame;
   vo_frame_state *f = c->frame;
   const int n = s->n;
