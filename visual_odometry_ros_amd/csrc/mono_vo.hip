@@ -829,7 +829,13 @@ extern "C" int vo_mvo_enqueue(vo_mvo *s, const void *img, int stride, int on_dev
         if (rc == VO_OK) deferred = 2;
       }
     }
-    RC(mvo_ingest(s, img, stride, on_device, !defer));
+    {
+      const int rc_in = mvo_ingest(s, img, stride, on_device, !defer);
+      if (rc_in < 0) {
+        if (deferred == 2) (void)hipStreamSynchronize(c->stream2);
+        return rc_in;
+      }
+    }
   }
   // from here on the driver's state moves; every error return below puts ALL of it back (slots, tables, the advance step's
   // sequence number, the prefetch mark — as vo_svo_enqueue does), so that the caller can hand the image over again
@@ -843,6 +849,7 @@ extern "C" int vo_mvo_enqueue(vo_mvo *s, const void *img, int stride, int on_dev
     s->seq = keep_seq;
     s->prefetched = keep_pre;
     s->chained = keep_chained;
+    if (deferred == 2) (void)hipStreamSynchronize(c->stream2);  // (the detector reads the CALLER's image: finished before "refused")
     return rc;
   };
   s->prefetched = false;

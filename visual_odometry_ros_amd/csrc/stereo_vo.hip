@@ -360,7 +360,10 @@ extern "C" int vo_svo_enqueue(vo_svo *s, const void *left, const void *right, in
       issued = c->early_issued != 0;
       c->early_bins = nullptr;
     }
-    RC(rc_in);
+    if (rc_in < 0) {
+      if (issued && on_device) (void)hipStreamSynchronize(c->stream2);  // (as in undo below)
+      return rc_in;
+    }
   }
   // from here on the driver's state moves; every error return below puts it back (slots, tables, both id counters), so
   // that the caller can hand the pair over again — or another one — and track against the right previous image
@@ -383,6 +386,7 @@ extern "C" int vo_svo_enqueue(vo_svo *s, const void *left, const void *right, in
     c->next_landmark_id = keep.next_landmark_id;
     s->pending = false;
     s->pending_first = false;
+    if (issued) (void)hipStreamSynchronize(c->stream2);  // (the detector reads the CALLER's image: it has finished before we say "refused")
     return rc;
   };
   s->prefetched = false;
