@@ -1529,7 +1529,7 @@ def run_mono_loop(cfg, args, rank, local_rank, world, torch, V, barrier, dev, im
         ctx.set_image_device(2, d_I[k].data_ptr(), W, H, W)
         n_kp_bins.append(bins_with_keypoints(fe, 2))
     ctx.synchronize()
-    ptr = [(d_I[k].data_ptr(), W) for k in range(F)]
+    ptr = [np.ascontiguousarray(I) for I in mono] if args.host_images else [(d_I[k].data_ptr(), W) for k in range(F)]
     prefetch = not args.no_prefetch
     state = {"k": 0}
     traj, infos, stamps = [], [], []
@@ -1558,7 +1558,7 @@ def run_mono_loop(cfg, args, rank, local_rank, world, torch, V, barrier, dev, im
         traj.append(np.array(i.T_wc, np.float32).reshape(4, 4))
 
     # (the library's sequence loop behind the initialisation: the 5-point hook is fed the frame index from here)
-    lib_loop = args.host_loop == "library" and prefetch
+    lib_loop = args.host_loop == "library" and prefetch and not args.host_images  # (runSequence takes device addresses)
     kf_before = [0]
     issue(0)
     for _ in range(LOOP_PRIME):
@@ -1629,7 +1629,7 @@ def run_mono_loop(cfg, args, rank, local_rank, world, torch, V, barrier, dev, im
                                "(age, parallax), keyframe rule, reconstruction"
                                + (", mono local BA over the keyframe window" if args.lba else "; local BA off (--lba 0)")
                                + "; first image + initialisation (5-point pose from a caller hook) happen before the timed frames",
-                   "track_set": "closed loop", "playback": "forward", "images": "resident in HBM", "local_ba": bool(args.lba),
+                   "track_set": "closed loop", "playback": "forward", "images": "pageable host arrays, H2D inside the timed region" if args.host_images else "resident in HBM", "local_ba": bool(args.lba),
                    "strict_border": int(args.strict_border), "next_image": "prefetched (vo_mvo_prefetch)" if prefetch else "with its frame",
                    "host_loop": "library (vo_mvo_run)" if lib_loop else "python (ctypes calls per frame)"},
         "loop": {"mean_tracks_in": round(float(I[:, 1].mean()), 1), "mean_final": round(float(I[:, 6].mean()), 1),

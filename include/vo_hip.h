@@ -652,7 +652,8 @@ int vo_mvo_track(vo_mvo *mvo, const void *img, int stride, int on_device, double
  * (see vo_svo_run). The 5-point hook is called from inside as usual. */
 int vo_mvo_run(vo_mvo *mvo, const void *const *img, int n_total, int stride, int on_device, int k_begin, int k_end,
                vo_mvo_frame_info *infos, double *stamps);
-/* the same in halves, and the next image handed over early (pyramid + per-bin candidate table on the side stream). A refused
+/* the same in halves, and the next image handed over early (pyramid + per-bin candidate table on the side stream). A host image is
+ * uploaded asynchronously: its buffer must stay untouched until that image's frame has returned (as for vo_svo_prefetch). A refused
  * vo_mvo_enqueue leaves the driver as it was (the image can be handed over again); an error return of vo_mvo_result ENDS the
  * stream, as the reference's throw ends its node (mono_vo.cpp:909-949): the frame is no longer in flight and the track set / pose
  * are where the failing step left them. */

@@ -440,7 +440,7 @@ static int mvo_ingest(vo_mvo *s, const void *img, int stride, int on_device, boo
   } else if (on_device) {
     RC(vo_set_image_device(c, slot, img, W, H, stride));
   } else {
-    RC(vo_set_image(c, slot, (const uint8_t *)img, W, H, stride));
+    RC(vo_set_image_host_async(c, slot, (const uint8_t *)img, W, H, stride));
   }
   if (detect) RC(vo_new_point_candidates_enqueue(c, slot, &s->prm.bins, s->tab_next));
   return VO_OK;
@@ -822,15 +822,25 @@ extern "C" int vo_mvo_enqueue(vo_mvo *s, const void *img, int stride, int on_dev
     const bool defer = s->init_done && s->n > 0 && c->ingest_side;
     if (defer) {
       deferred = 1;
-      if (on_device && !s->prm.rectify && vo_orb_cand_table(c, s->tab_next)) {
-        const int rc = vo_new_point_candidates_enqueue_image(c, (const uint8_t *)img, stride, s->prm.frame.width, s->prm.frame.height,
-                                                             &s->prm.bins, s->tab_next);
-        if (rc < 0) return rc;
-        if (rc == VO_OK) deferred = 2;
+      if (!s->prm.rectify && vo_orb_cand_table(c, s->tab_next)) {
+        if (on_device) {
+          const int rc = vo_new_point_candidates_enqueue_image(c, (const uint8_t *)img, stride, s->prm.frame.width, s->prm.frame.height,
+                                                               &s->prm.bins, s->tab_next);
+          if (rc < 0) return rc;
+          if (rc == VO_OK) deferred = 2;
+        } else {  // (a host image: behind its upload, vo_set_image_host_async)
+          c->early_bins = &s->prm.bins;
+          c->early_table = s->tab_next;
+          c->early_issued = 0;
+        }
       }
     }
     {
       const int rc_in = mvo_ingest(s, img, stride, on_device, !defer);
+      if (c->early_bins) {
+        if (c->early_issued) deferred = 2;
+        c->early_bins = nullptr;
+      }
       if (rc_in < 0) {
         if (deferred == 2) (void)hipStreamSynchronize(c->stream2);
         return rc_in;

@@ -363,6 +363,32 @@ extern "C" int vo_set_stereo_pair_host_async(vo_ctx *c, int slot_l, const uint8_
   return vo_pyramid_build_pair(c, slot_l, c->slots[slot_l].stage, slot_r, c->slots[slot_r].stage, width, height, width);
 }
 
+// One host image without a host synchronisation (MonoVO's ingestion; vo_set_image waits for the device twice): H2D into the
+// slot's staging plane and the pyramid chain on the ingest stream; consumers wait for the slot's event on the device.
+int vo_set_image_host_async(vo_ctx *c, int slot, const uint8_t *host, int width, int height, int stride) {
+  if (!c || !host) return VO_ERR_INVALID;
+  if (slot < 0 || slot >= c->cfg.n_slots) VO_FAIL(c, VO_ERR_INVALID, "slot out of range");
+  if (width <= 0 || height <= 0 || width > c->cfg.max_width || height > c->cfg.max_height || stride < width)
+    VO_FAIL(c, VO_ERR_CAPACITY, "image %dx%d exceeds vo_config %dx%d", width, height, c->cfg.max_width, c->cfg.max_height);
+  VO_CHECK_HIP(c, hipSetDevice(c->device));
+  vo_ingest_scope ingest(c);
+  hipStream_t s = c->stream;
+  vo_pyramid &P = c->slots[slot];
+  if (!P.stage) VO_CHECK_HIP(c, vo_dev_malloc(c, (void **)&P.stage, (size_t)c->cfg.max_width * c->cfg.max_height));
+  if (stride == width)
+    VO_CHECK_HIP(c, hipMemcpyAsync(P.stage, host, (size_t)width * height, hipMemcpyHostToDevice, s));
+  else
+    VO_CHECK_HIP(c, hipMemcpy2DAsync(P.stage, (size_t)width, host, (size_t)stride, (size_t)width, (size_t)height, hipMemcpyHostToDevice, s));
+  if (c->early_bins && s != c->stream2) {  // (MonoVO's synchronous call: the detection follows the upload on the side stream)
+    VO_CHECK_HIP(c, hipEventRecord(c->ev_fork, s));
+    VO_CHECK_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    const int rc = vo_new_point_candidates_enqueue_image(c, P.stage, width, width, height, c->early_bins, c->early_table);
+    if (rc < 0) return rc;
+    c->early_issued = rc == VO_OK ? 1 : 0;
+  }
+  return vo_pyramid_build(c, slot, P.stage, width, height, width);
+}
+
 extern "C" int vo_set_pyramid_window_hint(vo_ctx *c, int win) {
   if (!c || win < 0) return VO_ERR_INVALID;
   c->pyr_win_hint = win;

@@ -191,6 +191,7 @@ const vo_cand_table *vo_orb_cand_table(vo_ctx *c, int table);
 // the table of an image that is not (yet) a pyramid slot: `dev_img` is the image itself (device memory, `stride` bytes per row), read by
 // the tile kernels on the side stream with NO wait for anything — the caller orders the side stream behind whatever fills the
 // image. Returns 1 (nothing enqueued) where the tile kernels do not apply: the caller detects from the slot as usual.
+int vo_set_image_host_async(vo_ctx *c, int slot, const uint8_t *host, int width, int height, int stride);  // vo_capi.hip
 int vo_new_point_candidates_enqueue_image(vo_ctx *c, const uint8_t *dev_img, int stride, int w, int h, const vo_bin_params *bp, int table);
 
 // frame_pipeline.hip
