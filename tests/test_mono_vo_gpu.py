@@ -247,6 +247,51 @@ def test_mono_run_sequence_equals_the_three_calls(vo):
     assert sum(la) >= 2
 
 
+def test_mono_synchronous_call_equals_the_look_ahead_loop(vo):
+    """trackImage(img) as ONE call per image — with a host image (asynchronous upload, the detector behind it on the side stream) and
+    with a device image (the detector starts from the caller's image before the pyramid is queued), the candidates tracked by a
+    launch of their own that the BA launch joins on the device — against the loop that hands every image over one frame early:
+    poses, keyframe decisions, local-BA runs, final ids and ages, the same bits."""
+    from util import DeviceBuffer
+    from visual_odometry_ros_amd import synthetic as S
+    W, H, n = 752, 480, 14
+    st = S.StereoStream(width=W, height=H, K=MONO_K, n_u=40, n_v=25, seed=5, speed=0.25)
+    poses = st.poses(n)
+    host = [np.ascontiguousarray(st.render_pair(p)[0]) for p in poses]
+    bufs = [DeviceBuffer(I) for I in host]
+    imgs = [(b.data_ptr(), W) for b in bufs]
+    runs = {}
+    try:
+        for mode in ("look_ahead", "sync_device", "sync_host"):
+            hook = TruePoseHook(poses)
+            hook.k = 1  # (the initialisation is the only call: the stream never needs the fallback)
+            c = vo.Context(device=0, max_width=W, max_height=H, max_points=2512, n_slots=3, max_level=5)
+            try:
+                mvo = vo.MonoVO(c, W, H, MONO_K, 40, 25, hook, thres_translation=1.0, strict_border=4, local_ba=True)
+                if mode == "look_ahead":
+                    infos = mvo.runSequence(imgs, 0, n)[0]
+                elif mode == "sync_device":
+                    infos = [mvo.trackImage(im) for im in imgs]
+                else:
+                    infos = [mvo.trackImage(im) for im in host]
+                assert hook.calls == 1 and not any(i.used_five_point for i in infos[2:]), mode
+                g = mvo.getTracks()
+                runs[mode] = (np.stack([np.array(i.T_wc, np.float32) for i in infos]), [int(i.is_keyframe) for i in infos],
+                              [int(i.lba_ran) for i in infos], g["ids"].copy(), g["age"].copy(), c.frame_recoveries())
+                mvo.close()
+            finally:
+                c.close()
+    finally:
+        for b in bufs:
+            b.free()
+    Ta, ka, la, ia, aa, _ = runs["look_ahead"]
+    assert sum(la) >= 2
+    for mode in ("sync_device", "sync_host"):
+        Tb, kb, lb, ib, ab, rec = runs[mode]
+        assert rec == 0, mode
+        assert np.array_equal(_bits(Ta), _bits(Tb)) and ka == kb and la == lb and np.array_equal(ia, ib) and np.array_equal(aa, ab), mode
+
+
 def test_mono_loop_survives_a_join_timeout(vo):
     """The loop with the concurrent replay and a device-side join that cannot be met (VO_DBG_FAIL_JOIN): the first frame that takes
     the concurrent arrangement times out, is issued again in stream order (its track-set advance then runs as launches of its

@@ -468,6 +468,46 @@ def test_run_sequence_equals_the_three_calls(vo):
     assert sum(la) >= 5
 
 
+def test_synchronous_call_equals_the_look_ahead_loop(vo):
+    """trackStereoImages(left, right) as ONE call per pair — with host images (the detector starts behind the left upload, from
+    the slot's staging plane) and with device images (the detector starts from the caller's image, before the pyramids are
+    queued) — against the loop that hands every pair over one frame early: poses of every frame, keyframe decisions, local-BA
+    runs and the final ids, the same bits (local BA and the concurrent replay on)."""
+    from util import DeviceBuffer
+    W, H, K, n = 640, 240, (400.0, 400.0, 320.0, 120.0), 20
+    st, imgs = _stream(W, H, K, 20, 8, 9, 0.5, n)
+    bufs = [(DeviceBuffer(L), DeviceBuffer(R)) for L, R in imgs]
+    pairs = [((a.data_ptr(), W), (b.data_ptr(), W)) for a, b in bufs]
+    runs = {}
+    try:
+        for mode in ("look_ahead", "sync_device", "sync_host"):
+            c = vo.Context(device=0, max_width=W, max_height=H, max_points=4096, n_slots=5, max_level=4)
+            try:
+                svo = vo.StereoVO(c, W, H, K, K, st.T_lr, 20, 8, thres_fastscore=15, window_size=21, max_level=4, strict_border=4,
+                                  local_ba=True, thres_trans=0.9)
+                if mode == "look_ahead":
+                    infos = svo.runSequence(pairs, 0, n)[0]
+                elif mode == "sync_device":
+                    infos = [svo.trackStereoImages(*pairs[k]) for k in range(n)]
+                else:
+                    infos = [svo.trackStereoImages(*imgs[k]) for k in range(n)]
+                runs[mode] = (np.stack([np.array(i.T_wc, np.float32) for i in infos]), [int(i.is_keyframe) for i in infos],
+                              [int(i.lba_ran) for i in infos], svo.getTracks()["ids"].copy(), c.frame_recoveries())
+                svo.close()
+            finally:
+                c.close()
+    finally:
+        for a, b in bufs:
+            a.free()
+            b.free()
+    Ta, ka, la, ia, _ = runs["look_ahead"]
+    assert sum(la) >= 4
+    for mode in ("sync_device", "sync_host"):
+        Tb, kb, lb, ib, rec = runs[mode]
+        assert rec == 0, mode
+        assert np.array_equal(_bits(Ta), _bits(Tb)) and ka == kb and la == lb and np.array_equal(ia, ib), mode
+
+
 def test_closed_loop_survives_a_join_timeout():
     """The loop in strict-border mode 3 with a device-side join that cannot be met (VO_DEBUG_FAIL_JOIN, fresh child process):
     the first steady-state frame is issued again with the stream-ordered replay — and with it the DLT workers and the
