@@ -64,6 +64,27 @@ def test_pyramid_tile_kernel_every_padded_byte(oracle, emu_pyr, tmp_path, w, h, 
 
 
 @pytest.fixture(scope="module")
+def plan_check(tmp_path_factory):
+    return _compile(tmp_path_factory, "plan_check")
+
+
+@pytest.mark.parametrize("case", [
+    (1241, 376, 8, 1.2, 31, 48, 32, 64), (752, 480, 8, 1.2, 31, 48, 32, 64), (3840, 2160, 8, 1.2, 31, 48, 32, 64),
+    (3840, 2160, 8, 1.2, 31, 56, 48, 96),  # the tile orb_prepare takes for images of more than 1024 small tiles
+    (1920, 1080, 8, 1.2, 31, 56, 48, 96), (640, 240, 8, 1.2, 31, 40, 24, 64), (333, 251, 8, 1.2, 31, 48, 32, 64),
+    (620, 188, 3, 1.5, 16, 48, 32, 64), (2000, 40 + 2 * 31 + 9, 2, 1.2, 31, 48, 32, 64),
+])
+def test_orb_tile_plan_invariants(plan_check, case):
+    """csrc/orb_plan.hpp at sizes the emulated kernels are too slow for (3840 x 2160, both tile sizes): the owned intervals
+    partition every level's detection rectangle, every staged region holds its owned pixels + the ring FAST / non-max / Harris
+    read and the source footprint of the level above, the coefficient tables stay inside their source level, and the LDS
+    areas (regions, table slices, score tiles, stash) neither overlap nor pass the limit."""
+    w, h, nl, sf, edge, tw, th, kb = case
+    r = subprocess.run([plan_check, str(w), str(h), str(nl), repr(sf), str(edge), str(tw), str(th), str(kb * 1024)], capture_output=True, text=True)
+    assert r.returncode == 0, (case, r.returncode, r.stderr)
+
+
+@pytest.fixture(scope="module")
 def emu_orb(tmp_path_factory):
     return _compile(tmp_path_factory, "emu_orb")
 
