@@ -150,3 +150,96 @@ def test_orb_tile_kernels_table(oracle, emu_orb, tmp_path, case):
     assert n_det == d["xy"].shape[0]
     assert set(np.unique(has).tolist()) <= {0, 1} and int(has.sum()) == cand.shape[0]
     assert np.array_equal(xy[has == 1].view(np.uint32), cand.view(np.uint32)) and np.all(xy[has == 0] == 0)
+
+
+# ---- orb_finish_kernel alone, on candidate lists of 4K size ---------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def emu_finish(tmp_path_factory):
+    return _compile(tmp_path_factory, "emu_finish")
+
+
+def _finish_reference(levels, nbu, nbv, iu, iv, max_out):
+    """retainBest(2 n_l) on the score, retainBest(n_l) on the response (keypoint.cpp: everything >= the value of that rank
+    stays), then per bin the first keypoint of largest response in (level, y, x) order — written with numpy sorts, nothing
+    shared with the kernel."""
+    f = np.float32
+    best = {}
+    total = 0
+    surv = []
+    for l, (x, y, sc, r, quota, scale) in enumerate(levels):
+        n = len(sc)
+        keep = np.ones(n, bool)
+        if n > 2 * quota:
+            keep = sc >= np.sort(sc)[::-1][2 * quota - 1] if quota else np.zeros(n, bool)
+        if keep.sum() > quota:
+            keep &= (r >= np.sort(r[keep])[::-1][quota - 1]) if quota else False
+        surv.append(int(keep.sum()))
+        total += surv[-1]
+        for i in np.nonzero(keep)[0]:
+            xs = f(x[i]) * f(scale) if l else f(x[i])
+            ys = f(y[i]) * f(scale) if l else f(y[i])
+            u, v = int(np.floor(xs * iu)), int(np.floor(ys * iv))
+            if not (0 <= u < nbu and 0 <= v < nbv) or not (r[i] > -1.0):
+                continue
+            k = (float(r[i]), -l, -int(y[i]), -int(x[i]))
+            b = v * nbu + u
+            if b not in best or k > best[b][0]:
+                best[b] = (k, xs, ys)
+    xy = np.zeros((nbu * nbv, 2), f)
+    has = np.zeros(nbu * nbv, np.uint8)
+    for b, (_, xs, ys) in best.items():
+        has[b] = 1
+        xy[b] = (xs, ys)
+    return xy, has, min(total, max_out), surv
+
+
+FINISH_CASES = [  # (finishing workgroups per level, histogram copies, capacity of a level's survivor list)
+    (26, 64, 16384),   # 3840 x 2160 as orb_prepare sets it up
+    (4, 3, 16384),     # slices of more than one round of 8 192 scores per workgroup
+    (1, 1, 16384),
+    (3, 2, 1024),      # the first cut leaves more than the list holds: the radix fall-back over 171 000 candidates
+]
+
+
+@pytest.mark.parametrize("case", range(len(FINISH_CASES)))
+def test_orb_finish_kernel_on_4k_candidate_lists(emu_finish, tmp_path, case):
+    """orb_finish_kernel on levels of 171 000 / 60 000 / 20 000 / ... candidates (the 3840 x 2160 case: more than the emulated
+    tile kernel can produce in this suite's time), with score ties at the first cut, response ties at the second, levels
+    below their quota and an empty level: table, presence, keypoint count and per-level survivors against a numpy reference;
+    histogram copies, counters, tickets and keys left zeroed."""
+    import struct
+    parts, copies, cidx_cap = FINISH_CASES[case]
+    rng = np.random.default_rng(17)
+    W, H, nbu, nbv, cand_cap, max_out = 3840, 2160, 100, 80, 518400, 14096
+    ns = [171000, 60000, 20000, 5000, 2600, 300, 10, 0]
+    quotas = [2172, 1810, 1508, 1257, 1047, 873, 727, 606]
+    f = np.float32
+    iu, iv = f(1.0) / f(W // nbu), f(1.0) / f(H // nbv)
+    levels, blob = [], b""
+    for l, (n, q) in enumerate(zip(ns, quotas)):
+        scale = f(1.2 ** l)
+        lw, lh = int(round(W / float(scale))), int(round(H / float(scale)))
+        x = rng.integers(31, lw - 31, n).astype(np.int16)
+        y = rng.integers(31, lh - 31, n).astype(np.int16)
+        sc = np.clip(rng.normal(30, 6, n), 16, 255).astype(np.uint8)            # a few dozen distinct values: wide ties
+        r = (rng.normal(1e-4, 5e-5, n)).astype(f)
+        coarse = rng.random(n) < 0.3
+        r[coarse] = np.round(r[coarse] * f(2e4)) / f(2e4)                        # coarse values: ties at the second cut
+        r[r == 0] = f(1e-7)                                                       # (+-0 order differently as keys: not part of this test)
+        if n > 5:
+            r[:3] = f(-2.0)                                                       # never beats the initial max_score of -1
+        levels.append((x, y, sc, r, q, scale))
+        blob += struct.pack("iif", n, q, float(scale)) + x.tobytes() + y.tobytes() + sc.tobytes() + r.tobytes()
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    fin.write_bytes(blob)
+    subprocess.check_call([emu_finish, str(len(ns)), str(parts), str(copies), str(cidx_cap), str(cand_cap), str(max_out), str(nbu), str(nbv),
+                           "%08x" % iu.view(np.uint32), "%08x" % iv.view(np.uint32), str(fin), str(fout)])
+    raw = fout.read_bytes()
+    flags, n_det, dirty, nb = struct.unpack_from("4i", raw, 0)
+    xy = np.frombuffer(raw, np.float32, 2 * nb, 16).reshape(nb, 2)
+    has = np.frombuffer(raw, np.uint8, nb, 16 + 8 * nb)
+    surv = np.frombuffer(raw, np.int32, len(ns), 16 + 9 * nb)
+    xy_ref, has_ref, n_ref, surv_ref = _finish_reference(levels, nbu, nbv, iu, iv, max_out)
+    assert (flags, dirty, nb) == (0, 0, nbu * nbv)
+    assert surv.tolist() == surv_ref and n_det == n_ref
+    assert np.array_equal(has, has_ref) and np.array_equal(xy.view(np.uint32), xy_ref.view(np.uint32))
