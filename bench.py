@@ -75,7 +75,9 @@ CONFIGS = {
             # feature_tracker.thres_sampson above 100: step [7] of the reference drops every feature below image row 660
             # (stereo_vo.cpp:659, a constant) — never at KITTI's 376 rows, 70 % of a 2160-row image: with the KITTI value (60) a 4K
             # stream cannot hold more than ~3900 of its 8000 buckets (measured). The YAML parameter is the reference's own switch.
-            thres_sampson=120.0),
+            thres_sampson=120.0,
+            # a keyframe every ~13 frames at this speed: nine of them (the local BA's window) need ~120 untimed frames
+            prime=125),
 }
 UNTRIANGULATED = 0.10  # share of the track set whose landmark has no 3-D point yet (new since the last keyframe)
 N_NEW_OPEN = 150       # candidates of the open-loop comparison workload
@@ -1206,6 +1208,8 @@ def main():
         return rendezvous_check(rank, world, args.rendezvous_timeout, cpus)
 
     cfg = CONFIGS[args.config]
+    global LOOP_PRIME
+    LOOP_PRIME = cfg.get("prime", LOOP_PRIME)  # (a configuration whose keyframes are rarer needs more untimed frames to fill the window)
     loop = args.mode == "loop" and cfg["kind"] == "stereo"
     mono_loop = args.mode == "loop" and cfg["kind"] == "mono"
     imgs = None
