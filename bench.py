@@ -1132,7 +1132,7 @@ def cpu_baseline_loop(cfg, args, st, imgs, traj, V, local_rank):
                    "note": "pose error: device loop against the CPU loop in the reference's summation order, both free-running; "
                            "bit-exactness: device loop against the CPU loop in the kernels' summation order (ids, pixels, flags, "
                            "poses after every frame, local-BA solves included); track ids against the reference-order loop: equal "
-                           "until the two free-running loops part at one feature's inlier gate (frame 9 of 24 on this stream: "
+                           "until the two free-running loops part at one feature's inlier gate (frame 9 of 24 on the configs[1] stream: "
                            "tests/test_stereo_vo_gpu.py, DESIGN.md \u00a72)"},
     }
 
