@@ -108,13 +108,13 @@ def bins_with_keypoints(fe, slot):
     return int(fe.getCandidates(0)[1].sum())
 
 
-def stamped_counters(config, workload="loop"):
+def stamped_counters(config, workload="loop", kernel="frame_track"):
     """HBM traffic (PMC) and VALU instruction counts (SQ) of the dominant kernel from the committed rocprofv3 counter
     passes — quoted only while the kernel's sources still hash to what the passes ran on (a stale file is dropped)."""
     out = {"traffic": None, "valu_wave_instructions_per_launch": None, "counters_note": None}
     try:
-        from visual_odometry_ros_amd.build import kernel_source_sha
-        sha = kernel_source_sha()
+        from visual_odometry_ros_amd import build as VB
+        sha = VB.kernel_source_sha(VB.MONO_KERNEL_SOURCES if kernel == "mono_track" else VB.FRAME_KERNEL_SOURCES)
     except Exception:
         return out
     stale = []
@@ -139,7 +139,7 @@ def stamped_counters(config, workload="loop"):
             out["traffic"] = d.get("hbm_bytes_per_launch")
         else:
             for k, e in d.get("kernels", {}).items():
-                if "frame_track" in k and "SQ_INSTS_VALU" in e:
+                if kernel in k and "SQ_INSTS_VALU" in e:
                     out["valu_wave_instructions_per_launch"] = e["SQ_INSTS_VALU"]
                     out["sq_launch_note"] = f"{e.get('SQ_WAVES')} wavefronts per launch in the counter pass"
     if stale:
@@ -1612,6 +1612,7 @@ def run_mono_loop(cfg, args, rank, local_rank, world, torch, V, barrier, dev, im
         b8d += klt_bytes_per_point_level(win) * (2 * n_in * eff_levels + n_cand * (eff_levels + eff_levels_bwd)) + IC_BYTES_8D * n_klt
         bdes += (IC_RECORD_BYTES * n_in if args.strict_border else 0) + POINT_IO_BYTES * (n_in + n_cand)
     achieved = (b8d / launches) / (klt_ms / launches * 1e-3) / 1e9 if klt_n else 0.0
+    counters = stamped_counters(args.config, "loop", "mono_track")
     # trajectory against the renderer's ground truth, up to the scale the initialisation fixes (|t| of the first motion = 1)
     T0i = np.linalg.inv(poses_gt[0])
     gt = np.stack([(T0i @ p)[:3, 3] for p in poses_gt[:len(traj)]])
@@ -1643,13 +1644,16 @@ def run_mono_loop(cfg, args, rank, local_rank, world, torch, V, barrier, dev, im
                  "untimed_frames": LOOP_PRIME + args.warmup,
                  "end_point_error_scaled": round(float(np.linalg.norm(est[-1] * sc - gt[-1])), 4), "path_m": round(float(np.linalg.norm(gt[-1])), 1)},
         "roofline": {"bound": "hbm", "kernel": f"mono_track_kernel<{win}>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": counters["traffic"],
                      "alg_bytes_per_launch": {"survey_8d": round(b8d / launches), "design_records": round(bdes / launches)},
                      "avg_launch_us": round(1e3 * klt_ms / launches, 2),
                      "note": "algorithmic bytes per SURVEY 8(d): forward + backward PyrLK of every feature, every bin's candidate forward + "
                              "backward (speculative), IC tiles; the path is issue/latency-bound at these sizes"},
+        "roofline_issue": issue_roofline(counters, klt_ms, launches),
         "per_rank_fps": [round(p[0] / p[1], 2) for p in per_rank],
     }
+    if counters["counters_note"]:
+        out["roofline"]["counters_note"] = counters["counters_note"]
     if ctx.debug_switches:
         out["config"]["debug_switches"] = dict(ctx.debug_switches)
     mvo.close()

@@ -50,8 +50,9 @@ def main():
                                        for x in sorted(f_per, key=lambda q: -f_per[q])[:14]}
     out["command"] = "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace --output-format csv -- python3 bench.py --no-cpu-baseline --strict-border 1 --no-secondary --steps 60 --warmup 10 (two passes; counter collection serialises kernels across queues, hence the stream-ordered replay; tools/run_profiles.sh)"
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from visual_odometry_ros_amd.build import kernel_source_sha
-    out["kernel_source_sha"] = kernel_source_sha()  # bench.py quotes these numbers only while the kernel's sources still hash to this
+    from visual_odometry_ros_amd import build as VB
+    # bench.py quotes these numbers only while the kernel's sources still hash to this
+    out["kernel_source_sha"] = VB.kernel_source_sha(VB.MONO_KERNEL_SOURCES if "mono_track" in kern else VB.FRAME_KERNEL_SOURCES)
     if len(sys.argv) > 5:
         out["command"] = sys.argv[5]
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"{tag}_frame_pmc.json")

@@ -25,7 +25,7 @@ def main():
     out = {"units": "per launch averages; SQ cycle counters in quad-cycles (MI355X_MICROARCH.md)", "kernels": {}}
     for sub in ("a", "b"):
         for k, cs in load(os.path.join(d, sub)).items():
-            if not any(x in k for x in ("frame_track", "frame_replay", "gn_pose", "orb_tile", "orb_finish", "pyr_build", "svo_", "sba_")):
+            if not any(x in k for x in ("frame_track", "frame_replay", "mono_track", "mono_replay", "gn_pose", "orb_tile", "orb_finish", "pyr_build", "svo_", "mvo_", "sba_")):
                 continue
             e = out["kernels"].setdefault(k, {})
             for name, (tot, n) in cs.items():
@@ -39,8 +39,9 @@ def main():
                     e["frac_" + c] = round(e[c] / e["SQ_WAVE_CYCLES"], 4)
     out["command"] = "rocprofv3 --pmc <8 SQ counters> --kernel-trace --output-format csv -- python3 bench.py --no-cpu-baseline --no-secondary --steps 40 --warmup 10 (two passes; tools/run_pmc_sq.sh)"
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from visual_odometry_ros_amd.build import kernel_source_sha
-    out["kernel_source_sha"] = kernel_source_sha()
+    from visual_odometry_ros_amd import build as VB
+    mono = any("mono_track" in k for k in out["kernels"])
+    out["kernel_source_sha"] = VB.kernel_source_sha(VB.MONO_KERNEL_SOURCES if mono else VB.FRAME_KERNEL_SOURCES)
     if len(sys.argv) > 3:
         out["command"] = sys.argv[3]
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"{tag}_frame_sq_counters.json")

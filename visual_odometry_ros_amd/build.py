@@ -37,6 +37,7 @@ def headers():
 
 
 FRAME_KERNEL_SOURCES = ("frame_fused.hip", "klt_device.hpp", "ic_device.hpp", "vo_internal.hpp")
+MONO_KERNEL_SOURCES = ("frame_mono.hip", "klt_device.hpp", "ic_device.hpp", "vo_internal.hpp")
 
 
 def kernel_source_sha(names=FRAME_KERNEL_SOURCES):
