@@ -262,7 +262,7 @@ def test_mono_synchronous_call_equals_the_look_ahead_loop(vo):
     imgs = [(b.data_ptr(), W) for b in bufs]
     runs = {}
     try:
-        for mode in ("look_ahead", "sync_device", "sync_host"):
+        for mode in ("look_ahead", "look_ahead_host", "sync_device", "sync_host"):
             hook = TruePoseHook(poses)
             hook.k = 1  # (the initialisation is the only call: the stream never needs the fallback)
             c = vo.Context(device=0, max_width=W, max_height=H, max_points=2512, n_slots=3, max_level=5)
@@ -270,6 +270,8 @@ def test_mono_synchronous_call_equals_the_look_ahead_loop(vo):
                 mvo = vo.MonoVO(c, W, H, MONO_K, 40, 25, hook, thres_translation=1.0, strict_border=4, local_ba=True)
                 if mode == "look_ahead":
                     infos = mvo.runSequence(imgs, 0, n)[0]
+                elif mode == "look_ahead_host":  # (numpy images through the library's loop: uploaded one frame ahead)
+                    infos = mvo.runSequence(host, 0, 5)[0] + mvo.runSequence(host, 5, n)[0]
                 elif mode == "sync_device":
                     infos = [mvo.trackImage(im) for im in imgs]
                 else:
@@ -286,7 +288,7 @@ def test_mono_synchronous_call_equals_the_look_ahead_loop(vo):
             b.free()
     Ta, ka, la, ia, aa, _ = runs["look_ahead"]
     assert sum(la) >= 2
-    for mode in ("sync_device", "sync_host"):
+    for mode in ("look_ahead_host", "sync_device", "sync_host"):
         Tb, kb, lb, ib, ab, rec = runs[mode]
         assert rec == 0, mode
         assert np.array_equal(_bits(Ta), _bits(Tb)) and ka == kb and la == lb and np.array_equal(ia, ib) and np.array_equal(aa, ab), mode

@@ -480,13 +480,15 @@ def test_synchronous_call_equals_the_look_ahead_loop(vo):
     pairs = [((a.data_ptr(), W), (b.data_ptr(), W)) for a, b in bufs]
     runs = {}
     try:
-        for mode in ("look_ahead", "sync_device", "sync_host"):
+        for mode in ("look_ahead", "look_ahead_host", "sync_device", "sync_host"):
             c = vo.Context(device=0, max_width=W, max_height=H, max_points=4096, n_slots=5, max_level=4)
             try:
                 svo = vo.StereoVO(c, W, H, K, K, st.T_lr, 20, 8, thres_fastscore=15, window_size=21, max_level=4, strict_border=4,
                                   local_ba=True, thres_trans=0.9)
                 if mode == "look_ahead":
                     infos = svo.runSequence(pairs, 0, n)[0]
+                elif mode == "look_ahead_host":  # (numpy images through the library's loop: uploaded one frame ahead)
+                    infos = svo.runSequence(imgs, 0, 7)[0] + svo.runSequence(imgs, 7, n)[0]
                 elif mode == "sync_device":
                     infos = [svo.trackStereoImages(*pairs[k]) for k in range(n)]
                 else:
@@ -502,7 +504,7 @@ def test_synchronous_call_equals_the_look_ahead_loop(vo):
             b.free()
     Ta, ka, la, ia, _ = runs["look_ahead"]
     assert sum(la) >= 4
-    for mode in ("sync_device", "sync_host"):
+    for mode in ("look_ahead_host", "sync_device", "sync_host"):
         Tb, kb, lb, ib, rec = runs[mode]
         assert rec == 0, mode
         assert np.array_equal(_bits(Ta), _bits(Tb)) and ka == kb and la == lb and np.array_equal(ia, ib), mode

@@ -897,11 +897,22 @@ class StereoVO:
         return self._out()
 
     def runSequence(self, pairs, k_begin=0, k_end=None):
-        """A recorded sequence of (device address, stride) pairs — [((left, stride), (right, stride)), ...] — through the loop
-        inside the library (vo_svo_run): frames k_begin .. k_end - 1 are collected; frame k_end is left in flight for the next
-        call (or result()). Returns (list of SvoFrameInfo, numpy array of CLOCK_MONOTONIC stamps)."""
+        """A recorded sequence of (device address, stride) pairs — [((left, stride), (right, stride)), ...] — or of (left, right)
+        numpy u8 images of one size and layout (host memory: uploaded one frame ahead, under the frame in flight) through the
+        loop inside the library (vo_svo_run): frames k_begin .. k_end - 1 are collected; frame k_end is left in flight for the
+        next call (or result()). Returns (list of SvoFrameInfo, numpy array of CLOCK_MONOTONIC stamps)."""
         n = len(pairs)
         k_end = n if k_end is None else int(k_end)
+        host = n > 0 and isinstance(pairs[0][0], np.ndarray)
+        if host:  # (the arrays themselves are handed to the library: they are kept alive with the list, below)
+            if getattr(self, "_seq_ref", None) is not pairs or len(getattr(self, "_seq_host", ())) != n:
+                self._seq_host = [(_u8(L), _u8(R)) for L, R in pairs]
+                st0 = self._seq_host[0][0].strides[0]
+                if any(a.ndim != 2 or a.shape != b.shape or a.strides[0] != st0 or b.strides[0] != st0 for a, b in self._seq_host):
+                    raise ValueError("runSequence: host images must be u8 planes of one size and row stride")
+            src = [((a.ctypes.data, a.strides[0]), (b.ctypes.data, b.strides[0])) for a, b in self._seq_host]
+        else:
+            src = pairs
         # The address arrays are kept between calls on the SAME list object (held here, so its id cannot be reused) of the
         # same length, and the entries this call hands to the library (k_begin .. k_end + 1) are compared with them: a list
         # that was changed in place, or another list, rebuilds the arrays.
@@ -909,18 +920,19 @@ class StereoVO:
         fresh = getattr(self, "_seq_ref", None) is not pairs or L is None or len(L) != n
         if not fresh:
             for k in range(max(int(k_begin), 0), min(k_end + 2, n)):
-                if L[k] != int(pairs[k][0][0]) or R[k] != int(pairs[k][1][0]):
+                if L[k] != int(src[k][0][0]) or R[k] != int(src[k][1][0]):
                     fresh = True
                     break
         if fresh:
-            self._seq_L = (C.c_void_p * n)(*[int(p[0][0]) for p in pairs])
-            self._seq_R = (C.c_void_p * n)(*[int(p[1][0]) for p in pairs])
+            self._seq_L = (C.c_void_p * n)(*[int(p[0][0]) for p in src])
+            self._seq_R = (C.c_void_p * n)(*[int(p[1][0]) for p in src])
             self._seq_ref = pairs
-        self._seq_stride = int(pairs[0][0][1])
+        self._seq_stride = int(src[0][0][1])
         m = k_end - int(k_begin)
         infos = (SvoFrameInfo * max(m, 1))()
         stamps = np.zeros(max(m, 1), np.float64)
-        rc = self.lib.vo_svo_run(self._h, self._seq_L, self._seq_R, n, self._seq_stride, 1, int(k_begin), k_end, infos, stamps.ctypes.data)
+        rc = self.lib.vo_svo_run(self._h, self._seq_L, self._seq_R, n, self._seq_stride, 0 if host else 1, int(k_begin), k_end, infos,
+                                 stamps.ctypes.data)
         if rc < 0:
             self.ctx.check(rc)
         out = [SvoFrameInfo.from_buffer_copy(infos[j]) for j in range(m)]
@@ -1373,25 +1385,36 @@ class MonoVO:
         return self._out()
 
     def runSequence(self, images, k_begin=0, k_end=None):
-        """A recorded sequence of (device address, stride) images through the loop inside the library (vo_mvo_run): frames
-        k_begin .. k_end - 1 are collected, frame k_end is left in flight. Returns (list of MvoFrameInfo, stamps)."""
+        """A recorded sequence of (device address, stride) images — or of numpy u8 images of one size and layout (host memory) —
+        through the loop inside the library (vo_mvo_run): frames k_begin .. k_end - 1 are collected, frame k_end is left in
+        flight. Returns (list of MvoFrameInfo, stamps)."""
         n = len(images)
         k_end = n if k_end is None else int(k_end)
+        host = n > 0 and isinstance(images[0], np.ndarray)
+        if host:
+            if getattr(self, "_seq_ref", None) is not images or len(getattr(self, "_seq_host", ())) != n:
+                self._seq_host = [_u8(I) for I in images]
+                st0 = self._seq_host[0].strides[0]
+                if any(a.ndim != 2 or a.shape != self._seq_host[0].shape or a.strides[0] != st0 for a in self._seq_host):
+                    raise ValueError("runSequence: host images must be u8 planes of one size and row stride")
+            src = [(a.ctypes.data, a.strides[0]) for a in self._seq_host]
+        else:
+            src = images
         I = getattr(self, "_seq_I", None)  # kept between calls on the same, unchanged list only (as StereoVO.runSequence)
         fresh = getattr(self, "_seq_ref", None) is not images or I is None or len(I) != n
         if not fresh:
             for k in range(max(int(k_begin), 0), min(k_end + 2, n)):
-                if I[k] != int(images[k][0]):
+                if I[k] != int(src[k][0]):
                     fresh = True
                     break
         if fresh:
-            self._seq_I = (C.c_void_p * n)(*[int(p[0]) for p in images])
+            self._seq_I = (C.c_void_p * n)(*[int(p[0]) for p in src])
             self._seq_ref = images
-        self._seq_stride = int(images[0][1])
+        self._seq_stride = int(src[0][1])
         m = k_end - int(k_begin)
         infos = (MvoFrameInfo * max(m, 1))()
         stamps = np.zeros(max(m, 1), np.float64)
-        rc = self.lib.vo_mvo_run(self._h, self._seq_I, n, self._seq_stride, 1, int(k_begin), k_end, infos, stamps.ctypes.data)
+        rc = self.lib.vo_mvo_run(self._h, self._seq_I, n, self._seq_stride, 0 if host else 1, int(k_begin), k_end, infos, stamps.ctypes.data)
         if rc < 0:
             self.ctx.check(rc)
         out = [MvoFrameInfo.from_buffer_copy(infos[j]) for j in range(m)]
