@@ -4,7 +4,7 @@ KERNELS' order (SUM_TREE, 512 partials — what the device reproduces bit for bi
 flags, keyframe decisions and poses part, and at which gate? (tests/test_stereo_vo_gpu.py: _vs_reference_order runs the
 device loop against the SUM_SEQ loop on the GPU box; this script finds and explains the fork without a GPU.)
 
-  python tools/tools_seq_vs_tree.py [--frames 24] [--mono]
+  python tests/measure/seq_vs_tree.py [--frames 24] [--mono]
 """
 import argparse
 import os
@@ -12,7 +12,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

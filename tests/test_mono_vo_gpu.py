@@ -137,7 +137,7 @@ def test_mono_loop_with_undistortion(vo, oracle):
 
 
 # ---- against the CPU loop in the REFERENCE's summation order (see tests/test_stereo_vo_gpu.py: _vs_reference_order) -----------
-# Measured (CPU, SUM_SEQ loop against SUM_TREE loop, tools/tools_seq_vs_tree.py --mono): ids, flags, keyframe decisions equal for
+# Measured (CPU, SUM_SEQ loop against SUM_TREE loop, tests/measure/seq_vs_tree.py --mono): ids, flags, keyframe decisions equal for
 # frames 0..21 of 24 at 752x480 with the mono local BA; frame 22 differs by one landmark (1832 against 1833 entries; equal again
 # at frame 23: the landmark dies); poses within 8.3e-5 (the mono scale is fixed once, at the initialisation, so differences only add up).
 _MONO_SEQ_FORK_FRAME = 22

@@ -247,7 +247,7 @@ def test_closed_loop_kitti_size_sliding_window(vo, oracle):
 # The kernels sum trackWithScale's 264 taps as 64 lane partials + a butterfly and the pose-only BA's normal equations as 512
 # partials + a tree (oracle SUM_TREE, what every other loop test compares with, bit for bit); the reference adds them one after
 # the other (SUM_SEQ). Both loops run free, so the last bits of a frame's refined pixels enter the next frame's priors.
-# Measured (tools/tools_seq_vs_tree.py runs the same comparison on the CPU alone, SUM_SEQ loop against SUM_TREE loop): ids,
+# Measured (tests/measure/seq_vs_tree.py runs the same comparison on the CPU alone, SUM_SEQ loop against SUM_TREE loop): ids,
 # flags and keyframe decisions are equal for frames 0..8; at frame 9 the sets fork at the pose-only BA's inlier gate
 # `0.5 (|rx_l| + |ry_l| + |rx_r| + |ry_r|) >= thres_poseba_error = 3.0` (motion_estimator.cpp:950-958): features 416 and 592 have
 # 3.2767 / 3.0527 in the reference's order (outliers, stage 3) and 2.9246 / 2.7198 in the kernels' (inliers, stage 4). Not an
